@@ -1,0 +1,264 @@
+/*
+ * shasta_mi355x.h -- C ABI of libshasta_mi355x.so
+ *
+ * MI355X-native (gfx950, hand-written HIP) drop-in for the two hot functions of
+ * the Shasta assembler's overlap detection (citations are /root/reference/ paths):
+ *
+ *   seam 1  LowHash0::LowHash0(...)                    src/LowHash0.hpp:32-52, src/LowHash0.cpp:23-257
+ *           <- Assembler::findAlignmentCandidatesLowHash0   src/AssemblerLowHash.cpp:10-55
+ *   seam 2  Assembler::computeAlignments(opts, threads)     src/Assembler.hpp:264-270, src/AssemblerAlign.cpp:208-304
+ *           with alignMethod 4 (Align4::align, src/Align4.hpp:88-95, src/Align4.cpp:30)
+ *
+ * Plain C: pointers, sizes, PODs.  No C++/torch types cross this boundary.
+ * Inputs are borrowed for the duration of a call (they are PROT_READ mmaps of
+ * Shasta's Data/ files in the real caller).  Output buffers are owned by the
+ * library and released with the matching *_free call.  Every function returns
+ * 0 on success, non-zero on failure; shasta_mi355x_last_error() returns the
+ * message for the calling thread (the C++ adapter rethrows std::runtime_error,
+ * matching SHASTA_ASSERT / src/SHASTA_ASSERT.cpp:18-29).
+ *
+ * There is NO CPU fallback behind this ABI: if no gfx950 device is usable every
+ * compute entry point fails with an error.
+ */
+#ifndef SHASTA_MI355X_H
+#define SHASTA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Layout-compatible PODs                                                     */
+/* ------------------------------------------------------------------------- */
+
+/* shasta::OrientedReadPair, src/OrientedReadPair.hpp:18-86 (12 bytes, 3 pad). */
+typedef struct shasta_oriented_read_pair {
+    uint32_t readIds[2];     /* readIds[0] < readIds[1]                         */
+    uint8_t  isSameStrand;   /* bool                                            */
+    uint8_t  pad[3];         /* written as 0 by this library                    */
+} shasta_oriented_read_pair;
+
+/* shasta::AlignmentInfo, src/Alignment.hpp:86-447 (52 bytes). */
+typedef struct shasta_alignment_info {
+    struct {
+        uint32_t markerCount;    /* markers in this oriented read                */
+        uint32_t firstOrdinal;
+        uint32_t lastOrdinal;
+    } data[2];
+    uint32_t markerCount;        /* aligned markers                              */
+    int32_t  minOrdinalOffset;
+    int32_t  maxOrdinalOffset;
+    int32_t  averageOrdinalOffset;
+    uint32_t maxSkip;
+    uint32_t maxDrift;
+    uint8_t  isInReadGraph;      /* bit 0; cleared                               */
+    uint8_t  pad[3];
+} shasta_alignment_info;
+
+/* shasta::AlignmentData, src/Alignment.hpp:393-421 (64 bytes). */
+typedef struct shasta_alignment_data {
+    shasta_oriented_read_pair pair;
+    shasta_alignment_info     info;
+} shasta_alignment_data;
+
+/* Arguments of LowHash0::LowHash0 that are numbers (src/LowHash0.hpp:32-43),
+ * in the same order and with the same meaning. */
+typedef struct shasta_lowhash0_params {
+    uint64_t m;                          /* consecutive markers per feature      */
+    double   hashFraction;
+    uint64_t minHashIterationCount;      /* 0 => alignmentCandidatesPerRead rules */
+    double   alignmentCandidatesPerRead;
+    uint64_t log2MinHashBucketCount;     /* 0 => 5 + log2 estimate (:73-98)       */
+    uint64_t minBucketSize;
+    uint64_t maxBucketSize;
+    uint64_t minFrequency;
+} shasta_lowhash0_params;
+
+/* What LowHash0 leaves behind besides the two memory mapped outputs: the
+ * per-iteration console line (src/LowHash0.cpp:193-196) and the rows of
+ * LowHashBucketHistogram.csv (:566-613). */
+typedef struct shasta_lowhash0_result {
+    uint64_t candidateCount;
+    shasta_oriented_read_pair* candidates;  /* (readId0, readId1, strand) order  */
+    uint32_t log2BucketCount;               /* the value actually used           */
+    uint32_t iterationCount;                /* iterations actually run           */
+    uint64_t* highFrequency;                /* [iterationCount]                  */
+    uint64_t* total;                        /* [iterationCount]                  */
+    uint64_t histogramRowCount;
+    uint64_t* histogram;                    /* rows {iteration,bucketSize,bucketCount} */
+    double   seconds;                       /* wall time of the call             */
+    double   deviceSeconds;                 /* HIP-event time of the device part */
+} shasta_lowhash0_result;
+
+/* Align4::Options (src/Align4.hpp:106-121) plus the two outer switches of
+ * computeAlignmentsThreadFunction (src/AssemblerAlign.cpp:316-331). */
+typedef struct shasta_align4_options {
+    uint64_t deltaX;
+    uint64_t deltaY;
+    uint64_t minEntryCountPerCell;
+    uint64_t maxDistanceFromBoundary;
+    uint64_t minAlignedMarkerCount;
+    double   minAlignedFraction;
+    uint64_t maxSkip;
+    uint64_t maxDrift;
+    uint64_t maxTrim;
+    uint64_t maxBand;
+    int64_t  matchScore;      /* carried for fidelity; Align4 itself always uses */
+    int64_t  mismatchScore;   /* 6/-1/-1 (src/Align4.hpp:159-161: the members are */
+    int64_t  gapScore;        /* never assigned from Options).                   */
+    uint8_t  suppressContainments;
+    uint8_t  pad[7];
+} shasta_align4_options;
+
+/* Per-candidate status codes. */
+enum {
+    SHASTA_ALIGN_STORED        = 0,  /* passed every filter; one AlignmentData row  */
+    SHASTA_ALIGN_REJECTED      = 1,  /* aligned but failed a filter (:439-472)      */
+    SHASTA_ALIGN_EMPTY         = 2,  /* Align4 found no acceptable component        */
+    SHASTA_ALIGN_SKIPPED       = 3,  /* resource limit: the reference's "skip+log"  */
+                                     /* lane (src/AssemblerAlign.cpp:419-435)       */
+    SHASTA_ALIGN_TIE_FLAG      = 0x80 /* or-ed in: two components tied on           */
+                                     /* markerCount; reference order is libstdc++   */
+                                     /* hash-order dependent (src/Align4.cpp:792-872)*/
+};
+
+typedef struct shasta_align4_result {
+    uint64_t alignmentCount;
+    shasta_alignment_data* alignmentData;    /* [alignmentCount], candidate order   */
+    uint64_t* compressedToc;                 /* [alignmentCount+1]                  */
+    uint8_t*  compressedData;                /* shasta::compress bytes              */
+    uint8_t*  status;                        /* [candidateCount]                    */
+    /* Diagnostics for parity tests: the alignment Align4 returned for EVERY
+     * candidate (before the outer filters).  ordinals are (x,y) pairs. */
+    uint64_t* ordinalsToc;                   /* [candidateCount+1], in pairs        */
+    uint32_t* ordinals;                      /* 2 * ordinalsToc[candidateCount]     */
+    uint64_t  dpCellCount;                   /* sum of nx * bandWidth over DPs run  */
+    uint64_t  kmerIdBytes;                   /* sum of 4*(nx+ny) over candidates    */
+    double    seconds;
+    double    deviceSeconds;
+} shasta_align4_result;
+
+/* ------------------------------------------------------------------------- */
+/* Library / device                                                           */
+/* ------------------------------------------------------------------------- */
+
+const char* shasta_mi355x_last_error(void);
+const char* shasta_mi355x_version(void);
+/* Number of usable gfx950 devices (0 if none; never throws). */
+int shasta_mi355x_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* One-shot, host-pointer seams (what the C++ adapter calls)                  */
+/* ------------------------------------------------------------------------- */
+
+/* Seam 1.  markersToc has 2*readCount+1 entries (Markers.toc), markersData is
+ * Markers.data: packed 7-byte CompressedMarker {u32 kmerId, u24 position}
+ * (src/Marker.hpp:56-70).  readFlags is ReadFlags (1 byte per read, bit 0 =
+ * isPalindromic, src/ReadFlags.hpp:10-30).  readLowHashStatistics receives
+ * readCount*3 u64 {sparse, good, crowded}, zeroed by the callee
+ * (src/LowHash0.cpp:123-125). */
+int shasta_mi355x_lowhash0(
+    uint64_t readCount,
+    const uint64_t* markersToc,
+    const void* markersData,
+    const uint8_t* readFlags,
+    const shasta_lowhash0_params* params,
+    uint64_t* readLowHashStatistics,
+    shasta_lowhash0_result* result);
+void shasta_mi355x_lowhash0_free(shasta_lowhash0_result* result);
+
+/* Seam 2 (method 4).  Aligns candidates[i] = (readId0 strand 0, readId1 strand
+ * isSameStrand?0:1), applies the filters of src/AssemblerAlign.cpp:439-472 and
+ * returns AlignmentData + CompressedAlignments in candidate order (the
+ * reference's order for threadCount==1). */
+int shasta_mi355x_align4_batch(
+    uint64_t readCount,
+    const uint64_t* markersToc,
+    const void* markersData,
+    uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* options,
+    int wantOrdinals,
+    shasta_align4_result* result);
+void shasta_mi355x_align4_free(shasta_align4_result* result);
+
+/* ------------------------------------------------------------------------- */
+/* Device-resident context (bench, multi-GPU driver, staged tests)            */
+/* ------------------------------------------------------------------------- */
+
+typedef struct shasta_mi355x_ctx shasta_mi355x_ctx;
+
+/* Creates a context on HIP device `device` with its own non-blocking stream. */
+shasta_mi355x_ctx* shasta_mi355x_create(int device);
+void shasta_mi355x_destroy(shasta_mi355x_ctx*);
+
+/* Uploads Markers.{toc,data} and runs the marker-strip kernel
+ * (LowHash0::createKmerIds, src/LowHash0.cpp:261-308) so that the dense
+ * uint32 kmerIds[M] + toc live in HBM.  readFlags may be NULL (all zero). */
+int shasta_mi355x_set_markers(
+    shasta_mi355x_ctx*, uint64_t readCount,
+    const uint64_t* markersToc, const void* markersData, const uint8_t* readFlags);
+
+/* Adopts kmer ids that are already dense on the HOST (uint32 per marker); used
+ * by synthetic benchmarks that never materialise 7-byte markers. */
+int shasta_mi355x_set_kmer_ids(
+    shasta_mi355x_ctx*, uint64_t readCount,
+    const uint64_t* markersToc, const uint32_t* kmerIds, const uint8_t* readFlags);
+
+/* Restricts the reads this context hashes / owns to [readBegin, readEnd) and
+ * the buckets it owns to rank `rank` of `worldSize` (multi-GPU sharding,
+ * SURVEY section 8e).  Default: everything, rank 0 of 1. */
+int shasta_mi355x_set_shard(shasta_mi355x_ctx*, int rank, int worldSize,
+    uint64_t readBegin, uint64_t readEnd);
+
+/* LowHash0 on the resident markers.  Same outputs as the one-shot seam. */
+int shasta_mi355x_lowhash0_run(
+    shasta_mi355x_ctx*, const shasta_lowhash0_params* params,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result* result);
+
+/* Align4 batch on the resident markers. */
+int shasta_mi355x_align4_run(
+    shasta_mi355x_ctx*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* options, int wantOrdinals,
+    shasta_align4_result* result);
+
+/* Timing of the dominant kernels of the last *_run call on this context,
+ * measured with HIP events on the context's stream. */
+typedef struct shasta_mi355x_kernel_times {
+    double   lowhashHashSeconds;     /* sum over launches of the window-hash kernel */
+    uint64_t lowhashHashLaunches;
+    uint64_t lowhashHashBytes;       /* algorithmic bytes of those launches        */
+    double   alignDpSeconds;         /* sum over launches of the banded DP kernel   */
+    uint64_t alignDpLaunches;
+    uint64_t alignDpCells;
+    uint64_t alignBytes;             /* sum 4(nx+ny)+8a                             */
+} shasta_mi355x_kernel_times;
+int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx*, shasta_mi355x_kernel_times*);
+
+/* ------------------------------------------------------------------------- */
+/* Unit seams used by the parity tests                                        */
+/* ------------------------------------------------------------------------- */
+
+/* MurmurHash64A (src/MurmurHash2.cpp:96-140) of every window of m kmer ids,
+ * seed = 37*iteration: out[i] for i in [0, n-m+1).  Device computes; host
+ * pointers in and out. */
+int shasta_mi355x_hash_windows(
+    const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);
+
+/* Banded overlap DP + traceback on one pair (src/Align4.cpp:993-1088).  Writes
+ * the diagonal-and-equal steps as (x,y) pairs; returns their number in *count
+ * (capacity is in pairs). */
+int shasta_mi355x_banded_dp(
+    const uint32_t* kmerIds0, uint32_t nx,
+    const uint32_t* kmerIds1, uint32_t ny,
+    int32_t bandMin, int32_t bandMax,
+    uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,229 @@
+"""TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for the two checker libraries:
+
+  RefLib     oracle/_ref/libshasta_ref.so   the reference's own LowHash0 / Align4 control
+                                            flow compiled in place (oracle/ref_build/)
+  OracleLib  oracle/_build/liboracle.so     the CPU restatement in this directory
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Nothing under shasta_amd/ does.
+"""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+
+from shasta_amd import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(HERE, "_ref", "libshasta_ref.so")
+ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+def oracle_available():
+    return os.path.exists(ORACLE_SO)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class _Base:
+    prefix = ""
+
+    def __init__(self, path):
+        self.lib = C.CDLL(path)
+        self.path = path
+        f = getattr(self.lib, self.prefix + "last_error")
+        f.restype = C.c_char_p
+        self._last_error = f
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self._last_error().decode()))
+
+    def _align4(self, toc, data7, candidates, options, want_ordinals):
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        res = abi.Align4Result()
+        fn = getattr(self.lib, self.prefix + "align4_batch")
+        fn.restype = C.c_int
+        rc = fn(C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+                C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+                C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
+        self._check(rc, self.prefix + "align4_batch")
+        out = abi.Align4Output(res, len(candidates), want_ordinals)
+        getattr(self.lib, self.prefix + "align4_free")(C.byref(res))
+        return out
+
+
+class RefLib(_Base):
+    prefix = "ref_"
+
+    def __init__(self):
+        super().__init__(REF_SO)
+        self.lib.ref_murmur64a.restype = C.c_uint64
+
+    def murmur64a(self, data, seed):
+        b = bytes(data)
+        return int(self.lib.ref_murmur64a(b, C.c_int(len(b)), C.c_uint64(seed)))
+
+    def test_alignment_compression(self):
+        self._check(self.lib.ref_test_alignment_compression(), "testAlignmentCompression")
+
+    def compress(self, ordinals):
+        o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self._check(self.lib.ref_compress(abi.as_ptr(o, C.c_uint32), C.c_uint64(len(o)),
+                                          C.byref(p), C.byref(n)), "ref_compress")
+        out = abi.copy_array(p, n.value, "u1")
+        self.lib.ref_free(p)
+        return out
+
+    def decompress(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        p = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        self._check(self.lib.ref_decompress(abi.as_ptr(d, C.c_uint8), C.c_uint64(len(d)),
+                                            C.byref(p), C.byref(n)), "ref_decompress")
+        out = abi.copy_array(p, 2 * n.value, "<u4").reshape(-1, 2)
+        self.lib.ref_free(p)
+        return out
+
+    def alignment_info(self, ordinals, nx, ny):
+        o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
+        info = abi.AlignmentInfo()
+        self._check(self.lib.ref_alignment_info(abi.as_ptr(o, C.c_uint32), C.c_uint64(len(o)),
+                                                C.c_uint32(nx), C.c_uint32(ny), C.byref(info)),
+                    "ref_alignment_info")
+        return info
+
+    def markers_from_fasta(self, path, k=10, probability=0.1, seed=231, min_read_length=10000, threads=0):
+        rc_ = C.c_uint64()
+        toc = C.POINTER(C.c_uint64)()
+        data = C.POINTER(C.c_uint8)()
+        self._check(self.lib.ref_markers_from_fasta(
+            path.encode(), C.c_uint64(k), C.c_double(probability), C.c_int(seed),
+            C.c_uint64(min_read_length), C.c_uint64(threads),
+            C.byref(rc_), C.byref(toc), C.byref(data)), "ref_markers_from_fasta")
+        n = 2 * rc_.value
+        toc_a = abi.copy_array(toc, n + 1, "<u8")
+        data_a = abi.copy_array(data, 7 * int(toc_a[-1]), "u1")
+        self.lib.ref_free(toc)
+        self.lib.ref_free(data)
+        return toc_a, data_a
+
+    def lowhash0(self, toc, data7, flags, params, threads=0, work_dir=None):
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        flags = np.zeros(read_count, np.uint8) if flags is None else np.ascontiguousarray(flags, np.uint8)
+        stats = np.zeros((read_count, 3), dtype=np.uint64)
+        res = abi.LowHash0Result()
+        with tempfile.TemporaryDirectory() as tmp:
+            wd = work_dir or tmp
+            rc = self.lib.ref_lowhash0(
+                C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+                abi.as_ptr(flags, C.c_uint8), C.byref(params), C.c_uint64(threads), wd.encode(),
+                abi.as_ptr(stats, C.c_uint64), C.byref(res))
+            self._check(rc, "ref_lowhash0")
+            out = abi.LowHash0Output(res, stats)
+            if work_dir is None:
+                with open(os.path.join(tmp, "LowHashBucketHistogram.csv"), "rb") as f:
+                    out.histogram_csv = f.read()
+        self.lib.ref_lowhash0_free(C.byref(res))
+        return out
+
+    def align4_batch(self, toc, data7, candidates, options, want_ordinals=True):
+        return self._align4(toc, data7, candidates, options, want_ordinals)
+
+
+class OracleLib(_Base):
+    prefix = "oracle_"
+
+    def __init__(self):
+        super().__init__(ORACLE_SO)
+        self.lib.oracle_murmur64a.restype = C.c_uint64
+
+    def murmur64a(self, data, seed):
+        b = bytes(data)
+        return int(self.lib.oracle_murmur64a(b, C.c_int(len(b)), C.c_uint64(seed)))
+
+    def hash_windows(self, kmer_ids, m, iteration):
+        k = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
+        n = len(k)
+        out = np.zeros(max(0, n - m + 1), dtype=np.uint64)
+        self._check(self.lib.oracle_hash_windows(abi.as_ptr(k, C.c_uint32), C.c_uint64(n), C.c_uint64(m),
+                                                 C.c_uint64(iteration), abi.as_ptr(out, C.c_uint64)),
+                    "oracle_hash_windows")
+        return out
+
+    def lowhash0(self, toc, data7, flags, params, threads=1):
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        flags = np.zeros(read_count, np.uint8) if flags is None else np.ascontiguousarray(flags, np.uint8)
+        stats = np.zeros((read_count, 3), dtype=np.uint64)
+        res = abi.LowHash0Result()
+        rc = self.lib.oracle_lowhash0(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            abi.as_ptr(flags, C.c_uint8), C.byref(params), C.c_uint64(threads),
+            abi.as_ptr(stats, C.c_uint64), C.byref(res))
+        self._check(rc, "oracle_lowhash0")
+        out = abi.LowHash0Output(res, stats)
+        self.lib.oracle_lowhash0_free(C.byref(res))
+        return out
+
+    def align4_batch(self, toc, data7, candidates, options, want_ordinals=True, threads=1):
+        self.lib.oracle_set_threads(C.c_uint64(threads))
+        return self._align4(toc, data7, candidates, options, want_ordinals)
+
+    def banded_dp(self, k0, k1, band_min, band_max):
+        k0 = np.ascontiguousarray(k0, dtype=np.uint32)
+        k1 = np.ascontiguousarray(k1, dtype=np.uint32)
+        cap = min(len(k0), len(k1)) + 1
+        out = np.zeros((cap, 2), dtype=np.uint32)
+        count = C.c_uint64()
+        score = C.c_int32()
+        self._check(self.lib.oracle_banded_dp(
+            abi.as_ptr(k0, C.c_uint32), C.c_uint32(len(k0)), abi.as_ptr(k1, C.c_uint32), C.c_uint32(len(k1)),
+            C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
+            C.byref(count), C.byref(score)), "oracle_banded_dp")
+        return out[:count.value].copy(), score.value
+
+    def compress(self, ordinals):
+        o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self._check(self.lib.oracle_compress(abi.as_ptr(o, C.c_uint32), C.c_uint64(len(o)),
+                                             C.byref(p), C.byref(n)), "oracle_compress")
+        out = abi.copy_array(p, n.value, "u1")
+        self.lib.oracle_free(p)
+        return out
+
+    def decompress(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        p = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        self._check(self.lib.oracle_decompress(abi.as_ptr(d, C.c_uint8), C.c_uint64(len(d)),
+                                               C.byref(p), C.byref(n)), "oracle_decompress")
+        out = abi.copy_array(p, 2 * n.value, "<u4").reshape(-1, 2)
+        self.lib.oracle_free(p)
+        return out
+
+    def alignment_info(self, ordinals, nx, ny):
+        o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
+        info = abi.AlignmentInfo()
+        self._check(self.lib.oracle_alignment_info(abi.as_ptr(o, C.c_uint32), C.c_uint64(len(o)),
+                                                   C.c_uint32(nx), C.c_uint32(ny), C.byref(info)),
+                    "oracle_alignment_info")
+        return info

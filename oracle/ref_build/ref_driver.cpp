@@ -1,0 +1,550 @@
+// TEST INFRASTRUCTURE ONLY -- builds into oracle/_ref/libshasta_ref.so.
+//
+// C-ABI harness around the REFERENCE's own translation units, compiled in place
+// from /root/reference/src (see Makefile; no reference source is copied into
+// this repository).  It drives, without the Assembler facade (which would pull
+// in Boost):
+//
+//   ReadLoader -> (restated randomlySelectKmers) -> MarkerFinder      [fixture generation]
+//   LowHash0::LowHash0                                                [seam 1 oracle]
+//   Align4::align + AlignmentInfo + shasta::compress                  [seam 2 oracle]
+//
+// Non-reference code in this file: the k-mer table fill (restating
+// src/AssemblerKmers.cpp:33-100,147-180) and the per-candidate driver loop
+// (restating src/AssemblerAlign.cpp:378-483 for alignMethod 4, threadCount 1).
+// The banded DP behind Align4 is NOT SeqAn: see shims/seqan/align.h.
+
+// Reads keeps its vectors private; the harness needs to size readFlags without
+// loading bases.  Access control does not change layout.
+// (standard headers first, so that only Shasta headers see the redefinition)
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+#define private public
+#include "Reads.hpp"
+#undef private
+
+#include "Align4.hpp"
+#include "Alignment.hpp"
+#include "compressAlignment.hpp"
+#include "Kmer.hpp"
+#include "LowHash0.hpp"
+#include "Marker.hpp"
+#include "MarkerFinder.hpp"
+#include "MemoryMappedAllocator.hpp"
+#include "MemoryMappedVector.hpp"
+#include "MemoryMappedVectorOfVectors.hpp"
+#include "MurmurHash2.hpp"
+#include "OrientedReadPair.hpp"
+#include "orderPairs.hpp"
+#include "ReadLoader.hpp"
+using namespace shasta;
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unistd.h>
+
+#include "../../include/shasta_mi355x.h"
+
+static_assert(sizeof(CompressedMarker) == 7, "CompressedMarker");
+static_assert(sizeof(OrientedReadPair) == sizeof(shasta_oriented_read_pair), "OrientedReadPair");
+static_assert(sizeof(AlignmentInfo) == sizeof(shasta_alignment_info), "AlignmentInfo");
+static_assert(sizeof(AlignmentData) == sizeof(shasta_alignment_data), "AlignmentData");
+static_assert(sizeof(Align4::Options) == 104, "Align4::Options");
+
+static thread_local std::string lastError;
+
+namespace {
+
+using Markers = MemoryMapped::VectorOfVectors<CompressedMarker, uint64_t>;
+
+void fillMarkers(Markers& markers, uint64_t readCount, const uint64_t* toc, const void* data)
+{
+    markers.createNew("", 4096);
+    const uint64_t n = 2 * readCount;
+    markers.beginPass1(n);
+    for(uint64_t i = 0; i < n; i++) {
+        markers.incrementCount(i, toc[i+1] - toc[i]);
+    }
+    markers.beginPass2();
+    markers.endPass2(false);
+    if(toc[n]) {
+        std::memcpy(markers.begin(), data, 7ULL * toc[n]);
+    }
+}
+
+class CoutCapture {
+public:
+    CoutCapture() : old(std::cout.rdbuf(ss.rdbuf())) {}
+    ~CoutCapture() { std::cout.rdbuf(old); }
+    std::string str() const { return ss.str(); }
+private:
+    std::stringstream ss;
+    std::streambuf* old;
+};
+
+class ChdirGuard {
+public:
+    explicit ChdirGuard(const char* dir)
+    {
+        if(!getcwd(old, sizeof(old))) old[0] = 0;
+        if(dir && dir[0]) { if(chdir(dir)) throw std::runtime_error("chdir failed"); }
+    }
+    ~ChdirGuard() { if(old[0]) { if(chdir(old)) {} } }
+private:
+    char old[4096];
+};
+
+template<class T> T* mallocCopy(const std::vector<T>& v)
+{
+    T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if(!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+}  // namespace
+
+
+extern "C" {
+
+const char* ref_last_error() { return lastError.c_str(); }
+
+uint64_t ref_murmur64a(const void* key, int len, uint64_t seed)
+{
+    return MurmurHash64A(key, len, seed);
+}
+
+// Calls the reference's own codec self test (src/compressAlignment.cpp:160-220).
+int ref_test_alignment_compression()
+{
+    try { CoutCapture c; testAlignmentCompression(); return 0; }
+    catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// shasta::compress on an ordinal list; returns malloc'd bytes.
+int ref_compress(const uint32_t* ordinals, uint64_t n, uint8_t** bytes, uint64_t* byteCount)
+{
+    try {
+        Alignment a;
+        a.ordinals.resize(n);
+        for(uint64_t i = 0; i < n; i++) a.ordinals[i] = {ordinals[2*i], ordinals[2*i+1]};
+        string s;
+        compress(a, s);
+        *byteCount = s.size();
+        *bytes = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, s.size())));
+        std::memcpy(*bytes, s.data(), s.size());
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+int ref_decompress(const uint8_t* bytes, uint64_t byteCount, uint32_t** ordinals, uint64_t* n)
+{
+    try {
+        Alignment a;
+        const char* p = reinterpret_cast<const char*>(bytes);
+        decompress(span<const char>(p, p + byteCount), a);
+        *n = a.ordinals.size();
+        *ordinals = static_cast<uint32_t*>(std::malloc(std::max<size_t>(1, 8 * a.ordinals.size())));
+        for(uint64_t i = 0; i < a.ordinals.size(); i++) {
+            (*ordinals)[2*i] = a.ordinals[i][0];
+            (*ordinals)[2*i+1] = a.ordinals[i][1];
+        }
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// AlignmentInfo::create (src/Alignment.cpp:67-113).
+int ref_alignment_info(const uint32_t* ordinals, uint64_t n, uint32_t nx, uint32_t ny,
+    shasta_alignment_info* out)
+{
+    try {
+        Alignment a;
+        a.ordinals.resize(n);
+        for(uint64_t i = 0; i < n; i++) a.ordinals[i] = {ordinals[2*i], ordinals[2*i+1]};
+        AlignmentInfo info;
+        info.create(a, nx, ny);
+        std::memset(out, 0, sizeof(*out));
+        for(int i = 0; i < 2; i++) {
+            out->data[i].markerCount = info.data[i].markerCount;
+            out->data[i].firstOrdinal = info.data[i].firstOrdinal;
+            out->data[i].lastOrdinal = info.data[i].lastOrdinal;
+        }
+        out->markerCount = info.markerCount;
+        out->minOrdinalOffset = info.minOrdinalOffset;
+        out->maxOrdinalOffset = info.maxOrdinalOffset;
+        out->averageOrdinalOffset = info.averageOrdinalOffset;
+        out->maxSkip = info.maxSkip;
+        out->maxDrift = info.maxDrift;
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+void ref_free(void* p) { std::free(p); }
+
+
+// --------------------------------------------------------------------------
+// FASTA -> markers, with the reference's ReadLoader and MarkerFinder.
+// --------------------------------------------------------------------------
+int ref_markers_from_fasta(
+    const char* fastaPath, uint64_t k, double probability, int seed,
+    uint64_t minReadLength, uint64_t threadCount,
+    uint64_t* readCountOut, uint64_t** tocOut, uint8_t** dataOut)
+{
+    try {
+        CoutCapture capture;
+        if(threadCount == 0) threadCount = std::thread::hardware_concurrency();
+        Reads reads;
+        reads.createNew(1, "", "", "", "", "", "", 4096);
+        {
+            ReadLoader loader(fastaPath, 1, minReadLength, false, threadCount, "", 4096, reads);
+        }
+
+        // K-mer table: src/AssemblerKmers.cpp:147-180 (initializeKmerTable) and
+        // :33-100 (randomlySelectKmers), restated.
+        MemoryMapped::Vector<KmerInfo> kmerTable;
+        kmerTable.createNew("", 4096);
+        const uint64_t kmerCount = 1ULL << (2ULL * k);
+        kmerTable.resize(kmerCount);
+        for(uint64_t kmerId = 0; kmerId < kmerCount; kmerId++) {
+            const Kmer kmer(kmerId, k);
+            KmerInfo& info = kmerTable[kmerId];
+            info.frequency = 0;
+            info.reverseComplementedKmerId = KmerId(kmer.reverseComplement(k).id(k));
+            info.isMarker = false;
+            info.isRleKmer = true;
+            for(size_t i = 1; i < k; i++) {
+                if(kmer[i-1] == kmer[i]) { info.isRleKmer = false; break; }
+            }
+            info.hash = 0;
+        }
+        const double p = 1. - std::sqrt(1. - probability);
+        std::mt19937 randomSource(seed);
+        std::uniform_real_distribution<> uniformDistribution;
+        for(uint64_t kmerId = 0; kmerId < kmerCount; kmerId++) {
+            const double x = uniformDistribution(randomSource);
+            if(x <= p) {
+                kmerTable[kmerId].isMarker = true;
+                kmerTable[kmerTable[kmerId].reverseComplementedKmerId].isMarker = true;
+            }
+        }
+
+        Markers markers;
+        markers.createNew("", 4096);
+        {
+            MarkerFinder finder(k, kmerTable, reads, markers, threadCount);
+        }
+
+        const uint64_t n = markers.size();
+        *readCountOut = n / 2;
+        uint64_t* toc = static_cast<uint64_t*>(std::malloc((n + 1) * sizeof(uint64_t)));
+        toc[0] = 0;
+        for(uint64_t i = 0; i < n; i++) toc[i+1] = toc[i] + markers.size(i);
+        uint8_t* data = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(1, 7 * toc[n])));
+        if(toc[n]) std::memcpy(data, markers.begin(), 7 * toc[n]);
+        *tocOut = toc;
+        *dataOut = data;
+        markers.remove();
+        kmerTable.remove();
+        reads.remove();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+
+// --------------------------------------------------------------------------
+// Seam 1: the reference LowHash0, unmodified.
+// --------------------------------------------------------------------------
+int ref_lowhash0(
+    uint64_t readCount,
+    const uint64_t* markersToc,
+    const void* markersData,
+    const uint8_t* readFlags,
+    const shasta_lowhash0_params* params,
+    uint64_t threadCount,
+    const char* workDirectory,      // the two CSV side files are written here
+    uint64_t* readLowHashStatistics,
+    shasta_lowhash0_result* result)
+{
+    try {
+        std::memset(result, 0, sizeof(*result));
+        ChdirGuard cd(workDirectory);
+        Markers markers;
+        fillMarkers(markers, readCount, markersToc, markersData);
+
+        Reads reads;
+        reads.createNew(1, "", "", "", "", "", "", 4096);
+        reads.readFlags.resize(readCount);
+        for(uint64_t i = 0; i < readCount; i++) {
+            ReadFlags f;
+            if(readFlags) *reinterpret_cast<uint8_t*>(&f) = readFlags[i];
+            reads.readFlags[i] = f;
+        }
+
+        MemoryMapped::Vector<KmerInfo> kmerTable;      // never dereferenced by LowHash0
+        kmerTable.createNew("", 4096);
+        MemoryMapped::Vector<OrientedReadPair> candidates;
+        candidates.createNew("", 4096);
+        MemoryMapped::Vector< array<uint64_t, 3> > statistics;
+        statistics.createNew("", 4096);
+
+        std::string console;
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            CoutCapture capture;
+            LowHash0 lowHash0(
+                params->m, params->hashFraction,
+                params->minHashIterationCount, params->alignmentCandidatesPerRead,
+                params->log2MinHashBucketCount,
+                params->minBucketSize, params->maxBucketSize, params->minFrequency,
+                threadCount, kmerTable, reads, markers, candidates, statistics, "", 4096);
+            console = capture.str();
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        result->seconds = std::chrono::duration<double>(t1 - t0).count();
+
+        // Outputs.
+        result->candidateCount = candidates.size();
+        result->candidates = static_cast<shasta_oriented_read_pair*>(
+            std::calloc(std::max<uint64_t>(1, candidates.size()), sizeof(shasta_oriented_read_pair)));
+        for(uint64_t i = 0; i < candidates.size(); i++) {
+            result->candidates[i].readIds[0] = candidates[i].readIds[0];
+            result->candidates[i].readIds[1] = candidates[i].readIds[1];
+            result->candidates[i].isSameStrand = candidates[i].isSameStrand ? 1 : 0;
+        }
+        for(uint64_t i = 0; i < readCount; i++) {
+            for(int c = 0; c < 3; c++) readLowHashStatistics[3*i + c] = statistics[i][c];
+        }
+
+        // Console lines (src/LowHash0.cpp:97-98, :193-196).
+        std::vector<uint64_t> high, total;
+        {
+            std::istringstream s(console);
+            std::string line;
+            while(std::getline(s, line)) {
+                unsigned long long it, h, t, c;
+                unsigned l2; unsigned long long bc;
+                if(std::sscanf(line.c_str(),
+                    "Alignment candidates after lowhash iteration %llu: high frequency %llu, total %llu, capacity %llu.",
+                    &it, &h, &t, &c) == 4) {
+                    high.push_back(h); total.push_back(t);
+                } else if(std::sscanf(line.c_str(),
+                    "LowHash0 algorithm will use 2^%u = %llu buckets.", &l2, &bc) == 2) {
+                    result->log2BucketCount = l2;
+                }
+            }
+        }
+        result->iterationCount = uint32_t(high.size());
+        result->highFrequency = mallocCopy(high);
+        result->total = mallocCopy(total);
+
+        // LowHashBucketHistogram.csv (src/LowHash0.cpp:586-595).
+        std::vector<uint64_t> rows;
+        {
+            std::ifstream csv("LowHashBucketHistogram.csv");
+            std::string line;
+            std::getline(csv, line);
+            while(std::getline(csv, line)) {
+                unsigned long long a, b, c, d;
+                if(std::sscanf(line.c_str(), "%llu,%llu,%llu,%llu", &a, &b, &c, &d) == 4) {
+                    rows.push_back(a); rows.push_back(b); rows.push_back(c);
+                }
+            }
+        }
+        result->histogramRowCount = rows.size() / 3;
+        result->histogram = mallocCopy(rows);
+
+        candidates.remove();
+        statistics.remove();
+        kmerTable.remove();
+        markers.remove();
+        reads.remove();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+void ref_lowhash0_free(shasta_lowhash0_result* r)
+{
+    std::free(r->candidates); std::free(r->highFrequency); std::free(r->total); std::free(r->histogram);
+    std::memset(r, 0, sizeof(*r));
+}
+
+
+// --------------------------------------------------------------------------
+// Seam 2: per-candidate loop of src/AssemblerAlign.cpp:378-483 (method 4,
+// one thread => output in candidate order) around the reference Align4::align.
+// --------------------------------------------------------------------------
+static void sortedMarkersOf(const span<const CompressedMarker>& um, vector< pair<KmerId, uint32_t> >& sm)
+{
+    // src/AssemblerAlign4.cpp:243-258
+    const uint64_t n = um.size();
+    sm.resize(n);
+    for(uint64_t ordinal = 0; ordinal < n; ordinal++) {
+        sm[ordinal] = make_pair(KmerId(um[ordinal].kmerId), uint32_t(ordinal));
+    }
+    sort(sm.begin(), sm.end(), OrderPairsByFirstOnly<KmerId, uint32_t>());
+}
+
+static void copyInfo(const AlignmentInfo& info, shasta_alignment_info& out)
+{
+    std::memset(&out, 0, sizeof(out));
+    for(int i = 0; i < 2; i++) {
+        out.data[i].markerCount = info.data[i].markerCount;
+        out.data[i].firstOrdinal = info.data[i].firstOrdinal;
+        out.data[i].lastOrdinal = info.data[i].lastOrdinal;
+    }
+    out.markerCount = info.markerCount;
+    out.minOrdinalOffset = info.minOrdinalOffset;
+    out.maxOrdinalOffset = info.maxOrdinalOffset;
+    out.averageOrdinalOffset = info.averageOrdinalOffset;
+    out.maxSkip = info.maxSkip;
+    out.maxDrift = info.maxDrift;
+}
+
+int ref_align4_batch(
+    uint64_t readCount,
+    const uint64_t* markersToc,
+    const void* markersData,
+    uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* o,
+    int wantOrdinals,
+    shasta_align4_result* result)
+{
+    try {
+        std::memset(result, 0, sizeof(*result));
+        const auto t0 = std::chrono::steady_clock::now();
+        CoutCapture capture;
+        const CompressedMarker* all = static_cast<const CompressedMarker*>(markersData);
+
+        Align4::Options options;
+        options.deltaX = o->deltaX;
+        options.deltaY = o->deltaY;
+        options.minEntryCountPerCell = o->minEntryCountPerCell;
+        options.maxDistanceFromBoundary = o->maxDistanceFromBoundary;
+        options.minAlignedMarkerCount = o->minAlignedMarkerCount;
+        options.minAlignedFraction = o->minAlignedFraction;
+        options.maxSkip = o->maxSkip;
+        options.maxDrift = o->maxDrift;
+        options.maxTrim = o->maxTrim;
+        options.maxBand = o->maxBand;
+        options.matchScore = o->matchScore;
+        options.mismatchScore = o->mismatchScore;
+        options.gapScore = o->gapScore;
+
+        MemoryMapped::ByteAllocator byteAllocator("", 4096, 2ULL * 1024 * 1024 * 1024);
+
+        std::vector<shasta_alignment_data> alignmentData;
+        std::vector<uint64_t> compressedToc(1, 0);
+        std::vector<uint8_t> compressedData;
+        std::vector<uint8_t> status(candidateCount, SHASTA_ALIGN_EMPTY);
+        std::vector<uint64_t> ordinalsToc(1, 0);
+        std::vector<uint32_t> ordinals;
+
+        array<vector< pair<KmerId, uint32_t> >, 2> sorted;
+        Alignment alignment;
+        AlignmentInfo alignmentInfo;
+        string compressedAlignment;
+
+        for(uint64_t i = 0; i < candidateCount; i++) {
+            const shasta_oriented_read_pair& c = candidates[i];
+            SHASTA_ASSERT(c.readIds[0] < c.readIds[1]);
+            SHASTA_ASSERT(c.readIds[1] < readCount);
+            const OrientedReadId or0(c.readIds[0], 0);
+            const OrientedReadId or1(c.readIds[1], c.isSameStrand ? 0 : 1);
+            array<span<const CompressedMarker>, 2> m;
+            m[0] = span<const CompressedMarker>(all + markersToc[or0.getValue()], all + markersToc[or0.getValue() + 1]);
+            m[1] = span<const CompressedMarker>(all + markersToc[or1.getValue()], all + markersToc[or1.getValue() + 1]);
+            array<span< const pair<KmerId, uint32_t> >, 2> sm;
+            for(int j = 0; j < 2; j++) {
+                sortedMarkersOf(m[j], sorted[j]);
+                const pair<KmerId, uint32_t>* b = sorted[j].data();
+                sm[j] = span< const pair<KmerId, uint32_t> >(b, b + sorted[j].size());
+            }
+
+            bool failed = false;
+            try {
+                Align4::align(m, sm, options, byteAllocator, alignment, alignmentInfo, false);
+                SHASTA_ASSERT(byteAllocator.isEmpty());
+            } catch(...) {
+                failed = true;          // src/AssemblerAlign.cpp:419-435: skip this candidate
+            }
+            if(failed) {
+                status[i] = SHASTA_ALIGN_SKIPPED;
+                if(wantOrdinals) ordinalsToc.push_back(ordinals.size() / 2);
+                continue;
+            }
+
+            if(wantOrdinals) {
+                for(const auto& p : alignment.ordinals) { ordinals.push_back(p[0]); ordinals.push_back(p[1]); }
+                ordinalsToc.push_back(ordinals.size() / 2);
+            }
+            if(alignment.ordinals.empty()) { status[i] = SHASTA_ALIGN_EMPTY; }
+            else { status[i] = SHASTA_ALIGN_REJECTED; }
+
+            // Filters, src/AssemblerAlign.cpp:439-472.
+            if(alignment.ordinals.size() < o->minAlignedMarkerCount) continue;
+            if(min(alignmentInfo.alignedFraction(0), alignmentInfo.alignedFraction(1)) < o->minAlignedFraction) continue;
+            uint32_t leftTrim, rightTrim;
+            tie(leftTrim, rightTrim) = alignmentInfo.computeTrim();
+            if(leftTrim > o->maxTrim || rightTrim > o->maxTrim) continue;
+            if(alignment.maxSkip() > o->maxSkip) continue;
+            if(alignment.maxDrift() > o->maxDrift) continue;
+            if(o->suppressContainments && alignmentInfo.isContaining(uint32_t(o->maxTrim))) continue;
+
+            status[i] = SHASTA_ALIGN_STORED;
+            shasta_alignment_data ad;
+            std::memset(&ad, 0, sizeof(ad));
+            ad.pair = c;
+            ad.pair.pad[0] = ad.pair.pad[1] = ad.pair.pad[2] = 0;
+            copyInfo(alignmentInfo, ad.info);
+            alignmentData.push_back(ad);
+            shasta::compress(alignment, compressedAlignment);
+            compressedData.insert(compressedData.end(), compressedAlignment.begin(), compressedAlignment.end());
+            compressedToc.push_back(compressedData.size());
+        }
+
+        result->alignmentCount = alignmentData.size();
+        result->alignmentData = mallocCopy(alignmentData);
+        result->compressedToc = mallocCopy(compressedToc);
+        result->compressedData = mallocCopy(compressedData);
+        result->status = mallocCopy(status);
+        if(wantOrdinals) {
+            result->ordinalsToc = mallocCopy(ordinalsToc);
+            result->ordinals = mallocCopy(ordinals);
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        result->seconds = std::chrono::duration<double>(t1 - t0).count();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+void ref_align4_free(shasta_align4_result* r)
+{
+    std::free(r->alignmentData); std::free(r->compressedToc); std::free(r->compressedData);
+    std::free(r->status); std::free(r->ordinalsToc); std::free(r->ordinals);
+    std::memset(r, 0, sizeof(*r));
+}
+
+}  // extern "C"
