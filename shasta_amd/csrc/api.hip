@@ -1,0 +1,158 @@
+// C ABI of libshasta_mi355x.so (include/shasta_mi355x.h).  Exceptions never cross
+// the boundary: every entry point returns non-zero and records the message.
+#include "context.hpp"
+
+#include <cstring>
+#include <string>
+
+using namespace shasta_mi355x;
+
+struct shasta_mi355x_ctx { Context impl; explicit shasta_mi355x_ctx(int d) : impl(d) {} };
+
+static thread_local std::string lastError;
+
+#define API_BEGIN try {
+#define API_END(rc) } catch(const std::exception& e) { lastError = e.what(); return rc; } \
+                      catch(...) { lastError = "unknown error"; return rc; }
+
+extern "C" {
+
+const char* shasta_mi355x_last_error(void) { return lastError.c_str(); }
+const char* shasta_mi355x_version(void) { return "shasta_mi355x 0.1 (gfx950)"; }
+
+int shasta_mi355x_device_count(void)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for(int i = 0; i < n; i++) {
+        hipDeviceProp_t prop;
+        if(hipGetDeviceProperties(&prop, i) == hipSuccess && std::string(prop.gcnArchName).rfind("gfx950", 0) == 0) ++usable;
+    }
+    return usable;
+}
+
+shasta_mi355x_ctx* shasta_mi355x_create(int device)
+{
+    API_BEGIN
+    return new shasta_mi355x_ctx(device);
+    API_END(nullptr)
+}
+
+void shasta_mi355x_destroy(shasta_mi355x_ctx* c) { delete c; }
+
+int shasta_mi355x_set_markers(shasta_mi355x_ctx* c, uint64_t readCount,
+    const uint64_t* markersToc, const void* markersData, const uint8_t* readFlags)
+{
+    API_BEGIN
+    if(!c || !markersToc || (!markersData && markersToc[2 * readCount])) throw std::runtime_error("set_markers: null argument");
+    c->impl.setMarkers(readCount, markersToc, markersData, nullptr, readFlags);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_set_kmer_ids(shasta_mi355x_ctx* c, uint64_t readCount,
+    const uint64_t* markersToc, const uint32_t* kmerIds, const uint8_t* readFlags)
+{
+    API_BEGIN
+    if(!c || !markersToc || (!kmerIds && markersToc[2 * readCount])) throw std::runtime_error("set_kmer_ids: null argument");
+    c->impl.setMarkers(readCount, markersToc, nullptr, kmerIds, readFlags);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_set_shard(shasta_mi355x_ctx* c, int rank, int worldSize, uint64_t readBegin, uint64_t readEnd)
+{
+    API_BEGIN
+    if(!c) throw std::runtime_error("set_shard: null context");
+    if(worldSize < 1 || rank < 0 || rank >= worldSize || readBegin > readEnd || readEnd > c->impl.readCount) {
+        throw std::runtime_error("set_shard: invalid shard");
+    }
+    c->impl.rank = rank; c->impl.worldSize = worldSize;
+    c->impl.readBegin = readBegin; c->impl.readEnd = readEnd;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lowhash0_run(shasta_mi355x_ctx* c, const shasta_lowhash0_params* params,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result* result)
+{
+    API_BEGIN
+    if(!c || !params || !readLowHashStatistics || !result) throw std::runtime_error("lowhash0_run: null argument");
+    lowhash0Run(c->impl, *params, readLowHashStatistics, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lowhash0(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    const uint8_t* readFlags, const shasta_lowhash0_params* params,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result* result)
+{
+    API_BEGIN
+    if(!markersToc || !params || !readLowHashStatistics || !result) throw std::runtime_error("lowhash0: null argument");
+    int device = 0;
+    (void)hipGetDevice(&device);
+    shasta_mi355x_ctx c(device);
+    c.impl.setMarkers(readCount, markersToc, markersData, nullptr, readFlags);
+    lowhash0Run(c.impl, *params, readLowHashStatistics, *result);
+    return 0;
+    API_END(1)
+}
+
+void shasta_mi355x_lowhash0_free(shasta_lowhash0_result* r) { if(r) lowhash0Free(*r); }
+
+int shasta_mi355x_align4_run(shasta_mi355x_ctx* c, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align4_options* options,
+    int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!c || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align4_run: null argument");
+    align4Run(c->impl, candidateCount, candidates, *options, wantOrdinals != 0, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_align4_batch(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* options, int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!markersToc || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align4_batch: null argument");
+    int device = 0;
+    (void)hipGetDevice(&device);
+    shasta_mi355x_ctx c(device);
+    c.impl.setMarkers(readCount, markersToc, markersData, nullptr, nullptr);
+    align4Run(c.impl, candidateCount, candidates, *options, wantOrdinals != 0, *result);
+    return 0;
+    API_END(1)
+}
+
+void shasta_mi355x_align4_free(shasta_align4_result* r) { if(r) align4Free(*r); }
+
+int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx* c, shasta_mi355x_kernel_times* t)
+{
+    API_BEGIN
+    if(!c || !t) throw std::runtime_error("get_kernel_times: null argument");
+    *t = c->impl.times;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_hash_windows(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out)
+{
+    API_BEGIN
+    hashWindowsUnit(kmerIds, n, m, iteration, out);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_banded_dp(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny,
+    int32_t bandMin, int32_t bandMax, uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score)
+{
+    API_BEGIN
+    bandedDpUnit(k0, nx, k1, ny, bandMin, bandMax, ordinals, capacity, count, score);
+    return 0;
+    API_END(1)
+}
+
+}  // extern "C"

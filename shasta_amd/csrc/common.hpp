@@ -1,0 +1,70 @@
+// Shared host-side plumbing for libshasta_mi355x.so: error propagation, device
+// buffers, the context object.  gfx950 only; no CPU fallback anywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace shasta_mi355x {
+
+inline void hipCheck(hipError_t e, const char* what, const char* file, int line)
+{
+    if(e != hipSuccess) {
+        throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " in " + what +
+            " at " + file + ":" + std::to_string(line));
+    }
+}
+#define HIP_CHECK(x) ::shasta_mi355x::hipCheck((x), #x, __FILE__, __LINE__)
+
+// Mirrors SHASTA_ASSERT (src/SHASTA_ASSERT.hpp): throws std::runtime_error.
+#define MI355X_ASSERT(x) do { if(!(x)) throw std::runtime_error( \
+    std::string("Assertion failed: ") + #x + " at " + __FILE__ + ":" + std::to_string(__LINE__)); } while(0)
+
+// A device allocation that only grows.  HBM is 288 GB: buffers are sized once
+// from the marker count and kept for the life of the context.
+template<class T> class DeviceBuffer {
+public:
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+    void release() { if(p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    // Ensures capacity >= n.  Contents are NOT preserved unless keep is true.
+    void reserve(size_t n, hipStream_t stream = nullptr, bool keep = false)
+    {
+        if(n <= cap) return;
+        size_t newCap = n + n / 8 + 64;
+        T* q = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&q), newCap * sizeof(T)));
+        if(keep && p && cap) {
+            HIP_CHECK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        if(p) (void)hipFree(p);
+        p = q; cap = newCap;
+    }
+    T* data() const { return p; }
+    size_t capacity() const { return cap; }
+    void swap(DeviceBuffer& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
+private:
+    T* p = nullptr;
+    size_t cap = 0;
+};
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventTimer() { HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); }
+    ~EventTimer() { if(a) (void)hipEventDestroy(a); if(b) (void)hipEventDestroy(b); }
+    void start(hipStream_t s) { HIP_CHECK(hipEventRecord(a, s)); }
+    void stop(hipStream_t s) { HIP_CHECK(hipEventRecord(b, s)); }
+    double seconds() { HIP_CHECK(hipEventSynchronize(b)); float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b)); return ms * 1e-3; }
+};
+
+inline unsigned divUp(uint64_t a, uint64_t b) { return unsigned((a + b - 1) / b); }
+
+}  // namespace shasta_mi355x

@@ -1,0 +1,59 @@
+// The device-resident state behind shasta_mi355x_ctx: Shasta's Markers laid out
+// for HBM (dense uint32 kmerIds[M] + uint64 toc[2R+1] + 1-byte ReadFlags[R]),
+// one HIP stream, and the grow-only workspaces of the two stages.
+#pragma once
+
+#include "common.hpp"
+#include "primitives.hpp"
+#include "../../include/shasta_mi355x.h"
+
+#include <memory>
+#include <vector>
+
+namespace shasta_mi355x {
+
+constexpr int HASH_TILE = 256;        // markers per hash-kernel tile
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // Markers in HBM.
+    uint64_t readCount = 0;
+    uint64_t markerCount = 0;                // both strands
+    std::vector<uint64_t> hostToc;           // 2R+1
+    DeviceBuffer<uint64_t> toc;              // 2R+1
+    DeviceBuffer<uint32_t> kmerIds;          // M
+    DeviceBuffer<uint8_t> readFlags;         // R
+    DeviceBuffer<uint32_t> tileFirstRead;    // ceil(M/HASH_TILE)+1: oriented read owning the tile's first marker
+
+    // Shard: reads hashed here, bucket range owned here.
+    int rank = 0, worldSize = 1;
+    uint64_t readBegin = 0, readEnd = 0;
+
+    RadixSortWorkspace sortWs;
+    shasta_mi355x_kernel_times times = {};
+
+    // Sorted markers (Assembler::computeSortedMarkers, src/AssemblerAlign4.cpp:190-261),
+    // built lazily by the Align4 stage and kept while the markers do not change.
+    bool sortedMarkersValid = false;
+    DeviceBuffer<uint32_t> sortedKmerIds;    // M, per oriented read sorted by kmerId
+    DeviceBuffer<uint32_t> sortedOrdinals;   // M
+
+    explicit Context(int device);
+    ~Context();
+    void setMarkers(uint64_t readCount, const uint64_t* toc, const void* data7,
+        const uint32_t* denseKmerIds, const uint8_t* flags);
+};
+
+// Stage entry points (lowhash0.hip, align4.hip).
+void lowhash0Run(Context&, const shasta_lowhash0_params&, uint64_t* readLowHashStatistics, shasta_lowhash0_result&);
+void lowhash0Free(shasta_lowhash0_result&);
+void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&);
+void align4Free(shasta_align4_result&);
+void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);
+void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
+    uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score);
+
+}  // namespace shasta_mi355x

@@ -1,0 +1,757 @@
+// LowHash0 on MI355X (gfx950).  Replaces LowHash0::LowHash0 and its passes
+// (/root/reference/src/LowHash0.cpp:23-257, :261-308, :314-484, :493-613).
+//
+// The reference keeps 2^log2 bucket counters and fills a CSR of buckets with
+// atomics; here every iteration is
+//   K1  hashWindowsKernel    one pass over the dense kmerIds (4 B/marker), MurmurHash64A per
+//                            m-marker window, keep hash < threshold, block-staged compaction
+//   K2  radix sort of the ~f*M records on the bucket id (replaces count/toc/fill)
+//   K3  bucket boundaries, per-read {sparse,good,crowded} statistics, bucket-size histogram
+//   K4  all ordered pairs of each admissible bucket -> 64-bit pair keys
+//   K5  sort + run-length of the pair keys, merge into the running (key, frequency) table
+//   K6  (after the loop) frequency >= minFrequency -> OrientedReadPair list
+// Bit-exactness notes follow SURVEY.md Appendix A.1.
+#include "context.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <limits>
+#include <map>
+
+namespace shasta_mi355x {
+
+// ---------------------------------------------------------------------------
+// MurmurHash64A (src/MurmurHash2.cpp:96-140) specialised for a window of m
+// little-endian uint32 kmer ids: len = 4m, blocks = pairs of ids, odd m leaves
+// a 4-byte tail (switch cases 4..1 = the 32-bit word itself).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t murmurMix(uint64_t k)
+{
+    const uint64_t mul = 0xc6a4a7935bd1e995ULL;
+    k *= mul; k ^= k >> 47; k *= mul;
+    return k;
+}
+
+template<int M_FIXED>
+__device__ __forceinline__ uint64_t murmurWindow(const uint32_t* w, uint32_t m, uint64_t seed)
+{
+    const uint64_t mul = 0xc6a4a7935bd1e995ULL;
+    const uint32_t mm = M_FIXED ? uint32_t(M_FIXED) : m;
+    uint64_t h = seed ^ (uint64_t(4u * mm) * mul);
+    const uint32_t blocks = mm >> 1;
+#pragma unroll
+    for(uint32_t b = 0; b < blocks; b++) {
+        const uint64_t k = uint64_t(w[2 * b]) | (uint64_t(w[2 * b + 1]) << 32);
+        h ^= murmurMix(k);
+        h *= mul;
+    }
+    if(mm & 1u) {
+        h ^= uint64_t(w[mm - 1]);
+        h *= mul;
+    }
+    h ^= h >> 47; h *= mul; h ^= h >> 47;
+    return h;
+}
+
+// ---------------------------------------------------------------------------
+// K0: CompressedMarker (packed 7 bytes: u32 kmerId, u24 position,
+// src/Marker.hpp:56-70) -> dense kmerIds.  LowHash0::createKmerIds :286-308.
+// words must be readable 8 bytes past the last marker.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+stripMarkersKernel(const uint32_t* __restrict__ words, uint32_t* __restrict__ kmerIds, uint64_t n)
+{
+    for(uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint64_t byte = 7ULL * i;
+        const uint64_t w = byte >> 2;
+        const uint32_t lo = words[w], hi = words[w + 1];
+        kmerIds[i] = __builtin_amdgcn_alignbyte(hi, lo, uint32_t(byte & 3u));
+    }
+}
+
+// Oriented read containing the first marker of each hash tile (upper_bound on toc).
+__global__ void __launch_bounds__(256)
+tileFirstReadKernel(const uint64_t* __restrict__ toc, uint64_t orientedReadCount, uint64_t markerCount,
+    uint32_t* __restrict__ tileFirstRead, uint64_t tileCount)
+{
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(t > tileCount) return;
+    const uint64_t i = t * HASH_TILE;
+    if(i >= markerCount) { tileFirstRead[t] = uint32_t(orientedReadCount ? orientedReadCount - 1 : 0); return; }
+    uint64_t lo = 0, hi = orientedReadCount + 1;       // first idx in [0, 2R] with toc[idx] > i
+    while(lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if(toc[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    tileFirstRead[t] = uint32_t(lo - 1);
+}
+
+// ---------------------------------------------------------------------------
+// K1: pass 1 of the reference (src/LowHash0.cpp:314-360).
+// One thread per window; a block walks tiles of 256 consecutive markers with a
+// (m-1)-marker halo staged in LDS, so every kmer id is read from HBM once.
+// Low hashes are staged in LDS and flushed with one global atomic per ~1000.
+// ---------------------------------------------------------------------------
+constexpr int HASH_THREADS = HASH_TILE;
+constexpr int HASH_HALO = 32;                 // supports m <= 33
+constexpr int HASH_STAGE = 1024;
+
+template<int M_FIXED>
+__global__ void __launch_bounds__(HASH_THREADS)
+hashWindowsKernel(
+    const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc,
+    const uint8_t* __restrict__ readFlags, const uint32_t* __restrict__ tileFirstRead,
+    uint64_t markerBegin, uint64_t markerEnd, uint64_t markerCount,
+    uint32_t m, uint64_t seed, uint64_t hashThreshold, uint32_t mask,
+    uint32_t* __restrict__ outKeys, uint64_t* __restrict__ outVals,
+    unsigned long long* __restrict__ counter, uint64_t capacity)
+{
+    __shared__ uint32_t sK[HASH_TILE + HASH_HALO];
+    __shared__ uint32_t sKeys[HASH_STAGE];
+    __shared__ uint64_t sVals[HASH_STAGE];
+    __shared__ uint32_t sFill;
+    __shared__ unsigned long long sBase;
+
+    const uint32_t mm = M_FIXED ? uint32_t(M_FIXED) : m;
+    const int tid = int(threadIdx.x);
+    const int lane = tid & 63;
+    if(tid == 0) sFill = 0;
+    __syncthreads();
+
+    const uint64_t firstTile = markerBegin / HASH_TILE;
+    const uint64_t lastTile = (markerEnd + HASH_TILE - 1) / HASH_TILE;      // exclusive
+    for(uint64_t tile = firstTile + blockIdx.x; tile < lastTile; tile += gridDim.x) {
+        const uint64_t base = tile * HASH_TILE;
+        const uint64_t i = base + uint64_t(tid);
+        sK[tid] = (i < markerCount) ? kmerIds[i] : 0u;
+        if(tid < int(mm) - 1) {
+            const uint64_t j = base + HASH_TILE + uint64_t(tid);
+            sK[HASH_TILE + tid] = (j < markerCount) ? kmerIds[j] : 0u;
+        }
+        __syncthreads();
+
+        bool hit = false;
+        uint64_t hash = 0;
+        uint32_t orientedReadId = 0;
+        if(i >= markerBegin && i < markerEnd) {
+            uint32_t r = tileFirstRead[tile];
+            while(toc[r + 1] <= i) ++r;
+            const uint64_t end = toc[r + 1];
+            // Reads with fewer than m markers (:337) and palindromic reads (:325) produce nothing.
+            if(i + mm <= end && !(readFlags[r >> 1] & 1u)) {
+                hash = murmurWindow<M_FIXED>(&sK[tid], mm, seed);
+                hit = hash < hashThreshold;                                   // :350, strict
+                orientedReadId = r;
+            }
+        }
+        const uint64_t votes = __ballot(hit);
+        if(votes) {
+            uint32_t waveBase = 0;
+            if(lane == 0) waveBase = atomicAdd(&sFill, uint32_t(__popcll(votes)));
+            waveBase = __shfl(waveBase, 0, WAVE);
+            if(hit) {
+                const uint32_t slot = waveBase + uint32_t(__popcll(votes & laneMaskLt()));
+                sKeys[slot] = uint32_t(hash) & mask;                          // bucket id, :352
+                sVals[slot] = (hash & 0xffffffff00000000ULL) | orientedReadId; // BucketEntry: hashHighBits, orientedReadId
+            }
+        }
+        __syncthreads();
+        if(sFill > HASH_STAGE - HASH_TILE) {
+            const uint32_t fill = sFill;
+            if(tid == 0) sBase = atomicAdd(counter, (unsigned long long)fill);
+            __syncthreads();
+            for(uint32_t k = tid; k < fill; k += HASH_THREADS) {
+                const uint64_t dst = sBase + k;
+                if(dst < capacity) { outKeys[dst] = sKeys[k]; outVals[dst] = sVals[k]; }
+            }
+            __syncthreads();
+            if(tid == 0) sFill = 0;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const uint32_t fill = sFill;
+    if(fill) {
+        if(tid == 0) sBase = atomicAdd(counter, (unsigned long long)fill);
+        __syncthreads();
+        for(uint32_t k = tid; k < fill; k += HASH_THREADS) {
+            const uint64_t dst = sBase + k;
+            if(dst < capacity) { outKeys[dst] = sKeys[k]; outVals[dst] = sVals[k]; }
+        }
+    }
+}
+
+// Unit seam: all window hashes of one kmer-id array.
+__global__ void __launch_bounds__(256)
+hashAllWindowsKernel(const uint32_t* __restrict__ kmerIds, uint64_t n, uint32_t m, uint64_t seed, uint64_t* __restrict__ out)
+{
+    const uint64_t j = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(j + m > n) return;
+    uint32_t w[HASH_HALO + 1];
+    for(uint32_t k = 0; k < m; k++) w[k] = kmerIds[j + k];
+    out[j] = murmurWindow<0>(w, m, seed);
+}
+
+// ---------------------------------------------------------------------------
+// K3/K4 helpers on the sorted records.
+// ---------------------------------------------------------------------------
+template<class K>
+__global__ void __launch_bounds__(256)
+markHeadsKernel(const K* __restrict__ keys, uint64_t n, uint32_t* __restrict__ flags)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    else if(i == n) flags[i] = 0u;
+}
+
+// starts[g] = index of the first element of group g; starts[groupCount] = n.
+template<class K>
+__global__ void __launch_bounds__(256)
+groupStartsKernel(const K* __restrict__ keys, const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ starts)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i < n) {
+        if(i == 0 || keys[i] != keys[i - 1]) starts[pos[i]] = uint32_t(i);
+    } else if(i == n) {
+        starts[pos[n]] = uint32_t(n);
+    }
+}
+
+constexpr int SIZE_HIST_CAP = 2048;
+
+// Per record: pass-2 statistics (src/LowHash0.cpp:386-393), bucket-size histogram
+// (:566-613, one vote per bucket = per head record), and the number of pairs this
+// record starts in pass 3 (:430-457).
+__global__ void __launch_bounds__(256)
+bucketStatsKernel(
+    const uint32_t* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos,
+    const uint32_t* __restrict__ starts, uint64_t n,
+    uint64_t minBucketSize, uint64_t maxBucketSize,
+    unsigned long long* __restrict__ stats,             // [R][3]
+    unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP]
+    uint32_t* __restrict__ overflowSizes, uint32_t* __restrict__ overflowCount, uint32_t overflowCapacity,
+    uint64_t* __restrict__ pairCounts)                  // [n+1]
+{
+    __shared__ uint32_t sHist[SIZE_HIST_CAP];
+    for(int k = threadIdx.x; k < SIZE_HIST_CAP; k += blockDim.x) sHist[k] = 0;
+    __syncthreads();
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i < n) {
+        const uint32_t b = pos[i + 1] - 1;
+        const uint32_t begin = starts[b], end = starts[b + 1];
+        const uint64_t size = end - begin;
+        const uint64_t v = vals[i];
+        const uint32_t orientedReadId = uint32_t(v);
+        const uint32_t readId = orientedReadId >> 1;
+        const int cls = (size < minBucketSize) ? 0 : ((size > maxBucketSize) ? 2 : 1);
+        atomicAdd(&stats[3ULL * readId + cls], 1ULL);
+        if(i == begin) {
+            if(size < SIZE_HIST_CAP) atomicAdd(&sHist[size], 1u);
+            else {
+                const uint32_t o = atomicAdd(overflowCount, 1u);
+                if(o < overflowCapacity) overflowSizes[o] = uint32_t(size);
+            }
+        }
+        uint64_t count = 0;
+        const uint64_t minSize = minBucketSize > 2 ? minBucketSize : 2;       // :436
+        if(size >= minSize && size <= maxBucketSize) {
+            const uint32_t hashHigh = uint32_t(v >> 32);
+            for(uint32_t j = begin; j < end; j++) {
+                const uint64_t u = vals[j];
+                count += (uint32_t(u >> 32) == hashHigh && (uint32_t(u) >> 1) > readId) ? 1u : 0u;   // :443, :450
+            }
+        }
+        pairCounts[i] = count;
+    } else if(i == n) {
+        pairCounts[i] = 0;
+    }
+    __syncthreads();
+    for(int k = threadIdx.x; k < SIZE_HIST_CAP; k += blockDim.x) {
+        const uint32_t c = sHist[k];
+        if(c) atomicAdd(&sizeHist[k], (unsigned long long)c);
+    }
+}
+
+// Pair key: readId0 | readId1 | strandBit packed so that integer order is the
+// reference's (readId0, readId1, strand) order (src/LowHash0.hpp:131-134); strand
+// bit 0 = same strand.
+__global__ void __launch_bounds__(256)
+pairWriteKernel(
+    const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts,
+    const uint64_t* __restrict__ pairOffsets, uint64_t n, int readBits, uint64_t* __restrict__ pairKeys)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    uint64_t dst = pairOffsets[i];
+    if(pairOffsets[i + 1] == dst) return;
+    const uint32_t b = pos[i + 1] - 1;
+    const uint32_t begin = starts[b], end = starts[b + 1];
+    const uint64_t v = vals[i];
+    const uint32_t hashHigh = uint32_t(v >> 32);
+    const uint32_t o0 = uint32_t(v);
+    const uint32_t readId0 = o0 >> 1;
+    for(uint32_t j = begin; j < end; j++) {
+        const uint64_t u = vals[j];
+        const uint32_t o1 = uint32_t(u);
+        if(uint32_t(u >> 32) == hashHigh && (o1 >> 1) > readId0) {
+            pairKeys[dst++] = (uint64_t(readId0) << (readBits + 1)) | (uint64_t(o1 >> 1) << 1) | uint64_t((o0 ^ o1) & 1u);
+        }
+    }
+}
+
+// Run-length encode sorted pair keys into (key, count mod 2^16) appended at the
+// end of the running table.  uint16 wrap: src/LowHash0.hpp:116, .cpp:521-555.
+__global__ void __launch_bounds__(256)
+runLengthKernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ starts, uint64_t groupCount,
+    uint64_t* __restrict__ outKeys, uint32_t* __restrict__ outCounts)
+{
+    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(g >= groupCount) return;
+    const uint32_t begin = starts[g], end = starts[g + 1];
+    outKeys[g] = keys[begin];
+    outCounts[g] = (end - begin) & 0xffffu;
+}
+
+// Fold groups of equal keys of the (sorted) table, summing frequencies mod 2^16.
+__global__ void __launch_bounds__(256)
+foldTableKernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
+    const uint32_t* __restrict__ starts, uint64_t groupCount,
+    uint64_t* __restrict__ outKeys, uint32_t* __restrict__ outCounts)
+{
+    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(g >= groupCount) return;
+    const uint32_t begin = starts[g], end = starts[g + 1];
+    uint32_t s = 0;
+    for(uint32_t j = begin; j < end; j++) s += counts[j];
+    outKeys[g] = keys[begin];
+    outCounts[g] = s & 0xffffu;
+}
+
+__global__ void __launch_bounds__(256)
+countHighFrequencyKernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t minFrequency, unsigned long long* __restrict__ out)
+{
+    uint32_t c = 0;
+    for(uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+        c += counts[i] >= minFrequency ? 1u : 0u;
+    }
+    for(int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, WAVE);
+    if((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+__global__ void __launch_bounds__(256)
+candidateFlagsKernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t minFrequency, uint32_t* __restrict__ flags)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i < n) flags[i] = counts[i] >= minFrequency ? 1u : 0u;
+    else if(i == n) flags[i] = 0u;
+}
+
+// K6: src/LowHash0.cpp:204-214.
+__global__ void __launch_bounds__(256)
+emitCandidatesKernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, uint64_t n, int readBits,
+    shasta_oriented_read_pair* __restrict__ out)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= n || pos[i + 1] == pos[i]) return;
+    const uint64_t k = keys[i];
+    shasta_oriented_read_pair p;
+    p.readIds[0] = uint32_t(k >> (readBits + 1));
+    p.readIds[1] = uint32_t((k >> 1) & ((1ULL << readBits) - 1ULL));
+    p.isSameStrand = (k & 1ULL) ? 0 : 1;
+    p.pad[0] = p.pad[1] = p.pad[2] = 0;
+    out[pos[i]] = p;
+}
+
+// ---------------------------------------------------------------------------
+// Context: markers in HBM.
+// ---------------------------------------------------------------------------
+Context::Context(int deviceArg) : device(deviceArg)
+{
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    if(deviceArg < 0 || deviceArg >= n) throw std::runtime_error("shasta_mi355x: no such HIP device " + std::to_string(deviceArg));
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if(std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        throw std::runtime_error(std::string("shasta_mi355x is built for gfx950 only; device is ") + prop.gcnArchName);
+    }
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+
+Context::~Context()
+{
+    if(stream) { (void)hipSetDevice(device); (void)hipStreamDestroy(stream); }
+}
+
+void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const void* data7,
+    const uint32_t* denseKmerIds, const uint8_t* flags)
+{
+    HIP_CHECK(hipSetDevice(device));
+    MI355X_ASSERT(readCountArg < (1ULL << 31));
+    readCount = readCountArg;
+    const uint64_t orientedReadCount = 2 * readCount;
+    hostToc.assign(tocArg, tocArg + orientedReadCount + 1);
+    MI355X_ASSERT(hostToc[0] == 0);
+    for(uint64_t i = 0; i < orientedReadCount; i++) MI355X_ASSERT(hostToc[i] <= hostToc[i + 1]);
+    markerCount = hostToc[orientedReadCount];
+    sortedMarkersValid = false;
+    readBegin = 0; readEnd = readCount;
+
+    toc.reserve(orientedReadCount + 1, stream);
+    HIP_CHECK(hipMemcpyAsync(toc.data(), hostToc.data(), (orientedReadCount + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    readFlags.reserve(std::max<uint64_t>(1, readCount), stream);
+    if(flags) HIP_CHECK(hipMemcpyAsync(readFlags.data(), flags, readCount, hipMemcpyHostToDevice, stream));
+    else HIP_CHECK(hipMemsetAsync(readFlags.data(), 0, std::max<uint64_t>(1, readCount), stream));
+
+    kmerIds.reserve(markerCount + HASH_TILE + HASH_HALO, stream);
+    if(markerCount) {
+        if(denseKmerIds) {
+            HIP_CHECK(hipMemcpyAsync(kmerIds.data(), denseKmerIds, markerCount * 4, hipMemcpyHostToDevice, stream));
+        } else {
+            DeviceBuffer<uint32_t> packed;
+            const uint64_t words = (7 * markerCount + 3) / 4 + 2;
+            packed.reserve(words, stream);
+            HIP_CHECK(hipMemsetAsync(packed.data() + (words - 3), 0, 3 * 4, stream));
+            HIP_CHECK(hipMemcpyAsync(packed.data(), data7, 7 * markerCount, hipMemcpyHostToDevice, stream));
+            const unsigned blocks = std::min<uint64_t>(divUp(markerCount, 256), 8192);
+            hipLaunchKernelGGL(stripMarkersKernel, dim3(blocks), dim3(256), 0, stream,
+                (const uint32_t*)packed.data(), kmerIds.data(), markerCount);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+    }
+    const uint64_t tileCount = (markerCount + HASH_TILE - 1) / HASH_TILE;
+    tileFirstRead.reserve(tileCount + 1, stream);
+    hipLaunchKernelGGL(tileFirstReadKernel, dim3(divUp(tileCount + 1, 256)), dim3(256), 0, stream,
+        (const uint64_t*)toc.data(), orientedReadCount, markerCount, tileFirstRead.data(), tileCount);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// ---------------------------------------------------------------------------
+// Host orchestration of the iteration loop.
+// ---------------------------------------------------------------------------
+namespace {
+
+template<class T> T readDevice(const T* p, hipStream_t s)
+{
+    T v;
+    HIP_CHECK(hipMemcpyAsync(&v, p, sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return v;
+}
+
+template<class T> T* mallocCopy(const std::vector<T>& v)
+{
+    T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if(!p) throw std::bad_alloc();
+    if(!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+int bitsFor(uint64_t maxValue) { int b = 1; while((maxValue >> b) != 0) ++b; return b; }
+
+void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uint32_t mask,
+    uint64_t markerBegin, uint64_t markerEnd,
+    uint32_t* outKeys, uint64_t* outVals, unsigned long long* counter, uint64_t capacity)
+{
+    const uint64_t tiles = (markerEnd + HASH_TILE - 1) / HASH_TILE - markerBegin / HASH_TILE;
+    if(tiles == 0) return;
+    // Persistent blocks: enough to fill 256 CUs x 8 blocks, each walking many tiles so
+    // that one global atomic serves ~1000 low hashes.
+    const unsigned blocks = unsigned(std::min<uint64_t>(tiles, 256 * 8));
+#define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL(hashWindowsKernel<MF>, dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
+        (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), (const uint8_t*)ctx.readFlags.data(), \
+        (const uint32_t*)ctx.tileFirstRead.data(), markerBegin, markerEnd, ctx.markerCount, \
+        m, seed, threshold, mask, outKeys, outVals, counter, capacity)
+    switch(m) {
+        case 3: SHASTA_LAUNCH_HASH(3); break;
+        case 4: SHASTA_LAUNCH_HASH(4); break;
+        case 5: SHASTA_LAUNCH_HASH(5); break;
+        case 6: SHASTA_LAUNCH_HASH(6); break;
+        default: SHASTA_LAUNCH_HASH(0); break;
+    }
+#undef SHASTA_LAUNCH_HASH
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLowHashStatistics, shasta_lowhash0_result& result)
+{
+    std::memset(&result, 0, sizeof(result));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const uint64_t readCount = ctx.readCount;
+    const uint64_t M = ctx.markerCount;
+    if(p.m == 0 || p.m > HASH_HALO + 1) throw std::runtime_error("LowHash0: m must be in [1, 33].");
+    if(readCount == 0) throw std::runtime_error("LowHash0: no reads.");
+
+    // Bucket count, src/LowHash0.cpp:73-98.
+    const uint64_t estimate = uint64_t(p.hashFraction * double(M));
+    const uint32_t log2Estimate = estimate ? 64 - uint32_t(__builtin_clzl(estimate)) : 0;
+    uint64_t log2BucketCount = p.log2MinHashBucketCount;
+    if(log2BucketCount == 0) log2BucketCount = 5 + log2Estimate;
+    else if(log2BucketCount < log2Estimate) throw std::runtime_error("log2MinHashBucketCount is unreasonably small.");
+    if(log2BucketCount > 31) log2BucketCount = 31;
+    const uint64_t bucketCount = 1ULL << log2BucketCount;
+    const uint32_t mask = uint32_t(bucketCount - 1);
+    result.log2BucketCount = uint32_t(log2BucketCount);
+    // :109
+    const uint64_t hashThreshold = uint64_t(double(p.hashFraction) * double(std::numeric_limits<uint64_t>::max()));
+    const int readBits = bitsFor(readCount - 1);
+    const int pairKeyBits = 2 * readBits + 1;
+    const uint32_t minFrequency = uint32_t(std::min<uint64_t>(p.minFrequency, 0x10000));   // frequency is uint16
+
+    const uint64_t markerBegin = ctx.hostToc[2 * ctx.readBegin];
+    const uint64_t markerEnd = ctx.hostToc[2 * ctx.readEnd];
+
+    // Workspaces.
+    uint64_t recCapacity = std::max<uint64_t>(1 << 16, uint64_t(2.0 * p.hashFraction * double(markerEnd - markerBegin)) + (1 << 16));
+    DeviceBuffer<uint32_t> recKeysA, recKeysB, flags, pos, starts, scanTemp32, overflowSizes;
+    DeviceBuffer<uint64_t> recValsA, recValsB, pairCounts, scanTemp64, pairKeysA, pairKeysB, tableKeysA, tableKeysB;
+    DeviceBuffer<uint32_t> tableCountsA, tableCountsB;
+    DeviceBuffer<unsigned long long> scalars, stats, sizeHist;
+    DeviceBuffer<shasta_oriented_read_pair> candidatesDevice;
+    scalars.reserve(8, stream);
+    stats.reserve(3 * readCount, stream);
+    sizeHist.reserve(SIZE_HIST_CAP, stream);
+    const uint32_t overflowCapacity = 1 << 20;
+    overflowSizes.reserve(overflowCapacity + 1, stream);
+    uint32_t* overflowCount = overflowSizes.data() + overflowCapacity;
+    HIP_CHECK(hipMemsetAsync(stats.data(), 0, 3 * readCount * sizeof(unsigned long long), stream));
+    unsigned long long* counter = scalars.data();
+    unsigned long long* highCounter = scalars.data() + 1;
+
+    uint64_t tableSize = 0;
+    std::vector<uint64_t> highFrequencyPerIteration, totalPerIteration, histogramRows;
+    std::vector<uint32_t> hostOverflow;
+    std::vector<unsigned long long> hostHist(SIZE_HIST_CAP);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hashEvents;
+    hipEvent_t evBegin, evEnd;
+    HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
+    HIP_CHECK(hipEventRecord(evBegin, stream));
+
+    uint64_t highFrequency = 0;
+    for(uint64_t iteration = 0; ; iteration++) {
+        // Iteration control, src/LowHash0.cpp:136-157.
+        if(p.minHashIterationCount == 0) {
+            const double current = 2. * double(highFrequency) / double(readCount);
+            if(current >= p.alignmentCandidatesPerRead) break;
+        } else if(iteration == p.minHashIterationCount) {
+            break;
+        }
+
+        // K1.
+        uint64_t n = 0;
+        for(;;) {
+            recKeysA.reserve(recCapacity, stream); recKeysB.reserve(recCapacity, stream);
+            recValsA.reserve(recCapacity, stream); recValsB.reserve(recCapacity, stream);
+            HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+            HIP_CHECK(hipEventRecord(a, stream));
+            launchHash(ctx, uint32_t(p.m), iteration * 37, hashThreshold, mask, markerBegin, markerEnd,
+                recKeysA.data(), recValsA.data(), counter, recCapacity);
+            HIP_CHECK(hipEventRecord(b, stream));
+            hashEvents.push_back(std::make_pair(a, b));
+            n = readDevice(counter, stream);
+            if(n <= recCapacity) break;
+            recCapacity = n + n / 4;           // estimate was too small: grow and redo this iteration
+        }
+        MI355X_ASSERT(n < (1ULL << 32) - 1);
+
+        // K2: bucket the records (radix partition on the bucket id).
+        uint32_t* keys = recKeysA.data(); uint64_t* vals = recValsA.data();
+        if(radixSort<uint32_t, uint64_t, true>(recKeysA.data(), recKeysB.data(), recValsA.data(), recValsB.data(),
+            n, int(log2BucketCount), ctx.sortWs, stream)) {
+            keys = recKeysB.data(); vals = recValsB.data();
+        }
+
+        // K3: bucket boundaries, statistics, histogram, pair counts.
+        uint64_t bucketsUsed = 0, pairCount = 0;
+        HIP_CHECK(hipMemsetAsync(sizeHist.data(), 0, SIZE_HIST_CAP * sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(overflowCount, 0, 4, stream));
+        if(n) {
+            flags.reserve(n + 1, stream); pos.reserve(n + 1, stream); starts.reserve(n + 2, stream);
+            scanTemp32.reserve(scanTempElements(n + 1), stream);
+            pairCounts.reserve(n + 1, stream); scanTemp64.reserve(scanTempElements(n + 1), stream);
+            const unsigned g = divUp(n + 1, 256);
+            hipLaunchKernelGGL(markHeadsKernel<uint32_t>, dim3(g), dim3(256), 0, stream, (const uint32_t*)keys, n, flags.data());
+            exclusiveScan<uint32_t>(flags.data(), pos.data(), n + 1, scanTemp32.data(), stream);
+            hipLaunchKernelGGL(groupStartsKernel<uint32_t>, dim3(g), dim3(256), 0, stream,
+                (const uint32_t*)keys, (const uint32_t*)pos.data(), n, starts.data());
+            hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
+                (const uint32_t*)keys, (const uint64_t*)vals, (const uint32_t*)pos.data(), (const uint32_t*)starts.data(), n,
+                p.minBucketSize, p.maxBucketSize, stats.data(), sizeHist.data(),
+                overflowSizes.data(), overflowCount, overflowCapacity, pairCounts.data());
+            exclusiveScan<uint64_t>(pairCounts.data(), pairCounts.data(), n + 1, scanTemp64.data(), stream);
+            HIP_CHECK(hipGetLastError());
+            bucketsUsed = readDevice(pos.data() + n, stream);
+            pairCount = readDevice(pairCounts.data() + n, stream);
+        }
+
+        // Histogram rows (src/LowHash0.cpp:586-595): iteration, bucketSize, bucketCount.
+        {
+            HIP_CHECK(hipMemcpyAsync(hostHist.data(), sizeHist.data(), SIZE_HIST_CAP * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            const uint32_t overflow = readDevice(overflowCount, stream);
+            if(overflow > overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
+            std::map<uint64_t, uint64_t> rows;
+            if(bucketCount > bucketsUsed) rows[0] = bucketCount - bucketsUsed;
+            for(int s = 1; s < SIZE_HIST_CAP; s++) if(hostHist[s]) rows[uint64_t(s)] = hostHist[s];
+            if(overflow) {
+                hostOverflow.resize(overflow);
+                HIP_CHECK(hipMemcpyAsync(hostOverflow.data(), overflowSizes.data(), overflow * 4ULL, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                for(uint32_t s : hostOverflow) ++rows[s];
+            }
+            for(const auto& r : rows) { histogramRows.push_back(iteration); histogramRows.push_back(r.first); histogramRows.push_back(r.second); }
+        }
+
+        // K4 + K5.
+        if(pairCount) {
+            MI355X_ASSERT(pairCount < (1ULL << 32) - 1);
+            pairKeysA.reserve(pairCount, stream); pairKeysB.reserve(pairCount, stream);
+            hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
+                (const uint64_t*)vals, (const uint32_t*)pos.data(), (const uint32_t*)starts.data(),
+                (const uint64_t*)pairCounts.data(), n, readBits, pairKeysA.data());
+            uint64_t* pk = pairKeysA.data();
+            if(radixSort<uint64_t, uint32_t, false>(pairKeysA.data(), pairKeysB.data(), nullptr, nullptr, pairCount, pairKeyBits, ctx.sortWs, stream)) {
+                pk = pairKeysB.data();
+            }
+            flags.reserve(pairCount + 1, stream); pos.reserve(pairCount + 1, stream); starts.reserve(pairCount + 2, stream);
+            scanTemp32.reserve(scanTempElements(pairCount + 1), stream);
+            const unsigned g = divUp(pairCount + 1, 256);
+            hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(g), dim3(256), 0, stream, (const uint64_t*)pk, pairCount, flags.data());
+            exclusiveScan<uint32_t>(flags.data(), pos.data(), pairCount + 1, scanTemp32.data(), stream);
+            hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(g), dim3(256), 0, stream,
+                (const uint64_t*)pk, (const uint32_t*)pos.data(), pairCount, starts.data());
+            HIP_CHECK(hipGetLastError());
+            const uint64_t uniqueCount = readDevice(pos.data() + pairCount, stream);
+
+            // Append the run-length encoded new pairs to the table, sort, fold.
+            const uint64_t merged = tableSize + uniqueCount;
+            MI355X_ASSERT(merged < (1ULL << 32) - 1);
+            tableKeysA.reserve(merged, stream, true); tableCountsA.reserve(merged, stream, true);
+            tableKeysB.reserve(merged, stream); tableCountsB.reserve(merged, stream);
+            hipLaunchKernelGGL(runLengthKernel, dim3(divUp(uniqueCount, 256)), dim3(256), 0, stream,
+                (const uint64_t*)pk, (const uint32_t*)starts.data(), uniqueCount,
+                tableKeysA.data() + tableSize, tableCountsA.data() + tableSize);
+            if(tableSize == 0) {
+                tableSize = uniqueCount;          // already sorted and unique
+            } else {
+                uint64_t* tk = tableKeysA.data(); uint32_t* tc = tableCountsA.data();
+                uint64_t* ok = tableKeysB.data(); uint32_t* oc = tableCountsB.data();
+                if(radixSort<uint64_t, uint32_t, true>(tableKeysA.data(), tableKeysB.data(), tableCountsA.data(), tableCountsB.data(),
+                    merged, pairKeyBits, ctx.sortWs, stream)) {
+                    std::swap(tk, ok); std::swap(tc, oc);
+                }
+                flags.reserve(merged + 1, stream); pos.reserve(merged + 1, stream); starts.reserve(merged + 2, stream);
+                scanTemp32.reserve(scanTempElements(merged + 1), stream);
+                const unsigned gm = divUp(merged + 1, 256);
+                hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream, (const uint64_t*)tk, merged, flags.data());
+                exclusiveScan<uint32_t>(flags.data(), pos.data(), merged + 1, scanTemp32.data(), stream);
+                hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream,
+                    (const uint64_t*)tk, (const uint32_t*)pos.data(), merged, starts.data());
+                HIP_CHECK(hipGetLastError());
+                const uint64_t folded = readDevice(pos.data() + merged, stream);
+                hipLaunchKernelGGL(foldTableKernel, dim3(divUp(folded, 256)), dim3(256), 0, stream,
+                    (const uint64_t*)tk, (const uint32_t*)tc, (const uint32_t*)starts.data(), folded, ok, oc);
+                HIP_CHECK(hipGetLastError());
+                // Result is in (ok, oc); make it the A side.
+                if(ok != tableKeysA.data()) { tableKeysA.swap(tableKeysB); tableCountsA.swap(tableCountsB); }
+                tableSize = folded;
+            }
+        }
+
+        // Per-iteration summary (src/LowHash0.cpp:184-196).
+        highFrequency = 0;
+        if(tableSize) {
+            HIP_CHECK(hipMemsetAsync(highCounter, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(countHighFrequencyKernel, dim3(std::min<unsigned>(divUp(tableSize, 256), 2048)), dim3(256), 0, stream,
+                (const uint32_t*)tableCountsA.data(), tableSize, minFrequency, highCounter);
+            HIP_CHECK(hipGetLastError());
+            highFrequency = readDevice(highCounter, stream);
+        }
+        highFrequencyPerIteration.push_back(highFrequency);
+        totalPerIteration.push_back(tableSize);
+    }
+
+    // K6.
+    uint64_t candidateCount = 0;
+    std::vector<shasta_oriented_read_pair> hostCandidates;
+    if(tableSize) {
+        flags.reserve(tableSize + 1, stream); pos.reserve(tableSize + 1, stream);
+        scanTemp32.reserve(scanTempElements(tableSize + 1), stream);
+        const unsigned g = divUp(tableSize + 1, 256);
+        hipLaunchKernelGGL(candidateFlagsKernel, dim3(g), dim3(256), 0, stream,
+            (const uint32_t*)tableCountsA.data(), tableSize, minFrequency, flags.data());
+        exclusiveScan<uint32_t>(flags.data(), pos.data(), tableSize + 1, scanTemp32.data(), stream);
+        HIP_CHECK(hipGetLastError());
+        candidateCount = readDevice(pos.data() + tableSize, stream);
+        if(candidateCount) {
+            candidatesDevice.reserve(candidateCount, stream);
+            hipLaunchKernelGGL(emitCandidatesKernel, dim3(g), dim3(256), 0, stream,
+                (const uint64_t*)tableKeysA.data(), (const uint32_t*)pos.data(), tableSize, readBits, candidatesDevice.data());
+            HIP_CHECK(hipGetLastError());
+            hostCandidates.resize(candidateCount);
+            HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), candidatesDevice.data(),
+                candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
+        }
+    }
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
+    HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(evEnd, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
+    result.deviceSeconds = ms * 1e-3;
+    ctx.times.lowhashHashSeconds = 0; ctx.times.lowhashHashLaunches = 0; ctx.times.lowhashHashBytes = 0;
+    for(auto& e : hashEvents) {
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
+        ctx.times.lowhashHashSeconds += t * 1e-3;
+        ctx.times.lowhashHashLaunches += 1;
+        // Algorithmic bytes of one launch: 4 B per marker read + 12 B per low hash written.
+        ctx.times.lowhashHashBytes += 4 * (markerEnd - markerBegin);
+        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
+
+    result.candidateCount = candidateCount;
+    result.candidates = mallocCopy(hostCandidates);
+    result.iterationCount = uint32_t(highFrequencyPerIteration.size());
+    result.highFrequency = mallocCopy(highFrequencyPerIteration);
+    result.total = mallocCopy(totalPerIteration);
+    result.histogramRowCount = histogramRows.size() / 3;
+    result.histogram = mallocCopy(histogramRows);
+    result.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void lowhash0Free(shasta_lowhash0_result& r)
+{
+    std::free(r.candidates); std::free(r.highFrequency); std::free(r.total); std::free(r.histogram);
+    std::memset(&r, 0, sizeof(r));
+}
+
+void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out)
+{
+    if(m == 0 || m > HASH_HALO + 1) throw std::runtime_error("hash_windows: m must be in [1, 33].");
+    if(n < m) return;
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    if(count == 0) throw std::runtime_error("shasta_mi355x: no HIP device.");
+    DeviceBuffer<uint32_t> in; DeviceBuffer<uint64_t> o;
+    in.reserve(n); o.reserve(n);
+    HIP_CHECK(hipMemcpy(in.data(), kmerIds, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(hashAllWindowsKernel, dim3(divUp(n, 256)), dim3(256), 0, nullptr,
+        (const uint32_t*)in.data(), n, uint32_t(m), iteration * 37, o.data());
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, o.data(), (n - m + 1) * 8, hipMemcpyDeviceToHost));
+}
+
+}  // namespace shasta_mi355x

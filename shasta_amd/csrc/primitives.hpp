@@ -1,0 +1,232 @@
+// Device-wide building blocks written for gfx950 wave64: exclusive scan and a
+// stable LSD radix sort (8-bit digits, wave-match ranking).  These replace the
+// CPU structures of the reference's bucket build: the count[] / toc[] arrays of
+// MemoryMapped::VectorOfVectors::beginPass1/beginPass2/storeMultithreaded
+// (src/MemoryMappedVectorOfVectors.hpp:315-393) and the per-read std::sort +
+// merge of LowHash0::pass3ThreadFunction (src/LowHash0.cpp:462-468).
+#pragma once
+
+#include "common.hpp"
+
+namespace shasta_mi355x {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int laneId() { return int(threadIdx.x) & 63; }
+__device__ __forceinline__ uint64_t laneMaskLt() { return (1ULL << laneId()) - 1ULL; }
+
+// ----------------------------------------------------------------------------
+// Exclusive scan.
+// ----------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+// Block-wide exclusive scan of one value per thread; returns the exclusive
+// prefix and writes the block total to *total (valid in every thread).
+template<class T>
+__device__ __forceinline__ T blockExclusiveScan(T v, T* total)
+{
+    __shared__ T waveSums[SCAN_THREADS / WAVE];
+    const int lane = laneId();
+    const int wave = int(threadIdx.x) >> 6;
+    T inclusive = v;
+#pragma unroll
+    for(int d = 1; d < WAVE; d <<= 1) {
+        const T o = __shfl_up(inclusive, d, WAVE);
+        if(lane >= d) inclusive += o;
+    }
+    if(lane == WAVE - 1) waveSums[wave] = inclusive;
+    __syncthreads();
+    T waveOffset = 0, all = 0;
+#pragma unroll
+    for(int w = 0; w < SCAN_THREADS / WAVE; w++) {
+        const T s = waveSums[w];
+        if(w < wave) waveOffset += s;
+        all += s;
+    }
+    __syncthreads();
+    *total = all;
+    return waveOffset + inclusive - v;
+}
+
+template<class T>
+__global__ void __launch_bounds__(SCAN_THREADS)
+scanReduceKernel(const T* __restrict__ in, T* __restrict__ blockSums, uint64_t n)
+{
+    const uint64_t base = uint64_t(blockIdx.x) * SCAN_TILE + uint64_t(threadIdx.x) * SCAN_ITEMS;
+    T s = 0;
+#pragma unroll
+    for(int i = 0; i < SCAN_ITEMS; i++) if(base + i < n) s += in[base + i];
+    T total;
+    (void)blockExclusiveScan<T>(s, &total);
+    if(threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+
+template<class T>
+__global__ void __launch_bounds__(SCAN_THREADS)
+scanDownsweepKernel(const T* in, T* out, const T* blockOffsets, uint64_t n)   // out may alias in
+{
+    const uint64_t base = uint64_t(blockIdx.x) * SCAN_TILE + uint64_t(threadIdx.x) * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T s = 0;
+#pragma unroll
+    for(int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : T(0); s += v[i]; }
+    T total;
+    T prefix = blockExclusiveScan<T>(s, &total) + (blockOffsets ? blockOffsets[blockIdx.x] : T(0));
+#pragma unroll
+    for(int i = 0; i < SCAN_ITEMS; i++) {
+        if(base + i < n) out[base + i] = prefix;
+        prefix += v[i];
+    }
+}
+
+// Temporary elements needed by exclusiveScan for n inputs.
+inline size_t scanTempElements(uint64_t n)
+{
+    size_t t = 0;
+    while(n > SCAN_TILE) { n = (n + SCAN_TILE - 1) / SCAN_TILE; t += n; }
+    return t + 1;
+}
+
+// out may alias in.  temp must hold scanTempElements(n) elements.
+template<class T>
+inline void exclusiveScan(const T* in, T* out, uint64_t n, T* temp, hipStream_t stream)
+{
+    if(n == 0) return;
+    const unsigned blocks = divUp(n, SCAN_TILE);
+    if(blocks == 1) {
+        hipLaunchKernelGGL(scanDownsweepKernel<T>, dim3(1), dim3(SCAN_THREADS), 0, stream, in, out, (const T*)nullptr, n);
+        return;
+    }
+    hipLaunchKernelGGL(scanReduceKernel<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, temp, n);
+    exclusiveScan<T>(temp, temp, blocks, temp + blocks, stream);
+    hipLaunchKernelGGL(scanDownsweepKernel<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, (const T*)temp, n);
+}
+
+// ----------------------------------------------------------------------------
+// Stable LSD radix sort, 8 bits per pass.
+// A block owns RS_TILE consecutive keys; each of its 4 waves owns a contiguous
+// quarter, so (wave, round, lane) order is global index order and ranking per
+// wave with ballot-match keeps the pass stable.
+// ----------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int RS_ROUNDS = 16;
+constexpr int RS_PER_WAVE = RS_ROUNDS * WAVE;
+constexpr int RS_TILE = RS_WAVES * RS_PER_WAVE;      // 4096 keys per block
+constexpr int RS_BINS = 256;
+
+template<class K>
+__global__ void __launch_bounds__(RS_THREADS)
+radixHistogramKernel(const K* __restrict__ keys, uint32_t* __restrict__ counts, uint64_t n, int shift, unsigned numBlocks)
+{
+    __shared__ uint32_t hist[RS_BINS];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t tileBase = uint64_t(blockIdx.x) * RS_TILE;
+#pragma unroll 4
+    for(int r = 0; r < RS_TILE / RS_THREADS; r++) {
+        const uint64_t i = tileBase + uint64_t(r) * RS_THREADS + threadIdx.x;
+        if(i < n) atomicAdd(&hist[unsigned(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[uint64_t(threadIdx.x) * numBlocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+template<class K, class V, bool HAS_V>
+__global__ void __launch_bounds__(RS_THREADS)
+radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
+    const V* __restrict__ valsIn, V* __restrict__ valsOut,
+    const uint32_t* __restrict__ offsets, uint64_t n, int shift, unsigned numBlocks)
+{
+    __shared__ uint32_t counters[RS_WAVES][RS_BINS];   // per-wave digit counts, then destination bases
+    const int lane = laneId();
+    const int wave = int(threadIdx.x) >> 6;
+#pragma unroll
+    for(int w = 0; w < RS_WAVES; w++) counters[w][threadIdx.x] = 0;
+    __syncthreads();
+
+    const uint64_t waveBase = uint64_t(blockIdx.x) * RS_TILE + uint64_t(wave) * RS_PER_WAVE;
+    K key[RS_ROUNDS];
+    uint32_t rank[RS_ROUNDS];
+#pragma unroll
+    for(int r = 0; r < RS_ROUNDS; r++) {
+        const uint64_t i = waveBase + uint64_t(r) * WAVE + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keysIn[i] : K(0);
+        const unsigned digit = unsigned(key[r] >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for(int b = 0; b < 8; b++) {
+            const uint64_t vote = __ballot((digit >> b) & 1u);
+            peers &= ((digit >> b) & 1u) ? vote : ~vote;
+        }
+        // Wave-synchronous: one wave owns counters[wave][*].
+        uint32_t prev = 0;
+        const int leader = __ffsll((unsigned long long)peers) - 1;
+        if(valid && lane == leader) {
+            prev = counters[wave][digit];
+            counters[wave][digit] = prev + uint32_t(__popcll(peers));
+        }
+        prev = __shfl(prev, leader < 0 ? 0 : leader, WAVE);
+        rank[r] = prev + uint32_t(__popcll(peers & laneMaskLt()));
+        __builtin_amdgcn_wave_barrier();   // keep the per-wave LDS read-modify-write of successive rounds in order
+    }
+    __syncthreads();
+    {
+        // Thread d turns the per-wave counts of digit d into destination bases.
+        const unsigned d = threadIdx.x;
+        uint32_t base = offsets[uint64_t(d) * numBlocks + blockIdx.x];
+#pragma unroll
+        for(int w = 0; w < RS_WAVES; w++) {
+            const uint32_t c = counters[w][d];
+            counters[w][d] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int r = 0; r < RS_ROUNDS; r++) {
+        const uint64_t i = waveBase + uint64_t(r) * WAVE + lane;
+        if(i < n) {
+            const unsigned digit = unsigned(key[r] >> shift) & 255u;
+            const uint32_t dst = counters[wave][digit] + rank[r];
+            keysOut[dst] = key[r];
+            if(HAS_V) valsOut[dst] = valsIn[i];
+        }
+    }
+}
+
+struct RadixSortWorkspace {
+    DeviceBuffer<uint32_t> counts;
+    DeviceBuffer<uint32_t> scanTemp;
+};
+
+// Sorts n (< 2^32) keys on bits [0, bits) with 8-bit passes, ping-ponging between
+// (keysA, valsA) and (keysB, valsB).  Returns true if the result is in B.
+template<class K, class V, bool HAS_V>
+inline bool radixSort(K* keysA, K* keysB, V* valsA, V* valsB, uint64_t n, int bits,
+    RadixSortWorkspace& ws, hipStream_t stream)
+{
+    if(n == 0 || bits <= 0) return false;
+    MI355X_ASSERT(n < (1ULL << 32));
+    const unsigned numBlocks = divUp(n, RS_TILE);
+    const uint64_t countN = uint64_t(RS_BINS) * numBlocks;
+    ws.counts.reserve(countN, stream);
+    ws.scanTemp.reserve(scanTempElements(countN), stream);
+    bool inB = false;
+    for(int shift = 0; shift < bits; shift += 8) {
+        K* kin = inB ? keysB : keysA;  K* kout = inB ? keysA : keysB;
+        V* vin = inB ? valsB : valsA;  V* vout = inB ? valsA : valsB;
+        hipLaunchKernelGGL(radixHistogramKernel<K>, dim3(numBlocks), dim3(RS_THREADS), 0, stream,
+            (const K*)kin, ws.counts.data(), n, shift, numBlocks);
+        exclusiveScan<uint32_t>(ws.counts.data(), ws.counts.data(), countN, ws.scanTemp.data(), stream);
+        hipLaunchKernelGGL((radixScatterKernel<K, V, HAS_V>), dim3(numBlocks), dim3(RS_THREADS), 0, stream,
+            (const K*)kin, kout, (const V*)vin, vout, (const uint32_t*)ws.counts.data(), n, shift, numBlocks);
+        inB = !inB;
+    }
+    return inB;
+}
+
+}  // namespace shasta_mi355x

@@ -1,0 +1,201 @@
+"""ctypes loader for shasta_amd/_build/libshasta_mi355x.so.
+
+There is no CPU fallback: if the HIP library is missing, or no gfx950 device is
+usable, every compute call raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "_build", "libshasta_mi355x.so")
+
+# Every symbol include/shasta_mi355x.h declares.
+EXPORTS = [
+    "shasta_mi355x_last_error", "shasta_mi355x_version", "shasta_mi355x_device_count",
+    "shasta_mi355x_lowhash0", "shasta_mi355x_lowhash0_free",
+    "shasta_mi355x_align4_batch", "shasta_mi355x_align4_free",
+    "shasta_mi355x_create", "shasta_mi355x_destroy",
+    "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids", "shasta_mi355x_set_shard",
+    "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_get_kernel_times",
+    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp",
+]
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path=SO_PATH):
+        if not os.path.exists(path):
+            raise LibraryNotBuilt(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C shasta_amd/csrc). There is no CPU fallback." % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        for name in EXPORTS:
+            getattr(self.lib, name)          # AttributeError if the ABI is incomplete
+        self.lib.shasta_mi355x_last_error.restype = C.c_char_p
+        self.lib.shasta_mi355x_version.restype = C.c_char_p
+        self.lib.shasta_mi355x_create.restype = C.c_void_p
+        self.lib.shasta_mi355x_create.argtypes = [C.c_int]
+        self.lib.shasta_mi355x_destroy.argtypes = [C.c_void_p]
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.shasta_mi355x_last_error().decode()))
+
+    def version(self):
+        return self.lib.shasta_mi355x_version().decode()
+
+    def device_count(self):
+        return int(self.lib.shasta_mi355x_device_count())
+
+    # --- one-shot seams -------------------------------------------------------------
+    def lowhash0(self, toc, data7, flags, params):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        flags = np.zeros(read_count, np.uint8) if flags is None else np.ascontiguousarray(flags, np.uint8)
+        stats = np.zeros((read_count, 3), dtype=np.uint64)
+        res = abi.LowHash0Result()
+        rc = self.lib.shasta_mi355x_lowhash0(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            abi.as_ptr(flags, C.c_uint8), C.byref(params), abi.as_ptr(stats, C.c_uint64), C.byref(res))
+        self._check(rc, "shasta_mi355x_lowhash0")
+        out = abi.LowHash0Output(res, stats)
+        self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
+        return out
+
+    def align4_batch(self, toc, data7, candidates, options, want_ordinals=True):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        res = abi.Align4Result()
+        rc = self.lib.shasta_mi355x_align4_batch(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
+        self._check(rc, "shasta_mi355x_align4_batch")
+        out = abi.Align4Output(res, len(candidates), want_ordinals)
+        self.lib.shasta_mi355x_align4_free(C.byref(res))
+        return out
+
+    # --- unit seams -------------------------------------------------------------------
+    def hash_windows(self, kmer_ids, m, iteration):
+        k = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
+        out = np.zeros(max(0, len(k) - m + 1), dtype=np.uint64)
+        self._check(self.lib.shasta_mi355x_hash_windows(
+            abi.as_ptr(k, C.c_uint32), C.c_uint64(len(k)), C.c_uint64(m), C.c_uint64(iteration),
+            abi.as_ptr(out, C.c_uint64)), "shasta_mi355x_hash_windows")
+        return out
+
+    def banded_dp(self, k0, k1, band_min, band_max):
+        k0 = np.ascontiguousarray(k0, dtype=np.uint32)
+        k1 = np.ascontiguousarray(k1, dtype=np.uint32)
+        cap = min(len(k0), len(k1)) + 1
+        out = np.zeros((cap, 2), dtype=np.uint32)
+        count = C.c_uint64()
+        score = C.c_int32()
+        self._check(self.lib.shasta_mi355x_banded_dp(
+            abi.as_ptr(k0, C.c_uint32), C.c_uint32(len(k0)), abi.as_ptr(k1, C.c_uint32), C.c_uint32(len(k1)),
+            C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
+            C.byref(count), C.byref(score)), "shasta_mi355x_banded_dp")
+        return out[:count.value].copy(), score.value
+
+    def context(self, device=0):
+        return Context(self, device)
+
+
+class Context:
+    """Device-resident markers + the two stages (shasta_mi355x_ctx)."""
+
+    def __init__(self, library, device=0):
+        self.library = library
+        self.lib = library.lib
+        self.handle = self.lib.shasta_mi355x_create(C.c_int(device))
+        if not self.handle:
+            raise RuntimeError("shasta_mi355x_create failed: %s" % self.lib.shasta_mi355x_last_error().decode())
+        self.read_count = 0
+
+    def close(self):
+        if self.handle:
+            self.lib.shasta_mi355x_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_markers(self, toc, data7, flags=None):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        self.read_count = (len(toc) - 1) // 2
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self.library._check(self.lib.shasta_mi355x_set_markers(
+            C.c_void_p(self.handle), C.c_uint64(self.read_count), abi.as_ptr(toc, C.c_uint64),
+            C.c_void_p(data7.ctypes.data), fp), "shasta_mi355x_set_markers")
+
+    def set_kmer_ids(self, toc, kmer_ids, flags=None):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        kmer_ids = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
+        self.read_count = (len(toc) - 1) // 2
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self.library._check(self.lib.shasta_mi355x_set_kmer_ids(
+            C.c_void_p(self.handle), C.c_uint64(self.read_count), abi.as_ptr(toc, C.c_uint64),
+            abi.as_ptr(kmer_ids, C.c_uint32), fp), "shasta_mi355x_set_kmer_ids")
+
+    def set_shard(self, rank, world_size, read_begin, read_end):
+        self.library._check(self.lib.shasta_mi355x_set_shard(
+            C.c_void_p(self.handle), C.c_int(rank), C.c_int(world_size),
+            C.c_uint64(read_begin), C.c_uint64(read_end)), "shasta_mi355x_set_shard")
+
+    def lowhash0(self, params):
+        stats = np.zeros((self.read_count, 3), dtype=np.uint64)
+        res = abi.LowHash0Result()
+        self.library._check(self.lib.shasta_mi355x_lowhash0_run(
+            C.c_void_p(self.handle), C.byref(params), abi.as_ptr(stats, C.c_uint64), C.byref(res)),
+            "shasta_mi355x_lowhash0_run")
+        out = abi.LowHash0Output(res, stats)
+        self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
+        return out
+
+    def align4(self, candidates, options, want_ordinals=False):
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        res = abi.Align4Result()
+        self.library._check(self.lib.shasta_mi355x_align4_run(
+            C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_align4_run")
+        out = abi.Align4Output(res, len(candidates), want_ordinals)
+        self.lib.shasta_mi355x_align4_free(C.byref(res))
+        return out
+
+    def kernel_times(self):
+        t = abi.KernelTimes()
+        self.library._check(self.lib.shasta_mi355x_get_kernel_times(C.c_void_p(self.handle), C.byref(t)),
+                            "shasta_mi355x_get_kernel_times")
+        return t
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        _cached = Library()
+    return _cached

