@@ -1,9 +1,1039 @@
-// placeholder, replaced below
+// Align4 (Shasta alignment method 4) on MI355X (gfx950).  Replaces, for a batch of
+// alignment candidates, Assembler::computeAlignmentsThreadFunction with
+// alignMethod 4 (/root/reference/src/AssemblerAlign.cpp:308-496) ->
+// Align4::align (src/Align4.cpp:30-166), AlignmentInfo::create
+// (src/Alignment.cpp:67-113) and shasta::compress (src/compressAlignment.cpp:11-67).
+//
+//   K8/K9  align4CellsKernel   one workgroup per candidate: LDS hash join of the two
+//                              marker sequences (replaces computeSortedMarkers + the merge
+//                              join of createAlignmentMatrix, :195-267), per-cell entry
+//                              counts in an LDS table (createCells :380-436), forward /
+//                              backward reachability (:682-788) and 8-connected components
+//                              (:792-868) by label propagation, one DP task per component.
+//   K10    bandedDpKernel<C>   one wavefront per task: anti-diagonal banded overlap DP with
+//                              each lane owning C adjacent diagonals (neighbour exchange =
+//                              one __shfl per step), 2-bit trace packed with __ballot and
+//                              streamed to HBM, wave-cooperative traceback through an LDS
+//                              window (computeBandedAlignment :993-1088; the SeqAn call it
+//                              wraps is restated -- tie policy as in oracle/banded_dp.hpp).
+//   K11    select / finalize / compress kernels: best component (:126-147), filters
+//                              (src/Align4.cpp:944-981, src/AssemblerAlign.cpp:439-472),
+//                              AlignmentInfo, streak compression.
+// Integer work throughout; no MFMA.  Bit-exactness notes: SURVEY.md Appendix A.2.
 #include "context.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
 namespace shasta_mi355x {
-void align4Run(Context&, uint64_t, const shasta_oriented_read_pair*, const shasta_align4_options&, bool, shasta_align4_result&)
-{ throw std::runtime_error("align4: not built yet"); }
-void align4Free(shasta_align4_result&) {}
-void bandedDpUnit(const uint32_t*, uint32_t, const uint32_t*, uint32_t, int32_t, int32_t, uint32_t*, uint64_t, uint64_t*, int32_t*)
-{ throw std::runtime_error("banded_dp: not built yet"); }
+namespace {
+
+constexpr int NEG_SCORE = -(1 << 29);
+constexpr int MATCH_SCORE = 6, MISMATCH_SCORE = -1, GAP_SCORE = -1;    // src/Align4.hpp:159-161
+
+struct PairDesc { uint64_t begin0, begin1; uint32_t nx, ny; };
+struct DpTask { uint32_t pair; int32_t bandMin, bandMax; uint32_t label; };
+struct DpResult {
+    uint64_t ordBegin;             // first (x,y) pair of this alignment in the ordinal scratch
+    long long sumOffset;
+    uint32_t markerCount, first0, first1, last0, last1;
+    int32_t minOffset, maxOffset;
+    uint32_t maxSkip, maxDrift;
+    uint32_t passes;               // inner filters of src/Align4.cpp:944-981
+    int32_t score;
+    uint32_t pad;
+};
+
+struct DeviceOptions {
+    uint32_t deltaX, deltaY;
+    uint64_t minEntryCountPerCell, maxDistanceFromBoundary, minAlignedMarkerCount;
+    double minAlignedFraction;
+    uint64_t maxSkip, maxDrift, maxTrim, maxBand;
+    uint32_t suppressContainments;
+};
+
+// ---------------------------------------------------------------------------
+// K8/K9: cells.
+// ---------------------------------------------------------------------------
+constexpr int CELLS_THREADS = 256;
+constexpr int MATCH_CHUNK = 2048;          // markers of read 1 hashed per round
+constexpr int MATCH_SLOTS = 4096;
+constexpr int CELL_SLOTS = 2048;
+constexpr int MAX_CELLS = 1024;
+constexpr uint32_t EMPTY32 = 0xffffffffu;
+constexpr uint64_t EMPTY64 = ~0ULL;
+
+constexpr uint32_t F_NEAR_LT = 1, F_NEAR_RB = 2, F_FWD = 4, F_BWD = 8;
+constexpr uint8_t PAIR_RESOURCE = 1;       // a fixed-size on-chip table overflowed: candidate is skipped + reported
+
+__device__ __forceinline__ uint32_t hash32(uint32_t k) { return k * 2654435761u; }
+
+// getxy, src/Align4.cpp:184-191 (int32, C++ truncating division).
+__device__ __forceinline__ void getxy(uint32_t X, uint32_t Y, uint32_t nx, int32_t& x, int32_t& y)
+{
+    const int32_t Xs = int32_t(X), Ys = int32_t(Y);
+    x = (Xs - Ys + int32_t(nx) - 1) / 2;
+    y = (Xs + Ys - int32_t(nx) + 1) / 2;
 }
+
+__global__ void __launch_bounds__(CELLS_THREADS)
+align4CellsKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, uint32_t pairCount,
+    DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags)
+{
+    __shared__ uint64_t matchTab[MATCH_SLOTS];
+    __shared__ uint32_t cellKeys[CELL_SLOTS];
+    __shared__ uint32_t cellVals[CELL_SLOTS];      // entry count, then compact cell index
+    __shared__ uint32_t cKey[MAX_CELLS];
+    __shared__ uint32_t cFlags[MAX_CELLS];
+    __shared__ uint32_t cLabel[MAX_CELLS];
+    __shared__ uint32_t cYMin[MAX_CELLS];
+    __shared__ uint32_t cYMax[MAX_CELLS];
+    __shared__ uint32_t sCells, sOverflow, sChanged;
+
+    const uint32_t pair = blockIdx.x;
+    if(pair >= pairCount) return;
+    const int tid = int(threadIdx.x);
+    const PairDesc pd = pairs[pair];
+    const uint32_t nx = pd.nx, ny = pd.ny;
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+
+    for(int k = tid; k < CELL_SLOTS; k += CELLS_THREADS) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
+    if(tid == 0) { sCells = 0; sOverflow = 0; sChanged = 0; }
+
+    // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
+    for(uint32_t chunk = 0; chunk < ny; chunk += MATCH_CHUNK) {
+        __syncthreads();
+        for(int k = tid; k < MATCH_SLOTS; k += CELLS_THREADS) matchTab[k] = EMPTY64;
+        __syncthreads();
+        const uint32_t chunkEnd = min(ny, chunk + uint32_t(MATCH_CHUNK));
+        for(uint32_t y = chunk + tid; y < chunkEnd; y += CELLS_THREADS) {
+            const uint32_t k = p1[y];
+            const unsigned long long entry = (uint64_t(k) << 32) | y;
+            uint32_t slot = hash32(k) >> (32 - 12);
+            for(;;) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
+                if(old == EMPTY64) break;
+                slot = (slot + 1) & (MATCH_SLOTS - 1);
+            }
+        }
+        __syncthreads();
+        for(uint32_t x = tid; x < nx; x += CELLS_THREADS) {
+            const uint32_t k = p0[x];
+            uint32_t slot = hash32(k) >> (32 - 12);
+            for(;;) {
+                const uint64_t e = matchTab[slot];
+                if(e == EMPTY64) break;
+                if(uint32_t(e >> 32) == k) {
+                    const uint32_t y = uint32_t(e);
+                    const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
+                    const uint32_t iX = X / opt.deltaX, iY = Y / opt.deltaY;
+                    if(iX >= 65536u || iY >= 65535u) { sOverflow = 1; }
+                    else {
+                        const uint32_t key = (iY << 16) | iX;
+                        uint32_t cs = hash32(key) >> (32 - 11);
+                        int probe = 0;
+                        for(; probe < CELL_SLOTS; probe++) {
+                            const uint32_t old = atomicCAS(&cellKeys[cs], EMPTY32, key);
+                            if(old == EMPTY32 || old == key) { atomicAdd(&cellVals[cs], 1u); break; }
+                            cs = (cs + 1) & (CELL_SLOTS - 1);
+                        }
+                        if(probe == CELL_SLOTS) sOverflow = 1;
+                    }
+                }
+                slot = (slot + 1) & (MATCH_SLOTS - 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // Keep cells with enough entries (:417) and give them compact indices.
+    for(int k = tid; k < CELL_SLOTS; k += CELLS_THREADS) {
+        const uint32_t key = cellKeys[k];
+        if(key == EMPTY32) continue;
+        if(uint64_t(cellVals[k]) >= opt.minEntryCountPerCell) {
+            const uint32_t idx = atomicAdd(&sCells, 1u);
+            if(idx < MAX_CELLS) { cKey[idx] = key; cellVals[k] = idx; }
+            else { sOverflow = 1; cellVals[k] = EMPTY32; }
+        } else {
+            cellVals[k] = EMPTY32;
+        }
+    }
+    __syncthreads();
+    if(sOverflow) { if(tid == 0) pairFlags[pair] = PAIR_RESOURCE; return; }
+    const int n = int(sCells);
+    if(n == 0) return;
+
+    auto find = [&](int32_t iX, int32_t iY) -> int {
+        if(iX < 0 || iY < 0 || iX >= 65536 || iY >= 65535) return -1;
+        const uint32_t key = (uint32_t(iY) << 16) | uint32_t(iX);
+        uint32_t cs = hash32(key) >> (32 - 11);
+        for(int probe = 0; probe < CELL_SLOTS; probe++) {
+            const uint32_t k = cellKeys[cs];
+            if(k == EMPTY32) return -1;
+            if(k == key) return int(cellVals[cs]);          // EMPTY32 (-1) for dropped cells
+            cs = (cs + 1) & (CELL_SLOTS - 1);
+        }
+        return -1;
+    };
+
+    // Boundary flags (:424-429 with the corner rules of :530-626).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t key = cKey[c];
+        const uint32_t iX = key & 0xffffu, iY = key >> 16;
+        int32_t x, y;
+        getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t left = x < 0 ? 0u : uint32_t(x);
+        getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
+        getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t top = y < 0 ? 0u : uint32_t(y);
+        getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
+        uint32_t f = 0;
+        if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) f |= F_NEAR_LT | F_FWD;
+        if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) f |= F_NEAR_RB;
+        cFlags[c] = f;
+        cYMin[c] = EMPTY32; cYMax[c] = 0;
+    }
+
+    // forwardSearch (:682-729): a cell is forward accessible if a forward accessible cell
+    // lies at (iX-1 or iX, iY-1..iY+1).  Label propagation to the fixed point.
+    for(;;) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            if(cFlags[c] & F_FWD) continue;
+            const int32_t iX = int32_t(cKey[c] & 0xffffu), iY = int32_t(cKey[c] >> 16);
+            bool reach = false;
+            for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = -1; dX <= 0; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(iX + dX, iY + dY);
+                if(j >= 0 && (cFlags[j] & F_FWD)) { reach = true; break; }
+            }
+            if(reach) { atomicOr(&cFlags[c], F_FWD); sChanged = 1; }
+        }
+        __syncthreads();
+        if(!sChanged) break;
+    }
+    // backwardSearch (:736-787): seeds near right/bottom AND forward accessible; a cell is
+    // backward accessible if a backward accessible cell lies at (iX or iX+1, iY-1..iY+1).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t f = cFlags[c];
+        if((f & F_NEAR_RB) && (f & F_FWD)) cFlags[c] = f | F_BWD;
+    }
+    for(;;) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            if(cFlags[c] & F_BWD) continue;
+            const int32_t iX = int32_t(cKey[c] & 0xffffu), iY = int32_t(cKey[c] >> 16);
+            bool reach = false;
+            for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = 0; dX <= 1; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(iX + dX, iY + dY);
+                if(j >= 0 && (cFlags[j] & F_BWD)) { reach = true; break; }
+            }
+            if(reach) { atomicOr(&cFlags[c], F_BWD); sChanged = 1; }
+        }
+        __syncthreads();
+        if(!sChanged) break;
+    }
+
+    // Connected components of active cells, 8-neighbourhood (:792-868): min-label propagation.
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t f = cFlags[c];
+        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? cKey[c] : EMPTY32;
+    }
+    for(;;) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            const uint32_t mine = cLabel[c];
+            if(mine == EMPTY32) continue;
+            const int32_t iX = int32_t(cKey[c] & 0xffffu), iY = int32_t(cKey[c] >> 16);
+            uint32_t best = mine;
+            for(int dY = -1; dY <= 1; dY++) for(int dX = -1; dX <= 1; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(iX + dX, iY + dY);
+                if(j >= 0) best = min(best, cLabel[j]);
+            }
+            if(best < mine) { atomicMin(&cLabel[c], best); sChanged = 1; }
+        }
+        __syncthreads();
+        if(!sChanged) break;
+    }
+    // iY range of each component, stored at its root cell (the cell whose key is the label).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t label = cLabel[c];
+        if(label == EMPTY32) continue;
+        const int r = find(int32_t(label & 0xffffu), int32_t(label >> 16));
+        const uint32_t iY = cKey[c] >> 16;
+        atomicMin(&cYMin[r], iY);
+        atomicMax(&cYMax[r], iY);
+    }
+    __syncthreads();
+    // One banded alignment per component (:890-934).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        if(cLabel[c] != cKey[c]) continue;
+        const uint32_t YMin = cYMin[c] * opt.deltaY;
+        const uint32_t YMax = (cYMax[c] + 1) * opt.deltaY - 1;
+        const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
+        const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
+        const int32_t bandWidth = bandMax - bandMin + 1;
+        if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;             // :929
+        if(bandWidth > 1024) { pairFlags[pair] = PAIR_RESOURCE; continue; }
+        const uint32_t t = atomicAdd(taskCount, 1u);
+        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = cKey[c]; tasks[t] = task; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Task geometry shared by the sizing kernel and the DP kernel.
+// ---------------------------------------------------------------------------
+struct TaskGeometry { int32_t s0, sEnd; uint32_t rows, rowWords; int cls; };
+
+__host__ __device__ inline int classOfWidth(int32_t w) { return w <= 64 ? 0 : (w <= 128 ? 1 : (w <= 256 ? 2 : (w <= 512 ? 3 : 4))); }
+__host__ __device__ inline int lanesDiagonals(int cls) { return cls == 0 ? 1 : (1 << cls); }   // C = 1,2,4,8,16
+
+__host__ __device__ inline TaskGeometry taskGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
+{
+    TaskGeometry g;
+    const int32_t w = bandMax - bandMin + 1;
+    g.cls = classOfWidth(w);
+    const int C = lanesDiagonals(g.cls);
+    const int32_t sMin = bandMin > 0 ? bandMin : (bandMax < 0 ? -bandMax : 0);
+    g.s0 = sMin - ((sMin + bandMin) & 1);          // (s0 + bandMin) is even
+    g.sEnd = int32_t(nx + ny);
+    const uint32_t steps = uint32_t(g.sEnd - g.s0 + 2);
+    if(C == 1) { g.rows = (steps + 1) / 2; g.rowWords = 2; }
+    else { g.rows = steps; g.rowWords = uint32_t(C); }
+    return g;
+}
+
+__global__ void __launch_bounds__(256)
+sizeTasksKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
+    uint64_t* __restrict__ traceWords, uint64_t* __restrict__ ordCap,
+    uint32_t* __restrict__ classLists, uint32_t* __restrict__ classCounts, uint32_t listStride,
+    unsigned long long* __restrict__ dpCells)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < taskCount) {
+        const DpTask task = tasks[t];
+        const PairDesc pd = pairs[task.pair];
+        const TaskGeometry g = taskGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+        traceWords[t] = uint64_t(g.rows) * g.rowWords;
+        ordCap[t] = min(pd.nx, pd.ny);
+        const uint32_t k = atomicAdd(&classCounts[g.cls], 1u);
+        classLists[uint64_t(g.cls) * listStride + k] = t;
+        atomicAdd(dpCells, (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1));
+    } else if(t == taskCount) {
+        traceWords[t] = 0; ordCap[t] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K10: banded overlap DP + traceback, one wavefront per task.
+//
+// DP cell (i,j) (i symbols of read 0, j of read 1 consumed) lives on diagonal
+// d = i-j = bandMin + b and anti-diagonal s = i+j.  Lane l owns diagonals
+// b = l*C .. l*C+C-1 and keeps H[c] = the latest value on each.  On step s only
+// diagonals with (s+d) even hold a cell; its three predecessors are H[c] itself
+// (s-2, diagonal), H of b-1 (s-1, horizontal) and H of b+1 (s-1, vertical).
+// Trace codes (2 bits): 0 diagonal+equal kmers, 1 diagonal+different, 2 vertical,
+// 3 horizontal.  Tie policy: diagonal >= vertical >= horizontal; end cell = first
+// maximum in (i, then j) order over last row / last column (oracle/banded_dp.hpp).
+// ---------------------------------------------------------------------------
+struct CellContext {
+    const uint32_t* p0; const uint32_t* p1;
+    int32_t nx, ny, bandMin, width;
+};
+
+__device__ __forceinline__ uint32_t dpCell(
+    const CellContext& cc, int32_t b, int32_t s, bool enabled, int32_t left, int32_t right, int32_t& h,
+    int32_t& bestScore, int32_t& bestI, int32_t& bestJ)
+{
+    const int32_t d = cc.bandMin + b;
+    const int32_t sd = s + d;
+    const int32_t i = sd >> 1;
+    const int32_t j = i - d;
+    const bool valid = enabled && (b < cc.width) && (sd >= 0) && (j >= 0) && (i <= cc.nx) && (j <= cc.ny);
+    uint32_t dir = 0;
+    if(valid) {
+        int32_t v;
+        if(i == 0 || j == 0) {
+            v = 0;                                                  // free leading gaps
+        } else {
+            const bool eq = cc.p0[i - 1] == cc.p1[j - 1];
+            v = h + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+            dir = eq ? 0u : 1u;
+            const int32_t vert = right + GAP_SCORE;                 // from (i, j-1): diagonal b+1
+            const int32_t hori = left + GAP_SCORE;                  // from (i-1, j): diagonal b-1
+            if(vert > v) { v = vert; dir = 2u; }
+            if(hori > v) { v = hori; dir = 3u; }
+        }
+        h = v;
+        if(i == cc.nx || j == cc.ny) {                              // free trailing gaps
+            if(v > bestScore || (v == bestScore && (i < bestI || (i == bestI && j < bestJ)))) {
+                bestScore = v; bestI = i; bestJ = j;
+            }
+        }
+    }
+    return dir;
+}
+
+template<int C>
+__global__ void __launch_bounds__(256)
+bandedDpKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const DpTask* __restrict__ tasks, const uint32_t* __restrict__ taskList, uint32_t listCount,
+    const uint64_t* __restrict__ traceOffsets, const uint64_t* __restrict__ ordOffsets,
+    uint64_t* __restrict__ trace, uint32_t* __restrict__ ordScratch,
+    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    constexpr int RW = (C == 1) ? 2 : C;                 // 64-bit words per trace row
+    __shared__ uint64_t window[4][64 * RW];
+    const int lane = laneId();
+    const int wave = int(threadIdx.x) >> 6;
+    const uint32_t idx = blockIdx.x * 4 + wave;
+    if(idx >= listCount) return;                         // whole wave leaves; no block barriers below
+    const uint32_t t = taskList[idx];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    CellContext cc;
+    cc.p0 = kmerIds + pd.begin0; cc.p1 = kmerIds + pd.begin1;
+    cc.nx = int32_t(pd.nx); cc.ny = int32_t(pd.ny);
+    cc.bandMin = task.bandMin; cc.width = task.bandMax - task.bandMin + 1;
+    const TaskGeometry g = taskGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    uint64_t* __restrict__ tr = trace + traceOffsets[t];
+
+    int32_t H[C];
+#pragma unroll
+    for(int c = 0; c < C; c++) H[c] = NEG_SCORE;
+    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+
+    if(C == 1) {
+        const bool evenLane = (lane & 1) == 0;
+        for(int32_t s = g.s0; s <= g.sEnd; s += 2) {
+            int32_t left = __shfl_up(H[0], 1, WAVE);   if(lane == 0) left = NEG_SCORE;
+            int32_t right = __shfl_down(H[0], 1, WAVE); if(lane == 63) right = NEG_SCORE;
+            uint32_t dir = dpCell(cc, lane, s, evenLane, left, right, H[0], bestScore, bestI, bestJ);
+            left = __shfl_up(H[0], 1, WAVE);   if(lane == 0) left = NEG_SCORE;
+            right = __shfl_down(H[0], 1, WAVE); if(lane == 63) right = NEG_SCORE;
+            const uint32_t dirB = dpCell(cc, lane, s + 1, !evenLane, left, right, H[0], bestScore, bestI, bestJ);
+            if(!evenLane) dir = dirB;
+            const uint64_t lo = __ballot(dir & 1u), hi = __ballot(dir & 2u);
+            if(lane == 0) {
+                const uint64_t row = uint64_t(s - g.s0) >> 1;
+                tr[row * 2] = lo; tr[row * 2 + 1] = hi;
+            }
+        }
+    } else {
+        for(int32_t s = g.s0; s <= g.sEnd; s += 2) {
+            {   // (s + bandMin) even: even c hold cells
+                int32_t left = __shfl_up(H[C - 1], 1, WAVE); if(lane == 0) left = NEG_SCORE;
+                const uint64_t rowBase = uint64_t(s - g.s0) * RW;
+#pragma unroll
+                for(int c = 0; c < C; c += 2) {
+                    const int32_t l = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
+                    const uint32_t dir = dpCell(cc, lane * C + c, s, true, l, H[c + 1], H[c], bestScore, bestI, bestJ);
+                    const uint64_t lo = __ballot(dir & 1u), hi = __ballot(dir & 2u);
+                    if(lane == 0) { tr[rowBase + c] = lo; tr[rowBase + c + 1] = hi; }
+                }
+            }
+            {   // s+1: odd c hold cells
+                int32_t right = __shfl_down(H[0], 1, WAVE); if(lane == 63) right = NEG_SCORE;
+                const uint64_t rowBase = uint64_t(s + 1 - g.s0) * RW;
+#pragma unroll
+                for(int c = 1; c < C; c += 2) {
+                    const int32_t r = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
+                    const uint32_t dir = dpCell(cc, lane * C + c, s + 1, true, H[c - 1], r, H[c], bestScore, bestI, bestJ);
+                    const uint64_t lo = __ballot(dir & 1u), hi = __ballot(dir & 2u);
+                    if(lane == 0) { tr[rowBase + (c - 1)] = lo; tr[rowBase + c] = hi; }
+                }
+            }
+        }
+    }
+
+    // End cell: maximum score, ties to the smallest (i, j).
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) {
+        const int32_t os = __shfl_xor(bestScore, d, WAVE);
+        const int32_t oi = __shfl_xor(bestI, d, WAVE);
+        const int32_t oj = __shfl_xor(bestJ, d, WAVE);
+        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) {
+            bestScore = os; bestI = oi; bestJ = oj;
+        }
+    }
+
+    // Make this wave's trace stores (lane 0) visible to the loads of all its lanes below:
+    // same CU, same L1 -- a workgroup-scope release/acquire (store drain) is sufficient.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // Traceback: every lane walks the same path; the trace is read through a 64-row LDS
+    // window that the wave refills with one coalesced load per row.
+    uint64_t* win = window[wave];
+    int64_t winStart = -1;
+    const uint64_t ordBase = ordOffsets[t];
+    const uint32_t cap = min(pd.nx, pd.ny);
+    uint32_t pos = cap;
+    uint32_t count = 0, prevX = 0, prevY = 0, last0 = 0, last1 = 0, first0 = 0, first1 = 0, maxSkip = 0, maxDrift = 0;
+    int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
+    long long sumOffset = 0;
+    int32_t i = bestI, j = bestJ;
+    const bool ok = bestScore > NEG_SCORE;
+    while(ok && i > 0 && j > 0) {
+        const int32_t s = i + j;
+        const int32_t b = i - j - cc.bandMin;
+        const int64_t row = (C == 1) ? (int64_t(s - g.s0) >> 1) : int64_t(s - g.s0);
+        if(winStart < 0 || row < winStart || row >= winStart + 64) {
+            winStart = row >= 63 ? row - 63 : 0;
+            const int64_t r = winStart + lane;
+            __builtin_amdgcn_wave_barrier();
+            if(r < int64_t(g.rows)) {
+#pragma unroll
+                for(int w = 0; w < RW; w++) win[lane * RW + w] = tr[uint64_t(r) * RW + w];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int rl = int(row - winStart);
+        int bit, word;
+        if(C == 1) { bit = b; word = rl * 2; }
+        else { bit = b / C; word = rl * RW + ((b % C) & ~1); }
+        const uint64_t lo = win[word], hi = win[word + 1];
+        const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
+        if(dir == 0u) {
+            // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
+            const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
+            --pos;
+            if(lane == 0) { ordScratch[2 * (ordBase + pos)] = x; ordScratch[2 * (ordBase + pos) + 1] = y; }
+            const int32_t offset = int32_t(x) - int32_t(y);
+            if(count == 0) { last0 = x; last1 = y; }
+            else {
+                maxSkip = max(maxSkip, max(prevX - x, prevY - y));
+                const int32_t prevOffset = int32_t(prevX) - int32_t(prevY);
+                const int32_t drift = offset - prevOffset;
+                maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
+            }
+            minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
+            sumOffset += offset;
+            first0 = x; first1 = y; prevX = x; prevY = y;
+            ++count;
+            --i; --j;
+        } else if(dir == 1u) { --i; --j; }
+        else if(dir == 2u) { --j; }
+        else { --i; }
+    }
+
+    if(lane == 0) {
+        DpResult r;
+        r.ordBegin = ordBase + pos;
+        r.sumOffset = sumOffset;
+        r.markerCount = count; r.first0 = first0; r.first1 = first1; r.last0 = last0; r.last1 = last1;
+        r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+        r.score = bestScore; r.pad = 0;
+        // Inner acceptance, src/Align4.cpp:944-981.
+        bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+        if(pass) {
+            const double f0 = double(count) / double(last0 + 1 - first0);
+            const double f1 = double(count) / double(last1 + 1 - first1);
+            if(min(f0, f1) < opt.minAlignedFraction) pass = false;
+            if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
+            const uint32_t leftTrim = min(first0, first1);
+            const uint32_t rightTrim = min(pd.nx - 1 - last0, pd.ny - 1 - last1);
+            if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
+        }
+        r.passes = pass ? 1u : 0u;
+        results[t] = r;
+        // Best component = most aligned markers (:132-139); ties resolved towards the
+        // component whose first cell in (iY,iX) order comes first, and flagged later.
+        if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+winnerKernel(const DpTask* __restrict__ tasks, const DpResult* __restrict__ results, uint32_t taskCount,
+    const unsigned long long* __restrict__ pairBest, uint32_t* __restrict__ pairWinner, uint8_t* __restrict__ pairTie)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= taskCount) return;
+    const DpResult r = results[t];
+    if(!r.passes) return;
+    const DpTask task = tasks[t];
+    const unsigned long long best = pairBest[task.pair];
+    const unsigned long long key = ((unsigned long long)r.markerCount << 32) | (unsigned long long)(0xffffffffu - task.label);
+    if(key == best) pairWinner[task.pair] = t;
+    else if((key >> 32) == (best >> 32)) pairTie[task.pair] = 1;
+}
+
+// Per candidate: AlignmentInfo (src/Alignment.cpp:67-113) and the outer filters of
+// src/AssemblerAlign.cpp:439-472.
+__global__ void __launch_bounds__(256)
+finalizeKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_read_pair* __restrict__ candidates, uint32_t pairCount,
+    const DpResult* __restrict__ results, const unsigned long long* __restrict__ pairBest,
+    const uint32_t* __restrict__ pairWinner, const uint8_t* __restrict__ pairTie, const uint8_t* __restrict__ pairFlags,
+    DeviceOptions opt, int wantOrdinals,
+    uint8_t* __restrict__ status, shasta_alignment_data* __restrict__ rows,
+    uint32_t* __restrict__ storedFlags, uint64_t* __restrict__ ordCounts)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p == pairCount) { storedFlags[p] = 0; ordCounts[p] = 0; return; }
+    if(p > pairCount) return;
+    uint8_t st;
+    uint32_t stored = 0;
+    uint64_t ordCount = 0;
+    if(pairFlags[p] & PAIR_RESOURCE) {
+        st = SHASTA_ALIGN_SKIPPED;
+    } else if(pairBest[p] == 0) {
+        st = SHASTA_ALIGN_EMPTY;
+    } else {
+        const DpResult r = results[pairWinner[p]];
+        const PairDesc pd = pairs[p];
+        shasta_alignment_data row;
+        row.pair = candidates[p];
+        row.pair.isSameStrand = row.pair.isSameStrand ? 1 : 0;
+        row.pair.pad[0] = row.pair.pad[1] = row.pair.pad[2] = 0;
+        row.info.data[0].markerCount = pd.nx; row.info.data[0].firstOrdinal = r.first0; row.info.data[0].lastOrdinal = r.last0;
+        row.info.data[1].markerCount = pd.ny; row.info.data[1].firstOrdinal = r.first1; row.info.data[1].lastOrdinal = r.last1;
+        row.info.markerCount = r.markerCount;
+        row.info.minOrdinalOffset = r.minOffset; row.info.maxOrdinalOffset = r.maxOffset;
+        row.info.averageOrdinalOffset = int32_t(round(double(r.sumOffset) / double(r.markerCount)));
+        row.info.maxSkip = r.maxSkip; row.info.maxDrift = r.maxDrift;
+        row.info.isInReadGraph = 0; row.info.pad[0] = row.info.pad[1] = row.info.pad[2] = 0;
+        rows[p] = row;
+        bool good = uint64_t(r.markerCount) >= opt.minAlignedMarkerCount;
+        const double f0 = double(r.markerCount) / double(r.last0 + 1 - r.first0);
+        const double f1 = double(r.markerCount) / double(r.last1 + 1 - r.first1);
+        if(min(f0, f1) < opt.minAlignedFraction) good = false;
+        const uint32_t lt0 = r.first0, lt1 = r.first1, rt0 = pd.nx - 1 - r.last0, rt1 = pd.ny - 1 - r.last1;
+        if(uint64_t(min(lt0, lt1)) > opt.maxTrim || uint64_t(min(rt0, rt1)) > opt.maxTrim) good = false;
+        if(uint64_t(r.maxSkip) > opt.maxSkip || uint64_t(r.maxDrift) > opt.maxDrift) good = false;
+        if(opt.suppressContainments) {
+            const uint32_t mt = uint32_t(opt.maxTrim);
+            if((lt0 <= mt && rt0 <= mt) || (lt1 <= mt && rt1 <= mt)) good = false;       // isContaining
+        }
+        st = good ? SHASTA_ALIGN_STORED : SHASTA_ALIGN_REJECTED;
+        if(pairTie[p]) st |= SHASTA_ALIGN_TIE_FLAG;
+        stored = good ? 1u : 0u;
+        ordCount = (wantOrdinals || good) ? r.markerCount : 0;
+    }
+    status[p] = st;
+    storedFlags[p] = stored;
+    ordCounts[p] = ordCount;
+}
+
+__global__ void __launch_bounds__(256)
+gatherOrdinalsKernel(const DpResult* __restrict__ results, const uint32_t* __restrict__ pairWinner,
+    const uint64_t* __restrict__ ordToc, uint32_t pairCount, const uint32_t* __restrict__ ordScratch, uint32_t* __restrict__ ordOut)
+{
+    // One wave per candidate copies its alignment.
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if(p >= pairCount) return;
+    const uint64_t begin = ordToc[p], n = ordToc[p + 1] - begin;
+    if(n == 0) return;
+    const uint64_t src = results[pairWinner[p]].ordBegin;
+    for(uint64_t k = laneId(); k < 2 * n; k += WAVE) ordOut[2 * begin + k] = ordScratch[2 * src + k];
+}
+
+// shasta::compress (src/compressAlignment.cpp:11-67; formats compressAlignment.hpp:101-321).
+// One thread per stored alignment; WRITE=false counts bytes.
+template<bool WRITE>
+__device__ __forceinline__ uint64_t compressAlignment(const uint32_t* __restrict__ ord, uint64_t n, uint8_t* __restrict__ out)
+{
+    uint64_t bytes = 0;
+    uint32_t ordinal0 = 0, ordinal1 = 0;
+    for(uint64_t i = 0; i < n; ) {
+        const uint32_t x = ord[2 * i], y = ord[2 * i + 1];
+        const int32_t skip0 = int32_t(x) - int32_t(ordinal0);
+        const int32_t skip1 = int32_t(y) - int32_t(ordinal1);
+        ordinal0 = x; ordinal1 = y;
+        uint32_t streak = 1;
+        for(uint64_t j = i + 1; j < n; j++, streak++) {
+            if(ord[2 * j] != ordinal0 + 1 || ord[2 * j + 1] != ordinal1 + 1) break;
+            ++ordinal0; ++ordinal1;
+        }
+        i += streak;
+        const uint64_t u0 = uint32_t(skip0), u1 = uint32_t(skip1), nm1 = uint64_t(streak) - 1;
+        uint64_t v; int len;
+        if(skip0 >= 0 && skip0 <= 3 && skip1 >= 0 && skip1 <= 3 && streak <= 8) {
+            v = 0 | (u0 & 3) << 1 | (u1 & 3) << 3 | (nm1 & 7) << 5; len = 1;
+        } else if(skip0 >= -8 && skip0 <= 7 && skip1 >= -8 && skip1 <= 7 && streak <= 32) {
+            v = 1 | (u0 & 0xf) << 3 | (u1 & 0xf) << 7 | (nm1 & 0x1f) << 11; len = 2;
+        } else if(skip0 >= -512 && skip0 <= 511 && skip1 >= -512 && skip1 <= 511 && streak <= 512) {
+            v = 3 | (u0 & 0x3ff) << 3 | (u1 & 0x3ff) << 13 | (nm1 & 0x1ff) << 23; len = 4;
+        } else if(skip0 >= -524288 && skip0 <= 524287 && skip1 >= -524288 && skip1 <= 524287 && streak <= 2097152) {
+            v = 5 | (u0 & 0xfffff) << 3 | (u1 & 0xfffff) << 23 | (nm1 & 0x1fffff) << 43; len = 8;
+        } else {
+            v = 0; len = 16;
+        }
+        if(WRITE) {
+            if(len == 16) {
+                const uint32_t w[4] = {7u, uint32_t(skip0), uint32_t(skip1), uint32_t(nm1)};
+                for(int k = 0; k < 16; k++) out[bytes + k] = uint8_t(w[k >> 2] >> (8 * (k & 3)));
+            } else {
+                for(int k = 0; k < len; k++) out[bytes + k] = uint8_t(v >> (8 * k));
+            }
+        }
+        bytes += len;
+    }
+    return bytes;
+}
+
+__global__ void __launch_bounds__(256)
+compressSizeKernel(const uint32_t* __restrict__ storedFlags, const DpResult* __restrict__ results,
+    const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch, uint32_t pairCount, uint64_t* __restrict__ sizes)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p == pairCount) { sizes[p] = 0; return; }
+    if(p > pairCount) return;
+    uint64_t s = 0;
+    if(storedFlags[p]) {
+        const DpResult r = results[pairWinner[p]];
+        s = compressAlignment<false>(ordScratch + 2 * r.ordBegin, r.markerCount, nullptr);
+    }
+    sizes[p] = s;
+}
+
+__global__ void __launch_bounds__(256)
+compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __restrict__ storedIndex,
+    const DpResult* __restrict__ results, const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch,
+    uint32_t pairCount, const uint64_t* __restrict__ byteOffsets, uint8_t* __restrict__ bytes,
+    uint64_t* __restrict__ compressedToc, const shasta_alignment_data* __restrict__ rows, shasta_alignment_data* __restrict__ rowsOut)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= pairCount || !storedFlags[p]) return;
+    const DpResult r = results[pairWinner[p]];
+    compressAlignment<true>(ordScratch + 2 * r.ordBegin, r.markerCount, bytes + byteOffsets[p]);
+    const uint32_t k = storedIndex[p];
+    compressedToc[k] = byteOffsets[p];
+    rowsOut[k] = rows[p];
+}
+
+template<class T> T readDevice(const T* p, hipStream_t s)
+{
+    T v;
+    HIP_CHECK(hipMemcpyAsync(&v, p, sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return v;
+}
+
+template<class T> T* mallocCopy(const std::vector<T>& v)
+{
+    T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if(!p) throw std::bad_alloc();
+    if(!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+DeviceOptions makeOptions(const shasta_align4_options& o)
+{
+    DeviceOptions d;
+    // Aligner's constructor narrows deltaX/deltaY through int32_t (src/Align4.cpp:56-57).
+    d.deltaX = uint32_t(int32_t(o.deltaX)); d.deltaY = uint32_t(int32_t(o.deltaY));
+    if(d.deltaX == 0 || d.deltaY == 0) throw std::runtime_error("Align4: deltaX and deltaY must be positive.");
+    d.minEntryCountPerCell = o.minEntryCountPerCell;
+    d.maxDistanceFromBoundary = o.maxDistanceFromBoundary;
+    d.minAlignedMarkerCount = o.minAlignedMarkerCount;
+    d.minAlignedFraction = o.minAlignedFraction;
+    d.maxSkip = o.maxSkip; d.maxDrift = o.maxDrift; d.maxTrim = o.maxTrim; d.maxBand = o.maxBand;
+    d.suppressContainments = o.suppressContainments ? 1u : 0u;
+    return d;
+}
+
+struct BatchScratch {
+    DeviceBuffer<PairDesc> pairs;
+    DeviceBuffer<shasta_oriented_read_pair> candidates;
+    DeviceBuffer<DpTask> tasks;
+    DeviceBuffer<uint32_t> counters;            // [0]=taskCount, [1..5]=class counts
+    DeviceBuffer<uint8_t> pairFlags, pairTie, status;
+    DeviceBuffer<unsigned long long> pairBest, dpCells;
+    DeviceBuffer<uint32_t> pairWinner, classLists, storedFlags, storedIndex, scanTemp32;
+    DeviceBuffer<uint64_t> traceWords, ordCap, scanTemp64, trace, ordCounts, sizes;
+    DeviceBuffer<uint32_t> ordScratch, ordOut;
+    DeviceBuffer<DpResult> results;
+    DeviceBuffer<shasta_alignment_data> rows, rowsOut;
+    DeviceBuffer<uint64_t> compressedToc;
+    DeviceBuffer<uint8_t> bytes;
+};
+
+template<int C>
+void launchDp(Context& ctx, BatchScratch& b, int cls, uint32_t count, uint32_t listStride, const DeviceOptions& opt)
+{
+    if(count == 0) return;
+    hipLaunchKernelGGL(bandedDpKernel<C>, dim3(divUp(count, 4)), dim3(256), 0, ctx.stream,
+        (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(),
+        (const uint32_t*)(b.classLists.data() + uint64_t(cls) * listStride), count,
+        (const uint64_t*)b.traceWords.data(), (const uint64_t*)b.ordCap.data(),
+        b.trace.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options& options, bool wantOrdinals, shasta_align4_result& result)
+{
+    std::memset(&result, 0, sizeof(result));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const DeviceOptions opt = makeOptions(options);
+
+    std::vector<shasta_alignment_data> outRows;
+    std::vector<uint64_t> outCompressedToc(1, 0), outOrdinalsToc(1, 0);
+    std::vector<uint8_t> outBytes, outStatus(candidateCount);
+    std::vector<uint32_t> outOrdinals;
+    uint64_t dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0;
+    double dpSeconds = 0;
+    uint64_t dpLaunches = 0;
+    hipEvent_t evBegin, evEnd, evA, evB;
+    HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
+    HIP_CHECK(hipEventCreate(&evA)); HIP_CHECK(hipEventCreate(&evB));
+    HIP_CHECK(hipEventRecord(evBegin, stream));
+
+    BatchScratch b;
+    const uint64_t BATCH = 1ULL << 17;
+    std::vector<PairDesc> hostPairs;
+    std::vector<uint64_t> hostToc64;
+    std::vector<uint8_t> hostStatus;
+    for(uint64_t batchBegin = 0; batchBegin < candidateCount; batchBegin += BATCH) {
+        const uint32_t n = uint32_t(std::min<uint64_t>(BATCH, candidateCount - batchBegin));
+        hostPairs.resize(n);
+        for(uint32_t k = 0; k < n; k++) {
+            const shasta_oriented_read_pair& c = candidates[batchBegin + k];
+            if(!(c.readIds[0] < c.readIds[1]) || c.readIds[1] >= ctx.readCount) {
+                throw std::runtime_error("Align4: invalid alignment candidate (need readId0 < readId1 < readCount).");
+            }
+            const uint64_t o0 = 2ULL * c.readIds[0];                                  // strand 0, src/AssemblerAlign.cpp:382
+            const uint64_t o1 = 2ULL * c.readIds[1] + (c.isSameStrand ? 0 : 1);      // :383
+            PairDesc pd;
+            pd.begin0 = ctx.hostToc[o0]; pd.begin1 = ctx.hostToc[o1];
+            const uint64_t nx = ctx.hostToc[o0 + 1] - pd.begin0, ny = ctx.hostToc[o1 + 1] - pd.begin1;
+            MI355X_ASSERT(nx < (1ULL << 30) && ny < (1ULL << 30));
+            pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
+            hostPairs[k] = pd;
+            kmerIdBytes += 4 * (nx + ny);
+        }
+        const uint32_t taskCapacity = 8 * n + 1024;
+        b.pairs.reserve(n, stream); b.candidates.reserve(n, stream); b.tasks.reserve(taskCapacity, stream);
+        b.counters.reserve(8, stream); b.pairFlags.reserve(n, stream); b.pairTie.reserve(n, stream); b.status.reserve(n, stream);
+        b.pairBest.reserve(n, stream); b.dpCells.reserve(1, stream); b.pairWinner.reserve(n, stream);
+        b.storedFlags.reserve(n + 1, stream); b.storedIndex.reserve(n + 1, stream);
+        b.scanTemp32.reserve(scanTempElements(uint64_t(n) + 1), stream);
+        b.ordCounts.reserve(n + 1, stream); b.sizes.reserve(n + 1, stream);
+        b.rows.reserve(n, stream); b.rowsOut.reserve(n, stream); b.compressedToc.reserve(n + 1, stream);
+        HIP_CHECK(hipMemcpyAsync(b.pairs.data(), hostPairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.candidates.data(), candidates + batchBegin, n * sizeof(shasta_oriented_read_pair), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 8 * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(b.pairFlags.data(), 0, n, stream));
+        HIP_CHECK(hipMemsetAsync(b.pairTie.data(), 0, n, stream));
+        HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, n * sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
+
+        // K8/K9.
+        hipLaunchKernelGGL(align4CellsKernel, dim3(n), dim3(CELLS_THREADS), 0, stream,
+            (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), n, opt,
+            b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
+        HIP_CHECK(hipGetLastError());
+        const uint32_t taskCount = readDevice(b.counters.data(), stream);
+        if(taskCount > taskCapacity) throw std::runtime_error("Align4: task list overflow.");
+
+        // Size the tasks, lay out the trace and ordinal scratch, bin by band-width class.
+        uint32_t classCounts[5] = {0, 0, 0, 0, 0};
+        const uint32_t listStride = std::max<uint32_t>(1, taskCount);
+        if(taskCount) {
+            b.traceWords.reserve(taskCount + 1, stream); b.ordCap.reserve(taskCount + 1, stream);
+            b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
+            b.classLists.reserve(5ULL * listStride, stream); b.results.reserve(taskCount, stream);
+            hipLaunchKernelGGL(sizeTasksKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
+                (const DpTask*)b.tasks.data(), (const PairDesc*)b.pairs.data(), taskCount,
+                b.traceWords.data(), b.ordCap.data(), b.classLists.data(), b.counters.data() + 1, listStride, b.dpCells.data());
+            exclusiveScan<uint64_t>(b.traceWords.data(), b.traceWords.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
+            exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
+            HIP_CHECK(hipGetLastError());
+            const uint64_t traceTotal = readDevice(b.traceWords.data() + taskCount, stream);
+            const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);
+            HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            dpCellsTotal += readDevice(b.dpCells.data(), stream);
+            b.trace.reserve(traceTotal + 64, stream);
+            b.ordScratch.reserve(2 * ordTotal + 2, stream);
+
+            // K10.
+            HIP_CHECK(hipEventRecord(evA, stream));
+            launchDp<1>(ctx, b, 0, classCounts[0], listStride, opt);
+            launchDp<2>(ctx, b, 1, classCounts[1], listStride, opt);
+            launchDp<4>(ctx, b, 2, classCounts[2], listStride, opt);
+            launchDp<8>(ctx, b, 3, classCounts[3], listStride, opt);
+            launchDp<16>(ctx, b, 4, classCounts[4], listStride, opt);
+            HIP_CHECK(hipEventRecord(evB, stream));
+            hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+                (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
+                (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data());
+            HIP_CHECK(hipGetLastError());
+        } else {
+            b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
+        }
+
+        // K11.
+        const unsigned gp = divUp(uint64_t(n) + 1, 256);
+        hipLaunchKernelGGL(finalizeKernel, dim3(gp), dim3(256), 0, stream,
+            (const PairDesc*)b.pairs.data(), (const shasta_oriented_read_pair*)b.candidates.data(), n,
+            (const DpResult*)b.results.data(), (const unsigned long long*)b.pairBest.data(),
+            (const uint32_t*)b.pairWinner.data(), (const uint8_t*)b.pairTie.data(), (const uint8_t*)b.pairFlags.data(),
+            opt, wantOrdinals ? 1 : 0, b.status.data(), b.rows.data(), b.storedFlags.data(), b.ordCounts.data());
+        exclusiveScan<uint32_t>(b.storedFlags.data(), b.storedIndex.data(), uint64_t(n) + 1, b.scanTemp32.data(), stream);
+        b.scanTemp64.reserve(scanTempElements(uint64_t(n) + 1), stream);
+        exclusiveScan<uint64_t>(b.ordCounts.data(), b.ordCounts.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
+        hipLaunchKernelGGL(compressSizeKernel, dim3(gp), dim3(256), 0, stream,
+            (const uint32_t*)b.storedFlags.data(), (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(),
+            (const uint32_t*)b.ordScratch.data(), n, b.sizes.data());
+        exclusiveScan<uint64_t>(b.sizes.data(), b.sizes.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
+        HIP_CHECK(hipGetLastError());
+        const uint32_t storedCount = readDevice(b.storedIndex.data() + n, stream);
+        const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
+        const uint64_t byteTotal = readDevice(b.sizes.data() + n, stream);
+        b.bytes.reserve(byteTotal + 1, stream);
+        hipLaunchKernelGGL(compressWriteKernel, dim3(gp), dim3(256), 0, stream,
+            (const uint32_t*)b.storedFlags.data(), (const uint32_t*)b.storedIndex.data(), (const DpResult*)b.results.data(),
+            (const uint32_t*)b.pairWinner.data(), (const uint32_t*)b.ordScratch.data(), n,
+            (const uint64_t*)b.sizes.data(), b.bytes.data(), b.compressedToc.data(),
+            (const shasta_alignment_data*)b.rows.data(), b.rowsOut.data());
+        HIP_CHECK(hipGetLastError());
+
+        // Copy this batch's results out, in candidate order.
+        const size_t rowBase = outRows.size();
+        outRows.resize(rowBase + storedCount);
+        hostToc64.resize(storedCount);
+        if(storedCount) {
+            HIP_CHECK(hipMemcpyAsync(outRows.data() + rowBase, b.rowsOut.data(), storedCount * sizeof(shasta_alignment_data), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(hostToc64.data(), b.compressedToc.data(), storedCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        }
+        const size_t byteBase = outBytes.size();
+        outBytes.resize(byteBase + byteTotal);
+        if(byteTotal) HIP_CHECK(hipMemcpyAsync(outBytes.data() + byteBase, b.bytes.data(), byteTotal, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(outStatus.data() + batchBegin, b.status.data(), n, hipMemcpyDeviceToHost, stream));
+        std::vector<uint64_t> hostOrdToc;
+        const size_t ordBaseOut = outOrdinals.size() / 2;
+        if(wantOrdinals) {
+            hostOrdToc.resize(uint64_t(n) + 1);
+            HIP_CHECK(hipMemcpyAsync(hostOrdToc.data(), b.ordCounts.data(), (uint64_t(n) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            if(ordTotalOut) {
+                b.ordOut.reserve(2 * ordTotalOut, stream);
+                hipLaunchKernelGGL(gatherOrdinalsKernel, dim3(divUp(uint64_t(n) * 64, 256)), dim3(256), 0, stream,
+                    (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(), (const uint64_t*)b.ordCounts.data(), n,
+                    (const uint32_t*)b.ordScratch.data(), b.ordOut.data());
+                HIP_CHECK(hipGetLastError());
+                outOrdinals.resize(2 * (ordBaseOut + ordTotalOut));
+                HIP_CHECK(hipMemcpyAsync(outOrdinals.data() + 2 * ordBaseOut, b.ordOut.data(), 2 * ordTotalOut * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            }
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        // CSR of CompressedAlignments: end offset of each stored alignment.
+        for(uint32_t k = 0; k < storedCount; k++) {
+            outCompressedToc.push_back(byteBase + (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal));
+        }
+        if(wantOrdinals) for(uint32_t k = 1; k <= n; k++) outOrdinalsToc.push_back(ordBaseOut + hostOrdToc[k]);
+        for(uint32_t k = 0; k < storedCount; k++) alignedBytes += 8ULL * outRows[rowBase + k].info.markerCount;
+        if(taskCount) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
+            dpSeconds += ms * 1e-3;
+            for(int c = 0; c < 5; c++) dpLaunches += classCounts[c] ? 1 : 0;
+        }
+    }
+
+    HIP_CHECK(hipEventRecord(evEnd, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
+    result.deviceSeconds = ms * 1e-3;
+    (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
+
+    ctx.times.alignDpSeconds = dpSeconds;
+    ctx.times.alignDpLaunches = dpLaunches;
+    ctx.times.alignDpCells = dpCellsTotal;
+    ctx.times.alignBytes = kmerIdBytes + alignedBytes;
+
+    result.alignmentCount = outRows.size();
+    result.alignmentData = mallocCopy(outRows);
+    result.compressedToc = mallocCopy(outCompressedToc);
+    result.compressedData = mallocCopy(outBytes);
+    result.status = mallocCopy(outStatus);
+    if(wantOrdinals) { result.ordinalsToc = mallocCopy(outOrdinalsToc); result.ordinals = mallocCopy(outOrdinals); }
+    result.dpCellCount = dpCellsTotal;
+    result.kmerIdBytes = kmerIdBytes;
+    result.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void align4Free(shasta_align4_result& r)
+{
+    std::free(r.alignmentData); std::free(r.compressedToc); std::free(r.compressedData);
+    std::free(r.status); std::free(r.ordinalsToc); std::free(r.ordinals);
+    std::memset(&r, 0, sizeof(r));
+}
+
+// Unit seam: one banded DP on the device (used by the parity tests of K10 alone).
+void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
+    uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score)
+{
+    int device = 0;
+    HIP_CHECK(hipGetDevice(&device));
+    Context ctx(device);
+    if(bandMin > bandMax || bandMax - bandMin + 1 > 1024) throw std::runtime_error("banded_dp: band width must be in [1, 1024].");
+    if(bandMin > int32_t(nx) || bandMax < -int32_t(ny) || nx == 0 || ny == 0) {
+        *count = 0; *score = int32_t(0x80000000);
+        return;
+    }
+    std::vector<uint64_t> toc = {0, nx, uint64_t(nx) + ny};
+    std::vector<uint32_t> all(k0, k0 + nx);
+    all.insert(all.end(), k1, k1 + ny);
+    // A context with one "read" whose two strands are the two sequences.
+    ctx.setMarkers(1, toc.data(), nullptr, all.data(), nullptr);
+    hipStream_t stream = ctx.stream;
+    BatchScratch b;
+    PairDesc pd; pd.begin0 = 0; pd.begin1 = nx; pd.nx = nx; pd.ny = ny;
+    DpTask task; task.pair = 0; task.bandMin = bandMin; task.bandMax = bandMax; task.label = 0;
+    const TaskGeometry g = taskGeometry(bandMin, bandMax, nx, ny);
+    b.pairs.reserve(1, stream); b.tasks.reserve(1, stream); b.classLists.reserve(1, stream);
+    b.traceWords.reserve(2, stream); b.ordCap.reserve(2, stream); b.results.reserve(1, stream);
+    b.pairBest.reserve(1, stream);
+    b.trace.reserve(uint64_t(g.rows) * g.rowWords + 64, stream);
+    b.ordScratch.reserve(2ULL * std::min(nx, ny) + 2, stream);
+    const uint32_t zero32 = 0; const uint64_t zeros[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(b.pairs.data(), &pd, sizeof(pd), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(b.tasks.data(), &task, sizeof(task), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(b.classLists.data(), &zero32, 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(b.traceWords.data(), zeros, 16, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(b.ordCap.data(), zeros, 16, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8, stream));
+    DeviceOptions opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
+    switch(g.cls) {
+        case 0: launchDp<1>(ctx, b, 0, 1, 1, opt); break;
+        case 1: launchDp<2>(ctx, b, 0, 1, 1, opt); break;
+        case 2: launchDp<4>(ctx, b, 0, 1, 1, opt); break;
+        case 3: launchDp<8>(ctx, b, 0, 1, 1, opt); break;
+        default: launchDp<16>(ctx, b, 0, 1, 1, opt); break;
+    }
+    DpResult r;
+    HIP_CHECK(hipMemcpyAsync(&r, b.results.data(), sizeof(r), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if(r.markerCount > capacity) throw std::runtime_error("banded_dp: output capacity too small.");
+    if(r.markerCount) {
+        HIP_CHECK(hipMemcpy(ordinals, b.ordScratch.data() + 2 * r.ordBegin, 8ULL * r.markerCount, hipMemcpyDeviceToHost));
+    }
+    *count = r.markerCount;
+    *score = r.score;
+}
+
+}  // namespace shasta_mi355x
