@@ -65,7 +65,8 @@ constexpr uint32_t EMPTY32 = 0xffffffffu;
 constexpr uint64_t EMPTY64 = ~0ULL;
 
 constexpr uint32_t F_NEAR_LT = 1, F_NEAR_RB = 2, F_FWD = 4, F_BWD = 8;
-constexpr uint8_t PAIR_RESOURCE = 1;       // a fixed-size on-chip table overflowed: candidate is skipped + reported
+constexpr uint8_t PAIR_RESOURCE = 1;       // a cell table overflowed: retried with a larger table in HBM
+constexpr uint8_t PAIR_TOO_LONG = 2;       // outside the supported geometry (iX/iY >= 2^16 or band > 1024): skipped + reported
 
 __device__ __forceinline__ uint32_t hash32(uint32_t k) { return k * 2654435761u; }
 
@@ -77,31 +78,62 @@ __device__ __forceinline__ void getxy(uint32_t X, uint32_t Y, uint32_t nx, int32
     y = (Xs + Ys - int32_t(nx) + 1) / 2;
 }
 
+// Reads of block-shared mutable state.  SMALL: LDS.  BIG: the tables live in HBM scratch and
+// are updated with atomics (L2); plain loads could hit a stale line of this CU's L1, so
+// they bypass it (agent-scope relaxed load = global_load sc1).
+template<bool BIG> __device__ __forceinline__ uint32_t ld(const uint32_t* p)
+{
+    if(BIG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// One workgroup per candidate.  SMALL keeps the cell table (CELL_SLOTS) and the kept-cell
+// list (MAX_CELLS) in LDS; BIG uses a per-candidate region of HBM scratch of 2^slotsLog2
+// table slots (layout: keys[S] vals[S] cKey[S/2] cFlags[S/2] cLabel[S/2] cYMin[S/2] cYMax[S/2]).
+template<bool BIG>
 __global__ void __launch_bounds__(CELLS_THREADS)
 align4CellsKernel(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, uint32_t pairCount,
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const uint32_t* __restrict__ pairList, uint32_t listCount,
     DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
-    uint8_t* __restrict__ pairFlags)
+    uint8_t* __restrict__ pairFlags,
+    uint32_t* __restrict__ bigScratch, const uint64_t* __restrict__ bigOffsets, const uint8_t* __restrict__ bigSlotsLog2)
 {
     __shared__ uint64_t matchTab[MATCH_SLOTS];
-    __shared__ uint32_t cellKeys[CELL_SLOTS];
-    __shared__ uint32_t cellVals[CELL_SLOTS];      // entry count, then compact cell index
-    __shared__ uint32_t cKey[MAX_CELLS];
-    __shared__ uint32_t cFlags[MAX_CELLS];
-    __shared__ uint32_t cLabel[MAX_CELLS];
-    __shared__ uint32_t cYMin[MAX_CELLS];
-    __shared__ uint32_t cYMax[MAX_CELLS];
+    __shared__ uint32_t sCellKeys[BIG ? 1 : CELL_SLOTS];
+    __shared__ uint32_t sCellVals[BIG ? 1 : CELL_SLOTS];
+    __shared__ uint32_t sKey[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sFlags[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sLabel[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sYMin[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sYMax[BIG ? 1 : MAX_CELLS];
     __shared__ uint32_t sCells, sOverflow, sChanged;
 
-    const uint32_t pair = blockIdx.x;
-    if(pair >= pairCount) return;
+    if(blockIdx.x >= listCount) return;
+    const uint32_t pair = pairList[blockIdx.x];
     const int tid = int(threadIdx.x);
     const PairDesc pd = pairs[pair];
     const uint32_t nx = pd.nx, ny = pd.ny;
     const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
     const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
 
-    for(int k = tid; k < CELL_SLOTS; k += CELLS_THREADS) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
+    uint32_t *cellKeys, *cellVals, *cKey, *cFlags, *cLabel, *cYMin, *cYMax;
+    int slotsLog2;
+    if(BIG) {
+        slotsLog2 = int(bigSlotsLog2[blockIdx.x]);
+        const uint64_t S = 1ULL << slotsLog2;
+        uint32_t* base = bigScratch + bigOffsets[blockIdx.x];
+        cellKeys = base; cellVals = base + S; cKey = base + 2 * S; cFlags = cKey + S / 2;
+        cLabel = cFlags + S / 2; cYMin = cLabel + S / 2; cYMax = cYMin + S / 2;
+    } else {
+        slotsLog2 = 11;
+        cellKeys = sCellKeys; cellVals = sCellVals; cKey = sKey; cFlags = sFlags; cLabel = sLabel; cYMin = sYMin; cYMax = sYMax;
+    }
+    const uint32_t slots = 1u << slotsLog2;
+    const uint32_t maxCells = BIG ? slots / 2 : uint32_t(MAX_CELLS);
+    const int hashShift = 32 - slotsLog2;
+
+    for(uint32_t k = tid; k < slots; k += CELLS_THREADS) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
     if(tid == 0) { sCells = 0; sOverflow = 0; sChanged = 0; }
 
     // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
@@ -131,17 +163,17 @@ align4CellsKernel(
                     const uint32_t y = uint32_t(e);
                     const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
                     const uint32_t iX = X / opt.deltaX, iY = Y / opt.deltaY;
-                    if(iX >= 65536u || iY >= 65535u) { sOverflow = 1; }
+                    if(iX >= 65536u || iY >= 65535u) { sOverflow = 2; }
                     else {
                         const uint32_t key = (iY << 16) | iX;
-                        uint32_t cs = hash32(key) >> (32 - 11);
-                        int probe = 0;
-                        for(; probe < CELL_SLOTS; probe++) {
+                        uint32_t cs = hash32(key) >> hashShift;
+                        uint32_t probe = 0;
+                        for(; probe < slots; probe++) {
                             const uint32_t old = atomicCAS(&cellKeys[cs], EMPTY32, key);
                             if(old == EMPTY32 || old == key) { atomicAdd(&cellVals[cs], 1u); break; }
-                            cs = (cs + 1) & (CELL_SLOTS - 1);
+                            cs = (cs + 1) & (slots - 1);
                         }
-                        if(probe == CELL_SLOTS) sOverflow = 1;
+                        if(probe == slots) sOverflow = 1;
                     }
                 }
                 slot = (slot + 1) & (MATCH_SLOTS - 1);
@@ -151,38 +183,38 @@ align4CellsKernel(
     __syncthreads();
 
     // Keep cells with enough entries (:417) and give them compact indices.
-    for(int k = tid; k < CELL_SLOTS; k += CELLS_THREADS) {
-        const uint32_t key = cellKeys[k];
+    for(uint32_t k = tid; k < slots; k += CELLS_THREADS) {
+        const uint32_t key = ld<BIG>(&cellKeys[k]);
         if(key == EMPTY32) continue;
-        if(uint64_t(cellVals[k]) >= opt.minEntryCountPerCell) {
+        if(uint64_t(ld<BIG>(&cellVals[k])) >= opt.minEntryCountPerCell) {
             const uint32_t idx = atomicAdd(&sCells, 1u);
-            if(idx < MAX_CELLS) { cKey[idx] = key; cellVals[k] = idx; }
+            if(idx < maxCells) { cKey[idx] = key; cellVals[k] = idx; }
             else { sOverflow = 1; cellVals[k] = EMPTY32; }
         } else {
             cellVals[k] = EMPTY32;
         }
     }
     __syncthreads();
-    if(sOverflow) { if(tid == 0) pairFlags[pair] = PAIR_RESOURCE; return; }
+    if(sOverflow) { if(tid == 0) pairFlags[pair] = (sOverflow == 2) ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
     const int n = int(sCells);
     if(n == 0) return;
 
     auto find = [&](int32_t iX, int32_t iY) -> int {
         if(iX < 0 || iY < 0 || iX >= 65536 || iY >= 65535) return -1;
         const uint32_t key = (uint32_t(iY) << 16) | uint32_t(iX);
-        uint32_t cs = hash32(key) >> (32 - 11);
-        for(int probe = 0; probe < CELL_SLOTS; probe++) {
-            const uint32_t k = cellKeys[cs];
+        uint32_t cs = hash32(key) >> hashShift;
+        for(uint32_t probe = 0; probe < slots; probe++) {
+            const uint32_t k = ld<BIG>(&cellKeys[cs]);
             if(k == EMPTY32) return -1;
-            if(k == key) return int(cellVals[cs]);          // EMPTY32 (-1) for dropped cells
-            cs = (cs + 1) & (CELL_SLOTS - 1);
+            if(k == key) return int(ld<BIG>(&cellVals[cs]));          // EMPTY32 (-1) for dropped cells
+            cs = (cs + 1) & (slots - 1);
         }
         return -1;
     };
 
     // Boundary flags (:424-429 with the corner rules of :530-626).
     for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t key = cKey[c];
+        const uint32_t key = ld<BIG>(&cKey[c]);
         const uint32_t iX = key & 0xffffu, iY = key >> 16;
         int32_t x, y;
         getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
@@ -207,13 +239,14 @@ align4CellsKernel(
         if(tid == 0) sChanged = 0;
         __syncthreads();
         for(int c = tid; c < n; c += CELLS_THREADS) {
-            if(cFlags[c] & F_FWD) continue;
-            const int32_t iX = int32_t(cKey[c] & 0xffffu), iY = int32_t(cKey[c] >> 16);
+            if(ld<BIG>(&cFlags[c]) & F_FWD) continue;
+            const uint32_t key = ld<BIG>(&cKey[c]);
+            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
             bool reach = false;
             for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = -1; dX <= 0; dX++) {
                 if(dX == 0 && dY == 0) continue;
                 const int j = find(iX + dX, iY + dY);
-                if(j >= 0 && (cFlags[j] & F_FWD)) { reach = true; break; }
+                if(j >= 0 && (ld<BIG>(&cFlags[j]) & F_FWD)) { reach = true; break; }
             }
             if(reach) { atomicOr(&cFlags[c], F_FWD); sChanged = 1; }
         }
@@ -223,21 +256,22 @@ align4CellsKernel(
     // backwardSearch (:736-787): seeds near right/bottom AND forward accessible; a cell is
     // backward accessible if a backward accessible cell lies at (iX or iX+1, iY-1..iY+1).
     for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t f = cFlags[c];
-        if((f & F_NEAR_RB) && (f & F_FWD)) cFlags[c] = f | F_BWD;
+        const uint32_t f = ld<BIG>(&cFlags[c]);
+        if((f & F_NEAR_RB) && (f & F_FWD)) atomicOr(&cFlags[c], F_BWD);
     }
     for(;;) {
         __syncthreads();
         if(tid == 0) sChanged = 0;
         __syncthreads();
         for(int c = tid; c < n; c += CELLS_THREADS) {
-            if(cFlags[c] & F_BWD) continue;
-            const int32_t iX = int32_t(cKey[c] & 0xffffu), iY = int32_t(cKey[c] >> 16);
+            if(ld<BIG>(&cFlags[c]) & F_BWD) continue;
+            const uint32_t key = ld<BIG>(&cKey[c]);
+            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
             bool reach = false;
             for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = 0; dX <= 1; dX++) {
                 if(dX == 0 && dY == 0) continue;
                 const int j = find(iX + dX, iY + dY);
-                if(j >= 0 && (cFlags[j] & F_BWD)) { reach = true; break; }
+                if(j >= 0 && (ld<BIG>(&cFlags[j]) & F_BWD)) { reach = true; break; }
             }
             if(reach) { atomicOr(&cFlags[c], F_BWD); sChanged = 1; }
         }
@@ -247,22 +281,23 @@ align4CellsKernel(
 
     // Connected components of active cells, 8-neighbourhood (:792-868): min-label propagation.
     for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t f = cFlags[c];
-        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? cKey[c] : EMPTY32;
+        const uint32_t f = ld<BIG>(&cFlags[c]);
+        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? ld<BIG>(&cKey[c]) : EMPTY32;
     }
     for(;;) {
         __syncthreads();
         if(tid == 0) sChanged = 0;
         __syncthreads();
         for(int c = tid; c < n; c += CELLS_THREADS) {
-            const uint32_t mine = cLabel[c];
+            const uint32_t mine = ld<BIG>(&cLabel[c]);
             if(mine == EMPTY32) continue;
-            const int32_t iX = int32_t(cKey[c] & 0xffffu), iY = int32_t(cKey[c] >> 16);
+            const uint32_t key = ld<BIG>(&cKey[c]);
+            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
             uint32_t best = mine;
             for(int dY = -1; dY <= 1; dY++) for(int dX = -1; dX <= 1; dX++) {
                 if(dX == 0 && dY == 0) continue;
                 const int j = find(iX + dX, iY + dY);
-                if(j >= 0) best = min(best, cLabel[j]);
+                if(j >= 0) best = min(best, ld<BIG>(&cLabel[j]));
             }
             if(best < mine) { atomicMin(&cLabel[c], best); sChanged = 1; }
         }
@@ -271,26 +306,27 @@ align4CellsKernel(
     }
     // iY range of each component, stored at its root cell (the cell whose key is the label).
     for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t label = cLabel[c];
+        const uint32_t label = ld<BIG>(&cLabel[c]);
         if(label == EMPTY32) continue;
         const int r = find(int32_t(label & 0xffffu), int32_t(label >> 16));
-        const uint32_t iY = cKey[c] >> 16;
+        const uint32_t iY = ld<BIG>(&cKey[c]) >> 16;
         atomicMin(&cYMin[r], iY);
         atomicMax(&cYMax[r], iY);
     }
     __syncthreads();
     // One banded alignment per component (:890-934).
     for(int c = tid; c < n; c += CELLS_THREADS) {
-        if(cLabel[c] != cKey[c]) continue;
-        const uint32_t YMin = cYMin[c] * opt.deltaY;
-        const uint32_t YMax = (cYMax[c] + 1) * opt.deltaY - 1;
+        const uint32_t key = ld<BIG>(&cKey[c]);
+        if(ld<BIG>(&cLabel[c]) != key) continue;
+        const uint32_t YMin = ld<BIG>(&cYMin[c]) * opt.deltaY;
+        const uint32_t YMax = (ld<BIG>(&cYMax[c]) + 1) * opt.deltaY - 1;
         const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
         const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
         const int32_t bandWidth = bandMax - bandMin + 1;
         if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;             // :929
-        if(bandWidth > 1024) { pairFlags[pair] = PAIR_RESOURCE; continue; }
+        if(bandWidth > 1024) { pairFlags[pair] = PAIR_TOO_LONG; continue; }
         const uint32_t t = atomicAdd(taskCount, 1u);
-        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = cKey[c]; tasks[t] = task; }
+        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
     }
 }
 
@@ -590,7 +626,7 @@ finalizeKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_read_pa
     uint8_t st;
     uint32_t stored = 0;
     uint64_t ordCount = 0;
-    if(pairFlags[p] & PAIR_RESOURCE) {
+    if(pairFlags[p]) {
         st = SHASTA_ALIGN_SKIPPED;
     } else if(pairBest[p] == 0) {
         st = SHASTA_ALIGN_EMPTY;
@@ -761,7 +797,9 @@ struct BatchScratch {
     DeviceBuffer<DpResult> results;
     DeviceBuffer<shasta_alignment_data> rows, rowsOut;
     DeviceBuffer<uint64_t> compressedToc;
-    DeviceBuffer<uint8_t> bytes;
+    DeviceBuffer<uint8_t> bytes, bigLog2;
+    DeviceBuffer<uint32_t> pairList, bigScratch;
+    DeviceBuffer<uint64_t> bigOffsets;
 };
 
 template<int C>
@@ -839,11 +877,73 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
 
-        // K8/K9.
-        hipLaunchKernelGGL(align4CellsKernel, dim3(n), dim3(CELLS_THREADS), 0, stream,
-            (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), n, opt,
-            b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
-        HIP_CHECK(hipGetLastError());
+        // K8/K9.  Candidates whose cell table fits LDS go first; the others (and any that
+        // overflow) run with a table in HBM scratch, retried with 8x the slots on overflow.
+        {
+            std::vector<uint32_t> list, bigList;
+            std::vector<uint8_t> bigLog2, hostFlags(n);
+            auto estimateLog2 = [&](uint32_t k) {
+                const uint64_t nx = hostPairs[k].nx, ny = hostPairs[k].ny;
+                const uint64_t cells = nx * ny / 4096 + (nx + ny) / 8 + 1024;
+                int l = 13;
+                while((1ULL << l) < 2 * cells && l < 24) ++l;
+                return uint8_t(l);
+            };
+            for(uint32_t k = 0; k < n; k++) {
+                if(uint64_t(hostPairs[k].nx) * hostPairs[k].ny > (1ULL << 24)) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
+                else list.push_back(k);
+            }
+            b.pairList.reserve(n, stream);
+            if(!list.empty()) {
+                HIP_CHECK(hipMemcpyAsync(b.pairList.data(), list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
+                hipLaunchKernelGGL(align4CellsKernel<false>, dim3(unsigned(list.size())), dim3(CELLS_THREADS), 0, stream,
+                    (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), uint32_t(list.size()), opt,
+                    b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),
+                    (uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)nullptr);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                for(uint32_t k : list) if(hostFlags[k] == PAIR_RESOURCE) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
+            }
+            const uint64_t scratchWordCap = 1ULL << 31;             // 8 GiB of HBM scratch per launch
+            while(!bigList.empty()) {
+                // Clear the flags of the candidates about to be retried.
+                for(uint32_t k : bigList) hostFlags[k] = 0;
+                HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
+                size_t begin = 0;
+                while(begin < bigList.size()) {
+                    std::vector<uint64_t> offsets;
+                    uint64_t words = 0;
+                    size_t end = begin;
+                    while(end < bigList.size()) {
+                        const uint64_t need = (9ULL << bigLog2[end]) / 2;              // 4.5 words per slot
+                        if(end > begin && words + need > scratchWordCap) break;
+                        offsets.push_back(words); words += need; ++end;
+                    }
+                    const uint32_t count = uint32_t(end - begin);
+                    b.bigScratch.reserve(words, stream); b.bigOffsets.reserve(count, stream); b.bigLog2.reserve(count, stream);
+                    HIP_CHECK(hipMemcpyAsync(b.pairList.data(), bigList.data() + begin, count * 4ULL, hipMemcpyHostToDevice, stream));
+                    HIP_CHECK(hipMemcpyAsync(b.bigOffsets.data(), offsets.data(), count * 8ULL, hipMemcpyHostToDevice, stream));
+                    HIP_CHECK(hipMemcpyAsync(b.bigLog2.data(), bigLog2.data() + begin, count, hipMemcpyHostToDevice, stream));
+                    hipLaunchKernelGGL(align4CellsKernel<true>, dim3(count), dim3(CELLS_THREADS), 0, stream,
+                        (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), count, opt,
+                        b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),
+                        b.bigScratch.data(), (const uint64_t*)b.bigOffsets.data(), (const uint8_t*)b.bigLog2.data());
+                    HIP_CHECK(hipGetLastError());
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    begin = end;
+                }
+                HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                std::vector<uint32_t> nextList; std::vector<uint8_t> nextLog2;
+                for(size_t q = 0; q < bigList.size(); q++) {
+                    if(hostFlags[bigList[q]] == PAIR_RESOURCE && bigLog2[q] < 24) {
+                        nextList.push_back(bigList[q]); nextLog2.push_back(uint8_t(std::min(24, bigLog2[q] + 3)));
+                    }
+                }
+                bigList.swap(nextList); bigLog2.swap(nextLog2);
+            }
+        }
         const uint32_t taskCount = readDevice(b.counters.data(), stream);
         if(taskCount > taskCapacity) throw std::runtime_error("Align4: task list overflow.");
 
