@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the overlap-detection hot path (LowHash0 + Align4) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over the workload: LowHash0 (10 MinHash
+iterations) on the resident markers -> candidate list -> Align4 on every candidate ->
+AlignmentData + CompressedAlignments on the host.  Inputs (kmer ids, toc) are resident
+in HBM before the timed region.  Workload: BASELINE.json configs[2]
+("Synthetic 100k reads, 1xMI355X, LowHash0 + Align4 banded marker alignment end-to-end"),
+generated at marker level (shasta_amd/synthetic.py; SURVEY F5: the path never reads bases).
+
+Prints ONE JSON line on rank 0 (see the keys below).  `value` = candidate read pairs
+aligned per second, whole job.  The CPU baseline is the reference's own code
+(oracle/_ref, compiled in place from /root/reference) when that library is present,
+otherwise the CPU restatement (oracle/), timed on this host on a 1/10-scale sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_workload(n_reads, seed):
+    from shasta_amd import synthetic
+    # 45x coverage: n_reads * 1500 genome markers per read / genome markers.
+    genome_markers = max(20000, int(round(n_reads * 1500 / 45.0)))
+    return synthetic.marker_reads(n_reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
+                                  keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed)
+
+
+def lowhash_params():
+    from shasta_amd import abi
+    # m=4, f=0.01, 10 iterations, minBucketSize/maxBucketSize/minFrequency 5/30/5.
+    return abi.default_lowhash0_params(minBucketSize=5, maxBucketSize=30, minFrequency=5)
+
+
+def align_options():
+    from shasta_amd import abi
+    return abi.default_align4_options()
+
+
+def cpu_baseline(n_reads_sample, seed):
+    """Reference CPU path on a bounded sample of the same workload (1/10 scale, same coverage)."""
+    from oracle import bindings
+    from shasta_amd import synthetic
+    cores = os.cpu_count() or 1
+    toc, kmer = make_workload(n_reads_sample, seed)
+    data7 = synthetic.pack_markers(toc, kmer)
+    p, o = lowhash_params(), align_options()
+    if bindings.ref_available():
+        lib, kind = bindings.RefLib(), "reference"
+        lh = lib.lowhash0(toc, data7, None, p, threads=cores)
+        t_lh = lh.seconds
+        cand = lh.candidates
+        # The per-thread 2 GiB arena of the reference is a fixed setup cost (seconds): time two
+        # sample sizes and use the incremental rate.
+        n1, n2 = min(len(cand), 4000), min(len(cand), 24000)
+        t1 = lib.align4_batch(toc, data7, cand[:n1], o, want_ordinals=False, threads=cores).seconds
+        t2 = lib.align4_batch(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores).seconds
+        per_pair = (t2 - t1) / max(1, n2 - n1) if n2 > n1 else t2 / max(1, n2)
+    else:
+        if not bindings.oracle_available():
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        lib, kind, used = bindings.OracleLib(), "port", cores
+        t0 = time.time()
+        lh = lib.lowhash0(toc, data7, None, p)
+        t_lh = time.time() - t0
+        cand = lh.candidates
+        n2 = min(len(cand), 24000)
+        t0 = time.time()
+        lib.align4_batch(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores)
+        per_pair = (time.time() - t0) / max(1, n2)
+    pairs = len(cand)
+    total = t_lh + pairs * per_pair
+    return {
+        "value": pairs / total if total > 0 else 0.0,
+        "unit": "candidate read-pairs aligned/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": "%d reads (1/10-scale workload, same 45x coverage, M=%d markers): LowHash0 %.2f s on %d threads "
+                  "-> %d candidates; Align4 %.3f ms/candidate incremental over %d candidates on %d threads "
+                  "(restated DP, reference control flow)" % (
+                      n_reads_sample, int(toc[-1]), t_lh, cores, pairs, per_pair * 1e3, n2, cores),
+        "lowhash0_seconds": t_lh,
+        "align4_seconds_per_pair": per_pair,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lowhash-only", action="store_true", help="BASELINE configs[1]")
+    args = ap.parse_args()
+
+    import torch
+    import shasta_amd
+    from shasta_amd import abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+
+    lib = shasta_amd.load()
+    assert lib.device_count() >= 1, "no gfx950 device: the HIP path cannot run (there is no CPU fallback)"
+
+    # Workload.  Multi-GPU: weak scaling, every rank owns `reads` reads (its own genome region).
+    toc, kmer = make_workload(args.reads, 12345 + rank)
+    marker_count = int(toc[-1])
+    ctx = lib.context(local_rank)
+    ctx.set_kmer_ids(toc, kmer)                     # host -> HBM, outside the timed region
+    del kmer
+    p, o = lowhash_params(), align_options()
+
+    def step():
+        lh = ctx.lowhash0(p)
+        if args.lowhash_only:
+            return lh, None
+        al = ctx.align4(lh.candidates, o, want_ordinals=False)
+        return lh, al
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    hash_s = hash_n = hash_b = dp_s = dp_cells = dp_bytes = 0
+    lh_dev = al_dev = 0.0
+    for _ in range(args.steps):
+        lh, al = step()
+        kt = ctx.kernel_times()
+        hash_s += kt.lowhashHashSeconds; hash_n += kt.lowhashHashLaunches; hash_b += kt.lowhashHashBytes
+        lh_dev += lh.device_seconds
+        if al is not None:
+            dp_s += kt.alignDpSeconds; dp_cells += kt.alignDpCells; dp_bytes += kt.alignBytes
+            al_dev += al.device_seconds
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([len(lh.candidates), 0 if al is None else len(al.alignment_data)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        pairs_total, stored_total = int(c[0].item()), int(c[1].item())
+    else:
+        pairs_total, stored_total = len(lh.candidates), 0 if al is None else len(al.alignment_data)
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = elapsed / steps * 1e3
+        value = pairs_total / (elapsed / steps)
+        hash_avg = hash_s / max(1, hash_n)
+        hash_gbs = (hash_b / max(1, hash_n)) / hash_avg / 1e9 if hash_avg > 0 else 0.0
+        kernels = {
+            "lowhash0_hash_windows": {
+                "launches_per_step": hash_n // steps, "avg_ms": hash_avg * 1e3,
+                "algorithmic_bytes_per_launch": hash_b // max(1, hash_n), "achieved_GBps": hash_gbs,
+                "seconds_per_step": hash_s / steps,
+            },
+        }
+        dominant = "lowhash0_hash_windows"
+        roofline = {"bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hash_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": dominant}
+        if al is not None and dp_s > 0:
+            dp_gbs = dp_bytes / dp_s / 1e9
+            kernels["align4_banded_dp"] = {
+                "seconds_per_step": dp_s / steps, "gcups": dp_cells / dp_s / 1e9,
+                "algorithmic_bytes_per_step": dp_bytes // steps, "achieved_GBps": dp_gbs,
+                "note": "integer VALU/LDS-bound wavefront DP: HBM fraction is low by construction (SURVEY 8d)",
+            }
+            if dp_s > hash_s:
+                roofline = {"bound": "hbm", "achieved": dp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": dp_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "align4_banded_dp",
+                            "gcups": dp_cells / dp_s / 1e9}
+        out = {
+            "metric": "candidate read-pairs aligned/sec (LowHash0+Align4)" if not args.lowhash_only
+                      else "candidate read-pairs found/sec (LowHash0 only)",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32/i32 (integer hash + integer DP)",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: synthetic ONT-like reads, marker level, %d reads/GPU, "
+                            "mean 1500 markers (~20 kb) per oriented read, 45x coverage; LowHash0 m=4 f=0.01 "
+                            "10 iterations 5/30/5; Align4 200/10/10/100, maxBand 1000, 6/-1/-1" % args.reads,
+                "reads_per_gpu": args.reads, "markers_per_gpu": marker_count,
+                "candidates": pairs_total, "alignments_stored": stored_total,
+                "parallelism": "1 GPU" if world == 1 else "%d independent read partitions, no data-path collective" % world,
+            },
+            "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps},
+            "kernels": kernels,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(max(2000, args.reads // 10), 777)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

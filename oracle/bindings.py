@@ -143,8 +143,22 @@ class RefLib(_Base):
         self.lib.ref_lowhash0_free(C.byref(res))
         return out
 
-    def align4_batch(self, toc, data7, candidates, options, want_ordinals=True):
-        return self._align4(toc, data7, candidates, options, want_ordinals)
+    def align4_batch(self, toc, data7, candidates, options, want_ordinals=True, threads=1):
+        """threads=1 reproduces the reference's single-thread output order; any thread count
+        gives the same rows here because results are gathered in candidate order."""
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        res = abi.Align4Result()
+        rc = self.lib.ref_align4_batch_mt(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.c_uint64(threads), C.byref(res))
+        self._check(rc, "ref_align4_batch_mt")
+        out = abi.Align4Output(res, len(candidates), want_ordinals)
+        self.lib.ref_align4_free(C.byref(res))
+        return out
 
 
 class OracleLib(_Base):

@@ -27,7 +27,9 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <random>
 #include <sstream>
 #include <string>
@@ -422,7 +424,7 @@ static void copyInfo(const AlignmentInfo& info, shasta_alignment_info& out)
     out.maxDrift = info.maxDrift;
 }
 
-int ref_align4_batch(
+int ref_align4_batch_mt(
     uint64_t readCount,
     const uint64_t* markersToc,
     const void* markersData,
@@ -430,6 +432,7 @@ int ref_align4_batch(
     const shasta_oriented_read_pair* candidates,
     const shasta_align4_options* o,
     int wantOrdinals,
+    uint64_t threadCount,
     shasta_align4_result* result)
 {
     try {
@@ -437,6 +440,7 @@ int ref_align4_batch(
         const auto t0 = std::chrono::steady_clock::now();
         CoutCapture capture;
         const CompressedMarker* all = static_cast<const CompressedMarker*>(markersData);
+        if(threadCount == 0) threadCount = std::thread::hardware_concurrency();
 
         Align4::Options options;
         options.deltaX = o->deltaX;
@@ -453,74 +457,96 @@ int ref_align4_batch(
         options.mismatchScore = o->mismatchScore;
         options.gapScore = o->gapScore;
 
-        MemoryMapped::ByteAllocator byteAllocator("", 4096, 2ULL * 1024 * 1024 * 1024);
+        struct PerCandidate { uint8_t status = SHASTA_ALIGN_EMPTY; AlignmentInfo info; Alignment alignment; };
+        std::vector<PerCandidate> per(candidateCount);
+        std::atomic<uint64_t> next(0);
+        std::string firstError;
+        std::mutex errorMutex;
 
+        // One worker = the body of computeAlignmentsThreadFunction (src/AssemblerAlign.cpp:308-496)
+        // for alignMethod 4: dynamic batches of 10 candidates (:243-249), its own 2 GiB arena (:353-355).
+        auto worker = [&]() {
+            try {
+                MemoryMapped::ByteAllocator byteAllocator("", 4096, 2ULL * 1024 * 1024 * 1024);
+                array<vector< pair<KmerId, uint32_t> >, 2> sorted;
+                for(;;) {
+                    const uint64_t begin = next.fetch_add(10);
+                    if(begin >= candidateCount) break;
+                    const uint64_t end = std::min(candidateCount, begin + 10);
+                    for(uint64_t i = begin; i < end; i++) {
+                        const shasta_oriented_read_pair& c = candidates[i];
+                        SHASTA_ASSERT(c.readIds[0] < c.readIds[1]);
+                        SHASTA_ASSERT(c.readIds[1] < readCount);
+                        const OrientedReadId or0(c.readIds[0], 0);
+                        const OrientedReadId or1(c.readIds[1], c.isSameStrand ? 0 : 1);
+                        array<span<const CompressedMarker>, 2> m;
+                        m[0] = span<const CompressedMarker>(all + markersToc[or0.getValue()], all + markersToc[or0.getValue() + 1]);
+                        m[1] = span<const CompressedMarker>(all + markersToc[or1.getValue()], all + markersToc[or1.getValue() + 1]);
+                        array<span< const pair<KmerId, uint32_t> >, 2> sm;
+                        for(int j = 0; j < 2; j++) {
+                            sortedMarkersOf(m[j], sorted[j]);
+                            const pair<KmerId, uint32_t>* b = sorted[j].data();
+                            sm[j] = span< const pair<KmerId, uint32_t> >(b, b + sorted[j].size());
+                        }
+                        PerCandidate& pc = per[i];
+                        try {
+                            Align4::align(m, sm, options, byteAllocator, pc.alignment, pc.info, false);
+                            SHASTA_ASSERT(byteAllocator.isEmpty());
+                        } catch(...) {
+                            pc.status = SHASTA_ALIGN_SKIPPED;    // :419-435: skip this candidate
+                            pc.alignment.clear();
+                            continue;
+                        }
+                        const Alignment& alignment = pc.alignment;
+                        const AlignmentInfo& alignmentInfo = pc.info;
+                        pc.status = alignment.ordinals.empty() ? SHASTA_ALIGN_EMPTY : SHASTA_ALIGN_REJECTED;
+                        // Filters, src/AssemblerAlign.cpp:439-472.
+                        if(alignment.ordinals.size() < o->minAlignedMarkerCount) continue;
+                        if(min(alignmentInfo.alignedFraction(0), alignmentInfo.alignedFraction(1)) < o->minAlignedFraction) continue;
+                        uint32_t leftTrim, rightTrim;
+                        tie(leftTrim, rightTrim) = alignmentInfo.computeTrim();
+                        if(leftTrim > o->maxTrim || rightTrim > o->maxTrim) continue;
+                        if(alignment.maxSkip() > o->maxSkip) continue;
+                        if(alignment.maxDrift() > o->maxDrift) continue;
+                        if(o->suppressContainments && alignmentInfo.isContaining(uint32_t(o->maxTrim))) continue;
+                        pc.status = SHASTA_ALIGN_STORED;
+                    }
+                }
+            } catch(std::exception& e) {
+                std::lock_guard<std::mutex> lock(errorMutex);
+                if(firstError.empty()) firstError = e.what();
+            }
+        };
+        std::vector<std::thread> threads;
+        for(uint64_t t = 1; t < threadCount; t++) threads.emplace_back(worker);
+        worker();
+        for(auto& t : threads) t.join();
+        if(!firstError.empty()) throw std::runtime_error(firstError);
+
+        // Gather in candidate order (the reference's order for threadCount == 1, :262-283).
         std::vector<shasta_alignment_data> alignmentData;
         std::vector<uint64_t> compressedToc(1, 0);
         std::vector<uint8_t> compressedData;
         std::vector<uint8_t> status(candidateCount, SHASTA_ALIGN_EMPTY);
         std::vector<uint64_t> ordinalsToc(1, 0);
         std::vector<uint32_t> ordinals;
-
-        array<vector< pair<KmerId, uint32_t> >, 2> sorted;
-        Alignment alignment;
-        AlignmentInfo alignmentInfo;
         string compressedAlignment;
-
         for(uint64_t i = 0; i < candidateCount; i++) {
-            const shasta_oriented_read_pair& c = candidates[i];
-            SHASTA_ASSERT(c.readIds[0] < c.readIds[1]);
-            SHASTA_ASSERT(c.readIds[1] < readCount);
-            const OrientedReadId or0(c.readIds[0], 0);
-            const OrientedReadId or1(c.readIds[1], c.isSameStrand ? 0 : 1);
-            array<span<const CompressedMarker>, 2> m;
-            m[0] = span<const CompressedMarker>(all + markersToc[or0.getValue()], all + markersToc[or0.getValue() + 1]);
-            m[1] = span<const CompressedMarker>(all + markersToc[or1.getValue()], all + markersToc[or1.getValue() + 1]);
-            array<span< const pair<KmerId, uint32_t> >, 2> sm;
-            for(int j = 0; j < 2; j++) {
-                sortedMarkersOf(m[j], sorted[j]);
-                const pair<KmerId, uint32_t>* b = sorted[j].data();
-                sm[j] = span< const pair<KmerId, uint32_t> >(b, b + sorted[j].size());
-            }
-
-            bool failed = false;
-            try {
-                Align4::align(m, sm, options, byteAllocator, alignment, alignmentInfo, false);
-                SHASTA_ASSERT(byteAllocator.isEmpty());
-            } catch(...) {
-                failed = true;          // src/AssemblerAlign.cpp:419-435: skip this candidate
-            }
-            if(failed) {
-                status[i] = SHASTA_ALIGN_SKIPPED;
-                if(wantOrdinals) ordinalsToc.push_back(ordinals.size() / 2);
-                continue;
-            }
-
+            const PerCandidate& pc = per[i];
+            status[i] = pc.status;
             if(wantOrdinals) {
-                for(const auto& p : alignment.ordinals) { ordinals.push_back(p[0]); ordinals.push_back(p[1]); }
+                for(const auto& p : pc.alignment.ordinals) { ordinals.push_back(p[0]); ordinals.push_back(p[1]); }
                 ordinalsToc.push_back(ordinals.size() / 2);
             }
-            if(alignment.ordinals.empty()) { status[i] = SHASTA_ALIGN_EMPTY; }
-            else { status[i] = SHASTA_ALIGN_REJECTED; }
-
-            // Filters, src/AssemblerAlign.cpp:439-472.
-            if(alignment.ordinals.size() < o->minAlignedMarkerCount) continue;
-            if(min(alignmentInfo.alignedFraction(0), alignmentInfo.alignedFraction(1)) < o->minAlignedFraction) continue;
-            uint32_t leftTrim, rightTrim;
-            tie(leftTrim, rightTrim) = alignmentInfo.computeTrim();
-            if(leftTrim > o->maxTrim || rightTrim > o->maxTrim) continue;
-            if(alignment.maxSkip() > o->maxSkip) continue;
-            if(alignment.maxDrift() > o->maxDrift) continue;
-            if(o->suppressContainments && alignmentInfo.isContaining(uint32_t(o->maxTrim))) continue;
-
-            status[i] = SHASTA_ALIGN_STORED;
+            if(pc.status != SHASTA_ALIGN_STORED) continue;
             shasta_alignment_data ad;
             std::memset(&ad, 0, sizeof(ad));
-            ad.pair = c;
+            ad.pair = candidates[i];
+            ad.pair.isSameStrand = ad.pair.isSameStrand ? 1 : 0;
             ad.pair.pad[0] = ad.pair.pad[1] = ad.pair.pad[2] = 0;
-            copyInfo(alignmentInfo, ad.info);
+            copyInfo(pc.info, ad.info);
             alignmentData.push_back(ad);
-            shasta::compress(alignment, compressedAlignment);
+            shasta::compress(pc.alignment, compressedAlignment);
             compressedData.insert(compressedData.end(), compressedAlignment.begin(), compressedAlignment.end());
             compressedToc.push_back(compressedData.size());
         }
@@ -538,6 +564,14 @@ int ref_align4_batch(
         result->seconds = std::chrono::duration<double>(t1 - t0).count();
         return 0;
     } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+int ref_align4_batch(
+    uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* o, int wantOrdinals, shasta_align4_result* result)
+{
+    return ref_align4_batch_mt(readCount, markersToc, markersData, candidateCount, candidates, o, wantOrdinals, 1, result);
 }
 
 void ref_align4_free(shasta_align4_result* r)

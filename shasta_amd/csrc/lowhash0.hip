@@ -531,6 +531,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     std::vector<uint32_t> hostOverflow;
     std::vector<unsigned long long> hostHist(SIZE_HIST_CAP);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> hashEvents;
+    std::vector<uint64_t> hashRecords;
     hipEvent_t evBegin, evEnd;
     HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
     HIP_CHECK(hipEventRecord(evBegin, stream));
@@ -559,6 +560,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
             HIP_CHECK(hipEventRecord(b, stream));
             hashEvents.push_back(std::make_pair(a, b));
             n = readDevice(counter, stream);
+            hashRecords.push_back(std::min(n, recCapacity));
             if(n <= recCapacity) break;
             recCapacity = n + n / 4;           // estimate was too small: grow and redo this iteration
         }
@@ -711,13 +713,14 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
     ctx.times.lowhashHashSeconds = 0; ctx.times.lowhashHashLaunches = 0; ctx.times.lowhashHashBytes = 0;
-    for(auto& e : hashEvents) {
+    for(size_t k = 0; k < hashEvents.size(); k++) {
+        auto& e = hashEvents[k];
         float t = 0;
         HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
         ctx.times.lowhashHashSeconds += t * 1e-3;
         ctx.times.lowhashHashLaunches += 1;
         // Algorithmic bytes of one launch: 4 B per marker read + 12 B per low hash written.
-        ctx.times.lowhashHashBytes += 4 * (markerEnd - markerBegin);
+        ctx.times.lowhashHashBytes += 4 * (markerEnd - markerBegin) + 12 * hashRecords[k];
         (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
     }
     (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
