@@ -331,6 +331,227 @@ align4CellsKernel(
 }
 
 // ---------------------------------------------------------------------------
+// K8/K9, fast path: ONE WAVEFRONT per candidate, everything in LDS, no block barriers that
+// wait on other waves.  Used when the cell table (CW_CELL_SLOTS) and the kept-cell list
+// (CW_MAX_CELLS) suffice; candidates that overflow fall back to align4CellsKernel<true>.
+// Reachability and components run on neighbour indices resolved once per cell, so each
+// propagation sweep costs a handful of LDS reads per cell.
+// ---------------------------------------------------------------------------
+constexpr int CW_MATCH_CHUNK = 1024;
+constexpr int CW_MATCH_SLOTS = 2048;
+constexpr int CW_CELL_SLOTS = 2048;
+constexpr int CW_MAX_CELLS = 128;          // two cells per lane
+constexpr uint32_t FWD_NEIGHBOURS = (1u << 0) | (1u << 1) | (1u << 3) | (1u << 5) | (1u << 6);   // dX in {-1,0}
+constexpr uint32_t BWD_NEIGHBOURS = (1u << 1) | (1u << 2) | (1u << 4) | (1u << 6) | (1u << 7);   // dX in {0,+1}
+
+__global__ void __launch_bounds__(WAVE)
+align4CellsWaveKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const uint32_t* __restrict__ pairList, uint32_t listCount,
+    DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags)
+{
+    __shared__ uint64_t matchTab[CW_MATCH_SLOTS];
+    __shared__ uint32_t cellKeys[CW_CELL_SLOTS];
+    __shared__ uint32_t cellVals[CW_CELL_SLOTS];
+    __shared__ uint32_t cKey[CW_MAX_CELLS], cFlags[CW_MAX_CELLS], cLabel[CW_MAX_CELLS], cYMin[CW_MAX_CELLS], cYMax[CW_MAX_CELLS];
+    __shared__ uint8_t cNbr[CW_MAX_CELLS][8];
+
+    if(blockIdx.x >= listCount) return;
+    const uint32_t pair = pairList[blockIdx.x];
+    const int lane = int(threadIdx.x);
+    const PairDesc pd = pairs[pair];
+    const uint32_t nx = pd.nx, ny = pd.ny;
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+    int overflow = 0;
+
+    for(int k = lane; k < CW_CELL_SLOTS; k += WAVE) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
+
+    for(uint32_t chunk = 0; chunk < ny; chunk += CW_MATCH_CHUNK) {
+        __syncthreads();
+        for(int k = lane; k < CW_MATCH_SLOTS; k += WAVE) matchTab[k] = EMPTY64;
+        __syncthreads();
+        const uint32_t chunkEnd = min(ny, chunk + uint32_t(CW_MATCH_CHUNK));
+        for(uint32_t y = chunk + lane; y < chunkEnd; y += WAVE) {
+            const uint32_t k = p1[y];
+            const unsigned long long entry = (uint64_t(k) << 32) | y;
+            uint32_t slot = hash32(k) >> (32 - 11);
+            for(;;) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
+                if(old == EMPTY64) break;
+                slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
+            }
+        }
+        __syncthreads();
+        for(uint32_t x = lane; x < nx; x += WAVE) {
+            const uint32_t k = p0[x];
+            uint32_t slot = hash32(k) >> (32 - 11);
+            for(;;) {
+                const uint64_t e = matchTab[slot];
+                if(e == EMPTY64) break;
+                if(uint32_t(e >> 32) == k) {
+                    const uint32_t y = uint32_t(e);
+                    const uint32_t X = x + y, Y = nx + y - x - 1;
+                    const uint32_t iX = X / opt.deltaX, iY = Y / opt.deltaY;
+                    if(iX >= 65536u || iY >= 65535u) { overflow = 2; }
+                    else {
+                        const uint32_t key = (iY << 16) | iX;
+                        uint32_t cs = hash32(key) >> (32 - 11);
+                        int probe = 0;
+                        for(; probe < CW_CELL_SLOTS; probe++) {
+                            const uint32_t old = atomicCAS(&cellKeys[cs], EMPTY32, key);
+                            if(old == EMPTY32 || old == key) { atomicAdd(&cellVals[cs], 1u); break; }
+                            cs = (cs + 1) & (CW_CELL_SLOTS - 1);
+                        }
+                        if(probe == CW_CELL_SLOTS) overflow = 1;
+                    }
+                }
+                slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // Keep cells with enough entries; compact with a wave prefix (deterministic order).
+    int n = 0;
+    for(int k0 = 0; k0 < CW_CELL_SLOTS; k0 += WAVE) {
+        const int k = k0 + lane;
+        const uint32_t key = cellKeys[k];
+        const bool keep = (key != EMPTY32) && (uint64_t(cellVals[k]) >= opt.minEntryCountPerCell);
+        const uint64_t votes = __ballot(keep);
+        const int idx = n + __popcll(votes & laneMaskLt());
+        if(key != EMPTY32) {
+            if(keep && idx < CW_MAX_CELLS) { cKey[idx] = key; cellVals[k] = uint32_t(idx); }
+            else cellVals[k] = EMPTY32;
+        }
+        n += __popcll(votes);
+    }
+    if(n > CW_MAX_CELLS) overflow = max(overflow, 1);
+    const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
+    if(anyHard || anySoft) { if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
+    if(n == 0) return;
+    __syncthreads();
+
+    auto find = [&](int32_t iX, int32_t iY) -> int {
+        if(iX < 0 || iY < 0 || iX >= 65536 || iY >= 65535) return -1;
+        const uint32_t key = (uint32_t(iY) << 16) | uint32_t(iX);
+        uint32_t cs = hash32(key) >> (32 - 11);
+        for(int probe = 0; probe < CW_CELL_SLOTS; probe++) {
+            const uint32_t k = cellKeys[cs];
+            if(k == EMPTY32) return -1;
+            if(k == key) return int(cellVals[cs]);
+            cs = (cs + 1) & (CW_CELL_SLOTS - 1);
+        }
+        return -1;
+    };
+
+    // Per cell: boundary flags and the indices of its 8 neighbours.
+    for(int c = lane; c < n; c += WAVE) {
+        const uint32_t key = cKey[c];
+        const uint32_t iX = key & 0xffffu, iY = key >> 16;
+        int32_t x, y;
+        getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t left = x < 0 ? 0u : uint32_t(x);
+        getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
+        getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t top = y < 0 ? 0u : uint32_t(y);
+        getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
+        uint32_t f = 0;
+        if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) f |= F_NEAR_LT | F_FWD;
+        if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) f |= F_NEAR_RB;
+        cFlags[c] = f;
+        cYMin[c] = EMPTY32; cYMax[c] = 0;
+        int k = 0;
+        for(int dY = -1; dY <= 1; dY++) for(int dX = -1; dX <= 1; dX++) {
+            if(dX == 0 && dY == 0) continue;
+            const int j = find(int32_t(iX) + dX, int32_t(iY) + dY);
+            cNbr[c][k++] = uint8_t(j < 0 ? 255 : j);
+        }
+    }
+    __syncthreads();
+
+    // forwardSearch (:682-729).
+    for(;;) {
+        bool changed = false;
+        for(int c = lane; c < n; c += WAVE) {
+            if(cFlags[c] & F_FWD) continue;
+            for(int k = 0; k < 8; k++) {
+                if(!((FWD_NEIGHBOURS >> k) & 1u)) continue;
+                const uint32_t j = cNbr[c][k];
+                if(j != 255u && (cFlags[j] & F_FWD)) { cFlags[c] |= F_FWD; changed = true; break; }
+            }
+        }
+        __syncthreads();
+        if(!__any(changed)) break;
+    }
+    // backwardSearch (:736-787).
+    for(int c = lane; c < n; c += WAVE) {
+        const uint32_t f = cFlags[c];
+        if((f & F_NEAR_RB) && (f & F_FWD)) cFlags[c] = f | F_BWD;
+    }
+    __syncthreads();
+    for(;;) {
+        bool changed = false;
+        for(int c = lane; c < n; c += WAVE) {
+            if(cFlags[c] & F_BWD) continue;
+            for(int k = 0; k < 8; k++) {
+                if(!((BWD_NEIGHBOURS >> k) & 1u)) continue;
+                const uint32_t j = cNbr[c][k];
+                if(j != 255u && (cFlags[j] & F_BWD)) { cFlags[c] |= F_BWD; changed = true; break; }
+            }
+        }
+        __syncthreads();
+        if(!__any(changed)) break;
+    }
+    // Components of active cells (:792-868): min-key label propagation.
+    for(int c = lane; c < n; c += WAVE) {
+        const uint32_t f = cFlags[c];
+        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? cKey[c] : EMPTY32;
+    }
+    __syncthreads();
+    for(;;) {
+        bool changed = false;
+        for(int c = lane; c < n; c += WAVE) {
+            const uint32_t mine = cLabel[c];
+            if(mine == EMPTY32) continue;
+            uint32_t best = mine;
+            for(int k = 0; k < 8; k++) {
+                const uint32_t j = cNbr[c][k];
+                if(j != 255u) best = min(best, cLabel[j]);
+            }
+            if(best < mine) { cLabel[c] = best; changed = true; }
+        }
+        __syncthreads();
+        if(!__any(changed)) break;
+    }
+    for(int c = lane; c < n; c += WAVE) {
+        const uint32_t label = cLabel[c];
+        if(label == EMPTY32) continue;
+        const int r = find(int32_t(label & 0xffffu), int32_t(label >> 16));
+        const uint32_t iY = cKey[c] >> 16;
+        atomicMin(&cYMin[r], iY);
+        atomicMax(&cYMax[r], iY);
+    }
+    __syncthreads();
+    for(int c = lane; c < n; c += WAVE) {
+        const uint32_t key = cKey[c];
+        if(cLabel[c] != key) continue;
+        const uint32_t YMin = cYMin[c] * opt.deltaY;
+        const uint32_t YMax = (cYMax[c] + 1) * opt.deltaY - 1;
+        const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
+        const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
+        const int32_t bandWidth = bandMax - bandMin + 1;
+        if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;
+        if(bandWidth > 1024) { pairFlags[pair] = PAIR_TOO_LONG; continue; }
+        const uint32_t t = atomicAdd(taskCount, 1u);
+        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Task geometry shared by the sizing kernel and the DP kernel.
 // ---------------------------------------------------------------------------
 struct TaskGeometry { int32_t s0, sEnd; uint32_t rows, rowWords; int cls; };
@@ -360,6 +581,7 @@ sizeTasksKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ p
     unsigned long long* __restrict__ dpCells)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cells = 0;
     if(t < taskCount) {
         const DpTask task = tasks[t];
         const PairDesc pd = pairs[task.pair];
@@ -368,10 +590,12 @@ sizeTasksKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ p
         ordCap[t] = min(pd.nx, pd.ny);
         const uint32_t k = atomicAdd(&classCounts[g.cls], 1u);
         classLists[uint64_t(g.cls) * listStride + k] = t;
-        atomicAdd(dpCells, (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1));
+        cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
     } else if(t == taskCount) {
         traceWords[t] = 0; ordCap[t] = 0;
     }
+    for(int d = 32; d >= 1; d >>= 1) cells += __shfl_down(cells, d, WAVE);
+    if(laneId() == 0 && cells) atomicAdd(dpCells, cells);
 }
 
 // ---------------------------------------------------------------------------
@@ -896,10 +1120,9 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
             b.pairList.reserve(n, stream);
             if(!list.empty()) {
                 HIP_CHECK(hipMemcpyAsync(b.pairList.data(), list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
-                hipLaunchKernelGGL(align4CellsKernel<false>, dim3(unsigned(list.size())), dim3(CELLS_THREADS), 0, stream,
+                hipLaunchKernelGGL(align4CellsWaveKernel, dim3(unsigned(list.size())), dim3(WAVE), 0, stream,
                     (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), uint32_t(list.size()), opt,
-                    b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),
-                    (uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)nullptr);
+                    b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
