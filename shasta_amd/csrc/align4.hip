@@ -354,8 +354,7 @@ align4CellsWaveKernel(
     __shared__ uint64_t matchTab[CW_MATCH_SLOTS];
     __shared__ uint32_t cellKeys[CW_CELL_SLOTS];
     __shared__ uint32_t cellVals[CW_CELL_SLOTS];
-    __shared__ uint32_t cKey[CW_MAX_CELLS], cFlags[CW_MAX_CELLS], cLabel[CW_MAX_CELLS], cYMin[CW_MAX_CELLS], cYMax[CW_MAX_CELLS];
-    __shared__ uint8_t cNbr[CW_MAX_CELLS][8];
+    __shared__ uint32_t cKey[CW_MAX_CELLS], cFlags[CW_MAX_CELLS + 1], cLabel[CW_MAX_CELLS + 1], cYMin[CW_MAX_CELLS], cYMax[CW_MAX_CELLS];
 
     if(blockIdx.x >= listCount) return;
     const uint32_t pair = pairList[blockIdx.x];
@@ -373,19 +372,34 @@ align4CellsWaveKernel(
         for(int k = lane; k < CW_MATCH_SLOTS; k += WAVE) matchTab[k] = EMPTY64;
         __syncthreads();
         const uint32_t chunkEnd = min(ny, chunk + uint32_t(CW_MATCH_CHUNK));
-        for(uint32_t y = chunk + lane; y < chunkEnd; y += WAVE) {
-            const uint32_t k = p1[y];
-            const unsigned long long entry = (uint64_t(k) << 32) | y;
-            uint32_t slot = hash32(k) >> (32 - 11);
-            for(;;) {
-                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
-                if(old == EMPTY64) break;
-                slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
+        for(uint32_t y0 = chunk + lane; y0 < chunkEnd; y0 += 4 * WAVE) {
+            uint32_t kk[4];
+#pragma unroll
+            for(int u = 0; u < 4; u++) { const uint32_t y = y0 + u * WAVE; kk[u] = (y < chunkEnd) ? p1[y] : 0u; }
+#pragma unroll
+            for(int u = 0; u < 4; u++) {
+                const uint32_t y = y0 + u * WAVE;
+                if(y >= chunkEnd) continue;
+                const uint32_t k = kk[u];
+                const unsigned long long entry = (uint64_t(k) << 32) | y;
+                uint32_t slot = hash32(k) >> (32 - 11);
+                for(;;) {
+                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
+                    if(old == EMPTY64) break;
+                    slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
+                }
             }
         }
         __syncthreads();
-        for(uint32_t x = lane; x < nx; x += WAVE) {
-            const uint32_t k = p0[x];
+        for(uint32_t x0 = lane; x0 < nx; x0 += 4 * WAVE) {
+          uint32_t kk[4];
+#pragma unroll
+          for(int u = 0; u < 4; u++) { const uint32_t x = x0 + u * WAVE; kk[u] = (x < nx) ? p0[x] : 0u; }
+#pragma unroll
+          for(int u = 0; u < 4; u++) {
+            const uint32_t x = x0 + u * WAVE;
+            if(x >= nx) continue;
+            const uint32_t k = kk[u];
             uint32_t slot = hash32(k) >> (32 - 11);
             for(;;) {
                 const uint64_t e = matchTab[slot];
@@ -409,6 +423,7 @@ align4CellsWaveKernel(
                 }
                 slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
             }
+          }
         }
     }
     __syncthreads();
@@ -446,8 +461,15 @@ align4CellsWaveKernel(
         return -1;
     };
 
-    // Per cell: boundary flags and the indices of its 8 neighbours.
-    for(int c = lane; c < n; c += WAVE) {
+    // Per cell (two per lane: c = lane, lane+64): boundary flags and the indices of the 8
+    // neighbours, kept in registers; index CW_MAX_CELLS is a dummy cell (flags 0, label EMPTY).
+    uint32_t nbr[2][8];
+#pragma unroll
+    for(int q = 0; q < 2; q++) {
+        const int c = lane + q * WAVE;
+#pragma unroll
+        for(int k = 0; k < 8; k++) nbr[q][k] = CW_MAX_CELLS;
+        if(c >= n) continue;
         const uint32_t key = cKey[c];
         const uint32_t iX = key & 0xffffu, iY = key >> 16;
         int32_t x, y;
@@ -465,64 +487,68 @@ align4CellsWaveKernel(
         cFlags[c] = f;
         cYMin[c] = EMPTY32; cYMax[c] = 0;
         int k = 0;
-        for(int dY = -1; dY <= 1; dY++) for(int dX = -1; dX <= 1; dX++) {
-            if(dX == 0 && dY == 0) continue;
-            const int j = find(int32_t(iX) + dX, int32_t(iY) + dY);
-            cNbr[c][k++] = uint8_t(j < 0 ? 255 : j);
+#pragma unroll
+        for(int dY = -1; dY <= 1; dY++) {
+#pragma unroll
+            for(int dX = -1; dX <= 1; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(int32_t(iX) + dX, int32_t(iY) + dY);
+                nbr[q][k++] = uint32_t(j < 0 ? CW_MAX_CELLS : j);
+            }
         }
     }
+    if(lane == 0) { cFlags[CW_MAX_CELLS] = 0; cLabel[CW_MAX_CELLS] = EMPTY32; }
     __syncthreads();
 
-    // forwardSearch (:682-729).
+    // forwardSearch (:682-729): Jacobi sweeps; every sweep issues its LDS reads back to back.
     for(;;) {
         bool changed = false;
-        for(int c = lane; c < n; c += WAVE) {
-            if(cFlags[c] & F_FWD) continue;
-            for(int k = 0; k < 8; k++) {
-                if(!((FWD_NEIGHBOURS >> k) & 1u)) continue;
-                const uint32_t j = cNbr[c][k];
-                if(j != 255u && (cFlags[j] & F_FWD)) { cFlags[c] |= F_FWD; changed = true; break; }
-            }
+#pragma unroll
+        for(int q = 0; q < 2; q++) {
+            const int c = lane + q * WAVE;
+            const uint32_t reach = cFlags[nbr[q][0]] | cFlags[nbr[q][1]] | cFlags[nbr[q][3]] | cFlags[nbr[q][5]] | cFlags[nbr[q][6]];
+            if(c < n && !(cFlags[c] & F_FWD) && (reach & F_FWD)) { cFlags[c] |= F_FWD; changed = true; }
         }
         __syncthreads();
         if(!__any(changed)) break;
     }
     // backwardSearch (:736-787).
-    for(int c = lane; c < n; c += WAVE) {
-        const uint32_t f = cFlags[c];
-        if((f & F_NEAR_RB) && (f & F_FWD)) cFlags[c] = f | F_BWD;
+#pragma unroll
+    for(int q = 0; q < 2; q++) {
+        const int c = lane + q * WAVE;
+        if(c < n) { const uint32_t f = cFlags[c]; if((f & F_NEAR_RB) && (f & F_FWD)) cFlags[c] = f | F_BWD; }
     }
     __syncthreads();
     for(;;) {
         bool changed = false;
-        for(int c = lane; c < n; c += WAVE) {
-            if(cFlags[c] & F_BWD) continue;
-            for(int k = 0; k < 8; k++) {
-                if(!((BWD_NEIGHBOURS >> k) & 1u)) continue;
-                const uint32_t j = cNbr[c][k];
-                if(j != 255u && (cFlags[j] & F_BWD)) { cFlags[c] |= F_BWD; changed = true; break; }
-            }
+#pragma unroll
+        for(int q = 0; q < 2; q++) {
+            const int c = lane + q * WAVE;
+            const uint32_t reach = cFlags[nbr[q][1]] | cFlags[nbr[q][2]] | cFlags[nbr[q][4]] | cFlags[nbr[q][6]] | cFlags[nbr[q][7]];
+            if(c < n && !(cFlags[c] & F_BWD) && (reach & F_BWD)) { cFlags[c] |= F_BWD; changed = true; }
         }
         __syncthreads();
         if(!__any(changed)) break;
     }
     // Components of active cells (:792-868): min-key label propagation.
-    for(int c = lane; c < n; c += WAVE) {
-        const uint32_t f = cFlags[c];
-        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? cKey[c] : EMPTY32;
+#pragma unroll
+    for(int q = 0; q < 2; q++) {
+        const int c = lane + q * WAVE;
+        if(c < n) { const uint32_t f = cFlags[c]; cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? cKey[c] : EMPTY32; }
     }
     __syncthreads();
     for(;;) {
         bool changed = false;
-        for(int c = lane; c < n; c += WAVE) {
-            const uint32_t mine = cLabel[c];
-            if(mine == EMPTY32) continue;
-            uint32_t best = mine;
-            for(int k = 0; k < 8; k++) {
-                const uint32_t j = cNbr[c][k];
-                if(j != 255u) best = min(best, cLabel[j]);
+#pragma unroll
+        for(int q = 0; q < 2; q++) {
+            const int c = lane + q * WAVE;
+            uint32_t best = EMPTY32;
+#pragma unroll
+            for(int k = 0; k < 8; k++) best = min(best, cLabel[nbr[q][k]]);
+            if(c < n) {
+                const uint32_t mine = cLabel[c];
+                if(mine != EMPTY32 && best < mine) { cLabel[c] = best; changed = true; }
             }
-            if(best < mine) { cLabel[c] = best; changed = true; }
         }
         __syncthreads();
         if(!__any(changed)) break;
@@ -582,14 +608,28 @@ sizeTasksKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ p
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long cells = 0;
+    int cls = -1;
     if(t < taskCount) {
         const DpTask task = tasks[t];
         const PairDesc pd = pairs[task.pair];
         const TaskGeometry g = taskGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
         traceWords[t] = uint64_t(g.rows) * g.rowWords;
         ordCap[t] = min(pd.nx, pd.ny);
-        const uint32_t k = atomicAdd(&classCounts[g.cls], 1u);
-        classLists[uint64_t(g.cls) * listStride + k] = t;
+        cls = g.cls;
+    }
+    // Wave-aggregated append to the per-class task lists.
+#pragma unroll
+    for(int c5 = 0; c5 < 5; c5++) {
+        const uint64_t votes = __ballot(cls == c5);
+        if(!votes) continue;
+        uint32_t base = 0;
+        if(laneId() == __ffsll((unsigned long long)votes) - 1) base = atomicAdd(&classCounts[c5], uint32_t(__popcll(votes)));
+        base = __shfl(base, __ffsll((unsigned long long)votes) - 1, WAVE);
+        if(cls == c5) classLists[uint64_t(c5) * listStride + base + uint32_t(__popcll(votes & laneMaskLt()))] = t;
+    }
+    if(t < taskCount) {
+        const DpTask task = tasks[t];
+        const PairDesc pd = pairs[task.pair];
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
     } else if(t == taskCount) {
         traceWords[t] = 0; ordCap[t] = 0;
