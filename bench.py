@@ -53,7 +53,9 @@ def cpu_baseline(n_reads_sample, seed):
     """Reference CPU path on a bounded sample of the same workload (1/10 scale, same coverage)."""
     from oracle import bindings
     from shasta_amd import synthetic
-    cores = os.cpu_count() or 1
+    # Threads actually used = "cores" of the report.  Capped at 64: every reference Align4 thread
+    # zero-fills its own 2 GiB arena (src/AssemblerAlign.cpp:353-355) before its first candidate.
+    cores = min(os.cpu_count() or 1, 64)
     toc, kmer = make_workload(n_reads_sample, seed)
     data7 = synthetic.pack_markers(toc, kmer)
     p, o = lowhash_params(), align_options()
