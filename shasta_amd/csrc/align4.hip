@@ -341,6 +341,15 @@ constexpr int CW_MATCH_CHUNK = 1024;
 constexpr int CW_MATCH_SLOTS = 2048;
 constexpr int CW_CELL_SLOTS = 2048;
 constexpr int CW_MAX_CELLS = 128;          // two cells per lane
+#ifdef SHASTA_PROFILE_PHASES
+__device__ unsigned long long g_phaseCycles[16];
+#define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    if(threadIdx.x == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
+#define PHASE_BEGIN() unsigned long long phaseT_ = __builtin_readcyclecounter()
+#else
+#define PHASE_MARK(k) do {} while(0)
+#define PHASE_BEGIN() do {} while(0)
+#endif
 constexpr uint32_t FWD_NEIGHBOURS = (1u << 0) | (1u << 1) | (1u << 3) | (1u << 5) | (1u << 6);   // dX in {-1,0}
 constexpr uint32_t BWD_NEIGHBOURS = (1u << 1) | (1u << 2) | (1u << 4) | (1u << 6) | (1u << 7);   // dX in {0,+1}
 
@@ -364,13 +373,16 @@ align4CellsWaveKernel(
     const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
     const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
     int overflow = 0;
+    PHASE_BEGIN();
 
     for(int k = lane; k < CW_CELL_SLOTS; k += WAVE) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
+    PHASE_MARK(0);
 
     for(uint32_t chunk = 0; chunk < ny; chunk += CW_MATCH_CHUNK) {
         __syncthreads();
         for(int k = lane; k < CW_MATCH_SLOTS; k += WAVE) matchTab[k] = EMPTY64;
         __syncthreads();
+        PHASE_MARK(1);
         const uint32_t chunkEnd = min(ny, chunk + uint32_t(CW_MATCH_CHUNK));
         for(uint32_t y0 = chunk + lane; y0 < chunkEnd; y0 += 4 * WAVE) {
             uint32_t kk[4];
@@ -391,6 +403,7 @@ align4CellsWaveKernel(
             }
         }
         __syncthreads();
+        PHASE_MARK(2);
         for(uint32_t x0 = lane; x0 < nx; x0 += 4 * WAVE) {
           uint32_t kk[4];
 #pragma unroll
@@ -425,6 +438,7 @@ align4CellsWaveKernel(
             }
           }
         }
+        PHASE_MARK(3);
     }
     __syncthreads();
 
@@ -445,6 +459,7 @@ align4CellsWaveKernel(
     if(n > CW_MAX_CELLS) overflow = max(overflow, 1);
     const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
     if(anyHard || anySoft) { if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
+    PHASE_MARK(4);
     if(n == 0) return;
     __syncthreads();
 
@@ -500,6 +515,7 @@ align4CellsWaveKernel(
     if(lane == 0) { cFlags[CW_MAX_CELLS] = 0; cLabel[CW_MAX_CELLS] = EMPTY32; }
     __syncthreads();
 
+    PHASE_MARK(5);
     // forwardSearch (:682-729): Jacobi sweeps; every sweep issues its LDS reads back to back.
     for(;;) {
         bool changed = false;
@@ -530,6 +546,7 @@ align4CellsWaveKernel(
         __syncthreads();
         if(!__any(changed)) break;
     }
+    PHASE_MARK(6);
     // Components of active cells (:792-868): min-key label propagation.
 #pragma unroll
     for(int q = 0; q < 2; q++) {
@@ -553,6 +570,7 @@ align4CellsWaveKernel(
         __syncthreads();
         if(!__any(changed)) break;
     }
+    PHASE_MARK(7);
     for(int c = lane; c < n; c += WAVE) {
         const uint32_t label = cLabel[c];
         if(label == EMPTY32) continue;
@@ -575,6 +593,7 @@ align4CellsWaveKernel(
         const uint32_t t = atomicAdd(taskCount, 1u);
         if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
     }
+    PHASE_MARK(8);
 }
 
 // ---------------------------------------------------------------------------
@@ -1321,6 +1340,17 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     result.deviceSeconds = ms * 1e-3;
     (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
 
+#ifdef SHASTA_PROFILE_PHASES
+    {
+        unsigned long long h[16];
+        HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phaseCycles), sizeof(h)));
+        std::fprintf(stderr, "phase cycles (lane-0 sums, 100 MHz ticks):");
+        for(int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", h[k]);
+        std::fprintf(stderr, "\n");
+        std::memset(h, 0, sizeof(h));
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phaseCycles), h, sizeof(h)));
+    }
+#endif
     ctx.times.alignDpSeconds = dpSeconds;
     ctx.times.alignDpLaunches = dpLaunches;
     ctx.times.alignDpCells = dpCellsTotal;
