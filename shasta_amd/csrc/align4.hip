@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 namespace shasta_mi355x {
@@ -331,269 +332,447 @@ align4CellsKernel(
 }
 
 // ---------------------------------------------------------------------------
-// K8/K9, fast path: ONE WAVEFRONT per candidate, everything in LDS, no block barriers that
-// wait on other waves.  Used when the cell table (CW_CELL_SLOTS) and the kept-cell list
-// (CW_MAX_CELLS) suffice; candidates that overflow fall back to align4CellsKernel<true>.
-// Reachability and components run on neighbour indices resolved once per cell, so each
-// propagation sweep costs a handful of LDS reads per cell.
+// K8/K9, fast path.  A CHUNK is a set of candidates that share one oriented read: read 0
+// (candidates arrive sorted by readId0, src/LowHash0.cpp:204-214, and read 0 is always on
+// strand 0, src/AssemblerAlign.cpp:382) or, when read 1 is the shorter one, read 1 ("swapped",
+// gathered by the host).  One workgroup per chunk; its waves share the table of that read and
+// then work on different candidates of the chunk without ever synchronising again.
+//   build   read 0's kmer ids are copied to LDS and indexed by a two-choice bucketised LDS hash
+//           table (buckets of four 16-bit slots = one ds_read_b64; slot = hash tag | ordinal);
+//   probe   a candidate's other read is streamed through the table, four markers per lane per
+//           round: both buckets are read, the eight slots are tag-matched with SWAR compares,
+//           the kmer ids are compared in LDS: fixed trip count, no probe chains;
+//   count   (x,y) -> cell by magic-number division (getXY + createCells,
+//           src/Align4.cpp:171-177,380-436); consecutive lanes that hit the same cell are
+//           folded into one LDS atomic; the increment that reaches minEntryCountPerCell
+//           appends the cell to the kept list (:417);
+//   graph   the kept cells (Q per lane) live in registers; their forward/backward adjacency is
+//           a bit mask per cell, so forwardSearch / backwardSearch (:682-788) and the connected
+//           components (:792-868) are iterated ballots with no memory traffic;
+//   tasks   one DP task per component (:890-934), staged in LDS, appended with one global atomic.
+// Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
+// larger class, finally by align4CellsKernel<true>.
+// Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | per wave:
+//   cellKeys[SC] | cellCnt[SC] | kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
 // ---------------------------------------------------------------------------
-constexpr int CW_MATCH_CHUNK = 1024;
-constexpr int CW_MATCH_SLOTS = 2048;
-constexpr int CW_CELL_SLOTS = 2048;
-constexpr int CW_MAX_CELLS = 128;          // two cells per lane
+// firstMember indexes the member list (candidate indices of the batch).
+struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
+
 #ifdef SHASTA_PROFILE_PHASES
 __device__ unsigned long long g_phaseCycles[16];
 #define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
-    if(threadIdx.x == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
+    if((threadIdx.x & 63) == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
 #define PHASE_BEGIN() unsigned long long phaseT_ = __builtin_readcyclecounter()
 #else
 #define PHASE_MARK(k) do {} while(0)
 #define PHASE_BEGIN() do {} while(0)
 #endif
-constexpr uint32_t FWD_NEIGHBOURS = (1u << 0) | (1u << 1) | (1u << 3) | (1u << 5) | (1u << 6);   // dX in {-1,0}
-constexpr uint32_t BWD_NEIGHBOURS = (1u << 1) | (1u << 2) | (1u << 4) | (1u << 6) | (1u << 7);   // dX in {0,+1}
 
-__global__ void __launch_bounds__(WAVE)
-align4CellsWaveKernel(
+// floor(v / d) with magic = min(floor(2^32 / d), 2^32 - 1): the estimate is at most 2 low.
+__device__ __forceinline__ uint32_t divMagic(uint32_t v, uint32_t d, uint32_t magic)
+{
+    uint32_t q = __umulhi(v, magic);
+    uint32_t r = v - q * d;
+    if(r >= d) { ++q; r -= d; }
+    if(r >= d) { ++q; }
+    return q;
+}
+
+// LDS traffic of ONE wave is ordered by the hardware; this only stops the compiler from moving
+// LDS accesses across it and drains the counters.  Waves of a chunk never wait for each other
+// after the build, so no s_barrier may appear in the per-candidate code.
+__device__ __forceinline__ void waveLdsSync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t hash32b(uint32_t k) { return k * 0x85ebca6bu; }
+
+// Bits 15 and 31 of the result flag the 16-bit halves of v that are zero (exact, no carries).
+__device__ __forceinline__ uint32_t zeroHalves(uint32_t v)
+{
+    return ~(((v & 0x7fff7fffu) + 0x7fff7fffu) | v | 0x7fff7fffu);
+}
+
+constexpr int CELLS_UNROLL = 4;           // markers per lane per round
+constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
+__host__ __device__ inline size_t cellsWaveLdsWords(int scLog2, int Q)
+{
+    return 2 * (size_t(1) << scLog2) + 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
+}
+__host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
+{
+    return 2 * (size_t(1) << naLog2) + size_t(waves) * cellsWaveLdsWords(scLog2, Q);
+}
+
+template<int Q>
+__global__ void __launch_bounds__(256)
+align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
-    const uint32_t* __restrict__ pairList, uint32_t listCount,
-    DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
+    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
+    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
     uint8_t* __restrict__ pairFlags)
 {
-    __shared__ uint64_t matchTab[CW_MATCH_SLOTS];
-    __shared__ uint32_t cellKeys[CW_CELL_SLOTS];
-    __shared__ uint32_t cellVals[CW_CELL_SLOTS];
-    __shared__ uint32_t cKey[CW_MAX_CELLS], cFlags[CW_MAX_CELLS + 1], cLabel[CW_MAX_CELLS + 1], cYMin[CW_MAX_CELLS], cYMax[CW_MAX_CELLS];
-
-    if(blockIdx.x >= listCount) return;
-    const uint32_t pair = pairList[blockIdx.x];
-    const int lane = int(threadIdx.x);
-    const PairDesc pd = pairs[pair];
-    const uint32_t nx = pd.nx, ny = pd.ny;
-    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
-    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
-    int overflow = 0;
+    extern __shared__ uint32_t ldsWords[];
+    __shared__ uint32_t tableOverflow;
+    constexpr int MAXC = 64 * Q;
+    if(blockIdx.x >= chunkCount) return;
+    const CellsChunk chunk = chunks[blockIdx.x];
+    const int lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint32_t NA = 1u << chunk.naLog2, SC = 1u << chunk.scLog2;
+    const int bucketShift = 32 - (int(chunk.naLog2) - 1), scShift = 32 - int(chunk.scLog2);
+    const int xBits = int(chunk.naLog2);
+    const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
+    uint32_t* const aKmers = ldsWords;
+    uint32_t* const aSlots = aKmers + NA;
+    uint32_t* const cellKeys = aSlots + NA + wave * cellsWaveLdsWords(int(chunk.scLog2), Q);
+    uint32_t* const cellCnt = cellKeys + SC;
+    uint32_t* const kept = cellCnt + SC;
+    uint32_t* const scratch = kept + MAXC;                        // [0] kept count, [1] min, [2] max, [3] staged tasks
+    uint32_t* const stage = scratch + 8;
+    const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
     PHASE_BEGIN();
 
-    for(int k = lane; k < CW_CELL_SLOTS; k += WAVE) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
-    PHASE_MARK(0);
+    // Tag of a kmer id (never all ones, so that an empty slot matches no tag) and its two buckets.
+    auto tagOf = [&](uint32_t h) { const uint32_t t = (h >> 4) & tagMask; return t == tagMask ? 0u : t; };
 
-    for(uint32_t chunk = 0; chunk < ny; chunk += CW_MATCH_CHUNK) {
-        __syncthreads();
-        for(int k = lane; k < CW_MATCH_SLOTS; k += WAVE) matchTab[k] = EMPTY64;
-        __syncthreads();
-        PHASE_MARK(1);
-        const uint32_t chunkEnd = min(ny, chunk + uint32_t(CW_MATCH_CHUNK));
-        for(uint32_t y0 = chunk + lane; y0 < chunkEnd; y0 += 4 * WAVE) {
-            uint32_t kk[4];
-#pragma unroll
-            for(int u = 0; u < 4; u++) { const uint32_t y = y0 + u * WAVE; kk[u] = (y < chunkEnd) ? p1[y] : 0u; }
-#pragma unroll
-            for(int u = 0; u < 4; u++) {
-                const uint32_t y = y0 + u * WAVE;
-                if(y >= chunkEnd) continue;
-                const uint32_t k = kk[u];
-                const unsigned long long entry = (uint64_t(k) << 32) | y;
-                uint32_t slot = hash32(k) >> (32 - 11);
-                for(;;) {
-                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
-                    if(old == EMPTY64) break;
-                    slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
-                }
-            }
+    // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
+    //     candidates gathered by the host because they share a short read 1) read 1 ---
+    const PairDesc pdFirst = pairs[members[chunk.firstMember]];
+    const bool swapped = chunk.swapped != 0;
+    const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
+    const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
+    for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
+    if(threadIdx.x == 0) tableOverflow = 0;
+    if(lane == 0) scratch[3] = 0;
+    __syncthreads();
+    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
+        const uint32_t km = tabSeq[t];
+        aKmers[t] = km;
+        const uint32_t h = hash32(km);
+        const uint32_t b1 = h >> bucketShift, b2 = hash32b(km) >> bucketShift;
+        const uint32_t entry = (tagOf(h) << xBits) | t;
+        for(;;) {
+            // Free slots of the two candidate buckets; take the emptier bucket (ties: the first).
+            const uint32_t u0 = aSlots[2 * b1], u1 = aSlots[2 * b1 + 1], v0 = aSlots[2 * b2], v1 = aSlots[2 * b2 + 1];
+            const uint32_t fu0 = zeroHalves(~u0), fu1 = zeroHalves(~u1), fv0 = zeroHalves(~v0), fv1 = zeroHalves(~v1);
+            const int freeU = __popc(fu0) + __popc(fu1), freeV = __popc(fv0) + __popc(fv1);
+            if(freeU == 0 && freeV == 0) { tableOverflow = 1; break; }
+            const bool useV = freeV > freeU;
+            const uint32_t f0 = useV ? fv0 : fu0, f1 = useV ? fv1 : fu1;
+            const uint32_t w0 = useV ? v0 : u0, w1 = useV ? v1 : u1;
+            const uint32_t base = 2 * (useV ? b2 : b1);
+            const bool second = f0 == 0;
+            const uint32_t f = second ? f1 : f0, old = second ? w1 : w0;
+            const int shift = (f & 0x8000u) ? 0 : 16;
+            const uint32_t updated = (old & ~(0xffffu << shift)) | (entry << shift);
+            if(atomicCAS(&aSlots[base + (second ? 1 : 0)], old, updated) == old) break;
         }
-        __syncthreads();
-        PHASE_MARK(2);
-        for(uint32_t x0 = lane; x0 < nx; x0 += 4 * WAVE) {
-          uint32_t kk[4];
+    }
+    __syncthreads();
+    PHASE_MARK(0);
+    if(tableOverflow) {
+        // More than eight markers of the tabled read share both buckets (a tandem repeat): the
+        // whole chunk goes to the next class.
+        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = PAIR_RESOURCE;
+        return;
+    }
+
+    for(uint32_t c = wave; c < chunk.count; c += waves) {
+        const uint32_t pair = members[chunk.firstMember + c];
+        const PairDesc pd = pairs[pair];
+        const uint32_t nx = pd.nx, ny = pd.ny;
+        const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
+        const uint32_t streamCount = swapped ? nx : ny;
+        int overflow = 0;
+
+        for(uint32_t k = lane; k < SC; k += WAVE) { cellKeys[k] = EMPTY32; cellCnt[k] = 0; }
+        if(lane == 0) scratch[0] = 0;
+        waveLdsSync();
+        PHASE_MARK(1);
+
+        // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
+        // Counts the hits of one round: hit[u] with table ordinal ti[u] and stream ordinal t.
+        auto countHits = [&](const bool (&hit)[CELLS_UNROLL], const uint32_t (&ti)[CELLS_UNROLL], uint32_t s0) {
+            bool pending[CELLS_UNROLL];
+            uint32_t key[CELLS_UNROLL], cs[CELLS_UNROLL], len[CELLS_UNROLL], probes[CELLS_UNROLL];
 #pragma unroll
-          for(int u = 0; u < 4; u++) { const uint32_t x = x0 + u * WAVE; kk[u] = (x < nx) ? p0[x] : 0u; }
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                const uint32_t t = s0 + u * WAVE + lane;
+                const uint32_t x = swapped ? t : ti[u], y = swapped ? ti[u] : t;
+                const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
+                const uint32_t iX = divMagic(X, opt.deltaX, magicX), iY = divMagic(Y, opt.deltaY, magicY);
+                bool h = hit[u];
+                if(h && (iX >= 65536u || iY >= 65535u)) { overflow = 2; h = false; }
+                key[u] = h ? ((iY << 16) | iX) : EMPTY32;
+                // Fold runs of consecutive lanes with the same cell into their first lane.
+                const uint32_t prevKey = __shfl_up(key[u], 1, WAVE);
+                const bool head = h && (lane == 0 || prevKey != key[u]);
+                const uint64_t hits = __ballot(h), heads = __ballot(head);
+                const uint64_t stops = (heads | ~hits) >> 1 >> lane;           // bit k: lane + 1 + k ends the run
+                len[u] = stops ? uint32_t(__ffsll((unsigned long long)stops)) : uint32_t(WAVE - lane);
+                pending[u] = head;
+                cs[u] = hash32(key[u]) >> scShift;
+                probes[u] = 0;
+            }
+            while(__any(pending[0] | pending[1] | pending[2] | pending[3])) {
 #pragma unroll
-          for(int u = 0; u < 4; u++) {
-            const uint32_t x = x0 + u * WAVE;
-            if(x >= nx) continue;
-            const uint32_t k = kk[u];
-            uint32_t slot = hash32(k) >> (32 - 11);
-            for(;;) {
-                const uint64_t e = matchTab[slot];
-                if(e == EMPTY64) break;
-                if(uint32_t(e >> 32) == k) {
-                    const uint32_t y = uint32_t(e);
-                    const uint32_t X = x + y, Y = nx + y - x - 1;
-                    const uint32_t iX = X / opt.deltaX, iY = Y / opt.deltaY;
-                    if(iX >= 65536u || iY >= 65535u) { overflow = 2; }
-                    else {
-                        const uint32_t key = (iY << 16) | iX;
-                        uint32_t cs = hash32(key) >> (32 - 11);
-                        int probe = 0;
-                        for(; probe < CW_CELL_SLOTS; probe++) {
-                            const uint32_t old = atomicCAS(&cellKeys[cs], EMPTY32, key);
-                            if(old == EMPTY32 || old == key) { atomicAdd(&cellVals[cs], 1u); break; }
-                            cs = (cs + 1) & (CW_CELL_SLOTS - 1);
+                for(int u = 0; u < CELLS_UNROLL; u++) {
+                    if(pending[u]) {
+                        const uint32_t old = atomicCAS(&cellKeys[cs[u]], EMPTY32, key[u]);
+                        if(old == EMPTY32 || old == key[u]) {
+                            const uint32_t before = atomicAdd(&cellCnt[cs[u]], len[u]);
+                            if(before < threshold && before + len[u] >= threshold) {           // :417
+                                const uint32_t idx = atomicAdd(&scratch[0], 1u);
+                                if(idx < uint32_t(MAXC)) kept[idx] = key[u];
+                            }
+                            pending[u] = false;
+                        } else {
+                            cs[u] = (cs[u] + 1) & (SC - 1);
+                            if(++probes[u] == SC) { overflow = max(overflow, 1); pending[u] = false; }
                         }
-                        if(probe == CW_CELL_SLOTS) overflow = 1;
                     }
                 }
-                slot = (slot + 1) & (CW_MATCH_SLOTS - 1);
             }
-          }
+        };
+
+        uint32_t kmNext[CELLS_UNROLL];
+#pragma unroll
+        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        for(uint32_t s0 = 0; s0 < streamCount; s0 += CELLS_UNROLL * WAVE) {
+            uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], m[CELLS_UNROLL][4], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
+            bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                km[u] = kmNext[u];
+                const uint32_t tn = s0 + (CELLS_UNROLL + u) * WAVE + lane;
+                kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
+                valid[u] = s0 + u * WAVE + lane < streamCount;
+            }
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                const uint32_t h = hash32(km[u]);
+                const uint32_t b1 = h >> bucketShift, b2 = hash32b(km[u]) >> bucketShift;
+                w[u][0] = aSlots[2 * b1]; w[u][1] = aSlots[2 * b1 + 1];
+                w[u][2] = aSlots[2 * b2]; w[u][3] = aSlots[2 * b2 + 1];
+                const uint32_t pattern = (tagOf(h) << xBits) * 0x00010001u, fieldMask = (tagMask << xBits) * 0x00010001u;
+                const bool same = b1 == b2;
+#pragma unroll
+                for(int i = 0; i < 4; i++) m[u][i] = zeroHalves((w[u][i] ^ pattern) & fieldMask);
+                if(same) { m[u][2] = 0; m[u][3] = 0; }
+                if(!valid[u]) { m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; }
+            }
+            // Resolve the tag matches (usually one per marker) against the kmer ids in LDS.
+            for(;;) {
+                bool more = false;
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) {
+                    // First tag match of this marker (static register indexing only).
+                    const bool s0m = m[u][0] != 0, s1m = !s0m && m[u][1] != 0, s2m = !s0m && !s1m && m[u][2] != 0;
+                    const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
+                    const uint32_t ww = s0m ? w[u][0] : (s1m ? w[u][1] : (s2m ? w[u][2] : w[u][3]));
+                    const bool cand = mm != 0;
+                    const bool low = (mm & 0x8000u) != 0;
+                    ti[u] = (low ? ww : (ww >> 16)) & xMask;
+                    ka[u] = aKmers[cand ? ti[u] : 0u];
+                    const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
+                    if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
+                    hit[u] = cand;
+                    more |= (m[u][0] | m[u][1] | m[u][2] | m[u][3]) != 0;
+                }
+                bool anyHit = false;
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = hit[u] && ka[u] == km[u]; anyHit |= hit[u]; }
+                if(__any(anyHit)) countHits(hit, ti, s0);
+                if(!__any(more)) break;
+            }
+        }
+        waveLdsSync();
+        PHASE_MARK(2);
+
+        const int n = int(scratch[0]);
+        if(n > MAXC) overflow = max(overflow, 1);
+        const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
+        if(anyHard || anySoft) { if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : PAIR_RESOURCE; continue; }
+        if(n == 0) continue;
+        const int nq = (n + WAVE - 1) / WAVE;
+
+        // --- kept cells in registers: boundary flags (:424-429 with the corner rules of :530-626) ---
+        uint32_t key[Q], flags[Q];
+#pragma unroll
+        for(int q = 0; q < Q; q++) {
+            const int cc = lane + q * WAVE;
+            key[q] = EMPTY32; flags[q] = 0;
+            if(cc >= n) continue;
+            key[q] = kept[cc];
+            const uint32_t iX = key[q] & 0xffffu, iY = key[q] >> 16;
+            int32_t x, y;
+            getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+            const uint32_t left = x < 0 ? 0u : uint32_t(x);
+            getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
+            const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
+            getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
+            const uint32_t top = y < 0 ? 0u : uint32_t(y);
+            getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+            const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
+            if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) flags[q] |= F_NEAR_LT;
+            if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) flags[q] |= F_NEAR_RB;
+        }
+        // Adjacency masks.  before[q][r] bit j: cell 64 r + j lies at (iX-1 or iX, iY-1..iY+1) of
+        // this lane's cell q (a forward move leads from it to this cell); after: (iX or iX+1, ...).
+        uint64_t before[Q][Q], after[Q][Q];
+#pragma unroll
+        for(int q = 0; q < Q; q++)
+#pragma unroll
+            for(int r = 0; r < Q; r++) { before[q][r] = 0; after[q][r] = 0; }
+#pragma unroll
+        for(int r = 0; r < Q; r++) {
+            if(r >= nq) break;
+            const int jEnd = min(WAVE, n - r * WAVE);
+            for(int j = 0; j < jEnd; j++) {
+                const uint32_t other = __builtin_amdgcn_readlane(key[r], j);
+                const int32_t oX = int32_t(other & 0xffffu), oY = int32_t(other >> 16);
+                const uint64_t bit = 1ULL << j;
+#pragma unroll
+                for(int q = 0; q < Q; q++) {
+                    if(q >= nq) break;
+                    const int32_t dX = oX - int32_t(key[q] & 0xffffu), dY = oY - int32_t(key[q] >> 16);
+                    const bool near = key[q] != EMPTY32 && dY >= -1 && dY <= 1 && other != key[q];
+                    if(near && (dX == -1 || dX == 0)) before[q][r] |= bit;
+                    if(near && (dX == 0 || dX == 1)) after[q][r] |= bit;
+                }
+            }
         }
         PHASE_MARK(3);
-    }
-    __syncthreads();
 
-    // Keep cells with enough entries; compact with a wave prefix (deterministic order).
-    int n = 0;
-    for(int k0 = 0; k0 < CW_CELL_SLOTS; k0 += WAVE) {
-        const int k = k0 + lane;
-        const uint32_t key = cellKeys[k];
-        const bool keep = (key != EMPTY32) && (uint64_t(cellVals[k]) >= opt.minEntryCountPerCell);
-        const uint64_t votes = __ballot(keep);
-        const int idx = n + __popcll(votes & laneMaskLt());
-        if(key != EMPTY32) {
-            if(keep && idx < CW_MAX_CELLS) { cKey[idx] = key; cellVals[k] = uint32_t(idx); }
-            else cellVals[k] = EMPTY32;
-        }
-        n += __popcll(votes);
-    }
-    if(n > CW_MAX_CELLS) overflow = max(overflow, 1);
-    const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
-    if(anyHard || anySoft) { if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
-    PHASE_MARK(4);
-    if(n == 0) return;
-    __syncthreads();
-
-    auto find = [&](int32_t iX, int32_t iY) -> int {
-        if(iX < 0 || iY < 0 || iX >= 65536 || iY >= 65535) return -1;
-        const uint32_t key = (uint32_t(iY) << 16) | uint32_t(iX);
-        uint32_t cs = hash32(key) >> (32 - 11);
-        for(int probe = 0; probe < CW_CELL_SLOTS; probe++) {
-            const uint32_t k = cellKeys[cs];
-            if(k == EMPTY32) return -1;
-            if(k == key) return int(cellVals[cs]);
-            cs = (cs + 1) & (CW_CELL_SLOTS - 1);
-        }
-        return -1;
-    };
-
-    // Per cell (two per lane: c = lane, lane+64): boundary flags and the indices of the 8
-    // neighbours, kept in registers; index CW_MAX_CELLS is a dummy cell (flags 0, label EMPTY).
-    uint32_t nbr[2][8];
+        // forwardSearch (:682-729): seeds near left/top; closure under forward moves.
+        uint64_t fwd[Q], bwd[Q];
 #pragma unroll
-    for(int q = 0; q < 2; q++) {
-        const int c = lane + q * WAVE;
+        for(int q = 0; q < Q; q++) fwd[q] = __ballot((flags[q] & F_NEAR_LT) != 0);
+        for(;;) {
+            bool changed = false;
 #pragma unroll
-        for(int k = 0; k < 8; k++) nbr[q][k] = CW_MAX_CELLS;
-        if(c >= n) continue;
-        const uint32_t key = cKey[c];
-        const uint32_t iX = key & 0xffffu, iY = key >> 16;
-        int32_t x, y;
-        getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
-        const uint32_t left = x < 0 ? 0u : uint32_t(x);
-        getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
-        const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
-        getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
-        const uint32_t top = y < 0 ? 0u : uint32_t(y);
-        getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
-        const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
-        uint32_t f = 0;
-        if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) f |= F_NEAR_LT | F_FWD;
-        if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) f |= F_NEAR_RB;
-        cFlags[c] = f;
-        cYMin[c] = EMPTY32; cYMax[c] = 0;
-        int k = 0;
+            for(int q = 0; q < Q; q++) {
+                if(q >= nq) break;
+                uint64_t reach = 0;
 #pragma unroll
-        for(int dY = -1; dY <= 1; dY++) {
-#pragma unroll
-            for(int dX = -1; dX <= 1; dX++) {
-                if(dX == 0 && dY == 0) continue;
-                const int j = find(int32_t(iX) + dX, int32_t(iY) + dY);
-                nbr[q][k++] = uint32_t(j < 0 ? CW_MAX_CELLS : j);
+                for(int r = 0; r < Q; r++) reach |= before[q][r] & fwd[r];
+                const uint64_t grown = fwd[q] | __ballot(reach != 0);
+                changed |= grown != fwd[q];
+                fwd[q] = grown;
             }
+            if(!changed) break;
         }
-    }
-    if(lane == 0) { cFlags[CW_MAX_CELLS] = 0; cLabel[CW_MAX_CELLS] = EMPTY32; }
-    __syncthreads();
-
-    PHASE_MARK(5);
-    // forwardSearch (:682-729): Jacobi sweeps; every sweep issues its LDS reads back to back.
-    for(;;) {
-        bool changed = false;
+        // backwardSearch (:736-787): seeds near right/bottom AND forward accessible.
 #pragma unroll
-        for(int q = 0; q < 2; q++) {
-            const int c = lane + q * WAVE;
-            const uint32_t reach = cFlags[nbr[q][0]] | cFlags[nbr[q][1]] | cFlags[nbr[q][3]] | cFlags[nbr[q][5]] | cFlags[nbr[q][6]];
-            if(c < n && !(cFlags[c] & F_FWD) && (reach & F_FWD)) { cFlags[c] |= F_FWD; changed = true; }
+        for(int q = 0; q < Q; q++) bwd[q] = __ballot((flags[q] & F_NEAR_RB) != 0) & fwd[q];
+        for(;;) {
+            bool changed = false;
+#pragma unroll
+            for(int q = 0; q < Q; q++) {
+                if(q >= nq) break;
+                uint64_t reach = 0;
+#pragma unroll
+                for(int r = 0; r < Q; r++) reach |= after[q][r] & bwd[r];
+                const uint64_t grown = bwd[q] | __ballot(reach != 0);
+                changed |= grown != bwd[q];
+                bwd[q] = grown;
+            }
+            if(!changed) break;
         }
-        __syncthreads();
-        if(!__any(changed)) break;
-    }
-    // backwardSearch (:736-787).
+        PHASE_MARK(4);
+        // Connected components of the active cells, 8-neighbourhood (:792-868), one at a time,
+        // seeded at the remaining active cell with the smallest key; one banded alignment per
+        // component (:890-934).
+        uint64_t remaining[Q];
+        bool anyRemaining = false;
 #pragma unroll
-    for(int q = 0; q < 2; q++) {
-        const int c = lane + q * WAVE;
-        if(c < n) { const uint32_t f = cFlags[c]; if((f & F_NEAR_RB) && (f & F_FWD)) cFlags[c] = f | F_BWD; }
-    }
-    __syncthreads();
-    for(;;) {
-        bool changed = false;
+        for(int q = 0; q < Q; q++) { remaining[q] = fwd[q] & bwd[q]; anyRemaining |= remaining[q] != 0; }
+        while(anyRemaining) {
+            uint32_t myMin = EMPTY32;
 #pragma unroll
-        for(int q = 0; q < 2; q++) {
-            const int c = lane + q * WAVE;
-            const uint32_t reach = cFlags[nbr[q][1]] | cFlags[nbr[q][2]] | cFlags[nbr[q][4]] | cFlags[nbr[q][6]] | cFlags[nbr[q][7]];
-            if(c < n && !(cFlags[c] & F_BWD) && (reach & F_BWD)) { cFlags[c] |= F_BWD; changed = true; }
+            for(int q = 0; q < Q; q++) if((remaining[q] >> lane) & 1ULL) myMin = min(myMin, key[q]);
+            if(lane == 0) { scratch[1] = EMPTY32; }
+            waveLdsSync();
+            if(myMin != EMPTY32) atomicMin(&scratch[1], myMin);
+            waveLdsSync();
+            const uint32_t seedKey = scratch[1];
+            uint64_t comp[Q];
+#pragma unroll
+            for(int q = 0; q < Q; q++) comp[q] = __ballot(key[q] == seedKey);
+            for(;;) {
+                bool changed = false;
+#pragma unroll
+                for(int q = 0; q < Q; q++) {
+                    if(q >= nq) break;
+                    uint64_t reach = 0;
+#pragma unroll
+                    for(int r = 0; r < Q; r++) reach |= (before[q][r] | after[q][r]) & comp[r];
+                    const uint64_t grown = comp[q] | (__ballot(reach != 0) & remaining[q]);
+                    changed |= grown != comp[q];
+                    comp[q] = grown;
+                }
+                if(!changed) break;
+            }
+            // iY range of the component.
+            if(lane == 0) { scratch[1] = EMPTY32; scratch[2] = 0; }
+            waveLdsSync();
+#pragma unroll
+            for(int q = 0; q < Q; q++) {
+                if((comp[q] >> lane) & 1ULL) { atomicMin(&scratch[1], key[q] >> 16); atomicMax(&scratch[2], key[q] >> 16); }
+            }
+            waveLdsSync();
+            const uint32_t YMin = scratch[1] * opt.deltaY;
+            const uint32_t YMax = (scratch[2] + 1) * opt.deltaY - 1;
+            const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
+            const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
+            const int32_t bandWidth = bandMax - bandMin + 1;
+            if(int64_t(bandWidth) <= int64_t(opt.maxBand)) {                      // :929
+                if(bandWidth > 1024) { if(lane == 0) pairFlags[pair] = PAIR_TOO_LONG; }
+                else {
+                    uint32_t staged = scratch[3];
+                    if(staged == CELLS_STAGE) {
+                        // Staging area full: append it to the task list.
+                        uint32_t base = 0;
+                        if(lane == 0) base = atomicAdd(taskCount, staged);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        for(uint32_t k = lane; k < 4 * staged; k += WAVE) {
+                            const uint32_t t = base + k / 4;
+                            if(t < taskCapacity) reinterpret_cast<uint32_t*>(tasks)[4ULL * base + k] = stage[k];
+                        }
+                        waveLdsSync();
+                        staged = 0;
+                    }
+                    if(lane == 0) {
+                        stage[4 * staged] = pair; stage[4 * staged + 1] = uint32_t(bandMin);
+                        stage[4 * staged + 2] = uint32_t(bandMax); stage[4 * staged + 3] = seedKey;
+                        scratch[3] = staged + 1;
+                    }
+                    waveLdsSync();
+                }
+            }
+            anyRemaining = false;
+#pragma unroll
+            for(int q = 0; q < Q; q++) { remaining[q] &= ~comp[q]; anyRemaining |= remaining[q] != 0; }
         }
-        __syncthreads();
-        if(!__any(changed)) break;
+        PHASE_MARK(5);
+    }
+    // Append this wave's staged tasks.
+    waveLdsSync();
+    const uint32_t staged = scratch[3];
+    if(staged) {
+        uint32_t base = 0;
+        if(lane == 0) base = atomicAdd(taskCount, staged);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for(uint32_t k = lane; k < 4 * staged; k += WAVE) {
+            const uint32_t t = base + k / 4;
+            if(t < taskCapacity) reinterpret_cast<uint32_t*>(tasks)[4ULL * base + k] = stage[k];
+        }
     }
     PHASE_MARK(6);
-    // Components of active cells (:792-868): min-key label propagation.
-#pragma unroll
-    for(int q = 0; q < 2; q++) {
-        const int c = lane + q * WAVE;
-        if(c < n) { const uint32_t f = cFlags[c]; cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? cKey[c] : EMPTY32; }
-    }
-    __syncthreads();
-    for(;;) {
-        bool changed = false;
-#pragma unroll
-        for(int q = 0; q < 2; q++) {
-            const int c = lane + q * WAVE;
-            uint32_t best = EMPTY32;
-#pragma unroll
-            for(int k = 0; k < 8; k++) best = min(best, cLabel[nbr[q][k]]);
-            if(c < n) {
-                const uint32_t mine = cLabel[c];
-                if(mine != EMPTY32 && best < mine) { cLabel[c] = best; changed = true; }
-            }
-        }
-        __syncthreads();
-        if(!__any(changed)) break;
-    }
-    PHASE_MARK(7);
-    for(int c = lane; c < n; c += WAVE) {
-        const uint32_t label = cLabel[c];
-        if(label == EMPTY32) continue;
-        const int r = find(int32_t(label & 0xffffu), int32_t(label >> 16));
-        const uint32_t iY = cKey[c] >> 16;
-        atomicMin(&cYMin[r], iY);
-        atomicMax(&cYMax[r], iY);
-    }
-    __syncthreads();
-    for(int c = lane; c < n; c += WAVE) {
-        const uint32_t key = cKey[c];
-        if(cLabel[c] != key) continue;
-        const uint32_t YMin = cYMin[c] * opt.deltaY;
-        const uint32_t YMax = (cYMax[c] + 1) * opt.deltaY - 1;
-        const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
-        const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
-        const int32_t bandWidth = bandMax - bandMin + 1;
-        if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;
-        if(bandWidth > 1024) { pairFlags[pair] = PAIR_TOO_LONG; continue; }
-        const uint32_t t = atomicAdd(taskCount, 1u);
-        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
-    }
-    PHASE_MARK(8);
 }
 
 // ---------------------------------------------------------------------------
@@ -1082,8 +1261,44 @@ struct BatchScratch {
     DeviceBuffer<uint64_t> compressedToc;
     DeviceBuffer<uint8_t> bytes, bigLog2;
     DeviceBuffer<uint32_t> pairList, bigScratch;
+    DeviceBuffer<CellsChunk> chunks;
     DeviceBuffer<uint64_t> bigOffsets;
 };
+
+constexpr int CELLS_CLASSES = 3;
+constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {11, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
+constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {10, 11, 12};
+constexpr int CELLS_Q[CELLS_CLASSES] = {2, 4, 4};
+constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {4, 4, 1};   // waves of a chunk that share read 0's table
+constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 8};
+constexpr uint32_t CELLS_SHARE_MIN = 3;                        // smaller chunks run as one wave
+
+// kind 0: one-wave workgroups; kind 1: CELLS_SHARED_WAVES waves share the table.
+template<int Q>
+void launchCellsChunksQ(Context& ctx, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity)
+{
+    const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, waves) * sizeof(uint32_t);
+    static bool attributeSet = false;
+    if(!attributeSet) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attributeSet = true;
+    }
+    MI355X_ASSERT(bytes <= 160 * 1024 - 64);
+    hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ctx.stream,
+        (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
+        opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
+    HIP_CHECK(hipGetLastError());
+}
+
+void launchCellsChunks(Context& ctx, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity)
+{
+    if(count == 0) return;
+    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
+    else launchCellsChunksQ<4>(ctx, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
+}
 
 template<int C>
 void launchDp(Context& ctx, BatchScratch& b, int cls, uint32_t count, uint32_t listStride, const DeviceOptions& opt)
@@ -1160,10 +1375,11 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
 
-        // K8/K9.  Candidates whose cell table fits LDS go first; the others (and any that
-        // overflow) run with a table in HBM scratch, retried with 8x the slots on overflow.
+        // K8/K9.  Chunks of candidates sharing read 0 run in LDS (three table-size classes);
+        // whatever overflows its tables climbs one class, and finally runs with tables in HBM
+        // scratch (align4CellsKernel<true>, retried with 8x the slots on overflow).
         {
-            std::vector<uint32_t> list, bigList;
+            std::vector<uint32_t> bigList;
             std::vector<uint8_t> bigLog2, hostFlags(n);
             auto estimateLog2 = [&](uint32_t k) {
                 const uint64_t nx = hostPairs[k].nx, ny = hostPairs[k].ny;
@@ -1172,21 +1388,130 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
                 while((1ULL << l) < 2 * cells && l < 24) ++l;
                 return uint8_t(l);
             };
-            for(uint32_t k = 0; k < n; k++) {
-                if(uint64_t(hostPairs[k].nx) * hostPairs[k].ny > (1ULL << 24)) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
-                else list.push_back(k);
+            // Class of a candidate: table of the tabled read at load <= 1/2, cell table sized for the
+            // expected number of distinct cells (random background ~ nx*ny / alphabet, plus the
+            // diagonal) at load <= 3/4.  Overflow is detected on the device and climbs one class.
+            auto classFor = [&](uint64_t tabled, uint64_t nx, uint64_t ny) -> int {
+                if(nx >= 65535 || ny >= 65535) return CELLS_CLASSES;
+                const uint64_t cells = (nx * ny >> 13) + (nx + ny) / 32 + 32;
+                for(int c = 0; c < CELLS_CLASSES; c++) {
+                    if(tabled < (1ULL << CELLS_NA_LOG2[c]) && 4 * cells <= (3ULL << CELLS_SC_LOG2[c])) return c;
+                }
+                return CELLS_CLASSES;
+            };
+            std::vector<int> pairClass(n);
+            std::vector<CellsChunk> classChunks[CELLS_CLASSES][2];     // [class][0 = one wave, 1 = shared table]
+            std::vector<uint32_t> members;                             // candidate indices, chunk after chunk
+            members.reserve(n);
+            auto addChunk = [&](const uint32_t* list, uint32_t count, bool swapped, int c) {
+                CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = uint16_t(count); ch.swapped = swapped ? 1 : 0;
+                ch.naLog2 = uint32_t(CELLS_NA_LOG2[c]); ch.scLog2 = uint32_t(CELLS_SC_LOG2[c]);
+                members.insert(members.end(), list, list + count);
+                const int kind = (CELLS_SHARED_WAVES[c] > 1 && count >= CELLS_SHARE_MIN) ? 1 : 0;
+                classChunks[c][kind].push_back(ch);
+            };
+            // Every candidate tables whichever of its two reads lands in the smaller class (ties: read
+            // 0) and is grouped with the other candidates that table the same oriented read.
+            {
+                struct Keyed { uint64_t tabled; uint32_t pair; uint8_t cls, swapped; };
+                std::vector<Keyed> keyed;
+                keyed.reserve(n);
+                for(uint32_t q = 0; q < n; q++) {
+                    const PairDesc& pd = hostPairs[q];
+                    const int c0 = classFor(pd.nx, pd.nx, pd.ny);
+                    const int c1 = pd.ny < pd.nx ? classFor(pd.ny, pd.nx, pd.ny) : CELLS_CLASSES;
+                    const bool sw = c1 < c0;
+                    const int c = sw ? c1 : c0;
+                    pairClass[q] = c;
+                    if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); continue; }
+                    Keyed kd; kd.tabled = sw ? pd.begin1 : pd.begin0; kd.pair = q; kd.cls = uint8_t(c); kd.swapped = sw ? 1 : 0;
+                    keyed.push_back(kd);
+                }
+                std::sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) {
+                    if(a.swapped != b.swapped) return a.swapped < b.swapped;
+                    if(a.tabled != b.tabled) return a.tabled < b.tabled;
+                    if(a.cls != b.cls) return a.cls < b.cls;
+                    return a.pair < b.pair;
+                });
+                std::vector<uint32_t> list;
+                for(size_t k = 0; k < keyed.size(); ) {
+                    size_t e = k + 1;
+                    const int c = keyed[k].cls;
+                    while(e < keyed.size() && e - k < CELLS_CHUNK_MAX[c] && keyed[e].swapped == keyed[k].swapped &&
+                        keyed[e].tabled == keyed[k].tabled && keyed[e].cls == keyed[k].cls) ++e;
+                    list.clear();
+                    for(size_t q = k; q < e; q++) list.push_back(keyed[q].pair);
+                    addChunk(list.data(), uint32_t(list.size()), keyed[k].swapped != 0, c);
+                    k = e;
+                }
             }
-            b.pairList.reserve(n, stream);
-            if(!list.empty()) {
-                HIP_CHECK(hipMemcpyAsync(b.pairList.data(), list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
-                hipLaunchKernelGGL(align4CellsWaveKernel, dim3(unsigned(list.size())), dim3(WAVE), 0, stream,
-                    (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), uint32_t(list.size()), opt,
-                    b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
-                HIP_CHECK(hipGetLastError());
+            static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
+            if(debug) {
+                for(int c = 0; c < CELLS_CLASSES; c++) for(int kind = 0; kind < 2; kind++) {
+                    uint64_t pairsIn = 0, sw = 0;
+                    for(const CellsChunk& ch : classChunks[c][kind]) { pairsIn += ch.count; sw += ch.swapped; }
+                    std::fprintf(stderr, "cells: class %d kind %d: %zu chunks, %llu candidates, %llu swapped\n", c, kind,
+                        classChunks[c][kind].size(), (unsigned long long)pairsIn, (unsigned long long)sw);
+                }
+                std::fprintf(stderr, "cells: HBM-scratch list %zu\n", bigList.size());
+            }
+            const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX, 0xffffffffULL));
+            const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY, 0xffffffffULL));
+            b.pairList.reserve(2ULL * n + 16, stream);
+            size_t membersUploaded = 0;
+            for(int round = 0; round < CELLS_CLASSES; round++) {
+                bool any = false;
+                if(members.size() > membersUploaded) {
+                    MI355X_ASSERT(members.size() <= 2ULL * n + 16);
+                    HIP_CHECK(hipMemcpyAsync(b.pairList.data() + membersUploaded, members.data() + membersUploaded,
+                        (members.size() - membersUploaded) * 4, hipMemcpyHostToDevice, stream));
+                    membersUploaded = members.size();
+                }
+                for(int c = 0; c < CELLS_CLASSES; c++) {
+                    std::vector<CellsChunk>& single = classChunks[c][0];
+                    std::vector<CellsChunk>& shared = classChunks[c][1];
+                    if(single.empty() && shared.empty()) continue;
+                    any = true;
+                    b.chunks.reserve(single.size() + shared.size(), stream);
+                    if(!single.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data(), single.data(), single.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
+                    if(!shared.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data() + single.size(), shared.data(), shared.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
+                    launchCellsChunks(ctx, b, c, CELLS_SHARED_WAVES[c], b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity);
+                    launchCellsChunks(ctx, b, c, 1, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity);
+                    HIP_CHECK(hipStreamSynchronize(stream));      // the lists are reused below
+                    single.clear(); shared.clear();
+                }
+                if(!any) break;
+                // Candidates that overflowed their tables climb one class.
                 HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
-                for(uint32_t k : list) if(hostFlags[k] == PAIR_RESOURCE) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
+                bool retry = false;
+                for(uint32_t k = 0; k < n; k++) {
+                    if(hostFlags[k] != PAIR_RESOURCE) continue;
+                    retry = true;
+                    hostFlags[k] = 0;
+                    // Retry alone in the next class whose table holds one of the two reads
+                    // (read 0 if both fit).
+                    int c = pairClass[k] + 1;
+                    bool sw = false;
+                    for(; c < CELLS_CLASSES; c++) {
+                        const uint64_t cap = 1ULL << CELLS_NA_LOG2[c];
+                        if(hostPairs[k].nx < cap) { sw = false; break; }
+                        if(hostPairs[k].ny < cap) { sw = true; break; }
+                    }
+                    pairClass[k] = c;
+                    if(c >= CELLS_CLASSES) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
+                    else addChunk(&k, 1, sw, c);
+                }
+                if(!retry) break;
+                if(debug) {
+                    for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: round %d retries -> class %d: %zu\n", round, c, classChunks[c][0].size());
+                    std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu\n", round, bigList.size());
+                }
+                HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
             }
+            HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            b.pairList.reserve(n, stream);
             const uint64_t scratchWordCap = 1ULL << 31;             // 8 GiB of HBM scratch per launch
             while(!bigList.empty()) {
                 // Clear the flags of the candidates about to be retried.
@@ -1344,7 +1669,7 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     {
         unsigned long long h[16];
         HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phaseCycles), sizeof(h)));
-        std::fprintf(stderr, "phase cycles (lane-0 sums, 100 MHz ticks):");
+        std::fprintf(stderr, "phase cycles (lane-0 sums):");
         for(int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", h[k]);
         std::fprintf(stderr, "\n");
         std::memset(h, 0, sizeof(h));
