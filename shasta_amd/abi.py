@@ -170,6 +170,31 @@ def copy_array(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+def view_array(ptr, n, dtype, owner):
+    """Zero-copy numpy view of n items behind a ctypes pointer; `owner` keeps the C buffers alive."""
+    dtype = np.dtype(dtype)
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = C.cast(ptr, C.POINTER(C.c_uint8 * (n * dtype.itemsize))).contents
+    a = np.frombuffer(buf, dtype=dtype, count=n)
+    a.flags.writeable = False
+    owner._views.append(a)
+    return a
+
+
+class _ResultOwner:
+    """Owns a C result struct; the library's free function runs when the last view is gone."""
+
+    def __init__(self, res, free):
+        self.res, self.free, self._views = res, free, []
+
+    def __del__(self):
+        try:
+            self.free(C.byref(self.res))
+        except Exception:
+            pass
+
+
 class LowHash0Output:
     """Python-side copy of shasta_lowhash0_result + the statistics table."""
 
@@ -189,16 +214,23 @@ class LowHash0Output:
 
 
 class Align4Output:
-    def __init__(self, res, candidate_count, want_ordinals):
+    def __init__(self, res, candidate_count, want_ordinals, free=None):
+        """With `free` (the library's *_free function) the arrays are zero-copy views of the C
+        buffers, released when this object goes away; without it they are copies."""
+        if free is not None:
+            self._owner = _ResultOwner(res, free)
+            get = lambda ptr, n, dtype: view_array(ptr, n, dtype, self._owner)
+        else:
+            get = copy_array
         n = int(res.alignmentCount)
-        self.alignment_data = copy_array(res.alignmentData, n, ALIGNMENT_DATA_DTYPE)
-        self.compressed_toc = copy_array(res.compressedToc, n + 1, "<u8")
+        self.alignment_data = get(res.alignmentData, n, ALIGNMENT_DATA_DTYPE)
+        self.compressed_toc = get(res.compressedToc, n + 1, "<u8")
         nbytes = int(self.compressed_toc[-1]) if n + 1 > 0 and len(self.compressed_toc) else 0
-        self.compressed_data = copy_array(res.compressedData, nbytes, "u1")
-        self.status = copy_array(res.status, candidate_count, "u1")
+        self.compressed_data = get(res.compressedData, nbytes, "u1")
+        self.status = get(res.status, candidate_count, "u1")
         if want_ordinals and res.ordinalsToc:
-            self.ordinals_toc = copy_array(res.ordinalsToc, candidate_count + 1, "<u8")
-            self.ordinals = copy_array(res.ordinals, 2 * int(self.ordinals_toc[-1]), "<u4").reshape(-1, 2)
+            self.ordinals_toc = get(res.ordinalsToc, candidate_count + 1, "<u8")
+            self.ordinals = get(res.ordinals, 2 * int(self.ordinals_toc[-1]), "<u4").reshape(-1, 2)
         else:
             self.ordinals_toc = None
             self.ordinals = None

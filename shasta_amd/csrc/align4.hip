@@ -23,9 +23,12 @@
 #include "context.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <thread>
 
 namespace shasta_mi355x {
 namespace {
@@ -776,243 +779,265 @@ align4CellsChunkKernel(
 }
 
 // ---------------------------------------------------------------------------
-// Task geometry shared by the sizing kernel and the DP kernel.
+// K10: banded overlap DP (computeBandedAlignment, src/Align4.cpp:993-1088; the SeqAn call it
+// wraps is restated -- tie policy as in oracle/banded_dp.hpp).
+//
+// DP cell (i,j) (i symbols of read 0, j of read 1 consumed) lives on diagonal d = i-j =
+// bandMin + b and anti-diagonal s = i+j.  On step s only diagonals with (s+d) even hold a cell;
+// its three predecessors are the same diagonal at s-2 (diagonal move), diagonal b-1 at s-1
+// (horizontal, from (i-1,j)) and diagonal b+1 at s-1 (vertical, from (i,j-1)).
+//
+//   forward   bandedDpForwardKernel<G,C>: a task occupies G lanes, each lane owns C adjacent
+//             diagonals in registers; narrow bands are packed 64/G tasks to a wavefront (tasks
+//             are sorted by class and length first, so bundled tasks have the same trip count).
+//             One loop iteration advances two anti-diagonals (all C cells of a lane); the only
+//             cross-lane traffic is one shuffle up and one down.  The kmer ids a lane compares
+//             slide through register windows fed by one prefetched load per read and iteration.
+//             Trace: 2 bits per cell, one __ballot per bit plane, 2C 64-bit words per iteration.
+//   end cell  free end gaps: the best border cell = max over the final value of each diagonal,
+//             ties to the smallest (i, j) -- a G-lane reduction after the loop.
+//   trace     dpTracebackKernel: ONE LANE per task walks its path through the packed trace
+//             (64 tasks per wavefront in flight), writes the aligned ordinals and accumulates
+//             AlignmentInfo's metrics (src/Alignment.cpp:67-113, :4-31).
+// Trace codes: 0 diagonal+equal kmers, 1 diagonal+different, 2 vertical, 3 horizontal.  Tie
+// policy: diagonal >= vertical >= horizontal.
 // ---------------------------------------------------------------------------
-struct TaskGeometry { int32_t s0, sEnd; uint32_t rows, rowWords; int cls; };
+constexpr int DP_CLASSES = 6;
+__host__ __device__ inline int dpClassOfWidth(int32_t w) { return w <= 32 ? 0 : (w <= 64 ? 1 : (w <= 128 ? 2 : (w <= 256 ? 3 : (w <= 512 ? 4 : 5)))); }
+__host__ __device__ inline int dpLanes(int cls) { return cls == 0 ? 16 : (cls == 1 ? 32 : 64); }          // G
+__host__ __device__ inline int dpDiagonals(int cls) { return cls <= 2 ? 2 : (1 << (cls - 1)); }             // C = 2,2,2,4,8,16
 
-__host__ __device__ inline int classOfWidth(int32_t w) { return w <= 64 ? 0 : (w <= 128 ? 1 : (w <= 256 ? 2 : (w <= 512 ? 3 : 4))); }
-__host__ __device__ inline int lanesDiagonals(int cls) { return cls == 0 ? 1 : (1 << cls); }   // C = 1,2,4,8,16
-
-__host__ __device__ inline TaskGeometry taskGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
+struct DpGeometry { int32_t s0; uint32_t iters; int cls; };
+__host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
 {
-    TaskGeometry g;
-    const int32_t w = bandMax - bandMin + 1;
-    g.cls = classOfWidth(w);
-    const int C = lanesDiagonals(g.cls);
+    DpGeometry g;
+    g.cls = dpClassOfWidth(bandMax - bandMin + 1);
     const int32_t sMin = bandMin > 0 ? bandMin : (bandMax < 0 ? -bandMax : 0);
     g.s0 = sMin - ((sMin + bandMin) & 1);          // (s0 + bandMin) is even
-    g.sEnd = int32_t(nx + ny);
-    const uint32_t steps = uint32_t(g.sEnd - g.s0 + 2);
-    if(C == 1) { g.rows = (steps + 1) / 2; g.rowWords = 2; }
-    else { g.rows = steps; g.rowWords = uint32_t(C); }
+    g.iters = uint32_t((int32_t(nx + ny) - g.s0) / 2 + 1);
     return g;
 }
 
+// What the forward kernel leaves for the traceback of a task.
+struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase; };
+
+// Per task: sort key (class, iterations), ordinal capacity, statistics.
 __global__ void __launch_bounds__(256)
-sizeTasksKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
-    uint64_t* __restrict__ traceWords, uint64_t* __restrict__ ordCap,
-    uint32_t* __restrict__ classLists, uint32_t* __restrict__ classCounts, uint32_t listStride,
-    unsigned long long* __restrict__ dpCells)
+dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
+    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long cells = 0;
+    unsigned long long cells = 0, words = 0;
     int cls = -1;
     if(t < taskCount) {
         const DpTask task = tasks[t];
         const PairDesc pd = pairs[task.pair];
-        const TaskGeometry g = taskGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-        traceWords[t] = uint64_t(g.rows) * g.rowWords;
-        ordCap[t] = min(pd.nx, pd.ny);
+        const DpGeometry g = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
         cls = g.cls;
-    }
-    // Wave-aggregated append to the per-class task lists.
-#pragma unroll
-    for(int c5 = 0; c5 < 5; c5++) {
-        const uint64_t votes = __ballot(cls == c5);
-        if(!votes) continue;
-        uint32_t base = 0;
-        if(laneId() == __ffsll((unsigned long long)votes) - 1) base = atomicAdd(&classCounts[c5], uint32_t(__popcll(votes)));
-        base = __shfl(base, __ffsll((unsigned long long)votes) - 1, WAVE);
-        if(cls == c5) classLists[uint64_t(c5) * listStride + base + uint32_t(__popcll(votes & laneMaskLt()))] = t;
-    }
-    if(t < taskCount) {
-        const DpTask task = tasks[t];
-        const PairDesc pd = pairs[task.pair];
+        keys[t] = (uint32_t(g.cls) << 24) | min(g.iters, 0xffffffu);
+        ids[t] = t;
+        ordCap[t] = min(pd.nx, pd.ny);
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
+        words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls));
     } else if(t == taskCount) {
-        traceWords[t] = 0; ordCap[t] = 0;
+        ordCap[t] = 0;
     }
-    for(int d = 32; d >= 1; d >>= 1) cells += __shfl_down(cells, d, WAVE);
-    if(laneId() == 0 && cells) atomicAdd(dpCells, cells);
+#pragma unroll
+    for(int c = 0; c < DP_CLASSES; c++) {
+        const uint64_t votes = __ballot(cls == c);
+        if(votes && laneId() == __ffsll((unsigned long long)votes) - 1) atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
+    }
+    for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
+    if(laneId() == 0 && cells) { atomicAdd(&sums[0], cells); atomicAdd(&sums[1], words); }
 }
 
-// ---------------------------------------------------------------------------
-// K10: banded overlap DP + traceback, one wavefront per task.
-//
-// DP cell (i,j) (i symbols of read 0, j of read 1 consumed) lives on diagonal
-// d = i-j = bandMin + b and anti-diagonal s = i+j.  Lane l owns diagonals
-// b = l*C .. l*C+C-1 and keeps H[c] = the latest value on each.  On step s only
-// diagonals with (s+d) even hold a cell; its three predecessors are H[c] itself
-// (s-2, diagonal), H of b-1 (s-1, horizontal) and H of b+1 (s-1, vertical).
-// Trace codes (2 bits): 0 diagonal+equal kmers, 1 diagonal+different, 2 vertical,
-// 3 horizontal.  Tie policy: diagonal >= vertical >= horizontal; end cell = first
-// maximum in (i, then j) order over last row / last column (oracle/banded_dp.hpp).
-// ---------------------------------------------------------------------------
-struct CellContext {
-    const uint32_t* p0; const uint32_t* p1;
-    int32_t nx, ny, bandMin, width;
-};
+// Trace words of each bundle (64/G consecutive tasks of the sorted list of one class).
+struct DpClassLayout { uint32_t taskStart[DP_CLASSES + 1]; uint32_t bundleStart[DP_CLASSES + 1]; };
 
-__device__ __forceinline__ uint32_t dpCell(
-    const CellContext& cc, int32_t b, int32_t s, bool enabled, int32_t left, int32_t right, int32_t& h,
-    int32_t& bestScore, int32_t& bestI, int32_t& bestJ)
-{
-    const int32_t d = cc.bandMin + b;
-    const int32_t sd = s + d;
-    const int32_t i = sd >> 1;
-    const int32_t j = i - d;
-    const bool valid = enabled && (b < cc.width) && (sd >= 0) && (j >= 0) && (i <= cc.nx) && (j <= cc.ny);
-    uint32_t dir = 0;
-    if(valid) {
-        int32_t v;
-        if(i == 0 || j == 0) {
-            v = 0;                                                  // free leading gaps
-        } else {
-            const bool eq = cc.p0[i - 1] == cc.p1[j - 1];
-            v = h + (eq ? MATCH_SCORE : MISMATCH_SCORE);
-            dir = eq ? 0u : 1u;
-            const int32_t vert = right + GAP_SCORE;                 // from (i, j-1): diagonal b+1
-            const int32_t hori = left + GAP_SCORE;                  // from (i-1, j): diagonal b-1
-            if(vert > v) { v = vert; dir = 2u; }
-            if(hori > v) { v = hori; dir = 3u; }
-        }
-        h = v;
-        if(i == cc.nx || j == cc.ny) {                              // free trailing gaps
-            if(v > bestScore || (v == bestScore && (i < bestI || (i == bestI && j < bestJ)))) {
-                bestScore = v; bestI = i; bestJ = j;
-            }
-        }
-    }
-    return dir;
-}
-
-template<int C>
 __global__ void __launch_bounds__(256)
-bandedDpKernel(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
-    const DpTask* __restrict__ tasks, const uint32_t* __restrict__ taskList, uint32_t listCount,
-    const uint64_t* __restrict__ traceOffsets, const uint64_t* __restrict__ ordOffsets,
-    uint64_t* __restrict__ trace, uint32_t* __restrict__ ordScratch,
-    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, uint64_t* __restrict__ bundleWords)
 {
-    constexpr int RW = (C == 1) ? 2 : C;                 // 64-bit words per trace row
-    __shared__ uint64_t window[4][64 * RW];
+    const uint32_t bundle = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = layout.bundleStart[DP_CLASSES];
+    if(bundle > total) return;
+    if(bundle == total) { bundleWords[bundle] = 0; return; }
+    int cls = 0;
+    while(bundle >= layout.bundleStart[cls + 1]) ++cls;
+    const uint32_t T = 64u / uint32_t(dpLanes(cls));
+    const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
+    const uint32_t last = min(first + T, layout.taskStart[cls + 1]) - 1;
+    bundleWords[bundle] = uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls));   // sorted ascending
+}
+
+template<int G, int C>
+__global__ void __launch_bounds__(256)
+bandedDpForwardKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
+    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,            // this class's segment of the sorted list
+    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,      // this class's segment
+    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
+{
+    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C;
     const int lane = laneId();
-    const int wave = int(threadIdx.x) >> 6;
-    const uint32_t idx = blockIdx.x * 4 + wave;
-    if(idx >= listCount) return;                         // whole wave leaves; no block barriers below
-    const uint32_t t = taskList[idx];
+    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(bundle >= bundleCount) return;                     // whole wave leaves; no block barriers below
+    const int g = lane / G, l = lane % G;
+    const uint32_t pos = bundle * T + uint32_t(g);
+    const bool hasTask = pos < taskCount;
+    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
     const DpTask task = tasks[t];
     const PairDesc pd = pairs[task.pair];
-    CellContext cc;
-    cc.p0 = kmerIds + pd.begin0; cc.p1 = kmerIds + pd.begin1;
-    cc.nx = int32_t(pd.nx); cc.ny = int32_t(pd.ny);
-    cc.bandMin = task.bandMin; cc.width = task.bandMax - task.bandMin + 1;
-    const TaskGeometry g = taskGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    uint64_t* __restrict__ tr = trace + traceOffsets[t];
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
+    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    uint32_t iters = geo.iters;
+#pragma unroll
+    for(int d = G; d < WAVE; d <<= 1) iters = max(iters, uint32_t(__shfl_xor(int(iters), d, WAVE)));
+    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
 
+    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
+    int32_t lo[C];
+    uint32_t span[C];
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t b = l * C + c, d = bandMin + b;
+        const int32_t first = d < 0 ? -d : d;
+        const int32_t last = min(2 * nx - d, 2 * ny + d);
+        const bool exists = hasTask && b < width && d <= nx && d >= -ny && last >= first;
+        lo[c] = exists ? first : 0x40000000;
+        span[c] = exists ? uint32_t(last - first) : 0u;
+    }
     int32_t H[C];
 #pragma unroll
     for(int c = 0; c < C; c++) H[c] = NEG_SCORE;
+
+    // Register windows of the kmer ids: aw[k] = A[ib + l HC - 1 + k], bw[h] = B[jb - l HC - 1 - h],
+    // ib = (s + bandMin) / 2, jb = ib - bandMin.  Indices are clamped; clamped values belong to
+    // cells that are not in the matrix.
+    int32_t ib = (geo.s0 + bandMin) / 2;
+    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
+    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
+    uint32_t aw[HC + 1], bw[HC];
+#pragma unroll
+    for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
+#pragma unroll
+    for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
+    uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
+    uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
+
+    auto cell = [&](int c, int32_t s, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
+        const bool eq = a == bk;
+        const int32_t dg = hd + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+        const int32_t vg = hv + GAP_SCORE;                          // from (i, j-1): diagonal b+1
+        const int32_t hg = hh + GAP_SCORE;                          // from (i-1, j): diagonal b-1
+        const bool isV = vg > dg;
+        const int32_t m1 = max(dg, vg);
+        const bool isH = hg > m1;
+        int32_t v = max(m1, hg);
+        const bool valid = uint32_t(s - lo[c]) <= span[c];
+        v = (s == lo[c]) ? 0 : v;                                   // i == 0 or j == 0: free leading gaps
+        H[c] = valid ? v : H[c];
+        loPlane = __ballot(isH || (!isV && !eq));
+        hiPlane = __ballot(isV || isH);
+    };
+
+    int32_t s = geo.s0;
+    for(uint32_t it = 0; it < iters; it++, s += 2) {
+        uint64_t words[RW];
+        {   // anti-diagonal s: even c hold cells
+            int32_t left = __shfl_up(H[C - 1], 1, G); if(l == 0) left = NEG_SCORE;
+#pragma unroll
+            for(int c = 0; c < C; c += 2) {
+                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
+                cell(c, s, aw[c / 2], bw[c / 2], H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
+            }
+        }
+        {   // anti-diagonal s+1: odd c hold cells
+            int32_t right = __shfl_down(H[0], 1, G); if(l == G - 1) right = NEG_SCORE;
+#pragma unroll
+            for(int c = 1; c < C; c += 2) {
+                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
+                cell(c, s + 1, aw[c / 2 + 1], bw[c / 2], H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
+            }
+        }
+        // Lane k stores word k of this iteration's trace record.
+        uint64_t mine = words[0];
+#pragma unroll
+        for(int k = 1; k < RW; k++) mine = (lane == k) ? words[k] : mine;
+        if(lane < RW) tr[uint64_t(it) * RW + lane] = mine;
+        // Slide the windows.
+#pragma unroll
+        for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
+        aw[HC] = aNext1; aNext1 = aNext2;
+#pragma unroll
+        for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
+        bw[0] = bNext1; bNext1 = bNext2;
+        ++ib;
+        aNext2 = loadA(ib + 1 + l * HC + HC);
+        bNext2 = loadB(ib + 1 - bandMin - l * HC);
+    }
+
+    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
     int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
-
-    if(C == 1) {
-        const bool evenLane = (lane & 1) == 0;
-        for(int32_t s = g.s0; s <= g.sEnd; s += 2) {
-            int32_t left = __shfl_up(H[0], 1, WAVE);   if(lane == 0) left = NEG_SCORE;
-            int32_t right = __shfl_down(H[0], 1, WAVE); if(lane == 63) right = NEG_SCORE;
-            uint32_t dir = dpCell(cc, lane, s, evenLane, left, right, H[0], bestScore, bestI, bestJ);
-            left = __shfl_up(H[0], 1, WAVE);   if(lane == 0) left = NEG_SCORE;
-            right = __shfl_down(H[0], 1, WAVE); if(lane == 63) right = NEG_SCORE;
-            const uint32_t dirB = dpCell(cc, lane, s + 1, !evenLane, left, right, H[0], bestScore, bestI, bestJ);
-            if(!evenLane) dir = dirB;
-            const uint64_t lo = __ballot(dir & 1u), hi = __ballot(dir & 2u);
-            if(lane == 0) {
-                const uint64_t row = uint64_t(s - g.s0) >> 1;
-                tr[row * 2] = lo; tr[row * 2 + 1] = hi;
-            }
-        }
-    } else {
-        for(int32_t s = g.s0; s <= g.sEnd; s += 2) {
-            {   // (s + bandMin) even: even c hold cells
-                int32_t left = __shfl_up(H[C - 1], 1, WAVE); if(lane == 0) left = NEG_SCORE;
-                const uint64_t rowBase = uint64_t(s - g.s0) * RW;
 #pragma unroll
-                for(int c = 0; c < C; c += 2) {
-                    const int32_t l = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
-                    const uint32_t dir = dpCell(cc, lane * C + c, s, true, l, H[c + 1], H[c], bestScore, bestI, bestJ);
-                    const uint64_t lo = __ballot(dir & 1u), hi = __ballot(dir & 2u);
-                    if(lane == 0) { tr[rowBase + c] = lo; tr[rowBase + c + 1] = hi; }
-                }
-            }
-            {   // s+1: odd c hold cells
-                int32_t right = __shfl_down(H[0], 1, WAVE); if(lane == 63) right = NEG_SCORE;
-                const uint64_t rowBase = uint64_t(s + 1 - g.s0) * RW;
-#pragma unroll
-                for(int c = 1; c < C; c += 2) {
-                    const int32_t r = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
-                    const uint32_t dir = dpCell(cc, lane * C + c, s + 1, true, H[c - 1], r, H[c], bestScore, bestI, bestJ);
-                    const uint64_t lo = __ballot(dir & 1u), hi = __ballot(dir & 2u);
-                    if(lane == 0) { tr[rowBase + (c - 1)] = lo; tr[rowBase + c] = hi; }
-                }
-            }
-        }
+    for(int c = 0; c < C; c++) {
+        const int32_t d = bandMin + l * C + c;
+        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
+        const int32_t v = (lo[c] != 0x40000000) ? H[c] : NEG_SCORE;
+        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
     }
-
-    // End cell: maximum score, ties to the smallest (i, j).
 #pragma unroll
-    for(int d = 32; d >= 1; d >>= 1) {
-        const int32_t os = __shfl_xor(bestScore, d, WAVE);
-        const int32_t oi = __shfl_xor(bestI, d, WAVE);
-        const int32_t oj = __shfl_xor(bestJ, d, WAVE);
-        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) {
-            bestScore = os; bestI = oi; bestJ = oj;
-        }
+    for(int d = G / 2; d >= 1; d >>= 1) {
+        const int32_t os = __shfl_xor(bestScore, d, G);
+        const int32_t oi = __shfl_xor(bestI, d, G);
+        const int32_t oj = __shfl_xor(bestJ, d, G);
+        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
     }
+    if(hasTask && l == 0) {
+        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
+        ends[t] = e;
+    }
+}
 
-    // Make this wave's trace stores (lane 0) visible to the loads of all its lanes below:
-    // same CU, same L1 -- a workgroup-scope release/acquire (store drain) is sufficient.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-    // Traceback: every lane walks the same path; the trace is read through a 64-row LDS
-    // window that the wave refills with one coalesced load per row.
-    uint64_t* win = window[wave];
-    int64_t winStart = -1;
+// One lane per task: walk the path from the end cell through the packed trace.
+__global__ void __launch_bounds__(256)
+dpTracebackKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
+    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
+    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if(idx >= taskCount) return;
+    const uint32_t t = sortedIds[idx];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const DpEnd e = ends[t];
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    const int C = dpDiagonals(geo.cls);
+    const uint32_t RW = uint32_t(2 * C);
+    const uint64_t* __restrict__ tr = trace + e.traceOffset;
     const uint64_t ordBase = ordOffsets[t];
-    const uint32_t cap = min(pd.nx, pd.ny);
-    uint32_t pos = cap;
+    uint32_t pos = min(pd.nx, pd.ny);
     uint32_t count = 0, prevX = 0, prevY = 0, last0 = 0, last1 = 0, first0 = 0, first1 = 0, maxSkip = 0, maxDrift = 0;
     int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
     long long sumOffset = 0;
-    int32_t i = bestI, j = bestJ;
-    const bool ok = bestScore > NEG_SCORE;
+    int32_t i = e.bestI, j = e.bestJ;
+    const bool ok = e.score > NEG_SCORE;
     while(ok && i > 0 && j > 0) {
-        const int32_t s = i + j;
-        const int32_t b = i - j - cc.bandMin;
-        const int64_t row = (C == 1) ? (int64_t(s - g.s0) >> 1) : int64_t(s - g.s0);
-        if(winStart < 0 || row < winStart || row >= winStart + 64) {
-            winStart = row >= 63 ? row - 63 : 0;
-            const int64_t r = winStart + lane;
-            __builtin_amdgcn_wave_barrier();
-            if(r < int64_t(g.rows)) {
-#pragma unroll
-                for(int w = 0; w < RW; w++) win[lane * RW + w] = tr[uint64_t(r) * RW + w];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        const int rl = int(row - winStart);
-        int bit, word;
-        if(C == 1) { bit = b; word = rl * 2; }
-        else { bit = b / C; word = rl * RW + ((b % C) & ~1); }
-        const uint64_t lo = win[word], hi = win[word + 1];
-        const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
+        const int32_t b = i - j - task.bandMin;
+        const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
+        const uint32_t c = uint32_t(b) % uint32_t(C), bit = e.laneBase + uint32_t(b) / uint32_t(C);
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(tr + uint64_t(it) * RW + 2 * c);
+        const uint32_t dir = uint32_t((w.x >> bit) & 1ULL) | (uint32_t((w.y >> bit) & 1ULL) << 1);
         if(dir == 0u) {
             // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
             const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
             --pos;
-            if(lane == 0) { ordScratch[2 * (ordBase + pos)] = x; ordScratch[2 * (ordBase + pos) + 1] = y; }
+            *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(x, y);
             const int32_t offset = int32_t(x) - int32_t(y);
             if(count == 0) { last0 = x; last1 = y; }
             else {
@@ -1031,30 +1056,28 @@ bandedDpKernel(
         else { --i; }
     }
 
-    if(lane == 0) {
-        DpResult r;
-        r.ordBegin = ordBase + pos;
-        r.sumOffset = sumOffset;
-        r.markerCount = count; r.first0 = first0; r.first1 = first1; r.last0 = last0; r.last1 = last1;
-        r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
-        r.score = bestScore; r.pad = 0;
-        // Inner acceptance, src/Align4.cpp:944-981.
-        bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
-        if(pass) {
-            const double f0 = double(count) / double(last0 + 1 - first0);
-            const double f1 = double(count) / double(last1 + 1 - first1);
-            if(min(f0, f1) < opt.minAlignedFraction) pass = false;
-            if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
-            const uint32_t leftTrim = min(first0, first1);
-            const uint32_t rightTrim = min(pd.nx - 1 - last0, pd.ny - 1 - last1);
-            if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
-        }
-        r.passes = pass ? 1u : 0u;
-        results[t] = r;
-        // Best component = most aligned markers (:132-139); ties resolved towards the
-        // component whose first cell in (iY,iX) order comes first, and flagged later.
-        if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
+    DpResult r;
+    r.ordBegin = ordBase + pos;
+    r.sumOffset = sumOffset;
+    r.markerCount = count; r.first0 = first0; r.first1 = first1; r.last0 = last0; r.last1 = last1;
+    r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+    r.score = e.score; r.pad = 0;
+    // Inner acceptance, src/Align4.cpp:944-981.
+    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+    if(pass) {
+        const double f0 = double(count) / double(last0 + 1 - first0);
+        const double f1 = double(count) / double(last1 + 1 - first1);
+        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
+        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
+        const uint32_t leftTrim = min(first0, first1);
+        const uint32_t rightTrim = min(pd.nx - 1 - last0, pd.ny - 1 - last1);
+        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
     }
+    r.passes = pass ? 1u : 0u;
+    results[t] = r;
+    // Best component = most aligned markers (:132-139); ties resolved towards the
+    // component whose first cell in (iY,iX) order comes first, and flagged later.
+    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
 }
 
 __global__ void __launch_bounds__(256)
@@ -1262,8 +1285,14 @@ struct BatchScratch {
     DeviceBuffer<uint8_t> bytes, bigLog2;
     DeviceBuffer<uint32_t> pairList, bigScratch;
     DeviceBuffer<CellsChunk> chunks;
+    DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, iterations)
+    DeviceBuffer<uint64_t> bundleWords;
+    DeviceBuffer<DpEnd> ends;
     DeviceBuffer<uint64_t> bigOffsets;
 };
+
+// A host worker's stream and sort workspace (two workers pipeline the batches of one call).
+struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; };
 
 constexpr int CELLS_CLASSES = 3;
 constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {11, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
@@ -1275,7 +1304,7 @@ constexpr uint32_t CELLS_SHARE_MIN = 3;                        // smaller chunks
 
 // kind 0: one-wave workgroups; kind 1: CELLS_SHARED_WAVES waves share the table.
 template<int Q>
-void launchCellsChunksQ(Context& ctx, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
+void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity)
 {
     const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, waves) * sizeof(uint32_t);
@@ -1286,30 +1315,96 @@ void launchCellsChunksQ(Context& ctx, BatchScratch& b, int cls, int waves, const
         attributeSet = true;
     }
     MI355X_ASSERT(bytes <= 160 * 1024 - 64);
-    hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ctx.stream,
+    hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ws.stream,
         (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
         opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
     HIP_CHECK(hipGetLastError());
 }
 
-void launchCellsChunks(Context& ctx, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
+void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity)
 {
     if(count == 0) return;
-    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
-    else launchCellsChunksQ<4>(ctx, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
+    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
+    else launchCellsChunksQ<4>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
 }
 
-template<int C>
-void launchDp(Context& ctx, BatchScratch& b, int cls, uint32_t count, uint32_t listStride, const DeviceOptions& opt)
+template<int G, int C>
+void launchDpForward(Context& ctx, const WorkStream& ws, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
 {
-    if(count == 0) return;
-    hipLaunchKernelGGL(bandedDpKernel<C>, dim3(divUp(count, 4)), dim3(256), 0, ctx.stream,
+    const uint32_t taskCount = layout.taskStart[cls + 1] - layout.taskStart[cls];
+    const uint32_t bundleCount = layout.bundleStart[cls + 1] - layout.bundleStart[cls];
+    if(taskCount == 0) return;
+    hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, ws.stream,
         (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(),
-        (const uint32_t*)(b.classLists.data() + uint64_t(cls) * listStride), count,
-        (const uint64_t*)b.traceWords.data(), (const uint64_t*)b.ordCap.data(),
-        b.trace.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
+        sortedIds + layout.taskStart[cls], taskCount,
+        (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
+        b.trace.data(), b.ends.data());
     HIP_CHECK(hipGetLastError());
+}
+
+// K10 for the taskCount tasks in b.tasks (pairs in b.pairs): fills b.results, b.ordScratch and
+// b.pairBest.  Returns the number of DP cells (sum of nx * bandWidth); forwardSeconds gets the
+// HIP-event time of the forward launches when evA/evB are given.
+uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
+    hipEvent_t evA, hipEvent_t evB, uint32_t* launches)
+{
+    hipStream_t stream = ws.stream;
+    b.dpKeysA.reserve(taskCount, stream); b.dpKeysB.reserve(taskCount, stream);
+    b.dpIdsA.reserve(taskCount, stream); b.dpIdsB.reserve(taskCount, stream);
+    b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
+    b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
+    b.results.reserve(taskCount, stream); b.ends.reserve(taskCount, stream);
+    b.counters.reserve(16, stream); b.dpCells.reserve(2, stream);
+    HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
+    HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, 2 * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(dpSizeKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
+        (const DpTask*)b.tasks.data(), (const PairDesc*)b.pairs.data(), taskCount,
+        b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
+    exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
+    const bool inB = radixSort<uint32_t, uint32_t, true>(b.dpKeysA.data(), b.dpKeysB.data(), b.dpIdsA.data(), b.dpIdsB.data(),
+        taskCount, 27, *ws.sortWs, stream);
+    const uint32_t* sortedKeys = inB ? b.dpKeysB.data() : b.dpKeysA.data();
+    const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
+    HIP_CHECK(hipGetLastError());
+    uint32_t classCounts[DP_CLASSES];
+    unsigned long long sums[2];
+    HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, sizeof(classCounts), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(sums, b.dpCells.data(), sizeof(sums), hipMemcpyDeviceToHost, stream));
+    const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
+    DpClassLayout layout;
+    layout.taskStart[0] = 0; layout.bundleStart[0] = 0;
+    for(int c = 0; c < DP_CLASSES; c++) {
+        const uint32_t T = 64u / uint32_t(dpLanes(c));
+        layout.taskStart[c + 1] = layout.taskStart[c] + classCounts[c];
+        layout.bundleStart[c + 1] = layout.bundleStart[c] + (classCounts[c] + T - 1) / T;
+    }
+    MI355X_ASSERT(layout.taskStart[DP_CLASSES] == taskCount);
+    const uint32_t bundleTotal = layout.bundleStart[DP_CLASSES];
+    b.bundleWords.reserve(uint64_t(bundleTotal) + 1, stream);
+    b.scanTemp64.reserve(scanTempElements(uint64_t(bundleTotal) + 1), stream);
+    hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(bundleTotal) + 1, 256)), dim3(256), 0, stream,
+        sortedKeys, layout, b.bundleWords.data());
+    exclusiveScan<uint64_t>(b.bundleWords.data(), b.bundleWords.data(), uint64_t(bundleTotal) + 1, b.scanTemp64.data(), stream);
+    // sums[1] bounds the trace (a bundle needs no more than the sum over its tasks): no read-back.
+    b.trace.reserve(sums[1] + 64, stream);
+    b.ordScratch.reserve(2 * ordTotal + 2, stream);
+
+    if(evA) HIP_CHECK(hipEventRecord(evA, stream));
+    launchDpForward<16, 2>(ctx, ws, b, sortedIds, layout, 0);
+    launchDpForward<32, 2>(ctx, ws, b, sortedIds, layout, 1);
+    launchDpForward<64, 2>(ctx, ws, b, sortedIds, layout, 2);
+    launchDpForward<64, 4>(ctx, ws, b, sortedIds, layout, 3);
+    launchDpForward<64, 8>(ctx, ws, b, sortedIds, layout, 4);
+    launchDpForward<64, 16>(ctx, ws, b, sortedIds, layout, 5);
+    hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+        (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds, taskCount,
+        (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
+        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
+    HIP_CHECK(hipGetLastError());
+    if(evB) HIP_CHECK(hipEventRecord(evB, stream));
+    if(launches) { *launches = 1; for(int c = 0; c < DP_CLASSES; c++) *launches += classCounts[c] ? 1 : 0; }
+    return sums[0];
 }
 
 }  // namespace
@@ -1320,27 +1415,55 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     std::memset(&result, 0, sizeof(result));
     const auto t0 = std::chrono::steady_clock::now();
     HIP_CHECK(hipSetDevice(ctx.device));
-    hipStream_t stream = ctx.stream;
     const DeviceOptions opt = makeOptions(options);
-
-    std::vector<shasta_alignment_data> outRows;
-    std::vector<uint64_t> outCompressedToc(1, 0), outOrdinalsToc(1, 0);
-    std::vector<uint8_t> outBytes, outStatus(candidateCount);
-    std::vector<uint32_t> outOrdinals;
-    uint64_t dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0;
-    double dpSeconds = 0;
-    uint64_t dpLaunches = 0;
-    hipEvent_t evBegin, evEnd, evA, evB;
-    HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
-    HIP_CHECK(hipEventCreate(&evA)); HIP_CHECK(hipEventCreate(&evB));
-    HIP_CHECK(hipEventRecord(evBegin, stream));
-
-    BatchScratch b;
     const uint64_t BATCH = 1ULL << 17;
-    std::vector<PairDesc> hostPairs;
-    std::vector<uint64_t> hostToc64;
-    std::vector<uint8_t> hostStatus;
-    for(uint64_t batchBegin = 0; batchBegin < candidateCount; batchBegin += BATCH) {
+    const uint64_t batchCount = (candidateCount + BATCH - 1) / BATCH;
+
+    struct BatchOutput {
+        std::vector<shasta_alignment_data> rows;
+        std::vector<uint64_t> tocEnds, ordToc;
+        std::vector<uint8_t> bytes;
+        std::vector<uint32_t> ordinals;
+        uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
+        double dpSeconds = 0;
+    };
+    std::vector<BatchOutput> outputs(batchCount);
+    std::vector<uint8_t> outStatus(candidateCount);
+
+    // Two host workers, each with its own stream and grow-only scratch kept in the context, take
+    // the batches alternately: one worker's host-side preparation and result copies overlap the
+    // other's kernels.
+    struct Worker {
+        hipStream_t stream = nullptr;
+        RadixSortWorkspace* sortWs = nullptr;
+        BatchScratch* scratch = nullptr;
+        hipEvent_t evA = nullptr, evB = nullptr;
+        std::vector<PairDesc> hostPairs;
+        std::vector<uint64_t> hostToc64;
+        std::string error;
+    };
+    const int workerCount = batchCount > 1 ? 2 : 1;
+    Worker workers[2];
+    if(!ctx.stream2) HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream2, hipStreamNonBlocking));
+    for(int k = 0; k < 2; k++) {
+        if(!ctx.alignScratch[k]) ctx.alignScratch[k] = std::make_shared<BatchScratch>();
+        workers[k].stream = k == 0 ? ctx.stream : ctx.stream2;
+        workers[k].sortWs = k == 0 ? &ctx.sortWs : &ctx.sortWs2;
+        workers[k].scratch = static_cast<BatchScratch*>(ctx.alignScratch[k].get());
+        HIP_CHECK(hipEventCreate(&workers[k].evA)); HIP_CHECK(hipEventCreate(&workers[k].evB));
+    }
+    hipEvent_t evBegin, evEnd, evOther;
+    HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd)); HIP_CHECK(hipEventCreate(&evOther));
+    HIP_CHECK(hipEventRecord(evBegin, ctx.stream));
+
+    auto processBatch = [&](Worker& w, uint64_t batchIndex) {
+        hipStream_t stream = w.stream;
+        const WorkStream ws{w.stream, w.sortWs};
+        BatchScratch& b = *w.scratch;
+        BatchOutput& out = outputs[batchIndex];
+        std::vector<PairDesc>& hostPairs = w.hostPairs;
+        std::vector<uint64_t>& hostToc64 = w.hostToc64;
+        const uint64_t batchBegin = batchIndex * BATCH;
         const uint32_t n = uint32_t(std::min<uint64_t>(BATCH, candidateCount - batchBegin));
         hostPairs.resize(n);
         for(uint32_t k = 0; k < n; k++) {
@@ -1356,11 +1479,11 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
             MI355X_ASSERT(nx < (1ULL << 30) && ny < (1ULL << 30));
             pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
             hostPairs[k] = pd;
-            kmerIdBytes += 4 * (nx + ny);
+            out.kmerIdBytes += 4 * (nx + ny);
         }
         const uint32_t taskCapacity = 8 * n + 1024;
         b.pairs.reserve(n, stream); b.candidates.reserve(n, stream); b.tasks.reserve(taskCapacity, stream);
-        b.counters.reserve(8, stream); b.pairFlags.reserve(n, stream); b.pairTie.reserve(n, stream); b.status.reserve(n, stream);
+        b.counters.reserve(16, stream); b.pairFlags.reserve(n, stream); b.pairTie.reserve(n, stream); b.status.reserve(n, stream);
         b.pairBest.reserve(n, stream); b.dpCells.reserve(1, stream); b.pairWinner.reserve(n, stream);
         b.storedFlags.reserve(n + 1, stream); b.storedIndex.reserve(n + 1, stream);
         b.scanTemp32.reserve(scanTempElements(uint64_t(n) + 1), stream);
@@ -1475,8 +1598,8 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
                     b.chunks.reserve(single.size() + shared.size(), stream);
                     if(!single.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data(), single.data(), single.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
                     if(!shared.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data() + single.size(), shared.data(), shared.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
-                    launchCellsChunks(ctx, b, c, CELLS_SHARED_WAVES[c], b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity);
-                    launchCellsChunks(ctx, b, c, 1, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity);
+                    launchCellsChunks(ctx, ws, b, c, CELLS_SHARED_WAVES[c], b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity);
+                    launchCellsChunks(ctx, ws, b, c, 1, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity);
                     HIP_CHECK(hipStreamSynchronize(stream));      // the lists are reused below
                     single.clear(); shared.clear();
                 }
@@ -1554,34 +1677,10 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         const uint32_t taskCount = readDevice(b.counters.data(), stream);
         if(taskCount > taskCapacity) throw std::runtime_error("Align4: task list overflow.");
 
-        // Size the tasks, lay out the trace and ordinal scratch, bin by band-width class.
-        uint32_t classCounts[5] = {0, 0, 0, 0, 0};
-        const uint32_t listStride = std::max<uint32_t>(1, taskCount);
+        // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
+        uint32_t dpLaunchesBatch = 0;
         if(taskCount) {
-            b.traceWords.reserve(taskCount + 1, stream); b.ordCap.reserve(taskCount + 1, stream);
-            b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
-            b.classLists.reserve(5ULL * listStride, stream); b.results.reserve(taskCount, stream);
-            hipLaunchKernelGGL(sizeTasksKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
-                (const DpTask*)b.tasks.data(), (const PairDesc*)b.pairs.data(), taskCount,
-                b.traceWords.data(), b.ordCap.data(), b.classLists.data(), b.counters.data() + 1, listStride, b.dpCells.data());
-            exclusiveScan<uint64_t>(b.traceWords.data(), b.traceWords.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
-            exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
-            HIP_CHECK(hipGetLastError());
-            const uint64_t traceTotal = readDevice(b.traceWords.data() + taskCount, stream);
-            const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);
-            HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            dpCellsTotal += readDevice(b.dpCells.data(), stream);
-            b.trace.reserve(traceTotal + 64, stream);
-            b.ordScratch.reserve(2 * ordTotal + 2, stream);
-
-            // K10.
-            HIP_CHECK(hipEventRecord(evA, stream));
-            launchDp<1>(ctx, b, 0, classCounts[0], listStride, opt);
-            launchDp<2>(ctx, b, 1, classCounts[1], listStride, opt);
-            launchDp<4>(ctx, b, 2, classCounts[2], listStride, opt);
-            launchDp<8>(ctx, b, 3, classCounts[3], listStride, opt);
-            launchDp<16>(ctx, b, 4, classCounts[4], listStride, opt);
-            HIP_CHECK(hipEventRecord(evB, stream));
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, opt, w.evA, w.evB, &dpLaunchesBatch);
             hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
                 (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
                 (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data());
@@ -1616,54 +1715,74 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
             (const shasta_alignment_data*)b.rows.data(), b.rowsOut.data());
         HIP_CHECK(hipGetLastError());
 
-        // Copy this batch's results out, in candidate order.
-        const size_t rowBase = outRows.size();
-        outRows.resize(rowBase + storedCount);
+        // Copy this batch's results out (assembled in candidate order once every batch is done).
+        out.rows.resize(storedCount);
         hostToc64.resize(storedCount);
         if(storedCount) {
-            HIP_CHECK(hipMemcpyAsync(outRows.data() + rowBase, b.rowsOut.data(), storedCount * sizeof(shasta_alignment_data), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(out.rows.data(), b.rowsOut.data(), storedCount * sizeof(shasta_alignment_data), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(hostToc64.data(), b.compressedToc.data(), storedCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         }
-        const size_t byteBase = outBytes.size();
-        outBytes.resize(byteBase + byteTotal);
-        if(byteTotal) HIP_CHECK(hipMemcpyAsync(outBytes.data() + byteBase, b.bytes.data(), byteTotal, hipMemcpyDeviceToHost, stream));
+        out.bytes.resize(byteTotal);
+        if(byteTotal) HIP_CHECK(hipMemcpyAsync(out.bytes.data(), b.bytes.data(), byteTotal, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(outStatus.data() + batchBegin, b.status.data(), n, hipMemcpyDeviceToHost, stream));
-        std::vector<uint64_t> hostOrdToc;
-        const size_t ordBaseOut = outOrdinals.size() / 2;
         if(wantOrdinals) {
-            hostOrdToc.resize(uint64_t(n) + 1);
-            HIP_CHECK(hipMemcpyAsync(hostOrdToc.data(), b.ordCounts.data(), (uint64_t(n) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            out.ordToc.resize(uint64_t(n) + 1);
+            HIP_CHECK(hipMemcpyAsync(out.ordToc.data(), b.ordCounts.data(), (uint64_t(n) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            out.ordinals.resize(2 * ordTotalOut);
             if(ordTotalOut) {
                 b.ordOut.reserve(2 * ordTotalOut, stream);
                 hipLaunchKernelGGL(gatherOrdinalsKernel, dim3(divUp(uint64_t(n) * 64, 256)), dim3(256), 0, stream,
                     (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(), (const uint64_t*)b.ordCounts.data(), n,
                     (const uint32_t*)b.ordScratch.data(), b.ordOut.data());
                 HIP_CHECK(hipGetLastError());
-                outOrdinals.resize(2 * (ordBaseOut + ordTotalOut));
-                HIP_CHECK(hipMemcpyAsync(outOrdinals.data() + 2 * ordBaseOut, b.ordOut.data(), 2 * ordTotalOut * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(out.ordinals.data(), b.ordOut.data(), 2 * ordTotalOut * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             }
         }
         HIP_CHECK(hipStreamSynchronize(stream));
-        // CSR of CompressedAlignments: end offset of each stored alignment.
-        for(uint32_t k = 0; k < storedCount; k++) {
-            outCompressedToc.push_back(byteBase + (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal));
-        }
-        if(wantOrdinals) for(uint32_t k = 1; k <= n; k++) outOrdinalsToc.push_back(ordBaseOut + hostOrdToc[k]);
-        for(uint32_t k = 0; k < storedCount; k++) alignedBytes += 8ULL * outRows[rowBase + k].info.markerCount;
+        // CSR of CompressedAlignments: end offset of each stored alignment, relative to this batch.
+        out.tocEnds.resize(storedCount);
+        for(uint32_t k = 0; k < storedCount; k++) out.tocEnds[k] = (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal);
+        for(uint32_t k = 0; k < storedCount; k++) out.alignedBytes += 8ULL * out.rows[k].info.markerCount;
         if(taskCount) {
             float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
-            dpSeconds += ms * 1e-3;
-            for(int c = 0; c < 5; c++) dpLaunches += classCounts[c] ? 1 : 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, w.evA, w.evB));
+            out.dpSeconds = ms * 1e-3;
+            out.dpLaunches = dpLaunchesBatch;
         }
-    }
 
-    HIP_CHECK(hipEventRecord(evEnd, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    };
+
+    std::atomic<uint64_t> nextBatch(0);
+    auto workerLoop = [&](int k) {
+        try {
+            HIP_CHECK(hipSetDevice(ctx.device));
+            for(;;) {
+                const uint64_t batchIndex = nextBatch.fetch_add(1);
+                if(batchIndex >= batchCount) break;
+                processBatch(workers[k], batchIndex);
+            }
+        } catch(const std::exception& e) {
+            workers[k].error = e.what();
+            nextBatch.store(batchCount);
+        }
+    };
+    if(workerCount == 2) {
+        std::thread other(workerLoop, 1);
+        workerLoop(0);
+        other.join();
+    } else {
+        workerLoop(0);
+    }
+    HIP_CHECK(hipEventRecord(evOther, ctx.stream2));
+    HIP_CHECK(hipStreamWaitEvent(ctx.stream, evOther, 0));
+    HIP_CHECK(hipEventRecord(evEnd, ctx.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx.stream));
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
-    (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
+    (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evOther);
+    for(int k = 0; k < 2; k++) { (void)hipEventDestroy(workers[k].evA); (void)hipEventDestroy(workers[k].evB); }
+    for(int k = 0; k < 2; k++) if(!workers[k].error.empty()) throw std::runtime_error(workers[k].error);
 
 #ifdef SHASTA_PROFILE_PHASES
     {
@@ -1676,17 +1795,45 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phaseCycles), h, sizeof(h)));
     }
 #endif
+
+    // Assemble the outputs in candidate order.
+    uint64_t rowTotal = 0, byteTotalAll = 0, ordTotalAll = 0, dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
+    double dpSeconds = 0;
+    for(const BatchOutput& o : outputs) {
+        rowTotal += o.rows.size(); byteTotalAll += o.bytes.size(); ordTotalAll += o.ordinals.size() / 2;
+        dpCellsTotal += o.dpCells; kmerIdBytes += o.kmerIdBytes; alignedBytes += o.alignedBytes; dpLaunches += o.dpLaunches;
+        dpSeconds += o.dpSeconds;
+    }
+    auto allocate = [](size_t bytes) { void* p = std::malloc(std::max<size_t>(1, bytes)); if(!p) throw std::bad_alloc(); return p; };
+    result.alignmentData = static_cast<shasta_alignment_data*>(allocate(rowTotal * sizeof(shasta_alignment_data)));
+    result.compressedToc = static_cast<uint64_t*>(allocate((rowTotal + 1) * sizeof(uint64_t)));
+    result.compressedData = static_cast<uint8_t*>(allocate(byteTotalAll));
+    result.status = mallocCopy(outStatus);
+    if(wantOrdinals) {
+        result.ordinalsToc = static_cast<uint64_t*>(allocate((candidateCount + 1) * sizeof(uint64_t)));
+        result.ordinals = static_cast<uint32_t*>(allocate(2 * ordTotalAll * sizeof(uint32_t)));
+        result.ordinalsToc[0] = 0;
+    }
+    result.compressedToc[0] = 0;
+    uint64_t rowBase = 0, byteBase = 0, ordBase = 0;
+    for(uint64_t k = 0; k < batchCount; k++) {
+        const BatchOutput& o = outputs[k];
+        if(!o.rows.empty()) std::memcpy(result.alignmentData + rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
+        if(!o.bytes.empty()) std::memcpy(result.compressedData + byteBase, o.bytes.data(), o.bytes.size());
+        for(size_t q = 0; q < o.tocEnds.size(); q++) result.compressedToc[rowBase + q + 1] = byteBase + o.tocEnds[q];
+        if(wantOrdinals) {
+            if(!o.ordinals.empty()) std::memcpy(result.ordinals + 2 * ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
+            for(size_t q = 1; q < o.ordToc.size(); q++) result.ordinalsToc[k * BATCH + q] = ordBase + o.ordToc[q];
+            ordBase += o.ordinals.size() / 2;
+        }
+        rowBase += o.rows.size(); byteBase += o.bytes.size();
+    }
+
     ctx.times.alignDpSeconds = dpSeconds;
     ctx.times.alignDpLaunches = dpLaunches;
     ctx.times.alignDpCells = dpCellsTotal;
     ctx.times.alignBytes = kmerIdBytes + alignedBytes;
-
-    result.alignmentCount = outRows.size();
-    result.alignmentData = mallocCopy(outRows);
-    result.compressedToc = mallocCopy(outCompressedToc);
-    result.compressedData = mallocCopy(outBytes);
-    result.status = mallocCopy(outStatus);
-    if(wantOrdinals) { result.ordinalsToc = mallocCopy(outOrdinalsToc); result.ordinals = mallocCopy(outOrdinals); }
+    result.alignmentCount = rowTotal;
     result.dpCellCount = dpCellsTotal;
     result.kmerIdBytes = kmerIdBytes;
     result.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1720,29 +1867,15 @@ void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t 
     BatchScratch b;
     PairDesc pd; pd.begin0 = 0; pd.begin1 = nx; pd.nx = nx; pd.ny = ny;
     DpTask task; task.pair = 0; task.bandMin = bandMin; task.bandMax = bandMax; task.label = 0;
-    const TaskGeometry g = taskGeometry(bandMin, bandMax, nx, ny);
-    b.pairs.reserve(1, stream); b.tasks.reserve(1, stream); b.classLists.reserve(1, stream);
-    b.traceWords.reserve(2, stream); b.ordCap.reserve(2, stream); b.results.reserve(1, stream);
-    b.pairBest.reserve(1, stream);
-    b.trace.reserve(uint64_t(g.rows) * g.rowWords + 64, stream);
-    b.ordScratch.reserve(2ULL * std::min(nx, ny) + 2, stream);
-    const uint32_t zero32 = 0; const uint64_t zeros[2] = {0, 0};
+    b.pairs.reserve(1, stream); b.tasks.reserve(1, stream); b.pairBest.reserve(1, stream);
     HIP_CHECK(hipMemcpyAsync(b.pairs.data(), &pd, sizeof(pd), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(b.tasks.data(), &task, sizeof(task), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(b.classLists.data(), &zero32, 4, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(b.traceWords.data(), zeros, 16, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(b.ordCap.data(), zeros, 16, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8, stream));
     DeviceOptions opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
-    switch(g.cls) {
-        case 0: launchDp<1>(ctx, b, 0, 1, 1, opt); break;
-        case 1: launchDp<2>(ctx, b, 0, 1, 1, opt); break;
-        case 2: launchDp<4>(ctx, b, 0, 1, 1, opt); break;
-        case 3: launchDp<8>(ctx, b, 0, 1, 1, opt); break;
-        default: launchDp<16>(ctx, b, 0, 1, 1, opt); break;
-    }
+    const WorkStream ws{ctx.stream, &ctx.sortWs};
+    (void)runDpTasks(ctx, ws, b, 1, opt, nullptr, nullptr, nullptr);
     DpResult r;
     HIP_CHECK(hipMemcpyAsync(&r, b.results.data(), sizeof(r), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));

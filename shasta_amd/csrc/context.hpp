@@ -31,7 +31,9 @@ struct Context {
     int rank = 0, worldSize = 1;
     uint64_t readBegin = 0, readEnd = 0;
 
-    RadixSortWorkspace sortWs;
+    RadixSortWorkspace sortWs, sortWs2;
+    hipStream_t stream2 = nullptr;           // second worker of the Align4 stage
+    std::shared_ptr<void> alignScratch[2];   // grow-only batch scratch of the two workers
     shasta_mi355x_kernel_times times = {};
 
     // Sorted markers (Assembler::computeSortedMarkers, src/AssemblerAlign4.cpp:190-261),

@@ -382,7 +382,10 @@ Context::Context(int deviceArg) : device(deviceArg)
 
 Context::~Context()
 {
-    if(stream) { (void)hipSetDevice(device); (void)hipStreamDestroy(stream); }
+    (void)hipSetDevice(device);
+    alignScratch[0].reset(); alignScratch[1].reset();
+    if(stream2) (void)hipStreamDestroy(stream2);
+    if(stream) (void)hipStreamDestroy(stream);
 }
 
 void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const void* data7,

@@ -83,9 +83,7 @@ class Library:
             C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
         self._check(rc, "shasta_mi355x_align4_batch")
-        out = abi.Align4Output(res, len(candidates), want_ordinals)
-        self.lib.shasta_mi355x_align4_free(C.byref(res))
-        return out
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
 
     # --- unit seams -------------------------------------------------------------------
     def hash_windows(self, kmer_ids, m, iteration):
@@ -180,9 +178,7 @@ class Context:
         self.library._check(self.lib.shasta_mi355x_align4_run(
             C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_align4_run")
-        out = abi.Align4Output(res, len(candidates), want_ordinals)
-        self.lib.shasta_mi355x_align4_free(C.byref(res))
-        return out
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
 
     def kernel_times(self):
         t = abi.KernelTimes()
