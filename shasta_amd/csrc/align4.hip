@@ -1165,45 +1165,96 @@ gatherOrdinalsKernel(const DpResult* __restrict__ results, const uint32_t* __res
 }
 
 // shasta::compress (src/compressAlignment.cpp:11-67; formats compressAlignment.hpp:101-321).
-// One thread per stored alignment; WRITE=false counts bytes.
-template<bool WRITE>
-__device__ __forceinline__ uint64_t compressAlignment(const uint32_t* __restrict__ ord, uint64_t n, uint8_t* __restrict__ out)
+// A streak is a maximal run of marker pairs that advance both ordinals by one; its record holds
+// (skip0, skip1) from the last pair of the previous streak (from (0,0) for the first) and its
+// length, in the smallest of five formats (1/2/4/8/16 bytes).
+struct StreakRecord { uint64_t bits; uint32_t w[3]; int len; };
+
+__device__ __forceinline__ StreakRecord makeStreakRecord(int32_t skip0, int32_t skip1, uint32_t streak)
 {
-    uint64_t bytes = 0;
-    uint32_t ordinal0 = 0, ordinal1 = 0;
-    for(uint64_t i = 0; i < n; ) {
-        const uint32_t x = ord[2 * i], y = ord[2 * i + 1];
-        const int32_t skip0 = int32_t(x) - int32_t(ordinal0);
-        const int32_t skip1 = int32_t(y) - int32_t(ordinal1);
-        ordinal0 = x; ordinal1 = y;
-        uint32_t streak = 1;
-        for(uint64_t j = i + 1; j < n; j++, streak++) {
-            if(ord[2 * j] != ordinal0 + 1 || ord[2 * j + 1] != ordinal1 + 1) break;
-            ++ordinal0; ++ordinal1;
+    StreakRecord r;
+    const uint64_t u0 = uint32_t(skip0), u1 = uint32_t(skip1), nm1 = uint64_t(streak) - 1;
+    r.w[0] = uint32_t(skip0); r.w[1] = uint32_t(skip1); r.w[2] = uint32_t(nm1);
+    if(skip0 >= 0 && skip0 <= 3 && skip1 >= 0 && skip1 <= 3 && streak <= 8) {
+        r.bits = 0 | (u0 & 3) << 1 | (u1 & 3) << 3 | (nm1 & 7) << 5; r.len = 1;
+    } else if(skip0 >= -8 && skip0 <= 7 && skip1 >= -8 && skip1 <= 7 && streak <= 32) {
+        r.bits = 1 | (u0 & 0xf) << 3 | (u1 & 0xf) << 7 | (nm1 & 0x1f) << 11; r.len = 2;
+    } else if(skip0 >= -512 && skip0 <= 511 && skip1 >= -512 && skip1 <= 511 && streak <= 512) {
+        r.bits = 3 | (u0 & 0x3ff) << 3 | (u1 & 0x3ff) << 13 | (nm1 & 0x1ff) << 23; r.len = 4;
+    } else if(skip0 >= -524288 && skip0 <= 524287 && skip1 >= -524288 && skip1 <= 524287 && streak <= 2097152) {
+        r.bits = 5 | (u0 & 0xfffff) << 3 | (u1 & 0xfffff) << 23 | (nm1 & 0x1fffff) << 43; r.len = 8;
+    } else {
+        r.bits = 7; r.len = 16;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void writeStreakRecord(const StreakRecord& r, uint8_t* __restrict__ out)
+{
+    if(r.len == 16) {
+        const uint32_t w[4] = {7u, r.w[0], r.w[1], r.w[2]};
+        for(int k = 0; k < 16; k++) out[k] = uint8_t(w[k >> 2] >> (8 * (k & 3)));
+    } else {
+        for(int k = 0; k < r.len; k++) out[k] = uint8_t(r.bits >> (8 * k));
+    }
+}
+
+// One wavefront per stored alignment: lanes flag the streak starts of 64 marker pairs at a time;
+// a start lane knows its skips at once and its length when the next start is seen (the last
+// start of a chunk is carried to the next chunk).  WRITE=false only counts the bytes.
+template<bool WRITE>
+__device__ __forceinline__ uint64_t compressAlignmentWave(const uint32_t* __restrict__ ord, uint32_t n, uint8_t* __restrict__ out)
+{
+    const int lane = laneId();
+    uint64_t bytes = 0;                       // wave-uniform
+    bool havePending = false;                 // wave-uniform: a streak whose end is not known yet
+    uint32_t pendingStart = 0; int32_t pendingSkip0 = 0, pendingSkip1 = 0;
+    uint32_t carryX = 0, carryY = 0;          // last pair of the previous chunk ((0,0) before the first)
+    for(uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t i = base + lane;
+        const bool valid = i < n;
+        uint2 xy = make_uint2(0, 0);
+        if(valid) xy = *reinterpret_cast<const uint2*>(ord + 2 * uint64_t(i));
+        uint32_t px = __shfl_up(xy.x, 1, WAVE), py = __shfl_up(xy.y, 1, WAVE);
+        if(lane == 0) { px = carryX; py = carryY; }
+        const bool start = valid && (i == 0 || xy.x != px + 1 || xy.y != py + 1);
+        const uint64_t starts = __ballot(start);
+        const int32_t skip0 = int32_t(xy.x) - int32_t(px), skip1 = int32_t(xy.y) - int32_t(py);
+        // The first start of this chunk closes the pending streak.
+        if(havePending && starts) {
+            const uint32_t first = base + uint32_t(__ffsll((unsigned long long)starts) - 1);
+            const StreakRecord r = makeStreakRecord(pendingSkip0, pendingSkip1, first - pendingStart);
+            if(WRITE && lane == 0) writeStreakRecord(r, out + bytes);
+            bytes += uint64_t(r.len);
+            havePending = false;
         }
-        i += streak;
-        const uint64_t u0 = uint32_t(skip0), u1 = uint32_t(skip1), nm1 = uint64_t(streak) - 1;
-        uint64_t v; int len;
-        if(skip0 >= 0 && skip0 <= 3 && skip1 >= 0 && skip1 <= 3 && streak <= 8) {
-            v = 0 | (u0 & 3) << 1 | (u1 & 3) << 3 | (nm1 & 7) << 5; len = 1;
-        } else if(skip0 >= -8 && skip0 <= 7 && skip1 >= -8 && skip1 <= 7 && streak <= 32) {
-            v = 1 | (u0 & 0xf) << 3 | (u1 & 0xf) << 7 | (nm1 & 0x1f) << 11; len = 2;
-        } else if(skip0 >= -512 && skip0 <= 511 && skip1 >= -512 && skip1 <= 511 && streak <= 512) {
-            v = 3 | (u0 & 0x3ff) << 3 | (u1 & 0x3ff) << 13 | (nm1 & 0x1ff) << 23; len = 4;
-        } else if(skip0 >= -524288 && skip0 <= 524287 && skip1 >= -524288 && skip1 <= 524287 && streak <= 2097152) {
-            v = 5 | (u0 & 0xfffff) << 3 | (u1 & 0xfffff) << 23 | (nm1 & 0x1fffff) << 43; len = 8;
-        } else {
-            v = 0; len = 16;
+        // Starts of this chunk that are closed by a later start of the same chunk.
+        const uint64_t later = (starts >> 1) >> lane;
+        const bool closed = start && later != 0;
+        uint32_t length = closed ? uint32_t(__ffsll((unsigned long long)later)) : 0u;
+        StreakRecord r = makeStreakRecord(skip0, skip1, closed ? length : 1u);
+        const uint32_t len = closed ? uint32_t(r.len) : 0u;
+        // Exclusive prefix of the record lengths over the wave.
+        uint32_t inclusive = len;
+#pragma unroll
+        for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inclusive, d, WAVE); if(lane >= d) inclusive += o; }
+        if(WRITE && closed) writeStreakRecord(r, out + bytes + (inclusive - len));
+        bytes += uint64_t(__shfl(inclusive, WAVE - 1, WAVE));
+        // The last start of the chunk stays pending.
+        if(starts) {
+            const int lastLane = 63 - __clzll((unsigned long long)starts);
+            havePending = true;
+            pendingStart = base + uint32_t(lastLane);
+            pendingSkip0 = __shfl(skip0, lastLane, WAVE);
+            pendingSkip1 = __shfl(skip1, lastLane, WAVE);
         }
-        if(WRITE) {
-            if(len == 16) {
-                const uint32_t w[4] = {7u, uint32_t(skip0), uint32_t(skip1), uint32_t(nm1)};
-                for(int k = 0; k < 16; k++) out[bytes + k] = uint8_t(w[k >> 2] >> (8 * (k & 3)));
-            } else {
-                for(int k = 0; k < len; k++) out[bytes + k] = uint8_t(v >> (8 * k));
-            }
-        }
-        bytes += len;
+        const int lastValid = int(min(uint32_t(WAVE), n - base)) - 1;
+        carryX = __shfl(xy.x, lastValid, WAVE); carryY = __shfl(xy.y, lastValid, WAVE);
+    }
+    if(havePending) {
+        const StreakRecord r = makeStreakRecord(pendingSkip0, pendingSkip1, n - pendingStart);
+        if(WRITE && lane == 0) writeStreakRecord(r, out + bytes);
+        bytes += uint64_t(r.len);
     }
     return bytes;
 }
@@ -1212,15 +1263,14 @@ __global__ void __launch_bounds__(256)
 compressSizeKernel(const uint32_t* __restrict__ storedFlags, const DpResult* __restrict__ results,
     const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch, uint32_t pairCount, uint64_t* __restrict__ sizes)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if(p == pairCount) { sizes[p] = 0; return; }
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if(p > pairCount) return;
     uint64_t s = 0;
-    if(storedFlags[p]) {
+    if(p < pairCount && storedFlags[p]) {
         const DpResult r = results[pairWinner[p]];
-        s = compressAlignment<false>(ordScratch + 2 * r.ordBegin, r.markerCount, nullptr);
+        s = compressAlignmentWave<false>(ordScratch + 2 * r.ordBegin, r.markerCount, nullptr);
     }
-    sizes[p] = s;
+    if(laneId() == 0) sizes[p] = s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1229,13 +1279,14 @@ compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __
     uint32_t pairCount, const uint64_t* __restrict__ byteOffsets, uint8_t* __restrict__ bytes,
     uint64_t* __restrict__ compressedToc, const shasta_alignment_data* __restrict__ rows, shasta_alignment_data* __restrict__ rowsOut)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if(p >= pairCount || !storedFlags[p]) return;
     const DpResult r = results[pairWinner[p]];
-    compressAlignment<true>(ordScratch + 2 * r.ordBegin, r.markerCount, bytes + byteOffsets[p]);
+    (void)compressAlignmentWave<true>(ordScratch + 2 * r.ordBegin, r.markerCount, bytes + byteOffsets[p]);
     const uint32_t k = storedIndex[p];
-    compressedToc[k] = byteOffsets[p];
-    rowsOut[k] = rows[p];
+    if(laneId() == 0) compressedToc[k] = byteOffsets[p];
+    // The 64-byte AlignmentData row: one dword per lane.
+    if(laneId() < 16) reinterpret_cast<uint32_t*>(rowsOut + k)[laneId()] = reinterpret_cast<const uint32_t*>(rows + p)[laneId()];
 }
 
 template<class T> T readDevice(const T* p, hipStream_t s)
@@ -1699,7 +1750,8 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         exclusiveScan<uint32_t>(b.storedFlags.data(), b.storedIndex.data(), uint64_t(n) + 1, b.scanTemp32.data(), stream);
         b.scanTemp64.reserve(scanTempElements(uint64_t(n) + 1), stream);
         exclusiveScan<uint64_t>(b.ordCounts.data(), b.ordCounts.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
-        hipLaunchKernelGGL(compressSizeKernel, dim3(gp), dim3(256), 0, stream,
+        const unsigned gw = divUp((uint64_t(n) + 1) * WAVE, 256);
+        hipLaunchKernelGGL(compressSizeKernel, dim3(gw), dim3(256), 0, stream,
             (const uint32_t*)b.storedFlags.data(), (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(),
             (const uint32_t*)b.ordScratch.data(), n, b.sizes.data());
         exclusiveScan<uint64_t>(b.sizes.data(), b.sizes.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
@@ -1708,7 +1760,7 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
         const uint64_t byteTotal = readDevice(b.sizes.data() + n, stream);
         b.bytes.reserve(byteTotal + 1, stream);
-        hipLaunchKernelGGL(compressWriteKernel, dim3(gp), dim3(256), 0, stream,
+        hipLaunchKernelGGL(compressWriteKernel, dim3(gw), dim3(256), 0, stream,
             (const uint32_t*)b.storedFlags.data(), (const uint32_t*)b.storedIndex.data(), (const DpResult*)b.results.data(),
             (const uint32_t*)b.pairWinner.data(), (const uint32_t*)b.ordScratch.data(), n,
             (const uint64_t*)b.sizes.data(), b.bytes.data(), b.compressedToc.data(),
