@@ -356,7 +356,7 @@ align4CellsKernel(
 // Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
 // larger class, finally by align4CellsKernel<true>.
 // Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | per wave:
-//   cellKeys[SC] | cellCnt[SC] | kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
+//   cells[SC] (iY | iX | count packed) | kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
 // ---------------------------------------------------------------------------
 // firstMember indexes the member list (candidate indices of the batch).
 struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
@@ -399,10 +399,11 @@ __device__ __forceinline__ uint32_t zeroHalves(uint32_t v)
 }
 
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
+constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
 constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
 __host__ __device__ inline size_t cellsWaveLdsWords(int scLog2, int Q)
 {
-    return 2 * (size_t(1) << scLog2) + 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
+    return (size_t(1) << scLog2) + 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
 }
 __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
 {
@@ -410,7 +411,7 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 }
 
 template<int Q>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(384)
 align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
@@ -419,7 +420,10 @@ align4CellsChunkKernel(
     uint8_t* __restrict__ pairFlags)
 {
     extern __shared__ uint32_t ldsWords[];
-    __shared__ uint32_t tableOverflow;
+    // Markers whose two buckets were both full when they arrived (the two-choice table runs at two
+    // entries per four-slot bucket on average, so a nearly full table overflows now and then).
+    constexpr uint32_t STASH = 32;
+    __shared__ uint32_t stashCount, stashKmer[STASH], stashOrdinal[STASH];
     constexpr int MAXC = 64 * Q;
     if(blockIdx.x >= chunkCount) return;
     const CellsChunk chunk = chunks[blockIdx.x];
@@ -431,9 +435,8 @@ align4CellsChunkKernel(
     const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
     uint32_t* const aKmers = ldsWords;
     uint32_t* const aSlots = aKmers + NA;
-    uint32_t* const cellKeys = aSlots + NA + wave * cellsWaveLdsWords(int(chunk.scLog2), Q);
-    uint32_t* const cellCnt = cellKeys + SC;
-    uint32_t* const kept = cellCnt + SC;
+    uint32_t* const cells = aSlots + NA + wave * cellsWaveLdsWords(int(chunk.scLog2), Q);
+    uint32_t* const kept = cells + SC;
     uint32_t* const scratch = kept + MAXC;                        // [0] kept count, [1] min, [2] max, [3] staged tasks
     uint32_t* const stage = scratch + 8;
     const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
@@ -449,7 +452,7 @@ align4CellsChunkKernel(
     const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
     const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
     for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
-    if(threadIdx.x == 0) tableOverflow = 0;
+    if(threadIdx.x == 0) stashCount = 0;
     if(lane == 0) scratch[3] = 0;
     __syncthreads();
     for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
@@ -463,7 +466,11 @@ align4CellsChunkKernel(
             const uint32_t u0 = aSlots[2 * b1], u1 = aSlots[2 * b1 + 1], v0 = aSlots[2 * b2], v1 = aSlots[2 * b2 + 1];
             const uint32_t fu0 = zeroHalves(~u0), fu1 = zeroHalves(~u1), fv0 = zeroHalves(~v0), fv1 = zeroHalves(~v1);
             const int freeU = __popc(fu0) + __popc(fu1), freeV = __popc(fv0) + __popc(fv1);
-            if(freeU == 0 && freeV == 0) { tableOverflow = 1; break; }
+            if(freeU == 0 && freeV == 0) {
+                const uint32_t k = atomicAdd(&stashCount, 1u);
+                if(k < STASH) { stashKmer[k] = km; stashOrdinal[k] = t; }
+                break;
+            }
             const bool useV = freeV > freeU;
             const uint32_t f0 = useV ? fv0 : fu0, f1 = useV ? fv1 : fu1;
             const uint32_t w0 = useV ? v0 : u0, w1 = useV ? v1 : u1;
@@ -477,10 +484,11 @@ align4CellsChunkKernel(
     }
     __syncthreads();
     PHASE_MARK(0);
-    if(tableOverflow) {
-        // More than eight markers of the tabled read share both buckets (a tandem repeat): the
-        // whole chunk goes to the next class.
-        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = PAIR_RESOURCE;
+    const uint32_t stashed = stashCount;
+    if(stashed > STASH) {
+        // Too many markers of the tabled read share their buckets (a tandem repeat): the whole
+        // chunk goes to the next class.
+        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x80);
         return;
     }
 
@@ -490,9 +498,9 @@ align4CellsChunkKernel(
         const uint32_t nx = pd.nx, ny = pd.ny;
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
-        int overflow = 0;
+        int overflow = 0, reason = 0;
 
-        for(uint32_t k = lane; k < SC; k += WAVE) { cellKeys[k] = EMPTY32; cellCnt[k] = 0; }
+        for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
         if(lane == 0) scratch[0] = 0;
         waveLdsSync();
         PHASE_MARK(1);
@@ -501,7 +509,7 @@ align4CellsChunkKernel(
         // Counts the hits of one round: hit[u] with table ordinal ti[u] and stream ordinal t.
         auto countHits = [&](const bool (&hit)[CELLS_UNROLL], const uint32_t (&ti)[CELLS_UNROLL], uint32_t s0) {
             bool pending[CELLS_UNROLL];
-            uint32_t key[CELLS_UNROLL], cs[CELLS_UNROLL], len[CELLS_UNROLL], probes[CELLS_UNROLL];
+            uint32_t key[CELLS_UNROLL], packed[CELLS_UNROLL], cs[CELLS_UNROLL], len[CELLS_UNROLL], probes[CELLS_UNROLL];
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
                 const uint32_t t = s0 + u * WAVE + lane;
@@ -510,6 +518,9 @@ align4CellsChunkKernel(
                 const uint32_t iX = divMagic(X, opt.deltaX, magicX), iY = divMagic(Y, opt.deltaY, magicY);
                 bool h = hit[u];
                 if(h && (iX >= 65536u || iY >= 65535u)) { overflow = 2; h = false; }
+                // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; larger geometry
+                // climbs to the HBM-scratch kernel.
+                if(h && (iX >= (1u << CELLS_IX_BITS) || iY >= (1u << CELLS_IY_BITS))) { overflow = max(overflow, 1); reason |= 4; h = false; }
                 key[u] = h ? ((iY << 16) | iX) : EMPTY32;
                 // Fold runs of consecutive lanes with the same cell into their first lane.
                 const uint32_t prevKey = __shfl_up(key[u], 1, WAVE);
@@ -518,6 +529,7 @@ align4CellsChunkKernel(
                 const uint64_t stops = (heads | ~hits) >> 1 >> lane;           // bit k: lane + 1 + k ends the run
                 len[u] = stops ? uint32_t(__ffsll((unsigned long long)stops)) : uint32_t(WAVE - lane);
                 pending[u] = head;
+                packed[u] = (iY << CELLS_IX_BITS) | iX;
                 cs[u] = hash32(key[u]) >> scShift;
                 probes[u] = 0;
             }
@@ -525,17 +537,25 @@ align4CellsChunkKernel(
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) {
                     if(pending[u]) {
-                        const uint32_t old = atomicCAS(&cellKeys[cs[u]], EMPTY32, key[u]);
-                        if(old == EMPTY32 || old == key[u]) {
-                            const uint32_t before = atomicAdd(&cellCnt[cs[u]], len[u]);
+                        const uint32_t cur = *reinterpret_cast<volatile uint32_t*>(&cells[cs[u]]);
+                        bool done = false;
+                        uint32_t before = 0;
+                        if(cur != EMPTY32 && (cur >> CELLS_COUNT_BITS) == packed[u]) {
+                            before = atomicAdd(&cells[cs[u]], len[u]) & ((1u << CELLS_COUNT_BITS) - 1);
+                            done = true;
+                        } else if(cur == EMPTY32) {
+                            // Claim the slot; on failure look at the same slot again.
+                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << CELLS_COUNT_BITS) | len[u]) == EMPTY32;
+                        } else {
+                            cs[u] = (cs[u] + 1) & (SC - 1);
+                            if(++probes[u] == SC) { overflow = max(overflow, 1); reason |= 1; pending[u] = false; }
+                        }
+                        if(done) {
                             if(before < threshold && before + len[u] >= threshold) {           // :417
                                 const uint32_t idx = atomicAdd(&scratch[0], 1u);
                                 if(idx < uint32_t(MAXC)) kept[idx] = key[u];
                             }
                             pending[u] = false;
-                        } else {
-                            cs[u] = (cs[u] + 1) & (SC - 1);
-                            if(++probes[u] == SC) { overflow = max(overflow, 1); pending[u] = false; }
                         }
                     }
                 }
@@ -592,14 +612,27 @@ align4CellsChunkKernel(
                 if(__any(anyHit)) countHits(hit, ti, s0);
                 if(!__any(more)) break;
             }
+            // The few markers that did not fit their buckets.
+            for(uint32_t k = 0; k < stashed; k++) {
+                const uint32_t sk = stashKmer[k], so = stashOrdinal[k];
+                bool anyHit = false;
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
+                if(__any(anyHit)) countHits(hit, ti, s0);
+            }
         }
         waveLdsSync();
         PHASE_MARK(2);
 
         const int n = int(scratch[0]);
-        if(n > MAXC) overflow = max(overflow, 1);
+        if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
         const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
-        if(anyHard || anySoft) { if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : PAIR_RESOURCE; continue; }
+        if(anyHard || anySoft) {
+            // Bits 4-6 carry the reason (cell table full / kept list full / geometry) for diagnostics.
+            const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0);
+            if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
+            continue;
+        }
         if(n == 0) continue;
         const int nq = (n + WAVE - 1) / WAVE;
 
@@ -1347,10 +1380,10 @@ struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; };
 
 constexpr int CELLS_CLASSES = 3;
 constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {11, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
-constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {10, 11, 12};
+constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {11, 12, 12};
 constexpr int CELLS_Q[CELLS_CLASSES] = {2, 4, 4};
-constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {4, 4, 1};   // waves of a chunk that share read 0's table
-constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 8};
+constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {4, 6, 4};   // waves of a chunk that share the tabled read
+constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 16};
 constexpr uint32_t CELLS_SHARE_MIN = 3;                        // smaller chunks run as one wave
 
 // kind 0: one-wave workgroups; kind 1: CELLS_SHARED_WAVES waves share the table.
@@ -1362,10 +1395,10 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
     static bool attributeSet = false;
     if(!attributeSet) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attributeSet = true;
     }
-    MI355X_ASSERT(bytes <= 160 * 1024 - 64);
+    MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
     hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ws.stream,
         (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
         opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
@@ -1565,8 +1598,11 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
             // Class of a candidate: table of the tabled read at load <= 1/2, cell table sized for the
             // expected number of distinct cells (random background ~ nx*ny / alphabet, plus the
             // diagonal) at load <= 3/4.  Overflow is detected on the device and climbs one class.
+            // The packed LDS cell word counts up to 2^CELLS_COUNT_BITS - 1 entries; a cell holds at most
+            // ceil(deltaX * deltaY / 2) (one (x,y) per lattice point of the right parity).
+            const bool packedOk = (uint64_t(opt.deltaX) * opt.deltaY + 1) / 2 < (1ULL << CELLS_COUNT_BITS);
             auto classFor = [&](uint64_t tabled, uint64_t nx, uint64_t ny) -> int {
-                if(nx >= 65535 || ny >= 65535) return CELLS_CLASSES;
+                if(nx >= 65535 || ny >= 65535 || !packedOk) return CELLS_CLASSES;
                 const uint64_t cells = (nx * ny >> 13) + (nx + ny) / 32 + 32;
                 for(int c = 0; c < CELLS_CLASSES; c++) {
                     if(tabled < (1ULL << CELLS_NA_LOG2[c]) && 4 * cells <= (3ULL << CELLS_SC_LOG2[c])) return c;
@@ -1659,8 +1695,10 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
                 HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
                 bool retry = false;
+                uint64_t reasonHistogram[16] = {0};
                 for(uint32_t k = 0; k < n; k++) {
-                    if(hostFlags[k] != PAIR_RESOURCE) continue;
+                    if((hostFlags[k] & 0x0f) != PAIR_RESOURCE) continue;
+                    if(debug) ++reasonHistogram[hostFlags[k] >> 4];
                     retry = true;
                     hostFlags[k] = 0;
                     // Retry alone in the next class whose table holds one of the two reads
@@ -1679,7 +1717,9 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
                 if(!retry) break;
                 if(debug) {
                     for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: round %d retries -> class %d: %zu\n", round, c, classChunks[c][0].size());
-                    std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu\n", round, bigList.size());
+                    std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu; reasons cell-table %llu kept-list %llu geometry %llu both %llu tabled-read %llu\n", round, bigList.size(),
+                        (unsigned long long)reasonHistogram[1], (unsigned long long)reasonHistogram[2], (unsigned long long)reasonHistogram[4],
+                        (unsigned long long)(reasonHistogram[3] + reasonHistogram[5] + reasonHistogram[6] + reasonHistogram[7]), (unsigned long long)reasonHistogram[8]);
                 }
                 HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
             }
