@@ -243,6 +243,12 @@ int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx*, shasta_mi355x_kernel_time
 /* Unit seams used by the parity tests                                        */
 /* ------------------------------------------------------------------------- */
 
+/* Profiling aid, no counterpart in the reference: moves exactly `bytes` through HBM with the
+ * access pattern of the window-hash kernel (mode 0: dword reads) or of the DP trace (mode 1:
+ * 8-byte record stores), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known
+ * byte count (MI355X_MICROARCH.md, HBM section). */
+int shasta_mi355x_calibrate(uint64_t bytes, int mode);
+
 /* MurmurHash64A (src/MurmurHash2.cpp:96-140) of every window of m kmer ids,
  * seed = 37*iteration: out[i] for i in [0, n-m+1).  Device computes; host
  * pointers in and out. */

@@ -872,7 +872,7 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
         ids[t] = t;
         ordCap[t] = min(pd.nx, pd.ny);
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
-        words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls));
+        words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls)) + 32;
     } else if(t == taskCount) {
         ordCap[t] = 0;
     }
@@ -900,7 +900,9 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
     const uint32_t T = 64u / uint32_t(dpLanes(cls));
     const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
     const uint32_t last = min(first + T, layout.taskStart[cls + 1]) - 1;
-    bundleWords[bundle] = uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls));   // sorted ascending
+    // sorted ascending: the last task has the most iterations.  Rounded to 256 bytes so that the
+    // traceback's chunks are whole cache lines.
+    bundleWords[bundle] = (uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
 }
 
 template<int G, int C>
@@ -1035,7 +1037,12 @@ bandedDpForwardKernel(
     }
 }
 
-// One lane per task: walk the path from the end cell through the packed trace.
+// One lane per task: walk the path from the end cell through the packed trace.  The trace is
+// consumed in chunks of CW words (128 or 256 bytes, whole cache lines): the chunk under the
+// path sits in the lane's private LDS window, the next one (the path only moves towards smaller
+// anti-diagonals) is already in flight in registers, so every line is fetched once and its
+// latency is covered by the walk through the previous chunk.
+template<int CW>
 __global__ void __launch_bounds__(256)
 dpTracebackKernel(
     const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
@@ -1043,6 +1050,8 @@ dpTracebackKernel(
     const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
     DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
 {
+    constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
+    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if(idx >= taskCount) return;
     const uint32_t t = sortedIds[idx];
@@ -1052,7 +1061,8 @@ dpTracebackKernel(
     const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
     const int C = dpDiagonals(geo.cls);
     const uint32_t RW = uint32_t(2 * C);
-    const uint64_t* __restrict__ tr = trace + e.traceOffset;
+    const uint32_t itersPerChunk = uint32_t(CW) / RW;
+    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);
     uint32_t count = 0, prevX = 0, prevY = 0, last0 = 0, last1 = 0, first0 = 0, first1 = 0, maxSkip = 0, maxDrift = 0;
@@ -1060,35 +1070,57 @@ dpTracebackKernel(
     long long sumOffset = 0;
     int32_t i = e.bestI, j = e.bestJ;
     const bool ok = e.score > NEG_SCORE;
-    while(ok && i > 0 && j > 0) {
-        const int32_t b = i - j - task.bandMin;
-        const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
-        const uint32_t c = uint32_t(b) % uint32_t(C), bit = e.laneBase + uint32_t(b) / uint32_t(C);
-        const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(tr + uint64_t(it) * RW + 2 * c);
-        const uint32_t dir = uint32_t((w.x >> bit) & 1ULL) | (uint32_t((w.y >> bit) & 1ULL) << 1);
-        if(dir == 0u) {
-            // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
-            const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
-            --pos;
-            *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(x, y);
-            const int32_t offset = int32_t(x) - int32_t(y);
-            if(count == 0) { last0 = x; last1 = y; }
-            else {
-                maxSkip = max(maxSkip, max(prevX - x, prevY - y));
-                const int32_t prevOffset = int32_t(prevX) - int32_t(prevY);
-                const int32_t drift = offset - prevOffset;
-                maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
+    // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
+    // the same point of the program, then walks until its path leaves the chunk.  The wave waits
+    // for memory once per epoch, for loads issued a whole epoch earlier.
+    bool active = ok && i > 0 && j > 0;
+    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) / itersPerChunk) : -1;
+    uint4 next[QUADS];
+#pragma unroll
+    for(int k = 0; k < QUADS; k++) next[k] = active ? tr[chunk * QUADS + k] : make_uint4(0, 0, 0, 0);
+    while(__any(active)) {
+        if(active) {
+#pragma unroll
+            for(int k = 0; k < QUADS; k++) window[k * 256 + threadIdx.x] = next[k];
+            if(chunk > 0) {
+#pragma unroll
+                for(int k = 0; k < QUADS; k++) next[k] = tr[(chunk - 1) * QUADS + k];
             }
-            minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
-            sumOffset += offset;
-            first0 = x; first1 = y; prevX = x; prevY = y;
-            ++count;
-            --i; --j;
-        } else if(dir == 1u) { --i; --j; }
-        else if(dir == 2u) { --j; }
-        else { --i; }
+        }
+        while(active) {
+            const int32_t b = i - j - task.bandMin;
+            const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
+            if(int64_t(it / itersPerChunk) != chunk) break;
+            const uint32_t c = uint32_t(b) % uint32_t(C), bit = e.laneBase + uint32_t(b) / uint32_t(C);
+            const uint32_t word = (it % itersPerChunk) * RW + 2 * c;           // even: one 16-byte piece
+            const uint4 w = window[(word >> 1) * 256 + threadIdx.x];
+            const uint64_t lo = uint64_t(w.x) | (uint64_t(w.y) << 32), hi = uint64_t(w.z) | (uint64_t(w.w) << 32);
+            const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
+            if(dir == 0u) {
+                // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
+                const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
+                --pos;
+                *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(x, y);
+                const int32_t offset = int32_t(x) - int32_t(y);
+                if(count == 0) { last0 = x; last1 = y; }
+                else {
+                    maxSkip = max(maxSkip, max(prevX - x, prevY - y));
+                    const int32_t prevOffset = int32_t(prevX) - int32_t(prevY);
+                    const int32_t drift = offset - prevOffset;
+                    maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
+                }
+                minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
+                sumOffset += offset;
+                first0 = x; first1 = y; prevX = x; prevY = y;
+                ++count;
+                --i; --j;
+            } else if(dir == 1u) { --i; --j; }
+            else if(dir == 2u) { --j; }
+            else { --i; }
+            active = i > 0 && j > 0;
+        }
+        --chunk;
     }
-
     DpResult r;
     r.ordBegin = ordBase + pos;
     r.sumOffset = sumOffset;
@@ -1481,10 +1513,18 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     launchDpForward<64, 4>(ctx, ws, b, sortedIds, layout, 3);
     launchDpForward<64, 8>(ctx, ws, b, sortedIds, layout, 4);
     launchDpForward<64, 16>(ctx, ws, b, sortedIds, layout, 5);
-    hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
-        (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds, taskCount,
-        (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
-        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
+    {
+        // 256-byte chunks (8 iterations of the narrow classes); class 5 holds one iteration per chunk.
+        const uint32_t small = 0, large = taskCount - small;
+        if(small) hipLaunchKernelGGL(dpTracebackKernel<16>, dim3(divUp(small, 256)), dim3(256), 0, stream,
+            (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds, small,
+            (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
+            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
+        if(large) hipLaunchKernelGGL(dpTracebackKernel<32>, dim3(divUp(large, 256)), dim3(256), 0, stream,
+            (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds + small, large,
+            (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
+            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
+    }
     HIP_CHECK(hipGetLastError());
     if(evB) HIP_CHECK(hipEventRecord(evB, stream));
     if(launches) { *launches = 1; for(int c = 0; c < DP_CLASSES; c++) *launches += classCounts[c] ? 1 : 0; }

@@ -138,6 +138,14 @@ int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx* c, shasta_mi355x_kernel_ti
     API_END(1)
 }
 
+int shasta_mi355x_calibrate(uint64_t bytes, int mode)
+{
+    API_BEGIN
+    calibrateUnit(bytes, mode);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_hash_windows(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out)
 {
     API_BEGIN

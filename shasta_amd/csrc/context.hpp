@@ -54,6 +54,7 @@ void lowhash0Free(shasta_lowhash0_result&);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&);
 void align4Free(shasta_align4_result&);
+void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);
 void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
     uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score);

@@ -744,6 +744,46 @@ void lowhash0Free(shasta_lowhash0_result& r)
     std::memset(&r, 0, sizeof(r));
 }
 
+// ---------------------------------------------------------------------------
+// PMC calibration (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE must be calibrated
+// on a known byte count in the kernel's own access pattern).  Reads `bytes` with the hash
+// kernel's pattern (one dword per lane, 256-marker tiles) or writes `bytes` with the DP trace's
+// pattern (four lanes of a wave store 8 bytes each per record).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+calibrateReadDwordKernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out)
+{
+    uint32_t acc = 0;
+    for(uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) acc ^= in[i];
+    if(acc == 0x12345678u) out[0] = acc;      // keeps the loads alive; practically never true
+}
+
+__global__ void __launch_bounds__(256)
+calibrateWriteRecordKernel(uint64_t* __restrict__ out, uint64_t records)
+{
+    const uint64_t wave = (uint64_t(blockIdx.x) * 256 + threadIdx.x) >> 6, waves = (uint64_t(gridDim.x) * 256) >> 6;
+    const int lane = int(threadIdx.x) & 63;
+    for(uint64_t r = wave; r < records; r += waves) if(lane < 4) out[4 * r + lane] = r + lane;
+}
+
+void calibrateUnit(uint64_t bytes, int mode)
+{
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    if(count == 0) throw std::runtime_error("shasta_mi355x: no HIP device.");
+    DeviceBuffer<uint32_t> buffer;
+    buffer.reserve(bytes / 4 + 64);
+    HIP_CHECK(hipMemset(buffer.data(), 1, bytes));
+    HIP_CHECK(hipDeviceSynchronize());
+    if(mode == 0) {
+        hipLaunchKernelGGL(calibrateReadDwordKernel, dim3(2048), dim3(256), 0, nullptr, (const uint32_t*)buffer.data(), bytes / 4, buffer.data() + bytes / 4);
+    } else {
+        hipLaunchKernelGGL(calibrateWriteRecordKernel, dim3(2048), dim3(256), 0, nullptr, reinterpret_cast<uint64_t*>(buffer.data()), bytes / 32);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+}
+
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out)
 {
     if(m == 0 || m > HASH_HALO + 1) throw std::runtime_error("hash_windows: m must be in [1, 33].");

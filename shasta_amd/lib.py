@@ -22,7 +22,7 @@ EXPORTS = [
     "shasta_mi355x_create", "shasta_mi355x_destroy",
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids", "shasta_mi355x_set_shard",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_get_kernel_times",
-    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp",
+    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate",
 ]
 
 
@@ -106,6 +106,9 @@ class Library:
             C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
             C.byref(count), C.byref(score)), "shasta_mi355x_banded_dp")
         return out[:count.value].copy(), score.value
+
+    def calibrate(self, nbytes, mode):
+        self._check(self.lib.shasta_mi355x_calibrate(C.c_uint64(nbytes), C.c_int(mode)), "shasta_mi355x_calibrate")
 
     def context(self, device=0):
         return Context(self, device)
