@@ -208,6 +208,12 @@ int shasta_mi355x_set_kmer_ids(
     shasta_mi355x_ctx*, uint64_t readCount,
     const uint64_t* markersToc, const uint32_t* kmerIds, const uint8_t* readFlags);
 
+/* Same, with the dense kmer ids already in HBM on this context's device (e.g. the output of
+ * an all-gather of the ranks' shards). */
+int shasta_mi355x_set_kmer_ids_device(
+    shasta_mi355x_ctx*, uint64_t readCount,
+    const uint64_t* markersToc, const void* kmerIdsDevice, const uint8_t* readFlags);
+
 /* Restricts the reads this context hashes / owns to [readBegin, readEnd) and
  * the buckets it owns to rank `rank` of `worldSize` (multi-GPU sharding,
  * SURVEY section 8e).  Default: everything, rank 0 of 1. */
@@ -225,6 +231,46 @@ int shasta_mi355x_align4_run(
     const shasta_oriented_read_pair* candidates,
     const shasta_align4_options* options, int wantOrdinals,
     shasta_align4_result* result);
+
+/* -------------------------------------------------------------------------
+ * LowHash0 in stages, for one job sharded over several GPUs.
+ * One process per GPU; every rank holds all markers (set_markers / set_kmer_ids*), hashes the
+ * reads of its own range, owns the bucket ids [rank, rank+1) * 2^log2 / worldSize and the pair
+ * keys whose readId0 lies in its read range.  Between the stages the CALLER moves data between
+ * ranks (RCCL all-to-all over xGMI in shasta_amd/distributed.py); this library never talks to
+ * another process.  Pointers named *Device are device memory of this context's GPU, valid until
+ * the next stage call.  readBoundaries has worldSize+1 read ids, [0 .. readCount].
+ *   lh_begin   -> log2BucketCount
+ *   per iteration (same iteration control as src/LowHash0.cpp:136-157, on all-reduced counts):
+ *     lh_hash     K1+K2: records {bucketId u32} / {hashHigh:32 | orientedReadId:32 u64}, sorted by
+ *                 bucket id; sendOffsets[r..r+1] = the records rank r owns
+ *       -- all-to-all of records --
+ *     lh_buckets  K3-K5a on the n received records: statistics (partial sums kept on the device),
+ *                 bucket-size histogram bins [0,2048) + list of larger sizes, bucketsUsed, and the
+ *                 run-length encoded pair keys {key u64}/{count u32}, sorted; sendOffsets by owner
+ *                 of readId0
+ *       -- all-to-all of runs --
+ *     lh_merge    K5b: fold the n received runs into this rank's pair table; this rank's share of
+ *                 the iteration's "high frequency" and "total" counters (all-reduce them)
+ *   lh_finish  K6: this rank's candidates (sorted; concatenating the ranks in order gives the
+ *              reference's order) -- free with shasta_mi355x_free -- and its partial
+ *              readLowHashStatistics[readCount*3] (all-reduce them).
+ * ------------------------------------------------------------------------- */
+#define SHASTA_MI355X_SIZE_HISTOGRAM_BINS 2048
+int shasta_mi355x_lh_begin(shasta_mi355x_ctx*, const shasta_lowhash0_params* params, int rank, int worldSize,
+    const uint64_t* readBoundaries, uint32_t* log2BucketCount);
+int shasta_mi355x_lh_hash(shasta_mi355x_ctx*, uint64_t iteration, uint64_t* sendOffsets,
+    const void** keysDevice, const void** valsDevice);
+int shasta_mi355x_lh_buckets(shasta_mi355x_ctx*, const void* keysDevice, const void* valsDevice, uint64_t n,
+    uint64_t* sendOffsets, const void** runKeysDevice, const void** runCountsDevice, uint64_t* bucketsUsed,
+    uint64_t* sizeHistogram, uint32_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount);
+int shasta_mi355x_lh_merge(shasta_mi355x_ctx*, const void* runKeysDevice, const void* runCountsDevice, uint64_t n,
+    uint64_t* highFrequency, uint64_t* tableSize);
+int shasta_mi355x_lh_finish(shasta_mi355x_ctx*, uint64_t* readLowHashStatistics,
+    shasta_oriented_read_pair** candidates, uint64_t* candidateCount);
+void shasta_mi355x_free(void*);
+/* Synchronous copy on the context's stream; kind 0 host->device, 1 device->host, 2 device->device. */
+int shasta_mi355x_memcpy(shasta_mi355x_ctx*, void* dst, const void* src, uint64_t bytes, int kind);
 
 /* Timing of the dominant kernels of the last *_run call on this context,
  * measured with HIP events on the context's stream. */

@@ -2,7 +2,9 @@
 // the boundary: every entry point returns non-zero and records the message.
 #include "context.hpp"
 
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <string>
 
 using namespace shasta_mi355x;
@@ -60,6 +62,94 @@ int shasta_mi355x_set_kmer_ids(shasta_mi355x_ctx* c, uint64_t readCount,
     return 0;
     API_END(1)
 }
+
+int shasta_mi355x_set_kmer_ids_device(shasta_mi355x_ctx* c, uint64_t readCount,
+    const uint64_t* markersToc, const void* kmerIdsDevice, const uint8_t* readFlags)
+{
+    API_BEGIN
+    if(!c || !markersToc || (!kmerIdsDevice && markersToc[2 * readCount])) throw std::runtime_error("set_kmer_ids_device: null argument");
+    c->impl.setMarkers(readCount, markersToc, nullptr, static_cast<const uint32_t*>(kmerIdsDevice), readFlags, true);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_memcpy(shasta_mi355x_ctx* c, void* dst, const void* src, uint64_t bytes, int kind)
+{
+    API_BEGIN
+    if(!c) throw std::runtime_error("memcpy: null context");
+    HIP_CHECK(hipSetDevice(c->impl.device));
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    if(bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, k, c->impl.stream));
+    HIP_CHECK(hipStreamSynchronize(c->impl.stream));
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_begin(shasta_mi355x_ctx* c, const shasta_lowhash0_params* params, int rank, int worldSize,
+    const uint64_t* readBoundaries, uint32_t* log2BucketCount)
+{
+    API_BEGIN
+    if(!c || !params || !readBoundaries) throw std::runtime_error("lh_begin: null argument");
+    lowhash0Begin(c->impl, *params, rank, worldSize, readBoundaries, log2BucketCount);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_hash(shasta_mi355x_ctx* c, uint64_t iteration, uint64_t* sendOffsets, const void** keysDevice, const void** valsDevice)
+{
+    API_BEGIN
+    if(!c || !sendOffsets || !keysDevice || !valsDevice) throw std::runtime_error("lh_hash: null argument");
+    const uint32_t* k = nullptr; const uint64_t* v = nullptr;
+    lowhash0Hash(c->impl, iteration, sendOffsets, &k, &v);
+    *keysDevice = k; *valsDevice = v;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_buckets(shasta_mi355x_ctx* c, const void* keysDevice, const void* valsDevice, uint64_t n,
+    uint64_t* sendOffsets, const void** runKeysDevice, const void** runCountsDevice, uint64_t* bucketsUsed,
+    uint64_t* sizeHistogram, uint32_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount)
+{
+    API_BEGIN
+    if(!c || !sendOffsets || !runKeysDevice || !runCountsDevice || !bucketsUsed || !sizeHistogram || !overflowCount) throw std::runtime_error("lh_buckets: null argument");
+    const uint64_t* rk = nullptr; const uint32_t* rc = nullptr;
+    std::vector<uint32_t> overflow;
+    lowhash0Buckets(c->impl, static_cast<const uint32_t*>(keysDevice), static_cast<const uint64_t*>(valsDevice), n,
+        sendOffsets, &rk, &rc, bucketsUsed, sizeHistogram, overflow);
+    if(overflow.size() > overflowCapacity) throw std::runtime_error("lh_buckets: overflow list capacity too small");
+    if(!overflow.empty()) std::memcpy(overflowSizes, overflow.data(), overflow.size() * 4);
+    *overflowCount = overflow.size();
+    *runKeysDevice = rk; *runCountsDevice = rc;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_merge(shasta_mi355x_ctx* c, const void* runKeysDevice, const void* runCountsDevice, uint64_t n,
+    uint64_t* highFrequency, uint64_t* tableSize)
+{
+    API_BEGIN
+    if(!c || !highFrequency || !tableSize) throw std::runtime_error("lh_merge: null argument");
+    lowhash0Merge(c->impl, static_cast<const uint64_t*>(runKeysDevice), static_cast<const uint32_t*>(runCountsDevice), n, highFrequency, tableSize);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_finish(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistics,
+    shasta_oriented_read_pair** candidates, uint64_t* candidateCount)
+{
+    API_BEGIN
+    if(!c || !readLowHashStatistics || !candidates || !candidateCount) throw std::runtime_error("lh_finish: null argument");
+    std::vector<shasta_oriented_read_pair> v;
+    lowhash0Finish(c->impl, readLowHashStatistics, v);
+    shasta_oriented_read_pair* p = static_cast<shasta_oriented_read_pair*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(shasta_oriented_read_pair)));
+    if(!p) throw std::bad_alloc();
+    if(!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(shasta_oriented_read_pair));
+    *candidates = p; *candidateCount = v.size();
+    return 0;
+    API_END(1)
+}
+
+void shasta_mi355x_free(void* p) { std::free(p); }
 
 int shasta_mi355x_set_shard(shasta_mi355x_ctx* c, int rank, int worldSize, uint64_t readBegin, uint64_t readEnd)
 {

@@ -34,6 +34,7 @@ struct Context {
     RadixSortWorkspace sortWs, sortWs2;
     hipStream_t stream2 = nullptr;           // second worker of the Align4 stage
     std::shared_ptr<void> alignScratch[2];   // grow-only batch scratch of the two workers
+    std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress (staged / multi-GPU API)
     shasta_mi355x_kernel_times times = {};
 
     // Sorted markers (Assembler::computeSortedMarkers, src/AssemblerAlign4.cpp:190-261),
@@ -45,12 +46,20 @@ struct Context {
     explicit Context(int device);
     ~Context();
     void setMarkers(uint64_t readCount, const uint64_t* toc, const void* data7,
-        const uint32_t* denseKmerIds, const uint8_t* flags);
+        const uint32_t* denseKmerIds, const uint8_t* flags, bool denseOnDevice = false);
 };
 
 // Stage entry points (lowhash0.hip, align4.hip).
 void lowhash0Run(Context&, const shasta_lowhash0_params&, uint64_t* readLowHashStatistics, shasta_lowhash0_result&);
 void lowhash0Free(shasta_lowhash0_result&);
+// Staged form of the same job (one GPU or one rank of several); device pointers in and out.
+constexpr int LOWHASH0_SIZE_HISTOGRAM_BINS = 2048;
+void lowhash0Begin(Context&, const shasta_lowhash0_params&, int rank, int world, const uint64_t* readBoundaries, uint32_t* log2BucketCount);
+void lowhash0Hash(Context&, uint64_t iteration, uint64_t* sendOffsets, const uint32_t** keys, const uint64_t** vals);
+void lowhash0Buckets(Context&, const uint32_t* keys, const uint64_t* vals, uint64_t n, uint64_t* sendOffsets,
+    const uint64_t** runKeys, const uint32_t** runCounts, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint32_t>& overflow);
+void lowhash0Merge(Context&, const uint64_t* runKeys, const uint32_t* runCounts, uint64_t n, uint64_t* highFrequency, uint64_t* tableSize);
+void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&);
 void align4Free(shasta_align4_result&);

@@ -383,13 +383,13 @@ Context::Context(int deviceArg) : device(deviceArg)
 Context::~Context()
 {
     (void)hipSetDevice(device);
-    alignScratch[0].reset(); alignScratch[1].reset();
+    alignScratch[0].reset(); alignScratch[1].reset(); lowhashJob.reset();
     if(stream2) (void)hipStreamDestroy(stream2);
     if(stream) (void)hipStreamDestroy(stream);
 }
 
 void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const void* data7,
-    const uint32_t* denseKmerIds, const uint8_t* flags)
+    const uint32_t* denseKmerIds, const uint8_t* flags, bool denseOnDevice)
 {
     HIP_CHECK(hipSetDevice(device));
     MI355X_ASSERT(readCountArg < (1ULL << 31));
@@ -411,7 +411,8 @@ void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const vo
     kmerIds.reserve(markerCount + HASH_TILE + HASH_HALO, stream);
     if(markerCount) {
         if(denseKmerIds) {
-            HIP_CHECK(hipMemcpyAsync(kmerIds.data(), denseKmerIds, markerCount * 4, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(kmerIds.data(), denseKmerIds, markerCount * 4,
+                denseOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         } else {
             DeviceBuffer<uint32_t> packed;
             const uint64_t words = (7 * markerCount + 3) / 4 + 2;
@@ -482,6 +483,375 @@ void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uin
 
 }  // namespace
 
+// first index i in [0, n] with keys[i] >= bounds[k], for every k (keys sorted ascending).
+template<class K>
+__global__ void __launch_bounds__(64)
+lowerBoundsKernel(const K* __restrict__ keys, uint64_t n, const K* __restrict__ bounds, uint32_t count, uint64_t* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= count) return;
+    const K bound = bounds[k];
+    uint64_t lo = 0, hi = n;
+    while(lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if(keys[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    out[k] = lo;
+}
+
+// ---------------------------------------------------------------------------
+// The LowHash0 job: the state of one LowHash0::LowHash0 call, advanced in stages so that the
+// same code runs on one GPU (lowhash0Run) and sharded over several (each rank hashes
+// its own reads, owns a contiguous range of bucket ids and of readId0; the two exchange steps
+// happen between the stages, in the caller).
+//   hash(iteration)            K1 on the rank's reads, records sorted by bucket id, split by bucket owner
+//   buckets(records)           K2-K5a on the records this rank owns: statistics, histogram, pair keys,
+//                              sorted + run-length encoded, split by owner of readId0
+//   merge(pairs)               K5b: fold the (key, count) runs this rank owns into its pair table
+//   finish()                   K6: candidates of the rank's readId0 range, statistics (partial sums)
+// ---------------------------------------------------------------------------
+struct LowHash0Job {
+    shasta_lowhash0_params p;
+    int rank = 0, world = 1;
+    std::vector<uint64_t> boundaries;       // world + 1 read ids: rank r owns readId0 in [boundaries[r], boundaries[r+1])
+    uint64_t log2BucketCount = 0, bucketCount = 0, hashThreshold = 0;
+    uint32_t mask = 0, minFrequency = 0;
+    int readBits = 0, pairKeyBits = 0;
+    uint64_t markerBegin = 0, markerEnd = 0;
+    uint64_t recCapacity = 0, tableSize = 0;
+    DeviceBuffer<uint32_t> recKeysA, recKeysB, flags, pos, starts, scanTemp32, overflowSizes, boundKeys32;
+    DeviceBuffer<uint64_t> recValsA, recValsB, pairCounts, scanTemp64, pairKeysA, pairKeysB, tableKeysA, tableKeysB, runKeys, boundKeys64, boundOut;
+    DeviceBuffer<uint32_t> tableCountsA, tableCountsB, runCounts;
+    DeviceBuffer<unsigned long long> scalars, stats, sizeHist;
+    DeviceBuffer<shasta_oriented_read_pair> candidatesDevice;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hashEvents;
+    std::vector<uint64_t> hashRecords;
+    static constexpr uint32_t overflowCapacity = 1 << 20;
+    ~LowHash0Job() { for(auto& e : hashEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+};
+
+namespace {
+LowHash0Job& jobOf(Context& ctx)
+{
+    if(!ctx.lowhashJob) throw std::runtime_error("LowHash0: no job in progress (call begin first).");
+    return *static_cast<LowHash0Job*>(ctx.lowhashJob.get());
+}
+}  // namespace
+
+void lowhash0Begin(Context& ctx, const shasta_lowhash0_params& p, int rank, int world, const uint64_t* readBoundaries, uint32_t* log2BucketCountOut)
+{
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const uint64_t readCount = ctx.readCount;
+    const uint64_t M = ctx.markerCount;
+    if(p.m == 0 || p.m > HASH_HALO + 1) throw std::runtime_error("LowHash0: m must be in [1, 33].");
+    if(readCount == 0) throw std::runtime_error("LowHash0: no reads.");
+    if(world < 1 || rank < 0 || rank >= world) throw std::runtime_error("LowHash0: invalid rank / world size.");
+    auto jobPtr = std::make_shared<LowHash0Job>();
+    LowHash0Job& job = *jobPtr;
+    job.p = p; job.rank = rank; job.world = world;
+    job.boundaries.assign(size_t(world) + 1, 0);
+    if(readBoundaries) job.boundaries.assign(readBoundaries, readBoundaries + world + 1);
+    else { MI355X_ASSERT(world == 1); job.boundaries[0] = 0; job.boundaries[1] = readCount; }
+    MI355X_ASSERT(job.boundaries[0] == 0 && job.boundaries[world] == readCount);
+    for(int r = 0; r < world; r++) MI355X_ASSERT(job.boundaries[r] <= job.boundaries[r + 1]);
+
+    // Bucket count, src/LowHash0.cpp:73-98 (from the marker count of ALL reads).
+    const uint64_t estimate = uint64_t(p.hashFraction * double(M));
+    const uint32_t log2Estimate = estimate ? 64 - uint32_t(__builtin_clzl(estimate)) : 0;
+    uint64_t log2BucketCount = p.log2MinHashBucketCount;
+    if(log2BucketCount == 0) log2BucketCount = 5 + log2Estimate;
+    else if(log2BucketCount < log2Estimate) throw std::runtime_error("log2MinHashBucketCount is unreasonably small.");
+    if(log2BucketCount > 31) log2BucketCount = 31;
+    job.log2BucketCount = log2BucketCount;
+    job.bucketCount = 1ULL << log2BucketCount;
+    job.mask = uint32_t(job.bucketCount - 1);
+    // :109
+    job.hashThreshold = uint64_t(double(p.hashFraction) * double(std::numeric_limits<uint64_t>::max()));
+    job.readBits = bitsFor(readCount - 1);
+    job.pairKeyBits = 2 * job.readBits + 1;
+    job.minFrequency = uint32_t(std::min<uint64_t>(p.minFrequency, 0x10000));   // frequency is uint16
+    // This rank hashes the reads of its own range.
+    job.markerBegin = ctx.hostToc[2 * job.boundaries[rank]];
+    job.markerEnd = ctx.hostToc[2 * job.boundaries[rank + 1]];
+    job.recCapacity = std::max<uint64_t>(1 << 16, uint64_t(2.0 * p.hashFraction * double(job.markerEnd - job.markerBegin)) + (1 << 16));
+
+    job.scalars.reserve(8, stream);
+    job.stats.reserve(3 * readCount, stream);
+    job.sizeHist.reserve(SIZE_HIST_CAP, stream);
+    job.overflowSizes.reserve(LowHash0Job::overflowCapacity + 1, stream);
+    job.boundKeys32.reserve(size_t(world) + 1, stream); job.boundKeys64.reserve(size_t(world) + 1, stream);
+    job.boundOut.reserve(size_t(world) + 1, stream);
+    HIP_CHECK(hipMemsetAsync(job.stats.data(), 0, 3 * readCount * sizeof(unsigned long long), stream));
+    // Split keys: first bucket id of every bucket owner, first pair key of every readId0 owner.
+    std::vector<uint32_t> b32(size_t(world) + 1);
+    std::vector<uint64_t> b64(size_t(world) + 1);
+    for(int r = 0; r <= world; r++) {
+        const uint64_t firstBucket = (uint64_t(r) * job.bucketCount + uint64_t(world) - 1) / uint64_t(world);
+        b32[r] = uint32_t(std::min<uint64_t>(firstBucket, 0xffffffffULL));
+        b64[r] = job.boundaries[r] << (job.readBits + 1);
+    }
+    HIP_CHECK(hipMemcpyAsync(job.boundKeys32.data(), b32.data(), b32.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(job.boundKeys64.data(), b64.data(), b64.size() * 8, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    ctx.lowhashJob = jobPtr;
+    if(log2BucketCountOut) *log2BucketCountOut = uint32_t(log2BucketCount);
+}
+
+// Stage 1.  sendOffsets[r..r+1] delimit the records owned by rank r in (*keys, *vals).
+void lowhash0Hash(Context& ctx, uint64_t iteration, uint64_t* sendOffsets, const uint32_t** keysOut, const uint64_t** valsOut)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    unsigned long long* counter = job.scalars.data();
+    uint64_t n = 0;
+    for(;;) {
+        job.recKeysA.reserve(job.recCapacity, stream); job.recKeysB.reserve(job.recCapacity, stream);
+        job.recValsA.reserve(job.recCapacity, stream); job.recValsB.reserve(job.recCapacity, stream);
+        HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+        hipEvent_t a, b;
+        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, stream));
+        launchHash(ctx, uint32_t(job.p.m), iteration * 37, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
+            job.recKeysA.data(), job.recValsA.data(), counter, job.recCapacity);
+        HIP_CHECK(hipEventRecord(b, stream));
+        job.hashEvents.push_back(std::make_pair(a, b));
+        n = readDevice(counter, stream);
+        job.hashRecords.push_back(std::min(n, job.recCapacity));
+        if(n <= job.recCapacity) break;
+        job.recCapacity = n + n / 4;           // estimate was too small: grow and redo this iteration
+    }
+    MI355X_ASSERT(n < (1ULL << 32) - 1);
+    // K2: bucket the records (radix partition on the bucket id); bucket owners are contiguous.
+    const uint32_t* keys = job.recKeysA.data(); const uint64_t* vals = job.recValsA.data();
+    if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
+        n, int(job.log2BucketCount), ctx.sortWs, stream)) {
+        keys = job.recKeysB.data(); vals = job.recValsB.data();
+    }
+    if(job.world == 1) {
+        sendOffsets[0] = 0; sendOffsets[1] = n;
+    } else {
+        hipLaunchKernelGGL(lowerBoundsKernel<uint32_t>, dim3(divUp(uint64_t(job.world) + 1, 64)), dim3(64), 0, stream,
+            keys, n, (const uint32_t*)job.boundKeys32.data(), uint32_t(job.world + 1), job.boundOut.data());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(sendOffsets, job.boundOut.data(), (size_t(job.world) + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        sendOffsets[0] = 0; sendOffsets[job.world] = n;     // the last bound may exceed 32 bits when log2 = 32 is approached
+    }
+    *keysOut = keys; *valsOut = vals;
+}
+
+// Stage 2.  (keys, vals): the n records of the buckets this rank owns (device pointers; any
+// order when world > 1).  Produces the run-length encoded pair keys, split by owner of readId0.
+void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsIn, uint64_t n,
+    uint64_t* sendOffsets, const uint64_t** runKeysOut, const uint32_t** runCountsOut,
+    uint64_t* bucketsUsedOut, uint64_t* sizeHistogramOut /*SIZE_HIST_CAP*/, std::vector<uint32_t>& overflowOut)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const shasta_lowhash0_params& p = job.p;
+    MI355X_ASSERT(n < (1ULL << 32) - 1);
+    const uint32_t* keys = keysIn; const uint64_t* vals = valsIn;
+    if(job.world > 1 && n) {
+        // Concatenation of one sorted run per sender: sort again.
+        job.recKeysA.reserve(n, stream); job.recKeysB.reserve(n, stream); job.recValsA.reserve(n, stream); job.recValsB.reserve(n, stream);
+        if(keysIn != job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 4, hipMemcpyDeviceToDevice, stream));
+        if(valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
+        keys = job.recKeysA.data(); vals = job.recValsA.data();
+        if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
+            n, int(job.log2BucketCount), ctx.sortWs, stream)) {
+            keys = job.recKeysB.data(); vals = job.recValsB.data();
+        }
+    }
+
+    // K3: bucket boundaries, statistics, histogram, pair counts.
+    uint64_t bucketsUsed = 0, pairCount = 0;
+    uint32_t* overflowCount = job.overflowSizes.data() + LowHash0Job::overflowCapacity;
+    HIP_CHECK(hipMemsetAsync(job.sizeHist.data(), 0, SIZE_HIST_CAP * sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(overflowCount, 0, 4, stream));
+    if(n) {
+        job.flags.reserve(n + 1, stream); job.pos.reserve(n + 1, stream); job.starts.reserve(n + 2, stream);
+        job.scanTemp32.reserve(scanTempElements(n + 1), stream);
+        job.pairCounts.reserve(n + 1, stream); job.scanTemp64.reserve(scanTempElements(n + 1), stream);
+        const unsigned g = divUp(n + 1, 256);
+        hipLaunchKernelGGL(markHeadsKernel<uint32_t>, dim3(g), dim3(256), 0, stream, keys, n, job.flags.data());
+        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), n + 1, job.scanTemp32.data(), stream);
+        hipLaunchKernelGGL(groupStartsKernel<uint32_t>, dim3(g), dim3(256), 0, stream,
+            keys, (const uint32_t*)job.pos.data(), n, job.starts.data());
+        hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
+            keys, vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), n,
+            p.minBucketSize, p.maxBucketSize, job.stats.data(), job.sizeHist.data(),
+            job.overflowSizes.data(), overflowCount, LowHash0Job::overflowCapacity, job.pairCounts.data());
+        exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), n + 1, job.scanTemp64.data(), stream);
+        HIP_CHECK(hipGetLastError());
+        bucketsUsed = readDevice(job.pos.data() + n, stream);
+        pairCount = readDevice(job.pairCounts.data() + n, stream);
+    }
+    *bucketsUsedOut = bucketsUsed;
+    {
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
+        HIP_CHECK(hipMemcpyAsync(sizeHistogramOut, job.sizeHist.data(), SIZE_HIST_CAP * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        const uint32_t overflow = readDevice(overflowCount, stream);
+        if(overflow > LowHash0Job::overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
+        overflowOut.resize(overflow);
+        if(overflow) {
+            HIP_CHECK(hipMemcpyAsync(overflowOut.data(), job.overflowSizes.data(), overflow * 4ULL, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+    }
+
+    // K4 + K5a: pair keys, sorted, run-length encoded.
+    uint64_t uniqueCount = 0;
+    if(pairCount) {
+        MI355X_ASSERT(pairCount < (1ULL << 32) - 1);
+        job.pairKeysA.reserve(pairCount, stream); job.pairKeysB.reserve(pairCount, stream);
+        hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
+            vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(),
+            (const uint64_t*)job.pairCounts.data(), n, job.readBits, job.pairKeysA.data());
+        uint64_t* pk = job.pairKeysA.data();
+        if(radixSort<uint64_t, uint32_t, false>(job.pairKeysA.data(), job.pairKeysB.data(), nullptr, nullptr, pairCount, job.pairKeyBits, ctx.sortWs, stream)) {
+            pk = job.pairKeysB.data();
+        }
+        job.flags.reserve(pairCount + 1, stream); job.pos.reserve(pairCount + 1, stream); job.starts.reserve(pairCount + 2, stream);
+        job.scanTemp32.reserve(scanTempElements(pairCount + 1), stream);
+        const unsigned g = divUp(pairCount + 1, 256);
+        hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(g), dim3(256), 0, stream, (const uint64_t*)pk, pairCount, job.flags.data());
+        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), pairCount + 1, job.scanTemp32.data(), stream);
+        hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(g), dim3(256), 0, stream,
+            (const uint64_t*)pk, (const uint32_t*)job.pos.data(), pairCount, job.starts.data());
+        HIP_CHECK(hipGetLastError());
+        uniqueCount = readDevice(job.pos.data() + pairCount, stream);
+        job.runKeys.reserve(uniqueCount, stream); job.runCounts.reserve(uniqueCount, stream);
+        hipLaunchKernelGGL(runLengthKernel, dim3(divUp(uniqueCount, 256)), dim3(256), 0, stream,
+            (const uint64_t*)pk, (const uint32_t*)job.starts.data(), uniqueCount, job.runKeys.data(), job.runCounts.data());
+        HIP_CHECK(hipGetLastError());
+    }
+    if(job.world == 1 || uniqueCount == 0) {
+        for(int r = 0; r <= job.world; r++) sendOffsets[r] = (r == job.world) ? uniqueCount : 0;
+        if(job.world > 1) for(int r = 1; r < job.world; r++) sendOffsets[r] = 0;
+    } else {
+        hipLaunchKernelGGL(lowerBoundsKernel<uint64_t>, dim3(divUp(uint64_t(job.world) + 1, 64)), dim3(64), 0, stream,
+            (const uint64_t*)job.runKeys.data(), uniqueCount, (const uint64_t*)job.boundKeys64.data(), uint32_t(job.world + 1), job.boundOut.data());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(sendOffsets, job.boundOut.data(), (size_t(job.world) + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        sendOffsets[0] = 0; sendOffsets[job.world] = uniqueCount;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    *runKeysOut = job.runKeys.data(); *runCountsOut = job.runCounts.data();
+}
+
+// Stage 3.  (runKeys, runCounts): n (key, count) runs whose readId0 this rank owns.
+void lowhash0Merge(Context& ctx, const uint64_t* runKeys, const uint32_t* runCounts, uint64_t n, uint64_t* highFrequencyOut, uint64_t* tableSizeOut)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    if(n) {
+        const uint64_t merged = job.tableSize + n;
+        MI355X_ASSERT(merged < (1ULL << 32) - 1);
+        job.tableKeysA.reserve(merged, stream, true); job.tableCountsA.reserve(merged, stream, true);
+        job.tableKeysB.reserve(merged, stream); job.tableCountsB.reserve(merged, stream);
+        HIP_CHECK(hipMemcpyAsync(job.tableKeysA.data() + job.tableSize, runKeys, n * 8, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(job.tableCountsA.data() + job.tableSize, runCounts, n * 4, hipMemcpyDeviceToDevice, stream));
+        if(job.tableSize == 0 && job.world == 1) {
+            job.tableSize = n;          // one sender: already sorted and unique
+        } else {
+            uint64_t* tk = job.tableKeysA.data(); uint32_t* tc = job.tableCountsA.data();
+            uint64_t* ok = job.tableKeysB.data(); uint32_t* oc = job.tableCountsB.data();
+            if(radixSort<uint64_t, uint32_t, true>(job.tableKeysA.data(), job.tableKeysB.data(), job.tableCountsA.data(), job.tableCountsB.data(),
+                merged, job.pairKeyBits, ctx.sortWs, stream)) {
+                std::swap(tk, ok); std::swap(tc, oc);
+            }
+            job.flags.reserve(merged + 1, stream); job.pos.reserve(merged + 1, stream); job.starts.reserve(merged + 2, stream);
+            job.scanTemp32.reserve(scanTempElements(merged + 1), stream);
+            const unsigned gm = divUp(merged + 1, 256);
+            hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream, (const uint64_t*)tk, merged, job.flags.data());
+            exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), merged + 1, job.scanTemp32.data(), stream);
+            hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream,
+                (const uint64_t*)tk, (const uint32_t*)job.pos.data(), merged, job.starts.data());
+            HIP_CHECK(hipGetLastError());
+            const uint64_t folded = readDevice(job.pos.data() + merged, stream);
+            hipLaunchKernelGGL(foldTableKernel, dim3(divUp(folded, 256)), dim3(256), 0, stream,
+                (const uint64_t*)tk, (const uint32_t*)tc, (const uint32_t*)job.starts.data(), folded, ok, oc);
+            HIP_CHECK(hipGetLastError());
+            // Result is in (ok, oc); make it the A side.
+            if(ok != job.tableKeysA.data()) { job.tableKeysA.swap(job.tableKeysB); job.tableCountsA.swap(job.tableCountsB); }
+            job.tableSize = folded;
+        }
+    }
+    // Per-iteration summary (src/LowHash0.cpp:184-196): this rank's share.
+    uint64_t highFrequency = 0;
+    if(job.tableSize) {
+        unsigned long long* highCounter = job.scalars.data() + 1;
+        HIP_CHECK(hipMemsetAsync(highCounter, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(countHighFrequencyKernel, dim3(std::min<unsigned>(divUp(job.tableSize, 256), 2048)), dim3(256), 0, stream,
+            (const uint32_t*)job.tableCountsA.data(), job.tableSize, job.minFrequency, highCounter);
+        HIP_CHECK(hipGetLastError());
+        highFrequency = readDevice(highCounter, stream);
+    }
+    *highFrequencyOut = highFrequency; *tableSizeOut = job.tableSize;
+}
+
+// Stage 4.  Candidates of this rank's readId0 range (sorted), statistics (this rank's partial
+// sums, readCount x 3), hash-kernel timing; ends the job.
+void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& hostCandidates)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const uint64_t readCount = ctx.readCount;
+    hostCandidates.clear();
+    // K6.
+    if(job.tableSize) {
+        job.flags.reserve(job.tableSize + 1, stream); job.pos.reserve(job.tableSize + 1, stream);
+        job.scanTemp32.reserve(scanTempElements(job.tableSize + 1), stream);
+        const unsigned g = divUp(job.tableSize + 1, 256);
+        hipLaunchKernelGGL(candidateFlagsKernel, dim3(g), dim3(256), 0, stream,
+            (const uint32_t*)job.tableCountsA.data(), job.tableSize, job.minFrequency, job.flags.data());
+        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), job.tableSize + 1, job.scanTemp32.data(), stream);
+        HIP_CHECK(hipGetLastError());
+        const uint64_t candidateCount = readDevice(job.pos.data() + job.tableSize, stream);
+        if(candidateCount) {
+            job.candidatesDevice.reserve(candidateCount, stream);
+            hipLaunchKernelGGL(emitCandidatesKernel, dim3(g), dim3(256), 0, stream,
+                (const uint64_t*)job.tableKeysA.data(), (const uint32_t*)job.pos.data(), job.tableSize, job.readBits, job.candidatesDevice.data());
+            HIP_CHECK(hipGetLastError());
+            hostCandidates.resize(candidateCount);
+            HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), job.candidatesDevice.data(),
+                candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
+        }
+    }
+    HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, job.stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+
+    ctx.times.lowhashHashSeconds = 0; ctx.times.lowhashHashLaunches = 0; ctx.times.lowhashHashBytes = 0;
+    for(size_t k = 0; k < job.hashEvents.size(); k++) {
+        auto& e = job.hashEvents[k];
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
+        ctx.times.lowhashHashSeconds += t * 1e-3;
+        ctx.times.lowhashHashLaunches += 1;
+        // Algorithmic bytes of one launch: 4 B per marker read + 12 B per low hash written (SURVEY 8d).
+        ctx.times.lowhashHashBytes += 4 * (job.markerEnd - job.markerBegin) + 12 * job.hashRecords[k];
+    }
+    ctx.lowhashJob.reset();
+}
+
+// Histogram rows (src/LowHash0.cpp:586-595) of one iteration from the (summed) size histogram.
+static void appendHistogramRows(uint64_t iteration, uint64_t bucketCount, uint64_t bucketsUsed,
+    const uint64_t* sizeHistogram, const std::vector<uint32_t>& overflow, std::vector<uint64_t>& histogramRows)
+{
+    std::map<uint64_t, uint64_t> rows;
+    if(bucketCount > bucketsUsed) rows[0] = bucketCount - bucketsUsed;
+    for(int s = 1; s < SIZE_HIST_CAP; s++) if(sizeHistogram[s]) rows[uint64_t(s)] = sizeHistogram[s];
+    for(uint32_t s : overflow) ++rows[s];
+    for(const auto& r : rows) { histogramRows.push_back(iteration); histogramRows.push_back(r.first); histogramRows.push_back(r.second); }
+}
+
+// The whole of LowHash0::LowHash0 on one GPU: the stages above, no exchange in between.
 void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLowHashStatistics, shasta_lowhash0_result& result)
 {
     std::memset(&result, 0, sizeof(result));
@@ -489,246 +859,53 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
     const uint64_t readCount = ctx.readCount;
-    const uint64_t M = ctx.markerCount;
-    if(p.m == 0 || p.m > HASH_HALO + 1) throw std::runtime_error("LowHash0: m must be in [1, 33].");
-    if(readCount == 0) throw std::runtime_error("LowHash0: no reads.");
-
-    // Bucket count, src/LowHash0.cpp:73-98.
-    const uint64_t estimate = uint64_t(p.hashFraction * double(M));
-    const uint32_t log2Estimate = estimate ? 64 - uint32_t(__builtin_clzl(estimate)) : 0;
-    uint64_t log2BucketCount = p.log2MinHashBucketCount;
-    if(log2BucketCount == 0) log2BucketCount = 5 + log2Estimate;
-    else if(log2BucketCount < log2Estimate) throw std::runtime_error("log2MinHashBucketCount is unreasonably small.");
-    if(log2BucketCount > 31) log2BucketCount = 31;
-    const uint64_t bucketCount = 1ULL << log2BucketCount;
-    const uint32_t mask = uint32_t(bucketCount - 1);
-    result.log2BucketCount = uint32_t(log2BucketCount);
-    // :109
-    const uint64_t hashThreshold = uint64_t(double(p.hashFraction) * double(std::numeric_limits<uint64_t>::max()));
-    const int readBits = bitsFor(readCount - 1);
-    const int pairKeyBits = 2 * readBits + 1;
-    const uint32_t minFrequency = uint32_t(std::min<uint64_t>(p.minFrequency, 0x10000));   // frequency is uint16
-
-    const uint64_t markerBegin = ctx.hostToc[2 * ctx.readBegin];
-    const uint64_t markerEnd = ctx.hostToc[2 * ctx.readEnd];
-
-    // Workspaces.
-    uint64_t recCapacity = std::max<uint64_t>(1 << 16, uint64_t(2.0 * p.hashFraction * double(markerEnd - markerBegin)) + (1 << 16));
-    DeviceBuffer<uint32_t> recKeysA, recKeysB, flags, pos, starts, scanTemp32, overflowSizes;
-    DeviceBuffer<uint64_t> recValsA, recValsB, pairCounts, scanTemp64, pairKeysA, pairKeysB, tableKeysA, tableKeysB;
-    DeviceBuffer<uint32_t> tableCountsA, tableCountsB;
-    DeviceBuffer<unsigned long long> scalars, stats, sizeHist;
-    DeviceBuffer<shasta_oriented_read_pair> candidatesDevice;
-    scalars.reserve(8, stream);
-    stats.reserve(3 * readCount, stream);
-    sizeHist.reserve(SIZE_HIST_CAP, stream);
-    const uint32_t overflowCapacity = 1 << 20;
-    overflowSizes.reserve(overflowCapacity + 1, stream);
-    uint32_t* overflowCount = overflowSizes.data() + overflowCapacity;
-    HIP_CHECK(hipMemsetAsync(stats.data(), 0, 3 * readCount * sizeof(unsigned long long), stream));
-    unsigned long long* counter = scalars.data();
-    unsigned long long* highCounter = scalars.data() + 1;
-
-    uint64_t tableSize = 0;
-    std::vector<uint64_t> highFrequencyPerIteration, totalPerIteration, histogramRows;
-    std::vector<uint32_t> hostOverflow;
-    std::vector<unsigned long long> hostHist(SIZE_HIST_CAP);
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> hashEvents;
-    std::vector<uint64_t> hashRecords;
     hipEvent_t evBegin, evEnd;
     HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
     HIP_CHECK(hipEventRecord(evBegin, stream));
+    uint32_t log2BucketCount = 0;
+    lowhash0Begin(ctx, p, 0, 1, nullptr, &log2BucketCount);
+    result.log2BucketCount = log2BucketCount;
+    const uint64_t bucketCount = 1ULL << log2BucketCount;
 
-    uint64_t highFrequency = 0;
-    for(uint64_t iteration = 0; ; iteration++) {
-        // Iteration control, src/LowHash0.cpp:136-157.
-        if(p.minHashIterationCount == 0) {
-            const double current = 2. * double(highFrequency) / double(readCount);
-            if(current >= p.alignmentCandidatesPerRead) break;
-        } else if(iteration == p.minHashIterationCount) {
-            break;
-        }
-
-        // K1.
-        uint64_t n = 0;
-        for(;;) {
-            recKeysA.reserve(recCapacity, stream); recKeysB.reserve(recCapacity, stream);
-            recValsA.reserve(recCapacity, stream); recValsB.reserve(recCapacity, stream);
-            HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
-            hipEvent_t a, b;
-            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-            HIP_CHECK(hipEventRecord(a, stream));
-            launchHash(ctx, uint32_t(p.m), iteration * 37, hashThreshold, mask, markerBegin, markerEnd,
-                recKeysA.data(), recValsA.data(), counter, recCapacity);
-            HIP_CHECK(hipEventRecord(b, stream));
-            hashEvents.push_back(std::make_pair(a, b));
-            n = readDevice(counter, stream);
-            hashRecords.push_back(std::min(n, recCapacity));
-            if(n <= recCapacity) break;
-            recCapacity = n + n / 4;           // estimate was too small: grow and redo this iteration
-        }
-        MI355X_ASSERT(n < (1ULL << 32) - 1);
-
-        // K2: bucket the records (radix partition on the bucket id).
-        uint32_t* keys = recKeysA.data(); uint64_t* vals = recValsA.data();
-        if(radixSort<uint32_t, uint64_t, true>(recKeysA.data(), recKeysB.data(), recValsA.data(), recValsB.data(),
-            n, int(log2BucketCount), ctx.sortWs, stream)) {
-            keys = recKeysB.data(); vals = recValsB.data();
-        }
-
-        // K3: bucket boundaries, statistics, histogram, pair counts.
-        uint64_t bucketsUsed = 0, pairCount = 0;
-        HIP_CHECK(hipMemsetAsync(sizeHist.data(), 0, SIZE_HIST_CAP * sizeof(unsigned long long), stream));
-        HIP_CHECK(hipMemsetAsync(overflowCount, 0, 4, stream));
-        if(n) {
-            flags.reserve(n + 1, stream); pos.reserve(n + 1, stream); starts.reserve(n + 2, stream);
-            scanTemp32.reserve(scanTempElements(n + 1), stream);
-            pairCounts.reserve(n + 1, stream); scanTemp64.reserve(scanTempElements(n + 1), stream);
-            const unsigned g = divUp(n + 1, 256);
-            hipLaunchKernelGGL(markHeadsKernel<uint32_t>, dim3(g), dim3(256), 0, stream, (const uint32_t*)keys, n, flags.data());
-            exclusiveScan<uint32_t>(flags.data(), pos.data(), n + 1, scanTemp32.data(), stream);
-            hipLaunchKernelGGL(groupStartsKernel<uint32_t>, dim3(g), dim3(256), 0, stream,
-                (const uint32_t*)keys, (const uint32_t*)pos.data(), n, starts.data());
-            hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
-                (const uint32_t*)keys, (const uint64_t*)vals, (const uint32_t*)pos.data(), (const uint32_t*)starts.data(), n,
-                p.minBucketSize, p.maxBucketSize, stats.data(), sizeHist.data(),
-                overflowSizes.data(), overflowCount, overflowCapacity, pairCounts.data());
-            exclusiveScan<uint64_t>(pairCounts.data(), pairCounts.data(), n + 1, scanTemp64.data(), stream);
-            HIP_CHECK(hipGetLastError());
-            bucketsUsed = readDevice(pos.data() + n, stream);
-            pairCount = readDevice(pairCounts.data() + n, stream);
-        }
-
-        // Histogram rows (src/LowHash0.cpp:586-595): iteration, bucketSize, bucketCount.
-        {
-            HIP_CHECK(hipMemcpyAsync(hostHist.data(), sizeHist.data(), SIZE_HIST_CAP * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            const uint32_t overflow = readDevice(overflowCount, stream);
-            if(overflow > overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
-            std::map<uint64_t, uint64_t> rows;
-            if(bucketCount > bucketsUsed) rows[0] = bucketCount - bucketsUsed;
-            for(int s = 1; s < SIZE_HIST_CAP; s++) if(hostHist[s]) rows[uint64_t(s)] = hostHist[s];
-            if(overflow) {
-                hostOverflow.resize(overflow);
-                HIP_CHECK(hipMemcpyAsync(hostOverflow.data(), overflowSizes.data(), overflow * 4ULL, hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-                for(uint32_t s : hostOverflow) ++rows[s];
-            }
-            for(const auto& r : rows) { histogramRows.push_back(iteration); histogramRows.push_back(r.first); histogramRows.push_back(r.second); }
-        }
-
-        // K4 + K5.
-        if(pairCount) {
-            MI355X_ASSERT(pairCount < (1ULL << 32) - 1);
-            pairKeysA.reserve(pairCount, stream); pairKeysB.reserve(pairCount, stream);
-            hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
-                (const uint64_t*)vals, (const uint32_t*)pos.data(), (const uint32_t*)starts.data(),
-                (const uint64_t*)pairCounts.data(), n, readBits, pairKeysA.data());
-            uint64_t* pk = pairKeysA.data();
-            if(radixSort<uint64_t, uint32_t, false>(pairKeysA.data(), pairKeysB.data(), nullptr, nullptr, pairCount, pairKeyBits, ctx.sortWs, stream)) {
-                pk = pairKeysB.data();
-            }
-            flags.reserve(pairCount + 1, stream); pos.reserve(pairCount + 1, stream); starts.reserve(pairCount + 2, stream);
-            scanTemp32.reserve(scanTempElements(pairCount + 1), stream);
-            const unsigned g = divUp(pairCount + 1, 256);
-            hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(g), dim3(256), 0, stream, (const uint64_t*)pk, pairCount, flags.data());
-            exclusiveScan<uint32_t>(flags.data(), pos.data(), pairCount + 1, scanTemp32.data(), stream);
-            hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(g), dim3(256), 0, stream,
-                (const uint64_t*)pk, (const uint32_t*)pos.data(), pairCount, starts.data());
-            HIP_CHECK(hipGetLastError());
-            const uint64_t uniqueCount = readDevice(pos.data() + pairCount, stream);
-
-            // Append the run-length encoded new pairs to the table, sort, fold.
-            const uint64_t merged = tableSize + uniqueCount;
-            MI355X_ASSERT(merged < (1ULL << 32) - 1);
-            tableKeysA.reserve(merged, stream, true); tableCountsA.reserve(merged, stream, true);
-            tableKeysB.reserve(merged, stream); tableCountsB.reserve(merged, stream);
-            hipLaunchKernelGGL(runLengthKernel, dim3(divUp(uniqueCount, 256)), dim3(256), 0, stream,
-                (const uint64_t*)pk, (const uint32_t*)starts.data(), uniqueCount,
-                tableKeysA.data() + tableSize, tableCountsA.data() + tableSize);
-            if(tableSize == 0) {
-                tableSize = uniqueCount;          // already sorted and unique
-            } else {
-                uint64_t* tk = tableKeysA.data(); uint32_t* tc = tableCountsA.data();
-                uint64_t* ok = tableKeysB.data(); uint32_t* oc = tableCountsB.data();
-                if(radixSort<uint64_t, uint32_t, true>(tableKeysA.data(), tableKeysB.data(), tableCountsA.data(), tableCountsB.data(),
-                    merged, pairKeyBits, ctx.sortWs, stream)) {
-                    std::swap(tk, ok); std::swap(tc, oc);
-                }
-                flags.reserve(merged + 1, stream); pos.reserve(merged + 1, stream); starts.reserve(merged + 2, stream);
-                scanTemp32.reserve(scanTempElements(merged + 1), stream);
-                const unsigned gm = divUp(merged + 1, 256);
-                hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream, (const uint64_t*)tk, merged, flags.data());
-                exclusiveScan<uint32_t>(flags.data(), pos.data(), merged + 1, scanTemp32.data(), stream);
-                hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream,
-                    (const uint64_t*)tk, (const uint32_t*)pos.data(), merged, starts.data());
-                HIP_CHECK(hipGetLastError());
-                const uint64_t folded = readDevice(pos.data() + merged, stream);
-                hipLaunchKernelGGL(foldTableKernel, dim3(divUp(folded, 256)), dim3(256), 0, stream,
-                    (const uint64_t*)tk, (const uint32_t*)tc, (const uint32_t*)starts.data(), folded, ok, oc);
-                HIP_CHECK(hipGetLastError());
-                // Result is in (ok, oc); make it the A side.
-                if(ok != tableKeysA.data()) { tableKeysA.swap(tableKeysB); tableCountsA.swap(tableCountsB); }
-                tableSize = folded;
-            }
-        }
-
-        // Per-iteration summary (src/LowHash0.cpp:184-196).
-        highFrequency = 0;
-        if(tableSize) {
-            HIP_CHECK(hipMemsetAsync(highCounter, 0, sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(countHighFrequencyKernel, dim3(std::min<unsigned>(divUp(tableSize, 256), 2048)), dim3(256), 0, stream,
-                (const uint32_t*)tableCountsA.data(), tableSize, minFrequency, highCounter);
-            HIP_CHECK(hipGetLastError());
-            highFrequency = readDevice(highCounter, stream);
-        }
-        highFrequencyPerIteration.push_back(highFrequency);
-        totalPerIteration.push_back(tableSize);
-    }
-
-    // K6.
-    uint64_t candidateCount = 0;
+    std::vector<uint64_t> highFrequencyPerIteration, totalPerIteration, histogramRows, sizeHistogram(SIZE_HIST_CAP);
+    std::vector<uint32_t> overflow;
     std::vector<shasta_oriented_read_pair> hostCandidates;
-    if(tableSize) {
-        flags.reserve(tableSize + 1, stream); pos.reserve(tableSize + 1, stream);
-        scanTemp32.reserve(scanTempElements(tableSize + 1), stream);
-        const unsigned g = divUp(tableSize + 1, 256);
-        hipLaunchKernelGGL(candidateFlagsKernel, dim3(g), dim3(256), 0, stream,
-            (const uint32_t*)tableCountsA.data(), tableSize, minFrequency, flags.data());
-        exclusiveScan<uint32_t>(flags.data(), pos.data(), tableSize + 1, scanTemp32.data(), stream);
-        HIP_CHECK(hipGetLastError());
-        candidateCount = readDevice(pos.data() + tableSize, stream);
-        if(candidateCount) {
-            candidatesDevice.reserve(candidateCount, stream);
-            hipLaunchKernelGGL(emitCandidatesKernel, dim3(g), dim3(256), 0, stream,
-                (const uint64_t*)tableKeysA.data(), (const uint32_t*)pos.data(), tableSize, readBits, candidatesDevice.data());
-            HIP_CHECK(hipGetLastError());
-            hostCandidates.resize(candidateCount);
-            HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), candidatesDevice.data(),
-                candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
+    try {
+        uint64_t highFrequency = 0;
+        for(uint64_t iteration = 0; ; iteration++) {
+            // Iteration control, src/LowHash0.cpp:136-157.
+            if(p.minHashIterationCount == 0) {
+                const double current = 2. * double(highFrequency) / double(readCount);
+                if(current >= p.alignmentCandidatesPerRead) break;
+            } else if(iteration == p.minHashIterationCount) {
+                break;
+            }
+            uint64_t offsets[2];
+            const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
+            lowhash0Hash(ctx, iteration, offsets, &keys, &vals);
+            const uint64_t* runKeys = nullptr; const uint32_t* runCounts = nullptr;
+            uint64_t bucketsUsed = 0;
+            lowhash0Buckets(ctx, keys, vals, offsets[1], offsets, &runKeys, &runCounts, &bucketsUsed, sizeHistogram.data(), overflow);
+            appendHistogramRows(iteration, bucketCount, bucketsUsed, sizeHistogram.data(), overflow, histogramRows);
+            uint64_t tableSize = 0;
+            lowhash0Merge(ctx, runKeys, runCounts, offsets[1], &highFrequency, &tableSize);
+            highFrequencyPerIteration.push_back(highFrequency);
+            totalPerIteration.push_back(tableSize);
         }
+        lowhash0Finish(ctx, readLowHashStatistics, hostCandidates);
+    } catch(...) {
+        ctx.lowhashJob.reset();
+        (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
+        throw;
     }
-    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
-    HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipEventRecord(evEnd, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
-    ctx.times.lowhashHashSeconds = 0; ctx.times.lowhashHashLaunches = 0; ctx.times.lowhashHashBytes = 0;
-    for(size_t k = 0; k < hashEvents.size(); k++) {
-        auto& e = hashEvents[k];
-        float t = 0;
-        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
-        ctx.times.lowhashHashSeconds += t * 1e-3;
-        ctx.times.lowhashHashLaunches += 1;
-        // Algorithmic bytes of one launch: 4 B per marker read + 12 B per low hash written (SURVEY 8d).
-        ctx.times.lowhashHashBytes += 4 * (markerEnd - markerBegin) + 12 * hashRecords[k];
-        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
-    }
     (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
 
-    result.candidateCount = candidateCount;
+    result.candidateCount = hostCandidates.size();
     result.candidates = mallocCopy(hostCandidates);
     result.iterationCount = uint32_t(highFrequencyPerIteration.size());
     result.highFrequency = mallocCopy(highFrequencyPerIteration);

@@ -1,0 +1,187 @@
+"""One LowHash0 + Align4 job sharded over several GPUs of a node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  The reference has no
+counterpart -- it is a single shared-memory process -- so this module follows the reference's
+*semantics* (src/LowHash0.cpp) and produces its exact output:
+
+* reads are split into contiguous ranges balanced by marker count; every rank hashes its own
+  range (no communication);
+* bucket ids are owned in contiguous ranges: all-to-all(v) of the low-hash records (12 bytes
+  each) per iteration;
+* pair keys are owned by the rank whose read range contains readId0: all-to-all(v) of the
+  run-length encoded keys; the per-iteration counters, the bucket-size histogram and the per-read
+  statistics are all-reduced;
+* each rank's candidates are sorted and cover its readId0 range, so the concatenation in rank
+  order is the reference's candidate list;
+* Align4 candidates are independent: the candidate list is all-gathered and re-split evenly.
+
+The compute stages are behind a small backend interface (tensors in, tensors out): the product
+backend is HipBackend (the C ABI's shasta_mi355x_lh_* entry points); the CPU tests plug in a numpy
+backend to exercise this file's sharding and exchange logic under gloo.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import abi
+
+SIZE_HISTOGRAM_BINS = 2048
+
+
+def read_boundaries(toc, world):
+    """world+1 read ids splitting the reads into contiguous ranges of about equal marker count."""
+    toc = np.asarray(toc, dtype=np.uint64)
+    read_count = (len(toc) - 1) // 2
+    per_read_end = toc[2::2].astype(np.float64)          # markers up to and including each read
+    total = float(toc[-1])
+    b = [0]
+    for r in range(1, world):
+        b.append(int(np.searchsorted(per_read_end, total * r / world, side="left")))
+    b.append(read_count)
+    return np.maximum.accumulate(np.asarray(b, dtype=np.uint64))
+
+
+class HipBackend:
+    """The stages on this rank's GPU through the C ABI (include/shasta_mi355x.h, lh_* entry points)."""
+
+    def __init__(self, ctx, device):
+        self.ctx = ctx
+        self.device = torch.device(device)
+
+    def begin(self, params, rank, world, boundaries):
+        return self.ctx.lh_begin(params, rank, world, boundaries)
+
+    def _tensor_from(self, ptr, n, dtype):
+        t = torch.empty(int(n), dtype=dtype, device=self.device)
+        if n:
+            self.ctx.memcpy(t.data_ptr(), ptr, int(n) * t.element_size(), 2)
+        return t
+
+    def hash(self, iteration):
+        offsets, keys, vals = self.ctx.lh_hash(iteration)
+        n = int(offsets[-1])
+        return offsets, self._tensor_from(keys, n, torch.int32), self._tensor_from(vals, n, torch.int64)
+
+    def buckets(self, keys, vals):
+        torch.cuda.synchronize(self.device)
+        n = keys.numel()
+        offsets, rk, rc, used, hist, overflow = self.ctx.lh_buckets(keys.data_ptr() if n else 0, vals.data_ptr() if n else 0, n)
+        m = int(offsets[-1])
+        return offsets, self._tensor_from(rk, m, torch.int64), self._tensor_from(rc, m, torch.int32), used, hist, overflow
+
+    def merge(self, run_keys, run_counts):
+        torch.cuda.synchronize(self.device)
+        n = run_keys.numel()
+        return self.ctx.lh_merge(run_keys.data_ptr() if n else 0, run_counts.data_ptr() if n else 0, n)
+
+    def finish(self):
+        return self.ctx.lh_finish()
+
+
+def _comm_device(tensor_device):
+    """Collectives run on the tensors' device with nccl (RCCL) and on the host with gloo."""
+    return tensor_device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def exchange(tensors, send_offsets, group=None):
+    """all-to-all(v): tensors share the split send_offsets (world+1); returns the received tensors."""
+    world = dist.get_world_size(group)
+    send_counts = np.diff(np.asarray(send_offsets, dtype=np.int64))
+    assert len(send_counts) == world
+    home = tensors[0].device
+    comm = _comm_device(home)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=comm)
+    rc = torch.empty(world, dtype=torch.int64, device=comm)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    out = []
+    for t in tensors:
+        src = t.to(comm).contiguous()
+        dst = torch.empty(sum(recv_counts), dtype=t.dtype, device=comm)
+        dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=[int(x) for x in send_counts], group=group)
+        out.append(dst.to(home))
+    return out
+
+
+def all_reduce_sum_u64(array, device, group=None):
+    """Sum of uint64 numpy arrays over the ranks (two's complement wrap-around = uint64 arithmetic)."""
+    a = np.ascontiguousarray(array, dtype=np.uint64)
+    t = torch.from_numpy(a.view(np.int64).copy()).to(_comm_device(torch.device(device)))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy().view(np.uint64).reshape(a.shape)
+
+
+class LowHash0Result:
+    def __init__(self):
+        self.candidates = None          # this rank's (sorted) share
+        self.statistics = None          # global (all-reduced)
+        self.high_frequency = None
+        self.total = None
+        self.histogram = None
+        self.log2_bucket_count = 0
+
+
+def lowhash0(backend, params, read_count, boundaries, group=None):
+    """Runs the job; every rank gets the global counters/statistics and its own share of the candidates."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    device = backend.device
+    log2 = backend.begin(params, rank, world, boundaries)
+    bucket_count = 1 << log2
+    high_per_iteration, total_per_iteration, histogram_rows = [], [], []
+    high_frequency = 0
+    iteration = 0
+    while True:
+        # Iteration control, src/LowHash0.cpp:136-157 (on the global counter: every rank decides alike).
+        if params.minHashIterationCount == 0:
+            if 2.0 * float(high_frequency) / float(read_count) >= params.alignmentCandidatesPerRead:
+                break
+        elif iteration == params.minHashIterationCount:
+            break
+        offsets, keys, vals = backend.hash(iteration)
+        keys, vals = exchange([keys, vals], offsets, group)                       # C1: records to bucket owners
+        offsets, run_keys, run_counts, used, hist, overflow = backend.buckets(keys, vals)
+        run_keys, run_counts = exchange([run_keys, run_counts], offsets, group)   # C2: runs to readId0 owners
+        high, total = backend.merge(run_keys, run_counts)
+        # Counters + histogram of this iteration, summed over the ranks.
+        packed = np.concatenate([np.asarray([high, total, used], dtype=np.uint64), np.asarray(hist, dtype=np.uint64)])
+        packed = all_reduce_sum_u64(packed, device, group)
+        high_frequency, total_all, used_all = int(packed[0]), int(packed[1]), int(packed[2])
+        hist_all = packed[3:]
+        # Bucket sizes beyond the histogram bins are rare: gather the lists.
+        lists = [None] * world
+        dist.all_gather_object(lists, np.asarray(overflow, dtype=np.uint32).tolist(), group=group)
+        rows = {}
+        if bucket_count > used_all:
+            rows[0] = bucket_count - used_all
+        for s in np.nonzero(hist_all[1:])[0] + 1:
+            rows[int(s)] = int(hist_all[s])
+        for lst in lists:
+            for s in lst:
+                rows[int(s)] = rows.get(int(s), 0) + 1
+        for s in sorted(rows):
+            histogram_rows.append((iteration, s, rows[s]))
+        high_per_iteration.append(high_frequency)
+        total_per_iteration.append(total_all)
+        iteration += 1
+    candidates, stats = backend.finish()
+    out = LowHash0Result()
+    out.candidates = candidates
+    out.statistics = all_reduce_sum_u64(stats, device, group)
+    out.high_frequency = np.asarray(high_per_iteration, dtype=np.uint64)
+    out.total = np.asarray(total_per_iteration, dtype=np.uint64)
+    out.histogram = np.asarray(histogram_rows, dtype=np.uint64).reshape(-1, 3)
+    out.log2_bucket_count = log2
+    return out
+
+
+def gather_candidates(local_candidates, group=None):
+    """The global candidate list (rank order = the reference's order) on every rank."""
+    world = dist.get_world_size(group)
+    lists = [None] * world
+    dist.all_gather_object(lists, np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE).tobytes(), group=group)
+    return np.concatenate([np.frombuffer(b, dtype=abi.PAIR_DTYPE) for b in lists]) if world else local_candidates
+
+
+def candidate_slice(count, rank, world):
+    """Even split of the candidate list for Align4 (candidates are independent)."""
+    return (count * rank) // world, (count * (rank + 1)) // world

@@ -23,6 +23,9 @@ EXPORTS = [
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids", "shasta_mi355x_set_shard",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_get_kernel_times",
     "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate",
+    "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
+    "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
+    "shasta_mi355x_lh_finish",
 ]
 
 
@@ -45,6 +48,7 @@ class Library:
         self.lib.shasta_mi355x_create.restype = C.c_void_p
         self.lib.shasta_mi355x_create.argtypes = [C.c_int]
         self.lib.shasta_mi355x_destroy.argtypes = [C.c_void_p]
+        self.lib.shasta_mi355x_free.argtypes = [C.c_void_p]
 
     def _check(self, rc, what):
         if rc != 0:
@@ -159,6 +163,73 @@ class Context:
         self.library._check(self.lib.shasta_mi355x_set_kmer_ids(
             C.c_void_p(self.handle), C.c_uint64(self.read_count), abi.as_ptr(toc, C.c_uint64),
             abi.as_ptr(kmer_ids, C.c_uint32), fp), "shasta_mi355x_set_kmer_ids")
+
+    def set_kmer_ids_device(self, toc, kmer_ids_device_ptr, flags=None):
+        """Adopts dense kmer ids that already live in this GPU's memory (device pointer as int)."""
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        self.read_count = (len(toc) - 1) // 2
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self.library._check(self.lib.shasta_mi355x_set_kmer_ids_device(
+            C.c_void_p(self.handle), C.c_uint64(self.read_count), abi.as_ptr(toc, C.c_uint64),
+            C.c_void_p(int(kmer_ids_device_ptr)), fp), "shasta_mi355x_set_kmer_ids_device")
+
+    def memcpy(self, dst, src, nbytes, kind):
+        """Synchronous copy on the context's stream; kind 0 host->device, 1 device->host, 2 device->device."""
+        self.library._check(self.lib.shasta_mi355x_memcpy(
+            C.c_void_p(self.handle), C.c_void_p(int(dst)), C.c_void_p(int(src)), C.c_uint64(int(nbytes)), C.c_int(kind)),
+            "shasta_mi355x_memcpy")
+
+    # --- LowHash0 in stages (one rank of a job sharded over several GPUs; include/shasta_mi355x.h) ---
+    def lh_begin(self, params, rank, world, boundaries):
+        b = np.ascontiguousarray(boundaries, dtype=np.uint64)
+        assert len(b) == world + 1
+        log2 = C.c_uint32()
+        self.library._check(self.lib.shasta_mi355x_lh_begin(
+            C.c_void_p(self.handle), C.byref(params), C.c_int(rank), C.c_int(world), abi.as_ptr(b, C.c_uint64),
+            C.byref(log2)), "shasta_mi355x_lh_begin")
+        self._world = world
+        return int(log2.value)
+
+    def lh_hash(self, iteration):
+        """-> (send offsets uint64[world+1], device pointer of keys u32, device pointer of vals u64)."""
+        offsets = np.zeros(self._world + 1, dtype=np.uint64)
+        keys, vals = C.c_void_p(), C.c_void_p()
+        self.library._check(self.lib.shasta_mi355x_lh_hash(
+            C.c_void_p(self.handle), C.c_uint64(iteration), abi.as_ptr(offsets, C.c_uint64),
+            C.byref(keys), C.byref(vals)), "shasta_mi355x_lh_hash")
+        return offsets, keys.value or 0, vals.value or 0
+
+    def lh_buckets(self, keys_ptr, vals_ptr, n):
+        """-> (send offsets, run keys ptr, run counts ptr, bucketsUsed, size histogram uint64[2048], overflow sizes)."""
+        offsets = np.zeros(self._world + 1, dtype=np.uint64)
+        run_keys, run_counts = C.c_void_p(), C.c_void_p()
+        used, overflow_count = C.c_uint64(), C.c_uint64()
+        hist = np.zeros(2048, dtype=np.uint64)
+        overflow = np.zeros(1 << 20, dtype=np.uint32)
+        self.library._check(self.lib.shasta_mi355x_lh_buckets(
+            C.c_void_p(self.handle), C.c_void_p(int(keys_ptr)), C.c_void_p(int(vals_ptr)), C.c_uint64(int(n)),
+            abi.as_ptr(offsets, C.c_uint64), C.byref(run_keys), C.byref(run_counts), C.byref(used),
+            abi.as_ptr(hist, C.c_uint64), abi.as_ptr(overflow, C.c_uint32), C.c_uint64(len(overflow)),
+            C.byref(overflow_count)), "shasta_mi355x_lh_buckets")
+        return offsets, run_keys.value or 0, run_counts.value or 0, int(used.value), hist, overflow[:overflow_count.value].copy()
+
+    def lh_merge(self, run_keys_ptr, run_counts_ptr, n):
+        high, total = C.c_uint64(), C.c_uint64()
+        self.library._check(self.lib.shasta_mi355x_lh_merge(
+            C.c_void_p(self.handle), C.c_void_p(int(run_keys_ptr)), C.c_void_p(int(run_counts_ptr)), C.c_uint64(int(n)),
+            C.byref(high), C.byref(total)), "shasta_mi355x_lh_merge")
+        return int(high.value), int(total.value)
+
+    def lh_finish(self):
+        """-> (this rank's candidates, this rank's partial statistics uint64[R,3])."""
+        stats = np.zeros((self.read_count, 3), dtype=np.uint64)
+        cand = C.POINTER(abi.OrientedReadPair)()
+        count = C.c_uint64()
+        self.library._check(self.lib.shasta_mi355x_lh_finish(
+            C.c_void_p(self.handle), abi.as_ptr(stats, C.c_uint64), C.byref(cand), C.byref(count)), "shasta_mi355x_lh_finish")
+        out = abi.copy_array(cand, int(count.value), abi.PAIR_DTYPE)
+        self.lib.shasta_mi355x_free(cand)
+        return out, stats
 
     def set_shard(self, rank, world_size, read_begin, read_end):
         self.library._check(self.lib.shasta_mi355x_set_shard(
