@@ -120,29 +120,71 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # SHASTA_BENCH_BACKEND=gloo + SHASTA_BENCH_ONE_DEVICE=1: functional test of the multi-rank path
+        # on a box with one GPU (host-staged transport, every rank on cuda:0); never used for numbers.
+        if os.environ.get("SHASTA_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("SHASTA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(0)
 
     lib = shasta_amd.load()
     assert lib.device_count() >= 1, "no gfx950 device: the HIP path cannot run (there is no CPU fallback)"
-
-    # Workload.  Multi-GPU: weak scaling, every rank owns `reads` reads (its own genome region).
-    toc, kmer = make_workload(args.reads, 12345 + rank)
-    marker_count = int(toc[-1])
-    ctx = lib.context(local_rank)
-    ctx.set_kmer_ids(toc, kmer)                     # host -> HBM, outside the timed region
-    del kmer
     p, o = lowhash_params(), align_options()
+    ctx = lib.context(local_rank)
 
-    def step():
-        lh = ctx.lowhash0(p)
-        if args.lowhash_only:
-            return lh, None
-        al = ctx.align4(lh.candidates, o, want_ordinals=False)
-        return lh, al
+    if world == 1:
+        # Workload: BASELINE configs[2].
+        toc, kmer = make_workload(args.reads, 12345)
+        marker_count = int(toc[-1])
+        ctx.set_kmer_ids(toc, kmer)                     # host -> HBM, outside the timed region
+        del kmer
+
+        def step():
+            lh = ctx.lowhash0(p)
+            if args.lowhash_only:
+                return lh, None, len(lh.candidates)
+            al = ctx.align4(lh.candidates, o, want_ordinals=False)
+            return lh, al, len(lh.candidates)
+    else:
+        # ONE job over all GPUs (weak scaling: `reads` reads per GPU of one read set at the same
+        # coverage).  Every rank generates its own read range, the dense kmer ids are all-gathered
+        # over xGMI so that every GPU holds every read (Align4 needs both reads of a candidate),
+        # LowHash0 runs sharded with its two all-to-all exchanges, the candidate list is re-split
+        # evenly for Align4.  Setup (generation, all-gather) is outside the timed region.
+        from shasta_amd import distributed, synthetic
+        device = torch.device("cuda", local_rank)
+        genome_markers = max(20000, int(round(world * args.reads * 1500 / 45.0)))
+        toc_s, kmer_s = synthetic.marker_reads(args.reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
+                                               keep_probability=0.8, spurious_probability=0.25, k=10, seed=12345,
+                                               shard=rank, shard_count=world)
+        sizes = [None] * world
+        dist.all_gather_object(sizes, np.diff(toc_s.astype(np.int64)).astype(np.uint32).tobytes())
+        per_shard = [np.frombuffer(b, dtype=np.uint32).astype(np.uint64) for b in sizes]
+        toc = np.zeros(2 * world * args.reads + 1, dtype=np.uint64)
+        toc[1:] = np.cumsum(np.concatenate(per_shard))
+        shard_markers = [int(x.sum()) for x in per_shard]
+        mine = torch.from_numpy(kmer_s.view(np.int32)).to(device)
+        everything = distributed.all_gather_padded(mine, shard_markers)    # C3: every GPU gets every read's kmer ids
+        del mine, kmer_s
+        torch.cuda.synchronize()
+        ctx.set_kmer_ids_device(toc, everything.data_ptr())
+        del everything
+        marker_count = int(toc[-1])
+        read_count = world * args.reads
+        backend = distributed.HipBackend(ctx, device)
+        boundaries = np.arange(0, read_count + 1, args.reads, dtype=np.uint64)     # the generated shards
+
+        def step():
+            lh = distributed.lowhash0(backend, p, read_count, boundaries)
+            candidates = distributed.gather_candidates(lh.candidates)
+            if args.lowhash_only:
+                return lh, None, len(candidates)
+            lo, hi = distributed.candidate_slice(len(candidates), rank, world)
+            al = ctx.align4(candidates[lo:hi], o, want_ordinals=False)
+            return lh, al, len(candidates)
 
     def sync():
         if dist is not None:
@@ -156,26 +198,27 @@ def main():
     hash_s = hash_n = hash_b = dp_s = dp_cells = dp_bytes = 0
     lh_dev = al_dev = lh_wall = al_wall = 0.0
     for _ in range(args.steps):
-        lh, al = step()
+        lh, al, pairs_total = step()
         kt = ctx.kernel_times()
         hash_s += kt.lowhashHashSeconds; hash_n += kt.lowhashHashLaunches; hash_b += kt.lowhashHashBytes
-        lh_dev += lh.device_seconds
-        lh_wall += lh.seconds
+        if world == 1:
+            lh_dev += lh.device_seconds
+            lh_wall += lh.seconds
         if al is not None:
             dp_s += kt.alignDpSeconds; dp_cells += kt.alignDpCells; dp_bytes += kt.alignBytes
             al_dev += al.device_seconds
             al_wall += al.seconds
     sync()
     elapsed = time.perf_counter() - t0
+    stored_total = 0 if al is None else len(al.alignment_data)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        comm = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([len(lh.candidates), 0 if al is None else len(al.alignment_data)], dtype=torch.int64, device="cuda")
+        c = torch.tensor([stored_total], dtype=torch.int64, device=comm)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        pairs_total, stored_total = int(c[0].item()), int(c[1].item())
-    else:
-        pairs_total, stored_total = len(lh.candidates), 0 if al is None else len(al.alignment_data)
+        stored_total = int(c[0].item())
 
     if rank == 0:
         steps = max(1, args.steps)
@@ -222,9 +265,11 @@ def main():
                 "workload": "BASELINE configs[2]: synthetic ONT-like reads, marker level, %d reads/GPU, "
                             "mean 1500 markers (~20 kb) per oriented read, 45x coverage; LowHash0 m=4 f=0.01 "
                             "10 iterations 5/30/5; Align4 200/10/10/100, maxBand 1000, 6/-1/-1" % args.reads,
-                "reads_per_gpu": args.reads, "markers_per_gpu": marker_count,
+                "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
-                "parallelism": "1 GPU" if world == 1 else "%d independent read partitions, no data-path collective" % world,
+                "parallelism": "1 GPU" if world == 1 else
+                               "%d GPUs, one job: reads sharded by id range, RCCL all-to-all of low-hash records and of pair "
+                               "keys per MinHash iteration, candidates re-split evenly for Align4" % world,
             },
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
                                        "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps},

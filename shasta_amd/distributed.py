@@ -103,6 +103,19 @@ def exchange(tensors, send_offsets, group=None):
     return out
 
 
+def all_gather_padded(tensor, counts, group=None):
+    """All-gather of 1-D tensors of different lengths (counts[r] elements from rank r), concatenated."""
+    world = dist.get_world_size(group)
+    home = tensor.device
+    comm = _comm_device(home)
+    pad = max(int(c) for c in counts)
+    mine = torch.zeros(pad, dtype=tensor.dtype, device=comm)
+    mine[:tensor.numel()] = tensor.to(comm)
+    parts = [torch.empty(pad, dtype=tensor.dtype, device=comm) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat([parts[r][:int(counts[r])].to(home) for r in range(world)])
+
+
 def all_reduce_sum_u64(array, device, group=None):
     """Sum of uint64 numpy arrays over the ranks (two's complement wrap-around = uint64 arithmetic)."""
     a = np.ascontiguousarray(array, dtype=np.uint64)

@@ -47,19 +47,29 @@ def marker_alphabet(k=10, probability=0.1, seed=231):
     return np.nonzero(marker)[0].astype(np.uint32), rc.astype(np.uint32)
 
 
-def marker_reads(n_reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=700,
-                 keep_probability=0.65, spurious_probability=0.06, k=10, seed=12345,
-                 repeat_fraction=0.02):
-    """Returns (toc uint64[2R+1], kmer_ids uint32[M]) for R = n_reads reads, both strands."""
-    rng = np.random.default_rng(seed)
-    alphabet, rc_table = marker_alphabet(k=k)
+def marker_genome(rng, alphabet, genome_markers, repeat_fraction=0.02):
+    """A random genome over the marker alphabet with a few 200-marker repeats, as real genomes have."""
     genome = alphabet[rng.integers(0, len(alphabet), size=genome_markers)]
-    # A few repeats: copy short segments elsewhere, as real genomes have.
     n_rep = int(repeat_fraction * genome_markers / 200)
     for _ in range(n_rep):
         a = int(rng.integers(0, genome_markers - 200))
         b = int(rng.integers(0, genome_markers - 200))
         genome[b:b + 200] = genome[a:a + 200]
+    return genome
+
+
+def marker_reads(n_reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=700,
+                 keep_probability=0.65, spurious_probability=0.06, k=10, seed=12345,
+                 repeat_fraction=0.02, shard=None, shard_count=1):
+    """Returns (toc uint64[2R+1], kmer_ids uint32[M]) for R = n_reads reads, both strands.
+    With shard / shard_count the genome (from `seed`) is common to all shards and the n_reads reads
+    of shard `shard` come from their own stream, so that shards generated on different ranks are
+    consecutive read ranges of one read set."""
+    rng = np.random.default_rng(seed)
+    alphabet, rc_table = marker_alphabet(k=k)
+    genome = marker_genome(rng, alphabet, genome_markers, repeat_fraction)
+    if shard is not None:
+        rng = np.random.default_rng([seed, 1000003 + int(shard), int(shard_count)])
 
     mu = np.log(mean_markers) - 0.5 * sigma * sigma
     span = np.maximum(min_markers, rng.lognormal(mu, sigma, size=n_reads)).astype(np.int64)
