@@ -122,6 +122,34 @@ class RefLib(_Base):
         self.lib.ref_free(data)
         return toc_a, data_a
 
+    # --- Data/ directory fixtures through the reference's own containers ---
+    def write_data_dir(self, directory, toc, data7, flags=None):
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self._check(self.lib.ref_write_data_dir(directory.encode(), C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64),
+                                                C.c_void_p(data7.ctypes.data), fp), "ref_write_data_dir")
+
+    def open_vector(self, path, object_size):
+        """-> (data as uint8[objectCount, objectSize], file size implied by the header)."""
+        count, size = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.ref_open_vector(path.encode(), C.c_uint64(object_size), C.byref(count), C.byref(size), None, C.c_uint64(0)), "ref_open_vector")
+        out = np.zeros((count.value, object_size), dtype=np.uint8)
+        self._check(self.lib.ref_open_vector(path.encode(), C.c_uint64(object_size), C.byref(count), C.byref(size),
+                                             C.c_void_p(out.ctypes.data), C.c_uint64(out.nbytes)), "ref_open_vector")
+        return out, int(size.value)
+
+    def lowhash0_files(self, directory, params, work_dir, threads=1):
+        self._check(self.lib.ref_lowhash0_files(directory.encode(), C.byref(params), C.c_uint64(threads), work_dir.encode()), "ref_lowhash0_files")
+
+    def store_alignments(self, directory, alignment_data, compressed_toc, compressed_data):
+        rows = np.ascontiguousarray(alignment_data)
+        toc = _u64(compressed_toc)
+        data = np.ascontiguousarray(compressed_data, dtype=np.uint8)
+        self._check(self.lib.ref_store_alignments(directory.encode(), C.c_uint64(len(rows)), C.c_void_p(rows.ctypes.data),
+                                                  abi.as_ptr(toc, C.c_uint64), C.c_void_p(data.ctypes.data)), "ref_store_alignments")
+
     def lowhash0(self, toc, data7, flags, params, threads=0, work_dir=None):
         toc = _u64(toc)
         data7 = np.ascontiguousarray(data7, dtype=np.uint8)

@@ -582,3 +582,135 @@ void ref_align4_free(shasta_align4_result* r)
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Data/ directory fixtures written and checked by the reference's own containers
+// (MemoryMapped::Vector / VectorOfVectors), for the host layer's file-format tests.
+// ---------------------------------------------------------------------------
+namespace {
+template<size_t N> struct Blob { char bytes[N]; };
+template<size_t N> int openBlobVector(const std::string& path, uint64_t* objectCount, uint64_t* fileSize, void* out, uint64_t outCapacity)
+{
+    MemoryMapped::Vector< Blob<N> > v;
+    v.accessExistingReadOnly(path);
+    *objectCount = v.size();
+    *fileSize = 4096 + N * v.capacity();
+    if(out) {
+        if(N * v.size() > outCapacity) throw std::runtime_error("output capacity too small");
+        if(v.size()) std::memcpy(out, v.begin(), N * v.size());
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int ref_write_data_dir(const char* dir, uint64_t readCount, const uint64_t* toc, const void* data7, const uint8_t* flags)
+{
+    try {
+        const std::string d(dir);
+        Markers markers;
+        markers.createNew(d + "/Markers", 4096);
+        for(uint64_t i = 0; i < 2 * readCount; i++) {
+            const CompressedMarker* b = reinterpret_cast<const CompressedMarker*>(static_cast<const char*>(data7) + 7 * toc[i]);
+            markers.appendVector(b, b + (toc[i + 1] - toc[i]));
+        }
+        markers.unreserve();
+        MemoryMapped::Vector<ReadFlags> readFlags;
+        readFlags.createNew(d + "/ReadFlags", 4096);
+        readFlags.resize(readCount);
+        for(uint64_t i = 0; i < readCount; i++) {
+            ReadFlags f;
+            if(flags) *reinterpret_cast<uint8_t*>(&f) = flags[i];
+            readFlags[i] = f;
+        }
+        readFlags.unreserve();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// Opens <path> with MemoryMapped::Vector<T>::accessExistingReadOnly for a T of objectSize bytes
+// (the reference's magic number / file size / object size checks) and optionally copies the data.
+int ref_open_vector(const char* path, uint64_t objectSize, uint64_t* objectCount, uint64_t* fileSize, void* out, uint64_t outCapacity)
+{
+    try {
+        switch(objectSize) {
+            case 1: return openBlobVector<1>(path, objectCount, fileSize, out, outCapacity);
+            case 4: return openBlobVector<4>(path, objectCount, fileSize, out, outCapacity);
+            case 7: return openBlobVector<7>(path, objectCount, fileSize, out, outCapacity);
+            case 8: return openBlobVector<8>(path, objectCount, fileSize, out, outCapacity);
+            case 12: return openBlobVector<12>(path, objectCount, fileSize, out, outCapacity);
+            case 24: return openBlobVector<24>(path, objectCount, fileSize, out, outCapacity);
+            case 64: return openBlobVector<64>(path, objectCount, fileSize, out, outCapacity);
+            default: throw std::runtime_error("unsupported object size");
+        }
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// The reference's LowHash0 over an existing Data/ directory: inputs opened from Markers /
+// ReadFlags, outputs created as AlignmentCandidates / ReadLowHashStatistics exactly as
+// Assembler::findAlignmentCandidatesLowHash0 does (src/AssemblerLowHash.cpp:25-54).
+int ref_lowhash0_files(const char* dir, const shasta_lowhash0_params* params, uint64_t threadCount, const char* workDirectory)
+{
+    try {
+        const std::string d(dir);
+        ChdirGuard cd(workDirectory);
+        Markers markers;
+        markers.accessExistingReadOnly(d + "/Markers");
+        MemoryMapped::Vector<ReadFlags> flagsFile;
+        flagsFile.accessExistingReadOnly(d + "/ReadFlags");
+        const uint64_t readCount = markers.size() / 2;
+        Reads reads;
+        reads.createNew(1, "", "", "", "", "", "", 4096);
+        reads.readFlags.resize(readCount);
+        for(uint64_t i = 0; i < readCount; i++) reads.readFlags[i] = flagsFile[i];
+        MemoryMapped::Vector<KmerInfo> kmerTable;
+        kmerTable.createNew("", 4096);
+        MemoryMapped::Vector<OrientedReadPair> candidates;
+        candidates.createNew(d + "/AlignmentCandidates", 4096);
+        MemoryMapped::Vector< array<uint64_t, 3> > statistics;
+        statistics.createNew(d + "/ReadLowHashStatistics", 4096);
+        {
+            CoutCapture capture;
+            LowHash0 lowHash0(
+                params->m, params->hashFraction,
+                params->minHashIterationCount, params->alignmentCandidatesPerRead,
+                params->log2MinHashBucketCount,
+                params->minBucketSize, params->maxBucketSize, params->minFrequency,
+                threadCount, kmerTable, reads, markers, candidates, statistics, d + "/", 4096);
+            std::ofstream console("LowHash0.console");
+            console << capture.str();
+        }
+        candidates.unreserve();
+        statistics.unreserve();
+        kmerTable.remove();
+        reads.remove();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// AlignmentData + CompressedAlignments written the way Assembler::computeAlignments stores them
+// (src/AssemblerAlign.cpp:262-287).
+int ref_store_alignments(const char* dir, uint64_t alignmentCount, const shasta_alignment_data* rows,
+    const uint64_t* compressedToc, const uint8_t* compressedData)
+{
+    try {
+        const std::string d(dir);
+        MemoryMapped::Vector<AlignmentData> alignmentData;
+        alignmentData.createNew(d + "/AlignmentData", 4096);
+        MemoryMapped::VectorOfVectors<char, uint64_t> compressedAlignments;
+        compressedAlignments.createNew(d + "/CompressedAlignments", 4096);
+        for(uint64_t i = 0; i < alignmentCount; i++) {
+            AlignmentData ad;
+            std::memcpy(&ad, rows + i, sizeof(ad));
+            alignmentData.push_back(ad);
+            const char* b = reinterpret_cast<const char*>(compressedData) + compressedToc[i];
+            compressedAlignments.appendVector(b, b + (compressedToc[i + 1] - compressedToc[i]));
+        }
+        alignmentData.unreserve();
+        compressedAlignments.unreserve();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+}  // extern "C"

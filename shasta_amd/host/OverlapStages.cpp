@@ -1,0 +1,221 @@
+#include "OverlapStages.hpp"
+
+#include <algorithm>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+namespace shasta_mi355x {
+namespace host {
+
+namespace {
+std::string dataName(const std::string& directory, const std::string& name)
+{
+    if(directory.empty()) return name;
+    return directory.back() == '/' ? directory + name : directory + "/" + name;
+}
+}  // namespace
+
+LowHash0::LowHash0(
+    size_t m, double hashFraction, size_t minHashIterationCount, double alignmentCandidatesPerRead,
+    size_t log2MinHashBucketCount, size_t minBucketSize, size_t maxBucketSize, size_t minFrequency,
+    size_t /* threadCount: the device does the work */,
+    const ReadFlagsVector& readFlags, const Markers& markers,
+    AlignmentCandidates& candidates, ReadLowHashStatistics& readLowHashStatistics,
+    const std::string& /* largeDataFileNamePrefix: no temporary files are needed */, size_t /* largeDataPageSize */)
+{
+    const uint64_t orientedReadCount = markers.size();
+    const uint64_t readCount = orientedReadCount / 2;
+    if(readCount == 0 || readFlags.size() != readCount) throw std::runtime_error("LowHash0: markers / read flags are not consistent.");
+
+    shasta_lowhash0_params p{};
+    p.m = m; p.hashFraction = hashFraction; p.minHashIterationCount = minHashIterationCount;
+    p.alignmentCandidatesPerRead = alignmentCandidatesPerRead; p.log2MinHashBucketCount = log2MinHashBucketCount;
+    p.minBucketSize = minBucketSize; p.maxBucketSize = maxBucketSize; p.minFrequency = minFrequency;
+
+    // src/LowHash0.cpp:123-125: one zeroed {sparse, good, crowded} triplet per read.
+    readLowHashStatistics.resize(readCount);
+
+    shasta_lowhash0_result r{};
+    if(shasta_mi355x_lowhash0(readCount, markers.toc.begin(), markers.data.begin(), readFlags.begin(), &p,
+        reinterpret_cast<uint64_t*>(readLowHashStatistics.begin()), &r)) {
+        throw std::runtime_error(shasta_mi355x_last_error());
+    }
+
+    // Console lines of src/LowHash0.cpp:89-98,193-196 ("capacity" is the reference's std::vector
+    // capacity, an allocator detail: the table size is printed in its place).
+    if(log2MinHashBucketCount > 31) {
+        std::cout << "log2MinHashBucketCount reduced from " << log2MinHashBucketCount << " to maximum allowed value 31." << std::endl;
+    }
+    std::cout << "LowHash0 algorithm will use 2^" << r.log2BucketCount;
+    std::cout << " = " << (1ULL << r.log2BucketCount) << " buckets. " << std::endl;
+    for(uint32_t iteration = 0; iteration < r.iterationCount; iteration++) {
+        std::cout << "Alignment candidates after lowhash iteration " << iteration;
+        std::cout << ": high frequency " << r.highFrequency[iteration];
+        std::cout << ", total " << r.total[iteration];
+        std::cout << ", capacity " << r.total[iteration] << "." << std::endl;
+    }
+
+    // LowHashBucketHistogram.csv, src/LowHash0.cpp:128,586-595.
+    {
+        std::ofstream csv("LowHashBucketHistogram.csv");
+        csv << "Iteration,BucketSize,BucketCount,FeatureCount\n";
+        for(uint64_t k = 0; k < r.histogramRowCount; k++) {
+            const uint64_t iteration = r.histogram[3 * k], bucketSize = r.histogram[3 * k + 1], frequency = r.histogram[3 * k + 2];
+            csv << iteration << "," << bucketSize << "," << frequency << "," << bucketSize * frequency << "\n";
+        }
+    }
+
+    // src/LowHash0.cpp:204-217.
+    for(uint64_t i = 0; i < r.candidateCount; i++) candidates.push_back(r.candidates[i]);
+    std::cout << "Found " << candidates.size() << " alignment candidates." << std::endl;
+    std::cout << "Average number of alignment candidates per oriented read is ";
+    std::cout << (2. * double(candidates.size())) / double(orientedReadCount) << "." << std::endl;
+    shasta_mi355x_lowhash0_free(&r);
+
+    // ReadLowHashStatistics.csv, src/LowHash0.cpp:220-243.
+    {
+        std::ofstream csv("ReadLowHashStatistics.csv");
+        csv << "ReadId,Palindromic,Features,Sparse,Good,Crowded,Total,FeatureSampling,"
+            "SparseFraction,GoodFraction,CrowdedFraction\n";
+        for(uint64_t readId = 0; readId < readCount; readId++) {
+            const std::array<uint64_t, 3>& counters = readLowHashStatistics[readId];
+            const uint64_t total = uint64_t(std::accumulate(counters.begin(), counters.end(), 0));   // int accumulator, as the reference
+            const uint64_t featureCount = markers.size(2 * readId) - (m - 1);
+            const double featureSampling = double(total) / double(featureCount);
+            csv << readId << ",";
+            csv << ((readFlags[readId] & 1) ? "Yes," : "No,");
+            csv << featureCount << ",";
+            csv << counters[0] << "," << counters[1] << "," << counters[2] << ",";
+            csv << total << ",";
+            csv << featureSampling << ",";
+            if(total == 0) csv << ",,\n";
+            else {
+                csv << double(counters[0]) / double(total) << ",";
+                csv << double(counters[1]) / double(total) << ",";
+                csv << double(counters[2]) / double(total) << "\n";
+            }
+        }
+    }
+}
+
+void findAlignmentCandidatesLowHash0(
+    const std::string& dataDirectory,
+    size_t m, double hashFraction, size_t minHashIterationCount, double alignmentCandidatesPerRead,
+    size_t log2MinHashBucketCount, size_t minBucketSize, size_t maxBucketSize, size_t minFrequency,
+    size_t threadCount, size_t largeDataPageSize)
+{
+    // checkMarkersAreOpen / reads: src/AssemblerLowHash.cpp:25-29.
+    Markers markers;
+    markers.accessExistingReadOnly(dataName(dataDirectory, "Markers"));
+    ReadFlagsVector readFlags;
+    readFlags.accessExistingReadOnly(dataName(dataDirectory, "ReadFlags"));
+    if(markers.size() / 2 == 0) throw std::runtime_error("Assertion failed: readCount > 0");
+
+    AlignmentCandidates candidates;
+    ReadLowHashStatistics readLowHashStatistics;
+    candidates.createNew(dataName(dataDirectory, "AlignmentCandidates"), largeDataPageSize);                 // :32
+    readLowHashStatistics.createNew(dataName(dataDirectory, "ReadLowHashStatistics"), largeDataPageSize);    // :33
+
+    LowHash0 lowHash(m, hashFraction, minHashIterationCount, alignmentCandidatesPerRead, log2MinHashBucketCount,
+        minBucketSize, maxBucketSize, minFrequency, threadCount, readFlags, markers, candidates, readLowHashStatistics,
+        dataDirectory, largeDataPageSize);
+
+    candidates.unreserve();                                                                                  // :54
+    readLowHashStatistics.unreserve();
+}
+
+void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
+    const std::string& dataDirectory, size_t largeDataPageSize)
+{
+    AlignmentTable table;
+    table.createNew(dataName(dataDirectory, "AlignmentTable"), largeDataPageSize);
+    // Every stored alignment appears under its two oriented reads and under their reverse
+    // complements (:513-536).
+    auto orientedReads = [](const shasta_alignment_data& ad, uint32_t (&o)[4]) {
+        const uint32_t o0 = ad.pair.readIds[0] << 1, o1 = (ad.pair.readIds[1] << 1) | (ad.pair.isSameStrand ? 0u : 1u);
+        o[0] = o0; o[1] = o1; o[2] = o0 ^ 1u; o[3] = o1 ^ 1u;
+    };
+    std::vector<uint32_t> counts(2 * readCount, 0);
+    for(uint64_t i = 0; i < alignmentData.size(); i++) { uint32_t o[4]; orientedReads(alignmentData[i], o); for(uint32_t v : o) ++counts[v]; }
+    table.fillFromCounts(counts);
+    std::vector<uint32_t> cursor(2 * readCount);
+    for(uint64_t k = 0; k < 2 * readCount; k++) cursor[k] = table.toc[k];
+    for(uint64_t i = 0; i < alignmentData.size(); i++) {
+        uint32_t o[4]; orientedReads(alignmentData[i], o);
+        for(uint32_t v : o) table.data[cursor[v]++] = uint32_t(i);
+    }
+    // Sort each section by the other oriented read, then by alignment index (:541-566).
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    for(uint64_t o0 = 0; o0 < 2 * readCount; o0++) {
+        uint32_t* section = table.begin(o0);
+        const uint64_t n = table.size(o0);
+        v.clear();
+        for(uint64_t k = 0; k < n; k++) {
+            const shasta_alignment_data& ad = alignmentData[section[k]];
+            // AlignmentData::getOther (src/Alignment.hpp:424-446): the partner of o0 in this alignment,
+            // reverse complemented if o0 appears reverse complemented.
+            uint32_t o[4]; orientedReads(ad, o);
+            uint32_t other;
+            if(o0 == o[0]) other = o[1];
+            else if(o0 == o[1]) other = o[0];
+            else if(o0 == o[2]) other = o[3];
+            else other = o[2];
+            v.push_back(std::make_pair(other, section[k]));
+        }
+        std::sort(v.begin(), v.end());
+        for(uint64_t k = 0; k < n; k++) section[k] = v[k].second;
+    }
+    table.unreserve();
+}
+
+void computeAlignments(const std::string& dataDirectory, const AlignOptions& alignOptions, size_t /* threadCount */, size_t largeDataPageSize)
+{
+    if(alignOptions.alignMethod != 4) throw std::runtime_error("computeAlignments: this library implements alignMethod 4 only.");
+    Markers markers;
+    markers.accessExistingReadOnly(dataName(dataDirectory, "Markers"));
+    AlignmentCandidates candidates;
+    candidates.accessExistingReadOnly(dataName(dataDirectory, "AlignmentCandidates"));
+    const uint64_t readCount = markers.size() / 2;
+
+    shasta_align4_options o{};
+    o.deltaX = alignOptions.align4DeltaX; o.deltaY = alignOptions.align4DeltaY;
+    o.minEntryCountPerCell = alignOptions.align4MinEntryCountPerCell;
+    o.maxDistanceFromBoundary = alignOptions.align4MaxDistanceFromBoundary;
+    o.minAlignedMarkerCount = alignOptions.minAlignedMarkerCount;
+    o.minAlignedFraction = alignOptions.minAlignedFraction;
+    o.maxSkip = alignOptions.maxSkip; o.maxDrift = alignOptions.maxDrift; o.maxTrim = alignOptions.maxTrim;
+    o.maxBand = uint64_t(alignOptions.maxBand);
+    o.matchScore = alignOptions.matchScore; o.mismatchScore = alignOptions.mismatchScore; o.gapScore = alignOptions.gapScore;
+    o.suppressContainments = alignOptions.suppressContainments ? 1 : 0;
+
+    shasta_align4_result r{};
+    if(shasta_mi355x_align4_batch(readCount, markers.toc.begin(), markers.data.begin(),
+        candidates.size(), candidates.begin(), &o, 0, &r)) {
+        throw std::runtime_error(shasta_mi355x_last_error());
+    }
+    uint64_t skipped = 0;
+    for(uint64_t i = 0; i < candidates.size(); i++) if((r.status[i] & 0x7f) == SHASTA_ALIGN_SKIPPED) ++skipped;
+    if(skipped) std::cout << skipped << " alignment candidates were skipped (resource limits), as the reference skips candidates whose alignment throws." << std::endl;
+
+    AlignmentDataVector alignmentData;
+    CompressedAlignments compressedAlignments;
+    alignmentData.createNew(dataName(dataDirectory, "AlignmentData"), largeDataPageSize);                    // :263
+    compressedAlignments.createNew(dataName(dataDirectory, "CompressedAlignments"), largeDataPageSize);      // :264
+    alignmentData.append(r.alignmentData, r.alignmentCount);
+    for(uint64_t i = 0; i < r.alignmentCount; i++) {
+        compressedAlignments.appendVector(reinterpret_cast<const char*>(r.compressedData + r.compressedToc[i]),
+            r.compressedToc[i + 1] - r.compressedToc[i]);
+    }
+    shasta_mi355x_align4_free(&r);
+    alignmentData.unreserve();                                                                               // :286-287
+    compressedAlignments.unreserve();
+    std::cout << "Found and stored " << alignmentData.size() << " good alignments." << std::endl;           // :294
+    computeAlignmentTable(readCount, alignmentData, dataDirectory, largeDataPageSize);                        // :296
+}
+
+}  // namespace host
+}  // namespace shasta_mi355x

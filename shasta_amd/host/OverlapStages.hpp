@@ -1,0 +1,74 @@
+// Host side of the two seams, in C++ as in the reference: the same entry points, argument lists,
+// console lines and side files, over Shasta's Data/ directory -- with the work done by
+// libshasta_mi355x.so through its C ABI (include/shasta_mi355x.h).
+//
+//   LowHash0                          <-> shasta::LowHash0::LowHash0          src/LowHash0.hpp:32-52
+//   findAlignmentCandidatesLowHash0   <-> Assembler::findAlignmentCandidatesLowHash0   src/AssemblerLowHash.cpp:10-55
+//   computeAlignments                 <-> Assembler::computeAlignments (alignMethod 4)  src/AssemblerAlign.cpp:208-304
+//   computeAlignmentTable             <-> Assembler::computeAlignmentTable    src/AssemblerAlign.cpp:509-571
+#pragma once
+
+#include "MappedVector.hpp"
+#include "../../include/shasta_mi355x.h"
+
+#include <array>
+#include <string>
+
+namespace shasta_mi355x {
+namespace host {
+
+#pragma pack(push, 1)
+struct CompressedMarker7 { uint8_t bytes[7]; };          // src/Marker.hpp:56-70
+#pragma pack(pop)
+static_assert(sizeof(CompressedMarker7) == 7, "CompressedMarker is 7 packed bytes");
+
+using Markers = MappedVectorOfVectors<CompressedMarker7, uint64_t>;          // Data/Markers.{toc,data}
+using ReadFlagsVector = MappedVector<uint8_t>;                               // Data/ReadFlags (bit 0 = isPalindromic)
+using AlignmentCandidates = MappedVector<shasta_oriented_read_pair>;         // Data/AlignmentCandidates
+using ReadLowHashStatistics = MappedVector<std::array<uint64_t, 3>>;         // Data/ReadLowHashStatistics
+using AlignmentDataVector = MappedVector<shasta_alignment_data>;             // Data/AlignmentData
+using CompressedAlignments = MappedVectorOfVectors<char, uint64_t>;          // Data/CompressedAlignments.{toc,data}
+using AlignmentTable = MappedVectorOfVectors<uint32_t, uint32_t>;            // Data/AlignmentTable.{toc,data}
+
+// The [Align] options computeAlignments reads (src/AssemblerOptions.hpp:177-198); defaults of
+// src/AssemblerOptions.cpp:380-489.
+struct AlignOptions {
+    int alignMethod = 4;
+    uint64_t maxSkip = 30, maxDrift = 30, maxTrim = 30;
+    uint64_t minAlignedMarkerCount = 100;
+    double minAlignedFraction = 0.;
+    int matchScore = 6, mismatchScore = -1, gapScore = -1;
+    int maxBand = 1000;
+    bool suppressContainments = false;
+    uint64_t align4DeltaX = 200, align4DeltaY = 10, align4MinEntryCountPerCell = 10, align4MaxDistanceFromBoundary = 100;
+};
+
+// Same argument list as the reference's constructor, with the two arguments it only uses for
+// the palindromic flag / not at all (Reads, kmerTable) replaced by the ReadFlags vector.  The
+// constructor does all the work, like the reference's.
+class LowHash0 {
+public:
+    LowHash0(
+        size_t m, double hashFraction, size_t minHashIterationCount, double alignmentCandidatesPerRead,
+        size_t log2MinHashBucketCount, size_t minBucketSize, size_t maxBucketSize, size_t minFrequency,
+        size_t threadCount,
+        const ReadFlagsVector& readFlags, const Markers& markers,
+        AlignmentCandidates& candidates, ReadLowHashStatistics& readLowHashStatistics,
+        const std::string& largeDataFileNamePrefix, size_t largeDataPageSize);
+};
+
+// dataDirectory = the run's Data/ directory (largeDataFileNamePrefix).  Side files are written to
+// the current directory, as the reference does.
+void findAlignmentCandidatesLowHash0(
+    const std::string& dataDirectory,
+    size_t m, double hashFraction, size_t minHashIterationCount, double alignmentCandidatesPerRead,
+    size_t log2MinHashBucketCount, size_t minBucketSize, size_t maxBucketSize, size_t minFrequency,
+    size_t threadCount, size_t largeDataPageSize = 4096);
+
+void computeAlignments(const std::string& dataDirectory, const AlignOptions&, size_t threadCount, size_t largeDataPageSize = 4096);
+
+void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
+    const std::string& dataDirectory, size_t largeDataPageSize = 4096);
+
+}  // namespace host
+}  // namespace shasta_mi355x

@@ -1,0 +1,41 @@
+// shasta_mi355x_stage: the stage-level entry points of the reference's scripts
+// (scripts/FindAlignmentCandidatesLowHash0.py, scripts/ComputeAlignments.py) on an existing
+// Data/ directory, with the work done on the GPU.
+//   shasta_mi355x_stage lowhash0 <Data> [m hashFraction minHashIterationCount alignmentCandidatesPerRead
+//                                        log2MinHashBucketCount minBucketSize maxBucketSize minFrequency]
+//   shasta_mi355x_stage align    <Data> [minAlignedMarkerCount minAlignedFraction maxSkip maxDrift maxTrim suppressContainments]
+// Exit codes follow srcMain/main.cpp:103-129: 0 success, 1 std::runtime_error / other exception.
+#include "OverlapStages.hpp"
+
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+using namespace shasta_mi355x::host;
+
+int main(int argc, char** argv)
+{
+    try {
+        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage lowhash0|align <DataDirectory> [options...]");
+        const std::string command = argv[1], data = argv[2];
+        auto arg = [&](int k, const char* fallback) { return std::string(argc > k ? argv[k] : fallback); };
+        if(command == "lowhash0") {
+            // Defaults: MinHashOptions, src/AssemblerOptions.cpp:327-371.
+            findAlignmentCandidatesLowHash0(data,
+                std::stoull(arg(3, "4")), std::stod(arg(4, "0.01")), std::stoull(arg(5, "10")), std::stod(arg(6, "20")),
+                std::stoull(arg(7, "0")), std::stoull(arg(8, "0")), std::stoull(arg(9, "10")), std::stoull(arg(10, "2")), 0);
+        } else if(command == "align") {
+            AlignOptions o;
+            o.minAlignedMarkerCount = std::stoull(arg(3, "100")); o.minAlignedFraction = std::stod(arg(4, "0"));
+            o.maxSkip = std::stoull(arg(5, "30")); o.maxDrift = std::stoull(arg(6, "30")); o.maxTrim = std::stoull(arg(7, "30"));
+            o.suppressContainments = std::stoull(arg(8, "0")) != 0;
+            computeAlignments(data, o, 0);
+        } else {
+            throw std::runtime_error("unknown command " + command);
+        }
+        return 0;
+    } catch(const std::exception& e) {
+        std::cout << e.what() << std::endl;
+        return 1;
+    }
+}

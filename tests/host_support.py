@@ -1,0 +1,65 @@
+"""ctypes access to the host layer's file classes (shasta_amd/host/test_shim.cpp) for the tests."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from shasta_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "shasta_amd", "_build", "libshasta_host_shim.so")
+STAGE = os.path.join(ROOT, "shasta_amd", "_build", "shasta_mi355x_stage")
+
+
+class HostShim:
+    def __init__(self):
+        self.lib = C.CDLL(SHIM)
+        self.lib.host_last_error.restype = C.c_char_p
+
+    def _check(self, rc, what):
+        if rc:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.host_last_error().decode()))
+
+    def write_data_dir(self, directory, toc, data7, flags=None):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self._check(self.lib.host_write_data_dir(directory.encode(), C.c_uint64((len(toc) - 1) // 2), abi.as_ptr(toc, C.c_uint64),
+                                                 C.c_void_p(data7.ctypes.data), fp), "host_write_data_dir")
+
+    def open_vector(self, path, object_size):
+        count, size = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.host_open_vector(path.encode(), C.c_uint64(object_size), C.byref(count), C.byref(size), None, C.c_uint64(0)), "host_open_vector")
+        out = np.zeros((count.value, object_size), dtype=np.uint8)
+        self._check(self.lib.host_open_vector(path.encode(), C.c_uint64(object_size), C.byref(count), C.byref(size),
+                                              C.c_void_p(out.ctypes.data), C.c_uint64(out.nbytes)), "host_open_vector")
+        return out, int(size.value)
+
+    def store_alignments(self, directory, alignment_data, compressed_toc, compressed_data):
+        rows = np.ascontiguousarray(alignment_data)
+        toc = np.ascontiguousarray(compressed_toc, dtype=np.uint64)
+        data = np.ascontiguousarray(compressed_data, dtype=np.uint8)
+        self._check(self.lib.host_store_alignments(directory.encode(), C.c_uint64(len(rows)), C.c_void_p(rows.ctypes.data),
+                                                   abi.as_ptr(toc, C.c_uint64), C.c_void_p(data.ctypes.data)), "host_store_alignments")
+
+    def compute_alignment_table(self, directory, read_count):
+        self._check(self.lib.host_compute_alignment_table(directory.encode(), C.c_uint64(read_count)), "host_compute_alignment_table")
+
+
+def alignment_table_expected(read_count, alignment_data):
+    """Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571) in numpy/python: per oriented
+    read, the indices of the stored alignments it takes part in (directly or reverse complemented),
+    sorted by (other oriented read, alignment index)."""
+    sections = [[] for _ in range(2 * read_count)]
+    for i, ad in enumerate(alignment_data):
+        o0 = int(ad["readId0"]) << 1
+        o1 = (int(ad["readId1"]) << 1) | (0 if ad["isSameStrand"] else 1)
+        for a, b in ((o0, o1), (o1, o0), (o0 ^ 1, o1 ^ 1), (o1 ^ 1, o0 ^ 1)):
+            sections[a].append((b, i))
+    toc = np.zeros(2 * read_count + 1, dtype=np.uint32)
+    data = []
+    for k, sec in enumerate(sections):
+        sec.sort()
+        data += [i for _, i in sec]
+        toc[k + 1] = len(data)
+    return toc, np.asarray(data, dtype=np.uint32)

@@ -1,0 +1,76 @@
+"""The C++ host layer (shasta_amd/host/): Shasta's Data/ file formats against the reference's own
+MemoryMapped containers (oracle/_ref), and computeAlignmentTable against its specification."""
+import os
+
+import numpy as np
+import pytest
+
+from shasta_amd import abi
+from tests import host_support, support
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if not os.path.exists(host_support.SHIM):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(host_support.ROOT, "shasta_amd", "csrc"), "host"])
+    return host_support.HostShim()
+
+
+def test_files_written_by_the_host_layer_open_in_the_reference(shim, ref_lib, tmp_path):
+    toc, kmer, data7 = support.small_marker_set(n_reads=60, genome_markers=5000, seed=81)
+    flags = np.zeros(60, np.uint8)
+    flags[[5, 9]] = 1
+    d = str(tmp_path)
+    shim.write_data_dir(d, toc, data7, flags)
+    # The reference's accessExistingReadOnly checks magic number, file size and object size.
+    m_toc, size = ref_lib.open_vector(os.path.join(d, "Markers.toc"), 8)
+    assert size == os.path.getsize(os.path.join(d, "Markers.toc")) and size % 4096 == 0
+    assert np.array_equal(m_toc.view("<u8").reshape(-1), np.asarray(toc, np.uint64))
+    m_data, size = ref_lib.open_vector(os.path.join(d, "Markers.data"), 7)
+    assert 0 <= os.path.getsize(os.path.join(d, "Markers.data")) - size < 7     # capacity is a whole number of objects
+    assert np.array_equal(m_data.reshape(-1), data7)
+    f, _ = ref_lib.open_vector(os.path.join(d, "ReadFlags"), 1)
+    assert np.array_equal(f.reshape(-1), flags)
+    with pytest.raises(RuntimeError, match="unexpected object size"):
+        ref_lib.open_vector(os.path.join(d, "Markers.data"), 8)
+
+
+def test_files_written_by_the_reference_open_in_the_host_layer_and_are_byte_identical(shim, ref_lib, tmp_path):
+    toc, kmer, data7 = support.small_marker_set(n_reads=60, genome_markers=5000, seed=82)
+    a, b = str(tmp_path / "ref"), str(tmp_path / "host")
+    os.makedirs(a); os.makedirs(b)
+    ref_lib.write_data_dir(a, toc, data7, None)
+    shim.write_data_dir(b, toc, data7, None)
+    for name, size in (("Markers.toc", 8), ("Markers.data", 7), ("ReadFlags", 1)):
+        x, _ = shim.open_vector(os.path.join(a, name), size)
+        y, _ = ref_lib.open_vector(os.path.join(a, name), size)
+        assert np.array_equal(x, y)
+        # Same header and same bytes as the reference's own file, after unreserve().
+        assert open(os.path.join(a, name), "rb").read() == open(os.path.join(b, name), "rb").read(), name
+    with pytest.raises(RuntimeError, match="unexpected object size"):
+        shim.open_vector(os.path.join(a, "Markers.toc"), 4)
+    with open(os.path.join(a, "ReadFlags"), "r+b") as f:
+        f.seek(56); f.write(b"\0" * 8)                       # clobber the magic number
+    with pytest.raises(RuntimeError, match="unexpected magic number"):
+        shim.open_vector(os.path.join(a, "ReadFlags"), 1)
+
+
+def test_stored_alignments_and_alignment_table(shim, ref_lib, oracle_lib, tmp_path):
+    toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=9000, seed=83)
+    p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)
+    cand = oracle_lib.lowhash0(toc, data7, None, p).candidates
+    al = oracle_lib.align4_batch(toc, data7, cand, abi.default_align4_options(minAlignedMarkerCount=40), want_ordinals=False, threads=0)
+    assert len(al.alignment_data) > 50
+    a, b = str(tmp_path / "ref"), str(tmp_path / "host")
+    os.makedirs(a); os.makedirs(b)
+    ref_lib.store_alignments(a, al.alignment_data, al.compressed_toc, al.compressed_data)
+    shim.store_alignments(b, al.alignment_data, al.compressed_toc, al.compressed_data)
+    for name in ("AlignmentData", "CompressedAlignments.toc", "CompressedAlignments.data"):
+        assert open(os.path.join(a, name), "rb").read() == open(os.path.join(b, name), "rb").read(), name
+    shim.compute_alignment_table(b, 150)
+    t, _ = ref_lib.open_vector(os.path.join(b, "AlignmentTable.toc"), 4)
+    dta, _ = ref_lib.open_vector(os.path.join(b, "AlignmentTable.data"), 4)
+    toc_expected, data_expected = host_support.alignment_table_expected(150, al.alignment_data)
+    assert np.array_equal(t.view("<u4").reshape(-1), toc_expected)
+    assert np.array_equal(dta.view("<u4").reshape(-1), data_expected)
