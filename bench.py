@@ -49,6 +49,29 @@ def align_options():
     return abi.default_align4_options()
 
 
+def load_traffic():
+    """HBM bytes per launch per kernel from the calibrated PMC passes (scripts/gpu_pmc.sh +
+    scripts/pmc_traffic.py, committed as profiles/r01_traffic_100k_reads.json)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_100k_reads.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def traffic_of(table, kernel_name):
+    """Traffic only applies to the workload it was measured on (100 k reads, 1 GPU); otherwise null."""
+    if table is None or TRAFFIC_WORKLOAD["reads"] != table.get("workload_reads"):
+        return None
+    for k, v in table.get("kernels", {}).items():
+        if kernel_name.replace(" ", "") in k.replace(" ", "") or k.replace(" ", "").endswith(kernel_name.replace(" ", "")):
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
+TRAFFIC_WORKLOAD = {"reads": None}
+
+
 def cpu_baseline(n_reads_sample, seed):
     """Reference CPU path on a bounded sample of the same workload (1/10 scale, same coverage)."""
     from oracle import bindings
@@ -113,6 +136,7 @@ def main():
     import shasta_amd
     from shasta_amd import abi
 
+    TRAFFIC_WORKLOAD["reads"] = args.reads if int(os.environ.get("WORLD_SIZE", "1")) == 1 else None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,7 +170,7 @@ def main():
             lh = ctx.lowhash0(p)
             if args.lowhash_only:
                 return lh, None, len(lh.candidates)
-            al = ctx.align4(lh.candidates, o, want_ordinals=False)
+            al = ctx.align4(lh.candidates, o, want_ordinals=False, borrow=True)
             return lh, al, len(lh.candidates)
     else:
         # ONE job over all GPUs (weak scaling: `reads` reads per GPU of one read set at the same
@@ -183,7 +207,7 @@ def main():
             if args.lowhash_only:
                 return lh, None, len(candidates)
             lo, hi = distributed.candidate_slice(len(candidates), rank, world)
-            al = ctx.align4(candidates[lo:hi], o, want_ordinals=False)
+            al = ctx.align4(candidates[lo:hi], o, want_ordinals=False, borrow=True)
             return lh, al, len(candidates)
 
     def sync():
@@ -197,6 +221,8 @@ def main():
     t0 = time.perf_counter()
     hash_s = hash_n = hash_b = dp_s = dp_cells = dp_bytes = 0
     lh_dev = al_dev = lh_wall = al_wall = 0.0
+    fw_s, fw_n, fw_cells, fw_bytes = [0.0] * 6, [0] * 6, [0] * 6, [0] * 6
+    tb_s = tb_n = 0
     for _ in range(args.steps):
         lh, al, pairs_total = step()
         kt = ctx.kernel_times()
@@ -206,6 +232,10 @@ def main():
             lh_wall += lh.seconds
         if al is not None:
             dp_s += kt.alignDpSeconds; dp_cells += kt.alignDpCells; dp_bytes += kt.alignBytes
+            for c in range(6):
+                fw_s[c] += kt.dpForwardSeconds[c]; fw_n[c] += kt.dpForwardLaunches[c]
+                fw_cells[c] += kt.dpForwardCells[c]; fw_bytes[c] += kt.dpForwardBytes[c]
+            tb_s += kt.dpTracebackSeconds; tb_n += kt.dpTracebackLaunches
             al_dev += al.device_seconds
             al_wall += al.seconds
     sync()
@@ -227,26 +257,44 @@ def main():
         hash_avg = hash_s / max(1, hash_n)
         hash_gbs = (hash_b / max(1, hash_n)) / hash_avg / 1e9 if hash_avg > 0 else 0.0
         kernels = {
-            "lowhash0_hash_windows": {
+            "hashWindowsKernel<4>": {
                 "launches_per_step": hash_n // steps, "avg_ms": hash_avg * 1e3,
                 "algorithmic_bytes_per_launch": hash_b // max(1, hash_n), "achieved_GBps": hash_gbs,
                 "seconds_per_step": hash_s / steps,
             },
         }
-        dominant = "lowhash0_hash_windows"
+        traffic_table = load_traffic()
         roofline = {"bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": hash_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": dominant}
+                    "frac": hash_gbs / HBM_PEAK_GBS, "traffic": traffic_of(traffic_table, "hashWindowsKernel"),
+                    "kernel": "hashWindowsKernel<4> (LowHash0 K1)"}
+        dominant_s = hash_s
         if al is not None and dp_s > 0:
-            dp_gbs = dp_bytes / dp_s / 1e9
             kernels["align4_banded_dp"] = {
                 "seconds_per_step": dp_s / steps, "gcups": dp_cells / dp_s / 1e9,
-                "algorithmic_bytes_per_step": dp_bytes // steps, "achieved_GBps": dp_gbs,
-                "note": "integer VALU/LDS-bound wavefront DP: HBM fraction is low by construction (SURVEY 8d)",
+                "algorithmic_bytes_per_step": dp_bytes // steps, "achieved_GBps": dp_bytes / dp_s / 1e9,
+                "note": "forward DP kernels + traceback, both streams; integer VALU-bound wavefront DP, not HBM-bound (SURVEY 8d)",
             }
-            if dp_s > hash_s:
-                roofline = {"bound": "hbm", "achieved": dp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": dp_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "align4_banded_dp",
-                            "gcups": dp_cells / dp_s / 1e9}
+            names = ["bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<32, 2>", "bandedDpForwardKernel<64, 2>",
+                     "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"]
+            for c in range(6):
+                if fw_n[c] == 0:
+                    continue
+                avg = fw_s[c] / fw_n[c]
+                per_launch = fw_bytes[c] / fw_n[c]
+                kernels[names[c]] = {"launches_per_step": fw_n[c] // steps, "avg_ms": avg * 1e3,
+                                     "algorithmic_bytes_per_launch": int(per_launch), "achieved_GBps": per_launch / avg / 1e9,
+                                     "gcups": fw_cells[c] / fw_s[c] / 1e9, "seconds_per_step": fw_s[c] / steps}
+                if fw_s[c] > dominant_s:
+                    dominant_s = fw_s[c]
+                    roofline = {"bound": "hbm", "achieved": per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": per_launch / avg / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of(traffic_table, names[c]),
+                                "kernel": names[c], "gcups": fw_cells[c] / fw_s[c] / 1e9,
+                                "note": "dominant kernel by time; integer max-plus DP bound by VALU issue: its algorithmic bytes "
+                                        "(4(nx+ny) per task) are tiny against its work (nx x bandWidth cells), so the HBM fraction "
+                                        "is low by construction; traffic is dominated by the 2-bit/cell trace it writes"}
+            if tb_n:
+                kernels["dpTracebackKernel<32>"] = {"launches_per_step": tb_n // steps, "avg_ms": tb_s / tb_n * 1e3,
+                                                    "seconds_per_step": tb_s / steps}
         out = {
             "metric": "candidate read-pairs aligned/sec (LowHash0+Align4)" if not args.lowhash_only
                       else "candidate read-pairs found/sec (LowHash0 only)",

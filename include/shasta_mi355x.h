@@ -139,6 +139,8 @@ typedef struct shasta_align4_result {
     uint64_t  kmerIdBytes;                   /* sum of 4*(nx+ny) over candidates    */
     double    seconds;
     double    deviceSeconds;
+    void*     owner;        /* NULL: the arrays are released by shasta_mi355x_align4_free; otherwise they
+                               belong to that context (align4_run_borrowed) and free only clears the struct */
 } shasta_align4_result;
 
 /* ------------------------------------------------------------------------- */
@@ -272,6 +274,16 @@ void shasta_mi355x_free(void*);
 /* Synchronous copy on the context's stream; kind 0 host->device, 1 device->host, 2 device->device. */
 int shasta_mi355x_memcpy(shasta_mi355x_ctx*, void* dst, const void* src, uint64_t bytes, int kind);
 
+/* Same as align4_run, but the result arrays belong to the context: they stay valid until the next
+ * align4_run_borrowed on this context (or its destruction) and shasta_mi355x_align4_free only
+ * clears the struct.  For callers that consume the result at once (the C++ adapter copies it into
+ * the memory mapped vectors): saves allocating, faulting in and unmapping the result every call. */
+int shasta_mi355x_align4_run_borrowed(
+    shasta_mi355x_ctx*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* options, int wantOrdinals,
+    shasta_align4_result* result);
+
 /* Timing of the dominant kernels of the last *_run call on this context,
  * measured with HIP events on the context's stream. */
 typedef struct shasta_mi355x_kernel_times {
@@ -282,6 +294,15 @@ typedef struct shasta_mi355x_kernel_times {
     uint64_t alignDpLaunches;
     uint64_t alignDpCells;
     uint64_t alignBytes;             /* sum 4(nx+ny)+8a                             */
+    /* The forward DP kernel per band-width class (0: <=32 diagonals ... 5: <=1024): HIP-event time
+     * of its launches, number of launches, DP cells (nx * bandWidth) and algorithmic bytes
+     * (4(nx+ny) per task) they covered. */
+    double   dpForwardSeconds[6];
+    uint64_t dpForwardLaunches[6];
+    uint64_t dpForwardCells[6];
+    uint64_t dpForwardBytes[6];
+    double   dpTracebackSeconds;
+    uint64_t dpTracebackLaunches;
 } shasta_mi355x_kernel_times;
 int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx*, shasta_mi355x_kernel_times*);
 

@@ -1,6 +1,6 @@
 """Turn the FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_pmc.sh) into per-launch HBM traffic per kernel,
 calibrated on the known-byte-count kernels as MI355X_MICROARCH.md (HBM section) prescribes.
-usage: python scripts/pmc_traffic.py gpurun_out > profiles/rNN_traffic.json"""
+usage: python scripts/pmc_traffic.py gpurun_out <reads> > profiles/rNN_traffic_<reads>.json"""
 import collections
 import csv
 import json
@@ -9,6 +9,7 @@ import re
 import sys
 
 root = sys.argv[1]
+workload_reads = int(sys.argv[2]) if len(sys.argv) > 2 else None
 
 
 def load(tag, counter):
@@ -27,7 +28,7 @@ def load(tag, counter):
     return agg, order
 
 
-out = {"unit": "bytes per launch", "note": "FETCH_SIZE/WRITE_SIZE are reported in KiB; factors = known bytes / reported bytes "
+out = {"workload_reads": workload_reads, "unit": "bytes per launch", "note": "FETCH_SIZE/WRITE_SIZE are reported in KiB; factors = known bytes / reported bytes "
        "on calibrateReadDwordKernel (dword loads, the hash kernel's pattern) and calibrateWriteRecordKernel "
        "(4 lanes x 8 B record stores, the DP trace's pattern)"}
 _, cal_f = load("fetch_cal", "FETCH_SIZE")

@@ -96,6 +96,7 @@ class Align4Result(C.Structure):
         ("kmerIdBytes", C.c_uint64),
         ("seconds", C.c_double),
         ("deviceSeconds", C.c_double),
+        ("owner", C.c_void_p),
     ]
 
 
@@ -108,6 +109,12 @@ class KernelTimes(C.Structure):
         ("alignDpLaunches", C.c_uint64),
         ("alignDpCells", C.c_uint64),
         ("alignBytes", C.c_uint64),
+        ("dpForwardSeconds", C.c_double * 6),
+        ("dpForwardLaunches", C.c_uint64 * 6),
+        ("dpForwardCells", C.c_uint64 * 6),
+        ("dpForwardBytes", C.c_uint64 * 6),
+        ("dpTracebackSeconds", C.c_double),
+        ("dpTracebackLaunches", C.c_uint64),
     ]
 
 

@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <thread>
 
 namespace shasta_mi355x {
@@ -371,15 +373,9 @@ __device__ unsigned long long g_phaseCycles[16];
 #define PHASE_BEGIN() do {} while(0)
 #endif
 
-// floor(v / d) with magic = min(floor(2^32 / d), 2^32 - 1): the estimate is at most 2 low.
-__device__ __forceinline__ uint32_t divMagic(uint32_t v, uint32_t d, uint32_t magic)
-{
-    uint32_t q = __umulhi(v, magic);
-    uint32_t r = v - q * d;
-    if(r >= d) { ++q; r -= d; }
-    if(r >= d) { ++q; }
-    return q;
-}
+// floor(v / d) = umulhi(v, magic) with magic = floor(2^32 / d) + 1, exact whenever v * d < 2^32
+// (the host only sends a candidate to this kernel if (nx + ny) * max(deltaX, deltaY) < 2^32).
+__device__ __forceinline__ uint32_t divMagic(uint32_t v, uint32_t magic) { return __umulhi(v, magic); }
 
 // LDS traffic of ONE wave is ordered by the hardware; this only stops the compiler from moving
 // LDS accesses across it and drains the counters.  Waves of a chunk never wait for each other
@@ -515,12 +511,10 @@ align4CellsChunkKernel(
                 const uint32_t t = s0 + u * WAVE + lane;
                 const uint32_t x = swapped ? t : ti[u], y = swapped ? ti[u] : t;
                 const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
-                const uint32_t iX = divMagic(X, opt.deltaX, magicX), iY = divMagic(Y, opt.deltaY, magicY);
-                bool h = hit[u];
-                if(h && (iX >= 65536u || iY >= 65535u)) { overflow = 2; h = false; }
-                // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; larger geometry
-                // climbs to the HBM-scratch kernel.
-                if(h && (iX >= (1u << CELLS_IX_BITS) || iY >= (1u << CELLS_IY_BITS))) { overflow = max(overflow, 1); reason |= 4; h = false; }
+                const uint32_t iX = divMagic(X, magicX), iY = divMagic(Y, magicY);
+                // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; the host only sends
+                // candidates whose cell indices fit (others run in the HBM-scratch kernel).
+                const bool h = hit[u];
                 key[u] = h ? ((iY << 16) | iX) : EMPTY32;
                 // Fold runs of consecutive lanes with the same cell into their first lane.
                 const uint32_t prevKey = __shfl_up(key[u], 1, WAVE);
@@ -858,7 +852,7 @@ struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneB
 __global__ void __launch_bounds__(256)
 dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
-    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound
+    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long cells = 0, words = 0;
@@ -880,6 +874,13 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
     for(int c = 0; c < DP_CLASSES; c++) {
         const uint64_t votes = __ballot(cls == c);
         if(votes && laneId() == __ffsll((unsigned long long)votes) - 1) atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
+    }
+    if(cls >= 0) {
+        // Per class (rare contention: tasks of a wave mostly share a class after the cells kernels).
+        const DpTask task = tasks[t];
+        const PairDesc pd = pairs[task.pair];
+        atomicAdd(&sums[2 + cls], cells);
+        atomicAdd(&sums[8 + cls], 4ULL * (uint64_t(pd.nx) + pd.ny));
     }
     for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
     if(laneId() == 0 && cells) { atomicAdd(&sums[0], cells); atomicAdd(&sums[1], words); }
@@ -1404,11 +1405,14 @@ struct BatchScratch {
     DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, iterations)
     DeviceBuffer<uint64_t> bundleWords;
     DeviceBuffer<DpEnd> ends;
+    PinnedBuffer pinRows, pinToc, pinBytes, pinStatus, pinOrdToc, pinOrdinals;   // device-to-host staging
     DeviceBuffer<uint64_t> bigOffsets;
 };
 
 // A host worker's stream and sort workspace (two workers pipeline the batches of one call).
-struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; };
+// `wide` is a side stream for the few wide-band DP tasks (one wavefront each, latency-bound): they
+// overlap the narrow classes instead of occupying the GPU alone.
+struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; hipStream_t wide; };
 
 constexpr int CELLS_CLASSES = 3;
 constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {11, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
@@ -1446,12 +1450,12 @@ void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int 
 }
 
 template<int G, int C>
-void launchDpForward(Context& ctx, const WorkStream& ws, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
+void launchDpForward(Context& ctx, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
 {
     const uint32_t taskCount = layout.taskStart[cls + 1] - layout.taskStart[cls];
     const uint32_t bundleCount = layout.bundleStart[cls + 1] - layout.bundleStart[cls];
     if(taskCount == 0) return;
-    hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, ws.stream,
+    hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
         (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(),
         sortedIds + layout.taskStart[cls], taskCount,
         (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
@@ -1462,8 +1466,16 @@ void launchDpForward(Context& ctx, const WorkStream& ws, BatchScratch& b, const 
 // K10 for the taskCount tasks in b.tasks (pairs in b.pairs): fills b.results, b.ordScratch and
 // b.pairBest.  Returns the number of DP cells (sum of nx * bandWidth); forwardSeconds gets the
 // HIP-event time of the forward launches when evA/evB are given.
+// Timing events of one batch's DP: start/stop around the forward launch of every class and around the traceback.
+struct DpEvents {
+    hipEvent_t start[DP_CLASSES + 1], stop[DP_CLASSES + 1], fork, join;
+    void create() { for(int k = 0; k <= DP_CLASSES; k++) { HIP_CHECK(hipEventCreate(&start[k])); HIP_CHECK(hipEventCreate(&stop[k])); } HIP_CHECK(hipEventCreate(&fork)); HIP_CHECK(hipEventCreate(&join)); }
+    void destroy() { for(int k = 0; k <= DP_CLASSES; k++) { (void)hipEventDestroy(start[k]); (void)hipEventDestroy(stop[k]); } (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
+};
+struct DpBatchStats { uint64_t cells[DP_CLASSES] = {0}, bytes[DP_CLASSES] = {0}; uint32_t tasks[DP_CLASSES] = {0}; };
+
 uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
-    hipEvent_t evA, hipEvent_t evB, uint32_t* launches)
+    DpEvents* ev, DpBatchStats* stats)
 {
     hipStream_t stream = ws.stream;
     b.dpKeysA.reserve(taskCount, stream); b.dpKeysB.reserve(taskCount, stream);
@@ -1471,9 +1483,9 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
     b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
     b.results.reserve(taskCount, stream); b.ends.reserve(taskCount, stream);
-    b.counters.reserve(16, stream); b.dpCells.reserve(2, stream);
+    b.counters.reserve(16, stream); b.dpCells.reserve(16, stream);
     HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
-    HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, 2 * sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, 16 * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(dpSizeKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
         (const DpTask*)b.tasks.data(), (const PairDesc*)b.pairs.data(), taskCount,
         b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
@@ -1484,7 +1496,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
     HIP_CHECK(hipGetLastError());
     uint32_t classCounts[DP_CLASSES];
-    unsigned long long sums[2];
+    unsigned long long sums[16];
     HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, sizeof(classCounts), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(sums, b.dpCells.data(), sizeof(sums), hipMemcpyDeviceToHost, stream));
     const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
@@ -1506,13 +1518,25 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     b.trace.reserve(sums[1] + 64, stream);
     b.ordScratch.reserve(2 * ordTotal + 2, stream);
 
-    if(evA) HIP_CHECK(hipEventRecord(evA, stream));
-    launchDpForward<16, 2>(ctx, ws, b, sortedIds, layout, 0);
-    launchDpForward<32, 2>(ctx, ws, b, sortedIds, layout, 1);
-    launchDpForward<64, 2>(ctx, ws, b, sortedIds, layout, 2);
-    launchDpForward<64, 4>(ctx, ws, b, sortedIds, layout, 3);
-    launchDpForward<64, 8>(ctx, ws, b, sortedIds, layout, 4);
-    launchDpForward<64, 16>(ctx, ws, b, sortedIds, layout, 5);
+    // Wide bands (classes 3-5: few tasks, one wavefront each) go to the side stream, widest first;
+    // the narrow classes run on the main stream meanwhile.
+    const bool fork = ws.wide != nullptr && ev != nullptr && (classCounts[3] || classCounts[4] || classCounts[5]);
+    hipStream_t wideStream = fork ? ws.wide : stream;
+    if(fork) { HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); }
+    auto timed = [&](int cls, hipStream_t st, auto launch) {
+        if(ev) HIP_CHECK(hipEventRecord(ev->start[cls], st));
+        launch(st);
+        if(ev) HIP_CHECK(hipEventRecord(ev->stop[cls], st));
+    };
+    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(ctx, st, b, sortedIds, layout, 5); });
+    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(ctx, st, b, sortedIds, layout, 4); });
+    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(ctx, st, b, sortedIds, layout, 3); });
+    if(fork) HIP_CHECK(hipEventRecord(ev->join, ws.wide));
+    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(ctx, st, b, sortedIds, layout, 1); });
+    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(ctx, st, b, sortedIds, layout, 2); });
+    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(ctx, st, b, sortedIds, layout, 0); });
+    if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
+    if(ev) HIP_CHECK(hipEventRecord(ev->start[DP_CLASSES], stream));
     {
         // 256-byte chunks (8 iterations of the narrow classes); class 5 holds one iteration per chunk.
         const uint32_t small = 0, large = taskCount - small;
@@ -1526,15 +1550,36 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
             (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
     }
     HIP_CHECK(hipGetLastError());
-    if(evB) HIP_CHECK(hipEventRecord(evB, stream));
-    if(launches) { *launches = 1; for(int c = 0; c < DP_CLASSES; c++) *launches += classCounts[c] ? 1 : 0; }
+    if(ev) HIP_CHECK(hipEventRecord(ev->stop[DP_CLASSES], stream));
+    if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = sums[2 + c]; stats->bytes[c] = sums[8 + c]; stats->tasks[c] = classCounts[c]; }
     return sums[0];
 }
+
+struct BatchOutput {
+    std::vector<shasta_alignment_data> rows;
+    std::vector<uint64_t> tocEnds, ordToc;
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> ordinals;
+    uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
+    double dpSeconds = 0, forwardSeconds[DP_CLASSES] = {0}, tracebackSeconds = 0;
+    DpBatchStats dpStats;
+    bool hadTasks = false;
+};
+
+// Results of a "borrowed" call live here, in the context, and are reused by the next call: no
+// half-gigabyte malloc / page-fault / munmap cycle per call.
+struct AlignStore {
+    std::vector<BatchOutput> outputs;
+    std::vector<shasta_alignment_data> rows;
+    std::vector<uint64_t> compressedToc, ordinalsToc;
+    std::vector<uint8_t> bytes, status;
+    std::vector<uint32_t> ordinals;
+};
 
 }  // namespace
 
 void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
-    const shasta_align4_options& options, bool wantOrdinals, shasta_align4_result& result)
+    const shasta_align4_options& options, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
 {
     std::memset(&result, 0, sizeof(result));
     const auto t0 = std::chrono::steady_clock::now();
@@ -1543,16 +1588,20 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     const uint64_t BATCH = 1ULL << 17;
     const uint64_t batchCount = (candidateCount + BATCH - 1) / BATCH;
 
-    struct BatchOutput {
-        std::vector<shasta_alignment_data> rows;
-        std::vector<uint64_t> tocEnds, ordToc;
-        std::vector<uint8_t> bytes;
-        std::vector<uint32_t> ordinals;
-        uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
-        double dpSeconds = 0;
-    };
-    std::vector<BatchOutput> outputs(batchCount);
-    std::vector<uint8_t> outStatus(candidateCount);
+    if(borrowed && !ctx.alignStore) ctx.alignStore = std::make_shared<AlignStore>();
+    AlignStore localStore;
+    AlignStore& store = borrowed ? *static_cast<AlignStore*>(ctx.alignStore.get()) : localStore;
+    std::vector<BatchOutput>& outputs = store.outputs;
+    if(outputs.size() < batchCount) outputs.resize(batchCount);
+    for(uint64_t k = 0; k < batchCount; k++) {
+        BatchOutput& o = outputs[k];
+        o.dpCells = o.kmerIdBytes = o.alignedBytes = o.dpLaunches = 0; o.dpSeconds = o.tracebackSeconds = 0; o.hadTasks = false;
+        for(int c = 0; c < DP_CLASSES; c++) o.forwardSeconds[c] = 0;
+        o.dpStats = DpBatchStats();
+        o.ordToc.clear(); o.ordinals.clear();
+    }
+    std::vector<uint8_t>& outStatus = store.status;
+    outStatus.resize(std::max<uint64_t>(1, candidateCount));
 
     // Two host workers, each with its own stream and grow-only scratch kept in the context, take
     // the batches alternately: one worker's host-side preparation and result copies overlap the
@@ -1561,7 +1610,8 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         hipStream_t stream = nullptr;
         RadixSortWorkspace* sortWs = nullptr;
         BatchScratch* scratch = nullptr;
-        hipEvent_t evA = nullptr, evB = nullptr;
+        hipStream_t wide = nullptr;
+        DpEvents ev;
         std::vector<PairDesc> hostPairs;
         std::vector<uint64_t> hostToc64;
         std::string error;
@@ -1574,7 +1624,9 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         workers[k].stream = k == 0 ? ctx.stream : ctx.stream2;
         workers[k].sortWs = k == 0 ? &ctx.sortWs : &ctx.sortWs2;
         workers[k].scratch = static_cast<BatchScratch*>(ctx.alignScratch[k].get());
-        HIP_CHECK(hipEventCreate(&workers[k].evA)); HIP_CHECK(hipEventCreate(&workers[k].evB));
+        if(!ctx.wideStream[k]) HIP_CHECK(hipStreamCreateWithFlags(&ctx.wideStream[k], hipStreamNonBlocking));
+        workers[k].wide = ctx.wideStream[k];
+        workers[k].ev.create();
     }
     hipEvent_t evBegin, evEnd, evOther;
     HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd)); HIP_CHECK(hipEventCreate(&evOther));
@@ -1582,7 +1634,7 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
 
     auto processBatch = [&](Worker& w, uint64_t batchIndex) {
         hipStream_t stream = w.stream;
-        const WorkStream ws{w.stream, w.sortWs};
+        const WorkStream ws{w.stream, w.sortWs, w.wide};
         BatchScratch& b = *w.scratch;
         BatchOutput& out = outputs[batchIndex];
         std::vector<PairDesc>& hostPairs = w.hostPairs;
@@ -1640,9 +1692,12 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
             // diagonal) at load <= 3/4.  Overflow is detected on the device and climbs one class.
             // The packed LDS cell word counts up to 2^CELLS_COUNT_BITS - 1 entries; a cell holds at most
             // ceil(deltaX * deltaY / 2) (one (x,y) per lattice point of the right parity).
-            const bool packedOk = (uint64_t(opt.deltaX) * opt.deltaY + 1) / 2 < (1ULL << CELLS_COUNT_BITS);
+            const bool packedOk = (uint64_t(opt.deltaX) * opt.deltaY + 1) / 2 < (1ULL << CELLS_COUNT_BITS) && opt.deltaX >= 2 && opt.deltaY >= 2;
             auto classFor = [&](uint64_t tabled, uint64_t nx, uint64_t ny) -> int {
                 if(nx >= 65535 || ny >= 65535 || !packedOk) return CELLS_CLASSES;
+                // Cell indices must fit the packed word and the single-multiply division must be exact.
+                if((nx + ny) / opt.deltaX >= (1ULL << CELLS_IX_BITS) || (nx + ny) / opt.deltaY >= (1ULL << CELLS_IY_BITS)) return CELLS_CLASSES;
+                if((nx + ny) * std::max<uint64_t>(opt.deltaX, opt.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
                 const uint64_t cells = (nx * ny >> 13) + (nx + ny) / 32 + 32;
                 for(int c = 0; c < CELLS_CLASSES; c++) {
                     if(tabled < (1ULL << CELLS_NA_LOG2[c]) && 4 * cells <= (3ULL << CELLS_SC_LOG2[c])) return c;
@@ -1705,8 +1760,9 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
                 }
                 std::fprintf(stderr, "cells: HBM-scratch list %zu\n", bigList.size());
             }
-            const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX, 0xffffffffULL));
-            const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY, 0xffffffffULL));
+            // deltaX, deltaY >= 2 here (packedOk fails for 1 x anything >= 2046... and d = 1 gives magic 2^32): guard.
+            const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX + 1, 0xffffffffULL));
+            const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY + 1, 0xffffffffULL));
             b.pairList.reserve(2ULL * n + 16, stream);
             size_t membersUploaded = 0;
             for(int round = 0; round < CELLS_CLASSES; round++) {
@@ -1809,9 +1865,9 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         if(taskCount > taskCapacity) throw std::runtime_error("Align4: task list overflow.");
 
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
-        uint32_t dpLaunchesBatch = 0;
         if(taskCount) {
-            out.dpCells += runDpTasks(ctx, ws, b, taskCount, opt, w.evA, w.evB, &dpLaunchesBatch);
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, opt, &w.ev, &out.dpStats);
+            out.hadTasks = true;
             hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
                 (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
                 (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data());
@@ -1848,27 +1904,39 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         HIP_CHECK(hipGetLastError());
 
         // Copy this batch's results out (assembled in candidate order once every batch is done).
-        out.rows.resize(storedCount);
-        hostToc64.resize(storedCount);
+        // Device -> pinned staging (asynchronous, PCIe speed) -> the batch's output vectors.
+        void* pinRows = b.pinRows.reserve(storedCount * sizeof(shasta_alignment_data));
+        void* pinToc = b.pinToc.reserve(storedCount * sizeof(uint64_t));
+        void* pinBytes = b.pinBytes.reserve(byteTotal);
+        void* pinStatus = b.pinStatus.reserve(n);
+        void* pinOrdToc = nullptr; void* pinOrdinals = nullptr;
         if(storedCount) {
-            HIP_CHECK(hipMemcpyAsync(out.rows.data(), b.rowsOut.data(), storedCount * sizeof(shasta_alignment_data), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(hostToc64.data(), b.compressedToc.data(), storedCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(pinRows, b.rowsOut.data(), storedCount * sizeof(shasta_alignment_data), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(pinToc, b.compressedToc.data(), storedCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         }
-        out.bytes.resize(byteTotal);
-        if(byteTotal) HIP_CHECK(hipMemcpyAsync(out.bytes.data(), b.bytes.data(), byteTotal, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(outStatus.data() + batchBegin, b.status.data(), n, hipMemcpyDeviceToHost, stream));
+        if(byteTotal) HIP_CHECK(hipMemcpyAsync(pinBytes, b.bytes.data(), byteTotal, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(pinStatus, b.status.data(), n, hipMemcpyDeviceToHost, stream));
         if(wantOrdinals) {
-            out.ordToc.resize(uint64_t(n) + 1);
-            HIP_CHECK(hipMemcpyAsync(out.ordToc.data(), b.ordCounts.data(), (uint64_t(n) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-            out.ordinals.resize(2 * ordTotalOut);
+            pinOrdToc = b.pinOrdToc.reserve((uint64_t(n) + 1) * sizeof(uint64_t));
+            pinOrdinals = b.pinOrdinals.reserve(2 * ordTotalOut * sizeof(uint32_t));
+            HIP_CHECK(hipMemcpyAsync(pinOrdToc, b.ordCounts.data(), (uint64_t(n) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
             if(ordTotalOut) {
                 b.ordOut.reserve(2 * ordTotalOut, stream);
                 hipLaunchKernelGGL(gatherOrdinalsKernel, dim3(divUp(uint64_t(n) * 64, 256)), dim3(256), 0, stream,
                     (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(), (const uint64_t*)b.ordCounts.data(), n,
                     (const uint32_t*)b.ordScratch.data(), b.ordOut.data());
                 HIP_CHECK(hipGetLastError());
-                HIP_CHECK(hipMemcpyAsync(out.ordinals.data(), b.ordOut.data(), 2 * ordTotalOut * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(pinOrdinals, b.ordOut.data(), 2 * ordTotalOut * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             }
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        out.rows.assign(static_cast<const shasta_alignment_data*>(pinRows), static_cast<const shasta_alignment_data*>(pinRows) + storedCount);
+        hostToc64.assign(static_cast<const uint64_t*>(pinToc), static_cast<const uint64_t*>(pinToc) + storedCount);
+        out.bytes.assign(static_cast<const uint8_t*>(pinBytes), static_cast<const uint8_t*>(pinBytes) + byteTotal);
+        std::memcpy(outStatus.data() + batchBegin, pinStatus, n);
+        if(wantOrdinals) {
+            out.ordToc.assign(static_cast<const uint64_t*>(pinOrdToc), static_cast<const uint64_t*>(pinOrdToc) + uint64_t(n) + 1);
+            out.ordinals.assign(static_cast<const uint32_t*>(pinOrdinals), static_cast<const uint32_t*>(pinOrdinals) + 2 * ordTotalOut);
         }
         HIP_CHECK(hipStreamSynchronize(stream));
         // CSR of CompressedAlignments: end offset of each stored alignment, relative to this batch.
@@ -1877,9 +1945,17 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         for(uint32_t k = 0; k < storedCount; k++) out.alignedBytes += 8ULL * out.rows[k].info.markerCount;
         if(taskCount) {
             float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, w.evA, w.evB));
-            out.dpSeconds = ms * 1e-3;
-            out.dpLaunches = dpLaunchesBatch;
+            for(int c = 0; c < DP_CLASSES; c++) {
+                if(!out.dpStats.tasks[c]) continue;
+                HIP_CHECK(hipEventElapsedTime(&ms, w.ev.start[c], w.ev.stop[c]));
+                out.forwardSeconds[c] = ms * 1e-3;
+                out.dpSeconds += ms * 1e-3;
+                ++out.dpLaunches;
+            }
+            HIP_CHECK(hipEventElapsedTime(&ms, w.ev.start[DP_CLASSES], w.ev.stop[DP_CLASSES]));
+            out.tracebackSeconds = ms * 1e-3;
+            out.dpSeconds += ms * 1e-3;
+            ++out.dpLaunches;
         }
 
     };
@@ -1913,7 +1989,7 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
     (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evOther);
-    for(int k = 0; k < 2; k++) { (void)hipEventDestroy(workers[k].evA); (void)hipEventDestroy(workers[k].evB); }
+    for(int k = 0; k < 2; k++) workers[k].ev.destroy();
     for(int k = 0; k < 2; k++) if(!workers[k].error.empty()) throw std::runtime_error(workers[k].error);
 
 #ifdef SHASTA_PROFILE_PHASES
@@ -1931,20 +2007,35 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     // Assemble the outputs in candidate order.
     uint64_t rowTotal = 0, byteTotalAll = 0, ordTotalAll = 0, dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
     double dpSeconds = 0;
-    for(const BatchOutput& o : outputs) {
+    for(uint64_t k = 0; k < batchCount; k++) {
+        const BatchOutput& o = outputs[k];
         rowTotal += o.rows.size(); byteTotalAll += o.bytes.size(); ordTotalAll += o.ordinals.size() / 2;
         dpCellsTotal += o.dpCells; kmerIdBytes += o.kmerIdBytes; alignedBytes += o.alignedBytes; dpLaunches += o.dpLaunches;
         dpSeconds += o.dpSeconds;
     }
-    auto allocate = [](size_t bytes) { void* p = std::malloc(std::max<size_t>(1, bytes)); if(!p) throw std::bad_alloc(); return p; };
-    result.alignmentData = static_cast<shasta_alignment_data*>(allocate(rowTotal * sizeof(shasta_alignment_data)));
-    result.compressedToc = static_cast<uint64_t*>(allocate((rowTotal + 1) * sizeof(uint64_t)));
-    result.compressedData = static_cast<uint8_t*>(allocate(byteTotalAll));
-    result.status = mallocCopy(outStatus);
-    if(wantOrdinals) {
-        result.ordinalsToc = static_cast<uint64_t*>(allocate((candidateCount + 1) * sizeof(uint64_t)));
-        result.ordinals = static_cast<uint32_t*>(allocate(2 * ordTotalAll * sizeof(uint32_t)));
-        result.ordinalsToc[0] = 0;
+    if(borrowed) {
+        store.rows.resize(std::max<uint64_t>(1, rowTotal)); store.compressedToc.resize(rowTotal + 1);
+        store.bytes.resize(std::max<uint64_t>(1, byteTotalAll));
+        result.alignmentData = store.rows.data(); result.compressedToc = store.compressedToc.data();
+        result.compressedData = store.bytes.data(); result.status = store.status.data();
+        if(wantOrdinals) {
+            store.ordinalsToc.resize(candidateCount + 1); store.ordinals.resize(std::max<uint64_t>(1, 2 * ordTotalAll));
+            result.ordinalsToc = store.ordinalsToc.data(); result.ordinals = store.ordinals.data();
+            result.ordinalsToc[0] = 0;
+        }
+        result.owner = &ctx;
+    } else {
+        auto allocate = [](size_t bytes) { void* p = std::malloc(std::max<size_t>(1, bytes)); if(!p) throw std::bad_alloc(); return p; };
+        result.alignmentData = static_cast<shasta_alignment_data*>(allocate(rowTotal * sizeof(shasta_alignment_data)));
+        result.compressedToc = static_cast<uint64_t*>(allocate((rowTotal + 1) * sizeof(uint64_t)));
+        result.compressedData = static_cast<uint8_t*>(allocate(byteTotalAll));
+        result.status = static_cast<uint8_t*>(allocate(candidateCount));
+        if(candidateCount) std::memcpy(result.status, outStatus.data(), candidateCount);
+        if(wantOrdinals) {
+            result.ordinalsToc = static_cast<uint64_t*>(allocate((candidateCount + 1) * sizeof(uint64_t)));
+            result.ordinals = static_cast<uint32_t*>(allocate(2 * ordTotalAll * sizeof(uint32_t)));
+            result.ordinalsToc[0] = 0;
+        }
     }
     result.compressedToc[0] = 0;
     uint64_t rowBase = 0, byteBase = 0, ordBase = 0;
@@ -1961,6 +2052,18 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         rowBase += o.rows.size(); byteBase += o.bytes.size();
     }
 
+    for(int c = 0; c < DP_CLASSES; c++) { ctx.times.dpForwardSeconds[c] = 0; ctx.times.dpForwardLaunches[c] = 0; ctx.times.dpForwardCells[c] = 0; ctx.times.dpForwardBytes[c] = 0; }
+    ctx.times.dpTracebackSeconds = 0; ctx.times.dpTracebackLaunches = 0;
+    for(uint64_t k = 0; k < batchCount; k++) {
+        const BatchOutput& o = outputs[k];
+        if(!o.hadTasks) continue;
+        for(int c = 0; c < DP_CLASSES; c++) {
+            if(!o.dpStats.tasks[c]) continue;
+            ctx.times.dpForwardSeconds[c] += o.forwardSeconds[c]; ctx.times.dpForwardLaunches[c] += 1;
+            ctx.times.dpForwardCells[c] += o.dpStats.cells[c]; ctx.times.dpForwardBytes[c] += o.dpStats.bytes[c];
+        }
+        ctx.times.dpTracebackSeconds += o.tracebackSeconds; ctx.times.dpTracebackLaunches += 1;
+    }
     ctx.times.alignDpSeconds = dpSeconds;
     ctx.times.alignDpLaunches = dpLaunches;
     ctx.times.alignDpCells = dpCellsTotal;
@@ -1973,6 +2076,7 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
 
 void align4Free(shasta_align4_result& r)
 {
+    if(r.owner) { std::memset(&r, 0, sizeof(r)); return; }     // borrowed: the arrays belong to the context
     std::free(r.alignmentData); std::free(r.compressedToc); std::free(r.compressedData);
     std::free(r.status); std::free(r.ordinalsToc); std::free(r.ordinals);
     std::memset(&r, 0, sizeof(r));
@@ -2006,8 +2110,8 @@ void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t 
     DeviceOptions opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
-    const WorkStream ws{ctx.stream, &ctx.sortWs};
-    (void)runDpTasks(ctx, ws, b, 1, opt, nullptr, nullptr, nullptr);
+    const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
+    (void)runDpTasks(ctx, ws, b, 1, opt, nullptr, nullptr);
     DpResult r;
     HIP_CHECK(hipMemcpyAsync(&r, b.results.data(), sizeof(r), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));

@@ -202,6 +202,17 @@ int shasta_mi355x_align4_run(shasta_mi355x_ctx* c, uint64_t candidateCount,
     API_END(1)
 }
 
+int shasta_mi355x_align4_run_borrowed(shasta_mi355x_ctx* c, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align4_options* options,
+    int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!c || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align4_run_borrowed: null argument");
+    align4Run(c->impl, candidateCount, candidates, *options, wantOrdinals != 0, *result, true);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_align4_batch(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
     uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options* options, int wantOrdinals, shasta_align4_result* result)

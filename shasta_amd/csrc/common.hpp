@@ -56,6 +56,31 @@ private:
     size_t cap = 0;
 };
 
+// Page-locked host staging memory that only grows (device-to-host copies into pageable memory go
+// through the runtime's small bounce buffers; into pinned memory they run at PCIe speed).
+class PinnedBuffer {
+public:
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() { if(p) (void)hipHostFree(p); }
+    void* reserve(size_t bytes)
+    {
+        if(bytes > cap) {
+            if(p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t newCap = bytes + bytes / 4 + 4096;
+            HIP_CHECK(hipHostMalloc(&p, newCap, hipHostMallocDefault));
+            cap = newCap;
+        }
+        return p;
+    }
+    void* data() const { return p; }
+private:
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
     EventTimer() { HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); }

@@ -33,7 +33,9 @@ struct Context {
 
     RadixSortWorkspace sortWs, sortWs2;
     hipStream_t stream2 = nullptr;           // second worker of the Align4 stage
+    hipStream_t wideStream[2] = {nullptr, nullptr};   // side streams for the wide-band DP classes
     std::shared_ptr<void> alignScratch[2];   // grow-only batch scratch of the two workers
+    std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress (staged / multi-GPU API)
     shasta_mi355x_kernel_times times = {};
 
@@ -61,7 +63,7 @@ void lowhash0Buckets(Context&, const uint32_t* keys, const uint64_t* vals, uint6
 void lowhash0Merge(Context&, const uint64_t* runKeys, const uint32_t* runCounts, uint64_t n, uint64_t* highFrequency, uint64_t* tableSize);
 void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
-    const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&);
+    const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
 void align4Free(shasta_align4_result&);
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);

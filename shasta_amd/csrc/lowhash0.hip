@@ -385,6 +385,7 @@ Context::~Context()
     (void)hipSetDevice(device);
     alignScratch[0].reset(); alignScratch[1].reset(); lowhashJob.reset();
     if(stream2) (void)hipStreamDestroy(stream2);
+    for(hipStream_t w : wideStream) if(w) (void)hipStreamDestroy(w);
     if(stream) (void)hipStreamDestroy(stream);
 }
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "shasta_mi355x_align4_batch", "shasta_mi355x_align4_free",
     "shasta_mi355x_create", "shasta_mi355x_destroy",
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids", "shasta_mi355x_set_shard",
-    "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_get_kernel_times",
+    "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_get_kernel_times",
     "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
@@ -246,10 +246,13 @@ class Context:
         self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
         return out
 
-    def align4(self, candidates, options, want_ordinals=False):
+    def align4(self, candidates, options, want_ordinals=False, borrow=False):
+        """borrow=True: the arrays of the result are views of memory owned by this context, valid
+        until the next borrowed call (align4_run_borrowed)."""
         candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
         res = abi.Align4Result()
-        self.library._check(self.lib.shasta_mi355x_align4_run(
+        entry = self.lib.shasta_mi355x_align4_run_borrowed if borrow else self.lib.shasta_mi355x_align4_run
+        self.library._check(entry(
             C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_align4_run")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
