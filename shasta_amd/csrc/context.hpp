@@ -25,7 +25,7 @@ struct Context {
     DeviceBuffer<uint64_t> toc;              // 2R+1
     DeviceBuffer<uint32_t> kmerIds;          // M
     DeviceBuffer<uint8_t> readFlags;         // R
-    DeviceBuffer<uint32_t> tileFirstRead;    // ceil(M/HASH_TILE)+1: oriented read owning the tile's first marker
+    DeviceBuffer<uint4> tileDesc;            // ceil(M/HASH_TILE)+1: {first oriented read, its palindromic flag, its end (u64)} per hash tile
 
     // Shard: reads hashed here, bucket range owned here.
     int rank = 0, worldSize = 1;

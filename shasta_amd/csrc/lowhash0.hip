@@ -70,21 +70,28 @@ stripMarkersKernel(const uint32_t* __restrict__ words, uint32_t* __restrict__ km
     }
 }
 
-// Oriented read containing the first marker of each hash tile (upper_bound on toc).
+// Per hash tile (256 consecutive markers): the oriented read that owns its first marker, where
+// that read ends, and the read's palindromic flag -- everything most threads of the tile need,
+// in one 16-byte record (upper_bound on toc).
 __global__ void __launch_bounds__(256)
-tileFirstReadKernel(const uint64_t* __restrict__ toc, uint64_t orientedReadCount, uint64_t markerCount,
-    uint32_t* __restrict__ tileFirstRead, uint64_t tileCount)
+tileDescKernel(const uint64_t* __restrict__ toc, const uint8_t* __restrict__ readFlags, uint64_t orientedReadCount, uint64_t markerCount,
+    uint4* __restrict__ tileDesc, uint64_t tileCount)
 {
     const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if(t > tileCount) return;
     const uint64_t i = t * HASH_TILE;
-    if(i >= markerCount) { tileFirstRead[t] = uint32_t(orientedReadCount ? orientedReadCount - 1 : 0); return; }
-    uint64_t lo = 0, hi = orientedReadCount + 1;       // first idx in [0, 2R] with toc[idx] > i
-    while(lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if(toc[mid] > i) hi = mid; else lo = mid + 1;
+    uint32_t r = uint32_t(orientedReadCount ? orientedReadCount - 1 : 0);
+    if(i < markerCount) {
+        uint64_t lo = 0, hi = orientedReadCount + 1;       // first idx in [0, 2R] with toc[idx] > i
+        while(lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if(toc[mid] > i) hi = mid; else lo = mid + 1;
+        }
+        r = uint32_t(lo - 1);
     }
-    tileFirstRead[t] = uint32_t(lo - 1);
+    const uint64_t end = orientedReadCount ? toc[r + 1] : 0;
+    const uint32_t flags = orientedReadCount ? uint32_t(readFlags[r >> 1] & 1u) : 0u;
+    tileDesc[t] = make_uint4(r, flags, uint32_t(end), uint32_t(end >> 32));
 }
 
 // ---------------------------------------------------------------------------
@@ -101,7 +108,7 @@ template<int M_FIXED>
 __global__ void __launch_bounds__(HASH_THREADS)
 hashWindowsKernel(
     const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc,
-    const uint8_t* __restrict__ readFlags, const uint32_t* __restrict__ tileFirstRead,
+    const uint8_t* __restrict__ readFlags, const uint4* __restrict__ tileDesc,
     uint64_t markerBegin, uint64_t markerEnd, uint64_t markerCount,
     uint32_t m, uint64_t seed, uint64_t hashThreshold, uint32_t mask,
     uint32_t* __restrict__ outKeys, uint64_t* __restrict__ outVals,
@@ -121,25 +128,45 @@ hashWindowsKernel(
 
     const uint64_t firstTile = markerBegin / HASH_TILE;
     const uint64_t lastTile = (markerEnd + HASH_TILE - 1) / HASH_TILE;      // exclusive
-    for(uint64_t tile = firstTile + blockIdx.x; tile < lastTile; tile += gridDim.x) {
+    // The loads of a tile (its kmer ids, the halo, its descriptor) are issued two tiles ahead, so
+    // their latency is covered by the work on the tiles in between.
+    auto loadTile = [&](uint64_t tile, uint32_t& k, uint32_t& halo, uint4& desc) {
+        const uint64_t base = tile * HASH_TILE;
+        const uint64_t i = base + uint64_t(tid), j = base + HASH_TILE + uint64_t(tid);
+        k = (i < markerCount) ? kmerIds[i] : 0u;
+        halo = (tid < int(mm) - 1 && j < markerCount) ? kmerIds[j] : 0u;
+        desc = tileDesc[tile];
+    };
+    uint64_t tile = firstTile + blockIdx.x;
+    uint32_t curK = 0, curHalo = 0, nextK = 0, nextHalo = 0, next2K = 0, next2Halo = 0;
+    uint4 curDesc = make_uint4(0, 0, 0, 0), nextDesc = make_uint4(0, 0, 0, 0), next2Desc = make_uint4(0, 0, 0, 0);
+    if(tile < lastTile) loadTile(tile, curK, curHalo, curDesc);
+    if(tile + gridDim.x < lastTile) loadTile(tile + gridDim.x, nextK, nextHalo, nextDesc);
+    for(; tile < lastTile; tile += gridDim.x) {
+        const uint64_t next2Tile = tile + 2ULL * gridDim.x;
+        if(next2Tile < lastTile) loadTile(next2Tile, next2K, next2Halo, next2Desc);
         const uint64_t base = tile * HASH_TILE;
         const uint64_t i = base + uint64_t(tid);
-        sK[tid] = (i < markerCount) ? kmerIds[i] : 0u;
-        if(tid < int(mm) - 1) {
-            const uint64_t j = base + HASH_TILE + uint64_t(tid);
-            sK[HASH_TILE + tid] = (j < markerCount) ? kmerIds[j] : 0u;
-        }
+        sK[tid] = curK;
+        if(tid < int(mm) - 1) sK[HASH_TILE + tid] = curHalo;
         __syncthreads();
 
         bool hit = false;
         uint64_t hash = 0;
         uint32_t orientedReadId = 0;
         if(i >= markerBegin && i < markerEnd) {
-            uint32_t r = tileFirstRead[tile];
-            while(toc[r + 1] <= i) ++r;
-            const uint64_t end = toc[r + 1];
+            uint32_t r = curDesc.x;
+            uint64_t end = uint64_t(curDesc.z) | (uint64_t(curDesc.w) << 32);
+            bool palindromic = (curDesc.y & 1u) != 0;
+            if(i >= end) {
+                // Past the end of the tile's first read: a read boundary inside the tile (rare).
+                ++r;
+                while(toc[r + 1] <= i) ++r;
+                end = toc[r + 1];
+                palindromic = (readFlags[r >> 1] & 1u) != 0;
+            }
             // Reads with fewer than m markers (:337) and palindromic reads (:325) produce nothing.
-            if(i + mm <= end && !(readFlags[r >> 1] & 1u)) {
+            if(i + mm <= end && !palindromic) {
                 hash = murmurWindow<M_FIXED>(&sK[tid], mm, seed);
                 hit = hash < hashThreshold;                                   // :350, strict
                 orientedReadId = r;
@@ -169,6 +196,8 @@ hashWindowsKernel(
             if(tid == 0) sFill = 0;
             __syncthreads();
         }
+        curK = nextK; curHalo = nextHalo; curDesc = nextDesc;
+        nextK = next2K; nextHalo = next2Halo; nextDesc = next2Desc;
     }
     __syncthreads();
     const uint32_t fill = sFill;
@@ -428,9 +457,9 @@ void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const vo
         }
     }
     const uint64_t tileCount = (markerCount + HASH_TILE - 1) / HASH_TILE;
-    tileFirstRead.reserve(tileCount + 1, stream);
-    hipLaunchKernelGGL(tileFirstReadKernel, dim3(divUp(tileCount + 1, 256)), dim3(256), 0, stream,
-        (const uint64_t*)toc.data(), orientedReadCount, markerCount, tileFirstRead.data(), tileCount);
+    tileDesc.reserve(tileCount + 1, stream);
+    hipLaunchKernelGGL(tileDescKernel, dim3(divUp(tileCount + 1, 256)), dim3(256), 0, stream,
+        (const uint64_t*)toc.data(), (const uint8_t*)readFlags.data(), orientedReadCount, markerCount, tileDesc.data(), tileCount);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -469,7 +498,7 @@ void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uin
     const unsigned blocks = unsigned(std::min<uint64_t>(tiles, 256 * 8));
 #define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL(hashWindowsKernel<MF>, dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
         (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), (const uint8_t*)ctx.readFlags.data(), \
-        (const uint32_t*)ctx.tileFirstRead.data(), markerBegin, markerEnd, ctx.markerCount, \
+        (const uint4*)ctx.tileDesc.data(), markerBegin, markerEnd, ctx.markerCount, \
         m, seed, threshold, mask, outKeys, outVals, counter, capacity)
     switch(m) {
         case 3: SHASTA_LAUNCH_HASH(3); break;
