@@ -77,7 +77,8 @@ def cpu_baseline(n_reads_sample, seed):
     from oracle import bindings
     from shasta_amd import synthetic
     # Threads actually used = "cores" of the report.  Capped at 64: every reference Align4 thread
-    # zero-fills its own 2 GiB arena (src/AssemblerAlign.cpp:353-355) before its first candidate.
+    # zero-fills its own 2 GiB arena (src/AssemblerAlign.cpp:353-355) before its first candidate, and a
+    # run with one thread per core of a 256-core box (512 GiB of arenas) took the GPU box down.
     cores = min(os.cpu_count() or 1, 64)
     toc, kmer = make_workload(n_reads_sample, seed)
     data7 = synthetic.pack_markers(toc, kmer)

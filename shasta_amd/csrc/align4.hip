@@ -348,9 +348,9 @@ align4CellsKernel(
 //           round: both buckets are read, the eight slots are tag-matched with SWAR compares,
 //           the kmer ids are compared in LDS: fixed trip count, no probe chains;
 //   count   (x,y) -> cell by magic-number division (getXY + createCells,
-//           src/Align4.cpp:171-177,380-436); consecutive lanes that hit the same cell are
-//           folded into one LDS atomic; the increment that reaches minEntryCountPerCell
-//           appends the cell to the kept list (:417);
+//           src/Align4.cpp:171-177,380-436), one LDS atomic per hit on a packed cell word (folding
+//           equal neighbours first costs more instructions than the atomics it saves); the
+//           increment that reaches minEntryCountPerCell appends the cell to the kept list (:417);
 //   graph   the kept cells (Q per lane) live in registers; their forward/backward adjacency is
 //           a bit mask per cell, so forwardSearch / backwardSearch (:682-788) and the connected
 //           components (:792-868) are iterated ballots with no memory traffic;
@@ -516,13 +516,8 @@ align4CellsChunkKernel(
                 // candidates whose cell indices fit (others run in the HBM-scratch kernel).
                 const bool h = hit[u];
                 key[u] = h ? ((iY << 16) | iX) : EMPTY32;
-                // Fold runs of consecutive lanes with the same cell into their first lane.
-                const uint32_t prevKey = __shfl_up(key[u], 1, WAVE);
-                const bool head = h && (lane == 0 || prevKey != key[u]);
-                const uint64_t hits = __ballot(h), heads = __ballot(head);
-                const uint64_t stops = (heads | ~hits) >> 1 >> lane;           // bit k: lane + 1 + k ends the run
-                len[u] = stops ? uint32_t(__ffsll((unsigned long long)stops)) : uint32_t(WAVE - lane);
-                pending[u] = head;
+                len[u] = 1;
+                pending[u] = h;
                 packed[u] = (iY << CELLS_IX_BITS) | iX;
                 cs[u] = hash32(key[u]) >> scShift;
                 probes[u] = 0;
