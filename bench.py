@@ -204,7 +204,7 @@ def main():
 
         def step():
             lh = distributed.lowhash0(backend, p, read_count, boundaries)
-            candidates = distributed.gather_candidates(lh.candidates)
+            candidates = distributed.gather_candidates(lh.candidates, device)
             if args.lowhash_only:
                 return lh, None, len(candidates)
             lo, hi = distributed.candidate_slice(len(candidates), rank, world)

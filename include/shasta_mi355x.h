@@ -216,12 +216,6 @@ int shasta_mi355x_set_kmer_ids_device(
     shasta_mi355x_ctx*, uint64_t readCount,
     const uint64_t* markersToc, const void* kmerIdsDevice, const uint8_t* readFlags);
 
-/* Restricts the reads this context hashes / owns to [readBegin, readEnd) and
- * the buckets it owns to rank `rank` of `worldSize` (multi-GPU sharding,
- * SURVEY section 8e).  Default: everything, rank 0 of 1. */
-int shasta_mi355x_set_shard(shasta_mi355x_ctx*, int rank, int worldSize,
-    uint64_t readBegin, uint64_t readEnd);
-
 /* LowHash0 on the resident markers.  Same outputs as the one-shot seam. */
 int shasta_mi355x_lowhash0_run(
     shasta_mi355x_ctx*, const shasta_lowhash0_params* params,

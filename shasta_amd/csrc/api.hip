@@ -151,19 +151,6 @@ int shasta_mi355x_lh_finish(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistic
 
 void shasta_mi355x_free(void* p) { std::free(p); }
 
-int shasta_mi355x_set_shard(shasta_mi355x_ctx* c, int rank, int worldSize, uint64_t readBegin, uint64_t readEnd)
-{
-    API_BEGIN
-    if(!c) throw std::runtime_error("set_shard: null context");
-    if(worldSize < 1 || rank < 0 || rank >= worldSize || readBegin > readEnd || readEnd > c->impl.readCount) {
-        throw std::runtime_error("set_shard: invalid shard");
-    }
-    c->impl.rank = rank; c->impl.worldSize = worldSize;
-    c->impl.readBegin = readBegin; c->impl.readEnd = readEnd;
-    return 0;
-    API_END(1)
-}
-
 int shasta_mi355x_lowhash0_run(shasta_mi355x_ctx* c, const shasta_lowhash0_params* params,
     uint64_t* readLowHashStatistics, shasta_lowhash0_result* result)
 {

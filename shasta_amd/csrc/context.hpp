@@ -27,10 +27,6 @@ struct Context {
     DeviceBuffer<uint8_t> readFlags;         // R
     DeviceBuffer<uint4> tileDesc;            // ceil(M/HASH_TILE)+1: {first oriented read, its palindromic flag, its end (u64)} per hash tile
 
-    // Shard: reads hashed here, bucket range owned here.
-    int rank = 0, worldSize = 1;
-    uint64_t readBegin = 0, readEnd = 0;
-
     RadixSortWorkspace sortWs, sortWs2;
     hipStream_t stream2 = nullptr;           // second worker of the Align4 stage
     hipStream_t wideStream[2] = {nullptr, nullptr};   // side streams for the wide-band DP classes
@@ -38,12 +34,6 @@ struct Context {
     std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress (staged / multi-GPU API)
     shasta_mi355x_kernel_times times = {};
-
-    // Sorted markers (Assembler::computeSortedMarkers, src/AssemblerAlign4.cpp:190-261),
-    // built lazily by the Align4 stage and kept while the markers do not change.
-    bool sortedMarkersValid = false;
-    DeviceBuffer<uint32_t> sortedKmerIds;    // M, per oriented read sorted by kmerId
-    DeviceBuffer<uint32_t> sortedOrdinals;   // M
 
     explicit Context(int device);
     ~Context();

@@ -429,8 +429,6 @@ void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const vo
     MI355X_ASSERT(hostToc[0] == 0);
     for(uint64_t i = 0; i < orientedReadCount; i++) MI355X_ASSERT(hostToc[i] <= hostToc[i + 1]);
     markerCount = hostToc[orientedReadCount];
-    sortedMarkersValid = false;
-    readBegin = 0; readEnd = readCount;
 
     toc.reserve(orientedReadCount + 1, stream);
     HIP_CHECK(hipMemcpyAsync(toc.data(), hostToc.data(), (orientedReadCount + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));

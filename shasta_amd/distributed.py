@@ -156,13 +156,15 @@ def lowhash0(backend, params, read_count, boundaries, group=None):
         run_keys, run_counts = exchange([run_keys, run_counts], offsets, group)   # C2: runs to readId0 owners
         high, total = backend.merge(run_keys, run_counts)
         # Counters + histogram of this iteration, summed over the ranks.
-        packed = np.concatenate([np.asarray([high, total, used], dtype=np.uint64), np.asarray(hist, dtype=np.uint64)])
+        packed = np.concatenate([np.asarray([high, total, used, len(overflow)], dtype=np.uint64), np.asarray(hist, dtype=np.uint64)])
         packed = all_reduce_sum_u64(packed, device, group)
-        high_frequency, total_all, used_all = int(packed[0]), int(packed[1]), int(packed[2])
-        hist_all = packed[3:]
-        # Bucket sizes beyond the histogram bins are rare: gather the lists.
-        lists = [None] * world
-        dist.all_gather_object(lists, np.asarray(overflow, dtype=np.uint32).tolist(), group=group)
+        high_frequency, total_all, used_all, overflow_all = int(packed[0]), int(packed[1]), int(packed[2]), int(packed[3])
+        hist_all = packed[4:]
+        # Bucket sizes beyond the histogram bins are rare: gather the lists only when there are any.
+        lists = [[]] * world
+        if overflow_all:
+            lists = [None] * world
+            dist.all_gather_object(lists, np.asarray(overflow, dtype=np.uint32).tolist(), group=group)
         rows = {}
         if bucket_count > used_all:
             rows[0] = bucket_count - used_all
@@ -187,12 +189,20 @@ def lowhash0(backend, params, read_count, boundaries, group=None):
     return out
 
 
-def gather_candidates(local_candidates, group=None):
-    """The global candidate list (rank order = the reference's order) on every rank."""
+def gather_candidates(local_candidates, device="cpu", group=None):
+    """The global candidate list (rank order = the reference's order) on every rank.  Candidates are
+    12-byte records; they travel as int32 triplets in one padded all-gather (24 MB per million)."""
     world = dist.get_world_size(group)
-    lists = [None] * world
-    dist.all_gather_object(lists, np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE).tobytes(), group=group)
-    return np.concatenate([np.frombuffer(b, dtype=abi.PAIR_DTYPE) for b in lists]) if world else local_candidates
+    local = np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE)
+    home = torch.device(device)
+    comm = _comm_device(home)
+    mine = torch.tensor([len(local)], dtype=torch.int64, device=comm)
+    parts = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    counts = [int(p.item()) for p in parts]
+    flat = torch.from_numpy(local.view(np.int32).reshape(-1).copy()).to(home)
+    gathered = all_gather_padded(flat, [3 * c for c in counts], group)
+    return gathered.cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
 
 
 def candidate_slice(count, rank, world):

@@ -20,7 +20,7 @@ EXPORTS = [
     "shasta_mi355x_lowhash0", "shasta_mi355x_lowhash0_free",
     "shasta_mi355x_align4_batch", "shasta_mi355x_align4_free",
     "shasta_mi355x_create", "shasta_mi355x_destroy",
-    "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids", "shasta_mi355x_set_shard",
+    "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_get_kernel_times",
     "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
@@ -230,11 +230,6 @@ class Context:
         out = abi.copy_array(cand, int(count.value), abi.PAIR_DTYPE)
         self.lib.shasta_mi355x_free(cand)
         return out, stats
-
-    def set_shard(self, rank, world_size, read_begin, read_end):
-        self.library._check(self.lib.shasta_mi355x_set_shard(
-            C.c_void_p(self.handle), C.c_int(rank), C.c_int(world_size),
-            C.c_uint64(read_begin), C.c_uint64(read_end)), "shasta_mi355x_set_shard")
 
     def lowhash0(self, params):
         stats = np.zeros((self.read_count, 3), dtype=np.uint64)

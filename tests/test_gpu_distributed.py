@@ -33,7 +33,7 @@ def _worker(rank, world, port, out_dir, seed, kw):
             backend = distributed.HipBackend(ctx, "cuda:0")
             boundaries = distributed.read_boundaries(toc, world)
             out = distributed.lowhash0(backend, p, 400, boundaries)
-            everything = distributed.gather_candidates(out.candidates)
+            everything = distributed.gather_candidates(out.candidates, "cuda:0")
             lo, hi = distributed.candidate_slice(len(everything), rank, world)
             o = abi.default_align4_options(minAlignedMarkerCount=40)
             al = ctx.align4(everything[lo:hi], o, want_ordinals=True)
