@@ -5,6 +5,7 @@
 #include <iostream>
 #include <numeric>
 #include <stdexcept>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -128,48 +129,73 @@ void findAlignmentCandidatesLowHash0(
     readLowHashStatistics.unreserve();
 }
 
+namespace {
+
+// The four oriented reads an oriented read pair appears under: its two oriented reads and their
+// reverse complements (src/AssemblerAlign.cpp:513-536, src/AssemblerAlignmentCandidates.cpp:392-416).
+inline void orientedReadsOf(const shasta_oriented_read_pair& pair, uint32_t (&o)[4])
+{
+    const uint32_t o0 = pair.readIds[0] << 1, o1 = (pair.readIds[1] << 1) | (pair.isSameStrand ? 0u : 1u);
+    o[0] = o0; o[1] = o1; o[2] = o0 ^ 1u; o[3] = o1 ^ 1u;
+}
+
+// OrientedReadPair::getOther (src/OrientedReadPair.hpp:63-85): the partner of o0 in this pair,
+// reverse complemented if o0 appears reverse complemented.
+inline uint32_t otherOrientedRead(const shasta_oriented_read_pair& pair, uint32_t o0)
+{
+    uint32_t o[4];
+    orientedReadsOf(pair, o);
+    if(o0 == o[0]) return o[1];
+    if(o0 == o[1]) return o[0];
+    if(o0 == o[2]) return o[3];
+    return o[2];
+}
+
+// Per oriented read, the indices of the pairs it takes part in, sorted by (other oriented read,
+// index): the common shape of the candidate table and of the alignment table.  The sort key holds
+// the index as uint32, as the reference's vector< pair<OrientedReadId, uint32_t> > does.
+template<class Table, class PairOf>
+void fillPairTable(Table& table, uint64_t readCount, uint64_t pairCount, PairOf pairOf)
+{
+    using Int = typename std::remove_reference<decltype(table.toc[0])>::type;
+    using Index = typename std::remove_reference<decltype(table.data[0])>::type;
+    std::vector<Int> counts(2 * readCount, 0);
+    for(uint64_t i = 0; i < pairCount; i++) { uint32_t o[4]; orientedReadsOf(pairOf(i), o); for(uint32_t v : o) ++counts[v]; }
+    table.fillFromCounts(counts);
+    std::vector<uint64_t> cursor(2 * readCount);
+    for(uint64_t k = 0; k < 2 * readCount; k++) cursor[k] = uint64_t(table.toc[k]);
+    for(uint64_t i = 0; i < pairCount; i++) {
+        uint32_t o[4]; orientedReadsOf(pairOf(i), o);
+        for(uint32_t v : o) table.data[cursor[v]++] = Index(i);
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    for(uint64_t o0 = 0; o0 < 2 * readCount; o0++) {
+        Index* section = table.begin(o0);
+        const uint64_t n = table.size(o0);
+        v.clear();
+        for(uint64_t k = 0; k < n; k++) v.push_back(std::make_pair(otherOrientedRead(pairOf(uint64_t(section[k])), uint32_t(o0)), uint32_t(section[k])));
+        std::sort(v.begin(), v.end());
+        for(uint64_t k = 0; k < n; k++) section[k] = Index(v[k].second);
+    }
+    table.unreserve();
+}
+
+}  // namespace
+
+void computeCandidateTable(uint64_t readCount, const AlignmentCandidates& candidates,
+    const std::string& dataDirectory, size_t largeDataPageSize)
+{
+    CandidateTable table;
+    table.createNew(dataName(dataDirectory, "CandidateTable"), largeDataPageSize);
+    fillPairTable(table, readCount, candidates.size(), [&](uint64_t i) -> const shasta_oriented_read_pair& { return candidates[i]; });
+}
+
 void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
     const std::string& dataDirectory, size_t largeDataPageSize)
 {
     AlignmentTable table;
     table.createNew(dataName(dataDirectory, "AlignmentTable"), largeDataPageSize);
-    // Every stored alignment appears under its two oriented reads and under their reverse
-    // complements (:513-536).
-    auto orientedReads = [](const shasta_alignment_data& ad, uint32_t (&o)[4]) {
-        const uint32_t o0 = ad.pair.readIds[0] << 1, o1 = (ad.pair.readIds[1] << 1) | (ad.pair.isSameStrand ? 0u : 1u);
-        o[0] = o0; o[1] = o1; o[2] = o0 ^ 1u; o[3] = o1 ^ 1u;
-    };
-    std::vector<uint32_t> counts(2 * readCount, 0);
-    for(uint64_t i = 0; i < alignmentData.size(); i++) { uint32_t o[4]; orientedReads(alignmentData[i], o); for(uint32_t v : o) ++counts[v]; }
-    table.fillFromCounts(counts);
-    std::vector<uint32_t> cursor(2 * readCount);
-    for(uint64_t k = 0; k < 2 * readCount; k++) cursor[k] = table.toc[k];
-    for(uint64_t i = 0; i < alignmentData.size(); i++) {
-        uint32_t o[4]; orientedReads(alignmentData[i], o);
-        for(uint32_t v : o) table.data[cursor[v]++] = uint32_t(i);
-    }
-    // Sort each section by the other oriented read, then by alignment index (:541-566).
-    std::vector<std::pair<uint32_t, uint32_t>> v;
-    for(uint64_t o0 = 0; o0 < 2 * readCount; o0++) {
-        uint32_t* section = table.begin(o0);
-        const uint64_t n = table.size(o0);
-        v.clear();
-        for(uint64_t k = 0; k < n; k++) {
-            const shasta_alignment_data& ad = alignmentData[section[k]];
-            // AlignmentData::getOther (src/Alignment.hpp:424-446): the partner of o0 in this alignment,
-            // reverse complemented if o0 appears reverse complemented.
-            uint32_t o[4]; orientedReads(ad, o);
-            uint32_t other;
-            if(o0 == o[0]) other = o[1];
-            else if(o0 == o[1]) other = o[0];
-            else if(o0 == o[2]) other = o[3];
-            else other = o[2];
-            v.push_back(std::make_pair(other, section[k]));
-        }
-        std::sort(v.begin(), v.end());
-        for(uint64_t k = 0; k < n; k++) section[k] = v[k].second;
-    }
-    table.unreserve();
+    fillPairTable(table, readCount, alignmentData.size(), [&](uint64_t i) -> const shasta_oriented_read_pair& { return alignmentData[i].pair; });
 }
 
 void computeAlignments(const std::string& dataDirectory, const AlignOptions& alignOptions, size_t /* threadCount */, size_t largeDataPageSize)

@@ -6,6 +6,7 @@
 //   findAlignmentCandidatesLowHash0   <-> Assembler::findAlignmentCandidatesLowHash0   src/AssemblerLowHash.cpp:10-55
 //   computeAlignments                 <-> Assembler::computeAlignments (alignMethod 4)  src/AssemblerAlign.cpp:208-304
 //   computeAlignmentTable             <-> Assembler::computeAlignmentTable    src/AssemblerAlign.cpp:509-571
+//   computeCandidateTable             <-> AlignmentCandidates::computeCandidateTable    src/AssemblerAlignmentCandidates.cpp:388-447
 #pragma once
 
 #include "MappedVector.hpp"
@@ -29,6 +30,7 @@ using ReadLowHashStatistics = MappedVector<std::array<uint64_t, 3>>;         // 
 using AlignmentDataVector = MappedVector<shasta_alignment_data>;             // Data/AlignmentData
 using CompressedAlignments = MappedVectorOfVectors<char, uint64_t>;          // Data/CompressedAlignments.{toc,data}
 using AlignmentTable = MappedVectorOfVectors<uint32_t, uint32_t>;            // Data/AlignmentTable.{toc,data}
+using CandidateTable = MappedVectorOfVectors<uint64_t, uint64_t>;            // Data/CandidateTable.{toc,data}
 
 // The [Align] options computeAlignments reads (src/AssemblerOptions.hpp:177-198); defaults of
 // src/AssemblerOptions.cpp:380-489.
@@ -66,6 +68,11 @@ void findAlignmentCandidatesLowHash0(
     size_t threadCount, size_t largeDataPageSize = 4096);
 
 void computeAlignments(const std::string& dataDirectory, const AlignOptions&, size_t threadCount, size_t largeDataPageSize = 4096);
+
+// AlignmentCandidates::computeCandidateTable (src/AssemblerAlignmentCandidates.cpp:388-447): the step the
+// reference runs between the two seams (srcMain/main.cpp:706).  Host work: a CSR index + per-row sort.
+void computeCandidateTable(uint64_t readCount, const AlignmentCandidates& candidates,
+    const std::string& dataDirectory, size_t largeDataPageSize = 4096);
 
 void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
     const std::string& dataDirectory, size_t largeDataPageSize = 4096);

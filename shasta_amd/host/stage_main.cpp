@@ -3,6 +3,7 @@
 // Data/ directory, with the work done on the GPU.
 //   shasta_mi355x_stage lowhash0 <Data> [m hashFraction minHashIterationCount alignmentCandidatesPerRead
 //                                        log2MinHashBucketCount minBucketSize maxBucketSize minFrequency]
+//   shasta_mi355x_stage candidate-table <Data>
 //   shasta_mi355x_stage align    <Data> [minAlignedMarkerCount minAlignedFraction maxSkip maxDrift maxTrim suppressContainments]
 // Exit codes follow srcMain/main.cpp:103-129: 0 success, 1 std::runtime_error / other exception.
 #include "OverlapStages.hpp"
@@ -16,7 +17,7 @@ using namespace shasta_mi355x::host;
 int main(int argc, char** argv)
 {
     try {
-        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage lowhash0|align <DataDirectory> [options...]");
+        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage lowhash0|candidate-table|align <DataDirectory> [options...]");
         const std::string command = argv[1], data = argv[2];
         auto arg = [&](int k, const char* fallback) { return std::string(argc > k ? argv[k] : fallback); };
         if(command == "lowhash0") {
@@ -24,6 +25,13 @@ int main(int argc, char** argv)
             findAlignmentCandidatesLowHash0(data,
                 std::stoull(arg(3, "4")), std::stod(arg(4, "0.01")), std::stoull(arg(5, "10")), std::stod(arg(6, "20")),
                 std::stoull(arg(7, "0")), std::stoull(arg(8, "0")), std::stoull(arg(9, "10")), std::stoull(arg(10, "2")), 0);
+        } else if(command == "candidate-table") {
+            // Assembler::computeCandidateTable, between the two seams (srcMain/main.cpp:706).
+            Markers markers;
+            markers.accessExistingReadOnly(data + "/Markers");
+            AlignmentCandidates candidates;
+            candidates.accessExistingReadOnly(data + "/AlignmentCandidates");
+            computeCandidateTable(markers.size() / 2, candidates, data);
         } else if(command == "align") {
             AlignOptions o;
             o.minAlignedMarkerCount = std::stoull(arg(3, "100")); o.minAlignedFraction = std::stod(arg(4, "0"));

@@ -82,6 +82,26 @@ int host_store_alignments(const char* dir, uint64_t alignmentCount, const shasta
     SHIM_END
 }
 
+int host_store_candidates(const char* dir, uint64_t count, const shasta_oriented_read_pair* pairs)
+{
+    SHIM_BEGIN
+    AlignmentCandidates candidates;
+    candidates.createNew(std::string(dir) + "/AlignmentCandidates");
+    candidates.append(pairs, count);
+    candidates.unreserve();
+    SHIM_END
+}
+
+int host_compute_candidate_table(const char* dir, uint64_t readCount)
+{
+    SHIM_BEGIN
+    const std::string d(dir);
+    AlignmentCandidates candidates;
+    candidates.accessExistingReadOnly(d + "/AlignmentCandidates");
+    computeCandidateTable(readCount, candidates, d);
+    SHIM_END
+}
+
 int host_compute_alignment_table(const char* dir, uint64_t readCount)
 {
     SHIM_BEGIN

@@ -42,24 +42,32 @@ class HostShim:
         self._check(self.lib.host_store_alignments(directory.encode(), C.c_uint64(len(rows)), C.c_void_p(rows.ctypes.data),
                                                    abi.as_ptr(toc, C.c_uint64), C.c_void_p(data.ctypes.data)), "host_store_alignments")
 
+    def store_candidates(self, directory, candidates):
+        c = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        self._check(self.lib.host_store_candidates(directory.encode(), C.c_uint64(len(c)), C.c_void_p(c.ctypes.data)), "host_store_candidates")
+
+    def compute_candidate_table(self, directory, read_count):
+        self._check(self.lib.host_compute_candidate_table(directory.encode(), C.c_uint64(read_count)), "host_compute_candidate_table")
+
     def compute_alignment_table(self, directory, read_count):
         self._check(self.lib.host_compute_alignment_table(directory.encode(), C.c_uint64(read_count)), "host_compute_alignment_table")
 
 
-def alignment_table_expected(read_count, alignment_data):
-    """Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571) in numpy/python: per oriented
-    read, the indices of the stored alignments it takes part in (directly or reverse complemented),
-    sorted by (other oriented read, alignment index)."""
+def alignment_table_expected(read_count, alignment_data, index_dtype=np.uint32):
+    """Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571) and
+    AlignmentCandidates::computeCandidateTable (src/AssemblerAlignmentCandidates.cpp:388-447) in python:
+    per oriented read, the indices of the pairs it takes part in (directly or reverse complemented),
+    sorted by (other oriented read, index)."""
     sections = [[] for _ in range(2 * read_count)]
     for i, ad in enumerate(alignment_data):
         o0 = int(ad["readId0"]) << 1
         o1 = (int(ad["readId1"]) << 1) | (0 if ad["isSameStrand"] else 1)
         for a, b in ((o0, o1), (o1, o0), (o0 ^ 1, o1 ^ 1), (o1 ^ 1, o0 ^ 1)):
             sections[a].append((b, i))
-    toc = np.zeros(2 * read_count + 1, dtype=np.uint32)
+    toc = np.zeros(2 * read_count + 1, dtype=index_dtype)
     data = []
     for k, sec in enumerate(sections):
         sec.sort()
         data += [i for _, i in sec]
         toc[k + 1] = len(data)
-    return toc, np.asarray(data, dtype=np.uint32)
+    return toc, np.asarray(data, dtype=index_dtype)

@@ -74,3 +74,19 @@ def test_stored_alignments_and_alignment_table(shim, ref_lib, oracle_lib, tmp_pa
     toc_expected, data_expected = host_support.alignment_table_expected(150, al.alignment_data)
     assert np.array_equal(t.view("<u4").reshape(-1), toc_expected)
     assert np.array_equal(dta.view("<u4").reshape(-1), data_expected)
+
+
+def test_candidate_table(shim, ref_lib, oracle_lib, tmp_path):
+    toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=9000, seed=84)
+    cand = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)).candidates
+    assert len(cand) > 200
+    d = str(tmp_path)
+    shim.store_candidates(d, cand)
+    stored, _ = ref_lib.open_vector(os.path.join(d, "AlignmentCandidates"), 12)      # opens in the reference
+    assert np.array_equal(stored.view("<u4").reshape(-1, 3)[:, 0], cand["readId0"])
+    shim.compute_candidate_table(d, 150)
+    t, _ = ref_lib.open_vector(os.path.join(d, "CandidateTable.toc"), 8)
+    dta, _ = ref_lib.open_vector(os.path.join(d, "CandidateTable.data"), 8)
+    toc_expected, data_expected = host_support.alignment_table_expected(150, cand, np.uint64)
+    assert np.array_equal(t.view("<u8").reshape(-1), toc_expected)
+    assert np.array_equal(dta.view("<u8").reshape(-1), data_expected)
