@@ -204,12 +204,11 @@ def main():
 
         def step():
             lh = distributed.lowhash0(backend, p, read_count, boundaries)
-            candidates = distributed.gather_candidates(lh.candidates, device)
+            share, total = distributed.candidate_share(lh.candidates, device)
             if args.lowhash_only:
-                return lh, None, len(candidates)
-            lo, hi = distributed.candidate_slice(len(candidates), rank, world)
-            al = ctx.align4(candidates[lo:hi], o, want_ordinals=False, borrow=True)
-            return lh, al, len(candidates)
+                return lh, None, total
+            al = ctx.align4(share, o, want_ordinals=False, borrow=True)
+            return lh, al, total
 
     def sync():
         if dist is not None:

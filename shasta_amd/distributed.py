@@ -205,6 +205,25 @@ def gather_candidates(local_candidates, device="cpu", group=None):
     return gathered.cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
 
 
+def candidate_share(local_candidates, device="cpu", group=None):
+    """This rank's even share of the global candidate list for Align4, and the list's length.  The
+    list is all-gathered on the device; only the share crosses to the host."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local = np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE)
+    home = torch.device(device)
+    comm = _comm_device(home)
+    mine = torch.tensor([len(local)], dtype=torch.int64, device=comm)
+    parts = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    counts = [int(p.item()) for p in parts]
+    total = sum(counts)
+    flat = torch.from_numpy(local.view(np.int32).reshape(-1).copy()).to(home)
+    gathered = all_gather_padded(flat, [3 * c for c in counts], group)
+    lo, hi = candidate_slice(total, rank, world)
+    share = gathered[3 * lo:3 * hi].cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
+    return share, total
+
+
 def candidate_slice(count, rank, world):
     """Even split of the candidate list for Align4 (candidates are independent)."""
     return (count * rank) // world, (count * (rank + 1)) // world

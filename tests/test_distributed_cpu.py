@@ -30,6 +30,8 @@ def _worker(rank, world, port, out_dir, seed, kw):
         out = distributed.lowhash0(backend, p, 120, boundaries)
         everything = distributed.gather_candidates(out.candidates)
         lo, hi = distributed.candidate_slice(len(everything), rank, world)
+        share, total = distributed.candidate_share(out.candidates)
+        assert total == len(everything) and np.array_equal(share, everything[lo:hi])
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
                  candidates=np.stack([everything["readId0"], everything["readId1"], everything["isSameStrand"]], axis=1),
                  local=np.stack([out.candidates["readId0"], out.candidates["readId1"], out.candidates["isSameStrand"]], axis=1),
