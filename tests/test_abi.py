@@ -1,0 +1,59 @@
+"""The C ABI on a machine without a GPU: the library loads, exports exactly the entry points
+include/shasta_mi355x.h declares, its PODs have the reference's sizes, and every compute entry
+point fails loudly (no CPU fallback) instead of computing."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import shasta_amd
+from shasta_amd import abi, lib as libmod
+from tests import support
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "shasta_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(shasta_mi355x_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_entry_point():
+    library = shasta_amd.load()
+    declared = declared_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(library.lib, name), name
+    assert sorted(libmod.EXPORTS) == declared          # the Python mirror binds the whole header, nothing else
+    assert "gfx950" in library.version()
+
+
+def test_pod_sizes_match_the_reference_structs():
+    # SURVEY Appendix B (verified there by compiling the reference headers).
+    assert C.sizeof(abi.OrientedReadPair) == 12
+    assert C.sizeof(abi.AlignmentInfo) == 52
+    assert C.sizeof(abi.AlignmentData) == 64
+    assert abi.PAIR_DTYPE.itemsize == 12 and abi.ALIGNMENT_DATA_DTYPE.itemsize == 64
+
+
+def test_missing_library_is_an_error_not_a_fallback(tmp_path):
+    with pytest.raises(libmod.LibraryNotBuilt, match="no CPU fallback"):
+        libmod.Library(str(tmp_path / "libshasta_mi355x.so"))
+
+
+@pytest.mark.skipif(shasta_amd.load().device_count() > 0, reason="a gfx950 device is present")
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    library = shasta_amd.load()
+    assert library.device_count() == 0
+    toc, kmer, data7 = support.small_marker_set(n_reads=20, genome_markers=3000, seed=1)
+    with pytest.raises(RuntimeError):
+        library.lowhash0(toc, data7, None, abi.default_lowhash0_params())
+    with pytest.raises(RuntimeError):
+        library.align4_batch(toc, data7, abi.make_pairs([0], [1], [1]), abi.default_align4_options())
+    with pytest.raises(RuntimeError):
+        library.context(0)
+    with pytest.raises(RuntimeError):
+        library.hash_windows(np.arange(10, dtype=np.uint32), 4, 0)
