@@ -1,0 +1,110 @@
+"""The stage-level Python surface of the reference for this path: `shasta.Assembler` and
+`shasta.AlignOptions` (pybind11, src/PythonModule.cpp:85-107,135-345) with the same method and
+attribute names, over an existing Data/ directory, for the two hot functions and the table step
+between them.  The reference's stage scripts (scripts/FindAlignmentCandidatesLowHash0.py,
+scripts/ComputeAlignments.py) run unchanged with `import shasta_amd.assembler as shasta`.
+
+The work happens in libshasta_mi355x_host.so (C++ host layer, shasta_amd/host/) which calls the GPU
+library through its C ABI; there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_SO = os.path.join(HERE, "_build", "libshasta_mi355x_host.so")
+
+
+class _HostAlignOptions(C.Structure):
+    _fields_ = [
+        ("alignMethod", C.c_int64),
+        ("maxSkip", C.c_uint64), ("maxDrift", C.c_uint64), ("maxTrim", C.c_uint64), ("minAlignedMarkerCount", C.c_uint64),
+        ("minAlignedFraction", C.c_double),
+        ("matchScore", C.c_int64), ("mismatchScore", C.c_int64), ("gapScore", C.c_int64), ("maxBand", C.c_int64),
+        ("suppressContainments", C.c_uint64),
+        ("align4DeltaX", C.c_uint64), ("align4DeltaY", C.c_uint64),
+        ("align4MinEntryCountPerCell", C.c_uint64), ("align4MaxDistanceFromBoundary", C.c_uint64),
+    ]
+
+
+class AlignOptions:
+    """shasta.AlignOptions: same attributes (src/PythonModule.cpp:85-107), defaults of
+    src/AssemblerOptions.cpp:380-489 except alignMethod, which is 4 (the method this library implements)."""
+
+    def __init__(self):
+        self.alignMethod = 4
+        self.maxSkip = 30
+        self.maxDrift = 30
+        self.maxTrim = 30
+        self.maxMarkerFrequency = 10                 # methods 0/1/3 only
+        self.minAlignedMarkerCount = 100
+        self.minAlignedFraction = 0.0
+        self.matchScore = 6
+        self.mismatchScore = -1
+        self.gapScore = -1
+        self.downsamplingFactor = 0.1                # method 3 only
+        self.bandExtend = 10                         # method 3 only
+        self.maxBand = 1000
+        self.sameChannelReadAlignmentSuppressDeltaThreshold = 0
+        self.suppressContainments = False
+        self.align4DeltaX = 200
+        self.align4DeltaY = 10
+        self.align4MinEntryCountPerCell = 10
+        self.align4MaxDistanceFromBoundary = 100
+
+
+class Assembler:
+    """shasta.Assembler for the overlap-detection stages.  Construct it on a run's Data/ directory
+    (the reference's default largeDataFileNamePrefix is "Data/")."""
+
+    def __init__(self, largeDataFileNamePrefix="Data/", createNew=False, readRepresentation=1, largeDataPageSize=4096):
+        if createNew:
+            raise RuntimeError("shasta_amd.Assembler works on an existing Data/ directory (createNew is not supported).")
+        if not os.path.exists(HOST_SO):
+            raise RuntimeError("%s is missing: build with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                               "There is no CPU fallback." % HOST_SO)
+        self._lib = C.CDLL(HOST_SO)
+        self._lib.shasta_mi355x_host_last_error.restype = C.c_char_p
+        self._data = largeDataFileNamePrefix.rstrip("/") or "."
+        self._page = int(largeDataPageSize)
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self._lib.shasta_mi355x_host_last_error().decode())
+
+    def _require(self, *names):
+        for name in names:
+            if not os.path.exists(os.path.join(self._data, name)):
+                raise RuntimeError("Error accessing %s: the file could not be opened." % os.path.join(self._data, name))
+
+    # The reference's access* calls map the files; here they check that the files exist.
+    def accessKmers(self):
+        pass                                          # the k-mer table is not used by this path
+
+    def accessMarkers(self):
+        self._require("Markers.toc", "Markers.data", "ReadFlags")
+
+    def accessAlignmentCandidates(self):
+        self._require("AlignmentCandidates")
+
+    def findAlignmentCandidatesLowHash0(self, m, hashFraction, minHashIterationCount, alignmentCandidatesPerRead,
+                                        minBucketSize, maxBucketSize, minFrequency, log2MinHashBucketCount=0, threadCount=0):
+        self._check(self._lib.shasta_mi355x_host_find_alignment_candidates_lowhash0(
+            self._data.encode(), C.c_uint64(m), C.c_double(hashFraction), C.c_uint64(minHashIterationCount),
+            C.c_double(alignmentCandidatesPerRead), C.c_uint64(log2MinHashBucketCount), C.c_uint64(minBucketSize),
+            C.c_uint64(maxBucketSize), C.c_uint64(minFrequency), C.c_uint64(threadCount), C.c_uint64(self._page)))
+
+    def computeCandidateTable(self):
+        self._check(self._lib.shasta_mi355x_host_compute_candidate_table(self._data.encode(), C.c_uint64(self._page)))
+
+    def computeAlignments(self, alignOptions, threadCount=0):
+        o = _HostAlignOptions(
+            alignMethod=int(alignOptions.alignMethod), maxSkip=int(alignOptions.maxSkip), maxDrift=int(alignOptions.maxDrift),
+            maxTrim=int(alignOptions.maxTrim), minAlignedMarkerCount=int(alignOptions.minAlignedMarkerCount),
+            minAlignedFraction=float(alignOptions.minAlignedFraction), matchScore=int(alignOptions.matchScore),
+            mismatchScore=int(alignOptions.mismatchScore), gapScore=int(alignOptions.gapScore), maxBand=int(alignOptions.maxBand),
+            suppressContainments=1 if alignOptions.suppressContainments else 0,
+            align4DeltaX=int(alignOptions.align4DeltaX), align4DeltaY=int(alignOptions.align4DeltaY),
+            align4MinEntryCountPerCell=int(alignOptions.align4MinEntryCountPerCell),
+            align4MaxDistanceFromBoundary=int(alignOptions.align4MaxDistanceFromBoundary))
+        self._check(self._lib.shasta_mi355x_host_compute_alignments(self._data.encode(), C.byref(o), C.c_uint64(threadCount),
+                                                                    C.c_uint64(self._page)))

@@ -1,0 +1,72 @@
+// C entry points of the host layer (libshasta_mi355x_host.so): the stage functions of
+// OverlapStages.hpp over a Data/ directory, for callers that are not C++ (the Python
+// shasta_amd.Assembler mirror of the reference's pybind11 class, src/PythonModule.cpp:135-345).
+// Returns 0 on success; shasta_mi355x_host_last_error() gives the message otherwise.
+#include "OverlapStages.hpp"
+
+#include <string>
+
+using namespace shasta_mi355x::host;
+
+static thread_local std::string hostError;
+#define HOST_BEGIN try {
+#define HOST_END } catch(const std::exception& e) { hostError = e.what(); return 1; } return 0;
+
+extern "C" {
+
+const char* shasta_mi355x_host_last_error(void) { return hostError.c_str(); }
+
+// Assembler::findAlignmentCandidatesLowHash0, src/AssemblerLowHash.cpp:10-55.
+int shasta_mi355x_host_find_alignment_candidates_lowhash0(
+    const char* dataDirectory, uint64_t m, double hashFraction, uint64_t minHashIterationCount,
+    double alignmentCandidatesPerRead, uint64_t log2MinHashBucketCount, uint64_t minBucketSize,
+    uint64_t maxBucketSize, uint64_t minFrequency, uint64_t threadCount, uint64_t largeDataPageSize)
+{
+    HOST_BEGIN
+    findAlignmentCandidatesLowHash0(dataDirectory, m, hashFraction, minHashIterationCount, alignmentCandidatesPerRead,
+        log2MinHashBucketCount, minBucketSize, maxBucketSize, minFrequency, threadCount, largeDataPageSize);
+    HOST_END
+}
+
+// Assembler::computeCandidateTable, src/AssemblerAlignmentCandidates.cpp:379-447.
+int shasta_mi355x_host_compute_candidate_table(const char* dataDirectory, uint64_t largeDataPageSize)
+{
+    HOST_BEGIN
+    const std::string d(dataDirectory);
+    Markers markers;
+    markers.accessExistingReadOnly(d + "/Markers");
+    AlignmentCandidates candidates;
+    candidates.accessExistingReadOnly(d + "/AlignmentCandidates");
+    computeCandidateTable(markers.size() / 2, candidates, d, largeDataPageSize);
+    HOST_END
+}
+
+// The numeric members of AlignOptions that method 4 reads, in the order of src/AssemblerOptions.hpp:177-198.
+struct shasta_mi355x_host_align_options {
+    int64_t alignMethod;
+    uint64_t maxSkip, maxDrift, maxTrim, minAlignedMarkerCount;
+    double minAlignedFraction;
+    int64_t matchScore, mismatchScore, gapScore, maxBand;
+    uint64_t suppressContainments;
+    uint64_t align4DeltaX, align4DeltaY, align4MinEntryCountPerCell, align4MaxDistanceFromBoundary;
+};
+
+// Assembler::computeAlignments, src/AssemblerAlign.cpp:208-304.
+int shasta_mi355x_host_compute_alignments(const char* dataDirectory, const shasta_mi355x_host_align_options* o,
+    uint64_t threadCount, uint64_t largeDataPageSize)
+{
+    HOST_BEGIN
+    AlignOptions a;
+    a.alignMethod = int(o->alignMethod);
+    a.maxSkip = o->maxSkip; a.maxDrift = o->maxDrift; a.maxTrim = o->maxTrim;
+    a.minAlignedMarkerCount = o->minAlignedMarkerCount; a.minAlignedFraction = o->minAlignedFraction;
+    a.matchScore = int(o->matchScore); a.mismatchScore = int(o->mismatchScore); a.gapScore = int(o->gapScore);
+    a.maxBand = int(o->maxBand); a.suppressContainments = o->suppressContainments != 0;
+    a.align4DeltaX = o->align4DeltaX; a.align4DeltaY = o->align4DeltaY;
+    a.align4MinEntryCountPerCell = o->align4MinEntryCountPerCell;
+    a.align4MaxDistanceFromBoundary = o->align4MaxDistanceFromBoundary;
+    computeAlignments(dataDirectory, a, threadCount, largeDataPageSize);
+    HOST_END
+}
+
+}  // extern "C"
