@@ -289,6 +289,12 @@ def main():
                     roofline = {"bound": "hbm", "achieved": per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": per_launch / avg / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of(traffic_table, names[c]),
                                 "kernel": names[c], "gcups": fw_cells[c] / fw_s[c] / 1e9,
+                                # What actually bounds it: 75 VALU instructions per lane and loop iteration (2 cells) in the
+                                # compiled loop; 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-instructions/s
+                                # (MI355X_MICROARCH.md: 157.3 TFLOPS fp32 = 2 flops x that).
+                                "valu": {"lane_instructions_per_cell": 37.5, "peak_lane_instructions_per_s": 78.6e12,
+                                         "ceiling_gcups": 78.6e12 / 37.5 / 1e9,
+                                         "frac": (fw_cells[c] / fw_s[c]) / (78.6e12 / 37.5)},
                                 "note": "dominant kernel by time; integer max-plus DP bound by VALU issue: its algorithmic bytes "
                                         "(4(nx+ny) per task) are tiny against its work (nx x bandWidth cells), so the HBM fraction "
                                         "is low by construction; traffic is dominated by the 2-bit/cell trace it writes"}
