@@ -1532,18 +1532,11 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(ctx, st, b, sortedIds, layout, 0); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     if(ev) HIP_CHECK(hipEventRecord(ev->start[DP_CLASSES], stream));
-    {
-        // 256-byte chunks (8 iterations of the narrow classes); class 5 holds one iteration per chunk.
-        const uint32_t small = 0, large = taskCount - small;
-        if(small) hipLaunchKernelGGL(dpTracebackKernel<16>, dim3(divUp(small, 256)), dim3(256), 0, stream,
-            (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds, small,
-            (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
-            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
-        if(large) hipLaunchKernelGGL(dpTracebackKernel<32>, dim3(divUp(large, 256)), dim3(256), 0, stream,
-            (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds + small, large,
-            (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
-            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
-    }
+    // 256-byte trace chunks: 8 iterations of the narrow classes, one iteration of the widest class.
+    hipLaunchKernelGGL(dpTracebackKernel<32>, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+        (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds, taskCount,
+        (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
+        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
     HIP_CHECK(hipGetLastError());
     if(ev) HIP_CHECK(hipEventRecord(ev->stop[DP_CLASSES], stream));
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = sums[2 + c]; stats->bytes[c] = sums[8 + c]; stats->tasks[c] = classCounts[c]; }
