@@ -640,6 +640,7 @@ int ref_open_vector(const char* path, uint64_t objectSize, uint64_t* objectCount
             case 7: return openBlobVector<7>(path, objectCount, fileSize, out, outCapacity);
             case 8: return openBlobVector<8>(path, objectCount, fileSize, out, outCapacity);
             case 12: return openBlobVector<12>(path, objectCount, fileSize, out, outCapacity);
+            case 16: return openBlobVector<16>(path, objectCount, fileSize, out, outCapacity);
             case 24: return openBlobVector<24>(path, objectCount, fileSize, out, outCapacity);
             case 64: return openBlobVector<64>(path, objectCount, fileSize, out, outCapacity);
             default: throw std::runtime_error("unsupported object size");

@@ -96,6 +96,14 @@ class Assembler:
     def computeCandidateTable(self):
         self._check(self._lib.shasta_mi355x_host_compute_candidate_table(self._data.encode(), C.c_uint64(self._page)))
 
+    def accessAlignmentData(self):
+        self._require("AlignmentData", "AlignmentTable.toc", "AlignmentTable.data")
+
+    def createReadGraph(self, maxAlignmentCount, maxTrim):
+        """ReadGraph.creationMethod 0 (src/AssemblerReadGraph.cpp:35-104): host work on the stored alignments."""
+        self._check(self._lib.shasta_mi355x_host_create_read_graph(
+            self._data.encode(), C.c_uint32(maxAlignmentCount), C.c_uint32(maxTrim), C.c_uint64(self._page)))
+
     def computeAlignments(self, alignOptions, threadCount=0):
         o = _HostAlignOptions(
             alignMethod=int(alignOptions.alignMethod), maxSkip=int(alignOptions.maxSkip), maxDrift=int(alignOptions.maxDrift),

@@ -60,11 +60,15 @@ public:
     }
 
     // Same checks and messages as MemoryMapped::Vector::accessExisting (:624-642).
-    void accessExistingReadOnly(const std::string& name)
+    void accessExistingReadOnly(const std::string& name) { accessExisting(name, false); }
+    void accessExistingReadWrite(const std::string& name) { accessExisting(name, true); }
+
+private:
+    void accessExisting(const std::string& name, bool readWrite)
     {
         close();
-        fileName = name; writable = false;
-        const int fd = ::open(name.c_str(), O_RDONLY);
+        fileName = name; writable = readWrite;
+        const int fd = ::open(name.c_str(), readWrite ? O_RDWR : O_RDONLY);
         if(fd < 0) throw std::runtime_error("Error accessing " + name + ": the file could not be opened.");
         struct stat st;
         if(::fstat(fd, &st) != 0 || uint64_t(st.st_size) < sizeof(MappedHeader)) { ::close(fd); throw std::runtime_error("Error accessing " + name + ": file too small."); }
@@ -78,6 +82,7 @@ public:
         }
     }
 
+public:
     bool isOpen() const { return header != nullptr; }
     uint64_t size() const { return header ? header->objectCount : 0; }
     uint64_t capacity() const { return header ? header->capacity : 0; }

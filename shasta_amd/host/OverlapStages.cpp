@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <numeric>
 #include <stdexcept>
@@ -196,6 +197,75 @@ void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignm
     AlignmentTable table;
     table.createNew(dataName(dataDirectory, "AlignmentTable"), largeDataPageSize);
     fillPairTable(table, readCount, alignmentData.size(), [&](uint64_t i) -> const shasta_oriented_read_pair& { return alignmentData[i].pair; });
+}
+
+uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignmentCount, uint32_t /* maxTrim: unused by the reference too */,
+    size_t largeDataPageSize)
+{
+    AlignmentDataVector alignmentData;
+    alignmentData.accessExistingReadWrite(dataName(dataDirectory, "AlignmentData"));
+    AlignmentTable alignmentTable;
+    alignmentTable.accessExistingReadOnly(dataName(dataDirectory, "AlignmentTable"));
+    const uint64_t orientedReadCount = alignmentTable.size();
+    const uint64_t readCount = orientedReadCount / 2;
+
+    // For each read, keep only the best maxAlignmentCount alignments (:55-95): pairs (markerCount,
+    // alignmentId), the largest first; ties go to the larger alignment id, as std::greater on the pair does.
+    std::vector<bool> keepAlignment(alignmentData.size(), false);
+    std::vector<std::pair<uint32_t, uint32_t>> readAlignments;
+    for(uint64_t readId = 0; readId < readCount; readId++) {
+        readAlignments.clear();
+        const uint32_t* section = alignmentTable.begin(2 * readId);
+        for(uint64_t k = 0; k < alignmentTable.size(2 * readId); k++) {
+            readAlignments.push_back(std::make_pair(alignmentData[section[k]].info.markerCount, section[k]));
+        }
+        if(readAlignments.size() > maxAlignmentCount) {
+            std::nth_element(readAlignments.begin(), readAlignments.begin() + maxAlignmentCount, readAlignments.end(),
+                std::greater<std::pair<uint32_t, uint32_t>>());
+            readAlignments.resize(maxAlignmentCount);
+        }
+        for(const auto& p : readAlignments) keepAlignment[p.second] = true;
+    }
+    const uint64_t keepCount = uint64_t(std::count(keepAlignment.begin(), keepAlignment.end(), true));
+    std::cout << "Keeping " << keepCount << " alignments of " << keepAlignment.size() << std::endl;     // :97-98
+
+    // Edges: one per kept alignment plus its reverse complement (:115-143).
+    ReadGraphEdges edges;
+    edges.createNew(dataName(dataDirectory, "ReadGraphEdges"), largeDataPageSize);
+    for(uint64_t alignmentId = 0; alignmentId < alignmentData.size(); alignmentId++) {
+        shasta_alignment_data& alignment = alignmentData[alignmentId];
+        alignment.info.isInReadGraph = keepAlignment[alignmentId] ? 1 : 0;
+        if(!keepAlignment[alignmentId]) continue;
+        ReadGraphEdge16 edge;
+        edge.alignmentIdAndFlags = alignmentId & 0x3fffffffffffffffULL;
+        edge.orientedReadIds[0] = alignment.pair.readIds[0] << 1;
+        edge.orientedReadIds[1] = (alignment.pair.readIds[1] << 1) | (alignment.pair.isSameStrand ? 0u : 1u);
+        edges.push_back(edge);
+        edge.orientedReadIds[0] ^= 1u; edge.orientedReadIds[1] ^= 1u;
+        edges.push_back(edge);
+    }
+    edges.unreserve();
+
+    // Connectivity: per oriented read the indices of its edges.  The reference fills each row from
+    // the back (VectorOfVectors::store, src/MemoryMappedVectorOfVectors.hpp:383-386): descending edge index.
+    ReadGraphConnectivity connectivity;
+    connectivity.createNew(dataName(dataDirectory, "ReadGraphConnectivity"), largeDataPageSize);
+    std::vector<uint32_t> counts(orientedReadCount, 0);
+    for(uint64_t i = 0; i < edges.size(); i++) { ++counts[edges[i].orientedReadIds[0]]; ++counts[edges[i].orientedReadIds[1]]; }
+    connectivity.fillFromCounts(counts);
+    for(uint64_t i = 0; i < edges.size(); i++) {
+        for(int k = 0; k < 2; k++) {
+            const uint32_t o = edges[i].orientedReadIds[k];
+            connectivity.begin(o)[--counts[o]] = uint32_t(i);
+        }
+    }
+    connectivity.unreserve();
+
+    uint64_t isolatedReadCount = 0;
+    for(uint64_t readId = 0; readId < readCount; readId++) if(connectivity.size(2 * readId) == 0) ++isolatedReadCount;
+    std::cout << "The read graph has " << edges.size() / 2 << " edges (and as many reverse complemented); "
+        << isolatedReadCount << " reads are isolated." << std::endl;
+    return keepCount;
 }
 
 void computeAlignments(const std::string& dataDirectory, const AlignOptions& alignOptions, size_t /* threadCount */, size_t largeDataPageSize)

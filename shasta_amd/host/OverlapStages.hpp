@@ -7,6 +7,7 @@
 //   computeAlignments                 <-> Assembler::computeAlignments (alignMethod 4)  src/AssemblerAlign.cpp:208-304
 //   computeAlignmentTable             <-> Assembler::computeAlignmentTable    src/AssemblerAlign.cpp:509-571
 //   computeCandidateTable             <-> AlignmentCandidates::computeCandidateTable    src/AssemblerAlignmentCandidates.cpp:388-447
+//   createReadGraph                   <-> Assembler::createReadGraph          src/AssemblerReadGraph.cpp:35-157
 #pragma once
 
 #include "MappedVector.hpp"
@@ -31,6 +32,13 @@ using AlignmentDataVector = MappedVector<shasta_alignment_data>;             // 
 using CompressedAlignments = MappedVectorOfVectors<char, uint64_t>;          // Data/CompressedAlignments.{toc,data}
 using AlignmentTable = MappedVectorOfVectors<uint32_t, uint32_t>;            // Data/AlignmentTable.{toc,data}
 using CandidateTable = MappedVectorOfVectors<uint64_t, uint64_t>;            // Data/CandidateTable.{toc,data}
+
+// shasta::ReadGraphEdge, src/ReadGraph.hpp:37-57 (16 bytes: two OrientedReadIds, then
+// alignmentId:62 | crossesStrands:1 | hasInconsistentAlignment:1 in one little-endian uint64).
+struct ReadGraphEdge16 { uint32_t orientedReadIds[2]; uint64_t alignmentIdAndFlags; };
+static_assert(sizeof(ReadGraphEdge16) == 16, "ReadGraphEdge is 16 bytes");
+using ReadGraphEdges = MappedVector<ReadGraphEdge16>;                        // Data/ReadGraphEdges
+using ReadGraphConnectivity = MappedVectorOfVectors<uint32_t, uint32_t>;     // Data/ReadGraphConnectivity.{toc,data}
 
 // The [Align] options computeAlignments reads (src/AssemblerOptions.hpp:177-198); defaults of
 // src/AssemblerOptions.cpp:380-489.
@@ -73,6 +81,12 @@ void computeAlignments(const std::string& dataDirectory, const AlignOptions&, si
 // reference runs between the two seams (srcMain/main.cpp:706).  Host work: a CSR index + per-row sort.
 void computeCandidateTable(uint64_t readCount, const AlignmentCandidates& candidates,
     const std::string& dataDirectory, size_t largeDataPageSize = 4096);
+
+// Assembler::createReadGraph + createReadGraphUsingSelectedAlignments (src/AssemblerReadGraph.cpp:35-157),
+// the first consumer of the alignments (ReadGraph.creationMethod 0): per read keep the
+// maxAlignmentCount alignments with the most aligned markers, set AlignmentInfo::isInReadGraph in
+// Data/AlignmentData, write Data/ReadGraphEdges and Data/ReadGraphConnectivity.  Returns the number kept.
+uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignmentCount, uint32_t maxTrim, size_t largeDataPageSize = 4096);
 
 void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
     const std::string& dataDirectory, size_t largeDataPageSize = 4096);

@@ -69,4 +69,12 @@ int shasta_mi355x_host_compute_alignments(const char* dataDirectory, const shast
     HOST_END
 }
 
+// Assembler::createReadGraph, src/AssemblerReadGraph.cpp:35-104.
+int shasta_mi355x_host_create_read_graph(const char* dataDirectory, uint32_t maxAlignmentCount, uint32_t maxTrim, uint64_t largeDataPageSize)
+{
+    HOST_BEGIN
+    (void)createReadGraph(dataDirectory, maxAlignmentCount, maxTrim, largeDataPageSize);
+    HOST_END
+}
+
 }  // extern "C"

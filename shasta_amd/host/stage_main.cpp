@@ -4,6 +4,7 @@
 //   shasta_mi355x_stage lowhash0 <Data> [m hashFraction minHashIterationCount alignmentCandidatesPerRead
 //                                        log2MinHashBucketCount minBucketSize maxBucketSize minFrequency]
 //   shasta_mi355x_stage candidate-table <Data>
+//   shasta_mi355x_stage read-graph <Data> [maxAlignmentCount maxTrim]
 //   shasta_mi355x_stage align    <Data> [minAlignedMarkerCount minAlignedFraction maxSkip maxDrift maxTrim suppressContainments]
 // Exit codes follow srcMain/main.cpp:103-129: 0 success, 1 std::runtime_error / other exception.
 #include "OverlapStages.hpp"
@@ -17,7 +18,7 @@ using namespace shasta_mi355x::host;
 int main(int argc, char** argv)
 {
     try {
-        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage lowhash0|candidate-table|align <DataDirectory> [options...]");
+        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage lowhash0|candidate-table|align|read-graph <DataDirectory> [options...]");
         const std::string command = argv[1], data = argv[2];
         auto arg = [&](int k, const char* fallback) { return std::string(argc > k ? argv[k] : fallback); };
         if(command == "lowhash0") {
@@ -38,6 +39,9 @@ int main(int argc, char** argv)
             o.maxSkip = std::stoull(arg(5, "30")); o.maxDrift = std::stoull(arg(6, "30")); o.maxTrim = std::stoull(arg(7, "30"));
             o.suppressContainments = std::stoull(arg(8, "0")) != 0;
             computeAlignments(data, o, 0);
+        } else if(command == "read-graph") {
+            // Assembler::createReadGraph(maxAlignmentCount, maxTrim), srcMain/main.cpp:718-722 (ReadGraph.creationMethod 0).
+            createReadGraph(data, uint32_t(std::stoul(arg(3, "6"))), uint32_t(std::stoul(arg(4, "30"))));
         } else {
             throw std::runtime_error("unknown command " + command);
         }

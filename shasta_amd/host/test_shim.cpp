@@ -57,6 +57,7 @@ int host_open_vector(const char* path, uint64_t objectSize, uint64_t* objectCoun
         case 7: readBlobVector<7>(path, objectCount, fileBytes, out, capacity); break;
         case 8: readBlobVector<8>(path, objectCount, fileBytes, out, capacity); break;
         case 12: readBlobVector<12>(path, objectCount, fileBytes, out, capacity); break;
+        case 16: readBlobVector<16>(path, objectCount, fileBytes, out, capacity); break;
         case 24: readBlobVector<24>(path, objectCount, fileBytes, out, capacity); break;
         case 64: readBlobVector<64>(path, objectCount, fileBytes, out, capacity); break;
         default: throw std::runtime_error("unsupported object size");
@@ -99,6 +100,13 @@ int host_compute_candidate_table(const char* dir, uint64_t readCount)
     AlignmentCandidates candidates;
     candidates.accessExistingReadOnly(d + "/AlignmentCandidates");
     computeCandidateTable(readCount, candidates, d);
+    SHIM_END
+}
+
+int host_create_read_graph(const char* dir, uint32_t maxAlignmentCount, uint64_t* keepCount)
+{
+    SHIM_BEGIN
+    *keepCount = createReadGraph(dir, maxAlignmentCount, 30);
     SHIM_END
 }
 

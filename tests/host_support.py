@@ -49,6 +49,11 @@ class HostShim:
     def compute_candidate_table(self, directory, read_count):
         self._check(self.lib.host_compute_candidate_table(directory.encode(), C.c_uint64(read_count)), "host_compute_candidate_table")
 
+    def create_read_graph(self, directory, max_alignment_count):
+        kept = C.c_uint64()
+        self._check(self.lib.host_create_read_graph(directory.encode(), C.c_uint32(max_alignment_count), C.byref(kept)), "host_create_read_graph")
+        return int(kept.value)
+
     def compute_alignment_table(self, directory, read_count):
         self._check(self.lib.host_compute_alignment_table(directory.encode(), C.c_uint64(read_count)), "host_compute_alignment_table")
 
@@ -71,3 +76,34 @@ def alignment_table_expected(read_count, alignment_data, index_dtype=np.uint32):
         data += [i for _, i in sec]
         toc[k + 1] = len(data)
     return toc, np.asarray(data, dtype=index_dtype)
+
+
+def read_graph_expected(read_count, alignment_data, max_alignment_count):
+    """Assembler::createReadGraph + createReadGraphUsingSelectedAlignments (src/AssemblerReadGraph.cpp:35-157)
+    in python: kept flags, edges (oriented read pair, alignment id) and connectivity rows."""
+    per_read = [[] for _ in range(read_count)]
+    for i, ad in enumerate(alignment_data):
+        per_read[int(ad["readId0"])].append((int(ad["markerCount"]), i))
+        per_read[int(ad["readId1"])].append((int(ad["markerCount"]), i))
+    keep = np.zeros(len(alignment_data), bool)
+    for lst in per_read:
+        for _, i in sorted(lst, reverse=True)[:max_alignment_count]:
+            keep[i] = True
+    edges = []
+    for i, ad in enumerate(alignment_data):
+        if not keep[i]:
+            continue
+        o0 = int(ad["readId0"]) << 1
+        o1 = (int(ad["readId1"]) << 1) | (0 if ad["isSameStrand"] else 1)
+        edges.append((o0, o1, i))
+        edges.append((o0 ^ 1, o1 ^ 1, i))
+    rows = [[] for _ in range(2 * read_count)]
+    for e, (a, b, _) in enumerate(edges):
+        rows[a].append(e)
+        rows[b].append(e)
+    toc = np.zeros(2 * read_count + 1, np.uint32)
+    data = []
+    for k, row in enumerate(rows):
+        data += sorted(row, reverse=True)                 # VectorOfVectors::store fills a row from the back
+        toc[k + 1] = len(data)
+    return keep, edges, toc, np.asarray(data, np.uint32)

@@ -90,3 +90,34 @@ def test_candidate_table(shim, ref_lib, oracle_lib, tmp_path):
     toc_expected, data_expected = host_support.alignment_table_expected(150, cand, np.uint64)
     assert np.array_equal(t.view("<u8").reshape(-1), toc_expected)
     assert np.array_equal(dta.view("<u8").reshape(-1), data_expected)
+
+
+@pytest.mark.parametrize("max_alignment_count", [2, 6])
+def test_read_graph_selection(shim, ref_lib, oracle_lib, tmp_path, max_alignment_count):
+    toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=9000, seed=87)
+    cand = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)).candidates
+    al = oracle_lib.align4_batch(toc, data7, cand, abi.default_align4_options(minAlignedMarkerCount=40), want_ordinals=False, threads=0)
+    rows = al.alignment_data
+    assert len(rows) > 150
+    d = str(tmp_path)
+    shim.store_alignments(d, rows, al.compressed_toc, al.compressed_data)
+    shim.compute_alignment_table(d, 150)
+    kept = shim.create_read_graph(d, max_alignment_count)
+    keep, edges, ctoc, cdata = host_support.read_graph_expected(150, rows, max_alignment_count)
+    assert kept == int(keep.sum()) and 0 < kept <= len(rows) and (max_alignment_count == 6 or kept < len(rows))
+    # isInReadGraph is set in place in AlignmentData (bit 0 of byte 60); nothing else changes.
+    after, _ = ref_lib.open_vector(os.path.join(d, "AlignmentData"), 64)
+    assert np.array_equal((after[:, 60] & 1).astype(bool), keep)
+    got = np.frombuffer(after.tobytes(), dtype=abi.ALIGNMENT_DATA_DTYPE)
+    for field in abi.ALIGNMENT_DATA_DTYPE.names:
+        assert np.array_equal(got[field], rows[field]), field
+    e, _ = ref_lib.open_vector(os.path.join(d, "ReadGraphEdges"), 16)
+    assert len(e) == len(edges)
+    o = e[:, 0:8].copy().view("<u4").reshape(-1, 2)
+    ids = e[:, 8:16].copy().view("<u8").reshape(-1)
+    assert np.array_equal(o, np.asarray([(a, b) for a, b, _ in edges], np.uint32).reshape(-1, 2))
+    assert np.array_equal(ids, np.asarray([i for _, _, i in edges], np.uint64))          # flag bits 62, 63 are zero
+    assert np.all(o[:, 0] < o[:, 1])
+    t, _ = ref_lib.open_vector(os.path.join(d, "ReadGraphConnectivity.toc"), 4)
+    c, _ = ref_lib.open_vector(os.path.join(d, "ReadGraphConnectivity.data"), 4)
+    assert np.array_equal(t.view("<u4").reshape(-1), ctoc) and np.array_equal(c.view("<u4").reshape(-1), cdata)
