@@ -72,14 +72,27 @@ def traffic_of(table, kernel_name):
 TRAFFIC_WORKLOAD = {"reads": None}
 
 
+def available_memory_gib():
+    """MemAvailable of /proc/meminfo in GiB (a large number when it cannot be read)."""
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) >> 20
+    except OSError:
+        pass
+    return 1 << 20
+
+
 def cpu_baseline(n_reads_sample, seed):
     """Reference CPU path on a bounded sample of the same workload (1/10 scale, same coverage)."""
     from oracle import bindings
     from shasta_amd import synthetic
     # Threads actually used = "cores" of the report.  Capped at 64: every reference Align4 thread
     # zero-fills its own 2 GiB arena (src/AssemblerAlign.cpp:353-355) before its first candidate, and a
-    # run with one thread per core of a 256-core box (512 GiB of arenas) took the GPU box down.
-    cores = min(os.cpu_count() or 1, 64)
+    # run with one thread per core of a 256-core box (512 GiB of arenas) took the GPU box down.  Also kept
+    # under a quarter of the available memory (4 GiB per thread: the arena + the thread's share of the rest).
+    cores = min(os.cpu_count() or 1, 64, max(1, available_memory_gib() // 4))
     toc, kmer = make_workload(n_reads_sample, seed)
     data7 = synthetic.pack_markers(toc, kmer)
     p, o = lowhash_params(), align_options()
