@@ -113,6 +113,29 @@ typedef struct shasta_align4_options {
     uint8_t  pad[7];
 } shasta_align4_options;
 
+/* Align method 3 (the default of the shipped configurations): the numeric arguments of
+ * Assembler::alignOrientedReads3 (src/AssemblerAlign3.cpp:22-33; defaults
+ * src/AssemblerOptions.cpp:419-449), k (the marker length: the down-sampling hash
+ * KmerInfo::hash is MurmurHash2 of kmerId + its reverse complement,
+ * src/AssemblerKmers.cpp:182-186) and the outer filters of computeAlignmentsThreadFunction
+ * (src/AssemblerAlign.cpp:439-472). */
+typedef struct shasta_align3_options {
+    int64_t  matchScore;
+    int64_t  mismatchScore;
+    int64_t  gapScore;
+    double   downsamplingFactor;     /* fraction of the markers kept in step 1      */
+    int64_t  bandExtend;             /* step-2 band = step-1 offset range +- this   */
+    int64_t  maxBand;                /* wider step-2 bands give an empty alignment  */
+    uint64_t k;
+    uint64_t minAlignedMarkerCount;
+    double   minAlignedFraction;
+    uint64_t maxSkip;
+    uint64_t maxDrift;
+    uint64_t maxTrim;
+    uint8_t  suppressContainments;
+    uint8_t  pad[7];
+} shasta_align3_options;
+
 /* Per-candidate status codes. */
 enum {
     SHASTA_ALIGN_STORED        = 0,  /* passed every filter; one AlignmentData row  */

@@ -189,6 +189,29 @@ class RefLib(_Base):
         return out
 
 
+    def align3_batch(self, toc, data7, candidates, options, want_ordinals=True, threads=1):
+        """Align method 3 through the reference's own Assembler::alignOrientedReads3."""
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        res = abi.Align4Result()
+        rc = self.lib.ref_align3_batch_mt(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.c_uint64(threads), C.byref(res))
+        self._check(rc, "ref_align3_batch_mt")
+        out = abi.Align4Output(res, len(candidates), want_ordinals)
+        self.lib.ref_align4_free(C.byref(res))
+        return out
+
+    def kmer_hashes(self, k):
+        """KmerInfo::hash of all 4^k k-mer ids (src/AssemblerKmers.cpp:182-186)."""
+        out = np.zeros(1 << (2 * k), dtype=np.uint32)
+        self._check(self.lib.ref_kmer_hashes(C.c_uint64(k), abi.as_ptr(out, C.c_uint32)), "ref_kmer_hashes")
+        return out
+
+
 class OracleLib(_Base):
     prefix = "oracle_"
 
@@ -228,6 +251,40 @@ class OracleLib(_Base):
     def align4_batch(self, toc, data7, candidates, options, want_ordinals=True, threads=1):
         self.lib.oracle_set_threads(C.c_uint64(threads))
         return self._align4(toc, data7, candidates, options, want_ordinals)
+
+    def align3_batch(self, toc, data7, candidates, options, want_ordinals=True, threads=1):
+        self.lib.oracle_set_threads(C.c_uint64(threads))
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        res = abi.Align4Result()
+        rc = self.lib.oracle_align3_batch(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
+        self._check(rc, "oracle_align3_batch")
+        out = abi.Align4Output(res, len(candidates), want_ordinals)
+        self.lib.oracle_align4_free(C.byref(res))
+        return out
+
+    def align3_stages(self, k0, k1, options):
+        """-> dict of the stage products of method 3 for one pair of kmer-id sequences."""
+        k0 = np.ascontiguousarray(k0, dtype=np.uint32)
+        k1 = np.ascontiguousarray(k1, dtype=np.uint32)
+        out = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.oracle_align3_stages(
+            abi.as_ptr(k0, C.c_uint32), C.c_uint32(len(k0)), abi.as_ptr(k1, C.c_uint32), C.c_uint32(len(k1)),
+            C.byref(options), abi.as_ptr(out, C.c_int64)), "oracle_align3_stages")
+        names = ["downsampled0", "downsampled1", "aligned", "offsetMin", "offsetMax", "bandMin", "bandMax", "bandTooWide"]
+        return dict(zip(names, (int(v) for v in out)))
+
+    def kmer_hashes(self, kmer_ids, k):
+        ids = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
+        out = np.zeros(len(ids), dtype=np.uint32)
+        self._check(self.lib.oracle_kmer_hashes(abi.as_ptr(ids, C.c_uint32), C.c_uint64(len(ids)), C.c_uint64(k),
+                                                abi.as_ptr(out, C.c_uint32)), "oracle_kmer_hashes")
+        return out
 
     def banded_dp(self, k0, k1, band_min, band_max):
         k0 = np.ascontiguousarray(k0, dtype=np.uint32)

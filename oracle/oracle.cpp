@@ -191,6 +191,121 @@ int oracle_align4_batch(
     } catch(std::exception& e) { lastError = e.what(); return 1; }
 }
 
+// Align method 3 (restated.hpp: align3).  Same result layout as the Align4 batch; status EMPTY
+// = empty alignment, SKIPPED = the reference's exception lane.
+int oracle_align3_batch(
+    uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options* o, int wantOrdinals, shasta_align4_result* result)
+{
+    try {
+        std::memset(result, 0, sizeof(*result));
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint32_t> kmerIds;
+        extractKmerIds(static_cast<const uint8_t*>(markersData), markersToc[2 * readCount], kmerIds);
+        Align3Options opt;
+        opt.matchScore = int32_t(o->matchScore); opt.mismatchScore = int32_t(o->mismatchScore); opt.gapScore = int32_t(o->gapScore);
+        opt.downsamplingFactor = o->downsamplingFactor;
+        opt.bandExtend = int32_t(o->bandExtend); opt.maxBand = int32_t(o->maxBand); opt.k = o->k;
+        Align4Options filters;
+        filters.minAlignedMarkerCount = o->minAlignedMarkerCount;
+        filters.minAlignedFraction = o->minAlignedFraction;
+        filters.maxSkip = o->maxSkip; filters.maxDrift = o->maxDrift; filters.maxTrim = o->maxTrim;
+
+        struct PerCandidate { Ordinals ord; Info info; uint8_t status; uint64_t dpCells; };
+        std::vector<PerCandidate> per(candidateCount);
+        const uint64_t threadCount = std::max<uint64_t>(1, threadCountSetting.load());
+        std::atomic<uint64_t> next(0);
+        auto work = [&]() {
+            Align3Trace trace;
+            for(;;) {
+                const uint64_t begin = next.fetch_add(10);
+                if(begin >= candidateCount) break;
+                const uint64_t end = std::min(candidateCount, begin + 10);
+                for(uint64_t i = begin; i < end; i++) {
+                    const auto& c = candidates[i];
+                    const uint64_t or0 = 2ULL * c.readIds[0];
+                    const uint64_t or1 = 2ULL * c.readIds[1] + (c.isSameStrand ? 0 : 1);
+                    const uint32_t nx = uint32_t(markersToc[or0 + 1] - markersToc[or0]);
+                    const uint32_t ny = uint32_t(markersToc[or1 + 1] - markersToc[or1]);
+                    PerCandidate& pc = per[i];
+                    const bool ok = align3(kmerIds.data() + markersToc[or0], nx, kmerIds.data() + markersToc[or1], ny,
+                        opt, pc.ord, pc.info, &trace);
+                    pc.dpCells = trace.dpCells;
+                    if(!ok) { pc.status = SHASTA_ALIGN_SKIPPED; pc.ord.clear(); }
+                    else if(pc.ord.empty()) pc.status = SHASTA_ALIGN_EMPTY;
+                    else pc.status = passesOuterFilters(pc.ord, pc.info, filters, o->suppressContainments != 0) ?
+                        SHASTA_ALIGN_STORED : SHASTA_ALIGN_REJECTED;
+                }
+            }
+        };
+        std::vector<std::thread> threads;
+        for(uint64_t t = 1; t < threadCount; t++) threads.emplace_back(work);
+        work();
+        for(auto& t : threads) t.join();
+
+        std::vector<shasta_alignment_data> alignmentData;
+        std::vector<uint64_t> compressedToc(1, 0), ordinalsToc(1, 0);
+        std::vector<uint8_t> compressedData, bytes, status(candidateCount);
+        std::vector<uint32_t> ordinals;
+        for(uint64_t i = 0; i < candidateCount; i++) {
+            const PerCandidate& pc = per[i];
+            status[i] = pc.status;
+            result->dpCellCount += pc.dpCells;
+            const auto& c = candidates[i];
+            const uint64_t or0 = 2ULL * c.readIds[0], or1 = 2ULL * c.readIds[1] + (c.isSameStrand ? 0 : 1);
+            result->kmerIdBytes += 4 * (markersToc[or0 + 1] - markersToc[or0] + markersToc[or1 + 1] - markersToc[or1]);
+            if(wantOrdinals) {
+                for(const auto& p : pc.ord) { ordinals.push_back(p.first); ordinals.push_back(p.second); }
+                ordinalsToc.push_back(ordinals.size() / 2);
+            }
+            if(pc.status != SHASTA_ALIGN_STORED) continue;
+            shasta_alignment_data ad;
+            std::memset(&ad, 0, sizeof(ad));
+            ad.pair.readIds[0] = c.readIds[0]; ad.pair.readIds[1] = c.readIds[1];
+            ad.pair.isSameStrand = c.isSameStrand ? 1 : 0;
+            copyInfo(pc.info, ad.info);
+            alignmentData.push_back(ad);
+            compress(pc.ord, bytes);
+            compressedData.insert(compressedData.end(), bytes.begin(), bytes.end());
+            compressedToc.push_back(compressedData.size());
+        }
+        result->alignmentCount = alignmentData.size();
+        result->alignmentData = mallocCopy(alignmentData);
+        result->compressedToc = mallocCopy(compressedToc);
+        result->compressedData = mallocCopy(compressedData);
+        result->status = mallocCopy(status);
+        if(wantOrdinals) { result->ordinalsToc = mallocCopy(ordinalsToc); result->ordinals = mallocCopy(ordinals); }
+        result->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// Stage products of method 3 for one pair of kmer-id sequences: out[8] = {downsampled count 0, 1,
+// step 1 aligned (0/1), offsetMin, offsetMax, bandMin, bandMax, band too wide (0/1)}.
+int oracle_align3_stages(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny,
+    const shasta_align3_options* o, int64_t* out)
+{
+    try {
+        Align3Options opt;
+        opt.matchScore = int32_t(o->matchScore); opt.mismatchScore = int32_t(o->mismatchScore); opt.gapScore = int32_t(o->gapScore);
+        opt.downsamplingFactor = o->downsamplingFactor;
+        opt.bandExtend = int32_t(o->bandExtend); opt.maxBand = int32_t(o->maxBand); opt.k = o->k;
+        Ordinals ord; Info info; Align3Trace t;
+        align3(k0, nx, k1, ny, opt, ord, info, &t);
+        out[0] = t.downsampledCount[0]; out[1] = t.downsampledCount[1]; out[2] = t.downsampledAligned ? 1 : 0;
+        out[3] = t.offsetMin; out[4] = t.offsetMax; out[5] = t.bandMin; out[6] = t.bandMax; out[7] = t.bandTooWide ? 1 : 0;
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// KmerInfo::hash of kmerIds[i] for marker length k.
+int oracle_kmer_hashes(const uint32_t* kmerIds, uint64_t n, uint64_t k, uint32_t* out)
+{
+    for(uint64_t i = 0; i < n; i++) out[i] = kmerDownsamplingHash(kmerIds[i], k);
+    return 0;
+}
+
 void oracle_align4_free(shasta_align4_result* r)
 {
     std::free(r->alignmentData); std::free(r->compressedToc); std::free(r->compressedData);

@@ -8,6 +8,7 @@
 //   ReadLoader -> (restated randomlySelectKmers) -> MarkerFinder      [fixture generation]
 //   LowHash0::LowHash0                                                [seam 1 oracle]
 //   Align4::align + AlignmentInfo + shasta::compress                  [seam 2 oracle]
+//   Assembler::alignOrientedReads3 (ref_align3.cpp / ref_facade.hpp)  [align method 3 oracle]
 //
 // Non-reference code in this file: the k-mer table fill (restating
 // src/AssemblerKmers.cpp:33-100,147-180) and the per-candidate driver loop
@@ -54,6 +55,7 @@
 #include "OrientedReadPair.hpp"
 #include "orderPairs.hpp"
 #include "ReadLoader.hpp"
+#include "ref_facade.hpp"
 using namespace shasta;
 
 #include <chrono>
@@ -572,6 +574,161 @@ int ref_align4_batch(
     const shasta_align4_options* o, int wantOrdinals, shasta_align4_result* result)
 {
     return ref_align4_batch_mt(readCount, markersToc, markersData, candidateCount, candidates, o, wantOrdinals, 1, result);
+}
+
+// --------------------------------------------------------------------------
+// Align method 3: the same per-candidate loop around the reference's own
+// Assembler::alignOrientedReads3 (src/AssemblerAlign3.cpp, compiled in place by ref_align3.cpp).
+// Non-reference code: the k-mer table fill (reverse complement and hash fields, restating
+// src/AssemblerKmers.cpp:147-186) and the loop (src/AssemblerAlign.cpp:378-483).
+// --------------------------------------------------------------------------
+static void fillKmerTableForDownsampling(MemoryMapped::Vector<KmerInfo>& kmerTable, uint64_t k)
+{
+    kmerTable.createNew("", 4096);
+    const uint64_t kmerCount = 1ULL << (2ULL * k);
+    kmerTable.resize(kmerCount);
+    for(uint64_t kmerId = 0; kmerId < kmerCount; kmerId++) {
+        const Kmer kmer(kmerId, k);
+        KmerInfo& info = kmerTable[kmerId];
+        info.frequency = 0;
+        info.reverseComplementedKmerId = KmerId(kmer.reverseComplement(k).id(k));
+        info.isMarker = false;
+        info.isRleKmer = false;
+    }
+    for(uint64_t kmerId = 0; kmerId < kmerCount; kmerId++) {
+        const uint64_t n = kmerId + kmerTable[kmerId].reverseComplementedKmerId;    // :184
+        kmerTable[kmerId].hash = MurmurHash2(&n, sizeof(n), 13477);                 // :185
+    }
+}
+
+// KmerInfo::hash of every k-mer id (4^k values), for checking the restated hash.
+int ref_kmer_hashes(uint64_t k, uint32_t* out)
+{
+    try {
+        MemoryMapped::Vector<KmerInfo> kmerTable;
+        fillKmerTableForDownsampling(kmerTable, k);
+        for(uint64_t i = 0; i < kmerTable.size(); i++) out[i] = kmerTable[i].hash;
+        kmerTable.remove();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+int ref_align3_batch_mt(
+    uint64_t readCount,
+    const uint64_t* markersToc,
+    const void* markersData,
+    uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options* o,
+    int wantOrdinals,
+    uint64_t threadCount,
+    shasta_align4_result* result)
+{
+    try {
+        std::memset(result, 0, sizeof(*result));
+        const auto t0 = std::chrono::steady_clock::now();
+        CoutCapture capture;
+        if(threadCount == 0) threadCount = std::thread::hardware_concurrency();
+
+        Assembler assembler;
+        fillMarkers(assembler.markers, readCount, markersToc, markersData);
+        fillKmerTableForDownsampling(assembler.kmerTable, o->k);
+
+        struct PerCandidate { uint8_t status = SHASTA_ALIGN_EMPTY; AlignmentInfo info; Alignment alignment; };
+        std::vector<PerCandidate> per(candidateCount);
+        std::atomic<uint64_t> next(0);
+        std::string firstError;
+        std::mutex errorMutex;
+
+        auto worker = [&]() {
+            try {
+                for(;;) {
+                    const uint64_t begin = next.fetch_add(10);
+                    if(begin >= candidateCount) break;
+                    const uint64_t end = std::min(candidateCount, begin + 10);
+                    for(uint64_t i = begin; i < end; i++) {
+                        const shasta_oriented_read_pair& c = candidates[i];
+                        SHASTA_ASSERT(c.readIds[0] < c.readIds[1]);
+                        SHASTA_ASSERT(c.readIds[1] < readCount);
+                        const OrientedReadId or0(c.readIds[0], 0);
+                        const OrientedReadId or1(c.readIds[1], c.isSameStrand ? 0 : 1);
+                        PerCandidate& pc = per[i];
+                        try {
+                            assembler.alignOrientedReads3(or0, or1,
+                                int(o->matchScore), int(o->mismatchScore), int(o->gapScore),
+                                o->downsamplingFactor, int(o->bandExtend), int(o->maxBand),
+                                pc.alignment, pc.info);
+                        } catch(...) {
+                            pc.status = SHASTA_ALIGN_SKIPPED;    // :419-435: skip this candidate
+                            pc.alignment.clear();
+                            continue;
+                        }
+                        const Alignment& alignment = pc.alignment;
+                        const AlignmentInfo& alignmentInfo = pc.info;
+                        pc.status = alignment.ordinals.empty() ? SHASTA_ALIGN_EMPTY : SHASTA_ALIGN_REJECTED;
+                        // Filters, src/AssemblerAlign.cpp:439-472.
+                        if(alignment.ordinals.size() < o->minAlignedMarkerCount) continue;
+                        if(min(alignmentInfo.alignedFraction(0), alignmentInfo.alignedFraction(1)) < o->minAlignedFraction) continue;
+                        uint32_t leftTrim, rightTrim;
+                        tie(leftTrim, rightTrim) = alignmentInfo.computeTrim();
+                        if(leftTrim > o->maxTrim || rightTrim > o->maxTrim) continue;
+                        if(alignment.maxSkip() > o->maxSkip) continue;
+                        if(alignment.maxDrift() > o->maxDrift) continue;
+                        if(o->suppressContainments && alignmentInfo.isContaining(uint32_t(o->maxTrim))) continue;
+                        pc.status = SHASTA_ALIGN_STORED;
+                    }
+                }
+            } catch(std::exception& e) {
+                std::lock_guard<std::mutex> lock(errorMutex);
+                if(firstError.empty()) firstError = e.what();
+            }
+        };
+        std::vector<std::thread> threads;
+        for(uint64_t t = 1; t < threadCount; t++) threads.emplace_back(worker);
+        worker();
+        for(auto& t : threads) t.join();
+        assembler.markers.remove();
+        assembler.kmerTable.remove();
+        if(!firstError.empty()) throw std::runtime_error(firstError);
+
+        std::vector<shasta_alignment_data> alignmentData;
+        std::vector<uint64_t> compressedToc(1, 0);
+        std::vector<uint8_t> compressedData;
+        std::vector<uint8_t> status(candidateCount, SHASTA_ALIGN_EMPTY);
+        std::vector<uint64_t> ordinalsToc(1, 0);
+        std::vector<uint32_t> ordinals;
+        string compressedAlignment;
+        for(uint64_t i = 0; i < candidateCount; i++) {
+            const PerCandidate& pc = per[i];
+            status[i] = pc.status;
+            if(wantOrdinals) {
+                for(const auto& p : pc.alignment.ordinals) { ordinals.push_back(p[0]); ordinals.push_back(p[1]); }
+                ordinalsToc.push_back(ordinals.size() / 2);
+            }
+            if(pc.status != SHASTA_ALIGN_STORED) continue;
+            shasta_alignment_data ad;
+            std::memset(&ad, 0, sizeof(ad));
+            ad.pair = candidates[i];
+            ad.pair.isSameStrand = ad.pair.isSameStrand ? 1 : 0;
+            ad.pair.pad[0] = ad.pair.pad[1] = ad.pair.pad[2] = 0;
+            copyInfo(pc.info, ad.info);
+            alignmentData.push_back(ad);
+            shasta::compress(pc.alignment, compressedAlignment);
+            compressedData.insert(compressedData.end(), compressedAlignment.begin(), compressedAlignment.end());
+            compressedToc.push_back(compressedData.size());
+        }
+        result->alignmentCount = alignmentData.size();
+        result->alignmentData = mallocCopy(alignmentData);
+        result->compressedToc = mallocCopy(compressedToc);
+        result->compressedData = mallocCopy(compressedData);
+        result->status = mallocCopy(status);
+        if(wantOrdinals) {
+            result->ordinalsToc = mallocCopy(ordinalsToc);
+            result->ordinals = mallocCopy(ordinals);
+        }
+        result->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
 }
 
 void ref_align4_free(shasta_align4_result* r)

@@ -1,8 +1,8 @@
 // TEST INFRASTRUCTURE ONLY.
 // Minimal stand-in for <seqan/align.h> (SeqAn 2.4.0 is not installed in this
 // container) so that /root/reference/src/Align4.cpp can be compiled IN PLACE,
-// unmodified, into oracle/_ref/.  It provides exactly the names used at
-// src/Align4.cpp:1001-1043.  The dynamic programming itself is delegated to
+// unmodified, into oracle/_ref/ (and src/AssemblerAlign3.cpp, see ../ref_align3.cpp).  It
+// provides exactly the names used at src/Align4.cpp:1001-1043 and src/AssemblerAlign3.cpp:42-260.  The dynamic programming itself is delegated to
 // oracle/banded_dp.hpp (restated algorithm; tie policy UNPINNED, see there).
 // Every other line of Align4 executed by oracle/_ref is the reference's own.
 #ifndef SHIM_SEQAN_ALIGN_H
@@ -64,6 +64,18 @@ inline int globalAlignment(
         score.match, score.mismatch, score.gap,
         lowerDiagonal, upperDiagonal, g.dp);
     return g.dp.ok ? g.dp.score : MinValue<int>::VALUE;
+}
+
+// Unbanded overload (step 1 of align method 3, src/AssemblerAlign3.cpp:118-122): the same
+// recurrence over the whole matrix, i.e. every diagonal -ny .. nx is inside the band.
+template<class T>
+inline int globalAlignment(
+    Graph< Alignment< StringSet< String<T>, Dependent<> > > >& g,
+    const Score<int, Simple>& score,
+    AlignConfig<true, true, true, true> config,
+    LinearGaps gaps)
+{
+    return globalAlignment(g, score, config, -int(g.seq1.size()), int(g.seq0.size()), gaps);
 }
 
 // Two gapped rows, concatenated; gap symbol is '-' == 45 (src/Align4.cpp:1007).

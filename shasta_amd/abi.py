@@ -83,6 +83,25 @@ class Align4Options(C.Structure):
     ]
 
 
+class Align3Options(C.Structure):
+    _fields_ = [
+        ("matchScore", C.c_int64),
+        ("mismatchScore", C.c_int64),
+        ("gapScore", C.c_int64),
+        ("downsamplingFactor", C.c_double),
+        ("bandExtend", C.c_int64),
+        ("maxBand", C.c_int64),
+        ("k", C.c_uint64),
+        ("minAlignedMarkerCount", C.c_uint64),
+        ("minAlignedFraction", C.c_double),
+        ("maxSkip", C.c_uint64),
+        ("maxDrift", C.c_uint64),
+        ("maxTrim", C.c_uint64),
+        ("suppressContainments", C.c_uint8),
+        ("pad", C.c_uint8 * 7),
+    ]
+
+
 class Align4Result(C.Structure):
     _fields_ = [
         ("alignmentCount", C.c_uint64),
@@ -122,6 +141,7 @@ assert C.sizeof(OrientedReadPair) == 12
 assert C.sizeof(AlignmentInfo) == 52
 assert C.sizeof(AlignmentData) == 64
 assert C.sizeof(Align4Options) == 112
+assert C.sizeof(Align3Options) == 104
 
 SHASTA_ALIGN_STORED = 0
 SHASTA_ALIGN_REJECTED = 1
@@ -159,6 +179,16 @@ def default_align4_options(**kw):
                       minAlignedMarkerCount=100, minAlignedFraction=0.0, maxSkip=30, maxDrift=30,
                       maxTrim=30, maxBand=1000, matchScore=6, mismatchScore=-1, gapScore=-1,
                       suppressContainments=0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def default_align3_options(**kw):
+    """Align.* defaults of src/AssemblerOptions.cpp:380-449 for alignMethod 3 (k: Kmers.k default 10)."""
+    o = Align3Options(matchScore=6, mismatchScore=-1, gapScore=-1, downsamplingFactor=0.1, bandExtend=10,
+                      maxBand=1000, k=10, minAlignedMarkerCount=100, minAlignedFraction=0.0, maxSkip=30,
+                      maxDrift=30, maxTrim=30, suppressContainments=0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -19,6 +19,14 @@ ALIGN_OPTION_SETS = [
          suppressContainments=1),
 ]
 
+# Must match tests/golden/make_golden_align3.py (align method 3; k = 10 in both marker sets).
+ALIGN3_OPTION_SETS = [
+    dict(),                                                           # src/AssemblerOptions.cpp defaults
+    dict(downsamplingFactor=0.05, minAlignedMarkerCount=10, minAlignedFraction=0.1, maxSkip=100, maxDrift=100,
+         maxTrim=100, suppressContainments=1),                        # the shipped Nanopore confs
+    dict(downsamplingFactor=0.3, bandExtend=3, maxBand=40, minAlignedMarkerCount=30),   # "band too wide" lane
+]
+
 
 class Golden:
     def __init__(self, name):
@@ -58,6 +66,16 @@ def check_align(out, z, i):
     assert np.array_equal(out.info_table(), z["al%d_info" % i])
     assert np.array_equal(out.compressed_toc, z["al%d_compressed_toc" % i])
     assert np.array_equal(out.compressed_data, z["al%d_compressed_data" % i])
+
+
+def check_align3(out, z, i):
+    import hashlib
+    assert np.array_equal(out.status, z["m3_%d_status" % i])
+    assert np.array_equal(np.diff(out.ordinals_toc.astype(np.int64)), z["m3_%d_marker_count" % i])
+    assert hashlib.md5(out.ordinals.tobytes()).hexdigest().encode() == z["m3_%d_ordinals_md5" % i].tobytes()
+    assert np.array_equal(out.info_table(), z["m3_%d_info" % i])
+    assert np.array_equal(out.compressed_toc, z["m3_%d_compressed_toc" % i])
+    assert np.array_equal(out.compressed_data, z["m3_%d_compressed_data" % i])
 
 
 def same_lowhash(a, b):

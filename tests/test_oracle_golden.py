@@ -37,6 +37,17 @@ def test_align4_restatement_matches_reference_fixture(oracle_lib, name, i):
     support.check_align(out, g.z, i)
 
 
+@pytest.mark.parametrize("name", ["tiny", "synth"])
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_align3_restatement_matches_reference_fixture(oracle_lib, name, i):
+    # Fixture = the reference's own Assembler::alignOrientedReads3 (tests/golden/make_golden_align3.py).
+    g = support.Golden(name + ".npz")
+    z = np.load(support.GOLDEN + "/" + name + "_align3.npz")
+    o = abi.default_align3_options(**support.ALIGN3_OPTION_SETS[i])
+    out = oracle_lib.align3_batch(g.toc, g.data7, g.candidates(0), o, want_ordinals=True, threads=0)
+    support.check_align3(out, z, i)
+
+
 def test_codec_known_answer(oracle_lib):
     # The table of the reference's testAlignmentCompression (src/compressAlignment.cpp:160-220):
     # streak formats 2,1,2,0,2,3,4,3 => 4+2+4+1+4+8+16+8 bytes.

@@ -62,3 +62,29 @@ def test_lowhash0_and_align4_on_marker_level_reads(ref_lib, oracle_lib, seed):
     if keep.all():
         y.status &= 0x7f
         support.same_align(x, y)
+
+
+def test_kmer_downsampling_hash(ref_lib, oracle_lib):
+    # KmerInfo::hash through the reference's Kmer class and MurmurHash2 vs the restatement.
+    for k in (4, 7, 10):
+        ids = np.arange(1 << (2 * k), dtype=np.uint32)
+        assert np.array_equal(ref_lib.kmer_hashes(k), oracle_lib.kmer_hashes(ids, k))
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (21, dict()),
+    (22, dict(downsamplingFactor=0.05, minAlignedMarkerCount=40)),
+    (23, dict(downsamplingFactor=0.25, bandExtend=2, maxBand=30, minAlignedMarkerCount=20, suppressContainments=1)),
+    (24, dict(downsamplingFactor=0.0005, minAlignedMarkerCount=40)),     # mostly empty down-sampled reads
+])
+def test_align3_on_marker_level_reads(ref_lib, oracle_lib, seed, kw):
+    toc, kmer, data7 = support.small_marker_set(n_reads=250, genome_markers=15000, seed=seed)
+    p = abi.default_lowhash0_params(minBucketSize=3, maxBucketSize=30, minFrequency=2)
+    cand = ref_lib.lowhash0(toc, data7, None, p, threads=2).candidates[:600]
+    assert len(cand) > 100
+    o = abi.default_align3_options(**kw)
+    x = ref_lib.align3_batch(toc, data7, cand, o, threads=4)
+    y = oracle_lib.align3_batch(toc, data7, cand, o, threads=0)
+    support.same_align(x, y)
+    assert np.array_equal(x.compressed_data, y.compressed_data)
+
