@@ -301,6 +301,31 @@ int shasta_mi355x_align4_run_borrowed(
     const shasta_align4_options* options, int wantOrdinals,
     shasta_align4_result* result);
 
+/* Align method 3 (Assembler::alignOrientedReads3, src/AssemblerAlign3.cpp:22-314, called from
+ * computeAlignmentsThreadFunction, src/AssemblerAlign.cpp:404-409) for every candidate, then the
+ * same filters and outputs as the method-4 seam; results are released with
+ * shasta_mi355x_align4_free.  Status EMPTY = empty alignment (a read without down-sampled markers,
+ * nothing aligned in step 1, or a band wider than maxBand); SKIPPED = a pair whose down-sampled
+ * matrix has more than 8192 diagonals (down-sampled markers of the two reads + 1: reads of some
+ * 500 kb at the default factor), which this version does not align.  Limits: scores 6/-1/-1 (every
+ * shipped configuration), maxBand <= 1023, k <= 16.  `borrowed` != 0: result arrays belong to the
+ * context, as align4_run_borrowed. */
+int shasta_mi355x_align3_run(
+    shasta_mi355x_ctx*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options* options, int wantOrdinals, int borrowed,
+    shasta_align4_result* result);
+/* One-shot form on host markers (what the C++ adapter calls for alignMethod 3). */
+int shasta_mi355x_align3_batch(
+    uint64_t readCount,
+    const uint64_t* markersToc,
+    const void* markersData,
+    uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options* options,
+    int wantOrdinals,
+    shasta_align4_result* result);
+
 /* Timing of the dominant kernels of the last *_run call on this context,
  * measured with HIP events on the context's stream. */
 typedef struct shasta_mi355x_kernel_times {

@@ -1,0 +1,234 @@
+// Align method 3 (Shasta's default alignment method) on MI355X: the device pieces that are its own.
+// Included by align4.hip inside its anonymous namespace, after the banded DP kernels it reuses.
+//
+// Assembler::alignOrientedReads3 (/root/reference/src/AssemblerAlign3.cpp:22-314) aligns a pair in
+// two steps:
+//   step 1  markers whose k-mer hash is under a threshold (down-sampling, :66-82) are aligned
+//           without a band (:118-130); the aligned columns with equal k-mer ids give a range of
+//           ordinal offsets (:198-223);
+//   step 2  all markers are aligned inside that range +- bandExtend (:224-260), unless it is
+//           wider than maxBand (:236-241).
+// Both steps are the overlap DP of K10 (bandedDpForwardKernel; step 1 runs it with every
+// diagonal of the small down-sampled matrix inside the band).  What is new here:
+//   downsampleKernel   the kept markers of every oriented read, once per context: their kmer ids
+//                      and ordinals, CSR by oriented read (a wavefront per read, ballot compaction);
+//   align3BandKernel   the traceback of step 1: one lane per pair walks the packed trace, maps the
+//                      matched columns back to ordinals, and appends the step-2 DP task;
+//   align3WideDpKernel step 1 of the pairs whose down-sampled matrix has more than the 1024
+//                      diagonals a register-resident DP task holds (long reads): one wavefront per
+//                      pair, the three live anti-diagonals in LDS, 64 diagonals at a time.
+// Integer work, HBM-bound only in downsampleKernel (4 bytes read per marker, 8 written per kept one).
+
+// KmerInfo::hash (src/AssemblerKmers.cpp:182-186): MurmurHash2 (32-bit, seed 13477,
+// src/MurmurHash2.cpp:37-85) of the 8 bytes of kmerId + reverseComplement(kmerId).  A k-mer id is
+// two k-bit planes, (high bits of the bases) << k | (low bits), first base at the plane's most
+// significant bit (src/ShortBaseSequence.hpp:89-105); the reverse complement flips every bit and
+// reverses each plane (:109-117).
+__device__ __forceinline__ uint32_t kmerDownsamplingHash(uint32_t kmerId, uint32_t k)
+{
+    const uint32_t mask = uint32_t((1ULL << k) - 1ULL);
+    const uint32_t lo = ~kmerId & mask, hi = ~(kmerId >> k) & mask;
+    const uint32_t rlo = __brev(lo) >> (32u - k), rhi = __brev(hi) >> (32u - k);
+    const uint64_t n = uint64_t(kmerId) + ((uint64_t(rhi) << k) | uint64_t(rlo));
+    const uint32_t m = 0x5bd1e995u;
+    uint32_t h = 13477u ^ 8u;
+    uint32_t w = uint32_t(n);
+    w *= m; w ^= w >> 24; w *= m;
+    h *= m; h ^= w;
+    w = uint32_t(n >> 32);
+    w *= m; w ^= w >> 24; w *= m;
+    h *= m; h ^= w;
+    h ^= h >> 13; h *= m; h ^= h >> 15;
+    return h;
+}
+
+// One wavefront per oriented read.  WRITE = false counts the kept markers (counts[2R] = 0 closes
+// the array for the scan); WRITE = true writes them at dsToc[read], in ordinal order.
+template<bool WRITE>
+__global__ void __launch_bounds__(256)
+downsampleKernel(const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc, uint64_t orientedReadCount,
+    uint32_t k, uint32_t hashThreshold, uint64_t* __restrict__ counts,
+    const uint64_t* __restrict__ dsToc, uint32_t* __restrict__ dsKmerIds, uint32_t* __restrict__ dsOrdinals)
+{
+    const uint64_t r = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int lane = laneId();
+    if(r > orientedReadCount) return;
+    if(r == orientedReadCount) {
+        if(!WRITE && lane == 0) counts[r] = 0;
+        return;
+    }
+    const uint64_t begin = toc[r], n = toc[r + 1] - begin;
+    const uint64_t outBase = WRITE ? dsToc[r] : 0;
+    uint64_t kept = 0;                                   // wave-uniform
+    for(uint64_t base = 0; base < n; base += WAVE) {
+        const uint64_t i = base + uint64_t(lane);
+        uint32_t id = 0;
+        bool keep = false;
+        if(i < n) {
+            id = kmerIds[begin + i];
+            keep = kmerDownsamplingHash(id, k) < hashThreshold;
+        }
+        const uint64_t votes = __ballot(keep);
+        if(WRITE && keep) {
+            const uint64_t pos = outBase + kept + uint64_t(__popcll(votes & laneMaskLt()));
+            dsKmerIds[pos] = id;
+            dsOrdinals[pos] = uint32_t(i);
+        }
+        kept += uint64_t(__popcll(votes));
+    }
+    if(!WRITE && lane == 0) counts[r] = kept;
+}
+
+// Step 1 of a pair with more than 1024 diagonals: the same recurrence, tie policy and end-cell
+// rule as bandedDpForwardKernel over every diagonal d = i - j = b - ny, b in [0, nx + ny], of the
+// down-sampled matrix.  One wavefront per task sweeps the anti-diagonals s = i + j; the values of
+// anti-diagonals s, s-1, s-2 live in three LDS rows of W = nx + ny + 1 words (cells that do not
+// exist hold NEG_SCORE), a lane owns diagonal 64 q + lane of chunk q.  Trace: two bit planes per
+// (s, q), at words 2 (s Q + q) and 2 (s Q + q) + 1 of the task's trace, Q = ceil(W / 64); codes as
+// in bandedDpForwardKernel.  Sized for the few long pairs of a batch, not tuned further.
+struct WideTask { uint32_t pair, chunks; uint64_t traceOffset; };
+struct WideEnd { int32_t bestI, bestJ, score, pad; };
+constexpr uint32_t ALIGN3_WIDE_MAX_DIAGONALS = 8192;      // 3 rows of 32 KB
+
+__global__ void __launch_bounds__(64)
+align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ dsPairs,
+    const WideTask* __restrict__ tasks, uint32_t taskCount, uint32_t rowWords,
+    uint64_t* __restrict__ trace, WideEnd* __restrict__ ends)
+{
+    extern __shared__ int32_t wideRows[];                  // 3 x rowWords
+    const uint32_t t = blockIdx.x;
+    if(t >= taskCount) return;
+    const int lane = laneId();
+    const WideTask task = tasks[t];
+    const PairDesc pd = dsPairs[task.pair];
+    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+    const int32_t W = nx + ny + 1;
+    const uint32_t Q = task.chunks;
+    uint64_t* __restrict__ tr = trace + task.traceOffset;
+    for(uint32_t k = uint32_t(lane); k < 3u * rowWords; k += WAVE) wideRows[k] = NEG_SCORE;
+    __syncthreads();
+    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+    for(int32_t s = 0; s <= nx + ny; s++) {
+        int32_t* const cur = wideRows + uint32_t(s % 3) * rowWords;
+        const int32_t* const prev1 = wideRows + uint32_t((s + 2) % 3) * rowWords;     // s - 1
+        const int32_t* const prev2 = wideRows + uint32_t((s + 1) % 3) * rowWords;     // s - 2
+        for(uint32_t q = 0; q < Q; q++) {
+            const int32_t b = int32_t(q * 64u) + lane, d = b - ny;
+            // Cell (i, j) of this anti-diagonal on diagonal d, if it exists.
+            const int32_t i2 = s + d, j2 = s - d;
+            const bool exists = b < W && i2 >= 0 && j2 >= 0 && ((i2 & 1) == 0) && (i2 >> 1) <= nx && (j2 >> 1) <= ny;
+            const int32_t i = i2 >> 1, j = j2 >> 1;
+            int32_t v = NEG_SCORE;
+            bool isV = false, isH = false, eq = false;
+            if(exists) {
+                if(i == 0 || j == 0) v = 0;                                            // free leading gaps
+                else {
+                    eq = p0[i - 1] == p1[j - 1];
+                    const int32_t dg = prev2[b] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+                    const int32_t vg = (b + 1 < W ? prev1[b + 1] : NEG_SCORE) + GAP_SCORE;     // from (i, j-1)
+                    const int32_t hg = (b >= 1 ? prev1[b - 1] : NEG_SCORE) + GAP_SCORE;        // from (i-1, j)
+                    isV = vg > dg;
+                    const int32_t m1 = max(dg, vg);
+                    isH = hg > m1;
+                    v = max(m1, hg);
+                }
+                // Free trailing gaps: the best cell of the last row and column, ties to the smallest (i, j).
+                if((i == nx || j == ny) && (v > bestScore || (v == bestScore && (i < bestI || (i == bestI && j < bestJ))))) {
+                    bestScore = v; bestI = i; bestJ = j;
+                }
+            }
+            if(b < int32_t(rowWords)) cur[b] = v;
+            const uint64_t loPlane = __ballot(exists && (isH || (!isV && !eq)));
+            const uint64_t hiPlane = __ballot(exists && (isV || isH));
+            if(lane == 0) { tr[2ULL * (uint64_t(s) * Q + q)] = loPlane; tr[2ULL * (uint64_t(s) * Q + q) + 1] = hiPlane; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for(int dlt = 32; dlt >= 1; dlt >>= 1) {
+        const int32_t os = __shfl_xor(bestScore, dlt, WAVE);
+        const int32_t oi = __shfl_xor(bestI, dlt, WAVE);
+        const int32_t oj = __shfl_xor(bestJ, dlt, WAVE);
+        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+    }
+    if(lane == 0) { WideEnd e; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.pad = 0; ends[t] = e; }
+}
+
+// Traceback of step 1, one lane per task (= per candidate that has a step-1 DP).  The trace is the
+// one bandedDpForwardKernel (WIDE = false) or align3WideDpKernel (WIDE = true) wrote for the
+// down-sampled pair; code 0 is a diagonal step over equal k-mer ids, the only columns that count
+// (:207-216).  A pair with such columns and a band no wider than maxBand gets its step-2 task
+// appended to tasks2 (order is irrelevant: one task per pair).  The band is clipped to the
+// diagonals of the matrix, -ny .. nx (the reference leaves that to SeqAn, :226-227).
+template<bool WIDE>
+__global__ void __launch_bounds__(256)
+align3BandKernel(
+    const PairDesc* __restrict__ dsPairs, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks1,
+    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
+    const DpEnd* __restrict__ ends, const WideTask* __restrict__ wideTasks, const WideEnd* __restrict__ wideEnds,
+    const uint64_t* __restrict__ trace, const uint32_t* __restrict__ dsOrdinals,
+    int32_t bandExtend, int32_t maxBand, DpTask* __restrict__ tasks2, uint32_t* __restrict__ taskCount2)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if(idx >= taskCount) return;
+    uint32_t pair;
+    int32_t i, j, score, bandMin1 = 0, s0 = 0;
+    uint32_t C = 1, laneBase = 0, Q = 0;
+    const uint64_t* __restrict__ tr;
+    if(WIDE) {
+        const WideTask task = wideTasks[idx];
+        const WideEnd e = wideEnds[idx];
+        pair = task.pair; i = e.bestI; j = e.bestJ; score = e.score; Q = task.chunks;
+        tr = trace + task.traceOffset;
+    } else {
+        const uint32_t t = sortedIds[idx];
+        const DpTask task = tasks1[t];
+        const DpEnd e = ends[t];
+        pair = task.pair; i = e.bestI; j = e.bestJ; score = e.score; bandMin1 = task.bandMin; laneBase = e.laneBase;
+        const PairDesc dsGeo = dsPairs[pair];
+        const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, dsGeo.nx, dsGeo.ny);
+        C = uint32_t(dpDiagonals(geo.cls)); s0 = geo.s0;
+        tr = trace + e.traceOffset;
+    }
+    if(score <= NEG_SCORE) return;
+    const PairDesc ds = dsPairs[pair];
+    const uint32_t RW = 2u * C;
+    const uint32_t* __restrict__ ord0 = dsOrdinals + ds.begin0;
+    const uint32_t* __restrict__ ord1 = dsOrdinals + ds.begin1;
+    int32_t offsetMin = 0x7fffffff, offsetMax = int32_t(0x80000000);
+    while(i > 0 && j > 0) {
+        uint64_t lo, hi;
+        uint32_t bit;
+        if(WIDE) {
+            const uint32_t b = uint32_t(i - j + int32_t(ds.ny));
+            const uint64_t w = 2ULL * (uint64_t(uint32_t(i + j)) * Q + (b >> 6));
+            lo = tr[w]; hi = tr[w + 1]; bit = b & 63u;
+        } else {
+            const uint32_t b = uint32_t(i - j - bandMin1);
+            const uint64_t it = uint64_t(uint32_t(i + j - s0) >> 1);
+            const uint32_t c = b % C;
+            lo = tr[it * RW + 2u * c]; hi = tr[it * RW + 2u * c + 1u]; bit = laneBase + b / C;
+        }
+        const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
+        if(dir == 0u) {
+            const int32_t offset = int32_t(ord0[i - 1]) - int32_t(ord1[j - 1]);
+            offsetMin = min(offsetMin, offset);
+            offsetMax = max(offsetMax, offset);
+            --i; --j;
+        } else if(dir == 1u) { --i; --j; }
+        else if(dir == 2u) { --j; }
+        else { --i; }
+    }
+    if(offsetMin > offsetMax) return;                    // no aligned column: empty alignment (:185-192)
+    const int32_t bandMin = offsetMin - bandExtend, bandMax = offsetMax + bandExtend;   // :224-225
+    if(bandMax - bandMin > maxBand) return;              // :236-241
+    const PairDesc pd = pairs[pair];
+    DpTask out;
+    out.pair = pair;
+    out.bandMin = max(bandMin, -int32_t(pd.ny));
+    out.bandMax = min(bandMax, int32_t(pd.nx));
+    out.label = 0;
+    tasks2[atomicAdd(taskCount2, 1u)] = out;
+}

@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -1350,6 +1351,8 @@ compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __
     if(laneId() < 16) reinterpret_cast<uint32_t*>(rowsOut + k)[laneId()] = reinterpret_cast<const uint32_t*>(rows + p)[laneId()];
 }
 
+#include "align3.hpp"
+
 template<class T> T readDevice(const T* p, hipStream_t s)
 {
     T v;
@@ -1402,6 +1405,10 @@ struct BatchScratch {
     DeviceBuffer<DpEnd> ends;
     PinnedBuffer pinRows, pinToc, pinBytes, pinStatus, pinOrdToc, pinOrdinals;   // device-to-host staging
     DeviceBuffer<uint64_t> bigOffsets;
+    DeviceBuffer<PairDesc> dsPairs;             // align method 3, step 1: the down-sampled pairs
+    DeviceBuffer<DpTask> tasks1;                //                         and their (unbanded) DP tasks
+    DeviceBuffer<WideTask> wideTasks;           //                         pairs with more than 1024 diagonals
+    DeviceBuffer<WideEnd> wideEnds;
 };
 
 // A host worker's stream and sort workspace (two workers pipeline the batches of one call).
@@ -1444,14 +1451,17 @@ void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int 
     else launchCellsChunksQ<4>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
 }
 
+// What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
+struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; };
+
 template<int G, int C>
-void launchDpForward(Context& ctx, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
+void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
 {
     const uint32_t taskCount = layout.taskStart[cls + 1] - layout.taskStart[cls];
     const uint32_t bundleCount = layout.bundleStart[cls + 1] - layout.bundleStart[cls];
     if(taskCount == 0) return;
     hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
-        (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(),
+        in.kmerIds, in.pairs, in.tasks,
         sortedIds + layout.taskStart[cls], taskCount,
         (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
         b.trace.data(), b.ends.data());
@@ -1469,10 +1479,18 @@ struct DpEvents {
 };
 struct DpBatchStats { uint64_t cells[DP_CLASSES] = {0}, bytes[DP_CLASSES] = {0}; uint32_t tasks[DP_CLASSES] = {0}; };
 
-uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
-    DpEvents* ev, DpBatchStats* stats)
+// Forward half of K10 for taskCount tasks: sort by (band class, iterations), bundle, lay out the
+// trace, run the forward kernel of every class.  Leaves b.trace / b.ends for a traceback kernel.
+struct DpForwardState {
+    const uint32_t* sortedIds;
+    uint32_t classCounts[DP_CLASSES];
+    unsigned long long sums[16];          // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
+};
+
+DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev)
 {
     hipStream_t stream = ws.stream;
+    DpForwardState f;
     b.dpKeysA.reserve(taskCount, stream); b.dpKeysB.reserve(taskCount, stream);
     b.dpIdsA.reserve(taskCount, stream); b.dpIdsB.reserve(taskCount, stream);
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
@@ -1482,18 +1500,19 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
     HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, 16 * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(dpSizeKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
-        (const DpTask*)b.tasks.data(), (const PairDesc*)b.pairs.data(), taskCount,
+        in.tasks, in.pairs, taskCount,
         b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
     exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
     const bool inB = radixSort<uint32_t, uint32_t, true>(b.dpKeysA.data(), b.dpKeysB.data(), b.dpIdsA.data(), b.dpIdsB.data(),
         taskCount, 27, *ws.sortWs, stream);
     const uint32_t* sortedKeys = inB ? b.dpKeysB.data() : b.dpKeysA.data();
     const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
+    f.sortedIds = sortedIds;
     HIP_CHECK(hipGetLastError());
-    uint32_t classCounts[DP_CLASSES];
-    unsigned long long sums[16];
-    HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, sizeof(classCounts), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(sums, b.dpCells.data(), sizeof(sums), hipMemcpyDeviceToHost, stream));
+    uint32_t* classCounts = f.classCounts;
+    unsigned long long* sums = f.sums;
+    HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, sizeof(f.classCounts), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(sums, b.dpCells.data(), sizeof(f.sums), hipMemcpyDeviceToHost, stream));
     const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
     DpClassLayout layout;
     layout.taskStart[0] = 0; layout.bundleStart[0] = 0;
@@ -1511,7 +1530,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     exclusiveScan<uint64_t>(b.bundleWords.data(), b.bundleWords.data(), uint64_t(bundleTotal) + 1, b.scanTemp64.data(), stream);
     // sums[1] bounds the trace (a bundle needs no more than the sum over its tasks): no read-back.
     b.trace.reserve(sums[1] + 64, stream);
-    b.ordScratch.reserve(2 * ordTotal + 2, stream);
+    if(reserveOrdinals) b.ordScratch.reserve(2 * ordTotal + 2, stream);
 
     // Wide bands (classes 3-5: few tasks, one wavefront each) go to the side stream, widest first;
     // the narrow classes run on the main stream meanwhile.
@@ -1523,24 +1542,33 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
         launch(st);
         if(ev) HIP_CHECK(hipEventRecord(ev->stop[cls], st));
     };
-    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(ctx, st, b, sortedIds, layout, 5); });
-    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(ctx, st, b, sortedIds, layout, 4); });
-    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(ctx, st, b, sortedIds, layout, 3); });
+    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 5); });
+    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4); });
+    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3); });
     if(fork) HIP_CHECK(hipEventRecord(ev->join, ws.wide));
-    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(ctx, st, b, sortedIds, layout, 1); });
-    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(ctx, st, b, sortedIds, layout, 2); });
-    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(ctx, st, b, sortedIds, layout, 0); });
+    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(in, st, b, sortedIds, layout, 1); });
+    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(in, st, b, sortedIds, layout, 2); });
+    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
+    return f;
+}
+
+uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
+    DpEvents* ev, DpBatchStats* stats)
+{
+    hipStream_t stream = ws.stream;
+    const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data()};
+    const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev);
     if(ev) HIP_CHECK(hipEventRecord(ev->start[DP_CLASSES], stream));
     // 256-byte trace chunks: 8 iterations of the narrow classes, one iteration of the widest class.
     hipLaunchKernelGGL(dpTracebackKernel<32>, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
-        (const PairDesc*)b.pairs.data(), (const DpTask*)b.tasks.data(), sortedIds, taskCount,
+        in.pairs, in.tasks, f.sortedIds, taskCount,
         (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
         (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
     HIP_CHECK(hipGetLastError());
     if(ev) HIP_CHECK(hipEventRecord(ev->stop[DP_CLASSES], stream));
-    if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = sums[2 + c]; stats->bytes[c] = sums[8 + c]; stats->tasks[c] = classCounts[c]; }
-    return sums[0];
+    if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[8 + c]; stats->tasks[c] = f.classCounts[c]; }
+    return f.sums[0];
 }
 
 struct BatchOutput {
@@ -1564,15 +1592,68 @@ struct AlignStore {
     std::vector<uint32_t> ordinals;
 };
 
-}  // namespace
+// Align method 3: what alignOrientedReads3 needs besides the outer filters.
+struct Align3Plan { uint32_t k, hashThreshold; int32_t bandExtend, maxBand; };
 
-void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
-    const shasta_align4_options& options, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
+// The markers method 3 keeps in step 1 (src/AssemblerAlign3.cpp:66-82), for every oriented read:
+// CSR of kmer ids and ordinals.  Built once per context and (k, threshold); dropped by setMarkers.
+struct Downsampled {
+    uint32_t k = 0, hashThreshold = 0;
+    DeviceBuffer<uint64_t> toc, scanTemp;         // 2R+1
+    DeviceBuffer<uint32_t> kmerIds, ordinals;
+    std::vector<uint64_t> hostToc;
+};
+
+const Downsampled& ensureDownsampled(Context& ctx, const Align3Plan& plan)
+{
+    Downsampled* d = static_cast<Downsampled*>(ctx.downsampled.get());
+    if(d && d->k == plan.k && d->hashThreshold == plan.hashThreshold) return *d;
+    ctx.downsampled = std::make_shared<Downsampled>();
+    d = static_cast<Downsampled*>(ctx.downsampled.get());
+    d->k = plan.k; d->hashThreshold = plan.hashThreshold;
+    hipStream_t stream = ctx.stream;
+    const uint64_t orientedReadCount = 2 * ctx.readCount;
+    d->toc.reserve(orientedReadCount + 1, stream);
+    d->scanTemp.reserve(scanTempElements(orientedReadCount + 1), stream);
+    const unsigned grid = divUp((orientedReadCount + 1) * WAVE, 256);
+    hipLaunchKernelGGL(downsampleKernel<false>, dim3(grid), dim3(256), 0, stream,
+        (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), orientedReadCount, plan.k, plan.hashThreshold,
+        d->toc.data(), (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    HIP_CHECK(hipGetLastError());
+    exclusiveScan<uint64_t>(d->toc.data(), d->toc.data(), orientedReadCount + 1, d->scanTemp.data(), stream);
+    d->hostToc.resize(orientedReadCount + 1);
+    HIP_CHECK(hipMemcpyAsync(d->hostToc.data(), d->toc.data(), (orientedReadCount + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const uint64_t total = d->hostToc[orientedReadCount];
+    d->kmerIds.reserve(total + 1, stream); d->ordinals.reserve(total + 1, stream);
+    hipLaunchKernelGGL(downsampleKernel<true>, dim3(grid), dim3(256), 0, stream,
+        (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), orientedReadCount, plan.k, plan.hashThreshold,
+        (uint64_t*)nullptr, (const uint64_t*)d->toc.data(), d->kmerIds.data(), d->ordinals.data());
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return *d;
+}
+
+// The widest step-1 matrix the register-resident DP classes hold (every diagonal of the down-sampled
+// pair, -ny .. nx); wider ones, up to ALIGN3_WIDE_MAX_DIAGONALS, run in align3WideDpKernel.
+constexpr uint32_t ALIGN3_MAX_STEP1_DIAGONALS = 1024;
+
+// Both alignment methods.  m3 == nullptr: method 4 (DP tasks from the cells kernels); otherwise
+// method 3 (DP tasks from the down-sampled step).  opt holds the outer filters either way.
+void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const DeviceOptions& opt, const Align3Plan* m3, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
 {
     std::memset(&result, 0, sizeof(result));
     const auto t0 = std::chrono::steady_clock::now();
     HIP_CHECK(hipSetDevice(ctx.device));
-    const DeviceOptions opt = makeOptions(options);
+    const Downsampled* ds = m3 ? &ensureDownsampled(ctx, *m3) : nullptr;
+    // Method 3 has no inner acceptance (src/Align4.cpp:944-981 belongs to method 4): its one DP per
+    // pair is kept whenever it aligned anything, and only the outer filters apply.
+    DeviceOptions dpOpt = opt;
+    if(m3) {
+        dpOpt.minAlignedMarkerCount = 0; dpOpt.minAlignedFraction = 0.;
+        dpOpt.maxSkip = dpOpt.maxDrift = dpOpt.maxTrim = ~0ULL;
+    }
     const uint64_t BATCH = 1ULL << 17;
     const uint64_t batchCount = (candidateCount + BATCH - 1) / BATCH;
 
@@ -1662,6 +1743,88 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
         HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
 
+        if(m3) {
+            // Method 3, step 1: every diagonal of the down-sampled pair, then the band of step 2.
+            std::vector<PairDesc> dsPairs(n);
+            std::vector<DpTask> tasks1;
+            std::vector<WideTask> wide;
+            std::vector<uint8_t> hostFlags(n, 0);
+            tasks1.reserve(n);
+            for(uint32_t k = 0; k < n; k++) {
+                const shasta_oriented_read_pair& c = candidates[batchBegin + k];
+                const uint64_t o0 = 2ULL * c.readIds[0], o1 = 2ULL * c.readIds[1] + (c.isSameStrand ? 0 : 1);
+                PairDesc pd;
+                pd.begin0 = ds->hostToc[o0]; pd.begin1 = ds->hostToc[o1];
+                pd.nx = uint32_t(ds->hostToc[o0 + 1] - pd.begin0); pd.ny = uint32_t(ds->hostToc[o1 + 1] - pd.begin1);
+                dsPairs[k] = pd;
+                if(pd.nx == 0 || pd.ny == 0) continue;                           // empty alignment, src/AssemblerAlign3.cpp:101-107
+                const uint64_t diagonals = uint64_t(pd.nx) + pd.ny + 1;
+                if(diagonals <= ALIGN3_MAX_STEP1_DIAGONALS) {
+                    DpTask t; t.pair = k; t.bandMin = -int32_t(pd.ny); t.bandMax = int32_t(pd.nx); t.label = 0;
+                    tasks1.push_back(t);
+                } else if(diagonals <= ALIGN3_WIDE_MAX_DIAGONALS) {
+                    WideTask t; t.pair = k; t.chunks = uint32_t((diagonals + 63) / 64); t.traceOffset = 0;
+                    wide.push_back(t);
+                } else {
+                    hostFlags[k] = PAIR_TOO_LONG;
+                }
+            }
+            const uint32_t taskCount1 = uint32_t(tasks1.size());
+            b.dsPairs.reserve(n, stream); b.tasks1.reserve(std::max<uint32_t>(1, taskCount1), stream);
+            HIP_CHECK(hipMemcpyAsync(b.dsPairs.data(), dsPairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
+            if(taskCount1) {
+                HIP_CHECK(hipMemcpyAsync(b.tasks1.data(), tasks1.data(), taskCount1 * sizeof(DpTask), hipMemcpyHostToDevice, stream));
+                const DpInput in{ds->kmerIds.data(), b.dsPairs.data(), b.tasks1.data()};
+                const DpForwardState f = runDpForward(ws, b, in, taskCount1, false, nullptr);
+                out.dpCells += f.sums[0];
+                hipLaunchKernelGGL(align3BandKernel<false>, dim3(divUp(taskCount1, 256)), dim3(256), 0, stream,
+                    in.pairs, (const PairDesc*)b.pairs.data(), in.tasks, f.sortedIds, taskCount1,
+                    (const DpEnd*)b.ends.data(), (const WideTask*)nullptr, (const WideEnd*)nullptr,
+                    (const uint64_t*)b.trace.data(), (const uint32_t*)ds->ordinals.data(),
+                    m3->bandExtend, m3->maxBand, b.tasks.data(), b.counters.data());
+                HIP_CHECK(hipGetLastError());
+            }
+            // The long pairs, a few gigabytes of trace at a time.
+            const uint64_t traceWordBudget = 1ULL << 29;
+            for(size_t begin = 0; begin < wide.size(); ) {
+                size_t end = begin;
+                uint64_t words = 0;
+                uint32_t rowWords = 0;
+                while(end < wide.size()) {
+                    const PairDesc& pd = dsPairs[wide[end].pair];
+                    const uint64_t need = 2ULL * (uint64_t(pd.nx) + pd.ny + 1) * wide[end].chunks;
+                    if(end > begin && words + need > traceWordBudget) break;
+                    wide[end].traceOffset = words;
+                    words += need;
+                    rowWords = std::max(rowWords, wide[end].chunks * 64u);
+                    out.dpCells += uint64_t(pd.nx) * (uint64_t(pd.nx) + pd.ny + 1);
+                    ++end;
+                }
+                const uint32_t count = uint32_t(end - begin);
+                b.wideTasks.reserve(count, stream); b.wideEnds.reserve(count, stream); b.trace.reserve(words + 64, stream);
+                HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), wide.data() + begin, count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
+                const size_t ldsBytes = 3 * size_t(rowWords) * sizeof(int32_t);
+                static std::once_flag attributeOnce;
+                std::call_once(attributeOnce, [] {
+                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
+                });
+                hipLaunchKernelGGL(align3WideDpKernel, dim3(count), dim3(64), ldsBytes, stream,
+                    (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
+                    b.trace.data(), b.wideEnds.data());
+                HIP_CHECK(hipGetLastError());
+                hipLaunchKernelGGL(align3BandKernel<true>, dim3(divUp(count, 256)), dim3(256), 0, stream,
+                    (const PairDesc*)b.dsPairs.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)nullptr, (const uint32_t*)nullptr, count,
+                    (const DpEnd*)nullptr, (const WideTask*)b.wideTasks.data(), (const WideEnd*)b.wideEnds.data(),
+                    (const uint64_t*)b.trace.data(), (const uint32_t*)ds->ordinals.data(),
+                    m3->bandExtend, m3->maxBand, b.tasks.data(), b.counters.data());
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(stream));
+                begin = end;
+            }
+            HIP_CHECK(hipStreamSynchronize(stream));      // the host vectors above are done with
+        } else
         // K8/K9.  Chunks of candidates sharing read 0 run in LDS (three table-size classes);
         // whatever overflows its tables climbs one class, and finally runs with tables in HBM
         // scratch (align4CellsKernel<true>, retried with 8x the slots on overflow).
@@ -1854,7 +2017,7 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
 
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount) {
-            out.dpCells += runDpTasks(ctx, ws, b, taskCount, opt, &w.ev, &out.dpStats);
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats);
             out.hadTasks = true;
             hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
                 (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
@@ -2060,6 +2223,42 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     result.dpCellCount = dpCellsTotal;
     result.kmerIdBytes = kmerIdBytes;
     result.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options& options, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
+{
+    alignRun(ctx, candidateCount, candidates, makeOptions(options), nullptr, wantOrdinals, result, borrowed);
+}
+
+// Align method 3 on the resident markers (Assembler::alignOrientedReads3 for every candidate, then
+// the filters of src/AssemblerAlign.cpp:439-472).  Same result layout as align4Run.
+void align3Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options& o, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
+{
+    // The DP kernels carry the scores as compile-time constants (the values every shipped
+    // configuration uses for method 3 and the ones method 4 hard-wires).
+    if(o.matchScore != MATCH_SCORE || o.mismatchScore != MISMATCH_SCORE || o.gapScore != GAP_SCORE) {
+        throw std::runtime_error("Align3: only matchScore 6, mismatchScore -1, gapScore -1 are supported.");
+    }
+    if(o.k < 1 || o.k > 16) throw std::runtime_error("Align3: k must be in [1, 16].");
+    if(!(o.downsamplingFactor >= 0. && o.downsamplingFactor <= 1.)) throw std::runtime_error("Align3: downsamplingFactor must be in [0, 1].");
+    if(o.bandExtend < 0 || o.bandExtend > (1 << 20)) throw std::runtime_error("Align3: bandExtend must be in [0, 2^20].");
+    if(o.maxBand < 0 || o.maxBand > 1023) throw std::runtime_error("Align3: maxBand must be in [0, 1023] (1024 diagonals per DP).");
+    Align3Plan plan;
+    plan.k = uint32_t(o.k);
+    plan.hashThreshold = uint32_t(o.downsamplingFactor * double(std::numeric_limits<uint32_t>::max()));   // src/AssemblerAlign3.cpp:71-72
+    plan.bandExtend = int32_t(o.bandExtend); plan.maxBand = int32_t(o.maxBand);
+    DeviceOptions opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.deltaX = opt.deltaY = 1;
+    opt.minAlignedMarkerCount = o.minAlignedMarkerCount;
+    opt.minAlignedFraction = o.minAlignedFraction;
+    opt.maxSkip = o.maxSkip; opt.maxDrift = o.maxDrift; opt.maxTrim = o.maxTrim; opt.maxBand = uint64_t(o.maxBand);
+    opt.suppressContainments = o.suppressContainments ? 1u : 0u;
+    alignRun(ctx, candidateCount, candidates, opt, &plan, wantOrdinals, result, borrowed);
 }
 
 void align4Free(shasta_align4_result& r)

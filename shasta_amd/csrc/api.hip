@@ -217,6 +217,32 @@ int shasta_mi355x_align4_batch(uint64_t readCount, const uint64_t* markersToc, c
 
 void shasta_mi355x_align4_free(shasta_align4_result* r) { if(r) align4Free(*r); }
 
+int shasta_mi355x_align3_run(shasta_mi355x_ctx* c, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align3_options* options,
+    int wantOrdinals, int borrowed, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!c || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align3_run: null argument");
+    align3Run(c->impl, candidateCount, candidates, *options, wantOrdinals != 0, *result, borrowed != 0);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_align3_batch(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options* options, int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!markersToc || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align3_batch: null argument");
+    int device = 0;
+    (void)hipGetDevice(&device);
+    shasta_mi355x_ctx c(device);
+    c.impl.setMarkers(readCount, markersToc, markersData, nullptr, nullptr);
+    align3Run(c.impl, candidateCount, candidates, *options, wantOrdinals != 0, *result);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx* c, shasta_mi355x_kernel_times* t)
 {
     API_BEGIN

@@ -33,6 +33,7 @@ struct Context {
     std::shared_ptr<void> alignScratch[2];   // grow-only batch scratch of the two workers
     std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress (staged / multi-GPU API)
+    std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
     shasta_mi355x_kernel_times times = {};
 
     explicit Context(int device);
@@ -54,6 +55,8 @@ void lowhash0Merge(Context&, const uint64_t* runKeys, const uint32_t* runCounts,
 void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
+void align3Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options&, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
 void align4Free(shasta_align4_result&);
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);

@@ -429,6 +429,7 @@ void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const vo
     MI355X_ASSERT(hostToc[0] == 0);
     for(uint64_t i = 0; i < orientedReadCount; i++) MI355X_ASSERT(hostToc[i] <= hostToc[i + 1]);
     markerCount = hostToc[orientedReadCount];
+    downsampled.reset();
 
     toc.reserve(orientedReadCount + 1, stream);
     HIP_CHECK(hipMemcpyAsync(toc.data(), hostToc.data(), (orientedReadCount + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));

@@ -26,6 +26,7 @@ EXPORTS = [
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish",
+    "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
 ]
 
 
@@ -87,6 +88,20 @@ class Library:
             C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
         self._check(rc, "shasta_mi355x_align4_batch")
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def align3_batch(self, toc, data7, candidates, options, want_ordinals=True):
+        """Align method 3, one-shot on host markers (options: abi.Align3Options)."""
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        res = abi.Align4Result()
+        rc = self.lib.shasta_mi355x_align3_batch(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
+        self._check(rc, "shasta_mi355x_align3_batch")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
 
     # --- unit seams -------------------------------------------------------------------
@@ -250,6 +265,16 @@ class Context:
         self.library._check(entry(
             C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_align4_run")
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def align3(self, candidates, options, want_ordinals=False, borrow=False):
+        """Align method 3 on the resident markers (options: abi.Align3Options)."""
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        res = abi.Align4Result()
+        self.library._check(self.lib.shasta_mi355x_align3_run(
+            C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.c_int(1 if borrow else 0), C.byref(res)),
+            "shasta_mi355x_align3_run")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
 
     def kernel_times(self):

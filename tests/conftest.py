@@ -29,9 +29,27 @@ def ref_lib():
     return bindings.RefLib()
 
 
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "_build", "libshasta_mi355x_emu.so")
+
+
 @pytest.fixture(scope="session")
-def gpu_lib():
-    """The product library on a real GPU.  Fails loudly (no skip, no fallback)."""
+def emu_lib():
+    """The kernel SOURCES of shasta_amd/csrc compiled by g++ against the wave64 emulator of
+    tests/emu (test infrastructure: kernels run on CPU fibers; nothing in the product loads it)."""
+    import subprocess
+    from shasta_amd import lib as libmod
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return libmod.Library(EMU_SO)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib(request):
+    """The product library on a real GPU.  Fails loudly (no skip, no fallback).
+    Developer switch: SHASTA_EMU=1 pytest -m gpu runs the same tests on the emulated build
+    (kernel sources on CPU fibers) -- a pre-flight for a machine without a GPU, never a result."""
+    if os.environ.get("SHASTA_EMU") == "1":
+        return request.getfixturevalue("emu_lib")
     import shasta_amd
     lib = shasta_amd.load()
     assert lib.device_count() >= 1, "no gfx950 device visible: the HIP path cannot run"

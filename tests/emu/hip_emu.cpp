@@ -1,0 +1,303 @@
+// TEST INFRASTRUCTURE ONLY -- see include/hip/hip_runtime.h.
+// Fiber scheduler (one OS thread runs one workgroup at a time; its work-items are fibers that
+// switch only at cross-lane operations and barriers) and the host runtime stubs.
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+// void hipemu_switch(void** saveSp, void* loadSp): System V x86-64 callee-saved registers.
+extern "C" void hipemu_switch(void** saveSp, void* loadSp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+
+namespace hipemu {
+
+thread_local Fiber* cur = nullptr;
+
+namespace {
+
+enum State { RUNNABLE = 0, WAIT_WAVE, WAIT_BLOCK, DONE };
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+struct Worker {                       // per OS thread
+    void* schedulerSp = nullptr;
+    char* stacks = nullptr;
+    size_t stackCount = 0;
+    const Launch* launch = nullptr;
+    std::string error;
+    ~Worker() { if(stacks) munmap(stacks, stackCount * STACK_BYTES); }
+    void reserve(size_t n)
+    {
+        if(n <= stackCount) return;
+        if(stacks) munmap(stacks, stackCount * STACK_BYTES);
+        stacks = static_cast<char*>(mmap(nullptr, n * STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+        if(stacks == MAP_FAILED) { stacks = nullptr; throw std::runtime_error("hipemu: cannot map fiber stacks"); }
+        stackCount = n;
+    }
+};
+thread_local Worker worker;
+
+void yieldToScheduler()
+{
+    Fiber* f = cur;
+    hipemu_switch(&f->sp, worker.schedulerSp);
+}
+
+void fiberEntry()
+{
+    Fiber* f = cur;
+    try {
+        worker.launch->invoke(worker.launch->args);
+    } catch(const std::exception& e) {
+        worker.error = e.what();
+    }
+    f->state = DONE;
+    yieldToScheduler();
+    std::abort();                     // a finished fiber is never resumed
+}
+
+void prepare(Fiber& f, char* stackTop)
+{
+    // Layout, low to high: r15 r14 r13 r12 rbx rbp | return address = fiberEntry | (alignment slot).
+    uintptr_t top = reinterpret_cast<uintptr_t>(stackTop) & ~uintptr_t(15);
+    void** p = reinterpret_cast<void**>(top);
+    *--p = nullptr;                                   // so that rsp % 16 == 8 on entry, as after a call
+    *--p = reinterpret_cast<void*>(&fiberEntry);
+    for(int i = 0; i < 6; i++) *--p = nullptr;
+    f.sp = p;
+}
+
+// Completes the collective of the lanes in `group` (all waiting at the same call site).
+void releaseGroup(std::vector<Fiber>& fibers, int waveBase, uint64_t group)
+{
+    uint64_t ballot = 0;
+    int first = -1;
+    for(int l = 0; l < 64; l++) if((group >> l) & 1) {
+        const Fiber& f = fibers[waveBase + l];
+        if(first < 0) first = l;
+        if(f.kind == BALLOT && f.value) ballot |= 1ULL << l;
+    }
+    for(int l = 0; l < 64; l++) if((group >> l) & 1) {
+        Fiber& f = fibers[waveBase + l];
+        switch(f.kind) {
+        case BALLOT: f.result = ballot; break;
+        case SHUFFLE: {
+            const int src = int(f.aux);
+            // An inactive source lane returns garbage on hardware; the own value keeps runs reproducible.
+            f.result = (src >= 0 && src < 64 && ((group >> src) & 1)) ? fibers[waveBase + src].value : f.value;
+            break;
+        }
+        case FIRSTLANE: f.result = fibers[waveBase + first].value; break;
+        default: f.result = 0; break;
+        }
+    }
+    for(int l = 0; l < 64; l++) if((group >> l) & 1) fibers[waveBase + l].state = RUNNABLE;
+}
+
+void runBlock(const Launch& L, unsigned bx, unsigned by, unsigned bz)
+{
+    const unsigned n = L.block.x * L.block.y * L.block.z;
+    if(L.block.y != 1 || L.block.z != 1) throw std::runtime_error("hipemu: only one-dimensional workgroups are supported");
+    worker.reserve(n);
+    worker.launch = &L;
+    worker.error.clear();
+    std::vector<Fiber> fibers(n);
+    for(unsigned t = 0; t < n; t++) {
+        Fiber& f = fibers[t];
+        f.tIdx = Index{t, 0, 0}; f.bIdx = Index{bx, by, bz};
+        f.bDim = Index{L.block.x, L.block.y, L.block.z}; f.gDim = Index{L.grid.x, L.grid.y, L.grid.z};
+        f.lane = int(t & 63); f.wave = int(t >> 6); f.state = RUNNABLE; f.kind = 0; f.site = nullptr;
+        f.value = f.aux = f.result = 0;
+        prepare(f, worker.stacks + size_t(t + 1) * STACK_BYTES);
+    }
+    const unsigned waves = (n + 63) / 64;
+    unsigned done = 0;
+    while(done < n) {
+        bool progressed = false;
+        // Within a wavefront the highest lane runs first, so the usual leader (lane 0) runs last: a
+        // follower's LDS read that precedes the leader's LDS write in program order, with no
+        // cross-lane operation in between, sees the old value -- as it does in lock-step.
+        for(unsigned q = 0; q < n; q++) {
+            const unsigned w = q >> 6, top = std::min(n, (w + 1) * 64u) - 1;
+            const unsigned t = top - (q & 63u);
+            if(t < w * 64u || t >= n) continue;
+            Fiber& f = fibers[t];
+            if(f.state != RUNNABLE) continue;
+            progressed = true;
+            cur = &f;
+            hipemu_switch(&worker.schedulerSp, f.sp);
+            cur = nullptr;
+            if(f.state == DONE) ++done;
+        }
+        // Wavefronts whose live lanes all wait at one call site: the common case.
+        for(unsigned w = 0; w < waves; w++) {
+            const int base = int(w * 64), count = int(std::min(64u, n - w * 64));
+            uint64_t waiting = 0, live = 0;
+            const void* site = nullptr; bool same = true;
+            for(int l = 0; l < count; l++) {
+                const Fiber& f = fibers[base + l];
+                if(f.state == DONE) continue;
+                live |= 1ULL << l;
+                if(f.state == WAIT_WAVE) {
+                    if(!waiting) site = f.site; else if(f.site != site) same = false;
+                    waiting |= 1ULL << l;
+                }
+            }
+            if(waiting && waiting == live && same) { releaseGroup(fibers, base, waiting); progressed = true; }
+        }
+        // Workgroup barrier: every live work-item waits at it.
+        {
+            unsigned atBarrier = 0;
+            for(unsigned t = 0; t < n; t++) if(fibers[t].state == WAIT_BLOCK) ++atBarrier;
+            if(atBarrier && atBarrier == n - done) {
+                for(unsigned t = 0; t < n; t++) if(fibers[t].state == WAIT_BLOCK) fibers[t].state = RUNNABLE;
+                progressed = true;
+            }
+        }
+        if(progressed) continue;
+        // Divergence: the live lanes of a wavefront wait at different call sites (or some at the
+        // workgroup barrier).  The hardware runs the deeper branch first with only its lanes active;
+        // code layout puts that branch at the lower address.
+        bool released = false;
+        for(unsigned w = 0; w < waves && !released; w++) {
+            const int base = int(w * 64), count = int(std::min(64u, n - w * 64));
+            const void* lowest = nullptr;
+            for(int l = 0; l < count; l++) {
+                const Fiber& f = fibers[base + l];
+                if(f.state == WAIT_WAVE && (!lowest || f.site < lowest)) lowest = f.site;
+            }
+            if(!lowest) continue;
+            uint64_t group = 0;
+            for(int l = 0; l < count; l++) if(fibers[base + l].state == WAIT_WAVE && fibers[base + l].site == lowest) group |= 1ULL << l;
+            releaseGroup(fibers, base, group);
+            released = true;
+        }
+        if(!released) throw std::runtime_error("hipemu: deadlock (work-items wait at a workgroup barrier that others never reach)");
+    }
+    if(!worker.error.empty()) throw std::runtime_error("hipemu: exception inside a kernel: " + worker.error);
+}
+
+std::mutex errorMutex;
+
+}  // namespace
+
+uint64_t collective(int kind, uint64_t value, uint64_t aux)
+{
+    Fiber* f = cur;
+    f->kind = kind; f->value = value; f->aux = aux;
+    f->site = __builtin_return_address(0);
+    f->state = (kind == BLOCK_BARRIER) ? WAIT_BLOCK : WAIT_WAVE;
+    yieldToScheduler();
+    return f->result;
+}
+
+void launch(const Launch& L)
+{
+    const uint64_t blocks = uint64_t(L.grid.x) * L.grid.y * L.grid.z;
+    if(blocks == 0 || L.block.x == 0) throw std::runtime_error("hipemu: empty launch configuration");
+    static const unsigned maxThreads = [] {
+        const char* e = std::getenv("HIPEMU_THREADS");
+        const unsigned n = e ? unsigned(std::atoi(e)) : std::thread::hardware_concurrency();
+        return std::max(1u, n);
+    }();
+    std::atomic<uint64_t> next(0);
+    std::string error;
+    auto work = [&]() {
+        try {
+            for(;;) {
+                const uint64_t b = next.fetch_add(1);
+                if(b >= blocks) break;
+                const unsigned bx = unsigned(b % L.grid.x), by = unsigned((b / L.grid.x) % L.grid.y), bz = unsigned(b / (uint64_t(L.grid.x) * L.grid.y));
+                runBlock(L, bx, by, bz);
+            }
+        } catch(const std::exception& e) {
+            std::lock_guard<std::mutex> lock(errorMutex);
+            if(error.empty()) error = e.what();
+            next.store(blocks);
+        }
+    };
+    const unsigned threads = unsigned(std::min<uint64_t>(maxThreads, blocks));
+    if(threads <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for(unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+        work();
+        for(auto& t : pool) t.join();
+    }
+    if(!error.empty()) throw std::runtime_error(error);
+}
+
+}  // namespace hipemu
+
+// ---------------------------------------------------------------------------
+// Host runtime.
+// ---------------------------------------------------------------------------
+struct hipemuStream { int dummy; };
+struct hipemuEvent { std::chrono::steady_clock::time_point t; };
+
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int)
+{
+    std::memset(p, 0, sizeof(*p));
+    std::snprintf(p->name, sizeof(p->name), "CPU emulation of wave64 (test infrastructure)");
+    std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "gfx950:emulated-on-cpu");
+    p->multiProcessorCount = 256;
+    p->totalGlobalMem = size_t(16) << 30;
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { if(n) std::memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if(n) std::memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemuStream{0}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{std::chrono::steady_clock::now()}; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
+{
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

@@ -39,6 +39,28 @@ def test_pod_sizes_match_the_reference_structs():
     assert abi.PAIR_DTYPE.itemsize == 12 and abi.ALIGNMENT_DATA_DTYPE.itemsize == 64
 
 
+def test_ctypes_mirror_matches_the_header_layout(tmp_path):
+    # sizeof of every struct of the header as gcc lays it out vs the ctypes mirror.
+    import subprocess
+    structs = {
+        "shasta_oriented_read_pair": abi.OrientedReadPair, "shasta_alignment_info": abi.AlignmentInfo,
+        "shasta_alignment_data": abi.AlignmentData, "shasta_lowhash0_params": abi.LowHash0Params,
+        "shasta_lowhash0_result": abi.LowHash0Result, "shasta_align4_options": abi.Align4Options,
+        "shasta_align3_options": abi.Align3Options, "shasta_align4_result": abi.Align4Result,
+        "shasta_mi355x_kernel_times": abi.KernelTimes,
+    }
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "shasta_mi355x.h"\nint main(void) {\n' +
+                   "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in structs) + "return 0; }\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for name, mirror in structs.items():
+        assert int(out[name]) == C.sizeof(mirror), name
+    o = abi.default_align3_options()
+    assert (o.matchScore, o.mismatchScore, o.gapScore, o.bandExtend, o.maxBand, o.k) == (6, -1, -1, 10, 1000, 10)
+
+
 def test_missing_library_is_an_error_not_a_fallback(tmp_path):
     with pytest.raises(libmod.LibraryNotBuilt, match="no CPU fallback"):
         libmod.Library(str(tmp_path / "libshasta_mi355x.so"))
@@ -53,6 +75,8 @@ def test_compute_entry_points_fail_loudly_without_a_gpu():
         library.lowhash0(toc, data7, None, abi.default_lowhash0_params())
     with pytest.raises(RuntimeError):
         library.align4_batch(toc, data7, abi.make_pairs([0], [1], [1]), abi.default_align4_options())
+    with pytest.raises(RuntimeError):
+        library.align3_batch(toc, data7, abi.make_pairs([0], [1], [1]), abi.default_align3_options())
     with pytest.raises(RuntimeError):
         library.context(0)
     with pytest.raises(RuntimeError):

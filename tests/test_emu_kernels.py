@@ -1,0 +1,87 @@
+"""Pre-flight of the HIP kernel SOURCES without a GPU: shasta_amd/csrc/*.hip compiled unmodified by
+g++ against the wave64 emulator of tests/emu (work-items are fibers that meet at every cross-lane
+operation and barrier) and run through the same C ABI and the same checks as the -m gpu tests, at
+sizes a CPU finishes in seconds.  This is test infrastructure: it proves the kernel logic against
+the oracle, not the MI355X run (no LDS limits, no timing, no inter-workgroup memory model), and
+nothing in the product can load the emulated library.  The whole -m gpu suite runs on it with
+SHASTA_EMU=1 (see tests/conftest.py)."""
+import numpy as np
+import pytest
+
+from shasta_amd import abi
+from tests import align3_checks, support
+
+
+def test_emulated_library_is_the_same_abi(emu_lib):
+    assert emu_lib.device_count() == 1 and "gfx950" in emu_lib.version()
+
+
+@pytest.mark.parametrize("m", [3, 4, 5])
+def test_hash_windows(emu_lib, oracle_lib, m):
+    rng = np.random.default_rng(m)
+    k = rng.integers(0, 1 << 20, size=3000, dtype=np.uint32)
+    for iteration in (0, 7):
+        assert np.array_equal(emu_lib.hash_windows(k, m, iteration), oracle_lib.hash_windows(k, m, iteration))
+
+
+@pytest.mark.parametrize("width", [20, 65, 300, 1000])
+def test_banded_dp(emu_lib, oracle_lib, width):
+    from tests.test_gpu_align4 import noisy_copy
+    rng = np.random.default_rng(width)
+    for trial in range(3):
+        alphabet = (1 << 20) if trial % 2 == 0 else 12          # small alphabet: many score ties
+        n = int(rng.integers(150, 500))
+        genome = rng.integers(0, alphabet, size=n + 400, dtype=np.uint32)
+        a = noisy_copy(rng, genome[:n], alphabet=alphabet)
+        off = int(rng.integers(0, 300))
+        b = noisy_copy(rng, genome[off:off + n], alphabet=alphabet)
+        lo = off + int(rng.integers(-30, 30)) - width // 2
+        x, sx = oracle_lib.banded_dp(a, b, lo, lo + width - 1)
+        y, sy = emu_lib.banded_dp(a, b, lo, lo + width - 1)
+        assert sx == sy and np.array_equal(x, y)
+
+
+def test_lowhash0_and_align4(emu_lib, oracle_lib):
+    toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=12000, seed=5)
+    flags = np.zeros(150, np.uint8)
+    flags[[5, 17]] = 1
+    p = abi.default_lowhash0_params(minBucketSize=3, maxBucketSize=30, minFrequency=2)
+    a, b = emu_lib.lowhash0(toc, data7, flags, p), oracle_lib.lowhash0(toc, data7, flags, p)
+    support.same_lowhash(a, b)
+    cand = b.candidates[:400]
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    x = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+    y = emu_lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
+    if not (x.status & 0x80).any():
+        support.same_align(x, y)
+    else:
+        keep = (x.status & 0x80) == 0
+        assert np.array_equal(x.status[keep], y.status[keep])
+
+
+def test_lowhash0_golden_fixture(emu_lib):
+    g = support.Golden("tiny.npz")
+    out = emu_lib.lowhash0(g.toc, g.data7, None, abi.default_lowhash0_params())
+    support.check_lowhash(out, g.z, 0)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_align3_reference_fixture(emu_lib, i):
+    align3_checks.golden_fixture(emu_lib, "tiny", i)
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (21, dict()),
+    (23, dict(downsamplingFactor=0.25, bandExtend=2, maxBand=30, minAlignedMarkerCount=20, suppressContainments=1)),
+    (24, dict(downsamplingFactor=0.002, minAlignedMarkerCount=40)),
+])
+def test_align3_against_oracle(emu_lib, oracle_lib, seed, kw):
+    align3_checks.against_oracle(emu_lib, oracle_lib, seed, kw)
+
+
+def test_align3_context_paths(emu_lib, oracle_lib):
+    align3_checks.context_paths(emu_lib, oracle_lib)
+
+
+def test_align3_rejected_options(emu_lib):
+    align3_checks.rejected_options(emu_lib)

@@ -1,0 +1,33 @@
+"""Align method 3 (Assembler::alignOrientedReads3) on the MI355X through the C ABI: bit-exact
+against fixtures made by the reference's own code and against the oracle.  Named to run last:
+this path was written after the round's GPU access closed and has so far only run on the
+emulated build (tests/test_emu_kernels.py)."""
+import pytest
+
+from tests import align3_checks, support
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["tiny", "synth"])
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_align3_matches_reference_fixture(gpu_lib, name, i):
+    align3_checks.golden_fixture(gpu_lib, name, i)
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (21, dict()),
+    (22, dict(downsamplingFactor=0.05, minAlignedMarkerCount=40)),
+    (23, dict(downsamplingFactor=0.25, bandExtend=2, maxBand=30, minAlignedMarkerCount=20, suppressContainments=1)),
+    (24, dict(downsamplingFactor=0.002, minAlignedMarkerCount=40)),
+])
+def test_align3_matches_oracle(gpu_lib, oracle_lib, seed, kw):
+    align3_checks.against_oracle(gpu_lib, oracle_lib, seed, kw, n_reads=250, genome_markers=15000, limit=1500)
+
+
+def test_align3_on_a_context(gpu_lib, oracle_lib):
+    align3_checks.context_paths(gpu_lib, oracle_lib)
+
+
+def test_align3_unsupported_options_fail_loudly(gpu_lib):
+    align3_checks.rejected_options(gpu_lib)
