@@ -23,12 +23,14 @@ class _HostAlignOptions(C.Structure):
         ("suppressContainments", C.c_uint64),
         ("align4DeltaX", C.c_uint64), ("align4DeltaY", C.c_uint64),
         ("align4MinEntryCountPerCell", C.c_uint64), ("align4MaxDistanceFromBoundary", C.c_uint64),
+        ("downsamplingFactor", C.c_double), ("bandExtend", C.c_int64),
     ]
 
 
 class AlignOptions:
     """shasta.AlignOptions: same attributes (src/PythonModule.cpp:85-107), defaults of
-    src/AssemblerOptions.cpp:380-489 except alignMethod, which is 4 (the method this library implements)."""
+    src/AssemblerOptions.cpp:380-489 except alignMethod, which stays 4 here (the reference's default is 3;
+    this library implements both, method 3 has not run on the MI355X yet)."""
 
     def __init__(self):
         self.alignMethod = 4
@@ -56,13 +58,14 @@ class Assembler:
     """shasta.Assembler for the overlap-detection stages.  Construct it on a run's Data/ directory
     (the reference's default largeDataFileNamePrefix is "Data/")."""
 
-    def __init__(self, largeDataFileNamePrefix="Data/", createNew=False, readRepresentation=1, largeDataPageSize=4096):
+    def __init__(self, largeDataFileNamePrefix="Data/", createNew=False, readRepresentation=1, largeDataPageSize=4096,
+                 hostLibrary=HOST_SO):
         if createNew:
             raise RuntimeError("shasta_amd.Assembler works on an existing Data/ directory (createNew is not supported).")
-        if not os.path.exists(HOST_SO):
+        if not os.path.exists(hostLibrary):
             raise RuntimeError("%s is missing: build with `python -c 'import __graft_entry__ as g; g.build()'`. "
-                               "There is no CPU fallback." % HOST_SO)
-        self._lib = C.CDLL(HOST_SO)
+                               "There is no CPU fallback." % hostLibrary)
+        self._lib = C.CDLL(hostLibrary)
         self._lib.shasta_mi355x_host_last_error.restype = C.c_char_p
         self._data = largeDataFileNamePrefix.rstrip("/") or "."
         self._page = int(largeDataPageSize)
@@ -78,7 +81,7 @@ class Assembler:
 
     # The reference's access* calls map the files; here they check that the files exist.
     def accessKmers(self):
-        pass                                          # the k-mer table is not used by this path
+        pass      # only its size is used (k, for alignMethod 3); LowHash0 and method 4 never read it
 
     def accessMarkers(self):
         self._require("Markers.toc", "Markers.data", "ReadFlags")
@@ -113,6 +116,7 @@ class Assembler:
             suppressContainments=1 if alignOptions.suppressContainments else 0,
             align4DeltaX=int(alignOptions.align4DeltaX), align4DeltaY=int(alignOptions.align4DeltaY),
             align4MinEntryCountPerCell=int(alignOptions.align4MinEntryCountPerCell),
-            align4MaxDistanceFromBoundary=int(alignOptions.align4MaxDistanceFromBoundary))
+            align4MaxDistanceFromBoundary=int(alignOptions.align4MaxDistanceFromBoundary),
+            downsamplingFactor=float(alignOptions.downsamplingFactor), bandExtend=int(alignOptions.bandExtend))
         self._check(self._lib.shasta_mi355x_host_compute_alignments(self._data.encode(), C.byref(o), C.c_uint64(threadCount),
                                                                     C.c_uint64(self._page)))

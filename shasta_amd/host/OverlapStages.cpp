@@ -268,30 +268,63 @@ uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignment
     return keepCount;
 }
 
+// The marker length k of the run, from the size of Data/Kmers (Vector<KmerInfo>, 24-byte entries,
+// one per k-mer id: 4^k of them, src/AssemblerKmers.cpp:147-186).  Method 3 needs it for the
+// down-sampling hash, which the library recomputes from the k-mer id instead of reading the table.
+uint64_t markerLengthOf(const std::string& dataDirectory)
+{
+    struct KmerInfo24 { char bytes[24]; };                 // src/Kmer.hpp:22-39
+    MappedVector<KmerInfo24> kmers;
+    kmers.accessExistingReadOnly(dataName(dataDirectory, "Kmers"));
+    const uint64_t n = kmers.size();
+    uint64_t k = 0;
+    while(k < 32 && (1ULL << (2 * k)) < n) ++k;
+    if(n == 0 || (1ULL << (2 * k)) != n) throw std::runtime_error("computeAlignments: Data/Kmers does not hold 4^k entries.");
+    return k;
+}
+
 void computeAlignments(const std::string& dataDirectory, const AlignOptions& alignOptions, size_t /* threadCount */, size_t largeDataPageSize)
 {
-    if(alignOptions.alignMethod != 4) throw std::runtime_error("computeAlignments: this library implements alignMethod 4 only.");
+    if(alignOptions.alignMethod != 3 && alignOptions.alignMethod != 4) {
+        throw std::runtime_error("computeAlignments: this library implements alignMethod 3 and 4 only.");
+    }
     Markers markers;
     markers.accessExistingReadOnly(dataName(dataDirectory, "Markers"));
     AlignmentCandidates candidates;
     candidates.accessExistingReadOnly(dataName(dataDirectory, "AlignmentCandidates"));
     const uint64_t readCount = markers.size() / 2;
 
-    shasta_align4_options o{};
-    o.deltaX = alignOptions.align4DeltaX; o.deltaY = alignOptions.align4DeltaY;
-    o.minEntryCountPerCell = alignOptions.align4MinEntryCountPerCell;
-    o.maxDistanceFromBoundary = alignOptions.align4MaxDistanceFromBoundary;
-    o.minAlignedMarkerCount = alignOptions.minAlignedMarkerCount;
-    o.minAlignedFraction = alignOptions.minAlignedFraction;
-    o.maxSkip = alignOptions.maxSkip; o.maxDrift = alignOptions.maxDrift; o.maxTrim = alignOptions.maxTrim;
-    o.maxBand = uint64_t(alignOptions.maxBand);
-    o.matchScore = alignOptions.matchScore; o.mismatchScore = alignOptions.mismatchScore; o.gapScore = alignOptions.gapScore;
-    o.suppressContainments = alignOptions.suppressContainments ? 1 : 0;
-
     shasta_align4_result r{};
-    if(shasta_mi355x_align4_batch(readCount, markers.toc.begin(), markers.data.begin(),
-        candidates.size(), candidates.begin(), &o, 0, &r)) {
-        throw std::runtime_error(shasta_mi355x_last_error());
+    if(alignOptions.alignMethod == 3) {
+        // src/AssemblerAlign.cpp:404-409 -> Assembler::alignOrientedReads3.
+        shasta_align3_options o{};
+        o.matchScore = alignOptions.matchScore; o.mismatchScore = alignOptions.mismatchScore; o.gapScore = alignOptions.gapScore;
+        o.downsamplingFactor = alignOptions.downsamplingFactor;
+        o.bandExtend = alignOptions.bandExtend; o.maxBand = alignOptions.maxBand;
+        o.k = markerLengthOf(dataDirectory);
+        o.minAlignedMarkerCount = alignOptions.minAlignedMarkerCount;
+        o.minAlignedFraction = alignOptions.minAlignedFraction;
+        o.maxSkip = alignOptions.maxSkip; o.maxDrift = alignOptions.maxDrift; o.maxTrim = alignOptions.maxTrim;
+        o.suppressContainments = alignOptions.suppressContainments ? 1 : 0;
+        if(shasta_mi355x_align3_batch(readCount, markers.toc.begin(), markers.data.begin(),
+            candidates.size(), candidates.begin(), &o, 0, &r)) {
+            throw std::runtime_error(shasta_mi355x_last_error());
+        }
+    } else {
+        shasta_align4_options o{};
+        o.deltaX = alignOptions.align4DeltaX; o.deltaY = alignOptions.align4DeltaY;
+        o.minEntryCountPerCell = alignOptions.align4MinEntryCountPerCell;
+        o.maxDistanceFromBoundary = alignOptions.align4MaxDistanceFromBoundary;
+        o.minAlignedMarkerCount = alignOptions.minAlignedMarkerCount;
+        o.minAlignedFraction = alignOptions.minAlignedFraction;
+        o.maxSkip = alignOptions.maxSkip; o.maxDrift = alignOptions.maxDrift; o.maxTrim = alignOptions.maxTrim;
+        o.maxBand = uint64_t(alignOptions.maxBand);
+        o.matchScore = alignOptions.matchScore; o.mismatchScore = alignOptions.mismatchScore; o.gapScore = alignOptions.gapScore;
+        o.suppressContainments = alignOptions.suppressContainments ? 1 : 0;
+        if(shasta_mi355x_align4_batch(readCount, markers.toc.begin(), markers.data.begin(),
+            candidates.size(), candidates.begin(), &o, 0, &r)) {
+            throw std::runtime_error(shasta_mi355x_last_error());
+        }
     }
     uint64_t skipped = 0;
     for(uint64_t i = 0; i < candidates.size(); i++) if((r.status[i] & 0x7f) == SHASTA_ALIGN_SKIPPED) ++skipped;

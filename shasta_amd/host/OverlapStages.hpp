@@ -4,7 +4,7 @@
 //
 //   LowHash0                          <-> shasta::LowHash0::LowHash0          src/LowHash0.hpp:32-52
 //   findAlignmentCandidatesLowHash0   <-> Assembler::findAlignmentCandidatesLowHash0   src/AssemblerLowHash.cpp:10-55
-//   computeAlignments                 <-> Assembler::computeAlignments (alignMethod 4)  src/AssemblerAlign.cpp:208-304
+//   computeAlignments                 <-> Assembler::computeAlignments (alignMethod 3 or 4)  src/AssemblerAlign.cpp:208-304
 //   computeAlignmentTable             <-> Assembler::computeAlignmentTable    src/AssemblerAlign.cpp:509-571
 //   computeCandidateTable             <-> AlignmentCandidates::computeCandidateTable    src/AssemblerAlignmentCandidates.cpp:388-447
 //   createReadGraph                   <-> Assembler::createReadGraph          src/AssemblerReadGraph.cpp:35-157
@@ -49,6 +49,8 @@ struct AlignOptions {
     double minAlignedFraction = 0.;
     int matchScore = 6, mismatchScore = -1, gapScore = -1;
     int maxBand = 1000;
+    double downsamplingFactor = 0.1;          // method 3 only
+    int bandExtend = 10;                      // method 3 only
     bool suppressContainments = false;
     uint64_t align4DeltaX = 200, align4DeltaY = 10, align4MinEntryCountPerCell = 10, align4MaxDistanceFromBoundary = 100;
 };

@@ -41,7 +41,7 @@ int shasta_mi355x_host_compute_candidate_table(const char* dataDirectory, uint64
     HOST_END
 }
 
-// The numeric members of AlignOptions that method 4 reads, in the order of src/AssemblerOptions.hpp:177-198.
+// The numeric members of AlignOptions that methods 3 and 4 read, in the order of src/AssemblerOptions.hpp:177-198.
 struct shasta_mi355x_host_align_options {
     int64_t alignMethod;
     uint64_t maxSkip, maxDrift, maxTrim, minAlignedMarkerCount;
@@ -49,6 +49,8 @@ struct shasta_mi355x_host_align_options {
     int64_t matchScore, mismatchScore, gapScore, maxBand;
     uint64_t suppressContainments;
     uint64_t align4DeltaX, align4DeltaY, align4MinEntryCountPerCell, align4MaxDistanceFromBoundary;
+    double downsamplingFactor;     /* method 3 */
+    int64_t bandExtend;            /* method 3 */
 };
 
 // Assembler::computeAlignments, src/AssemblerAlign.cpp:208-304.
@@ -65,6 +67,7 @@ int shasta_mi355x_host_compute_alignments(const char* dataDirectory, const shast
     a.align4DeltaX = o->align4DeltaX; a.align4DeltaY = o->align4DeltaY;
     a.align4MinEntryCountPerCell = o->align4MinEntryCountPerCell;
     a.align4MaxDistanceFromBoundary = o->align4MaxDistanceFromBoundary;
+    a.downsamplingFactor = o->downsamplingFactor; a.bandExtend = int(o->bandExtend);
     computeAlignments(dataDirectory, a, threadCount, largeDataPageSize);
     HOST_END
 }

@@ -38,6 +38,8 @@ int main(int argc, char** argv)
             o.minAlignedMarkerCount = std::stoull(arg(3, "100")); o.minAlignedFraction = std::stod(arg(4, "0"));
             o.maxSkip = std::stoull(arg(5, "30")); o.maxDrift = std::stoull(arg(6, "30")); o.maxTrim = std::stoull(arg(7, "30"));
             o.suppressContainments = std::stoull(arg(8, "0")) != 0;
+            o.alignMethod = std::stoi(arg(9, "4"));                       // 3 needs Data/Kmers (for k)
+            o.downsamplingFactor = std::stod(arg(10, "0.1")); o.bandExtend = std::stoi(arg(11, "10"));
             computeAlignments(data, o, 0);
         } else if(command == "read-graph") {
             // Assembler::createReadGraph(maxAlignmentCount, maxTrim), srcMain/main.cpp:718-722 (ReadGraph.creationMethod 0).

@@ -83,6 +83,18 @@ int host_store_alignments(const char* dir, uint64_t alignmentCount, const shasta
     SHIM_END
 }
 
+// Data/Kmers with the 4^k entries of a run with marker length k (contents zero: only the size is read).
+int host_write_kmers(const char* dir, uint64_t k)
+{
+    SHIM_BEGIN
+    MappedVector< Blob<24> > kmers;
+    kmers.createNew(std::string(dir) + "/Kmers");
+    kmers.resize(1ULL << (2 * k));
+    std::memset(kmers.begin(), 0, 24 * kmers.size());
+    kmers.unreserve();
+    SHIM_END
+}
+
 int host_store_candidates(const char* dir, uint64_t count, const shasta_oriented_read_pair* pairs)
 {
     SHIM_BEGIN

@@ -42,6 +42,9 @@ class HostShim:
         self._check(self.lib.host_store_alignments(directory.encode(), C.c_uint64(len(rows)), C.c_void_p(rows.ctypes.data),
                                                    abi.as_ptr(toc, C.c_uint64), C.c_void_p(data.ctypes.data)), "host_store_alignments")
 
+    def write_kmers(self, directory, k):
+        self._check(self.lib.host_write_kmers(directory.encode(), C.c_uint64(k)), "host_write_kmers")
+
     def store_candidates(self, directory, candidates):
         c = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
         self._check(self.lib.host_store_candidates(directory.encode(), C.c_uint64(len(c)), C.c_void_p(c.ctypes.data)), "host_store_candidates")

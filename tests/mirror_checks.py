@@ -1,0 +1,49 @@
+"""The stage functions through shasta_amd.assembler (the reference's Python stage surface) on a Data/
+directory, outputs against the oracle; shared by the GPU test and its emulated pre-flight."""
+import os
+
+import numpy as np
+
+import shasta_amd.assembler as shasta
+from shasta_amd import abi
+from tests import host_support, support
+
+
+def stages_on_a_data_directory(oracle_lib, tmp_path, monkeypatch, host_library, align_method):
+    toc, kmer, data7 = support.small_marker_set(n_reads=120, genome_markers=9000, seed=86 + align_method)
+    d = str(tmp_path / "Data")
+    os.makedirs(d)
+    shim = host_support.HostShim()
+    shim.write_data_dir(d, toc, data7, None)
+    shim.write_kmers(d, 10)
+    monkeypatch.chdir(tmp_path)                                   # the CSV side files go to the run directory
+    a = shasta.Assembler(hostLibrary=host_library)                # default prefix "Data/", as in the reference
+    a.accessKmers(); a.accessMarkers()
+    a.findAlignmentCandidatesLowHash0(m=4, hashFraction=0.01, minHashIterationCount=10, alignmentCandidatesPerRead=20.0,
+                                      minBucketSize=2, maxBucketSize=30, minFrequency=2)
+    ref = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=2))
+    stored, _ = shim.open_vector(os.path.join(d, "AlignmentCandidates"), 12)
+    assert np.array_equal(stored.view("<u4").reshape(-1, 3)[:, :2], ref.candidate_tuples()[:, :2])
+    assert np.array_equal(stored[:, 8], ref.candidate_tuples()[:, 2].astype(np.uint8))
+    a.computeCandidateTable()
+    a.accessAlignmentCandidates()
+    o = shasta.AlignOptions()
+    o.alignMethod = align_method
+    o.minAlignedMarkerCount = 40
+    a.computeAlignments(o, 0)
+    if align_method == 3:
+        al = oracle_lib.align3_batch(toc, data7, ref.candidates, abi.default_align3_options(minAlignedMarkerCount=40),
+                                     want_ordinals=False, threads=0)
+    else:
+        al = oracle_lib.align4_batch(toc, data7, ref.candidates, abi.default_align4_options(minAlignedMarkerCount=40),
+                                     want_ordinals=False, threads=0)
+    rows, _ = shim.open_vector(os.path.join(d, "AlignmentData"), 64)
+    got = np.frombuffer(rows.tobytes(), dtype=abi.ALIGNMENT_DATA_DTYPE)
+    assert len(got) == len(al.alignment_data) > 20
+    for field in abi.ALIGNMENT_DATA_DTYPE.names:
+        assert np.array_equal(got[field], al.alignment_data[field]), field
+    blob, _ = shim.open_vector(os.path.join(d, "CompressedAlignments.data"), 1)
+    assert np.array_equal(blob.reshape(-1), al.compressed_data)
+    a.accessAlignmentData()
+    a.createReadGraph(6, 30)
+    assert os.path.exists(os.path.join(d, "ReadGraphEdges"))

@@ -47,6 +47,9 @@ def test_candidate_table_and_errors_through_the_mirror(ref_lib, oracle_lib, tmp_
     toc_expected, data_expected = host_support.alignment_table_expected(100, cand, np.uint64)
     assert np.array_equal(t.view("<u8").reshape(-1), toc_expected) and np.array_equal(dta.view("<u8").reshape(-1), data_expected)
     o = shasta.AlignOptions()
-    o.alignMethod = 3
-    with pytest.raises(RuntimeError, match="alignMethod 4 only"):
+    o.alignMethod = 1
+    with pytest.raises(RuntimeError, match="alignMethod 3 and 4 only"):
+        a.computeAlignments(o, 0)
+    o.alignMethod = 3                                   # needs k: the size of Data/Kmers
+    with pytest.raises(RuntimeError, match="Kmers"):
         a.computeAlignments(o, 0)

@@ -85,3 +85,12 @@ def test_align3_context_paths(emu_lib, oracle_lib):
 
 def test_align3_rejected_options(emu_lib):
     align3_checks.rejected_options(emu_lib)
+
+
+@pytest.mark.parametrize("align_method", [3, 4])
+def test_stages_on_a_data_directory(emu_lib, oracle_lib, tmp_path, monkeypatch, align_method):
+    # The C++ host layer (Data/ files in, Data/ files out) linked against the emulated library.
+    import os
+    from tests import mirror_checks
+    host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
+    mirror_checks.stages_on_a_data_directory(oracle_lib, tmp_path, monkeypatch, host, align_method)

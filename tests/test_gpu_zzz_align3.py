@@ -31,3 +31,10 @@ def test_align3_on_a_context(gpu_lib, oracle_lib):
 
 def test_align3_unsupported_options_fail_loudly(gpu_lib):
     align3_checks.rejected_options(gpu_lib)
+
+
+def test_align3_stage_on_a_data_directory(gpu_lib, oracle_lib, tmp_path, monkeypatch):
+    # computeAlignments with alignMethod 3 through the C++ host layer and the Python mirror.
+    import shasta_amd.assembler as shasta
+    from tests import mirror_checks
+    mirror_checks.stages_on_a_data_directory(oracle_lib, tmp_path, monkeypatch, shasta.HOST_SO, 3)
