@@ -326,6 +326,35 @@ int shasta_mi355x_align3_batch(
     int wantOrdinals,
     shasta_align4_result* result);
 
+/* -------------------------------------------------------------------------
+ * Seam 0, the producer of the path's input: marker finding,
+ * MarkerFinder::MarkerFinder (src/MarkerFinder.hpp:25-31, src/MarkerFinder.cpp:16-127) as called by
+ * Assembler::findMarkers (src/AssemblerMarkers.cpp:11-24).
+ *   reads       Shasta's LongBaseSequences (Data/Reads-Bases.{toc,data}, Data/Reads-BaseCount):
+ *               readsToc[readCount+1] are word offsets into readsData; a read of n bases has
+ *               2*ceil(n/64) words, per 64 bases the low bits then the high bits of the bases,
+ *               base 0 in the most significant bit (src/LongBaseSequence.hpp:33-41)
+ *   kmerTable   4^k entries of kmerInfoStride bytes; the byte at isMarkerOffset is KmerInfo::isMarker
+ *               (Data/Kmers: stride 24, offset 12; src/Kmer.hpp:22-39)
+ * Output: markersToc[2*readCount+1] and, if wantPacked, Markers.data (7-byte CompressedMarker
+ * records), both released by shasta_mi355x_find_markers_free.  ctx may be NULL (a temporary context
+ * is used); with a context the markers stay resident exactly as after shasta_mi355x_set_markers, so
+ * that LowHash0 and the aligners run without uploading 7 bytes per marker (readFlags as there).
+ * ------------------------------------------------------------------------- */
+typedef struct shasta_markers_result {
+    uint64_t  markerCount;         /* both strands                                */
+    uint64_t* markersToc;          /* [2*readCount+1]                             */
+    uint8_t*  markersData;         /* 7*markerCount bytes, or NULL                */
+    double    seconds;
+    double    deviceSeconds;
+} shasta_markers_result;
+int shasta_mi355x_find_markers(
+    shasta_mi355x_ctx* ctx, uint64_t readCount,
+    const uint64_t* readsToc, const uint64_t* readsData, const uint64_t* baseCounts,
+    uint64_t k, const void* kmerTable, uint64_t kmerInfoStride, uint64_t isMarkerOffset,
+    const uint8_t* readFlags, int wantPacked, shasta_markers_result* result);
+void shasta_mi355x_find_markers_free(shasta_markers_result* result);
+
 /* Timing of the dominant kernels of the last *_run call on this context,
  * measured with HIP events on the context's stream. */
 typedef struct shasta_mi355x_kernel_times {

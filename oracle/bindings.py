@@ -122,6 +122,27 @@ class RefLib(_Base):
         self.lib.ref_free(data)
         return toc_a, data_a
 
+    def reads_and_markers_from_fasta(self, path, k=10, probability=0.1, seed=231, min_read_length=10000, threads=0):
+        """-> dict(reads_toc, reads_data, base_counts, is_marker, toc, data7): what the reference's
+        MarkerFinder read (reads as stored, isMarker flags) and what it wrote."""
+        rc_ = C.c_uint64()
+        rt, rd, bc = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        im, toc, data = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint8)()
+        self._check(self.lib.ref_reads_and_markers_from_fasta(
+            path.encode(), C.c_uint64(k), C.c_double(probability), C.c_int(seed), C.c_uint64(min_read_length), C.c_uint64(threads),
+            C.byref(rc_), C.byref(rt), C.byref(rd), C.byref(bc), C.byref(im), C.byref(toc), C.byref(data)),
+            "ref_reads_and_markers_from_fasta")
+        r = rc_.value
+        out = {"reads_toc": abi.copy_array(rt, r + 1, "<u8")}
+        out["reads_data"] = abi.copy_array(rd, int(out["reads_toc"][-1]), "<u8")
+        out["base_counts"] = abi.copy_array(bc, r, "<u8")
+        out["is_marker"] = abi.copy_array(im, 1 << (2 * k), "u1")
+        out["toc"] = abi.copy_array(toc, 2 * r + 1, "<u8")
+        out["data7"] = abi.copy_array(data, 7 * int(out["toc"][-1]), "u1")
+        for ptr in (rt, rd, bc, im, toc, data):
+            self.lib.ref_free(ptr)
+        return out
+
     # --- Data/ directory fixtures through the reference's own containers ---
     def write_data_dir(self, directory, toc, data7, flags=None):
         toc = _u64(toc)
@@ -285,6 +306,19 @@ class OracleLib(_Base):
         self._check(self.lib.oracle_kmer_hashes(abi.as_ptr(ids, C.c_uint32), C.c_uint64(len(ids)), C.c_uint64(k),
                                                 abi.as_ptr(out, C.c_uint32)), "oracle_kmer_hashes")
         return out
+
+    def find_markers(self, reads_toc, reads_data, base_counts, k, is_marker):
+        """-> (toc uint64[2R+1], data7 uint8[7*M])."""
+        rt, rd, bc = _u64(reads_toc), _u64(reads_data), _u64(base_counts)
+        im = np.ascontiguousarray(is_marker, dtype=np.uint8)
+        toc = np.zeros(2 * len(bc) + 1, dtype=np.uint64)
+        p = C.POINTER(C.c_uint8)()
+        self._check(self.lib.oracle_find_markers(C.c_uint64(len(bc)), abi.as_ptr(rt, C.c_uint64), abi.as_ptr(rd, C.c_uint64),
+                                                 abi.as_ptr(bc, C.c_uint64), C.c_uint64(k), abi.as_ptr(im, C.c_uint8),
+                                                 abi.as_ptr(toc, C.c_uint64), C.byref(p)), "oracle_find_markers")
+        data = abi.copy_array(p, 7 * int(toc[-1]), "u1")
+        self.lib.oracle_free(p)
+        return toc, data
 
     def banded_dp(self, k0, k1, band_min, band_max):
         k0 = np.ascontiguousarray(k0, dtype=np.uint32)

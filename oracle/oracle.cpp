@@ -306,6 +306,26 @@ int oracle_kmer_hashes(const uint32_t* kmerIds, uint64_t n, uint64_t k, uint32_t
     return 0;
 }
 
+// Marker finding for readCount reads (restated.hpp: findMarkersOfRead).  toc gets 2*readCount+1
+// entries; *data is malloc'ed (7 bytes per marker; free with oracle_free).
+int oracle_find_markers(uint64_t readCount, const uint64_t* readsToc, const uint64_t* readsData, const uint64_t* baseCounts,
+    uint64_t k, const uint8_t* isMarker, uint64_t* toc, uint8_t** data)
+{
+    try {
+        std::vector<uint8_t> all, s0, s1;
+        toc[0] = 0;
+        for(uint64_t r = 0; r < readCount; r++) {
+            findMarkersOfRead(readsData + readsToc[r], baseCounts[r], k, isMarker, s0, s1);
+            all.insert(all.end(), s0.begin(), s0.end());
+            toc[2 * r + 1] = all.size() / 7;
+            all.insert(all.end(), s1.begin(), s1.end());
+            toc[2 * r + 2] = all.size() / 7;
+        }
+        *data = mallocCopy(all);
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
 void oracle_align4_free(shasta_align4_result* r)
 {
     std::free(r->alignmentData); std::free(r->compressedToc); std::free(r->compressedData);

@@ -277,6 +277,80 @@ int ref_markers_from_fasta(
 }
 
 
+// The same chain, also returning what the reference's MarkerFinder READ: the reads as stored
+// (LongBaseSequences: two bit planes per 64 bases, src/LongBaseSequence.hpp:33-41), their base counts
+// and the isMarker flag of every k-mer id.  For the parity tests of marker finding
+// (MarkerFinder::MarkerFinder, src/MarkerFinder.cpp:16-127).
+int ref_reads_and_markers_from_fasta(
+    const char* fastaPath, uint64_t k, double probability, int seed,
+    uint64_t minReadLength, uint64_t threadCount,
+    uint64_t* readCountOut, uint64_t** readsTocOut, uint64_t** readsDataOut, uint64_t** baseCountsOut,
+    uint8_t** isMarkerOut, uint64_t** tocOut, uint8_t** dataOut)
+{
+    try {
+        CoutCapture capture;
+        if(threadCount == 0) threadCount = std::thread::hardware_concurrency();
+        Reads reads;
+        reads.createNew(1, "", "", "", "", "", "", 4096);
+        {
+            ReadLoader loader(fastaPath, 1, minReadLength, false, threadCount, "", 4096, reads);
+        }
+        MemoryMapped::Vector<KmerInfo> kmerTable;
+        kmerTable.createNew("", 4096);
+        const uint64_t kmerCount = 1ULL << (2ULL * k);
+        kmerTable.resize(kmerCount);
+        for(uint64_t kmerId = 0; kmerId < kmerCount; kmerId++) {
+            const Kmer kmer(kmerId, k);
+            KmerInfo& info = kmerTable[kmerId];
+            info.frequency = 0;
+            info.reverseComplementedKmerId = KmerId(kmer.reverseComplement(k).id(k));
+            info.isMarker = false;
+            info.isRleKmer = true;
+            info.hash = 0;
+        }
+        const double p = 1. - std::sqrt(1. - probability);
+        std::mt19937 randomSource(seed);
+        std::uniform_real_distribution<> uniformDistribution;
+        for(uint64_t kmerId = 0; kmerId < kmerCount; kmerId++) {
+            const double x = uniformDistribution(randomSource);
+            if(x <= p) {
+                kmerTable[kmerId].isMarker = true;
+                kmerTable[kmerTable[kmerId].reverseComplementedKmerId].isMarker = true;
+            }
+        }
+        Markers markers;
+        markers.createNew("", 4096);
+        {
+            MarkerFinder finder(k, kmerTable, reads, markers, threadCount);
+        }
+
+        const uint64_t readCount = reads.readCount();
+        *readCountOut = readCount;
+        std::vector<uint64_t> readsToc(readCount + 1, 0), baseCounts(readCount), words;
+        for(uint64_t r = 0; r < readCount; r++) {
+            const LongBaseSequenceView v = reads.getRead(ReadId(r));
+            baseCounts[r] = v.baseCount;
+            const uint64_t n = LongBaseSequenceView::wordCount(v.baseCount);
+            words.insert(words.end(), v.begin, v.begin + n);
+            readsToc[r + 1] = words.size();
+        }
+        std::vector<uint8_t> isMarker(kmerCount);
+        for(uint64_t i = 0; i < kmerCount; i++) isMarker[i] = kmerTable[i].isMarker ? 1 : 0;
+        *readsTocOut = mallocCopy(readsToc); *readsDataOut = mallocCopy(words); *baseCountsOut = mallocCopy(baseCounts);
+        *isMarkerOut = mallocCopy(isMarker);
+
+        const uint64_t n = markers.size();
+        std::vector<uint64_t> toc(n + 1, 0);
+        for(uint64_t i = 0; i < n; i++) toc[i+1] = toc[i] + markers.size(i);
+        std::vector<uint8_t> data(7 * toc[n]);
+        if(toc[n]) std::memcpy(data.data(), markers.begin(), 7 * toc[n]);
+        *tocOut = mallocCopy(toc); *dataOut = mallocCopy(data);
+        markers.remove(); kmerTable.remove(); reads.remove();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+
 // --------------------------------------------------------------------------
 // Seam 1: the reference LowHash0, unmodified.
 // --------------------------------------------------------------------------

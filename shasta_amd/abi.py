@@ -119,6 +119,16 @@ class Align4Result(C.Structure):
     ]
 
 
+class MarkersResult(C.Structure):
+    _fields_ = [
+        ("markerCount", C.c_uint64),
+        ("markersToc", C.POINTER(C.c_uint64)),
+        ("markersData", C.POINTER(C.c_uint8)),
+        ("seconds", C.c_double),
+        ("deviceSeconds", C.c_double),
+    ]
+
+
 class KernelTimes(C.Structure):
     _fields_ = [
         ("lowhashHashSeconds", C.c_double),

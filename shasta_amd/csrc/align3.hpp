@@ -20,16 +20,11 @@
 // Integer work, HBM-bound only in downsampleKernel (4 bytes read per marker, 8 written per kept one).
 
 // KmerInfo::hash (src/AssemblerKmers.cpp:182-186): MurmurHash2 (32-bit, seed 13477,
-// src/MurmurHash2.cpp:37-85) of the 8 bytes of kmerId + reverseComplement(kmerId).  A k-mer id is
-// two k-bit planes, (high bits of the bases) << k | (low bits), first base at the plane's most
-// significant bit (src/ShortBaseSequence.hpp:89-105); the reverse complement flips every bit and
-// reverses each plane (:109-117).
+// src/MurmurHash2.cpp:37-85) of the 8 bytes of kmerId + reverseComplementKmerId(kmerId)
+// (primitives.hpp).
 __device__ __forceinline__ uint32_t kmerDownsamplingHash(uint32_t kmerId, uint32_t k)
 {
-    const uint32_t mask = uint32_t((1ULL << k) - 1ULL);
-    const uint32_t lo = ~kmerId & mask, hi = ~(kmerId >> k) & mask;
-    const uint32_t rlo = __brev(lo) >> (32u - k), rhi = __brev(hi) >> (32u - k);
-    const uint64_t n = uint64_t(kmerId) + ((uint64_t(rhi) << k) | uint64_t(rlo));
+    const uint64_t n = uint64_t(kmerId) + uint64_t(reverseComplementKmerId(kmerId, k));
     const uint32_t m = 0x5bd1e995u;
     uint32_t h = 13477u ^ 8u;
     uint32_t w = uint32_t(n);

@@ -243,6 +243,29 @@ int shasta_mi355x_align3_batch(uint64_t readCount, const uint64_t* markersToc, c
     API_END(1)
 }
 
+int shasta_mi355x_find_markers(shasta_mi355x_ctx* c, uint64_t readCount,
+    const uint64_t* readsToc, const uint64_t* readsData, const uint64_t* baseCounts,
+    uint64_t k, const void* kmerTable, uint64_t kmerInfoStride, uint64_t isMarkerOffset,
+    const uint8_t* readFlags, int wantPacked, shasta_markers_result* result)
+{
+    API_BEGIN
+    if(!readsToc || (!readsData && readsToc[readCount]) || (!baseCounts && readCount) || !kmerTable || !result) {
+        throw std::runtime_error("find_markers: null argument");
+    }
+    if(c) {
+        findMarkers(c->impl, readCount, readsToc, readsData, baseCounts, k, kmerTable, kmerInfoStride, isMarkerOffset, readFlags, wantPacked != 0, *result);
+    } else {
+        int device = 0;
+        (void)hipGetDevice(&device);
+        shasta_mi355x_ctx temporary(device);
+        findMarkers(temporary.impl, readCount, readsToc, readsData, baseCounts, k, kmerTable, kmerInfoStride, isMarkerOffset, readFlags, wantPacked != 0, *result);
+    }
+    return 0;
+    API_END(1)
+}
+
+void shasta_mi355x_find_markers_free(shasta_markers_result* r) { if(r) findMarkersFree(*r); }
+
 int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx* c, shasta_mi355x_kernel_times* t)
 {
     API_BEGIN

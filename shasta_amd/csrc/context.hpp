@@ -58,6 +58,11 @@ void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pai
 void align3Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align3_options&, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
 void align4Free(shasta_align4_result&);
+// markers.hip: MarkerFinder on the device; the context holds the markers afterwards.
+void findMarkers(Context&, uint64_t readCount, const uint64_t* readsToc, const uint64_t* readsData, const uint64_t* baseCounts,
+    uint64_t k, const void* kmerTable, uint64_t kmerInfoStride, uint64_t isMarkerOffset, const uint8_t* readFlags,
+    bool wantPacked, shasta_markers_result&);
+void findMarkersFree(shasta_markers_result&);
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);
 void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,

@@ -15,6 +15,17 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ int laneId() { return int(threadIdx.x) & 63; }
 __device__ __forceinline__ uint64_t laneMaskLt() { return (1ULL << laneId()) - 1ULL; }
 
+// Id of the reverse complement of a k-mer (k <= 16).  A k-mer id is two k-bit planes, (high bits of
+// the k bases) << k | (low bits), first base at the plane's most significant bit
+// (/root/reference/src/ShortBaseSequence.hpp:89-105); complementing flips every bit, reversing
+// reverses each plane (:109-117).
+__device__ __forceinline__ uint32_t reverseComplementKmerId(uint32_t kmerId, uint32_t k)
+{
+    const uint32_t mask = uint32_t((1ULL << k) - 1ULL);
+    const uint32_t low = ~kmerId & mask, high = ~(kmerId >> k) & mask;
+    return ((__brev(high) >> (32u - k)) << k) | (__brev(low) >> (32u - k));
+}
+
 // ----------------------------------------------------------------------------
 // Exclusive scan.
 // ----------------------------------------------------------------------------

@@ -27,6 +27,7 @@ EXPORTS = [
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish",
     "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
+    "shasta_mi355x_find_markers", "shasta_mi355x_find_markers_free",
 ]
 
 
@@ -103,6 +104,28 @@ class Library:
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
         self._check(rc, "shasta_mi355x_align3_batch")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def find_markers(self, reads_toc, reads_data, base_counts, k, is_marker, want_packed=True, context=None, flags=None):
+        """Marker finding (MarkerFinder).  Reads as Shasta stores them (two bit planes per 64 bases),
+        is_marker = one byte per k-mer id.  -> (toc uint64[2R+1], data7 uint8[7*M] or None).  With a
+        context the markers stay resident on it, as after set_markers."""
+        rt = np.ascontiguousarray(reads_toc, dtype=np.uint64)
+        rd = np.ascontiguousarray(reads_data, dtype=np.uint64)
+        bc = np.ascontiguousarray(base_counts, dtype=np.uint64)
+        im = np.ascontiguousarray(is_marker, dtype=np.uint8)
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        res = abi.MarkersResult()
+        handle = C.c_void_p(context.handle) if context is not None else C.c_void_p(None)
+        self._check(self.lib.shasta_mi355x_find_markers(
+            handle, C.c_uint64(len(bc)), abi.as_ptr(rt, C.c_uint64), abi.as_ptr(rd, C.c_uint64), abi.as_ptr(bc, C.c_uint64),
+            C.c_uint64(k), C.c_void_p(im.ctypes.data), C.c_uint64(1), C.c_uint64(0), fp,
+            C.c_int(1 if want_packed else 0), C.byref(res)), "shasta_mi355x_find_markers")
+        toc = abi.copy_array(res.markersToc, 2 * len(bc) + 1, "<u8")
+        data = abi.copy_array(res.markersData, 7 * int(res.markerCount), "u1") if want_packed else None
+        self.lib.shasta_mi355x_find_markers_free(C.byref(res))
+        if context is not None:
+            context.read_count = len(bc)
+        return toc, data
 
     # --- unit seams -------------------------------------------------------------------
     def hash_windows(self, kmer_ids, m, iteration):

@@ -94,3 +94,12 @@ def test_stages_on_a_data_directory(emu_lib, oracle_lib, tmp_path, monkeypatch, 
     from tests import mirror_checks
     host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
     mirror_checks.stages_on_a_data_directory(oracle_lib, tmp_path, monkeypatch, host, align_method)
+
+
+def test_marker_finding(emu_lib, oracle_lib):
+    from tests import marker_checks
+    marker_checks.golden_fixture(emu_lib.find_markers)
+    for seed, k in ((1, 10), (2, 7), (5, 12)):
+        marker_checks.against_oracle(emu_lib, oracle_lib, seed, k)
+    marker_checks.resident_markers_feed_lowhash0(emu_lib)
+

@@ -38,3 +38,13 @@ def test_align3_stage_on_a_data_directory(gpu_lib, oracle_lib, tmp_path, monkeyp
     import shasta_amd.assembler as shasta
     from tests import mirror_checks
     mirror_checks.stages_on_a_data_directory(oracle_lib, tmp_path, monkeypatch, shasta.HOST_SO, 3)
+
+
+def test_marker_finding(gpu_lib, oracle_lib):
+    # SURVEY 8f row 2 (MarkerFinder): also written after the GPU closed; emulation-verified only so far.
+    from tests import marker_checks
+    marker_checks.golden_fixture(gpu_lib.find_markers)
+    for seed, k in ((1, 10), (2, 7), (5, 12)):
+        marker_checks.against_oracle(gpu_lib, oracle_lib, seed, k)
+    marker_checks.resident_markers_feed_lowhash0(gpu_lib)
+

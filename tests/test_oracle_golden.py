@@ -48,6 +48,12 @@ def test_align3_restatement_matches_reference_fixture(oracle_lib, name, i):
     support.check_align3(out, z, i)
 
 
+def test_marker_finding_restatement_matches_reference_fixture(oracle_lib):
+    # Input = what the reference's MarkerFinder read (tests/golden/make_golden_reads.py), output = tiny.npz.
+    from tests import marker_checks
+    marker_checks.golden_fixture(oracle_lib.find_markers)
+
+
 def test_codec_known_answer(oracle_lib):
     # The table of the reference's testAlignmentCompression (src/compressAlignment.cpp:160-220):
     # streak formats 2,1,2,0,2,3,4,3 => 4+2+4+1+4+8+16+8 bytes.

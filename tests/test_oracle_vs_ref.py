@@ -88,3 +88,13 @@ def test_align3_on_marker_level_reads(ref_lib, oracle_lib, seed, kw):
     support.same_align(x, y)
     assert np.array_equal(x.compressed_data, y.compressed_data)
 
+
+@pytest.mark.parametrize("k,seed", [(8, 5), (10, 6), (12, 7)])
+def test_marker_finding(ref_lib, oracle_lib, tmp_path, k, seed):
+    from shasta_amd import synthetic
+    fasta = str(tmp_path / "reads.fasta")
+    synthetic.fasta_reads(fasta, n_reads=25, genome_length=40000, mean_length=12000.0, seed=seed)
+    z = ref_lib.reads_and_markers_from_fasta(fasta, k=k, probability=0.15, seed=seed)
+    toc, data = oracle_lib.find_markers(z["reads_toc"], z["reads_data"], z["base_counts"], k, z["is_marker"])
+    assert np.array_equal(toc, z["toc"]) and np.array_equal(data, z["data7"]) and int(toc[-1]) > 10000
+
