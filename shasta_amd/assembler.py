@@ -89,6 +89,11 @@ class Assembler:
     def accessAlignmentCandidates(self):
         self._require("AlignmentCandidates")
 
+    def findMarkers(self, threadCount=0):
+        """shasta.Assembler.findMarkers (src/PythonModule.cpp; src/AssemblerMarkers.cpp:11-24)."""
+        self._require("Reads-Bases.toc", "Reads-Bases.data", "Reads-BaseCount", "Kmers")
+        self._check(self._lib.shasta_mi355x_host_find_markers(self._data.encode(), C.c_uint64(threadCount), C.c_uint64(self._page)))
+
     def findAlignmentCandidatesLowHash0(self, m, hashFraction, minHashIterationCount, alignmentCandidatesPerRead,
                                         minBucketSize, maxBucketSize, minFrequency, log2MinHashBucketCount=0, threadCount=0):
         self._check(self._lib.shasta_mi355x_host_find_alignment_candidates_lowhash0(

@@ -268,6 +268,36 @@ uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignment
     return keepCount;
 }
 
+void findMarkers(const std::string& dataDirectory, size_t /* threadCount */, size_t largeDataPageSize)
+{
+    struct KmerInfo24 { char bytes[24]; };                 // src/Kmer.hpp:22-39: isMarker is byte 12
+    ReadBases bases;
+    bases.accessExistingReadOnly(dataName(dataDirectory, "Reads-Bases"));
+    ReadBaseCounts baseCounts;
+    baseCounts.accessExistingReadOnly(dataName(dataDirectory, "Reads-BaseCount"));
+    MappedVector<KmerInfo24> kmers;
+    kmers.accessExistingReadOnly(dataName(dataDirectory, "Kmers"));
+    const uint64_t readCount = baseCounts.size();
+    if(bases.size() != readCount) throw std::runtime_error("findMarkers: Reads-Bases and Reads-BaseCount disagree.");
+    uint64_t k = 0;
+    while(k < 32 && (1ULL << (2 * k)) < kmers.size()) ++k;
+    if(kmers.size() == 0 || (1ULL << (2 * k)) != kmers.size()) throw std::runtime_error("findMarkers: Data/Kmers does not hold 4^k entries.");
+
+    shasta_markers_result r{};
+    if(shasta_mi355x_find_markers(nullptr, readCount, bases.toc.begin(), bases.data.begin(), baseCounts.begin(),
+        k, kmers.begin(), sizeof(KmerInfo24), 12, nullptr, 1, &r)) {
+        throw std::runtime_error(shasta_mi355x_last_error());
+    }
+    Markers markers;
+    markers.createNew(dataName(dataDirectory, "Markers"), largeDataPageSize);                                // :16
+    for(uint64_t i = 0; i < 2 * readCount; i++) {
+        markers.appendVector(reinterpret_cast<const CompressedMarker7*>(r.markersData + 7 * r.markersToc[i]),
+            r.markersToc[i + 1] - r.markersToc[i]);
+    }
+    shasta_mi355x_find_markers_free(&r);
+    markers.unreserve();                                                                                     // MarkerFinder.cpp:49
+}
+
 // The marker length k of the run, from the size of Data/Kmers (Vector<KmerInfo>, 24-byte entries,
 // one per k-mer id: 4^k of them, src/AssemblerKmers.cpp:147-186).  Method 3 needs it for the
 // down-sampling hash, which the library recomputes from the k-mer id instead of reading the table.

@@ -6,6 +6,7 @@
 //   findAlignmentCandidatesLowHash0   <-> Assembler::findAlignmentCandidatesLowHash0   src/AssemblerLowHash.cpp:10-55
 //   computeAlignments                 <-> Assembler::computeAlignments (alignMethod 3 or 4)  src/AssemblerAlign.cpp:208-304
 //   computeAlignmentTable             <-> Assembler::computeAlignmentTable    src/AssemblerAlign.cpp:509-571
+//   findMarkers                       <-> Assembler::findMarkers              src/AssemblerMarkers.cpp:11-24
 //   computeCandidateTable             <-> AlignmentCandidates::computeCandidateTable    src/AssemblerAlignmentCandidates.cpp:388-447
 //   createReadGraph                   <-> Assembler::createReadGraph          src/AssemblerReadGraph.cpp:35-157
 #pragma once
@@ -78,6 +79,12 @@ void findAlignmentCandidatesLowHash0(
     size_t threadCount, size_t largeDataPageSize = 4096);
 
 void computeAlignments(const std::string& dataDirectory, const AlignOptions&, size_t threadCount, size_t largeDataPageSize = 4096);
+
+// Assembler::findMarkers (src/AssemblerMarkers.cpp:11-24): Reads-Bases.{toc,data} + Reads-BaseCount + Kmers
+// -> Markers.{toc,data}.  The step that produces the input of the two seams above.
+using ReadBases = MappedVectorOfVectors<uint64_t, uint64_t>;                 // Data/Reads-Bases.{toc,data} (src/LongBaseSequence.hpp:298-301)
+using ReadBaseCounts = MappedVector<uint64_t>;                               // Data/Reads-BaseCount
+void findMarkers(const std::string& dataDirectory, size_t threadCount, size_t largeDataPageSize = 4096);
 
 // AlignmentCandidates::computeCandidateTable (src/AssemblerAlignmentCandidates.cpp:388-447): the step the
 // reference runs between the two seams (srcMain/main.cpp:706).  Host work: a CSR index + per-row sort.

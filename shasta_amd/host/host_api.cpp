@@ -28,6 +28,14 @@ int shasta_mi355x_host_find_alignment_candidates_lowhash0(
     HOST_END
 }
 
+// Assembler::findMarkers, src/AssemblerMarkers.cpp:11-24.
+int shasta_mi355x_host_find_markers(const char* dataDirectory, uint64_t threadCount, uint64_t largeDataPageSize)
+{
+    HOST_BEGIN
+    findMarkers(dataDirectory, threadCount, largeDataPageSize);
+    HOST_END
+}
+
 // Assembler::computeCandidateTable, src/AssemblerAlignmentCandidates.cpp:379-447.
 int shasta_mi355x_host_compute_candidate_table(const char* dataDirectory, uint64_t largeDataPageSize)
 {

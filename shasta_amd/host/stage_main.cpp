@@ -26,6 +26,9 @@ int main(int argc, char** argv)
             findAlignmentCandidatesLowHash0(data,
                 std::stoull(arg(3, "4")), std::stod(arg(4, "0.01")), std::stoull(arg(5, "10")), std::stod(arg(6, "20")),
                 std::stoull(arg(7, "0")), std::stoull(arg(8, "0")), std::stoull(arg(9, "10")), std::stoull(arg(10, "2")), 0);
+        } else if(command == "markers") {
+            // Assembler::findMarkers (srcMain/main.cpp: the step before the two seams).
+            findMarkers(data, 0);
         } else if(command == "candidate-table") {
             // Assembler::computeCandidateTable, between the two seams (srcMain/main.cpp:706).
             Markers markers;

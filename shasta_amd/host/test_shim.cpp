@@ -83,15 +83,33 @@ int host_store_alignments(const char* dir, uint64_t alignmentCount, const shasta
     SHIM_END
 }
 
-// Data/Kmers with the 4^k entries of a run with marker length k (contents zero: only the size is read).
-int host_write_kmers(const char* dir, uint64_t k)
+// Data/Kmers with the 4^k entries of a run with marker length k: zero except the isMarker byte
+// (offset 12 of KmerInfo, src/Kmer.hpp:22-39) when isMarker is given.
+int host_write_kmers(const char* dir, uint64_t k, const uint8_t* isMarker)
 {
     SHIM_BEGIN
     MappedVector< Blob<24> > kmers;
     kmers.createNew(std::string(dir) + "/Kmers");
     kmers.resize(1ULL << (2 * k));
     std::memset(kmers.begin(), 0, 24 * kmers.size());
+    if(isMarker) for(uint64_t i = 0; i < kmers.size(); i++) kmers[i].bytes[12] = char(isMarker[i] ? 1 : 0);
     kmers.unreserve();
+    SHIM_END
+}
+
+// Data/Reads-Bases.{toc,data} and Data/Reads-BaseCount (LongBaseSequences, src/LongBaseSequence.cpp:8-20).
+int host_write_reads(const char* dir, uint64_t readCount, const uint64_t* readsToc, const uint64_t* readsData, const uint64_t* baseCounts)
+{
+    SHIM_BEGIN
+    const std::string d(dir);
+    ReadBases bases;
+    bases.createNew(d + "/Reads-Bases");
+    for(uint64_t r = 0; r < readCount; r++) bases.appendVector(readsData + readsToc[r], readsToc[r + 1] - readsToc[r]);
+    bases.unreserve();
+    ReadBaseCounts counts;
+    counts.createNew(d + "/Reads-BaseCount");
+    counts.append(baseCounts, readCount);
+    counts.unreserve();
     SHIM_END
 }
 

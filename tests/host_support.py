@@ -42,8 +42,16 @@ class HostShim:
         self._check(self.lib.host_store_alignments(directory.encode(), C.c_uint64(len(rows)), C.c_void_p(rows.ctypes.data),
                                                    abi.as_ptr(toc, C.c_uint64), C.c_void_p(data.ctypes.data)), "host_store_alignments")
 
-    def write_kmers(self, directory, k):
-        self._check(self.lib.host_write_kmers(directory.encode(), C.c_uint64(k)), "host_write_kmers")
+    def write_kmers(self, directory, k, is_marker=None):
+        im = abi.as_ptr(np.ascontiguousarray(is_marker, np.uint8), C.c_uint8) if is_marker is not None else None
+        self._check(self.lib.host_write_kmers(directory.encode(), C.c_uint64(k), im), "host_write_kmers")
+
+    def write_reads(self, directory, reads_toc, reads_data, base_counts):
+        rt = np.ascontiguousarray(reads_toc, np.uint64)
+        rd = np.ascontiguousarray(reads_data, np.uint64)
+        bc = np.ascontiguousarray(base_counts, np.uint64)
+        self._check(self.lib.host_write_reads(directory.encode(), C.c_uint64(len(bc)), abi.as_ptr(rt, C.c_uint64),
+                                              abi.as_ptr(rd, C.c_uint64), abi.as_ptr(bc, C.c_uint64)), "host_write_reads")
 
     def store_candidates(self, directory, candidates):
         c = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)

@@ -47,3 +47,23 @@ def stages_on_a_data_directory(oracle_lib, tmp_path, monkeypatch, host_library, 
     a.accessAlignmentData()
     a.createReadGraph(6, 30)
     assert os.path.exists(os.path.join(d, "ReadGraphEdges"))
+
+
+def find_markers_on_a_data_directory(tmp_path, host_library):
+    """Reads-Bases / Reads-BaseCount / Kmers in, Markers.{toc,data} out: the files the reference's
+    findMarkers wrote for the same reads (tiny.npz)."""
+    from tests import marker_checks
+    rt, rd, bc, im = marker_checks.tiny_reads()
+    g = support.Golden("tiny.npz")
+    d = str(tmp_path / "Data")
+    os.makedirs(d)
+    shim = host_support.HostShim()
+    shim.write_reads(d, rt, rd, bc)
+    shim.write_kmers(d, 10, im)
+    a = shasta.Assembler(d, hostLibrary=host_library)
+    a.findMarkers()
+    toc, _ = shim.open_vector(os.path.join(d, "Markers.toc"), 8)
+    data, _ = shim.open_vector(os.path.join(d, "Markers.data"), 7)
+    assert np.array_equal(toc.view("<u8").reshape(-1), g.toc)
+    assert np.array_equal(data.reshape(-1), g.data7)
+

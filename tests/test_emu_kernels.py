@@ -103,3 +103,10 @@ def test_marker_finding(emu_lib, oracle_lib):
         marker_checks.against_oracle(emu_lib, oracle_lib, seed, k)
     marker_checks.resident_markers_feed_lowhash0(emu_lib)
 
+
+def test_find_markers_on_a_data_directory(emu_lib, tmp_path):
+    import os
+    from tests import mirror_checks
+    host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
+    mirror_checks.find_markers_on_a_data_directory(tmp_path, host)
+

@@ -48,3 +48,9 @@ def test_marker_finding(gpu_lib, oracle_lib):
         marker_checks.against_oracle(gpu_lib, oracle_lib, seed, k)
     marker_checks.resident_markers_feed_lowhash0(gpu_lib)
 
+
+def test_find_markers_stage_on_a_data_directory(gpu_lib, tmp_path):
+    import shasta_amd.assembler as shasta
+    from tests import mirror_checks
+    mirror_checks.find_markers_on_a_data_directory(tmp_path, shasta.HOST_SO)
+
