@@ -1914,12 +1914,14 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             // deltaX, deltaY >= 2 here (packedOk fails for 1 x anything >= 2046... and d = 1 gives magic 2^32): guard.
             const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX + 1, 0xffffffffULL));
             const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY + 1, 0xffffffffULL));
-            b.pairList.reserve(2ULL * n + 16, stream);
+            // Every candidate is a member once, plus once per class it climbs to after an overflow.
+            const uint64_t memberCapacity = uint64_t(CELLS_CLASSES) * n + 16;
+            b.pairList.reserve(memberCapacity, stream);
             size_t membersUploaded = 0;
             for(int round = 0; round < CELLS_CLASSES; round++) {
                 bool any = false;
                 if(members.size() > membersUploaded) {
-                    MI355X_ASSERT(members.size() <= 2ULL * n + 16);
+                    MI355X_ASSERT(members.size() <= memberCapacity);
                     HIP_CHECK(hipMemcpyAsync(b.pairList.data() + membersUploaded, members.data() + membersUploaded,
                         (members.size() - membersUploaded) * 4, hipMemcpyHostToDevice, stream));
                     membersUploaded = members.size();

@@ -110,3 +110,9 @@ def test_find_markers_on_a_data_directory(emu_lib, tmp_path):
     host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
     mirror_checks.find_markers_on_a_data_directory(tmp_path, host)
 
+
+def test_adversarial_inputs(emu_lib, oracle_lib):
+    from tests import adversarial
+    adversarial.aligners(emu_lib, oracle_lib, long_reads=False)
+    adversarial.lowhash0(emu_lib, oracle_lib)
+
