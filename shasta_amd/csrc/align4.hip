@@ -851,7 +851,7 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
     uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long cells = 0, words = 0;
+    unsigned long long cells = 0, words = 0, bytes = 0;
     int cls = -1;
     if(t < taskCount) {
         const DpTask task = tasks[t];
@@ -863,20 +863,23 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
         ordCap[t] = min(pd.nx, pd.ny);
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
         words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls)) + 32;
+        bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
     } else if(t == taskCount) {
         ordCap[t] = 0;
     }
+    // Per class: one atomic per wavefront and class present in it (tasks of a wave mostly share a
+    // class after the cells kernels); one atomic per task serialises the whole launch on six addresses.
 #pragma unroll
     for(int c = 0; c < DP_CLASSES; c++) {
         const uint64_t votes = __ballot(cls == c);
-        if(votes && laneId() == __ffsll((unsigned long long)votes) - 1) atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
-    }
-    if(cls >= 0) {
-        // Per class (rare contention: tasks of a wave mostly share a class after the cells kernels).
-        const DpTask task = tasks[t];
-        const PairDesc pd = pairs[task.pair];
-        atomicAdd(&sums[2 + cls], cells);
-        atomicAdd(&sums[8 + cls], 4ULL * (uint64_t(pd.nx) + pd.ny));
+        if(votes == 0) continue;
+        unsigned long long classCells = cls == c ? cells : 0, classBytes = cls == c ? bytes : 0;
+        for(int d = 32; d >= 1; d >>= 1) { classCells += __shfl_down(classCells, d, WAVE); classBytes += __shfl_down(classBytes, d, WAVE); }
+        if(laneId() == 0) {
+            atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
+            atomicAdd(&sums[2 + c], classCells);
+            atomicAdd(&sums[8 + c], classBytes);
+        }
     }
     for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
     if(laneId() == 0 && cells) { atomicAdd(&sums[0], cells); atomicAdd(&sums[1], words); }
@@ -1726,7 +1729,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
         }
-        const uint32_t taskCapacity = 8 * n + 1024;
+        // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
+        // SHASTA_MI355X_INITIAL_TASKS overrides the first guess (tests use it to force the second run).
+        uint32_t taskCapacity = 8 * n + 1024;
+        if(const char* e = std::getenv("SHASTA_MI355X_INITIAL_TASKS")) taskCapacity = uint32_t(std::max(1L, std::atol(e)));
         b.pairs.reserve(n, stream); b.candidates.reserve(n, stream); b.tasks.reserve(taskCapacity, stream);
         b.counters.reserve(16, stream); b.pairFlags.reserve(n, stream); b.pairTie.reserve(n, stream); b.status.reserve(n, stream);
         b.pairBest.reserve(n, stream); b.dpCells.reserve(1, stream); b.pairWinner.reserve(n, stream);
@@ -1743,6 +1749,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
 
+        uint32_t taskCount = 0;
+        for(;;) {
         if(m3) {
             // Method 3, step 1: every diagonal of the down-sampled pair, then the band of step 2.
             std::vector<PairDesc> dsPairs(n);
@@ -2014,8 +2022,18 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 bigList.swap(nextList); bigLog2.swap(nextLog2);
             }
         }
-        const uint32_t taskCount = readDevice(b.counters.data(), stream);
-        if(taskCount > taskCapacity) throw std::runtime_error("Align4: task list overflow.");
+        taskCount = readDevice(b.counters.data(), stream);
+        if(taskCount <= taskCapacity) break;
+        // More DP tasks than the list was sized for (many small components per candidate: low-complexity
+        // reads, or options that keep nearly every cell).  The count is exact -- stores past the
+        // capacity were dropped, the counter was not -- so the stage runs once more with room for all.
+        if(m3) throw std::runtime_error("Align3: task list overflow.");
+        if(std::getenv("SHASTA_MI355X_DEBUG")) std::fprintf(stderr, "cells: %u DP tasks exceed the capacity %u: running the stage again\n", taskCount, taskCapacity);
+        taskCapacity = taskCount + 1024;
+        b.tasks.reserve(taskCapacity, stream);
+        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 8 * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(b.pairFlags.data(), 0, n, stream));
+        }
 
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount) {

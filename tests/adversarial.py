@@ -100,3 +100,22 @@ def lowhash0(lib, oracle_lib):
                      ([g[:600]] * 40, P(minBucketSize=2, maxBucketSize=100, minFrequency=2))):
         t, _, d = build(reads)
         support.same_lowhash(lib.lowhash0(t, d, None, p), oracle_lib.lowhash0(t, d, None, p))
+
+
+def task_list_overflow(lib, oracle_lib, monkeypatch):
+    """More DP tasks than the list was sized for (in production: thousands of small components per
+    batch, e.g. minEntryCountPerCell = 1 on repeat-rich reads): the cells stage runs again with the
+    exact count.  Forced here by a tiny first guess."""
+    toc, kmer, data7 = support.small_marker_set(n_reads=100, genome_markers=8000, seed=9)
+    p = abi.default_lowhash0_params(minBucketSize=3, maxBucketSize=30, minFrequency=2)
+    cand = oracle_lib.lowhash0(toc, data7, None, p).candidates[:300]
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    ref = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+    monkeypatch.setenv("SHASTA_MI355X_INITIAL_TASKS", "7")
+    out = lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
+    monkeypatch.delenv("SHASTA_MI355X_INITIAL_TASKS")
+    assert (ref.status == abi.SHASTA_ALIGN_STORED).sum() > 100
+    if not (ref.status & 0x80).any():
+        support.same_align(ref, out)
+    assert out.dp_cell_count == ref.dp_cell_count
+

@@ -52,6 +52,12 @@ def test_lowhash0_and_align4(emu_lib, oracle_lib):
     o = abi.default_align4_options(minAlignedMarkerCount=40)
     x = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
     y = emu_lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
+    assert y.dp_cell_count == x.dp_cell_count and y.kmer_id_bytes == x.kmer_id_bytes     # dpSizeKernel's sums
+    with emu_lib.context(0) as ctx:
+        ctx.set_kmer_ids(toc, kmer)
+        z = ctx.align4(cand, o)
+        t = ctx.kernel_times()
+    assert sum(t.dpForwardCells) == z.dp_cell_count == x.dp_cell_count and sum(t.dpForwardBytes) > 0
     if not (x.status & 0x80).any():
         support.same_align(x, y)
     else:
@@ -111,8 +117,9 @@ def test_find_markers_on_a_data_directory(emu_lib, tmp_path):
     mirror_checks.find_markers_on_a_data_directory(tmp_path, host)
 
 
-def test_adversarial_inputs(emu_lib, oracle_lib):
+def test_adversarial_inputs(emu_lib, oracle_lib, monkeypatch):
     from tests import adversarial
     adversarial.aligners(emu_lib, oracle_lib, long_reads=False)
     adversarial.lowhash0(emu_lib, oracle_lib)
+    adversarial.task_list_overflow(emu_lib, oracle_lib, monkeypatch)
 

@@ -55,8 +55,9 @@ def test_find_markers_stage_on_a_data_directory(gpu_lib, tmp_path):
     mirror_checks.find_markers_on_a_data_directory(tmp_path, shasta.HOST_SO)
 
 
-def test_adversarial_inputs(gpu_lib, oracle_lib):
+def test_adversarial_inputs(gpu_lib, oracle_lib, monkeypatch):
     from tests import adversarial
     adversarial.aligners(gpu_lib, oracle_lib)
     adversarial.lowhash0(gpu_lib, oracle_lib)
+    adversarial.task_list_overflow(gpu_lib, oracle_lib, monkeypatch)
 
