@@ -70,6 +70,7 @@ def traffic_of(table, kernel_name):
 
 
 TRAFFIC_WORKLOAD = {"reads": None}
+DRY_RUN_LIBRARY = os.environ.get("SHASTA_BENCH_LIBRARY")      # see main(): pre-flight without a GPU, never a result
 
 
 def available_memory_gib():
@@ -106,7 +107,9 @@ def cpu_baseline(n_reads_sample, seed):
         n1, n2 = min(len(cand), 4000), min(len(cand), 24000)
         t1 = lib.align4_batch(toc, data7, cand[:n1], o, want_ordinals=False, threads=cores).seconds
         t2 = lib.align4_batch(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores).seconds
-        per_pair = (t2 - t1) / max(1, n2 - n1) if n2 > n1 else t2 / max(1, n2)
+        per_pair = (t2 - t1) / (n2 - n1) if n2 > n1 else 0.0
+        if per_pair <= 0.0:                                 # too few candidates for the difference to mean anything
+            per_pair = t2 / max(1, n2)
     else:
         if not bindings.oracle_available():
             import subprocess
@@ -166,9 +169,18 @@ def main():
         dist.init_process_group(os.environ.get("SHASTA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         dist = None
-        torch.cuda.set_device(0)
+        if not DRY_RUN_LIBRARY:
+            torch.cuda.set_device(0)
 
-    lib = shasta_amd.load()
+    if DRY_RUN_LIBRARY:
+        # Pre-flight of THIS SCRIPT on a machine without a GPU: SHASTA_BENCH_LIBRARY names the emulated
+        # build of the library (tests/emu: kernel sources on CPU fibers).  The line it prints is marked
+        # as a dry run and is never a measurement.
+        from shasta_amd import lib as libmod
+        assert world == 1, "the dry run covers the single-GPU path"
+        lib = libmod.Library(DRY_RUN_LIBRARY)
+    else:
+        lib = shasta_amd.load()
     assert lib.device_count() >= 1, "no gfx950 device: the HIP path cannot run (there is no CPU fallback)"
     p, o = lowhash_params(), align_options()
     ctx = lib.context(local_rank)
@@ -226,7 +238,8 @@ def main():
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not DRY_RUN_LIBRARY:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -327,7 +340,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32/i32 (integer hash + integer DP)",
-            "data": "synthetic",
+            "data": "synthetic" if not DRY_RUN_LIBRARY else "synthetic; DRY RUN ON THE EMULATED BUILD - NOT A MEASUREMENT",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic ONT-like reads, marker level, %d reads/GPU, "
                             "mean 1500 markers (~20 kb) per oriented read, 45x coverage; LowHash0 m=4 f=0.01 "
@@ -344,7 +357,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(max(2000, args.reads // 10), 777)
+            out["cpu_baseline"] = cpu_baseline(max(2000, args.reads // 10) if not DRY_RUN_LIBRARY else 300, 777)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out))
     ctx.close()

@@ -84,3 +84,24 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys):
     assert d["kernels"]["hashWindowsKernel<4>"]["launches_per_step"] == 10
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 64
     assert d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)
+
+
+def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
+    """The real bench.py, real library calls (emulated build), real CPU baseline: every key of the
+    driver's contract, the roofline and cpu_baseline objects, and the dry-run marker."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "150", "--steps", "1", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert "NOT A MEASUREMENT" in line["data"] and line["n_gpus"] == 1 and line["value"] > 0
+    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(line["roofline"])
+    assert set(["value", "unit", "cores", "kind", "sample"]) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["value"] > 0
+    assert line["config"]["candidates"] > 0 and "workload" in line["config"]
+
