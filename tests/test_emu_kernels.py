@@ -123,3 +123,8 @@ def test_adversarial_inputs(emu_lib, oracle_lib, monkeypatch):
     adversarial.lowhash0(emu_lib, oracle_lib)
     adversarial.task_list_overflow(emu_lib, oracle_lib, monkeypatch)
 
+
+def test_smoke_body(emu_lib):
+    import __graft_entry__
+    __graft_entry__.smoke_on(emu_lib)
+
