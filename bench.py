@@ -163,10 +163,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         # SHASTA_BENCH_BACKEND=gloo + SHASTA_BENCH_ONE_DEVICE=1: functional test of the multi-rank path
         # on a box with one GPU (host-staged transport, every rank on cuda:0); never used for numbers.
-        if os.environ.get("SHASTA_BENCH_ONE_DEVICE"):
+        if os.environ.get("SHASTA_BENCH_ONE_DEVICE") or DRY_RUN_LIBRARY:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(os.environ.get("SHASTA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        if not DRY_RUN_LIBRARY:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo" if DRY_RUN_LIBRARY else os.environ.get("SHASTA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         dist = None
         if not DRY_RUN_LIBRARY:
@@ -177,7 +178,6 @@ def main():
         # build of the library (tests/emu: kernel sources on CPU fibers).  The line it prints is marked
         # as a dry run and is never a measurement.
         from shasta_amd import lib as libmod
-        assert world == 1, "the dry run covers the single-GPU path"
         lib = libmod.Library(DRY_RUN_LIBRARY)
     else:
         lib = shasta_amd.load()
@@ -205,7 +205,7 @@ def main():
         # LowHash0 runs sharded with its two all-to-all exchanges, the candidate list is re-split
         # evenly for Align4.  Setup (generation, all-gather) is outside the timed region.
         from shasta_amd import distributed, synthetic
-        device = torch.device("cuda", local_rank)
+        device = torch.device("cuda", local_rank) if not DRY_RUN_LIBRARY else torch.device("cpu")
         genome_markers = max(20000, int(round(world * args.reads * 1500 / 45.0)))
         toc_s, kmer_s = synthetic.marker_reads(args.reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
                                                keep_probability=0.8, spurious_probability=0.25, k=10, seed=12345,
@@ -219,7 +219,8 @@ def main():
         mine = torch.from_numpy(kmer_s.view(np.int32)).to(device)
         everything = distributed.all_gather_padded(mine, shard_markers)    # C3: every GPU gets every read's kmer ids
         del mine, kmer_s
-        torch.cuda.synchronize()
+        if not DRY_RUN_LIBRARY:
+            torch.cuda.synchronize()
         ctx.set_kmer_ids_device(toc, everything.data_ptr())
         del everything
         marker_count = int(toc[-1])

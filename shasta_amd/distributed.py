@@ -62,15 +62,19 @@ class HipBackend:
         n = int(offsets[-1])
         return offsets, self._tensor_from(keys, n, torch.int32), self._tensor_from(vals, n, torch.int64)
 
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def buckets(self, keys, vals):
-        torch.cuda.synchronize(self.device)
+        self._sync()
         n = keys.numel()
         offsets, rk, rc, used, hist, overflow = self.ctx.lh_buckets(keys.data_ptr() if n else 0, vals.data_ptr() if n else 0, n)
         m = int(offsets[-1])
         return offsets, self._tensor_from(rk, m, torch.int64), self._tensor_from(rc, m, torch.int32), used, hist, overflow
 
     def merge(self, run_keys, run_counts):
-        torch.cuda.synchronize(self.device)
+        self._sync()
         n = run_keys.numel()
         return self.ctx.lh_merge(run_keys.data_ptr() if n else 0, run_counts.data_ptr() if n else 0, n)
 

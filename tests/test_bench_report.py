@@ -105,3 +105,27 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert set(["value", "unit", "cores", "kind", "sample"]) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["value"] > 0
     assert line["config"]["candidates"] > 0 and "workload" in line["config"]
 
+
+def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):
+    """The N > 1 path of the real bench.py as the driver launches it (torch.distributed.run, one process
+    per rank): sharded generation, all-gather of the kmer ids, staged LowHash0 with both exchanges,
+    candidate re-split, Align4 -- on the emulated build over gloo.  Control flow only."""
+    import os
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, HIPEMU_THREADS="4")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "150"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line
+    assert line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0
+
