@@ -128,3 +128,10 @@ def test_smoke_body(emu_lib):
     import __graft_entry__
     __graft_entry__.smoke_on(emu_lib)
 
+
+def test_two_ranks_equal_single_process_oracle(emu_lib, oracle_lib):
+    # The sharded job (staged lh_* entry points, both exchanges, candidate re-split) on two ranks.
+    from tests import dist_checks
+    seed, kw = dist_checks.CASES[0]
+    dist_checks.two_ranks_equal_single_process_oracle(oracle_lib, seed, kw, library_path=emu_lib.path, port_base=29800)
+
