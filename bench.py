@@ -44,6 +44,13 @@ def lowhash_params():
     return abi.default_lowhash0_params(minBucketSize=5, maxBucketSize=30, minFrequency=5)
 
 
+def align3_options():
+    # alignMethod 3 with the values of the shipped Nanopore configurations (downsamplingFactor 0.05) on
+    # top of the defaults of src/AssemblerOptions.cpp:419-449; k = 10 as the synthetic marker alphabet.
+    from shasta_amd import abi
+    return abi.default_align3_options(downsamplingFactor=0.05)
+
+
 def align_options():
     from shasta_amd import abi
     return abi.default_align4_options()
@@ -85,7 +92,7 @@ def available_memory_gib():
     return 1 << 20
 
 
-def cpu_baseline(n_reads_sample, seed):
+def cpu_baseline(n_reads_sample, seed, align_method=4):
     """Reference CPU path on a bounded sample of the same workload (1/10 scale, same coverage)."""
     from oracle import bindings
     from shasta_amd import synthetic
@@ -96,7 +103,7 @@ def cpu_baseline(n_reads_sample, seed):
     cores = min(os.cpu_count() or 1, 64, max(1, available_memory_gib() // 4))
     toc, kmer = make_workload(n_reads_sample, seed)
     data7 = synthetic.pack_markers(toc, kmer)
-    p, o = lowhash_params(), align_options()
+    p, o = lowhash_params(), (align_options() if align_method == 4 else align3_options())
     if bindings.ref_available():
         lib, kind = bindings.RefLib(), "reference"
         lh = lib.lowhash0(toc, data7, None, p, threads=cores)
@@ -105,8 +112,9 @@ def cpu_baseline(n_reads_sample, seed):
         # The per-thread 2 GiB arena of the reference is a fixed setup cost (seconds): time two
         # sample sizes and use the incremental rate.
         n1, n2 = min(len(cand), 4000), min(len(cand), 24000)
-        t1 = lib.align4_batch(toc, data7, cand[:n1], o, want_ordinals=False, threads=cores).seconds
-        t2 = lib.align4_batch(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores).seconds
+        align = lib.align4_batch if align_method == 4 else lib.align3_batch
+        t1 = align(toc, data7, cand[:n1], o, want_ordinals=False, threads=cores).seconds
+        t2 = align(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores).seconds
         per_pair = (t2 - t1) / (n2 - n1) if n2 > n1 else 0.0
         if per_pair <= 0.0:                                 # too few candidates for the difference to mean anything
             per_pair = t2 / max(1, n2)
@@ -121,7 +129,7 @@ def cpu_baseline(n_reads_sample, seed):
         cand = lh.candidates
         n2 = min(len(cand), 24000)
         t0 = time.time()
-        lib.align4_batch(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores)
+        (lib.align4_batch if align_method == 4 else lib.align3_batch)(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores)
         per_pair = (time.time() - t0) / max(1, n2)
     pairs = len(cand)
     total = t_lh + pairs * per_pair
@@ -131,11 +139,11 @@ def cpu_baseline(n_reads_sample, seed):
         "cores": cores,
         "kind": kind,
         "sample": "%d reads (1/10-scale workload, same 45x coverage, M=%d markers): LowHash0 %.2f s on %d threads "
-                  "-> %d candidates; Align4 %.3f ms/candidate incremental over %d candidates on %d threads "
+                  "-> %d candidates; align method %d %.3f ms/candidate incremental over %d candidates on %d threads "
                   "(restated DP, reference control flow)" % (
-                      n_reads_sample, int(toc[-1]), t_lh, cores, pairs, per_pair * 1e3, n2, cores),
+                      n_reads_sample, int(toc[-1]), t_lh, cores, pairs, align_method, per_pair * 1e3, n2, cores),
         "lowhash0_seconds": t_lh,
-        "align4_seconds_per_pair": per_pair,
+        "align_seconds_per_pair": per_pair,
     }
 
 
@@ -147,6 +155,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lowhash-only", action="store_true", help="BASELINE configs[1]")
+    ap.add_argument("--align-method", type=int, default=4, choices=[3, 4],
+                    help="4 = Align4 (BASELINE's metric, the default); 3 = the reference's default method, for comparison")
     args = ap.parse_args()
 
     import torch
@@ -182,8 +192,13 @@ def main():
     else:
         lib = shasta_amd.load()
     assert lib.device_count() >= 1, "no gfx950 device: the HIP path cannot run (there is no CPU fallback)"
-    p, o = lowhash_params(), align_options()
+    p, o = lowhash_params(), (align_options() if args.align_method == 4 else align3_options())
     ctx = lib.context(local_rank)
+
+    def align(candidates):
+        if args.align_method == 4:
+            return ctx.align4(candidates, o, want_ordinals=False, borrow=True)
+        return ctx.align3(candidates, o, want_ordinals=False, borrow=True)
 
     if world == 1:
         # Workload: BASELINE configs[2].
@@ -196,7 +211,7 @@ def main():
             lh = ctx.lowhash0(p)
             if args.lowhash_only:
                 return lh, None, len(lh.candidates)
-            al = ctx.align4(lh.candidates, o, want_ordinals=False, borrow=True)
+            al = align(lh.candidates)
             return lh, al, len(lh.candidates)
     else:
         # ONE job over all GPUs (weak scaling: `reads` reads per GPU of one read set at the same
@@ -233,7 +248,7 @@ def main():
             share, total = distributed.candidate_share(lh.candidates, device)
             if args.lowhash_only:
                 return lh, None, total
-            al = ctx.align4(share, o, want_ordinals=False, borrow=True)
+            al = align(share)
             return lh, al, total
 
     def sync():
@@ -329,7 +344,8 @@ def main():
                 kernels["dpTracebackKernel<32>"] = {"launches_per_step": tb_n // steps, "avg_ms": tb_s / tb_n * 1e3,
                                                     "seconds_per_step": tb_s / steps}
         out = {
-            "metric": "candidate read-pairs aligned/sec (LowHash0+Align4)" if not args.lowhash_only
+            "metric": ("candidate read-pairs aligned/sec (LowHash0+Align4)" if args.align_method == 4
+                       else "candidate read-pairs aligned/sec (LowHash0+align method 3)") if not args.lowhash_only
                       else "candidate read-pairs found/sec (LowHash0 only)",
             "value": value,
             "unit": "pairs/s",
@@ -345,7 +361,9 @@ def main():
             "config": {
                 "workload": "BASELINE configs[2]: synthetic ONT-like reads, marker level, %d reads/GPU, "
                             "mean 1500 markers (~20 kb) per oriented read, 45x coverage; LowHash0 m=4 f=0.01 "
-                            "10 iterations 5/30/5; Align4 200/10/10/100, maxBand 1000, 6/-1/-1" % args.reads,
+                            "10 iterations 5/30/5; %s" % (args.reads, "Align4 200/10/10/100, maxBand 1000, 6/-1/-1"
+                                                          if args.align_method == 4 else
+                                                          "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"),
                 "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
                 "parallelism": "1 GPU" if world == 1 else
@@ -358,7 +376,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(max(2000, args.reads // 10) if not DRY_RUN_LIBRARY else 300, 777)
+            out["cpu_baseline"] = cpu_baseline(max(2000, args.reads // 10) if not DRY_RUN_LIBRARY else 300, 777, args.align_method)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out))
     ctx.close()

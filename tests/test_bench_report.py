@@ -62,7 +62,7 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys):
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
     monkeypatch.setattr(shasta_amd, "load", lambda: FakeLibrary())
     monkeypatch.setattr(bench, "make_workload", lambda reads, seed: (np.zeros(2 * 10 + 1, np.uint64), np.zeros(0, np.uint32)))
-    monkeypatch.setattr(bench, "cpu_baseline", lambda reads, seed: {"value": 18000.0, "unit": "candidate read-pairs aligned/s",
+    monkeypatch.setattr(bench, "cpu_baseline", lambda reads, seed, method=4: {"value": 18000.0, "unit": "candidate read-pairs aligned/s",
                                                                      "cores": 64, "kind": "reference", "sample": "fake"})
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--reads", "100000"])
