@@ -1,0 +1,39 @@
+#!/bin/bash
+# usage: scripts/gpu_first_call.sh [reads]   (ONE gpurun call, about 12 GPU-minutes at 100k reads)
+# The first thing to run when a GPU is available again: everything that was written while the GPU was
+# closed has only run on the emulated build.  In order, each step under its own
+# timeout so that a hang cannot reach gpurun's limit:
+#   1. the -m gpu suite file by file (validated files first, the new ones last), so that one failure
+#      does not hide the rest;
+#   2. bench.py for BASELINE's metric (method 4), then the comparison line for method 3;
+#   3. rocprofv3 kernel-trace stats of both (copy the CSVs you keep into profiles/).
+READS=${1:-100000}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+echo "host: $(nproc) cores, $(free -g | awk '/Mem:/{print $2" GiB RAM, "$7" GiB available"}')"
+for f in tests/test_gpu_lowhash0.py tests/test_gpu_align4.py tests/test_gpu_host_stages.py tests/test_gpu_distributed.py \
+         tests/test_gpu_zz_assembler_mirror.py tests/test_gpu_zzz_align3.py tests/test_gpu_zz_large_properties.py; do
+  echo "== $f"
+  timeout 900 python -m pytest $f -q -m gpu --timeout 300 2>&1 | tail -4
+done
+for M in 4 3; do
+  timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --align-method $M --no-cpu-baseline > gpurun_out/bench_m$M.json 2> gpurun_out/bench_m$M.err
+  echo "bench method $M rc=$?"; tail -c 400 gpurun_out/bench_m$M.err
+done
+cd /tmp && export TMPDIR=/tmp
+for M in 4 3; do
+  timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_m$M -o m$M --output-format csv -- \
+    python $GRAFT_REPO_ROOT/bench.py --reads $READS --steps 2 --warmup 1 --align-method $M --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_m$M.log 2>&1
+  echo "rocprof method $M rc=$?"
+done
+cd $GRAFT_REPO_ROOT
+python - <<PY
+import json
+for f in ("gpurun_out/bench_m4.json", "gpurun_out/bench_m3.json"):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f, d['metric'], 'value', d['value'], 'ms/step', d['ms_per_step'], d['stage_seconds_per_step'], 'cand', d['config']['candidates'], 'stored', d['config']['alignments_stored'])
+        print(json.dumps(d['kernels']))
+    except Exception as e:
+        print(f, 'unreadable', e)
+PY
