@@ -316,8 +316,13 @@ def main():
                 "algorithmic_bytes_per_step": dp_bytes // steps, "achieved_GBps": dp_bytes / dp_s / 1e9,
                 "note": "forward DP kernels + traceback, both streams; integer VALU-bound wavefront DP, not HBM-bound (SURVEY 8d)",
             }
-            names = ["bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<32, 2>", "bandedDpForwardKernel<64, 2>",
-                     "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"]
+            # Which forward kernel ran (include/shasta_mi355x.h: shasta_mi355x_dp_forward_version) and what its
+            # compiled loop issues per cell and lane (scripts/isa_loop.py on the <32, 2> instantiation: first
+            # version 75 VALU instructions per iteration of two cells; second version 247 per eight steady iterations).
+            dp_version = lib.dp_forward_version()
+            kernel_name = "bandedDpForwardKernel" if dp_version == 1 else "bandedDpForwardKernel2"
+            lane_instructions_per_cell = 37.5 if dp_version == 1 else 15.4
+            names = [kernel_name + suffix for suffix in ("<16, 2>", "<32, 2>", "<64, 2>", "<64, 4>", "<64, 8>", "<64, 16>")]
             for c in range(6):
                 if fw_n[c] == 0:
                     continue
@@ -331,12 +336,13 @@ def main():
                     roofline = {"bound": "hbm", "achieved": per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": per_launch / avg / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of(traffic_table, names[c]),
                                 "kernel": names[c], "gcups": fw_cells[c] / fw_s[c] / 1e9,
-                                # What actually bounds it: 75 VALU instructions per lane and loop iteration (2 cells) in the
-                                # compiled loop; 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-instructions/s
+                                # What actually bounds it: VALU instructions per lane and cell in the compiled loop against
+                                # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-instructions/s
                                 # (MI355X_MICROARCH.md: 157.3 TFLOPS fp32 = 2 flops x that).
-                                "valu": {"lane_instructions_per_cell": 37.5, "peak_lane_instructions_per_s": 78.6e12,
-                                         "ceiling_gcups": 78.6e12 / 37.5 / 1e9,
-                                         "frac": (fw_cells[c] / fw_s[c]) / (78.6e12 / 37.5)},
+                                "valu": {"lane_instructions_per_cell": lane_instructions_per_cell, "peak_lane_instructions_per_s": 78.6e12,
+                                         "ceiling_gcups": 78.6e12 / lane_instructions_per_cell / 1e9,
+                                         "frac": (fw_cells[c] / fw_s[c]) / (78.6e12 / lane_instructions_per_cell)},
+                                "dp_forward_version": dp_version,
                                 "note": "dominant kernel by time; integer max-plus DP bound by VALU issue: its algorithmic bytes "
                                         "(4(nx+ny) per task) are tiny against its work (nx x bandWidth cells), so the HBM fraction "
                                         "is low by construction; traffic is dominated by the 2-bit/cell trace it writes"}

@@ -402,6 +402,12 @@ int shasta_mi355x_banded_dp(
     int32_t bandMin, int32_t bandMax,
     uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score);
 
+/* Which forward kernel of the banded DP (K10b) this process uses: 2 (the block-unrolled kernel) unless
+ * SHASTA_MI355X_DP_FORWARD=1 forces the first version, or unless the two versions disagreed in the
+ * start-up comparison on this device (then 1, with a message on stderr).  Runs that comparison if it
+ * has not run yet; negative on error.  For tests and bench reports -- the reference has no counterpart. */
+int shasta_mi355x_dp_forward_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@
 #include <mutex>
 #include <set>
 #include <thread>
+#include <type_traits>
 
 namespace shasta_mi355x {
 namespace {
@@ -1037,6 +1038,280 @@ bandedDpForwardKernel(
     }
 }
 
+// ---- forward kernel, second version ---------------------------------------------------------
+// Same tasks, bundles, trace format and DpEnd as bandedDpForwardKernel, which stays beside it
+// (SHASTA_MI355X_DP_FORWARD=1) until this one has been timed on the MI355X.  Every change comes
+// from the first version's ISA (75 VALU instructions per iteration for two cells per lane,
+// scripts/isa_loop.py):
+//  * three phases, general / steady / general.  In the steady phase (all but about a band width
+//    of iterations at either end) every cell of the wavefront that exists is inside the matrix and
+//    past the first cell of its diagonal, and every kmer-id load is in range: no validity tests,
+//    no index clamps.  It runs in blocks of DP_BLOCK iterations, fully unrolled: a lane's kmer ids
+//    of a block are DP_BLOCK + C/2 consecutive elements per read, fetched as one 16-byte load per
+//    read and block, one block ahead -- no sliding register windows, no per-iteration address;
+//  * scores are kept biased by -NEG_SCORE, so "outside the band" is 0 and the neighbour exchange
+//    is one DPP shift with zero fill (row_shr/shl for 16-lane groups, wave_shr/shl otherwise)
+//    instead of ds_bpermute + select -- same decisions: max, compare and adding a constant commute
+//    with the bias, and nothing overflows (|score| < 2^27);
+//  * trace planes: one ballot per comparison (the mask v_cmp wrote anyway), combined on the
+//    scalar unit; the ballot of a combined predicate is compiled to v_cndmask + v_cmp;
+//  * the trace record goes from lane 0 into a 256-byte LDS line per wavefront and leaves as one
+//    coalesced 4-byte store per lane when the line is full, instead of a select chain over the
+//    lanes and a partial store every iteration;
+//  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
+constexpr int DP_BLOCK = 4;
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// The value of the lane below / above in a G-lane group; 0 at the group's edge.
+template<int G> __device__ __forceinline__ int32_t fromLaneBelow(int32_t v, int l)
+{
+    constexpr int ctrl = (G == 16) ? 0x111 : 0x138;             // row_shr:1 : wave_shr:1; bound_ctrl = zero fill
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    if constexpr (G == 32) r = (l == 0) ? 0 : r;
+    return r;
+}
+template<int G> __device__ __forceinline__ int32_t fromLaneAbove(int32_t v, int l)
+{
+    constexpr int ctrl = (G == 16) ? 0x101 : 0x130;             // row_shl:1 : wave_shl:1
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    if constexpr (G == 32) r = (l == G - 1) ? 0 : r;
+    return r;
+}
+struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // four consecutive kmer ids, 4-byte aligned
+
+template<int G, int C>
+__global__ void __launch_bounds__(256)
+bandedDpForwardKernel2(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
+    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
+    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,
+    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
+{
+    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C, U = DP_BLOCK;
+    constexpr int F = 32 / RW;                            // iterations per 256-byte trace line
+    constexpr int AL = F > U ? F : U;                     // steady iterations come in groups of AL: whole blocks, whole lines
+    constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
+    static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
+    __shared__ uint64_t traceLines[4 * 32];               // one 256-byte line per wavefront of the block
+    const int lane = laneId();
+    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(bundle >= bundleCount) return;                     // whole wave leaves: all 64 lanes are active below, no block barriers
+    uint64_t* const line = traceLines + 32 * (threadIdx.x >> 6);
+    const int g = lane / G, l = lane % G;
+    const uint32_t pos = bundle * T + uint32_t(g);
+    const bool hasTask = pos < taskCount;
+    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
+    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    uint32_t itersLane = geo.iters;
+#pragma unroll
+    for(int d = G; d < WAVE; d <<= 1) itersLane = max(itersLane, uint32_t(__shfl_xor(int(itersLane), d, WAVE)));
+    const uint32_t iters = __builtin_amdgcn_readfirstlane(itersLane);
+    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
+
+    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
+    int32_t lo[C];
+    uint32_t span[C];
+    bool exists[C];
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t b = l * C + c, d = bandMin + b;
+        const int32_t first = d < 0 ? -d : d;
+        const int32_t last = min(2 * nx - d, 2 * ny + d);
+        exists[c] = hasTask && b < width && d <= nx && d >= -ny && last >= first;
+        lo[c] = exists[c] ? first : NO_DIAGONAL;
+        span[c] = exists[c] ? uint32_t(last - first) : 0u;
+    }
+    int32_t H[C];                                         // biased: score + BIAS; 0 = no cell
+#pragma unroll
+    for(int c = 0; c < C; c++) H[c] = 0;
+
+    // Iteration `it` works at ib = ib0 + it: it compares A[ib + l HC - 1 + k], k = 0..HC, with
+    // B[ib - bandMin - l HC - 1 - h], h = 0..HC-1.
+    const int32_t ib0 = (geo.s0 + bandMin) / 2;
+    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
+    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
+
+    // One anti-diagonal pair.  STEADY: every existing cell is valid and past its first cell.
+    auto cell = [&](auto steadyTag, int c, int32_t sc, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
+        constexpr bool STEADY = decltype(steadyTag)::value;
+        const bool eq = a == bk;
+        const int32_t dg = hd + (eq ? MATCH_SCORE - GAP_SCORE : MISMATCH_SCORE - GAP_SCORE);   // the three candidates before the gap penalty they share
+        const bool isV = hv > dg;                                   // from (i, j-1): diagonal b+1
+        const int32_t m1 = max(dg, hv);
+        const bool isH = hh > m1;                                   // from (i-1, j): diagonal b-1
+        int32_t v = max(m1, hh) + GAP_SCORE;
+        if constexpr (STEADY) {
+            H[c] = exists[c] ? v : 0;
+        } else {
+            const bool valid = uint32_t(sc - lo[c]) <= span[c];
+            v = (sc == lo[c]) ? BIAS : v;                           // i == 0 or j == 0: free leading gaps
+            H[c] = valid ? v : H[c];
+        }
+        const uint64_t bEq = ballot64(eq), bV = ballot64(isV), bH = ballot64(isH);
+        loPlane = bH | ~(bV | bEq);                                 // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
+        hiPlane = bV | bH;
+    };
+    // aw(k), bw(h): the kmer ids of this iteration.
+    auto antiDiagonals = [&](auto steadyTag, int32_t s, auto aw, auto bw, uint64_t (&words)[RW]) {
+        {   // anti-diagonal s: even c hold cells
+            const int32_t left = fromLaneBelow<G>(H[C - 1], l);
+#pragma unroll
+            for(int c = 0; c < C; c += 2) {
+                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
+                cell(steadyTag, c, s, aw(c / 2), bw(c / 2), H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
+            }
+        }
+        {   // anti-diagonal s+1: odd c hold cells
+            const int32_t right = fromLaneAbove<G>(H[0], l);
+#pragma unroll
+            for(int c = 1; c < C; c += 2) {
+                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
+                cell(steadyTag, c, s + 1, aw(c / 2 + 1), bw(c / 2), H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
+            }
+        }
+    };
+    // The record of an iteration goes to slot (it mod F) of the wavefront's line; a full line leaves as
+    // one coalesced store.  Lane 0 writes, all lanes read: the wave barrier keeps the compiler from
+    // moving the read up (the hardware runs a wavefront's LDS operations in order).
+    auto putRecord = [&](int slot, const uint64_t (&words)[RW]) {
+        if(lane == 0) {
+            ulonglong2* __restrict__ record = reinterpret_cast<ulonglong2*>(line + slot * RW);
+#pragma unroll
+            for(int k = 0; k < C; k++) { ulonglong2 w; w.x = words[2 * k]; w.y = words[2 * k + 1]; record[k] = w; }
+        }
+    };
+    auto flushLine = [&](uint32_t lineIndex) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t d = reinterpret_cast<const uint32_t*>(line)[lane];
+        reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = d;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // General iterations [from, to): sliding register windows fed by clamped loads two iterations ahead.
+    auto general = [&](uint32_t from, uint32_t to) {
+        if(from >= to) return;
+        const int32_t ib = ib0 + int32_t(from);
+        uint32_t aw[HC + 1], bw[HC];
+#pragma unroll
+        for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
+#pragma unroll
+        for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
+        uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
+        uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
+        for(uint32_t it = from; it < to; it++) {
+            uint64_t words[RW];
+            antiDiagonals(std::false_type{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
+            putRecord(int(it % F), words);
+            if(it % F == F - 1) flushLine(it / F);
+#pragma unroll
+            for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
+            aw[HC] = aNext1; aNext1 = aNext2;
+#pragma unroll
+            for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
+            bw[0] = bNext1; bNext1 = bNext2;
+            aNext2 = loadA(ib0 + int32_t(it) + 2 + l * HC + HC);
+            bNext2 = loadB(ib0 + int32_t(it) + 2 - bandMin - l * HC);
+        }
+    };
+
+    // Steady iterations.  A cell (lane, c) is steady at `it` when lo < s0 + 2 it + (c & 1) <= lo + span;
+    // the block that starts at itB loads A[iaBlock + itB + j], B[jbBlock + itB + j], j = 0..U-1
+    // (the new elements of the block after it).
+    const int32_t iaBlock = ib0 + U + l * HC + HC - 1, jbBlock = ib0 + U - bandMin - l * HC - 1;
+    int32_t itLo = 0, itHi = int32_t(iters) - 1;          // cells steady on [itLo, itHi]
+    int32_t startLo = max(-iaBlock, -jbBlock), startHi = min(nx - U - iaBlock, ny - U - jbBlock);   // block starts whose loads are in range
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        if(exists[c]) {
+            itLo = max(itLo, (lo[c] + 2 - geo.s0 - (c & 1)) >> 1);
+            itHi = min(itHi, (lo[c] + int32_t(span[c]) - geo.s0 - (c & 1)) >> 1);
+        }
+    }
+#pragma unroll
+    for(int d = 1; d < WAVE; d <<= 1) {
+        itLo = max(itLo, __shfl_xor(itLo, d, WAVE)); itHi = min(itHi, __shfl_xor(itHi, d, WAVE));
+        startLo = max(startLo, __shfl_xor(startLo, d, WAVE)); startHi = min(startHi, __shfl_xor(startHi, d, WAVE));
+    }
+    // Groups of AL iterations starting at multiples of AL: the first at steadyBegin, every block start in
+    // [startLo, startHi], every iteration in [itLo, itHi].
+    const int32_t firstStart = (max(max(itLo, startLo), 0) + AL - 1) / AL * AL;
+    const int32_t lastGroupStart = min(itHi - (AL - 1), startHi - (AL - U));
+    const uint32_t groups = __builtin_amdgcn_readfirstlane(uint32_t(lastGroupStart >= firstStart ? (lastGroupStart - firstStart) / AL + 1 : 0));
+    const uint32_t steadyBegin = __builtin_amdgcn_readfirstlane(uint32_t(firstStart));
+
+    if(groups == 0) {
+        general(0, iters);
+    } else {
+        general(0, steadyBegin);
+        {
+            // Block registers: a[x] = A[ib + l HC - 1 + x], x = 0..U+HC-1; e[x] = B[ib - bandMin - l HC - HC + x], x = 0..U+HC-2.
+            // Iteration u of the block: aw(k) = a[u + k], bw(h) = e[u + HC - 1 - h].
+            const int32_t ib = ib0 + int32_t(steadyBegin);
+            uint32_t a[U + HC], e[U + HC - 1];
+#pragma unroll
+            for(int x = 0; x < U + HC; x++) a[x] = loadA(ib + l * HC - 1 + x);
+#pragma unroll
+            for(int x = 0; x < U + HC - 1; x++) e[x] = loadB(ib - bandMin - l * HC - HC + x);
+            const uint32_t* __restrict__ pa = p0 + (int64_t(iaBlock) + int64_t(steadyBegin));
+            const uint32_t* __restrict__ pb = p1 + (int64_t(jbBlock) + int64_t(steadyBegin));
+            uint32_t lineIndex = steadyBegin / F;
+            for(uint32_t grp = 0; grp < groups; grp++) {
+#pragma unroll
+                for(int blk = 0; blk < AL / U; blk++) {
+                    const KmerQuad newA = *reinterpret_cast<const KmerQuad*>(pa);
+                    const KmerQuad newB = *reinterpret_cast<const KmerQuad*>(pb);
+                    pa += U; pb += U;
+#pragma unroll
+                    for(int u = 0; u < U; u++) {
+                        uint64_t words[RW];
+                        antiDiagonals(std::true_type{}, 0, [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
+                        const int slot = (blk * U + u) % F;
+                        putRecord(slot, words);
+                        if(slot == F - 1) { flushLine(lineIndex); ++lineIndex; }
+                    }
+#pragma unroll
+                    for(int x = 0; x < HC; x++) a[x] = a[x + U];
+#pragma unroll
+                    for(int j = 0; j < U; j++) a[HC + j] = newA.v[j];
+#pragma unroll
+                    for(int x = 0; x < HC - 1; x++) e[x] = e[x + U];
+#pragma unroll
+                    for(int j = 0; j < U; j++) e[HC - 1 + j] = newB.v[j];
+                }
+            }
+        }
+        general(steadyBegin + groups * AL, iters);
+    }
+    if(iters % F != 0) flushLine(iters / F);              // the last, partial line (the bundle's trace is a whole number of lines)
+
+    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
+    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t d = bandMin + l * C + c;
+        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
+        const int32_t v = exists[c] ? H[c] - BIAS : NEG_SCORE;
+        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
+    }
+#pragma unroll
+    for(int d = G / 2; d >= 1; d >>= 1) {
+        const int32_t os = __shfl_xor(bestScore, d, G);
+        const int32_t oi = __shfl_xor(bestI, d, G);
+        const int32_t oj = __shfl_xor(bestJ, d, G);
+        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+    }
+    if(hasTask && l == 0) {
+        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
+        ends[t] = e;
+    }
+}
+
 // One lane per task: walk the path from the end cell through the packed trace.  The trace is
 // consumed in chunks of CW words (128 or 256 bytes, whole cache lines): the chunk under the
 // path sits in the lane's private LDS window, the next one (the path only moves towards smaller
@@ -1457,13 +1732,17 @@ void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
 struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; };
 
+// Which forward kernel runs: bandedDpForwardKernel2 unless SHASTA_MI355X_DP_FORWARD=1, or unless it
+// disagrees with the first version on this device (dpForwardSelfTest, once per process, loud).
+int chooseDpForwardVersion();
+
 template<int G, int C>
-void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
+void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls, int version)
 {
     const uint32_t taskCount = layout.taskStart[cls + 1] - layout.taskStart[cls];
     const uint32_t bundleCount = layout.bundleStart[cls + 1] - layout.bundleStart[cls];
     if(taskCount == 0) return;
-    hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((version == 1 ? bandedDpForwardKernel<G, C> : bandedDpForwardKernel2<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
         in.kmerIds, in.pairs, in.tasks,
         sortedIds + layout.taskStart[cls], taskCount,
         (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
@@ -1494,6 +1773,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
 {
     hipStream_t stream = ws.stream;
     DpForwardState f;
+    const int version = chooseDpForwardVersion();
     b.dpKeysA.reserve(taskCount, stream); b.dpKeysB.reserve(taskCount, stream);
     b.dpIdsA.reserve(taskCount, stream); b.dpIdsB.reserve(taskCount, stream);
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
@@ -1545,13 +1825,13 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         launch(st);
         if(ev) HIP_CHECK(hipEventRecord(ev->stop[cls], st));
     };
-    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 5); });
-    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4); });
-    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3); });
+    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 5, version); });
+    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4, version); });
+    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3, version); });
     if(fork) HIP_CHECK(hipEventRecord(ev->join, ws.wide));
-    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(in, st, b, sortedIds, layout, 1); });
-    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(in, st, b, sortedIds, layout, 2); });
-    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0); });
+    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(in, st, b, sortedIds, layout, 1, version); });
+    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(in, st, b, sortedIds, layout, 2, version); });
+    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0, version); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     return f;
 }
@@ -1572,6 +1852,98 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     if(ev) HIP_CHECK(hipEventRecord(ev->stop[DP_CLASSES], stream));
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[8 + c]; stats->tasks[c] = f.classCounts[c]; }
     return f.sums[0];
+}
+
+// The two forward kernels on a batch of synthetic tasks (every band class, sequences over a small
+// alphabet so that score ties are everywhere): true when every DpResult and every ordinal agrees.
+thread_local int dpForwardOverride = 0;
+bool dpForwardSelfTest()
+{
+    int device = 0;
+    HIP_CHECK(hipGetDevice(&device));
+    Context ctx(device);
+    const int widths[DP_CLASSES] = {24, 50, 100, 200, 400, 800};
+    std::vector<uint32_t> all;
+    std::vector<PairDesc> pairs;
+    std::vector<DpTask> tasks;
+    uint64_t x = 0x9e3779b97f4a7c15ULL;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return uint32_t(x >> 20); };
+    for(int cls = 0; cls < DP_CLASSES; cls++) {
+        for(int rep = 0; rep < 2; rep++) {
+            // Two noisy copies of one sequence, the second one shifted: an overlap alignment near diagonal `shift`.
+            const uint32_t n = uint32_t(widths[cls]) + 260u + next() % 200u, shift = next() % 150u;
+            std::vector<uint32_t> base(n + shift);
+            for(auto& v : base) v = next() % 7u;
+            PairDesc pd; pd.begin0 = all.size();
+            for(uint32_t i = 0; i < n; i++) { if(next() % 16u == 0) continue; all.push_back(next() % 11u == 0 ? next() % 7u : base[i]); }
+            pd.nx = uint32_t(all.size() - pd.begin0); pd.begin1 = all.size();
+            for(uint32_t i = shift; i < n + shift; i++) { if(next() % 16u == 0) continue; all.push_back(next() % 11u == 0 ? next() % 7u : base[i]); }
+            pd.ny = uint32_t(all.size() - pd.begin1);
+            DpTask t; t.pair = uint32_t(pairs.size()); t.label = 0;
+            t.bandMin = -int32_t(shift) - widths[cls] / 2 + (rep ? 7 : 0); t.bandMax = t.bandMin + widths[cls] - 1;
+            pairs.push_back(pd); tasks.push_back(t);
+        }
+    }
+    const uint32_t taskCount = uint32_t(tasks.size());
+    std::vector<uint64_t> toc = {0, all.size() / 2, all.size()};
+    ctx.setMarkers(1, toc.data(), nullptr, all.data(), nullptr);
+    hipStream_t stream = ctx.stream;
+    DeviceOptions opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
+    const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
+    std::vector<DpResult> results[2];
+    std::vector<uint32_t> ordinals[2];
+    for(int version = 1; version <= 2; version++) {
+        BatchScratch b;
+        b.pairs.reserve(pairs.size(), stream); b.tasks.reserve(taskCount, stream); b.pairBest.reserve(pairs.size(), stream);
+        HIP_CHECK(hipMemcpyAsync(b.pairs.data(), pairs.data(), pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.tasks.data(), tasks.data(), taskCount * sizeof(DpTask), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8 * pairs.size(), stream));
+        dpForwardOverride = version;
+        try { (void)runDpTasks(ctx, ws, b, taskCount, opt, nullptr, nullptr); } catch(...) { dpForwardOverride = 0; throw; }
+        dpForwardOverride = 0;
+        std::vector<DpResult>& r = results[version - 1];
+        r.resize(taskCount);
+        HIP_CHECK(hipMemcpyAsync(r.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for(const DpResult& d : r) {
+            std::vector<uint32_t> o(2 * size_t(d.markerCount));
+            if(d.markerCount) HIP_CHECK(hipMemcpy(o.data(), b.ordScratch.data() + 2 * d.ordBegin, 8ULL * d.markerCount, hipMemcpyDeviceToHost));
+            ordinals[version - 1].insert(ordinals[version - 1].end(), o.begin(), o.end());
+        }
+    }
+    bool aligned = false;
+    for(uint32_t i = 0; i < taskCount; i++) {
+        const DpResult& p = results[0][i]; const DpResult& q = results[1][i];
+        if(p.markerCount != q.markerCount || p.score != q.score || p.ordBegin != q.ordBegin || p.first0 != q.first0 || p.first1 != q.first1 ||
+            p.last0 != q.last0 || p.last1 != q.last1 || p.sumOffset != q.sumOffset || p.maxSkip != q.maxSkip || p.maxDrift != q.maxDrift) return false;
+        aligned = aligned || p.markerCount > 100;
+    }
+    return aligned && ordinals[0] == ordinals[1];
+}
+
+int chooseDpForwardVersion()
+{
+    if(dpForwardOverride) return dpForwardOverride;
+    static std::atomic<int> choice{0};
+    static std::mutex mutex;
+    int v = choice.load();
+    if(v) return v;
+    std::lock_guard<std::mutex> lock(mutex);
+    v = choice.load();
+    if(v) return v;
+    if(const char* e = std::getenv("SHASTA_MI355X_DP_FORWARD")) {
+        v = std::atoi(e) == 1 ? 1 : 2;
+    } else if(dpForwardSelfTest()) {
+        v = 2;
+    } else {
+        std::fprintf(stderr, "shasta_mi355x: the two forward DP kernels disagree on this device; using the first version "
+            "(set SHASTA_MI355X_DP_FORWARD=2 to force the second).\n");
+        v = 1;
+    }
+    choice.store(v);
+    return v;
 }
 
 struct BatchOutput {
@@ -2290,6 +2662,8 @@ void align4Free(shasta_align4_result& r)
 }
 
 // Unit seam: one banded DP on the device (used by the parity tests of K10 alone).
+int dpForwardVersion() { return chooseDpForwardVersion(); }
+
 void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
     uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score)
 {

@@ -300,4 +300,11 @@ int shasta_mi355x_banded_dp(const uint32_t* k0, uint32_t nx, const uint32_t* k1,
     API_END(1)
 }
 
+int shasta_mi355x_dp_forward_version(void)
+{
+    API_BEGIN
+    return dpForwardVersion();
+    API_END(-1)
+}
+
 }  // extern "C"

@@ -22,7 +22,7 @@ EXPORTS = [
     "shasta_mi355x_create", "shasta_mi355x_destroy",
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_get_kernel_times",
-    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate",
+    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate", "shasta_mi355x_dp_forward_version",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish",
@@ -148,6 +148,12 @@ class Library:
             C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
             C.byref(count), C.byref(score)), "shasta_mi355x_banded_dp")
         return out[:count.value].copy(), score.value
+
+    def dp_forward_version(self):
+        v = int(self.lib.shasta_mi355x_dp_forward_version())
+        if v < 0:
+            raise RuntimeError("shasta_mi355x_dp_forward_version failed: %s" % self.lib.shasta_mi355x_last_error().decode())
+        return v
 
     def calibrate(self, nbytes, mode):
         self._check(self.lib.shasta_mi355x_calibrate(C.c_uint64(nbytes), C.c_int(mode)), "shasta_mi355x_calibrate")

@@ -1,0 +1,71 @@
+"""Banded DP of one library against the oracle over a sweep of band geometries (every band class,
+tiny and ragged matrices, bands hanging over every corner, small alphabets = score ties).  Run as a
+script in a process of its own by the tests, because the forward-kernel version
+(SHASTA_MI355X_DP_FORWARD) is fixed once per process:
+
+    python tests/dp_versions_check.py <library.so> <expected version> [seed]
+
+Test infrastructure: the oracle is the checker, the library is what is checked."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTHS = (1, 2, 3, 16, 20, 31, 32, 33, 64, 65, 100, 128, 129, 256, 300, 512, 513, 1000)
+
+
+def noisy(rng, x, alphabet):
+    keep = rng.random(len(x)) > 0.06
+    y = x[keep].copy()
+    sub = rng.random(len(y)) < 0.08
+    y[sub] = rng.integers(0, alphabet, size=int(sub.sum()), dtype=np.uint32)
+    return y
+
+
+def sweep(lib, orc, seed, trials=6):
+    rng = np.random.default_rng(seed)
+    cases = bad = 0
+    for width in WIDTHS:
+        for trial in range(trials):
+            alphabet = (1 << 20) if trial % 2 == 0 else 12
+            n = int(rng.integers(5, 900)) if trial < 4 else int(rng.integers(1, 40))
+            m = max(1, n + int(rng.integers(-(n // 2), n // 2 + 1)))
+            genome = rng.integers(0, alphabet, size=n + m + 1400, dtype=np.uint32)
+            off = int(rng.integers(0, 300))
+            a = noisy(rng, genome[:n], alphabet)
+            b = noisy(rng, genome[off:off + m], alphabet)
+            if len(a) == 0 or len(b) == 0:
+                continue
+            center = off if trial % 3 else -off
+            lo = center + int(rng.integers(-30, 30)) - width // 2
+            x, sx = orc.banded_dp(a, b, lo, lo + width - 1)
+            y, sy = lib.banded_dp(a, b, lo, lo + width - 1)
+            cases += 1
+            if not (sx == sy and np.array_equal(x, y)):
+                bad += 1
+                print("MISMATCH width %d trial %d nx %d ny %d bandMin %d: score %d / %d, %d / %d markers"
+                      % (width, trial, len(a), len(b), lo, sx, sy, len(x), len(y)))
+    return cases, bad
+
+
+def main():
+    from oracle import bindings
+    from shasta_amd import lib as libmod
+    lib = libmod.Library(sys.argv[1])
+    expected = int(sys.argv[2])
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    version = lib.dp_forward_version()
+    print("forward kernel version", version)
+    if version != expected:
+        sys.exit("expected forward kernel version %d, the library chose %d" % (expected, version))
+    cases, bad = sweep(lib, bindings.OracleLib(), seed)
+    print("cases %d bad %d" % (cases, bad))
+    sys.exit(1 if bad or cases < 80 else 0)
+
+
+if __name__ == "__main__":
+    main()

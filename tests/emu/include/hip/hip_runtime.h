@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <tuple>
@@ -38,6 +39,7 @@ struct dim3 {
 };
 struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
@@ -142,6 +144,7 @@ void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t dyna
 // Device intrinsics.
 // ---------------------------------------------------------------------------
 __forceinline__ uint64_t __ballot(int predicate) { return hipemu::collective(hipemu::BALLOT, predicate ? 1 : 0, 0); }
+__forceinline__ uint64_t __builtin_amdgcn_ballot_w64(bool predicate) { return hipemu::collective(hipemu::BALLOT, predicate ? 1 : 0, 0); }
 __forceinline__ int __any(int predicate) { return __ballot(predicate) != 0; }
 __forceinline__ int __all(int predicate) { return __ballot(!predicate) == 0; }
 __forceinline__ void __syncthreads() { (void)hipemu::collective(hipemu::BLOCK_BARRIER, 0, 0); }
@@ -178,6 +181,23 @@ template<class T> __forceinline__ T __shfl_xor(T v, int mask, int width = 64)
 __forceinline__ uint32_t __builtin_amdgcn_readlane(uint32_t v, int lane)
 {
     return uint32_t(hipemu::collective(hipemu::SHUFFLE, v, uint64_t(lane)));
+}
+// v_mov_b32_dpp with row_mask = bank_mask = 0xf: the controls the kernels use (shifts by one lane).
+// A lane whose source is outside the row / wavefront keeps `old`, or gets 0 with bound_ctrl.
+__forceinline__ int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int rowMask, int bankMask, bool boundCtrl)
+{
+    const int lane = hipemu::cur->lane;
+    int from = -1;
+    switch(ctrl) {
+        case 0x111: from = (lane % 16) >= 1 ? lane - 1 : -1; break;      // row_shr:1
+        case 0x101: from = (lane % 16) <= 14 ? lane + 1 : -1; break;     // row_shl:1
+        case 0x138: from = lane >= 1 ? lane - 1 : -1; break;             // wave_shr:1
+        case 0x130: from = lane <= 62 ? lane + 1 : -1; break;            // wave_shl:1
+        default: std::fprintf(stderr, "hip_emu: DPP control 0x%x is not modelled\n", ctrl); std::abort();
+    }
+    if(rowMask != 0xf || bankMask != 0xf) { std::fprintf(stderr, "hip_emu: DPP row/bank masks are not modelled\n"); std::abort(); }
+    const uint32_t got = uint32_t(hipemu::collective(hipemu::SHUFFLE, uint32_t(src), uint64_t(from < 0 ? lane : from)));
+    return from < 0 ? (boundCtrl ? 0 : old) : int(got);
 }
 __forceinline__ uint32_t __builtin_amdgcn_readfirstlane(uint32_t v)
 {

@@ -48,6 +48,11 @@ class FakeContext:
 
 
 class FakeLibrary:
+    version = 1
+
+    def dp_forward_version(self):
+        return self.version
+
     def device_count(self):
         return 1
 
@@ -55,11 +60,13 @@ class FakeLibrary:
         return FakeContext()
 
 
-def test_bench_prints_one_contract_line(monkeypatch, capsys):
+@pytest.mark.parametrize("dp_version", [1, 2])
+def test_bench_prints_one_contract_line(monkeypatch, capsys, dp_version):
     import torch
     import shasta_amd
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(FakeLibrary, "version", dp_version)
     monkeypatch.setattr(shasta_amd, "load", lambda: FakeLibrary())
     monkeypatch.setattr(bench, "make_workload", lambda reads, seed: (np.zeros(2 * 10 + 1, np.uint64), np.zeros(0, np.uint32)))
     monkeypatch.setattr(bench, "cpu_baseline", lambda reads, seed, method=4: {"value": 18000.0, "unit": "candidate read-pairs aligned/s",
@@ -79,8 +86,12 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # The dominant kernel of the fake timings is the <=64-diagonal DP class; its traffic comes from the committed PMC file.
-    assert r["kernel"] == "bandedDpForwardKernel<32, 2>" and r["traffic"] and r["traffic"] > 1e9
+    # The dominant kernel of the fake timings is the <=64-diagonal DP class; the traffic in the committed PMC file was
+    # measured on the first version of the kernel and is not reported for the second.
+    if dp_version == 1:
+        assert r["kernel"] == "bandedDpForwardKernel<32, 2>" and r["traffic"] and r["traffic"] > 1e9
+    else:
+        assert r["kernel"] == "bandedDpForwardKernel2<32, 2>" and r["traffic"] is None and r["dp_forward_version"] == 2
     assert d["kernels"]["hashWindowsKernel<4>"]["launches_per_step"] == 10
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 64
     assert d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)

@@ -5,11 +5,15 @@ sizes a CPU finishes in seconds.  This is test infrastructure: it proves the ker
 the oracle, not the MI355X run (no LDS limits, no timing, no inter-workgroup memory model), and
 nothing in the product can load the emulated library.  The whole -m gpu suite runs on it with
 SHASTA_EMU=1 (see tests/conftest.py)."""
+import os
+
 import numpy as np
 import pytest
 
 from shasta_amd import abi
 from tests import align3_checks, support
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_emulated_library_is_the_same_abi(emu_lib):
@@ -135,3 +139,19 @@ def test_two_ranks_equal_single_process_oracle(emu_lib, oracle_lib):
     seed, kw = dist_checks.CASES[0]
     dist_checks.two_ranks_equal_single_process_oracle(oracle_lib, seed, kw, library_path=emu_lib.path, port_base=29800)
 
+
+
+@pytest.mark.parametrize("version", [1, 2, 0])
+def test_forward_dp_versions(emu_lib, oracle_lib, version):
+    """Both forward kernels (0: the library's own choice after its start-up comparison, which must be
+    the second) against the oracle over a geometry sweep -- each in a process of its own, the
+    version is fixed per process."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("SHASTA_MI355X_DP_FORWARD", None)
+    if version:
+        env["SHASTA_MI355X_DP_FORWARD"] = str(version)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_versions_check.py"), emu_lib.path, str(version or 2), "5"],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
