@@ -12,10 +12,13 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 echo "host: $(nproc) cores, $(free -g | awk '/Mem:/{print $2" GiB RAM, "$7" GiB available"}')"
 for f in tests/test_gpu_lowhash0.py tests/test_gpu_align4.py tests/test_gpu_host_stages.py tests/test_gpu_distributed.py \
-         tests/test_gpu_zz_assembler_mirror.py tests/test_gpu_zzz_align3.py tests/test_gpu_zzzz_large_properties.py; do
+         tests/test_gpu_zz_assembler_mirror.py tests/test_gpu_zzz_align3.py tests/test_gpu_zzz_dp_versions.py tests/test_gpu_zzzz_large_properties.py; do
   echo "== $f"
   timeout 900 python -m pytest $f -q -m gpu --timeout 300 2>&1 | tail -4
 done
+# A/B of the two forward DP kernels (DESIGN.md section 4, K10b'): method 4 with the first version forced.
+SHASTA_MI355X_DP_FORWARD=1 timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_m4_dp1.json 2> gpurun_out/bench_m4_dp1.err
+echo "bench method 4, first forward kernel rc=$?"; tail -c 300 gpurun_out/bench_m4_dp1.err
 for M in 4 3; do
   timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --align-method $M --no-cpu-baseline > gpurun_out/bench_m$M.json 2> gpurun_out/bench_m$M.err
   echo "bench method $M rc=$?"; tail -c 400 gpurun_out/bench_m$M.err
@@ -29,7 +32,7 @@ done
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import json
-for f in ("gpurun_out/bench_m4.json", "gpurun_out/bench_m3.json"):
+for f in ("gpurun_out/bench_m4_dp1.json", "gpurun_out/bench_m4.json", "gpurun_out/bench_m3.json"):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         print(f, d['metric'], 'value', d['value'], 'ms/step', d['ms_per_step'], d['stage_seconds_per_step'], 'cand', d['config']['candidates'], 'stored', d['config']['alignments_stored'])
