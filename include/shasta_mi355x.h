@@ -402,6 +402,21 @@ int shasta_mi355x_banded_dp(
     int32_t bandMin, int32_t bandMax,
     uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score);
 
+/* -------------------------------------------------------------------------
+ * Palindromic-read flagging: the device half of
+ * Assembler::flagPalindromicReads (src/AssemblerAlign.cpp:652-770, parameters
+ * src/AssemblerOptions.cpp:255-288).  For every read of the context's markers:
+ * the number of marker pairs (ordinal i on strand 0, ordinal j on strand 1) with
+ * equal kmer ids and |i - j| < deltaThreshold.  Every marker of the reference's
+ * method-0 self-alignment that it counts as near-diagonal (:738-749) is such a
+ * pair, so a read with double(bound[r]) / double(markerCount) below
+ * nearDiagonalFractionThreshold cannot be flagged (:750-752); the others are decided
+ * by the host layer with the reference's own sequential graph search
+ * (shasta_amd/host/PalindromicReads.cpp).  bound: host pointer, readCount entries.
+ * deltaThreshold must be in [1, 4096].
+ * ------------------------------------------------------------------------- */
+int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx*, uint64_t deltaThreshold, uint32_t* bound);
+
 /* Which forward kernel of the banded DP (K10b) this process uses: 2 (the block-unrolled kernel) unless
  * SHASTA_MI355X_DP_FORWARD=1 forces the first version, or unless the two versions disagreed in the
  * start-up comparison on this device (then 1, with a message on stderr).  Runs that comparison if it

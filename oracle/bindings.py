@@ -99,6 +99,29 @@ class RefLib(_Base):
         self.lib.ref_free(p)
         return out
 
+    def flag_palindromic_reads(self, toc, data7, max_skip=100, max_drift=100, max_marker_frequency=10,
+                               aligned_fraction_threshold=0.1, near_diagonal_fraction_threshold=0.1, delta_threshold=100, threads=1):
+        """The reference's method-0 self-alignment of every read + the flag rule (src/AssemblerAlign.cpp:702-770).
+        Returns (flags u8[R], aligned marker count u32[R], near-diagonal marker count u32[R], FNV-1a digest of the
+        aligned ordinals u64[R])."""
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        flags = np.zeros(read_count, np.uint8)
+        aligned = np.zeros(read_count, np.uint32)
+        near = np.zeros(read_count, np.uint32)
+        digests = np.zeros(read_count, np.uint64)
+        rc = self.lib.ref_flag_palindromic_reads(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint32(max_skip), C.c_uint32(max_drift), C.c_uint32(max_marker_frequency),
+            C.c_double(aligned_fraction_threshold), C.c_double(near_diagonal_fraction_threshold), C.c_uint32(delta_threshold),
+            C.c_uint64(threads), abi.as_ptr(flags, C.c_uint8), abi.as_ptr(aligned, C.c_uint32), abi.as_ptr(near, C.c_uint32),
+            abi.as_ptr(digests, C.c_uint64))
+        if rc:
+            self.lib.ref_palindromic_last_error.restype = C.c_char_p
+            raise RuntimeError("ref_flag_palindromic_reads failed: %s" % self.lib.ref_palindromic_last_error().decode())
+        return flags, aligned, near, digests
+
     def alignment_info(self, ordinals, nx, ny):
         o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
         info = abi.AlignmentInfo()
@@ -243,6 +266,24 @@ class OracleLib(_Base):
     def murmur64a(self, data, seed):
         b = bytes(data)
         return int(self.lib.oracle_murmur64a(b, C.c_int(len(b)), C.c_uint64(seed)))
+
+    def flag_palindromic_reads(self, toc, data7, max_skip=100, max_drift=100, max_marker_frequency=10,
+                               aligned_fraction_threshold=0.1, near_diagonal_fraction_threshold=0.1, delta_threshold=100):
+        """Restated method 0 + flag rule (oracle/method0.hpp); same returns as RefLib.flag_palindromic_reads."""
+        toc = _u64(toc)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        flags = np.zeros(read_count, np.uint8)
+        aligned = np.zeros(read_count, np.uint32)
+        near = np.zeros(read_count, np.uint32)
+        digests = np.zeros(read_count, np.uint64)
+        self._check(self.lib.oracle_flag_palindromic_reads(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint32(max_skip), C.c_uint32(max_drift), C.c_uint32(max_marker_frequency),
+            C.c_double(aligned_fraction_threshold), C.c_double(near_diagonal_fraction_threshold), C.c_uint32(delta_threshold),
+            abi.as_ptr(flags, C.c_uint8), abi.as_ptr(aligned, C.c_uint32), abi.as_ptr(near, C.c_uint32),
+            abi.as_ptr(digests, C.c_uint64)), "oracle_flag_palindromic_reads")
+        return flags, aligned, near, digests
 
     def hash_windows(self, kmer_ids, m, iteration):
         k = np.ascontiguousarray(kmer_ids, dtype=np.uint32)

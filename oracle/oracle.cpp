@@ -4,6 +4,7 @@
 // against it field by field.  Used by tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg ONLY.
 #include "restated.hpp"
+#include "method0.hpp"
 #include "../include/shasta_mi355x.h"
 
 #include <atomic>
@@ -412,6 +413,34 @@ int oracle_alignment_info(const uint32_t* ordinals, uint64_t n, uint32_t nx, uin
     createInfo(ord, nx, ny, info);
     copyInfo(info, *out);
     return 0;
+}
+
+// Palindromic-read flagging: method-0 self-alignment of every read + the flag rule.
+// flags / alignedCount / nearDiagonalCount / digests: readCount entries each (the last three optional).
+int oracle_flag_palindromic_reads(
+    uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint32_t maxSkip, uint32_t maxDrift, uint32_t maxMarkerFrequency,
+    double alignedFractionThreshold, double nearDiagonalFractionThreshold, uint32_t deltaThreshold,
+    uint8_t* flags, uint32_t* alignedCount, uint32_t* nearDiagonalCount, uint64_t* digests)
+{
+    try {
+        const uint8_t* all = static_cast<const uint8_t*>(markersData);
+        std::array<std::vector<uint32_t>, 2> kmerIds;
+        std::vector<std::array<uint32_t, 2>> alignment;
+        for(uint64_t r = 0; r < readCount; r++) {
+            for(uint64_t s = 0; s < 2; s++) {
+                const uint64_t begin = markersToc[2 * r + s], end = markersToc[2 * r + s + 1];
+                extractKmerIds(all + 7 * begin, end - begin, kmerIds[s]);
+            }
+            const method0::ReadVerdict v = method0::flagRead(kmerIds, maxSkip, maxDrift, maxMarkerFrequency,
+                alignedFractionThreshold, nearDiagonalFractionThreshold, deltaThreshold, alignment);
+            flags[r] = v.palindromic ? 1 : 0;
+            if(alignedCount) alignedCount[r] = v.alignedMarkerCount;
+            if(nearDiagonalCount) nearDiagonalCount[r] = v.nearDiagonalMarkerCount;
+            if(digests) digests[r] = method0::digest(alignment);
+        }
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
 }
 
 }  // extern "C"

@@ -94,6 +94,18 @@ class Assembler:
         self._require("Reads-Bases.toc", "Reads-Bases.data", "Reads-BaseCount", "Kmers")
         self._check(self._lib.shasta_mi355x_host_find_markers(self._data.encode(), C.c_uint64(threadCount), C.c_uint64(self._page)))
 
+    def flagPalindromicReads(self, maxSkip, maxDrift, maxMarkerFrequency, alignedFractionThreshold,
+                             nearDiagonalFractionThreshold, deltaThreshold, threadCount=0):
+        """shasta.Assembler.flagPalindromicReads (src/PythonModule.cpp:251-259; src/AssemblerAlign.cpp:652-698):
+        sets the isPalindromic bit of Data/ReadFlags.  Returns (reads, reads settled by the device screen, flagged)."""
+        self._require("Markers.toc", "Markers.data", "ReadFlags")
+        counts = (C.c_uint64 * 3)()
+        self._check(self._lib.shasta_mi355x_host_flag_palindromic_reads(
+            self._data.encode(), C.c_uint32(maxSkip), C.c_uint32(maxDrift), C.c_uint32(maxMarkerFrequency),
+            C.c_double(alignedFractionThreshold), C.c_double(nearDiagonalFractionThreshold), C.c_uint32(deltaThreshold),
+            C.c_uint64(threadCount), counts))
+        return int(counts[0]), int(counts[1]), int(counts[2])
+
     def findAlignmentCandidatesLowHash0(self, m, hashFraction, minHashIterationCount, alignmentCandidatesPerRead,
                                         minBucketSize, maxBucketSize, minFrequency, log2MinHashBucketCount=0, threadCount=0):
         self._check(self._lib.shasta_mi355x_host_find_alignment_candidates_lowhash0(

@@ -300,6 +300,15 @@ int shasta_mi355x_banded_dp(const uint32_t* k0, uint32_t nx, const uint32_t* k1,
     API_END(1)
 }
 
+int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx* c, uint64_t deltaThreshold, uint32_t* bound)
+{
+    API_BEGIN
+    if(!c || !bound) throw std::runtime_error("palindromic_screen: null argument");
+    palindromicScreen(c->impl, deltaThreshold, bound);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_dp_forward_version(void)
 {
     API_BEGIN

@@ -63,6 +63,8 @@ void findMarkers(Context&, uint64_t readCount, const uint64_t* readsToc, const u
     uint64_t k, const void* kmerTable, uint64_t kmerInfoStride, uint64_t isMarkerOffset, const uint8_t* readFlags,
     bool wantPacked, shasta_markers_result&);
 void findMarkersFree(shasta_markers_result&);
+// palindromic.hip: per read, an upper bound on the near-diagonal marker count of its self-alignment.
+void palindromicScreen(Context&, uint64_t deltaThreshold, uint32_t* bound);
 int dpForwardVersion();          // align4.hip: 1 or 2, decided once per process (environment, else a comparison on the device)
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);

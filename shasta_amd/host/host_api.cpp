@@ -3,6 +3,7 @@
 // shasta_amd.Assembler mirror of the reference's pybind11 class, src/PythonModule.cpp:135-345).
 // Returns 0 on success; shasta_mi355x_host_last_error() gives the message otherwise.
 #include "OverlapStages.hpp"
+#include "PalindromicReads.hpp"
 
 #include <string>
 
@@ -85,6 +86,36 @@ int shasta_mi355x_host_create_read_graph(const char* dataDirectory, uint32_t max
 {
     HOST_BEGIN
     (void)createReadGraph(dataDirectory, maxAlignmentCount, maxTrim, largeDataPageSize);
+    HOST_END
+}
+
+// Assembler::flagPalindromicReads, src/AssemblerAlign.cpp:652-698.  alignment (optional): for tests, the method-0
+// self-alignment of one read is available through shasta_mi355x_host_self_alignment_method0.
+int shasta_mi355x_host_flag_palindromic_reads(const char* dataDirectory, uint32_t maxSkip, uint32_t maxDrift, uint32_t maxMarkerFrequency,
+    double alignedFractionThreshold, double nearDiagonalFractionThreshold, uint32_t deltaThreshold, uint64_t threadCount,
+    uint64_t* counts /* optional: readCount, screenedOut, palindromic */)
+{
+    HOST_BEGIN
+    PalindromicReadOptions o;
+    o.maxSkip = maxSkip; o.maxDrift = maxDrift; o.maxMarkerFrequency = maxMarkerFrequency;
+    o.alignedFractionThreshold = alignedFractionThreshold; o.nearDiagonalFractionThreshold = nearDiagonalFractionThreshold;
+    o.deltaThreshold = deltaThreshold;
+    const PalindromicReadCounts c = flagPalindromicReads(dataDirectory, o, threadCount);
+    if(counts) { counts[0] = c.readCount; counts[1] = c.screenedOut; counts[2] = c.palindromic; }
+    HOST_END
+}
+
+// Alignment method 0 of a read against its reverse complement (the host half of the step above), for unit
+// parity: ordinals gets 2 * (*count) values, (ordinal0, ordinal1) per aligned marker; capacity is in pairs.
+int shasta_mi355x_host_self_alignment_method0(const uint32_t* kmerIds0, const uint32_t* kmerIds1, uint32_t n,
+    uint32_t maxSkip, uint32_t maxDrift, uint32_t maxMarkerFrequency, uint32_t* ordinals, uint64_t capacity, uint64_t* count)
+{
+    HOST_BEGIN
+    std::vector<std::pair<uint32_t, uint32_t>> alignment;
+    selfAlignmentMethod0(kmerIds0, kmerIds1, n, maxSkip, maxDrift, maxMarkerFrequency, alignment);
+    if(alignment.size() > capacity) throw std::runtime_error("self_alignment_method0: output capacity too small.");
+    for(size_t i = 0; i < alignment.size(); i++) { ordinals[2 * i] = alignment[i].first; ordinals[2 * i + 1] = alignment[i].second; }
+    *count = alignment.size();
     HOST_END
 }
 

@@ -3,11 +3,13 @@
 // Data/ directory, with the work done on the GPU.
 //   shasta_mi355x_stage lowhash0 <Data> [m hashFraction minHashIterationCount alignmentCandidatesPerRead
 //                                        log2MinHashBucketCount minBucketSize maxBucketSize minFrequency]
+//   shasta_mi355x_stage palindromic <Data> [maxSkip maxDrift maxMarkerFrequency alignedFractionThreshold nearDiagonalFractionThreshold deltaThreshold]
 //   shasta_mi355x_stage candidate-table <Data>
 //   shasta_mi355x_stage read-graph <Data> [maxAlignmentCount maxTrim]
 //   shasta_mi355x_stage align    <Data> [minAlignedMarkerCount minAlignedFraction maxSkip maxDrift maxTrim suppressContainments]
 // Exit codes follow srcMain/main.cpp:103-129: 0 success, 1 std::runtime_error / other exception.
 #include "OverlapStages.hpp"
+#include "PalindromicReads.hpp"
 
 #include <cstdlib>
 #include <iostream>
@@ -18,7 +20,7 @@ using namespace shasta_mi355x::host;
 int main(int argc, char** argv)
 {
     try {
-        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage lowhash0|candidate-table|align|read-graph <DataDirectory> [options...]");
+        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage markers|palindromic|lowhash0|candidate-table|align|read-graph <DataDirectory> [options...]");
         const std::string command = argv[1], data = argv[2];
         auto arg = [&](int k, const char* fallback) { return std::string(argc > k ? argv[k] : fallback); };
         if(command == "lowhash0") {
@@ -29,6 +31,14 @@ int main(int argc, char** argv)
         } else if(command == "markers") {
             // Assembler::findMarkers (srcMain/main.cpp: the step before the two seams).
             findMarkers(data, 0);
+        } else if(command == "palindromic") {
+            // Assembler::flagPalindromicReads, srcMain/main.cpp:654-663, the step before LowHash0; defaults src/AssemblerOptions.cpp:255-288.
+            PalindromicReadOptions o;
+            o.maxSkip = uint32_t(std::stoul(arg(3, "100"))); o.maxDrift = uint32_t(std::stoul(arg(4, "100")));
+            o.maxMarkerFrequency = uint32_t(std::stoul(arg(5, "10")));
+            o.alignedFractionThreshold = std::stod(arg(6, "0.1")); o.nearDiagonalFractionThreshold = std::stod(arg(7, "0.1"));
+            o.deltaThreshold = uint32_t(std::stoul(arg(8, "100")));
+            (void)flagPalindromicReads(data, o, 0);
         } else if(command == "candidate-table") {
             // Assembler::computeCandidateTable, between the two seams (srcMain/main.cpp:706).
             Markers markers;

@@ -28,6 +28,7 @@ EXPORTS = [
     "shasta_mi355x_lh_finish",
     "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
     "shasta_mi355x_find_markers", "shasta_mi355x_find_markers_free",
+    "shasta_mi355x_palindromic_screen",
 ]
 
 
@@ -305,6 +306,14 @@ class Context:
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.c_int(1 if borrow else 0), C.byref(res)),
             "shasta_mi355x_align3_run")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def palindromic_screen(self, delta_threshold):
+        """Per read: an upper bound on the near-diagonal marker count of its method-0 self-alignment."""
+        bound = np.zeros(self.read_count, dtype=np.uint32)
+        self.library._check(self.lib.shasta_mi355x_palindromic_screen(
+            C.c_void_p(self.handle), C.c_uint64(delta_threshold), abi.as_ptr(bound, C.c_uint32)),
+            "shasta_mi355x_palindromic_screen")
+        return bound
 
     def kernel_times(self):
         t = abi.KernelTimes()
