@@ -1147,6 +1147,7 @@ bandedDpForwardKernel2(
         const bool isH = hh > m1;                                   // from (i-1, j): diagonal b-1
         int32_t v = max(m1, hh) + GAP_SCORE;
         if constexpr (STEADY) {
+            SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
             H[c] = exists[c] ? v : 0;
         } else {
             const bool valid = uint32_t(sc - lo[c]) <= span[c];
@@ -1188,6 +1189,7 @@ bandedDpForwardKernel2(
     };
     auto flushLine = [&](uint32_t lineIndex) {
         __builtin_amdgcn_wave_barrier();
+        SHASTA_DEVICE_CHECK(uint64_t(lineIndex) * 32 + 32 <= ((uint64_t(iters) * RW + 31) & ~31ULL));      // inside the bundle's trace (dpBundleKernel)
         const uint32_t d = reinterpret_cast<const uint32_t*>(line)[lane];
         reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = d;
         __builtin_amdgcn_wave_barrier();
@@ -1264,13 +1266,14 @@ bandedDpForwardKernel2(
             for(uint32_t grp = 0; grp < groups; grp++) {
 #pragma unroll
                 for(int blk = 0; blk < AL / U; blk++) {
+                    SHASTA_DEVICE_CHECK(pa >= p0 && pa + U <= p0 + nx && pb >= p1 && pb + U <= p1 + ny);
                     const KmerQuad newA = *reinterpret_cast<const KmerQuad*>(pa);
                     const KmerQuad newB = *reinterpret_cast<const KmerQuad*>(pb);
                     pa += U; pb += U;
 #pragma unroll
                     for(int u = 0; u < U; u++) {
                         uint64_t words[RW];
-                        antiDiagonals(std::true_type{}, 0, [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
+                        antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
                         const int slot = (blk * U + u) % F;
                         putRecord(slot, words);
                         if(slot == F - 1) { flushLine(lineIndex); ++lineIndex; }

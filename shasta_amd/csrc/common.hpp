@@ -90,6 +90,12 @@ struct EventTimer {
     double seconds() { HIP_CHECK(hipEventSynchronize(b)); float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b)); return ms * 1e-3; }
 };
 
+// An invariant of device code that the emulated build (tests/emu, -DSHASTA_DEVICE_CHECK=...) verifies on
+// every lane; compiled out of the product.
+#ifndef SHASTA_DEVICE_CHECK
+#define SHASTA_DEVICE_CHECK(x) ((void)0)
+#endif
+
 inline unsigned divUp(uint64_t a, uint64_t b) { return unsigned((a + b - 1) / b); }
 
 }  // namespace shasta_mi355x
