@@ -1092,7 +1092,7 @@ bandedDpForwardKernel2(
     constexpr int AL = F > U ? F : U;                     // steady iterations come in groups of AL: whole blocks, whole lines
     constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
     static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
-    __shared__ uint64_t traceLines[4 * 32];               // one 256-byte line per wavefront of the block
+    __shared__ __attribute__((aligned(16))) uint64_t traceLines[4 * 32];   // one 256-byte line per wavefront of the block (16-byte LDS writes)
     const int lane = laneId();
     const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(bundle >= bundleCount) return;                     // whole wave leaves: all 64 lanes are active below, no block barriers

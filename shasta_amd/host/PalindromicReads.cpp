@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <queue>
 #include <stdexcept>
 #include <thread>
@@ -223,6 +224,7 @@ PalindromicReadCounts flagPalindromicReads(const std::string& dataDirectory, con
     }
     std::atomic<uint64_t> next(0);
     std::string firstError;
+    std::mutex errorMutex;
     auto worker = [&]() {
         try {
             Method0 work;
@@ -249,7 +251,8 @@ PalindromicReadCounts flagPalindromicReads(const std::string& dataDirectory, con
                 flags[r] = uint8_t(flags[r] | 1u);
             }
         } catch(const std::exception& e) {
-            firstError = e.what();
+            std::lock_guard<std::mutex> lock(errorMutex);
+            if(firstError.empty()) firstError = e.what();
         }
     };
     std::vector<std::thread> threads;
