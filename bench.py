@@ -302,6 +302,7 @@ def main():
             "hashWindowsKernel<4>": {
                 "launches_per_step": hash_n // steps, "avg_ms": hash_avg * 1e3,
                 "algorithmic_bytes_per_launch": hash_b // max(1, hash_n), "achieved_GBps": hash_gbs,
+                "frac_of_hbm_peak": hash_gbs / HBM_PEAK_GBS,      # the HBM-natured kernel of the path
                 "seconds_per_step": hash_s / steps,
             },
         }
