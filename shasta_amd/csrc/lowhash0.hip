@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -104,7 +105,14 @@ constexpr int HASH_THREADS = HASH_TILE;
 constexpr int HASH_HALO = 32;                 // supports m <= 33
 constexpr int HASH_STAGE = 1024;
 
-template<int M_FIXED>
+// SHARED_MIX: the 8-byte block (kmer ids j, j+1) is block b of window j - 2b, and its transform
+// murmurMix -- two of the three 64-bit multiplies a block costs -- does not depend on the window:
+// every thread transforms the block that starts at its marker once, into LDS, and a window reads
+// the m/2 transforms it needs.  2 + m/2 + (m odd) + 1 multiplies per window instead of
+// 3 (m/2) + (m odd) + 1 (m = 4: 5 instead of 7); the kernel is bound by those quarter-rate
+// multiplies, not by HBM.  Same hashes; SHASTA_MI355X_HASH=1 runs the
+// version without sharing (the one timed on the MI355X in round 1).
+template<int M_FIXED, bool SHARED_MIX>
 __global__ void __launch_bounds__(HASH_THREADS)
 hashWindowsKernel(
     const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc,
@@ -119,6 +127,7 @@ hashWindowsKernel(
     __shared__ uint64_t sVals[HASH_STAGE];
     __shared__ uint32_t sFill;
     __shared__ unsigned long long sBase;
+    __shared__ uint64_t sMix[SHARED_MIX ? HASH_TILE + HASH_HALO : 1];
 
     const uint32_t mm = M_FIXED ? uint32_t(M_FIXED) : m;
     const int tid = int(threadIdx.x);
@@ -150,6 +159,12 @@ hashWindowsKernel(
         sK[tid] = curK;
         if(tid < int(mm) - 1) sK[HASH_TILE + tid] = curHalo;
         __syncthreads();
+        if constexpr (SHARED_MIX) {
+            // Blocks that start at positions 0 .. HASH_TILE + m - 3 of the tile (the last window's last block).
+            sMix[tid] = murmurMix(uint64_t(sK[tid]) | (uint64_t(sK[tid + 1]) << 32));
+            if(tid + 2 < int(mm)) sMix[HASH_TILE + tid] = murmurMix(uint64_t(sK[HASH_TILE + tid]) | (uint64_t(sK[HASH_TILE + tid + 1]) << 32));
+            __syncthreads();
+        }
 
         bool hit = false;
         uint64_t hash = 0;
@@ -167,7 +182,18 @@ hashWindowsKernel(
             }
             // Reads with fewer than m markers (:337) and palindromic reads (:325) produce nothing.
             if(i + mm <= end && !palindromic) {
-                hash = murmurWindow<M_FIXED>(&sK[tid], mm, seed);
+                if constexpr (SHARED_MIX) {
+                    const uint64_t mul = 0xc6a4a7935bd1e995ULL;
+                    uint64_t h = seed ^ (uint64_t(4u * mm) * mul);
+                    const uint32_t blocks = mm >> 1;
+#pragma unroll
+                    for(uint32_t b = 0; b < blocks; b++) { h ^= sMix[tid + 2 * int(b)]; h *= mul; }
+                    if(mm & 1u) { h ^= uint64_t(sK[tid + int(mm) - 1]); h *= mul; }
+                    h ^= h >> 47; h *= mul; h ^= h >> 47;
+                    hash = h;
+                } else {
+                    hash = murmurWindow<M_FIXED>(&sK[tid], mm, seed);
+                }
                 hit = hash < hashThreshold;                                   // :350, strict
                 orientedReadId = r;
             }
@@ -495,7 +521,8 @@ void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uin
     // Persistent blocks: enough to fill 256 CUs x 8 blocks, each walking many tiles so
     // that one global atomic serves ~1000 low hashes.
     const unsigned blocks = unsigned(std::min<uint64_t>(tiles, 256 * 8));
-#define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL(hashWindowsKernel<MF>, dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
+    static const bool shared = [] { const char* e = std::getenv("SHASTA_MI355X_HASH"); return !(e != nullptr && std::atoi(e) == 1); }();
+#define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL((shared ? hashWindowsKernel<MF, true> : hashWindowsKernel<MF, false>), dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
         (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), (const uint8_t*)ctx.readFlags.data(), \
         (const uint4*)ctx.tileDesc.data(), markerBegin, markerEnd, ctx.markerCount, \
         m, seed, threshold, mask, outKeys, outVals, counter, capacity)

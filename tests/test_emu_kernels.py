@@ -155,3 +155,17 @@ def test_forward_dp_versions(emu_lib, oracle_lib, version):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_versions_check.py"), emu_lib.path, str(version or 2), "5"],
                          env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("version", [1, 2])
+def test_window_hash_kernel_versions_for_every_m(emu_lib, version):
+    """K1 with and without shared block transforms, m = 1 .. 13, through LowHash0 against the oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("SHASTA_MI355X_HASH", None)
+    if version == 1:
+        env["SHASTA_MI355X_HASH"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hash_versions_check.py"), emu_lib.path],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
