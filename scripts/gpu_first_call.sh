@@ -12,7 +12,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 echo "host: $(nproc) cores, $(free -g | awk '/Mem:/{print $2" GiB RAM, "$7" GiB available"}')"
 for f in tests/test_gpu_lowhash0.py tests/test_gpu_align4.py tests/test_gpu_host_stages.py tests/test_gpu_distributed.py \
-         tests/test_gpu_zz_assembler_mirror.py tests/test_gpu_zzz_align3.py tests/test_gpu_zzz_dp_versions.py tests/test_gpu_zzz_palindromic.py tests/test_gpu_zzzz_large_properties.py; do
+         tests/test_gpu_zz_assembler_mirror.py tests/test_gpu_zzz_align3.py  tests/test_gpu_zzz_palindromic.py tests/test_gpu_zzzz_large_properties.py tests/test_gpu_zzzzz_kernel_versions.py; do
   echo "== $f"
   timeout 900 python -m pytest $f -q -m gpu --timeout 300 2>&1 | tail -4
 done
