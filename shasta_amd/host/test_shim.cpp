@@ -48,6 +48,18 @@ int host_write_data_dir(const char* dir, uint64_t readCount, const uint64_t* toc
     SHIM_END
 }
 
+// Data/ReadFlags alone (the reference's ReadLoader writes it with the reads).
+int host_write_read_flags(const char* dir, uint64_t readCount, const uint8_t* flags)
+{
+    SHIM_BEGIN
+    ReadFlagsVector readFlags;
+    readFlags.createNew(std::string(dir) + "/ReadFlags");
+    readFlags.resize(readCount);
+    for(uint64_t i = 0; i < readCount; i++) readFlags[i] = flags ? flags[i] : 0;
+    readFlags.unreserve();
+    SHIM_END
+}
+
 int host_open_vector(const char* path, uint64_t objectSize, uint64_t* objectCount, uint64_t* fileBytes, void* out, uint64_t capacity)
 {
     SHIM_BEGIN

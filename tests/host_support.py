@@ -27,6 +27,10 @@ class HostShim:
         self._check(self.lib.host_write_data_dir(directory.encode(), C.c_uint64((len(toc) - 1) // 2), abi.as_ptr(toc, C.c_uint64),
                                                  C.c_void_p(data7.ctypes.data), fp), "host_write_data_dir")
 
+    def write_read_flags(self, directory, read_count, flags=None):
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self._check(self.lib.host_write_read_flags(directory.encode(), C.c_uint64(read_count), fp), "host_write_read_flags")
+
     def open_vector(self, path, object_size):
         count, size = C.c_uint64(), C.c_uint64()
         self._check(self.lib.host_open_vector(path.encode(), C.c_uint64(object_size), C.byref(count), C.byref(size), None, C.c_uint64(0)), "host_open_vector")

@@ -67,3 +67,48 @@ def find_markers_on_a_data_directory(tmp_path, host_library):
     assert np.array_equal(toc.view("<u8").reshape(-1), g.toc)
     assert np.array_equal(data.reshape(-1), g.data7)
 
+
+
+def whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host_library):
+    """Reads -> markers -> palindromic flags -> LowHash0 -> candidate table -> Align4 -> read graph through the Python
+    mirror on one Data/ directory, every stage reading the files the previous one wrote; against what the
+    reference produced from the same 20 real reads (tiny.npz, palindromic.npz: made by the reference's own code)."""
+    from tests import marker_checks, palindromic_checks as pc
+    rt, rd, bc, im = marker_checks.tiny_reads()
+    g = support.Golden("tiny.npz")
+    read_count = len(bc)
+    d = str(tmp_path / "Data")
+    os.makedirs(d)
+    shim = host_support.HostShim()
+    shim.write_reads(d, rt, rd, bc)
+    shim.write_kmers(d, 10, im)
+    shim.write_read_flags(d, read_count, np.ones(read_count, np.uint8))     # stale flags: the stage must reset them
+    monkeypatch.chdir(tmp_path)
+    a = shasta.Assembler(hostLibrary=host_library)
+    a.accessKmers()
+    a.findMarkers()
+    toc, _ = shim.open_vector(os.path.join(d, "Markers.toc"), 8)
+    assert np.array_equal(toc.view("<u8").reshape(-1), g.toc)
+    a.accessMarkers()
+    counts = a.flagPalindromicReads(100, 100, 10, 0.1, 0.1, 100)
+    z, _ = pc.golden()
+    flags, _ = shim.open_vector(os.path.join(d, "ReadFlags"), 1)
+    assert np.array_equal(flags.reshape(-1) & 1, z["tiny_0_flags"]) and counts[0] == read_count and counts[2] == 0
+    a.findAlignmentCandidatesLowHash0(m=4, hashFraction=0.01, minHashIterationCount=10, alignmentCandidatesPerRead=20.0,
+                                      minBucketSize=0, maxBucketSize=10, minFrequency=2)
+    stored, _ = shim.open_vector(os.path.join(d, "AlignmentCandidates"), 12)
+    expected = g.z["lh0_candidates"]
+    assert np.array_equal(stored.view("<u4").reshape(-1, 3)[:, :2], expected[:, :2])
+    assert np.array_equal(stored[:, 8], expected[:, 2].astype(np.uint8))
+    a.computeCandidateTable()
+    a.accessAlignmentCandidates()
+    a.computeAlignments(shasta.AlignOptions(), 0)
+    al = oracle_lib.align4_batch(g.toc, g.data7, g.candidates(0), abi.default_align4_options(), want_ordinals=False, threads=0)
+    rows, _ = shim.open_vector(os.path.join(d, "AlignmentData"), 64)
+    got = np.frombuffer(rows.tobytes(), dtype=abi.ALIGNMENT_DATA_DTYPE)
+    assert len(got) == len(al.alignment_data) > 50
+    for field in abi.ALIGNMENT_DATA_DTYPE.names:
+        assert np.array_equal(got[field], al.alignment_data[field]), field
+    a.accessAlignmentData()
+    a.createReadGraph(6, 30)
+    assert os.path.exists(os.path.join(d, "ReadGraphEdges"))

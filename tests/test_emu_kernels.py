@@ -169,3 +169,9 @@ def test_window_hash_kernel_versions_for_every_m(emu_lib, version):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hash_versions_check.py"), emu_lib.path],
                          env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_whole_chain_on_the_tiny_reads(emu_lib, oracle_lib, tmp_path, monkeypatch):
+    from tests import mirror_checks
+    host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
+    mirror_checks.whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host)

@@ -72,3 +72,9 @@ def test_stage_executable_prints_the_reference_lines(gpu_lib, tmp_path):
     assert "Palindromic fraction is " in out.stdout
     stored, _ = host_support.HostShim().open_vector(os.path.join(d, "ReadFlags"), 1)
     assert np.array_equal(stored.reshape(-1) & 1, z["hairpins_0_flags"])
+
+
+def test_whole_chain_on_the_tiny_reads(gpu_lib, oracle_lib, tmp_path, monkeypatch):
+    # reads -> markers -> palindromic flags -> LowHash0 -> candidate table -> Align4 -> read graph on one Data/ directory
+    from tests import mirror_checks
+    mirror_checks.whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host_library_of(gpu_lib))
