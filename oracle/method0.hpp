@@ -10,7 +10,7 @@
 //   CompactUndirectedGraph::sortVertices       src/CompactUndirectedGraph.hpp:503-510
 //   AlignmentGraph::createEdges                src/AlignmentGraph.cpp:289-395
 //   CompactUndirectedGraph::doneAddingEdges    src/CompactUndirectedGraph.hpp:536-582
-//   findShortestPath                           src/shortestPath.hpp:57-161
+//   findShortestPath                           src/route.hpp:57-161
 //   Assembler::flagPalindromicReadsThreadFunction   src/AssemblerAlign.cpp:702-770
 // The result of the reference depends on how std::sort orders equal keys (twice) and on how
 // std::priority_queue orders equal distances; the restatement therefore makes the same standard-library
@@ -62,45 +62,44 @@ inline void align(const std::array<std::vector<uint32_t>, 2>& kmerIds, size_t ma
         std::sort(markers[s].begin(), markers[s].end());
     }
 
-    // createVertices
+    // createVertices: one vertex per pair of markers with the same kmer id, unless that kmer id occurs
+    // more than maxMarkerFrequency times on either strand (then its markers stop counting as markers).
     std::vector<std::pair<GraphVertex, size_t>> vertexTable;      // the size_t is CompactUndirectedGraph's edge index, 0 while sorting
-    std::array<std::vector<bool>, 2> isLowFrequencyMarker;
-    for(size_t i = 0; i < 2; i++) isLowFrequencyMarker[i].assign(markers[i].size(), true);
+    std::array<std::vector<bool>, 2> keepsItsOrdinal;
+    for(size_t s = 0; s < 2; s++) keepsItsOrdinal[s].assign(markers[s].size(), true);
     {
-        auto it0 = markers[0].begin(), it1 = markers[1].begin();
-        const auto end0 = markers[0].end(), end1 = markers[1].end();
-        while(it0 != end0 && it1 != end1) {
-            if(it0->kmerId < it1->kmerId) ++it0;
-            else if(it1->kmerId < it0->kmerId) ++it1;
-            else {
-                const uint32_t kmerId = it0->kmerId;
-                auto it0End = it0, it1End = it1;
-                while(it0End != end0 && it0End->kmerId == kmerId) ++it0End;
-                while(it1End != end1 && it1End->kmerId == kmerId) ++it1End;
-                const size_t streakLength0 = size_t(it0End - it0), streakLength1 = size_t(it1End - it1);
-                if(streakLength0 > maxMarkerFrequency || streakLength1 > maxMarkerFrequency) {
-                    for(auto jt0 = it0; jt0 != it0End; ++jt0) isLowFrequencyMarker[0][jt0->ordinal] = false;
-                    for(auto jt1 = it1; jt1 != it1End; ++jt1) isLowFrequencyMarker[1][jt1->ordinal] = false;
-                } else {
-                    for(auto jt0 = it0; jt0 != it0End; ++jt0) {
-                        for(auto jt1 = it1; jt1 != it1End; ++jt1) {
-                            GraphVertex vertex;
-                            vertex.ordinals = {size_t(jt0->ordinal), size_t(jt1->ordinal)};
-                            vertexTable.push_back(std::make_pair(vertex, size_t(0)));
-                        }
+        const std::vector<MarkerWithOrdinal>& m0 = markers[0];
+        const std::vector<MarkerWithOrdinal>& m1 = markers[1];
+        size_t p0 = 0, p1 = 0;
+        while(p0 < m0.size() && p1 < m1.size()) {
+            if(m0[p0].kmerId < m1[p1].kmerId) { ++p0; continue; }
+            if(m1[p1].kmerId < m0[p0].kmerId) { ++p1; continue; }
+            const uint32_t common = m0[p0].kmerId;
+            size_t q0 = p0, q1 = p1;                              // ends of the two runs of this kmer id
+            while(q0 < m0.size() && m0[q0].kmerId == common) ++q0;
+            while(q1 < m1.size() && m1[q1].kmerId == common) ++q1;
+            if(q0 - p0 > maxMarkerFrequency || q1 - p1 > maxMarkerFrequency) {
+                for(size_t k = p0; k < q0; k++) keepsItsOrdinal[0][m0[k].ordinal] = false;
+                for(size_t k = p1; k < q1; k++) keepsItsOrdinal[1][m1[k].ordinal] = false;
+            } else {
+                for(size_t k0 = p0; k0 < q0; k0++) {
+                    for(size_t k1 = p1; k1 < q1; k1++) {
+                        GraphVertex vertex;
+                        vertex.ordinals = {size_t(m0[k0].ordinal), size_t(m1[k1].ordinal)};
+                        vertexTable.push_back(std::make_pair(vertex, size_t(0)));
                     }
                 }
-                it0 = it0End;
-                it1 = it1End;
             }
+            p0 = q0;
+            p1 = q1;
         }
     }
-    std::array<std::vector<uint32_t>, 2> correctedOrdinals;
+    std::array<std::vector<uint32_t>, 2> rank;
     for(size_t i = 0; i < 2; i++) {
-        correctedOrdinals[i].resize(markers[i].size());
-        uint32_t correctedOrdinal = 0;
+        rank[i].resize(markers[i].size());
+        uint32_t nextRank = 0;
         for(size_t j = 0; j < markers[i].size(); j++) {
-            correctedOrdinals[i][j] = isLowFrequencyMarker[i][j] ? correctedOrdinal++ : std::numeric_limits<uint32_t>::max();
+            rank[i][j] = keepsItsOrdinal[i][j] ? nextRank++ : std::numeric_limits<uint32_t>::max();
         }
     }
 
@@ -111,55 +110,55 @@ inline void align(const std::array<std::vector<uint32_t>, 2>& kmerIds, size_t ma
     vertexTable.push_back(std::make_pair(GraphVertex(), size_t(0)));
 
     // createEdges
-    std::vector<GraphEdge> edgeTable;
+    std::vector<GraphEdge> edges;
     const uint32_t markerCount0 = uint32_t(markers[0].size()), markerCount1 = uint32_t(markers[1].size());
     for(size_t vA = 0; vA < vertexTable.size(); vA++) {
         if(vA == vStart || vA == vFinish) continue;
-        const GraphVertex& vertexA = vertexTable[vA].first;
-        const int correctedOrdinalA0 = int(correctedOrdinals[0][vertexA.ordinals[0]]);
-        const int correctedOrdinalA1 = int(correctedOrdinals[1][vertexA.ordinals[1]]);
+        const GraphVertex& from = vertexTable[vA].first;
+        const int a0 = int(rank[0][from.ordinals[0]]);
+        const int a1 = int(rank[1][from.ordinals[1]]);
         for(size_t vB = vA + 1; vB < vertexTable.size(); vB++) {
             if(vB == vStart || vB == vFinish) continue;
-            const GraphVertex& vertexB = vertexTable[vB].first;
-            const int correctedOrdinalB0 = int(correctedOrdinals[0][vertexB.ordinals[0]]);
-            if(correctedOrdinalB0 > correctedOrdinalA0 + int(maxSkip)) break;
-            const int correctedOrdinalB1 = int(correctedOrdinals[1][vertexB.ordinals[1]]);
-            if(correctedOrdinalB1 < correctedOrdinalA1) continue;
-            if(size_t(std::abs(correctedOrdinalB1 - correctedOrdinalA1)) > maxSkip) continue;
+            const GraphVertex& to = vertexTable[vB].first;
+            const int b0 = int(rank[0][to.ordinals[0]]);
+            if(b0 > a0 + int(maxSkip)) break;
+            const int b1 = int(rank[1][to.ordinals[1]]);
+            if(b1 < a1) continue;
+            if(size_t(std::abs(b1 - a1)) > maxSkip) continue;
             if(maxDrift < maxSkip) {
-                const int offsetA = correctedOrdinalA0 - correctedOrdinalA1;
-                const int offsetB = correctedOrdinalB0 - correctedOrdinalB1;
-                if(size_t(std::abs(offsetA - offsetB)) > maxDrift) continue;
+                const int diagonalA = a0 - a1;
+                const int diagonalB = b0 - b1;
+                if(size_t(std::abs(diagonalA - diagonalB)) > maxDrift) continue;
             }
-            const int delta0 = correctedOrdinalB0 - correctedOrdinalA0;
-            const int delta1 = correctedOrdinalB1 - correctedOrdinalA1;
-            const size_t weight = size_t(std::abs(delta0 - 1) + std::abs(delta1 - 1));
-            edgeTable.push_back(GraphEdge{{vA, vB}, weight});
+            const int step0 = b0 - a0;
+            const int step1 = b1 - a1;
+            const size_t weight = size_t(std::abs(step0 - 1) + std::abs(step1 - 1));
+            edges.push_back(GraphEdge{{vA, vB}, weight});
         }
     }
     for(size_t v = 0; v < vertexTable.size(); v++) {
         if(v == vStart || v == vFinish) continue;
         const GraphVertex& vertex = vertexTable[v].first;
-        const int correctedOrdinal0 = int(correctedOrdinals[0][vertex.ordinals[0]]);
-        const int correctedOrdinal1 = int(correctedOrdinals[1][vertex.ordinals[1]]);
-        const int deltaFinish0 = int(markerCount0) - correctedOrdinal0;
-        const int deltaFinish1 = int(markerCount1) - correctedOrdinal1;
-        edgeTable.push_back(GraphEdge{{v, vStart}, uint64_t(std::abs(correctedOrdinal0) + std::abs(correctedOrdinal1))});
-        edgeTable.push_back(GraphEdge{{v, vFinish}, uint64_t(std::abs(deltaFinish0) + std::abs(deltaFinish1))});
+        const int c0 = int(rank[0][vertex.ordinals[0]]);
+        const int c1 = int(rank[1][vertex.ordinals[1]]);
+        const int toEnd0 = int(markerCount0) - c0;
+        const int toEnd1 = int(markerCount1) - c1;
+        edges.push_back(GraphEdge{{v, vStart}, uint64_t(std::abs(c0) + std::abs(c1))});
+        edges.push_back(GraphEdge{{v, vFinish}, uint64_t(std::abs(toEnd0) + std::abs(toEnd1))});
     }
 
     // doneAddingEdges: degree count, running sum, fill backwards, reverse every list.
-    for(const GraphEdge& e : edgeTable) { ++vertexTable[e.vertices[0]].second; ++vertexTable[e.vertices[1]].second; }
+    for(const GraphEdge& e : edges) { ++vertexTable[e.vertices[0]].second; ++vertexTable[e.vertices[1]].second; }
     size_t total = 0;
     for(auto& p : vertexTable) { total += p.second; p.second = total; }
     vertexTable.push_back(std::make_pair(GraphVertex(), total));
-    std::vector<size_t> edgeLists(total);
-    for(size_t e = 0; e < edgeTable.size(); e++) {
-        edgeLists[--vertexTable[edgeTable[e].vertices[0]].second] = e;
-        edgeLists[--vertexTable[edgeTable[e].vertices[1]].second] = e;
+    std::vector<size_t> incidence(total);
+    for(size_t e = 0; e < edges.size(); e++) {
+        incidence[--vertexTable[edges[e].vertices[0]].second] = e;
+        incidence[--vertexTable[edges[e].vertices[1]].second] = e;
     }
     for(size_t v = 0; v + 1 < vertexTable.size(); v++) {
-        std::reverse(edgeLists.begin() + vertexTable[v].second, edgeLists.begin() + vertexTable[v + 1].second);
+        std::reverse(incidence.begin() + vertexTable[v].second, incidence.begin() + vertexTable[v + 1].second);
     }
     const size_t vertexCount = vertexTable.size() - 1;
 
@@ -175,39 +174,39 @@ inline void align(const std::array<std::vector<uint32_t>, 2>& kmerIds, size_t ma
     vertexTable[vStart].first.distance = 0;
     std::priority_queue<std::pair<uint64_t, size_t>, std::vector<std::pair<uint64_t, size_t>>, OrderByDistanceGreater> q;
     q.push(std::make_pair(uint64_t(0), vStart));
-    std::vector<size_t> shortestPath;
+    std::vector<size_t> route;
     while(!q.empty()) {
         const auto p0 = q.top();
         q.pop();
-        const uint64_t distance0 = p0.first;
+        const uint64_t reached = p0.first;
         const size_t v0 = p0.second;
-        GraphVertex& vertex0 = vertexTable[v0].first;
-        if(vertex0.color == 1) continue;
-        vertex0.color = 1;
+        GraphVertex& here = vertexTable[v0].first;
+        if(here.color == 1) continue;
+        here.color = 1;
         if(v0 == vFinish) {
             size_t v = v0;
             while(true) {
-                shortestPath.push_back(v);
+                route.push_back(v);
                 if(v == vStart) break;
                 v = vertexTable[v].first.predecessor;
             }
-            std::reverse(shortestPath.begin(), shortestPath.end());
+            std::reverse(route.begin(), route.end());
             break;
         }
         for(size_t k = vertexTable[v0].second; k != vertexTable[v0 + 1].second; k++) {
-            const GraphEdge& e01 = edgeTable[edgeLists[k]];
-            const size_t v1 = e01.vertices[0] == v0 ? e01.vertices[1] : e01.vertices[0];
-            GraphVertex& vertex1 = vertexTable[v1].first;
-            if(vertex1.color == 1) continue;
-            const uint64_t distance1 = distance0 + e01.weight;
-            if(distance1 < vertex1.distance) {
-                q.push(std::make_pair(distance1, v1));
-                vertex1.predecessor = v0;
-                vertex1.distance = distance1;
+            const GraphEdge& link = edges[incidence[k]];
+            const size_t v1 = link.vertices[0] == v0 ? link.vertices[1] : link.vertices[0];
+            GraphVertex& there = vertexTable[v1].first;
+            if(there.color == 1) continue;
+            const uint64_t candidate = reached + link.weight;
+            if(candidate < there.distance) {
+                q.push(std::make_pair(candidate, v1));
+                there.predecessor = v0;
+                there.distance = candidate;
             }
         }
     }
-    for(const size_t v : shortestPath) {
+    for(const size_t v : route) {
         if(v == vStart || v == vFinish) continue;
         const GraphVertex& vertex = vertexTable[v].first;
         alignment.push_back({uint32_t(vertex.ordinals[0]), uint32_t(vertex.ordinals[1])});
