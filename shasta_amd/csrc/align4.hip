@@ -1188,6 +1188,7 @@ bandedDpForwardKernel2(
         }
     };
     auto flushLine = [&](uint32_t lineIndex) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         SHASTA_DEVICE_CHECK(uint64_t(lineIndex) * 32 + 32 <= ((uint64_t(iters) * RW + 31) & ~31ULL));      // inside the bundle's trace (dpBundleKernel)
         const uint32_t d = reinterpret_cast<const uint32_t*>(line)[lane];

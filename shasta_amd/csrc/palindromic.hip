@@ -53,6 +53,8 @@ palindromicScreenKernel(const uint32_t* __restrict__ kmerIds, const uint64_t* __
             const int64_t j = first + int64_t(w);
             window[w] = (j >= 0 && j < int64_t(n1)) ? b[j] : 0xffffffffu;
         }
+        // One wavefront's LDS operations run in order; the fence drains them and stops the compiler from moving the reads up.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const uint32_t i = i0 + uint32_t(lane);
         if(i < n) {
