@@ -2668,6 +2668,55 @@ void align4Free(shasta_align4_result& r)
 // Unit seam: one banded DP on the device (used by the parity tests of K10 alone).
 int dpForwardVersion() { return chooseDpForwardVersion(); }
 
+// Unit seam: K10 on many (pair, band) tasks at once -- sorted, bundled and run exactly as the tasks of an Align4 batch
+// are, so that wavefronts hold several tasks of different geometry.  Task t aligns kmerIds[begin0[t] .. +nx[t]) with
+// kmerIds[begin1[t] .. +ny[t]) inside [bandMin[t], bandMax[t]].  Results in task order: counts[t] aligned pairs,
+// scores[t], and the pairs themselves concatenated in ordinals.
+void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t taskCount,
+    const uint64_t* begin0, const uint32_t* nx, const uint64_t* begin1, const uint32_t* ny, const int32_t* bandMin, const int32_t* bandMax,
+    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity)
+{
+    int device = 0;
+    HIP_CHECK(hipGetDevice(&device));
+    Context ctx(device);
+    if(taskCount == 0) return;
+    if(taskCount > (1u << 24)) throw std::runtime_error("banded_dp_many: too many tasks.");
+    std::vector<PairDesc> pairs(taskCount);
+    std::vector<DpTask> tasks(taskCount);
+    for(uint64_t t = 0; t < taskCount; t++) {
+        if(nx[t] == 0 || ny[t] == 0 || begin0[t] + nx[t] > kmerCount || begin1[t] + ny[t] > kmerCount) throw std::runtime_error("banded_dp_many: a sequence is empty or outside kmerIds.");
+        if(bandMin[t] > bandMax[t] || bandMax[t] - bandMin[t] + 1 > 1024) throw std::runtime_error("banded_dp_many: band width must be in [1, 1024].");
+        if(bandMin[t] > int32_t(nx[t]) || bandMax[t] < -int32_t(ny[t])) throw std::runtime_error("banded_dp_many: the band misses the matrix.");
+        pairs[t].begin0 = begin0[t]; pairs[t].begin1 = begin1[t]; pairs[t].nx = nx[t]; pairs[t].ny = ny[t];
+        tasks[t].pair = uint32_t(t); tasks[t].bandMin = bandMin[t]; tasks[t].bandMax = bandMax[t]; tasks[t].label = 0;
+    }
+    std::vector<uint64_t> toc = {0, kmerCount / 2, kmerCount};
+    ctx.setMarkers(1, toc.data(), nullptr, kmerIds, nullptr);
+    hipStream_t stream = ctx.stream;
+    BatchScratch b;
+    b.pairs.reserve(taskCount, stream); b.tasks.reserve(taskCount, stream); b.pairBest.reserve(taskCount, stream);
+    HIP_CHECK(hipMemcpyAsync(b.pairs.data(), pairs.data(), taskCount * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(b.tasks.data(), tasks.data(), taskCount * sizeof(DpTask), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8 * taskCount, stream));
+    DeviceOptions opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
+    const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
+    (void)runDpTasks(ctx, ws, b, uint32_t(taskCount), opt, nullptr, nullptr);
+    std::vector<DpResult> results(taskCount);
+    HIP_CHECK(hipMemcpyAsync(results.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    uint64_t used = 0;
+    for(uint64_t t = 0; t < taskCount; t++) {
+        const DpResult& r = results[t];
+        if(used + r.markerCount > capacity) throw std::runtime_error("banded_dp_many: output capacity too small.");
+        if(r.markerCount) HIP_CHECK(hipMemcpy(ordinals + 2 * used, b.ordScratch.data() + 2 * r.ordBegin, 8ULL * r.markerCount, hipMemcpyDeviceToHost));
+        counts[t] = r.markerCount;
+        scores[t] = r.score;
+        used += r.markerCount;
+    }
+}
+
 void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
     uint32_t* ordinals, uint64_t capacity, uint64_t* count, int32_t* score)
 {

@@ -22,7 +22,7 @@ EXPORTS = [
     "shasta_mi355x_create", "shasta_mi355x_destroy",
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_get_kernel_times",
-    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_calibrate", "shasta_mi355x_dp_forward_version",
+    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_banded_dp_many", "shasta_mi355x_calibrate", "shasta_mi355x_dp_forward_version",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish",
@@ -149,6 +149,24 @@ class Library:
             C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
             C.byref(count), C.byref(score)), "shasta_mi355x_banded_dp")
         return out[:count.value].copy(), score.value
+
+    def banded_dp_many(self, kmer_ids, begin0, nx, begin1, ny, band_min, band_max):
+        """K10 on many tasks bundled as in an Align4 batch -> list of (ordinals [n, 2], score) per task."""
+        k = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
+        b0 = np.ascontiguousarray(begin0, np.uint64); b1 = np.ascontiguousarray(begin1, np.uint64)
+        n0 = np.ascontiguousarray(nx, np.uint32); n1 = np.ascontiguousarray(ny, np.uint32)
+        lo = np.ascontiguousarray(band_min, np.int32); hi = np.ascontiguousarray(band_max, np.int32)
+        t = len(b0)
+        cap = int(np.minimum(n0, n1).astype(np.uint64).sum()) + 1
+        counts = np.zeros(t, np.uint64); scores = np.zeros(t, np.int32); out = np.zeros(2 * cap, np.uint32)
+        self._check(self.lib.shasta_mi355x_banded_dp_many(
+            abi.as_ptr(k, C.c_uint32), C.c_uint64(len(k)), C.c_uint64(t),
+            abi.as_ptr(b0, C.c_uint64), abi.as_ptr(n0, C.c_uint32), abi.as_ptr(b1, C.c_uint64), abi.as_ptr(n1, C.c_uint32),
+            abi.as_ptr(lo, C.c_int32), abi.as_ptr(hi, C.c_int32),
+            abi.as_ptr(counts, C.c_uint64), abi.as_ptr(scores, C.c_int32), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap)),
+            "shasta_mi355x_banded_dp_many")
+        ends = np.cumsum(counts).astype(np.int64)
+        return [(out[2 * (e - int(c)):2 * e].reshape(-1, 2), int(s)) for e, c, s in zip(ends, counts, scores)]
 
     def dp_forward_version(self):
         v = int(self.lib.shasta_mi355x_dp_forward_version())

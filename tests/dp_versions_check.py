@@ -52,6 +52,45 @@ def sweep(lib, orc, seed, trials=6):
     return cases, bad
 
 
+def many(lib, orc, seed, tasks=140):
+    """Tasks of every band class in ONE call, so that wavefronts hold several tasks of different geometry (the path of an
+    Align4 batch: sorted by class and length, 4 / 2 / 1 tasks per wavefront); every task against the oracle."""
+    rng = np.random.default_rng(seed)
+    pieces, spec = [], []
+    at = 0
+    for t in range(tasks):
+        width = int(rng.choice([1, 5, 20, 32, 33, 50, 64, 65, 100, 128, 200, 256, 300, 512, 600, 1000], p=[.04, .06, .2, .06, .06, .15, .06, .06, .1, .04, .05, .03, .03, .02, .02, .02]))
+        alphabet = (1 << 20) if t % 2 == 0 else 9
+        n = int(rng.integers(3, 700)) if t % 5 else int(rng.integers(700, 1500))
+        m = max(1, n + int(rng.integers(-(n // 2), n // 2 + 1)))
+        genome = rng.integers(0, alphabet, size=n + m + 400, dtype=np.uint32)
+        off = int(rng.integers(0, 200))
+        a = noisy(rng, genome[:n], alphabet)
+        b = noisy(rng, genome[off:off + m], alphabet)
+        if len(a) == 0 or len(b) == 0:
+            continue
+        center = off if t % 3 else -off
+        lo = center + int(rng.integers(-20, 20)) - width // 2
+        lo = max(lo, -len(b) - width + 1)
+        lo = min(lo, len(a))
+        hi = lo + width - 1
+        if hi < -len(b) or lo > len(a):
+            continue
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), lo, hi))
+        at += len(a) + len(b)
+    kmer = np.concatenate(pieces)
+    spec = np.asarray(spec, dtype=np.int64)
+    got = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5])
+    bad = 0
+    for (b0, nx, b1, ny, lo, hi), (y, sy) in zip(spec, got):
+        x, sx = orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi))
+        if not (sx == sy and np.array_equal(x, y)):
+            bad += 1
+            print("MISMATCH in a batch: nx %d ny %d band [%d, %d]: score %d / %d, %d / %d markers" % (nx, ny, lo, hi, sx, sy, len(x), len(y)))
+    return len(spec), bad
+
+
 def main():
     from oracle import bindings
     from shasta_amd import lib as libmod
@@ -62,9 +101,12 @@ def main():
     print("forward kernel version", version)
     if version != expected:
         sys.exit("expected forward kernel version %d, the library chose %d" % (expected, version))
-    cases, bad = sweep(lib, bindings.OracleLib(), seed)
+    orc = bindings.OracleLib()
+    cases, bad = sweep(lib, orc, seed)
     print("cases %d bad %d" % (cases, bad))
-    sys.exit(1 if bad or cases < 80 else 0)
+    batch, bad_in_batch = many(lib, orc, seed + 100)
+    print("tasks in one batch %d bad %d" % (batch, bad_in_batch))
+    sys.exit(1 if bad or bad_in_batch or cases < 80 or batch < 100 else 0)
 
 
 if __name__ == "__main__":
