@@ -373,6 +373,8 @@ def main():
                                                           "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"),
                 "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
+                "kernel_versions": {"dp_forward": lib.dp_forward_version() if al is not None else None,
+                                    "window_hash": 1 if os.environ.get("SHASTA_MI355X_HASH") == "1" else 2},
                 "parallelism": "1 GPU" if world == 1 else
                                "%d GPUs, one job: reads sharded by id range, RCCL all-to-all of low-hash records and of pair "
                                "keys per MinHash iteration, candidates re-split evenly for Align4" % world,
