@@ -175,3 +175,9 @@ def test_whole_chain_on_the_tiny_reads(emu_lib, oracle_lib, tmp_path, monkeypatc
     from tests import mirror_checks
     host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
     mirror_checks.whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host)
+
+
+def test_randomized_campaign(emu_lib, oracle_lib):
+    from tests import campaign
+    assert campaign.align4(emu_lib, oracle_lib, range(900, 910)) > 1000
+    assert campaign.lowhash0(emu_lib, oracle_lib, range(950, 975)) >= 15

@@ -78,3 +78,11 @@ def test_whole_chain_on_the_tiny_reads(gpu_lib, oracle_lib, tmp_path, monkeypatc
     # reads -> markers -> palindromic flags -> LowHash0 -> candidate table -> Align4 -> read graph on one Data/ directory
     from tests import mirror_checks
     mirror_checks.whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host_library_of(gpu_lib))
+
+
+def test_randomized_campaign(gpu_lib, oracle_lib):
+    # seeded random read sets, candidate lists and parameter draws through both stages, against the oracle
+    from tests import campaign
+    emulated = os.environ.get("SHASTA_EMU") == "1"
+    assert campaign.align4(gpu_lib, oracle_lib, range(1000, 1010 if emulated else 1060)) > 1000
+    assert campaign.lowhash0(gpu_lib, oracle_lib, range(1100, 1125 if emulated else 1250)) >= 15
