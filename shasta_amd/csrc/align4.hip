@@ -20,6 +20,9 @@
 //                              (src/Align4.cpp:944-981, src/AssemblerAlign.cpp:439-472),
 //                              AlignmentInfo, streak compression.
 // Integer work throughout; no MFMA.  Bit-exactness notes: SURVEY.md Appendix A.2.
+// This file: the shared types and constants, then the kernels (align4_cells.hpp K8/K9, align4_dp.hpp K10,
+// align4_finish.hpp K11, align3.hpp for method 3), then the host side: batches, the class ladder of the cells
+// stage, the DP launches, result assembly.
 #include "context.hpp"
 
 #include <algorithm>
@@ -61,1578 +64,9 @@ struct DeviceOptions {
     uint32_t suppressContainments;
 };
 
-// ---------------------------------------------------------------------------
-// K8/K9: cells.
-// ---------------------------------------------------------------------------
-constexpr int CELLS_THREADS = 256;
-constexpr int MATCH_CHUNK = 2048;          // markers of read 1 hashed per round
-constexpr int MATCH_SLOTS = 4096;
-constexpr int CELL_SLOTS = 2048;
-constexpr int MAX_CELLS = 1024;
-constexpr uint32_t EMPTY32 = 0xffffffffu;
-constexpr uint64_t EMPTY64 = ~0ULL;
-
-constexpr uint32_t F_NEAR_LT = 1, F_NEAR_RB = 2, F_FWD = 4, F_BWD = 8;
-constexpr uint8_t PAIR_RESOURCE = 1;       // a cell table overflowed: retried with a larger table in HBM
-constexpr uint8_t PAIR_TOO_LONG = 2;       // outside the supported geometry (iX/iY >= 2^16 or band > 1024): skipped + reported
-
-__device__ __forceinline__ uint32_t hash32(uint32_t k) { return k * 2654435761u; }
-
-// getxy, src/Align4.cpp:184-191 (int32, C++ truncating division).
-__device__ __forceinline__ void getxy(uint32_t X, uint32_t Y, uint32_t nx, int32_t& x, int32_t& y)
-{
-    const int32_t Xs = int32_t(X), Ys = int32_t(Y);
-    x = (Xs - Ys + int32_t(nx) - 1) / 2;
-    y = (Xs + Ys - int32_t(nx) + 1) / 2;
-}
-
-// Reads of block-shared mutable state.  SMALL: LDS.  BIG: the tables live in HBM scratch and
-// are updated with atomics (L2); plain loads could hit a stale line of this CU's L1, so
-// they bypass it (agent-scope relaxed load = global_load sc1).
-template<bool BIG> __device__ __forceinline__ uint32_t ld(const uint32_t* p)
-{
-    if(BIG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-
-// One workgroup per candidate.  SMALL keeps the cell table (CELL_SLOTS) and the kept-cell
-// list (MAX_CELLS) in LDS; BIG uses a per-candidate region of HBM scratch of 2^slotsLog2
-// table slots (layout: keys[S] vals[S] cKey[S/2] cFlags[S/2] cLabel[S/2] cYMin[S/2] cYMax[S/2]).
-template<bool BIG>
-__global__ void __launch_bounds__(CELLS_THREADS)
-align4CellsKernel(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
-    const uint32_t* __restrict__ pairList, uint32_t listCount,
-    DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
-    uint8_t* __restrict__ pairFlags,
-    uint32_t* __restrict__ bigScratch, const uint64_t* __restrict__ bigOffsets, const uint8_t* __restrict__ bigSlotsLog2)
-{
-    __shared__ uint64_t matchTab[MATCH_SLOTS];
-    __shared__ uint32_t sCellKeys[BIG ? 1 : CELL_SLOTS];
-    __shared__ uint32_t sCellVals[BIG ? 1 : CELL_SLOTS];
-    __shared__ uint32_t sKey[BIG ? 1 : MAX_CELLS];
-    __shared__ uint32_t sFlags[BIG ? 1 : MAX_CELLS];
-    __shared__ uint32_t sLabel[BIG ? 1 : MAX_CELLS];
-    __shared__ uint32_t sYMin[BIG ? 1 : MAX_CELLS];
-    __shared__ uint32_t sYMax[BIG ? 1 : MAX_CELLS];
-    __shared__ uint32_t sCells, sOverflow, sChanged;
-
-    if(blockIdx.x >= listCount) return;
-    const uint32_t pair = pairList[blockIdx.x];
-    const int tid = int(threadIdx.x);
-    const PairDesc pd = pairs[pair];
-    const uint32_t nx = pd.nx, ny = pd.ny;
-    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
-    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
-
-    uint32_t *cellKeys, *cellVals, *cKey, *cFlags, *cLabel, *cYMin, *cYMax;
-    int slotsLog2;
-    if(BIG) {
-        slotsLog2 = int(bigSlotsLog2[blockIdx.x]);
-        const uint64_t S = 1ULL << slotsLog2;
-        uint32_t* base = bigScratch + bigOffsets[blockIdx.x];
-        cellKeys = base; cellVals = base + S; cKey = base + 2 * S; cFlags = cKey + S / 2;
-        cLabel = cFlags + S / 2; cYMin = cLabel + S / 2; cYMax = cYMin + S / 2;
-    } else {
-        slotsLog2 = 11;
-        cellKeys = sCellKeys; cellVals = sCellVals; cKey = sKey; cFlags = sFlags; cLabel = sLabel; cYMin = sYMin; cYMax = sYMax;
-    }
-    const uint32_t slots = 1u << slotsLog2;
-    const uint32_t maxCells = BIG ? slots / 2 : uint32_t(MAX_CELLS);
-    const int hashShift = 32 - slotsLog2;
-
-    for(uint32_t k = tid; k < slots; k += CELLS_THREADS) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
-    if(tid == 0) { sCells = 0; sOverflow = 0; sChanged = 0; }
-
-    // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
-    for(uint32_t chunk = 0; chunk < ny; chunk += MATCH_CHUNK) {
-        __syncthreads();
-        for(int k = tid; k < MATCH_SLOTS; k += CELLS_THREADS) matchTab[k] = EMPTY64;
-        __syncthreads();
-        const uint32_t chunkEnd = min(ny, chunk + uint32_t(MATCH_CHUNK));
-        for(uint32_t y = chunk + tid; y < chunkEnd; y += CELLS_THREADS) {
-            const uint32_t k = p1[y];
-            const unsigned long long entry = (uint64_t(k) << 32) | y;
-            uint32_t slot = hash32(k) >> (32 - 12);
-            for(;;) {
-                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
-                if(old == EMPTY64) break;
-                slot = (slot + 1) & (MATCH_SLOTS - 1);
-            }
-        }
-        __syncthreads();
-        for(uint32_t x = tid; x < nx; x += CELLS_THREADS) {
-            const uint32_t k = p0[x];
-            uint32_t slot = hash32(k) >> (32 - 12);
-            for(;;) {
-                const uint64_t e = matchTab[slot];
-                if(e == EMPTY64) break;
-                if(uint32_t(e >> 32) == k) {
-                    const uint32_t y = uint32_t(e);
-                    const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
-                    const uint32_t iX = X / opt.deltaX, iY = Y / opt.deltaY;
-                    if(iX >= 65536u || iY >= 65535u) { sOverflow = 2; }
-                    else {
-                        const uint32_t key = (iY << 16) | iX;
-                        uint32_t cs = hash32(key) >> hashShift;
-                        uint32_t probe = 0;
-                        for(; probe < slots; probe++) {
-                            const uint32_t old = atomicCAS(&cellKeys[cs], EMPTY32, key);
-                            if(old == EMPTY32 || old == key) { atomicAdd(&cellVals[cs], 1u); break; }
-                            cs = (cs + 1) & (slots - 1);
-                        }
-                        if(probe == slots) sOverflow = 1;
-                    }
-                }
-                slot = (slot + 1) & (MATCH_SLOTS - 1);
-            }
-        }
-    }
-    __syncthreads();
-
-    // Keep cells with enough entries (:417) and give them compact indices.
-    for(uint32_t k = tid; k < slots; k += CELLS_THREADS) {
-        const uint32_t key = ld<BIG>(&cellKeys[k]);
-        if(key == EMPTY32) continue;
-        if(uint64_t(ld<BIG>(&cellVals[k])) >= opt.minEntryCountPerCell) {
-            const uint32_t idx = atomicAdd(&sCells, 1u);
-            if(idx < maxCells) { cKey[idx] = key; cellVals[k] = idx; }
-            else { sOverflow = 1; cellVals[k] = EMPTY32; }
-        } else {
-            cellVals[k] = EMPTY32;
-        }
-    }
-    __syncthreads();
-    if(sOverflow) { if(tid == 0) pairFlags[pair] = (sOverflow == 2) ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
-    const int n = int(sCells);
-    if(n == 0) return;
-
-    auto find = [&](int32_t iX, int32_t iY) -> int {
-        if(iX < 0 || iY < 0 || iX >= 65536 || iY >= 65535) return -1;
-        const uint32_t key = (uint32_t(iY) << 16) | uint32_t(iX);
-        uint32_t cs = hash32(key) >> hashShift;
-        for(uint32_t probe = 0; probe < slots; probe++) {
-            const uint32_t k = ld<BIG>(&cellKeys[cs]);
-            if(k == EMPTY32) return -1;
-            if(k == key) return int(ld<BIG>(&cellVals[cs]));          // EMPTY32 (-1) for dropped cells
-            cs = (cs + 1) & (slots - 1);
-        }
-        return -1;
-    };
-
-    // Boundary flags (:424-429 with the corner rules of :530-626).
-    for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t key = ld<BIG>(&cKey[c]);
-        const uint32_t iX = key & 0xffffu, iY = key >> 16;
-        int32_t x, y;
-        getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
-        const uint32_t left = x < 0 ? 0u : uint32_t(x);
-        getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
-        const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
-        getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
-        const uint32_t top = y < 0 ? 0u : uint32_t(y);
-        getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
-        const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
-        uint32_t f = 0;
-        if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) f |= F_NEAR_LT | F_FWD;
-        if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) f |= F_NEAR_RB;
-        cFlags[c] = f;
-        cYMin[c] = EMPTY32; cYMax[c] = 0;
-    }
-
-    // forwardSearch (:682-729): a cell is forward accessible if a forward accessible cell
-    // lies at (iX-1 or iX, iY-1..iY+1).  Label propagation to the fixed point.
-    for(;;) {
-        __syncthreads();
-        if(tid == 0) sChanged = 0;
-        __syncthreads();
-        for(int c = tid; c < n; c += CELLS_THREADS) {
-            if(ld<BIG>(&cFlags[c]) & F_FWD) continue;
-            const uint32_t key = ld<BIG>(&cKey[c]);
-            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
-            bool reach = false;
-            for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = -1; dX <= 0; dX++) {
-                if(dX == 0 && dY == 0) continue;
-                const int j = find(iX + dX, iY + dY);
-                if(j >= 0 && (ld<BIG>(&cFlags[j]) & F_FWD)) { reach = true; break; }
-            }
-            if(reach) { atomicOr(&cFlags[c], F_FWD); sChanged = 1; }
-        }
-        __syncthreads();
-        if(!sChanged) break;
-    }
-    // backwardSearch (:736-787): seeds near right/bottom AND forward accessible; a cell is
-    // backward accessible if a backward accessible cell lies at (iX or iX+1, iY-1..iY+1).
-    for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t f = ld<BIG>(&cFlags[c]);
-        if((f & F_NEAR_RB) && (f & F_FWD)) atomicOr(&cFlags[c], F_BWD);
-    }
-    for(;;) {
-        __syncthreads();
-        if(tid == 0) sChanged = 0;
-        __syncthreads();
-        for(int c = tid; c < n; c += CELLS_THREADS) {
-            if(ld<BIG>(&cFlags[c]) & F_BWD) continue;
-            const uint32_t key = ld<BIG>(&cKey[c]);
-            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
-            bool reach = false;
-            for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = 0; dX <= 1; dX++) {
-                if(dX == 0 && dY == 0) continue;
-                const int j = find(iX + dX, iY + dY);
-                if(j >= 0 && (ld<BIG>(&cFlags[j]) & F_BWD)) { reach = true; break; }
-            }
-            if(reach) { atomicOr(&cFlags[c], F_BWD); sChanged = 1; }
-        }
-        __syncthreads();
-        if(!sChanged) break;
-    }
-
-    // Connected components of active cells, 8-neighbourhood (:792-868): min-label propagation.
-    for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t f = ld<BIG>(&cFlags[c]);
-        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? ld<BIG>(&cKey[c]) : EMPTY32;
-    }
-    for(;;) {
-        __syncthreads();
-        if(tid == 0) sChanged = 0;
-        __syncthreads();
-        for(int c = tid; c < n; c += CELLS_THREADS) {
-            const uint32_t mine = ld<BIG>(&cLabel[c]);
-            if(mine == EMPTY32) continue;
-            const uint32_t key = ld<BIG>(&cKey[c]);
-            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
-            uint32_t best = mine;
-            for(int dY = -1; dY <= 1; dY++) for(int dX = -1; dX <= 1; dX++) {
-                if(dX == 0 && dY == 0) continue;
-                const int j = find(iX + dX, iY + dY);
-                if(j >= 0) best = min(best, ld<BIG>(&cLabel[j]));
-            }
-            if(best < mine) { atomicMin(&cLabel[c], best); sChanged = 1; }
-        }
-        __syncthreads();
-        if(!sChanged) break;
-    }
-    // iY range of each component, stored at its root cell (the cell whose key is the label).
-    for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t label = ld<BIG>(&cLabel[c]);
-        if(label == EMPTY32) continue;
-        const int r = find(int32_t(label & 0xffffu), int32_t(label >> 16));
-        const uint32_t iY = ld<BIG>(&cKey[c]) >> 16;
-        atomicMin(&cYMin[r], iY);
-        atomicMax(&cYMax[r], iY);
-    }
-    __syncthreads();
-    // One banded alignment per component (:890-934).
-    for(int c = tid; c < n; c += CELLS_THREADS) {
-        const uint32_t key = ld<BIG>(&cKey[c]);
-        if(ld<BIG>(&cLabel[c]) != key) continue;
-        const uint32_t YMin = ld<BIG>(&cYMin[c]) * opt.deltaY;
-        const uint32_t YMax = (ld<BIG>(&cYMax[c]) + 1) * opt.deltaY - 1;
-        const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
-        const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
-        const int32_t bandWidth = bandMax - bandMin + 1;
-        if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;             // :929
-        if(bandWidth > 1024) { pairFlags[pair] = PAIR_TOO_LONG; continue; }
-        const uint32_t t = atomicAdd(taskCount, 1u);
-        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K8/K9, fast path.  A CHUNK is a set of candidates that share one oriented read: read 0
-// (candidates arrive sorted by readId0, src/LowHash0.cpp:204-214, and read 0 is always on
-// strand 0, src/AssemblerAlign.cpp:382) or, when read 1 is the shorter one, read 1 ("swapped",
-// gathered by the host).  One workgroup per chunk; its waves share the table of that read and
-// then work on different candidates of the chunk without ever synchronising again.
-//   build   read 0's kmer ids are copied to LDS and indexed by a two-choice bucketised LDS hash
-//           table (buckets of four 16-bit slots = one ds_read_b64; slot = hash tag | ordinal);
-//   probe   a candidate's other read is streamed through the table, four markers per lane per
-//           round: both buckets are read, the eight slots are tag-matched with SWAR compares,
-//           the kmer ids are compared in LDS: fixed trip count, no probe chains;
-//   count   (x,y) -> cell by magic-number division (getXY + createCells,
-//           src/Align4.cpp:171-177,380-436), one LDS atomic per hit on a packed cell word (folding
-//           equal neighbours first costs more instructions than the atomics it saves); the
-//           increment that reaches minEntryCountPerCell appends the cell to the kept list (:417);
-//   graph   the kept cells (Q per lane) live in registers; their forward/backward adjacency is
-//           a bit mask per cell, so forwardSearch / backwardSearch (:682-788) and the connected
-//           components (:792-868) are iterated ballots with no memory traffic;
-//   tasks   one DP task per component (:890-934), staged in LDS, appended with one global atomic.
-// Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
-// larger class, finally by align4CellsKernel<true>.
-// Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | per wave:
-//   cells[SC] (iY | iX | count packed) | kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
-// ---------------------------------------------------------------------------
-// firstMember indexes the member list (candidate indices of the batch).
-struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
-
-#ifdef SHASTA_PROFILE_PHASES
-__device__ unsigned long long g_phaseCycles[16];
-#define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
-    if((threadIdx.x & 63) == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
-#define PHASE_BEGIN() unsigned long long phaseT_ = __builtin_readcyclecounter()
-#else
-#define PHASE_MARK(k) do {} while(0)
-#define PHASE_BEGIN() do {} while(0)
-#endif
-
-// floor(v / d) = umulhi(v, magic) with magic = floor(2^32 / d) + 1, exact whenever v * d < 2^32
-// (the host only sends a candidate to this kernel if (nx + ny) * max(deltaX, deltaY) < 2^32).
-__device__ __forceinline__ uint32_t divMagic(uint32_t v, uint32_t magic) { return __umulhi(v, magic); }
-
-// LDS traffic of ONE wave is ordered by the hardware; this only stops the compiler from moving
-// LDS accesses across it and drains the counters.  Waves of a chunk never wait for each other
-// after the build, so no s_barrier may appear in the per-candidate code.
-__device__ __forceinline__ void waveLdsSync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t hash32b(uint32_t k) { return k * 0x85ebca6bu; }
-
-// Bits 15 and 31 of the result flag the 16-bit halves of v that are zero (exact, no carries).
-__device__ __forceinline__ uint32_t zeroHalves(uint32_t v)
-{
-    return ~(((v & 0x7fff7fffu) + 0x7fff7fffu) | v | 0x7fff7fffu);
-}
-
-constexpr int CELLS_UNROLL = 4;           // markers per lane per round
-constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
-constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
-__host__ __device__ inline size_t cellsWaveLdsWords(int scLog2, int Q)
-{
-    return (size_t(1) << scLog2) + 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
-}
-__host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
-{
-    return 2 * (size_t(1) << naLog2) + size_t(waves) * cellsWaveLdsWords(scLog2, Q);
-}
-
-template<int Q>
-__global__ void __launch_bounds__(384)
-align4CellsChunkKernel(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
-    const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
-    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
-    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
-    uint8_t* __restrict__ pairFlags)
-{
-    extern __shared__ uint32_t ldsWords[];
-    // Markers whose two buckets were both full when they arrived (the two-choice table runs at two
-    // entries per four-slot bucket on average, so a nearly full table overflows now and then).
-    constexpr uint32_t STASH = 32;
-    __shared__ uint32_t stashCount, stashKmer[STASH], stashOrdinal[STASH];
-    constexpr int MAXC = 64 * Q;
-    if(blockIdx.x >= chunkCount) return;
-    const CellsChunk chunk = chunks[blockIdx.x];
-    const int lane = laneId();
-    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const uint32_t NA = 1u << chunk.naLog2, SC = 1u << chunk.scLog2;
-    const int bucketShift = 32 - (int(chunk.naLog2) - 1), scShift = 32 - int(chunk.scLog2);
-    const int xBits = int(chunk.naLog2);
-    const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
-    uint32_t* const aKmers = ldsWords;
-    uint32_t* const aSlots = aKmers + NA;
-    uint32_t* const cells = aSlots + NA + wave * cellsWaveLdsWords(int(chunk.scLog2), Q);
-    uint32_t* const kept = cells + SC;
-    uint32_t* const scratch = kept + MAXC;                        // [0] kept count, [1] min, [2] max, [3] staged tasks
-    uint32_t* const stage = scratch + 8;
-    const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
-    PHASE_BEGIN();
-
-    // Tag of a kmer id (never all ones, so that an empty slot matches no tag) and its two buckets.
-    auto tagOf = [&](uint32_t h) { const uint32_t t = (h >> 4) & tagMask; return t == tagMask ? 0u : t; };
-
-    // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
-    //     candidates gathered by the host because they share a short read 1) read 1 ---
-    const PairDesc pdFirst = pairs[members[chunk.firstMember]];
-    const bool swapped = chunk.swapped != 0;
-    const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
-    const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
-    for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
-    if(threadIdx.x == 0) stashCount = 0;
-    if(lane == 0) scratch[3] = 0;
-    __syncthreads();
-    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
-        const uint32_t km = tabSeq[t];
-        aKmers[t] = km;
-        const uint32_t h = hash32(km);
-        const uint32_t b1 = h >> bucketShift, b2 = hash32b(km) >> bucketShift;
-        const uint32_t entry = (tagOf(h) << xBits) | t;
-        for(;;) {
-            // Free slots of the two candidate buckets; take the emptier bucket (ties: the first).
-            const uint32_t u0 = aSlots[2 * b1], u1 = aSlots[2 * b1 + 1], v0 = aSlots[2 * b2], v1 = aSlots[2 * b2 + 1];
-            const uint32_t fu0 = zeroHalves(~u0), fu1 = zeroHalves(~u1), fv0 = zeroHalves(~v0), fv1 = zeroHalves(~v1);
-            const int freeU = __popc(fu0) + __popc(fu1), freeV = __popc(fv0) + __popc(fv1);
-            if(freeU == 0 && freeV == 0) {
-                const uint32_t k = atomicAdd(&stashCount, 1u);
-                if(k < STASH) { stashKmer[k] = km; stashOrdinal[k] = t; }
-                break;
-            }
-            const bool useV = freeV > freeU;
-            const uint32_t f0 = useV ? fv0 : fu0, f1 = useV ? fv1 : fu1;
-            const uint32_t w0 = useV ? v0 : u0, w1 = useV ? v1 : u1;
-            const uint32_t base = 2 * (useV ? b2 : b1);
-            const bool second = f0 == 0;
-            const uint32_t f = second ? f1 : f0, old = second ? w1 : w0;
-            const int shift = (f & 0x8000u) ? 0 : 16;
-            const uint32_t updated = (old & ~(0xffffu << shift)) | (entry << shift);
-            if(atomicCAS(&aSlots[base + (second ? 1 : 0)], old, updated) == old) break;
-        }
-    }
-    __syncthreads();
-    PHASE_MARK(0);
-    const uint32_t stashed = stashCount;
-    if(stashed > STASH) {
-        // Too many markers of the tabled read share their buckets (a tandem repeat): the whole
-        // chunk goes to the next class.
-        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x80);
-        return;
-    }
-
-    for(uint32_t c = wave; c < chunk.count; c += waves) {
-        const uint32_t pair = members[chunk.firstMember + c];
-        const PairDesc pd = pairs[pair];
-        const uint32_t nx = pd.nx, ny = pd.ny;
-        const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
-        const uint32_t streamCount = swapped ? nx : ny;
-        int overflow = 0, reason = 0;
-
-        for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
-        if(lane == 0) scratch[0] = 0;
-        waveLdsSync();
-        PHASE_MARK(1);
-
-        // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
-        // Counts the hits of one round: hit[u] with table ordinal ti[u] and stream ordinal t.
-        auto countHits = [&](const bool (&hit)[CELLS_UNROLL], const uint32_t (&ti)[CELLS_UNROLL], uint32_t s0) {
-            bool pending[CELLS_UNROLL];
-            uint32_t key[CELLS_UNROLL], packed[CELLS_UNROLL], cs[CELLS_UNROLL], len[CELLS_UNROLL], probes[CELLS_UNROLL];
-#pragma unroll
-            for(int u = 0; u < CELLS_UNROLL; u++) {
-                const uint32_t t = s0 + u * WAVE + lane;
-                const uint32_t x = swapped ? t : ti[u], y = swapped ? ti[u] : t;
-                const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
-                const uint32_t iX = divMagic(X, magicX), iY = divMagic(Y, magicY);
-                // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; the host only sends
-                // candidates whose cell indices fit (others run in the HBM-scratch kernel).
-                const bool h = hit[u];
-                key[u] = h ? ((iY << 16) | iX) : EMPTY32;
-                len[u] = 1;
-                pending[u] = h;
-                packed[u] = (iY << CELLS_IX_BITS) | iX;
-                cs[u] = hash32(key[u]) >> scShift;
-                probes[u] = 0;
-            }
-            while(__any(pending[0] | pending[1] | pending[2] | pending[3])) {
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) {
-                    if(pending[u]) {
-                        const uint32_t cur = *reinterpret_cast<volatile uint32_t*>(&cells[cs[u]]);
-                        bool done = false;
-                        uint32_t before = 0;
-                        if(cur != EMPTY32 && (cur >> CELLS_COUNT_BITS) == packed[u]) {
-                            before = atomicAdd(&cells[cs[u]], len[u]) & ((1u << CELLS_COUNT_BITS) - 1);
-                            done = true;
-                        } else if(cur == EMPTY32) {
-                            // Claim the slot; on failure look at the same slot again.
-                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << CELLS_COUNT_BITS) | len[u]) == EMPTY32;
-                        } else {
-                            cs[u] = (cs[u] + 1) & (SC - 1);
-                            if(++probes[u] == SC) { overflow = max(overflow, 1); reason |= 1; pending[u] = false; }
-                        }
-                        if(done) {
-                            if(before < threshold && before + len[u] >= threshold) {           // :417
-                                const uint32_t idx = atomicAdd(&scratch[0], 1u);
-                                if(idx < uint32_t(MAXC)) kept[idx] = key[u];
-                            }
-                            pending[u] = false;
-                        }
-                    }
-                }
-            }
-        };
-
-        uint32_t kmNext[CELLS_UNROLL];
-#pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
-        for(uint32_t s0 = 0; s0 < streamCount; s0 += CELLS_UNROLL * WAVE) {
-            uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], m[CELLS_UNROLL][4], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
-            bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
-#pragma unroll
-            for(int u = 0; u < CELLS_UNROLL; u++) {
-                km[u] = kmNext[u];
-                const uint32_t tn = s0 + (CELLS_UNROLL + u) * WAVE + lane;
-                kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
-                valid[u] = s0 + u * WAVE + lane < streamCount;
-            }
-#pragma unroll
-            for(int u = 0; u < CELLS_UNROLL; u++) {
-                const uint32_t h = hash32(km[u]);
-                const uint32_t b1 = h >> bucketShift, b2 = hash32b(km[u]) >> bucketShift;
-                w[u][0] = aSlots[2 * b1]; w[u][1] = aSlots[2 * b1 + 1];
-                w[u][2] = aSlots[2 * b2]; w[u][3] = aSlots[2 * b2 + 1];
-                const uint32_t pattern = (tagOf(h) << xBits) * 0x00010001u, fieldMask = (tagMask << xBits) * 0x00010001u;
-                const bool same = b1 == b2;
-#pragma unroll
-                for(int i = 0; i < 4; i++) m[u][i] = zeroHalves((w[u][i] ^ pattern) & fieldMask);
-                if(same) { m[u][2] = 0; m[u][3] = 0; }
-                if(!valid[u]) { m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; }
-            }
-            // Resolve the tag matches (usually one per marker) against the kmer ids in LDS.
-            for(;;) {
-                bool more = false;
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) {
-                    // First tag match of this marker (static register indexing only).
-                    const bool s0m = m[u][0] != 0, s1m = !s0m && m[u][1] != 0, s2m = !s0m && !s1m && m[u][2] != 0;
-                    const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
-                    const uint32_t ww = s0m ? w[u][0] : (s1m ? w[u][1] : (s2m ? w[u][2] : w[u][3]));
-                    const bool cand = mm != 0;
-                    const bool low = (mm & 0x8000u) != 0;
-                    ti[u] = (low ? ww : (ww >> 16)) & xMask;
-                    ka[u] = aKmers[cand ? ti[u] : 0u];
-                    const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
-                    if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
-                    hit[u] = cand;
-                    more |= (m[u][0] | m[u][1] | m[u][2] | m[u][3]) != 0;
-                }
-                bool anyHit = false;
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = hit[u] && ka[u] == km[u]; anyHit |= hit[u]; }
-                if(__any(anyHit)) countHits(hit, ti, s0);
-                if(!__any(more)) break;
-            }
-            // The few markers that did not fit their buckets.
-            for(uint32_t k = 0; k < stashed; k++) {
-                const uint32_t sk = stashKmer[k], so = stashOrdinal[k];
-                bool anyHit = false;
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
-                if(__any(anyHit)) countHits(hit, ti, s0);
-            }
-        }
-        waveLdsSync();
-        PHASE_MARK(2);
-
-        const int n = int(scratch[0]);
-        if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
-        const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
-        if(anyHard || anySoft) {
-            // Bits 4-6 carry the reason (cell table full / kept list full / geometry) for diagnostics.
-            const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0);
-            if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
-            continue;
-        }
-        if(n == 0) continue;
-        const int nq = (n + WAVE - 1) / WAVE;
-
-        // --- kept cells in registers: boundary flags (:424-429 with the corner rules of :530-626) ---
-        uint32_t key[Q], flags[Q];
-#pragma unroll
-        for(int q = 0; q < Q; q++) {
-            const int cc = lane + q * WAVE;
-            key[q] = EMPTY32; flags[q] = 0;
-            if(cc >= n) continue;
-            key[q] = kept[cc];
-            const uint32_t iX = key[q] & 0xffffu, iY = key[q] >> 16;
-            int32_t x, y;
-            getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
-            const uint32_t left = x < 0 ? 0u : uint32_t(x);
-            getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
-            const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
-            getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
-            const uint32_t top = y < 0 ? 0u : uint32_t(y);
-            getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
-            const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
-            if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) flags[q] |= F_NEAR_LT;
-            if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) flags[q] |= F_NEAR_RB;
-        }
-        // Adjacency masks.  before[q][r] bit j: cell 64 r + j lies at (iX-1 or iX, iY-1..iY+1) of
-        // this lane's cell q (a forward move leads from it to this cell); after: (iX or iX+1, ...).
-        uint64_t before[Q][Q], after[Q][Q];
-#pragma unroll
-        for(int q = 0; q < Q; q++)
-#pragma unroll
-            for(int r = 0; r < Q; r++) { before[q][r] = 0; after[q][r] = 0; }
-#pragma unroll
-        for(int r = 0; r < Q; r++) {
-            if(r >= nq) break;
-            const int jEnd = min(WAVE, n - r * WAVE);
-            for(int j = 0; j < jEnd; j++) {
-                const uint32_t other = __builtin_amdgcn_readlane(key[r], j);
-                const int32_t oX = int32_t(other & 0xffffu), oY = int32_t(other >> 16);
-                const uint64_t bit = 1ULL << j;
-#pragma unroll
-                for(int q = 0; q < Q; q++) {
-                    if(q >= nq) break;
-                    const int32_t dX = oX - int32_t(key[q] & 0xffffu), dY = oY - int32_t(key[q] >> 16);
-                    const bool near = key[q] != EMPTY32 && dY >= -1 && dY <= 1 && other != key[q];
-                    if(near && (dX == -1 || dX == 0)) before[q][r] |= bit;
-                    if(near && (dX == 0 || dX == 1)) after[q][r] |= bit;
-                }
-            }
-        }
-        PHASE_MARK(3);
-
-        // forwardSearch (:682-729): seeds near left/top; closure under forward moves.
-        uint64_t fwd[Q], bwd[Q];
-#pragma unroll
-        for(int q = 0; q < Q; q++) fwd[q] = __ballot((flags[q] & F_NEAR_LT) != 0);
-        for(;;) {
-            bool changed = false;
-#pragma unroll
-            for(int q = 0; q < Q; q++) {
-                if(q >= nq) break;
-                uint64_t reach = 0;
-#pragma unroll
-                for(int r = 0; r < Q; r++) reach |= before[q][r] & fwd[r];
-                const uint64_t grown = fwd[q] | __ballot(reach != 0);
-                changed |= grown != fwd[q];
-                fwd[q] = grown;
-            }
-            if(!changed) break;
-        }
-        // backwardSearch (:736-787): seeds near right/bottom AND forward accessible.
-#pragma unroll
-        for(int q = 0; q < Q; q++) bwd[q] = __ballot((flags[q] & F_NEAR_RB) != 0) & fwd[q];
-        for(;;) {
-            bool changed = false;
-#pragma unroll
-            for(int q = 0; q < Q; q++) {
-                if(q >= nq) break;
-                uint64_t reach = 0;
-#pragma unroll
-                for(int r = 0; r < Q; r++) reach |= after[q][r] & bwd[r];
-                const uint64_t grown = bwd[q] | __ballot(reach != 0);
-                changed |= grown != bwd[q];
-                bwd[q] = grown;
-            }
-            if(!changed) break;
-        }
-        PHASE_MARK(4);
-        // Connected components of the active cells, 8-neighbourhood (:792-868), one at a time,
-        // seeded at the remaining active cell with the smallest key; one banded alignment per
-        // component (:890-934).
-        uint64_t remaining[Q];
-        bool anyRemaining = false;
-#pragma unroll
-        for(int q = 0; q < Q; q++) { remaining[q] = fwd[q] & bwd[q]; anyRemaining |= remaining[q] != 0; }
-        while(anyRemaining) {
-            uint32_t myMin = EMPTY32;
-#pragma unroll
-            for(int q = 0; q < Q; q++) if((remaining[q] >> lane) & 1ULL) myMin = min(myMin, key[q]);
-            if(lane == 0) { scratch[1] = EMPTY32; }
-            waveLdsSync();
-            if(myMin != EMPTY32) atomicMin(&scratch[1], myMin);
-            waveLdsSync();
-            const uint32_t seedKey = scratch[1];
-            uint64_t comp[Q];
-#pragma unroll
-            for(int q = 0; q < Q; q++) comp[q] = __ballot(key[q] == seedKey);
-            for(;;) {
-                bool changed = false;
-#pragma unroll
-                for(int q = 0; q < Q; q++) {
-                    if(q >= nq) break;
-                    uint64_t reach = 0;
-#pragma unroll
-                    for(int r = 0; r < Q; r++) reach |= (before[q][r] | after[q][r]) & comp[r];
-                    const uint64_t grown = comp[q] | (__ballot(reach != 0) & remaining[q]);
-                    changed |= grown != comp[q];
-                    comp[q] = grown;
-                }
-                if(!changed) break;
-            }
-            // iY range of the component.
-            if(lane == 0) { scratch[1] = EMPTY32; scratch[2] = 0; }
-            waveLdsSync();
-#pragma unroll
-            for(int q = 0; q < Q; q++) {
-                if((comp[q] >> lane) & 1ULL) { atomicMin(&scratch[1], key[q] >> 16); atomicMax(&scratch[2], key[q] >> 16); }
-            }
-            waveLdsSync();
-            const uint32_t YMin = scratch[1] * opt.deltaY;
-            const uint32_t YMax = (scratch[2] + 1) * opt.deltaY - 1;
-            const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
-            const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
-            const int32_t bandWidth = bandMax - bandMin + 1;
-            if(int64_t(bandWidth) <= int64_t(opt.maxBand)) {                      // :929
-                if(bandWidth > 1024) { if(lane == 0) pairFlags[pair] = PAIR_TOO_LONG; }
-                else {
-                    uint32_t staged = scratch[3];
-                    if(staged == CELLS_STAGE) {
-                        // Staging area full: append it to the task list.
-                        uint32_t base = 0;
-                        if(lane == 0) base = atomicAdd(taskCount, staged);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        for(uint32_t k = lane; k < 4 * staged; k += WAVE) {
-                            const uint32_t t = base + k / 4;
-                            if(t < taskCapacity) reinterpret_cast<uint32_t*>(tasks)[4ULL * base + k] = stage[k];
-                        }
-                        waveLdsSync();
-                        staged = 0;
-                    }
-                    if(lane == 0) {
-                        stage[4 * staged] = pair; stage[4 * staged + 1] = uint32_t(bandMin);
-                        stage[4 * staged + 2] = uint32_t(bandMax); stage[4 * staged + 3] = seedKey;
-                        scratch[3] = staged + 1;
-                    }
-                    waveLdsSync();
-                }
-            }
-            anyRemaining = false;
-#pragma unroll
-            for(int q = 0; q < Q; q++) { remaining[q] &= ~comp[q]; anyRemaining |= remaining[q] != 0; }
-        }
-        PHASE_MARK(5);
-    }
-    // Append this wave's staged tasks.
-    waveLdsSync();
-    const uint32_t staged = scratch[3];
-    if(staged) {
-        uint32_t base = 0;
-        if(lane == 0) base = atomicAdd(taskCount, staged);
-        base = __builtin_amdgcn_readfirstlane(base);
-        for(uint32_t k = lane; k < 4 * staged; k += WAVE) {
-            const uint32_t t = base + k / 4;
-            if(t < taskCapacity) reinterpret_cast<uint32_t*>(tasks)[4ULL * base + k] = stage[k];
-        }
-    }
-    PHASE_MARK(6);
-}
-
-// ---------------------------------------------------------------------------
-// K10: banded overlap DP (computeBandedAlignment, src/Align4.cpp:993-1088; the SeqAn call it
-// wraps is restated -- tie policy as in oracle/banded_dp.hpp).
-//
-// DP cell (i,j) (i symbols of read 0, j of read 1 consumed) lives on diagonal d = i-j =
-// bandMin + b and anti-diagonal s = i+j.  On step s only diagonals with (s+d) even hold a cell;
-// its three predecessors are the same diagonal at s-2 (diagonal move), diagonal b-1 at s-1
-// (horizontal, from (i-1,j)) and diagonal b+1 at s-1 (vertical, from (i,j-1)).
-//
-//   forward   bandedDpForwardKernel<G,C>: a task occupies G lanes, each lane owns C adjacent
-//             diagonals in registers; narrow bands are packed 64/G tasks to a wavefront (tasks
-//             are sorted by class and length first, so bundled tasks have the same trip count).
-//             One loop iteration advances two anti-diagonals (all C cells of a lane); the only
-//             cross-lane traffic is one shuffle up and one down.  The kmer ids a lane compares
-//             slide through register windows fed by one prefetched load per read and iteration.
-//             Trace: 2 bits per cell, one __ballot per bit plane, 2C 64-bit words per iteration.
-//   end cell  free end gaps: the best border cell = max over the final value of each diagonal,
-//             ties to the smallest (i, j) -- a G-lane reduction after the loop.
-//   trace     dpTracebackKernel: ONE LANE per task walks its path through the packed trace
-//             (64 tasks per wavefront in flight), writes the aligned ordinals and accumulates
-//             AlignmentInfo's metrics (src/Alignment.cpp:67-113, :4-31).
-// Trace codes: 0 diagonal+equal kmers, 1 diagonal+different, 2 vertical, 3 horizontal.  Tie
-// policy: diagonal >= vertical >= horizontal.
-// ---------------------------------------------------------------------------
-constexpr int DP_CLASSES = 6;
-__host__ __device__ inline int dpClassOfWidth(int32_t w) { return w <= 32 ? 0 : (w <= 64 ? 1 : (w <= 128 ? 2 : (w <= 256 ? 3 : (w <= 512 ? 4 : 5)))); }
-__host__ __device__ inline int dpLanes(int cls) { return cls == 0 ? 16 : (cls == 1 ? 32 : 64); }          // G
-__host__ __device__ inline int dpDiagonals(int cls) { return cls <= 2 ? 2 : (1 << (cls - 1)); }             // C = 2,2,2,4,8,16
-
-struct DpGeometry { int32_t s0; uint32_t iters; int cls; };
-__host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
-{
-    DpGeometry g;
-    g.cls = dpClassOfWidth(bandMax - bandMin + 1);
-    const int32_t sMin = bandMin > 0 ? bandMin : (bandMax < 0 ? -bandMax : 0);
-    g.s0 = sMin - ((sMin + bandMin) & 1);          // (s0 + bandMin) is even
-    g.iters = uint32_t((int32_t(nx + ny) - g.s0) / 2 + 1);
-    return g;
-}
-
-// What the forward kernel leaves for the traceback of a task.
-struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase; };
-
-// Per task: sort key (class, iterations), ordinal capacity, statistics.
-__global__ void __launch_bounds__(256)
-dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
-    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long cells = 0, words = 0, bytes = 0;
-    int cls = -1;
-    if(t < taskCount) {
-        const DpTask task = tasks[t];
-        const PairDesc pd = pairs[task.pair];
-        const DpGeometry g = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-        cls = g.cls;
-        keys[t] = (uint32_t(g.cls) << 24) | min(g.iters, 0xffffffu);
-        ids[t] = t;
-        ordCap[t] = min(pd.nx, pd.ny);
-        cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
-        words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls)) + 32;
-        bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
-    } else if(t == taskCount) {
-        ordCap[t] = 0;
-    }
-    // Per class: one atomic per wavefront and class present in it (tasks of a wave mostly share a
-    // class after the cells kernels); one atomic per task serialises the whole launch on six addresses.
-#pragma unroll
-    for(int c = 0; c < DP_CLASSES; c++) {
-        const uint64_t votes = __ballot(cls == c);
-        if(votes == 0) continue;
-        unsigned long long classCells = cls == c ? cells : 0, classBytes = cls == c ? bytes : 0;
-        for(int d = 32; d >= 1; d >>= 1) { classCells += __shfl_down(classCells, d, WAVE); classBytes += __shfl_down(classBytes, d, WAVE); }
-        if(laneId() == 0) {
-            atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
-            atomicAdd(&sums[2 + c], classCells);
-            atomicAdd(&sums[8 + c], classBytes);
-        }
-    }
-    for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
-    if(laneId() == 0 && cells) { atomicAdd(&sums[0], cells); atomicAdd(&sums[1], words); }
-}
-
-// Trace words of each bundle (64/G consecutive tasks of the sorted list of one class).
-struct DpClassLayout { uint32_t taskStart[DP_CLASSES + 1]; uint32_t bundleStart[DP_CLASSES + 1]; };
-
-__global__ void __launch_bounds__(256)
-dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, uint64_t* __restrict__ bundleWords)
-{
-    const uint32_t bundle = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = layout.bundleStart[DP_CLASSES];
-    if(bundle > total) return;
-    if(bundle == total) { bundleWords[bundle] = 0; return; }
-    int cls = 0;
-    while(bundle >= layout.bundleStart[cls + 1]) ++cls;
-    const uint32_t T = 64u / uint32_t(dpLanes(cls));
-    const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
-    const uint32_t last = min(first + T, layout.taskStart[cls + 1]) - 1;
-    // sorted ascending: the last task has the most iterations.  Rounded to 256 bytes so that the
-    // traceback's chunks are whole cache lines.
-    bundleWords[bundle] = (uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
-}
-
-template<int G, int C>
-__global__ void __launch_bounds__(256)
-bandedDpForwardKernel(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
-    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,            // this class's segment of the sorted list
-    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,      // this class's segment
-    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
-{
-    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C;
-    const int lane = laneId();
-    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if(bundle >= bundleCount) return;                     // whole wave leaves; no block barriers below
-    const int g = lane / G, l = lane % G;
-    const uint32_t pos = bundle * T + uint32_t(g);
-    const bool hasTask = pos < taskCount;
-    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
-    const DpTask task = tasks[t];
-    const PairDesc pd = pairs[task.pair];
-    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
-    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
-    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
-    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
-    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    uint32_t iters = geo.iters;
-#pragma unroll
-    for(int d = G; d < WAVE; d <<= 1) iters = max(iters, uint32_t(__shfl_xor(int(iters), d, WAVE)));
-    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
-
-    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
-    int32_t lo[C];
-    uint32_t span[C];
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        const int32_t b = l * C + c, d = bandMin + b;
-        const int32_t first = d < 0 ? -d : d;
-        const int32_t last = min(2 * nx - d, 2 * ny + d);
-        const bool exists = hasTask && b < width && d <= nx && d >= -ny && last >= first;
-        lo[c] = exists ? first : 0x40000000;
-        span[c] = exists ? uint32_t(last - first) : 0u;
-    }
-    int32_t H[C];
-#pragma unroll
-    for(int c = 0; c < C; c++) H[c] = NEG_SCORE;
-
-    // Register windows of the kmer ids: aw[k] = A[ib + l HC - 1 + k], bw[h] = B[jb - l HC - 1 - h],
-    // ib = (s + bandMin) / 2, jb = ib - bandMin.  Indices are clamped; clamped values belong to
-    // cells that are not in the matrix.
-    int32_t ib = (geo.s0 + bandMin) / 2;
-    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
-    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
-    uint32_t aw[HC + 1], bw[HC];
-#pragma unroll
-    for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
-#pragma unroll
-    for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
-    uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
-    uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
-
-    auto cell = [&](int c, int32_t s, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
-        const bool eq = a == bk;
-        const int32_t dg = hd + (eq ? MATCH_SCORE : MISMATCH_SCORE);
-        const int32_t vg = hv + GAP_SCORE;                          // from (i, j-1): diagonal b+1
-        const int32_t hg = hh + GAP_SCORE;                          // from (i-1, j): diagonal b-1
-        const bool isV = vg > dg;
-        const int32_t m1 = max(dg, vg);
-        const bool isH = hg > m1;
-        int32_t v = max(m1, hg);
-        const bool valid = uint32_t(s - lo[c]) <= span[c];
-        v = (s == lo[c]) ? 0 : v;                                   // i == 0 or j == 0: free leading gaps
-        H[c] = valid ? v : H[c];
-        loPlane = __ballot(isH || (!isV && !eq));
-        hiPlane = __ballot(isV || isH);
-    };
-
-    int32_t s = geo.s0;
-    for(uint32_t it = 0; it < iters; it++, s += 2) {
-        uint64_t words[RW];
-        {   // anti-diagonal s: even c hold cells
-            int32_t left = __shfl_up(H[C - 1], 1, G); if(l == 0) left = NEG_SCORE;
-#pragma unroll
-            for(int c = 0; c < C; c += 2) {
-                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
-                cell(c, s, aw[c / 2], bw[c / 2], H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
-            }
-        }
-        {   // anti-diagonal s+1: odd c hold cells
-            int32_t right = __shfl_down(H[0], 1, G); if(l == G - 1) right = NEG_SCORE;
-#pragma unroll
-            for(int c = 1; c < C; c += 2) {
-                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
-                cell(c, s + 1, aw[c / 2 + 1], bw[c / 2], H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
-            }
-        }
-        // Lane k stores word k of this iteration's trace record.
-        uint64_t mine = words[0];
-#pragma unroll
-        for(int k = 1; k < RW; k++) mine = (lane == k) ? words[k] : mine;
-        if(lane < RW) tr[uint64_t(it) * RW + lane] = mine;
-        // Slide the windows.
-#pragma unroll
-        for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
-        aw[HC] = aNext1; aNext1 = aNext2;
-#pragma unroll
-        for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
-        bw[0] = bNext1; bNext1 = bNext2;
-        ++ib;
-        aNext2 = loadA(ib + 1 + l * HC + HC);
-        bNext2 = loadB(ib + 1 - bandMin - l * HC);
-    }
-
-    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
-    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        const int32_t d = bandMin + l * C + c;
-        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
-        const int32_t v = (lo[c] != 0x40000000) ? H[c] : NEG_SCORE;
-        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
-    }
-#pragma unroll
-    for(int d = G / 2; d >= 1; d >>= 1) {
-        const int32_t os = __shfl_xor(bestScore, d, G);
-        const int32_t oi = __shfl_xor(bestI, d, G);
-        const int32_t oj = __shfl_xor(bestJ, d, G);
-        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
-    }
-    if(hasTask && l == 0) {
-        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
-        ends[t] = e;
-    }
-}
-
-// ---- forward kernel, second version ---------------------------------------------------------
-// Same tasks, bundles, trace format and DpEnd as bandedDpForwardKernel, which stays beside it
-// (SHASTA_MI355X_DP_FORWARD=1) until this one has been timed on the MI355X.  Every change comes
-// from the first version's ISA (75 VALU instructions per iteration for two cells per lane,
-// scripts/isa_loop.py):
-//  * three phases, general / steady / general.  In the steady phase (all but about a band width
-//    of iterations at either end) every cell of the wavefront that exists is inside the matrix and
-//    past the first cell of its diagonal, and every kmer-id load is in range: no validity tests,
-//    no index clamps.  It runs in blocks of DP_BLOCK iterations, fully unrolled: a lane's kmer ids
-//    of a block are DP_BLOCK + C/2 consecutive elements per read, fetched as one 16-byte load per
-//    read and block, one block ahead -- no sliding register windows, no per-iteration address;
-//  * scores are kept biased by -NEG_SCORE, so "outside the band" is 0 and the neighbour exchange
-//    is one DPP shift with zero fill (row_shr/shl for 16-lane groups, wave_shr/shl otherwise)
-//    instead of ds_bpermute + select -- same decisions: max, compare and adding a constant commute
-//    with the bias, and nothing overflows (|score| < 2^27);
-//  * trace planes: one ballot per comparison (the mask v_cmp wrote anyway), combined on the
-//    scalar unit; the ballot of a combined predicate is compiled to v_cndmask + v_cmp;
-//  * the trace record goes from lane 0 into a 256-byte LDS line per wavefront and leaves as one
-//    coalesced 4-byte store per lane when the line is full, instead of a select chain over the
-//    lanes and a partial store every iteration;
-//  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
-constexpr int DP_BLOCK = 4;
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
-// The value of the lane below / above in a G-lane group; 0 at the group's edge.
-template<int G> __device__ __forceinline__ int32_t fromLaneBelow(int32_t v, int l)
-{
-    constexpr int ctrl = (G == 16) ? 0x111 : 0x138;             // row_shr:1 : wave_shr:1; bound_ctrl = zero fill
-    int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
-    if constexpr (G == 32) r = (l == 0) ? 0 : r;
-    return r;
-}
-template<int G> __device__ __forceinline__ int32_t fromLaneAbove(int32_t v, int l)
-{
-    constexpr int ctrl = (G == 16) ? 0x101 : 0x130;             // row_shl:1 : wave_shl:1
-    int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
-    if constexpr (G == 32) r = (l == G - 1) ? 0 : r;
-    return r;
-}
-struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // four consecutive kmer ids, 4-byte aligned
-
-template<int G, int C>
-__global__ void __launch_bounds__(256)
-bandedDpForwardKernel2(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
-    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
-    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,
-    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
-{
-    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C, U = DP_BLOCK;
-    constexpr int F = 32 / RW;                            // iterations per 256-byte trace line
-    constexpr int AL = F > U ? F : U;                     // steady iterations come in groups of AL: whole blocks, whole lines
-    constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
-    static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
-    __shared__ __attribute__((aligned(16))) uint64_t traceLines[4 * 32];   // one 256-byte line per wavefront of the block (16-byte LDS writes)
-    const int lane = laneId();
-    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if(bundle >= bundleCount) return;                     // whole wave leaves: all 64 lanes are active below, no block barriers
-    uint64_t* const line = traceLines + 32 * (threadIdx.x >> 6);
-    const int g = lane / G, l = lane % G;
-    const uint32_t pos = bundle * T + uint32_t(g);
-    const bool hasTask = pos < taskCount;
-    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
-    const DpTask task = tasks[t];
-    const PairDesc pd = pairs[task.pair];
-    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
-    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
-    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
-    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
-    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    uint32_t itersLane = geo.iters;
-#pragma unroll
-    for(int d = G; d < WAVE; d <<= 1) itersLane = max(itersLane, uint32_t(__shfl_xor(int(itersLane), d, WAVE)));
-    const uint32_t iters = __builtin_amdgcn_readfirstlane(itersLane);
-    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
-
-    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
-    int32_t lo[C];
-    uint32_t span[C];
-    bool exists[C];
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        const int32_t b = l * C + c, d = bandMin + b;
-        const int32_t first = d < 0 ? -d : d;
-        const int32_t last = min(2 * nx - d, 2 * ny + d);
-        exists[c] = hasTask && b < width && d <= nx && d >= -ny && last >= first;
-        lo[c] = exists[c] ? first : NO_DIAGONAL;
-        span[c] = exists[c] ? uint32_t(last - first) : 0u;
-    }
-    int32_t H[C];                                         // biased: score + BIAS; 0 = no cell
-#pragma unroll
-    for(int c = 0; c < C; c++) H[c] = 0;
-
-    // Iteration `it` works at ib = ib0 + it: it compares A[ib + l HC - 1 + k], k = 0..HC, with
-    // B[ib - bandMin - l HC - 1 - h], h = 0..HC-1.
-    const int32_t ib0 = (geo.s0 + bandMin) / 2;
-    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
-    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
-
-    // One anti-diagonal pair.  STEADY: every existing cell is valid and past its first cell.
-    auto cell = [&](auto steadyTag, int c, int32_t sc, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
-        constexpr bool STEADY = decltype(steadyTag)::value;
-        const bool eq = a == bk;
-        const int32_t dg = hd + (eq ? MATCH_SCORE - GAP_SCORE : MISMATCH_SCORE - GAP_SCORE);   // the three candidates before the gap penalty they share
-        const bool isV = hv > dg;                                   // from (i, j-1): diagonal b+1
-        const int32_t m1 = max(dg, hv);
-        const bool isH = hh > m1;                                   // from (i-1, j): diagonal b-1
-        int32_t v = max(m1, hh) + GAP_SCORE;
-        if constexpr (STEADY) {
-            SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
-            H[c] = exists[c] ? v : 0;
-        } else {
-            const bool valid = uint32_t(sc - lo[c]) <= span[c];
-            v = (sc == lo[c]) ? BIAS : v;                           // i == 0 or j == 0: free leading gaps
-            H[c] = valid ? v : H[c];
-        }
-        const uint64_t bEq = ballot64(eq), bV = ballot64(isV), bH = ballot64(isH);
-        loPlane = bH | ~(bV | bEq);                                 // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
-        hiPlane = bV | bH;
-    };
-    // aw(k), bw(h): the kmer ids of this iteration.
-    auto antiDiagonals = [&](auto steadyTag, int32_t s, auto aw, auto bw, uint64_t (&words)[RW]) {
-        {   // anti-diagonal s: even c hold cells
-            const int32_t left = fromLaneBelow<G>(H[C - 1], l);
-#pragma unroll
-            for(int c = 0; c < C; c += 2) {
-                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
-                cell(steadyTag, c, s, aw(c / 2), bw(c / 2), H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
-            }
-        }
-        {   // anti-diagonal s+1: odd c hold cells
-            const int32_t right = fromLaneAbove<G>(H[0], l);
-#pragma unroll
-            for(int c = 1; c < C; c += 2) {
-                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
-                cell(steadyTag, c, s + 1, aw(c / 2 + 1), bw(c / 2), H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
-            }
-        }
-    };
-    // The record of an iteration goes to slot (it mod F) of the wavefront's line; a full line leaves as
-    // one coalesced store.  Lane 0 writes, all lanes read: the wave barrier keeps the compiler from
-    // moving the read up (the hardware runs a wavefront's LDS operations in order).
-    auto putRecord = [&](int slot, const uint64_t (&words)[RW]) {
-        if(lane == 0) {
-            ulonglong2* __restrict__ record = reinterpret_cast<ulonglong2*>(line + slot * RW);
-#pragma unroll
-            for(int k = 0; k < C; k++) { ulonglong2 w; w.x = words[2 * k]; w.y = words[2 * k + 1]; record[k] = w; }
-        }
-    };
-    auto flushLine = [&](uint32_t lineIndex) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        SHASTA_DEVICE_CHECK(uint64_t(lineIndex) * 32 + 32 <= ((uint64_t(iters) * RW + 31) & ~31ULL));      // inside the bundle's trace (dpBundleKernel)
-        const uint32_t d = reinterpret_cast<const uint32_t*>(line)[lane];
-        reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = d;
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    // General iterations [from, to): sliding register windows fed by clamped loads two iterations ahead.
-    auto general = [&](uint32_t from, uint32_t to) {
-        if(from >= to) return;
-        const int32_t ib = ib0 + int32_t(from);
-        uint32_t aw[HC + 1], bw[HC];
-#pragma unroll
-        for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
-#pragma unroll
-        for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
-        uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
-        uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
-        for(uint32_t it = from; it < to; it++) {
-            uint64_t words[RW];
-            antiDiagonals(std::false_type{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
-            putRecord(int(it % F), words);
-            if(it % F == F - 1) flushLine(it / F);
-#pragma unroll
-            for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
-            aw[HC] = aNext1; aNext1 = aNext2;
-#pragma unroll
-            for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
-            bw[0] = bNext1; bNext1 = bNext2;
-            aNext2 = loadA(ib0 + int32_t(it) + 2 + l * HC + HC);
-            bNext2 = loadB(ib0 + int32_t(it) + 2 - bandMin - l * HC);
-        }
-    };
-
-    // Steady iterations.  A cell (lane, c) is steady at `it` when lo < s0 + 2 it + (c & 1) <= lo + span;
-    // the block that starts at itB loads A[iaBlock + itB + j], B[jbBlock + itB + j], j = 0..U-1
-    // (the new elements of the block after it).
-    const int32_t iaBlock = ib0 + U + l * HC + HC - 1, jbBlock = ib0 + U - bandMin - l * HC - 1;
-    int32_t itLo = 0, itHi = int32_t(iters) - 1;          // cells steady on [itLo, itHi]
-    int32_t startLo = max(-iaBlock, -jbBlock), startHi = min(nx - U - iaBlock, ny - U - jbBlock);   // block starts whose loads are in range
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        if(exists[c]) {
-            itLo = max(itLo, (lo[c] + 2 - geo.s0 - (c & 1)) >> 1);
-            itHi = min(itHi, (lo[c] + int32_t(span[c]) - geo.s0 - (c & 1)) >> 1);
-        }
-    }
-#pragma unroll
-    for(int d = 1; d < WAVE; d <<= 1) {
-        itLo = max(itLo, __shfl_xor(itLo, d, WAVE)); itHi = min(itHi, __shfl_xor(itHi, d, WAVE));
-        startLo = max(startLo, __shfl_xor(startLo, d, WAVE)); startHi = min(startHi, __shfl_xor(startHi, d, WAVE));
-    }
-    // Groups of AL iterations starting at multiples of AL: the first at steadyBegin, every block start in
-    // [startLo, startHi], every iteration in [itLo, itHi].
-    const int32_t firstStart = (max(max(itLo, startLo), 0) + AL - 1) / AL * AL;
-    const int32_t lastGroupStart = min(itHi - (AL - 1), startHi - (AL - U));
-    const uint32_t groups = __builtin_amdgcn_readfirstlane(uint32_t(lastGroupStart >= firstStart ? (lastGroupStart - firstStart) / AL + 1 : 0));
-    const uint32_t steadyBegin = __builtin_amdgcn_readfirstlane(uint32_t(firstStart));
-
-    if(groups == 0) {
-        general(0, iters);
-    } else {
-        general(0, steadyBegin);
-        {
-            // Block registers: a[x] = A[ib + l HC - 1 + x], x = 0..U+HC-1; e[x] = B[ib - bandMin - l HC - HC + x], x = 0..U+HC-2.
-            // Iteration u of the block: aw(k) = a[u + k], bw(h) = e[u + HC - 1 - h].
-            const int32_t ib = ib0 + int32_t(steadyBegin);
-            uint32_t a[U + HC], e[U + HC - 1];
-#pragma unroll
-            for(int x = 0; x < U + HC; x++) a[x] = loadA(ib + l * HC - 1 + x);
-#pragma unroll
-            for(int x = 0; x < U + HC - 1; x++) e[x] = loadB(ib - bandMin - l * HC - HC + x);
-            const uint32_t* __restrict__ pa = p0 + (int64_t(iaBlock) + int64_t(steadyBegin));
-            const uint32_t* __restrict__ pb = p1 + (int64_t(jbBlock) + int64_t(steadyBegin));
-            uint32_t lineIndex = steadyBegin / F;
-            for(uint32_t grp = 0; grp < groups; grp++) {
-#pragma unroll
-                for(int blk = 0; blk < AL / U; blk++) {
-                    SHASTA_DEVICE_CHECK(pa >= p0 && pa + U <= p0 + nx && pb >= p1 && pb + U <= p1 + ny);
-                    const KmerQuad newA = *reinterpret_cast<const KmerQuad*>(pa);
-                    const KmerQuad newB = *reinterpret_cast<const KmerQuad*>(pb);
-                    pa += U; pb += U;
-#pragma unroll
-                    for(int u = 0; u < U; u++) {
-                        uint64_t words[RW];
-                        antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
-                        const int slot = (blk * U + u) % F;
-                        putRecord(slot, words);
-                        if(slot == F - 1) { flushLine(lineIndex); ++lineIndex; }
-                    }
-#pragma unroll
-                    for(int x = 0; x < HC; x++) a[x] = a[x + U];
-#pragma unroll
-                    for(int j = 0; j < U; j++) a[HC + j] = newA.v[j];
-#pragma unroll
-                    for(int x = 0; x < HC - 1; x++) e[x] = e[x + U];
-#pragma unroll
-                    for(int j = 0; j < U; j++) e[HC - 1 + j] = newB.v[j];
-                }
-            }
-        }
-        general(steadyBegin + groups * AL, iters);
-    }
-    if(iters % F != 0) flushLine(iters / F);              // the last, partial line (the bundle's trace is a whole number of lines)
-
-    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
-    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        const int32_t d = bandMin + l * C + c;
-        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
-        const int32_t v = exists[c] ? H[c] - BIAS : NEG_SCORE;
-        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
-    }
-#pragma unroll
-    for(int d = G / 2; d >= 1; d >>= 1) {
-        const int32_t os = __shfl_xor(bestScore, d, G);
-        const int32_t oi = __shfl_xor(bestI, d, G);
-        const int32_t oj = __shfl_xor(bestJ, d, G);
-        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
-    }
-    if(hasTask && l == 0) {
-        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
-        ends[t] = e;
-    }
-}
-
-// One lane per task: walk the path from the end cell through the packed trace.  The trace is
-// consumed in chunks of CW words (128 or 256 bytes, whole cache lines): the chunk under the
-// path sits in the lane's private LDS window, the next one (the path only moves towards smaller
-// anti-diagonals) is already in flight in registers, so every line is fetched once and its
-// latency is covered by the walk through the previous chunk.
-template<int CW>
-__global__ void __launch_bounds__(256)
-dpTracebackKernel(
-    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
-    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
-    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
-{
-    constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
-    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if(idx >= taskCount) return;
-    const uint32_t t = sortedIds[idx];
-    const DpTask task = tasks[t];
-    const PairDesc pd = pairs[task.pair];
-    const DpEnd e = ends[t];
-    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    const int C = dpDiagonals(geo.cls);
-    const uint32_t RW = uint32_t(2 * C);
-    const uint32_t itersPerChunk = uint32_t(CW) / RW;
-    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
-    const uint64_t ordBase = ordOffsets[t];
-    uint32_t pos = min(pd.nx, pd.ny);
-    uint32_t count = 0, prevX = 0, prevY = 0, last0 = 0, last1 = 0, first0 = 0, first1 = 0, maxSkip = 0, maxDrift = 0;
-    int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
-    long long sumOffset = 0;
-    int32_t i = e.bestI, j = e.bestJ;
-    const bool ok = e.score > NEG_SCORE;
-    // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
-    // the same point of the program, then walks until its path leaves the chunk.  The wave waits
-    // for memory once per epoch, for loads issued a whole epoch earlier.
-    bool active = ok && i > 0 && j > 0;
-    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) / itersPerChunk) : -1;
-    uint4 next[QUADS];
-#pragma unroll
-    for(int k = 0; k < QUADS; k++) next[k] = active ? tr[chunk * QUADS + k] : make_uint4(0, 0, 0, 0);
-    while(__any(active)) {
-        if(active) {
-#pragma unroll
-            for(int k = 0; k < QUADS; k++) window[k * 256 + threadIdx.x] = next[k];
-            if(chunk > 0) {
-#pragma unroll
-                for(int k = 0; k < QUADS; k++) next[k] = tr[(chunk - 1) * QUADS + k];
-            }
-        }
-        while(active) {
-            const int32_t b = i - j - task.bandMin;
-            const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
-            if(int64_t(it / itersPerChunk) != chunk) break;
-            const uint32_t c = uint32_t(b) % uint32_t(C), bit = e.laneBase + uint32_t(b) / uint32_t(C);
-            const uint32_t word = (it % itersPerChunk) * RW + 2 * c;           // even: one 16-byte piece
-            const uint4 w = window[(word >> 1) * 256 + threadIdx.x];
-            const uint64_t lo = uint64_t(w.x) | (uint64_t(w.y) << 32), hi = uint64_t(w.z) | (uint64_t(w.w) << 32);
-            const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
-            if(dir == 0u) {
-                // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
-                const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
-                --pos;
-                *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(x, y);
-                const int32_t offset = int32_t(x) - int32_t(y);
-                if(count == 0) { last0 = x; last1 = y; }
-                else {
-                    maxSkip = max(maxSkip, max(prevX - x, prevY - y));
-                    const int32_t prevOffset = int32_t(prevX) - int32_t(prevY);
-                    const int32_t drift = offset - prevOffset;
-                    maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
-                }
-                minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
-                sumOffset += offset;
-                first0 = x; first1 = y; prevX = x; prevY = y;
-                ++count;
-                --i; --j;
-            } else if(dir == 1u) { --i; --j; }
-            else if(dir == 2u) { --j; }
-            else { --i; }
-            active = i > 0 && j > 0;
-        }
-        --chunk;
-    }
-    DpResult r;
-    r.ordBegin = ordBase + pos;
-    r.sumOffset = sumOffset;
-    r.markerCount = count; r.first0 = first0; r.first1 = first1; r.last0 = last0; r.last1 = last1;
-    r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
-    r.score = e.score; r.pad = 0;
-    // Inner acceptance, src/Align4.cpp:944-981.
-    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
-    if(pass) {
-        const double f0 = double(count) / double(last0 + 1 - first0);
-        const double f1 = double(count) / double(last1 + 1 - first1);
-        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
-        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
-        const uint32_t leftTrim = min(first0, first1);
-        const uint32_t rightTrim = min(pd.nx - 1 - last0, pd.ny - 1 - last1);
-        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
-    }
-    r.passes = pass ? 1u : 0u;
-    results[t] = r;
-    // Best component = most aligned markers (:132-139); ties resolved towards the
-    // component whose first cell in (iY,iX) order comes first, and flagged later.
-    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
-}
-
-__global__ void __launch_bounds__(256)
-winnerKernel(const DpTask* __restrict__ tasks, const DpResult* __restrict__ results, uint32_t taskCount,
-    const unsigned long long* __restrict__ pairBest, uint32_t* __restrict__ pairWinner, uint8_t* __restrict__ pairTie)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if(t >= taskCount) return;
-    const DpResult r = results[t];
-    if(!r.passes) return;
-    const DpTask task = tasks[t];
-    const unsigned long long best = pairBest[task.pair];
-    const unsigned long long key = ((unsigned long long)r.markerCount << 32) | (unsigned long long)(0xffffffffu - task.label);
-    if(key == best) pairWinner[task.pair] = t;
-    else if((key >> 32) == (best >> 32)) pairTie[task.pair] = 1;
-}
-
-// Per candidate: AlignmentInfo (src/Alignment.cpp:67-113) and the outer filters of
-// src/AssemblerAlign.cpp:439-472.
-__global__ void __launch_bounds__(256)
-finalizeKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_read_pair* __restrict__ candidates, uint32_t pairCount,
-    const DpResult* __restrict__ results, const unsigned long long* __restrict__ pairBest,
-    const uint32_t* __restrict__ pairWinner, const uint8_t* __restrict__ pairTie, const uint8_t* __restrict__ pairFlags,
-    DeviceOptions opt, int wantOrdinals,
-    uint8_t* __restrict__ status, shasta_alignment_data* __restrict__ rows,
-    uint32_t* __restrict__ storedFlags, uint64_t* __restrict__ ordCounts)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if(p == pairCount) { storedFlags[p] = 0; ordCounts[p] = 0; return; }
-    if(p > pairCount) return;
-    uint8_t st;
-    uint32_t stored = 0;
-    uint64_t ordCount = 0;
-    if(pairFlags[p]) {
-        st = SHASTA_ALIGN_SKIPPED;
-    } else if(pairBest[p] == 0) {
-        st = SHASTA_ALIGN_EMPTY;
-    } else {
-        const DpResult r = results[pairWinner[p]];
-        const PairDesc pd = pairs[p];
-        shasta_alignment_data row;
-        row.pair = candidates[p];
-        row.pair.isSameStrand = row.pair.isSameStrand ? 1 : 0;
-        row.pair.pad[0] = row.pair.pad[1] = row.pair.pad[2] = 0;
-        row.info.data[0].markerCount = pd.nx; row.info.data[0].firstOrdinal = r.first0; row.info.data[0].lastOrdinal = r.last0;
-        row.info.data[1].markerCount = pd.ny; row.info.data[1].firstOrdinal = r.first1; row.info.data[1].lastOrdinal = r.last1;
-        row.info.markerCount = r.markerCount;
-        row.info.minOrdinalOffset = r.minOffset; row.info.maxOrdinalOffset = r.maxOffset;
-        row.info.averageOrdinalOffset = int32_t(round(double(r.sumOffset) / double(r.markerCount)));
-        row.info.maxSkip = r.maxSkip; row.info.maxDrift = r.maxDrift;
-        row.info.isInReadGraph = 0; row.info.pad[0] = row.info.pad[1] = row.info.pad[2] = 0;
-        rows[p] = row;
-        bool good = uint64_t(r.markerCount) >= opt.minAlignedMarkerCount;
-        const double f0 = double(r.markerCount) / double(r.last0 + 1 - r.first0);
-        const double f1 = double(r.markerCount) / double(r.last1 + 1 - r.first1);
-        if(min(f0, f1) < opt.minAlignedFraction) good = false;
-        const uint32_t lt0 = r.first0, lt1 = r.first1, rt0 = pd.nx - 1 - r.last0, rt1 = pd.ny - 1 - r.last1;
-        if(uint64_t(min(lt0, lt1)) > opt.maxTrim || uint64_t(min(rt0, rt1)) > opt.maxTrim) good = false;
-        if(uint64_t(r.maxSkip) > opt.maxSkip || uint64_t(r.maxDrift) > opt.maxDrift) good = false;
-        if(opt.suppressContainments) {
-            const uint32_t mt = uint32_t(opt.maxTrim);
-            if((lt0 <= mt && rt0 <= mt) || (lt1 <= mt && rt1 <= mt)) good = false;       // isContaining
-        }
-        st = good ? SHASTA_ALIGN_STORED : SHASTA_ALIGN_REJECTED;
-        if(pairTie[p]) st |= SHASTA_ALIGN_TIE_FLAG;
-        stored = good ? 1u : 0u;
-        ordCount = (wantOrdinals || good) ? r.markerCount : 0;
-    }
-    status[p] = st;
-    storedFlags[p] = stored;
-    ordCounts[p] = ordCount;
-}
-
-__global__ void __launch_bounds__(256)
-gatherOrdinalsKernel(const DpResult* __restrict__ results, const uint32_t* __restrict__ pairWinner,
-    const uint64_t* __restrict__ ordToc, uint32_t pairCount, const uint32_t* __restrict__ ordScratch, uint32_t* __restrict__ ordOut)
-{
-    // One wave per candidate copies its alignment.
-    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if(p >= pairCount) return;
-    const uint64_t begin = ordToc[p], n = ordToc[p + 1] - begin;
-    if(n == 0) return;
-    const uint64_t src = results[pairWinner[p]].ordBegin;
-    for(uint64_t k = laneId(); k < 2 * n; k += WAVE) ordOut[2 * begin + k] = ordScratch[2 * src + k];
-}
-
-// shasta::compress (src/compressAlignment.cpp:11-67; formats compressAlignment.hpp:101-321).
-// A streak is a maximal run of marker pairs that advance both ordinals by one; its record holds
-// (skip0, skip1) from the last pair of the previous streak (from (0,0) for the first) and its
-// length, in the smallest of five formats (1/2/4/8/16 bytes).
-struct StreakRecord { uint64_t bits; uint32_t w[3]; int len; };
-
-__device__ __forceinline__ StreakRecord makeStreakRecord(int32_t skip0, int32_t skip1, uint32_t streak)
-{
-    StreakRecord r;
-    const uint64_t u0 = uint32_t(skip0), u1 = uint32_t(skip1), nm1 = uint64_t(streak) - 1;
-    r.w[0] = uint32_t(skip0); r.w[1] = uint32_t(skip1); r.w[2] = uint32_t(nm1);
-    if(skip0 >= 0 && skip0 <= 3 && skip1 >= 0 && skip1 <= 3 && streak <= 8) {
-        r.bits = 0 | (u0 & 3) << 1 | (u1 & 3) << 3 | (nm1 & 7) << 5; r.len = 1;
-    } else if(skip0 >= -8 && skip0 <= 7 && skip1 >= -8 && skip1 <= 7 && streak <= 32) {
-        r.bits = 1 | (u0 & 0xf) << 3 | (u1 & 0xf) << 7 | (nm1 & 0x1f) << 11; r.len = 2;
-    } else if(skip0 >= -512 && skip0 <= 511 && skip1 >= -512 && skip1 <= 511 && streak <= 512) {
-        r.bits = 3 | (u0 & 0x3ff) << 3 | (u1 & 0x3ff) << 13 | (nm1 & 0x1ff) << 23; r.len = 4;
-    } else if(skip0 >= -524288 && skip0 <= 524287 && skip1 >= -524288 && skip1 <= 524287 && streak <= 2097152) {
-        r.bits = 5 | (u0 & 0xfffff) << 3 | (u1 & 0xfffff) << 23 | (nm1 & 0x1fffff) << 43; r.len = 8;
-    } else {
-        r.bits = 7; r.len = 16;
-    }
-    return r;
-}
-
-__device__ __forceinline__ void writeStreakRecord(const StreakRecord& r, uint8_t* __restrict__ out)
-{
-    if(r.len == 16) {
-        const uint32_t w[4] = {7u, r.w[0], r.w[1], r.w[2]};
-        for(int k = 0; k < 16; k++) out[k] = uint8_t(w[k >> 2] >> (8 * (k & 3)));
-    } else {
-        for(int k = 0; k < r.len; k++) out[k] = uint8_t(r.bits >> (8 * k));
-    }
-}
-
-// One wavefront per stored alignment: lanes flag the streak starts of 64 marker pairs at a time;
-// a start lane knows its skips at once and its length when the next start is seen (the last
-// start of a chunk is carried to the next chunk).  WRITE=false only counts the bytes.
-template<bool WRITE>
-__device__ __forceinline__ uint64_t compressAlignmentWave(const uint32_t* __restrict__ ord, uint32_t n, uint8_t* __restrict__ out)
-{
-    const int lane = laneId();
-    uint64_t bytes = 0;                       // wave-uniform
-    bool havePending = false;                 // wave-uniform: a streak whose end is not known yet
-    uint32_t pendingStart = 0; int32_t pendingSkip0 = 0, pendingSkip1 = 0;
-    uint32_t carryX = 0, carryY = 0;          // last pair of the previous chunk ((0,0) before the first)
-    for(uint32_t base = 0; base < n; base += WAVE) {
-        const uint32_t i = base + lane;
-        const bool valid = i < n;
-        uint2 xy = make_uint2(0, 0);
-        if(valid) xy = *reinterpret_cast<const uint2*>(ord + 2 * uint64_t(i));
-        uint32_t px = __shfl_up(xy.x, 1, WAVE), py = __shfl_up(xy.y, 1, WAVE);
-        if(lane == 0) { px = carryX; py = carryY; }
-        const bool start = valid && (i == 0 || xy.x != px + 1 || xy.y != py + 1);
-        const uint64_t starts = __ballot(start);
-        const int32_t skip0 = int32_t(xy.x) - int32_t(px), skip1 = int32_t(xy.y) - int32_t(py);
-        // The first start of this chunk closes the pending streak.
-        if(havePending && starts) {
-            const uint32_t first = base + uint32_t(__ffsll((unsigned long long)starts) - 1);
-            const StreakRecord r = makeStreakRecord(pendingSkip0, pendingSkip1, first - pendingStart);
-            if(WRITE && lane == 0) writeStreakRecord(r, out + bytes);
-            bytes += uint64_t(r.len);
-            havePending = false;
-        }
-        // Starts of this chunk that are closed by a later start of the same chunk.
-        const uint64_t later = (starts >> 1) >> lane;
-        const bool closed = start && later != 0;
-        uint32_t length = closed ? uint32_t(__ffsll((unsigned long long)later)) : 0u;
-        StreakRecord r = makeStreakRecord(skip0, skip1, closed ? length : 1u);
-        const uint32_t len = closed ? uint32_t(r.len) : 0u;
-        // Exclusive prefix of the record lengths over the wave.
-        uint32_t inclusive = len;
-#pragma unroll
-        for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inclusive, d, WAVE); if(lane >= d) inclusive += o; }
-        if(WRITE && closed) writeStreakRecord(r, out + bytes + (inclusive - len));
-        bytes += uint64_t(__shfl(inclusive, WAVE - 1, WAVE));
-        // The last start of the chunk stays pending.
-        if(starts) {
-            const int lastLane = 63 - __clzll((unsigned long long)starts);
-            havePending = true;
-            pendingStart = base + uint32_t(lastLane);
-            pendingSkip0 = __shfl(skip0, lastLane, WAVE);
-            pendingSkip1 = __shfl(skip1, lastLane, WAVE);
-        }
-        const int lastValid = int(min(uint32_t(WAVE), n - base)) - 1;
-        carryX = __shfl(xy.x, lastValid, WAVE); carryY = __shfl(xy.y, lastValid, WAVE);
-    }
-    if(havePending) {
-        const StreakRecord r = makeStreakRecord(pendingSkip0, pendingSkip1, n - pendingStart);
-        if(WRITE && lane == 0) writeStreakRecord(r, out + bytes);
-        bytes += uint64_t(r.len);
-    }
-    return bytes;
-}
-
-__global__ void __launch_bounds__(256)
-compressSizeKernel(const uint32_t* __restrict__ storedFlags, const DpResult* __restrict__ results,
-    const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch, uint32_t pairCount, uint64_t* __restrict__ sizes)
-{
-    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if(p > pairCount) return;
-    uint64_t s = 0;
-    if(p < pairCount && storedFlags[p]) {
-        const DpResult r = results[pairWinner[p]];
-        s = compressAlignmentWave<false>(ordScratch + 2 * r.ordBegin, r.markerCount, nullptr);
-    }
-    if(laneId() == 0) sizes[p] = s;
-}
-
-__global__ void __launch_bounds__(256)
-compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __restrict__ storedIndex,
-    const DpResult* __restrict__ results, const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch,
-    uint32_t pairCount, const uint64_t* __restrict__ byteOffsets, uint8_t* __restrict__ bytes,
-    uint64_t* __restrict__ compressedToc, const shasta_alignment_data* __restrict__ rows, shasta_alignment_data* __restrict__ rowsOut)
-{
-    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if(p >= pairCount || !storedFlags[p]) return;
-    const DpResult r = results[pairWinner[p]];
-    (void)compressAlignmentWave<true>(ordScratch + 2 * r.ordBegin, r.markerCount, bytes + byteOffsets[p]);
-    const uint32_t k = storedIndex[p];
-    if(laneId() == 0) compressedToc[k] = byteOffsets[p];
-    // The 64-byte AlignmentData row: one dword per lane.
-    if(laneId() < 16) reinterpret_cast<uint32_t*>(rowsOut + k)[laneId()] = reinterpret_cast<const uint32_t*>(rows + p)[laneId()];
-}
-
+#include "align4_cells.hpp"      // K8/K9
+#include "align4_dp.hpp"         // K10
+#include "align4_finish.hpp"     // K11
 #include "align3.hpp"
 
 template<class T> T readDevice(const T* p, hipStream_t s)

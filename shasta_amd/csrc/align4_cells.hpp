@@ -1,0 +1,748 @@
+// Align4 on MI355X, K8/K9: from a candidate's two marker sequences to its DP tasks -- the sparse marker-match
+// matrix in rotated (X, Y) cells, forward / backward reachability, components, one band per component
+// (/root/reference/src/Align4.cpp:195-267, 380-436, 682-872).  Included by align4.hip inside its anonymous namespace
+// (constants, PairDesc / DpTask / DeviceOptions are defined there).
+//   align4CellsChunkKernel<Q>   candidates that share one oriented read: one LDS table of that read per workgroup
+//   align4CellsKernel<BIG>      one workgroup per candidate, tables in HBM scratch: reads beyond the LDS classes
+#pragma once
+
+// ---------------------------------------------------------------------------
+// K8/K9: cells.
+// ---------------------------------------------------------------------------
+constexpr int CELLS_THREADS = 256;
+constexpr int MATCH_CHUNK = 2048;          // markers of read 1 hashed per round
+constexpr int MATCH_SLOTS = 4096;
+constexpr int CELL_SLOTS = 2048;
+constexpr int MAX_CELLS = 1024;
+constexpr uint32_t EMPTY32 = 0xffffffffu;
+constexpr uint64_t EMPTY64 = ~0ULL;
+
+constexpr uint32_t F_NEAR_LT = 1, F_NEAR_RB = 2, F_FWD = 4, F_BWD = 8;
+constexpr uint8_t PAIR_RESOURCE = 1;       // a cell table overflowed: retried with a larger table in HBM
+constexpr uint8_t PAIR_TOO_LONG = 2;       // outside the supported geometry (iX/iY >= 2^16 or band > 1024): skipped + reported
+
+__device__ __forceinline__ uint32_t hash32(uint32_t k) { return k * 2654435761u; }
+
+// getxy, src/Align4.cpp:184-191 (int32, C++ truncating division).
+__device__ __forceinline__ void getxy(uint32_t X, uint32_t Y, uint32_t nx, int32_t& x, int32_t& y)
+{
+    const int32_t Xs = int32_t(X), Ys = int32_t(Y);
+    x = (Xs - Ys + int32_t(nx) - 1) / 2;
+    y = (Xs + Ys - int32_t(nx) + 1) / 2;
+}
+
+// Reads of block-shared mutable state.  SMALL: LDS.  BIG: the tables live in HBM scratch and
+// are updated with atomics (L2); plain loads could hit a stale line of this CU's L1, so
+// they bypass it (agent-scope relaxed load = global_load sc1).
+template<bool BIG> __device__ __forceinline__ uint32_t ld(const uint32_t* p)
+{
+    if(BIG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// One workgroup per candidate.  SMALL keeps the cell table (CELL_SLOTS) and the kept-cell
+// list (MAX_CELLS) in LDS; BIG uses a per-candidate region of HBM scratch of 2^slotsLog2
+// table slots (layout: keys[S] vals[S] cKey[S/2] cFlags[S/2] cLabel[S/2] cYMin[S/2] cYMax[S/2]).
+template<bool BIG>
+__global__ void __launch_bounds__(CELLS_THREADS)
+align4CellsKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const uint32_t* __restrict__ pairList, uint32_t listCount,
+    DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags,
+    uint32_t* __restrict__ bigScratch, const uint64_t* __restrict__ bigOffsets, const uint8_t* __restrict__ bigSlotsLog2)
+{
+    __shared__ uint64_t matchTab[MATCH_SLOTS];
+    __shared__ uint32_t sCellKeys[BIG ? 1 : CELL_SLOTS];
+    __shared__ uint32_t sCellVals[BIG ? 1 : CELL_SLOTS];
+    __shared__ uint32_t sKey[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sFlags[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sLabel[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sYMin[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sYMax[BIG ? 1 : MAX_CELLS];
+    __shared__ uint32_t sCells, sOverflow, sChanged;
+
+    if(blockIdx.x >= listCount) return;
+    const uint32_t pair = pairList[blockIdx.x];
+    const int tid = int(threadIdx.x);
+    const PairDesc pd = pairs[pair];
+    const uint32_t nx = pd.nx, ny = pd.ny;
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+
+    uint32_t *cellKeys, *cellVals, *cKey, *cFlags, *cLabel, *cYMin, *cYMax;
+    int slotsLog2;
+    if(BIG) {
+        slotsLog2 = int(bigSlotsLog2[blockIdx.x]);
+        const uint64_t S = 1ULL << slotsLog2;
+        uint32_t* base = bigScratch + bigOffsets[blockIdx.x];
+        cellKeys = base; cellVals = base + S; cKey = base + 2 * S; cFlags = cKey + S / 2;
+        cLabel = cFlags + S / 2; cYMin = cLabel + S / 2; cYMax = cYMin + S / 2;
+    } else {
+        slotsLog2 = 11;
+        cellKeys = sCellKeys; cellVals = sCellVals; cKey = sKey; cFlags = sFlags; cLabel = sLabel; cYMin = sYMin; cYMax = sYMax;
+    }
+    const uint32_t slots = 1u << slotsLog2;
+    const uint32_t maxCells = BIG ? slots / 2 : uint32_t(MAX_CELLS);
+    const int hashShift = 32 - slotsLog2;
+
+    for(uint32_t k = tid; k < slots; k += CELLS_THREADS) { cellKeys[k] = EMPTY32; cellVals[k] = 0; }
+    if(tid == 0) { sCells = 0; sOverflow = 0; sChanged = 0; }
+
+    // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
+    for(uint32_t chunk = 0; chunk < ny; chunk += MATCH_CHUNK) {
+        __syncthreads();
+        for(int k = tid; k < MATCH_SLOTS; k += CELLS_THREADS) matchTab[k] = EMPTY64;
+        __syncthreads();
+        const uint32_t chunkEnd = min(ny, chunk + uint32_t(MATCH_CHUNK));
+        for(uint32_t y = chunk + tid; y < chunkEnd; y += CELLS_THREADS) {
+            const uint32_t k = p1[y];
+            const unsigned long long entry = (uint64_t(k) << 32) | y;
+            uint32_t slot = hash32(k) >> (32 - 12);
+            for(;;) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
+                if(old == EMPTY64) break;
+                slot = (slot + 1) & (MATCH_SLOTS - 1);
+            }
+        }
+        __syncthreads();
+        for(uint32_t x = tid; x < nx; x += CELLS_THREADS) {
+            const uint32_t k = p0[x];
+            uint32_t slot = hash32(k) >> (32 - 12);
+            for(;;) {
+                const uint64_t e = matchTab[slot];
+                if(e == EMPTY64) break;
+                if(uint32_t(e >> 32) == k) {
+                    const uint32_t y = uint32_t(e);
+                    const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
+                    const uint32_t iX = X / opt.deltaX, iY = Y / opt.deltaY;
+                    if(iX >= 65536u || iY >= 65535u) { sOverflow = 2; }
+                    else {
+                        const uint32_t key = (iY << 16) | iX;
+                        uint32_t cs = hash32(key) >> hashShift;
+                        uint32_t probe = 0;
+                        for(; probe < slots; probe++) {
+                            const uint32_t old = atomicCAS(&cellKeys[cs], EMPTY32, key);
+                            if(old == EMPTY32 || old == key) { atomicAdd(&cellVals[cs], 1u); break; }
+                            cs = (cs + 1) & (slots - 1);
+                        }
+                        if(probe == slots) sOverflow = 1;
+                    }
+                }
+                slot = (slot + 1) & (MATCH_SLOTS - 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // Keep cells with enough entries (:417) and give them compact indices.
+    for(uint32_t k = tid; k < slots; k += CELLS_THREADS) {
+        const uint32_t key = ld<BIG>(&cellKeys[k]);
+        if(key == EMPTY32) continue;
+        if(uint64_t(ld<BIG>(&cellVals[k])) >= opt.minEntryCountPerCell) {
+            const uint32_t idx = atomicAdd(&sCells, 1u);
+            if(idx < maxCells) { cKey[idx] = key; cellVals[k] = idx; }
+            else { sOverflow = 1; cellVals[k] = EMPTY32; }
+        } else {
+            cellVals[k] = EMPTY32;
+        }
+    }
+    __syncthreads();
+    if(sOverflow) { if(tid == 0) pairFlags[pair] = (sOverflow == 2) ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
+    const int n = int(sCells);
+    if(n == 0) return;
+
+    auto find = [&](int32_t iX, int32_t iY) -> int {
+        if(iX < 0 || iY < 0 || iX >= 65536 || iY >= 65535) return -1;
+        const uint32_t key = (uint32_t(iY) << 16) | uint32_t(iX);
+        uint32_t cs = hash32(key) >> hashShift;
+        for(uint32_t probe = 0; probe < slots; probe++) {
+            const uint32_t k = ld<BIG>(&cellKeys[cs]);
+            if(k == EMPTY32) return -1;
+            if(k == key) return int(ld<BIG>(&cellVals[cs]));          // EMPTY32 (-1) for dropped cells
+            cs = (cs + 1) & (slots - 1);
+        }
+        return -1;
+    };
+
+    // Boundary flags (:424-429 with the corner rules of :530-626).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t key = ld<BIG>(&cKey[c]);
+        const uint32_t iX = key & 0xffffu, iY = key >> 16;
+        int32_t x, y;
+        getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t left = x < 0 ? 0u : uint32_t(x);
+        getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
+        getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t top = y < 0 ? 0u : uint32_t(y);
+        getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
+        uint32_t f = 0;
+        if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) f |= F_NEAR_LT | F_FWD;
+        if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) f |= F_NEAR_RB;
+        cFlags[c] = f;
+        cYMin[c] = EMPTY32; cYMax[c] = 0;
+    }
+
+    // forwardSearch (:682-729): a cell is forward accessible if a forward accessible cell
+    // lies at (iX-1 or iX, iY-1..iY+1).  Label propagation to the fixed point.
+    for(;;) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            if(ld<BIG>(&cFlags[c]) & F_FWD) continue;
+            const uint32_t key = ld<BIG>(&cKey[c]);
+            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
+            bool reach = false;
+            for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = -1; dX <= 0; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(iX + dX, iY + dY);
+                if(j >= 0 && (ld<BIG>(&cFlags[j]) & F_FWD)) { reach = true; break; }
+            }
+            if(reach) { atomicOr(&cFlags[c], F_FWD); sChanged = 1; }
+        }
+        __syncthreads();
+        if(!sChanged) break;
+    }
+    // backwardSearch (:736-787): seeds near right/bottom AND forward accessible; a cell is
+    // backward accessible if a backward accessible cell lies at (iX or iX+1, iY-1..iY+1).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t f = ld<BIG>(&cFlags[c]);
+        if((f & F_NEAR_RB) && (f & F_FWD)) atomicOr(&cFlags[c], F_BWD);
+    }
+    for(;;) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            if(ld<BIG>(&cFlags[c]) & F_BWD) continue;
+            const uint32_t key = ld<BIG>(&cKey[c]);
+            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
+            bool reach = false;
+            for(int dY = -1; dY <= 1 && !reach; dY++) for(int dX = 0; dX <= 1; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(iX + dX, iY + dY);
+                if(j >= 0 && (ld<BIG>(&cFlags[j]) & F_BWD)) { reach = true; break; }
+            }
+            if(reach) { atomicOr(&cFlags[c], F_BWD); sChanged = 1; }
+        }
+        __syncthreads();
+        if(!sChanged) break;
+    }
+
+    // Connected components of active cells, 8-neighbourhood (:792-868): min-label propagation.
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t f = ld<BIG>(&cFlags[c]);
+        cLabel[c] = ((f & F_FWD) && (f & F_BWD)) ? ld<BIG>(&cKey[c]) : EMPTY32;
+    }
+    for(;;) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            const uint32_t mine = ld<BIG>(&cLabel[c]);
+            if(mine == EMPTY32) continue;
+            const uint32_t key = ld<BIG>(&cKey[c]);
+            const int32_t iX = int32_t(key & 0xffffu), iY = int32_t(key >> 16);
+            uint32_t best = mine;
+            for(int dY = -1; dY <= 1; dY++) for(int dX = -1; dX <= 1; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int j = find(iX + dX, iY + dY);
+                if(j >= 0) best = min(best, ld<BIG>(&cLabel[j]));
+            }
+            if(best < mine) { atomicMin(&cLabel[c], best); sChanged = 1; }
+        }
+        __syncthreads();
+        if(!sChanged) break;
+    }
+    // iY range of each component, stored at its root cell (the cell whose key is the label).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t label = ld<BIG>(&cLabel[c]);
+        if(label == EMPTY32) continue;
+        const int r = find(int32_t(label & 0xffffu), int32_t(label >> 16));
+        const uint32_t iY = ld<BIG>(&cKey[c]) >> 16;
+        atomicMin(&cYMin[r], iY);
+        atomicMax(&cYMax[r], iY);
+    }
+    __syncthreads();
+    // One banded alignment per component (:890-934).
+    for(int c = tid; c < n; c += CELLS_THREADS) {
+        const uint32_t key = ld<BIG>(&cKey[c]);
+        if(ld<BIG>(&cLabel[c]) != key) continue;
+        const uint32_t YMin = ld<BIG>(&cYMin[c]) * opt.deltaY;
+        const uint32_t YMax = (ld<BIG>(&cYMax[c]) + 1) * opt.deltaY - 1;
+        const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
+        const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
+        const int32_t bandWidth = bandMax - bandMin + 1;
+        if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;             // :929
+        if(bandWidth > 1024) { pairFlags[pair] = PAIR_TOO_LONG; continue; }
+        const uint32_t t = atomicAdd(taskCount, 1u);
+        if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K8/K9, fast path.  A CHUNK is a set of candidates that share one oriented read: read 0
+// (candidates arrive sorted by readId0, src/LowHash0.cpp:204-214, and read 0 is always on
+// strand 0, src/AssemblerAlign.cpp:382) or, when read 1 is the shorter one, read 1 ("swapped",
+// gathered by the host).  One workgroup per chunk; its waves share the table of that read and
+// then work on different candidates of the chunk without ever synchronising again.
+//   build   read 0's kmer ids are copied to LDS and indexed by a two-choice bucketised LDS hash
+//           table (buckets of four 16-bit slots = one ds_read_b64; slot = hash tag | ordinal);
+//   probe   a candidate's other read is streamed through the table, four markers per lane per
+//           round: both buckets are read, the eight slots are tag-matched with SWAR compares,
+//           the kmer ids are compared in LDS: fixed trip count, no probe chains;
+//   count   (x,y) -> cell by magic-number division (getXY + createCells,
+//           src/Align4.cpp:171-177,380-436), one LDS atomic per hit on a packed cell word (folding
+//           equal neighbours first costs more instructions than the atomics it saves); the
+//           increment that reaches minEntryCountPerCell appends the cell to the kept list (:417);
+//   graph   the kept cells (Q per lane) live in registers; their forward/backward adjacency is
+//           a bit mask per cell, so forwardSearch / backwardSearch (:682-788) and the connected
+//           components (:792-868) are iterated ballots with no memory traffic;
+//   tasks   one DP task per component (:890-934), staged in LDS, appended with one global atomic.
+// Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
+// larger class, finally by align4CellsKernel<true>.
+// Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | per wave:
+//   cells[SC] (iY | iX | count packed) | kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
+// ---------------------------------------------------------------------------
+// firstMember indexes the member list (candidate indices of the batch).
+struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
+
+#ifdef SHASTA_PROFILE_PHASES
+__device__ unsigned long long g_phaseCycles[16];
+#define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    if((threadIdx.x & 63) == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
+#define PHASE_BEGIN() unsigned long long phaseT_ = __builtin_readcyclecounter()
+#else
+#define PHASE_MARK(k) do {} while(0)
+#define PHASE_BEGIN() do {} while(0)
+#endif
+
+// floor(v / d) = umulhi(v, magic) with magic = floor(2^32 / d) + 1, exact whenever v * d < 2^32
+// (the host only sends a candidate to this kernel if (nx + ny) * max(deltaX, deltaY) < 2^32).
+__device__ __forceinline__ uint32_t divMagic(uint32_t v, uint32_t magic) { return __umulhi(v, magic); }
+
+// LDS traffic of ONE wave is ordered by the hardware; this only stops the compiler from moving
+// LDS accesses across it and drains the counters.  Waves of a chunk never wait for each other
+// after the build, so no s_barrier may appear in the per-candidate code.
+__device__ __forceinline__ void waveLdsSync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t hash32b(uint32_t k) { return k * 0x85ebca6bu; }
+
+// Bits 15 and 31 of the result flag the 16-bit halves of v that are zero (exact, no carries).
+__device__ __forceinline__ uint32_t zeroHalves(uint32_t v)
+{
+    return ~(((v & 0x7fff7fffu) + 0x7fff7fffu) | v | 0x7fff7fffu);
+}
+
+constexpr int CELLS_UNROLL = 4;           // markers per lane per round
+constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
+constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
+__host__ __device__ inline size_t cellsWaveLdsWords(int scLog2, int Q)
+{
+    return (size_t(1) << scLog2) + 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
+}
+__host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
+{
+    return 2 * (size_t(1) << naLog2) + size_t(waves) * cellsWaveLdsWords(scLog2, Q);
+}
+
+template<int Q>
+__global__ void __launch_bounds__(384)
+align4CellsChunkKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
+    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
+    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags)
+{
+    extern __shared__ uint32_t ldsWords[];
+    // Markers whose two buckets were both full when they arrived (the two-choice table runs at two
+    // entries per four-slot bucket on average, so a nearly full table overflows now and then).
+    constexpr uint32_t STASH = 32;
+    __shared__ uint32_t stashCount, stashKmer[STASH], stashOrdinal[STASH];
+    constexpr int MAXC = 64 * Q;
+    if(blockIdx.x >= chunkCount) return;
+    const CellsChunk chunk = chunks[blockIdx.x];
+    const int lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint32_t NA = 1u << chunk.naLog2, SC = 1u << chunk.scLog2;
+    const int bucketShift = 32 - (int(chunk.naLog2) - 1), scShift = 32 - int(chunk.scLog2);
+    const int xBits = int(chunk.naLog2);
+    const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
+    uint32_t* const aKmers = ldsWords;
+    uint32_t* const aSlots = aKmers + NA;
+    uint32_t* const cells = aSlots + NA + wave * cellsWaveLdsWords(int(chunk.scLog2), Q);
+    uint32_t* const kept = cells + SC;
+    uint32_t* const scratch = kept + MAXC;                        // [0] kept count, [1] min, [2] max, [3] staged tasks
+    uint32_t* const stage = scratch + 8;
+    const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
+    PHASE_BEGIN();
+
+    // Tag of a kmer id (never all ones, so that an empty slot matches no tag) and its two buckets.
+    auto tagOf = [&](uint32_t h) { const uint32_t t = (h >> 4) & tagMask; return t == tagMask ? 0u : t; };
+
+    // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
+    //     candidates gathered by the host because they share a short read 1) read 1 ---
+    const PairDesc pdFirst = pairs[members[chunk.firstMember]];
+    const bool swapped = chunk.swapped != 0;
+    const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
+    const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
+    for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
+    if(threadIdx.x == 0) stashCount = 0;
+    if(lane == 0) scratch[3] = 0;
+    __syncthreads();
+    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
+        const uint32_t km = tabSeq[t];
+        aKmers[t] = km;
+        const uint32_t h = hash32(km);
+        const uint32_t b1 = h >> bucketShift, b2 = hash32b(km) >> bucketShift;
+        const uint32_t entry = (tagOf(h) << xBits) | t;
+        for(;;) {
+            // Free slots of the two candidate buckets; take the emptier bucket (ties: the first).
+            const uint32_t u0 = aSlots[2 * b1], u1 = aSlots[2 * b1 + 1], v0 = aSlots[2 * b2], v1 = aSlots[2 * b2 + 1];
+            const uint32_t fu0 = zeroHalves(~u0), fu1 = zeroHalves(~u1), fv0 = zeroHalves(~v0), fv1 = zeroHalves(~v1);
+            const int freeU = __popc(fu0) + __popc(fu1), freeV = __popc(fv0) + __popc(fv1);
+            if(freeU == 0 && freeV == 0) {
+                const uint32_t k = atomicAdd(&stashCount, 1u);
+                if(k < STASH) { stashKmer[k] = km; stashOrdinal[k] = t; }
+                break;
+            }
+            const bool useV = freeV > freeU;
+            const uint32_t f0 = useV ? fv0 : fu0, f1 = useV ? fv1 : fu1;
+            const uint32_t w0 = useV ? v0 : u0, w1 = useV ? v1 : u1;
+            const uint32_t base = 2 * (useV ? b2 : b1);
+            const bool second = f0 == 0;
+            const uint32_t f = second ? f1 : f0, old = second ? w1 : w0;
+            const int shift = (f & 0x8000u) ? 0 : 16;
+            const uint32_t updated = (old & ~(0xffffu << shift)) | (entry << shift);
+            if(atomicCAS(&aSlots[base + (second ? 1 : 0)], old, updated) == old) break;
+        }
+    }
+    __syncthreads();
+    PHASE_MARK(0);
+    const uint32_t stashed = stashCount;
+    if(stashed > STASH) {
+        // Too many markers of the tabled read share their buckets (a tandem repeat): the whole
+        // chunk goes to the next class.
+        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x80);
+        return;
+    }
+
+    for(uint32_t c = wave; c < chunk.count; c += waves) {
+        const uint32_t pair = members[chunk.firstMember + c];
+        const PairDesc pd = pairs[pair];
+        const uint32_t nx = pd.nx, ny = pd.ny;
+        const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
+        const uint32_t streamCount = swapped ? nx : ny;
+        int overflow = 0, reason = 0;
+
+        for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
+        if(lane == 0) scratch[0] = 0;
+        waveLdsSync();
+        PHASE_MARK(1);
+
+        // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
+        // Counts the hits of one round: hit[u] with table ordinal ti[u] and stream ordinal t.
+        auto countHits = [&](const bool (&hit)[CELLS_UNROLL], const uint32_t (&ti)[CELLS_UNROLL], uint32_t s0) {
+            bool pending[CELLS_UNROLL];
+            uint32_t key[CELLS_UNROLL], packed[CELLS_UNROLL], cs[CELLS_UNROLL], len[CELLS_UNROLL], probes[CELLS_UNROLL];
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                const uint32_t t = s0 + u * WAVE + lane;
+                const uint32_t x = swapped ? t : ti[u], y = swapped ? ti[u] : t;
+                const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
+                const uint32_t iX = divMagic(X, magicX), iY = divMagic(Y, magicY);
+                // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; the host only sends
+                // candidates whose cell indices fit (others run in the HBM-scratch kernel).
+                const bool h = hit[u];
+                key[u] = h ? ((iY << 16) | iX) : EMPTY32;
+                len[u] = 1;
+                pending[u] = h;
+                packed[u] = (iY << CELLS_IX_BITS) | iX;
+                cs[u] = hash32(key[u]) >> scShift;
+                probes[u] = 0;
+            }
+            while(__any(pending[0] | pending[1] | pending[2] | pending[3])) {
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) {
+                    if(pending[u]) {
+                        const uint32_t cur = *reinterpret_cast<volatile uint32_t*>(&cells[cs[u]]);
+                        bool done = false;
+                        uint32_t before = 0;
+                        if(cur != EMPTY32 && (cur >> CELLS_COUNT_BITS) == packed[u]) {
+                            before = atomicAdd(&cells[cs[u]], len[u]) & ((1u << CELLS_COUNT_BITS) - 1);
+                            done = true;
+                        } else if(cur == EMPTY32) {
+                            // Claim the slot; on failure look at the same slot again.
+                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << CELLS_COUNT_BITS) | len[u]) == EMPTY32;
+                        } else {
+                            cs[u] = (cs[u] + 1) & (SC - 1);
+                            if(++probes[u] == SC) { overflow = max(overflow, 1); reason |= 1; pending[u] = false; }
+                        }
+                        if(done) {
+                            if(before < threshold && before + len[u] >= threshold) {           // :417
+                                const uint32_t idx = atomicAdd(&scratch[0], 1u);
+                                if(idx < uint32_t(MAXC)) kept[idx] = key[u];
+                            }
+                            pending[u] = false;
+                        }
+                    }
+                }
+            }
+        };
+
+        uint32_t kmNext[CELLS_UNROLL];
+#pragma unroll
+        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        for(uint32_t s0 = 0; s0 < streamCount; s0 += CELLS_UNROLL * WAVE) {
+            uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], m[CELLS_UNROLL][4], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
+            bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                km[u] = kmNext[u];
+                const uint32_t tn = s0 + (CELLS_UNROLL + u) * WAVE + lane;
+                kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
+                valid[u] = s0 + u * WAVE + lane < streamCount;
+            }
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                const uint32_t h = hash32(km[u]);
+                const uint32_t b1 = h >> bucketShift, b2 = hash32b(km[u]) >> bucketShift;
+                w[u][0] = aSlots[2 * b1]; w[u][1] = aSlots[2 * b1 + 1];
+                w[u][2] = aSlots[2 * b2]; w[u][3] = aSlots[2 * b2 + 1];
+                const uint32_t pattern = (tagOf(h) << xBits) * 0x00010001u, fieldMask = (tagMask << xBits) * 0x00010001u;
+                const bool same = b1 == b2;
+#pragma unroll
+                for(int i = 0; i < 4; i++) m[u][i] = zeroHalves((w[u][i] ^ pattern) & fieldMask);
+                if(same) { m[u][2] = 0; m[u][3] = 0; }
+                if(!valid[u]) { m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; }
+            }
+            // Resolve the tag matches (usually one per marker) against the kmer ids in LDS.
+            for(;;) {
+                bool more = false;
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) {
+                    // First tag match of this marker (static register indexing only).
+                    const bool s0m = m[u][0] != 0, s1m = !s0m && m[u][1] != 0, s2m = !s0m && !s1m && m[u][2] != 0;
+                    const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
+                    const uint32_t ww = s0m ? w[u][0] : (s1m ? w[u][1] : (s2m ? w[u][2] : w[u][3]));
+                    const bool cand = mm != 0;
+                    const bool low = (mm & 0x8000u) != 0;
+                    ti[u] = (low ? ww : (ww >> 16)) & xMask;
+                    ka[u] = aKmers[cand ? ti[u] : 0u];
+                    const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
+                    if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
+                    hit[u] = cand;
+                    more |= (m[u][0] | m[u][1] | m[u][2] | m[u][3]) != 0;
+                }
+                bool anyHit = false;
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = hit[u] && ka[u] == km[u]; anyHit |= hit[u]; }
+                if(__any(anyHit)) countHits(hit, ti, s0);
+                if(!__any(more)) break;
+            }
+            // The few markers that did not fit their buckets.
+            for(uint32_t k = 0; k < stashed; k++) {
+                const uint32_t sk = stashKmer[k], so = stashOrdinal[k];
+                bool anyHit = false;
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
+                if(__any(anyHit)) countHits(hit, ti, s0);
+            }
+        }
+        waveLdsSync();
+        PHASE_MARK(2);
+
+        const int n = int(scratch[0]);
+        if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
+        const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
+        if(anyHard || anySoft) {
+            // Bits 4-6 carry the reason (cell table full / kept list full / geometry) for diagnostics.
+            const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0);
+            if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
+            continue;
+        }
+        if(n == 0) continue;
+        const int nq = (n + WAVE - 1) / WAVE;
+
+        // --- kept cells in registers: boundary flags (:424-429 with the corner rules of :530-626) ---
+        uint32_t key[Q], flags[Q];
+#pragma unroll
+        for(int q = 0; q < Q; q++) {
+            const int cc = lane + q * WAVE;
+            key[q] = EMPTY32; flags[q] = 0;
+            if(cc >= n) continue;
+            key[q] = kept[cc];
+            const uint32_t iX = key[q] & 0xffffu, iY = key[q] >> 16;
+            int32_t x, y;
+            getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+            const uint32_t left = x < 0 ? 0u : uint32_t(x);
+            getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
+            const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
+            getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
+            const uint32_t top = y < 0 ? 0u : uint32_t(y);
+            getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+            const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
+            if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) flags[q] |= F_NEAR_LT;
+            if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) flags[q] |= F_NEAR_RB;
+        }
+        // Adjacency masks.  before[q][r] bit j: cell 64 r + j lies at (iX-1 or iX, iY-1..iY+1) of
+        // this lane's cell q (a forward move leads from it to this cell); after: (iX or iX+1, ...).
+        uint64_t before[Q][Q], after[Q][Q];
+#pragma unroll
+        for(int q = 0; q < Q; q++)
+#pragma unroll
+            for(int r = 0; r < Q; r++) { before[q][r] = 0; after[q][r] = 0; }
+#pragma unroll
+        for(int r = 0; r < Q; r++) {
+            if(r >= nq) break;
+            const int jEnd = min(WAVE, n - r * WAVE);
+            for(int j = 0; j < jEnd; j++) {
+                const uint32_t other = __builtin_amdgcn_readlane(key[r], j);
+                const int32_t oX = int32_t(other & 0xffffu), oY = int32_t(other >> 16);
+                const uint64_t bit = 1ULL << j;
+#pragma unroll
+                for(int q = 0; q < Q; q++) {
+                    if(q >= nq) break;
+                    const int32_t dX = oX - int32_t(key[q] & 0xffffu), dY = oY - int32_t(key[q] >> 16);
+                    const bool near = key[q] != EMPTY32 && dY >= -1 && dY <= 1 && other != key[q];
+                    if(near && (dX == -1 || dX == 0)) before[q][r] |= bit;
+                    if(near && (dX == 0 || dX == 1)) after[q][r] |= bit;
+                }
+            }
+        }
+        PHASE_MARK(3);
+
+        // forwardSearch (:682-729): seeds near left/top; closure under forward moves.
+        uint64_t fwd[Q], bwd[Q];
+#pragma unroll
+        for(int q = 0; q < Q; q++) fwd[q] = __ballot((flags[q] & F_NEAR_LT) != 0);
+        for(;;) {
+            bool changed = false;
+#pragma unroll
+            for(int q = 0; q < Q; q++) {
+                if(q >= nq) break;
+                uint64_t reach = 0;
+#pragma unroll
+                for(int r = 0; r < Q; r++) reach |= before[q][r] & fwd[r];
+                const uint64_t grown = fwd[q] | __ballot(reach != 0);
+                changed |= grown != fwd[q];
+                fwd[q] = grown;
+            }
+            if(!changed) break;
+        }
+        // backwardSearch (:736-787): seeds near right/bottom AND forward accessible.
+#pragma unroll
+        for(int q = 0; q < Q; q++) bwd[q] = __ballot((flags[q] & F_NEAR_RB) != 0) & fwd[q];
+        for(;;) {
+            bool changed = false;
+#pragma unroll
+            for(int q = 0; q < Q; q++) {
+                if(q >= nq) break;
+                uint64_t reach = 0;
+#pragma unroll
+                for(int r = 0; r < Q; r++) reach |= after[q][r] & bwd[r];
+                const uint64_t grown = bwd[q] | __ballot(reach != 0);
+                changed |= grown != bwd[q];
+                bwd[q] = grown;
+            }
+            if(!changed) break;
+        }
+        PHASE_MARK(4);
+        // Connected components of the active cells, 8-neighbourhood (:792-868), one at a time,
+        // seeded at the remaining active cell with the smallest key; one banded alignment per
+        // component (:890-934).
+        uint64_t remaining[Q];
+        bool anyRemaining = false;
+#pragma unroll
+        for(int q = 0; q < Q; q++) { remaining[q] = fwd[q] & bwd[q]; anyRemaining |= remaining[q] != 0; }
+        while(anyRemaining) {
+            uint32_t myMin = EMPTY32;
+#pragma unroll
+            for(int q = 0; q < Q; q++) if((remaining[q] >> lane) & 1ULL) myMin = min(myMin, key[q]);
+            if(lane == 0) { scratch[1] = EMPTY32; }
+            waveLdsSync();
+            if(myMin != EMPTY32) atomicMin(&scratch[1], myMin);
+            waveLdsSync();
+            const uint32_t seedKey = scratch[1];
+            uint64_t comp[Q];
+#pragma unroll
+            for(int q = 0; q < Q; q++) comp[q] = __ballot(key[q] == seedKey);
+            for(;;) {
+                bool changed = false;
+#pragma unroll
+                for(int q = 0; q < Q; q++) {
+                    if(q >= nq) break;
+                    uint64_t reach = 0;
+#pragma unroll
+                    for(int r = 0; r < Q; r++) reach |= (before[q][r] | after[q][r]) & comp[r];
+                    const uint64_t grown = comp[q] | (__ballot(reach != 0) & remaining[q]);
+                    changed |= grown != comp[q];
+                    comp[q] = grown;
+                }
+                if(!changed) break;
+            }
+            // iY range of the component.
+            if(lane == 0) { scratch[1] = EMPTY32; scratch[2] = 0; }
+            waveLdsSync();
+#pragma unroll
+            for(int q = 0; q < Q; q++) {
+                if((comp[q] >> lane) & 1ULL) { atomicMin(&scratch[1], key[q] >> 16); atomicMax(&scratch[2], key[q] >> 16); }
+            }
+            waveLdsSync();
+            const uint32_t YMin = scratch[1] * opt.deltaY;
+            const uint32_t YMax = (scratch[2] + 1) * opt.deltaY - 1;
+            const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
+            const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
+            const int32_t bandWidth = bandMax - bandMin + 1;
+            if(int64_t(bandWidth) <= int64_t(opt.maxBand)) {                      // :929
+                if(bandWidth > 1024) { if(lane == 0) pairFlags[pair] = PAIR_TOO_LONG; }
+                else {
+                    uint32_t staged = scratch[3];
+                    if(staged == CELLS_STAGE) {
+                        // Staging area full: append it to the task list.
+                        uint32_t base = 0;
+                        if(lane == 0) base = atomicAdd(taskCount, staged);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        for(uint32_t k = lane; k < 4 * staged; k += WAVE) {
+                            const uint32_t t = base + k / 4;
+                            if(t < taskCapacity) reinterpret_cast<uint32_t*>(tasks)[4ULL * base + k] = stage[k];
+                        }
+                        waveLdsSync();
+                        staged = 0;
+                    }
+                    if(lane == 0) {
+                        stage[4 * staged] = pair; stage[4 * staged + 1] = uint32_t(bandMin);
+                        stage[4 * staged + 2] = uint32_t(bandMax); stage[4 * staged + 3] = seedKey;
+                        scratch[3] = staged + 1;
+                    }
+                    waveLdsSync();
+                }
+            }
+            anyRemaining = false;
+#pragma unroll
+            for(int q = 0; q < Q; q++) { remaining[q] &= ~comp[q]; anyRemaining |= remaining[q] != 0; }
+        }
+        PHASE_MARK(5);
+    }
+    // Append this wave's staged tasks.
+    waveLdsSync();
+    const uint32_t staged = scratch[3];
+    if(staged) {
+        uint32_t base = 0;
+        if(lane == 0) base = atomicAdd(taskCount, staged);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for(uint32_t k = lane; k < 4 * staged; k += WAVE) {
+            const uint32_t t = base + k / 4;
+            if(t < taskCapacity) reinterpret_cast<uint32_t*>(tasks)[4ULL * base + k] = stage[k];
+        }
+    }
+    PHASE_MARK(6);
+}

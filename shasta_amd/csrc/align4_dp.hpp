@@ -1,0 +1,627 @@
+// Align4 on MI355X, K10: the banded overlap DP of every (candidate, component) task -- task geometry and sort keys,
+// bundles, the two forward kernels, the traceback (/root/reference/src/Align4.cpp:993-1088; the SeqAn call it wraps is
+// restated, tie policy as in oracle/banded_dp.hpp).  Included by align4.hip inside its anonymous namespace; align
+// method 3 (align3.hpp) runs the same kernels.
+#pragma once
+
+// ---------------------------------------------------------------------------
+// K10: banded overlap DP (computeBandedAlignment, src/Align4.cpp:993-1088; the SeqAn call it
+// wraps is restated -- tie policy as in oracle/banded_dp.hpp).
+//
+// DP cell (i,j) (i symbols of read 0, j of read 1 consumed) lives on diagonal d = i-j =
+// bandMin + b and anti-diagonal s = i+j.  On step s only diagonals with (s+d) even hold a cell;
+// its three predecessors are the same diagonal at s-2 (diagonal move), diagonal b-1 at s-1
+// (horizontal, from (i-1,j)) and diagonal b+1 at s-1 (vertical, from (i,j-1)).
+//
+//   forward   bandedDpForwardKernel<G,C>: a task occupies G lanes, each lane owns C adjacent
+//             diagonals in registers; narrow bands are packed 64/G tasks to a wavefront (tasks
+//             are sorted by class and length first, so bundled tasks have the same trip count).
+//             One loop iteration advances two anti-diagonals (all C cells of a lane); the only
+//             cross-lane traffic is one shuffle up and one down.  The kmer ids a lane compares
+//             slide through register windows fed by one prefetched load per read and iteration.
+//             Trace: 2 bits per cell, one __ballot per bit plane, 2C 64-bit words per iteration.
+//   end cell  free end gaps: the best border cell = max over the final value of each diagonal,
+//             ties to the smallest (i, j) -- a G-lane reduction after the loop.
+//   trace     dpTracebackKernel: ONE LANE per task walks its path through the packed trace
+//             (64 tasks per wavefront in flight), writes the aligned ordinals and accumulates
+//             AlignmentInfo's metrics (src/Alignment.cpp:67-113, :4-31).
+// Trace codes: 0 diagonal+equal kmers, 1 diagonal+different, 2 vertical, 3 horizontal.  Tie
+// policy: diagonal >= vertical >= horizontal.
+// ---------------------------------------------------------------------------
+constexpr int DP_CLASSES = 6;
+__host__ __device__ inline int dpClassOfWidth(int32_t w) { return w <= 32 ? 0 : (w <= 64 ? 1 : (w <= 128 ? 2 : (w <= 256 ? 3 : (w <= 512 ? 4 : 5)))); }
+__host__ __device__ inline int dpLanes(int cls) { return cls == 0 ? 16 : (cls == 1 ? 32 : 64); }          // G
+__host__ __device__ inline int dpDiagonals(int cls) { return cls <= 2 ? 2 : (1 << (cls - 1)); }             // C = 2,2,2,4,8,16
+
+struct DpGeometry { int32_t s0; uint32_t iters; int cls; };
+__host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
+{
+    DpGeometry g;
+    g.cls = dpClassOfWidth(bandMax - bandMin + 1);
+    const int32_t sMin = bandMin > 0 ? bandMin : (bandMax < 0 ? -bandMax : 0);
+    g.s0 = sMin - ((sMin + bandMin) & 1);          // (s0 + bandMin) is even
+    g.iters = uint32_t((int32_t(nx + ny) - g.s0) / 2 + 1);
+    return g;
+}
+
+// What the forward kernel leaves for the traceback of a task.
+struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase; };
+
+// Per task: sort key (class, iterations), ordinal capacity, statistics.
+__global__ void __launch_bounds__(256)
+dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
+    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cells = 0, words = 0, bytes = 0;
+    int cls = -1;
+    if(t < taskCount) {
+        const DpTask task = tasks[t];
+        const PairDesc pd = pairs[task.pair];
+        const DpGeometry g = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+        cls = g.cls;
+        keys[t] = (uint32_t(g.cls) << 24) | min(g.iters, 0xffffffu);
+        ids[t] = t;
+        ordCap[t] = min(pd.nx, pd.ny);
+        cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
+        words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls)) + 32;
+        bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
+    } else if(t == taskCount) {
+        ordCap[t] = 0;
+    }
+    // Per class: one atomic per wavefront and class present in it (tasks of a wave mostly share a
+    // class after the cells kernels); one atomic per task serialises the whole launch on six addresses.
+#pragma unroll
+    for(int c = 0; c < DP_CLASSES; c++) {
+        const uint64_t votes = __ballot(cls == c);
+        if(votes == 0) continue;
+        unsigned long long classCells = cls == c ? cells : 0, classBytes = cls == c ? bytes : 0;
+        for(int d = 32; d >= 1; d >>= 1) { classCells += __shfl_down(classCells, d, WAVE); classBytes += __shfl_down(classBytes, d, WAVE); }
+        if(laneId() == 0) {
+            atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
+            atomicAdd(&sums[2 + c], classCells);
+            atomicAdd(&sums[8 + c], classBytes);
+        }
+    }
+    for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
+    if(laneId() == 0 && cells) { atomicAdd(&sums[0], cells); atomicAdd(&sums[1], words); }
+}
+
+// Trace words of each bundle (64/G consecutive tasks of the sorted list of one class).
+struct DpClassLayout { uint32_t taskStart[DP_CLASSES + 1]; uint32_t bundleStart[DP_CLASSES + 1]; };
+
+__global__ void __launch_bounds__(256)
+dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, uint64_t* __restrict__ bundleWords)
+{
+    const uint32_t bundle = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = layout.bundleStart[DP_CLASSES];
+    if(bundle > total) return;
+    if(bundle == total) { bundleWords[bundle] = 0; return; }
+    int cls = 0;
+    while(bundle >= layout.bundleStart[cls + 1]) ++cls;
+    const uint32_t T = 64u / uint32_t(dpLanes(cls));
+    const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
+    const uint32_t last = min(first + T, layout.taskStart[cls + 1]) - 1;
+    // sorted ascending: the last task has the most iterations.  Rounded to 256 bytes so that the
+    // traceback's chunks are whole cache lines.
+    bundleWords[bundle] = (uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
+}
+
+template<int G, int C>
+__global__ void __launch_bounds__(256)
+bandedDpForwardKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
+    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,            // this class's segment of the sorted list
+    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,      // this class's segment
+    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
+{
+    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C;
+    const int lane = laneId();
+    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(bundle >= bundleCount) return;                     // whole wave leaves; no block barriers below
+    const int g = lane / G, l = lane % G;
+    const uint32_t pos = bundle * T + uint32_t(g);
+    const bool hasTask = pos < taskCount;
+    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
+    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    uint32_t iters = geo.iters;
+#pragma unroll
+    for(int d = G; d < WAVE; d <<= 1) iters = max(iters, uint32_t(__shfl_xor(int(iters), d, WAVE)));
+    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
+
+    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
+    int32_t lo[C];
+    uint32_t span[C];
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t b = l * C + c, d = bandMin + b;
+        const int32_t first = d < 0 ? -d : d;
+        const int32_t last = min(2 * nx - d, 2 * ny + d);
+        const bool exists = hasTask && b < width && d <= nx && d >= -ny && last >= first;
+        lo[c] = exists ? first : 0x40000000;
+        span[c] = exists ? uint32_t(last - first) : 0u;
+    }
+    int32_t H[C];
+#pragma unroll
+    for(int c = 0; c < C; c++) H[c] = NEG_SCORE;
+
+    // Register windows of the kmer ids: aw[k] = A[ib + l HC - 1 + k], bw[h] = B[jb - l HC - 1 - h],
+    // ib = (s + bandMin) / 2, jb = ib - bandMin.  Indices are clamped; clamped values belong to
+    // cells that are not in the matrix.
+    int32_t ib = (geo.s0 + bandMin) / 2;
+    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
+    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
+    uint32_t aw[HC + 1], bw[HC];
+#pragma unroll
+    for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
+#pragma unroll
+    for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
+    uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
+    uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
+
+    auto cell = [&](int c, int32_t s, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
+        const bool eq = a == bk;
+        const int32_t dg = hd + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+        const int32_t vg = hv + GAP_SCORE;                          // from (i, j-1): diagonal b+1
+        const int32_t hg = hh + GAP_SCORE;                          // from (i-1, j): diagonal b-1
+        const bool isV = vg > dg;
+        const int32_t m1 = max(dg, vg);
+        const bool isH = hg > m1;
+        int32_t v = max(m1, hg);
+        const bool valid = uint32_t(s - lo[c]) <= span[c];
+        v = (s == lo[c]) ? 0 : v;                                   // i == 0 or j == 0: free leading gaps
+        H[c] = valid ? v : H[c];
+        loPlane = __ballot(isH || (!isV && !eq));
+        hiPlane = __ballot(isV || isH);
+    };
+
+    int32_t s = geo.s0;
+    for(uint32_t it = 0; it < iters; it++, s += 2) {
+        uint64_t words[RW];
+        {   // anti-diagonal s: even c hold cells
+            int32_t left = __shfl_up(H[C - 1], 1, G); if(l == 0) left = NEG_SCORE;
+#pragma unroll
+            for(int c = 0; c < C; c += 2) {
+                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
+                cell(c, s, aw[c / 2], bw[c / 2], H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
+            }
+        }
+        {   // anti-diagonal s+1: odd c hold cells
+            int32_t right = __shfl_down(H[0], 1, G); if(l == G - 1) right = NEG_SCORE;
+#pragma unroll
+            for(int c = 1; c < C; c += 2) {
+                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
+                cell(c, s + 1, aw[c / 2 + 1], bw[c / 2], H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
+            }
+        }
+        // Lane k stores word k of this iteration's trace record.
+        uint64_t mine = words[0];
+#pragma unroll
+        for(int k = 1; k < RW; k++) mine = (lane == k) ? words[k] : mine;
+        if(lane < RW) tr[uint64_t(it) * RW + lane] = mine;
+        // Slide the windows.
+#pragma unroll
+        for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
+        aw[HC] = aNext1; aNext1 = aNext2;
+#pragma unroll
+        for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
+        bw[0] = bNext1; bNext1 = bNext2;
+        ++ib;
+        aNext2 = loadA(ib + 1 + l * HC + HC);
+        bNext2 = loadB(ib + 1 - bandMin - l * HC);
+    }
+
+    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
+    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t d = bandMin + l * C + c;
+        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
+        const int32_t v = (lo[c] != 0x40000000) ? H[c] : NEG_SCORE;
+        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
+    }
+#pragma unroll
+    for(int d = G / 2; d >= 1; d >>= 1) {
+        const int32_t os = __shfl_xor(bestScore, d, G);
+        const int32_t oi = __shfl_xor(bestI, d, G);
+        const int32_t oj = __shfl_xor(bestJ, d, G);
+        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+    }
+    if(hasTask && l == 0) {
+        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
+        ends[t] = e;
+    }
+}
+
+// ---- forward kernel, second version ---------------------------------------------------------
+// Same tasks, bundles, trace format and DpEnd as bandedDpForwardKernel, which stays beside it
+// (SHASTA_MI355X_DP_FORWARD=1) until this one has been timed on the MI355X.  Every change comes
+// from the first version's ISA (75 VALU instructions per iteration for two cells per lane,
+// scripts/isa_loop.py):
+//  * three phases, general / steady / general.  In the steady phase (all but about a band width
+//    of iterations at either end) every cell of the wavefront that exists is inside the matrix and
+//    past the first cell of its diagonal, and every kmer-id load is in range: no validity tests,
+//    no index clamps.  It runs in blocks of DP_BLOCK iterations, fully unrolled: a lane's kmer ids
+//    of a block are DP_BLOCK + C/2 consecutive elements per read, fetched as one 16-byte load per
+//    read and block, one block ahead -- no sliding register windows, no per-iteration address;
+//  * scores are kept biased by -NEG_SCORE, so "outside the band" is 0 and the neighbour exchange
+//    is one DPP shift with zero fill (row_shr/shl for 16-lane groups, wave_shr/shl otherwise)
+//    instead of ds_bpermute + select -- same decisions: max, compare and adding a constant commute
+//    with the bias, and nothing overflows (|score| < 2^27);
+//  * trace planes: one ballot per comparison (the mask v_cmp wrote anyway), combined on the
+//    scalar unit; the ballot of a combined predicate is compiled to v_cndmask + v_cmp;
+//  * the trace record goes from lane 0 into a 256-byte LDS line per wavefront and leaves as one
+//    coalesced 4-byte store per lane when the line is full, instead of a select chain over the
+//    lanes and a partial store every iteration;
+//  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
+constexpr int DP_BLOCK = 4;
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// The value of the lane below / above in a G-lane group; 0 at the group's edge.
+template<int G> __device__ __forceinline__ int32_t fromLaneBelow(int32_t v, int l)
+{
+    constexpr int ctrl = (G == 16) ? 0x111 : 0x138;             // row_shr:1 : wave_shr:1; bound_ctrl = zero fill
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    if constexpr (G == 32) r = (l == 0) ? 0 : r;
+    return r;
+}
+template<int G> __device__ __forceinline__ int32_t fromLaneAbove(int32_t v, int l)
+{
+    constexpr int ctrl = (G == 16) ? 0x101 : 0x130;             // row_shl:1 : wave_shl:1
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    if constexpr (G == 32) r = (l == G - 1) ? 0 : r;
+    return r;
+}
+struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // four consecutive kmer ids, 4-byte aligned
+
+template<int G, int C>
+__global__ void __launch_bounds__(256)
+bandedDpForwardKernel2(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
+    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
+    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,
+    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
+{
+    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C, U = DP_BLOCK;
+    constexpr int F = 32 / RW;                            // iterations per 256-byte trace line
+    constexpr int AL = F > U ? F : U;                     // steady iterations come in groups of AL: whole blocks, whole lines
+    constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
+    static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
+    __shared__ __attribute__((aligned(16))) uint64_t traceLines[4 * 32];   // one 256-byte line per wavefront of the block (16-byte LDS writes)
+    const int lane = laneId();
+    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(bundle >= bundleCount) return;                     // whole wave leaves: all 64 lanes are active below, no block barriers
+    uint64_t* const line = traceLines + 32 * (threadIdx.x >> 6);
+    const int g = lane / G, l = lane % G;
+    const uint32_t pos = bundle * T + uint32_t(g);
+    const bool hasTask = pos < taskCount;
+    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
+    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
+    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
+    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    uint32_t itersLane = geo.iters;
+#pragma unroll
+    for(int d = G; d < WAVE; d <<= 1) itersLane = max(itersLane, uint32_t(__shfl_xor(int(itersLane), d, WAVE)));
+    const uint32_t iters = __builtin_amdgcn_readfirstlane(itersLane);
+    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
+
+    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
+    int32_t lo[C];
+    uint32_t span[C];
+    bool exists[C];
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t b = l * C + c, d = bandMin + b;
+        const int32_t first = d < 0 ? -d : d;
+        const int32_t last = min(2 * nx - d, 2 * ny + d);
+        exists[c] = hasTask && b < width && d <= nx && d >= -ny && last >= first;
+        lo[c] = exists[c] ? first : NO_DIAGONAL;
+        span[c] = exists[c] ? uint32_t(last - first) : 0u;
+    }
+    int32_t H[C];                                         // biased: score + BIAS; 0 = no cell
+#pragma unroll
+    for(int c = 0; c < C; c++) H[c] = 0;
+
+    // Iteration `it` works at ib = ib0 + it: it compares A[ib + l HC - 1 + k], k = 0..HC, with
+    // B[ib - bandMin - l HC - 1 - h], h = 0..HC-1.
+    const int32_t ib0 = (geo.s0 + bandMin) / 2;
+    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
+    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
+
+    // One anti-diagonal pair.  STEADY: every existing cell is valid and past its first cell.
+    auto cell = [&](auto steadyTag, int c, int32_t sc, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
+        constexpr bool STEADY = decltype(steadyTag)::value;
+        const bool eq = a == bk;
+        const int32_t dg = hd + (eq ? MATCH_SCORE - GAP_SCORE : MISMATCH_SCORE - GAP_SCORE);   // the three candidates before the gap penalty they share
+        const bool isV = hv > dg;                                   // from (i, j-1): diagonal b+1
+        const int32_t m1 = max(dg, hv);
+        const bool isH = hh > m1;                                   // from (i-1, j): diagonal b-1
+        int32_t v = max(m1, hh) + GAP_SCORE;
+        if constexpr (STEADY) {
+            SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
+            H[c] = exists[c] ? v : 0;
+        } else {
+            const bool valid = uint32_t(sc - lo[c]) <= span[c];
+            v = (sc == lo[c]) ? BIAS : v;                           // i == 0 or j == 0: free leading gaps
+            H[c] = valid ? v : H[c];
+        }
+        const uint64_t bEq = ballot64(eq), bV = ballot64(isV), bH = ballot64(isH);
+        loPlane = bH | ~(bV | bEq);                                 // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
+        hiPlane = bV | bH;
+    };
+    // aw(k), bw(h): the kmer ids of this iteration.
+    auto antiDiagonals = [&](auto steadyTag, int32_t s, auto aw, auto bw, uint64_t (&words)[RW]) {
+        {   // anti-diagonal s: even c hold cells
+            const int32_t left = fromLaneBelow<G>(H[C - 1], l);
+#pragma unroll
+            for(int c = 0; c < C; c += 2) {
+                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
+                cell(steadyTag, c, s, aw(c / 2), bw(c / 2), H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
+            }
+        }
+        {   // anti-diagonal s+1: odd c hold cells
+            const int32_t right = fromLaneAbove<G>(H[0], l);
+#pragma unroll
+            for(int c = 1; c < C; c += 2) {
+                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
+                cell(steadyTag, c, s + 1, aw(c / 2 + 1), bw(c / 2), H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
+            }
+        }
+    };
+    // The record of an iteration goes to slot (it mod F) of the wavefront's line; a full line leaves as
+    // one coalesced store.  Lane 0 writes, all lanes read: the wave barrier keeps the compiler from
+    // moving the read up (the hardware runs a wavefront's LDS operations in order).
+    auto putRecord = [&](int slot, const uint64_t (&words)[RW]) {
+        if(lane == 0) {
+            ulonglong2* __restrict__ record = reinterpret_cast<ulonglong2*>(line + slot * RW);
+#pragma unroll
+            for(int k = 0; k < C; k++) { ulonglong2 w; w.x = words[2 * k]; w.y = words[2 * k + 1]; record[k] = w; }
+        }
+    };
+    auto flushLine = [&](uint32_t lineIndex) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        SHASTA_DEVICE_CHECK(uint64_t(lineIndex) * 32 + 32 <= ((uint64_t(iters) * RW + 31) & ~31ULL));      // inside the bundle's trace (dpBundleKernel)
+        const uint32_t d = reinterpret_cast<const uint32_t*>(line)[lane];
+        reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = d;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // General iterations [from, to): sliding register windows fed by clamped loads two iterations ahead.
+    auto general = [&](uint32_t from, uint32_t to) {
+        if(from >= to) return;
+        const int32_t ib = ib0 + int32_t(from);
+        uint32_t aw[HC + 1], bw[HC];
+#pragma unroll
+        for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
+#pragma unroll
+        for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
+        uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
+        uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
+        for(uint32_t it = from; it < to; it++) {
+            uint64_t words[RW];
+            antiDiagonals(std::false_type{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
+            putRecord(int(it % F), words);
+            if(it % F == F - 1) flushLine(it / F);
+#pragma unroll
+            for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
+            aw[HC] = aNext1; aNext1 = aNext2;
+#pragma unroll
+            for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
+            bw[0] = bNext1; bNext1 = bNext2;
+            aNext2 = loadA(ib0 + int32_t(it) + 2 + l * HC + HC);
+            bNext2 = loadB(ib0 + int32_t(it) + 2 - bandMin - l * HC);
+        }
+    };
+
+    // Steady iterations.  A cell (lane, c) is steady at `it` when lo < s0 + 2 it + (c & 1) <= lo + span;
+    // the block that starts at itB loads A[iaBlock + itB + j], B[jbBlock + itB + j], j = 0..U-1
+    // (the new elements of the block after it).
+    const int32_t iaBlock = ib0 + U + l * HC + HC - 1, jbBlock = ib0 + U - bandMin - l * HC - 1;
+    int32_t itLo = 0, itHi = int32_t(iters) - 1;          // cells steady on [itLo, itHi]
+    int32_t startLo = max(-iaBlock, -jbBlock), startHi = min(nx - U - iaBlock, ny - U - jbBlock);   // block starts whose loads are in range
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        if(exists[c]) {
+            itLo = max(itLo, (lo[c] + 2 - geo.s0 - (c & 1)) >> 1);
+            itHi = min(itHi, (lo[c] + int32_t(span[c]) - geo.s0 - (c & 1)) >> 1);
+        }
+    }
+#pragma unroll
+    for(int d = 1; d < WAVE; d <<= 1) {
+        itLo = max(itLo, __shfl_xor(itLo, d, WAVE)); itHi = min(itHi, __shfl_xor(itHi, d, WAVE));
+        startLo = max(startLo, __shfl_xor(startLo, d, WAVE)); startHi = min(startHi, __shfl_xor(startHi, d, WAVE));
+    }
+    // Groups of AL iterations starting at multiples of AL: the first at steadyBegin, every block start in
+    // [startLo, startHi], every iteration in [itLo, itHi].
+    const int32_t firstStart = (max(max(itLo, startLo), 0) + AL - 1) / AL * AL;
+    const int32_t lastGroupStart = min(itHi - (AL - 1), startHi - (AL - U));
+    const uint32_t groups = __builtin_amdgcn_readfirstlane(uint32_t(lastGroupStart >= firstStart ? (lastGroupStart - firstStart) / AL + 1 : 0));
+    const uint32_t steadyBegin = __builtin_amdgcn_readfirstlane(uint32_t(firstStart));
+
+    if(groups == 0) {
+        general(0, iters);
+    } else {
+        general(0, steadyBegin);
+        {
+            // Block registers: a[x] = A[ib + l HC - 1 + x], x = 0..U+HC-1; e[x] = B[ib - bandMin - l HC - HC + x], x = 0..U+HC-2.
+            // Iteration u of the block: aw(k) = a[u + k], bw(h) = e[u + HC - 1 - h].
+            const int32_t ib = ib0 + int32_t(steadyBegin);
+            uint32_t a[U + HC], e[U + HC - 1];
+#pragma unroll
+            for(int x = 0; x < U + HC; x++) a[x] = loadA(ib + l * HC - 1 + x);
+#pragma unroll
+            for(int x = 0; x < U + HC - 1; x++) e[x] = loadB(ib - bandMin - l * HC - HC + x);
+            const uint32_t* __restrict__ pa = p0 + (int64_t(iaBlock) + int64_t(steadyBegin));
+            const uint32_t* __restrict__ pb = p1 + (int64_t(jbBlock) + int64_t(steadyBegin));
+            uint32_t lineIndex = steadyBegin / F;
+            for(uint32_t grp = 0; grp < groups; grp++) {
+#pragma unroll
+                for(int blk = 0; blk < AL / U; blk++) {
+                    SHASTA_DEVICE_CHECK(pa >= p0 && pa + U <= p0 + nx && pb >= p1 && pb + U <= p1 + ny);
+                    const KmerQuad newA = *reinterpret_cast<const KmerQuad*>(pa);
+                    const KmerQuad newB = *reinterpret_cast<const KmerQuad*>(pb);
+                    pa += U; pb += U;
+#pragma unroll
+                    for(int u = 0; u < U; u++) {
+                        uint64_t words[RW];
+                        antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
+                        const int slot = (blk * U + u) % F;
+                        putRecord(slot, words);
+                        if(slot == F - 1) { flushLine(lineIndex); ++lineIndex; }
+                    }
+#pragma unroll
+                    for(int x = 0; x < HC; x++) a[x] = a[x + U];
+#pragma unroll
+                    for(int j = 0; j < U; j++) a[HC + j] = newA.v[j];
+#pragma unroll
+                    for(int x = 0; x < HC - 1; x++) e[x] = e[x + U];
+#pragma unroll
+                    for(int j = 0; j < U; j++) e[HC - 1 + j] = newB.v[j];
+                }
+            }
+        }
+        general(steadyBegin + groups * AL, iters);
+    }
+    if(iters % F != 0) flushLine(iters / F);              // the last, partial line (the bundle's trace is a whole number of lines)
+
+    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
+    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+#pragma unroll
+    for(int c = 0; c < C; c++) {
+        const int32_t d = bandMin + l * C + c;
+        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
+        const int32_t v = exists[c] ? H[c] - BIAS : NEG_SCORE;
+        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
+    }
+#pragma unroll
+    for(int d = G / 2; d >= 1; d >>= 1) {
+        const int32_t os = __shfl_xor(bestScore, d, G);
+        const int32_t oi = __shfl_xor(bestI, d, G);
+        const int32_t oj = __shfl_xor(bestJ, d, G);
+        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+    }
+    if(hasTask && l == 0) {
+        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
+        ends[t] = e;
+    }
+}
+
+// One lane per task: walk the path from the end cell through the packed trace.  The trace is
+// consumed in chunks of CW words (128 or 256 bytes, whole cache lines): the chunk under the
+// path sits in the lane's private LDS window, the next one (the path only moves towards smaller
+// anti-diagonals) is already in flight in registers, so every line is fetched once and its
+// latency is covered by the walk through the previous chunk.
+template<int CW>
+__global__ void __launch_bounds__(256)
+dpTracebackKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
+    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
+    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
+    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if(idx >= taskCount) return;
+    const uint32_t t = sortedIds[idx];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const DpEnd e = ends[t];
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    const int C = dpDiagonals(geo.cls);
+    const uint32_t RW = uint32_t(2 * C);
+    const uint32_t itersPerChunk = uint32_t(CW) / RW;
+    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
+    const uint64_t ordBase = ordOffsets[t];
+    uint32_t pos = min(pd.nx, pd.ny);
+    uint32_t count = 0, prevX = 0, prevY = 0, last0 = 0, last1 = 0, first0 = 0, first1 = 0, maxSkip = 0, maxDrift = 0;
+    int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
+    long long sumOffset = 0;
+    int32_t i = e.bestI, j = e.bestJ;
+    const bool ok = e.score > NEG_SCORE;
+    // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
+    // the same point of the program, then walks until its path leaves the chunk.  The wave waits
+    // for memory once per epoch, for loads issued a whole epoch earlier.
+    bool active = ok && i > 0 && j > 0;
+    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) / itersPerChunk) : -1;
+    uint4 next[QUADS];
+#pragma unroll
+    for(int k = 0; k < QUADS; k++) next[k] = active ? tr[chunk * QUADS + k] : make_uint4(0, 0, 0, 0);
+    while(__any(active)) {
+        if(active) {
+#pragma unroll
+            for(int k = 0; k < QUADS; k++) window[k * 256 + threadIdx.x] = next[k];
+            if(chunk > 0) {
+#pragma unroll
+                for(int k = 0; k < QUADS; k++) next[k] = tr[(chunk - 1) * QUADS + k];
+            }
+        }
+        while(active) {
+            const int32_t b = i - j - task.bandMin;
+            const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
+            if(int64_t(it / itersPerChunk) != chunk) break;
+            const uint32_t c = uint32_t(b) % uint32_t(C), bit = e.laneBase + uint32_t(b) / uint32_t(C);
+            const uint32_t word = (it % itersPerChunk) * RW + 2 * c;           // even: one 16-byte piece
+            const uint4 w = window[(word >> 1) * 256 + threadIdx.x];
+            const uint64_t lo = uint64_t(w.x) | (uint64_t(w.y) << 32), hi = uint64_t(w.z) | (uint64_t(w.w) << 32);
+            const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
+            if(dir == 0u) {
+                // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
+                const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
+                --pos;
+                *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(x, y);
+                const int32_t offset = int32_t(x) - int32_t(y);
+                if(count == 0) { last0 = x; last1 = y; }
+                else {
+                    maxSkip = max(maxSkip, max(prevX - x, prevY - y));
+                    const int32_t prevOffset = int32_t(prevX) - int32_t(prevY);
+                    const int32_t drift = offset - prevOffset;
+                    maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
+                }
+                minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
+                sumOffset += offset;
+                first0 = x; first1 = y; prevX = x; prevY = y;
+                ++count;
+                --i; --j;
+            } else if(dir == 1u) { --i; --j; }
+            else if(dir == 2u) { --j; }
+            else { --i; }
+            active = i > 0 && j > 0;
+        }
+        --chunk;
+    }
+    DpResult r;
+    r.ordBegin = ordBase + pos;
+    r.sumOffset = sumOffset;
+    r.markerCount = count; r.first0 = first0; r.first1 = first1; r.last0 = last0; r.last1 = last1;
+    r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+    r.score = e.score; r.pad = 0;
+    // Inner acceptance, src/Align4.cpp:944-981.
+    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+    if(pass) {
+        const double f0 = double(count) / double(last0 + 1 - first0);
+        const double f1 = double(count) / double(last1 + 1 - first1);
+        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
+        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
+        const uint32_t leftTrim = min(first0, first1);
+        const uint32_t rightTrim = min(pd.nx - 1 - last0, pd.ny - 1 - last1);
+        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
+    }
+    r.passes = pass ? 1u : 0u;
+    results[t] = r;
+    // Best component = most aligned markers (:132-139); ties resolved towards the
+    // component whose first cell in (iY,iX) order comes first, and flagged later.
+    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
+}
