@@ -3,7 +3,7 @@ tiny and ragged matrices, bands hanging over every corner, small alphabets = sco
 script in a process of its own by the tests, because the forward-kernel version
 (SHASTA_MI355X_DP_FORWARD) is fixed once per process:
 
-    python tests/dp_versions_check.py <library.so> <expected version> [seed]
+    python tests/dp_versions_check.py <library.so> <expected version> [seed] [tasks in the batch] [trials per width]
 
 Test infrastructure: the oracle is the checker, the library is what is checked."""
 import os
@@ -101,12 +101,14 @@ def main():
     print("forward kernel version", version)
     if version != expected:
         sys.exit("expected forward kernel version %d, the library chose %d" % (expected, version))
+    tasks = int(sys.argv[4]) if len(sys.argv) > 4 else 140
+    trials = int(sys.argv[5]) if len(sys.argv) > 5 else 6
     orc = bindings.OracleLib()
-    cases, bad = sweep(lib, orc, seed)
+    cases, bad = sweep(lib, orc, seed, trials)
     print("cases %d bad %d" % (cases, bad))
-    batch, bad_in_batch = many(lib, orc, seed + 100)
+    batch, bad_in_batch = many(lib, orc, seed + 100, tasks)
     print("tasks in one batch %d bad %d" % (batch, bad_in_batch))
-    sys.exit(1 if bad or bad_in_batch or cases < 80 or batch < 100 else 0)
+    sys.exit(1 if bad or bad_in_batch or cases < 12 * trials or batch < tasks * 2 // 3 else 0)
 
 
 if __name__ == "__main__":

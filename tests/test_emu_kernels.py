@@ -152,7 +152,7 @@ def test_forward_dp_versions(emu_lib, oracle_lib, version):
     env.pop("SHASTA_MI355X_DP_FORWARD", None)
     if version:
         env["SHASTA_MI355X_DP_FORWARD"] = str(version)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_versions_check.py"), emu_lib.path, str(version or 2), "5"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_versions_check.py"), emu_lib.path, str(version or 2), "5", "48", "3"],
                          env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
