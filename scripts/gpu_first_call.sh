@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/gpu_first_call.sh [reads]   (ONE gpurun call, about 12 GPU-minutes at 100k reads)
+# usage: scripts/gpu_first_call.sh [reads]   (ONE gpurun call, about 15 GPU-minutes at 100k reads)
 # The first thing to run when a GPU is available again: everything that was written while the GPU was
 # closed has only run on the emulated build.  In order, each step under its own
 # timeout so that a hang cannot reach gpurun's limit:
@@ -19,6 +19,18 @@ done
 # A/B of the two forward DP kernels (DESIGN.md section 4, K10b'): method 4 with the first version forced.
 SHASTA_MI355X_DP_FORWARD=1 timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_m4_dp1.json 2> gpurun_out/bench_m4_dp1.err
 echo "bench method 4, first forward kernel rc=$?"; tail -c 300 gpurun_out/bench_m4_dp1.err
+# A/B of the two window-hash kernels (LowHash0 only): the version without shared block transforms.
+SHASTA_MI355X_HASH=1 timeout 600 python bench.py --reads $READS --steps 3 --warmup 1 --lowhash-only --no-cpu-baseline > gpurun_out/bench_lh_hash1.json 2> gpurun_out/bench_lh_hash1.err
+timeout 600 python bench.py --reads $READS --steps 3 --warmup 1 --lowhash-only --no-cpu-baseline > gpurun_out/bench_lh.json 2> gpurun_out/bench_lh.err
+python - <<PY
+import json
+for f in ("gpurun_out/bench_lh_hash1.json", "gpurun_out/bench_lh.json"):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f, "hash kernel", d["kernels"]["hashWindowsKernel<4>"])
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
 for M in 4 3; do
   timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --align-method $M --no-cpu-baseline > gpurun_out/bench_m$M.json 2> gpurun_out/bench_m$M.err
   echo "bench method $M rc=$?"; tail -c 400 gpurun_out/bench_m$M.err
