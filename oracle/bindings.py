@@ -122,6 +122,21 @@ class RefLib(_Base):
             raise RuntimeError("ref_flag_palindromic_reads failed: %s" % self.lib.ref_palindromic_last_error().decode())
         return flags, aligned, near, digests
 
+    def suppress_alignment_flags(self, fasta_path, data_directory, read_id0, read_id1, delta):
+        """Loads the FASTA with the reference's ReadLoader into Reads files under data_directory and returns
+        (Assembler::suppressAlignment of every pair as u8, read count)."""
+        r0 = np.ascontiguousarray(read_id0, np.uint32)
+        r1 = np.ascontiguousarray(read_id1, np.uint32)
+        out = np.zeros(len(r0), np.uint8)
+        count = C.c_uint64()
+        rc = self.lib.ref_suppress_alignment_flags(fasta_path.encode(), data_directory.encode(), C.c_uint64(len(r0)),
+                                                   abi.as_ptr(r0, C.c_uint32), abi.as_ptr(r1, C.c_uint32), C.c_uint64(delta),
+                                                   abi.as_ptr(out, C.c_uint8), C.byref(count))
+        if rc:
+            self.lib.ref_suppress_last_error.restype = C.c_char_p
+            raise RuntimeError("ref_suppress_alignment_flags failed: %s" % self.lib.ref_suppress_last_error().decode())
+        return out, int(count.value)
+
     def alignment_info(self, ordinals, nx, ny):
         o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
         info = abi.AlignmentInfo()

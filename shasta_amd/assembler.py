@@ -113,6 +113,13 @@ class Assembler:
             C.c_double(alignmentCandidatesPerRead), C.c_uint64(log2MinHashBucketCount), C.c_uint64(minBucketSize),
             C.c_uint64(maxBucketSize), C.c_uint64(minFrequency), C.c_uint64(threadCount), C.c_uint64(self._page)))
 
+    def suppressAlignmentCandidates(self, delta, threadCount=0):
+        """shasta.Assembler.suppressAlignmentCandidates (src/AssemblerAlign.cpp:1168-1240): host step between the seams."""
+        self._require("ReadNames.toc", "ReadNames.data", "ReadMetaData.toc", "ReadMetaData.data", "AlignmentCandidates")
+        n = C.c_uint64()
+        self._check(self._lib.shasta_mi355x_host_suppress_alignment_candidates(self._data.encode(), C.c_uint64(delta), C.c_uint64(threadCount), C.byref(n)))
+        return int(n.value)
+
     def computeCandidateTable(self):
         self._check(self._lib.shasta_mi355x_host_compute_candidate_table(self._data.encode(), C.c_uint64(self._page)))
 

@@ -9,6 +9,7 @@
 //   findMarkers                       <-> Assembler::findMarkers              src/AssemblerMarkers.cpp:11-24
 //   computeCandidateTable             <-> AlignmentCandidates::computeCandidateTable    src/AssemblerAlignmentCandidates.cpp:388-447
 //   createReadGraph                   <-> Assembler::createReadGraph          src/AssemblerReadGraph.cpp:35-157
+//   suppressAlignmentCandidates       <-> Assembler::suppressAlignmentCandidates   src/AssemblerAlign.cpp:1168-1240
 #pragma once
 
 #include "MappedVector.hpp"
@@ -96,6 +97,12 @@ void computeCandidateTable(uint64_t readCount, const AlignmentCandidates& candid
 // maxAlignmentCount alignments with the most aligned markers, set AlignmentInfo::isInReadGraph in
 // Data/AlignmentData, write Data/ReadGraphEdges and Data/ReadGraphConnectivity.  Returns the number kept.
 uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignmentCount, uint32_t maxTrim, size_t largeDataPageSize = 4096);
+
+// Assembler::suppressAlignmentCandidates (src/AssemblerAlign.cpp:1168-1240; srcMain/main.cpp:697-702), between the two
+// seams in the human Nanopore configurations: drops candidates whose reads come from the same channel / sample / run
+// with `read=` numbers closer than delta.  Data/ReadNames, Data/ReadMetaData in; Data/AlignmentCandidates rewritten;
+// SuppressedAlignmentCandidates.csv and the reference's three console lines.  Returns the number dropped.
+uint64_t suppressAlignmentCandidates(const std::string& dataDirectory, uint64_t delta, size_t threadCount);
 
 void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
     const std::string& dataDirectory, size_t largeDataPageSize = 4096);

@@ -89,6 +89,15 @@ int shasta_mi355x_host_create_read_graph(const char* dataDirectory, uint32_t max
     HOST_END
 }
 
+// Assembler::suppressAlignmentCandidates, src/AssemblerAlign.cpp:1168-1240.
+int shasta_mi355x_host_suppress_alignment_candidates(const char* dataDirectory, uint64_t delta, uint64_t threadCount, uint64_t* suppressed)
+{
+    HOST_BEGIN
+    const uint64_t n = suppressAlignmentCandidates(dataDirectory, delta, threadCount);
+    if(suppressed) *suppressed = n;
+    HOST_END
+}
+
 // Assembler::flagPalindromicReads, src/AssemblerAlign.cpp:652-698.  alignment (optional): for tests, the method-0
 // self-alignment of one read is available through shasta_mi355x_host_self_alignment_method0.
 int shasta_mi355x_host_flag_palindromic_reads(const char* dataDirectory, uint32_t maxSkip, uint32_t maxDrift, uint32_t maxMarkerFrequency,

@@ -4,6 +4,7 @@
 //   shasta_mi355x_stage lowhash0 <Data> [m hashFraction minHashIterationCount alignmentCandidatesPerRead
 //                                        log2MinHashBucketCount minBucketSize maxBucketSize minFrequency]
 //   shasta_mi355x_stage palindromic <Data> [maxSkip maxDrift maxMarkerFrequency alignedFractionThreshold nearDiagonalFractionThreshold deltaThreshold]
+//   shasta_mi355x_stage suppress <Data> [delta]
 //   shasta_mi355x_stage candidate-table <Data>
 //   shasta_mi355x_stage read-graph <Data> [maxAlignmentCount maxTrim]
 //   shasta_mi355x_stage align    <Data> [minAlignedMarkerCount minAlignedFraction maxSkip maxDrift maxTrim suppressContainments]
@@ -20,7 +21,7 @@ using namespace shasta_mi355x::host;
 int main(int argc, char** argv)
 {
     try {
-        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage markers|palindromic|lowhash0|candidate-table|align|read-graph <DataDirectory> [options...]");
+        if(argc < 3) throw std::runtime_error("usage: shasta_mi355x_stage markers|palindromic|lowhash0|suppress|candidate-table|align|read-graph <DataDirectory> [options...]");
         const std::string command = argv[1], data = argv[2];
         auto arg = [&](int k, const char* fallback) { return std::string(argc > k ? argv[k] : fallback); };
         if(command == "lowhash0") {
@@ -39,6 +40,9 @@ int main(int argc, char** argv)
             o.alignedFractionThreshold = std::stod(arg(6, "0.1")); o.nearDiagonalFractionThreshold = std::stod(arg(7, "0.1"));
             o.deltaThreshold = uint32_t(std::stoul(arg(8, "100")));
             (void)flagPalindromicReads(data, o, 0);
+        } else if(command == "suppress") {
+            // Assembler::suppressAlignmentCandidates(delta), srcMain/main.cpp:697-702 (run when delta > 0).
+            (void)suppressAlignmentCandidates(data, std::stoull(arg(3, "30")), 0);
         } else if(command == "candidate-table") {
             // Assembler::computeCandidateTable, between the two seams (srcMain/main.cpp:706).
             Markers markers;
