@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_SO = os.path.join(HERE, "_build", "libshasta_mi355x_host.so")
+# SHASTA_MI355X_HOST_LIBRARY: a developer switch for the stage scripts (tests point it at the emulated twin of the host library).
+HOST_SO = os.environ.get("SHASTA_MI355X_HOST_LIBRARY") or os.path.join(HERE, "_build", "libshasta_mi355x_host.so")
 
 
 class _HostAlignOptions(C.Structure):

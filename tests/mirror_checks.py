@@ -112,3 +112,35 @@ def whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host_librar
     a.accessAlignmentData()
     a.createReadGraph(6, 30)
     assert os.path.exists(os.path.join(d, "ReadGraphEdges"))
+
+
+def stage_scripts_in_a_run_directory(oracle_lib, tmp_path, host_library):
+    """The stage scripts of scripts/ (the reference's own stage scripts with `import shasta_amd.assembler as shasta`)
+    run one after the other as processes in a run directory, on the 20 real reads; outputs against the reference's."""
+    import subprocess
+    import sys
+    from tests import marker_checks
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rt, rd, bc, im = marker_checks.tiny_reads()
+    g = support.Golden("tiny.npz")
+    d = str(tmp_path / "Data")
+    os.makedirs(d)
+    shim = host_support.HostShim()
+    shim.write_reads(d, rt, rd, bc)
+    shim.write_kmers(d, 10, im)
+    shim.write_read_flags(d, len(bc), None)
+    env = dict(os.environ, SHASTA_MI355X_HOST_LIBRARY=host_library)
+    for script, args in (("FindMarkers.py", []), ("FlagPalindromicReads.py", ["deltaThreshold=100"]),
+                         ("FindAlignmentCandidatesLowHash0.py", []), ("ComputeAlignments.py", ["minAlignedMarkerCount=100"]),
+                         ("CreateReadGraph.py", ["maxAlignmentCount=6"])):
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", script)] + args, cwd=str(tmp_path), env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, script + ": " + out.stdout[-1500:] + out.stderr[-1500:]
+        if script == "FlagPalindromicReads.py":
+            assert "Flagged 0 reads as palindromic out of 20 total." in out.stdout
+    stored, _ = shim.open_vector(os.path.join(d, "AlignmentCandidates"), 12)
+    assert np.array_equal(stored.view("<u4").reshape(-1, 3)[:, :2], g.z["lh0_candidates"][:, :2])
+    al = oracle_lib.align4_batch(g.toc, g.data7, g.candidates(0), abi.default_align4_options(), want_ordinals=False, threads=0)
+    rows, _ = shim.open_vector(os.path.join(d, "AlignmentData"), 64)
+    assert len(rows) == len(al.alignment_data) > 50
+    assert os.path.exists(os.path.join(d, "ReadGraphEdges")) and os.path.exists(os.path.join(d, "CandidateTable.toc"))

@@ -181,3 +181,9 @@ def test_randomized_campaign(emu_lib, oracle_lib):
     from tests import campaign
     assert campaign.align4(emu_lib, oracle_lib, range(900, 910)) > 1000
     assert campaign.lowhash0(emu_lib, oracle_lib, range(950, 975)) >= 15
+
+
+def test_stage_scripts_in_a_run_directory(emu_lib, oracle_lib, tmp_path):
+    from tests import mirror_checks
+    host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
+    mirror_checks.stage_scripts_in_a_run_directory(oracle_lib, tmp_path, host)

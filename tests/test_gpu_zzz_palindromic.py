@@ -86,3 +86,9 @@ def test_randomized_campaign(gpu_lib, oracle_lib):
     emulated = os.environ.get("SHASTA_EMU") == "1"
     assert campaign.align4(gpu_lib, oracle_lib, range(1000, 1010 if emulated else 1060)) > 1000
     assert campaign.lowhash0(gpu_lib, oracle_lib, range(1100, 1125 if emulated else 1250)) >= 15
+
+
+def test_stage_scripts_in_a_run_directory(gpu_lib, oracle_lib, tmp_path):
+    # scripts/FindMarkers.py ... CreateReadGraph.py as processes in a run directory
+    from tests import mirror_checks
+    mirror_checks.stage_scripts_in_a_run_directory(oracle_lib, tmp_path, host_library_of(gpu_lib))
