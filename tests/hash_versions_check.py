@@ -2,7 +2,7 @@
 has fixed-m instantiations, a generic one, and two versions: SHASTA_MI355X_HASH=1 is the one without shared
 block transforms).  Run as a script in a process of its own by the tests (the version is fixed per process):
 
-    python tests/hash_versions_check.py <library.so>
+    python tests/hash_versions_check.py <library.so> [reads per set]
 
 Test infrastructure: the oracle is the checker, the library is what is checked."""
 import os
@@ -34,9 +34,10 @@ def sweep(lib, orc, reads=120):
 def main():
     from oracle import bindings
     from shasta_amd import lib as libmod
-    checked = sweep(libmod.Library(sys.argv[1]), bindings.OracleLib())
+    reads = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+    checked = sweep(libmod.Library(sys.argv[1]), bindings.OracleLib(), reads)
     print("candidates compared", checked)
-    sys.exit(0 if checked > 1000 else 1)
+    sys.exit(0 if checked > 8 * reads else 1)
 
 
 if __name__ == "__main__":

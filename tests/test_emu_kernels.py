@@ -166,21 +166,15 @@ def test_window_hash_kernel_versions_for_every_m(emu_lib, version):
     env.pop("SHASTA_MI355X_HASH", None)
     if version == 1:
         env["SHASTA_MI355X_HASH"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hash_versions_check.py"), emu_lib.path],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hash_versions_check.py"), emu_lib.path, "60"],
                          env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_whole_chain_on_the_tiny_reads(emu_lib, oracle_lib, tmp_path, monkeypatch):
-    from tests import mirror_checks
-    host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
-    mirror_checks.whole_chain_on_the_tiny_reads(oracle_lib, tmp_path, monkeypatch, host)
-
-
 def test_randomized_campaign(emu_lib, oracle_lib):
     from tests import campaign
-    assert campaign.align4(emu_lib, oracle_lib, range(900, 910)) > 1000
-    assert campaign.lowhash0(emu_lib, oracle_lib, range(950, 975)) >= 15
+    assert campaign.align4(emu_lib, oracle_lib, range(900, 906)) > 600
+    assert campaign.lowhash0(emu_lib, oracle_lib, range(950, 966)) >= 8
 
 
 def test_stage_scripts_in_a_run_directory(emu_lib, oracle_lib, tmp_path):
