@@ -406,12 +406,16 @@ int shasta_mi355x_banded_dp(
  * wavefront exactly as the tasks of an Align4 batch are.  Task t aligns kmerIds[begin0[t] .. +nx[t]) with
  * kmerIds[begin1[t] .. +ny[t]) inside the band [bandMin[t], bandMax[t]] (width <= 1024, meeting the matrix).
  * counts[t] aligned pairs and scores[t] per task; the pairs of all tasks concatenated in ordinals
- * (capacity in pairs).  A unit seam for parity tests, like shasta_mi355x_banded_dp. */
+ * (capacity in pairs; ordinals may be NULL).  seconds (NULL or 7 entries): HIP-event time of the forward
+ * launch of each of the six band classes (widths <= 32, 64, 128, 256, 512, 1024) and of the traceback;
+ * cells (NULL or 6 entries): DP cells (nx x band width) per class.  A unit seam for parity tests and for
+ * timing one kernel version against another (scripts/dp_microbench.py), like shasta_mi355x_banded_dp. */
 int shasta_mi355x_banded_dp_many(
     const uint32_t* kmerIds, uint64_t kmerCount, uint64_t taskCount,
     const uint64_t* begin0, const uint32_t* nx, const uint64_t* begin1, const uint32_t* ny,
     const int32_t* bandMin, const int32_t* bandMax,
-    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity);
+    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity,
+    double* seconds, uint64_t* cells);
 
 /* -------------------------------------------------------------------------
  * Palindromic-read flagging: the device half of

@@ -1108,11 +1108,13 @@ int dpForwardVersion() { return chooseDpForwardVersion(); }
 // scores[t], and the pairs themselves concatenated in ordinals.
 void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t taskCount,
     const uint64_t* begin0, const uint32_t* nx, const uint64_t* begin1, const uint32_t* ny, const int32_t* bandMin, const int32_t* bandMax,
-    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity)
+    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity, double* seconds, uint64_t* cells)
 {
     int device = 0;
     HIP_CHECK(hipGetDevice(&device));
     Context ctx(device);
+    if(seconds) for(int c = 0; c <= DP_CLASSES; c++) seconds[c] = 0.;
+    if(cells) for(int c = 0; c < DP_CLASSES; c++) cells[c] = 0;
     if(taskCount == 0) return;
     if(taskCount > (1u << 24)) throw std::runtime_error("banded_dp_many: too many tasks.");
     std::vector<PairDesc> pairs(taskCount);
@@ -1136,15 +1138,27 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
     const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
-    (void)runDpTasks(ctx, ws, b, uint32_t(taskCount), opt, nullptr, nullptr);
+    DpEvents ev;
+    DpBatchStats stats;
+    ev.create();
+    try { (void)runDpTasks(ctx, ws, b, uint32_t(taskCount), opt, &ev, &stats); } catch(...) { ev.destroy(); throw; }
     std::vector<DpResult> results(taskCount);
     HIP_CHECK(hipMemcpyAsync(results.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    // HIP-event time of the forward launch of every band class and of the traceback (for kernel A/B runs).
+    for(int c = 0; c <= DP_CLASSES; c++) {
+        if(c < DP_CLASSES && !stats.tasks[c]) continue;
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev.start[c], ev.stop[c]));
+        if(seconds) seconds[c] = ms * 1e-3;
+        if(cells && c < DP_CLASSES) cells[c] = stats.cells[c];
+    }
+    ev.destroy();
     uint64_t used = 0;
     for(uint64_t t = 0; t < taskCount; t++) {
         const DpResult& r = results[t];
-        if(used + r.markerCount > capacity) throw std::runtime_error("banded_dp_many: output capacity too small.");
-        if(r.markerCount) HIP_CHECK(hipMemcpy(ordinals + 2 * used, b.ordScratch.data() + 2 * r.ordBegin, 8ULL * r.markerCount, hipMemcpyDeviceToHost));
+        if(ordinals && used + r.markerCount > capacity) throw std::runtime_error("banded_dp_many: output capacity too small.");
+        if(ordinals && r.markerCount) HIP_CHECK(hipMemcpy(ordinals + 2 * used, b.ordScratch.data() + 2 * r.ordBegin, 8ULL * r.markerCount, hipMemcpyDeviceToHost));
         counts[t] = r.markerCount;
         scores[t] = r.score;
         used += r.markerCount;

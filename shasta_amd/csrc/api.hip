@@ -302,10 +302,10 @@ int shasta_mi355x_banded_dp(const uint32_t* k0, uint32_t nx, const uint32_t* k1,
 
 int shasta_mi355x_banded_dp_many(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t taskCount,
     const uint64_t* begin0, const uint32_t* nx, const uint64_t* begin1, const uint32_t* ny, const int32_t* bandMin, const int32_t* bandMax,
-    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity)
+    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity, double* seconds, uint64_t* cells)
 {
     API_BEGIN
-    bandedDpManyUnit(kmerIds, kmerCount, taskCount, begin0, nx, begin1, ny, bandMin, bandMax, counts, scores, ordinals, capacity);
+    bandedDpManyUnit(kmerIds, kmerCount, taskCount, begin0, nx, begin1, ny, bandMin, bandMax, counts, scores, ordinals, capacity, seconds, cells);
     return 0;
     API_END(1)
 }

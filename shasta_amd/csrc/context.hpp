@@ -73,6 +73,6 @@ void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t 
 
 void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t taskCount,
     const uint64_t* begin0, const uint32_t* nx, const uint64_t* begin1, const uint32_t* ny, const int32_t* bandMin, const int32_t* bandMax,
-    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity);
+    uint64_t* counts, int32_t* scores, uint32_t* ordinals, uint64_t capacity, double* seconds, uint64_t* cells);
 
 }  // namespace shasta_mi355x

@@ -150,21 +150,32 @@ class Library:
             C.byref(count), C.byref(score)), "shasta_mi355x_banded_dp")
         return out[:count.value].copy(), score.value
 
-    def banded_dp_many(self, kmer_ids, begin0, nx, begin1, ny, band_min, band_max):
-        """K10 on many tasks bundled as in an Align4 batch -> list of (ordinals [n, 2], score) per task."""
+    def banded_dp_many(self, kmer_ids, begin0, nx, begin1, ny, band_min, band_max, timing=False):
+        """K10 on many tasks bundled as in an Align4 batch -> list of (ordinals [n, 2], score) per task.
+        timing=True: no ordinals are copied back; returns (counts, scores, seconds[7], cells[6]) instead."""
         k = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
         b0 = np.ascontiguousarray(begin0, np.uint64); b1 = np.ascontiguousarray(begin1, np.uint64)
         n0 = np.ascontiguousarray(nx, np.uint32); n1 = np.ascontiguousarray(ny, np.uint32)
         lo = np.ascontiguousarray(band_min, np.int32); hi = np.ascontiguousarray(band_max, np.int32)
         t = len(b0)
         cap = int(np.minimum(n0, n1).astype(np.uint64).sum()) + 1
-        counts = np.zeros(t, np.uint64); scores = np.zeros(t, np.int32); out = np.zeros(2 * cap, np.uint32)
+        counts = np.zeros(t, np.uint64); scores = np.zeros(t, np.int32)
+        seconds = np.zeros(7, np.float64); cells = np.zeros(6, np.uint64)
+        if timing:
+            self._check(self.lib.shasta_mi355x_banded_dp_many(
+                abi.as_ptr(k, C.c_uint32), C.c_uint64(len(k)), C.c_uint64(t),
+                abi.as_ptr(b0, C.c_uint64), abi.as_ptr(n0, C.c_uint32), abi.as_ptr(b1, C.c_uint64), abi.as_ptr(n1, C.c_uint32),
+                abi.as_ptr(lo, C.c_int32), abi.as_ptr(hi, C.c_int32),
+                abi.as_ptr(counts, C.c_uint64), abi.as_ptr(scores, C.c_int32), None, C.c_uint64(0),
+                abi.as_ptr(seconds, C.c_double), abi.as_ptr(cells, C.c_uint64)), "shasta_mi355x_banded_dp_many")
+            return counts, scores, seconds, cells
+        out = np.zeros(2 * cap, np.uint32)
         self._check(self.lib.shasta_mi355x_banded_dp_many(
             abi.as_ptr(k, C.c_uint32), C.c_uint64(len(k)), C.c_uint64(t),
             abi.as_ptr(b0, C.c_uint64), abi.as_ptr(n0, C.c_uint32), abi.as_ptr(b1, C.c_uint64), abi.as_ptr(n1, C.c_uint32),
             abi.as_ptr(lo, C.c_int32), abi.as_ptr(hi, C.c_int32),
-            abi.as_ptr(counts, C.c_uint64), abi.as_ptr(scores, C.c_int32), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap)),
-            "shasta_mi355x_banded_dp_many")
+            abi.as_ptr(counts, C.c_uint64), abi.as_ptr(scores, C.c_int32), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
+            None, None), "shasta_mi355x_banded_dp_many")
         ends = np.cumsum(counts).astype(np.int64)
         return [(out[2 * (e - int(c)):2 * e].reshape(-1, 2), int(s)) for e, c, s in zip(ends, counts, scores)]
 
