@@ -16,6 +16,11 @@ for f in tests/test_gpu_lowhash0.py tests/test_gpu_align4.py tests/test_gpu_host
   echo "== $f"
   timeout 900 python -m pytest $f -q -m gpu --timeout 300 2>&1 | tail -4
 done
+# Kernel-level A/B of the two forward DP kernels: HIP-event times per band class on the same synthetic tasks.
+for V in 1 2; do
+  SHASTA_MI355X_DP_FORWARD=$V timeout 600 python scripts/dp_microbench.py --tasks 40000 --repeat 3 > gpurun_out/dp_microbench_v$V.jsonl 2> gpurun_out/dp_microbench_v$V.err
+  echo "dp microbench version $V rc=$?"; tail -n 1 gpurun_out/dp_microbench_v$V.jsonl
+done
 # A/B of the two forward DP kernels (DESIGN.md section 4, K10b'): method 4 with the first version forced.
 SHASTA_MI355X_DP_FORWARD=1 timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_m4_dp1.json 2> gpurun_out/bench_m4_dp1.err
 echo "bench method 4, first forward kernel rc=$?"; tail -c 300 gpurun_out/bench_m4_dp1.err
