@@ -57,3 +57,21 @@ for f in ("gpurun_out/bench_m4_dp1.json", "gpurun_out/bench_m4.json", "gpurun_ou
     except Exception as e:
         print(f, 'unreadable', e)
 PY
+
+# Last, because it rebuilds the library: the direct-grid cell counter (compile-time experiment, DESIGN.md section 8;
+# align4_cells.hpp, SHASTA_CELLS_GRID).  Parity first, then the same bench line; the default build is restored after.
+make -s -C shasta_amd/csrc clean && make -s -C shasta_amd/csrc EXTRA=-DSHASTA_CELLS_GRID=1 > gpurun_out/build_grid.log 2>&1
+if [ -f shasta_amd/_build/libshasta_mi355x.so ]; then
+  timeout 900 python -m pytest tests/test_gpu_align4.py -q -m gpu --timeout 300 2>&1 | tail -3
+  timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_m4_grid.json 2> gpurun_out/bench_m4_grid.err
+  echo "bench method 4, grid cell counter rc=$?"
+  python - <<PY
+import json
+try:
+    d = json.loads(open("gpurun_out/bench_m4_grid.json").read().strip().splitlines()[-1])
+    print("grid cell counter: value", d["value"], "ms/step", d["ms_per_step"], d["stage_seconds_per_step"])
+except Exception as e:
+    print("gpurun_out/bench_m4_grid.json unreadable", e)
+PY
+fi
+make -s -C shasta_amd/csrc clean && make -s -C shasta_amd/csrc > gpurun_out/build_default.log 2>&1

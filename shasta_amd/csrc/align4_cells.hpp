@@ -443,6 +443,17 @@ align4CellsChunkKernel(
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
 
+#if SHASTA_CELLS_GRID
+        // Experiment (off by default): when the candidate's whole cell grid fits the wavefront's
+        // cell region as one byte per cell, count in a direct grid -- one LDS atomic per hit, no probing, no loop.
+        // A lane adds only while the byte is below the threshold, so a byte never exceeds threshold - 1 + 64.
+        const uint32_t gridX = divMagic(nx + ny - 2, magicX) + 1, gridY = divMagic(nx + ny - 2, magicY) + 1;
+        const bool useGrid = nx + ny >= 2 && uint64_t(gridX) * gridY <= 4ull * SC && threshold <= 191;
+        if(useGrid) {
+            const uint32_t gridWords = (gridX * gridY + 3) / 4;
+            for(uint32_t k = lane; k < gridWords; k += WAVE) cells[k] = 0;
+        } else
+#endif
         for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
         if(lane == 0) scratch[0] = 0;
         waveLdsSync();
@@ -469,6 +480,26 @@ align4CellsChunkKernel(
                 cs[u] = hash32(key[u]) >> scShift;
                 probes[u] = 0;
             }
+#if SHASTA_CELLS_GRID
+            if(useGrid) {
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) {
+                    if(pending[u]) {
+                        const uint32_t idx = (key[u] >> 16) * gridX + (key[u] & 0xffffu);
+                        const uint32_t word = idx >> 2, shift = 8u * (idx & 3u);
+                        const uint32_t cur = (*reinterpret_cast<volatile uint32_t*>(&cells[word]) >> shift) & 0xffu;
+                        if(cur < threshold) {
+                            const uint32_t before = (atomicAdd(&cells[word], 1u << shift) >> shift) & 0xffu;
+                            if(before + 1 == threshold) {                                         // :417
+                                const uint32_t at = atomicAdd(&scratch[0], 1u);
+                                if(at < uint32_t(MAXC)) kept[at] = key[u];
+                            }
+                        }
+                    }
+                }
+                return;
+            }
+#endif
             while(__any(pending[0] | pending[1] | pending[2] | pending[3])) {
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) {

@@ -39,6 +39,10 @@ def emu_lib():
     tests/emu (test infrastructure: kernels run on CPU fibers; nothing in the product loads it)."""
     import subprocess
     from shasta_amd import lib as libmod
+    if os.environ.get("SHASTA_EMU_LIBRARY"):
+        # An emulated build made with other compile-time options (e.g. make -C tests/emu OUT=... with
+        # -DSHASTA_CELLS_GRID=1 appended to FLAGS): experiments are pre-flighted like everything else.
+        return libmod.Library(os.environ["SHASTA_EMU_LIBRARY"])
     subprocess.check_call(["make", "-s", "-C", EMU_DIR])
     return libmod.Library(EMU_SO)
 
