@@ -318,7 +318,8 @@ bool dpForwardSelfTest()
             for(uint32_t i = shift; i < n + shift; i++) { if(next() % 16u == 0) continue; all.push_back(next() % 11u == 0 ? next() % 7u : base[i]); }
             pd.ny = uint32_t(all.size() - pd.begin1);
             DpTask t; t.pair = uint32_t(pairs.size()); t.label = 0;
-            t.bandMin = -int32_t(shift) - widths[cls] / 2 + (rep ? 7 : 0); t.bandMax = t.bandMin + widths[cls] - 1;
+            // sequence 0 position i and sequence 1 position j come from base[i] and base[shift + j]: the true diagonal is i - j = shift
+            t.bandMin = int32_t(shift) - widths[cls] / 2 + (rep ? 7 : 0); t.bandMax = t.bandMin + widths[cls] - 1;
             pairs.push_back(pd); tasks.push_back(t);
         }
     }
@@ -351,14 +352,14 @@ bool dpForwardSelfTest()
             ordinals[version - 1].insert(ordinals[version - 1].end(), o.begin(), o.end());
         }
     }
-    bool aligned = false;
+    uint32_t aligned = 0;
     for(uint32_t i = 0; i < taskCount; i++) {
         const DpResult& p = results[0][i]; const DpResult& q = results[1][i];
         if(p.markerCount != q.markerCount || p.score != q.score || p.ordBegin != q.ordBegin || p.first0 != q.first0 || p.first1 != q.first1 ||
             p.last0 != q.last0 || p.last1 != q.last1 || p.sumOffset != q.sumOffset || p.maxSkip != q.maxSkip || p.maxDrift != q.maxDrift) return false;
-        aligned = aligned || p.markerCount > 100;
+        if(p.markerCount > 100) ++aligned;
     }
-    return aligned && ordinals[0] == ordinals[1];
+    return aligned >= taskCount / 2 && ordinals[0] == ordinals[1];         // most tasks really align: the kernels ran on meaningful paths
 }
 
 int chooseDpForwardVersion()
