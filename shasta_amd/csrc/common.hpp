@@ -25,6 +25,23 @@ inline void hipCheck(hipError_t e, const char* what, const char* file, int line)
 #define MI355X_ASSERT(x) do { if(!(x)) throw std::runtime_error( \
     std::string("Assertion failed: ") + #x + " at " + __FILE__ + ":" + std::to_string(__LINE__)); } while(0)
 
+// double -> uint64_t exactly as the reference binary does it.  The reference is built with gcc for
+// x86-64 (staticLibrary/CMakeLists.txt), where an out-of-range conversion is not an error but a
+// definite bit pattern: cvttsd2si of (x - 2^63) xor 2^63 for x >= 2^63, cvttsd2si of x below, and
+// cvttsd2si itself returns 0x8000000000000000 for anything outside int64 (NaN included).  The C++
+// cast is undefined there and ROCm clang answers differently (hashFraction = 1.0: gcc 0, clang
+// 2^63), so src/LowHash0.cpp:74 and :109 are restated as this explicit function, not as a cast.
+inline uint64_t referenceDoubleToUint64(double x)
+{
+    const double two63 = 9223372036854775808.0;
+    auto cvttsd2si = [two63](double y) -> uint64_t {
+        if(!(y >= -two63 && y < two63)) return 0x8000000000000000ULL;
+        return uint64_t(int64_t(y));
+    };
+    if(x >= two63) return cvttsd2si(x - two63) ^ 0x8000000000000000ULL;
+    return cvttsd2si(x);
+}
+
 // A device allocation that only grows.  HBM is 288 GB: buffers are sized once
 // from the marker count and kept for the life of the context.
 template<class T> class DeviceBuffer {

@@ -613,7 +613,7 @@ void lowhash0Begin(Context& ctx, const shasta_lowhash0_params& p, int rank, int 
     for(int r = 0; r < world; r++) MI355X_ASSERT(job.boundaries[r] <= job.boundaries[r + 1]);
 
     // Bucket count, src/LowHash0.cpp:73-98 (from the marker count of ALL reads).
-    const uint64_t estimate = uint64_t(p.hashFraction * double(M));
+    const uint64_t estimate = referenceDoubleToUint64(p.hashFraction * double(M));
     const uint32_t log2Estimate = estimate ? 64 - uint32_t(__builtin_clzl(estimate)) : 0;
     uint64_t log2BucketCount = p.log2MinHashBucketCount;
     if(log2BucketCount == 0) log2BucketCount = 5 + log2Estimate;
@@ -623,14 +623,17 @@ void lowhash0Begin(Context& ctx, const shasta_lowhash0_params& p, int rank, int 
     job.bucketCount = 1ULL << log2BucketCount;
     job.mask = uint32_t(job.bucketCount - 1);
     // :109
-    job.hashThreshold = uint64_t(double(p.hashFraction) * double(std::numeric_limits<uint64_t>::max()));
+    job.hashThreshold = referenceDoubleToUint64(double(p.hashFraction) * double(std::numeric_limits<uint64_t>::max()));
     job.readBits = bitsFor(readCount - 1);
     job.pairKeyBits = 2 * job.readBits + 1;
     job.minFrequency = uint32_t(std::min<uint64_t>(p.minFrequency, 0x10000));   // frequency is uint16
     // This rank hashes the reads of its own range.
     job.markerBegin = ctx.hostToc[2 * job.boundaries[rank]];
     job.markerEnd = ctx.hostToc[2 * job.boundaries[rank + 1]];
-    job.recCapacity = std::max<uint64_t>(1 << 16, uint64_t(2.0 * p.hashFraction * double(job.markerEnd - job.markerBegin)) + (1 << 16));
+    // First guess only (the hash stage grows it and repeats the iteration when it was too small); the fraction is
+    // clamped because any double is a legal hashFraction in the reference (>= 1 keeps nothing, < 0 nearly everything).
+    const double expectedFraction = !(p.hashFraction > 0.) ? 0. : std::min(p.hashFraction, 1.);
+    job.recCapacity = std::max<uint64_t>(1 << 16, uint64_t(2.0 * expectedFraction * double(job.markerEnd - job.markerBegin)) + (1 << 16));
 
     job.scalars.reserve(8, stream);
     job.stats.reserve(3 * readCount, stream);

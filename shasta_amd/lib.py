@@ -355,7 +355,9 @@ _cached = None
 
 
 def load():
+    """The product library.  SHASTA_MI355X_LIBRARY names another in-tree hipcc build of the SAME sources
+    (other compile-time options, for A/B timing on the GPU box); it is still the HIP library: no fallback."""
     global _cached
     if _cached is None:
-        _cached = Library()
+        _cached = Library(os.environ.get("SHASTA_MI355X_LIBRARY") or SO_PATH)
     return _cached

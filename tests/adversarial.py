@@ -53,53 +53,117 @@ def read_sets(long_reads=True):
                              noisy(big[15000:15100])]
 
 
+READ_SET_NAMES = ["degenerate lengths", "tandem repeats", "alphabet of six", "identical, contained, reversed", "long reads"]
+
+
+def select(out, keep):
+    """Per-candidate view of an alignment result: status, ordinals, AlignmentInfo row and compressed
+    bytes of the candidates with keep[i], so that two results can be compared candidate by candidate."""
+    rows = np.cumsum(out.status & 0x7f == abi.SHASTA_ALIGN_STORED) - 1      # row of a stored candidate
+    info = out.info_table()
+    items = []
+    for i in np.flatnonzero(keep):
+        st = int(out.status[i])
+        if (st & 0x7f) != abi.SHASTA_ALIGN_STORED:
+            items.append((i, st, None, None, None)); continue
+        r = int(rows[i])
+        blob = out.compressed_data[int(out.compressed_toc[r]):int(out.compressed_toc[r + 1])].tobytes()
+        ords = None
+        if out.ordinals_toc is not None:
+            ords = out.ordinals[int(out.ordinals_toc[r]):int(out.ordinals_toc[r + 1])].tobytes()
+        items.append((i, st, ords, info[r].tobytes(), blob))
+    return items
+
+
+def aligner_case(lib, oracle_lib, name, long_reads=True):
+    reads = dict(read_sets(long_reads))[name]
+    toc, kmer, data7 = build(reads)
+    cand = all_pairs(len(reads))
+    o4 = abi.default_align4_options(minAlignedMarkerCount=10)
+    x = oracle_lib.align4_batch(toc, data7, cand, o4, want_ordinals=True, threads=0)
+    y = lib.align4_batch(toc, data7, cand, o4, want_ordinals=True)
+    ties = (x.status & 0x80) != 0
+    assert np.array_equal(x.status & 0x80, y.status & 0x80), name
+    if not ties.any():
+        support.same_align(x, y)
+    else:
+        # A tie between components (reference order = libstdc++ container order) is flagged on both sides;
+        # every candidate WITHOUT the flag must still agree in everything.
+        assert select(x, ~ties) == select(y, ~ties), name
+    o3 = abi.default_align3_options(minAlignedMarkerCount=10)
+    a = oracle_lib.align3_batch(toc, data7, cand, o3, want_ordinals=True, threads=0)
+    b = lib.align3_batch(toc, data7, cand, o3, want_ordinals=True)
+    support.same_align(a, b)
+    assert np.array_equal(a.compressed_data, b.compressed_data), name
+    return int(ties.sum()), len(cand)
+
+
 def aligners(lib, oracle_lib, long_reads=True):
-    for name, reads in read_sets(long_reads):
-        toc, kmer, data7 = build(reads)
-        cand = all_pairs(len(reads))
-        o4 = abi.default_align4_options(minAlignedMarkerCount=10)
-        x = oracle_lib.align4_batch(toc, data7, cand, o4, want_ordinals=True, threads=0)
-        y = lib.align4_batch(toc, data7, cand, o4, want_ordinals=True)
-        ties = (x.status & 0x80) != 0
-        assert np.array_equal(x.status & 0x80, y.status & 0x80), name
-        assert np.array_equal(x.status[~ties], y.status[~ties]), name
-        if not ties.any():
-            support.same_align(x, y)
-        o3 = abi.default_align3_options(minAlignedMarkerCount=10)
-        a = oracle_lib.align3_batch(toc, data7, cand, o3, want_ordinals=True, threads=0)
-        b = lib.align3_batch(toc, data7, cand, o3, want_ordinals=True)
-        support.same_align(a, b)
-        assert np.array_equal(a.compressed_data, b.compressed_data), name
+    for name, _ in read_sets(long_reads):
+        aligner_case(lib, oracle_lib, name, long_reads)
+
+
+def lowhash_cases():
+    rng = np.random.default_rng(11)
+    P = abi.default_lowhash0_params
+    cases = {"m=%d" % m: (None, P(m=m, minBucketSize=2, maxBucketSize=30)) for m in (1, 2, 7, 13)}
+    cases.update({
+        # hashFraction >= 1: the reference's threshold double -> uint64 is out of range; a gcc/x86-64 build
+        # (the reference's) gets 0, i.e. keeps nothing.  src/LowHash0.cpp:109.
+        "hashFraction=1": (None, P(hashFraction=1.0, minHashIterationCount=1, minBucketSize=2, maxBucketSize=1000)),
+        "hashFraction=1.5": (None, P(hashFraction=1.5, minHashIterationCount=1, minBucketSize=2, maxBucketSize=1000)),
+        "hashFraction just below 1": (None, P(hashFraction=0.9999999999999999, minHashIterationCount=1, minBucketSize=2, maxBucketSize=1000)),
+        "hashFraction=0.5": (None, P(hashFraction=0.5, minHashIterationCount=2, minBucketSize=2, maxBucketSize=1000)),
+        "hashFraction=0": (None, P(hashFraction=0.0, minHashIterationCount=2, minBucketSize=2, maxBucketSize=30)),
+        "log2 forced to 20": (None, P(log2MinHashBucketCount=20, minBucketSize=2, maxBucketSize=30)),
+        "maxBucketSize=2, minFrequency=1": (None, P(minBucketSize=0, maxBucketSize=2, minFrequency=1)),
+        "minFrequency=9": (None, P(minBucketSize=2, maxBucketSize=30, minFrequency=9)),
+        "iterate until 3 candidates per read": (None, P(minHashIterationCount=0, alignmentCandidatesPerRead=3.0, minBucketSize=2, maxBucketSize=30)),
+        "all reads palindromic": (np.ones(120, np.uint8), P(minBucketSize=2, maxBucketSize=30)),
+        "half of the reads palindromic": ((rng.random(120) < 0.5).astype(np.uint8), P(minBucketSize=2, maxBucketSize=30)),
+    })
+    return cases
+
+
+LOWHASH_CASE_NAMES = list(lowhash_cases().keys())
+LOWHASH_READ_SET_NAMES = ["empty and short reads", "a single read", "forty copies of one read"]
+
+
+def lowhash_case(lib, oracle_lib, name):
+    toc, kmer, data7 = support.small_marker_set(n_reads=120, genome_markers=8000, seed=3)
+    flags, p = lowhash_cases()[name]
+    support.same_lowhash(lib.lowhash0(toc, data7, flags, p), oracle_lib.lowhash0(toc, data7, flags, p))
+
+
+def lowhash_rejects_small_bucket_count(lib):
+    # A forced bucket count below the minimum is an error on both sides (src/LowHash0.cpp:85-96).
+    import pytest
+    toc, kmer, data7 = support.small_marker_set(n_reads=120, genome_markers=8000, seed=3)
+    with pytest.raises(RuntimeError):
+        lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(log2MinHashBucketCount=6))
+
+
+def lowhash_read_set(lib, oracle_lib, name):
+    # Empty reads, reads shorter than m, a single read, forty copies of one read.
+    rng = np.random.default_rng(11)
+    P = abi.default_lowhash0_params
+    g = rng.integers(0, A, size=3000, dtype=np.uint32)
+    short = [g[s:s + n] for s, n in zip(rng.integers(0, 2000, size=12), [0, 1, 2, 3, 4, 5, 300, 500, 0, 700, 3, 900])]
+    reads, p = {
+        "empty and short reads": (short, P(minBucketSize=1, maxBucketSize=30, minFrequency=1)),
+        "a single read": ([g[:800]], P(minBucketSize=1, maxBucketSize=30, minFrequency=1)),
+        "forty copies of one read": ([g[:600]] * 40, P(minBucketSize=2, maxBucketSize=100, minFrequency=2)),
+    }[name]
+    t, _, d = build(reads)
+    support.same_lowhash(lib.lowhash0(t, d, None, p), oracle_lib.lowhash0(t, d, None, p))
 
 
 def lowhash0(lib, oracle_lib):
-    toc, kmer, data7 = support.small_marker_set(n_reads=120, genome_markers=8000, seed=3)
-    rng = np.random.default_rng(11)
-    P = abi.default_lowhash0_params
-    cases = [(None, P(m=m, minBucketSize=2, maxBucketSize=30)) for m in (1, 2, 7)]
-    cases += [
-        (None, P(hashFraction=1.0, minHashIterationCount=1, minBucketSize=2, maxBucketSize=1000)),
-        (None, P(log2MinHashBucketCount=20, minBucketSize=2, maxBucketSize=30)),
-        (None, P(minBucketSize=0, maxBucketSize=2, minFrequency=1)),
-        (None, P(minBucketSize=2, maxBucketSize=30, minFrequency=9)),
-        (None, P(minHashIterationCount=0, alignmentCandidatesPerRead=3.0, minBucketSize=2, maxBucketSize=30)),
-        (np.ones(120, np.uint8), P(minBucketSize=2, maxBucketSize=30)),
-        ((rng.random(120) < 0.5).astype(np.uint8), P(minBucketSize=2, maxBucketSize=30)),
-    ]
-    for flags, p in cases:
-        support.same_lowhash(lib.lowhash0(toc, data7, flags, p), oracle_lib.lowhash0(toc, data7, flags, p))
-    # A forced bucket count below the minimum is an error on both sides (src/LowHash0.cpp:85-96).
-    import pytest
-    with pytest.raises(RuntimeError):
-        lib.lowhash0(toc, data7, None, P(log2MinHashBucketCount=6))
-    # Empty reads, reads shorter than m, a single read, forty copies of one read.
-    g = rng.integers(0, A, size=3000, dtype=np.uint32)
-    short = [g[s:s + n] for s, n in zip(rng.integers(0, 2000, size=12), [0, 1, 2, 3, 4, 5, 300, 500, 0, 700, 3, 900])]
-    for reads, p in ((short, P(minBucketSize=1, maxBucketSize=30, minFrequency=1)),
-                     ([g[:800]], P(minBucketSize=1, maxBucketSize=30, minFrequency=1)),
-                     ([g[:600]] * 40, P(minBucketSize=2, maxBucketSize=100, minFrequency=2))):
-        t, _, d = build(reads)
-        support.same_lowhash(lib.lowhash0(t, d, None, p), oracle_lib.lowhash0(t, d, None, p))
+    for name in LOWHASH_CASE_NAMES:
+        lowhash_case(lib, oracle_lib, name)
+    lowhash_rejects_small_bucket_count(lib)
+    for name in LOWHASH_READ_SET_NAMES:
+        lowhash_read_set(lib, oracle_lib, name)
 
 
 def task_list_overflow(lib, oracle_lib, monkeypatch):

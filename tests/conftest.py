@@ -35,7 +35,7 @@ EMU_SO = os.path.join(EMU_DIR, "_build", "libshasta_mi355x_emu.so")
 
 @pytest.fixture(scope="session")
 def emu_lib():
-    """The kernel SOURCES of shasta_amd/csrc compiled by g++ against the wave64 emulator of
+    """The kernel SOURCES of shasta_amd/csrc compiled by clang++ (host only) against the wave64 emulator of
     tests/emu (test infrastructure: kernels run on CPU fibers; nothing in the product loads it)."""
     import subprocess
     from shasta_amd import lib as libmod

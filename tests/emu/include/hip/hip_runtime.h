@@ -31,7 +31,14 @@
 #define __launch_bounds__(...)
 #define __shared__ thread_local            // block scope: one copy per OS thread = per resident workgroup
 #define HIP_SYMBOL(x) x
+#ifdef __clang__
+// clang knows __hip_atomic_load as a builtin in every language mode; its scope argument is checked.
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+#else
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#endif
 
 struct dim3 {
     unsigned x, y, z;
@@ -223,7 +230,9 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 {
     return uint32_t(((uint64_t(hi) << 32) | uint64_t(lo)) >> (8u * (c & 3u)));
 }
+#ifndef __clang__
 template<class T> __forceinline__ T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+#endif
 
 // Workgroups run on different OS threads: global atomics are real atomics (LDS ones need not be,
 // but one implementation serves both).

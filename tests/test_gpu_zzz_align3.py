@@ -55,9 +55,27 @@ def test_find_markers_stage_on_a_data_directory(gpu_lib, tmp_path):
     mirror_checks.find_markers_on_a_data_directory(tmp_path, shasta.HOST_SO)
 
 
-def test_adversarial_inputs(gpu_lib, oracle_lib, monkeypatch):
-    from tests import adversarial
-    adversarial.aligners(gpu_lib, oracle_lib)
-    adversarial.lowhash0(gpu_lib, oracle_lib)
-    adversarial.task_list_overflow(gpu_lib, oracle_lib, monkeypatch)
+from tests import adversarial
 
+
+@pytest.mark.parametrize("name", adversarial.READ_SET_NAMES)
+def test_adversarial_read_sets_through_both_aligners(gpu_lib, oracle_lib, name):
+    adversarial.aligner_case(gpu_lib, oracle_lib, name)
+
+
+@pytest.mark.parametrize("name", adversarial.LOWHASH_CASE_NAMES)
+def test_adversarial_lowhash0_parameters(gpu_lib, oracle_lib, name):
+    adversarial.lowhash_case(gpu_lib, oracle_lib, name)
+
+
+@pytest.mark.parametrize("name", adversarial.LOWHASH_READ_SET_NAMES)
+def test_adversarial_lowhash0_read_sets(gpu_lib, oracle_lib, name):
+    adversarial.lowhash_read_set(gpu_lib, oracle_lib, name)
+
+
+def test_lowhash0_rejects_a_bucket_count_below_the_minimum(gpu_lib):
+    adversarial.lowhash_rejects_small_bucket_count(gpu_lib)
+
+
+def test_task_list_overflow(gpu_lib, oracle_lib, monkeypatch):
+    adversarial.task_list_overflow(gpu_lib, oracle_lib, monkeypatch)
