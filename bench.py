@@ -10,10 +10,13 @@ in HBM before the timed region.  Workload: BASELINE.json configs[2]
 ("Synthetic 100k reads, 1xMI355X, LowHash0 + Align4 banded marker alignment end-to-end"),
 generated at marker level (shasta_amd/synthetic.py; SURVEY F5: the path never reads bases).
 
-Prints ONE JSON line on rank 0 (see the keys below).  `value` = candidate read pairs
-aligned per second, whole job.  The CPU baseline is the reference's own code
-(oracle/_ref, compiled in place from /root/reference) when that library is present,
-otherwise the CPU restatement (oracle/), timed on this host on a 1/10-scale sample.
+Prints ONE JSON line on rank 0.  `value` = candidate read pairs aligned per second, whole job.
+`kernels` has one row per kernel of the path (HIP-event times on the stream each is launched
+on, the library's kernel table); `roofline` describes the one with the largest total time.
+`cpu_baseline` (N = 1 only): the reference's own code (oracle/_ref, compiled in place from
+/root/reference) on the SAME read set on this host's cores -- LowHash0 in full, the aligner
+on a sample of its candidates -- which doubles as the parity check at the benchmark's own
+size (`parity_at_bench_size`): the checker is never inside the timed region.
 """
 import argparse
 import json
@@ -28,6 +31,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# Vector ALU peak in wavefront instructions per second: 256 CUs x 4 SIMDs x one wave64 instruction per 2 cycles x 2.4 GHz
+# (the guide's 157.3 TFLOP/s fp32 = 2 flops x 64 lanes x this).  Dependent integer chains measured on the device reach
+# 1.35-1.55 of the 2 instructions per cycle and CU (scripts/microbench/valu_rates.hip, profiles/r02_valu_rates.jsonl).
+VALU_PEAK_WAVE_INSTRUCTIONS_PER_S = 256 * 4 * 0.5 * 2.4e9
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_100k_reads.json")
+# Kernels whose natural bound is HBM (streaming / sorting); the others are bound by VALU issue and LDS (integer DP, hash joins).
+HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "run lengths", "pair table", "compress")
 
 
 def make_workload(n_reads, seed):
@@ -56,27 +66,25 @@ def align_options():
     return abi.default_align4_options()
 
 
-def load_traffic():
-    """HBM bytes per launch per kernel from the calibrated PMC passes (scripts/gpu_pmc.sh +
-    scripts/pmc_traffic.py, committed as profiles/r01_traffic_100k_reads.json)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_100k_reads.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)
+def load_pmc(reads):
+    """Per-kernel counters of the committed rocprofv3 --pmc passes over this very command (scripts/pmc_summary.py):
+    HBM bytes per launch (FETCH_SIZE x 2 as the guide prescribes for gfx950, + WRITE_SIZE) and VALU wave-instructions
+    per launch.  Only valid for the workload they were collected on."""
+    if not os.path.exists(PMC_FILE):
+        return {}
+    with open(PMC_FILE) as f:
+        d = json.load(f)
+    return d.get("kernels", {}) if d.get("workload_reads") == reads else {}
 
 
-def traffic_of(table, kernel_name):
-    """Traffic only applies to the workload it was measured on (100 k reads, 1 GPU); otherwise null."""
-    if table is None or TRAFFIC_WORKLOAD["reads"] != table.get("workload_reads"):
-        return None
-    for k, v in table.get("kernels", {}).items():
-        if kernel_name.replace(" ", "") in k.replace(" ", "") or k.replace(" ", "").endswith(kernel_name.replace(" ", "")):
-            return v["hbm_bytes_per_launch"]
+def pmc_of(pmc, name):
+    key = name.replace(" ", "")
+    for k, v in pmc.items():
+        if k.replace(" ", "") == key:
+            return v
     return None
 
 
-TRAFFIC_WORKLOAD = {"reads": None}
 DRY_RUN_LIBRARY = os.environ.get("SHASTA_BENCH_LIBRARY")      # see main(): pre-flight without a GPU, never a result
 
 
@@ -92,59 +100,113 @@ def available_memory_gib():
     return 1 << 20
 
 
-def cpu_baseline(n_reads_sample, seed, align_method=4):
-    """Reference CPU path on a bounded sample of the same workload (1/10 scale, same coverage)."""
+def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size):
+    """The reference CPU path on the SAME read set, on this host's cores, outside the timed region; its outputs
+    are compared with the device's (parity at the benchmark's own size).  LowHash0 runs in full; the aligner
+    on every (candidates / sample_size)-th candidate (the whole list would take minutes)."""
     from oracle import bindings
     from shasta_amd import synthetic
-    # Threads actually used = "cores" of the report.  Capped at 64: every reference Align4 thread
-    # zero-fills its own 2 GiB arena (src/AssemblerAlign.cpp:353-355) before its first candidate, and a
-    # run with one thread per core of a 256-core box (512 GiB of arenas) took the GPU box down.  Also kept
-    # under a quarter of the available memory (4 GiB per thread: the arena + the thread's share of the rest).
-    cores = min(os.cpu_count() or 1, 64, max(1, available_memory_gib() // 4))
-    toc, kmer = make_workload(n_reads_sample, seed)
+    host_cores = os.cpu_count() or 1
+    # Threads actually used = "cores" of the report.  Capped at 64: every reference Align4 thread zero-fills its own
+    # 2 GiB arena (src/AssemblerAlign.cpp:353-355) before its first candidate, and a run with one thread per core of a
+    # 256-core box (512 GiB of arenas) took a GPU box down in round 1.  Also kept under a quarter of the available
+    # memory (4 GiB per thread: the arena + the thread's share of the rest).
+    cores = min(host_cores, 64, max(1, available_memory_gib() // 4))
     data7 = synthetic.pack_markers(toc, kmer)
-    p, o = lowhash_params(), (align_options() if align_method == 4 else align3_options())
+    parity = {}
     if bindings.ref_available():
         lib, kind = bindings.RefLib(), "reference"
         lh = lib.lowhash0(toc, data7, None, p, threads=cores)
         t_lh = lh.seconds
-        cand = lh.candidates
-        # The per-thread 2 GiB arena of the reference is a fixed setup cost (seconds): time two
-        # sample sizes and use the incremental rate.
-        n1, n2 = min(len(cand), 4000), min(len(cand), 24000)
-        align = lib.align4_batch if align_method == 4 else lib.align3_batch
-        t1 = align(toc, data7, cand[:n1], o, want_ordinals=False, threads=cores).seconds
-        t2 = align(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores).seconds
-        per_pair = (t2 - t1) / (n2 - n1) if n2 > n1 else 0.0
-        if per_pair <= 0.0:                                 # too few candidates for the difference to mean anything
-            per_pair = t2 / max(1, n2)
     else:
         if not bindings.oracle_available():
             import subprocess
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-        lib, kind, used = bindings.OracleLib(), "port", cores
+        lib, kind = bindings.OracleLib(), "port"
         t0 = time.time()
         lh = lib.lowhash0(toc, data7, None, p)
         t_lh = time.time() - t0
-        cand = lh.candidates
-        n2 = min(len(cand), 24000)
-        t0 = time.time()
-        (lib.align4_batch if align_method == 4 else lib.align3_batch)(toc, data7, cand[:n2], o, want_ordinals=False, threads=cores)
-        per_pair = (time.time() - t0) / max(1, n2)
+    cand = lh.candidates
+    parity["lowhash0_candidates"] = len(cand)
+    parity["lowhash0_equal"] = bool(np.array_equal(lh.candidate_tuples(), gpu_lowhash.candidate_tuples())
+                                    and np.array_equal(lh.statistics, gpu_lowhash.statistics)
+                                    and np.array_equal(lh.high_frequency, gpu_lowhash.high_frequency)
+                                    and np.array_equal(lh.histogram, gpu_lowhash.histogram))
+    # The aligner on a sample spread over the whole candidate list.  The reference's per-thread 2 GiB arena is a fixed
+    # set-up cost (seconds): two sample sizes, incremental rate.
+    stride = max(1, len(cand) // max(1, sample_size))
+    sample = np.ascontiguousarray(cand[::stride])
+    small = np.ascontiguousarray(sample[:max(1, len(sample) // 10)])
+    align = lib.align4_batch if align_method == 4 else lib.align3_batch
+    t1 = align(toc, data7, small, o, want_ordinals=True, threads=cores).seconds
+    ref = align(toc, data7, sample, o, want_ordinals=True, threads=cores)
+    t2 = ref.seconds
+    per_pair = (t2 - t1) / (len(sample) - len(small)) if len(sample) > len(small) else 0.0
+    if per_pair <= 0.0:                                 # too few candidates for the difference to mean anything
+        per_pair = t2 / max(1, len(sample))
+    dev = (ctx.align4 if align_method == 4 else ctx.align3)(sample, o, want_ordinals=True)
+    ties = (ref.status & 0x80) != 0
+    parity["aligner_sampled_candidates"] = len(sample)
+    parity["aligner_ties_in_sample"] = int(ties.sum())
+    parity["aligner_tie_flags_equal"] = bool(np.array_equal(ref.status & 0x80, dev.status & 0x80))
+    a, b = ref.per_candidate(~ties), dev.per_candidate(~ties)
+    parity["aligner_mismatches"] = int(sum(1 for x, y in zip(a, b) if x != y)) + abs(len(a) - len(b))
     pairs = len(cand)
     total = t_lh + pairs * per_pair
     return {
         "value": pairs / total if total > 0 else 0.0,
         "unit": "candidate read-pairs aligned/s",
         "cores": cores,
-        "kind": kind,
-        "sample": "%d reads (1/10-scale workload, same 45x coverage, M=%d markers): LowHash0 %.2f s on %d threads "
-                  "-> %d candidates; align method %d %.3f ms/candidate incremental over %d candidates on %d threads "
-                  "(restated DP, reference control flow)" % (
-                      n_reads_sample, int(toc[-1]), t_lh, cores, pairs, align_method, per_pair * 1e3, n2, cores),
+        "host_cores": host_cores,
+        "kind": kind if kind == "port" else "reference (LowHash0 in full; aligner: incremental per-candidate rate on a sample x all candidates; DP = the restated SeqAn call)",
+        "sample": "the bench's own read set (%d reads, M=%d markers): LowHash0 %.2f s on %d of the host's %d cores -> %d candidates; "
+                  "align method %d on every %d-th candidate (%d): %.3f ms/candidate incremental on %d threads; anonymous 4 KiB pages "
+                  "(the reference warns such runs should not be used for benchmarking, srcMain/main.cpp:369-378)" % (
+                      (len(toc) - 1) // 2, int(toc[-1]), t_lh, cores, host_cores, pairs, align_method, stride, len(sample), per_pair * 1e3, cores),
         "lowhash0_seconds": t_lh,
         "align_seconds_per_pair": per_pair,
-    }
+    }, parity
+
+
+def kernel_rows(table, steps, pmc):
+    """kernels{} of the report from the library's kernel table (accumulated over the timed steps)."""
+    rows = {}
+    for name, r in table.items():
+        if r["launches"] == 0:
+            continue
+        avg = r["seconds"] / r["launches"]
+        per_launch = r["bytes"] / r["launches"]
+        row = {"launches_per_step": r["launches"] / steps, "avg_ms": avg * 1e3, "seconds_per_step": r["seconds"] / steps,
+               "algorithmic_bytes_per_launch": int(per_launch),
+               "achieved_GBps": per_launch / avg / 1e9 if avg > 0 else 0.0}
+        row["frac_of_hbm_peak"] = row["achieved_GBps"] / HBM_PEAK_GBS
+        if name.startswith("bandedDpForwardKernel") and r["seconds"] > 0:
+            row["gcups"] = r["work"] / r["seconds"] / 1e9
+        c = pmc_of(pmc, name)
+        if c:
+            row["hbm_traffic_bytes_per_launch"] = c.get("hbm_bytes_per_launch")
+            if c.get("valu_wave_instructions_per_launch") and avg > 0:
+                row["valu_issue_frac"] = c["valu_wave_instructions_per_launch"] / avg / VALU_PEAK_WAVE_INSTRUCTIONS_PER_S
+        rows[name] = row
+    return rows
+
+
+def roofline_of(name, row, pmc):
+    hbm = any(name.startswith(h) or h in name for h in HBM_NATURED)
+    r = {"bound": "hbm" if hbm else "valu", "achieved": row["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": row["achieved_GBps"] / HBM_PEAK_GBS, "traffic": row.get("hbm_traffic_bytes_per_launch"), "kernel": name,
+         "avg_launch_ms": row["avg_ms"]}
+    if not hbm:
+        c = pmc_of(pmc, name) or {}
+        r["valu"] = {"peak_wave_instructions_per_s": VALU_PEAK_WAVE_INSTRUCTIONS_PER_S,
+                     "wave_instructions_per_launch": c.get("valu_wave_instructions_per_launch"),
+                     "frac": row.get("valu_issue_frac"),
+                     "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass over this command (profiles/) / the live HIP-event launch time"}
+        r["note"] = ("dominant kernel by total time; integer work bound by VALU issue and LDS, not by HBM: its algorithmic bytes "
+                     "(4(nx+ny) per candidate or task) are tiny against its work, so the HBM fraction is low by construction")
+        if "gcups" in row:
+            r["gcups"] = row["gcups"]
+    return r
 
 
 def main():
@@ -154,6 +216,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on")
     ap.add_argument("--lowhash-only", action="store_true", help="BASELINE configs[1]")
     ap.add_argument("--align-method", type=int, default=4, choices=[3, 4],
                     help="4 = Align4 (BASELINE's metric, the default); 3 = the reference's default method, for comparison")
@@ -163,7 +226,6 @@ def main():
     import shasta_amd
     from shasta_amd import abi
 
-    TRAFFIC_WORKLOAD["reads"] = args.reads if int(os.environ.get("WORLD_SIZE", "1")) == 1 else None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,12 +262,14 @@ def main():
             return ctx.align4(candidates, o, want_ordinals=False, borrow=True)
         return ctx.align3(candidates, o, want_ordinals=False, borrow=True)
 
+    toc = kmer = None
     if world == 1:
         # Workload: BASELINE configs[2].
         toc, kmer = make_workload(args.reads, 12345)
         marker_count = int(toc[-1])
+        t0 = time.perf_counter()
         ctx.set_kmer_ids(toc, kmer)                     # host -> HBM, outside the timed region
-        del kmer
+        upload_seconds = time.perf_counter() - t0
 
         def step():
             lh = ctx.lowhash0(p)
@@ -242,6 +306,7 @@ def main():
         read_count = world * args.reads
         backend = distributed.HipBackend(ctx, device)
         boundaries = np.arange(0, read_count + 1, args.reads, dtype=np.uint64)     # the generated shards
+        upload_seconds = None
 
         def step():
             lh = distributed.lowhash0(backend, p, read_count, boundaries)
@@ -260,96 +325,51 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    ctx.kernel_table_reset()
     t0 = time.perf_counter()
-    hash_s = hash_n = hash_b = dp_s = dp_cells = dp_bytes = 0
     lh_dev = al_dev = lh_wall = al_wall = 0.0
-    fw_s, fw_n, fw_cells, fw_bytes = [0.0] * 6, [0] * 6, [0] * 6, [0] * 6
-    tb_s = tb_n = 0
     for _ in range(args.steps):
         lh, al, pairs_total = step()
-        kt = ctx.kernel_times()
-        hash_s += kt.lowhashHashSeconds; hash_n += kt.lowhashHashLaunches; hash_b += kt.lowhashHashBytes
         if world == 1:
             lh_dev += lh.device_seconds
             lh_wall += lh.seconds
         if al is not None:
-            dp_s += kt.alignDpSeconds; dp_cells += kt.alignDpCells; dp_bytes += kt.alignBytes
-            for c in range(6):
-                fw_s[c] += kt.dpForwardSeconds[c]; fw_n[c] += kt.dpForwardLaunches[c]
-                fw_cells[c] += kt.dpForwardCells[c]; fw_bytes[c] += kt.dpForwardBytes[c]
-            tb_s += kt.dpTracebackSeconds; tb_n += kt.dpTracebackLaunches
             al_dev += al.device_seconds
             al_wall += al.seconds
     sync()
     elapsed = time.perf_counter() - t0
+    table = ctx.kernel_table()
     stored_total = 0 if al is None else len(al.alignment_data)
+    status_counts = None
+    if al is not None:
+        st = np.asarray(al.status)
+        status_counts = [int(((st & 0x7f) == abi.SHASTA_ALIGN_STORED).sum()), int(((st & 0x7f) == abi.SHASTA_ALIGN_REJECTED).sum()),
+                         int(((st & 0x7f) == abi.SHASTA_ALIGN_EMPTY).sum()), int(((st & 0x7f) == abi.SHASTA_ALIGN_SKIPPED).sum()),
+                         int(((st & 0x80) != 0).sum())]
     if dist is not None:
         comm = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([stored_total], dtype=torch.int64, device=comm)
+        c = torch.tensor([stored_total] + (status_counts or [0] * 5), dtype=torch.int64, device=comm)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         stored_total = int(c[0].item())
+        if status_counts is not None:
+            status_counts = [int(x) for x in c[1:].tolist()]
 
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = elapsed / steps * 1e3
         value = pairs_total / (elapsed / steps)
-        hash_avg = hash_s / max(1, hash_n)
-        hash_gbs = (hash_b / max(1, hash_n)) / hash_avg / 1e9 if hash_avg > 0 else 0.0
-        kernels = {
-            "hashWindowsKernel<4>": {
-                "launches_per_step": hash_n // steps, "avg_ms": hash_avg * 1e3,
-                "algorithmic_bytes_per_launch": hash_b // max(1, hash_n), "achieved_GBps": hash_gbs,
-                "frac_of_hbm_peak": hash_gbs / HBM_PEAK_GBS,      # the HBM-natured kernel of the path
-                "seconds_per_step": hash_s / steps,
-            },
-        }
-        traffic_table = load_traffic()
-        roofline = {"bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": hash_gbs / HBM_PEAK_GBS, "traffic": traffic_of(traffic_table, "hashWindowsKernel"),
-                    "kernel": "hashWindowsKernel<4> (LowHash0 K1)"}
-        dominant_s = hash_s
-        if al is not None and dp_s > 0:
-            kernels["align4_banded_dp"] = {
-                "seconds_per_step": dp_s / steps, "gcups": dp_cells / dp_s / 1e9,
-                "algorithmic_bytes_per_step": dp_bytes // steps, "achieved_GBps": dp_bytes / dp_s / 1e9,
-                "note": "forward DP kernels + traceback, both streams; integer VALU-bound wavefront DP, not HBM-bound (SURVEY 8d)",
-            }
-            # Which forward kernel ran (include/shasta_mi355x.h: shasta_mi355x_dp_forward_version) and what its
-            # compiled loop issues per cell and lane (scripts/isa_loop.py on the <32, 2> instantiation: first
-            # version 75 VALU instructions per iteration of two cells; second version 247 per eight steady iterations).
-            dp_version = lib.dp_forward_version()
-            kernel_name = "bandedDpForwardKernel" if dp_version == 1 else "bandedDpForwardKernel2"
-            lane_instructions_per_cell = 37.5 if dp_version == 1 else 15.4
-            names = [kernel_name + suffix for suffix in ("<16, 2>", "<32, 2>", "<64, 2>", "<64, 4>", "<64, 8>", "<64, 16>")]
-            for c in range(6):
-                if fw_n[c] == 0:
-                    continue
-                avg = fw_s[c] / fw_n[c]
-                per_launch = fw_bytes[c] / fw_n[c]
-                kernels[names[c]] = {"launches_per_step": fw_n[c] // steps, "avg_ms": avg * 1e3,
-                                     "algorithmic_bytes_per_launch": int(per_launch), "achieved_GBps": per_launch / avg / 1e9,
-                                     "gcups": fw_cells[c] / fw_s[c] / 1e9, "seconds_per_step": fw_s[c] / steps}
-                if fw_s[c] > dominant_s:
-                    dominant_s = fw_s[c]
-                    roofline = {"bound": "hbm", "achieved": per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": per_launch / avg / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of(traffic_table, names[c]),
-                                "kernel": names[c], "gcups": fw_cells[c] / fw_s[c] / 1e9,
-                                # What actually bounds it: VALU instructions per lane and cell in the compiled loop against
-                                # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-instructions/s
-                                # (MI355X_MICROARCH.md: 157.3 TFLOPS fp32 = 2 flops x that).
-                                "valu": {"lane_instructions_per_cell": lane_instructions_per_cell, "peak_lane_instructions_per_s": 78.6e12,
-                                         "ceiling_gcups": 78.6e12 / lane_instructions_per_cell / 1e9,
-                                         "frac": (fw_cells[c] / fw_s[c]) / (78.6e12 / lane_instructions_per_cell)},
-                                "dp_forward_version": dp_version,
-                                "note": "dominant kernel by time; integer max-plus DP bound by VALU issue: its algorithmic bytes "
-                                        "(4(nx+ny) per task) are tiny against its work (nx x bandWidth cells), so the HBM fraction "
-                                        "is low by construction; traffic is dominated by the 2-bit/cell trace it writes"}
-            if tb_n:
-                kernels["dpTracebackKernel<32>"] = {"launches_per_step": tb_n // steps, "avg_ms": tb_s / tb_n * 1e3,
-                                                    "seconds_per_step": tb_s / steps}
+        pmc = load_pmc(args.reads) if world == 1 else {}
+        kernels = kernel_rows(table, steps, pmc)
+        kernel_seconds = sum(r["seconds_per_step"] for r in kernels.values())
+        for r in kernels.values():
+            r["share_of_kernel_time"] = r["seconds_per_step"] / kernel_seconds if kernel_seconds > 0 else 0.0
+        dominant = max(kernels, key=lambda k: kernels[k]["seconds_per_step"]) if kernels else None
+        roofline = roofline_of(dominant, kernels[dominant], pmc) if dominant else None
+        # The HBM-natured kernel of the path (K1), always reported beside the dominant one.
+        hash_name = next((k for k in kernels if k.startswith("hashWindowsKernel")), None)
         out = {
             "metric": ("candidate read-pairs aligned/sec (LowHash0+Align4)" if args.align_method == 4
                        else "candidate read-pairs aligned/sec (LowHash0+align method 3)") if not args.lowhash_only
@@ -373,19 +393,32 @@ def main():
                                                           "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"),
                 "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
-                "kernel_versions": {"dp_forward": lib.dp_forward_version() if al is not None else None,
-                                    "window_hash": 1 if os.environ.get("SHASTA_MI355X_HASH") == "1" else 2},
                 "parallelism": "1 GPU" if world == 1 else
                                "%d GPUs, one job: reads sharded by id range, RCCL all-to-all of low-hash records and of pair "
                                "keys per MinHash iteration, candidates re-split evenly for Align4" % world,
             },
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
                                        "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps},
+            "kernel_seconds_per_step": kernel_seconds,
             "kernels": kernels,
             "roofline": roofline,
         }
+        if status_counts is not None:
+            out["aligner_status"] = dict(zip(("stored", "rejected_by_filters", "empty", "skipped", "component_ties_flagged"), status_counts))
+        if hash_name:
+            h = kernels[hash_name]
+            out["hbm_natured_kernel"] = {"kernel": hash_name, "achieved_GBps": h["achieved_GBps"], "frac_of_hbm_peak": h["frac_of_hbm_peak"],
+                                         "avg_ms": h["avg_ms"], "traffic": h.get("hbm_traffic_bytes_per_launch"),
+                                         "valu_issue_frac": h.get("valu_issue_frac")}
+        if upload_seconds is not None:
+            # What the one-shot seam pays in addition when it is handed host buffers: the upload of the markers
+            # (here 4 B dense kmer ids per marker; 7 B packed through set_markers).  Never part of `value`.
+            out["pcie_inclusive"] = {"upload_seconds": upload_seconds, "upload_bytes": 4 * marker_count,
+                                     "value_with_upload_every_step": pairs_total / (elapsed / steps + upload_seconds)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(max(2000, args.reads // 10) if not DRY_RUN_LIBRARY else 300, 777, args.align_method)
+            lh_check = ctx.lowhash0(p)
+            out["cpu_baseline"], out["parity_at_bench_size"] = cpu_baseline(
+                ctx, toc, kmer, p, o, args.align_method, lh_check, args.baseline_sample if not DRY_RUN_LIBRARY else 200)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out))
     ctx.close()

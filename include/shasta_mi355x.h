@@ -160,6 +160,7 @@ typedef struct shasta_align4_result {
     uint32_t* ordinals;                      /* 2 * ordinalsToc[candidateCount]     */
     uint64_t  dpCellCount;                   /* sum of nx * bandWidth over DPs run  */
     uint64_t  kmerIdBytes;                   /* sum of 4*(nx+ny) over candidates    */
+    uint64_t  alignedBytes;                  /* sum of 8*markerCount over the stored alignments (8a) */
     double    seconds;
     double    deviceSeconds;
     void*     owner;        /* NULL: the arrays are released by shasta_mi355x_align4_free; otherwise they
@@ -355,27 +356,22 @@ int shasta_mi355x_find_markers(
     const uint8_t* readFlags, int wantPacked, shasta_markers_result* result);
 void shasta_mi355x_find_markers_free(shasta_markers_result* result);
 
-/* Timing of the dominant kernels of the last *_run call on this context,
- * measured with HIP events on the context's stream. */
-typedef struct shasta_mi355x_kernel_times {
-    double   lowhashHashSeconds;     /* sum over launches of the window-hash kernel */
-    uint64_t lowhashHashLaunches;
-    uint64_t lowhashHashBytes;       /* algorithmic bytes of those launches        */
-    double   alignDpSeconds;         /* sum over launches of the banded DP kernel   */
-    uint64_t alignDpLaunches;
-    uint64_t alignDpCells;
-    uint64_t alignBytes;             /* sum 4(nx+ny)+8a                             */
-    /* The forward DP kernel per band-width class (0: <=32 diagonals ... 5: <=1024): HIP-event time
-     * of its launches, number of launches, DP cells (nx * bandWidth) and algorithmic bytes
-     * (4(nx+ny) per task) they covered. */
-    double   dpForwardSeconds[6];
-    uint64_t dpForwardLaunches[6];
-    uint64_t dpForwardCells[6];
-    uint64_t dpForwardBytes[6];
-    double   dpTracebackSeconds;
-    uint64_t dpTracebackLaunches;
-} shasta_mi355x_kernel_times;
-int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx*, shasta_mi355x_kernel_times*);
+/* Per-kernel timing table of a context, for bench reports (no counterpart in the reference): every kernel
+ * launch of the stages is bracketed by two HIP events on the stream it is issued on.  One row per kernel
+ * name, accumulated over all calls on the context since the last reset: seconds = sum of the event
+ * durations of its launches; algorithmicBytes = sum over launches of SURVEY 8(d)'s per-unit figure x the
+ * units of the launch (0 where no such figure is defined); work = a kernel-specific unit count (windows
+ * hashed, DP cells nx x bandWidth, candidates, aligned markers ...).
+ * shasta_mi355x_kernel_table writes min(*count, capacity) rows and sets *count to the number of rows. */
+typedef struct shasta_mi355x_kernel_stat {
+    char     name[64];
+    double   seconds;
+    uint64_t launches;
+    uint64_t algorithmicBytes;
+    uint64_t work;
+} shasta_mi355x_kernel_stat;
+int shasta_mi355x_kernel_table(shasta_mi355x_ctx*, shasta_mi355x_kernel_stat* rows, uint64_t capacity, uint64_t* count);
+int shasta_mi355x_kernel_table_reset(shasta_mi355x_ctx*);
 
 /* ------------------------------------------------------------------------- */
 /* Unit seams used by the parity tests                                        */
@@ -431,12 +427,6 @@ int shasta_mi355x_banded_dp_many(
  * deltaThreshold must be in [1, 4096].
  * ------------------------------------------------------------------------- */
 int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx*, uint64_t deltaThreshold, uint32_t* bound);
-
-/* Which forward kernel of the banded DP (K10b) this process uses: 2 (the block-unrolled kernel) unless
- * SHASTA_MI355X_DP_FORWARD=1 forces the first version, or unless the two versions disagreed in the
- * start-up comparison on this device (then 1, with a message on stderr).  Runs that comparison if it
- * has not run yet; negative on error.  For tests and bench reports -- the reference has no counterpart. */
-int shasta_mi355x_dp_forward_version(void);
 
 #ifdef __cplusplus
 }

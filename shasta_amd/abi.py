@@ -113,6 +113,7 @@ class Align4Result(C.Structure):
         ("ordinals", C.POINTER(C.c_uint32)),
         ("dpCellCount", C.c_uint64),
         ("kmerIdBytes", C.c_uint64),
+        ("alignedBytes", C.c_uint64),
         ("seconds", C.c_double),
         ("deviceSeconds", C.c_double),
         ("owner", C.c_void_p),
@@ -129,21 +130,13 @@ class MarkersResult(C.Structure):
     ]
 
 
-class KernelTimes(C.Structure):
+class KernelStat(C.Structure):
     _fields_ = [
-        ("lowhashHashSeconds", C.c_double),
-        ("lowhashHashLaunches", C.c_uint64),
-        ("lowhashHashBytes", C.c_uint64),
-        ("alignDpSeconds", C.c_double),
-        ("alignDpLaunches", C.c_uint64),
-        ("alignDpCells", C.c_uint64),
-        ("alignBytes", C.c_uint64),
-        ("dpForwardSeconds", C.c_double * 6),
-        ("dpForwardLaunches", C.c_uint64 * 6),
-        ("dpForwardCells", C.c_uint64 * 6),
-        ("dpForwardBytes", C.c_uint64 * 6),
-        ("dpTracebackSeconds", C.c_double),
-        ("dpTracebackLaunches", C.c_uint64),
+        ("name", C.c_char * 64),
+        ("seconds", C.c_double),
+        ("launches", C.c_uint64),
+        ("algorithmicBytes", C.c_uint64),
+        ("work", C.c_uint64),
     ]
 
 
@@ -283,6 +276,7 @@ class Align4Output:
             self.ordinals = None
         self.dp_cell_count = int(res.dpCellCount)
         self.kmer_id_bytes = int(res.kmerIdBytes)
+        self.aligned_bytes = int(res.alignedBytes)
         self.seconds = float(res.seconds)
         self.device_seconds = float(res.deviceSeconds)
 
@@ -293,6 +287,25 @@ class Align4Output:
 
     def ordinals_of(self, i):
         return self.ordinals[int(self.ordinals_toc[i]):int(self.ordinals_toc[i + 1])]
+
+    def per_candidate(self, keep=None):
+        """[(candidate index, status, ordinals bytes or None, AlignmentInfo row bytes or None, compressed blob or None)]
+        for the candidates with keep[i] (all when keep is None): two results can be compared candidate by candidate."""
+        stored = (self.status & 0x7f) == SHASTA_ALIGN_STORED
+        rows = np.cumsum(stored) - 1
+        info = self.info_table()
+        which = np.arange(len(self.status)) if keep is None else np.flatnonzero(keep)
+        items = []
+        for i in which:
+            i = int(i)
+            ords = None if self.ordinals_toc is None else self.ordinals_of(i).tobytes()
+            if not stored[i]:
+                items.append((i, int(self.status[i]), ords, None, None))
+                continue
+            r = int(rows[i])
+            blob = self.compressed_data[int(self.compressed_toc[r]):int(self.compressed_toc[r + 1])].tobytes()
+            items.append((i, int(self.status[i]), ords, info[r].tobytes(), blob))
+        return items
 
 
 def make_pairs(readId0, readId1, isSameStrand):

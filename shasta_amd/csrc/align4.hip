@@ -138,12 +138,13 @@ constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {11, 12, 12};
 constexpr int CELLS_Q[CELLS_CLASSES] = {2, 4, 4};
 constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {4, 6, 4};   // waves of a chunk that share the tabled read
 constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 16};
-constexpr uint32_t CELLS_SHARE_MIN = 3;                        // smaller chunks run as one wave
+constexpr uint32_t CELLS_SHARE_MIN = 3;
+constexpr int ALIGN_DEFAULT_WORKERS = 2;                       // host workers (streams) that pipeline the batches of one call                        // smaller chunks run as one wave
 
 // kind 0: one-wave workgroups; kind 1: CELLS_SHARED_WAVES waves share the table.
 template<int Q>
 void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
-    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity)
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
     const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, waves) * sizeof(uint32_t);
     static bool attributeSet = false;
@@ -153,34 +154,33 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
         attributeSet = true;
     }
     MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
-    hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ws.stream,
-        (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
-        opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data());
+    // Booked under the template instance that runs (class 0: Q = 2; classes 1 and 2: Q = 4), the name a profiler shows.
+    // Algorithmic bytes: 4 (nx + ny) per candidate, summed by the caller; work = candidates.
+    SHASTA_TIMED(ctx, (Q == 2 ? "align4CellsChunkKernel<2>" : "align4CellsChunkKernel<4>"), ws.stream, kmerIdBytes, candidateCount,
+        hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ws.stream,
+            (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
+            opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data()));
     HIP_CHECK(hipGetLastError());
 }
 
 void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
-    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity)
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
     if(count == 0) return;
-    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
-    else launchCellsChunksQ<4>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity);
+    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+    else launchCellsChunksQ<4>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
 }
 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
 struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; };
 
-// Which forward kernel runs: bandedDpForwardKernel2 unless SHASTA_MI355X_DP_FORWARD=1, or unless it
-// disagrees with the first version on this device (dpForwardSelfTest, once per process, loud).
-int chooseDpForwardVersion();
-
 template<int G, int C>
-void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls, int version)
+void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
 {
     const uint32_t taskCount = layout.taskStart[cls + 1] - layout.taskStart[cls];
     const uint32_t bundleCount = layout.bundleStart[cls + 1] - layout.bundleStart[cls];
     if(taskCount == 0) return;
-    hipLaunchKernelGGL((version == 1 ? bandedDpForwardKernel<G, C> : bandedDpForwardKernel2<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
         in.kmerIds, in.pairs, in.tasks,
         sortedIds + layout.taskStart[cls], taskCount,
         (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
@@ -191,27 +191,29 @@ void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, con
 // K10 for the taskCount tasks in b.tasks (pairs in b.pairs): fills b.results, b.ordScratch and
 // b.pairBest.  Returns the number of DP cells (sum of nx * bandWidth); forwardSeconds gets the
 // HIP-event time of the forward launches when evA/evB are given.
-// Timing events of one batch's DP: start/stop around the forward launch of every class and around the traceback.
+// Events that fork the wide-band classes of one batch's DP to the side stream and join them again.
 struct DpEvents {
-    hipEvent_t start[DP_CLASSES + 1], stop[DP_CLASSES + 1], fork, join;
-    void create() { for(int k = 0; k <= DP_CLASSES; k++) { HIP_CHECK(hipEventCreate(&start[k])); HIP_CHECK(hipEventCreate(&stop[k])); } HIP_CHECK(hipEventCreate(&fork)); HIP_CHECK(hipEventCreate(&join)); }
-    void destroy() { for(int k = 0; k <= DP_CLASSES; k++) { (void)hipEventDestroy(start[k]); (void)hipEventDestroy(stop[k]); } (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
+    hipEvent_t fork, join;
+    void create() { HIP_CHECK(hipEventCreate(&fork)); HIP_CHECK(hipEventCreate(&join)); }
+    void destroy() { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
 };
 struct DpBatchStats { uint64_t cells[DP_CLASSES] = {0}, bytes[DP_CLASSES] = {0}; uint32_t tasks[DP_CLASSES] = {0}; };
+const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<32, 2>", "bandedDpForwardKernel<64, 2>",
+    "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"};
 
 // Forward half of K10 for taskCount tasks: sort by (band class, iterations), bundle, lay out the
 // trace, run the forward kernel of every class.  Leaves b.trace / b.ends for a traceback kernel.
 struct DpForwardState {
     const uint32_t* sortedIds;
+    uint32_t taskStart[DP_CLASSES + 1];   // class c = tasks [taskStart[c], taskStart[c + 1]) of the sorted list
     uint32_t classCounts[DP_CLASSES];
     unsigned long long sums[16];          // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
 };
 
-DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev)
+DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers)
 {
     hipStream_t stream = ws.stream;
     DpForwardState f;
-    const int version = chooseDpForwardVersion();
     b.dpKeysA.reserve(taskCount, stream); b.dpKeysB.reserve(taskCount, stream);
     b.dpIdsA.reserve(taskCount, stream); b.dpIdsB.reserve(taskCount, stream);
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
@@ -220,6 +222,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     b.counters.reserve(16, stream); b.dpCells.reserve(16, stream);
     HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
     HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, 16 * sizeof(unsigned long long), stream));
+    KernelTimers::Span prepareSpan;
+    if(timers) prepareSpan = timers->begin("DP task sizes, sort by (class, length), bundles", stream);
     hipLaunchKernelGGL(dpSizeKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
         in.tasks, in.pairs, taskCount,
         b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
@@ -243,12 +247,14 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         layout.bundleStart[c + 1] = layout.bundleStart[c] + (classCounts[c] + T - 1) / T;
     }
     MI355X_ASSERT(layout.taskStart[DP_CLASSES] == taskCount);
+    for(int c = 0; c <= DP_CLASSES; c++) f.taskStart[c] = layout.taskStart[c];
     const uint32_t bundleTotal = layout.bundleStart[DP_CLASSES];
     b.bundleWords.reserve(uint64_t(bundleTotal) + 1, stream);
     b.scanTemp64.reserve(scanTempElements(uint64_t(bundleTotal) + 1), stream);
     hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(bundleTotal) + 1, 256)), dim3(256), 0, stream,
         sortedKeys, layout, b.bundleWords.data());
     exclusiveScan<uint64_t>(b.bundleWords.data(), b.bundleWords.data(), uint64_t(bundleTotal) + 1, b.scanTemp64.data(), stream);
+    if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
     // sums[1] bounds the trace (a bundle needs no more than the sum over its tasks): no read-back.
     b.trace.reserve(sums[1] + 64, stream);
     if(reserveOrdinals) b.ordScratch.reserve(2 * ordTotal + 2, stream);
@@ -258,18 +264,20 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     const bool fork = ws.wide != nullptr && ev != nullptr && (classCounts[3] || classCounts[4] || classCounts[5]);
     hipStream_t wideStream = fork ? ws.wide : stream;
     if(fork) { HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); }
+    // Booked per class: algorithmic bytes 4 (nx + ny) per task, work = DP cells nx x bandWidth (dpSizeKernel's sums).
     auto timed = [&](int cls, hipStream_t st, auto launch) {
-        if(ev) HIP_CHECK(hipEventRecord(ev->start[cls], st));
+        if(!timers || classCounts[cls] == 0) { launch(st); return; }
+        const KernelTimers::Span span = timers->begin(DP_FORWARD_NAMES[cls], st);
         launch(st);
-        if(ev) HIP_CHECK(hipEventRecord(ev->stop[cls], st));
+        (void)timers->end(span, sums[8 + cls], sums[2 + cls]);
     };
-    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 5, version); });
-    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4, version); });
-    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3, version); });
+    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 5); });
+    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4); });
+    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3); });
     if(fork) HIP_CHECK(hipEventRecord(ev->join, ws.wide));
-    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(in, st, b, sortedIds, layout, 1, version); });
-    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(in, st, b, sortedIds, layout, 2, version); });
-    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0, version); });
+    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(in, st, b, sortedIds, layout, 1); });
+    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(in, st, b, sortedIds, layout, 2); });
+    timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     return f;
 }
@@ -279,110 +287,28 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
 {
     hipStream_t stream = ws.stream;
     const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data()};
-    const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev);
-    if(ev) HIP_CHECK(hipEventRecord(ev->start[DP_CLASSES], stream));
-    // 256-byte trace chunks: 8 iterations of the narrow classes, one iteration of the widest class.
-    hipLaunchKernelGGL(dpTracebackKernel<32>, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
-        in.pairs, in.tasks, f.sortedIds, taskCount,
-        (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
-        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data());
-    HIP_CHECK(hipGetLastError());
-    if(ev) HIP_CHECK(hipEventRecord(ev->stop[DP_CLASSES], stream));
+    const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
+    // The three traceback kernels over their class ranges of the sorted list (C = 2: classes 0-2; C = 4: class 3; wider: 4-5).
+    // Booked: the trace a kernel has to read = 2 bits per cell of the padded bands of its tasks (iterations x 2 C words, bounded
+    // by sums[1] for the whole batch: split by DP cells), work = tasks.
+    auto traceback = [&](const char* name, int firstClass, int lastClass, auto kernel) {
+        const uint32_t begin = f.taskStart[firstClass], end = f.taskStart[lastClass + 1];
+        if(end == begin) return;
+        unsigned long long cells = 0;
+        for(int c = firstClass; c <= lastClass; c++) cells += f.sums[2 + c];
+        const uint64_t traceBytes = f.sums[0] ? uint64_t(double(8 * f.sums[1]) * double(cells) / double(f.sums[0])) : 0;
+        SHASTA_TIMED(ctx, name, stream, traceBytes, end - begin,
+            hipLaunchKernelGGL(kernel, dim3(divUp(end - begin, 256)), dim3(256), 0, stream,
+                in.pairs, in.tasks, f.sortedIds, begin, end,
+                (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
+                (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
+        HIP_CHECK(hipGetLastError());
+    };
+    traceback("dpTracebackWideKernel<32>", 4, 5, dpTracebackWideKernel<32>);       // the longest walks first
+    traceback("dpTracebackKernel<4>", 3, 3, dpTracebackKernel<4>);
+    traceback("dpTracebackKernel<2>", 0, 2, dpTracebackKernel<2>);
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[8 + c]; stats->tasks[c] = f.classCounts[c]; }
     return f.sums[0];
-}
-
-// The two forward kernels on a batch of synthetic tasks (every band class, sequences over a small
-// alphabet so that score ties are everywhere): true when every DpResult and every ordinal agrees.
-thread_local int dpForwardOverride = 0;
-bool dpForwardSelfTest()
-{
-    int device = 0;
-    HIP_CHECK(hipGetDevice(&device));
-    Context ctx(device);
-    const int widths[DP_CLASSES] = {24, 50, 100, 200, 400, 800};
-    std::vector<uint32_t> all;
-    std::vector<PairDesc> pairs;
-    std::vector<DpTask> tasks;
-    uint64_t x = 0x9e3779b97f4a7c15ULL;
-    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return uint32_t(x >> 20); };
-    for(int cls = 0; cls < DP_CLASSES; cls++) {
-        for(int rep = 0; rep < 2; rep++) {
-            // Two noisy copies of one sequence, the second one shifted: an overlap alignment near diagonal `shift`.
-            const uint32_t n = uint32_t(widths[cls]) + 260u + next() % 200u, shift = next() % 150u;
-            std::vector<uint32_t> base(n + shift);
-            for(auto& v : base) v = next() % 7u;
-            PairDesc pd; pd.begin0 = all.size();
-            for(uint32_t i = 0; i < n; i++) { if(next() % 16u == 0) continue; all.push_back(next() % 11u == 0 ? next() % 7u : base[i]); }
-            pd.nx = uint32_t(all.size() - pd.begin0); pd.begin1 = all.size();
-            for(uint32_t i = shift; i < n + shift; i++) { if(next() % 16u == 0) continue; all.push_back(next() % 11u == 0 ? next() % 7u : base[i]); }
-            pd.ny = uint32_t(all.size() - pd.begin1);
-            DpTask t; t.pair = uint32_t(pairs.size()); t.label = 0;
-            // sequence 0 position i and sequence 1 position j come from base[i] and base[shift + j]: the true diagonal is i - j = shift
-            t.bandMin = int32_t(shift) - widths[cls] / 2 + (rep ? 7 : 0); t.bandMax = t.bandMin + widths[cls] - 1;
-            pairs.push_back(pd); tasks.push_back(t);
-        }
-    }
-    const uint32_t taskCount = uint32_t(tasks.size());
-    std::vector<uint64_t> toc = {0, all.size() / 2, all.size()};
-    ctx.setMarkers(1, toc.data(), nullptr, all.data(), nullptr);
-    hipStream_t stream = ctx.stream;
-    DeviceOptions opt;
-    std::memset(&opt, 0, sizeof(opt));
-    opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
-    const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
-    std::vector<DpResult> results[2];
-    std::vector<uint32_t> ordinals[2];
-    for(int version = 1; version <= 2; version++) {
-        BatchScratch b;
-        b.pairs.reserve(pairs.size(), stream); b.tasks.reserve(taskCount, stream); b.pairBest.reserve(pairs.size(), stream);
-        HIP_CHECK(hipMemcpyAsync(b.pairs.data(), pairs.data(), pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(b.tasks.data(), tasks.data(), taskCount * sizeof(DpTask), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8 * pairs.size(), stream));
-        dpForwardOverride = version;
-        try { (void)runDpTasks(ctx, ws, b, taskCount, opt, nullptr, nullptr); } catch(...) { dpForwardOverride = 0; throw; }
-        dpForwardOverride = 0;
-        std::vector<DpResult>& r = results[version - 1];
-        r.resize(taskCount);
-        HIP_CHECK(hipMemcpyAsync(r.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        for(const DpResult& d : r) {
-            std::vector<uint32_t> o(2 * size_t(d.markerCount));
-            if(d.markerCount) HIP_CHECK(hipMemcpy(o.data(), b.ordScratch.data() + 2 * d.ordBegin, 8ULL * d.markerCount, hipMemcpyDeviceToHost));
-            ordinals[version - 1].insert(ordinals[version - 1].end(), o.begin(), o.end());
-        }
-    }
-    uint32_t aligned = 0;
-    for(uint32_t i = 0; i < taskCount; i++) {
-        const DpResult& p = results[0][i]; const DpResult& q = results[1][i];
-        if(p.markerCount != q.markerCount || p.score != q.score || p.ordBegin != q.ordBegin || p.first0 != q.first0 || p.first1 != q.first1 ||
-            p.last0 != q.last0 || p.last1 != q.last1 || p.sumOffset != q.sumOffset || p.maxSkip != q.maxSkip || p.maxDrift != q.maxDrift) return false;
-        if(p.markerCount > 100) ++aligned;
-    }
-    return aligned >= taskCount / 2 && ordinals[0] == ordinals[1];         // most tasks really align: the kernels ran on meaningful paths
-}
-
-int chooseDpForwardVersion()
-{
-    if(dpForwardOverride) return dpForwardOverride;
-    static std::atomic<int> choice{0};
-    static std::mutex mutex;
-    int v = choice.load();
-    if(v) return v;
-    std::lock_guard<std::mutex> lock(mutex);
-    v = choice.load();
-    if(v) return v;
-    if(const char* e = std::getenv("SHASTA_MI355X_DP_FORWARD")) {
-        v = std::atoi(e) == 1 ? 1 : 2;
-    } else if(dpForwardSelfTest()) {
-        v = 2;
-    } else {
-        std::fprintf(stderr, "shasta_mi355x: the two forward DP kernels disagree on this device; using the first version "
-            "(set SHASTA_MI355X_DP_FORWARD=2 to force the second).\n");
-        v = 1;
-    }
-    choice.store(v);
-    return v;
 }
 
 struct BatchOutput {
@@ -390,8 +316,7 @@ struct BatchOutput {
     std::vector<uint64_t> tocEnds, ordToc;
     std::vector<uint8_t> bytes;
     std::vector<uint32_t> ordinals;
-    uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
-    double dpSeconds = 0, forwardSeconds[DP_CLASSES] = {0}, tracebackSeconds = 0;
+    uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0;
     DpBatchStats dpStats;
     bool hadTasks = false;
 };
@@ -478,17 +403,16 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     if(outputs.size() < batchCount) outputs.resize(batchCount);
     for(uint64_t k = 0; k < batchCount; k++) {
         BatchOutput& o = outputs[k];
-        o.dpCells = o.kmerIdBytes = o.alignedBytes = o.dpLaunches = 0; o.dpSeconds = o.tracebackSeconds = 0; o.hadTasks = false;
-        for(int c = 0; c < DP_CLASSES; c++) o.forwardSeconds[c] = 0;
+        o.dpCells = o.kmerIdBytes = o.alignedBytes = 0; o.hadTasks = false;
         o.dpStats = DpBatchStats();
         o.ordToc.clear(); o.ordinals.clear();
     }
     std::vector<uint8_t>& outStatus = store.status;
     outStatus.resize(std::max<uint64_t>(1, candidateCount));
 
-    // Two host workers, each with its own stream and grow-only scratch kept in the context, take
-    // the batches alternately: one worker's host-side preparation and result copies overlap the
-    // other's kernels.
+    // Several host workers, each with its own stream and grow-only scratch kept in the context, take
+    // the batches in turn: one worker's host-side preparation, result copies and its launches that
+    // cannot fill the device (a few long reads per batch) overlap the other workers' kernels.
     struct Worker {
         hipStream_t stream = nullptr;
         RadixSortWorkspace* sortWs = nullptr;
@@ -499,13 +423,20 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         std::vector<uint64_t> hostToc64;
         std::string error;
     };
-    const int workerCount = batchCount > 1 ? 2 : 1;
-    Worker workers[2];
-    if(!ctx.stream2) HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream2, hipStreamNonBlocking));
-    for(int k = 0; k < 2; k++) {
+    // SHASTA_MI355X_ALIGN_WORKERS overrides the number of workers (for timing experiments; 1 .. ALIGN_MAX_WORKERS).
+    static const int configuredWorkers = [] {
+        const char* e = std::getenv("SHASTA_MI355X_ALIGN_WORKERS");
+        const int n = e ? std::atoi(e) : ALIGN_DEFAULT_WORKERS;
+        return std::min(std::max(n, 1), int(Context::ALIGN_MAX_WORKERS));
+    }();
+    const int workerCount = int(std::min<uint64_t>(uint64_t(configuredWorkers), std::max<uint64_t>(1, batchCount)));
+    std::vector<Worker> workers;
+    workers.resize(size_t(workerCount));
+    for(int k = 0; k < workerCount; k++) {
         if(!ctx.alignScratch[k]) ctx.alignScratch[k] = std::make_shared<BatchScratch>();
-        workers[k].stream = k == 0 ? ctx.stream : ctx.stream2;
-        workers[k].sortWs = k == 0 ? &ctx.sortWs : &ctx.sortWs2;
+        if(k > 0 && !ctx.workerStream[k]) HIP_CHECK(hipStreamCreateWithFlags(&ctx.workerStream[k], hipStreamNonBlocking));
+        workers[k].stream = k == 0 ? ctx.stream : ctx.workerStream[k];
+        workers[k].sortWs = k == 0 ? &ctx.sortWs : &ctx.workerSortWs[k];
         workers[k].scratch = static_cast<BatchScratch*>(ctx.alignScratch[k].get());
         if(!ctx.wideStream[k]) HIP_CHECK(hipStreamCreateWithFlags(&ctx.wideStream[k], hipStreamNonBlocking));
         workers[k].wide = ctx.wideStream[k];
@@ -595,7 +526,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             if(taskCount1) {
                 HIP_CHECK(hipMemcpyAsync(b.tasks1.data(), tasks1.data(), taskCount1 * sizeof(DpTask), hipMemcpyHostToDevice, stream));
                 const DpInput in{ds->kmerIds.data(), b.dsPairs.data(), b.tasks1.data()};
-                const DpForwardState f = runDpForward(ws, b, in, taskCount1, false, nullptr);
+                const DpForwardState f = runDpForward(ws, b, in, taskCount1, false, nullptr, nullptr);
                 out.dpCells += f.sums[0];
                 hipLaunchKernelGGL(align3BandKernel<false>, dim3(divUp(taskCount1, 256)), dim3(256), 0, stream,
                     in.pairs, (const PairDesc*)b.pairs.data(), in.tasks, f.sortedIds, taskCount1,
@@ -753,8 +684,19 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     b.chunks.reserve(single.size() + shared.size(), stream);
                     if(!single.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data(), single.data(), single.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
                     if(!shared.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data() + single.size(), shared.data(), shared.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
-                    launchCellsChunks(ctx, ws, b, c, CELLS_SHARED_WAVES[c], b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity);
-                    launchCellsChunks(ctx, ws, b, c, 1, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity);
+                    auto bytesOf = [&](const std::vector<CellsChunk>& list, uint64_t& candidatesIn) {
+                        uint64_t bytes = 0;
+                        candidatesIn = 0;
+                        for(const CellsChunk& ch : list) {
+                            candidatesIn += ch.count;
+                            for(uint32_t q = 0; q < ch.count; q++) { const PairDesc& pd = hostPairs[members[ch.firstMember + q]]; bytes += 4ULL * (uint64_t(pd.nx) + pd.ny); }
+                        }
+                        return bytes;
+                    };
+                    uint64_t sharedCandidates = 0, singleCandidates = 0;
+                    const uint64_t sharedBytes = bytesOf(shared, sharedCandidates), singleBytes = bytesOf(single, singleCandidates);
+                    launchCellsChunks(ctx, ws, b, c, CELLS_SHARED_WAVES[c], b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity, sharedBytes, sharedCandidates);
+                    launchCellsChunks(ctx, ws, b, c, 1, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity, singleBytes, singleCandidates);
                     HIP_CHECK(hipStreamSynchronize(stream));      // the lists are reused below
                     single.clear(); shared.clear();
                 }
@@ -814,10 +756,13 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     HIP_CHECK(hipMemcpyAsync(b.pairList.data(), bigList.data() + begin, count * 4ULL, hipMemcpyHostToDevice, stream));
                     HIP_CHECK(hipMemcpyAsync(b.bigOffsets.data(), offsets.data(), count * 8ULL, hipMemcpyHostToDevice, stream));
                     HIP_CHECK(hipMemcpyAsync(b.bigLog2.data(), bigLog2.data() + begin, count, hipMemcpyHostToDevice, stream));
-                    hipLaunchKernelGGL(align4CellsKernel<true>, dim3(count), dim3(CELLS_THREADS), 0, stream,
-                        (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), count, opt,
-                        b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),
-                        b.bigScratch.data(), (const uint64_t*)b.bigOffsets.data(), (const uint8_t*)b.bigLog2.data());
+                    uint64_t bigBytes = 0;
+                    for(size_t q = begin; q < end; q++) bigBytes += 4ULL * (uint64_t(hostPairs[bigList[q]].nx) + hostPairs[bigList[q]].ny);
+                    SHASTA_TIMED(ctx, "align4CellsKernel<true>", stream, bigBytes, count,
+                        hipLaunchKernelGGL(align4CellsKernel<true>, dim3(count), dim3(CELLS_THREADS), 0, stream,
+                            (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), count, opt,
+                            b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),
+                            b.bigScratch.data(), (const uint64_t*)b.bigOffsets.data(), (const uint8_t*)b.bigLog2.data()));
                     HIP_CHECK(hipGetLastError());
                     HIP_CHECK(hipStreamSynchronize(stream));
                     begin = end;
@@ -850,9 +795,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(taskCount) {
             out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats);
             out.hadTasks = true;
-            hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
-                (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
-                (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data());
+            SHASTA_TIMED(ctx, "winnerKernel", stream, 0, taskCount,
+                hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+                    (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
+                    (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data()));
             HIP_CHECK(hipGetLastError());
         } else {
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
@@ -860,6 +806,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
 
         // K11.
         const unsigned gp = divUp(uint64_t(n) + 1, 256);
+        const KernelTimers::Span finalizeSpan = ctx.timers.begin("finalizeKernel + scans", stream);
         hipLaunchKernelGGL(finalizeKernel, dim3(gp), dim3(256), 0, stream,
             (const PairDesc*)b.pairs.data(), (const shasta_oriented_read_pair*)b.candidates.data(), n,
             (const DpResult*)b.results.data(), (const unsigned long long*)b.pairBest.data(),
@@ -868,21 +815,26 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         exclusiveScan<uint32_t>(b.storedFlags.data(), b.storedIndex.data(), uint64_t(n) + 1, b.scanTemp32.data(), stream);
         b.scanTemp64.reserve(scanTempElements(uint64_t(n) + 1), stream);
         exclusiveScan<uint64_t>(b.ordCounts.data(), b.ordCounts.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
+        (void)ctx.timers.end(finalizeSpan, 64ULL * n, n);
         const unsigned gw = divUp((uint64_t(n) + 1) * WAVE, 256);
+        const KernelTimers::Span sizeSpan = ctx.timers.begin("compressSizeKernel + scan", stream);
         hipLaunchKernelGGL(compressSizeKernel, dim3(gw), dim3(256), 0, stream,
             (const uint32_t*)b.storedFlags.data(), (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(),
             (const uint32_t*)b.ordScratch.data(), n, b.sizes.data());
         exclusiveScan<uint64_t>(b.sizes.data(), b.sizes.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
+        const size_t sizeHandle = ctx.timers.end(sizeSpan, 0, n);
         HIP_CHECK(hipGetLastError());
         const uint32_t storedCount = readDevice(b.storedIndex.data() + n, stream);
         const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
         const uint64_t byteTotal = readDevice(b.sizes.data() + n, stream);
         b.bytes.reserve(byteTotal + 1, stream);
+        const KernelTimers::Span writeSpan = ctx.timers.begin("compressWriteKernel", stream);
         hipLaunchKernelGGL(compressWriteKernel, dim3(gw), dim3(256), 0, stream,
             (const uint32_t*)b.storedFlags.data(), (const uint32_t*)b.storedIndex.data(), (const DpResult*)b.results.data(),
             (const uint32_t*)b.pairWinner.data(), (const uint32_t*)b.ordScratch.data(), n,
             (const uint64_t*)b.sizes.data(), b.bytes.data(), b.compressedToc.data(),
             (const shasta_alignment_data*)b.rows.data(), b.rowsOut.data());
+        const size_t writeHandle = ctx.timers.end(writeSpan, 0, storedCount);
         HIP_CHECK(hipGetLastError());
 
         // Copy this batch's results out (assembled in candidate order once every batch is done).
@@ -925,21 +877,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         out.tocEnds.resize(storedCount);
         for(uint32_t k = 0; k < storedCount; k++) out.tocEnds[k] = (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal);
         for(uint32_t k = 0; k < storedCount; k++) out.alignedBytes += 8ULL * out.rows[k].info.markerCount;
-        if(taskCount) {
-            float ms = 0;
-            for(int c = 0; c < DP_CLASSES; c++) {
-                if(!out.dpStats.tasks[c]) continue;
-                HIP_CHECK(hipEventElapsedTime(&ms, w.ev.start[c], w.ev.stop[c]));
-                out.forwardSeconds[c] = ms * 1e-3;
-                out.dpSeconds += ms * 1e-3;
-                ++out.dpLaunches;
-            }
-            HIP_CHECK(hipEventElapsedTime(&ms, w.ev.start[DP_CLASSES], w.ev.stop[DP_CLASSES]));
-            out.tracebackSeconds = ms * 1e-3;
-            out.dpSeconds += ms * 1e-3;
-            ++out.dpLaunches;
-        }
-
+        // Both compress kernels read the 8-byte ordinal pairs of the stored alignments; the second writes the blobs and the 64-byte rows.
+        ctx.timers.amend(sizeHandle, out.alignedBytes, n);
+        ctx.timers.amend(writeHandle, out.alignedBytes + byteTotal + 64ULL * storedCount, storedCount);
     };
 
     std::atomic<uint64_t> nextBatch(0);
@@ -956,23 +896,24 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             nextBatch.store(batchCount);
         }
     };
-    if(workerCount == 2) {
-        std::thread other(workerLoop, 1);
+    {
+        std::vector<std::thread> others;
+        for(int k = 1; k < workerCount; k++) others.emplace_back(workerLoop, k);
         workerLoop(0);
-        other.join();
-    } else {
-        workerLoop(0);
+        for(std::thread& t : others) t.join();
     }
-    HIP_CHECK(hipEventRecord(evOther, ctx.stream2));
-    HIP_CHECK(hipStreamWaitEvent(ctx.stream, evOther, 0));
+    for(int k = 1; k < workerCount; k++) {
+        HIP_CHECK(hipEventRecord(evOther, workers[k].stream));
+        HIP_CHECK(hipStreamWaitEvent(ctx.stream, evOther, 0));
+    }
     HIP_CHECK(hipEventRecord(evEnd, ctx.stream));
     HIP_CHECK(hipStreamSynchronize(ctx.stream));
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
     (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evOther);
-    for(int k = 0; k < 2; k++) workers[k].ev.destroy();
-    for(int k = 0; k < 2; k++) if(!workers[k].error.empty()) throw std::runtime_error(workers[k].error);
+    for(Worker& w : workers) w.ev.destroy();
+    for(Worker& w : workers) if(!w.error.empty()) throw std::runtime_error(w.error);
 
 #ifdef SHASTA_PROFILE_PHASES
     {
@@ -987,13 +928,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
 #endif
 
     // Assemble the outputs in candidate order.
-    uint64_t rowTotal = 0, byteTotalAll = 0, ordTotalAll = 0, dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0, dpLaunches = 0;
-    double dpSeconds = 0;
+    uint64_t rowTotal = 0, byteTotalAll = 0, ordTotalAll = 0, dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0;
     for(uint64_t k = 0; k < batchCount; k++) {
         const BatchOutput& o = outputs[k];
         rowTotal += o.rows.size(); byteTotalAll += o.bytes.size(); ordTotalAll += o.ordinals.size() / 2;
-        dpCellsTotal += o.dpCells; kmerIdBytes += o.kmerIdBytes; alignedBytes += o.alignedBytes; dpLaunches += o.dpLaunches;
-        dpSeconds += o.dpSeconds;
+        dpCellsTotal += o.dpCells; kmerIdBytes += o.kmerIdBytes; alignedBytes += o.alignedBytes;
     }
     if(borrowed) {
         store.rows.resize(std::max<uint64_t>(1, rowTotal)); store.compressedToc.resize(rowTotal + 1);
@@ -1034,25 +973,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         rowBase += o.rows.size(); byteBase += o.bytes.size();
     }
 
-    for(int c = 0; c < DP_CLASSES; c++) { ctx.times.dpForwardSeconds[c] = 0; ctx.times.dpForwardLaunches[c] = 0; ctx.times.dpForwardCells[c] = 0; ctx.times.dpForwardBytes[c] = 0; }
-    ctx.times.dpTracebackSeconds = 0; ctx.times.dpTracebackLaunches = 0;
-    for(uint64_t k = 0; k < batchCount; k++) {
-        const BatchOutput& o = outputs[k];
-        if(!o.hadTasks) continue;
-        for(int c = 0; c < DP_CLASSES; c++) {
-            if(!o.dpStats.tasks[c]) continue;
-            ctx.times.dpForwardSeconds[c] += o.forwardSeconds[c]; ctx.times.dpForwardLaunches[c] += 1;
-            ctx.times.dpForwardCells[c] += o.dpStats.cells[c]; ctx.times.dpForwardBytes[c] += o.dpStats.bytes[c];
-        }
-        ctx.times.dpTracebackSeconds += o.tracebackSeconds; ctx.times.dpTracebackLaunches += 1;
-    }
-    ctx.times.alignDpSeconds = dpSeconds;
-    ctx.times.alignDpLaunches = dpLaunches;
-    ctx.times.alignDpCells = dpCellsTotal;
-    ctx.times.alignBytes = kmerIdBytes + alignedBytes;
     result.alignmentCount = rowTotal;
     result.dpCellCount = dpCellsTotal;
     result.kmerIdBytes = kmerIdBytes;
+    result.alignedBytes = alignedBytes;
     result.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -1100,9 +1024,6 @@ void align4Free(shasta_align4_result& r)
     std::memset(&r, 0, sizeof(r));
 }
 
-// Unit seam: one banded DP on the device (used by the parity tests of K10 alone).
-int dpForwardVersion() { return chooseDpForwardVersion(); }
-
 // Unit seam: K10 on many (pair, band) tasks at once -- sorted, bundled and run exactly as the tasks of an Align4 batch
 // are, so that wavefronts hold several tasks of different geometry.  Task t aligns kmerIds[begin0[t] .. +nx[t]) with
 // kmerIds[begin1[t] .. +ny[t]) inside [bandMin[t], bandMax[t]].  Results in task order: counts[t] aligned pairs,
@@ -1146,15 +1067,12 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     std::vector<DpResult> results(taskCount);
     HIP_CHECK(hipMemcpyAsync(results.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    // HIP-event time of the forward launch of every band class and of the traceback (for kernel A/B runs).
-    for(int c = 0; c <= DP_CLASSES; c++) {
-        if(c < DP_CLASSES && !stats.tasks[c]) continue;
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, ev.start[c], ev.stop[c]));
-        if(seconds) seconds[c] = ms * 1e-3;
-        if(cells && c < DP_CLASSES) cells[c] = stats.cells[c];
-    }
     ev.destroy();
+    // HIP-event time of the forward launch of every band class and of the traceback (for kernel A/B runs).
+    for(const KernelTimers::Entry& e : ctx.timers.table()) {
+        for(int c = 0; c < DP_CLASSES; c++) if(e.name == DP_FORWARD_NAMES[c]) { if(seconds) seconds[c] = e.seconds; if(cells) cells[c] = stats.cells[c]; }
+        if(e.name.rfind("dpTraceback", 0) == 0 && seconds) seconds[DP_CLASSES] += e.seconds;
+    }
     uint64_t used = 0;
     for(uint64_t t = 0; t < taskCount; t++) {
         const DpResult& r = results[t];

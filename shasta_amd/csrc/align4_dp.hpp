@@ -1,5 +1,5 @@
 // Align4 on MI355X, K10: the banded overlap DP of every (candidate, component) task -- task geometry and sort keys,
-// bundles, the two forward kernels, the traceback (/root/reference/src/Align4.cpp:993-1088; the SeqAn call it wraps is
+// bundles, the forward kernel, the traceback (/root/reference/src/Align4.cpp:993-1088; the SeqAn call it wraps is
 // restated, tie policy as in oracle/banded_dp.hpp).  Included by align4.hip inside its anonymous namespace; align
 // method 3 (align3.hpp) runs the same kernels.
 #pragma once
@@ -108,143 +108,9 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
     bundleWords[bundle] = (uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
 }
 
-template<int G, int C>
-__global__ void __launch_bounds__(256)
-bandedDpForwardKernel(
-    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
-    const uint32_t* __restrict__ sortedIds, uint32_t taskCount,            // this class's segment of the sorted list
-    const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,      // this class's segment
-    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
-{
-    constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C;
-    const int lane = laneId();
-    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if(bundle >= bundleCount) return;                     // whole wave leaves; no block barriers below
-    const int g = lane / G, l = lane % G;
-    const uint32_t pos = bundle * T + uint32_t(g);
-    const bool hasTask = pos < taskCount;
-    const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
-    const DpTask task = tasks[t];
-    const PairDesc pd = pairs[task.pair];
-    const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
-    const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
-    const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
-    const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
-    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    uint32_t iters = geo.iters;
-#pragma unroll
-    for(int d = G; d < WAVE; d <<= 1) iters = max(iters, uint32_t(__shfl_xor(int(iters), d, WAVE)));
-    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
-
-    // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
-    int32_t lo[C];
-    uint32_t span[C];
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        const int32_t b = l * C + c, d = bandMin + b;
-        const int32_t first = d < 0 ? -d : d;
-        const int32_t last = min(2 * nx - d, 2 * ny + d);
-        const bool exists = hasTask && b < width && d <= nx && d >= -ny && last >= first;
-        lo[c] = exists ? first : 0x40000000;
-        span[c] = exists ? uint32_t(last - first) : 0u;
-    }
-    int32_t H[C];
-#pragma unroll
-    for(int c = 0; c < C; c++) H[c] = NEG_SCORE;
-
-    // Register windows of the kmer ids: aw[k] = A[ib + l HC - 1 + k], bw[h] = B[jb - l HC - 1 - h],
-    // ib = (s + bandMin) / 2, jb = ib - bandMin.  Indices are clamped; clamped values belong to
-    // cells that are not in the matrix.
-    int32_t ib = (geo.s0 + bandMin) / 2;
-    auto loadA = [&](int32_t idx) { return p0[min(max(idx, 0), nx - 1)]; };
-    auto loadB = [&](int32_t idx) { return p1[min(max(idx, 0), ny - 1)]; };
-    uint32_t aw[HC + 1], bw[HC];
-#pragma unroll
-    for(int k = 0; k <= HC; k++) aw[k] = loadA(ib + l * HC - 1 + k);
-#pragma unroll
-    for(int h = 0; h < HC; h++) bw[h] = loadB(ib - bandMin - l * HC - 1 - h);
-    uint32_t aNext1 = loadA(ib + l * HC + HC), aNext2 = loadA(ib + 1 + l * HC + HC);
-    uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
-
-    auto cell = [&](int c, int32_t s, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
-        const bool eq = a == bk;
-        const int32_t dg = hd + (eq ? MATCH_SCORE : MISMATCH_SCORE);
-        const int32_t vg = hv + GAP_SCORE;                          // from (i, j-1): diagonal b+1
-        const int32_t hg = hh + GAP_SCORE;                          // from (i-1, j): diagonal b-1
-        const bool isV = vg > dg;
-        const int32_t m1 = max(dg, vg);
-        const bool isH = hg > m1;
-        int32_t v = max(m1, hg);
-        const bool valid = uint32_t(s - lo[c]) <= span[c];
-        v = (s == lo[c]) ? 0 : v;                                   // i == 0 or j == 0: free leading gaps
-        H[c] = valid ? v : H[c];
-        loPlane = __ballot(isH || (!isV && !eq));
-        hiPlane = __ballot(isV || isH);
-    };
-
-    int32_t s = geo.s0;
-    for(uint32_t it = 0; it < iters; it++, s += 2) {
-        uint64_t words[RW];
-        {   // anti-diagonal s: even c hold cells
-            int32_t left = __shfl_up(H[C - 1], 1, G); if(l == 0) left = NEG_SCORE;
-#pragma unroll
-            for(int c = 0; c < C; c += 2) {
-                const int32_t hh = (c == 0) ? left : H[c == 0 ? 0 : c - 1];
-                cell(c, s, aw[c / 2], bw[c / 2], H[c], H[c + 1], hh, words[2 * c], words[2 * c + 1]);
-            }
-        }
-        {   // anti-diagonal s+1: odd c hold cells
-            int32_t right = __shfl_down(H[0], 1, G); if(l == G - 1) right = NEG_SCORE;
-#pragma unroll
-            for(int c = 1; c < C; c += 2) {
-                const int32_t hv = (c == C - 1) ? right : H[c == C - 1 ? c : c + 1];
-                cell(c, s + 1, aw[c / 2 + 1], bw[c / 2], H[c], hv, H[c - 1], words[2 * c], words[2 * c + 1]);
-            }
-        }
-        // Lane k stores word k of this iteration's trace record.
-        uint64_t mine = words[0];
-#pragma unroll
-        for(int k = 1; k < RW; k++) mine = (lane == k) ? words[k] : mine;
-        if(lane < RW) tr[uint64_t(it) * RW + lane] = mine;
-        // Slide the windows.
-#pragma unroll
-        for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
-        aw[HC] = aNext1; aNext1 = aNext2;
-#pragma unroll
-        for(int h = HC - 1; h >= 1; h--) bw[h] = bw[h - 1];
-        bw[0] = bNext1; bNext1 = bNext2;
-        ++ib;
-        aNext2 = loadA(ib + 1 + l * HC + HC);
-        bNext2 = loadB(ib + 1 - bandMin - l * HC);
-    }
-
-    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
-    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
-#pragma unroll
-    for(int c = 0; c < C; c++) {
-        const int32_t d = bandMin + l * C + c;
-        const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
-        const int32_t v = (lo[c] != 0x40000000) ? H[c] : NEG_SCORE;
-        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
-    }
-#pragma unroll
-    for(int d = G / 2; d >= 1; d >>= 1) {
-        const int32_t os = __shfl_xor(bestScore, d, G);
-        const int32_t oi = __shfl_xor(bestI, d, G);
-        const int32_t oj = __shfl_xor(bestJ, d, G);
-        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
-    }
-    if(hasTask && l == 0) {
-        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
-        ends[t] = e;
-    }
-}
-
-// ---- forward kernel, second version ---------------------------------------------------------
-// Same tasks, bundles, trace format and DpEnd as bandedDpForwardKernel, which stays beside it
-// (SHASTA_MI355X_DP_FORWARD=1) until this one has been timed on the MI355X.  Every change comes
-// from the first version's ISA (75 VALU instructions per iteration for two cells per lane,
-// scripts/isa_loop.py):
+// ---- forward kernel ---------------------------------------------------------------------------
+// (The round-1 kernel it replaced -- 75 VALU instructions per iteration, 830 GCUPS on the dominant class against 1360 --
+// is gone; what follows is what reading that kernel's ISA led to.)
 //  * three phases, general / steady / general.  In the steady phase (all but about a band width
 //    of iterations at either end) every cell of the wavefront that exists is inside the matrix and
 //    past the first cell of its diagonal, and every kmer-id load is in range: no validity tests,
@@ -283,7 +149,7 @@ struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // f
 
 template<int G, int C>
 __global__ void __launch_bounds__(256)
-bandedDpForwardKernel2(
+bandedDpForwardKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
     const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
     const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,
@@ -296,8 +162,9 @@ bandedDpForwardKernel2(
     static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
     __shared__ __attribute__((aligned(16))) uint64_t traceLines[4 * 32];   // one 256-byte line per wavefront of the block (16-byte LDS writes)
     const int lane = laneId();
-    const uint32_t bundle = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if(bundle >= bundleCount) return;                     // whole wave leaves: all 64 lanes are active below, no block barriers
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(slot >= bundleCount) return;                       // whole wave leaves: all 64 lanes are active below, no block barriers
+    const uint32_t bundle = bundleCount - 1 - slot;       // the list is sorted by ascending length: the longest bundles start first
     uint64_t* const line = traceLines + 32 * (threadIdx.x >> 6);
     const int g = lane / G, l = lane % G;
     const uint32_t pos = bundle * T + uint32_t(g);
@@ -518,110 +385,208 @@ bandedDpForwardKernel2(
     }
 }
 
-// One lane per task: walk the path from the end cell through the packed trace.  The trace is
-// consumed in chunks of CW words (128 or 256 bytes, whole cache lines): the chunk under the
-// path sits in the lane's private LDS window, the next one (the path only moves towards smaller
-// anti-diagonals) is already in flight in registers, so every line is fetched once and its
-// latency is covered by the walk through the previous chunk.
-template<int CW>
-__global__ void __launch_bounds__(256)
-dpTracebackKernel(
-    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
-    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
-    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+// Traceback.  ONE LANE per task (64 paths in flight per wavefront) walks from the end cell through the packed trace,
+// writes the aligned ordinals and accumulates AlignmentInfo's metrics (src/Alignment.cpp:67-113, :4-31).
+//
+// What the walk costs is latency, not bytes: a kernel of sorted tasks lasts as long as its longest path times the
+// time of one step.  So:
+//  * a path crosses every anti-diagonal pair, i.e. it visits the iterations of the forward kernel in strictly
+//    descending order, one or two cells in each.  The trace is consumed in 256-byte chunks (a whole number of
+//    iterations, 8 / 4 for C = 2 / 4 diagonals per lane); a lane holds its current chunk and the next one IN
+//    REGISTERS, and the walk through a chunk is unrolled over the chunk's iterations and the two possible cells of
+//    each, so that every register index is static: no LDS, no address arithmetic, no dependent memory access in a
+//    step.  The loads of the next chunk are issued a whole chunk ahead;
+//  * C is a template parameter (the round-1 kernel divided by a run-time C twice per step);
+//  * the longest tasks go first (the list is sorted by ascending length: lane order is reversed), so that the tail
+//    of the launch is made of short paths.
+// Tasks with C = 8 or 16 diagonals per lane (bands wider than 512: a handful per batch) walk through an LDS window
+// instead (dpTracebackWideKernel): the unrolled select chain over C record pairs would not pay.
+struct TracebackWalk {
+    uint32_t pos, count, prevX, prevY, last0, last1, first0, first1, maxSkip, maxDrift;
+    int32_t minOffset, maxOffset;
+    long long sumOffset;
+};
+
+// A diagonal step over equal kmers at cell (i, j): an aligned marker pair (src/Align4.cpp:1057-1061).
+__device__ __forceinline__ void tracebackMatch(TracebackWalk& w, int32_t i, int32_t j, uint64_t ordBase, uint32_t* __restrict__ ordScratch)
 {
-    constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
-    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if(idx >= taskCount) return;
-    const uint32_t t = sortedIds[idx];
-    const DpTask task = tasks[t];
-    const PairDesc pd = pairs[task.pair];
-    const DpEnd e = ends[t];
-    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    const int C = dpDiagonals(geo.cls);
-    const uint32_t RW = uint32_t(2 * C);
-    const uint32_t itersPerChunk = uint32_t(CW) / RW;
-    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
-    const uint64_t ordBase = ordOffsets[t];
-    uint32_t pos = min(pd.nx, pd.ny);
-    uint32_t count = 0, prevX = 0, prevY = 0, last0 = 0, last1 = 0, first0 = 0, first1 = 0, maxSkip = 0, maxDrift = 0;
-    int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
-    long long sumOffset = 0;
-    int32_t i = e.bestI, j = e.bestJ;
-    const bool ok = e.score > NEG_SCORE;
-    // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
-    // the same point of the program, then walks until its path leaves the chunk.  The wave waits
-    // for memory once per epoch, for loads issued a whole epoch earlier.
-    bool active = ok && i > 0 && j > 0;
-    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) / itersPerChunk) : -1;
-    uint4 next[QUADS];
-#pragma unroll
-    for(int k = 0; k < QUADS; k++) next[k] = active ? tr[chunk * QUADS + k] : make_uint4(0, 0, 0, 0);
-    while(__any(active)) {
-        if(active) {
-#pragma unroll
-            for(int k = 0; k < QUADS; k++) window[k * 256 + threadIdx.x] = next[k];
-            if(chunk > 0) {
-#pragma unroll
-                for(int k = 0; k < QUADS; k++) next[k] = tr[(chunk - 1) * QUADS + k];
-            }
-        }
-        while(active) {
-            const int32_t b = i - j - task.bandMin;
-            const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
-            if(int64_t(it / itersPerChunk) != chunk) break;
-            const uint32_t c = uint32_t(b) % uint32_t(C), bit = e.laneBase + uint32_t(b) / uint32_t(C);
-            const uint32_t word = (it % itersPerChunk) * RW + 2 * c;           // even: one 16-byte piece
-            const uint4 w = window[(word >> 1) * 256 + threadIdx.x];
-            const uint64_t lo = uint64_t(w.x) | (uint64_t(w.y) << 32), hi = uint64_t(w.z) | (uint64_t(w.w) << 32);
-            const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
-            if(dir == 0u) {
-                // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
-                const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
-                --pos;
-                *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(x, y);
-                const int32_t offset = int32_t(x) - int32_t(y);
-                if(count == 0) { last0 = x; last1 = y; }
-                else {
-                    maxSkip = max(maxSkip, max(prevX - x, prevY - y));
-                    const int32_t prevOffset = int32_t(prevX) - int32_t(prevY);
-                    const int32_t drift = offset - prevOffset;
-                    maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
-                }
-                minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
-                sumOffset += offset;
-                first0 = x; first1 = y; prevX = x; prevY = y;
-                ++count;
-                --i; --j;
-            } else if(dir == 1u) { --i; --j; }
-            else if(dir == 2u) { --j; }
-            else { --i; }
-            active = i > 0 && j > 0;
-        }
-        --chunk;
+    const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
+    --w.pos;
+    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + w.pos)) = make_uint2(x, y);
+    const int32_t offset = int32_t(x) - int32_t(y);
+    if(w.count == 0) { w.last0 = x; w.last1 = y; }
+    else {
+        w.maxSkip = max(w.maxSkip, max(w.prevX - x, w.prevY - y));
+        const int32_t prevOffset = int32_t(w.prevX) - int32_t(w.prevY);
+        const int32_t drift = offset - prevOffset;
+        w.maxDrift = max(w.maxDrift, uint32_t(drift < 0 ? -drift : drift));
     }
+    w.minOffset = min(w.minOffset, offset); w.maxOffset = max(w.maxOffset, offset);
+    w.sumOffset += offset;
+    w.first0 = x; w.first1 = y; w.prevX = x; w.prevY = y;
+    ++w.count;
+}
+
+// The DpResult of a finished walk, the inner acceptance of src/Align4.cpp:944-981, the candidate's best component.
+__device__ __forceinline__ void tracebackFinish(const TracebackWalk& w, const DpTask& task, const PairDesc& pd, const DpEnd& e, uint64_t ordBase,
+    uint32_t t, const DeviceOptions& opt, DpResult* __restrict__ results, unsigned long long* __restrict__ pairBest)
+{
     DpResult r;
-    r.ordBegin = ordBase + pos;
-    r.sumOffset = sumOffset;
-    r.markerCount = count; r.first0 = first0; r.first1 = first1; r.last0 = last0; r.last1 = last1;
-    r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+    r.ordBegin = ordBase + w.pos;
+    r.sumOffset = w.sumOffset;
+    r.markerCount = w.count; r.first0 = w.first0; r.first1 = w.first1; r.last0 = w.last0; r.last1 = w.last1;
+    r.minOffset = w.minOffset; r.maxOffset = w.maxOffset; r.maxSkip = w.maxSkip; r.maxDrift = w.maxDrift;
     r.score = e.score; r.pad = 0;
-    // Inner acceptance, src/Align4.cpp:944-981.
-    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+    bool pass = w.count > 0 && uint64_t(w.count) >= opt.minAlignedMarkerCount;
     if(pass) {
-        const double f0 = double(count) / double(last0 + 1 - first0);
-        const double f1 = double(count) / double(last1 + 1 - first1);
+        const double f0 = double(w.count) / double(w.last0 + 1 - w.first0);
+        const double f1 = double(w.count) / double(w.last1 + 1 - w.first1);
         if(min(f0, f1) < opt.minAlignedFraction) pass = false;
-        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
-        const uint32_t leftTrim = min(first0, first1);
-        const uint32_t rightTrim = min(pd.nx - 1 - last0, pd.ny - 1 - last1);
+        if(uint64_t(w.maxSkip) > opt.maxSkip || uint64_t(w.maxDrift) > opt.maxDrift) pass = false;
+        const uint32_t leftTrim = min(w.first0, w.first1);
+        const uint32_t rightTrim = min(pd.nx - 1 - w.last0, pd.ny - 1 - w.last1);
         if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
     }
     r.passes = pass ? 1u : 0u;
     results[t] = r;
     // Best component = most aligned markers (:132-139); ties resolved towards the
     // component whose first cell in (iY,iX) order comes first, and flagged later.
-    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
+    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)w.count << 32) | (unsigned long long)(0xffffffffu - task.label));
+}
+
+__device__ __forceinline__ TracebackWalk tracebackBegin(const PairDesc& pd)
+{
+    TracebackWalk w;
+    w.pos = min(pd.nx, pd.ny);
+    w.count = w.prevX = w.prevY = w.last0 = w.last1 = w.first0 = w.first1 = w.maxSkip = w.maxDrift = 0;
+    w.minOffset = 0x7fffffff; w.maxOffset = int32_t(0x80000000);
+    w.sumOffset = 0;
+    return w;
+}
+
+// Tasks [taskBegin, taskEnd) of the sorted list, all of a class with C diagonals per lane (C = 2 or 4).
+template<int C>
+__global__ void __launch_bounds__(256)
+dpTracebackKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
+    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
+    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    static_assert(C == 2 || C == 4, "register-resident chunks: C = 2 or 4");
+    constexpr int QUADS = 16;                              // 16-byte pieces of a 256-byte chunk
+    constexpr int IPC = QUADS / C;                         // iterations per chunk (a record = C pieces: {lo plane, hi plane} per diagonal of a lane)
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= taskEnd - taskBegin) return;
+    const uint32_t t = sortedIds[taskEnd - 1 - k];         // longest first
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const DpEnd e = ends[t];
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
+    const uint64_t ordBase = ordOffsets[t];
+    TracebackWalk w = tracebackBegin(pd);
+    int32_t i = e.bestI, j = e.bestJ;
+    bool active = e.score > NEG_SCORE && i > 0 && j > 0;
+    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) / uint32_t(IPC)) : -1;
+    uint4 cur[QUADS], next[QUADS];
+#pragma unroll
+    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[chunk * QUADS + q] : make_uint4(0, 0, 0, 0);
+    while(__any(active)) {
+        if(active) {
+#pragma unroll
+            for(int q = 0; q < QUADS; q++) cur[q] = next[q];
+            if(chunk > 0) {
+#pragma unroll
+                for(int q = 0; q < QUADS; q++) next[q] = tr[(chunk - 1) * QUADS + q];
+            }
+        }
+        // The iterations of this chunk in descending order; in each, at most two cells of the path (the cell of the
+        // odd anti-diagonal, then the one of the even anti-diagonal).
+#pragma unroll
+        for(int u = IPC - 1; u >= 0; u--) {
+#pragma unroll
+            for(int cellOfIteration = 0; cellOfIteration < 2; cellOfIteration++) {
+                const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
+                if(active && int64_t(it / uint32_t(IPC)) == chunk && int(it % uint32_t(IPC)) == u) {
+                    const uint32_t b = uint32_t(i - j - task.bandMin);
+                    const uint32_t c = b % uint32_t(C), bit = e.laneBase + b / uint32_t(C);
+                    uint4 rec = cur[u * C];
+#pragma unroll
+                    for(int cc = 1; cc < C; cc++) if(c == uint32_t(cc)) rec = cur[u * C + cc];
+                    const uint32_t lo = (bit & 32u) ? rec.y : rec.x, hi = (bit & 32u) ? rec.w : rec.z;
+                    const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
+                    if(dir == 0u) tracebackMatch(w, i, j, ordBase, ordScratch);
+                    i -= (dir != 2u) ? 1 : 0;
+                    j -= (dir != 3u) ? 1 : 0;
+                    active = i > 0 && j > 0;
+                }
+            }
+        }
+        --chunk;
+    }
+    tracebackFinish(w, task, pd, e, ordBase, t, opt, results, pairBest);
+}
+
+// Tasks [taskBegin, taskEnd) of the classes with 8 or 16 diagonals per lane: the chunk under the path sits in the
+// lane's private LDS window, the next one is in flight in registers.
+template<int CW>
+__global__ void __launch_bounds__(256)
+dpTracebackWideKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
+    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
+    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
+    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= taskEnd - taskBegin) return;
+    const uint32_t t = sortedIds[taskEnd - 1 - k];         // longest first
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const DpEnd e = ends[t];
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    const int cLog2 = geo.cls <= 2 ? 1 : geo.cls - 1;      // log2 of dpDiagonals(cls): C = 8, 16 for the classes this kernel is launched on
+    const uint32_t cMask = (1u << cLog2) - 1u;
+    const int ipcLog2 = 4 - cLog2;                         // CW / (2 C) iterations per chunk, CW = 32
+    static_assert(CW == 32, "chunk geometry");
+    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
+    const uint64_t ordBase = ordOffsets[t];
+    TracebackWalk w = tracebackBegin(pd);
+    int32_t i = e.bestI, j = e.bestJ;
+    // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
+    // the same point of the program, then walks until its path leaves the chunk.  The wave waits
+    // for memory once per epoch, for loads issued a whole epoch earlier.
+    bool active = e.score > NEG_SCORE && i > 0 && j > 0;
+    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) >> ipcLog2) : -1;
+    uint4 next[QUADS];
+#pragma unroll
+    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[chunk * QUADS + q] : make_uint4(0, 0, 0, 0);
+    while(__any(active)) {
+        if(active) {
+#pragma unroll
+            for(int q = 0; q < QUADS; q++) window[q * 256 + threadIdx.x] = next[q];
+            if(chunk > 0) {
+#pragma unroll
+                for(int q = 0; q < QUADS; q++) next[q] = tr[(chunk - 1) * QUADS + q];
+            }
+        }
+        while(active) {
+            const uint32_t b = uint32_t(i - j - task.bandMin);
+            const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
+            if(int64_t(it >> ipcLog2) != chunk) break;
+            const uint32_t c = b & cMask, bit = e.laneBase + (b >> cLog2);
+            const uint32_t piece = ((it & ((1u << ipcLog2) - 1u)) << cLog2) + c;     // one 16-byte piece = {lo plane, hi plane} of diagonal c
+            const uint4 rec = window[piece * 256 + threadIdx.x];
+            const uint32_t lo = (bit & 32u) ? rec.y : rec.x, hi = (bit & 32u) ? rec.w : rec.z;
+            const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
+            if(dir == 0u) tracebackMatch(w, i, j, ordBase, ordScratch);
+            i -= (dir != 2u) ? 1 : 0;
+            j -= (dir != 3u) ? 1 : 0;
+            active = i > 0 && j > 0;
+        }
+        --chunk;
+    }
+    tracebackFinish(w, task, pd, e, ordBase, t, opt, results, pairBest);
 }

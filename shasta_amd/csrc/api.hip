@@ -266,11 +266,32 @@ int shasta_mi355x_find_markers(shasta_mi355x_ctx* c, uint64_t readCount,
 
 void shasta_mi355x_find_markers_free(shasta_markers_result* r) { if(r) findMarkersFree(*r); }
 
-int shasta_mi355x_get_kernel_times(shasta_mi355x_ctx* c, shasta_mi355x_kernel_times* t)
+int shasta_mi355x_kernel_table(shasta_mi355x_ctx* c, shasta_mi355x_kernel_stat* rows, uint64_t capacity, uint64_t* count)
 {
     API_BEGIN
-    if(!c || !t) throw std::runtime_error("get_kernel_times: null argument");
-    *t = c->impl.times;
+    if(!c || !count || (capacity && !rows)) throw std::runtime_error("kernel_table: null argument");
+    const std::vector<KernelTimers::Entry> table = c->impl.timers.table();
+    uint64_t n = 0;
+    for(const KernelTimers::Entry& e : table) {
+        if(e.launches == 0) continue;
+        if(n < capacity) {
+            shasta_mi355x_kernel_stat& r = rows[n];
+            std::memset(&r, 0, sizeof(r));
+            std::strncpy(r.name, e.name.c_str(), sizeof(r.name) - 1);
+            r.seconds = e.seconds; r.launches = e.launches; r.algorithmicBytes = e.bytes; r.work = e.work;
+        }
+        ++n;
+    }
+    *count = n;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_kernel_table_reset(shasta_mi355x_ctx* c)
+{
+    API_BEGIN
+    if(!c) throw std::runtime_error("kernel_table_reset: null argument");
+    c->impl.timers.reset();
     return 0;
     API_END(1)
 }
@@ -317,13 +338,6 @@ int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx* c, uint64_t deltaThresho
     palindromicScreen(c->impl, deltaThreshold, bound);
     return 0;
     API_END(1)
-}
-
-int shasta_mi355x_dp_forward_version(void)
-{
-    API_BEGIN
-    return dpForwardVersion();
-    API_END(-1)
 }
 
 }  // extern "C"

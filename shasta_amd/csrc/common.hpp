@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -114,5 +115,84 @@ struct EventTimer {
 #endif
 
 inline unsigned divUp(uint64_t a, uint64_t b) { return unsigned((a + b - 1) / b); }
+
+// Per-kernel timing table of a context (shasta_mi355x_kernel_table): every launch of the stages is bracketed by two
+// HIP events recorded on the stream it is issued on; the durations, launch counts, algorithmic bytes (SURVEY 8d's
+// per-unit figure x the units of the launch) and a kernel-specific work count accumulate per kernel name until the
+// table is reset.  The two host workers of the aligner use it concurrently.
+class KernelTimers {
+public:
+    struct Entry { std::string name; double seconds = 0; uint64_t launches = 0, bytes = 0, work = 0; };
+    struct Span { int id = -1; hipEvent_t begin = nullptr, end = nullptr; hipStream_t stream = nullptr; };
+    ~KernelTimers() { for(hipEvent_t e : pool) (void)hipEventDestroy(e); for(Pending& p : pending) { (void)hipEventDestroy(p.begin); (void)hipEventDestroy(p.end); } }
+    Span begin(const char* name, hipStream_t stream)
+    {
+        Span s;
+        s.stream = stream;
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            s.id = idOf(name);
+            s.begin = take(); s.end = take();
+        }
+        HIP_CHECK(hipEventRecord(s.begin, stream));
+        return s;
+    }
+    // Returns a handle with which bytes / work can be set later (counts that are only known after a read-back).
+    size_t end(const Span& s, uint64_t bytes = 0, uint64_t work = 0)
+    {
+        HIP_CHECK(hipEventRecord(s.end, s.stream));
+        std::lock_guard<std::mutex> lock(mutex);
+        if(pending.size() >= 8192) collectLocked();       // a caller that never reads the table must not pile up events
+        pending.push_back(Pending{s.id, s.begin, s.end, bytes, work});
+        return serial + pending.size() - 1;
+    }
+    void amend(size_t handle, uint64_t bytes, uint64_t work)
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        if(handle >= serial && handle - serial < pending.size()) { pending[handle - serial].bytes = bytes; pending[handle - serial].work = work; }
+    }
+    // Folds every finished launch into the table.  The caller has synchronised the streams it launched on;
+    // a launch that is still running stays pending.
+    void collect() { std::lock_guard<std::mutex> lock(mutex); collectLocked(); }
+    void reset() { std::lock_guard<std::mutex> lock(mutex); collectLocked(); for(Entry& e : entries) { e.seconds = 0; e.launches = e.bytes = e.work = 0; } }
+    std::vector<Entry> table() { std::lock_guard<std::mutex> lock(mutex); collectLocked(); return entries; }
+private:
+    void collectLocked()
+    {
+        size_t kept = 0;
+        for(size_t k = 0; k < pending.size(); k++) {
+            Pending& p = pending[k];
+            float ms = 0;
+            if(hipEventQuery(p.end) == hipSuccess && hipEventElapsedTime(&ms, p.begin, p.end) == hipSuccess) {
+                Entry& e = entries[size_t(p.id)];
+                e.seconds += double(ms) * 1e-3; e.launches += 1; e.bytes += p.bytes; e.work += p.work;
+                pool.push_back(p.begin); pool.push_back(p.end);
+            } else {
+                pending[kept++] = p;
+            }
+        }
+        serial += pending.size() - kept;      // handles of folded launches expire
+        pending.resize(kept);
+    }
+    struct Pending { int id; hipEvent_t begin, end; uint64_t bytes, work; };
+    int idOf(const char* name)
+    {
+        for(size_t k = 0; k < entries.size(); k++) if(entries[k].name == name) return int(k);
+        entries.push_back(Entry()); entries.back().name = name;
+        return int(entries.size() - 1);
+    }
+    hipEvent_t take()
+    {
+        if(!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    std::mutex mutex;
+    std::vector<Entry> entries;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    size_t serial = 0;
+};
 
 }  // namespace shasta_mi355x

@@ -12,7 +12,7 @@
 
 namespace shasta_mi355x {
 
-constexpr int HASH_TILE = 256;        // markers per hash-kernel tile
+constexpr int HASH_TILE = 252;        // markers per hash-kernel tile: 63 lanes x 4 windows (the 64th lane holds the halo)
 
 struct Context {
     int device = 0;
@@ -27,20 +27,27 @@ struct Context {
     DeviceBuffer<uint8_t> readFlags;         // R
     DeviceBuffer<uint4> tileDesc;            // ceil(M/HASH_TILE)+1: {first oriented read, its palindromic flag, its end (u64)} per hash tile
 
-    RadixSortWorkspace sortWs, sortWs2;
-    hipStream_t stream2 = nullptr;           // second worker of the Align4 stage
-    hipStream_t wideStream[2] = {nullptr, nullptr};   // side streams for the wide-band DP classes
-    std::shared_ptr<void> alignScratch[2];   // grow-only batch scratch of the two workers
+    // The aligner runs its batches on several host workers (ALIGN_MAX_WORKERS at most), each with its own stream, sort
+    // workspace, side stream (wide-band DP classes) and grow-only batch scratch: worker 0 uses `stream` / `sortWs`.
+    static constexpr int ALIGN_MAX_WORKERS = 8;
+    RadixSortWorkspace sortWs, workerSortWs[ALIGN_MAX_WORKERS];
+    hipStream_t workerStream[ALIGN_MAX_WORKERS] = {};
+    hipStream_t wideStream[ALIGN_MAX_WORKERS] = {};
+    std::shared_ptr<void> alignScratch[ALIGN_MAX_WORKERS];
     std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress (staged / multi-GPU API)
     std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
-    shasta_mi355x_kernel_times times = {};
+    KernelTimers timers;                     // per-kernel HIP-event times since the last reset (shasta_mi355x_kernel_table)
 
     explicit Context(int device);
     ~Context();
     void setMarkers(uint64_t readCount, const uint64_t* toc, const void* data7,
         const uint32_t* denseKmerIds, const uint8_t* flags, bool denseOnDevice = false);
 };
+
+// One timed launch (or group of launches that form one step): events on `stream` around the statement(s).
+#define SHASTA_TIMED(ctx, name, stream, bytes, work, ...) do { const KernelTimers::Span span_ = (ctx).timers.begin(name, stream); \
+    __VA_ARGS__; (void)(ctx).timers.end(span_, bytes, work); } while(0)
 
 // Stage entry points (lowhash0.hip, align4.hip).
 void lowhash0Run(Context&, const shasta_lowhash0_params&, uint64_t* readLowHashStatistics, shasta_lowhash0_result&);
@@ -65,7 +72,6 @@ void findMarkers(Context&, uint64_t readCount, const uint64_t* readsToc, const u
 void findMarkersFree(shasta_markers_result&);
 // palindromic.hip: per read, an upper bound on the near-diagonal marker count of its self-alignment.
 void palindromicScreen(Context&, uint64_t deltaThreshold, uint32_t* bound);
-int dpForwardVersion();          // align4.hip: 1 or 2, decided once per process (environment, else a comparison on the device)
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);
 void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,

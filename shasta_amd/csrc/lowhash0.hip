@@ -97,22 +97,37 @@ tileDescKernel(const uint64_t* __restrict__ toc, const uint8_t* __restrict__ rea
 
 // ---------------------------------------------------------------------------
 // K1: pass 1 of the reference (src/LowHash0.cpp:314-360).
-// One thread per window; a block walks tiles of 256 consecutive markers with a
-// (m-1)-marker halo staged in LDS, so every kmer id is read from HBM once.
-// Low hashes are staged in LDS and flushed with one global atomic per ~1000.
+// What bounds it is the vector ALU, not HBM: MurmurHash64A costs five 64 x 64-bit multiplies per window at m = 4
+// even with everything shared that can be (profiles/r02_valu_rates.jsonl: a v_mul_lo_u32 issues at 0.6 of the rate
+// of an add), about 45 VALU instructions per window against 4 bytes read.  The round-1 kernel (one window per
+// thread, 256-marker block tiles in LDS, three block barriers per tile) issued 103 per window and ran at 0.90 ms per
+// launch of 3.0e8 windows whichever multiplies were shared.  This one has no block-level step at all:
+//  * a wavefront owns tiles of HASH_TILE = 252 consecutive markers: lane l < 63 hashes the FOUR windows that start at
+//    markers 4l .. 4l+3 of the tile, lane 63 only feeds its neighbour (its markers are the first four of the next tile);
+//  * one 16-byte load per lane and tile, issued one tile ahead; the markers and block transforms a lane needs from the
+//    next lane arrive by DPP wave shifts (m = 3, 4, 5: at most four markers and two transforms);
+//  * murmurMix of the 8-byte block that starts at a marker is computed once, by the lane that owns the marker
+//    (a block is block b of window j - 2b): 2 + m/2 + (m odd) + 1 multiplies per window instead of 3 (m/2) + (m odd) + 1;
+//  * low hashes go to a wavefront-private LDS stage whose fill level lives in a scalar register: no LDS atomics, one
+//    global atomic per ~190 records.
+// Any other m runs the same kernel with window contents loaded marker by marker (L1-resident re-reads): correct
+// for every m <= 33, not tuned.
 // ---------------------------------------------------------------------------
-constexpr int HASH_THREADS = HASH_TILE;
+constexpr int HASH_THREADS = 256;
 constexpr int HASH_HALO = 32;                 // supports m <= 33
-constexpr int HASH_STAGE = 1024;
+constexpr int HASH_STAGE = 512;               // records staged per wavefront (a tile adds at most HASH_TILE)
 
-// SHARED_MIX: the 8-byte block (kmer ids j, j+1) is block b of window j - 2b, and its transform
-// murmurMix -- two of the three 64-bit multiplies a block costs -- does not depend on the window:
-// every thread transforms the block that starts at its marker once, into LDS, and a window reads
-// the m/2 transforms it needs.  2 + m/2 + (m odd) + 1 multiplies per window instead of
-// 3 (m/2) + (m odd) + 1 (m = 4: 5 instead of 7); the kernel is bound by those quarter-rate
-// multiplies, not by HBM.  Same hashes; SHASTA_MI355X_HASH=1 runs the
-// version without sharing (the one timed on the MI355X in round 1).
-template<int M_FIXED, bool SHARED_MIX>
+// Lane l gets the value of lane l + 1 (wave_shl:1); lane 63 gets 0.
+__device__ __forceinline__ uint32_t fromNextLane(uint32_t v)
+{
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint64_t fromNextLane64(uint64_t v)
+{
+    return uint64_t(fromNextLane(uint32_t(v))) | (uint64_t(fromNextLane(uint32_t(v >> 32))) << 32);
+}
+
+template<int M_FIXED>
 __global__ void __launch_bounds__(HASH_THREADS)
 hashWindowsKernel(
     const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc,
@@ -122,119 +137,134 @@ hashWindowsKernel(
     uint32_t* __restrict__ outKeys, uint64_t* __restrict__ outVals,
     unsigned long long* __restrict__ counter, uint64_t capacity)
 {
-    __shared__ uint32_t sK[HASH_TILE + HASH_HALO];
-    __shared__ uint32_t sKeys[HASH_STAGE];
-    __shared__ uint64_t sVals[HASH_STAGE];
-    __shared__ uint32_t sFill;
-    __shared__ unsigned long long sBase;
-    __shared__ uint64_t sMix[SHARED_MIX ? HASH_TILE + HASH_HALO : 1];
-
+    __shared__ uint32_t stageKeys[HASH_THREADS / WAVE][HASH_STAGE];
+    __shared__ uint64_t stageVals[HASH_THREADS / WAVE][HASH_STAGE];
+    constexpr uint64_t mul = 0xc6a4a7935bd1e995ULL;
     const uint32_t mm = M_FIXED ? uint32_t(M_FIXED) : m;
-    const int tid = int(threadIdx.x);
-    const int lane = tid & 63;
-    if(tid == 0) sFill = 0;
-    __syncthreads();
+    const int lane = laneId();
+    const uint32_t waveInBlock = threadIdx.x >> 6;
+    uint32_t* const sKeys = stageKeys[waveInBlock];
+    uint64_t* const sVals = stageVals[waveInBlock];
+    uint32_t fill = 0;                                     // wave-uniform
 
-    const uint64_t firstTile = markerBegin / HASH_TILE;
-    const uint64_t lastTile = (markerEnd + HASH_TILE - 1) / HASH_TILE;      // exclusive
-    // The loads of a tile (its kmer ids, the halo, its descriptor) are issued two tiles ahead, so
-    // their latency is covered by the work on the tiles in between.
-    auto loadTile = [&](uint64_t tile, uint32_t& k, uint32_t& halo, uint4& desc) {
-        const uint64_t base = tile * HASH_TILE;
-        const uint64_t i = base + uint64_t(tid), j = base + HASH_TILE + uint64_t(tid);
-        k = (i < markerCount) ? kmerIds[i] : 0u;
-        halo = (tid < int(mm) - 1 && j < markerCount) ? kmerIds[j] : 0u;
-        desc = tileDesc[tile];
-    };
-    uint64_t tile = firstTile + blockIdx.x;
-    uint32_t curK = 0, curHalo = 0, nextK = 0, nextHalo = 0, next2K = 0, next2Halo = 0;
-    uint4 curDesc = make_uint4(0, 0, 0, 0), nextDesc = make_uint4(0, 0, 0, 0), next2Desc = make_uint4(0, 0, 0, 0);
-    if(tile < lastTile) loadTile(tile, curK, curHalo, curDesc);
-    if(tile + gridDim.x < lastTile) loadTile(tile + gridDim.x, nextK, nextHalo, nextDesc);
-    for(; tile < lastTile; tile += gridDim.x) {
-        const uint64_t next2Tile = tile + 2ULL * gridDim.x;
-        if(next2Tile < lastTile) loadTile(next2Tile, next2K, next2Halo, next2Desc);
-        const uint64_t base = tile * HASH_TILE;
-        const uint64_t i = base + uint64_t(tid);
-        sK[tid] = curK;
-        if(tid < int(mm) - 1) sK[HASH_TILE + tid] = curHalo;
-        __syncthreads();
-        if constexpr (SHARED_MIX) {
-            // Blocks that start at positions 0 .. HASH_TILE + m - 3 of the tile (the last window's last block).
-            sMix[tid] = murmurMix(uint64_t(sK[tid]) | (uint64_t(sK[tid + 1]) << 32));
-            if(tid + 2 < int(mm)) sMix[HASH_TILE + tid] = murmurMix(uint64_t(sK[HASH_TILE + tid]) | (uint64_t(sK[HASH_TILE + tid + 1]) << 32));
-            __syncthreads();
-        }
-
-        bool hit = false;
-        uint64_t hash = 0;
-        uint32_t orientedReadId = 0;
-        if(i >= markerBegin && i < markerEnd) {
-            uint32_t r = curDesc.x;
-            uint64_t end = uint64_t(curDesc.z) | (uint64_t(curDesc.w) << 32);
-            bool palindromic = (curDesc.y & 1u) != 0;
-            if(i >= end) {
-                // Past the end of the tile's first read: a read boundary inside the tile (rare).
-                ++r;
-                while(toc[r + 1] <= i) ++r;
-                end = toc[r + 1];
-                palindromic = (readFlags[r >> 1] & 1u) != 0;
-            }
-            // Reads with fewer than m markers (:337) and palindromic reads (:325) produce nothing.
-            if(i + mm <= end && !palindromic) {
-                if constexpr (SHARED_MIX) {
-                    const uint64_t mul = 0xc6a4a7935bd1e995ULL;
-                    uint64_t h = seed ^ (uint64_t(4u * mm) * mul);
-                    const uint32_t blocks = mm >> 1;
-#pragma unroll
-                    for(uint32_t b = 0; b < blocks; b++) { h ^= sMix[tid + 2 * int(b)]; h *= mul; }
-                    if(mm & 1u) { h ^= uint64_t(sK[tid + int(mm) - 1]); h *= mul; }
-                    h ^= h >> 47; h *= mul; h ^= h >> 47;
-                    hash = h;
-                } else {
-                    hash = murmurWindow<M_FIXED>(&sK[tid], mm, seed);
-                }
-                hit = hash < hashThreshold;                                   // :350, strict
-                orientedReadId = r;
-            }
-        }
-        const uint64_t votes = __ballot(hit);
-        if(votes) {
-            uint32_t waveBase = 0;
-            if(lane == 0) waveBase = atomicAdd(&sFill, uint32_t(__popcll(votes)));
-            waveBase = __shfl(waveBase, 0, WAVE);
-            if(hit) {
-                const uint32_t slot = waveBase + uint32_t(__popcll(votes & laneMaskLt()));
-                sKeys[slot] = uint32_t(hash) & mask;                          // bucket id, :352
-                sVals[slot] = (hash & 0xffffffff00000000ULL) | orientedReadId; // BucketEntry: hashHighBits, orientedReadId
-            }
-        }
-        __syncthreads();
-        if(sFill > HASH_STAGE - HASH_TILE) {
-            const uint32_t fill = sFill;
-            if(tid == 0) sBase = atomicAdd(counter, (unsigned long long)fill);
-            __syncthreads();
-            for(uint32_t k = tid; k < fill; k += HASH_THREADS) {
-                const uint64_t dst = sBase + k;
-                if(dst < capacity) { outKeys[dst] = sKeys[k]; outVals[dst] = sVals[k]; }
-            }
-            __syncthreads();
-            if(tid == 0) sFill = 0;
-            __syncthreads();
-        }
-        curK = nextK; curHalo = nextHalo; curDesc = nextDesc;
-        nextK = next2K; nextHalo = next2Halo; nextDesc = next2Desc;
-    }
-    __syncthreads();
-    const uint32_t fill = sFill;
-    if(fill) {
-        if(tid == 0) sBase = atomicAdd(counter, (unsigned long long)fill);
-        __syncthreads();
-        for(uint32_t k = tid; k < fill; k += HASH_THREADS) {
-            const uint64_t dst = sBase + k;
+    auto flush = [&]() {
+        unsigned long long base = 0;
+        if(lane == 0) base = atomicAdd(counter, (unsigned long long)fill);
+        base = (unsigned long long)(__builtin_amdgcn_readfirstlane(uint32_t(base))) |
+            ((unsigned long long)(__builtin_amdgcn_readfirstlane(uint32_t(base >> 32))) << 32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for(uint32_t k = uint32_t(lane); k < fill; k += WAVE) {
+            const uint64_t dst = base + k;
             if(dst < capacity) { outKeys[dst] = sKeys[k]; outVals[dst] = sVals[k]; }
         }
+        __builtin_amdgcn_wave_barrier();
+        fill = 0;
+    };
+    // Appends the hits of one window slot of the wavefront (at most 64) to the stage.
+    auto append = [&](bool hit, uint64_t hash, uint32_t orientedReadId) {
+        const uint64_t votes = __ballot(hit);
+        if(votes == 0) return;
+        if(hit) {
+            const uint32_t slot = fill + uint32_t(__popcll(votes & laneMaskLt()));
+            sKeys[slot] = uint32_t(hash) & mask;                              // bucket id, :352
+            sVals[slot] = (hash & 0xffffffff00000000ULL) | orientedReadId;    // BucketEntry: hashHighBits, orientedReadId
+        }
+        fill += uint32_t(__popcll(votes));
+    };
+
+    const uint64_t firstTile = markerBegin / HASH_TILE;
+    const uint64_t lastTile = (markerEnd + HASH_TILE - 1) / HASH_TILE;          // exclusive
+    const uint64_t waves = uint64_t(gridDim.x) * (HASH_THREADS / WAVE);
+    uint64_t tile = firstTile + uint64_t(blockIdx.x) * (HASH_THREADS / WAVE) + waveInBlock;
+    // kmerIds is readable HASH_TILE + HASH_HALO markers past markerCount (Context::setMarkers).
+    auto loadTile = [&](uint64_t t, uint4& k, uint4& desc) {
+        k = *reinterpret_cast<const uint4*>(kmerIds + t * HASH_TILE + 4 * uint64_t(lane));
+        desc = tileDesc[t];
+    };
+    uint4 nextK = make_uint4(0, 0, 0, 0), nextDesc = make_uint4(0, 0, 0, 0);
+    if(tile < lastTile) loadTile(tile, nextK, nextDesc);
+    for(; tile < lastTile; tile += waves) {
+        const uint4 K = nextK, desc = nextDesc;
+        if(tile + waves < lastTile) loadTile(tile + waves, nextK, nextDesc);
+        if(fill + HASH_TILE > HASH_STAGE) flush();                            // room for every window of this tile
+        const uint64_t i0 = tile * HASH_TILE + 4 * uint64_t(lane);           // first of this lane's four markers
+        const bool owner = lane < WAVE - 1;                                    // lane 63 only feeds lane 62
+
+        // The read of the lane's markers: the tile's first read unless a read boundary lies before them.
+        uint32_t r = desc.x;
+        uint64_t end = uint64_t(desc.z) | (uint64_t(desc.w) << 32);
+        bool palindromic = (desc.y & 1u) != 0;
+        // Fast path: all four windows lie in that read.  Otherwise every window finds its own read (rare: one or two
+        // lanes per read boundary).
+        const bool simple = i0 + 3 + mm <= end;
+        auto readOf = [&](uint64_t i, uint32_t& rr, uint64_t& ee, bool& pp) {
+            rr = r; ee = end; pp = palindromic;
+            if(i >= ee) {
+                ++rr;
+                while(toc[rr + 1] <= i) ++rr;
+                ee = toc[rr + 1];
+                pp = (readFlags[rr >> 1] & 1u) != 0;
+            }
+        };
+
+        uint64_t hash[4];
+        if constexpr (M_FIXED >= 3 && M_FIXED <= 5) {
+            // Markers 0..3 are the lane's own, 4..7 the next lane's.
+            const uint32_t k0 = K.x, k1 = K.y, k2 = K.z, k3 = K.w;
+            const uint32_t k4 = fromNextLane(K.x), k5 = fromNextLane(K.y), k6 = fromNextLane(K.z), k7 = fromNextLane(K.w);
+            // Block transforms that start at the lane's own markers, and the next lane's first two.
+            const uint64_t p0 = murmurMix(uint64_t(k0) | (uint64_t(k1) << 32)), p1 = murmurMix(uint64_t(k1) | (uint64_t(k2) << 32));
+            const uint64_t p2 = murmurMix(uint64_t(k2) | (uint64_t(k3) << 32)), p3 = murmurMix(uint64_t(k3) | (uint64_t(k4) << 32));
+            const uint64_t h0 = seed ^ (uint64_t(4u * M_FIXED) * mul);
+            auto finish = [&](uint64_t h) { h ^= h >> 47; h *= mul; h ^= h >> 47; return h; };
+            if constexpr (M_FIXED == 3) {
+                (void)k6; (void)k7;
+                hash[0] = finish(((h0 ^ p0) * mul ^ uint64_t(k2)) * mul);
+                hash[1] = finish(((h0 ^ p1) * mul ^ uint64_t(k3)) * mul);
+                hash[2] = finish(((h0 ^ p2) * mul ^ uint64_t(k4)) * mul);
+                hash[3] = finish(((h0 ^ p3) * mul ^ uint64_t(k5)) * mul);
+            } else {
+                const uint64_t p4 = fromNextLane64(p0), p5 = fromNextLane64(p1);
+                if constexpr (M_FIXED == 4) {
+                    (void)k5; (void)k6; (void)k7;
+                    hash[0] = finish(((h0 ^ p0) * mul ^ p2) * mul);
+                    hash[1] = finish(((h0 ^ p1) * mul ^ p3) * mul);
+                    hash[2] = finish(((h0 ^ p2) * mul ^ p4) * mul);
+                    hash[3] = finish(((h0 ^ p3) * mul ^ p5) * mul);
+                } else {
+                    (void)k5;
+                    hash[0] = finish((((h0 ^ p0) * mul ^ p2) * mul ^ uint64_t(k4)) * mul);
+                    hash[1] = finish((((h0 ^ p1) * mul ^ p3) * mul ^ uint64_t(k5)) * mul);
+                    hash[2] = finish((((h0 ^ p2) * mul ^ p4) * mul ^ uint64_t(k6)) * mul);
+                    hash[3] = finish((((h0 ^ p3) * mul ^ p5) * mul ^ uint64_t(k7)) * mul);
+                }
+            }
+        } else {
+            // Any m: the window's markers one by one (they are in L1 after the tile load).
+#pragma unroll
+            for(int w = 0; w < 4; w++) {
+                uint32_t win[HASH_HALO + 1];
+                for(uint32_t q = 0; q < mm; q++) win[q] = kmerIds[i0 + uint32_t(w) + q];
+                hash[w] = murmurWindow<0>(win, mm, seed);
+            }
+        }
+#pragma unroll
+        for(int w = 0; w < 4; w++) {
+            const uint64_t i = i0 + uint32_t(w);
+            bool ok = owner && i >= markerBegin && i < markerEnd;
+            uint32_t rr = r;
+            if(simple) ok = ok && !palindromic;
+            else if(ok) {
+                uint64_t ee; bool pp;
+                readOf(i, rr, ee, pp);
+                // Reads with fewer than m markers (:337) and palindromic reads (:325) produce nothing.
+                ok = i + mm <= ee && !pp;
+            }
+            append(ok && hash[w] < hashThreshold, hash[w], rr);               // :350, strict
+        }
     }
+    if(fill) flush();
 }
 
 // Unit seam: all window hashes of one kmer-id array.
@@ -438,8 +468,9 @@ Context::Context(int deviceArg) : device(deviceArg)
 Context::~Context()
 {
     (void)hipSetDevice(device);
-    alignScratch[0].reset(); alignScratch[1].reset(); lowhashJob.reset();
-    if(stream2) (void)hipStreamDestroy(stream2);
+    for(auto& scratch : alignScratch) scratch.reset();
+    lowhashJob.reset();
+    for(hipStream_t w : workerStream) if(w) (void)hipStreamDestroy(w);
     for(hipStream_t w : wideStream) if(w) (void)hipStreamDestroy(w);
     if(stream) (void)hipStreamDestroy(stream);
 }
@@ -463,7 +494,7 @@ void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const vo
     if(flags) HIP_CHECK(hipMemcpyAsync(readFlags.data(), flags, readCount, hipMemcpyHostToDevice, stream));
     else HIP_CHECK(hipMemsetAsync(readFlags.data(), 0, std::max<uint64_t>(1, readCount), stream));
 
-    kmerIds.reserve(markerCount + HASH_TILE + HASH_HALO, stream);
+    kmerIds.reserve(markerCount + 2 * HASH_TILE + HASH_HALO, stream);      // the hash kernel reads whole tiles and window halos past the end
     if(markerCount) {
         if(denseKmerIds) {
             HIP_CHECK(hipMemcpyAsync(kmerIds.data(), denseKmerIds, markerCount * 4,
@@ -512,17 +543,27 @@ template<class T> T* mallocCopy(const std::vector<T>& v)
 
 int bitsFor(uint64_t maxValue) { int b = 1; while((maxValue >> b) != 0) ++b; return b; }
 
+// The row of the kernel table a launch for this m is booked under (the template instance that runs).
+const char* hashKernelName(uint32_t m)
+{
+    switch(m) {
+        case 3: return "hashWindowsKernel<3>";
+        case 4: return "hashWindowsKernel<4>";
+        case 5: return "hashWindowsKernel<5>";
+        default: return "hashWindowsKernel<0> (any m)";
+    }
+}
+
 void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uint32_t mask,
     uint64_t markerBegin, uint64_t markerEnd,
     uint32_t* outKeys, uint64_t* outVals, unsigned long long* counter, uint64_t capacity)
 {
     const uint64_t tiles = (markerEnd + HASH_TILE - 1) / HASH_TILE - markerBegin / HASH_TILE;
     if(tiles == 0) return;
-    // Persistent blocks: enough to fill 256 CUs x 8 blocks, each walking many tiles so
-    // that one global atomic serves ~1000 low hashes.
-    const unsigned blocks = unsigned(std::min<uint64_t>(tiles, 256 * 8));
-    static const bool shared = [] { const char* e = std::getenv("SHASTA_MI355X_HASH"); return !(e != nullptr && std::atoi(e) == 1); }();
-#define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL((shared ? hashWindowsKernel<MF, true> : hashWindowsKernel<MF, false>), dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
+    // Persistent wavefronts: 256 CUs x 8 blocks x 4 independent wavefronts, each walking many tiles, so that one global
+    // atomic serves a few hundred low hashes.
+    const unsigned blocks = unsigned(std::min<uint64_t>(divUp(tiles, uint64_t(HASH_THREADS / WAVE)), 256 * 8));
+#define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL(hashWindowsKernel<MF>, dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
         (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), (const uint8_t*)ctx.readFlags.data(), \
         (const uint4*)ctx.tileDesc.data(), markerBegin, markerEnd, ctx.markerCount, \
         m, seed, threshold, mask, outKeys, outVals, counter, capacity)
@@ -530,7 +571,6 @@ void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uin
         case 3: SHASTA_LAUNCH_HASH(3); break;
         case 4: SHASTA_LAUNCH_HASH(4); break;
         case 5: SHASTA_LAUNCH_HASH(5); break;
-        case 6: SHASTA_LAUNCH_HASH(6); break;
         default: SHASTA_LAUNCH_HASH(0); break;
     }
 #undef SHASTA_LAUNCH_HASH
@@ -580,10 +620,7 @@ struct LowHash0Job {
     DeviceBuffer<uint32_t> tableCountsA, tableCountsB, runCounts;
     DeviceBuffer<unsigned long long> scalars, stats, sizeHist;
     DeviceBuffer<shasta_oriented_read_pair> candidatesDevice;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> hashEvents;
-    std::vector<uint64_t> hashRecords;
     static constexpr uint32_t overflowCapacity = 1 << 20;
-    ~LowHash0Job() { for(auto& e : hashEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
 };
 
 namespace {
@@ -669,24 +706,28 @@ void lowhash0Hash(Context& ctx, uint64_t iteration, uint64_t* sendOffsets, const
         job.recKeysA.reserve(job.recCapacity, stream); job.recKeysB.reserve(job.recCapacity, stream);
         job.recValsA.reserve(job.recCapacity, stream); job.recValsB.reserve(job.recCapacity, stream);
         HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
-        hipEvent_t a, b;
-        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-        HIP_CHECK(hipEventRecord(a, stream));
+        const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(job.p.m)), stream);
         launchHash(ctx, uint32_t(job.p.m), iteration * 37, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
             job.recKeysA.data(), job.recValsA.data(), counter, job.recCapacity);
-        HIP_CHECK(hipEventRecord(b, stream));
-        job.hashEvents.push_back(std::make_pair(a, b));
+        const size_t handle = ctx.timers.end(span);
         n = readDevice(counter, stream);
-        job.hashRecords.push_back(std::min(n, job.recCapacity));
+        // Algorithmic bytes of the launch: 4 B per marker read + 12 B per low hash written; work = markers.
+        ctx.timers.amend(handle, 4 * (job.markerEnd - job.markerBegin) + 12 * std::min(n, job.recCapacity), job.markerEnd - job.markerBegin);
         if(n <= job.recCapacity) break;
         job.recCapacity = n + n / 4;           // estimate was too small: grow and redo this iteration
     }
     MI355X_ASSERT(n < (1ULL << 32) - 1);
     // K2: bucket the records (radix partition on the bucket id); bucket owners are contiguous.
     const uint32_t* keys = job.recKeysA.data(); const uint64_t* vals = job.recValsA.data();
-    if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
-        n, int(job.log2BucketCount), ctx.sortWs, stream)) {
-        keys = job.recKeysB.data(); vals = job.recValsB.data();
+    {
+        // K2: 12 bytes per record read + written per 8-bit pass.
+        const uint64_t passes = (job.log2BucketCount + 7) / 8;
+        const KernelTimers::Span span = ctx.timers.begin("radix sort of low-hash records", stream);
+        if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
+            n, int(job.log2BucketCount), ctx.sortWs, stream)) {
+            keys = job.recKeysB.data(); vals = job.recValsB.data();
+        }
+        (void)ctx.timers.end(span, 2 * 12 * n * passes, n);
     }
     if(job.world == 1) {
         sendOffsets[0] = 0; sendOffsets[1] = n;
@@ -735,15 +776,17 @@ void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsI
         job.scanTemp32.reserve(scanTempElements(n + 1), stream);
         job.pairCounts.reserve(n + 1, stream); job.scanTemp64.reserve(scanTempElements(n + 1), stream);
         const unsigned g = divUp(n + 1, 256);
-        hipLaunchKernelGGL(markHeadsKernel<uint32_t>, dim3(g), dim3(256), 0, stream, keys, n, job.flags.data());
-        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), n + 1, job.scanTemp32.data(), stream);
-        hipLaunchKernelGGL(groupStartsKernel<uint32_t>, dim3(g), dim3(256), 0, stream,
-            keys, (const uint32_t*)job.pos.data(), n, job.starts.data());
-        hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
-            keys, vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), n,
-            p.minBucketSize, p.maxBucketSize, job.stats.data(), job.sizeHist.data(),
-            job.overflowSizes.data(), overflowCount, LowHash0Job::overflowCapacity, job.pairCounts.data());
-        exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), n + 1, job.scanTemp64.data(), stream);
+        SHASTA_TIMED(ctx, "bucket boundaries (heads, scan, starts)", stream, 12 * n, n,
+            hipLaunchKernelGGL(markHeadsKernel<uint32_t>, dim3(g), dim3(256), 0, stream, keys, n, job.flags.data());
+            exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), n + 1, job.scanTemp32.data(), stream);
+            hipLaunchKernelGGL(groupStartsKernel<uint32_t>, dim3(g), dim3(256), 0, stream,
+                keys, (const uint32_t*)job.pos.data(), n, job.starts.data()));
+        SHASTA_TIMED(ctx, "bucketStatsKernel + scan of pair counts", stream, 12 * n, n,
+            hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
+                keys, vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), n,
+                p.minBucketSize, p.maxBucketSize, job.stats.data(), job.sizeHist.data(),
+                job.overflowSizes.data(), overflowCount, LowHash0Job::overflowCapacity, job.pairCounts.data());
+            exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), n + 1, job.scanTemp64.data(), stream));
         HIP_CHECK(hipGetLastError());
         bucketsUsed = readDevice(job.pos.data() + n, stream);
         pairCount = readDevice(job.pairCounts.data() + n, stream);
@@ -766,13 +809,19 @@ void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsI
     if(pairCount) {
         MI355X_ASSERT(pairCount < (1ULL << 32) - 1);
         job.pairKeysA.reserve(pairCount, stream); job.pairKeysB.reserve(pairCount, stream);
-        hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
-            vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(),
-            (const uint64_t*)job.pairCounts.data(), n, job.readBits, job.pairKeysA.data());
+        SHASTA_TIMED(ctx, "pairWriteKernel", stream, 8 * pairCount, pairCount,
+            hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
+                vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(),
+                (const uint64_t*)job.pairCounts.data(), n, job.readBits, job.pairKeysA.data()));
         uint64_t* pk = job.pairKeysA.data();
-        if(radixSort<uint64_t, uint32_t, false>(job.pairKeysA.data(), job.pairKeysB.data(), nullptr, nullptr, pairCount, job.pairKeyBits, ctx.sortWs, stream)) {
-            pk = job.pairKeysB.data();
+        {
+            const KernelTimers::Span span = ctx.timers.begin("radix sort of pair keys", stream);
+            if(radixSort<uint64_t, uint32_t, false>(job.pairKeysA.data(), job.pairKeysB.data(), nullptr, nullptr, pairCount, job.pairKeyBits, ctx.sortWs, stream)) {
+                pk = job.pairKeysB.data();
+            }
+            (void)ctx.timers.end(span, 2 * 8 * pairCount * uint64_t((job.pairKeyBits + 7) / 8), pairCount);
         }
+        const KernelTimers::Span runSpan = ctx.timers.begin("run lengths of pair keys (heads, scan, starts, runs)", stream);
         job.flags.reserve(pairCount + 1, stream); job.pos.reserve(pairCount + 1, stream); job.starts.reserve(pairCount + 2, stream);
         job.scanTemp32.reserve(scanTempElements(pairCount + 1), stream);
         const unsigned g = divUp(pairCount + 1, 256);
@@ -786,6 +835,7 @@ void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsI
         hipLaunchKernelGGL(runLengthKernel, dim3(divUp(uniqueCount, 256)), dim3(256), 0, stream,
             (const uint64_t*)pk, (const uint32_t*)job.starts.data(), uniqueCount, job.runKeys.data(), job.runCounts.data());
         HIP_CHECK(hipGetLastError());
+        (void)ctx.timers.end(runSpan, 8 * pairCount + 12 * uniqueCount, pairCount);
     }
     if(job.world == 1 || uniqueCount == 0) {
         for(int r = 0; r <= job.world; r++) sendOffsets[r] = (r == job.world) ? uniqueCount : 0;
@@ -809,6 +859,7 @@ void lowhash0Merge(Context& ctx, const uint64_t* runKeys, const uint32_t* runCou
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
     if(n) {
+        const KernelTimers::Span mergeSpan = ctx.timers.begin("pair table merge (append + sort + fold)", stream);
         const uint64_t merged = job.tableSize + n;
         MI355X_ASSERT(merged < (1ULL << 32) - 1);
         job.tableKeysA.reserve(merged, stream, true); job.tableCountsA.reserve(merged, stream, true);
@@ -840,6 +891,7 @@ void lowhash0Merge(Context& ctx, const uint64_t* runKeys, const uint32_t* runCou
             if(ok != job.tableKeysA.data()) { job.tableKeysA.swap(job.tableKeysB); job.tableCountsA.swap(job.tableCountsB); }
             job.tableSize = folded;
         }
+        (void)ctx.timers.end(mergeSpan, 12 * merged, merged);
     }
     // Per-iteration summary (src/LowHash0.cpp:184-196): this rank's share.
     uint64_t highFrequency = 0;
@@ -886,16 +938,6 @@ void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<s
     HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, job.stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 
-    ctx.times.lowhashHashSeconds = 0; ctx.times.lowhashHashLaunches = 0; ctx.times.lowhashHashBytes = 0;
-    for(size_t k = 0; k < job.hashEvents.size(); k++) {
-        auto& e = job.hashEvents[k];
-        float t = 0;
-        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
-        ctx.times.lowhashHashSeconds += t * 1e-3;
-        ctx.times.lowhashHashLaunches += 1;
-        // Algorithmic bytes of one launch: 4 B per marker read + 12 B per low hash written.
-        ctx.times.lowhashHashBytes += 4 * (job.markerEnd - job.markerBegin) + 12 * job.hashRecords[k];
-    }
     ctx.lowhashJob.reset();
 }
 

@@ -21,8 +21,8 @@ EXPORTS = [
     "shasta_mi355x_align4_batch", "shasta_mi355x_align4_free",
     "shasta_mi355x_create", "shasta_mi355x_destroy",
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids",
-    "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_get_kernel_times",
-    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_banded_dp_many", "shasta_mi355x_calibrate", "shasta_mi355x_dp_forward_version",
+    "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_kernel_table", "shasta_mi355x_kernel_table_reset",
+    "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_banded_dp_many", "shasta_mi355x_calibrate",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish",
@@ -178,12 +178,6 @@ class Library:
             None, None), "shasta_mi355x_banded_dp_many")
         ends = np.cumsum(counts).astype(np.int64)
         return [(out[2 * (e - int(c)):2 * e].reshape(-1, 2), int(s)) for e, c, s in zip(ends, counts, scores)]
-
-    def dp_forward_version(self):
-        v = int(self.lib.shasta_mi355x_dp_forward_version())
-        if v < 0:
-            raise RuntimeError("shasta_mi355x_dp_forward_version failed: %s" % self.lib.shasta_mi355x_last_error().decode())
-        return v
 
     def calibrate(self, nbytes, mode):
         self._check(self.lib.shasta_mi355x_calibrate(C.c_uint64(nbytes), C.c_int(mode)), "shasta_mi355x_calibrate")
@@ -344,11 +338,18 @@ class Context:
             "shasta_mi355x_palindromic_screen")
         return bound
 
-    def kernel_times(self):
-        t = abi.KernelTimes()
-        self.library._check(self.lib.shasta_mi355x_get_kernel_times(C.c_void_p(self.handle), C.byref(t)),
-                            "shasta_mi355x_get_kernel_times")
-        return t
+    def kernel_table(self):
+        """{kernel name: {"seconds", "launches", "bytes", "work"}} accumulated on this context since the last reset."""
+        rows = (abi.KernelStat * 128)()
+        count = C.c_uint64(0)
+        self.library._check(self.lib.shasta_mi355x_kernel_table(C.c_void_p(self.handle), rows, C.c_uint64(128), C.byref(count)),
+                            "shasta_mi355x_kernel_table")
+        return {rows[k].name.decode(): {"seconds": rows[k].seconds, "launches": int(rows[k].launches),
+                                        "bytes": int(rows[k].algorithmicBytes), "work": int(rows[k].work)}
+                for k in range(min(128, count.value))}
+
+    def kernel_table_reset(self):
+        self.library._check(self.lib.shasta_mi355x_kernel_table_reset(C.c_void_p(self.handle)), "shasta_mi355x_kernel_table_reset")
 
 
 _cached = None

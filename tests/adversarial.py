@@ -56,25 +56,6 @@ def read_sets(long_reads=True):
 READ_SET_NAMES = ["degenerate lengths", "tandem repeats", "alphabet of six", "identical, contained, reversed", "long reads"]
 
 
-def select(out, keep):
-    """Per-candidate view of an alignment result: status, ordinals, AlignmentInfo row and compressed
-    bytes of the candidates with keep[i], so that two results can be compared candidate by candidate."""
-    rows = np.cumsum(out.status & 0x7f == abi.SHASTA_ALIGN_STORED) - 1      # row of a stored candidate
-    info = out.info_table()
-    items = []
-    for i in np.flatnonzero(keep):
-        st = int(out.status[i])
-        if (st & 0x7f) != abi.SHASTA_ALIGN_STORED:
-            items.append((i, st, None, None, None)); continue
-        r = int(rows[i])
-        blob = out.compressed_data[int(out.compressed_toc[r]):int(out.compressed_toc[r + 1])].tobytes()
-        ords = None
-        if out.ordinals_toc is not None:
-            ords = out.ordinals[int(out.ordinals_toc[r]):int(out.ordinals_toc[r + 1])].tobytes()
-        items.append((i, st, ords, info[r].tobytes(), blob))
-    return items
-
-
 def aligner_case(lib, oracle_lib, name, long_reads=True):
     reads = dict(read_sets(long_reads))[name]
     toc, kmer, data7 = build(reads)
@@ -89,7 +70,7 @@ def aligner_case(lib, oracle_lib, name, long_reads=True):
     else:
         # A tie between components (reference order = libstdc++ container order) is flagged on both sides;
         # every candidate WITHOUT the flag must still agree in everything.
-        assert select(x, ~ties) == select(y, ~ties), name
+        assert x.per_candidate(~ties) == y.per_candidate(~ties), name
     o3 = abi.default_align3_options(minAlignedMarkerCount=10)
     a = oracle_lib.align3_batch(toc, data7, cand, o3, want_ordinals=True, threads=0)
     b = lib.align3_batch(toc, data7, cand, o3, want_ordinals=True)

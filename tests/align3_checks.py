@@ -1,4 +1,4 @@
-"""Parity checks of align method 3 shared by the GPU tests (tests/test_gpu_zzz_align3.py) and
+"""Parity checks of align method 3 shared by the GPU tests (tests/test_gpu_align3_and_markers.py) and
 their pre-flight on the emulated build (tests/test_emu_kernels.py): `lib` is a
 shasta_amd.lib.Library, everything is compared bit for bit."""
 import numpy as np

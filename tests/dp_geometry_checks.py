@@ -1,11 +1,7 @@
-"""Banded DP of one library against the oracle over a sweep of band geometries (every band class,
-tiny and ragged matrices, bands hanging over every corner, small alphabets = score ties).  Run as a
-script in a process of its own by the tests, because the forward-kernel version
-(SHASTA_MI355X_DP_FORWARD) is fixed once per process:
-
-    python tests/dp_versions_check.py <library.so> <expected version> [seed] [tasks in the batch] [trials per width]
-
-Test infrastructure: the oracle is the checker, the library is what is checked."""
+"""Banded DP of a library against the oracle over a sweep of band geometries (every band class,
+tiny and ragged matrices, bands hanging over every corner, small alphabets = score ties): one task at a
+time (`sweep`) and many tasks of mixed geometry in one batch (`many`: several tasks to a wavefront, as in
+an Align4 batch).  Test infrastructure: the oracle is the checker, the library is what is checked."""
 import os
 import sys
 
@@ -91,25 +87,9 @@ def many(lib, orc, seed, tasks=140):
     return len(spec), bad
 
 
-def main():
-    from oracle import bindings
-    from shasta_amd import lib as libmod
-    lib = libmod.Library(sys.argv[1])
-    expected = int(sys.argv[2])
-    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    version = lib.dp_forward_version()
-    print("forward kernel version", version)
-    if version != expected:
-        sys.exit("expected forward kernel version %d, the library chose %d" % (expected, version))
-    tasks = int(sys.argv[4]) if len(sys.argv) > 4 else 140
-    trials = int(sys.argv[5]) if len(sys.argv) > 5 else 6
-    orc = bindings.OracleLib()
+def check(lib, orc, seed=11, tasks=140, trials=6):
     cases, bad = sweep(lib, orc, seed, trials)
-    print("cases %d bad %d" % (cases, bad))
+    assert bad == 0 and cases >= 12 * trials, (cases, bad)
     batch, bad_in_batch = many(lib, orc, seed + 100, tasks)
-    print("tasks in one batch %d bad %d" % (batch, bad_in_batch))
-    sys.exit(1 if bad or bad_in_batch or cases < 12 * trials or batch < tasks * 2 // 3 else 0)
-
-
-if __name__ == "__main__":
-    main()
+    assert bad_in_batch == 0 and batch >= tasks * 2 // 3, (batch, bad_in_batch)
+    return cases, batch

@@ -89,6 +89,7 @@ hipError_t hipEventCreate(hipEvent_t*);
 hipError_t hipEventDestroy(hipEvent_t);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);
+hipError_t hipEventQuery(hipEvent_t);
 hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int);
 template<class T> hipError_t hipMemcpyFromSymbol(void* dst, const T& symbol, size_t n) { std::memcpy(dst, &symbol, n); return hipSuccess; }

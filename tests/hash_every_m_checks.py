@@ -1,9 +1,5 @@
-"""LowHash0 of one library against the oracle for every window length m = 1 .. 13 (the window-hash kernel K1
-has fixed-m instantiations, a generic one, and two versions: SHASTA_MI355X_HASH=1 is the one without shared
-block transforms).  Run as a script in a process of its own by the tests (the version is fixed per process):
-
-    python tests/hash_versions_check.py <library.so> [reads per set]
-
+"""LowHash0 of a library against the oracle for every window length m = 1 .. 13 through the PRODUCTION window-hash
+kernel (its fixed-m instantiations and the generic one), with palindromic flags set on the first and last read.
 Test infrastructure: the oracle is the checker, the library is what is checked."""
 import os
 import sys
@@ -29,16 +25,3 @@ def sweep(lib, orc, reads=120):
         support.same_lowhash(a, b)
         checked += len(a.candidates)
     return checked
-
-
-def main():
-    from oracle import bindings
-    from shasta_amd import lib as libmod
-    reads = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-    checked = sweep(libmod.Library(sys.argv[1]), bindings.OracleLib(), reads)
-    print("candidates compared", checked)
-    sys.exit(0 if checked > 8 * reads else 1)
-
-
-if __name__ == "__main__":
-    main()

@@ -47,7 +47,7 @@ def test_ctypes_mirror_matches_the_header_layout(tmp_path):
         "shasta_alignment_data": abi.AlignmentData, "shasta_lowhash0_params": abi.LowHash0Params,
         "shasta_lowhash0_result": abi.LowHash0Result, "shasta_align4_options": abi.Align4Options,
         "shasta_align3_options": abi.Align3Options, "shasta_align4_result": abi.Align4Result,
-        "shasta_mi355x_kernel_times": abi.KernelTimes, "shasta_markers_result": abi.MarkersResult,
+        "shasta_mi355x_kernel_stat": abi.KernelStat, "shasta_markers_result": abi.MarkersResult,
     }
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "shasta_mi355x.h"\nint main(void) {\n' +

@@ -12,21 +12,23 @@ import bench
 from shasta_amd import abi
 
 
-class FakeTimes:
-    def __init__(self):
-        self.lowhashHashSeconds, self.lowhashHashLaunches, self.lowhashHashBytes = 0.01, 10, 10 * 1_250_000_000
-        self.alignDpSeconds, self.alignDpLaunches, self.alignDpCells, self.alignBytes = 0.4, 80, 190_000_000_000, 41_000_000_000
-        self.dpForwardSeconds = [0.04, 0.14, 0.10, 0.05, 0.003, 0.0]
-        self.dpForwardLaunches = [16, 16, 16, 16, 1, 0]
-        self.dpForwardCells = [int(1.5e10), int(1.1e11), int(5.5e10), int(1e9), int(1e6), 0]
-        self.dpForwardBytes = [16 * 296_000_000, 16 * 1_186_000_000, 16 * 353_000_000, 16 * 4_600_000, 33_000, 0]
-        self.dpTracebackSeconds, self.dpTracebackLaunches = 0.08, 16
+FAKE_TABLE = {
+    "hashWindowsKernel<4>": {"seconds": 0.02, "launches": 20, "bytes": 20 * 1_250_000_000, "work": 20 * 300_000_000},
+    "radix sort of low-hash records": {"seconds": 0.004, "launches": 20, "bytes": 20 * 300_000_000, "work": 20 * 3_000_000},
+    "align4CellsChunkKernel<2>": {"seconds": 0.22, "launches": 64, "bytes": 64 * 500_000_000, "work": 3_000_000},
+    "bandedDpForwardKernel<16, 2>": {"seconds": 0.08, "launches": 32, "bytes": 32 * 296_000_000, "work": int(3e10)},
+    "bandedDpForwardKernel<32, 2>": {"seconds": 0.28, "launches": 32, "bytes": 32 * 1_186_000_000, "work": int(2.2e11)},
+    "bandedDpForwardKernel<64, 2>": {"seconds": 0.20, "launches": 32, "bytes": 32 * 353_000_000, "work": int(1.1e11)},
+    "dpTracebackKernel<2>": {"seconds": 0.16, "launches": 32, "bytes": 32 * 1_800_000_000, "work": 32 * 150_000},
+}
 
 
 class FakeResult:
     def __init__(self, n):
         self.candidates = abi.make_pairs(np.arange(n), np.arange(n) + 1, np.ones(n))
         self.alignment_data = np.zeros(n - 1, dtype=abi.ALIGNMENT_DATA_DTYPE)
+        self.status = np.zeros(n, np.uint8)
+        self.status[-1] = abi.SHASTA_ALIGN_REJECTED
         self.device_seconds, self.seconds = 0.4, 0.5
 
 
@@ -40,19 +42,17 @@ class FakeContext:
     def align4(self, candidates, o, want_ordinals=False, borrow=False):
         return FakeResult(len(candidates))
 
-    def kernel_times(self):
-        return FakeTimes()
+    def kernel_table(self):
+        return FAKE_TABLE
+
+    def kernel_table_reset(self):
+        pass
 
     def close(self):
         pass
 
 
 class FakeLibrary:
-    version = 1
-
-    def dp_forward_version(self):
-        return self.version
-
     def device_count(self):
         return 1
 
@@ -60,17 +60,22 @@ class FakeLibrary:
         return FakeContext()
 
 
-@pytest.mark.parametrize("dp_version", [1, 2])
-def test_bench_prints_one_contract_line(monkeypatch, capsys, dp_version):
+def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     import torch
     import shasta_amd
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
-    monkeypatch.setattr(FakeLibrary, "version", dp_version)
     monkeypatch.setattr(shasta_amd, "load", lambda: FakeLibrary())
     monkeypatch.setattr(bench, "make_workload", lambda reads, seed: (np.zeros(2 * 10 + 1, np.uint64), np.zeros(0, np.uint32)))
-    monkeypatch.setattr(bench, "cpu_baseline", lambda reads, seed, method=4: {"value": 18000.0, "unit": "candidate read-pairs aligned/s",
-                                                                     "cores": 64, "kind": "reference", "sample": "fake"})
+    monkeypatch.setattr(bench, "cpu_baseline", lambda *a: ({"value": 18000.0, "unit": "candidate read-pairs aligned/s", "cores": 64,
+                                                           "host_cores": 256, "kind": "reference", "sample": "fake"},
+                                                          {"lowhash0_equal": True, "aligner_mismatches": 0}))
+    # Counters as scripts/pmc_summary.py writes them, for the workload of this run.
+    pmc = tmp_path / "pmc.json"
+    pmc.write_text(json.dumps({"workload_reads": 100000, "kernels": {
+        "bandedDpForwardKernel<32, 2>": {"hbm_bytes_per_launch": 2.6e9, "valu_wave_instructions_per_launch": 2.3e9},
+        "hashWindowsKernel<4>": {"hbm_bytes_per_launch": 1.5e9, "valu_wave_instructions_per_launch": 3.6e8}}}))
+    monkeypatch.setattr(bench, "PMC_FILE", str(pmc))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--reads", "100000"])
     bench.main()
@@ -78,23 +83,25 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, dp_version):
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_at_bench_size", "aligner_status"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # The dominant kernel of the fake timings is the <=64-diagonal DP class; the traffic in the committed PMC file was
-    # measured on the first version of the kernel and is not reported for the second.
-    if dp_version == 1:
-        assert r["kernel"] == "bandedDpForwardKernel<32, 2>" and r["traffic"] and r["traffic"] > 1e9
-    else:
-        assert r["kernel"] == "bandedDpForwardKernel2<32, 2>" and r["traffic"] is None and r["dp_forward_version"] == 2
-    assert d["kernels"]["hashWindowsKernel<4>"]["launches_per_step"] == 10
-    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 64
-    assert d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # The dominant kernel of the fake table is the <= 64-diagonal DP class: integer VALU work, with the measured
+    # instruction count of the PMC file over the live launch time as its VALU fraction.
+    assert r["kernel"] == "bandedDpForwardKernel<32, 2>" and r["bound"] == "valu" and r["traffic"] == 2.6e9
+    assert r["valu"]["frac"] == pytest.approx(2.3e9 / (0.28 / 32) / bench.VALU_PEAK_WAVE_INSTRUCTIONS_PER_S)
+    k = d["kernels"]
+    assert k["hashWindowsKernel<4>"]["launches_per_step"] == 10 and k["hashWindowsKernel<4>"]["avg_ms"] == pytest.approx(1.0)
+    assert k["hashWindowsKernel<4>"]["achieved_GBps"] == pytest.approx(1250.0)
+    assert sum(v["share_of_kernel_time"] for v in k.values()) == pytest.approx(1.0)
+    assert d["hbm_natured_kernel"]["kernel"] == "hashWindowsKernel<4>" and d["hbm_natured_kernel"]["traffic"] == 1.5e9
+    assert d["aligner_status"]["stored"] == 999 and d["aligner_status"]["rejected_by_filters"] == 1
+    assert d["cpu_baseline"]["cores"] == 64 and d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)
 
 
 def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
@@ -114,6 +121,9 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert "NOT A MEASUREMENT" in line["data"] and line["n_gpus"] == 1 and line["value"] > 0
     assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(line["roofline"])
     assert set(["value", "unit", "cores", "kind", "sample"]) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["value"] > 0
+    parity = line["parity_at_bench_size"]
+    assert parity["lowhash0_equal"] is True and parity["aligner_mismatches"] == 0 and parity["aligner_tie_flags_equal"] is True
+    assert any(k.startswith("align4CellsChunkKernel") for k in line["kernels"]) and any(k.startswith("dpTracebackKernel") for k in line["kernels"])
     assert line["config"]["candidates"] > 0 and "workload" in line["config"]
 
 

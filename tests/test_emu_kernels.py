@@ -60,8 +60,9 @@ def test_lowhash0_and_align4(emu_lib, oracle_lib):
     with emu_lib.context(0) as ctx:
         ctx.set_kmer_ids(toc, kmer)
         z = ctx.align4(cand, o)
-        t = ctx.kernel_times()
-    assert sum(t.dpForwardCells) == z.dp_cell_count == x.dp_cell_count and sum(t.dpForwardBytes) > 0
+        t = ctx.kernel_table()
+    forward = [v for k, v in t.items() if k.startswith("bandedDpForwardKernel")]
+    assert sum(v["work"] for v in forward) == z.dp_cell_count == x.dp_cell_count and sum(v["bytes"] for v in forward) > 0
     if not (x.status & 0x80).any():
         support.same_align(x, y)
     else:
@@ -150,34 +151,14 @@ def test_two_ranks_equal_single_process_oracle(emu_lib, oracle_lib):
 
 
 
-@pytest.mark.parametrize("version", [1, 2, 0])
-def test_forward_dp_versions(emu_lib, oracle_lib, version):
-    """Both forward kernels (0: the library's own choice after its start-up comparison, which must be
-    the second) against the oracle over a geometry sweep -- each in a process of its own, the
-    version is fixed per process."""
-    import subprocess
-    import sys
-    env = dict(os.environ)
-    env.pop("SHASTA_MI355X_DP_FORWARD", None)
-    if version:
-        env["SHASTA_MI355X_DP_FORWARD"] = str(version)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_versions_check.py"), emu_lib.path, str(version or 2), "5", "48", "3"],
-                         env=env, capture_output=True, text=True, timeout=1200)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+def test_banded_dp_geometries_against_oracle(emu_lib, oracle_lib):
+    from tests import dp_geometry_checks
+    dp_geometry_checks.check(emu_lib, oracle_lib, seed=5, tasks=48, trials=3)
 
 
-@pytest.mark.parametrize("version", [1, 2])
-def test_window_hash_kernel_versions_for_every_m(emu_lib, version):
-    """K1 with and without shared block transforms, m = 1 .. 13, through LowHash0 against the oracle."""
-    import subprocess
-    import sys
-    env = dict(os.environ)
-    env.pop("SHASTA_MI355X_HASH", None)
-    if version == 1:
-        env["SHASTA_MI355X_HASH"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hash_versions_check.py"), emu_lib.path, "60"],
-                         env=env, capture_output=True, text=True, timeout=1200)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+def test_window_hash_kernel_for_every_m(emu_lib, oracle_lib):
+    from tests import hash_every_m_checks
+    assert hash_every_m_checks.sweep(emu_lib, oracle_lib, reads=60) > 8 * 60
 
 
 def test_randomized_campaign(emu_lib, oracle_lib):

@@ -1,7 +1,5 @@
-"""Align method 3 (Assembler::alignOrientedReads3) on the MI355X through the C ABI: bit-exact
-against fixtures made by the reference's own code and against the oracle.  Named to run last:
-this path was written after the round's GPU access closed and has so far only run on the
-emulated build (tests/test_emu_kernels.py)."""
+"""Align method 3 (Assembler::alignOrientedReads3) and marker finding (MarkerFinder) on the MI355X through the
+C ABI: bit-exact against fixtures made by the reference's own code and against the oracle."""
 import pytest
 
 from tests import align3_checks, support
@@ -53,29 +51,3 @@ def test_find_markers_stage_on_a_data_directory(gpu_lib, tmp_path):
     import shasta_amd.assembler as shasta
     from tests import mirror_checks
     mirror_checks.find_markers_on_a_data_directory(tmp_path, shasta.HOST_SO)
-
-
-from tests import adversarial
-
-
-@pytest.mark.parametrize("name", adversarial.READ_SET_NAMES)
-def test_adversarial_read_sets_through_both_aligners(gpu_lib, oracle_lib, name):
-    adversarial.aligner_case(gpu_lib, oracle_lib, name)
-
-
-@pytest.mark.parametrize("name", adversarial.LOWHASH_CASE_NAMES)
-def test_adversarial_lowhash0_parameters(gpu_lib, oracle_lib, name):
-    adversarial.lowhash_case(gpu_lib, oracle_lib, name)
-
-
-@pytest.mark.parametrize("name", adversarial.LOWHASH_READ_SET_NAMES)
-def test_adversarial_lowhash0_read_sets(gpu_lib, oracle_lib, name):
-    adversarial.lowhash_read_set(gpu_lib, oracle_lib, name)
-
-
-def test_lowhash0_rejects_a_bucket_count_below_the_minimum(gpu_lib):
-    adversarial.lowhash_rejects_small_bucket_count(gpu_lib)
-
-
-def test_task_list_overflow(gpu_lib, oracle_lib, monkeypatch):
-    adversarial.task_list_overflow(gpu_lib, oracle_lib, monkeypatch)

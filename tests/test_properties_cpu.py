@@ -1,5 +1,5 @@
 """The property checker of tests/properties.py against the ORACLE's outputs on a small read set: proves
-the checker itself right (it is then applied to the large GPU runs in tests/test_gpu_zzzz_large_properties.py)."""
+the checker itself right (it is then applied to the large GPU runs in tests/test_gpu_large_properties.py)."""
 import numpy as np
 import pytest
 
