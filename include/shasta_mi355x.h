@@ -265,16 +265,19 @@ int shasta_mi355x_align4_run(
  *     lh_hash     K1+K2: records {bucketId u32} / {hashHigh:32 | orientedReadId:32 u64}, sorted by
  *                 bucket id; sendOffsets[r..r+1] = the records rank r owns
  *       -- all-to-all of records --
- *     lh_buckets  K3-K5a on the n received records: statistics (partial sums kept on the device),
- *                 bucket-size histogram bins [0,2048) + list of larger sizes, bucketsUsed, and the
- *                 run-length encoded pair keys {key u64}/{count u32}, sorted; sendOffsets by owner
- *                 of readId0
- *       -- all-to-all of runs --
- *     lh_merge    K5b: fold the n received runs into this rank's pair table; this rank's share of
- *                 the iteration's "high frequency" and "total" counters (all-reduce them)
- *   lh_finish  K6: this rank's candidates (sorted; concatenating the ranks in order gives the
- *              reference's order) -- free with shasta_mi355x_free -- and its partial
- *              readLowHashStatistics[readCount*3] (all-reduce them).
+ *     lh_buckets  K3 + K4 on the n received records: statistics (partial sums kept on the device),
+ *                 bucket-size histogram bins [0,2048) + list of larger sizes, bucketsUsed, and this
+ *                 iteration's pair keys {u64: readId0 | readId1 | strand bit}, sorted; sendOffsets by
+ *                 owner of readId0
+ *       -- all-to-all of pair keys (8 bytes each) --
+ *     lh_merge    appends the n received keys to this rank's keys of all iterations.  With evaluateNow
+ *                 (needed after every iteration only when minHashIterationCount = 0) it also evaluates
+ *                 them: this rank's share of the latest iteration's "high frequency" and "total"
+ *                 counters (all-reduce them); otherwise both come back 0
+ *   lh_finish  K5 + K6: evaluates the keys of all iterations at once; this rank's candidates (sorted;
+ *              concatenating the ranks in order gives the reference's order) -- free with
+ *              shasta_mi355x_free --, its partial readLowHashStatistics[readCount*3] and its share of
+ *              the per-iteration "high frequency" / "total" counters (all-reduce all three).
  * ------------------------------------------------------------------------- */
 #define SHASTA_MI355X_SIZE_HISTOGRAM_BINS 2048
 int shasta_mi355x_lh_begin(shasta_mi355x_ctx*, const shasta_lowhash0_params* params, int rank, int worldSize,
@@ -282,12 +285,13 @@ int shasta_mi355x_lh_begin(shasta_mi355x_ctx*, const shasta_lowhash0_params* par
 int shasta_mi355x_lh_hash(shasta_mi355x_ctx*, uint64_t iteration, uint64_t* sendOffsets,
     const void** keysDevice, const void** valsDevice);
 int shasta_mi355x_lh_buckets(shasta_mi355x_ctx*, const void* keysDevice, const void* valsDevice, uint64_t n,
-    uint64_t* sendOffsets, const void** runKeysDevice, const void** runCountsDevice, uint64_t* bucketsUsed,
+    uint64_t* sendOffsets, const void** pairKeysDevice, uint64_t* bucketsUsed,
     uint64_t* sizeHistogram, uint32_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount);
-int shasta_mi355x_lh_merge(shasta_mi355x_ctx*, const void* runKeysDevice, const void* runCountsDevice, uint64_t n,
-    uint64_t* highFrequency, uint64_t* tableSize);
+int shasta_mi355x_lh_merge(shasta_mi355x_ctx*, const void* pairKeysDevice, uint64_t n, int evaluateNow,
+    uint64_t* highFrequency, uint64_t* total);
 int shasta_mi355x_lh_finish(shasta_mi355x_ctx*, uint64_t* readLowHashStatistics,
-    shasta_oriented_read_pair** candidates, uint64_t* candidateCount);
+    shasta_oriented_read_pair** candidates, uint64_t* candidateCount,
+    uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount);
 void shasta_mi355x_free(void*);
 /* Synchronous copy on the context's stream; kind 0 host->device, 1 device->host, 2 device->device. */
 int shasta_mi355x_memcpy(shasta_mi355x_ctx*, void* dst, const void* src, uint64_t bytes, int kind);

@@ -134,12 +134,35 @@ struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; hipStream_t 
 
 constexpr int CELLS_CLASSES = 3;
 constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {11, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
-constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {11, 12, 12};
+// Timing experiments compile other geometries (make EXTRA=-DSHASTA_CELLS_SC0=9 ...): the LDS a workgroup takes
+// decides how many wavefronts a CU holds, and the cells kernels are bound by latency, not by instruction issue.
+#ifndef SHASTA_CELLS_SC0
+#define SHASTA_CELLS_SC0 11
+#endif
+#ifndef SHASTA_CELLS_SC1
+#define SHASTA_CELLS_SC1 12
+#endif
+#ifndef SHASTA_CELLS_SC2
+#define SHASTA_CELLS_SC2 12
+#endif
+#ifndef SHASTA_CELLS_WAVES0
+#define SHASTA_CELLS_WAVES0 4
+#endif
+#ifndef SHASTA_CELLS_WAVES1
+#define SHASTA_CELLS_WAVES1 6
+#endif
+#ifndef SHASTA_CELLS_WAVES2
+#define SHASTA_CELLS_WAVES2 4
+#endif
+#ifndef SHASTA_CELLS_ESTIMATE_SHIFT
+#define SHASTA_CELLS_ESTIMATE_SHIFT 13
+#endif
+constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2};
 constexpr int CELLS_Q[CELLS_CLASSES] = {2, 4, 4};
-constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {4, 6, 4};   // waves of a chunk that share the tabled read
+constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {SHASTA_CELLS_WAVES0, SHASTA_CELLS_WAVES1, SHASTA_CELLS_WAVES2};   // waves of a chunk that share the tabled read
 constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 16};
 constexpr uint32_t CELLS_SHARE_MIN = 3;
-constexpr int ALIGN_DEFAULT_WORKERS = 2;                       // host workers (streams) that pipeline the batches of one call                        // smaller chunks run as one wave
+constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call                        // smaller chunks run as one wave
 
 // kind 0: one-wave workgroups; kind 1: CELLS_SHARED_WAVES waves share the table.
 template<int Q>
@@ -147,12 +170,10 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
     const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, waves) * sizeof(uint32_t);
-    static bool attributeSet = false;
-    if(!attributeSet) {
+    std::call_once(ctx.cellsLdsAttribute[Q == 2 ? 0 : 1], [] {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attributeSet = true;
-    }
+    });
     MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
     // Booked under the template instance that runs (class 0: Q = 2; classes 1 and 2: Q = 4), the name a profiler shows.
     // Algorithmic bytes: 4 (nx + ny) per candidate, summed by the caller; work = candidates.
@@ -301,12 +322,24 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
             hipLaunchKernelGGL(kernel, dim3(divUp(end - begin, 256)), dim3(256), 0, stream,
                 in.pairs, in.tasks, f.sortedIds, begin, end,
                 (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
-                (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
+                (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data()));
         HIP_CHECK(hipGetLastError());
     };
+    // The wide classes are a handful of long walks (long reads have wide bands): a launch that lasts as long as its longest
+    // path and occupies a few wavefronts.  They run on the side stream beside the narrow classes.
+    const bool forkWide = ws.wide != nullptr && ev != nullptr && f.taskStart[DP_CLASSES] > f.taskStart[3] && f.taskStart[3] > 0;
+    hipStream_t main = stream;
+    if(forkWide) { HIP_CHECK(hipEventRecord(ev->fork, main)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); stream = ws.wide; }
     traceback("dpTracebackWideKernel<32>", 4, 5, dpTracebackWideKernel<32>);       // the longest walks first
     traceback("dpTracebackKernel<4>", 3, 3, dpTracebackKernel<4>);
+    if(forkWide) { HIP_CHECK(hipEventRecord(ev->join, ws.wide)); stream = main; }
     traceback("dpTracebackKernel<2>", 0, 2, dpTracebackKernel<2>);
+    if(forkWide) HIP_CHECK(hipStreamWaitEvent(main, ev->join, 0));
+    // Booked: 8 bytes per aligned pair are read (unknown here: at most min(nx, ny) per task; the caller amends nothing) -- work = tasks.
+    SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, taskCount,
+        hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(taskCount) * WAVE, 256)), dim3(256), 0, stream,
+            in.pairs, in.tasks, taskCount, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
+    HIP_CHECK(hipGetLastError());
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[8 + c]; stats->tasks[c] = f.classCounts[c]; }
     return f.sums[0];
 }
@@ -393,7 +426,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         dpOpt.minAlignedMarkerCount = 0; dpOpt.minAlignedFraction = 0.;
         dpOpt.maxSkip = dpOpt.maxDrift = dpOpt.maxTrim = ~0ULL;
     }
-    const uint64_t BATCH = 1ULL << 17;
+    // Candidates per batch (SHASTA_MI355X_ALIGN_BATCH_LOG2 overrides it for timing experiments, 10 .. 20).
+    static const uint64_t BATCH = [] {
+        const char* e = std::getenv("SHASTA_MI355X_ALIGN_BATCH_LOG2");
+        const int l = e ? std::atoi(e) : 17;
+        return 1ULL << std::min(std::max(l, 10), 20);
+    }();
     const uint64_t batchCount = (candidateCount + BATCH - 1) / BATCH;
 
     if(borrowed && !ctx.alignStore) ctx.alignStore = std::make_shared<AlignStore>();
@@ -555,8 +593,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 b.wideTasks.reserve(count, stream); b.wideEnds.reserve(count, stream); b.trace.reserve(words + 64, stream);
                 HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), wide.data() + begin, count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
                 const size_t ldsBytes = 3 * size_t(rowWords) * sizeof(int32_t);
-                static std::once_flag attributeOnce;
-                std::call_once(attributeOnce, [] {
+                std::call_once(ctx.wideDpLdsAttribute, [] {
                     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
                 });
@@ -599,7 +636,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 // Cell indices must fit the packed word and the single-multiply division must be exact.
                 if((nx + ny) / opt.deltaX >= (1ULL << CELLS_IX_BITS) || (nx + ny) / opt.deltaY >= (1ULL << CELLS_IY_BITS)) return CELLS_CLASSES;
                 if((nx + ny) * std::max<uint64_t>(opt.deltaX, opt.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
-                const uint64_t cells = (nx * ny >> 13) + (nx + ny) / 32 + 32;
+                const uint64_t cells = (nx * ny >> SHASTA_CELLS_ESTIMATE_SHIFT) + (nx + ny) / 32 + 32;
                 for(int c = 0; c < CELLS_CLASSES; c++) {
                     if(tabled < (1ULL << CELLS_NA_LOG2[c]) && 4 * cells <= (3ULL << CELLS_SC_LOG2[c])) return c;
                 }
@@ -959,18 +996,33 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
     }
     result.compressedToc[0] = 0;
-    uint64_t rowBase = 0, byteBase = 0, ordBase = 0;
+    // Every batch's share of the output arrays is known now: the copies (a few hundred megabytes) run on as many
+    // host threads as there were workers instead of one.
+    std::vector<uint64_t> rowBases(batchCount + 1, 0), byteBases(batchCount + 1, 0), ordBases(batchCount + 1, 0);
     for(uint64_t k = 0; k < batchCount; k++) {
-        const BatchOutput& o = outputs[k];
-        if(!o.rows.empty()) std::memcpy(result.alignmentData + rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
-        if(!o.bytes.empty()) std::memcpy(result.compressedData + byteBase, o.bytes.data(), o.bytes.size());
-        for(size_t q = 0; q < o.tocEnds.size(); q++) result.compressedToc[rowBase + q + 1] = byteBase + o.tocEnds[q];
-        if(wantOrdinals) {
-            if(!o.ordinals.empty()) std::memcpy(result.ordinals + 2 * ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
-            for(size_t q = 1; q < o.ordToc.size(); q++) result.ordinalsToc[k * BATCH + q] = ordBase + o.ordToc[q];
-            ordBase += o.ordinals.size() / 2;
+        rowBases[k + 1] = rowBases[k] + outputs[k].rows.size();
+        byteBases[k + 1] = byteBases[k] + outputs[k].bytes.size();
+        ordBases[k + 1] = ordBases[k] + outputs[k].ordinals.size() / 2;
+    }
+    auto assemble = [&](uint64_t first, uint64_t stride) {
+        for(uint64_t k = first; k < batchCount; k += stride) {
+            const BatchOutput& o = outputs[k];
+            const uint64_t rowBase = rowBases[k], byteBase = byteBases[k], ordBase = ordBases[k];
+            if(!o.rows.empty()) std::memcpy(result.alignmentData + rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
+            if(!o.bytes.empty()) std::memcpy(result.compressedData + byteBase, o.bytes.data(), o.bytes.size());
+            for(size_t q = 0; q < o.tocEnds.size(); q++) result.compressedToc[rowBase + q + 1] = byteBase + o.tocEnds[q];
+            if(wantOrdinals) {
+                if(!o.ordinals.empty()) std::memcpy(result.ordinals + 2 * ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
+                for(size_t q = 1; q < o.ordToc.size(); q++) result.ordinalsToc[k * BATCH + q] = ordBase + o.ordToc[q];
+            }
         }
-        rowBase += o.rows.size(); byteBase += o.bytes.size();
+    };
+    {
+        const uint64_t threads = std::min<uint64_t>(uint64_t(workerCount), std::max<uint64_t>(1, batchCount));
+        std::vector<std::thread> others;
+        for(uint64_t k = 1; k < threads; k++) others.emplace_back(assemble, k, threads);
+        assemble(0, threads);
+        for(std::thread& t : others) t.join();
     }
 
     result.alignmentCount = rowTotal;

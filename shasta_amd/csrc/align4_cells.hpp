@@ -353,8 +353,11 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
     return 2 * (size_t(1) << naLog2) + size_t(waves) * cellsWaveLdsWords(scLog2, Q);
 }
 
+#ifndef SHASTA_CELLS_MAX_THREADS
+#define SHASTA_CELLS_MAX_THREADS 384
+#endif
 template<int Q>
-__global__ void __launch_bounds__(384)
+__global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS)
 align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,

@@ -401,67 +401,19 @@ bandedDpForwardKernel(
 //    of the launch is made of short paths.
 // Tasks with C = 8 or 16 diagonals per lane (bands wider than 512: a handful per batch) walk through an LDS window
 // instead (dpTracebackWideKernel): the unrolled select chain over C record pairs would not pay.
-struct TracebackWalk {
-    uint32_t pos, count, prevX, prevY, last0, last1, first0, first1, maxSkip, maxDrift;
-    int32_t minOffset, maxOffset;
-    long long sumOffset;
-};
-
-// A diagonal step over equal kmers at cell (i, j): an aligned marker pair (src/Align4.cpp:1057-1061).
-__device__ __forceinline__ void tracebackMatch(TracebackWalk& w, int32_t i, int32_t j, uint64_t ordBase, uint32_t* __restrict__ ordScratch)
-{
-    const uint32_t x = uint32_t(i - 1), y = uint32_t(j - 1);
-    --w.pos;
-    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + w.pos)) = make_uint2(x, y);
-    const int32_t offset = int32_t(x) - int32_t(y);
-    if(w.count == 0) { w.last0 = x; w.last1 = y; }
-    else {
-        w.maxSkip = max(w.maxSkip, max(w.prevX - x, w.prevY - y));
-        const int32_t prevOffset = int32_t(w.prevX) - int32_t(w.prevY);
-        const int32_t drift = offset - prevOffset;
-        w.maxDrift = max(w.maxDrift, uint32_t(drift < 0 ? -drift : drift));
-    }
-    w.minOffset = min(w.minOffset, offset); w.maxOffset = max(w.maxOffset, offset);
-    w.sumOffset += offset;
-    w.first0 = x; w.first1 = y; w.prevX = x; w.prevY = y;
-    ++w.count;
-}
-
-// The DpResult of a finished walk, the inner acceptance of src/Align4.cpp:944-981, the candidate's best component.
-__device__ __forceinline__ void tracebackFinish(const TracebackWalk& w, const DpTask& task, const PairDesc& pd, const DpEnd& e, uint64_t ordBase,
-    uint32_t t, const DeviceOptions& opt, DpResult* __restrict__ results, unsigned long long* __restrict__ pairBest)
+// The walk itself only stores the aligned pairs (from the end of the task's ordinal range downwards) and counts
+// them; everything that can be computed from the stored pairs afterwards -- AlignmentInfo's metrics, the inner
+// acceptance -- is computed by dpMetricsKernel, a wavefront per task, in parallel: each instruction taken out of the
+// walk shortens the critical path of the launch (its longest path) by one issue slot per step.
+__device__ __forceinline__ void tracebackFinish(uint32_t pos, const PairDesc& pd, const DpEnd& e, uint64_t ordBase, uint32_t t, DpResult* __restrict__ results)
 {
     DpResult r;
-    r.ordBegin = ordBase + w.pos;
-    r.sumOffset = w.sumOffset;
-    r.markerCount = w.count; r.first0 = w.first0; r.first1 = w.first1; r.last0 = w.last0; r.last1 = w.last1;
-    r.minOffset = w.minOffset; r.maxOffset = w.maxOffset; r.maxSkip = w.maxSkip; r.maxDrift = w.maxDrift;
-    r.score = e.score; r.pad = 0;
-    bool pass = w.count > 0 && uint64_t(w.count) >= opt.minAlignedMarkerCount;
-    if(pass) {
-        const double f0 = double(w.count) / double(w.last0 + 1 - w.first0);
-        const double f1 = double(w.count) / double(w.last1 + 1 - w.first1);
-        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
-        if(uint64_t(w.maxSkip) > opt.maxSkip || uint64_t(w.maxDrift) > opt.maxDrift) pass = false;
-        const uint32_t leftTrim = min(w.first0, w.first1);
-        const uint32_t rightTrim = min(pd.nx - 1 - w.last0, pd.ny - 1 - w.last1);
-        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
-    }
-    r.passes = pass ? 1u : 0u;
+    r.ordBegin = ordBase + pos;
+    r.sumOffset = 0;
+    r.markerCount = min(pd.nx, pd.ny) - pos;
+    r.first0 = r.first1 = r.last0 = r.last1 = 0; r.minOffset = r.maxOffset = 0; r.maxSkip = r.maxDrift = 0;
+    r.passes = 0; r.score = e.score; r.pad = 0;
     results[t] = r;
-    // Best component = most aligned markers (:132-139); ties resolved towards the
-    // component whose first cell in (iY,iX) order comes first, and flagged later.
-    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)w.count << 32) | (unsigned long long)(0xffffffffu - task.label));
-}
-
-__device__ __forceinline__ TracebackWalk tracebackBegin(const PairDesc& pd)
-{
-    TracebackWalk w;
-    w.pos = min(pd.nx, pd.ny);
-    w.count = w.prevX = w.prevY = w.last0 = w.last1 = w.first0 = w.first1 = w.maxSkip = w.maxDrift = 0;
-    w.minOffset = 0x7fffffff; w.maxOffset = int32_t(0x80000000);
-    w.sumOffset = 0;
-    return w;
 }
 
 // Tasks [taskBegin, taskEnd) of the sorted list, all of a class with C diagonals per lane (C = 2 or 4).
@@ -470,8 +422,7 @@ __global__ void __launch_bounds__(256)
 dpTracebackKernel(
     const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
     const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
-    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
 {
     static_assert(C == 2 || C == 4, "register-resident chunks: C = 2 or 4");
     constexpr int QUADS = 16;                              // 16-byte pieces of a 256-byte chunk
@@ -485,30 +436,39 @@ dpTracebackKernel(
     const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
     const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
     const uint64_t ordBase = ordOffsets[t];
-    TracebackWalk w = tracebackBegin(pd);
+    uint32_t pos = min(pd.nx, pd.ny);                      // aligned pairs are stored from the end of the task's range downwards
     int32_t i = e.bestI, j = e.bestJ;
     bool active = e.score > NEG_SCORE && i > 0 && j > 0;
-    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) / uint32_t(IPC)) : -1;
+    // The walk in terms of the iteration relative to the current chunk: rel = iteration - chunk * IPC runs down from
+    // IPC - 1 (or from the end cell's iteration in the first chunk) to -1, where the chunk is exhausted.
+    int32_t chunk = active ? int32_t((uint32_t(i + j - geo.s0) >> 1) / uint32_t(IPC)) : -1;
     uint4 cur[QUADS], next[QUADS];
 #pragma unroll
-    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[chunk * QUADS + q] : make_uint4(0, 0, 0, 0);
+    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[int64_t(chunk) * QUADS + q] : make_uint4(0, 0, 0, 0);
     while(__any(active)) {
+        // An aligned pair found in iteration u of this chunk (at most one per iteration: it is a diagonal step out of the
+        // iteration) waits in matchX[u], matchY[u]; the pairs are stored together when the chunk is done.  A store inside
+        // the walk would make the walk wait for the prefetch below each time: loads and stores retire through one in-order
+        // counter, and the store's data registers may only be overwritten once it has retired.
+        uint32_t matchX[IPC], matchY[IPC], matched = 0;
         if(active) {
 #pragma unroll
             for(int q = 0; q < QUADS; q++) cur[q] = next[q];
             if(chunk > 0) {
 #pragma unroll
-                for(int q = 0; q < QUADS; q++) next[q] = tr[(chunk - 1) * QUADS + q];
+                for(int q = 0; q < QUADS; q++) next[q] = tr[int64_t(chunk - 1) * QUADS + q];
             }
         }
+        const int32_t iterationBase = chunk * IPC;
         // The iterations of this chunk in descending order; in each, at most two cells of the path (the cell of the
         // odd anti-diagonal, then the one of the even anti-diagonal).
 #pragma unroll
         for(int u = IPC - 1; u >= 0; u--) {
+            matchX[u] = 0; matchY[u] = 0;
 #pragma unroll
             for(int cellOfIteration = 0; cellOfIteration < 2; cellOfIteration++) {
-                const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
-                if(active && int64_t(it / uint32_t(IPC)) == chunk && int(it % uint32_t(IPC)) == u) {
+                const int32_t rel = ((i + j - geo.s0) >> 1) - iterationBase;
+                if(active && rel == u) {
                     const uint32_t b = uint32_t(i - j - task.bandMin);
                     const uint32_t c = b % uint32_t(C), bit = e.laneBase + b / uint32_t(C);
                     uint4 rec = cur[u * C];
@@ -516,16 +476,21 @@ dpTracebackKernel(
                     for(int cc = 1; cc < C; cc++) if(c == uint32_t(cc)) rec = cur[u * C + cc];
                     const uint32_t lo = (bit & 32u) ? rec.y : rec.x, hi = (bit & 32u) ? rec.w : rec.z;
                     const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
-                    if(dir == 0u) tracebackMatch(w, i, j, ordBase, ordScratch);
+                    // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
+                    if(dir == 0u) { matchX[u] = uint32_t(i - 1); matchY[u] = uint32_t(j - 1); matched |= 1u << u; }
                     i -= (dir != 2u) ? 1 : 0;
                     j -= (dir != 3u) ? 1 : 0;
                     active = i > 0 && j > 0;
                 }
             }
         }
+#pragma unroll
+        for(int u = IPC - 1; u >= 0; u--) {
+            if(matched & (1u << u)) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(matchX[u], matchY[u]); }
+        }
         --chunk;
     }
-    tracebackFinish(w, task, pd, e, ordBase, t, opt, results, pairBest);
+    tracebackFinish(pos, pd, e, ordBase, t, results);
 }
 
 // Tasks [taskBegin, taskEnd) of the classes with 8 or 16 diagonals per lane: the chunk under the path sits in the
@@ -535,8 +500,7 @@ __global__ void __launch_bounds__(256)
 dpTracebackWideKernel(
     const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
     const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch,
-    DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
 {
     constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
     __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
@@ -553,7 +517,7 @@ dpTracebackWideKernel(
     static_assert(CW == 32, "chunk geometry");
     const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
     const uint64_t ordBase = ordOffsets[t];
-    TracebackWalk w = tracebackBegin(pd);
+    uint32_t pos = min(pd.nx, pd.ny);                      // aligned pairs are stored from the end of the task's range downwards
     int32_t i = e.bestI, j = e.bestJ;
     // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
     // the same point of the program, then walks until its path leaves the chunk.  The wave waits
@@ -581,12 +545,68 @@ dpTracebackWideKernel(
             const uint4 rec = window[piece * 256 + threadIdx.x];
             const uint32_t lo = (bit & 32u) ? rec.y : rec.x, hi = (bit & 32u) ? rec.w : rec.z;
             const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
-            if(dir == 0u) tracebackMatch(w, i, j, ordBase, ordScratch);
+            if(dir == 0u) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(uint32_t(i - 1), uint32_t(j - 1)); }
             i -= (dir != 2u) ? 1 : 0;
             j -= (dir != 3u) ? 1 : 0;
             active = i > 0 && j > 0;
         }
         --chunk;
     }
-    tracebackFinish(w, task, pd, e, ordBase, t, opt, results, pairBest);
+    tracebackFinish(pos, pd, e, ordBase, t, results);
+}
+
+// AlignmentInfo's metrics of every task from its stored pairs (src/Alignment.cpp:67-113, :4-31), the inner acceptance
+// (src/Align4.cpp:944-981) and the candidate's best component (:132-139).  One wavefront per task: the pairs of a task
+// are contiguous and ascending, 8 bytes per lane per round.
+__global__ void __launch_bounds__(256)
+dpMetricsKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
+    const uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if(t >= taskCount) return;
+    const int lane = laneId();
+    DpResult r = results[t];
+    const uint32_t count = r.markerCount;
+    const uint2* __restrict__ p = reinterpret_cast<const uint2*>(ordScratch + 2 * r.ordBegin);
+    int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
+    long long sumOffset = 0;
+    uint32_t maxSkip = 0, maxDrift = 0;
+    for(uint32_t k = uint32_t(lane); k < count; k += WAVE) {
+        const uint2 a = p[k];
+        const int32_t offset = int32_t(a.x) - int32_t(a.y);
+        minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
+        sumOffset += offset;
+        if(k + 1 < count) {
+            const uint2 n = p[k + 1];
+            maxSkip = max(maxSkip, max(n.x - a.x, n.y - a.y));
+            const int32_t drift = (int32_t(n.x) - int32_t(n.y)) - offset;
+            maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
+        }
+    }
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) {
+        minOffset = min(minOffset, __shfl_xor(minOffset, d, WAVE)); maxOffset = max(maxOffset, __shfl_xor(maxOffset, d, WAVE));
+        sumOffset += __shfl_xor(sumOffset, d, WAVE);
+        maxSkip = max(maxSkip, uint32_t(__shfl_xor(int(maxSkip), d, WAVE))); maxDrift = max(maxDrift, uint32_t(__shfl_xor(int(maxDrift), d, WAVE)));
+    }
+    if(lane != 0) return;
+    const PairDesc pd = pairs[tasks[t].pair];
+    if(count) { const uint2 f = p[0], l = p[count - 1]; r.first0 = f.x; r.first1 = f.y; r.last0 = l.x; r.last1 = l.y; }
+    r.minOffset = minOffset; r.maxOffset = maxOffset; r.sumOffset = sumOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+    if(pass) {
+        const double f0 = double(count) / double(r.last0 + 1 - r.first0);
+        const double f1 = double(count) / double(r.last1 + 1 - r.first1);
+        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
+        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
+        const uint32_t leftTrim = min(r.first0, r.first1);
+        const uint32_t rightTrim = min(pd.nx - 1 - r.last0, pd.ny - 1 - r.last1);
+        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
+    }
+    r.passes = pass ? 1u : 0u;
+    results[t] = r;
+    // Best component = most aligned markers (:132-139); ties resolved towards the
+    // component whose first cell in (iY,iX) order comes first, and flagged later.
+    if(pass) atomicMax(&pairBest[tasks[t].pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - tasks[t].label));
 }

@@ -107,40 +107,45 @@ int shasta_mi355x_lh_hash(shasta_mi355x_ctx* c, uint64_t iteration, uint64_t* se
 }
 
 int shasta_mi355x_lh_buckets(shasta_mi355x_ctx* c, const void* keysDevice, const void* valsDevice, uint64_t n,
-    uint64_t* sendOffsets, const void** runKeysDevice, const void** runCountsDevice, uint64_t* bucketsUsed,
+    uint64_t* sendOffsets, const void** pairKeysDevice, uint64_t* bucketsUsed,
     uint64_t* sizeHistogram, uint32_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount)
 {
     API_BEGIN
-    if(!c || !sendOffsets || !runKeysDevice || !runCountsDevice || !bucketsUsed || !sizeHistogram || !overflowCount) throw std::runtime_error("lh_buckets: null argument");
-    const uint64_t* rk = nullptr; const uint32_t* rc = nullptr;
+    if(!c || !sendOffsets || !pairKeysDevice || !bucketsUsed || !sizeHistogram || !overflowCount) throw std::runtime_error("lh_buckets: null argument");
+    const uint64_t* pk = nullptr;
     std::vector<uint32_t> overflow;
     lowhash0Buckets(c->impl, static_cast<const uint32_t*>(keysDevice), static_cast<const uint64_t*>(valsDevice), n,
-        sendOffsets, &rk, &rc, bucketsUsed, sizeHistogram, overflow);
+        sendOffsets, &pk, bucketsUsed, sizeHistogram, overflow);
     if(overflow.size() > overflowCapacity) throw std::runtime_error("lh_buckets: overflow list capacity too small");
     if(!overflow.empty()) std::memcpy(overflowSizes, overflow.data(), overflow.size() * 4);
     *overflowCount = overflow.size();
-    *runKeysDevice = rk; *runCountsDevice = rc;
+    *pairKeysDevice = pk;
     return 0;
     API_END(1)
 }
 
-int shasta_mi355x_lh_merge(shasta_mi355x_ctx* c, const void* runKeysDevice, const void* runCountsDevice, uint64_t n,
-    uint64_t* highFrequency, uint64_t* tableSize)
+int shasta_mi355x_lh_merge(shasta_mi355x_ctx* c, const void* pairKeysDevice, uint64_t n, int evaluateNow,
+    uint64_t* highFrequency, uint64_t* total)
 {
     API_BEGIN
-    if(!c || !highFrequency || !tableSize) throw std::runtime_error("lh_merge: null argument");
-    lowhash0Merge(c->impl, static_cast<const uint64_t*>(runKeysDevice), static_cast<const uint32_t*>(runCountsDevice), n, highFrequency, tableSize);
+    if(!c || !highFrequency || !total) throw std::runtime_error("lh_merge: null argument");
+    lowhash0Merge(c->impl, static_cast<const uint64_t*>(pairKeysDevice), n, evaluateNow != 0, highFrequency, total);
     return 0;
     API_END(1)
 }
 
 int shasta_mi355x_lh_finish(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistics,
-    shasta_oriented_read_pair** candidates, uint64_t* candidateCount)
+    shasta_oriented_read_pair** candidates, uint64_t* candidateCount,
+    uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount)
 {
     API_BEGIN
-    if(!c || !readLowHashStatistics || !candidates || !candidateCount) throw std::runtime_error("lh_finish: null argument");
+    if(!c || !readLowHashStatistics || !candidates || !candidateCount || !iterationCount) throw std::runtime_error("lh_finish: null argument");
     std::vector<shasta_oriented_read_pair> v;
-    lowhash0Finish(c->impl, readLowHashStatistics, v);
+    std::vector<uint64_t> high, total;
+    lowhash0Finish(c->impl, readLowHashStatistics, v, high, total);
+    if(high.size() > iterationCapacity) throw std::runtime_error("lh_finish: iteration capacity too small");
+    for(size_t k = 0; k < high.size(); k++) { highFrequencyPerIteration[k] = high[k]; totalPerIteration[k] = total[k]; }
+    *iterationCount = high.size();
     shasta_oriented_read_pair* p = static_cast<shasta_oriented_read_pair*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(shasta_oriented_read_pair)));
     if(!p) throw std::bad_alloc();
     if(!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(shasta_oriented_read_pair));

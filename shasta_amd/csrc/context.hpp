@@ -8,6 +8,7 @@
 #include "../../include/shasta_mi355x.h"
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace shasta_mi355x {
@@ -35,8 +36,12 @@ struct Context {
     hipStream_t wideStream[ALIGN_MAX_WORKERS] = {};
     std::shared_ptr<void> alignScratch[ALIGN_MAX_WORKERS];
     std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
-    std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress (staged / multi-GPU API)
+    std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress
+    uint64_t lowhashRecordsHint = 0, lowhashPairsHint = 0;   // capacities the last jobs needed (first guesses of the next)
     std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
+    // Kernels that need more dynamic LDS than the default get the attribute once per context, i.e. on this context's device
+    // (hipFuncSetAttribute acts on the current device; the aligner's workers may get there at the same time).
+    std::once_flag cellsLdsAttribute[2], wideDpLdsAttribute;
     KernelTimers timers;                     // per-kernel HIP-event times since the last reset (shasta_mi355x_kernel_table)
 
     explicit Context(int device);
@@ -57,9 +62,10 @@ constexpr int LOWHASH0_SIZE_HISTOGRAM_BINS = 2048;
 void lowhash0Begin(Context&, const shasta_lowhash0_params&, int rank, int world, const uint64_t* readBoundaries, uint32_t* log2BucketCount);
 void lowhash0Hash(Context&, uint64_t iteration, uint64_t* sendOffsets, const uint32_t** keys, const uint64_t** vals);
 void lowhash0Buckets(Context&, const uint32_t* keys, const uint64_t* vals, uint64_t n, uint64_t* sendOffsets,
-    const uint64_t** runKeys, const uint32_t** runCounts, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint32_t>& overflow);
-void lowhash0Merge(Context&, const uint64_t* runKeys, const uint32_t* runCounts, uint64_t n, uint64_t* highFrequency, uint64_t* tableSize);
-void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates);
+    const uint64_t** pairKeys, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint32_t>& overflow);
+void lowhash0Merge(Context&, const uint64_t* pairKeys, uint64_t n, bool evaluateNow, uint64_t* highFrequency, uint64_t* total);
+void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates,
+    std::vector<uint64_t>& highFrequencyPerIteration, std::vector<uint64_t>& totalPerIteration);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
 void align3Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,

@@ -279,22 +279,41 @@ hashAllWindowsKernel(const uint32_t* __restrict__ kmerIds, uint64_t n, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
-// K3/K4 helpers on the sorted records.
+// K3 + K4 on the records of one iteration sorted by bucket id: bucket boundaries (first-record flags, their scan, the
+// start of every bucket), then per record the pass-2 statistics, one vote per bucket for the size histogram and the number
+// of pairs the record starts, a scan of those, and the pair keys.  No host value is needed anywhere in between: counts
+// stay on the device (primitives.hpp, Count), grids are sized from the capacity of the record buffers.
+// (A single kernel that finds a record's bucket by walking its neighbours was tried: 1.09 ms per iteration against
+// 0.35 ms for this chain -- dependent loads in the walk, and one atomic per wavefront on the append cursor.)
 // ---------------------------------------------------------------------------
-template<class K>
+constexpr int SIZE_HIST_CAP = 2048;
+constexpr int SIZE_HIST_LDS = 256;
+
+// Device-side counters of a LowHash0 job.
+enum : int {
+    C_RECORDS = 0,          // low hashes kept by the hash kernel of the current iteration
+    C_PAIRS = 1,            // pair keys appended so far (all iterations; or this iteration's, staged API)
+    C_OVERFLOW = 2,         // entries of the list of bucket sizes beyond the histogram bins
+    C_MAX_RECORDS = 3,      // largest C_RECORDS of any iteration
+    C_BUCKETS = 4,          // buckets used by the current iteration
+    C_COUNT = 8
+};
+
+// flags[i] = 1 where a bucket begins; flags[n] = 0 (n = the exact count; entries past it are never looked at).
 __global__ void __launch_bounds__(256)
-markHeadsKernel(const K* __restrict__ keys, uint64_t n, uint32_t* __restrict__ flags)
+markHeadsKernel(const uint32_t* __restrict__ keys, Count count, uint32_t* __restrict__ flags)
 {
+    const uint64_t n = count.get();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if(i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
     else if(i == n) flags[i] = 0u;
 }
 
-// starts[g] = index of the first element of group g; starts[groupCount] = n.
-template<class K>
+// pos = exclusive scan of flags.  starts[g] = index of the first record of bucket g; starts[bucket count] = n.
 __global__ void __launch_bounds__(256)
-groupStartsKernel(const K* __restrict__ keys, const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ starts)
+groupStartsKernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pos, Count count, uint32_t* __restrict__ starts)
 {
+    const uint64_t n = count.get();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if(i < n) {
         if(i == 0 || keys[i] != keys[i - 1]) starts[pos[i]] = uint32_t(i);
@@ -303,23 +322,21 @@ groupStartsKernel(const K* __restrict__ keys, const uint32_t* __restrict__ pos, 
     }
 }
 
-constexpr int SIZE_HIST_CAP = 2048;
-
-// Per record: pass-2 statistics (src/LowHash0.cpp:386-393), bucket-size histogram
-// (:566-613, one vote per bucket = per head record), and the number of pairs this
-// record starts in pass 3 (:430-457).
+// Per record: pass-2 statistics (src/LowHash0.cpp:386-393), bucket-size histogram (:566-613, one vote per bucket =
+// per first record), and the number of pairs this record starts in pass 3 (:430-457).
 __global__ void __launch_bounds__(256)
 bucketStatsKernel(
-    const uint32_t* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos,
-    const uint32_t* __restrict__ starts, uint64_t n,
-    uint64_t minBucketSize, uint64_t maxBucketSize,
+    const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts, Count count,
+    uint64_t minBucketSize, uint64_t maxBucketSize, uint32_t iteration,
     unsigned long long* __restrict__ stats,             // [R][3]
-    unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP]
-    uint32_t* __restrict__ overflowSizes, uint32_t* __restrict__ overflowCount, uint32_t overflowCapacity,
+    unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP] of this iteration
+    unsigned long long* __restrict__ overflowSizes, uint32_t overflowCapacity,     // iteration << 32 | size
+    unsigned long long* __restrict__ counters,
     uint64_t* __restrict__ pairCounts)                  // [n+1]
 {
-    __shared__ uint32_t sHist[SIZE_HIST_CAP];
-    for(int k = threadIdx.x; k < SIZE_HIST_CAP; k += blockDim.x) sHist[k] = 0;
+    __shared__ uint32_t sHist[SIZE_HIST_LDS];
+    const uint64_t n = count.get();
+    sHist[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if(i < n) {
@@ -332,44 +349,47 @@ bucketStatsKernel(
         const int cls = (size < minBucketSize) ? 0 : ((size > maxBucketSize) ? 2 : 1);
         atomicAdd(&stats[3ULL * readId + cls], 1ULL);
         if(i == begin) {
-            if(size < SIZE_HIST_CAP) atomicAdd(&sHist[size], 1u);
+            if(size < SIZE_HIST_LDS) atomicAdd(&sHist[size], 1u);
+            else if(size < SIZE_HIST_CAP) atomicAdd(&sizeHist[size], 1ULL);
             else {
-                const uint32_t o = atomicAdd(overflowCount, 1u);
-                if(o < overflowCapacity) overflowSizes[o] = uint32_t(size);
+                const unsigned long long o = atomicAdd(&counters[C_OVERFLOW], 1ULL);
+                if(o < overflowCapacity) overflowSizes[o] = ((unsigned long long)iteration << 32) | (unsigned long long)(size < 0xffffffffULL ? size : 0xffffffffULL);
             }
         }
-        uint64_t count = 0;
+        uint64_t pairs = 0;
         const uint64_t minSize = minBucketSize > 2 ? minBucketSize : 2;       // :436
         if(size >= minSize && size <= maxBucketSize) {
             const uint32_t hashHigh = uint32_t(v >> 32);
             for(uint32_t j = begin; j < end; j++) {
                 const uint64_t u = vals[j];
-                count += (uint32_t(u >> 32) == hashHigh && (uint32_t(u) >> 1) > readId) ? 1u : 0u;   // :443, :450
+                pairs += (uint32_t(u >> 32) == hashHigh && (uint32_t(u) >> 1) > readId) ? 1u : 0u;   // :443, :450
             }
         }
-        pairCounts[i] = count;
+        pairCounts[i] = pairs;
     } else if(i == n) {
         pairCounts[i] = 0;
     }
     __syncthreads();
-    for(int k = threadIdx.x; k < SIZE_HIST_CAP; k += blockDim.x) {
-        const uint32_t c = sHist[k];
-        if(c) atomicAdd(&sizeHist[k], (unsigned long long)c);
-    }
+    const uint32_t c = sHist[threadIdx.x];
+    if(c) atomicAdd(&sizeHist[threadIdx.x], (unsigned long long)c);
 }
 
-// Pair key: readId0 | readId1 | strandBit packed so that integer order is the
-// reference's (readId0, readId1, strand) order (src/LowHash0.hpp:131-134); strand
-// bit 0 = same strand.
+// Pass 3 (:424-459): every pair of records of an admissible bucket with equal hashHighBits and readId0 < readId1, as a
+// 64-bit key readId0 | readId1 | strandBit whose integer order is the reference's (readId0, readId1, strand) order
+// (src/LowHash0.hpp:131-134; strand bit 0 = same strand), appended after the keys of the earlier iterations
+// (counters[C_PAIRS]) and tagged with the iteration.  pairOffsets = exclusive scan of the counts above.
 __global__ void __launch_bounds__(256)
 pairWriteKernel(
     const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts,
-    const uint64_t* __restrict__ pairOffsets, uint64_t n, int readBits, uint64_t* __restrict__ pairKeys)
+    const uint64_t* __restrict__ pairOffsets, Count count, int readBits, uint32_t iteration,
+    const unsigned long long* __restrict__ counters, uint64_t* __restrict__ pairKeys, uint32_t* __restrict__ pairTags, uint64_t pairCapacity)
 {
+    const uint64_t n = count.get();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if(i >= n) return;
     uint64_t dst = pairOffsets[i];
     if(pairOffsets[i + 1] == dst) return;
+    dst += counters[C_PAIRS];
     const uint32_t b = pos[i + 1] - 1;
     const uint32_t begin = starts[b], end = starts[b + 1];
     const uint64_t v = vals[i];
@@ -380,56 +400,96 @@ pairWriteKernel(
         const uint64_t u = vals[j];
         const uint32_t o1 = uint32_t(u);
         if(uint32_t(u >> 32) == hashHigh && (o1 >> 1) > readId0) {
-            pairKeys[dst++] = (uint64_t(readId0) << (readBits + 1)) | (uint64_t(o1 >> 1) << 1) | uint64_t((o0 ^ o1) & 1u);
+            if(dst < pairCapacity) {                    // past the capacity the keys are dropped, the cursor stays exact: the job is run again with room
+                pairKeys[dst] = (uint64_t(readId0) << (readBits + 1)) | (uint64_t(o1 >> 1) << 1) | uint64_t((o0 ^ o1) & 1u);
+                if(pairTags) pairTags[dst] = iteration;
+            }
+            ++dst;
         }
     }
 }
 
-// Run-length encode sorted pair keys into (key, count mod 2^16) appended at the
-// end of the running table.  uint16 wrap: src/LowHash0.hpp:116, .cpp:521-555.
-__global__ void __launch_bounds__(256)
-runLengthKernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ starts, uint64_t groupCount,
-    uint64_t* __restrict__ outKeys, uint32_t* __restrict__ outCounts)
+// After the kernels of an iteration: its counters into the per-iteration table (rows of 4: records, buckets used,
+// pair cursor at its end, unused), the append cursor moved past its keys, the running maximum of the record count;
+// the record counter starts again.  pos / pairOffsets: the two scans above (null when there was nothing to scan).
+__global__ void noteIterationKernel(unsigned long long* __restrict__ counters, unsigned long long* __restrict__ iterationTable, uint32_t iteration,
+    Count count, const uint32_t* __restrict__ pos, const uint64_t* __restrict__ pairOffsets)
 {
-    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if(g >= groupCount) return;
-    const uint32_t begin = starts[g], end = starts[g + 1];
-    outKeys[g] = keys[begin];
-    outCounts[g] = (end - begin) & 0xffffu;
-}
-
-// Fold groups of equal keys of the (sorted) table, summing frequencies mod 2^16.
-__global__ void __launch_bounds__(256)
-foldTableKernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
-    const uint32_t* __restrict__ starts, uint64_t groupCount,
-    uint64_t* __restrict__ outKeys, uint32_t* __restrict__ outCounts)
-{
-    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if(g >= groupCount) return;
-    const uint32_t begin = starts[g], end = starts[g + 1];
-    uint32_t s = 0;
-    for(uint32_t j = begin; j < end; j++) s += counts[j];
-    outKeys[g] = keys[begin];
-    outCounts[g] = s & 0xffffu;
+    if(threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long records = count.device ? *count.device : count.bound;     // what the hash kernel found (may exceed the capacity)
+    const unsigned long long n = count.get();
+    const unsigned long long buckets = (pos && n) ? pos[n] : 0, pairs = (pairOffsets && n) ? pairOffsets[n] : 0;
+    counters[C_PAIRS] += pairs;
+    counters[C_BUCKETS] = buckets;
+    iterationTable[4ULL * iteration + 0] = records;
+    iterationTable[4ULL * iteration + 1] = buckets;
+    iterationTable[4ULL * iteration + 2] = counters[C_PAIRS];
+    iterationTable[4ULL * iteration + 3] = 0;
+    if(records > counters[C_MAX_RECORDS]) counters[C_MAX_RECORDS] = records;
+    counters[C_RECORDS] = 0;
 }
 
 __global__ void __launch_bounds__(256)
-countHighFrequencyKernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t minFrequency, unsigned long long* __restrict__ out)
-{
-    uint32_t c = 0;
-    for(uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
-        c += counts[i] >= minFrequency ? 1u : 0u;
-    }
-    for(int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, WAVE);
-    if((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
-}
-
-__global__ void __launch_bounds__(256)
-candidateFlagsKernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t minFrequency, uint32_t* __restrict__ flags)
+fillKernel(uint32_t* __restrict__ p, uint64_t n, uint32_t value)
 {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if(i < n) flags[i] = counts[i] >= minFrequency ? 1u : 0u;
-    else if(i == n) flags[i] = 0u;
+    if(i < n) p[i] = value;
+}
+
+// K5 for ALL iterations at once (src/LowHash0.cpp:462-472, merge :493-562, summary :184-196).  The pair keys of
+// every iteration, sorted by key with a STABLE sort: the occurrences of a pair are adjacent and in iteration order.
+// The reference folds them iteration after iteration into a uint16_t frequency (src/LowHash0.hpp:116: additions
+// wrap), and reports after each iteration how many pairs it holds (total) and how many have frequency >=
+// minFrequency (high frequency).  The thread of a pair's first occurrence replays that history: after the pair's
+// occurrences of iteration t, frequency = occurrences so far mod 2^16.  What it contributes to the two per-iteration
+// counters are DIFFERENCES -- +1 to total at the pair's first iteration, +-1 to high frequency at every iteration
+// where the pair crosses minFrequency -- accumulated per workgroup in LDS (one global atomic per workgroup, counter and
+// iteration: workgroups are persistent); the host takes the running sums.
+// flags[i] = 1 for the first occurrence of a pair whose final frequency makes it a candidate (:204-214).
+constexpr int EVALUATE_LDS_ITERATIONS = 2048;
+__global__ void __launch_bounds__(256)
+evaluatePairsKernel(
+    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ tags, uint64_t n, uint32_t iterations, uint32_t minFrequency,
+    unsigned long long* __restrict__ highDelta, unsigned long long* __restrict__ totalDelta, uint32_t* __restrict__ flags)
+{
+    __shared__ int sHigh[EVALUATE_LDS_ITERATIONS], sTotal[EVALUATE_LDS_ITERATIONS];
+    const bool inLds = iterations <= uint32_t(EVALUATE_LDS_ITERATIONS);
+    if(inLds) {
+        for(uint32_t t = threadIdx.x; t < iterations; t += blockDim.x) { sHigh[t] = 0; sTotal[t] = 0; }
+        __syncthreads();
+    }
+    auto add = [&](int* lds, unsigned long long* global, uint32_t t, int delta) {
+        if(inLds) atomicAdd(&lds[t], delta);
+        else atomicAdd(&global[t], (unsigned long long)(long long)delta);
+    };
+    for(uint64_t base = uint64_t(blockIdx.x) * blockDim.x; base <= n; base += uint64_t(gridDim.x) * blockDim.x) {
+        const uint64_t i = base + threadIdx.x;
+        if(i > n) continue;
+        if(i == n) { flags[i] = 0u; continue; }
+        const uint64_t key = keys[i];
+        uint32_t flag = 0;
+        if(i == 0 || keys[i - 1] != key) {
+            uint32_t occurrences = 0;
+            bool high = false, first = true;
+            uint64_t at = i;
+            while(at < n && keys[at] == key) {
+                const uint32_t t = tags[at];
+                while(at < n && keys[at] == key && tags[at] == t) { ++occurrences; ++at; }
+                if(first) { add(sTotal, totalDelta, t, 1); first = false; }
+                const bool now = (occurrences & 0xffffu) >= minFrequency;
+                if(now != high) { add(sHigh, highDelta, t, now ? 1 : -1); high = now; }
+            }
+            flag = high ? 1u : 0u;
+        }
+        flags[i] = flag;
+    }
+    if(inLds) {
+        __syncthreads();
+        for(uint32_t t = threadIdx.x; t < iterations; t += blockDim.x) {
+            if(sHigh[t]) atomicAdd(&highDelta[t], (unsigned long long)(long long)sHigh[t]);
+            if(sTotal[t]) atomicAdd(&totalDelta[t], (unsigned long long)(long long)sTotal[t]);
+        }
+    }
 }
 
 // K6: src/LowHash0.cpp:204-214.
@@ -596,15 +656,23 @@ lowerBoundsKernel(const K* __restrict__ keys, uint64_t n, const K* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// The LowHash0 job: the state of one LowHash0::LowHash0 call, advanced in stages so that the
-// same code runs on one GPU (lowhash0Run) and sharded over several (each rank hashes
-// its own reads, owns a contiguous range of bucket ids and of readId0; the two exchange steps
-// happen between the stages, in the caller).
-//   hash(iteration)            K1 on the rank's reads, records sorted by bucket id, split by bucket owner
-//   buckets(records)           K2-K5a on the records this rank owns: statistics, histogram, pair keys,
-//                              sorted + run-length encoded, split by owner of readId0
-//   merge(pairs)               K5b: fold the (key, count) runs this rank owns into its pair table
-//   finish()                   K6: candidates of the rank's readId0 range, statistics (partial sums)
+// The LowHash0 job: the state of one LowHash0::LowHash0 call.
+//
+// One GPU (lowhash0Run): per iteration the host only ENQUEUES -- hash, radix sort of the records, bucketKernel, a
+// one-thread kernel that files the iteration's counters -- and after the last iteration reads the counters back once.
+// The pair keys of all iterations accumulate in one array and are evaluated together (evaluatePairsKernel): one
+// sort instead of a table merge per iteration.  Capacities (records per iteration, pair keys) are guesses remembered
+// by the context; kernels never write past them, the counters stay exact, and a job whose guess was too small runs
+// again with room for everything (first call on a context at most).  With minHashIterationCount = 0 the iteration
+// control needs the high-frequency count after every iteration (src/LowHash0.cpp:137-149): then the accumulated keys
+// are evaluated after every iteration.
+//
+// Several GPUs: the same kernels behind stage functions, with the two exchanges in the caller --
+//   hash(iteration)      K1 on the rank's reads, records sorted by bucket id, split by bucket owner
+//   buckets(records)     the records this rank owns -> statistics, histogram, this iteration's pair keys sorted and
+//                        split by owner of readId0
+//   merge(keys)          appends the keys this rank owns; evaluates them on request
+//   finish()             candidates of the rank's readId0 range, statistics, per-iteration counters (partial sums)
 // ---------------------------------------------------------------------------
 struct LowHash0Job {
     shasta_lowhash0_params p;
@@ -614,13 +682,22 @@ struct LowHash0Job {
     uint32_t mask = 0, minFrequency = 0;
     int readBits = 0, pairKeyBits = 0;
     uint64_t markerBegin = 0, markerEnd = 0;
-    uint64_t recCapacity = 0, tableSize = 0;
-    DeviceBuffer<uint32_t> recKeysA, recKeysB, flags, pos, starts, scanTemp32, overflowSizes, boundKeys32;
-    DeviceBuffer<uint64_t> recValsA, recValsB, pairCounts, scanTemp64, pairKeysA, pairKeysB, tableKeysA, tableKeysB, runKeys, boundKeys64, boundOut;
-    DeviceBuffer<uint32_t> tableCountsA, tableCountsB, runCounts;
-    DeviceBuffer<unsigned long long> scalars, stats, sizeHist;
+    uint64_t recCapacity = 0, pairCapacity = 0;
+    uint64_t iterations = 0;                // iterations whose pair keys have been appended
+    uint64_t pairCount = 0;                 // accumulated pair keys (host copy, valid after a read-back)
+    uint64_t evaluatedIterations = ~0ULL, evaluatedPairs = ~0ULL, candidateCount = 0;
+    bool pairsInB = false;                  // which side of the ping-pong holds the accumulated keys
+    DeviceBuffer<uint32_t> recKeysA, recKeysB, pairTagsA, pairTagsB, flags, pos, starts, scanTemp32, boundKeys32;
+    DeviceBuffer<uint64_t> recValsA, recValsB, pairKeysA, pairKeysB, iterKeysA, iterKeysB, pairCounts, scanTemp64, boundKeys64, boundOut;
+    DeviceBuffer<unsigned long long> counters, stats, sizeHist, iterationTable, overflowSizes, highPerIteration, totalPerIteration;
     DeviceBuffer<shasta_oriented_read_pair> candidatesDevice;
+    uint64_t histRows = 0;                  // rows (iterations) sizeHist / iterationTable / high / total have room for
+    std::vector<size_t> hashHandles;        // kernel-table entries of the hash launches (bytes are filled in after the read-back)
+    std::vector<uint64_t> highHost, totalHost;
     static constexpr uint32_t overflowCapacity = 1 << 20;
+
+    uint64_t* pairKeys() { return pairsInB ? pairKeysB.data() : pairKeysA.data(); }
+    uint32_t* pairTags() { return pairsInB ? pairTagsB.data() : pairTagsA.data(); }
 };
 
 namespace {
@@ -628,6 +705,152 @@ LowHash0Job& jobOf(Context& ctx)
 {
     if(!ctx.lowhashJob) throw std::runtime_error("LowHash0: no job in progress (call begin first).");
     return *static_cast<LowHash0Job*>(ctx.lowhashJob.get());
+}
+
+// Room for `rows` iterations in the per-iteration tables (kept when growing: the dynamic iteration control adds rows).
+void reserveIterationRows(LowHash0Job& job, uint64_t rows, hipStream_t stream)
+{
+    if(rows <= job.histRows) return;
+    const uint64_t newRows = std::max<uint64_t>(rows, 2 * job.histRows);
+    DeviceBuffer<unsigned long long> hist, table;
+    hist.reserve(newRows * SIZE_HIST_CAP, stream); table.reserve(newRows * 4, stream);
+    HIP_CHECK(hipMemsetAsync(hist.data(), 0, newRows * SIZE_HIST_CAP * sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(table.data(), 0, newRows * 4 * sizeof(unsigned long long), stream));
+    if(job.histRows) {
+        HIP_CHECK(hipMemcpyAsync(hist.data(), job.sizeHist.data(), job.histRows * SIZE_HIST_CAP * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(table.data(), job.iterationTable.data(), job.histRows * 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    job.sizeHist.swap(hist); job.iterationTable.swap(table);
+    job.highPerIteration.reserve(newRows, stream); job.totalPerIteration.reserve(newRows, stream);
+    job.histRows = newRows;
+}
+
+void reservePairs(LowHash0Job& job, uint64_t capacity, hipStream_t stream, bool keep)
+{
+    job.pairKeysA.reserve(capacity, stream, keep); job.pairKeysB.reserve(capacity, stream, keep);
+    job.pairTagsA.reserve(capacity, stream, keep); job.pairTagsB.reserve(capacity, stream, keep);
+    job.pairCapacity = std::min<uint64_t>(std::min(job.pairKeysA.capacity(), job.pairKeysB.capacity()), std::min(job.pairTagsA.capacity(), job.pairTagsB.capacity()));
+}
+
+// K1 of one iteration into (recKeysA, recValsA); the record count stays on the device (counters[C_RECORDS]).
+void enqueueHash(Context& ctx, LowHash0Job& job, uint64_t iteration)
+{
+    hipStream_t stream = ctx.stream;
+    job.recKeysA.reserve(job.recCapacity, stream); job.recKeysB.reserve(job.recCapacity, stream);
+    job.recValsA.reserve(job.recCapacity, stream); job.recValsB.reserve(job.recCapacity, stream);
+    const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(job.p.m)), stream);
+    launchHash(ctx, uint32_t(job.p.m), iteration * 37, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
+        job.recKeysA.data(), job.recValsA.data(), job.counters.data() + C_RECORDS, job.recCapacity);
+    job.hashHandles.push_back(ctx.timers.end(span, 4 * (job.markerEnd - job.markerBegin), job.markerEnd - job.markerBegin));
+}
+
+// K2: the records sorted by bucket id (radix partition on the bucket id).  Which side holds the result depends on
+// the key width only.
+void enqueueSortRecords(Context& ctx, LowHash0Job& job, const uint32_t*& keys, const uint64_t*& vals, Count count)
+{
+    hipStream_t stream = ctx.stream;
+    keys = job.recKeysA.data(); vals = job.recValsA.data();
+    const uint64_t passes = (job.log2BucketCount + 7) / 8;
+    const KernelTimers::Span span = ctx.timers.begin("radix sort of low-hash records", stream);
+    if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
+        count, int(job.log2BucketCount), ctx.sortWs, stream)) {
+        keys = job.recKeysB.data(); vals = job.recValsB.data();
+    }
+    // 12 bytes per record read + written per 8-bit pass; the record count is booked from the expected fraction.
+    const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin));
+    (void)ctx.timers.end(span, 2 * 12 * expected * passes, expected);
+}
+
+// K3 + K4 on sorted records: statistics, histogram row `iteration`, pair keys appended at counters[C_PAIRS]; then the
+// iteration's counters are filed (noteIterationKernel).
+void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keys, const uint64_t* vals, Count count, uint64_t iteration,
+    uint64_t* pairKeys, uint32_t* pairTags, uint64_t pairCapacity)
+{
+    hipStream_t stream = ctx.stream;
+    const uint64_t bound = count.bound;
+    unsigned long long* counters = job.counters.data();
+    if(bound == 0) {
+        hipLaunchKernelGGL(noteIterationKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), uint32_t(iteration), count, (const uint32_t*)nullptr, (const uint64_t*)nullptr);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin));
+    job.flags.reserve(bound + 1, stream); job.pos.reserve(bound + 1, stream); job.starts.reserve(bound + 2, stream);
+    job.scanTemp32.reserve(scanTempElements(bound + 1), stream);
+    job.pairCounts.reserve(bound + 1, stream); job.scanTemp64.reserve(scanTempElements(bound + 1), stream);
+    const unsigned g = divUp(bound + 1, 256);
+    SHASTA_TIMED(ctx, "bucket boundaries (heads, scan, starts)", stream, 12 * expected, expected,
+        hipLaunchKernelGGL(markHeadsKernel, dim3(g), dim3(256), 0, stream, keys, count, job.flags.data());
+        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), bound + 1, job.scanTemp32.data(), stream);
+        hipLaunchKernelGGL(groupStartsKernel, dim3(g), dim3(256), 0, stream, keys, (const uint32_t*)job.pos.data(), count, job.starts.data()));
+    SHASTA_TIMED(ctx, "bucketStatsKernel + scan of pair counts", stream, 12 * expected, expected,
+        hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
+            vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), count,
+            job.p.minBucketSize, job.p.maxBucketSize, uint32_t(iteration), job.stats.data(), job.sizeHist.data() + iteration * SIZE_HIST_CAP,
+            job.overflowSizes.data(), LowHash0Job::overflowCapacity, counters, job.pairCounts.data());
+        exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), bound + 1, job.scanTemp64.data(), stream));
+    SHASTA_TIMED(ctx, "pairWriteKernel", stream, 0, expected,
+        hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(bound, 256)), dim3(256), 0, stream,
+            vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), (const uint64_t*)job.pairCounts.data(), count, job.readBits, uint32_t(iteration),
+            (const unsigned long long*)counters, pairKeys, pairTags, pairCapacity));
+    hipLaunchKernelGGL(noteIterationKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), uint32_t(iteration), count,
+        (const uint32_t*)job.pos.data(), (const uint64_t*)job.pairCounts.data());
+    HIP_CHECK(hipGetLastError());
+}
+
+// K5 over everything accumulated so far: sorts the pairCount keys, fills highPerIteration / totalPerIteration
+// [0, iterations) and the candidate flags + their scan.  Ends with ONE read-back (candidate count, both arrays).
+void evaluate(Context& ctx, LowHash0Job& job)
+{
+    hipStream_t stream = ctx.stream;
+    const uint64_t n = job.pairCount, iterations = job.iterations;
+    if(job.evaluatedIterations == iterations && job.evaluatedPairs == n) return;
+    MI355X_ASSERT(n < (1ULL << 32) - 1 && iterations < (1ULL << 32));
+    reserveIterationRows(job, std::max<uint64_t>(1, iterations), stream);
+    HIP_CHECK(hipMemsetAsync(job.highPerIteration.data(), 0, std::max<uint64_t>(1, iterations) * sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(job.totalPerIteration.data(), 0, std::max<uint64_t>(1, iterations) * sizeof(unsigned long long), stream));
+    job.candidateCount = 0;
+    job.highHost.assign(iterations, 0); job.totalHost.assign(iterations, 0);
+    if(n) {
+        {
+            const KernelTimers::Span span = ctx.timers.begin("radix sort of the pair keys of all iterations", stream);
+            uint64_t* ka = job.pairKeys(); uint64_t* kb = job.pairsInB ? job.pairKeysA.data() : job.pairKeysB.data();
+            uint32_t* ta = job.pairTags(); uint32_t* tb = job.pairsInB ? job.pairTagsA.data() : job.pairTagsB.data();
+            if(radixSort<uint64_t, uint32_t, true>(ka, kb, ta, tb, n, job.pairKeyBits, ctx.sortWs, stream)) job.pairsInB = !job.pairsInB;
+            (void)ctx.timers.end(span, 2 * 12 * n * uint64_t((job.pairKeyBits + 7) / 8), n);
+        }
+        job.flags.reserve(n + 1, stream); job.pos.reserve(n + 1, stream);
+        job.scanTemp32.reserve(scanTempElements(n + 1), stream);
+        SHASTA_TIMED(ctx, "evaluatePairsKernel + scan of candidate flags", stream, 12 * n, n,
+            hipLaunchKernelGGL(evaluatePairsKernel, dim3(std::min<unsigned>(divUp(n + 1, 256), 2048)), dim3(256), 0, stream,
+                (const uint64_t*)job.pairKeys(), (const uint32_t*)job.pairTags(), n, uint32_t(iterations), job.minFrequency,
+                job.highPerIteration.data(), job.totalPerIteration.data(), job.flags.data());
+            exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), n + 1, job.scanTemp32.data(), stream));
+        HIP_CHECK(hipGetLastError());
+        uint32_t candidates = 0;
+        HIP_CHECK(hipMemcpyAsync(&candidates, job.pos.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if(iterations) {
+            HIP_CHECK(hipMemcpyAsync(job.highHost.data(), job.highPerIteration.data(), iterations * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(job.totalHost.data(), job.totalPerIteration.data(), iterations * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        job.candidateCount = candidates;
+        // The kernel left differences: running sums (two's complement arithmetic carries the -1s).
+        for(uint64_t t = 1; t < iterations; t++) { job.highHost[t] += job.highHost[t - 1]; job.totalHost[t] += job.totalHost[t - 1]; }
+    }
+    job.evaluatedIterations = iterations; job.evaluatedPairs = n;
+}
+
+// Histogram rows (src/LowHash0.cpp:586-595) of one iteration from the (summed) size histogram.
+void appendHistogramRows(uint64_t iteration, uint64_t bucketCount, uint64_t bucketsUsed,
+    const uint64_t* sizeHistogram, const std::vector<uint32_t>& overflow, std::vector<uint64_t>& histogramRows)
+{
+    std::map<uint64_t, uint64_t> rows;
+    if(bucketCount > bucketsUsed) rows[0] = bucketCount - bucketsUsed;
+    for(int s = 1; s < SIZE_HIST_CAP; s++) if(sizeHistogram[s]) rows[uint64_t(s)] = sizeHistogram[s];
+    for(uint32_t s : overflow) ++rows[s];
+    for(const auto& r : rows) { histogramRows.push_back(iteration); histogramRows.push_back(r.first); histogramRows.push_back(r.second); }
 }
 }  // namespace
 
@@ -667,18 +890,22 @@ void lowhash0Begin(Context& ctx, const shasta_lowhash0_params& p, int rank, int 
     // This rank hashes the reads of its own range.
     job.markerBegin = ctx.hostToc[2 * job.boundaries[rank]];
     job.markerEnd = ctx.hostToc[2 * job.boundaries[rank + 1]];
-    // First guess only (the hash stage grows it and repeats the iteration when it was too small); the fraction is
-    // clamped because any double is a legal hashFraction in the reference (>= 1 keeps nothing, < 0 nearly everything).
+    // First guesses (grown, and the job repeated, when they turn out too small; remembered by the context); the
+    // fraction is clamped because any double is a legal hashFraction in the reference (>= 1 keeps nothing, < 0 nearly everything).
     const double expectedFraction = !(p.hashFraction > 0.) ? 0. : std::min(p.hashFraction, 1.);
     job.recCapacity = std::max<uint64_t>(1 << 16, uint64_t(2.0 * expectedFraction * double(job.markerEnd - job.markerBegin)) + (1 << 16));
+    job.recCapacity = std::max(job.recCapacity, ctx.lowhashRecordsHint);
+    const uint64_t plannedIterations = p.minHashIterationCount ? p.minHashIterationCount : 8;
+    reservePairs(job, std::max<uint64_t>(std::max<uint64_t>(1 << 20, plannedIterations * job.recCapacity / 2), ctx.lowhashPairsHint), stream, false);
 
-    job.scalars.reserve(8, stream);
+    job.counters.reserve(C_COUNT, stream);
     job.stats.reserve(3 * readCount, stream);
-    job.sizeHist.reserve(SIZE_HIST_CAP, stream);
-    job.overflowSizes.reserve(LowHash0Job::overflowCapacity + 1, stream);
+    job.overflowSizes.reserve(LowHash0Job::overflowCapacity, stream);
     job.boundKeys32.reserve(size_t(world) + 1, stream); job.boundKeys64.reserve(size_t(world) + 1, stream);
     job.boundOut.reserve(size_t(world) + 1, stream);
+    HIP_CHECK(hipMemsetAsync(job.counters.data(), 0, C_COUNT * sizeof(unsigned long long), stream));
     HIP_CHECK(hipMemsetAsync(job.stats.data(), 0, 3 * readCount * sizeof(unsigned long long), stream));
+    reserveIterationRows(job, std::max<uint64_t>(1, plannedIterations), stream);
     // Split keys: first bucket id of every bucket owner, first pair key of every readId0 owner.
     std::vector<uint32_t> b32(size_t(world) + 1);
     std::vector<uint64_t> b64(size_t(world) + 1);
@@ -700,35 +927,21 @@ void lowhash0Hash(Context& ctx, uint64_t iteration, uint64_t* sendOffsets, const
     LowHash0Job& job = jobOf(ctx);
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
-    unsigned long long* counter = job.scalars.data();
+    unsigned long long* counter = job.counters.data() + C_RECORDS;
     uint64_t n = 0;
     for(;;) {
-        job.recKeysA.reserve(job.recCapacity, stream); job.recKeysB.reserve(job.recCapacity, stream);
-        job.recValsA.reserve(job.recCapacity, stream); job.recValsB.reserve(job.recCapacity, stream);
         HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
-        const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(job.p.m)), stream);
-        launchHash(ctx, uint32_t(job.p.m), iteration * 37, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
-            job.recKeysA.data(), job.recValsA.data(), counter, job.recCapacity);
-        const size_t handle = ctx.timers.end(span);
+        enqueueHash(ctx, job, iteration);
         n = readDevice(counter, stream);
-        // Algorithmic bytes of the launch: 4 B per marker read + 12 B per low hash written; work = markers.
-        ctx.timers.amend(handle, 4 * (job.markerEnd - job.markerBegin) + 12 * std::min(n, job.recCapacity), job.markerEnd - job.markerBegin);
+        ctx.timers.amend(job.hashHandles.back(), 4 * (job.markerEnd - job.markerBegin) + 12 * std::min(n, job.recCapacity), job.markerEnd - job.markerBegin);
         if(n <= job.recCapacity) break;
         job.recCapacity = n + n / 4;           // estimate was too small: grow and redo this iteration
+        ctx.lowhashRecordsHint = job.recCapacity;
     }
+    HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
     MI355X_ASSERT(n < (1ULL << 32) - 1);
-    // K2: bucket the records (radix partition on the bucket id); bucket owners are contiguous.
-    const uint32_t* keys = job.recKeysA.data(); const uint64_t* vals = job.recValsA.data();
-    {
-        // K2: 12 bytes per record read + written per 8-bit pass.
-        const uint64_t passes = (job.log2BucketCount + 7) / 8;
-        const KernelTimers::Span span = ctx.timers.begin("radix sort of low-hash records", stream);
-        if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
-            n, int(job.log2BucketCount), ctx.sortWs, stream)) {
-            keys = job.recKeysB.data(); vals = job.recValsB.data();
-        }
-        (void)ctx.timers.end(span, 2 * 12 * n * passes, n);
-    }
+    const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
+    enqueueSortRecords(ctx, job, keys, vals, Count(n));
     if(job.world == 1) {
         sendOffsets[0] = 0; sendOffsets[1] = n;
     } else {
@@ -742,217 +955,128 @@ void lowhash0Hash(Context& ctx, uint64_t iteration, uint64_t* sendOffsets, const
     *keysOut = keys; *valsOut = vals;
 }
 
-// Stage 2.  (keys, vals): the n records of the buckets this rank owns (device pointers; any
-// order when world > 1).  Produces the run-length encoded pair keys, split by owner of readId0.
+// Stage 2.  (keys, vals): the n records of the buckets this rank owns (device pointers; any order when world > 1).
+// Produces this iteration's pair keys, sorted and split by owner of readId0.
 void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsIn, uint64_t n,
-    uint64_t* sendOffsets, const uint64_t** runKeysOut, const uint32_t** runCountsOut,
+    uint64_t* sendOffsets, const uint64_t** pairKeysOut,
     uint64_t* bucketsUsedOut, uint64_t* sizeHistogramOut /*SIZE_HIST_CAP*/, std::vector<uint32_t>& overflowOut)
 {
     LowHash0Job& job = jobOf(ctx);
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
-    const shasta_lowhash0_params& p = job.p;
     MI355X_ASSERT(n < (1ULL << 32) - 1);
+    const uint64_t iteration = job.iterations;
+    reserveIterationRows(job, iteration + 1, stream);
     const uint32_t* keys = keysIn; const uint64_t* vals = valsIn;
     if(job.world > 1 && n) {
         // Concatenation of one sorted run per sender: sort again.
         job.recKeysA.reserve(n, stream); job.recKeysB.reserve(n, stream); job.recValsA.reserve(n, stream); job.recValsB.reserve(n, stream);
         if(keysIn != job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 4, hipMemcpyDeviceToDevice, stream));
         if(valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
-        keys = job.recKeysA.data(); vals = job.recValsA.data();
-        if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
-            n, int(job.log2BucketCount), ctx.sortWs, stream)) {
-            keys = job.recKeysB.data(); vals = job.recValsB.data();
-        }
+        enqueueSortRecords(ctx, job, keys, vals, Count(n));
     }
-
-    // K3: bucket boundaries, statistics, histogram, pair counts.
-    uint64_t bucketsUsed = 0, pairCount = 0;
-    uint32_t* overflowCount = job.overflowSizes.data() + LowHash0Job::overflowCapacity;
-    HIP_CHECK(hipMemsetAsync(job.sizeHist.data(), 0, SIZE_HIST_CAP * sizeof(unsigned long long), stream));
-    HIP_CHECK(hipMemsetAsync(overflowCount, 0, 4, stream));
-    if(n) {
-        job.flags.reserve(n + 1, stream); job.pos.reserve(n + 1, stream); job.starts.reserve(n + 2, stream);
-        job.scanTemp32.reserve(scanTempElements(n + 1), stream);
-        job.pairCounts.reserve(n + 1, stream); job.scanTemp64.reserve(scanTempElements(n + 1), stream);
-        const unsigned g = divUp(n + 1, 256);
-        SHASTA_TIMED(ctx, "bucket boundaries (heads, scan, starts)", stream, 12 * n, n,
-            hipLaunchKernelGGL(markHeadsKernel<uint32_t>, dim3(g), dim3(256), 0, stream, keys, n, job.flags.data());
-            exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), n + 1, job.scanTemp32.data(), stream);
-            hipLaunchKernelGGL(groupStartsKernel<uint32_t>, dim3(g), dim3(256), 0, stream,
-                keys, (const uint32_t*)job.pos.data(), n, job.starts.data()));
-        SHASTA_TIMED(ctx, "bucketStatsKernel + scan of pair counts", stream, 12 * n, n,
-            hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
-                keys, vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), n,
-                p.minBucketSize, p.maxBucketSize, job.stats.data(), job.sizeHist.data(),
-                job.overflowSizes.data(), overflowCount, LowHash0Job::overflowCapacity, job.pairCounts.data());
-            exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), n + 1, job.scanTemp64.data(), stream));
-        HIP_CHECK(hipGetLastError());
-        bucketsUsed = readDevice(job.pos.data() + n, stream);
-        pairCount = readDevice(job.pairCounts.data() + n, stream);
-    }
+    // This iteration's pair keys go to a buffer of their own (they leave for their owners before they are appended),
+    // sized for the most a set of n records can produce: every record pairs with fewer than min(maxBucketSize, n) others.
+    unsigned long long* counters = job.counters.data();
+    const uint64_t perRecord = std::min<uint64_t>(std::min<uint64_t>(job.p.maxBucketSize, 1ULL << 31), n);
+    const uint64_t capacity = n * perRecord / 2 + 64;
+    MI355X_ASSERT(capacity < (1ULL << 32) - 1);
+    job.iterKeysA.reserve(capacity, stream); job.iterKeysB.reserve(capacity, stream);
+    const uint64_t overflowBefore = readDevice(counters + C_OVERFLOW, stream);
+    HIP_CHECK(hipMemsetAsync(counters + C_PAIRS, 0, sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(counters + C_BUCKETS, 0, sizeof(unsigned long long), stream));
+    enqueueBuckets(ctx, job, keys, vals, Count(n), iteration, job.iterKeysA.data(), nullptr, capacity);
+    const uint64_t pairCount = readDevice(counters + C_PAIRS, stream);
+    const uint64_t bucketsUsed = readDevice(counters + C_BUCKETS, stream);
+    MI355X_ASSERT(pairCount <= capacity);
     *bucketsUsedOut = bucketsUsed;
-    {
-        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
-        HIP_CHECK(hipMemcpyAsync(sizeHistogramOut, job.sizeHist.data(), SIZE_HIST_CAP * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        const uint32_t overflow = readDevice(overflowCount, stream);
-        if(overflow > LowHash0Job::overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
-        overflowOut.resize(overflow);
-        if(overflow) {
-            HIP_CHECK(hipMemcpyAsync(overflowOut.data(), job.overflowSizes.data(), overflow * 4ULL, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-        }
+    HIP_CHECK(hipMemcpyAsync(sizeHistogramOut, job.sizeHist.data() + iteration * SIZE_HIST_CAP, SIZE_HIST_CAP * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    const uint64_t overflowAfter = readDevice(counters + C_OVERFLOW, stream);
+    if(overflowAfter > LowHash0Job::overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
+    overflowOut.clear();
+    if(overflowAfter > overflowBefore) {
+        std::vector<unsigned long long> entries(overflowAfter - overflowBefore);
+        HIP_CHECK(hipMemcpyAsync(entries.data(), job.overflowSizes.data() + overflowBefore, entries.size() * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for(unsigned long long e : entries) overflowOut.push_back(uint32_t(e));
     }
-
-    // K4 + K5a: pair keys, sorted, run-length encoded.
-    uint64_t uniqueCount = 0;
+    const uint64_t* pk = job.iterKeysA.data();
     if(pairCount) {
         MI355X_ASSERT(pairCount < (1ULL << 32) - 1);
-        job.pairKeysA.reserve(pairCount, stream); job.pairKeysB.reserve(pairCount, stream);
-        SHASTA_TIMED(ctx, "pairWriteKernel", stream, 8 * pairCount, pairCount,
-            hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
-                vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(),
-                (const uint64_t*)job.pairCounts.data(), n, job.readBits, job.pairKeysA.data()));
-        uint64_t* pk = job.pairKeysA.data();
-        {
-            const KernelTimers::Span span = ctx.timers.begin("radix sort of pair keys", stream);
-            if(radixSort<uint64_t, uint32_t, false>(job.pairKeysA.data(), job.pairKeysB.data(), nullptr, nullptr, pairCount, job.pairKeyBits, ctx.sortWs, stream)) {
-                pk = job.pairKeysB.data();
-            }
-            (void)ctx.timers.end(span, 2 * 8 * pairCount * uint64_t((job.pairKeyBits + 7) / 8), pairCount);
-        }
-        const KernelTimers::Span runSpan = ctx.timers.begin("run lengths of pair keys (heads, scan, starts, runs)", stream);
-        job.flags.reserve(pairCount + 1, stream); job.pos.reserve(pairCount + 1, stream); job.starts.reserve(pairCount + 2, stream);
-        job.scanTemp32.reserve(scanTempElements(pairCount + 1), stream);
-        const unsigned g = divUp(pairCount + 1, 256);
-        hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(g), dim3(256), 0, stream, (const uint64_t*)pk, pairCount, job.flags.data());
-        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), pairCount + 1, job.scanTemp32.data(), stream);
-        hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(g), dim3(256), 0, stream,
-            (const uint64_t*)pk, (const uint32_t*)job.pos.data(), pairCount, job.starts.data());
-        HIP_CHECK(hipGetLastError());
-        uniqueCount = readDevice(job.pos.data() + pairCount, stream);
-        job.runKeys.reserve(uniqueCount, stream); job.runCounts.reserve(uniqueCount, stream);
-        hipLaunchKernelGGL(runLengthKernel, dim3(divUp(uniqueCount, 256)), dim3(256), 0, stream,
-            (const uint64_t*)pk, (const uint32_t*)job.starts.data(), uniqueCount, job.runKeys.data(), job.runCounts.data());
-        HIP_CHECK(hipGetLastError());
-        (void)ctx.timers.end(runSpan, 8 * pairCount + 12 * uniqueCount, pairCount);
+        const KernelTimers::Span span = ctx.timers.begin("radix sort of pair keys (one iteration, staged)", stream);
+        if(radixSort<uint64_t, uint32_t, false>(job.iterKeysA.data(), job.iterKeysB.data(), nullptr, nullptr, pairCount, job.pairKeyBits, ctx.sortWs, stream)) pk = job.iterKeysB.data();
+        (void)ctx.timers.end(span, 2 * 8 * pairCount * uint64_t((job.pairKeyBits + 7) / 8), pairCount);
     }
-    if(job.world == 1 || uniqueCount == 0) {
-        for(int r = 0; r <= job.world; r++) sendOffsets[r] = (r == job.world) ? uniqueCount : 0;
-        if(job.world > 1) for(int r = 1; r < job.world; r++) sendOffsets[r] = 0;
+    if(job.world == 1 || pairCount == 0) {
+        for(int r = 0; r <= job.world; r++) sendOffsets[r] = (r == job.world) ? pairCount : 0;
     } else {
         hipLaunchKernelGGL(lowerBoundsKernel<uint64_t>, dim3(divUp(uint64_t(job.world) + 1, 64)), dim3(64), 0, stream,
-            (const uint64_t*)job.runKeys.data(), uniqueCount, (const uint64_t*)job.boundKeys64.data(), uint32_t(job.world + 1), job.boundOut.data());
+            pk, pairCount, (const uint64_t*)job.boundKeys64.data(), uint32_t(job.world + 1), job.boundOut.data());
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(sendOffsets, job.boundOut.data(), (size_t(job.world) + 1) * 8, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        sendOffsets[0] = 0; sendOffsets[job.world] = uniqueCount;
+        sendOffsets[0] = 0; sendOffsets[job.world] = pairCount;
     }
     HIP_CHECK(hipStreamSynchronize(stream));
-    *runKeysOut = job.runKeys.data(); *runCountsOut = job.runCounts.data();
+    *pairKeysOut = pk;
 }
 
-// Stage 3.  (runKeys, runCounts): n (key, count) runs whose readId0 this rank owns.
-void lowhash0Merge(Context& ctx, const uint64_t* runKeys, const uint32_t* runCounts, uint64_t n, uint64_t* highFrequencyOut, uint64_t* tableSizeOut)
+// Stage 3.  keys: the n pair keys of this iteration whose readId0 this rank owns (device pointer).  Appends them;
+// with evaluateNow also evaluates everything appended so far and returns this rank's share of the latest iteration's
+// "high frequency" and "total" counters (the dynamic iteration control needs them after every iteration).
+void lowhash0Merge(Context& ctx, const uint64_t* keys, uint64_t n, bool evaluateNow, uint64_t* highFrequencyOut, uint64_t* totalOut)
 {
     LowHash0Job& job = jobOf(ctx);
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
     if(n) {
-        const KernelTimers::Span mergeSpan = ctx.timers.begin("pair table merge (append + sort + fold)", stream);
-        const uint64_t merged = job.tableSize + n;
-        MI355X_ASSERT(merged < (1ULL << 32) - 1);
-        job.tableKeysA.reserve(merged, stream, true); job.tableCountsA.reserve(merged, stream, true);
-        job.tableKeysB.reserve(merged, stream); job.tableCountsB.reserve(merged, stream);
-        HIP_CHECK(hipMemcpyAsync(job.tableKeysA.data() + job.tableSize, runKeys, n * 8, hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(job.tableCountsA.data() + job.tableSize, runCounts, n * 4, hipMemcpyDeviceToDevice, stream));
-        if(job.tableSize == 0 && job.world == 1) {
-            job.tableSize = n;          // one sender: already sorted and unique
-        } else {
-            uint64_t* tk = job.tableKeysA.data(); uint32_t* tc = job.tableCountsA.data();
-            uint64_t* ok = job.tableKeysB.data(); uint32_t* oc = job.tableCountsB.data();
-            if(radixSort<uint64_t, uint32_t, true>(job.tableKeysA.data(), job.tableKeysB.data(), job.tableCountsA.data(), job.tableCountsB.data(),
-                merged, job.pairKeyBits, ctx.sortWs, stream)) {
-                std::swap(tk, ok); std::swap(tc, oc);
-            }
-            job.flags.reserve(merged + 1, stream); job.pos.reserve(merged + 1, stream); job.starts.reserve(merged + 2, stream);
-            job.scanTemp32.reserve(scanTempElements(merged + 1), stream);
-            const unsigned gm = divUp(merged + 1, 256);
-            hipLaunchKernelGGL(markHeadsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream, (const uint64_t*)tk, merged, job.flags.data());
-            exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), merged + 1, job.scanTemp32.data(), stream);
-            hipLaunchKernelGGL(groupStartsKernel<uint64_t>, dim3(gm), dim3(256), 0, stream,
-                (const uint64_t*)tk, (const uint32_t*)job.pos.data(), merged, job.starts.data());
-            HIP_CHECK(hipGetLastError());
-            const uint64_t folded = readDevice(job.pos.data() + merged, stream);
-            hipLaunchKernelGGL(foldTableKernel, dim3(divUp(folded, 256)), dim3(256), 0, stream,
-                (const uint64_t*)tk, (const uint32_t*)tc, (const uint32_t*)job.starts.data(), folded, ok, oc);
-            HIP_CHECK(hipGetLastError());
-            // Result is in (ok, oc); make it the A side.
-            if(ok != job.tableKeysA.data()) { job.tableKeysA.swap(job.tableKeysB); job.tableCountsA.swap(job.tableCountsB); }
-            job.tableSize = folded;
-        }
-        (void)ctx.timers.end(mergeSpan, 12 * merged, merged);
-    }
-    // Per-iteration summary (src/LowHash0.cpp:184-196): this rank's share.
-    uint64_t highFrequency = 0;
-    if(job.tableSize) {
-        unsigned long long* highCounter = job.scalars.data() + 1;
-        HIP_CHECK(hipMemsetAsync(highCounter, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(countHighFrequencyKernel, dim3(std::min<unsigned>(divUp(job.tableSize, 256), 2048)), dim3(256), 0, stream,
-            (const uint32_t*)job.tableCountsA.data(), job.tableSize, job.minFrequency, highCounter);
+        const uint64_t needed = job.pairCount + n;
+        if(needed > job.pairCapacity) reservePairs(job, needed + needed / 2, stream, true);
+        HIP_CHECK(hipMemcpyAsync(job.pairKeys() + job.pairCount, keys, n * 8, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(fillKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, job.pairTags() + job.pairCount, n, uint32_t(job.iterations));
         HIP_CHECK(hipGetLastError());
-        highFrequency = readDevice(highCounter, stream);
+        job.pairCount = needed;
     }
-    *highFrequencyOut = highFrequency; *tableSizeOut = job.tableSize;
+    ++job.iterations;
+    *highFrequencyOut = 0; *totalOut = 0;
+    if(evaluateNow) {
+        evaluate(ctx, job);
+        *highFrequencyOut = job.highHost.back(); *totalOut = job.totalHost.back();
+    } else {
+        HIP_CHECK(hipStreamSynchronize(stream));          // `keys` may be reused by the caller
+    }
 }
 
-// Stage 4.  Candidates of this rank's readId0 range (sorted), statistics (this rank's partial
-// sums, readCount x 3), hash-kernel timing; ends the job.
-void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& hostCandidates)
+// Stage 4.  Candidates of this rank's readId0 range (sorted), statistics (this rank's partial sums, readCount x 3),
+// this rank's share of the per-iteration counters; ends the job.
+void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& hostCandidates,
+    std::vector<uint64_t>& highPerIteration, std::vector<uint64_t>& totalPerIteration)
 {
     LowHash0Job& job = jobOf(ctx);
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
     const uint64_t readCount = ctx.readCount;
+    evaluate(ctx, job);
+    highPerIteration = job.highHost; totalPerIteration = job.totalHost;
     hostCandidates.clear();
     // K6.
-    if(job.tableSize) {
-        job.flags.reserve(job.tableSize + 1, stream); job.pos.reserve(job.tableSize + 1, stream);
-        job.scanTemp32.reserve(scanTempElements(job.tableSize + 1), stream);
-        const unsigned g = divUp(job.tableSize + 1, 256);
-        hipLaunchKernelGGL(candidateFlagsKernel, dim3(g), dim3(256), 0, stream,
-            (const uint32_t*)job.tableCountsA.data(), job.tableSize, job.minFrequency, job.flags.data());
-        exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), job.tableSize + 1, job.scanTemp32.data(), stream);
+    if(job.candidateCount) {
+        job.candidatesDevice.reserve(job.candidateCount, stream);
+        SHASTA_TIMED(ctx, "emitCandidatesKernel", stream, 12 * job.candidateCount, job.candidateCount,
+            hipLaunchKernelGGL(emitCandidatesKernel, dim3(divUp(job.pairCount, 256)), dim3(256), 0, stream,
+                (const uint64_t*)job.pairKeys(), (const uint32_t*)job.pos.data(), job.pairCount, job.readBits, job.candidatesDevice.data()));
         HIP_CHECK(hipGetLastError());
-        const uint64_t candidateCount = readDevice(job.pos.data() + job.tableSize, stream);
-        if(candidateCount) {
-            job.candidatesDevice.reserve(candidateCount, stream);
-            hipLaunchKernelGGL(emitCandidatesKernel, dim3(g), dim3(256), 0, stream,
-                (const uint64_t*)job.tableKeysA.data(), (const uint32_t*)job.pos.data(), job.tableSize, job.readBits, job.candidatesDevice.data());
-            HIP_CHECK(hipGetLastError());
-            hostCandidates.resize(candidateCount);
-            HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), job.candidatesDevice.data(),
-                candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
-        }
+        hostCandidates.resize(job.candidateCount);
+        HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), job.candidatesDevice.data(),
+            job.candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
     }
     HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, job.stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-
+    ctx.lowhashPairsHint = std::max(ctx.lowhashPairsHint, job.pairCount + job.pairCount / 8);
     ctx.lowhashJob.reset();
 }
 
-// Histogram rows (src/LowHash0.cpp:586-595) of one iteration from the (summed) size histogram.
-static void appendHistogramRows(uint64_t iteration, uint64_t bucketCount, uint64_t bucketsUsed,
-    const uint64_t* sizeHistogram, const std::vector<uint32_t>& overflow, std::vector<uint64_t>& histogramRows)
-{
-    std::map<uint64_t, uint64_t> rows;
-    if(bucketCount > bucketsUsed) rows[0] = bucketCount - bucketsUsed;
-    for(int s = 1; s < SIZE_HIST_CAP; s++) if(sizeHistogram[s]) rows[uint64_t(s)] = sizeHistogram[s];
-    for(uint32_t s : overflow) ++rows[s];
-    for(const auto& r : rows) { histogramRows.push_back(iteration); histogramRows.push_back(r.first); histogramRows.push_back(r.second); }
-}
-
-// The whole of LowHash0::LowHash0 on one GPU: the stages above, no exchange in between.
+// The whole of LowHash0::LowHash0 on one GPU.
 void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLowHashStatistics, shasta_lowhash0_result& result)
 {
     std::memset(&result, 0, sizeof(result));
@@ -963,37 +1087,82 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     hipEvent_t evBegin, evEnd;
     HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
     HIP_CHECK(hipEventRecord(evBegin, stream));
-    uint32_t log2BucketCount = 0;
-    lowhash0Begin(ctx, p, 0, 1, nullptr, &log2BucketCount);
-    result.log2BucketCount = log2BucketCount;
-    const uint64_t bucketCount = 1ULL << log2BucketCount;
 
-    std::vector<uint64_t> highFrequencyPerIteration, totalPerIteration, histogramRows, sizeHistogram(SIZE_HIST_CAP);
-    std::vector<uint32_t> overflow;
+    std::vector<uint64_t> highFrequencyPerIteration, totalPerIteration, histogramRows;
     std::vector<shasta_oriented_read_pair> hostCandidates;
+    uint32_t log2BucketCount = 0;
     try {
-        uint64_t highFrequency = 0;
-        for(uint64_t iteration = 0; ; iteration++) {
-            // Iteration control, src/LowHash0.cpp:136-157.
-            if(p.minHashIterationCount == 0) {
-                const double current = 2. * double(highFrequency) / double(readCount);
-                if(current >= p.alignmentCandidatesPerRead) break;
-            } else if(iteration == p.minHashIterationCount) {
-                break;
+        for(int attempt = 0; ; attempt++) {
+            MI355X_ASSERT(attempt < 8);
+            lowhash0Begin(ctx, p, 0, 1, nullptr, &log2BucketCount);
+            LowHash0Job& job = jobOf(ctx);
+            unsigned long long* counters = job.counters.data();
+            unsigned long long host[C_COUNT];
+            bool again = false;
+            uint64_t highFrequency = 0;
+            for(uint64_t iteration = 0; ; iteration++) {
+                // Iteration control, src/LowHash0.cpp:136-157.
+                if(p.minHashIterationCount == 0) {
+                    const double current = 2. * double(highFrequency) / double(readCount);
+                    if(current >= p.alignmentCandidatesPerRead) break;
+                } else if(iteration == p.minHashIterationCount) {
+                    break;
+                }
+                reserveIterationRows(job, iteration + 1, stream);
+                enqueueHash(ctx, job, iteration);
+                const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
+                const Count records(job.recCapacity, counters + C_RECORDS);
+                enqueueSortRecords(ctx, job, keys, vals, records);
+                enqueueBuckets(ctx, job, keys, vals, records, iteration, job.pairKeys(), job.pairTags(), job.pairCapacity);
+                job.iterations = iteration + 1;
+                if(p.minHashIterationCount == 0) {
+                    // The iteration control needs this iteration's high-frequency count: read back, evaluate.
+                    HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    if(host[C_MAX_RECORDS] > job.recCapacity || host[C_PAIRS] > job.pairCapacity) { again = true; break; }
+                    job.pairCount = host[C_PAIRS];
+                    evaluate(ctx, job);
+                    highFrequency = job.highHost.back();
+                    // Room for the next iteration's keys, judged by this one's (checked again afterwards).
+                    const uint64_t perIteration = job.pairCount / job.iterations + 1;
+                    if(job.pairCount + 2 * perIteration > job.pairCapacity) reservePairs(job, 2 * (job.pairCount + 2 * perIteration), stream, true);
+                }
             }
-            uint64_t offsets[2];
-            const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
-            lowhash0Hash(ctx, iteration, offsets, &keys, &vals);
-            const uint64_t* runKeys = nullptr; const uint32_t* runCounts = nullptr;
-            uint64_t bucketsUsed = 0;
-            lowhash0Buckets(ctx, keys, vals, offsets[1], offsets, &runKeys, &runCounts, &bucketsUsed, sizeHistogram.data(), overflow);
-            appendHistogramRows(iteration, bucketCount, bucketsUsed, sizeHistogram.data(), overflow, histogramRows);
-            uint64_t tableSize = 0;
-            lowhash0Merge(ctx, runKeys, runCounts, offsets[1], &highFrequency, &tableSize);
-            highFrequencyPerIteration.push_back(highFrequency);
-            totalPerIteration.push_back(tableSize);
+            HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if(host[C_MAX_RECORDS] > job.recCapacity || host[C_PAIRS] > job.pairCapacity) again = true;
+            if(again) {
+                // A capacity guess was too small (keys or records were dropped, counters are exact): once more with room.
+                ctx.lowhashRecordsHint = std::max<uint64_t>(ctx.lowhashRecordsHint, host[C_MAX_RECORDS] + host[C_MAX_RECORDS] / 4);
+                const uint64_t iterationsDone = std::max<uint64_t>(1, job.iterations);
+                const uint64_t planned = p.minHashIterationCount ? p.minHashIterationCount : 2 * iterationsDone;
+                ctx.lowhashPairsHint = std::max<uint64_t>(ctx.lowhashPairsHint, (host[C_PAIRS] / iterationsDone + 1) * planned * 5 / 4);
+                ctx.lowhashJob.reset();
+                continue;
+            }
+            if(host[C_OVERFLOW] > LowHash0Job::overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
+            job.pairCount = host[C_PAIRS];
+            const uint64_t iterations = job.iterations;
+            // Per-iteration counters, histograms, the list of bucket sizes beyond the histogram bins.
+            std::vector<unsigned long long> table(4 * std::max<uint64_t>(1, iterations)), hist(SIZE_HIST_CAP * std::max<uint64_t>(1, iterations)), overflowEntries(host[C_OVERFLOW]);
+            if(iterations) {
+                HIP_CHECK(hipMemcpyAsync(table.data(), job.iterationTable.data(), 4 * iterations * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(hist.data(), job.sizeHist.data(), SIZE_HIST_CAP * iterations * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            }
+            if(!overflowEntries.empty()) HIP_CHECK(hipMemcpyAsync(overflowEntries.data(), job.overflowSizes.data(), overflowEntries.size() * 8, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            const uint64_t bucketCount = 1ULL << log2BucketCount;
+            for(uint64_t iteration = 0; iteration < iterations; iteration++) {
+                std::vector<uint32_t> overflow;
+                for(unsigned long long e : overflowEntries) if((e >> 32) == iteration) overflow.push_back(uint32_t(e));
+                static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
+                appendHistogramRows(iteration, bucketCount, table[4 * iteration + 1], reinterpret_cast<const uint64_t*>(hist.data()) + iteration * SIZE_HIST_CAP, overflow, histogramRows);
+                // Algorithmic bytes of the iteration's hash launch: 4 B per marker read + 12 B per low hash written.
+                if(iteration < job.hashHandles.size()) ctx.timers.amend(job.hashHandles[iteration], 4 * (job.markerEnd - job.markerBegin) + 12 * table[4 * iteration], job.markerEnd - job.markerBegin);
+            }
+            lowhash0Finish(ctx, readLowHashStatistics, hostCandidates, highFrequencyPerIteration, totalPerIteration);
+            break;
         }
-        lowhash0Finish(ctx, readLowHashStatistics, hostCandidates);
     } catch(...) {
         ctx.lowhashJob.reset();
         (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
@@ -1006,6 +1175,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     result.deviceSeconds = ms * 1e-3;
     (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
 
+    result.log2BucketCount = log2BucketCount;
     result.candidateCount = hostCandidates.size();
     result.candidates = mallocCopy(hostCandidates);
     result.iterationCount = uint32_t(highFrequencyPerIteration.size());

@@ -26,6 +26,22 @@ __device__ __forceinline__ uint32_t reverseComplementKmerId(uint32_t kmerId, uin
     return ((__brev(high) >> (32u - k)) << k) | (__brev(low) >> (32u - k));
 }
 
+// An element count a kernel is given: an upper bound known on the host (grids are sized from it) and, optionally, the
+// address of the exact count on the device, written by an earlier kernel of the same stream.  The host never reads the
+// exact count back between the launches: no stream synchronisation inside a chain of kernels.
+struct Count {
+    uint64_t bound;
+    const unsigned long long* device;
+    Count(uint64_t n) : bound(n), device(nullptr) {}
+    Count(uint64_t n, const unsigned long long* exact) : bound(n), device(exact) {}
+    __device__ __forceinline__ uint64_t get() const
+    {
+        if(device == nullptr) return bound;
+        const uint64_t exact = uint64_t(*device);
+        return exact < bound ? exact : bound;
+    }
+};
+
 // ----------------------------------------------------------------------------
 // Exclusive scan.
 // ----------------------------------------------------------------------------
@@ -130,9 +146,10 @@ constexpr int RS_BINS = 256;
 
 template<class K>
 __global__ void __launch_bounds__(RS_THREADS)
-radixHistogramKernel(const K* __restrict__ keys, uint32_t* __restrict__ counts, uint64_t n, int shift, unsigned numBlocks)
+radixHistogramKernel(const K* __restrict__ keys, uint32_t* __restrict__ counts, Count count, int shift, unsigned numBlocks)
 {
     __shared__ uint32_t hist[RS_BINS];
+    const uint64_t n = count.get();
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t tileBase = uint64_t(blockIdx.x) * RS_TILE;
@@ -149,9 +166,10 @@ template<class K, class V, bool HAS_V>
 __global__ void __launch_bounds__(RS_THREADS)
 radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
     const V* __restrict__ valsIn, V* __restrict__ valsOut,
-    const uint32_t* __restrict__ offsets, uint64_t n, int shift, unsigned numBlocks)
+    const uint32_t* __restrict__ offsets, Count count, int shift, unsigned numBlocks)
 {
     __shared__ uint32_t counters[RS_WAVES][RS_BINS];   // per-wave digit counts, then destination bases
+    const uint64_t n = count.get();
     const int lane = laneId();
     const int wave = int(threadIdx.x) >> 6;
 #pragma unroll
@@ -215,11 +233,13 @@ struct RadixSortWorkspace {
 };
 
 // Sorts n (< 2^32) keys on bits [0, bits) with 8-bit passes, ping-ponging between
-// (keysA, valsA) and (keysB, valsB).  Returns true if the result is in B.
+// (keysA, valsA) and (keysB, valsB).  Returns true if the result is in B (which side holds the result depends on
+// `bits` only, not on the count).
 template<class K, class V, bool HAS_V>
-inline bool radixSort(K* keysA, K* keysB, V* valsA, V* valsB, uint64_t n, int bits,
+inline bool radixSort(K* keysA, K* keysB, V* valsA, V* valsB, Count count, int bits,
     RadixSortWorkspace& ws, hipStream_t stream)
 {
+    const uint64_t n = count.bound;                    // grids and workspace from the bound; the kernels use the exact count
     if(n == 0 || bits <= 0) return false;
     MI355X_ASSERT(n < (1ULL << 32));
     const unsigned numBlocks = divUp(n, RS_TILE);
@@ -231,10 +251,10 @@ inline bool radixSort(K* keysA, K* keysB, V* valsA, V* valsB, uint64_t n, int bi
         K* kin = inB ? keysB : keysA;  K* kout = inB ? keysA : keysB;
         V* vin = inB ? valsB : valsA;  V* vout = inB ? valsA : valsB;
         hipLaunchKernelGGL(radixHistogramKernel<K>, dim3(numBlocks), dim3(RS_THREADS), 0, stream,
-            (const K*)kin, ws.counts.data(), n, shift, numBlocks);
+            (const K*)kin, ws.counts.data(), count, shift, numBlocks);
         exclusiveScan<uint32_t>(ws.counts.data(), ws.counts.data(), countN, ws.scanTemp.data(), stream);
         hipLaunchKernelGGL((radixScatterKernel<K, V, HAS_V>), dim3(numBlocks), dim3(RS_THREADS), 0, stream,
-            (const K*)kin, kout, (const V*)vin, vout, (const uint32_t*)ws.counts.data(), n, shift, numBlocks);
+            (const K*)kin, kout, (const V*)vin, vout, (const uint32_t*)ws.counts.data(), count, shift, numBlocks);
         inB = !inB;
     }
     return inB;

@@ -8,9 +8,9 @@ counterpart -- it is a single shared-memory process -- so this module follows th
   range (no communication);
 * bucket ids are owned in contiguous ranges: all-to-all(v) of the low-hash records (12 bytes
   each) per iteration;
-* pair keys are owned by the rank whose read range contains readId0: all-to-all(v) of the
-  run-length encoded keys; the per-iteration counters, the bucket-size histogram and the per-read
-  statistics are all-reduced;
+* pair keys are owned by the rank whose read range contains readId0: all-to-all(v) of the 8-byte
+  keys; the per-iteration counters, the bucket-size histograms and the per-read statistics are
+  all-reduced once, after the last iteration;
 * each rank's candidates are sorted and cover its readId0 range, so the concatenation in rank
   order is the reference's candidate list;
 * Align4 candidates are independent: the candidate list is all-gathered and re-split evenly.
@@ -69,14 +69,14 @@ class HipBackend:
     def buckets(self, keys, vals):
         self._sync()
         n = keys.numel()
-        offsets, rk, rc, used, hist, overflow = self.ctx.lh_buckets(keys.data_ptr() if n else 0, vals.data_ptr() if n else 0, n)
+        offsets, pk, used, hist, overflow = self.ctx.lh_buckets(keys.data_ptr() if n else 0, vals.data_ptr() if n else 0, n)
         m = int(offsets[-1])
-        return offsets, self._tensor_from(rk, m, torch.int64), self._tensor_from(rc, m, torch.int32), used, hist, overflow
+        return offsets, self._tensor_from(pk, m, torch.int64), used, hist, overflow
 
-    def merge(self, run_keys, run_counts):
+    def merge(self, pair_keys, evaluate_now):
         self._sync()
-        n = run_keys.numel()
-        return self.ctx.lh_merge(run_keys.data_ptr() if n else 0, run_counts.data_ptr() if n else 0, n)
+        n = pair_keys.numel()
+        return self.ctx.lh_merge(pair_keys.data_ptr() if n else 0, n, evaluate_now)
 
     def finish(self):
         return self.ctx.lh_finish()
@@ -139,55 +139,69 @@ class LowHash0Result:
 
 
 def lowhash0(backend, params, read_count, boundaries, group=None):
-    """Runs the job; every rank gets the global counters/statistics and its own share of the candidates."""
+    """Runs the job; every rank gets the global counters/statistics and its own share of the candidates.
+    Per MinHash iteration the ranks only exchange DATA (two all-to-all steps, each preceded by its counts); every
+    reduction -- per-iteration counters, bucket histograms, per-read statistics -- happens once, after the last
+    iteration.  Only minHashIterationCount = 0 needs the global high-frequency count after every iteration
+    (src/LowHash0.cpp:137-149): then the keys are evaluated and that one number all-reduced per iteration."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     device = backend.device
     log2 = backend.begin(params, rank, world, boundaries)
     bucket_count = 1 << log2
-    high_per_iteration, total_per_iteration, histogram_rows = [], [], []
+    dynamic = params.minHashIterationCount == 0
+    used_rows, hist_rows, overflow_lists = [], [], []
     high_frequency = 0
     iteration = 0
     while True:
         # Iteration control, src/LowHash0.cpp:136-157 (on the global counter: every rank decides alike).
-        if params.minHashIterationCount == 0:
+        if dynamic:
             if 2.0 * float(high_frequency) / float(read_count) >= params.alignmentCandidatesPerRead:
                 break
         elif iteration == params.minHashIterationCount:
             break
         offsets, keys, vals = backend.hash(iteration)
         keys, vals = exchange([keys, vals], offsets, group)                       # C1: records to bucket owners
-        offsets, run_keys, run_counts, used, hist, overflow = backend.buckets(keys, vals)
-        run_keys, run_counts = exchange([run_keys, run_counts], offsets, group)   # C2: runs to readId0 owners
-        high, total = backend.merge(run_keys, run_counts)
-        # Counters + histogram of this iteration, summed over the ranks.
-        packed = np.concatenate([np.asarray([high, total, used, len(overflow)], dtype=np.uint64), np.asarray(hist, dtype=np.uint64)])
-        packed = all_reduce_sum_u64(packed, device, group)
-        high_frequency, total_all, used_all, overflow_all = int(packed[0]), int(packed[1]), int(packed[2]), int(packed[3])
-        hist_all = packed[4:]
-        # Bucket sizes beyond the histogram bins are rare: gather the lists only when there are any.
-        lists = [[]] * world
-        if overflow_all:
-            lists = [None] * world
-            dist.all_gather_object(lists, np.asarray(overflow, dtype=np.uint32).tolist(), group=group)
+        offsets, pair_keys, used, hist, overflow = backend.buckets(keys, vals)
+        (pair_keys,) = exchange([pair_keys], offsets, group)                      # C2: pair keys to readId0 owners
+        high, _ = backend.merge(pair_keys, dynamic)
+        if dynamic:
+            high_frequency = int(all_reduce_sum_u64(np.asarray([high], dtype=np.uint64), device, group)[0])
+        used_rows.append(used)
+        hist_rows.append(np.asarray(hist, dtype=np.uint64))
+        overflow_lists.append(np.asarray(overflow, dtype=np.uint32).tolist())
+        iteration += 1
+    candidates, stats, high_rows, total_rows = backend.finish()
+    iterations = iteration
+    # One reduction for everything: [high | total | bucketsUsed | overflow counts | histograms] per iteration, then the statistics.
+    packed = np.concatenate([np.asarray(high_rows, dtype=np.uint64), np.asarray(total_rows, dtype=np.uint64),
+                             np.asarray(used_rows, dtype=np.uint64), np.asarray([len(o) for o in overflow_lists], dtype=np.uint64)]
+                            + hist_rows) if iterations else np.zeros(0, dtype=np.uint64)
+    packed = all_reduce_sum_u64(packed, device, group)
+    high_all, total_all = packed[:iterations], packed[iterations:2 * iterations]
+    used_all, overflow_all = packed[2 * iterations:3 * iterations], packed[3 * iterations:4 * iterations]
+    hist_all = packed[4 * iterations:].reshape(iterations, SIZE_HISTOGRAM_BINS) if iterations else np.zeros((0, SIZE_HISTOGRAM_BINS), np.uint64)
+    # Bucket sizes beyond the histogram bins are rare: gather the lists only when there are any.
+    lists = [[[] for _ in range(iterations)]] * world
+    if int(overflow_all.sum()):
+        lists = [None] * world
+        dist.all_gather_object(lists, overflow_lists, group=group)
+    histogram_rows = []
+    for it in range(iterations):
         rows = {}
-        if bucket_count > used_all:
-            rows[0] = bucket_count - used_all
-        for s in np.nonzero(hist_all[1:])[0] + 1:
-            rows[int(s)] = int(hist_all[s])
-        for lst in lists:
-            for s in lst:
+        if bucket_count > int(used_all[it]):
+            rows[0] = bucket_count - int(used_all[it])
+        for s in np.nonzero(hist_all[it][1:])[0] + 1:
+            rows[int(s)] = int(hist_all[it][s])
+        for per_rank in lists:
+            for s in per_rank[it]:
                 rows[int(s)] = rows.get(int(s), 0) + 1
         for s in sorted(rows):
-            histogram_rows.append((iteration, s, rows[s]))
-        high_per_iteration.append(high_frequency)
-        total_per_iteration.append(total_all)
-        iteration += 1
-    candidates, stats = backend.finish()
+            histogram_rows.append((it, s, rows[s]))
     out = LowHash0Result()
     out.candidates = candidates
     out.statistics = all_reduce_sum_u64(stats, device, group)
-    out.high_frequency = np.asarray(high_per_iteration, dtype=np.uint64)
-    out.total = np.asarray(total_per_iteration, dtype=np.uint64)
+    out.high_frequency = np.asarray(high_all, dtype=np.uint64)
+    out.total = np.asarray(total_all, dtype=np.uint64)
     out.histogram = np.asarray(histogram_rows, dtype=np.uint64).reshape(-1, 3)
     out.log2_bucket_count = log2
     return out

@@ -268,36 +268,42 @@ class Context:
         return offsets, keys.value or 0, vals.value or 0
 
     def lh_buckets(self, keys_ptr, vals_ptr, n):
-        """-> (send offsets, run keys ptr, run counts ptr, bucketsUsed, size histogram uint64[2048], overflow sizes)."""
+        """-> (send offsets, pair keys ptr (u64, sorted), bucketsUsed, size histogram uint64[2048], overflow sizes)."""
         offsets = np.zeros(self._world + 1, dtype=np.uint64)
-        run_keys, run_counts = C.c_void_p(), C.c_void_p()
+        pair_keys = C.c_void_p()
         used, overflow_count = C.c_uint64(), C.c_uint64()
         hist = np.zeros(2048, dtype=np.uint64)
         overflow = np.zeros(1 << 20, dtype=np.uint32)
         self.library._check(self.lib.shasta_mi355x_lh_buckets(
             C.c_void_p(self.handle), C.c_void_p(int(keys_ptr)), C.c_void_p(int(vals_ptr)), C.c_uint64(int(n)),
-            abi.as_ptr(offsets, C.c_uint64), C.byref(run_keys), C.byref(run_counts), C.byref(used),
+            abi.as_ptr(offsets, C.c_uint64), C.byref(pair_keys), C.byref(used),
             abi.as_ptr(hist, C.c_uint64), abi.as_ptr(overflow, C.c_uint32), C.c_uint64(len(overflow)),
             C.byref(overflow_count)), "shasta_mi355x_lh_buckets")
-        return offsets, run_keys.value or 0, run_counts.value or 0, int(used.value), hist, overflow[:overflow_count.value].copy()
+        return offsets, pair_keys.value or 0, int(used.value), hist, overflow[:overflow_count.value].copy()
 
-    def lh_merge(self, run_keys_ptr, run_counts_ptr, n):
+    def lh_merge(self, pair_keys_ptr, n, evaluate_now=False):
+        """Appends this iteration's keys; with evaluate_now -> this rank's (high frequency, total) of the iteration, else zeros."""
         high, total = C.c_uint64(), C.c_uint64()
         self.library._check(self.lib.shasta_mi355x_lh_merge(
-            C.c_void_p(self.handle), C.c_void_p(int(run_keys_ptr)), C.c_void_p(int(run_counts_ptr)), C.c_uint64(int(n)),
+            C.c_void_p(self.handle), C.c_void_p(int(pair_keys_ptr)), C.c_uint64(int(n)), C.c_int(1 if evaluate_now else 0),
             C.byref(high), C.byref(total)), "shasta_mi355x_lh_merge")
         return int(high.value), int(total.value)
 
-    def lh_finish(self):
-        """-> (this rank's candidates, this rank's partial statistics uint64[R,3])."""
+    def lh_finish(self, max_iterations=1 << 16):
+        """-> (this rank's candidates, its partial statistics uint64[R,3], its share of high frequency / total per iteration)."""
         stats = np.zeros((self.read_count, 3), dtype=np.uint64)
         cand = C.POINTER(abi.OrientedReadPair)()
-        count = C.c_uint64()
+        count, iterations = C.c_uint64(), C.c_uint64()
+        high = np.zeros(max_iterations, dtype=np.uint64)
+        total = np.zeros(max_iterations, dtype=np.uint64)
         self.library._check(self.lib.shasta_mi355x_lh_finish(
-            C.c_void_p(self.handle), abi.as_ptr(stats, C.c_uint64), C.byref(cand), C.byref(count)), "shasta_mi355x_lh_finish")
+            C.c_void_p(self.handle), abi.as_ptr(stats, C.c_uint64), C.byref(cand), C.byref(count),
+            abi.as_ptr(high, C.c_uint64), abi.as_ptr(total, C.c_uint64), C.c_uint64(max_iterations), C.byref(iterations)),
+            "shasta_mi355x_lh_finish")
         out = abi.copy_array(cand, int(count.value), abi.PAIR_DTYPE)
         self.lib.shasta_mi355x_free(cand)
-        return out, stats
+        k = int(iterations.value)
+        return out, stats, high[:k].copy(), total[:k].copy()
 
     def lowhash0(self, params):
         stats = np.zeros((self.read_count, 3), dtype=np.uint64)

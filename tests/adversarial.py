@@ -97,6 +97,13 @@ def lowhash_cases():
         "hashFraction=0.5": (None, P(hashFraction=0.5, minHashIterationCount=2, minBucketSize=2, maxBucketSize=1000)),
         "hashFraction=0": (None, P(hashFraction=0.0, minHashIterationCount=2, minBucketSize=2, maxBucketSize=30)),
         "log2 forced to 20": (None, P(log2MinHashBucketCount=20, minBucketSize=2, maxBucketSize=30)),
+        # The values of the human-genome runs: 2^31 buckets, where bit 31 of the hash takes part in neither the bucket id nor
+        # the match key (src/LowHash0.hpp:99-105), and a request beyond the cap of 31 (src/LowHash0.cpp:73-98).  The
+        # restatement was checked against the reference's own code at these values once (32 GB of bucket arrays: not a CI test).
+        "log2 = 31": (None, P(log2MinHashBucketCount=31, hashFraction=0.05, minHashIterationCount=3, minBucketSize=2, maxBucketSize=30, minFrequency=1)),
+        "log2 = 40 (capped at 31)": (None, P(log2MinHashBucketCount=40, hashFraction=0.05, minHashIterationCount=3, minBucketSize=2, maxBucketSize=30, minFrequency=1)),
+        # conf/Nanopore-UL-May2022.conf: MinHash 10/50/5 (here on 45x-like coverage of a small genome so that buckets of 10+ exist).
+        "minBucketSize/maxBucketSize/minFrequency 10/50/5": (None, P(hashFraction=0.05, minHashIterationCount=12, minBucketSize=10, maxBucketSize=50, minFrequency=5)),
         "maxBucketSize=2, minFrequency=1": (None, P(minBucketSize=0, maxBucketSize=2, minFrequency=1)),
         "minFrequency=9": (None, P(minBucketSize=2, maxBucketSize=30, minFrequency=9)),
         "iterate until 3 candidates per read": (None, P(minHashIterationCount=0, alignmentCandidatesPerRead=3.0, minBucketSize=2, maxBucketSize=30)),
@@ -107,7 +114,7 @@ def lowhash_cases():
 
 
 LOWHASH_CASE_NAMES = list(lowhash_cases().keys())
-LOWHASH_READ_SET_NAMES = ["empty and short reads", "a single read", "forty copies of one read"]
+LOWHASH_READ_SET_NAMES = ["empty and short reads", "a single read", "forty copies of one read", "uint16 frequency wrap"]
 
 
 def lowhash_case(lib, oracle_lib, name):
@@ -134,6 +141,12 @@ def lowhash_read_set(lib, oracle_lib, name):
         "empty and short reads": (short, P(minBucketSize=1, maxBucketSize=30, minFrequency=1)),
         "a single read": ([g[:800]], P(minBucketSize=1, maxBucketSize=30, minFrequency=1)),
         "forty copies of one read": ([g[:600]] * 40, P(minBucketSize=2, maxBucketSize=100, minFrequency=2)),
+        # Two reads that are the same tandem repeat: every one of the four window contents sits about 75 times in each,
+        # so one bucket yields about 75 x 75 pairs of the same (readId0, readId1, strand) and a pair passes 2^16
+        # occurrences within a few iterations: the reference's uint16_t frequency wraps (src/LowHash0.hpp:116), and a
+        # pair whose count wrapped below minFrequency is NOT a candidate.
+        "uint16 frequency wrap": ([np.tile(g[:4], 75), np.tile(g[:4], 75), g[100:400]],
+                                  P(hashFraction=0.9999999, minHashIterationCount=5, minBucketSize=2, maxBucketSize=1000, minFrequency=30000)),
     }[name]
     t, _, d = build(reads)
     support.same_lowhash(lib.lowhash0(t, d, None, p), oracle_lib.lowhash0(t, d, None, p))

@@ -28,6 +28,7 @@ class NumpyBackend:
         self.read_bits = max(1, int(self.read_count - 1).bit_length())
         self.stats = np.zeros((self.read_count, 3), np.uint64)
         self.table = {}
+        self.high_rows, self.total_rows = [], []
         self.min_frequency = min(int(params.minFrequency), 0x10000)
         return log2
 
@@ -89,23 +90,18 @@ class NumpyBackend:
                             strand_bit = (int(oriented[a]) ^ int(oriented[c])) & 1
                             pair_keys.append((int(reads[a]) << (self.read_bits + 1)) | (int(reads[c]) << 1) | strand_bit)
         pk = np.sort(np.asarray(pair_keys, dtype=np.uint64))
-        if len(pk):
-            heads = np.flatnonzero(np.r_[True, pk[1:] != pk[:-1]])
-            run_keys = pk[heads]
-            run_counts = (np.diff(np.r_[heads, len(pk)]) & 0xffff).astype(np.uint32)
-        else:
-            run_keys, run_counts = np.zeros(0, np.uint64), np.zeros(0, np.uint32)
         bounds = (self.boundaries.astype(np.uint64) << np.uint64(self.read_bits + 1))
-        offsets = self._owner_offsets(run_keys, bounds)
-        offsets[0], offsets[-1] = 0, len(run_keys)
-        return (offsets, torch.from_numpy(run_keys.view(np.int64).copy()), torch.from_numpy(run_counts.view(np.int32).copy()),
-                len(starts), hist, np.asarray(overflow, np.uint32))
+        offsets = self._owner_offsets(pk, bounds)
+        offsets[0], offsets[-1] = 0, len(pk)
+        return offsets, torch.from_numpy(pk.view(np.int64).copy()), len(starts), hist, np.asarray(overflow, np.uint32)
 
-    def merge(self, run_keys, run_counts):
-        for k, c in zip(run_keys.numpy().view(np.uint64).tolist(), run_counts.numpy().view(np.uint32).tolist()):
-            self.table[k] = (self.table.get(k, 0) + c) & 0xffff
-        high = sum(1 for c in self.table.values() if c >= self.min_frequency)
-        return high, len(self.table)
+    def merge(self, pair_keys, evaluate_now):
+        # The reference folds the iteration's pairs into a uint16 frequency (src/LowHash0.hpp:116: additions wrap).
+        for k in pair_keys.numpy().view(np.uint64).tolist():
+            self.table[k] = (self.table.get(k, 0) + 1) & 0xffff
+        self.high_rows.append(sum(1 for c in self.table.values() if c >= self.min_frequency))
+        self.total_rows.append(len(self.table))
+        return (self.high_rows[-1], self.total_rows[-1]) if evaluate_now else (0, 0)
 
     def finish(self):
         from shasta_amd import abi
@@ -113,4 +109,5 @@ class NumpyBackend:
         r0 = [k >> (self.read_bits + 1) for k in keys]
         r1 = [(k >> 1) & ((1 << self.read_bits) - 1) for k in keys]
         same = [0 if (k & 1) else 1 for k in keys]
-        return abi.make_pairs(np.asarray(r0, np.uint32), np.asarray(r1, np.uint32), np.asarray(same, np.uint8)), self.stats
+        return (abi.make_pairs(np.asarray(r0, np.uint32), np.asarray(r1, np.uint32), np.asarray(same, np.uint8)), self.stats,
+                np.asarray(self.high_rows, np.uint64), np.asarray(self.total_rows, np.uint64))
