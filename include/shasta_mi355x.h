@@ -432,6 +432,42 @@ int shasta_mi355x_banded_dp_many(
  * ------------------------------------------------------------------------- */
 int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx*, uint64_t deltaThreshold, uint32_t* bound);
 
+/* -------------------------------------------------------------------------
+ * Several GPUs of one node behind ONE blocking call from one process -- the shape of the reference's seams
+ * (src/AssemblerLowHash.cpp:36-52, src/AssemblerAlign.cpp:208-304 are single C++ calls that fan out over threads
+ * inside; SURVEY 8(b) proposed `int nGpus` on both entry points).  devices: deviceCount HIP device ids, or NULL
+ * for 0 .. deviceCount-1 (a device may be listed more than once: the sharded path then runs on fewer GPUs, which
+ * is how it is tested on a one-GPU box).  Results are identical to the one-GPU entry points for any device count.
+ * LowHash0: reads sharded by contiguous id ranges balanced by marker count, bucket ids and readId0 ranges owned by
+ * device, the two exchanges of an iteration as device-to-device copies over xGMI (hipMemcpyPeerAsync, each device
+ * pulls its segments), reductions on the host after the last iteration.  Aligners: contiguous candidate ranges
+ * balanced by the markers they touch, results concatenated in candidate order.
+ *   *_multi           one-shot forms of shasta_mi355x_lowhash0 / _align4_batch / _align3_batch (host pointers in)
+ *   shasta_mi355x_group   the markers stay resident on every device of the group between calls
+ * ------------------------------------------------------------------------- */
+typedef struct shasta_mi355x_group shasta_mi355x_group;
+shasta_mi355x_group* shasta_mi355x_group_create(int deviceCount, const int* devices);    /* NULL on error */
+void shasta_mi355x_group_destroy(shasta_mi355x_group*);
+int shasta_mi355x_group_set_markers(shasta_mi355x_group*, uint64_t readCount,
+    const uint64_t* markersToc, const void* markersData, const uint8_t* readFlags);
+int shasta_mi355x_group_set_kmer_ids(shasta_mi355x_group*, uint64_t readCount,
+    const uint64_t* markersToc, const uint32_t* kmerIds, const uint8_t* readFlags);
+int shasta_mi355x_group_lowhash0_run(shasta_mi355x_group*, const shasta_lowhash0_params*,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result*);
+int shasta_mi355x_group_align4_run(shasta_mi355x_group*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align4_options*, int wantOrdinals, shasta_align4_result*);
+int shasta_mi355x_group_align3_run(shasta_mi355x_group*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align3_options*, int wantOrdinals, shasta_align4_result*);
+int shasta_mi355x_lowhash0_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    const uint8_t* readFlags, const shasta_lowhash0_params*, int deviceCount, const int* devices,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result*);
+int shasta_mi355x_align4_batch_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options*, int wantOrdinals, int deviceCount, const int* devices, shasta_align4_result*);
+int shasta_mi355x_align3_batch_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options*, int wantOrdinals, int deviceCount, const int* devices, shasta_align4_result*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 using namespace shasta_mi355x;
 
 struct shasta_mi355x_ctx { Context impl; explicit shasta_mi355x_ctx(int d) : impl(d) {} };
+struct shasta_mi355x_group { Group impl; shasta_mi355x_group(int n, const int* devices) : impl(n, devices) {} };
 
 static thread_local std::string lastError;
 
@@ -341,6 +342,104 @@ int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx* c, uint64_t deltaThresho
     API_BEGIN
     if(!c || !bound) throw std::runtime_error("palindromic_screen: null argument");
     palindromicScreen(c->impl, deltaThreshold, bound);
+    return 0;
+    API_END(1)
+}
+
+shasta_mi355x_group* shasta_mi355x_group_create(int deviceCount, const int* devices)
+{
+    API_BEGIN
+    return new shasta_mi355x_group(deviceCount, devices);
+    API_END(nullptr)
+}
+
+void shasta_mi355x_group_destroy(shasta_mi355x_group* g) { delete g; }
+
+int shasta_mi355x_group_set_markers(shasta_mi355x_group* g, uint64_t readCount,
+    const uint64_t* markersToc, const void* markersData, const uint8_t* readFlags)
+{
+    API_BEGIN
+    if(!g || !markersToc || (!markersData && markersToc[2 * readCount])) throw std::runtime_error("group_set_markers: null argument");
+    g->impl.setMarkers(readCount, markersToc, markersData, nullptr, readFlags);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_group_set_kmer_ids(shasta_mi355x_group* g, uint64_t readCount,
+    const uint64_t* markersToc, const uint32_t* kmerIds, const uint8_t* readFlags)
+{
+    API_BEGIN
+    if(!g || !markersToc || (!kmerIds && markersToc[2 * readCount])) throw std::runtime_error("group_set_kmer_ids: null argument");
+    g->impl.setMarkers(readCount, markersToc, nullptr, kmerIds, readFlags);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_group_lowhash0_run(shasta_mi355x_group* g, const shasta_lowhash0_params* params,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result* result)
+{
+    API_BEGIN
+    if(!g || !params || !readLowHashStatistics || !result) throw std::runtime_error("group_lowhash0_run: null argument");
+    g->impl.lowhash0Run(*params, readLowHashStatistics, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_group_align4_run(shasta_mi355x_group* g, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align4_options* options, int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!g || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("group_align4_run: null argument");
+    g->impl.alignRun(candidateCount, candidates, options, nullptr, wantOrdinals != 0, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_group_align3_run(shasta_mi355x_group* g, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align3_options* options, int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!g || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("group_align3_run: null argument");
+    g->impl.alignRun(candidateCount, candidates, nullptr, options, wantOrdinals != 0, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lowhash0_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    const uint8_t* readFlags, const shasta_lowhash0_params* params, int deviceCount, const int* devices,
+    uint64_t* readLowHashStatistics, shasta_lowhash0_result* result)
+{
+    API_BEGIN
+    if(!markersToc || !params || !readLowHashStatistics || !result) throw std::runtime_error("lowhash0_multi: null argument");
+    shasta_mi355x_group g(deviceCount, devices);
+    g.impl.setMarkers(readCount, markersToc, markersData, nullptr, readFlags);
+    g.impl.lowhash0Run(*params, readLowHashStatistics, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_align4_batch_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align4_options* options, int wantOrdinals, int deviceCount, const int* devices, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!markersToc || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align4_batch_multi: null argument");
+    shasta_mi355x_group g(deviceCount, devices);
+    g.impl.setMarkers(readCount, markersToc, markersData, nullptr, nullptr);
+    g.impl.alignRun(candidateCount, candidates, options, nullptr, wantOrdinals != 0, *result);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_align3_batch_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
+    uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+    const shasta_align3_options* options, int wantOrdinals, int deviceCount, const int* devices, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!markersToc || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("align3_batch_multi: null argument");
+    shasta_mi355x_group g(deviceCount, devices);
+    g.impl.setMarkers(readCount, markersToc, markersData, nullptr, nullptr);
+    g.impl.alignRun(candidateCount, candidates, nullptr, options, wantOrdinals != 0, *result);
     return 0;
     API_END(1)
 }

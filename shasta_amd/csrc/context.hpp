@@ -50,6 +50,17 @@ struct Context {
         const uint32_t* denseKmerIds, const uint8_t* flags, bool denseOnDevice = false);
 };
 
+// Several devices of one node behind one call (multi.hip): one context per device, one host thread per device for the
+// duration of a call, device-to-device copies over xGMI between the stages of LowHash0.
+struct Group {
+    std::vector<std::unique_ptr<Context>> contexts;
+    Group(int deviceCount, const int* devices);          // devices == nullptr: 0 .. deviceCount - 1; a device may be listed more than once
+    void setMarkers(uint64_t readCount, const uint64_t* toc, const void* data7, const uint32_t* denseKmerIds, const uint8_t* flags);
+    void lowhash0Run(const shasta_lowhash0_params&, uint64_t* readLowHashStatistics, shasta_lowhash0_result&);
+    void alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
+        const shasta_align4_options* options4, const shasta_align3_options* options3, bool wantOrdinals, shasta_align4_result&);
+};
+
 // One timed launch (or group of launches that form one step): events on `stream` around the statement(s).
 #define SHASTA_TIMED(ctx, name, stream, bytes, work, ...) do { const KernelTimers::Span span_ = (ctx).timers.begin(name, stream); \
     __VA_ARGS__; (void)(ctx).timers.end(span_, bytes, work); } while(0)

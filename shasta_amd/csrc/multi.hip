@@ -63,7 +63,8 @@ template<class T> T* mallocCopy(const std::vector<T>& v)
 // Runs fn(rank) on one thread per device; the first error (by rank) is rethrown after all threads have ended.
 template<class F> void onEveryDevice(int world, CallBarrier& barrier, F fn)
 {
-    std::vector<std::string> errors(size_t(world));
+    std::vector<std::string> errors;
+    errors.resize(size_t(world));
     std::vector<std::thread> threads;
     auto body = [&](int rank) {
         try { fn(rank); }
@@ -148,8 +149,9 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
         std::vector<shasta_oriented_read_pair> candidates;
         uint32_t log2BucketCount = 0;
     };
-    std::vector<Rank> ranks(size_t(world), Rank());
-    for(Rank& r : ranks) r.offsets.assign(size_t(world) + 1, 0);
+    std::vector<std::unique_ptr<Rank>> rankStorage;                     // (device buffers do not move)
+    for(int r = 0; r < world; r++) { rankStorage.emplace_back(new Rank()); rankStorage.back()->offsets.assign(size_t(world) + 1, 0); }
+    auto rankOf = [&](int r) -> Rank& { return *rankStorage[size_t(r)]; };
     CallBarrier barrier(world);
     const bool dynamic = p.minHashIterationCount == 0;
     uint64_t highFrequencyShared = 0;
@@ -157,7 +159,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
 
     onEveryDevice(world, barrier, [&](int rank) {
         Context& ctx = *contexts[size_t(rank)];
-        Rank& me = ranks[size_t(rank)];
+        Rank& me = rankOf(rank);
         HIP_CHECK(hipSetDevice(ctx.device));
         hipStream_t stream = ctx.stream;
         hipEvent_t evBegin, evEnd;
@@ -170,7 +172,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
             auto pull = [&](int which, size_t bytes, void* destination) {
                 uint64_t at = 0;
                 for(int s = 0; s < world; s++) {
-                    const Rank& source = ranks[size_t(s)];
+                    const Rank& source = rankOf(s);
                     const uint64_t begin = source.offsets[size_t(rank)], count = source.offsets[size_t(rank) + 1] - begin;
                     if(count == 0) continue;
                     const char* from = static_cast<const char*>(which == 0 ? source.out0 : source.out1) + begin * bytes;
@@ -181,7 +183,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
             };
             auto incoming = [&]() {
                 uint64_t n = 0;
-                for(int s = 0; s < world; s++) n += ranks[size_t(s)].offsets[size_t(rank) + 1] - ranks[size_t(s)].offsets[size_t(rank)];
+                for(int s = 0; s < world; s++) n += rankOf(s).offsets[size_t(rank) + 1] - rankOf(s).offsets[size_t(rank)];
                 return n;
             };
             uint64_t highFrequency = 0;
@@ -205,7 +207,8 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
                 barrier.wait();                                   // every device has what it needs: the sources may be reused
                 const uint64_t* pairKeys = nullptr;
                 uint64_t used = 0;
-                std::vector<uint64_t> hist(size_t(LOWHASH0_SIZE_HISTOGRAM_BINS));
+                std::vector<uint64_t> hist;
+                hist.resize(size_t(LOWHASH0_SIZE_HISTOGRAM_BINS));
                 std::vector<uint32_t> overflow;
                 lowhash0Buckets(ctx, me.recvKeys.data(), me.recvVals.data(), records, me.offsets.data(), &pairKeys, &used, hist.data(), overflow);
                 me.out0 = pairKeys; me.out1 = nullptr;
@@ -223,7 +226,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
                 lowhash0Merge(ctx, me.recvPairs.data(), pairs, dynamic, &me.high, &total);
                 if(dynamic) {
                     barrier.wait();
-                    if(rank == 0) { highFrequencyShared = 0; for(const Rank& r : ranks) highFrequencyShared += r.high; }
+                    if(rank == 0) { highFrequencyShared = 0; for(int r = 0; r < world; r++) highFrequencyShared += rankOf(r).high; }
                     barrier.wait();
                     highFrequency = highFrequencyShared;
                 }
@@ -243,21 +246,23 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
 
     // Reductions and assembly, in rank order (each device's candidates are sorted and cover its readId0 range:
     // their concatenation is the reference's order).
-    const uint64_t iterations = ranks[0].highPerIteration.size();
+    const uint64_t iterations = rankOf(0).highPerIteration.size();
     std::vector<shasta_oriented_read_pair> candidates;
     std::vector<uint64_t> high(iterations, 0), total(iterations, 0), histogramRows;
     std::memset(readLowHashStatistics, 0, 3 * readCount * sizeof(uint64_t));
-    for(const Rank& r : ranks) {
+    for(int k = 0; k < world; k++) {
+        const Rank& r = rankOf(k);
         candidates.insert(candidates.end(), r.candidates.begin(), r.candidates.end());
         for(uint64_t k = 0; k < 3 * readCount; k++) readLowHashStatistics[k] += r.statistics[k];
         for(uint64_t t = 0; t < iterations; t++) { high[t] += r.highPerIteration[t]; total[t] += r.totalPerIteration[t]; }
     }
-    const uint64_t bucketCount = 1ULL << ranks[0].log2BucketCount;
+    const uint64_t bucketCount = 1ULL << rankOf(0).log2BucketCount;
     for(uint64_t t = 0; t < iterations; t++) {
         // Histogram rows (src/LowHash0.cpp:586-595) of the iteration from the summed bins.
         std::map<uint64_t, uint64_t> rows;
         uint64_t used = 0;
-        for(const Rank& r : ranks) {
+        for(int k = 0; k < world; k++) {
+            const Rank& r = rankOf(k);
             used += r.usedPerIteration[t];
             for(int s = 1; s < LOWHASH0_SIZE_HISTOGRAM_BINS; s++) {
                 const uint64_t c = r.histPerIteration[t * LOWHASH0_SIZE_HISTOGRAM_BINS + uint64_t(s)];
@@ -268,7 +273,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
         if(bucketCount > used) rows[0] = bucketCount - used;
         for(const auto& row : rows) { histogramRows.push_back(t); histogramRows.push_back(row.first); histogramRows.push_back(row.second); }
     }
-    result.log2BucketCount = ranks[0].log2BucketCount;
+    result.log2BucketCount = rankOf(0).log2BucketCount;
     result.candidateCount = candidates.size();
     result.candidates = mallocCopy(candidates);
     result.iterationCount = uint32_t(iterations);
@@ -311,7 +316,8 @@ void Group::alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* c
         }
         cut[size_t(world)] = candidateCount;
     }
-    std::vector<shasta_align4_result> parts(size_t(world));
+    std::vector<shasta_align4_result> parts;
+    parts.resize(size_t(world));
     for(shasta_align4_result& r : parts) std::memset(&r, 0, sizeof(r));
     CallBarrier barrier(world);
     try {

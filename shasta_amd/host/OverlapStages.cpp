@@ -1,5 +1,6 @@
 #include "OverlapStages.hpp"
 
+#include <cstdlib>
 #include <algorithm>
 #include <fstream>
 #include <functional>
@@ -19,7 +20,26 @@ std::string dataName(const std::string& directory, const std::string& name)
     if(directory.empty()) return name;
     return directory.back() == '/' ? directory + name : directory + "/" + name;
 }
+std::vector<int>& deviceList()
+{
+    static std::vector<int> list = [] {
+        std::vector<int> v;
+        if(const char* e = std::getenv("SHASTA_MI355X_DEVICES")) {
+            int value = 0; bool have = false;
+            for(const char* c = e; ; c++) {
+                if(*c >= '0' && *c <= '9') { value = 10 * value + (*c - '0'); have = true; }
+                else { if(have) v.push_back(value); value = 0; have = false; if(*c == 0) break; }
+            }
+        }
+        if(v.empty()) v.push_back(0);
+        return v;
+    }();
+    return list;
+}
 }  // namespace
+
+void setDevices(const std::vector<int>& d) { if(d.empty()) throw std::runtime_error("setDevices: empty device list."); deviceList() = d; }
+const std::vector<int>& devices() { return deviceList(); }
 
 LowHash0::LowHash0(
     size_t m, double hashFraction, size_t minHashIterationCount, double alignmentCandidatesPerRead,
@@ -42,8 +62,8 @@ LowHash0::LowHash0(
     readLowHashStatistics.resize(readCount);
 
     shasta_lowhash0_result r{};
-    if(shasta_mi355x_lowhash0(readCount, markers.toc.begin(), markers.data.begin(), readFlags.begin(), &p,
-        reinterpret_cast<uint64_t*>(readLowHashStatistics.begin()), &r)) {
+    if(shasta_mi355x_lowhash0_multi(readCount, markers.toc.begin(), markers.data.begin(), readFlags.begin(), &p,
+        int(devices().size()), devices().data(), reinterpret_cast<uint64_t*>(readLowHashStatistics.begin()), &r)) {
         throw std::runtime_error(shasta_mi355x_last_error());
     }
 
@@ -336,8 +356,8 @@ void computeAlignments(const std::string& dataDirectory, const AlignOptions& ali
         o.minAlignedFraction = alignOptions.minAlignedFraction;
         o.maxSkip = alignOptions.maxSkip; o.maxDrift = alignOptions.maxDrift; o.maxTrim = alignOptions.maxTrim;
         o.suppressContainments = alignOptions.suppressContainments ? 1 : 0;
-        if(shasta_mi355x_align3_batch(readCount, markers.toc.begin(), markers.data.begin(),
-            candidates.size(), candidates.begin(), &o, 0, &r)) {
+        if(shasta_mi355x_align3_batch_multi(readCount, markers.toc.begin(), markers.data.begin(),
+            candidates.size(), candidates.begin(), &o, 0, int(devices().size()), devices().data(), &r)) {
             throw std::runtime_error(shasta_mi355x_last_error());
         }
     } else {
@@ -351,8 +371,8 @@ void computeAlignments(const std::string& dataDirectory, const AlignOptions& ali
         o.maxBand = uint64_t(alignOptions.maxBand);
         o.matchScore = alignOptions.matchScore; o.mismatchScore = alignOptions.mismatchScore; o.gapScore = alignOptions.gapScore;
         o.suppressContainments = alignOptions.suppressContainments ? 1 : 0;
-        if(shasta_mi355x_align4_batch(readCount, markers.toc.begin(), markers.data.begin(),
-            candidates.size(), candidates.begin(), &o, 0, &r)) {
+        if(shasta_mi355x_align4_batch_multi(readCount, markers.toc.begin(), markers.data.begin(),
+            candidates.size(), candidates.begin(), &o, 0, int(devices().size()), devices().data(), &r)) {
             throw std::runtime_error(shasta_mi355x_last_error());
         }
     }

@@ -17,6 +17,7 @@
 
 #include <array>
 #include <string>
+#include <vector>
 
 namespace shasta_mi355x {
 namespace host {
@@ -80,6 +81,13 @@ void findAlignmentCandidatesLowHash0(
     size_t threadCount, size_t largeDataPageSize = 4096);
 
 void computeAlignments(const std::string& dataDirectory, const AlignOptions&, size_t threadCount, size_t largeDataPageSize = 4096);
+
+// The GPUs both seams run on -- a run-level setting like the reference's --threads, not an argument of the seams (they
+// keep the reference's signatures).  Default: the list in the environment variable SHASTA_MI355X_DEVICES ("0,1,2,3";
+// a device may be named more than once), else device 0.  More than one device: the sharded paths of
+// include/shasta_mi355x.h (*_multi), identical results.
+void setDevices(const std::vector<int>& devices);
+const std::vector<int>& devices();
 
 // Assembler::findMarkers (src/AssemblerMarkers.cpp:11-24): Reads-Bases.{toc,data} + Reads-BaseCount + Kmers
 // -> Markers.{toc,data}.  The step that produces the input of the two seams above.

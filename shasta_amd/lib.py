@@ -29,6 +29,9 @@ EXPORTS = [
     "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
     "shasta_mi355x_find_markers", "shasta_mi355x_find_markers_free",
     "shasta_mi355x_palindromic_screen",
+    "shasta_mi355x_group_create", "shasta_mi355x_group_destroy", "shasta_mi355x_group_set_markers", "shasta_mi355x_group_set_kmer_ids",
+    "shasta_mi355x_group_lowhash0_run", "shasta_mi355x_group_align4_run", "shasta_mi355x_group_align3_run",
+    "shasta_mi355x_lowhash0_multi", "shasta_mi355x_align4_batch_multi", "shasta_mi355x_align3_batch_multi",
 ]
 
 
@@ -105,6 +108,48 @@ class Library:
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res))
         self._check(rc, "shasta_mi355x_align3_batch")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    # One-shot calls over several devices (include/shasta_mi355x.h, *_multi): `devices` lists HIP device ids.
+    def lowhash0_multi(self, toc, data7, flags, params, devices):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        read_count = (len(toc) - 1) // 2
+        flags = np.zeros(read_count, np.uint8) if flags is None else np.ascontiguousarray(flags, np.uint8)
+        stats = np.zeros((read_count, 3), dtype=np.uint64)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        res = abi.LowHash0Result()
+        rc = self.lib.shasta_mi355x_lowhash0_multi(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            abi.as_ptr(flags, C.c_uint8), C.byref(params), C.c_int(len(dev)), abi.as_ptr(dev, C.c_int), abi.as_ptr(stats, C.c_uint64), C.byref(res))
+        self._check(rc, "shasta_mi355x_lowhash0_multi")
+        out = abi.LowHash0Output(res, stats)
+        self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
+        return out
+
+    def _align_batch_multi(self, entry, name, toc, data7, candidates, options, want_ordinals, devices):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        read_count = (len(toc) - 1) // 2
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        res = abi.Align4Result()
+        rc = entry(
+            C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+            C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.c_int(len(dev)), abi.as_ptr(dev, C.c_int), C.byref(res))
+        self._check(rc, name)
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def align4_batch_multi(self, toc, data7, candidates, options, devices, want_ordinals=True):
+        return self._align_batch_multi(self.lib.shasta_mi355x_align4_batch_multi, "shasta_mi355x_align4_batch_multi",
+                                       toc, data7, candidates, options, want_ordinals, devices)
+
+    def align3_batch_multi(self, toc, data7, candidates, options, devices, want_ordinals=True):
+        return self._align_batch_multi(self.lib.shasta_mi355x_align3_batch_multi, "shasta_mi355x_align3_batch_multi",
+                                       toc, data7, candidates, options, want_ordinals, devices)
+
+    def group(self, devices):
+        return Group(self, devices)
 
     def find_markers(self, reads_toc, reads_data, base_counts, k, is_marker, want_packed=True, context=None, flags=None):
         """Marker finding (MarkerFinder).  Reads as Shasta stores them (two bit planes per 64 bases),
@@ -184,6 +229,65 @@ class Library:
 
     def context(self, device=0):
         return Context(self, device)
+
+
+class Group:
+    """Several devices behind one call, markers resident on each (shasta_mi355x_group)."""
+
+    def __init__(self, library, devices):
+        self.library = library
+        self.lib = library.lib
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self.lib.shasta_mi355x_group_create.restype = C.c_void_p
+        self.handle = self.lib.shasta_mi355x_group_create(C.c_int(len(dev)), abi.as_ptr(dev, C.c_int))
+        if not self.handle:
+            raise RuntimeError("shasta_mi355x_group_create failed: %s" % self.lib.shasta_mi355x_last_error().decode())
+        self.read_count = 0
+
+    def close(self):
+        if self.handle:
+            self.lib.shasta_mi355x_group_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_kmer_ids(self, toc, kmer_ids, flags=None):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        kmer = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
+        self.read_count = (len(toc) - 1) // 2
+        fp = abi.as_ptr(np.ascontiguousarray(flags, np.uint8), C.c_uint8) if flags is not None else None
+        self.library._check(self.lib.shasta_mi355x_group_set_kmer_ids(
+            C.c_void_p(self.handle), C.c_uint64(self.read_count), abi.as_ptr(toc, C.c_uint64), abi.as_ptr(kmer, C.c_uint32), fp),
+            "shasta_mi355x_group_set_kmer_ids")
+
+    def lowhash0(self, params):
+        stats = np.zeros((self.read_count, 3), dtype=np.uint64)
+        res = abi.LowHash0Result()
+        self.library._check(self.lib.shasta_mi355x_group_lowhash0_run(
+            C.c_void_p(self.handle), C.byref(params), abi.as_ptr(stats, C.c_uint64), C.byref(res)), "shasta_mi355x_group_lowhash0_run")
+        out = abi.LowHash0Output(res, stats)
+        self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
+        return out
+
+    def align4(self, candidates, options, want_ordinals=False):
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        res = abi.Align4Result()
+        self.library._check(self.lib.shasta_mi355x_group_align4_run(
+            C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_group_align4_run")
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def align3(self, candidates, options, want_ordinals=False):
+        candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
+        res = abi.Align4Result()
+        self.library._check(self.lib.shasta_mi355x_group_align3_run(
+            C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
+            C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_group_align3_run")
+        return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
 
 
 class Context:

@@ -285,6 +285,9 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n 
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if(n) std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { if(n) std::memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if(n) std::memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemuStream{0}; return hipSuccess; }

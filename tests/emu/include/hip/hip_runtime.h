@@ -57,6 +57,7 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr hipError_t hipErrorInvalidValue = 1;
+constexpr hipError_t hipErrorPeerAccessAlreadyEnabled = 704;
 constexpr hipError_t hipErrorLaunchFailure = 719;
 typedef struct hipemuStream* hipStream_t;
 typedef struct hipemuEvent* hipEvent_t;
@@ -79,6 +80,9 @@ hipError_t hipHostMalloc(void**, size_t, unsigned);
 hipError_t hipHostFree(void*);
 hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind);
 hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t);
+hipError_t hipMemcpyPeerAsync(void*, int, const void*, int, size_t, hipStream_t);
+hipError_t hipDeviceCanAccessPeer(int*, int, int);
+hipError_t hipDeviceEnablePeerAccess(int, unsigned);
 hipError_t hipMemset(void*, int, size_t);
 hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t);
 hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);

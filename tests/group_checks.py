@@ -1,0 +1,60 @@
+"""Several devices behind one call (shasta_mi355x_group, *_multi): results identical to the one-device entry points
+and to the oracle for any device count.  On a box with one GPU (and on the emulated build) the device list names
+device 0 several times: every exchange, split and reduction of the sharded path still runs."""
+import numpy as np
+
+from shasta_amd import abi
+from tests import support
+
+
+def lowhash0_and_aligners(lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_reads=260, limit=900):
+    toc, kmer, data7 = support.small_marker_set(n_reads=n_reads, genome_markers=14000, seed=61)
+    flags = np.zeros(n_reads, np.uint8)
+    flags[[3, n_reads - 2]] = 1
+    cases = [abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=2),
+             abi.default_lowhash0_params(m=5, hashFraction=0.03, minHashIterationCount=0, alignmentCandidatesPerRead=6.0, minBucketSize=2, maxBucketSize=40)]
+    o4 = abi.default_align4_options(minAlignedMarkerCount=40)
+    o3 = abi.default_align3_options(minAlignedMarkerCount=40)
+    compared = 0
+    for p in cases:
+        ref = oracle_lib.lowhash0(toc, data7, flags, p)
+        assert len(ref.candidates) > 100
+        for devices in device_lists:
+            out = lib.lowhash0_multi(toc, data7, flags, p, devices)
+            support.same_lowhash(out, ref)
+            compared += 1
+    cand = ref.candidates[:limit]
+    x4 = oracle_lib.align4_batch(toc, data7, cand, o4, want_ordinals=True, threads=0)
+    x3 = oracle_lib.align3_batch(toc, data7, cand, o3, want_ordinals=True, threads=0)
+    for devices in device_lists:
+        y4 = lib.align4_batch_multi(toc, data7, cand, o4, devices, want_ordinals=True)
+        y3 = lib.align3_batch_multi(toc, data7, cand, o3, devices, want_ordinals=True)
+        if not (x4.status & 0x80).any():
+            support.same_align(x4, y4)
+        else:
+            assert x4.per_candidate((x4.status & 0x80) == 0) == y4.per_candidate((x4.status & 0x80) == 0)
+        support.same_align(x3, y3)
+        assert y4.dp_cell_count == x4.dp_cell_count
+    # The resident form: markers stay on every device of the group between calls.
+    with lib.group(device_lists[0]) as g:
+        g.set_kmer_ids(toc, kmer, flags)
+        a = g.lowhash0(cases[0])
+        support.same_lowhash(a, oracle_lib.lowhash0(toc, data7, flags, cases[0]))
+        b = g.align4(cand, o4, want_ordinals=True)
+        if not (x4.status & 0x80).any():
+            support.same_align(x4, b)
+    # Fewer candidates than devices, and none at all.
+    few = lib.align4_batch_multi(toc, data7, cand[:2], o4, (0, 0, 0), want_ordinals=True)
+    assert np.array_equal(few.status, x4.status[:2])
+    none = lib.align4_batch_multi(toc, data7, cand[:0], o4, (0, 0), want_ordinals=True)
+    assert len(none.status) == 0 and len(none.alignment_data) == 0
+    return compared
+
+
+def errors_do_not_hang(lib):
+    import pytest
+    toc, kmer, data7 = support.small_marker_set(n_reads=60, genome_markers=5000, seed=62)
+    with pytest.raises(RuntimeError, match="unreasonably small"):
+        lib.lowhash0_multi(toc, data7, None, abi.default_lowhash0_params(log2MinHashBucketCount=3), (0, 0))
+    with pytest.raises(RuntimeError):
+        lib.lowhash0_multi(toc, data7, None, abi.default_lowhash0_params(), (0, 99))      # no such device

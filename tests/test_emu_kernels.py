@@ -171,3 +171,9 @@ def test_stage_scripts_in_a_run_directory(emu_lib, oracle_lib, tmp_path):
     from tests import mirror_checks
     host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
     mirror_checks.stage_scripts_in_a_run_directory(oracle_lib, tmp_path, host)
+
+
+def test_several_devices_behind_one_call(emu_lib, oracle_lib):
+    from tests import group_checks
+    assert group_checks.lowhash0_and_aligners(emu_lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_reads=160, limit=300) == 4
+    group_checks.errors_do_not_hang(emu_lib)

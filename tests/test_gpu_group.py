@@ -1,0 +1,16 @@
+"""The in-process multi-GPU seam (include/shasta_mi355x.h: shasta_mi355x_group, *_multi) on the MI355X.  The box has one
+GPU: the device list names it two and three times, so the sharded LowHash0 (both exchanges as device-to-device copies,
+host-side reductions) and the split aligners run for real; a node with more GPUs runs the same code with distinct ids."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_several_devices_behind_one_call(gpu_lib, oracle_lib):
+    from tests import group_checks
+    assert group_checks.lowhash0_and_aligners(gpu_lib, oracle_lib) == 4
+
+
+def test_group_errors_do_not_hang(gpu_lib):
+    from tests import group_checks
+    group_checks.errors_do_not_hang(gpu_lib)

@@ -18,7 +18,11 @@ def _fields(pairs12):
     return a[:, 0:9]                      # readIds[2] + isSameStrand; the 3 padding bytes are unspecified in the reference
 
 
-def test_stage_executable_reproduces_the_reference_files(gpu_lib, ref_lib, oracle_lib, tmp_path):
+@pytest.mark.parametrize("devices", ["0", "0,0,0"])
+def test_stage_executable_reproduces_the_reference_files(gpu_lib, ref_lib, oracle_lib, tmp_path, monkeypatch, devices):
+    # devices = "0,0,0": the C++ host layer runs both seams through the sharded multi-device entry points
+    # (SHASTA_MI355X_DEVICES; the one GPU of the box named three times) -- same files, byte for byte.
+    monkeypatch.setenv("SHASTA_MI355X_DEVICES", devices)
     toc, kmer, data7 = support.small_marker_set(n_reads=300, genome_markers=20000, seed=91)
     flags = np.zeros(300, np.uint8)
     flags[[2, 250]] = 1
