@@ -310,7 +310,7 @@ def main():
 
         def step():
             lh = distributed.lowhash0(backend, p, read_count, boundaries)
-            share, total = distributed.candidate_share(lh.candidates, device)
+            share, total = distributed.candidate_share(lh.candidates, device, toc=toc)
             if args.lowhash_only:
                 return lh, None, total
             al = align(share)
@@ -395,7 +395,7 @@ def main():
                 "candidates": pairs_total, "alignments_stored": stored_total,
                 "parallelism": "1 GPU" if world == 1 else
                                "%d GPUs, one job: reads sharded by id range, RCCL all-to-all of low-hash records and of pair "
-                               "keys per MinHash iteration, candidates re-split evenly for Align4" % world,
+                               "keys per MinHash iteration, candidates re-split by sum(nx+ny) for Align4" % world,
             },
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
                                        "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps},

@@ -216,7 +216,13 @@ align3BandKernel(
         else if(dir == 2u) { --j; }
         else { --i; }
     }
-    if(offsetMin > offsetMax) return;                    // no aligned column: empty alignment (:185-192)
+    // No column of the down-sampled alignment pairs equal kmer ids.  When the down-sampled alignment has no aligned column at
+    // all the reference returns an empty alignment (:185-192).  When it has aligned columns but all of them are mismatches,
+    // the reference goes on with offsetMin = INT_MAX, offsetMax = INT_MIN (:196-222), overflows the band arithmetic and hands
+    // SeqAn a band whose lower diagonal lies above its upper one; what SeqAn 2.4.0 does with it cannot be checked here (the
+    // library is absent), the caller logs and skips such a pair if it throws (src/AssemblerAlign.cpp:419-435).  Either way
+    // nothing is stored for the pair; this path reports it as an empty alignment (status EMPTY, not SKIPPED).
+    if(offsetMin > offsetMax) return;
     const int32_t bandMin = offsetMin - bandExtend, bandMax = offsetMax + bandExtend;   // :224-225
     if(bandMax - bandMin > maxBand) return;              // :236-241
     const PairDesc pd = pairs[pair];

@@ -96,6 +96,9 @@ DeviceOptions makeOptions(const shasta_align4_options& o)
     d.minAlignedMarkerCount = o.minAlignedMarkerCount;
     d.minAlignedFraction = o.minAlignedFraction;
     d.maxSkip = o.maxSkip; d.maxDrift = o.maxDrift; d.maxTrim = o.maxTrim; d.maxBand = o.maxBand;
+    // The DP kernels hold a band of at most 1024 diagonals (src/AssemblerOptions.cpp: Align.maxBand defaults to 1000).  A
+    // wider limit would let components through that they cannot compute: refused here, loudly, instead of skipping pairs later.
+    if(o.maxBand > 1024) throw std::runtime_error("Align4: maxBand must not exceed 1024 (the banded DP kernels hold 1024 diagonals).");
     d.suppressContainments = o.suppressContainments ? 1u : 0u;
     return d;
 }
@@ -133,7 +136,10 @@ struct BatchScratch {
 struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; hipStream_t wide; };
 
 constexpr int CELLS_CLASSES = 3;
-constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {11, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
+#ifndef SHASTA_CELLS_NA0
+#define SHASTA_CELLS_NA0 11
+#endif
+constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
 // Timing experiments compile other geometries (make EXTRA=-DSHASTA_CELLS_SC0=9 ...): the LDS a workgroup takes
 // decides how many wavefronts a CU holds, and the cells kernels are bound by latency, not by instruction issue.
 #ifndef SHASTA_CELLS_SC0
@@ -429,7 +435,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     // Candidates per batch (SHASTA_MI355X_ALIGN_BATCH_LOG2 overrides it for timing experiments, 10 .. 20).
     static const uint64_t BATCH = [] {
         const char* e = std::getenv("SHASTA_MI355X_ALIGN_BATCH_LOG2");
-        const int l = e ? std::atoi(e) : 17;
+        const int l = e ? std::atoi(e) : 18;
         return 1ULL << std::min(std::max(l, 10), 20);
     }();
     const uint64_t batchCount = (candidateCount + BATCH - 1) / BATCH;

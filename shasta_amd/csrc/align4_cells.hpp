@@ -315,7 +315,19 @@ __device__ unsigned long long g_phaseCycles[16];
 #define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
     if((threadIdx.x & 63) == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
 #define PHASE_BEGIN() unsigned long long phaseT_ = __builtin_readcyclecounter()
+// Inside the stream loop: cycles of probe [7], first resolve pass [8], counting [9], further matches [10]; rounds [11],
+// iterations of the further-matches loop [12], count calls [13].
+#define SUBPHASE_DECLARE() unsigned long long sub_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, subT_ = 0
+#define SUBPHASE_START() subT_ = __builtin_readcyclecounter()
+#define SUBPHASE_ADD(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); sub_[k] += now_ - subT_; subT_ = now_; } while(0)
+#define SUBPHASE_COUNT(k) (++sub_[k])
+#define SUBPHASE_FLUSH() do { if((threadIdx.x & 63) == 0) for(int k_ = 0; k_ < 8; k_++) atomicAdd(&g_phaseCycles[7 + k_], sub_[k_]); for(int k_ = 0; k_ < 8; k_++) sub_[k_] = 0; } while(0)
 #else
+#define SUBPHASE_DECLARE() do {} while(0)
+#define SUBPHASE_START() do {} while(0)
+#define SUBPHASE_ADD(k) do {} while(0)
+#define SUBPHASE_COUNT(k) do {} while(0)
+#define SUBPHASE_FLUSH() do {} while(0)
 #define PHASE_MARK(k) do {} while(0)
 #define PHASE_BEGIN() do {} while(0)
 #endif
@@ -446,30 +458,32 @@ align4CellsChunkKernel(
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
 
-#if SHASTA_CELLS_GRID
-        // Experiment (off by default): when the candidate's whole cell grid fits the wavefront's
-        // cell region as one byte per cell, count in a direct grid -- one LDS atomic per hit, no probing, no loop.
-        // A lane adds only while the byte is below the threshold, so a byte never exceeds threshold - 1 + 64.
+        // When the candidate's whole cell grid fits the wavefront's cell region as one BYTE per cell (nx + ny up to about 4000
+        // at the default cell size: nearly every candidate of the first class), the entries are counted in a direct grid: one LDS
+        // atomic per hit, no keys, no probing.  A lane adds only while the byte is below the threshold, so a byte never exceeds
+        // threshold - 1 + 64.  Otherwise: the open-addressing table of packed (iY | iX | count) words.
         const uint32_t gridX = divMagic(nx + ny - 2, magicX) + 1, gridY = divMagic(nx + ny - 2, magicY) + 1;
         const bool useGrid = nx + ny >= 2 && uint64_t(gridX) * gridY <= 4ull * SC && threshold <= 191;
         if(useGrid) {
             const uint32_t gridWords = (gridX * gridY + 3) / 4;
             for(uint32_t k = lane; k < gridWords; k += WAVE) cells[k] = 0;
-        } else
-#endif
-        for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
+        } else {
+            for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
+        }
         if(lane == 0) scratch[0] = 0;
         waveLdsSync();
         PHASE_MARK(1);
 
         // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
-        // Counts the hits of one round: hit[u] with table ordinal ti[u] and stream ordinal t.
-        auto countHits = [&](const bool (&hit)[CELLS_UNROLL], const uint32_t (&ti)[CELLS_UNROLL], uint32_t s0) {
-            bool pending[CELLS_UNROLL];
-            uint32_t key[CELLS_UNROLL], packed[CELLS_UNROLL], cs[CELLS_UNROLL], len[CELLS_UNROLL], probes[CELLS_UNROLL];
+        // Counts hits: hit[u] with table ordinal ti[u] and stream ordinal ts[u] (N = 4 in a round's first pass, 1 for the
+        // further matches of a marker).
+        auto countHits = [&](auto nTag, const bool* hit, const uint32_t* ti, const uint32_t* ts) {
+            constexpr int N = decltype(nTag)::value;
+            bool pending[N];
+            uint32_t key[N], packed[N], cs[N], probes[N];
 #pragma unroll
-            for(int u = 0; u < CELLS_UNROLL; u++) {
-                const uint32_t t = s0 + u * WAVE + lane;
+            for(int u = 0; u < N; u++) {
+                const uint32_t t = ts[u];
                 const uint32_t x = swapped ? t : ti[u], y = swapped ? ti[u] : t;
                 const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
                 const uint32_t iX = divMagic(X, magicX), iY = divMagic(Y, magicY);
@@ -477,57 +491,64 @@ align4CellsChunkKernel(
                 // candidates whose cell indices fit (others run in the HBM-scratch kernel).
                 const bool h = hit[u];
                 key[u] = h ? ((iY << 16) | iX) : EMPTY32;
-                len[u] = 1;
                 pending[u] = h;
                 packed[u] = (iY << CELLS_IX_BITS) | iX;
                 cs[u] = hash32(key[u]) >> scShift;
                 probes[u] = 0;
             }
-#if SHASTA_CELLS_GRID
             if(useGrid) {
+                // All reads, then all atomics, then the (rare) threshold crossings: the LDS operations of the N slots are
+                // independent of each other, their latencies overlap.
+                uint32_t word[N], shift[N], before[N];
+                bool add[N];
 #pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) {
-                    if(pending[u]) {
-                        const uint32_t idx = (key[u] >> 16) * gridX + (key[u] & 0xffffu);
-                        const uint32_t word = idx >> 2, shift = 8u * (idx & 3u);
-                        const uint32_t cur = (*reinterpret_cast<volatile uint32_t*>(&cells[word]) >> shift) & 0xffu;
-                        if(cur < threshold) {
-                            const uint32_t before = (atomicAdd(&cells[word], 1u << shift) >> shift) & 0xffu;
-                            if(before + 1 == threshold) {                                         // :417
-                                const uint32_t at = atomicAdd(&scratch[0], 1u);
-                                if(at < uint32_t(MAXC)) kept[at] = key[u];
-                            }
-                        }
+                for(int u = 0; u < N; u++) {
+                    const uint32_t idx = (key[u] >> 16) * gridX + (key[u] & 0xffffu);
+                    word[u] = pending[u] ? idx >> 2 : 0u; shift[u] = 8u * (idx & 3u);
+                }
+#pragma unroll
+                for(int u = 0; u < N; u++) add[u] = pending[u] && ((*reinterpret_cast<volatile uint32_t*>(&cells[word[u]]) >> shift[u]) & 0xffu) < threshold;
+#pragma unroll
+                for(int u = 0; u < N; u++) before[u] = add[u] ? (atomicAdd(&cells[word[u]], 1u << shift[u]) >> shift[u]) & 0xffu : 0xffffu;
+#pragma unroll
+                for(int u = 0; u < N; u++) {
+                    if(before[u] + 1 == threshold) {                                          // :417
+                        const uint32_t at = atomicAdd(&scratch[0], 1u);
+                        if(at < uint32_t(MAXC)) kept[at] = key[u];
                     }
                 }
                 return;
             }
-#endif
-            while(__any(pending[0] | pending[1] | pending[2] | pending[3])) {
+            bool anyPending = false;
 #pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) {
+            for(int u = 0; u < N; u++) anyPending |= pending[u];
+            while(__any(anyPending)) {
+                anyPending = false;
+#pragma unroll
+                for(int u = 0; u < N; u++) {
                     if(pending[u]) {
                         const uint32_t cur = *reinterpret_cast<volatile uint32_t*>(&cells[cs[u]]);
                         bool done = false;
                         uint32_t before = 0;
                         if(cur != EMPTY32 && (cur >> CELLS_COUNT_BITS) == packed[u]) {
-                            before = atomicAdd(&cells[cs[u]], len[u]) & ((1u << CELLS_COUNT_BITS) - 1);
+                            before = atomicAdd(&cells[cs[u]], 1u) & ((1u << CELLS_COUNT_BITS) - 1);
                             done = true;
                         } else if(cur == EMPTY32) {
                             // Claim the slot; on failure look at the same slot again.
-                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << CELLS_COUNT_BITS) | len[u]) == EMPTY32;
+                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << CELLS_COUNT_BITS) | 1u) == EMPTY32;
                         } else {
                             cs[u] = (cs[u] + 1) & (SC - 1);
                             if(++probes[u] == SC) { overflow = max(overflow, 1); reason |= 1; pending[u] = false; }
                         }
                         if(done) {
-                            if(before < threshold && before + len[u] >= threshold) {           // :417
+                            if(before < threshold && before + 1 >= threshold) {                // :417
                                 const uint32_t idx = atomicAdd(&scratch[0], 1u);
                                 if(idx < uint32_t(MAXC)) kept[idx] = key[u];
                             }
                             pending[u] = false;
                         }
                     }
+                    anyPending |= pending[u];
                 }
             }
         };
@@ -535,7 +556,9 @@ align4CellsChunkKernel(
         uint32_t kmNext[CELLS_UNROLL];
 #pragma unroll
         for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        SUBPHASE_DECLARE();
         for(uint32_t s0 = 0; s0 < streamCount; s0 += CELLS_UNROLL * WAVE) {
+            SUBPHASE_START(); SUBPHASE_COUNT(4);
             uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], m[CELLS_UNROLL][4], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
             bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
 #pragma unroll
@@ -558,12 +581,13 @@ align4CellsChunkKernel(
                 if(same) { m[u][2] = 0; m[u][3] = 0; }
                 if(!valid[u]) { m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; }
             }
-            // Resolve the tag matches (usually one per marker) against the kmer ids in LDS.
-            for(;;) {
-                bool more = false;
+            SUBPHASE_ADD(0);
+            // First pass: the first tag match of each of the lane's four markers, resolved against the kmer ids in LDS.
+            uint32_t ts[CELLS_UNROLL];
+            {
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) {
-                    // First tag match of this marker (static register indexing only).
+                    // (static register indexing only)
                     const bool s0m = m[u][0] != 0, s1m = !s0m && m[u][1] != 0, s2m = !s0m && !s1m && m[u][2] != 0;
                     const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
                     const uint32_t ww = s0m ? w[u][0] : (s1m ? w[u][1] : (s2m ? w[u][2] : w[u][3]));
@@ -574,13 +598,52 @@ align4CellsChunkKernel(
                     const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
                     if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
                     hit[u] = cand;
-                    more |= (m[u][0] | m[u][1] | m[u][2] | m[u][3]) != 0;
+                    ts[u] = s0 + uint32_t(u) * WAVE + uint32_t(lane);
                 }
                 bool anyHit = false;
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = hit[u] && ka[u] == km[u]; anyHit |= hit[u]; }
-                if(__any(anyHit)) countHits(hit, ti, s0);
-                if(!__any(more)) break;
+                SUBPHASE_ADD(1);
+                if(__any(anyHit)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts); }
+                SUBPHASE_ADD(2);
+            }
+            // Further matches -- a kmer that occurs more than once in the tabled read (a random marker of a 1500-marker read
+            // over the 8000-marker alphabet of k = 10 has a second occurrence with probability 0.2: a handful of the 256
+            // markers of a round), or a false tag match in front of the true one.  Few lanes have any, so each iteration takes
+            // ONE further match per lane, whichever of the lane's four markers it belongs to: a quarter of the work of a pass
+            // over all four (round 1 repeated the full pass: 2.95 passes per round measured, profiles/r02_cells_phases.txt).
+            for(;;) {
+                uint32_t rest[CELLS_UNROLL];
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) rest[u] = m[u][0] | m[u][1] | m[u][2] | m[u][3];
+                if(!__any((rest[0] | rest[1] | rest[2] | rest[3]) != 0u)) break;
+                SUBPHASE_COUNT(5);
+                static_assert(CELLS_UNROLL == 4, "marker selection below");
+                const int us = rest[0] ? 0 : (rest[1] ? 1 : (rest[2] ? 2 : 3));              // the lane's first marker with a match left (3 when none)
+                uint32_t mw[4], wwv[4];
+#pragma unroll
+                for(int i = 0; i < 4; i++) {
+                    mw[i] = us == 0 ? m[0][i] : (us == 1 ? m[1][i] : (us == 2 ? m[2][i] : m[3][i]));
+                    wwv[i] = us == 0 ? w[0][i] : (us == 1 ? w[1][i] : (us == 2 ? w[2][i] : w[3][i]));
+                }
+                const uint32_t kmSel = us == 0 ? km[0] : (us == 1 ? km[1] : (us == 2 ? km[2] : km[3]));
+                const int is = mw[0] ? 0 : (mw[1] ? 1 : (mw[2] ? 2 : 3));
+                const uint32_t mm = mw[0] ? mw[0] : (mw[1] ? mw[1] : (mw[2] ? mw[2] : mw[3]));
+                const uint32_t ww = mw[0] ? wwv[0] : (mw[1] ? wwv[1] : (mw[2] ? wwv[2] : wwv[3]));
+                const bool cand = mm != 0;
+                const bool low = (mm & 0x8000u) != 0;
+                const uint32_t tiSel = (low ? ww : (ww >> 16)) & xMask;
+                const uint32_t kaSel = aKmers[cand ? tiSel : 0u];
+                const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++)
+#pragma unroll
+                    for(int i = 0; i < 4; i++) m[u][i] = (cand && us == u && is == i) ? cleared : m[u][i];
+                const bool hitSel = cand && kaSel == kmSel;
+                const uint32_t tsSel = s0 + uint32_t(us) * WAVE + uint32_t(lane);
+                SUBPHASE_ADD(3);
+                if(__any(hitSel)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, 1>{}, &hitSel, &tiSel, &tsSel); }
+                SUBPHASE_ADD(2);
             }
             // The few markers that did not fit their buckets.
             for(uint32_t k = 0; k < stashed; k++) {
@@ -588,9 +651,10 @@ align4CellsChunkKernel(
                 bool anyHit = false;
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
-                if(__any(anyHit)) countHits(hit, ti, s0);
+                if(__any(anyHit)) countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts);
             }
         }
+        SUBPHASE_FLUSH();
         waveLdsSync();
         PHASE_MARK(2);
 

@@ -123,9 +123,9 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
 //    with the bias, and nothing overflows (|score| < 2^27);
 //  * trace planes: one ballot per comparison (the mask v_cmp wrote anyway), combined on the
 //    scalar unit; the ballot of a combined predicate is compiled to v_cndmask + v_cmp;
-//  * the trace record goes from lane 0 into a 256-byte LDS line per wavefront and leaves as one
-//    coalesced 4-byte store per lane when the line is full, instead of a select chain over the
-//    lanes and a partial store every iteration;
+//  * the trace record goes from the scalar registers into a 256-byte line held in one vector register
+//    (v_writelane_b32, dword k in lane k) and leaves as one coalesced 4-byte store per lane when the
+//    line is full, instead of a select chain over the lanes and a partial store every iteration;
 //  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
 constexpr int DP_BLOCK = 4;
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -160,12 +160,10 @@ bandedDpForwardKernel(
     constexpr int AL = F > U ? F : U;                     // steady iterations come in groups of AL: whole blocks, whole lines
     constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
     static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
-    __shared__ __attribute__((aligned(16))) uint64_t traceLines[4 * 32];   // one 256-byte line per wavefront of the block (16-byte LDS writes)
     const int lane = laneId();
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(slot >= bundleCount) return;                       // whole wave leaves: all 64 lanes are active below, no block barriers
     const uint32_t bundle = bundleCount - 1 - slot;       // the list is sorted by ascending length: the longest bundles start first
-    uint64_t* const line = traceLines + 32 * (threadIdx.x >> 6);
     const int g = lane / G, l = lane % G;
     const uint32_t pos = bundle * T + uint32_t(g);
     const bool hasTask = pos < taskCount;
@@ -246,23 +244,29 @@ bandedDpForwardKernel(
             }
         }
     };
-    // The record of an iteration goes to slot (it mod F) of the wavefront's line; a full line leaves as
-    // one coalesced store.  Lane 0 writes, all lanes read: the wave barrier keeps the compiler from
-    // moving the read up (the hardware runs a wavefront's LDS operations in order).
-    auto putRecord = [&](int slot, const uint64_t (&words)[RW]) {
-        if(lane == 0) {
-            ulonglong2* __restrict__ record = reinterpret_cast<ulonglong2*>(line + slot * RW);
+    // The record of an iteration (RW ballot words, uniform across the wavefront) goes to slot (it mod F) of the wavefront's
+    // 256-byte line, which is ONE vector register: dword k of the line lives in lane k, written there by v_writelane_b32 straight
+    // from the scalar registers the ballots are in.  A full line leaves as one coalesced 4-byte store per lane.  (Round 1 staged
+    // the line in LDS -- lane 0 wrote it, every lane read it back: 12 % of the kernel's wave cycles were LDS issue stalls.)
+    uint32_t lineRegister = 0;
+    auto putRecord = [&](uint32_t slot, const uint64_t (&words)[RW]) {
 #pragma unroll
-            for(int k = 0; k < C; k++) { ulonglong2 w; w.x = words[2 * k]; w.y = words[2 * k + 1]; record[k] = w; }
+        for(int k = 0; k < RW; k++) {
+            lineRegister = writeLane(uint32_t(words[k]), (slot * RW + uint32_t(k)) * 2u, lineRegister);
+            lineRegister = writeLane(uint32_t(words[k] >> 32), (slot * RW + uint32_t(k)) * 2u + 1u, lineRegister);
+        }
+    };
+    // The same where the slot is a constant once the steady phase is unrolled: the lane select is an inline constant.
+    auto putRecordUnrolled = [&](int slot, const uint64_t (&words)[RW]) {
+#pragma unroll
+        for(int k = 0; k < RW; k++) {
+            lineRegister = writeLaneImmediate(uint32_t(words[k]), (slot * RW + k) * 2, lineRegister);
+            lineRegister = writeLaneImmediate(uint32_t(words[k] >> 32), (slot * RW + k) * 2 + 1, lineRegister);
         }
     };
     auto flushLine = [&](uint32_t lineIndex) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
         SHASTA_DEVICE_CHECK(uint64_t(lineIndex) * 32 + 32 <= ((uint64_t(iters) * RW + 31) & ~31ULL));      // inside the bundle's trace (dpBundleKernel)
-        const uint32_t d = reinterpret_cast<const uint32_t*>(line)[lane];
-        reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = d;
-        __builtin_amdgcn_wave_barrier();
+        reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = lineRegister;
     };
 
     // General iterations [from, to): sliding register windows fed by clamped loads two iterations ahead.
@@ -279,7 +283,7 @@ bandedDpForwardKernel(
         for(uint32_t it = from; it < to; it++) {
             uint64_t words[RW];
             antiDiagonals(std::false_type{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
-            putRecord(int(it % F), words);
+            putRecord(it % F, words);
             if(it % F == F - 1) flushLine(it / F);
 #pragma unroll
             for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
@@ -345,7 +349,7 @@ bandedDpForwardKernel(
                         uint64_t words[RW];
                         antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
                         const int slot = (blk * U + u) % F;
-                        putRecord(slot, words);
+                        putRecordUnrolled(slot, words);
                         if(slot == F - 1) { flushLine(lineIndex); ++lineIndex; }
                     }
 #pragma unroll

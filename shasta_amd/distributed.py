@@ -13,7 +13,8 @@ counterpart -- it is a single shared-memory process -- so this module follows th
   all-reduced once, after the last iteration;
 * each rank's candidates are sorted and cover its readId0 range, so the concatenation in rank
   order is the reference's candidate list;
-* Align4 candidates are independent: the candidate list is all-gathered and re-split evenly.
+* Align4 candidates are independent: the candidate list is all-gathered and re-split into contiguous
+  shares balanced by the markers they touch (sum of nx + ny).
 
 The compute stages are behind a small backend interface (tensors in, tensors out): the product
 backend is HipBackend (the C ABI's shasta_mi355x_lh_* entry points); the CPU tests plug in a numpy
@@ -223,9 +224,11 @@ def gather_candidates(local_candidates, device="cpu", group=None):
     return gathered.cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
 
 
-def candidate_share(local_candidates, device="cpu", group=None):
-    """This rank's even share of the global candidate list for Align4, and the list's length.  The
-    list is all-gathered on the device; only the share crosses to the host."""
+def candidate_share(local_candidates, device="cpu", group=None, toc=None):
+    """This rank's share of the global candidate list for the aligner, and the list's length.  The list is
+    all-gathered on the device; only the share crosses to the host.  With `toc` (Markers.toc of all reads) the
+    contiguous shares are balanced by the markers they touch, sum of nx + ny: reads differ in length by
+    an order of magnitude and the aligner's work follows them; without it the split is even."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     local = np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE)
     home = torch.device(device)
@@ -237,11 +240,30 @@ def candidate_share(local_candidates, device="cpu", group=None):
     total = sum(counts)
     flat = torch.from_numpy(local.view(np.int32).reshape(-1).copy()).to(home)
     gathered = all_gather_padded(flat, [3 * c for c in counts], group)
-    lo, hi = candidate_slice(total, rank, world)
-    share = gathered[3 * lo:3 * hi].cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
-    return share, total
+    if toc is None:
+        lo, hi = candidate_slice(total, rank, world)
+        return gathered[3 * lo:3 * hi].cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1), total
+    everything = gathered.cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
+    lo, hi = candidate_slice_by_markers(everything, toc, rank, world)
+    return everything[lo:hi], total
 
 
 def candidate_slice(count, rank, world):
-    """Even split of the candidate list for Align4 (candidates are independent)."""
+    """Even split of the candidate list (candidates are independent)."""
     return (count * rank) // world, (count * (rank + 1)) // world
+
+
+def candidate_slice_by_markers(candidates, toc, rank, world):
+    """Contiguous split with equal shares of sum(nx + ny + 64) -- the same rule as the in-process group
+    (shasta_amd/csrc/multi.hip, Group::alignRun)."""
+    toc = np.asarray(toc, dtype=np.int64)
+    sizes = np.diff(toc)
+    o0 = 2 * candidates["readId0"].astype(np.int64)
+    o1 = 2 * candidates["readId1"].astype(np.int64) + (candidates["isSameStrand"] == 0).astype(np.int64)
+    prefix = np.concatenate([[0], np.cumsum(sizes[o0] + sizes[o1] + 64)])
+    cuts = [0]
+    for r in range(1, world):
+        target = int(float(prefix[-1]) * float(r) / float(world))
+        cuts.append(min(max(int(np.searchsorted(prefix, target, side="left")), cuts[-1]), len(candidates)))
+    cuts.append(len(candidates))
+    return cuts[rank], cuts[rank + 1]

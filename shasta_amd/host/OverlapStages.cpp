@@ -75,10 +75,20 @@ LowHash0::LowHash0(
     std::cout << "LowHash0 algorithm will use 2^" << r.log2BucketCount;
     std::cout << " = " << (1ULL << r.log2BucketCount) << " buckets. " << std::endl;
     for(uint32_t iteration = 0; iteration < r.iterationCount; iteration++) {
+        // :143-146: with minHashIterationCount = 0 the reference prints the running average before every iteration but the first
+        // (and once more before it stops, below).
+        if(minHashIterationCount == 0 && iteration != 0) {
+            std::cout << "Average number of alignment candidates that each read is involved in is " <<
+                2. * double(r.highFrequency[iteration - 1]) / double(readCount) << std::endl;
+        }
         std::cout << "Alignment candidates after lowhash iteration " << iteration;
         std::cout << ": high frequency " << r.highFrequency[iteration];
         std::cout << ", total " << r.total[iteration];
         std::cout << ", capacity " << r.total[iteration] << "." << std::endl;
+    }
+    if(minHashIterationCount == 0 && r.iterationCount != 0) {
+        std::cout << "Average number of alignment candidates that each read is involved in is " <<
+            2. * double(r.highFrequency[r.iterationCount - 1]) / double(readCount) << std::endl;
     }
 
     // LowHashBucketHistogram.csv, src/LowHash0.cpp:128,586-595.

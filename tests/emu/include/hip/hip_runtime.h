@@ -235,6 +235,11 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 {
     return uint32_t(((uint64_t(hi) << 32) | uint64_t(lo)) >> (8u * (c & 3u)));
 }
+// v_writelane_b32 (shasta_amd/csrc/primitives.hpp uses inline assembly for it): lane `lane` of the result holds `value`
+// (uniform across the wavefront), every other lane keeps `old`.
+#define SHASTA_WRITELANE_DEFINED 1
+__forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uint32_t old) { return (uint32_t(threadIdx.x) & 63u) == (lane & 63u) ? value : old; }
+__forceinline__ uint32_t writeLaneImmediate(uint32_t value, int lane, uint32_t old) { return writeLane(value, uint32_t(lane), old); }
 #ifndef __clang__
 template<class T> __forceinline__ T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 #endif

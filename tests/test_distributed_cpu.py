@@ -32,6 +32,12 @@ def _worker(rank, world, port, out_dir, seed, kw):
         lo, hi = distributed.candidate_slice(len(everything), rank, world)
         share, total = distributed.candidate_share(out.candidates)
         assert total == len(everything) and np.array_equal(share, everything[lo:hi])
+        # The split by markers: contiguous, covers everything, and its shares of sum(nx + ny) differ by less than one candidate's worth.
+        blo, bhi = distributed.candidate_slice_by_markers(everything, toc, rank, world)
+        balanced, total2 = distributed.candidate_share(out.candidates, toc=toc)
+        assert total2 == total and np.array_equal(balanced, everything[blo:bhi])
+        cuts = [distributed.candidate_slice_by_markers(everything, toc, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(everything) and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
                  candidates=np.stack([everything["readId0"], everything["readId1"], everything["isSameStrand"]], axis=1),
                  local=np.stack([out.candidates["readId0"], out.candidates["readId1"], out.candidates["isSameStrand"]], axis=1),
