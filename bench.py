@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 VALU_PEAK_WAVE_INSTRUCTIONS_PER_S = 256 * 4 * 0.5 * 2.4e9
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_100k_reads.json")
 # Kernels whose natural bound is HBM (streaming / sorting); the others are bound by VALU issue and LDS (integer DP, hash joins).
-HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "run lengths", "pair table", "compress")
+HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
 
 
 def make_workload(n_reads, seed):
@@ -209,6 +209,37 @@ def roofline_of(name, row, pmc):
     return r
 
 
+def markers_bench(lib, ctx, args):
+    """The widening row `marker finding` (MarkerFinder, src/MarkerFinder.cpp:16-127) on its own: one step = the reads of the
+    workload (2-bit planes, 0.25 B per base, uploaded inside the step as the seam does) -> dense kmer ids + toc resident in HBM."""
+    from shasta_amd import synthetic
+    toc, data, counts = synthetic.packed_base_reads(args.reads, seed=12345)
+    is_marker = (np.random.default_rng(231).random(1 << 20) < 0.1).astype(np.uint8)
+    bases = int(counts.sum())
+
+    def step():
+        return lib.find_markers(toc, data, counts, 10, is_marker, want_packed=False, context=ctx)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_table_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mtoc, _ = step()
+    elapsed = time.perf_counter() - t0
+    steps = max(1, args.steps)
+    kernels = kernel_rows(ctx.kernel_table(), steps, {})
+    name = max(kernels, key=lambda k: kernels[k]["seconds_per_step"])
+    print(json.dumps({
+        "metric": "RLE bases scanned/sec (marker finding, SURVEY 8f row 2)", "value": bases / (elapsed / steps), "unit": "bases/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64 bit planes -> u32 kmer ids", "data": "synthetic",
+        "config": {"workload": "%d random run-length-encoded reads, mean 20 kb, k = 10, 10%% of the k-mers markers; reads uploaded inside the step"
+                               % args.reads, "bases": bases, "markers_both_strands": int(mtoc[-1])},
+        "kernels": kernels, "roofline": roofline_of(name, kernels[name], {})}))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +249,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on")
     ap.add_argument("--lowhash-only", action="store_true", help="BASELINE configs[1]")
+    ap.add_argument("--markers", action="store_true",
+                    help="marker finding only (SURVEY 8f row 2): random RLE reads of --reads x 20 kb, k = 10, 10 %% of the k-mers markers")
     ap.add_argument("--align-method", type=int, default=4, choices=[3, 4],
                     help="4 = Align4 (BASELINE's metric, the default); 3 = the reference's default method, for comparison")
     args = ap.parse_args()
@@ -256,6 +289,9 @@ def main():
     assert lib.device_count() >= 1, "no gfx950 device: the HIP path cannot run (there is no CPU fallback)"
     p, o = lowhash_params(), (align_options() if args.align_method == 4 else align3_options())
     ctx = lib.context(local_rank)
+    if args.markers:
+        markers_bench(lib, ctx, args)
+        return
 
     def align(candidates):
         if args.align_method == 4:
@@ -339,6 +375,20 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     table = ctx.kernel_table()
+    # Outside the timed region: one more pass with ONE aligner worker.  With six workers the kernels of different batches share
+    # the device, and the HIP-event duration of a launch includes the time it spent sharing; this pass gives every kernel's
+    # duration alone on the device (what a profiler's per-kernel view and the PMC passes see).
+    table_one_worker = None
+    if world == 1 and al is not None and not DRY_RUN_LIBRARY:
+        previous = os.environ.get("SHASTA_MI355X_ALIGN_WORKERS")
+        os.environ["SHASTA_MI355X_ALIGN_WORKERS"] = "1"
+        ctx.kernel_table_reset()
+        lh, al, pairs_total = step()
+        table_one_worker = ctx.kernel_table()
+        if previous is None:
+            del os.environ["SHASTA_MI355X_ALIGN_WORKERS"]
+        else:
+            os.environ["SHASTA_MI355X_ALIGN_WORKERS"] = previous
     stored_total = 0 if al is None else len(al.alignment_data)
     status_counts = None
     if al is not None:
@@ -368,6 +418,16 @@ def main():
             r["share_of_kernel_time"] = r["seconds_per_step"] / kernel_seconds if kernel_seconds > 0 else 0.0
         dominant = max(kernels, key=lambda k: kernels[k]["seconds_per_step"]) if kernels else None
         roofline = roofline_of(dominant, kernels[dominant], pmc) if dominant else None
+        kernels_one_worker = None
+        if table_one_worker is not None:
+            kernels_one_worker = kernel_rows(table_one_worker, 1, pmc)
+            if dominant in kernels_one_worker:
+                alone = roofline_of(dominant, kernels_one_worker[dominant], pmc)
+                roofline["one_worker"] = {k: alone[k] for k in ("achieved", "frac", "avg_launch_ms")}
+                if "valu" in alone:
+                    roofline["one_worker"]["valu_frac"] = alone["valu"]["frac"]
+                roofline["one_worker"]["note"] = ("the same kernel in a pass with one aligner worker (outside the timed region): its launches alone on the device; "
+                                                  "in the timed region six workers' kernels overlap and a launch's HIP-event duration includes the time it shares")
         # The HBM-natured kernel of the path (K1), always reported beside the dominant one.
         hash_name = next((k for k in kernels if k.startswith("hashWindowsKernel")), None)
         out = {
@@ -403,6 +463,9 @@ def main():
             "kernels": kernels,
             "roofline": roofline,
         }
+        if kernels_one_worker is not None:
+            out["kernels_one_worker"] = {k: {f: v[f] for f in ("avg_ms", "seconds_per_step", "achieved_GBps", "valu_issue_frac", "gcups") if f in v}
+                                         for k, v in kernels_one_worker.items()}
         if status_counts is not None:
             out["aligner_status"] = dict(zip(("stored", "rejected_by_filters", "empty", "skipped", "component_ties_flagged"), status_counts))
         if hash_name:

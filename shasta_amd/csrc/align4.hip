@@ -468,7 +468,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         std::string error;
     };
     // SHASTA_MI355X_ALIGN_WORKERS overrides the number of workers (for timing experiments; 1 .. ALIGN_MAX_WORKERS).
-    static const int configuredWorkers = [] {
+    const int configuredWorkers = [] {                 // read at every call: bench.py times one pass with a single worker
         const char* e = std::getenv("SHASTA_MI355X_ALIGN_WORKERS");
         const int n = e ? std::atoi(e) : ALIGN_DEFAULT_WORKERS;
         return std::min(std::max(n, 1), int(Context::ALIGN_MAX_WORKERS));

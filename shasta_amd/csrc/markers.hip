@@ -136,9 +136,13 @@ void findMarkers(Context& ctx, uint64_t readCount, const uint64_t* readsToc, con
     HIP_CHECK(hipMemcpyAsync(dBitmap.data(), bitmap.data(), bitmap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 
     const unsigned grid = divUp((readCount + 1) * WAVE, 256);
-    hipLaunchKernelGGL(markerSweepKernel<false>, dim3(grid), dim3(256), 0, stream,
-        (const uint64_t*)dData.data(), (const uint64_t*)dToc.data(), (const uint64_t*)dBaseCounts.data(), readCount, uint32_t(k),
-        (const uint32_t*)dBitmap.data(), dMarkersToc.data(), (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    // Algorithmic bytes: 0.25 B per base read by either sweep (two bit planes); the second also writes 8 B per marker and strand.
+    uint64_t baseCount = 0;
+    for(uint64_t r = 0; r < readCount; r++) baseCount += baseCounts[r];
+    SHASTA_TIMED(ctx, "markerSweepKernel<false> (count)", stream, baseCount / 4, baseCount,
+        hipLaunchKernelGGL(markerSweepKernel<false>, dim3(grid), dim3(256), 0, stream,
+            (const uint64_t*)dData.data(), (const uint64_t*)dToc.data(), (const uint64_t*)dBaseCounts.data(), readCount, uint32_t(k),
+            (const uint32_t*)dBitmap.data(), dMarkersToc.data(), (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr));
     HIP_CHECK(hipGetLastError());
     exclusiveScan<uint64_t>(dMarkersToc.data(), dMarkersToc.data(), 2 * readCount + 1, scanTemp.data(), stream);
     std::vector<uint64_t> markersToc(2 * readCount + 1);
@@ -146,9 +150,10 @@ void findMarkers(Context& ctx, uint64_t readCount, const uint64_t* readsToc, con
     HIP_CHECK(hipStreamSynchronize(stream));
     const uint64_t markerCount = markersToc[2 * readCount];
     dKmerIds.reserve(markerCount + 1, stream); dPositions.reserve(markerCount + 1, stream);
-    hipLaunchKernelGGL(markerSweepKernel<true>, dim3(grid), dim3(256), 0, stream,
-        (const uint64_t*)dData.data(), (const uint64_t*)dToc.data(), (const uint64_t*)dBaseCounts.data(), readCount, uint32_t(k),
-        (const uint32_t*)dBitmap.data(), (uint64_t*)nullptr, (const uint64_t*)dMarkersToc.data(), dKmerIds.data(), dPositions.data());
+    SHASTA_TIMED(ctx, "markerSweepKernel<true> (write)", stream, baseCount / 4 + 8 * markerCount, baseCount,
+        hipLaunchKernelGGL(markerSweepKernel<true>, dim3(grid), dim3(256), 0, stream,
+            (const uint64_t*)dData.data(), (const uint64_t*)dToc.data(), (const uint64_t*)dBaseCounts.data(), readCount, uint32_t(k),
+            (const uint32_t*)dBitmap.data(), (uint64_t*)nullptr, (const uint64_t*)dMarkersToc.data(), dKmerIds.data(), dPositions.data()));
     HIP_CHECK(hipGetLastError());
 
     result.markerCount = markerCount;
@@ -160,8 +165,9 @@ void findMarkers(Context& ctx, uint64_t readCount, const uint64_t* readsToc, con
         dPacked.reserve(7 * markerCount + 1, stream);
         if(markerCount) {
             const unsigned blocks = unsigned(std::min<uint64_t>(divUp(markerCount, 256), 16384));
-            hipLaunchKernelGGL(packMarkersKernel, dim3(blocks), dim3(256), 0, stream,
-                (const uint32_t*)dKmerIds.data(), (const uint32_t*)dPositions.data(), markerCount, dPacked.data());
+            SHASTA_TIMED(ctx, "packMarkersKernel", stream, 15 * markerCount, markerCount,
+                hipLaunchKernelGGL(packMarkersKernel, dim3(blocks), dim3(256), 0, stream,
+                    (const uint32_t*)dKmerIds.data(), (const uint32_t*)dPositions.data(), markerCount, dPacked.data()));
             HIP_CHECK(hipGetLastError());
         }
         result.markersData = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(1, 7 * markerCount)));

@@ -171,3 +171,32 @@ def fasta_reads(path, n_reads, genome_length, mean_length=15000.0, sigma=0.35, m
             f.write(b"\n")
             meta.append((start, length, flipped))
     return meta
+
+
+def packed_base_reads(n_reads, mean_bases=20000.0, sigma=0.5, min_bases=10500, seed=12345):
+    """Random run-length-encoded reads (no two equal adjacent bases, as Shasta stores reads in RLE space) in the layout of
+    Shasta's LongBaseSequences (src/LongBaseSequence.hpp:33-41): per read, per 64 bases two 64-bit words -- the low bits and the
+    high bits of the bases, first base in the most significant bit.  -> (reads_toc uint64[R+1] in words, reads_data uint64[],
+    base_counts uint64[R]).  For the marker-finding bench line; parity of that stage is tested on reference-made fixtures."""
+    rng = np.random.default_rng(seed)
+    mu = np.log(mean_bases) - 0.5 * sigma * sigma
+    lengths = np.maximum(min_bases, rng.lognormal(mu, sigma, size=n_reads)).astype(np.int64)
+    blocks = (lengths + 63) // 64
+    toc = np.zeros(n_reads + 1, dtype=np.uint64)
+    toc[1:] = np.cumsum(2 * blocks)
+    total_blocks = int(blocks.sum())
+    # One long RLE sequence cut into reads: base[i+1] = base[i] + 1..3 mod 4.
+    steps = rng.integers(1, 4, size=total_blocks * 64, dtype=np.uint8)
+    bases = (np.cumsum(steps, dtype=np.uint64) & np.uint64(3)).astype(np.uint8)
+    # Bases past the end of a read (padding of its last block) are zero.
+    block_start = np.concatenate([[0], np.cumsum(blocks)])[:-1] * 64
+    index = np.arange(total_blocks * 64, dtype=np.int64)
+    read_of_block = np.repeat(np.arange(n_reads), blocks)
+    read_of_base = np.repeat(read_of_block, 64)
+    bases[index - block_start[read_of_base] >= lengths[read_of_base]] = 0
+    low = np.packbits(bases & 1).view(">u8").astype(np.uint64)
+    high = np.packbits(bases >> 1).view(">u8").astype(np.uint64)
+    data = np.empty(2 * total_blocks, dtype=np.uint64)
+    data[0::2] = low
+    data[1::2] = high
+    return toc, data, lengths.astype(np.uint64)
