@@ -170,32 +170,42 @@ constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 16};
 constexpr uint32_t CELLS_SHARE_MIN = 3;
 constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call                        // smaller chunks run as one wave
 
-// kind 0: one-wave workgroups; kind 1: CELLS_SHARED_WAVES waves share the table.
-template<int Q>
+// kind 1: chunks of several candidates, CELLS_SHARED_WAVES wavefronts share the table and take the candidates in turn;
+// kind 0: chunks of one or two candidates, CELLS_COOP_WAVES wavefronts work on one candidate at a time (COOP).
+constexpr int CELLS_COOP_WAVES = 4;
+template<int Q, bool COOP>
 void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
-    const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, waves) * sizeof(uint32_t);
-    std::call_once(ctx.cellsLdsAttribute[Q == 2 ? 0 : 1], [] {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q>),
+    const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, COOP ? 1 : waves) * sizeof(uint32_t);
+    std::call_once(ctx.cellsLdsAttribute[(Q == 2 ? 0 : 1) + (COOP ? 2 : 0)], [] {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q, COOP>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     });
     MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
     // Booked under the template instance that runs (class 0: Q = 2; classes 1 and 2: Q = 4), the name a profiler shows.
     // Algorithmic bytes: 4 (nx + ny) per candidate, summed by the caller; work = candidates.
-    SHASTA_TIMED(ctx, (Q == 2 ? "align4CellsChunkKernel<2>" : "align4CellsChunkKernel<4>"), ws.stream, kmerIdBytes, candidateCount,
-        hipLaunchKernelGGL(align4CellsChunkKernel<Q>, dim3(count), dim3(WAVE * waves), bytes, ws.stream,
+    const char* const name = Q == 2 ? (COOP ? "align4CellsChunkKernel<2, true>" : "align4CellsChunkKernel<2, false>")
+                                    : (COOP ? "align4CellsChunkKernel<4, true>" : "align4CellsChunkKernel<4, false>");
+    SHASTA_TIMED(ctx, name, ws.stream, kmerIdBytes, candidateCount,
+        hipLaunchKernelGGL((align4CellsChunkKernel<Q, COOP>), dim3(count), dim3(WAVE * waves), bytes, ws.stream,
             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
             opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data()));
     HIP_CHECK(hipGetLastError());
 }
 
-void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
+void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, bool coop, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
     if(count == 0) return;
-    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
-    else launchCellsChunksQ<4>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+    const int waves = coop ? CELLS_COOP_WAVES : CELLS_SHARED_WAVES[cls];
+    if(CELLS_Q[cls] == 2) {
+        if(coop) launchCellsChunksQ<2, true>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+        else launchCellsChunksQ<2, false>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+    } else {
+        if(coop) launchCellsChunksQ<4, true>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+        else launchCellsChunksQ<4, false>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+    }
 }
 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
@@ -738,8 +748,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     };
                     uint64_t sharedCandidates = 0, singleCandidates = 0;
                     const uint64_t sharedBytes = bytesOf(shared, sharedCandidates), singleBytes = bytesOf(single, singleCandidates);
-                    launchCellsChunks(ctx, ws, b, c, CELLS_SHARED_WAVES[c], b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity, sharedBytes, sharedCandidates);
-                    launchCellsChunks(ctx, ws, b, c, 1, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity, singleBytes, singleCandidates);
+                    launchCellsChunks(ctx, ws, b, c, false, b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity, sharedBytes, sharedCandidates);
+                    launchCellsChunks(ctx, ws, b, c, true, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity, singleBytes, singleCandidates);
                     HIP_CHECK(hipStreamSynchronize(stream));      // the lists are reused below
                     single.clear(); shared.clear();
                 }

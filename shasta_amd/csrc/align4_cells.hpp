@@ -368,7 +368,12 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 #ifndef SHASTA_CELLS_MAX_THREADS
 #define SHASTA_CELLS_MAX_THREADS 384
 #endif
-template<int Q>
+// COOP: the chunk has fewer candidates than a workgroup has wavefronts (in practice one or two: candidates whose read 0 is too
+// long for the table, so that the shorter read 1 is tabled, and a batch holds few candidates per read 1).  Then the whole
+// workgroup works on ONE candidate at a time: all wavefronts build the table, each streams its share of the partner's rounds
+// into ONE cell region (LDS atomics work across wavefronts), wavefront 0 does the kept-cell graph.  Round 1 ran such chunks
+// as one-wavefront workgroups: a table build per candidate by 64 lanes, at 4-6 wavefronts per CU.
+template<int Q, bool COOP>
 __global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS)
 align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
@@ -393,7 +398,7 @@ align4CellsChunkKernel(
     const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
     uint32_t* const aKmers = ldsWords;
     uint32_t* const aSlots = aKmers + NA;
-    uint32_t* const cells = aSlots + NA + wave * cellsWaveLdsWords(int(chunk.scLog2), Q);
+    uint32_t* const cells = aSlots + NA + (COOP ? 0u : wave) * cellsWaveLdsWords(int(chunk.scLog2), Q);
     uint32_t* const kept = cells + SC;
     uint32_t* const scratch = kept + MAXC;                        // [0] kept count, [1] min, [2] max, [3] staged tasks
     uint32_t* const stage = scratch + 8;
@@ -450,7 +455,7 @@ align4CellsChunkKernel(
         return;
     }
 
-    for(uint32_t c = wave; c < chunk.count; c += waves) {
+    for(uint32_t c = COOP ? 0u : wave; c < chunk.count; c += COOP ? 1u : waves) {
         const uint32_t pair = members[chunk.firstMember + c];
         const PairDesc pd = pairs[pair];
         const uint32_t nx = pd.nx, ny = pd.ny;
@@ -464,14 +469,17 @@ align4CellsChunkKernel(
         // threshold - 1 + 64.  Otherwise: the open-addressing table of packed (iY | iX | count) words.
         const uint32_t gridX = divMagic(nx + ny - 2, magicX) + 1, gridY = divMagic(nx + ny - 2, magicY) + 1;
         const bool useGrid = nx + ny >= 2 && uint64_t(gridX) * gridY <= 4ull * SC && threshold <= 191;
-        if(useGrid) {
-            const uint32_t gridWords = (gridX * gridY + 3) / 4;
-            for(uint32_t k = lane; k < gridWords; k += WAVE) cells[k] = 0;
-        } else {
-            for(uint32_t k = lane; k < SC; k += WAVE) cells[k] = EMPTY32;
+        {
+            const uint32_t first = COOP ? threadIdx.x : uint32_t(lane), stride = COOP ? blockDim.x : uint32_t(WAVE);
+            if(useGrid) {
+                const uint32_t gridWords = (gridX * gridY + 3) / 4;
+                for(uint32_t k = first; k < gridWords; k += stride) cells[k] = 0;
+            } else {
+                for(uint32_t k = first; k < SC; k += stride) cells[k] = EMPTY32;
+            }
+            if(first == 0) { scratch[0] = 0; scratch[4] = 0; }
         }
-        if(lane == 0) scratch[0] = 0;
-        waveLdsSync();
+        if(COOP) __syncthreads(); else waveLdsSync();
         PHASE_MARK(1);
 
         // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
@@ -553,18 +561,21 @@ align4CellsChunkKernel(
             }
         };
 
+        // Rounds of CELLS_UNROLL x 64 markers: all of them for this wavefront, or (COOP) every waves-th one.
+        const uint32_t roundStride = (COOP ? waves : 1u) * uint32_t(CELLS_UNROLL * WAVE);
+        const uint32_t firstRound = COOP ? wave * uint32_t(CELLS_UNROLL * WAVE) : 0u;
         uint32_t kmNext[CELLS_UNROLL];
 #pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
         SUBPHASE_DECLARE();
-        for(uint32_t s0 = 0; s0 < streamCount; s0 += CELLS_UNROLL * WAVE) {
+        for(uint32_t s0 = firstRound; s0 < streamCount; s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
             uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], m[CELLS_UNROLL][4], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
             bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
                 km[u] = kmNext[u];
-                const uint32_t tn = s0 + (CELLS_UNROLL + u) * WAVE + lane;
+                const uint32_t tn = s0 + roundStride + u * WAVE + lane;
                 kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
                 valid[u] = s0 + u * WAVE + lane < streamCount;
             }
@@ -655,9 +666,19 @@ align4CellsChunkKernel(
             }
         }
         SUBPHASE_FLUSH();
-        waveLdsSync();
+        if(COOP) {
+            // What went wrong in any wavefront's share of the rounds reaches wavefront 0 through the region's scratch word.
+            if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
+            __syncthreads();
+            const uint32_t seen = scratch[4];
+            overflow = (seen & 0x10u) ? 2 : ((seen & 0x08u) ? 1 : 0); reason = int(seen & 7u);
+        } else {
+            waveLdsSync();
+        }
         PHASE_MARK(2);
 
+        // The kept-cell graph of the candidate: its own wavefront, or (COOP) wavefront 0 while the others wait at the barrier below.
+        if(!COOP || wave == 0) do {
         const int n = int(scratch[0]);
         if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
         const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
@@ -665,9 +686,9 @@ align4CellsChunkKernel(
             // Bits 4-6 carry the reason (cell table full / kept list full / geometry) for diagnostics.
             const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0);
             if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
-            continue;
+            break;
         }
-        if(n == 0) continue;
+        if(n == 0) break;
         const int nq = (n + WAVE - 1) / WAVE;
 
         // --- kept cells in registers: boundary flags (:424-429 with the corner rules of :530-626) ---
@@ -829,10 +850,12 @@ align4CellsChunkKernel(
             for(int q = 0; q < Q; q++) { remaining[q] &= ~comp[q]; anyRemaining |= remaining[q] != 0; }
         }
         PHASE_MARK(5);
+        } while(false);
+        if(COOP) __syncthreads();                                     // the region is cleared for the next candidate
     }
     // Append this wave's staged tasks.
     waveLdsSync();
-    const uint32_t staged = scratch[3];
+    const uint32_t staged = (!COOP || wave == 0) ? scratch[3] : 0u;
     if(staged) {
         uint32_t base = 0;
         if(lane == 0) base = atomicAdd(taskCount, staged);
