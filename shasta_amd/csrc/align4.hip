@@ -151,61 +151,56 @@ constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13};     // 
 #ifndef SHASTA_CELLS_SC2
 #define SHASTA_CELLS_SC2 12
 #endif
-#ifndef SHASTA_CELLS_WAVES0
-#define SHASTA_CELLS_WAVES0 4
-#endif
-#ifndef SHASTA_CELLS_WAVES1
-#define SHASTA_CELLS_WAVES1 6
-#endif
-#ifndef SHASTA_CELLS_WAVES2
-#define SHASTA_CELLS_WAVES2 4
-#endif
 #ifndef SHASTA_CELLS_ESTIMATE_SHIFT
 #define SHASTA_CELLS_ESTIMATE_SHIFT 13
 #endif
 constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2};
-constexpr int CELLS_Q[CELLS_CLASSES] = {2, 4, 4};
-constexpr int CELLS_SHARED_WAVES[CELLS_CLASSES] = {SHASTA_CELLS_WAVES0, SHASTA_CELLS_WAVES1, SHASTA_CELLS_WAVES2};   // waves of a chunk that share the tabled read
-constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {24, 24, 16};
-constexpr uint32_t CELLS_SHARE_MIN = 3;
-constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call                        // smaller chunks run as one wave
+// Kept cells per candidate: 64 Q (more: the candidate climbs a class, finally to the HBM-scratch kernel).  Q = 2 everywhere:
+// the kernel then needs 115 vector registers (4 wavefronts per SIMD) instead of 224 (2).
+#ifndef SHASTA_CELLS_Q1
+#define SHASTA_CELLS_Q1 2
+#endif
+#ifndef SHASTA_CELLS_Q2
+#define SHASTA_CELLS_Q2 2
+#endif
+#ifndef SHASTA_CELLS_CHUNK_MAX
+#define SHASTA_CELLS_CHUNK_MAX 24
+#endif
+constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2};
+constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16};
+constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call
 
-// kind 1: chunks of several candidates, CELLS_SHARED_WAVES wavefronts share the table and take the candidates in turn;
-// kind 0: chunks of one or two candidates, CELLS_COOP_WAVES wavefronts work on one candidate at a time (COOP).
-constexpr int CELLS_COOP_WAVES = 4;
-template<int Q, bool COOP>
-void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, int waves, const CellsChunk* chunks, uint32_t count,
+// Wavefronts of a chunk's workgroup: they stream one candidate at a time together, then take one kept-cell graph each.
+#ifndef SHASTA_CELLS_WAVES
+#define SHASTA_CELLS_WAVES 4
+#endif
+constexpr int CELLS_WAVES = SHASTA_CELLS_WAVES;
+template<int Q>
+void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
-    const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, COOP ? 1 : waves) * sizeof(uint32_t);
-    std::call_once(ctx.cellsLdsAttribute[(Q == 2 ? 0 : 1) + (COOP ? 2 : 0)], [] {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q, COOP>),
+    const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, CELLS_WAVES) * sizeof(uint32_t);
+    std::call_once(ctx.cellsLdsAttribute[Q == 2 ? 0 : 1], [] {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     });
     MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
-    // Booked under the template instance that runs (class 0: Q = 2; classes 1 and 2: Q = 4), the name a profiler shows.
+    // Booked under the template instance that runs, the name a profiler shows.
     // Algorithmic bytes: 4 (nx + ny) per candidate, summed by the caller; work = candidates.
-    const char* const name = Q == 2 ? (COOP ? "align4CellsChunkKernel<2, true>" : "align4CellsChunkKernel<2, false>")
-                                    : (COOP ? "align4CellsChunkKernel<4, true>" : "align4CellsChunkKernel<4, false>");
+    const char* const name = Q == 2 ? "align4CellsChunkKernel<2>" : "align4CellsChunkKernel<4>";
     SHASTA_TIMED(ctx, name, ws.stream, kmerIdBytes, candidateCount,
-        hipLaunchKernelGGL((align4CellsChunkKernel<Q, COOP>), dim3(count), dim3(WAVE * waves), bytes, ws.stream,
+        hipLaunchKernelGGL((align4CellsChunkKernel<Q>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, ws.stream,
             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
             opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data()));
     HIP_CHECK(hipGetLastError());
 }
 
-void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, bool coop, const CellsChunk* chunks, uint32_t count,
+void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
     if(count == 0) return;
-    const int waves = coop ? CELLS_COOP_WAVES : CELLS_SHARED_WAVES[cls];
-    if(CELLS_Q[cls] == 2) {
-        if(coop) launchCellsChunksQ<2, true>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
-        else launchCellsChunksQ<2, false>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
-    } else {
-        if(coop) launchCellsChunksQ<4, true>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
-        else launchCellsChunksQ<4, false>(ctx, ws, b, cls, waves, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
-    }
+    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+    else launchCellsChunksQ<4>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
 }
 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
@@ -659,15 +654,14 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 return CELLS_CLASSES;
             };
             std::vector<int> pairClass(n);
-            std::vector<CellsChunk> classChunks[CELLS_CLASSES][2];     // [class][0 = one wave, 1 = shared table]
+            std::vector<CellsChunk> classChunks[CELLS_CLASSES];
             std::vector<uint32_t> members;                             // candidate indices, chunk after chunk
             members.reserve(n);
             auto addChunk = [&](const uint32_t* list, uint32_t count, bool swapped, int c) {
                 CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = uint16_t(count); ch.swapped = swapped ? 1 : 0;
                 ch.naLog2 = uint32_t(CELLS_NA_LOG2[c]); ch.scLog2 = uint32_t(CELLS_SC_LOG2[c]);
                 members.insert(members.end(), list, list + count);
-                const int kind = (CELLS_SHARED_WAVES[c] > 1 && count >= CELLS_SHARE_MIN) ? 1 : 0;
-                classChunks[c][kind].push_back(ch);
+                classChunks[c].push_back(ch);
             };
             // Every candidate tables whichever of its two reads lands in the smaller class (ties: read
             // 0) and is grouped with the other candidates that table the same oriented read.
@@ -706,11 +700,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             }
             static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
             if(debug) {
-                for(int c = 0; c < CELLS_CLASSES; c++) for(int kind = 0; kind < 2; kind++) {
+                for(int c = 0; c < CELLS_CLASSES; c++) {
                     uint64_t pairsIn = 0, sw = 0;
-                    for(const CellsChunk& ch : classChunks[c][kind]) { pairsIn += ch.count; sw += ch.swapped; }
-                    std::fprintf(stderr, "cells: class %d kind %d: %zu chunks, %llu candidates, %llu swapped\n", c, kind,
-                        classChunks[c][kind].size(), (unsigned long long)pairsIn, (unsigned long long)sw);
+                    for(const CellsChunk& ch : classChunks[c]) { pairsIn += ch.count; sw += ch.swapped; }
+                    std::fprintf(stderr, "cells: class %d: %zu chunks, %llu candidates, %llu swapped\n", c,
+                        classChunks[c].size(), (unsigned long long)pairsIn, (unsigned long long)sw);
                 }
                 std::fprintf(stderr, "cells: HBM-scratch list %zu\n", bigList.size());
             }
@@ -729,34 +723,30 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                         (members.size() - membersUploaded) * 4, hipMemcpyHostToDevice, stream));
                     membersUploaded = members.size();
                 }
+                // The three classes' chunk lists go up side by side and their launches follow each other without the host
+                // in between (the lists are reused once the flags below have come back).
+                size_t chunkTotal = 0;
+                for(int c = 0; c < CELLS_CLASSES; c++) chunkTotal += classChunks[c].size();
+                b.chunks.reserve(chunkTotal, stream);
+                size_t chunkOffset = 0;
                 for(int c = 0; c < CELLS_CLASSES; c++) {
-                    std::vector<CellsChunk>& single = classChunks[c][0];
-                    std::vector<CellsChunk>& shared = classChunks[c][1];
-                    if(single.empty() && shared.empty()) continue;
+                    std::vector<CellsChunk>& list = classChunks[c];
+                    if(list.empty()) continue;
                     any = true;
-                    b.chunks.reserve(single.size() + shared.size(), stream);
-                    if(!single.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data(), single.data(), single.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
-                    if(!shared.empty()) HIP_CHECK(hipMemcpyAsync(b.chunks.data() + single.size(), shared.data(), shared.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
-                    auto bytesOf = [&](const std::vector<CellsChunk>& list, uint64_t& candidatesIn) {
-                        uint64_t bytes = 0;
-                        candidatesIn = 0;
-                        for(const CellsChunk& ch : list) {
-                            candidatesIn += ch.count;
-                            for(uint32_t q = 0; q < ch.count; q++) { const PairDesc& pd = hostPairs[members[ch.firstMember + q]]; bytes += 4ULL * (uint64_t(pd.nx) + pd.ny); }
-                        }
-                        return bytes;
-                    };
-                    uint64_t sharedCandidates = 0, singleCandidates = 0;
-                    const uint64_t sharedBytes = bytesOf(shared, sharedCandidates), singleBytes = bytesOf(single, singleCandidates);
-                    launchCellsChunks(ctx, ws, b, c, false, b.chunks.data() + single.size(), uint32_t(shared.size()), opt, magicX, magicY, taskCapacity, sharedBytes, sharedCandidates);
-                    launchCellsChunks(ctx, ws, b, c, true, b.chunks.data(), uint32_t(single.size()), opt, magicX, magicY, taskCapacity, singleBytes, singleCandidates);
-                    HIP_CHECK(hipStreamSynchronize(stream));      // the lists are reused below
-                    single.clear(); shared.clear();
+                    HIP_CHECK(hipMemcpyAsync(b.chunks.data() + chunkOffset, list.data(), list.size() * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
+                    uint64_t bytes = 0, candidatesIn = 0;
+                    for(const CellsChunk& ch : list) {
+                        candidatesIn += ch.count;
+                        for(uint32_t q = 0; q < ch.count; q++) { const PairDesc& pd = hostPairs[members[ch.firstMember + q]]; bytes += 4ULL * (uint64_t(pd.nx) + pd.ny); }
+                    }
+                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + chunkOffset, uint32_t(list.size()), opt, magicX, magicY, taskCapacity, bytes, candidatesIn);
+                    chunkOffset += list.size();
                 }
                 if(!any) break;
                 // Candidates that overflowed their tables climb one class.
                 HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
+                for(int c = 0; c < CELLS_CLASSES; c++) classChunks[c].clear();
                 bool retry = false;
                 uint64_t reasonHistogram[16] = {0};
                 for(uint32_t k = 0; k < n; k++) {
@@ -779,7 +769,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 }
                 if(!retry) break;
                 if(debug) {
-                    for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: round %d retries -> class %d: %zu\n", round, c, classChunks[c][0].size());
+                    for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: round %d retries -> class %d: %zu\n", round, c, classChunks[c].size());
                     std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu; reasons cell-table %llu kept-list %llu geometry %llu both %llu tabled-read %llu\n", round, bigList.size(),
                         (unsigned long long)reasonHistogram[1], (unsigned long long)reasonHistogram[2], (unsigned long long)reasonHistogram[4],
                         (unsigned long long)(reasonHistogram[3] + reasonHistogram[5] + reasonHistogram[6] + reasonHistogram[7]), (unsigned long long)reasonHistogram[8]);

@@ -287,25 +287,27 @@ align4CellsKernel(
 // K8/K9, fast path.  A CHUNK is a set of candidates that share one oriented read: read 0
 // (candidates arrive sorted by readId0, src/LowHash0.cpp:204-214, and read 0 is always on
 // strand 0, src/AssemblerAlign.cpp:382) or, when read 1 is the shorter one, read 1 ("swapped",
-// gathered by the host).  One workgroup per chunk; its waves share the table of that read and
-// then work on different candidates of the chunk without ever synchronising again.
-//   build   read 0's kmer ids are copied to LDS and indexed by a two-choice bucketised LDS hash
-//           table (buckets of four 16-bit slots = one ds_read_b64; slot = hash tag | ordinal);
-//   probe   a candidate's other read is streamed through the table, four markers per lane per
-//           round: both buckets are read, the eight slots are tag-matched with SWAR compares,
+// gathered by the host).  One workgroup of W wavefronts per chunk.  The whole workgroup works on ONE candidate at a time:
+//   build   all wavefronts copy the shared read's kmer ids to LDS and index them by a two-choice bucketised LDS hash
+//           table (buckets of four 16-bit slots = one ds_read_b64; slot = hash tag | ordinal), once per chunk;
+//   probe   a candidate's other read is streamed through the table, four markers per lane per round, every W-th round
+//           by the same wavefront: both buckets are read, the eight slots are tag-matched with SWAR compares,
 //           the kmer ids are compared in LDS: fixed trip count, no probe chains;
-//   count   (x,y) -> cell by magic-number division (getXY + createCells,
-//           src/Align4.cpp:171-177,380-436), one LDS atomic per hit on a packed cell word (folding
-//           equal neighbours first costs more instructions than the atomics it saves); the
-//           increment that reaches minEntryCountPerCell appends the cell to the kept list (:417);
-//   graph   the kept cells (Q per lane) live in registers; their forward/backward adjacency is
-//           a bit mask per cell, so forwardSearch / backwardSearch (:682-788) and the connected
-//           components (:792-868) are iterated ballots with no memory traffic;
-//   tasks   one DP task per component (:890-934), staged in LDS, appended with one global atomic.
+//   count   (x,y) -> cell by magic-number division (getXY + createCells, src/Align4.cpp:171-177,380-436), one LDS
+//           atomic per hit into ONE cell region shared by the wavefronts (LDS atomics work across them); the
+//           increment that reaches minEntryCountPerCell appends the cell to the candidate's kept list (:417);
+//   graph   after W candidates have been streamed (kept lists in W slots), wavefront w takes the w-th of them: the kept
+//           cells (Q per lane) live in registers; their forward/backward adjacency is a bit mask per cell, so
+//           forwardSearch / backwardSearch (:682-788) and the connected components (:792-868) are iterated ballots with
+//           no memory traffic -- W graphs at a time (round 2's first cooperative kernel left the graph to wavefront 0 while
+//           the others waited: with the stream W times faster, the graph had become half of a candidate's time);
+//   tasks   one DP task per component (:890-934), staged in the wavefront's slot, appended with one global atomic.
+// Round 1 gave each wavefront its own cell region and its own candidates (4-6 wavefronts of LDS per workgroup, 6-8
+// wavefronts per CU): the kernel is bound by the latency of its dependent LDS chains, so wavefronts per CU decide.
 // Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
 // larger class, finally by align4CellsKernel<true>.
-// Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | per wave:
-//   cells[SC] (iY | iX | count packed) | kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
+// Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | cells[SC] (one byte per cell of the grid,
+//   or iY | iX | count packed) | per wavefront a slot: kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
 // ---------------------------------------------------------------------------
 // firstMember indexes the member list (candidate indices of the batch).
 struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
@@ -356,24 +358,19 @@ __device__ __forceinline__ uint32_t zeroHalves(uint32_t v)
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
 constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
 constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
-__host__ __device__ inline size_t cellsWaveLdsWords(int scLog2, int Q)
+__host__ __device__ inline size_t cellsSlotLdsWords(int Q)
 {
-    return (size_t(1) << scLog2) + 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
+    return 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
 }
 __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
 {
-    return 2 * (size_t(1) << naLog2) + size_t(waves) * cellsWaveLdsWords(scLog2, Q);
+    return 2 * (size_t(1) << naLog2) + (size_t(1) << scLog2) + size_t(waves) * cellsSlotLdsWords(Q);
 }
 
 #ifndef SHASTA_CELLS_MAX_THREADS
 #define SHASTA_CELLS_MAX_THREADS 384
 #endif
-// COOP: the chunk has fewer candidates than a workgroup has wavefronts (in practice one or two: candidates whose read 0 is too
-// long for the table, so that the shorter read 1 is tabled, and a batch holds few candidates per read 1).  Then the whole
-// workgroup works on ONE candidate at a time: all wavefronts build the table, each streams its share of the partner's rounds
-// into ONE cell region (LDS atomics work across wavefronts), wavefront 0 does the kept-cell graph.  Round 1 ran such chunks
-// as one-wavefront workgroups: a table build per candidate by 64 lanes, at 4-6 wavefronts per CU.
-template<int Q, bool COOP>
+template<int Q>
 __global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS)
 align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
@@ -398,10 +395,16 @@ align4CellsChunkKernel(
     const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
     uint32_t* const aKmers = ldsWords;
     uint32_t* const aSlots = aKmers + NA;
-    uint32_t* const cells = aSlots + NA + (COOP ? 0u : wave) * cellsWaveLdsWords(int(chunk.scLog2), Q);
-    uint32_t* const kept = cells + SC;
-    uint32_t* const scratch = kept + MAXC;                        // [0] kept count, [1] min, [2] max, [3] staged tasks
-    uint32_t* const stage = scratch + 8;
+    uint32_t* const cells = aSlots + NA;
+    uint32_t* const slots = cells + SC;                           // slot w: kept[MAXC] | scratch[8] | stage[4 CELLS_STAGE]
+    // The slot the candidate being streamed appends its kept cells to (every wavefront), and this wavefront's own slot
+    // (graph of the candidate it was given, staged tasks).  scratch: [0] kept count, [1] min, [2] max, [3] staged tasks,
+    // [4] what went wrong while streaming.
+    uint32_t* kept = slots;
+    uint32_t* scratch = kept + MAXC;
+    uint32_t* const ownKept = slots + wave * cellsSlotLdsWords(Q);
+    uint32_t* const ownScratch = ownKept + MAXC;
+    uint32_t* const stage = ownScratch + 8;
     const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
     PHASE_BEGIN();
 
@@ -416,7 +419,7 @@ align4CellsChunkKernel(
     const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
     for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
     if(threadIdx.x == 0) stashCount = 0;
-    if(lane == 0) scratch[3] = 0;
+    if(lane == 0) ownScratch[3] = 0;
     __syncthreads();
     for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
         const uint32_t km = tabSeq[t];
@@ -455,10 +458,15 @@ align4CellsChunkKernel(
         return;
     }
 
-    for(uint32_t c = COOP ? 0u : wave; c < chunk.count; c += COOP ? 1u : waves) {
+    // Groups of `waves` candidates: streamed one after the other by the whole workgroup, then one graph per wavefront.
+    for(uint32_t group = 0; group < chunk.count; group += waves) {
+    const uint32_t groupEnd = min(group + waves, uint32_t(chunk.count));
+    for(uint32_t c = group; c < groupEnd; c++) {
         const uint32_t pair = members[chunk.firstMember + c];
         const PairDesc pd = pairs[pair];
         const uint32_t nx = pd.nx, ny = pd.ny;
+        kept = slots + (c - group) * cellsSlotLdsWords(Q);
+        scratch = kept + MAXC;
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
@@ -470,7 +478,7 @@ align4CellsChunkKernel(
         const uint32_t gridX = divMagic(nx + ny - 2, magicX) + 1, gridY = divMagic(nx + ny - 2, magicY) + 1;
         const bool useGrid = nx + ny >= 2 && uint64_t(gridX) * gridY <= 4ull * SC && threshold <= 191;
         {
-            const uint32_t first = COOP ? threadIdx.x : uint32_t(lane), stride = COOP ? blockDim.x : uint32_t(WAVE);
+            const uint32_t first = threadIdx.x, stride = blockDim.x;
             if(useGrid) {
                 const uint32_t gridWords = (gridX * gridY + 3) / 4;
                 for(uint32_t k = first; k < gridWords; k += stride) cells[k] = 0;
@@ -479,7 +487,7 @@ align4CellsChunkKernel(
             }
             if(first == 0) { scratch[0] = 0; scratch[4] = 0; }
         }
-        if(COOP) __syncthreads(); else waveLdsSync();
+        __syncthreads();
         PHASE_MARK(1);
 
         // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
@@ -561,9 +569,9 @@ align4CellsChunkKernel(
             }
         };
 
-        // Rounds of CELLS_UNROLL x 64 markers: all of them for this wavefront, or (COOP) every waves-th one.
-        const uint32_t roundStride = (COOP ? waves : 1u) * uint32_t(CELLS_UNROLL * WAVE);
-        const uint32_t firstRound = COOP ? wave * uint32_t(CELLS_UNROLL * WAVE) : 0u;
+        // Rounds of CELLS_UNROLL x 64 markers: every waves-th one for this wavefront.
+        const uint32_t roundStride = waves * uint32_t(CELLS_UNROLL * WAVE);
+        const uint32_t firstRound = wave * uint32_t(CELLS_UNROLL * WAVE);
         uint32_t kmNext[CELLS_UNROLL];
 #pragma unroll
         for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
@@ -666,19 +674,20 @@ align4CellsChunkKernel(
             }
         }
         SUBPHASE_FLUSH();
-        if(COOP) {
-            // What went wrong in any wavefront's share of the rounds reaches wavefront 0 through the region's scratch word.
-            if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
-            __syncthreads();
-            const uint32_t seen = scratch[4];
-            overflow = (seen & 0x10u) ? 2 : ((seen & 0x08u) ? 1 : 0); reason = int(seen & 7u);
-        } else {
-            waveLdsSync();
-        }
+        // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
+        if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
+        __syncthreads();                                              // the cell region is cleared for the next candidate
         PHASE_MARK(2);
+    }
 
-        // The kept-cell graph of the candidate: its own wavefront, or (COOP) wavefront 0 while the others wait at the barrier below.
-        if(!COOP || wave == 0) do {
+        // The kept-cell graphs of the group, one per wavefront.
+        if(group + wave < groupEnd) do {
+        const uint32_t pair = members[chunk.firstMember + group + wave];
+        const PairDesc pd = pairs[pair];
+        const uint32_t nx = pd.nx, ny = pd.ny;
+        kept = ownKept; scratch = ownScratch;
+        const uint32_t seen = scratch[4];
+        int overflow = (seen & 0x10u) ? 2 : ((seen & 0x08u) ? 1 : 0), reason = int(seen & 7u);
         const int n = int(scratch[0]);
         if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
         const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
@@ -851,11 +860,12 @@ align4CellsChunkKernel(
         }
         PHASE_MARK(5);
         } while(false);
-        if(COOP) __syncthreads();                                     // the region is cleared for the next candidate
+        __syncthreads();                                              // the slots are free for the next group
     }
     // Append this wave's staged tasks.
     waveLdsSync();
-    const uint32_t staged = (!COOP || wave == 0) ? scratch[3] : 0u;
+    scratch = ownScratch;
+    const uint32_t staged = scratch[3];
     if(staged) {
         uint32_t base = 0;
         if(lane == 0) base = atomicAdd(taskCount, staged);
