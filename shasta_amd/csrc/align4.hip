@@ -230,7 +230,7 @@ struct DpEvents {
     void destroy() { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
 };
 struct DpBatchStats { uint64_t cells[DP_CLASSES] = {0}, bytes[DP_CLASSES] = {0}; uint32_t tasks[DP_CLASSES] = {0}; };
-const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<32, 2>", "bandedDpForwardKernel<64, 2>",
+const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<16, 4>", "bandedDpForwardKernel<32, 4>",
     "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"};
 
 // Forward half of K10 for taskCount tasks: sort by (band class, iterations), bundle, lay out the
@@ -307,8 +307,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4); });
     timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3); });
     if(fork) HIP_CHECK(hipEventRecord(ev->join, ws.wide));
-    timed(1, stream, [&](hipStream_t st) { launchDpForward<32, 2>(in, st, b, sortedIds, layout, 1); });
-    timed(2, stream, [&](hipStream_t st) { launchDpForward<64, 2>(in, st, b, sortedIds, layout, 2); });
+    timed(1, stream, [&](hipStream_t st) { launchDpForward<16, 4>(in, st, b, sortedIds, layout, 1); });
+    timed(2, stream, [&](hipStream_t st) { launchDpForward<32, 4>(in, st, b, sortedIds, layout, 2); });
     timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     return f;
@@ -320,7 +320,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     hipStream_t stream = ws.stream;
     const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data()};
     const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
-    // The three traceback kernels over their class ranges of the sorted list (C = 2: classes 0-2; C = 4: class 3; wider: 4-5).
+    // The three traceback kernels over their class ranges of the sorted list (C = 2: class 0; C = 4: classes 1-3; wider: 4-5).
     // Booked: the trace a kernel has to read = 2 bits per cell of the padded bands of its tasks (iterations x 2 C words, bounded
     // by sums[1] for the whole batch: split by DP cells), work = tasks.
     auto traceback = [&](const char* name, int firstClass, int lastClass, auto kernel) {
@@ -338,13 +338,13 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     };
     // The wide classes are a handful of long walks (long reads have wide bands): a launch that lasts as long as its longest
     // path and occupies a few wavefronts.  They run on the side stream beside the narrow classes.
-    const bool forkWide = ws.wide != nullptr && ev != nullptr && f.taskStart[DP_CLASSES] > f.taskStart[3] && f.taskStart[3] > 0;
+    const bool forkWide = ws.wide != nullptr && ev != nullptr && f.taskStart[DP_CLASSES] > f.taskStart[4] && f.taskStart[4] > 0;
     hipStream_t main = stream;
     if(forkWide) { HIP_CHECK(hipEventRecord(ev->fork, main)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); stream = ws.wide; }
     traceback("dpTracebackWideKernel<32>", 4, 5, dpTracebackWideKernel<32>);       // the longest walks first
-    traceback("dpTracebackKernel<4>", 3, 3, dpTracebackKernel<4>);
     if(forkWide) { HIP_CHECK(hipEventRecord(ev->join, ws.wide)); stream = main; }
-    traceback("dpTracebackKernel<2>", 0, 2, dpTracebackKernel<2>);
+    traceback("dpTracebackKernel<4>", 1, 3, dpTracebackKernel<4>);
+    traceback("dpTracebackKernel<2>", 0, 0, dpTracebackKernel<2>);
     if(forkWide) HIP_CHECK(hipStreamWaitEvent(main, ev->join, 0));
     // Booked: 8 bytes per aligned pair are read (unknown here: at most min(nx, ny) per task; the caller amends nothing) -- work = tasks.
     SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, taskCount,

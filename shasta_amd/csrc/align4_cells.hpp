@@ -307,7 +307,7 @@ align4CellsKernel(
 // Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
 // larger class, finally by align4CellsKernel<true>.
 // Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | cells[SC] (one byte per cell of the grid,
-//   or iY | iX | count packed) | per wavefront a slot: kept[64 Q] | scratch[8] | stage[4 CELLS_STAGE].
+//   or iY | iX | count packed) | per wavefront a slot: kept[64 Q] (the graph's cell map[128 Q] later) | scratch[8] | stage[4 CELLS_STAGE].
 // ---------------------------------------------------------------------------
 // firstMember indexes the member list (candidate indices of the batch).
 struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
@@ -360,7 +360,7 @@ constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   /
 constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
 __host__ __device__ inline size_t cellsSlotLdsWords(int Q)
 {
-    return 64 * size_t(Q) + 8 + 4 * CELLS_STAGE;
+    return 128 * size_t(Q) + 8 + 4 * CELLS_STAGE;
 }
 __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
 {
@@ -388,7 +388,7 @@ align4CellsChunkKernel(
     if(blockIdx.x >= chunkCount) return;
     const CellsChunk chunk = chunks[blockIdx.x];
     const int lane = laneId();
-    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), waves = blockDim.x >> 6;       // scalar: loop control on the scalar unit
     const uint32_t NA = 1u << chunk.naLog2, SC = 1u << chunk.scLog2;
     const int bucketShift = 32 - (int(chunk.naLog2) - 1), scShift = 32 - int(chunk.scLog2);
     const int xBits = int(chunk.naLog2);
@@ -396,14 +396,14 @@ align4CellsChunkKernel(
     uint32_t* const aKmers = ldsWords;
     uint32_t* const aSlots = aKmers + NA;
     uint32_t* const cells = aSlots + NA;
-    uint32_t* const slots = cells + SC;                           // slot w: kept[MAXC] | scratch[8] | stage[4 CELLS_STAGE]
+    uint32_t* const slots = cells + SC;                           // slot w: kept[MAXC], later the map[2 MAXC] of the graph | scratch[8] | stage[4 CELLS_STAGE]
     // The slot the candidate being streamed appends its kept cells to (every wavefront), and this wavefront's own slot
     // (graph of the candidate it was given, staged tasks).  scratch: [0] kept count, [1] min, [2] max, [3] staged tasks,
     // [4] what went wrong while streaming.
     uint32_t* kept = slots;
-    uint32_t* scratch = kept + MAXC;
+    uint32_t* scratch = kept + 2 * MAXC;
     uint32_t* const ownKept = slots + wave * cellsSlotLdsWords(Q);
-    uint32_t* const ownScratch = ownKept + MAXC;
+    uint32_t* const ownScratch = ownKept + 2 * MAXC;
     uint32_t* const stage = ownScratch + 8;
     const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
     PHASE_BEGIN();
@@ -466,7 +466,7 @@ align4CellsChunkKernel(
         const PairDesc pd = pairs[pair];
         const uint32_t nx = pd.nx, ny = pd.ny;
         kept = slots + (c - group) * cellsSlotLdsWords(Q);
-        scratch = kept + MAXC;
+        scratch = kept + 2 * MAXC;
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
@@ -569,12 +569,16 @@ align4CellsChunkKernel(
             }
         };
 
-        // Rounds of CELLS_UNROLL x 64 markers: every waves-th one for this wavefront.
-        const uint32_t roundStride = waves * uint32_t(CELLS_UNROLL * WAVE);
-        const uint32_t firstRound = wave * uint32_t(CELLS_UNROLL * WAVE);
+        // The stream in groups of 64 markers dealt to the wavefronts in turn (group g to wavefront g mod waves: every wavefront
+        // gets the same number of groups, give or take one); a wavefront takes CELLS_UNROLL of its groups per round, and a slot of
+        // the last round whose group lies beyond the stream is skipped (wavefront-uniform).  Slot u of the round that starts at
+        // s0 holds markers s0 + u groupStride + lane.
+        const uint32_t groupStride = waves * uint32_t(WAVE);
+        const uint32_t roundStride = uint32_t(CELLS_UNROLL) * groupStride;
+        const uint32_t firstRound = wave * uint32_t(WAVE);
         uint32_t kmNext[CELLS_UNROLL];
 #pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * WAVE + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
         SUBPHASE_DECLARE();
         for(uint32_t s0 = firstRound; s0 < streamCount; s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
@@ -583,12 +587,16 @@ align4CellsChunkKernel(
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
                 km[u] = kmNext[u];
-                const uint32_t tn = s0 + roundStride + u * WAVE + lane;
+                const uint32_t tn = s0 + roundStride + u * groupStride + lane;
                 kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
-                valid[u] = s0 + u * WAVE + lane < streamCount;
+                valid[u] = s0 + u * groupStride + lane < streamCount;
             }
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
+                if(s0 + uint32_t(u) * groupStride >= streamCount) {                // no such group (uniform)
+                    w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0; m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0;
+                    continue;
+                }
                 const uint32_t h = hash32(km[u]);
                 const uint32_t b1 = h >> bucketShift, b2 = hash32b(km[u]) >> bucketShift;
                 w[u][0] = aSlots[2 * b1]; w[u][1] = aSlots[2 * b1 + 1];
@@ -606,6 +614,8 @@ align4CellsChunkKernel(
             {
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) {
+                    ts[u] = s0 + uint32_t(u) * groupStride + uint32_t(lane);
+                    if(s0 + uint32_t(u) * groupStride >= streamCount) { hit[u] = false; ti[u] = 0; ka[u] = 0; continue; }
                     // (static register indexing only)
                     const bool s0m = m[u][0] != 0, s1m = !s0m && m[u][1] != 0, s2m = !s0m && !s1m && m[u][2] != 0;
                     const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
@@ -617,7 +627,6 @@ align4CellsChunkKernel(
                     const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
                     if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
                     hit[u] = cand;
-                    ts[u] = s0 + uint32_t(u) * WAVE + uint32_t(lane);
                 }
                 bool anyHit = false;
 #pragma unroll
@@ -659,7 +668,7 @@ align4CellsChunkKernel(
 #pragma unroll
                     for(int i = 0; i < 4; i++) m[u][i] = (cand && us == u && is == i) ? cleared : m[u][i];
                 const bool hitSel = cand && kaSel == kmSel;
-                const uint32_t tsSel = s0 + uint32_t(us) * WAVE + uint32_t(lane);
+                const uint32_t tsSel = s0 + uint32_t(us) * groupStride + uint32_t(lane);
                 SUBPHASE_ADD(3);
                 if(__any(hitSel)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, 1>{}, &hitSel, &tiSel, &tsSel); }
                 SUBPHASE_ADD(2);
@@ -723,26 +732,60 @@ align4CellsChunkKernel(
         }
         // Adjacency masks.  before[q][r] bit j: cell 64 r + j lies at (iX-1 or iX, iY-1..iY+1) of
         // this lane's cell q (a forward move leads from it to this cell); after: (iX or iX+1, ...).
+        // The kept cells go into a small open-addressing map (cell -> index in the list) that takes the place of the list
+        // in the slot -- the keys are in registers by now -- and each lane looks its eight neighbours up: a fixed amount of work
+        // per candidate.  (Until round 2 every lane compared its cells with every kept cell, one readlane at a time: with the
+        // stream four times faster that loop had become the longest part of a candidate with an alignment.)
         uint64_t before[Q][Q], after[Q][Q];
 #pragma unroll
         for(int q = 0; q < Q; q++)
 #pragma unroll
             for(int r = 0; r < Q; r++) { before[q][r] = 0; after[q][r] = 0; }
+        {
+            constexpr int MAP = 2 * MAXC, MAP_LOG2 = (Q == 2 ? 8 : 9), IDX_BITS = MAP_LOG2 - 1;
+            static_assert(MAP == (1 << MAP_LOG2) && CELLS_IX_BITS + CELLS_IY_BITS + IDX_BITS < 32, "map entry");
+            uint32_t* const map = kept;
+            waveLdsSync();                                                  // every lane has read its keys
+            for(int k = lane; k < MAP; k += WAVE) map[k] = EMPTY32;
+            waveLdsSync();
 #pragma unroll
-        for(int r = 0; r < Q; r++) {
-            if(r >= nq) break;
-            const int jEnd = min(WAVE, n - r * WAVE);
-            for(int j = 0; j < jEnd; j++) {
-                const uint32_t other = __builtin_amdgcn_readlane(key[r], j);
-                const int32_t oX = int32_t(other & 0xffffu), oY = int32_t(other >> 16);
-                const uint64_t bit = 1ULL << j;
+            for(int q = 0; q < Q; q++) {
+                if(key[q] == EMPTY32) continue;
+                const uint32_t packed = ((key[q] >> 16) << CELLS_IX_BITS) | (key[q] & 0xffffu);
+                const uint32_t entry = (packed << IDX_BITS) | uint32_t(lane + q * WAVE);
+                uint32_t h = hash32(packed) >> (32 - MAP_LOG2);
+                while(atomicCAS(&map[h], EMPTY32, entry) != EMPTY32) h = (h + 1) & uint32_t(MAP - 1);
+            }
+            waveLdsSync();
 #pragma unroll
-                for(int q = 0; q < Q; q++) {
-                    if(q >= nq) break;
-                    const int32_t dX = oX - int32_t(key[q] & 0xffffu), dY = oY - int32_t(key[q] >> 16);
-                    const bool near = key[q] != EMPTY32 && dY >= -1 && dY <= 1 && other != key[q];
-                    if(near && (dX == -1 || dX == 0)) before[q][r] |= bit;
-                    if(near && (dX == 0 || dX == 1)) after[q][r] |= bit;
+            for(int q = 0; q < Q; q++) {
+                if(q >= nq) break;
+                const int32_t iX = int32_t(key[q] & 0xffffu), iY = int32_t(key[q] >> 16);
+                uint32_t target[8], h[8], e[8];
+                bool live[8];
+#pragma unroll
+                for(int d = 0; d < 8; d++) {                                 // the eight neighbours: all reads first
+                    const int dX = (d < 3) ? -1 : (d < 5 ? 0 : 1), dY = (d < 3) ? d - 1 : (d == 3 ? -1 : (d == 4 ? 1 : d - 6));
+                    const int32_t nX = iX + dX, nY = iY + dY;
+                    live[d] = key[q] != EMPTY32 && uint32_t(nX) < (1u << CELLS_IX_BITS) && uint32_t(nY) < (1u << CELLS_IY_BITS);
+                    target[d] = (uint32_t(nY) << CELLS_IX_BITS) | uint32_t(nX);
+                    h[d] = hash32(target[d]) >> (32 - MAP_LOG2);
+                    e[d] = map[live[d] ? h[d] : 0u];
+                }
+#pragma unroll
+                for(int d = 0; d < 8; d++) {
+                    const int dX = (d < 3) ? -1 : (d < 5 ? 0 : 1);
+                    while(live[d] && e[d] != EMPTY32 && (e[d] >> IDX_BITS) != target[d]) { h[d] = (h[d] + 1) & uint32_t(MAP - 1); e[d] = map[h[d]]; }
+                    const bool found = live[d] && e[d] != EMPTY32;
+                    const uint32_t index = e[d] & uint32_t(MAXC - 1);
+                    const uint64_t bit = 1ULL << (index & 63u);
+#pragma unroll
+                    for(int r = 0; r < Q; r++) {
+                        if(found && int(index >> 6) == r) {
+                            if(dX <= 0) before[q][r] |= bit;
+                            if(dX >= 0) after[q][r] |= bit;
+                        }
+                    }
                 }
             }
         }

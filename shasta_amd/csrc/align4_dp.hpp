@@ -30,8 +30,13 @@
 // ---------------------------------------------------------------------------
 constexpr int DP_CLASSES = 6;
 __host__ __device__ inline int dpClassOfWidth(int32_t w) { return w <= 32 ? 0 : (w <= 64 ? 1 : (w <= 128 ? 2 : (w <= 256 ? 3 : (w <= 512 ? 4 : 5)))); }
-__host__ __device__ inline int dpLanes(int cls) { return cls == 0 ? 16 : (cls == 1 ? 32 : 64); }          // G
-__host__ __device__ inline int dpDiagonals(int cls) { return cls <= 2 ? 2 : (1 << (cls - 1)); }             // C = 2,2,2,4,8,16
+// Lanes per task G and adjacent diagonals per lane C of the six band classes (G C = 32, 64, 128, 256, 512, 1024 diagonals).
+// Four diagonals per lane wherever the band allows it: a lane's cells of one anti-diagonal are independent of each other, and
+// the neighbour exchange (a DPP move per anti-diagonal, plus a select at the group edge when G = 32) is shared by twice the
+// cells -- (16, 4) instead of (32, 2) for the class most tasks fall into: 9.2 instead of 11.4 VALU instructions per cell.
+__host__ __device__ inline int dpLanes(int cls) { return cls <= 1 ? 16 : (cls == 2 ? 32 : 64); }            // G = 16,16,32,64,64,64
+__host__ __device__ inline int dpDiagonalsLog2(int cls) { return cls == 0 ? 1 : (cls <= 3 ? 2 : cls - 1); }
+__host__ __device__ inline int dpDiagonals(int cls) { return 1 << dpDiagonalsLog2(cls); }                   // C = 2,4,4,4,8,16
 
 struct DpGeometry { int32_t s0; uint32_t iters; int cls; };
 __host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
@@ -120,12 +125,17 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
 //  * scores are kept biased by -NEG_SCORE, so "outside the band" is 0 and the neighbour exchange
 //    is one DPP shift with zero fill (row_shr/shl for 16-lane groups, wave_shr/shl otherwise)
 //    instead of ds_bpermute + select -- same decisions: max, compare and adding a constant commute
-//    with the bias, and nothing overflows (|score| < 2^27);
+//    with the bias, and nothing overflows (|score| < 2^27, bias 2^29, i + j < 2^25);
+//  * and by the gap penalties of the cell's anti-diagonal (stored = score + bias - gap (i + j)): the three candidates of a
+//    cell then are stored(diagonal) + 8 or + 1, stored(vertical), stored(horizontal) -- the addition of the gap penalty
+//    to every cell is gone (9 -> 8 VALU instructions per cell);
 //  * trace planes: one ballot per comparison (the mask v_cmp wrote anyway), combined on the
 //    scalar unit; the ballot of a combined predicate is compiled to v_cndmask + v_cmp;
-//  * the trace record goes from the scalar registers into a 256-byte line held in one vector register
-//    (v_writelane_b32, dword k in lane k) and leaves as one coalesced 4-byte store per lane when the
-//    line is full, instead of a select chain over the lanes and a partial store every iteration;
+//  * the trace record goes from the scalar registers the ballots are in straight to memory: scalar stores
+//    (s_store_dwordx4, RW / 2 per iteration), no vector instruction at all.  (Round 1 staged the 256-byte line in LDS:
+//    12 % of the wave cycles were LDS issue stalls; the first version of round 2 assembled it in one vector register
+//    with v_writelane_b32, 2 RW VALU instructions per iteration of a kernel bound by VALU issue: 8 of 31 for C = 2.
+//    scripts/microbench/trace_store.hip measured both ways of writing the same records: identical bytes, 0.84 -> 0.62 ms.)
 //  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
 constexpr int DP_BLOCK = 4;
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -156,10 +166,9 @@ bandedDpForwardKernel(
     uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
 {
     constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C, U = DP_BLOCK;
-    constexpr int F = 32 / RW;                            // iterations per 256-byte trace line
-    constexpr int AL = F > U ? F : U;                     // steady iterations come in groups of AL: whole blocks, whole lines
+    constexpr int AL = U;                                 // steady iterations come in groups of AL: whole blocks
     constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
-    static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0 && AL % F == 0, "block / line geometry");
+    static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0, "block geometry");
     const int lane = laneId();
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(slot >= bundleCount) return;                       // whole wave leaves: all 64 lanes are active below, no block barriers
@@ -179,7 +188,7 @@ bandedDpForwardKernel(
 #pragma unroll
     for(int d = G; d < WAVE; d <<= 1) itersLane = max(itersLane, uint32_t(__shfl_xor(int(itersLane), d, WAVE)));
     const uint32_t iters = __builtin_amdgcn_readfirstlane(itersLane);
-    uint64_t* __restrict__ tr = trace + bundleOffsets[bundle];
+    uint64_t* __restrict__ tr = uniformPointer(trace + bundleOffsets[bundle]);
 
     // Per diagonal: first and last anti-diagonal that hold a cell of the matrix.
     int32_t lo[C];
@@ -194,7 +203,7 @@ bandedDpForwardKernel(
         lo[c] = exists[c] ? first : NO_DIAGONAL;
         span[c] = exists[c] ? uint32_t(last - first) : 0u;
     }
-    int32_t H[C];                                         // biased: score + BIAS; 0 = no cell
+    int32_t H[C];                                         // biased: score + BIAS - GAP_SCORE (i + j) of the diagonal's latest cell; 0 = no cell
 #pragma unroll
     for(int c = 0; c < C; c++) H[c] = 0;
 
@@ -208,17 +217,20 @@ bandedDpForwardKernel(
     auto cell = [&](auto steadyTag, int c, int32_t sc, uint32_t a, uint32_t bk, int32_t hd, int32_t hv, int32_t hh, uint64_t& loPlane, uint64_t& hiPlane) {
         constexpr bool STEADY = decltype(steadyTag)::value;
         const bool eq = a == bk;
-        const int32_t dg = hd + (eq ? MATCH_SCORE - GAP_SCORE : MISMATCH_SCORE - GAP_SCORE);   // the three candidates before the gap penalty they share
+        // Stored values are score + BIAS - GAP_SCORE (i + j): a gap move (one anti-diagonal on, one gap penalty) leaves the
+        // stored value as it is, a diagonal move (two anti-diagonals on) adds the match or mismatch score minus two gap
+        // penalties -- one addition per cell instead of two, same comparisons (all three candidates carry the same offset).
+        const int32_t dg = hd + (eq ? MATCH_SCORE - 2 * GAP_SCORE : MISMATCH_SCORE - 2 * GAP_SCORE);
         const bool isV = hv > dg;                                   // from (i, j-1): diagonal b+1
         const int32_t m1 = max(dg, hv);
         const bool isH = hh > m1;                                   // from (i-1, j): diagonal b-1
-        int32_t v = max(m1, hh) + GAP_SCORE;
+        int32_t v = max(m1, hh);
         if constexpr (STEADY) {
             SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
             H[c] = exists[c] ? v : 0;
         } else {
             const bool valid = uint32_t(sc - lo[c]) <= span[c];
-            v = (sc == lo[c]) ? BIAS : v;                           // i == 0 or j == 0: free leading gaps
+            v = (sc == lo[c]) ? BIAS - GAP_SCORE * sc : v;          // i == 0 or j == 0: free leading gaps (score 0)
             H[c] = valid ? v : H[c];
         }
         const uint64_t bEq = ballot64(eq), bV = ballot64(isV), bH = ballot64(isH);
@@ -244,29 +256,17 @@ bandedDpForwardKernel(
             }
         }
     };
-    // The record of an iteration (RW ballot words, uniform across the wavefront) goes to slot (it mod F) of the wavefront's
-    // 256-byte line, which is ONE vector register: dword k of the line lives in lane k, written there by v_writelane_b32 straight
-    // from the scalar registers the ballots are in.  A full line leaves as one coalesced 4-byte store per lane.  (Round 1 staged
-    // the line in LDS -- lane 0 wrote it, every lane read it back: 12 % of the kernel's wave cycles were LDS issue stalls.)
-    uint32_t lineRegister = 0;
-    auto putRecord = [&](uint32_t slot, const uint64_t (&words)[RW]) {
+    // The record of iteration `it`: RW ballot words, uniform across the wavefront, in scalar registers; they go to
+    // tr[it RW ...] as they are.
+    auto putRecord = [&](uint32_t it, const uint64_t (&words)[RW]) {
+        SHASTA_DEVICE_CHECK((uint64_t(it) + 1) * RW <= ((uint64_t(iters) * RW + 31) & ~31ULL));       // inside the bundle's trace (dpBundleKernel)
 #pragma unroll
-        for(int k = 0; k < RW; k++) {
-            lineRegister = writeLane(uint32_t(words[k]), (slot * RW + uint32_t(k)) * 2u, lineRegister);
-            lineRegister = writeLane(uint32_t(words[k] >> 32), (slot * RW + uint32_t(k)) * 2u + 1u, lineRegister);
-        }
+        for(int k = 0; k < RW; k += 2) scalarStore128(tr + uint64_t(it) * RW + k, words[k], words[k + 1]);
     };
-    // The same where the slot is a constant once the steady phase is unrolled: the lane select is an inline constant.
-    auto putRecordUnrolled = [&](int slot, const uint64_t (&words)[RW]) {
+    // The same for iteration `index` (a constant once the steady phase is unrolled) of the group whose records start at `base`.
+    auto putRecordOfGroup = [&](uint64_t* base, int index, const uint64_t (&words)[RW]) {
 #pragma unroll
-        for(int k = 0; k < RW; k++) {
-            lineRegister = writeLaneImmediate(uint32_t(words[k]), (slot * RW + k) * 2, lineRegister);
-            lineRegister = writeLaneImmediate(uint32_t(words[k] >> 32), (slot * RW + k) * 2 + 1, lineRegister);
-        }
-    };
-    auto flushLine = [&](uint32_t lineIndex) {
-        SHASTA_DEVICE_CHECK(uint64_t(lineIndex) * 32 + 32 <= ((uint64_t(iters) * RW + 31) & ~31ULL));      // inside the bundle's trace (dpBundleKernel)
-        reinterpret_cast<uint32_t*>(tr + uint64_t(lineIndex) * 32)[lane] = lineRegister;
+        for(int k = 0; k < RW; k += 2) scalarStore128At(base, (index * RW + k) * 8, words[k], words[k + 1]);
     };
 
     // General iterations [from, to): sliding register windows fed by clamped loads two iterations ahead.
@@ -283,8 +283,7 @@ bandedDpForwardKernel(
         for(uint32_t it = from; it < to; it++) {
             uint64_t words[RW];
             antiDiagonals(std::false_type{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
-            putRecord(it % F, words);
-            if(it % F == F - 1) flushLine(it / F);
+            putRecord(it, words);
 #pragma unroll
             for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
             aw[HC] = aNext1; aNext1 = aNext2;
@@ -336,8 +335,9 @@ bandedDpForwardKernel(
             for(int x = 0; x < U + HC - 1; x++) e[x] = loadB(ib - bandMin - l * HC - HC + x);
             const uint32_t* __restrict__ pa = p0 + (int64_t(iaBlock) + int64_t(steadyBegin));
             const uint32_t* __restrict__ pb = p1 + (int64_t(jbBlock) + int64_t(steadyBegin));
-            uint32_t lineIndex = steadyBegin / F;
-            for(uint32_t grp = 0; grp < groups; grp++) {
+            uint64_t* groupRecords = tr + uint64_t(steadyBegin) * RW;
+            SHASTA_DEVICE_CHECK((uint64_t(steadyBegin) + uint64_t(groups) * AL) * RW <= ((uint64_t(iters) * RW + 31) & ~31ULL));
+            for(uint32_t grp = 0; grp < groups; grp++, groupRecords += AL * RW) {
 #pragma unroll
                 for(int blk = 0; blk < AL / U; blk++) {
                     SHASTA_DEVICE_CHECK(pa >= p0 && pa + U <= p0 + nx && pb >= p1 && pb + U <= p1 + ny);
@@ -348,9 +348,7 @@ bandedDpForwardKernel(
                     for(int u = 0; u < U; u++) {
                         uint64_t words[RW];
                         antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
-                        const int slot = (blk * U + u) % F;
-                        putRecordUnrolled(slot, words);
-                        if(slot == F - 1) { flushLine(lineIndex); ++lineIndex; }
+                        putRecordOfGroup(groupRecords, blk * U + u, words);
                     }
 #pragma unroll
                     for(int x = 0; x < HC; x++) a[x] = a[x + U];
@@ -365,7 +363,7 @@ bandedDpForwardKernel(
         }
         general(steadyBegin + groups * AL, iters);
     }
-    if(iters % F != 0) flushLine(iters / F);              // the last, partial line (the bundle's trace is a whole number of lines)
+    scalarStoreFlush();                                   // the scalar data cache is write-back
 
     // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
     int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
@@ -373,7 +371,7 @@ bandedDpForwardKernel(
     for(int c = 0; c < C; c++) {
         const int32_t d = bandMin + l * C + c;
         const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
-        const int32_t v = exists[c] ? H[c] - BIAS : NEG_SCORE;
+        const int32_t v = exists[c] ? H[c] - BIAS + GAP_SCORE * (i + j) : NEG_SCORE;
         if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
     }
 #pragma unroll
@@ -515,7 +513,7 @@ dpTracebackWideKernel(
     const PairDesc pd = pairs[task.pair];
     const DpEnd e = ends[t];
     const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    const int cLog2 = geo.cls <= 2 ? 1 : geo.cls - 1;      // log2 of dpDiagonals(cls): C = 8, 16 for the classes this kernel is launched on
+    const int cLog2 = dpDiagonalsLog2(geo.cls);            // C = 8, 16 for the classes this kernel is launched on
     const uint32_t cMask = (1u << cLog2) - 1u;
     const int ipcLog2 = 4 - cLog2;                         // CW / (2 C) iterations per chunk, CW = 32
     static_assert(CW == 32, "chunk geometry");

@@ -43,6 +43,33 @@ __device__ __forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uin
 }
 #endif
 
+// s_store_dwordx4: 16 bytes that live in scalar registers (wave-uniform by construction: ballots) go to global memory without
+// passing through a vector register.  `address` must be wave-uniform (an SGPR pair) and 4-byte aligned.  The scalar data cache
+// is write-back: scalarStoreFlush() before the wavefront ends, or a later kernel may not see the data.
+// (The wave64 emulator of tests/emu supplies its own: SHASTA_SCALAR_STORE_DEFINED.)
+#ifndef SHASTA_SCALAR_STORE_DEFINED
+__device__ __forceinline__ void scalarStore128(void* address, uint64_t low, uint64_t high)
+{
+    const __uint128_t v = (__uint128_t(high) << 64) | __uint128_t(low);
+    asm volatile("s_store_dwordx4 %0, %1, 0x0" :: "s"(v), "s"(address) : "memory");
+}
+// The same at a byte offset that is a constant by the time the code is generated (an expression of unrolled loop counters):
+// it goes into the instruction, no address arithmetic.
+__device__ __forceinline__ void scalarStore128At(void* address, int byteOffset, uint64_t low, uint64_t high)
+{
+    const __uint128_t v = (__uint128_t(high) << 64) | __uint128_t(low);
+    asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(v), "s"(address), "i"(byteOffset) : "memory");
+}
+__device__ __forceinline__ void scalarStoreFlush() { asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
+// A wave-uniform pointer the compiler cannot prove uniform (it depends on threadIdx.x >> 6).
+template<class T> __device__ __forceinline__ T* uniformPointer(T* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return reinterpret_cast<T*>((uint64_t(hi) << 32) | lo);
+}
+#endif
+
 // An element count a kernel is given: an upper bound known on the host (grids are sized from it) and, optionally, the
 // address of the exact count on the device, written by an earlier kernel of the same stream.  The host never reads the
 // exact count back between the launches: no stream synchronisation inside a chain of kernels.

@@ -240,6 +240,15 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 #define SHASTA_WRITELANE_DEFINED 1
 __forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uint32_t old) { return (uint32_t(threadIdx.x) & 63u) == (lane & 63u) ? value : old; }
 __forceinline__ uint32_t writeLaneImmediate(uint32_t value, int lane, uint32_t old) { return writeLane(value, uint32_t(lane), old); }
+// s_store_dwordx4 + s_dcache_wb (inline assembly in primitives.hpp): lane 0 of the wavefront stores.
+#define SHASTA_SCALAR_STORE_DEFINED 1
+__forceinline__ void scalarStore128(void* address, uint64_t low, uint64_t high)
+{
+    if((uint32_t(threadIdx.x) & 63u) == 0) { uint64_t v[2] = {low, high}; std::memcpy(address, v, 16); }
+}
+__forceinline__ void scalarStore128At(void* address, int byteOffset, uint64_t low, uint64_t high) { scalarStore128(static_cast<char*>(address) + byteOffset, low, high); }
+__forceinline__ void scalarStoreFlush() {}
+template<class T> __forceinline__ T* uniformPointer(T* p) { return p; }
 #ifndef __clang__
 template<class T> __forceinline__ T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 #endif
