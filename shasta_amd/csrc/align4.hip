@@ -320,32 +320,17 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     hipStream_t stream = ws.stream;
     const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data()};
     const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
-    // The three traceback kernels over their class ranges of the sorted list (C = 2: class 0; C = 4: classes 1-3; wider: 4-5).
-    // Booked: the trace a kernel has to read = 2 bits per cell of the padded bands of its tasks (iterations x 2 C words, bounded
-    // by sums[1] for the whole batch: split by DP cells), work = tasks.
-    auto traceback = [&](const char* name, int firstClass, int lastClass, auto kernel) {
-        const uint32_t begin = f.taskStart[firstClass], end = f.taskStart[lastClass + 1];
-        if(end == begin) return;
-        unsigned long long cells = 0;
-        for(int c = firstClass; c <= lastClass; c++) cells += f.sums[2 + c];
-        const uint64_t traceBytes = f.sums[0] ? uint64_t(double(8 * f.sums[1]) * double(cells) / double(f.sums[0])) : 0;
-        SHASTA_TIMED(ctx, name, stream, traceBytes, end - begin,
-            hipLaunchKernelGGL(kernel, dim3(divUp(end - begin, 256)), dim3(256), 0, stream,
-                in.pairs, in.tasks, f.sortedIds, begin, end,
+    // The traceback of every class in one launch (the list is sorted by class, then length; the kernel takes it from the end).
+    // Booked: the trace it has to read = 2 bits per cell of the padded bands (iterations x 2 C words, bounded by sums[1] for
+    // the whole batch), work = tasks.
+    {
+        SHASTA_TIMED(ctx, "dpTracebackKernel", stream, 8 * f.sums[1], taskCount,
+            hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+                in.pairs, in.tasks, f.sortedIds, 0u, taskCount,
                 (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
                 (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data()));
         HIP_CHECK(hipGetLastError());
-    };
-    // The wide classes are a handful of long walks (long reads have wide bands): a launch that lasts as long as its longest
-    // path and occupies a few wavefronts.  They run on the side stream beside the narrow classes.
-    const bool forkWide = ws.wide != nullptr && ev != nullptr && f.taskStart[DP_CLASSES] > f.taskStart[4] && f.taskStart[4] > 0;
-    hipStream_t main = stream;
-    if(forkWide) { HIP_CHECK(hipEventRecord(ev->fork, main)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); stream = ws.wide; }
-    traceback("dpTracebackWideKernel<32>", 4, 5, dpTracebackWideKernel<32>);       // the longest walks first
-    if(forkWide) { HIP_CHECK(hipEventRecord(ev->join, ws.wide)); stream = main; }
-    traceback("dpTracebackKernel<4>", 1, 3, dpTracebackKernel<4>);
-    traceback("dpTracebackKernel<2>", 0, 0, dpTracebackKernel<2>);
-    if(forkWide) HIP_CHECK(hipStreamWaitEvent(main, ev->join, 0));
+    }
     // Booked: 8 bytes per aligned pair are read (unknown here: at most min(nx, ny) per task; the caller amends nothing) -- work = tasks.
     SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, taskCount,
         hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(taskCount) * WAVE, 256)), dim3(256), 0, stream,

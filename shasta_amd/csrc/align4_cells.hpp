@@ -458,13 +458,37 @@ align4CellsChunkKernel(
         return;
     }
 
+    // The stream in groups of 64 markers dealt to the wavefronts in turn (group g to wavefront g mod waves: every wavefront
+    // gets the same number of groups, give or take one); a wavefront takes CELLS_UNROLL of its groups per round, and a slot of
+    // the last round whose group lies beyond the stream is skipped (wavefront-uniform).  Slot u of the round that starts at
+    // s0 holds markers s0 + u groupStride + lane.
+    const uint32_t groupStride = waves * uint32_t(WAVE);
+    const uint32_t roundStride = uint32_t(CELLS_UNROLL) * groupStride;
+    const uint32_t firstRound = wave * uint32_t(WAVE);
+    // A candidate starts with a chain of dependent global loads (member list -> pair descriptor -> the first markers of
+    // its stream), a few microseconds during which the whole workgroup would wait: they are issued one candidate ahead
+    // (descriptor at the start of the previous candidate, first round of markers after the previous candidate's first round).
+    uint32_t pairAhead = members[chunk.firstMember];
+    PairDesc pdAhead = pdFirst;
+    uint32_t kmAhead[CELLS_UNROLL];
+    auto loadFirstRound = [&](const PairDesc& d) {
+        const uint32_t* __restrict__ seq = kmerIds + (swapped ? d.begin0 : d.begin1);
+        const uint32_t count = swapped ? d.nx : d.ny;
+#pragma unroll
+        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmAhead[u] = t < count ? seq[t] : 0u; }
+    };
+    loadFirstRound(pdAhead);
+
     // Groups of `waves` candidates: streamed one after the other by the whole workgroup, then one graph per wavefront.
     for(uint32_t group = 0; group < chunk.count; group += waves) {
     const uint32_t groupEnd = min(group + waves, uint32_t(chunk.count));
     for(uint32_t c = group; c < groupEnd; c++) {
-        const uint32_t pair = members[chunk.firstMember + c];
-        const PairDesc pd = pairs[pair];
+        const uint32_t pair = pairAhead;
+        const PairDesc pd = pdAhead;
         const uint32_t nx = pd.nx, ny = pd.ny;
+        const bool more = c + 1 < uint32_t(chunk.count);
+        if(more) { pairAhead = members[chunk.firstMember + c + 1]; pdAhead = pairs[pairAhead]; }
+        bool aheadLoaded = !more;
         kept = slots + (c - group) * cellsSlotLdsWords(Q);
         scratch = kept + 2 * MAXC;
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
@@ -485,7 +509,7 @@ align4CellsChunkKernel(
             } else {
                 for(uint32_t k = first; k < SC; k += stride) cells[k] = EMPTY32;
             }
-            if(first == 0) { scratch[0] = 0; scratch[4] = 0; }
+            if(first == 0) { scratch[0] = 0; scratch[4] = 0; scratch[5] = pair; scratch[6] = nx; scratch[7] = ny; }   // [5..7]: for the graph
         }
         __syncthreads();
         PHASE_MARK(1);
@@ -569,16 +593,9 @@ align4CellsChunkKernel(
             }
         };
 
-        // The stream in groups of 64 markers dealt to the wavefronts in turn (group g to wavefront g mod waves: every wavefront
-        // gets the same number of groups, give or take one); a wavefront takes CELLS_UNROLL of its groups per round, and a slot of
-        // the last round whose group lies beyond the stream is skipped (wavefront-uniform).  Slot u of the round that starts at
-        // s0 holds markers s0 + u groupStride + lane.
-        const uint32_t groupStride = waves * uint32_t(WAVE);
-        const uint32_t roundStride = uint32_t(CELLS_UNROLL) * groupStride;
-        const uint32_t firstRound = wave * uint32_t(WAVE);
         uint32_t kmNext[CELLS_UNROLL];
 #pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        for(int u = 0; u < CELLS_UNROLL; u++) kmNext[u] = kmAhead[u];
         SUBPHASE_DECLARE();
         for(uint32_t s0 = firstRound; s0 < streamCount; s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
@@ -681,7 +698,9 @@ align4CellsChunkKernel(
                 for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
                 if(__any(anyHit)) countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts);
             }
+            if(!aheadLoaded) { loadFirstRound(pdAhead); aheadLoaded = true; }
         }
+        if(!aheadLoaded) loadFirstRound(pdAhead);                     // (this wavefront had no round of its own)
         SUBPHASE_FLUSH();
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
         if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
@@ -691,10 +710,8 @@ align4CellsChunkKernel(
 
         // The kept-cell graphs of the group, one per wavefront.
         if(group + wave < groupEnd) do {
-        const uint32_t pair = members[chunk.firstMember + group + wave];
-        const PairDesc pd = pairs[pair];
-        const uint32_t nx = pd.nx, ny = pd.ny;
         kept = ownKept; scratch = ownScratch;
+        const uint32_t pair = scratch[5], nx = scratch[6], ny = scratch[7];
         const uint32_t seen = scratch[4];
         int overflow = (seen & 0x10u) ? 2 : ((seen & 0x08u) ? 1 : 0), reason = int(seen & 7u);
         const int n = int(scratch[0]);

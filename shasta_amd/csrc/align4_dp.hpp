@@ -387,22 +387,25 @@ bandedDpForwardKernel(
     }
 }
 
-// Traceback.  ONE LANE per task (64 paths in flight per wavefront) walks from the end cell through the packed trace,
-// writes the aligned ordinals and accumulates AlignmentInfo's metrics (src/Alignment.cpp:67-113, :4-31).
+// Traceback.  ONE LANE per task (64 paths in flight per wavefront) walks from the end cell through the packed trace and
+// writes the aligned ordinals.
 //
-// What the walk costs is latency, not bytes: a kernel of sorted tasks lasts as long as its longest path times the
+// What the walk costs is latency, not bytes: a launch over sorted tasks lasts as long as its longest path times the
 // time of one step.  So:
-//  * a path crosses every anti-diagonal pair, i.e. it visits the iterations of the forward kernel in strictly
-//    descending order, one or two cells in each.  The trace is consumed in 256-byte chunks (a whole number of
-//    iterations, 8 / 4 for C = 2 / 4 diagonals per lane); a lane holds its current chunk and the next one IN
-//    REGISTERS, and the walk through a chunk is unrolled over the chunk's iterations and the two possible cells of
-//    each, so that every register index is static: no LDS, no address arithmetic, no dependent memory access in a
-//    step.  The loads of the next chunk are issued a whole chunk ahead;
-//  * C is a template parameter (the round-1 kernel divided by a run-time C twice per step);
-//  * the longest tasks go first (the list is sorted by ascending length: lane order is reversed), so that the tail
-//    of the launch is made of short paths.
-// Tasks with C = 8 or 16 diagonals per lane (bands wider than 512: a handful per batch) walk through an LDS window
-// instead (dpTracebackWideKernel): the unrolled select chain over C record pairs would not pay.
+//  * the trace is consumed in 256-byte chunks (a whole number of iterations of the forward kernel: 8, 4, 2, 1 for C = 2,
+//    4, 8, 16 diagonals per lane).  The chunk under the path sits in the lane's private window of LDS, the next one is in
+//    flight in registers, its loads issued a whole chunk ahead: a step is a little address arithmetic, ONE LDS read of the
+//    two dwords that hold the cell's code, two bit extracts and the move;
+//  * the aligned pairs a lane finds in a chunk (at most one per iteration) wait in LDS and are stored together at the
+//    start of the next chunk, where the wave waits for the prefetch anyway: a store inside the walk makes the walk wait for
+//    the prefetch each time (loads and stores retire through one in-order counter);
+//  * ONE kernel for every band class, ONE launch per batch: the launch lasts as long as the longest path of the batch
+//    whichever way the classes are split, and three launches (this round's first version: register-resident chunks with
+//    the walk unrolled over a chunk's iterations and both cells of each for C = 2 and 4 -- 66 VALU instructions per
+//    possible cell, issued whether the lane's path was there or not -- plus this kernel for C = 8, 16) paid for three
+//    longest paths: 77 ms per step solo against 52 for this kernel alone, before it was trimmed;
+//  * the longest tasks go first (the list is sorted by class, then ascending length: lane order is reversed), so that
+//    the tail of the launch is made of short paths.
 // The walk itself only stores the aligned pairs (from the end of the task's ordinal range downwards) and counts
 // them; everything that can be computed from the stored pairs afterwards -- AlignmentInfo's metrics, the inner
 // acceptance -- is computed by dpMetricsKernel, a wavefront per task, in parallel: each instruction taken out of the
@@ -419,16 +422,16 @@ __device__ __forceinline__ void tracebackFinish(uint32_t pos, const PairDesc& pd
 }
 
 // Tasks [taskBegin, taskEnd) of the sorted list, all of a class with C diagonals per lane (C = 2 or 4).
-template<int C>
+constexpr int DP_TRACE_CHUNK_QUADS = 16;                    // 16-byte pieces of a 256-byte chunk: {low plane, high plane} of one diagonal of one iteration
 __global__ void __launch_bounds__(256)
 dpTracebackKernel(
     const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
     const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
     const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
 {
-    static_assert(C == 2 || C == 4, "register-resident chunks: C = 2 or 4");
-    constexpr int QUADS = 16;                              // 16-byte pieces of a 256-byte chunk
-    constexpr int IPC = QUADS / C;                         // iterations per chunk (a record = C pieces: {lo plane, hi plane} per diagonal of a lane)
+    constexpr int QUADS = DP_TRACE_CHUNK_QUADS, MAX_IPC = QUADS / 2;
+    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free 16-byte accesses for a wave
+    __shared__ uint2 found[256 * MAX_IPC];                 // [k][thread]: the aligned pairs of the current chunk
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if(k >= taskEnd - taskBegin) return;
     const uint32_t t = sortedIds[taskEnd - 1 - k];         // longest first
@@ -436,88 +439,12 @@ dpTracebackKernel(
     const PairDesc pd = pairs[task.pair];
     const DpEnd e = ends[t];
     const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
-    const uint64_t ordBase = ordOffsets[t];
-    uint32_t pos = min(pd.nx, pd.ny);                      // aligned pairs are stored from the end of the task's range downwards
-    int32_t i = e.bestI, j = e.bestJ;
-    bool active = e.score > NEG_SCORE && i > 0 && j > 0;
-    // The walk in terms of the iteration relative to the current chunk: rel = iteration - chunk * IPC runs down from
-    // IPC - 1 (or from the end cell's iteration in the first chunk) to -1, where the chunk is exhausted.
-    int32_t chunk = active ? int32_t((uint32_t(i + j - geo.s0) >> 1) / uint32_t(IPC)) : -1;
-    uint4 cur[QUADS], next[QUADS];
-#pragma unroll
-    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[int64_t(chunk) * QUADS + q] : make_uint4(0, 0, 0, 0);
-    while(__any(active)) {
-        // An aligned pair found in iteration u of this chunk (at most one per iteration: it is a diagonal step out of the
-        // iteration) waits in matchX[u], matchY[u]; the pairs are stored together when the chunk is done.  A store inside
-        // the walk would make the walk wait for the prefetch below each time: loads and stores retire through one in-order
-        // counter, and the store's data registers may only be overwritten once it has retired.
-        uint32_t matchX[IPC], matchY[IPC], matched = 0;
-        if(active) {
-#pragma unroll
-            for(int q = 0; q < QUADS; q++) cur[q] = next[q];
-            if(chunk > 0) {
-#pragma unroll
-                for(int q = 0; q < QUADS; q++) next[q] = tr[int64_t(chunk - 1) * QUADS + q];
-            }
-        }
-        const int32_t iterationBase = chunk * IPC;
-        // The iterations of this chunk in descending order; in each, at most two cells of the path (the cell of the
-        // odd anti-diagonal, then the one of the even anti-diagonal).
-#pragma unroll
-        for(int u = IPC - 1; u >= 0; u--) {
-            matchX[u] = 0; matchY[u] = 0;
-#pragma unroll
-            for(int cellOfIteration = 0; cellOfIteration < 2; cellOfIteration++) {
-                const int32_t rel = ((i + j - geo.s0) >> 1) - iterationBase;
-                if(active && rel == u) {
-                    const uint32_t b = uint32_t(i - j - task.bandMin);
-                    const uint32_t c = b % uint32_t(C), bit = e.laneBase + b / uint32_t(C);
-                    uint4 rec = cur[u * C];
-#pragma unroll
-                    for(int cc = 1; cc < C; cc++) if(c == uint32_t(cc)) rec = cur[u * C + cc];
-                    const uint32_t lo = (bit & 32u) ? rec.y : rec.x, hi = (bit & 32u) ? rec.w : rec.z;
-                    const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
-                    // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
-                    if(dir == 0u) { matchX[u] = uint32_t(i - 1); matchY[u] = uint32_t(j - 1); matched |= 1u << u; }
-                    i -= (dir != 2u) ? 1 : 0;
-                    j -= (dir != 3u) ? 1 : 0;
-                    active = i > 0 && j > 0;
-                }
-            }
-        }
-#pragma unroll
-        for(int u = IPC - 1; u >= 0; u--) {
-            if(matched & (1u << u)) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(matchX[u], matchY[u]); }
-        }
-        --chunk;
-    }
-    tracebackFinish(pos, pd, e, ordBase, t, results);
-}
-
-// Tasks [taskBegin, taskEnd) of the classes with 8 or 16 diagonals per lane: the chunk under the path sits in the
-// lane's private LDS window, the next one is in flight in registers.
-template<int CW>
-__global__ void __launch_bounds__(256)
-dpTracebackWideKernel(
-    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
-    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
-{
-    constexpr int QUADS = CW / 2;                          // 16-byte pieces of a chunk
-    __shared__ uint4 window[256 * QUADS];                  // [piece][thread]: conflict-free for a wave
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if(k >= taskEnd - taskBegin) return;
-    const uint32_t t = sortedIds[taskEnd - 1 - k];         // longest first
-    const DpTask task = tasks[t];
-    const PairDesc pd = pairs[task.pair];
-    const DpEnd e = ends[t];
-    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
-    const int cLog2 = dpDiagonalsLog2(geo.cls);            // C = 8, 16 for the classes this kernel is launched on
+    const int cLog2 = dpDiagonalsLog2(geo.cls);
     const uint32_t cMask = (1u << cLog2) - 1u;
-    const int ipcLog2 = 4 - cLog2;                         // CW / (2 C) iterations per chunk, CW = 32
-    static_assert(CW == 32, "chunk geometry");
+    const int ipcLog2 = 4 - cLog2;                         // QUADS / C iterations per chunk
+    const uint32_t ipcMask = (1u << ipcLog2) - 1u;
     const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
+    const uint32_t* const window32 = reinterpret_cast<const uint32_t*>(window) + 4 * threadIdx.x;
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);                      // aligned pairs are stored from the end of the task's range downwards
     int32_t i = e.bestI, j = e.bestJ;
@@ -525,35 +452,46 @@ dpTracebackWideKernel(
     // the same point of the program, then walks until its path leaves the chunk.  The wave waits
     // for memory once per epoch, for loads issued a whole epoch earlier.
     bool active = e.score > NEG_SCORE && i > 0 && j > 0;
-    int64_t chunk = active ? int64_t((uint32_t(i + j - geo.s0) >> 1) >> ipcLog2) : -1;
+    int32_t chunk = active ? int32_t((uint32_t(i + j - geo.s0) >> 1) >> ipcLog2) : -1;
     uint4 next[QUADS];
 #pragma unroll
-    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[chunk * QUADS + q] : make_uint4(0, 0, 0, 0);
+    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[int64_t(chunk) * QUADS + q] : make_uint4(0, 0, 0, 0);
+    uint32_t foundCount = 0;
+    auto storeFound = [&]() {
+        for(uint32_t q = 0; q < foundCount; q++) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = found[q * 256 + threadIdx.x]; }
+        foundCount = 0;
+    };
     while(__any(active)) {
+        // The pairs of the previous chunk leave here, where the wave waits for the prefetched chunk anyway (stores and
+        // loads retire through one in-order counter: stores issued after the prefetch would wait for it).
+        storeFound();
         if(active) {
 #pragma unroll
             for(int q = 0; q < QUADS; q++) window[q * 256 + threadIdx.x] = next[q];
             if(chunk > 0) {
 #pragma unroll
-                for(int q = 0; q < QUADS; q++) next[q] = tr[(chunk - 1) * QUADS + q];
+                for(int q = 0; q < QUADS; q++) next[q] = tr[int64_t(chunk - 1) * QUADS + q];
             }
         }
         while(active) {
             const uint32_t b = uint32_t(i - j - task.bandMin);
             const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
-            if(int64_t(it >> ipcLog2) != chunk) break;
-            const uint32_t c = b & cMask, bit = e.laneBase + (b >> cLog2);
-            const uint32_t piece = ((it & ((1u << ipcLog2) - 1u)) << cLog2) + c;     // one 16-byte piece = {lo plane, hi plane} of diagonal c
-            const uint4 rec = window[piece * 256 + threadIdx.x];
-            const uint32_t lo = (bit & 32u) ? rec.y : rec.x, hi = (bit & 32u) ? rec.w : rec.z;
+            if(int32_t(it >> ipcLog2) != chunk) break;
+            const uint32_t bit = e.laneBase + (b >> cLog2);
+            const uint32_t piece = ((it & ipcMask) << cLog2) + (b & cMask);
+            // The piece is {low plane: bits 0-31, 32-63; high plane: bits 0-31, 32-63}: the two dwords that hold bit `bit`.
+            const uint32_t* const word = window32 + piece * 1024u + ((bit >> 5) & 1u);
+            const uint32_t lo = word[0], hi = word[2];
             const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
-            if(dir == 0u) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(uint32_t(i - 1), uint32_t(j - 1)); }
+            // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
+            if(dir == 0u) { found[foundCount * 256 + threadIdx.x] = make_uint2(uint32_t(i - 1), uint32_t(j - 1)); ++foundCount; }
             i -= (dir != 2u) ? 1 : 0;
             j -= (dir != 3u) ? 1 : 0;
             active = i > 0 && j > 0;
         }
         --chunk;
     }
+    storeFound();
     tracebackFinish(pos, pd, e, ordBase, t, results);
 }
 

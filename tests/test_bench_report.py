@@ -19,7 +19,7 @@ FAKE_TABLE = {
     "bandedDpForwardKernel<16, 2>": {"seconds": 0.08, "launches": 32, "bytes": 32 * 296_000_000, "work": int(3e10)},
     "bandedDpForwardKernel<32, 2>": {"seconds": 0.28, "launches": 32, "bytes": 32 * 1_186_000_000, "work": int(2.2e11)},
     "bandedDpForwardKernel<64, 2>": {"seconds": 0.20, "launches": 32, "bytes": 32 * 353_000_000, "work": int(1.1e11)},
-    "dpTracebackKernel<2>": {"seconds": 0.16, "launches": 32, "bytes": 32 * 1_800_000_000, "work": 32 * 150_000},
+    "dpTracebackKernel": {"seconds": 0.16, "launches": 32, "bytes": 32 * 1_800_000_000, "work": 32 * 150_000},
 }
 
 
