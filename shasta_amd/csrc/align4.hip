@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -319,6 +320,27 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
 {
     hipStream_t stream = ws.stream;
     const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data()};
+    static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
+    if(debug) {
+        // Band widths of the batch's tasks, DP cells (nx x width) per width.
+        std::vector<DpTask> hostTasks(taskCount);
+        HIP_CHECK(hipMemcpyAsync(hostTasks.data(), b.tasks.data(), taskCount * sizeof(DpTask), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        uint32_t pairCount = 0;
+        for(const DpTask& t : hostTasks) pairCount = std::max(pairCount, t.pair + 1);
+        std::vector<PairDesc> hostPairs(pairCount);
+        HIP_CHECK(hipMemcpyAsync(hostPairs.data(), b.pairs.data(), hostPairs.size() * sizeof(PairDesc), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::map<int32_t, std::pair<uint64_t, uint64_t>> histogram;
+        for(const DpTask& t : hostTasks) {
+            const int32_t w = t.bandMax - t.bandMin + 1;
+            auto& h = histogram[w <= 300 ? w : ((w + 99) / 100) * 100];
+            h.first += 1; h.second += uint64_t(hostPairs[t.pair].nx) * uint64_t(w);
+        }
+        std::fprintf(stderr, "dp: band width -> tasks, cells:");
+        for(const auto& kv : histogram) std::fprintf(stderr, " %d: %llu, %.3g;", kv.first, (unsigned long long)kv.second.first, double(kv.second.second));
+        std::fprintf(stderr, "\n");
+    }
     const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
     // The traceback of every class in one launch (the list is sorted by class, then length; the kernel takes it from the end).
     // Booked: the trace it has to read = 2 bits per cell of the padded bands (iterations x 2 C words, bounded by sums[1] for

@@ -349,11 +349,10 @@ __device__ __forceinline__ void waveLdsSync()
 
 __device__ __forceinline__ uint32_t hash32b(uint32_t k) { return k * 0x85ebca6bu; }
 
-// Bits 15 and 31 of the result flag the 16-bit halves of v that are zero (exact, no carries).
-__device__ __forceinline__ uint32_t zeroHalves(uint32_t v)
-{
-    return ~(((v & 0x7fff7fffu) + 0x7fff7fffu) | v | 0x7fff7fffu);
-}
+// Bits 0 and 16 of the result flag the 16-bit halves of v that are zero: a packed 16-bit minimum with 1 (v_pk_min_u16) leaves
+// 0 in a zero half and 1 in any other; two instructions where the carry-free SWAR form took four.
+__device__ __forceinline__ uint32_t zeroHalves(uint32_t v) { return packedMinU16(v, 0x00010001u) ^ 0x00010001u; }
+constexpr uint32_t LOW_HALF = 1u, HIGH_HALF = 0x10000u;
 
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
 constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
@@ -443,7 +442,7 @@ align4CellsChunkKernel(
             const uint32_t base = 2 * (useV ? b2 : b1);
             const bool second = f0 == 0;
             const uint32_t f = second ? f1 : f0, old = second ? w1 : w0;
-            const int shift = (f & 0x8000u) ? 0 : 16;
+            const int shift = (f & LOW_HALF) ? 0 : 16;
             const uint32_t updated = (old & ~(0xffffu << shift)) | (entry << shift);
             if(atomicCAS(&aSlots[base + (second ? 1 : 0)], old, updated) == old) break;
         }
@@ -638,10 +637,10 @@ align4CellsChunkKernel(
                     const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
                     const uint32_t ww = s0m ? w[u][0] : (s1m ? w[u][1] : (s2m ? w[u][2] : w[u][3]));
                     const bool cand = mm != 0;
-                    const bool low = (mm & 0x8000u) != 0;
+                    const bool low = (mm & LOW_HALF) != 0;
                     ti[u] = (low ? ww : (ww >> 16)) & xMask;
                     ka[u] = aKmers[cand ? ti[u] : 0u];
-                    const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
+                    const uint32_t cleared = mm & (low ? ~LOW_HALF : ~HIGH_HALF);
                     if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
                     hit[u] = cand;
                 }
@@ -676,10 +675,10 @@ align4CellsChunkKernel(
                 const uint32_t mm = mw[0] ? mw[0] : (mw[1] ? mw[1] : (mw[2] ? mw[2] : mw[3]));
                 const uint32_t ww = mw[0] ? wwv[0] : (mw[1] ? wwv[1] : (mw[2] ? wwv[2] : wwv[3]));
                 const bool cand = mm != 0;
-                const bool low = (mm & 0x8000u) != 0;
+                const bool low = (mm & LOW_HALF) != 0;
                 const uint32_t tiSel = (low ? ww : (ww >> 16)) & xMask;
                 const uint32_t kaSel = aKmers[cand ? tiSel : 0u];
-                const uint32_t cleared = mm & (low ? ~0x8000u : ~0x80000000u);
+                const uint32_t cleared = mm & (low ? ~LOW_HALF : ~HIGH_HALF);
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++)
 #pragma unroll

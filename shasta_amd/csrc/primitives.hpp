@@ -43,6 +43,17 @@ __device__ __forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uin
 }
 #endif
 
+// v_pk_min_u16: the minimum of the two 16-bit halves of a and b, half by half (the compiler splits the generic vector form into
+// two 16-bit operations).  The wave64 emulator supplies its own (SHASTA_PACKED_MIN_DEFINED).
+#ifndef SHASTA_PACKED_MIN_DEFINED
+__device__ __forceinline__ uint32_t packedMinU16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
+
 // s_store_dwordx4: 16 bytes that live in scalar registers (wave-uniform by construction: ballots) go to global memory without
 // passing through a vector register.  `address` must be wave-uniform (an SGPR pair) and 4-byte aligned.  The scalar data cache
 // is write-back: scalarStoreFlush() before the wavefront ends, or a later kernel may not see the data.

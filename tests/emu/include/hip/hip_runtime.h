@@ -240,6 +240,13 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 #define SHASTA_WRITELANE_DEFINED 1
 __forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uint32_t old) { return (uint32_t(threadIdx.x) & 63u) == (lane & 63u) ? value : old; }
 __forceinline__ uint32_t writeLaneImmediate(uint32_t value, int lane, uint32_t old) { return writeLane(value, uint32_t(lane), old); }
+// v_pk_min_u16 (inline assembly in primitives.hpp).
+#define SHASTA_PACKED_MIN_DEFINED 1
+__forceinline__ uint32_t packedMinU16(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+    return (hi << 16) | lo;
+}
 // s_store_dwordx4 + s_dcache_wb (inline assembly in primitives.hpp): lane 0 of the wavefront stores.
 #define SHASTA_SCALAR_STORE_DEFINED 1
 __forceinline__ void scalarStore128(void* address, uint64_t low, uint64_t high)
