@@ -406,9 +406,9 @@ int shasta_mi355x_banded_dp(
  * wavefront exactly as the tasks of an Align4 batch are.  Task t aligns kmerIds[begin0[t] .. +nx[t]) with
  * kmerIds[begin1[t] .. +ny[t]) inside the band [bandMin[t], bandMax[t]] (width <= 1024, meeting the matrix).
  * counts[t] aligned pairs and scores[t] per task; the pairs of all tasks concatenated in ordinals
- * (capacity in pairs; ordinals may be NULL).  seconds (NULL or 7 entries): HIP-event time of the forward
- * launch of each of the six band classes (widths <= 32, 64, 128, 256, 512, 1024) and of the traceback;
- * cells (NULL or 6 entries): DP cells (nx x band width) per class.  A unit seam for parity tests and for
+ * (capacity in pairs; ordinals may be NULL).  seconds (NULL or 9 entries): HIP-event time of the forward
+ * launch of each of the eight band classes (widths <= 32, 48, 64, 80, 128, 256, 512, 1024) and of the traceback;
+ * cells (NULL or 8 entries): DP cells (nx x band width) per class.  A unit seam for parity tests and for
  * timing one kernel version against another (scripts/dp_microbench.py), like shasta_mi355x_banded_dp. */
 int shasta_mi355x_banded_dp_many(
     const uint32_t* kmerIds, uint64_t kmerCount, uint64_t taskCount,

@@ -48,15 +48,15 @@ def main():
     from shasta_amd import lib as libmod
     lib = libmod.Library(args.library) if args.library else shasta_amd.load()
     kmer, spec = tasks_of(args.tasks, args.length, 1)
-    names = ["<=32", "<=64", "<=128", "<=256", "<=512", "<=1024"]
+    names = ["<=32", "<=48", "<=64", "<=80", "<=128", "<=256", "<=512", "<=1024"]
     for r in range(args.repeat + 1):
         counts, scores, seconds, cells = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5], timing=True)
         if r == 0:
             continue                                     # warm-up (allocations, the start-up comparison of the two versions)
         line = {"tasks": args.tasks, "aligned_markers": int(counts.sum()),
-                "forward_ms": {names[c]: round(1e3 * seconds[c], 3) for c in range(6) if cells[c]},
-                "forward_gcups": {names[c]: round(float(cells[c]) / seconds[c] / 1e9, 1) for c in range(6) if cells[c] and seconds[c] > 0},
-                "forward_total_ms": round(1e3 * float(seconds[:6].sum()), 3), "traceback_ms": round(1e3 * float(seconds[6]), 3)}
+                "forward_ms": {names[c]: round(1e3 * seconds[c], 3) for c in range(8) if cells[c]},
+                "forward_gcups": {names[c]: round(float(cells[c]) / seconds[c] / 1e9, 1) for c in range(8) if cells[c] and seconds[c] > 0},
+                "forward_total_ms": round(1e3 * float(seconds[:8].sum()), 3), "traceback_ms": round(1e3 * float(seconds[8]), 3)}
         print(json.dumps(line))
 
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 2, twenty-third GPU call: batch sizes that divide the candidates evenly among the workers; LowHash0 alone.
+READS=${1:-100000}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 600 python bench.py --reads $READS --steps 5 --warmup 2 --no-cpu-baseline --lowhash-only > gpurun_out/bench23_lh.json 2> gpurun_out/bench23_lh.err
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench23_lh.json").read().strip().splitlines()[-1])
+print("lowhash only: ms/step %.1f" % d["ms_per_step"], {k: round(v * 1e3, 1) for k, v in d["stage_seconds_per_step"].items()})
+PY
+for CFG in "6 262144" "6 330700" "6 165400" "4 262144" "5 262144" "6 262144" "7 262144"; do
+  set -- $CFG
+  SHASTA_MI355X_ALIGN_WORKERS=$1 SHASTA_MI355X_ALIGN_BATCH=$2 timeout 600 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench23_w$1_b$2.json 2> gpurun_out/bench23_w$1_b$2.err; echo "bench workers $1 batch $2 rc=$?"
+  python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench23_w$1_b$2.json").read().strip().splitlines()[-1])
+print("workers $1 batch $2: value %.0f" % d["value"], "ms/step %.1f" % d["ms_per_step"], {k: round(v * 1e3, 1) for k, v in d["stage_seconds_per_step"].items()}, "kernel s/step %.3f" % d["kernel_seconds_per_step"])
+PY
+done

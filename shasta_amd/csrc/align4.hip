@@ -231,8 +231,8 @@ struct DpEvents {
     void destroy() { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
 };
 struct DpBatchStats { uint64_t cells[DP_CLASSES] = {0}, bytes[DP_CLASSES] = {0}; uint32_t tasks[DP_CLASSES] = {0}; };
-const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<16, 4>", "bandedDpForwardKernel<32, 4>",
-    "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"};
+const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<12, 4>", "bandedDpForwardKernel<16, 4>",
+    "bandedDpForwardKernel<20, 4>", "bandedDpForwardKernel<32, 4>", "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"};
 
 // Forward half of K10 for taskCount tasks: sort by (band class, iterations), bundle, lay out the
 // trace, run the forward kernel of every class.  Leaves b.trace / b.ends for a traceback kernel.
@@ -240,7 +240,7 @@ struct DpForwardState {
     const uint32_t* sortedIds;
     uint32_t taskStart[DP_CLASSES + 1];   // class c = tasks [taskStart[c], taskStart[c + 1]) of the sorted list
     uint32_t classCounts[DP_CLASSES];
-    unsigned long long sums[16];          // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
+    unsigned long long sums[2 + 2 * DP_CLASSES];   // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c
 };
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers)
@@ -252,9 +252,9 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
     b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
     b.results.reserve(taskCount, stream); b.ends.reserve(taskCount, stream);
-    b.counters.reserve(16, stream); b.dpCells.reserve(16, stream);
+    b.counters.reserve(16, stream); b.dpCells.reserve(2 + 2 * DP_CLASSES, stream);
     HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
-    HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, 16 * sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, (2 + 2 * DP_CLASSES) * sizeof(unsigned long long), stream));
     KernelTimers::Span prepareSpan;
     if(timers) prepareSpan = timers->begin("DP task sizes, sort by (class, length), bundles", stream);
     hipLaunchKernelGGL(dpSizeKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
@@ -292,9 +292,9 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     b.trace.reserve(sums[1] + 64, stream);
     if(reserveOrdinals) b.ordScratch.reserve(2 * ordTotal + 2, stream);
 
-    // Wide bands (classes 3-5: few tasks, one wavefront each) go to the side stream, widest first;
+    // Wide bands (classes 5-7: few tasks, one wavefront each) go to the side stream, widest first;
     // the narrow classes run on the main stream meanwhile.
-    const bool fork = ws.wide != nullptr && ev != nullptr && (classCounts[3] || classCounts[4] || classCounts[5]);
+    const bool fork = ws.wide != nullptr && ev != nullptr && (classCounts[5] || classCounts[6] || classCounts[7]);
     hipStream_t wideStream = fork ? ws.wide : stream;
     if(fork) { HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); }
     // Booked per class: algorithmic bytes 4 (nx + ny) per task, work = DP cells nx x bandWidth (dpSizeKernel's sums).
@@ -302,14 +302,16 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         if(!timers || classCounts[cls] == 0) { launch(st); return; }
         const KernelTimers::Span span = timers->begin(DP_FORWARD_NAMES[cls], st);
         launch(st);
-        (void)timers->end(span, sums[8 + cls], sums[2 + cls]);
+        (void)timers->end(span, sums[2 + DP_CLASSES + cls], sums[2 + cls]);
     };
-    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 5); });
-    timed(4, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 4); });
-    timed(3, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 3); });
+    timed(7, wideStream, [&](hipStream_t st) { launchDpForward<64, 16>(in, st, b, sortedIds, layout, 7); });
+    timed(6, wideStream, [&](hipStream_t st) { launchDpForward<64, 8>(in, st, b, sortedIds, layout, 6); });
+    timed(5, wideStream, [&](hipStream_t st) { launchDpForward<64, 4>(in, st, b, sortedIds, layout, 5); });
     if(fork) HIP_CHECK(hipEventRecord(ev->join, ws.wide));
-    timed(1, stream, [&](hipStream_t st) { launchDpForward<16, 4>(in, st, b, sortedIds, layout, 1); });
-    timed(2, stream, [&](hipStream_t st) { launchDpForward<32, 4>(in, st, b, sortedIds, layout, 2); });
+    timed(2, stream, [&](hipStream_t st) { launchDpForward<16, 4>(in, st, b, sortedIds, layout, 2); });
+    timed(1, stream, [&](hipStream_t st) { launchDpForward<12, 4>(in, st, b, sortedIds, layout, 1); });
+    timed(3, stream, [&](hipStream_t st) { launchDpForward<20, 4>(in, st, b, sortedIds, layout, 3); });
+    timed(4, stream, [&](hipStream_t st) { launchDpForward<32, 4>(in, st, b, sortedIds, layout, 4); });
     timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     return f;
@@ -358,7 +360,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
         hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(taskCount) * WAVE, 256)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
     HIP_CHECK(hipGetLastError());
-    if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[8 + c]; stats->tasks[c] = f.classCounts[c]; }
+    if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[2 + DP_CLASSES + c]; stats->tasks[c] = f.classCounts[c]; }
     return f.sums[0];
 }
 
@@ -444,8 +446,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         dpOpt.minAlignedMarkerCount = 0; dpOpt.minAlignedFraction = 0.;
         dpOpt.maxSkip = dpOpt.maxDrift = dpOpt.maxTrim = ~0ULL;
     }
-    // Candidates per batch (SHASTA_MI355X_ALIGN_BATCH_LOG2 overrides it for timing experiments, 10 .. 20).
-    static const uint64_t BATCH = [] {
+    // Candidates per batch (SHASTA_MI355X_ALIGN_BATCH_LOG2, or SHASTA_MI355X_ALIGN_BATCH for a size that is not a power of
+    // two, override it for timing experiments: 2^10 .. 2^20).
+    static const uint64_t BATCH = []() -> uint64_t {
+        if(const char* a = std::getenv("SHASTA_MI355X_ALIGN_BATCH")) return uint64_t(std::min(std::max(std::atol(a), 1024L), 1L << 20));
         const char* e = std::getenv("SHASTA_MI355X_ALIGN_BATCH_LOG2");
         const int l = e ? std::atoi(e) : 18;
         return 1ULL << std::min(std::max(l, 10), 20);
@@ -547,6 +551,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
 
+        // SHASTA_MI355X_DEBUG: where a batch spends its time on the host's clock (the kernels of other workers run meanwhile).
+        static const bool debugPhases = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
+        const auto phaseClock = [] { return std::chrono::steady_clock::now(); };
+        const auto phaseStart = phaseClock();
+        auto phaseMs = [&](std::chrono::steady_clock::time_point from) { return std::chrono::duration<double, std::milli>(phaseClock() - from).count(); };
+        double phaseCells = 0., phaseDp = 0., phaseFinish = 0.;
         uint32_t taskCount = 0;
         for(;;) {
         if(m3) {
@@ -841,6 +851,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipMemsetAsync(b.pairFlags.data(), 0, n, stream));
         }
 
+        phaseCells = phaseMs(phaseStart);
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount) {
             out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats);
@@ -854,6 +865,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
         }
 
+        if(debugPhases) { HIP_CHECK(hipStreamSynchronize(stream)); phaseDp = phaseMs(phaseStart) - phaseCells; }
         // K11.
         const unsigned gp = divUp(uint64_t(n) + 1, 256);
         const KernelTimers::Span finalizeSpan = ctx.timers.begin("finalizeKernel + scans", stream);
@@ -930,6 +942,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         // Both compress kernels read the 8-byte ordinal pairs of the stored alignments; the second writes the blobs and the 64-byte rows.
         ctx.timers.amend(sizeHandle, out.alignedBytes, n);
         ctx.timers.amend(writeHandle, out.alignedBytes + byteTotal + 64ULL * storedCount, storedCount);
+        if(debugPhases) {
+            phaseFinish = phaseMs(phaseStart) - phaseCells - phaseDp;
+            std::fprintf(stderr, "batch %llu (%u candidates, %u tasks): candidates -> DP tasks %.1f ms, DP %.1f ms, filters + compression + copies %.1f ms\n",
+                (unsigned long long)batchIndex, n, taskCount, phaseCells, phaseDp, phaseFinish);
+        }
     };
 
     std::atomic<uint64_t> nextBatch(0);

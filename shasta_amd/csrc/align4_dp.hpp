@@ -28,15 +28,25 @@
 // Trace codes: 0 diagonal+equal kmers, 1 diagonal+different, 2 vertical, 3 horizontal.  Tie
 // policy: diagonal >= vertical >= horizontal.
 // ---------------------------------------------------------------------------
-constexpr int DP_CLASSES = 6;
-__host__ __device__ inline int dpClassOfWidth(int32_t w) { return w <= 32 ? 0 : (w <= 64 ? 1 : (w <= 128 ? 2 : (w <= 256 ? 3 : (w <= 512 ? 4 : 5)))); }
-// Lanes per task G and adjacent diagonals per lane C of the six band classes (G C = 32, 64, 128, 256, 512, 1024 diagonals).
+// Band classes.  A task of class c occupies G lanes of a wavefront, a lane owns C adjacent diagonals: G C = 32, 48, 64, 80,
+// 128, 256, 512, 1024 diagonals.  Band widths are multiples of deltaY (10 by default): at 100 k reads the DP cells fall on
+// widths 30 (8 %), 40 (19 %), 50 (23 %), 60 (19 %), 70 (13 %), 80 (8 %), 90-120 (9 %) (profiles/r02_call21_band_widths.log);
+// with power-of-two classes only, 28 % of the lanes computed nothing (40 of 64, 70 of 128 ...), hence the classes of 12 and 20
+// lanes (five and three tasks per wavefront, 60 of its 64 lanes).
 // Four diagonals per lane wherever the band allows it: a lane's cells of one anti-diagonal are independent of each other, and
-// the neighbour exchange (a DPP move per anti-diagonal, plus a select at the group edge when G = 32) is shared by twice the
-// cells -- (16, 4) instead of (32, 2) for the class most tasks fall into: 9.2 instead of 11.4 VALU instructions per cell.
-__host__ __device__ inline int dpLanes(int cls) { return cls <= 1 ? 16 : (cls == 2 ? 32 : 64); }            // G = 16,16,32,64,64,64
-__host__ __device__ inline int dpDiagonalsLog2(int cls) { return cls == 0 ? 1 : (cls <= 3 ? 2 : cls - 1); }
-__host__ __device__ inline int dpDiagonals(int cls) { return 1 << dpDiagonalsLog2(cls); }                   // C = 2,4,4,4,8,16
+// the neighbour exchange (a DPP move per anti-diagonal, plus a select at the group edges unless the group is a DPP row or
+// the whole wavefront) is shared by twice the cells -- 9.3 instead of 11.4 VALU instructions per cell.
+constexpr int DP_CLASSES = 8;
+__host__ __device__ inline int dpClassOfWidth(int32_t w)
+{
+    return w <= 32 ? 0 : (w <= 48 ? 1 : (w <= 64 ? 2 : (w <= 80 ? 3 : (w <= 128 ? 4 : (w <= 256 ? 5 : (w <= 512 ? 6 : 7))))));
+}
+__host__ __device__ inline int dpLanes(int cls)                                                              // G = 16,12,16,20,32,64,64,64
+{
+    return cls == 0 ? 16 : (cls == 1 ? 12 : (cls == 2 ? 16 : (cls == 3 ? 20 : (cls == 4 ? 32 : 64))));
+}
+__host__ __device__ inline int dpDiagonalsLog2(int cls) { return cls == 0 ? 1 : (cls <= 5 ? 2 : cls - 3); }   // C = 2,4,4,4,4,4,8,16
+__host__ __device__ inline int dpDiagonals(int cls) { return 1 << dpDiagonalsLog2(cls); }
 
 struct DpGeometry { int32_t s0; uint32_t iters; int cls; };
 __host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMax, uint32_t nx, uint32_t ny)
@@ -56,7 +66,7 @@ struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneB
 __global__ void __launch_bounds__(256)
 dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
-    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [8+c] bytes of class c
+    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long cells = 0, words = 0, bytes = 0;
@@ -86,7 +96,7 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
         if(laneId() == 0) {
             atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
             atomicAdd(&sums[2 + c], classCells);
-            atomicAdd(&sums[8 + c], classBytes);
+            atomicAdd(&sums[2 + DP_CLASSES + c], classBytes);
         }
     }
     for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
@@ -145,14 +155,14 @@ template<int G> __device__ __forceinline__ int32_t fromLaneBelow(int32_t v, int 
 {
     constexpr int ctrl = (G == 16) ? 0x111 : 0x138;             // row_shr:1 : wave_shr:1; bound_ctrl = zero fill
     int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
-    if constexpr (G == 32) r = (l == 0) ? 0 : r;
+    if constexpr (G != 16 && G != 64) r = (l == 0) ? 0 : r;     // a group that is neither a DPP row nor the wavefront: its own edge
     return r;
 }
 template<int G> __device__ __forceinline__ int32_t fromLaneAbove(int32_t v, int l)
 {
     constexpr int ctrl = (G == 16) ? 0x101 : 0x130;             // row_shl:1 : wave_shl:1
     int32_t r = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
-    if constexpr (G == 32) r = (l == G - 1) ? 0 : r;
+    if constexpr (G != 16 && G != 64) r = (l == G - 1) ? 0 : r;
     return r;
 }
 struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // four consecutive kmer ids, 4-byte aligned
@@ -175,7 +185,7 @@ bandedDpForwardKernel(
     const uint32_t bundle = bundleCount - 1 - slot;       // the list is sorted by ascending length: the longest bundles start first
     const int g = lane / G, l = lane % G;
     const uint32_t pos = bundle * T + uint32_t(g);
-    const bool hasTask = pos < taskCount;
+    const bool hasTask = g < T && pos < taskCount;        // (64 - T G lanes of a wavefront are idle when G does not divide 64)
     const uint32_t t = sortedIds[hasTask ? pos : bundle * T];
     const DpTask task = tasks[t];
     const PairDesc pd = pairs[task.pair];
@@ -185,8 +195,9 @@ bandedDpForwardKernel(
     const int32_t bandMin = task.bandMin, width = task.bandMax - task.bandMin + 1;
     const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
     uint32_t itersLane = geo.iters;
+    itersLane = hasTask ? itersLane : 0u;
 #pragma unroll
-    for(int d = G; d < WAVE; d <<= 1) itersLane = max(itersLane, uint32_t(__shfl_xor(int(itersLane), d, WAVE)));
+    for(int d = 1; d < WAVE; d <<= 1) itersLane = max(itersLane, uint32_t(__shfl_xor(int(itersLane), d, WAVE)));
     const uint32_t iters = __builtin_amdgcn_readfirstlane(itersLane);
     uint64_t* __restrict__ tr = uniformPointer(trace + bundleOffsets[bundle]);
 
@@ -374,12 +385,25 @@ bandedDpForwardKernel(
         const int32_t v = exists[c] ? H[c] - BIAS + GAP_SCORE * (i + j) : NEG_SCORE;
         if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
     }
+    if constexpr ((G & (G - 1)) == 0) {
 #pragma unroll
-    for(int d = G / 2; d >= 1; d >>= 1) {
-        const int32_t os = __shfl_xor(bestScore, d, G);
-        const int32_t oi = __shfl_xor(bestI, d, G);
-        const int32_t oj = __shfl_xor(bestJ, d, G);
-        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+        for(int d = G / 2; d >= 1; d >>= 1) {
+            const int32_t os = __shfl_xor(bestScore, d, G);
+            const int32_t oi = __shfl_xor(bestI, d, G);
+            const int32_t oj = __shfl_xor(bestJ, d, G);
+            if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+        }
+    } else {
+        // A group of 12 or 20 lanes: every lane looks at the other lanes of its group in turn (the order is total, so every
+        // lane ends with the same cell).
+        const int32_t ownScore = bestScore, ownI = bestI, ownJ = bestJ;
+        for(int k = 1; k < G; k++) {
+            const int source = (g * G + (l + k) % G) & (WAVE - 1);
+            const int32_t os = __shfl(ownScore, source, WAVE);
+            const int32_t oi = __shfl(ownI, source, WAVE);
+            const int32_t oj = __shfl(ownJ, source, WAVE);
+            if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+        }
     }
     if(hasTask && l == 0) {
         DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);

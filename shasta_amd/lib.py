@@ -197,7 +197,7 @@ class Library:
 
     def banded_dp_many(self, kmer_ids, begin0, nx, begin1, ny, band_min, band_max, timing=False):
         """K10 on many tasks bundled as in an Align4 batch -> list of (ordinals [n, 2], score) per task.
-        timing=True: no ordinals are copied back; returns (counts, scores, seconds[7], cells[6]) instead."""
+        timing=True: no ordinals are copied back; returns (counts, scores, seconds[9], cells[8]) instead (eight band classes + the traceback)."""
         k = np.ascontiguousarray(kmer_ids, dtype=np.uint32)
         b0 = np.ascontiguousarray(begin0, np.uint64); b1 = np.ascontiguousarray(begin1, np.uint64)
         n0 = np.ascontiguousarray(nx, np.uint32); n1 = np.ascontiguousarray(ny, np.uint32)
@@ -205,7 +205,7 @@ class Library:
         t = len(b0)
         cap = int(np.minimum(n0, n1).astype(np.uint64).sum()) + 1
         counts = np.zeros(t, np.uint64); scores = np.zeros(t, np.int32)
-        seconds = np.zeros(7, np.float64); cells = np.zeros(6, np.uint64)
+        seconds = np.zeros(9, np.float64); cells = np.zeros(8, np.uint64)
         if timing:
             self._check(self.lib.shasta_mi355x_banded_dp_many(
                 abi.as_ptr(k, C.c_uint32), C.c_uint64(len(k)), C.c_uint64(t),

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WIDTHS = (1, 2, 3, 16, 20, 31, 32, 33, 64, 65, 100, 128, 129, 256, 300, 512, 513, 1000)
+WIDTHS = (1, 2, 3, 16, 20, 31, 32, 33, 40, 48, 49, 64, 65, 70, 80, 81, 100, 128, 129, 256, 300, 512, 513, 1000)
 
 
 def noisy(rng, x, alphabet):
@@ -55,7 +55,7 @@ def many(lib, orc, seed, tasks=140):
     pieces, spec = [], []
     at = 0
     for t in range(tasks):
-        width = int(rng.choice([1, 5, 20, 32, 33, 50, 64, 65, 100, 128, 200, 256, 300, 512, 600, 1000], p=[.04, .06, .2, .06, .06, .15, .06, .06, .1, .04, .05, .03, .03, .02, .02, .02]))
+        width = int(rng.choice([1, 5, 20, 32, 33, 40, 48, 49, 50, 64, 65, 70, 80, 81, 100, 128, 200, 256, 300, 512, 600, 1000], p=[.04, .04, .1, .04, .04, .1, .04, .04, .1, .04, .04, .08, .04, .04, .06, .03, .04, .02, .02, .02, .02, .01]))
         alphabet = (1 << 20) if t % 2 == 0 else 9
         n = int(rng.integers(3, 700)) if t % 5 else int(rng.integers(700, 1500))
         m = max(1, n + int(rng.integers(-(n // 2), n // 2 + 1)))
