@@ -83,17 +83,25 @@ downsampleKernel(const uint32_t* __restrict__ kmerIds, const uint64_t* __restric
 // in bandedDpForwardKernel.  Sized for the few long pairs of a batch, not tuned further.
 struct WideTask { uint32_t pair, chunks; uint64_t traceOffset; };
 struct WideEnd { int32_t bestI, bestJ, score, pad; };
-constexpr uint32_t ALIGN3_WIDE_MAX_DIAGONALS = 8192;      // 3 rows of 32 KB
+constexpr uint32_t ALIGN3_WIDE_MAX_DIAGONALS = 8192;      // 3 rows of 32 KB in LDS
+// Beyond that (down-sampled reads of more than 4096 markers each: reads of several hundred kilobases) the three rows live
+// in HBM scratch and a workgroup of four wavefronts shares the chunks of an anti-diagonal (HUGE): the reference has no limit
+// here (src/AssemblerAlign3.cpp:22-314), this path's limit is the size of the trace, 2 W ceil(W / 64) words per pair.
+constexpr uint32_t ALIGN3_HUGE_MAX_DIAGONALS = 65536;
 
-__global__ void __launch_bounds__(64)
+template<bool HUGE>
+__global__ void __launch_bounds__(HUGE ? 256 : 64)
 align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ dsPairs,
     const WideTask* __restrict__ tasks, uint32_t taskCount, uint32_t rowWords,
-    uint64_t* __restrict__ trace, WideEnd* __restrict__ ends)
+    uint64_t* __restrict__ trace, WideEnd* __restrict__ ends, int32_t* __restrict__ hugeRows)
 {
-    extern __shared__ int32_t wideRows[];                  // 3 x rowWords
+    extern __shared__ int32_t wideRows[];                  // 3 x rowWords (not HUGE)
+    __shared__ int32_t sBest[3 * 4];
     const uint32_t t = blockIdx.x;
     if(t >= taskCount) return;
     const int lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    int32_t* const rows = HUGE ? hugeRows + size_t(t) * 3u * rowWords : wideRows;
     const WideTask task = tasks[t];
     const PairDesc pd = dsPairs[task.pair];
     const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
@@ -102,14 +110,14 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
     const int32_t W = nx + ny + 1;
     const uint32_t Q = task.chunks;
     uint64_t* __restrict__ tr = trace + task.traceOffset;
-    for(uint32_t k = uint32_t(lane); k < 3u * rowWords; k += WAVE) wideRows[k] = NEG_SCORE;
+    for(uint32_t k = threadIdx.x; k < 3u * rowWords; k += blockDim.x) rows[k] = NEG_SCORE;
     __syncthreads();
     int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
     for(int32_t s = 0; s <= nx + ny; s++) {
-        int32_t* const cur = wideRows + uint32_t(s % 3) * rowWords;
-        const int32_t* const prev1 = wideRows + uint32_t((s + 2) % 3) * rowWords;     // s - 1
-        const int32_t* const prev2 = wideRows + uint32_t((s + 1) % 3) * rowWords;     // s - 2
-        for(uint32_t q = 0; q < Q; q++) {
+        int32_t* const cur = rows + uint32_t(s % 3) * rowWords;
+        const int32_t* const prev1 = rows + uint32_t((s + 2) % 3) * rowWords;     // s - 1
+        const int32_t* const prev2 = rows + uint32_t((s + 1) % 3) * rowWords;     // s - 2
+        for(uint32_t q = wave; q < Q; q += waves) {
             const int32_t b = int32_t(q * 64u) + lane, d = b - ny;
             // Cell (i, j) of this anti-diagonal on diagonal d, if it exists.
             const int32_t i2 = s + d, j2 = s - d;
@@ -148,7 +156,16 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const int32_t oj = __shfl_xor(bestJ, dlt, WAVE);
         if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
     }
-    if(lane == 0) { WideEnd e; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.pad = 0; ends[t] = e; }
+    if(HUGE) {
+        // The wavefronts' best cells meet in LDS.
+        if(lane == 0) { sBest[3 * wave] = bestScore; sBest[3 * wave + 1] = bestI; sBest[3 * wave + 2] = bestJ; }
+        __syncthreads();
+        for(uint32_t w = 0; w < waves; w++) {
+            const int32_t os = sBest[3 * w], oi = sBest[3 * w + 1], oj = sBest[3 * w + 2];
+            if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+        }
+    }
+    if(threadIdx.x == 0) { WideEnd e; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.pad = 0; ends[t] = e; }
 }
 
 // Traceback of step 1, one lane per task (= per candidate that has a step-1 DP).  The trace is the

@@ -128,6 +128,7 @@ struct BatchScratch {
     DeviceBuffer<PairDesc> dsPairs;             // align method 3, step 1: the down-sampled pairs
     DeviceBuffer<DpTask> tasks1;                //                         and their (unbanded) DP tasks
     DeviceBuffer<WideTask> wideTasks;           //                         pairs with more than 1024 diagonals
+    DeviceBuffer<int32_t> hugeRows;             //                         the three anti-diagonals of the pairs with more than 8192 diagonals
     DeviceBuffer<WideEnd> wideEnds;
 };
 
@@ -563,7 +564,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             // Method 3, step 1: every diagonal of the down-sampled pair, then the band of step 2.
             std::vector<PairDesc> dsPairs(n);
             std::vector<DpTask> tasks1;
-            std::vector<WideTask> wide;
+            std::vector<WideTask> wide, huge;
             std::vector<uint8_t> hostFlags(n, 0);
             tasks1.reserve(n);
             for(uint32_t k = 0; k < n; k++) {
@@ -578,9 +579,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 if(diagonals <= ALIGN3_MAX_STEP1_DIAGONALS) {
                     DpTask t; t.pair = k; t.bandMin = -int32_t(pd.ny); t.bandMax = int32_t(pd.nx); t.label = 0;
                     tasks1.push_back(t);
-                } else if(diagonals <= ALIGN3_WIDE_MAX_DIAGONALS) {
+                } else if(diagonals <= ALIGN3_HUGE_MAX_DIAGONALS) {
                     WideTask t; t.pair = k; t.chunks = uint32_t((diagonals + 63) / 64); t.traceOffset = 0;
-                    wide.push_back(t);
+                    (diagonals <= ALIGN3_WIDE_MAX_DIAGONALS ? wide : huge).push_back(t);
                 } else {
                     hostFlags[k] = PAIR_TOO_LONG;
                 }
@@ -603,6 +604,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             }
             // The long pairs, a few gigabytes of trace at a time.
             const uint64_t traceWordBudget = 1ULL << 29;
+            auto runWide = [&](std::vector<WideTask>& wide, bool hugeRows) {
             for(size_t begin = 0; begin < wide.size(); ) {
                 size_t end = begin;
                 uint64_t words = 0;
@@ -622,12 +624,18 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), wide.data() + begin, count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
                 const size_t ldsBytes = 3 * size_t(rowWords) * sizeof(int32_t);
                 std::call_once(ctx.wideDpLdsAttribute, [] {
-                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel),
+                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
                 });
-                hipLaunchKernelGGL(align3WideDpKernel, dim3(count), dim3(64), ldsBytes, stream,
+                if(hugeRows) {
+                    b.hugeRows.reserve(size_t(count) * 3u * rowWords, stream);
+                    hipLaunchKernelGGL(align3WideDpKernel<true>, dim3(count), dim3(256), 0, stream,
+                        (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
+                        b.trace.data(), b.wideEnds.data(), b.hugeRows.data());
+                } else
+                hipLaunchKernelGGL(align3WideDpKernel<false>, dim3(count), dim3(64), ldsBytes, stream,
                     (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
-                    b.trace.data(), b.wideEnds.data());
+                    b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr);
                 HIP_CHECK(hipGetLastError());
                 hipLaunchKernelGGL(align3BandKernel<true>, dim3(divUp(count, 256)), dim3(256), 0, stream,
                     (const PairDesc*)b.dsPairs.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)nullptr, (const uint32_t*)nullptr, count,
@@ -638,6 +646,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 HIP_CHECK(hipStreamSynchronize(stream));
                 begin = end;
             }
+            };
+            runWide(wide, false);
+            runWide(huge, true);
             HIP_CHECK(hipStreamSynchronize(stream));      // the host vectors above are done with
         } else
         // K8/K9.  Chunks of candidates sharing read 0 run in LDS (three table-size classes);

@@ -60,7 +60,7 @@ __host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMa
 }
 
 // What the forward kernel leaves for the traceback of a task.
-struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase; };
+struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase, bundleIterations, pad; };   // bundleIterations: of the longest task of the bundle
 
 // Per task: sort key (class, iterations), ordinal capacity, statistics.
 __global__ void __launch_bounds__(256)
@@ -406,7 +406,7 @@ bandedDpForwardKernel(
         }
     }
     if(hasTask && l == 0) {
-        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G);
+        DpEnd e; e.traceOffset = bundleOffsets[bundle]; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.laneBase = uint32_t(g * G); e.bundleIterations = iters; e.pad = 0;
         ends[t] = e;
     }
 }
@@ -476,10 +476,15 @@ dpTracebackKernel(
     // the same point of the program, then walks until its path leaves the chunk.  The wave waits
     // for memory once per epoch, for loads issued a whole epoch earlier.
     bool active = e.score > NEG_SCORE && i > 0 && j > 0;
-    int32_t chunk = active ? int32_t((uint32_t(i + j - geo.s0) >> 1) >> ipcLog2) : -1;
+    // The tasks of a bundle share their trace records, and they sit in adjacent lanes here: every one of them counts its
+    // chunks down from the BUNDLE's last chunk, so that the lanes of a bundle ask for the same 256 bytes in the same
+    // instruction (one request) -- each starting at its own last chunk, an epoch or two apart, made the 4 tasks of a bundle
+    // fetch the trace 2.3 times over (PMC: 19.6 GB per launch for 8.4 GB of trace).  A lane whose path starts lower waits.
+    const int32_t ownChunk = active ? int32_t((uint32_t(i + j - geo.s0) >> 1) >> ipcLog2) : -1;
+    int32_t chunk = active ? int32_t((e.bundleIterations - 1u) >> ipcLog2) : -1;
     uint4 next[QUADS];
 #pragma unroll
-    for(int q = 0; q < QUADS; q++) next[q] = active ? tr[int64_t(chunk) * QUADS + q] : make_uint4(0, 0, 0, 0);
+    for(int q = 0; q < QUADS; q++) next[q] = (active && chunk == ownChunk) ? tr[int64_t(chunk) * QUADS + q] : make_uint4(0, 0, 0, 0);
     uint32_t foundCount = 0;
     auto storeFound = [&]() {
         for(uint32_t q = 0; q < foundCount; q++) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = found[q * 256 + threadIdx.x]; }
@@ -489,15 +494,15 @@ dpTracebackKernel(
         // The pairs of the previous chunk leave here, where the wave waits for the prefetched chunk anyway (stores and
         // loads retire through one in-order counter: stores issued after the prefetch would wait for it).
         storeFound();
-        if(active) {
+        if(active && chunk <= ownChunk) {
 #pragma unroll
             for(int q = 0; q < QUADS; q++) window[q * 256 + threadIdx.x] = next[q];
-            if(chunk > 0) {
-#pragma unroll
-                for(int q = 0; q < QUADS; q++) next[q] = tr[int64_t(chunk - 1) * QUADS + q];
-            }
         }
-        while(active) {
+        if(active && chunk - 1 <= ownChunk && chunk > 0) {
+#pragma unroll
+            for(int q = 0; q < QUADS; q++) next[q] = tr[int64_t(chunk - 1) * QUADS + q];
+        }
+        while(active && chunk <= ownChunk) {
             const uint32_t b = uint32_t(i - j - task.bandMin);
             const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
             if(int32_t(it >> ipcLog2) != chunk) break;

@@ -94,6 +94,10 @@ def test_align3_context_paths(emu_lib, oracle_lib):
     align3_checks.context_paths(emu_lib, oracle_lib)
 
 
+def test_align3_long_reads(emu_lib, oracle_lib):
+    align3_checks.long_reads(emu_lib, oracle_lib)
+
+
 def test_align3_rejected_options(emu_lib):
     align3_checks.rejected_options(emu_lib)
 

@@ -27,6 +27,10 @@ def test_align3_on_a_context(gpu_lib, oracle_lib):
     align3_checks.context_paths(gpu_lib, oracle_lib)
 
 
+def test_align3_pairs_with_more_than_1024_and_more_than_8192_downsampled_diagonals(gpu_lib, oracle_lib):
+    align3_checks.long_reads(gpu_lib, oracle_lib)
+
+
 def test_align3_unsupported_options_fail_loudly(gpu_lib):
     align3_checks.rejected_options(gpu_lib)
 
