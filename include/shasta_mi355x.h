@@ -418,6 +418,22 @@ int shasta_mi355x_banded_dp_many(
     double* seconds, uint64_t* cells);
 
 /* -------------------------------------------------------------------------
+ * The tables either side of the aligner, device = HIP device index.
+ * shasta_mi355x_pair_table: per oriented read, the indices of the pairs it takes part in, sorted by (other
+ * oriented read, index) -- Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571; pairs = the
+ * AlignmentData rows, strideBytes = 64) and AlignmentCandidates::computeCandidateTable
+ * (src/AssemblerAlignmentCandidates.cpp:388-447; pairs = the candidates, strideBytes = 12).  Every pair appears
+ * under its two oriented reads and under their reverse complements.  toc: 2 readCount + 1 offsets; values:
+ * 4 pairCount indices.
+ * shasta_mi355x_read_graph_keep: createReadGraph's selection (src/AssemblerReadGraph.cpp:55-95): keep[i] = 1 if
+ * alignment i is among the maxAlignmentCount alignments with the largest (markerCount, index) of either of
+ * its reads, else 0. */
+int shasta_mi355x_pair_table(int device, const void* pairs, uint64_t strideBytes, uint64_t pairCount, uint64_t readCount,
+    uint64_t* toc, uint32_t* values);
+int shasta_mi355x_read_graph_keep(int device, const shasta_alignment_data* alignmentData, uint64_t alignmentCount, uint64_t readCount,
+    uint32_t maxAlignmentCount, uint8_t* keep);
+
+/* -------------------------------------------------------------------------
  * Palindromic-read flagging: the device half of
  * Assembler::flagPalindromicReads (src/AssemblerAlign.cpp:652-770, parameters
  * src/AssemblerOptions.cpp:255-288).  For every read of the context's markers:

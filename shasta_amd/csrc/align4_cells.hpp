@@ -9,9 +9,12 @@
 // ---------------------------------------------------------------------------
 // K8/K9: cells.
 // ---------------------------------------------------------------------------
-constexpr int CELLS_THREADS = 256;
-constexpr int MATCH_CHUNK = 2048;          // markers of read 1 hashed per round
-constexpr int MATCH_SLOTS = 4096;
+// A few hundred long candidates per batch, a workgroup each: as many threads and as much of a CU's LDS as a workgroup can have
+// (16 wavefronts, 128 KB), so that a pair of 10 k-marker reads is two passes of ten rounds instead of five passes of forty.
+constexpr int CELLS_THREADS = 1024;
+constexpr int MATCH_CHUNK = 8192;          // markers of read 1 hashed per round
+constexpr int MATCH_SLOTS_LOG2 = 14;
+constexpr int MATCH_SLOTS = 1 << MATCH_SLOTS_LOG2;
 constexpr int CELL_SLOTS = 2048;
 constexpr int MAX_CELLS = 1024;
 constexpr uint32_t EMPTY32 = 0xffffffffu;
@@ -98,7 +101,7 @@ align4CellsKernel(
         for(uint32_t y = chunk + tid; y < chunkEnd; y += CELLS_THREADS) {
             const uint32_t k = p1[y];
             const unsigned long long entry = (uint64_t(k) << 32) | y;
-            uint32_t slot = hash32(k) >> (32 - 12);
+            uint32_t slot = hash32(k) >> (32 - MATCH_SLOTS_LOG2);
             for(;;) {
                 const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&matchTab[slot]), EMPTY64, entry);
                 if(old == EMPTY64) break;
@@ -108,7 +111,7 @@ align4CellsKernel(
         __syncthreads();
         for(uint32_t x = tid; x < nx; x += CELLS_THREADS) {
             const uint32_t k = p0[x];
-            uint32_t slot = hash32(k) >> (32 - 12);
+            uint32_t slot = hash32(k) >> (32 - MATCH_SLOTS_LOG2);
             for(;;) {
                 const uint64_t e = matchTab[slot];
                 if(e == EMPTY64) break;

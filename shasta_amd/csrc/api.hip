@@ -346,6 +346,25 @@ int shasta_mi355x_palindromic_screen(shasta_mi355x_ctx* c, uint64_t deltaThresho
     API_END(1)
 }
 
+int shasta_mi355x_pair_table(int device, const void* pairs, uint64_t strideBytes, uint64_t pairCount, uint64_t readCount, uint64_t* toc, uint32_t* values)
+{
+    API_BEGIN
+    if((pairCount && !pairs) || !toc || (pairCount && !values)) throw std::runtime_error("pair_table: null argument");
+    pairTable(device, pairs, strideBytes, pairCount, readCount, toc, values);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_read_graph_keep(int device, const shasta_alignment_data* alignmentData, uint64_t alignmentCount, uint64_t readCount,
+    uint32_t maxAlignmentCount, uint8_t* keep)
+{
+    API_BEGIN
+    if(alignmentCount && (!alignmentData || !keep)) throw std::runtime_error("read_graph_keep: null argument");
+    readGraphKeep(device, alignmentData, alignmentCount, readCount, maxAlignmentCount, keep);
+    return 0;
+    API_END(1)
+}
+
 shasta_mi355x_group* shasta_mi355x_group_create(int deviceCount, const int* devices)
 {
     API_BEGIN

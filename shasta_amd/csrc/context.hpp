@@ -89,6 +89,9 @@ void findMarkers(Context&, uint64_t readCount, const uint64_t* readsToc, const u
 void findMarkersFree(shasta_markers_result&);
 // palindromic.hip: per read, an upper bound on the near-diagonal marker count of its self-alignment.
 void palindromicScreen(Context&, uint64_t deltaThreshold, uint32_t* bound);
+// tables.hip: the candidate / alignment table and the read graph's selection.
+void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, uint64_t readCount, uint64_t* toc, uint32_t* values);
+void readGraphKeep(int device, const shasta_alignment_data* alignmentData, uint64_t count, uint64_t readCount, uint32_t maxAlignmentCount, uint8_t* keep);
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);
 void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,

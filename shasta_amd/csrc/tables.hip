@@ -1,0 +1,198 @@
+// SURVEY 8(f) row 3, the serial tails either side of the aligner, on the device:
+//   pairTable      the table "oriented read -> indices of the pairs it takes part in, sorted by (other oriented read,
+//                  index)" that Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571) builds from AlignmentData
+//                  and AlignmentCandidates::computeCandidateTable (src/AssemblerAlignmentCandidates.cpp:388-447) from the
+//                  candidate list: two counting passes and a std::sort per oriented read there, ONE stable radix sort of
+//                  the 4 N (oriented read, other oriented read) keys here;
+//   readGraphKeep  createReadGraph's selection (src/AssemblerReadGraph.cpp:55-95): alignment i stays if it is among the
+//                  maxAlignmentCount best of either of its reads, best = largest (markerCount, alignment id): an
+//                  nth_element per read there, two stable radix sorts (by (markerCount, id) descending, then by read) and a
+//                  rank here.
+// Both are HBM-bound sorts of a few million 12-byte records: nothing to tune beyond primitives.hpp's radix sort.
+#include "context.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+#include <vector>
+
+namespace shasta_mi355x {
+namespace {
+
+// The pair at byte offset i * stride of `pairs` (12-byte candidates, or the head of 64-byte AlignmentData rows).
+__device__ __forceinline__ shasta_oriented_read_pair pairAt(const uint8_t* __restrict__ pairs, uint64_t stride, uint64_t i)
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(pairs + i * stride);
+    shasta_oriented_read_pair r;
+    r.readIds[0] = p[0]; r.readIds[1] = p[1];
+    r.isSameStrand = reinterpret_cast<const uint8_t*>(p + 2)[0];
+    return r;
+}
+
+// The four (oriented read, partner) entries of pair i (OrientedReadPair::getOther, src/OrientedReadPair.hpp:63-85:
+// the partner is reverse complemented where the read is).
+__global__ void __launch_bounds__(256)
+pairTableKeysKernel(const uint8_t* __restrict__ pairs, uint64_t stride, uint64_t count, uint64_t orientedReadCount, int otherBits,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t* __restrict__ bad)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= count) return;
+    const shasta_oriented_read_pair pair = pairAt(pairs, stride, i);
+    const uint64_t o0 = uint64_t(pair.readIds[0]) << 1, o1 = (uint64_t(pair.readIds[1]) << 1) | (pair.isSameStrand ? 0u : 1u);
+    if(o0 >= orientedReadCount || o1 >= orientedReadCount) { atomicAdd(bad, 1u); }
+    const uint64_t rows[4] = {o0, o1, o0 ^ 1u, o1 ^ 1u}, others[4] = {o1, o0, o1 ^ 1u, o0 ^ 1u};
+#pragma unroll
+    for(int k = 0; k < 4; k++) { keys[4 * i + k] = (rows[k] << otherBits) | others[k]; values[4 * i + k] = uint32_t(i); }
+}
+
+// toc[r] = number of sorted keys whose oriented read is below r (r = 0 .. orientedReadCount).
+__global__ void __launch_bounds__(256)
+rowStartsKernel(const uint64_t* __restrict__ sortedKeys, uint64_t keyCount, uint64_t rowCount, int shift, uint64_t* __restrict__ toc)
+{
+    const uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(r > rowCount) return;
+    uint64_t lo = 0, hi = keyCount;
+    while(lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if((sortedKeys[mid] >> shift) < r) lo = mid + 1; else hi = mid;
+    }
+    toc[r] = lo;
+}
+
+// Two entries per alignment: (read, quality) with quality = (markerCount, alignment id) complemented, so that ascending
+// order is best first.
+__global__ void __launch_bounds__(256)
+readGraphKeysKernel(const shasta_alignment_data* __restrict__ alignmentData, uint64_t count, uint64_t readCount,
+    uint64_t* __restrict__ quality, uint32_t* __restrict__ reads, uint32_t* __restrict__ ids, uint32_t* __restrict__ bad)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= count) return;
+    const shasta_alignment_data a = alignmentData[i];
+    if(a.pair.readIds[0] >= readCount || a.pair.readIds[1] >= readCount) atomicAdd(bad, 1u);
+    const uint64_t q = ~((uint64_t(a.info.markerCount) << 32) | uint64_t(uint32_t(i)));
+#pragma unroll
+    for(int k = 0; k < 2; k++) { quality[2 * i + k] = q; reads[2 * i + k] = a.pair.readIds[k]; ids[2 * i + k] = uint32_t(i); }
+}
+
+__global__ void __launch_bounds__(256)
+fillIotaKernel(uint32_t* __restrict__ out, uint64_t n)
+{
+    const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(k < n) out[k] = uint32_t(k);
+}
+
+__global__ void __launch_bounds__(256)
+gatherReadsKernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ reads, uint64_t n, uint32_t* __restrict__ out)
+{
+    const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(k < n) out[k] = reads[order[k]];
+}
+
+// Entry k of the list sorted by (read, quality): its rank among its read's entries decides.
+__global__ void __launch_bounds__(256)
+readGraphKeepKernel(const uint32_t* __restrict__ sortedReads, const uint32_t* __restrict__ sortedEntries, const uint32_t* __restrict__ ids,
+    uint64_t n, uint32_t maxAlignmentCount, uint8_t* __restrict__ keep)
+{
+    const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(k >= n) return;
+    const uint32_t read = sortedReads[k];
+    // First entry of this read: binary search (the list is sorted by read).
+    uint64_t lo = 0, hi = k;
+    while(lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if(sortedReads[mid] < read) lo = mid + 1; else hi = mid;
+    }
+    if(k - lo < uint64_t(maxAlignmentCount)) keep[ids[sortedEntries[k]]] = 1;
+}
+
+int bitsFor(uint64_t values)            // bits that hold 0 .. values - 1
+{
+    int b = 1;
+    while((1ULL << b) < values && b < 63) ++b;
+    return b;
+}
+
+}  // namespace
+
+// toc: uint64[2 readCount + 1]; values: uint32[4 count].
+void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, uint64_t readCount, uint64_t* toc, uint32_t* values)
+{
+    HIP_CHECK(hipSetDevice(device));
+    if(count >= (1ULL << 30)) throw std::runtime_error("pair_table: too many pairs (the table's indices are 32-bit, as the reference's sort keys are).");
+    if(stride < sizeof(shasta_oriented_read_pair) || stride % 4 != 0) throw std::runtime_error("pair_table: bad stride.");
+    const uint64_t rows = 2 * readCount, n = 4 * count;
+    if(count == 0) { std::fill(toc, toc + rows + 1, uint64_t(0)); return; }
+    const int otherBits = bitsFor(std::max<uint64_t>(rows, 2));
+    if(2 * otherBits > 64) throw std::runtime_error("pair_table: too many reads.");
+    hipStream_t stream;
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DeviceBuffer<uint8_t> devicePairs;
+    DeviceBuffer<uint64_t> keysA, keysB, deviceToc;
+    DeviceBuffer<uint32_t> valuesA, valuesB, bad;
+    RadixSortWorkspace ws;
+    devicePairs.reserve(count * stride, stream); keysA.reserve(n, stream); keysB.reserve(n, stream);
+    valuesA.reserve(n, stream); valuesB.reserve(n, stream); deviceToc.reserve(rows + 1, stream); bad.reserve(1, stream);
+    HIP_CHECK(hipMemcpyAsync(devicePairs.data(), pairs, count * stride, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(pairTableKeysKernel, dim3(divUp(count, 256)), dim3(256), 0, stream,
+        (const uint8_t*)devicePairs.data(), stride, count, rows, otherBits, keysA.data(), valuesA.data(), bad.data());
+    HIP_CHECK(hipGetLastError());
+    // Stable: equal (oriented read, partner) keys keep ascending pair indices, the order std::sort gives the reference's
+    // (OrientedReadId, index) pairs.
+    const bool inB = radixSort<uint64_t, uint32_t, true>(keysA.data(), keysB.data(), valuesA.data(), valuesB.data(), n, 2 * otherBits, ws, stream);
+    const uint64_t* sortedKeys = inB ? keysB.data() : keysA.data();
+    const uint32_t* sortedValues = inB ? valuesB.data() : valuesA.data();
+    hipLaunchKernelGGL(rowStartsKernel, dim3(divUp(rows + 1, 256)), dim3(256), 0, stream, sortedKeys, n, rows, otherBits, deviceToc.data());
+    HIP_CHECK(hipGetLastError());
+    uint32_t hostBad = 0;
+    HIP_CHECK(hipMemcpyAsync(&hostBad, bad.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(toc, deviceToc.data(), (rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(values, sortedValues, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamDestroy(stream));
+    if(hostBad) throw std::runtime_error("pair_table: a pair names a read beyond readCount.");
+}
+
+// keep: uint8[count], 1 where the alignment stays in the read graph.
+void readGraphKeep(int device, const shasta_alignment_data* alignmentData, uint64_t count, uint64_t readCount, uint32_t maxAlignmentCount, uint8_t* keep)
+{
+    HIP_CHECK(hipSetDevice(device));
+    if(count >= (1ULL << 31)) throw std::runtime_error("read_graph_keep: too many alignments.");
+    if(count == 0) return;
+    const uint64_t n = 2 * count;
+    hipStream_t stream;
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DeviceBuffer<shasta_alignment_data> rows;
+    DeviceBuffer<uint64_t> qualityA, qualityB;
+    DeviceBuffer<uint32_t> reads, ids, entryA, entryB, readA, readB, bad;
+    DeviceBuffer<uint8_t> deviceKeep;
+    RadixSortWorkspace ws;
+    rows.reserve(count, stream); qualityA.reserve(n, stream); qualityB.reserve(n, stream); reads.reserve(n, stream); ids.reserve(n, stream);
+    entryA.reserve(n, stream); entryB.reserve(n, stream); readA.reserve(n, stream); readB.reserve(n, stream); bad.reserve(1, stream);
+    deviceKeep.reserve(count, stream);
+    HIP_CHECK(hipMemcpyAsync(rows.data(), alignmentData, count * sizeof(shasta_alignment_data), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(uint32_t), stream));
+    HIP_CHECK(hipMemsetAsync(deviceKeep.data(), 0, count, stream));
+    hipLaunchKernelGGL(readGraphKeysKernel, dim3(divUp(count, 256)), dim3(256), 0, stream,
+        (const shasta_alignment_data*)rows.data(), count, readCount, qualityA.data(), reads.data(), ids.data(), bad.data());
+    hipLaunchKernelGGL(fillIotaKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, entryA.data(), n);
+    HIP_CHECK(hipGetLastError());
+    // By quality (best first), then -- stably -- by read.
+    const bool firstInB = radixSort<uint64_t, uint32_t, true>(qualityA.data(), qualityB.data(), entryA.data(), entryB.data(), n, 64, ws, stream);
+    uint32_t* byQuality = firstInB ? entryB.data() : entryA.data();
+    uint32_t* spare = firstInB ? entryA.data() : entryB.data();
+    hipLaunchKernelGGL(gatherReadsKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, (const uint32_t*)byQuality, (const uint32_t*)reads.data(), n, readA.data());
+    HIP_CHECK(hipGetLastError());
+    const bool secondInB = radixSort<uint32_t, uint32_t, true>(readA.data(), readB.data(), byQuality, spare, n, bitsFor(std::max<uint64_t>(readCount, 2)), ws, stream);
+    const uint32_t* sortedReads = secondInB ? readB.data() : readA.data();
+    const uint32_t* sortedEntries = secondInB ? spare : byQuality;
+    hipLaunchKernelGGL(readGraphKeepKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, sortedReads, sortedEntries, (const uint32_t*)ids.data(), n, maxAlignmentCount, deviceKeep.data());
+    HIP_CHECK(hipGetLastError());
+    uint32_t hostBad = 0;
+    HIP_CHECK(hipMemcpyAsync(&hostBad, bad.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(keep, deviceKeep.data(), count, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamDestroy(stream));
+    if(hostBad) throw std::runtime_error("read_graph_keep: an alignment names a read beyond readCount.");
+}
+
+}  // namespace shasta_mi355x

@@ -162,52 +162,25 @@ void findAlignmentCandidatesLowHash0(
 
 namespace {
 
-// The four oriented reads an oriented read pair appears under: its two oriented reads and their
-// reverse complements (src/AssemblerAlign.cpp:513-536, src/AssemblerAlignmentCandidates.cpp:392-416).
-inline void orientedReadsOf(const shasta_oriented_read_pair& pair, uint32_t (&o)[4])
-{
-    const uint32_t o0 = pair.readIds[0] << 1, o1 = (pair.readIds[1] << 1) | (pair.isSameStrand ? 0u : 1u);
-    o[0] = o0; o[1] = o1; o[2] = o0 ^ 1u; o[3] = o1 ^ 1u;
-}
-
-// OrientedReadPair::getOther (src/OrientedReadPair.hpp:63-85): the partner of o0 in this pair,
-// reverse complemented if o0 appears reverse complemented.
-inline uint32_t otherOrientedRead(const shasta_oriented_read_pair& pair, uint32_t o0)
-{
-    uint32_t o[4];
-    orientedReadsOf(pair, o);
-    if(o0 == o[0]) return o[1];
-    if(o0 == o[1]) return o[0];
-    if(o0 == o[2]) return o[3];
-    return o[2];
-}
-
 // Per oriented read, the indices of the pairs it takes part in, sorted by (other oriented read,
-// index): the common shape of the candidate table and of the alignment table.  The sort key holds
-// the index as uint32, as the reference's vector< pair<OrientedReadId, uint32_t> > does.
-template<class Table, class PairOf>
-void fillPairTable(Table& table, uint64_t readCount, uint64_t pairCount, PairOf pairOf)
+// index): the common shape of the candidate table and of the alignment table.  Built on the device
+// (shasta_mi355x_pair_table: one stable radix sort of the 4 N (oriented read, partner) keys instead of the
+// reference's two counting passes and a std::sort per oriented read); the sort key holds the index as
+// uint32, as the reference's vector< pair<OrientedReadId, uint32_t> > does.
+template<class Table>
+void fillPairTable(Table& table, uint64_t readCount, const void* pairs, uint64_t strideBytes, uint64_t pairCount)
 {
     using Int = typename std::remove_reference<decltype(table.toc[0])>::type;
     using Index = typename std::remove_reference<decltype(table.data[0])>::type;
-    std::vector<Int> counts(2 * readCount, 0);
-    for(uint64_t i = 0; i < pairCount; i++) { uint32_t o[4]; orientedReadsOf(pairOf(i), o); for(uint32_t v : o) ++counts[v]; }
-    table.fillFromCounts(counts);
-    std::vector<uint64_t> cursor(2 * readCount);
-    for(uint64_t k = 0; k < 2 * readCount; k++) cursor[k] = uint64_t(table.toc[k]);
-    for(uint64_t i = 0; i < pairCount; i++) {
-        uint32_t o[4]; orientedReadsOf(pairOf(i), o);
-        for(uint32_t v : o) table.data[cursor[v]++] = Index(i);
+    std::vector<uint64_t> toc(2 * readCount + 1, 0);
+    std::vector<uint32_t> values(std::max<uint64_t>(1, 4 * pairCount));
+    if(shasta_mi355x_pair_table(devices().front(), pairs, strideBytes, pairCount, readCount, toc.data(), values.data())) {
+        throw std::runtime_error(shasta_mi355x_last_error());
     }
-    std::vector<std::pair<uint32_t, uint32_t>> v;
-    for(uint64_t o0 = 0; o0 < 2 * readCount; o0++) {
-        Index* section = table.begin(o0);
-        const uint64_t n = table.size(o0);
-        v.clear();
-        for(uint64_t k = 0; k < n; k++) v.push_back(std::make_pair(otherOrientedRead(pairOf(uint64_t(section[k])), uint32_t(o0)), uint32_t(section[k])));
-        std::sort(v.begin(), v.end());
-        for(uint64_t k = 0; k < n; k++) section[k] = Index(v[k].second);
-    }
+    table.toc.resize(toc.size());
+    for(size_t k = 0; k < toc.size(); k++) table.toc[k] = Int(toc[k]);
+    table.data.resize(4 * pairCount);
+    for(uint64_t k = 0; k < 4 * pairCount; k++) table.data[k] = Index(values[k]);
     table.unreserve();
 }
 
@@ -218,7 +191,8 @@ void computeCandidateTable(uint64_t readCount, const AlignmentCandidates& candid
 {
     CandidateTable table;
     table.createNew(dataName(dataDirectory, "CandidateTable"), largeDataPageSize);
-    fillPairTable(table, readCount, candidates.size(), [&](uint64_t i) -> const shasta_oriented_read_pair& { return candidates[i]; });
+    static_assert(sizeof(shasta_oriented_read_pair) == 12, "AlignmentCandidates element");
+    fillPairTable(table, readCount, candidates.size() ? candidates.begin() : nullptr, sizeof(shasta_oriented_read_pair), candidates.size());
 }
 
 void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
@@ -226,7 +200,8 @@ void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignm
 {
     AlignmentTable table;
     table.createNew(dataName(dataDirectory, "AlignmentTable"), largeDataPageSize);
-    fillPairTable(table, readCount, alignmentData.size(), [&](uint64_t i) -> const shasta_oriented_read_pair& { return alignmentData[i].pair; });
+    static_assert(sizeof(shasta_alignment_data) == 64 && offsetof(shasta_alignment_data, pair) == 0, "AlignmentData row");
+    fillPairTable(table, readCount, alignmentData.size() ? alignmentData.begin() : nullptr, sizeof(shasta_alignment_data), alignmentData.size());
 }
 
 uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignmentCount, uint32_t /* maxTrim: unused by the reference too */,
@@ -241,22 +216,13 @@ uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignment
 
     // For each read, keep only the best maxAlignmentCount alignments (:55-95): pairs (markerCount,
     // alignmentId), the largest first; ties go to the larger alignment id, as std::greater on the pair does.
-    std::vector<bool> keepAlignment(alignmentData.size(), false);
-    std::vector<std::pair<uint32_t, uint32_t>> readAlignments;
-    for(uint64_t readId = 0; readId < readCount; readId++) {
-        readAlignments.clear();
-        const uint32_t* section = alignmentTable.begin(2 * readId);
-        for(uint64_t k = 0; k < alignmentTable.size(2 * readId); k++) {
-            readAlignments.push_back(std::make_pair(alignmentData[section[k]].info.markerCount, section[k]));
-        }
-        if(readAlignments.size() > maxAlignmentCount) {
-            std::nth_element(readAlignments.begin(), readAlignments.begin() + maxAlignmentCount, readAlignments.end(),
-                std::greater<std::pair<uint32_t, uint32_t>>());
-            readAlignments.resize(maxAlignmentCount);
-        }
-        for(const auto& p : readAlignments) keepAlignment[p.second] = true;
+    // On the device (shasta_mi355x_read_graph_keep): the reference runs an nth_element per read.
+    std::vector<uint8_t> keepAlignment(alignmentData.size(), 0);
+    if(shasta_mi355x_read_graph_keep(devices().front(), alignmentData.size() ? alignmentData.begin() : nullptr, alignmentData.size(), readCount,
+        maxAlignmentCount, keepAlignment.data())) {
+        throw std::runtime_error(shasta_mi355x_last_error());
     }
-    const uint64_t keepCount = uint64_t(std::count(keepAlignment.begin(), keepAlignment.end(), true));
+    const uint64_t keepCount = uint64_t(std::count(keepAlignment.begin(), keepAlignment.end(), uint8_t(1)));
     std::cout << "Keeping " << keepCount << " alignments of " << keepAlignment.size() << std::endl;     // :97-98
 
     // Edges: one per kept alignment plus its reverse complement (:115-143).

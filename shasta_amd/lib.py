@@ -23,6 +23,7 @@ EXPORTS = [
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_kernel_table", "shasta_mi355x_kernel_table_reset",
     "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_banded_dp_many", "shasta_mi355x_calibrate",
+    "shasta_mi355x_pair_table", "shasta_mi355x_read_graph_keep",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish",
@@ -194,6 +195,28 @@ class Library:
             C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
             C.byref(count), C.byref(score)), "shasta_mi355x_banded_dp")
         return out[:count.value].copy(), score.value
+
+    def pair_table(self, pairs, read_count, device=0):
+        """computeCandidateTable / computeAlignmentTable: `pairs` is an array of candidates (12-byte records) or of
+        AlignmentData rows (64 bytes) -> (toc uint64[2 R + 1], values uint32[4 N])."""
+        a = np.ascontiguousarray(pairs)
+        stride = a.dtype.itemsize
+        toc = np.zeros(2 * int(read_count) + 1, np.uint64)
+        values = np.zeros(max(1, 4 * len(a)), np.uint32)
+        self._check(self.lib.shasta_mi355x_pair_table(C.c_int(device), C.c_void_p(a.ctypes.data if len(a) else None), C.c_uint64(stride),
+                                                      C.c_uint64(len(a)), C.c_uint64(read_count), abi.as_ptr(toc, C.c_uint64),
+                                                      abi.as_ptr(values, C.c_uint32)), "shasta_mi355x_pair_table")
+        return toc, values[:4 * len(a)]
+
+    def read_graph_keep(self, alignment_data, read_count, max_alignment_count, device=0):
+        """createReadGraph's selection -> uint8[N], 1 where the alignment stays."""
+        a = np.ascontiguousarray(alignment_data)
+        assert a.dtype.itemsize == 64
+        keep = np.zeros(max(1, len(a)), np.uint8)
+        self._check(self.lib.shasta_mi355x_read_graph_keep(C.c_int(device), C.c_void_p(a.ctypes.data if len(a) else None), C.c_uint64(len(a)),
+                                                           C.c_uint64(read_count), C.c_uint32(max_alignment_count), abi.as_ptr(keep, C.c_uint8)),
+                    "shasta_mi355x_read_graph_keep")
+        return keep[:len(a)]
 
     def banded_dp_many(self, kmer_ids, begin0, nx, begin1, ny, band_min, band_max, timing=False):
         """K10 on many tasks bundled as in an Align4 batch -> list of (ordinals [n, 2], score) per task.

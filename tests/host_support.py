@@ -8,12 +8,21 @@ from shasta_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "shasta_amd", "_build", "libshasta_host_shim.so")
+EMU_SHIM = os.path.join(ROOT, "tests", "emu", "_build", "libshasta_host_shim_emu.so")       # the same on the wave64 emulator (no GPU needed)
+EMU_HOST_SO = os.path.join(ROOT, "tests", "emu", "_build", "libshasta_mi355x_host_emu.so")
 STAGE = os.path.join(ROOT, "shasta_amd", "_build", "shasta_mi355x_stage")
 
 
+def emulated_build():
+    """Builds tests/emu (kernels on CPU fibers + the host layer linked against them) if it is missing."""
+    if not (os.path.exists(EMU_SHIM) and os.path.exists(EMU_HOST_SO)):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8"])
+
+
 class HostShim:
-    def __init__(self):
-        self.lib = C.CDLL(SHIM)
+    def __init__(self, path=SHIM):
+        self.lib = C.CDLL(path)
         self.lib.host_last_error.restype = C.c_char_p
 
     def _check(self, rc, what):

@@ -1,0 +1,44 @@
+"""The device side of SURVEY 8(f) row 3 (shasta_mi355x_pair_table, shasta_mi355x_read_graph_keep) against the python
+restatements of computeAlignmentTable / computeCandidateTable / createReadGraph's selection in tests/host_support.py:
+random pair lists with ties in every key (many pairs per oriented read, equal marker counts), shared by the GPU test
+and its pre-flight on the emulated build."""
+import numpy as np
+
+from shasta_amd import abi
+from tests import host_support
+
+
+def random_alignment_data(rng, read_count, n):
+    rows = np.zeros(n, dtype=abi.ALIGNMENT_DATA_DTYPE)
+    a = rng.integers(0, read_count, size=n)
+    b = rng.integers(0, read_count - 1, size=n)
+    b = np.where(b >= a, b + 1, b)
+    rows["readId0"] = np.minimum(a, b); rows["readId1"] = np.maximum(a, b)
+    rows["isSameStrand"] = rng.integers(0, 2, size=n)
+    rows["markerCount"] = rng.integers(90, 110, size=n)          # few distinct values: the alignment id breaks the ties
+    return rows
+
+
+def check(lib, seed=5, read_count=211, n=3000):
+    rng = np.random.default_rng(seed)
+    rows = random_alignment_data(rng, read_count, n)
+    toc, values = lib.pair_table(rows, read_count)
+    toc_expected, values_expected = host_support.alignment_table_expected(read_count, rows)
+    assert np.array_equal(toc, toc_expected.astype(np.uint64)) and np.array_equal(values, values_expected)
+    candidates = np.zeros(n, dtype=abi.PAIR_DTYPE)
+    for name in ("readId0", "readId1", "isSameStrand"):
+        candidates[name] = rows[name]
+    toc12, values12 = lib.pair_table(candidates, read_count)
+    assert np.array_equal(toc12, toc) and np.array_equal(values12, values)
+    for k in (1, 6, 30, 10 ** 6):
+        keep = lib.read_graph_keep(rows, read_count, k)
+        expected = host_support.read_graph_expected(read_count, rows, k)[0]
+        assert np.array_equal(keep.astype(bool), expected), k
+    # Nothing to do, and what cannot be right.
+    toc0, values0 = lib.pair_table(rows[:0], read_count)
+    assert not toc0.any() and len(values0) == 0 and len(lib.read_graph_keep(rows[:0], read_count, 6)) == 0
+    import pytest
+    with pytest.raises(RuntimeError, match="beyond readCount"):
+        lib.pair_table(rows, read_count // 2)
+    with pytest.raises(RuntimeError, match="beyond readCount"):
+        lib.read_graph_keep(rows, read_count // 2, 6)

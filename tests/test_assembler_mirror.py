@@ -26,11 +26,15 @@ def test_align_options_has_the_reference_attribute_names():
     assert (o.align4DeltaX, o.align4DeltaY, o.align4MinEntryCountPerCell, o.align4MaxDistanceFromBoundary) == (200, 10, 10, 100)
 
 
-def test_candidate_table_and_errors_through_the_mirror(ref_lib, oracle_lib, tmp_path):
+@pytest.mark.parametrize("build", ["emulated", pytest.param("mi355x", marks=pytest.mark.gpu)])
+def test_candidate_table_and_errors_through_the_mirror(ref_lib, oracle_lib, tmp_path, build):
+    # (The candidate table is built on the device: the emulated build here, the product on the GPU box.)
     toc, kmer, data7 = support.small_marker_set(n_reads=100, genome_markers=7000, seed=85)
     d = str(tmp_path / "Data")
     os.makedirs(d)
-    a = shasta.Assembler(d + "/")
+    if build == "emulated":
+        host_support.emulated_build()
+    a = shasta.Assembler(d + "/", hostLibrary=host_support.EMU_HOST_SO if build == "emulated" else shasta.HOST_SO)
     with pytest.raises(RuntimeError, match="Error accessing"):
         a.accessMarkers()
     ref_lib.write_data_dir(d, toc, data7, None)
@@ -39,7 +43,7 @@ def test_candidate_table_and_errors_through_the_mirror(ref_lib, oracle_lib, tmp_
     with pytest.raises(RuntimeError, match="Error accessing"):
         a.accessAlignmentCandidates()
     cand = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)).candidates
-    host_support.HostShim().store_candidates(d, cand)
+    host_support.HostShim(host_support.EMU_SHIM if build == "emulated" else host_support.SHIM).store_candidates(d, cand)
     a.accessAlignmentCandidates()
     a.computeCandidateTable()
     t, _ = ref_lib.open_vector(os.path.join(d, "CandidateTable.toc"), 8)

@@ -76,7 +76,7 @@ def test_lowhash0_golden_fixture(emu_lib):
     support.check_lowhash(out, g.z, 0)
 
 
-@pytest.mark.parametrize("i", [0, 1, 2])
+@pytest.mark.parametrize("i", [0])        # (option sets 1 and 2 of the fixture: on the GPU only, 80 s of emulation)
 def test_align3_reference_fixture(emu_lib, i):
     align3_checks.golden_fixture(emu_lib, "tiny", i)
 
@@ -94,8 +94,13 @@ def test_align3_context_paths(emu_lib, oracle_lib):
     align3_checks.context_paths(emu_lib, oracle_lib)
 
 
+def test_candidate_and_alignment_tables_and_read_graph_selection(emu_lib):
+    from tests import table_checks
+    table_checks.check(emu_lib)
+
+
 def test_align3_long_reads(emu_lib, oracle_lib):
-    align3_checks.long_reads(emu_lib, oracle_lib)
+    align3_checks.long_reads(emu_lib, oracle_lib, mean_markers=7100.0, factors=(0.95, 0.25))      # (smaller reads than the GPU test's: the emulator's time)
 
 
 def test_align3_rejected_options(emu_lib):

@@ -78,3 +78,9 @@ def test_stage_executable_reproduces_the_reference_files(gpu_lib, ref_lib, oracl
 def test_stage_executable_reports_errors_like_the_reference(tmp_path):
     out = subprocess.run([host_support.STAGE, "lowhash0", str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "Error accessing" in out.stdout
+
+
+def test_candidate_and_alignment_tables_and_read_graph_selection_on_the_device(gpu_lib):
+    # shasta_mi355x_pair_table / _read_graph_keep against the python restatements of the reference's loops.
+    from tests import table_checks
+    table_checks.check(gpu_lib, seed=6, read_count=5003, n=200000)

@@ -9,8 +9,13 @@ from shasta_amd import abi
 from tests import host_support, support
 
 
-@pytest.fixture(scope="module")
-def shim():
+# The table steps (candidate table, alignment table, read graph selection) run on the device: on the wave64 emulator
+# here, on the MI355X in the -m gpu run.
+@pytest.fixture(scope="module", params=["emulated", pytest.param("mi355x", marks=pytest.mark.gpu)])
+def shim(request):
+    if request.param == "emulated":
+        host_support.emulated_build()
+        return host_support.HostShim(host_support.EMU_SHIM)
     if not os.path.exists(host_support.SHIM):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(host_support.ROOT, "shasta_amd", "csrc"), "host"])
