@@ -311,8 +311,8 @@ int shasta_mi355x_align4_run_borrowed(
  * same filters and outputs as the method-4 seam; results are released with
  * shasta_mi355x_align4_free.  Status EMPTY = empty alignment (a read without down-sampled markers,
  * nothing aligned in step 1, or a band wider than maxBand); SKIPPED = a pair whose down-sampled
- * matrix has more than 8192 diagonals (down-sampled markers of the two reads + 1: reads of some
- * 500 kb at the default factor), which this version does not align.  Limits: scores 6/-1/-1 (every
+ * matrix has more than 65536 diagonals (down-sampled markers of the two reads + 1: reads of several
+ * megabases at the default factor), which this version does not align.  Limits: scores 6/-1/-1 (every
  * shipped configuration), maxBand <= 1023, k <= 16.  `borrowed` != 0: result arrays belong to the
  * context, as align4_run_borrowed. */
 int shasta_mi355x_align3_run(
