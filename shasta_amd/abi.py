@@ -216,9 +216,9 @@ def view_array(ptr, n, dtype, owner):
     if not ptr or n == 0:
         return np.zeros(0, dtype=dtype)
     buf = C.cast(ptr, C.POINTER(C.c_uint8 * (n * dtype.itemsize))).contents
+    buf._owner = owner                           # every array and slice made from the view keeps the C buffers alive
     a = np.frombuffer(buf, dtype=dtype, count=n)
     a.flags.writeable = False
-    owner._views.append(a)
     return a
 
 
@@ -226,7 +226,7 @@ class _ResultOwner:
     """Owns a C result struct; the library's free function runs when the last view is gone."""
 
     def __init__(self, res, free):
-        self.res, self.free, self._views = res, free, []
+        self.res, self.free = res, free
 
     def __del__(self):
         try:
@@ -236,10 +236,15 @@ class _ResultOwner:
 
 
 class LowHash0Output:
-    """Python-side copy of shasta_lowhash0_result + the statistics table."""
+    """shasta_lowhash0_result + the statistics table.  With `free` (the library's shasta_mi355x_lowhash0_free) the candidate
+    list is a zero-copy, read-only view of the C buffer, released when this object goes away; without it, a copy."""
 
-    def __init__(self, res, stats):
-        self.candidates = copy_array(res.candidates, res.candidateCount, PAIR_DTYPE)
+    def __init__(self, res, stats, free=None):
+        if free is not None:
+            self._owner = _ResultOwner(res, free)
+            self.candidates = view_array(res.candidates, res.candidateCount, PAIR_DTYPE, self._owner)
+        else:
+            self.candidates = copy_array(res.candidates, res.candidateCount, PAIR_DTYPE)
         self.log2_bucket_count = int(res.log2BucketCount)
         self.high_frequency = copy_array(res.highFrequency, res.iterationCount, "<u8")
         self.total = copy_array(res.total, res.iterationCount, "<u8")
