@@ -358,6 +358,10 @@ __device__ __forceinline__ uint32_t zeroHalves(uint32_t v) { return packedMinU16
 constexpr uint32_t LOW_HALF = 1u, HIGH_HALF = 0x10000u;
 
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
+#ifndef SHASTA_CELLS_FURTHER
+#define SHASTA_CELLS_FURTHER 2
+#endif
+constexpr int CELLS_FURTHER = SHASTA_CELLS_FURTHER;   // further matches a lane takes per iteration after the first pass
 constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
 constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
 __host__ __device__ inline size_t cellsSlotLdsWords(int Q)
@@ -468,18 +472,10 @@ align4CellsChunkKernel(
     const uint32_t roundStride = uint32_t(CELLS_UNROLL) * groupStride;
     const uint32_t firstRound = wave * uint32_t(WAVE);
     // A candidate starts with a chain of dependent global loads (member list -> pair descriptor -> the first markers of
-    // its stream), a few microseconds during which the whole workgroup would wait: they are issued one candidate ahead
-    // (descriptor at the start of the previous candidate, first round of markers after the previous candidate's first round).
+    // its stream): the descriptor is loaded one candidate ahead.  (Loading the first round of markers ahead as well cost
+    // twelve vector registers and bought nothing measurable: the wait it removed was taken by the next barrier.)
     uint32_t pairAhead = members[chunk.firstMember];
     PairDesc pdAhead = pdFirst;
-    uint32_t kmAhead[CELLS_UNROLL];
-    auto loadFirstRound = [&](const PairDesc& d) {
-        const uint32_t* __restrict__ seq = kmerIds + (swapped ? d.begin0 : d.begin1);
-        const uint32_t count = swapped ? d.nx : d.ny;
-#pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmAhead[u] = t < count ? seq[t] : 0u; }
-    };
-    loadFirstRound(pdAhead);
 
     // Groups of `waves` candidates: streamed one after the other by the whole workgroup, then one graph per wavefront.
     for(uint32_t group = 0; group < chunk.count; group += waves) {
@@ -490,7 +486,6 @@ align4CellsChunkKernel(
         const uint32_t nx = pd.nx, ny = pd.ny;
         const bool more = c + 1 < uint32_t(chunk.count);
         if(more) { pairAhead = members[chunk.firstMember + c + 1]; pdAhead = pairs[pairAhead]; }
-        bool aheadLoaded = !more;
         kept = slots + (c - group) * cellsSlotLdsWords(Q);
         scratch = kept + 2 * MAXC;
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
@@ -597,7 +592,7 @@ align4CellsChunkKernel(
 
         uint32_t kmNext[CELLS_UNROLL];
 #pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) kmNext[u] = kmAhead[u];
+        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
         SUBPHASE_DECLARE();
         for(uint32_t s0 = firstRound; s0 < streamCount; s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
@@ -656,41 +651,54 @@ align4CellsChunkKernel(
             }
             // Further matches -- a kmer that occurs more than once in the tabled read (a random marker of a 1500-marker read
             // over the 8000-marker alphabet of k = 10 has a second occurrence with probability 0.2: a handful of the 256
-            // markers of a round), or a false tag match in front of the true one.  Few lanes have any, so each iteration takes
-            // ONE further match per lane, whichever of the lane's four markers it belongs to: a quarter of the work of a pass
-            // over all four (round 1 repeated the full pass: 2.95 passes per round measured, profiles/r02_cells_phases.txt).
-            for(;;) {
-                uint32_t rest[CELLS_UNROLL];
+            // markers of a round), or a false tag match in front of the true one.  Half of the kernel's time went here
+            // (a build without this loop: 69 -> 35 ms solo), at 2.5 iterations per round with few lanes at work in each.  So:
+            // the match flags that are left (bits 0 and 16 of the sixteen words) are packed into ONE mask per lane, bit 4 u + i
+            // for the low half of word i of marker u, bit 16 + 4 u + i for the high half; an iteration takes the lane's next
+            // CELLS_FURTHER set bits -- find-first-bit, a four-level select of the word, the kmer compare in LDS -- and counts
+            // them together (independent LDS chains).  (Before: the marker, then the word, then the half were found with
+            // select chains over all sixteen words, and the flag was cleared with sixteen more, per match.)
+            {
+                uint32_t pending = 0;
 #pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) rest[u] = m[u][0] | m[u][1] | m[u][2] | m[u][3];
-                if(!__any((rest[0] | rest[1] | rest[2] | rest[3]) != 0u)) break;
-                SUBPHASE_COUNT(5);
-                static_assert(CELLS_UNROLL == 4, "marker selection below");
-                const int us = rest[0] ? 0 : (rest[1] ? 1 : (rest[2] ? 2 : 3));              // the lane's first marker with a match left (3 when none)
-                uint32_t mw[4], wwv[4];
-#pragma unroll
-                for(int i = 0; i < 4; i++) {
-                    mw[i] = us == 0 ? m[0][i] : (us == 1 ? m[1][i] : (us == 2 ? m[2][i] : m[3][i]));
-                    wwv[i] = us == 0 ? w[0][i] : (us == 1 ? w[1][i] : (us == 2 ? w[2][i] : w[3][i]));
+                for(int u = CELLS_UNROLL - 1; u >= 0; u--) {
+                    const uint32_t ofMarker = m[u][0] | (m[u][1] << 1) | (m[u][2] << 2) | (m[u][3] << 3);
+                    pending = (pending << 4) | ofMarker;
                 }
-                const uint32_t kmSel = us == 0 ? km[0] : (us == 1 ? km[1] : (us == 2 ? km[2] : km[3]));
-                const int is = mw[0] ? 0 : (mw[1] ? 1 : (mw[2] ? 2 : 3));
-                const uint32_t mm = mw[0] ? mw[0] : (mw[1] ? mw[1] : (mw[2] ? mw[2] : mw[3]));
-                const uint32_t ww = mw[0] ? wwv[0] : (mw[1] ? wwv[1] : (mw[2] ? wwv[2] : wwv[3]));
-                const bool cand = mm != 0;
-                const bool low = (mm & LOW_HALF) != 0;
-                const uint32_t tiSel = (low ? ww : (ww >> 16)) & xMask;
-                const uint32_t kaSel = aKmers[cand ? tiSel : 0u];
-                const uint32_t cleared = mm & (low ? ~LOW_HALF : ~HIGH_HALF);
+                while(__any(pending != 0u)) {
+                    SUBPHASE_COUNT(5);
+                    bool hitF[CELLS_FURTHER];
+                    uint32_t tiF[CELLS_FURTHER], tsF[CELLS_FURTHER];
+                    bool anyHit = false;
 #pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++)
+                    for(int f = 0; f < CELLS_FURTHER; f++) {
+                        const bool has = pending != 0u;
+                        const uint32_t bit = has ? uint32_t(__ffs(int(pending))) - 1u : 0u;
+                        pending &= pending - 1u;
+                        const uint32_t word = bit & 15u;                               // 4 u + i
+                        // Word `word` of the sixteen, kmer `word >> 2` of the four: a tree of v_cndmask on the index bits (laneSelect:
+                        // written as `b ? x : y`, or bitwise, the compiler turns the tree into an indexed load from a copy of the
+                        // words in scratch memory).
+                        const uint64_t c0 = __ballot((word & 1u) != 0u), c1 = __ballot((word & 2u) != 0u), c2 = __ballot((word & 4u) != 0u), c3 = __ballot((word & 8u) != 0u);
+                        uint32_t level1[8], level2[4], level3[2];
 #pragma unroll
-                    for(int i = 0; i < 4; i++) m[u][i] = (cand && us == u && is == i) ? cleared : m[u][i];
-                const bool hitSel = cand && kaSel == kmSel;
-                const uint32_t tsSel = s0 + uint32_t(us) * groupStride + uint32_t(lane);
-                SUBPHASE_ADD(3);
-                if(__any(hitSel)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, 1>{}, &hitSel, &tiSel, &tsSel); }
-                SUBPHASE_ADD(2);
+                        for(int k = 0; k < 8; k++) level1[k] = laneSelect(c0, w[k >> 1][2 * (k & 1) + 1], w[k >> 1][2 * (k & 1)]);
+#pragma unroll
+                        for(int k = 0; k < 4; k++) level2[k] = laneSelect(c1, level1[2 * k + 1], level1[2 * k]);
+#pragma unroll
+                        for(int k = 0; k < 2; k++) level3[k] = laneSelect(c2, level2[2 * k + 1], level2[2 * k]);
+                        const uint32_t ww = laneSelect(c3, level3[1], level3[0]);
+                        const uint32_t kmSel = laneSelect(c3, laneSelect(c2, km[3], km[2]), laneSelect(c2, km[1], km[0]));
+                        tiF[f] = ((bit & 16u) ? (ww >> 16) : ww) & xMask;
+                        const uint32_t kaSel = aKmers[has ? tiF[f] : 0u];
+                        hitF[f] = has && kaSel == kmSel;
+                        tsF[f] = s0 + (word >> 2) * groupStride + uint32_t(lane);
+                        anyHit |= hitF[f];
+                    }
+                    SUBPHASE_ADD(3);
+                    if(__any(anyHit)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, CELLS_FURTHER>{}, hitF, tiF, tsF); }
+                    SUBPHASE_ADD(2);
+                }
             }
             // The few markers that did not fit their buckets.
             for(uint32_t k = 0; k < stashed; k++) {
@@ -700,9 +708,7 @@ align4CellsChunkKernel(
                 for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
                 if(__any(anyHit)) countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts);
             }
-            if(!aheadLoaded) { loadFirstRound(pdAhead); aheadLoaded = true; }
         }
-        if(!aheadLoaded) loadFirstRound(pdAhead);                     // (this wavefront had no round of its own)
         SUBPHASE_FLUSH();
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
         if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
@@ -818,7 +824,7 @@ align4CellsChunkKernel(
             bool changed = false;
 #pragma unroll
             for(int q = 0; q < Q; q++) {
-                if(q >= nq) break;
+                // (cells beyond n hold no key: empty masks; a `break` here makes the index dynamic and the masks go to scratch memory)
                 uint64_t reach = 0;
 #pragma unroll
                 for(int r = 0; r < Q; r++) reach |= before[q][r] & fwd[r];
@@ -835,7 +841,7 @@ align4CellsChunkKernel(
             bool changed = false;
 #pragma unroll
             for(int q = 0; q < Q; q++) {
-                if(q >= nq) break;
+                // (cells beyond n hold no key: empty masks; a `break` here makes the index dynamic and the masks go to scratch memory)
                 uint64_t reach = 0;
 #pragma unroll
                 for(int r = 0; r < Q; r++) reach |= after[q][r] & bwd[r];
@@ -869,7 +875,7 @@ align4CellsChunkKernel(
                 bool changed = false;
 #pragma unroll
                 for(int q = 0; q < Q; q++) {
-                    if(q >= nq) break;
+                    // (cells beyond n hold no key: empty masks; a `break` here makes the index dynamic and the masks go to scratch memory)
                     uint64_t reach = 0;
 #pragma unroll
                     for(int r = 0; r < Q; r++) reach |= (before[q][r] | after[q][r]) & comp[r];

@@ -218,6 +218,7 @@ __forceinline__ uint32_t __builtin_amdgcn_readfirstlane(uint32_t v)
 
 __forceinline__ int __popc(unsigned v) { return __builtin_popcount(v); }
 __forceinline__ int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+__forceinline__ int __ffs(int v) { return __builtin_ffs(v); }
 __forceinline__ int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 __forceinline__ int __ffsll(long long v) { return __builtin_ffsll(v); }
 __forceinline__ int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
@@ -240,6 +241,9 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 #define SHASTA_WRITELANE_DEFINED 1
 __forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uint32_t old) { return (uint32_t(threadIdx.x) & 63u) == (lane & 63u) ? value : old; }
 __forceinline__ uint32_t writeLaneImmediate(uint32_t value, int lane, uint32_t old) { return writeLane(value, uint32_t(lane), old); }
+// v_cndmask_b32 on a ballot (inline assembly in primitives.hpp).
+#define SHASTA_LANE_SELECT_DEFINED 1
+__forceinline__ uint32_t laneSelect(uint64_t laneMask, uint32_t ifSet, uint32_t ifClear) { return ((laneMask >> (uint32_t(threadIdx.x) & 63u)) & 1ull) ? ifSet : ifClear; }
 // v_pk_min_u16 (inline assembly in primitives.hpp).
 #define SHASTA_PACKED_MIN_DEFINED 1
 __forceinline__ uint32_t packedMinU16(uint32_t a, uint32_t b)
