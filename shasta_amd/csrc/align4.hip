@@ -181,6 +181,8 @@ template<int Q>
 void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
 {
+    // (Fewer workgroups per CU -- 3 instead of 4, by padding the LDS request -- so that other workers' kernels find registers on
+    // the same CU: 57 -> 66 ms solo and 214 -> 225 ms per step, scripts/gpu_r02_call29.sh.)
     const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[cls], CELLS_SC_LOG2[cls], Q, CELLS_WAVES) * sizeof(uint32_t);
     std::call_once(ctx.cellsLdsAttribute[Q == 2 ? 0 : 1], [] {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<Q>),

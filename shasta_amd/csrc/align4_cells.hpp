@@ -517,21 +517,14 @@ align4CellsChunkKernel(
         auto countHits = [&](auto nTag, const bool* hit, const uint32_t* ti, const uint32_t* ts) {
             constexpr int N = decltype(nTag)::value;
             bool pending[N];
-            uint32_t key[N], packed[N], cs[N], probes[N];
+            uint32_t iX[N], iY[N];
 #pragma unroll
             for(int u = 0; u < N; u++) {
                 const uint32_t t = ts[u];
                 const uint32_t x = swapped ? t : ti[u], y = swapped ? ti[u] : t;
                 const uint32_t X = x + y, Y = nx + y - x - 1;                  // getXY, :171-177
-                const uint32_t iX = divMagic(X, magicX), iY = divMagic(Y, magicY);
-                // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; the host only sends
-                // candidates whose cell indices fit (others run in the HBM-scratch kernel).
-                const bool h = hit[u];
-                key[u] = h ? ((iY << 16) | iX) : EMPTY32;
-                pending[u] = h;
-                packed[u] = (iY << CELLS_IX_BITS) | iX;
-                cs[u] = hash32(key[u]) >> scShift;
-                probes[u] = 0;
+                iX[u] = divMagic(X, magicX); iY[u] = divMagic(Y, magicY);
+                pending[u] = hit[u];
             }
             if(useGrid) {
                 // All reads, then all atomics, then the (rare) threshold crossings: the LDS operations of the N slots are
@@ -540,7 +533,7 @@ align4CellsChunkKernel(
                 bool add[N];
 #pragma unroll
                 for(int u = 0; u < N; u++) {
-                    const uint32_t idx = (key[u] >> 16) * gridX + (key[u] & 0xffffu);
+                    const uint32_t idx = iY[u] * gridX + iX[u];
                     word[u] = pending[u] ? idx >> 2 : 0u; shift[u] = 8u * (idx & 3u);
                 }
 #pragma unroll
@@ -551,10 +544,20 @@ align4CellsChunkKernel(
                 for(int u = 0; u < N; u++) {
                     if(before[u] + 1 == threshold) {                                          // :417
                         const uint32_t at = atomicAdd(&scratch[0], 1u);
-                        if(at < uint32_t(MAXC)) kept[at] = key[u];
+                        if(at < uint32_t(MAXC)) kept[at] = (iY[u] << 16) | iX[u];
                     }
                 }
                 return;
+            }
+            // The LDS cell table packs (iY:12 | iX:10 | count:10) in one word; the host only sends
+            // candidates whose cell indices fit (others run in the HBM-scratch kernel).
+            uint32_t key[N], packed[N], cs[N], probes[N];
+#pragma unroll
+            for(int u = 0; u < N; u++) {
+                key[u] = pending[u] ? ((iY[u] << 16) | iX[u]) : EMPTY32;
+                packed[u] = (iY[u] << CELLS_IX_BITS) | iX[u];
+                cs[u] = hash32(key[u]) >> scShift;
+                probes[u] = 0;
             }
             bool anyPending = false;
 #pragma unroll
