@@ -376,8 +376,15 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 #ifndef SHASTA_CELLS_MAX_THREADS
 #define SHASTA_CELLS_MAX_THREADS 384
 #endif
+// Wavefronts per SIMD the register allocator must make room for.  Five: 96 vector registers (the kernel wants 111 and spills
+// four dwords), and the first class's 29 KB of LDS per workgroup lets five workgroups share a CU: 55 -> 50 ms solo
+// (scripts/gpu_r02_call30.sh).  At the start of the round the same constraint cost 20 spilled dwords and made the kernel slower.
+#ifndef SHASTA_CELLS_WAVES_PER_SIMD
+#define SHASTA_CELLS_WAVES_PER_SIMD 5
+#endif
+#define SHASTA_CELLS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SHASTA_CELLS_WAVES_PER_SIMD, SHASTA_CELLS_WAVES_PER_SIMD)))
 template<int Q>
-__global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS)
+__global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS) SHASTA_CELLS_OCCUPANCY
 align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
@@ -599,7 +606,8 @@ align4CellsChunkKernel(
         SUBPHASE_DECLARE();
         for(uint32_t s0 = firstRound; s0 < streamCount; s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
-            uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], m[CELLS_UNROLL][4], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
+            // matches[u]: the tag matches of marker u, bit i for the low half of its word i, bit 16 + i for the high half.
+            uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], matches[CELLS_UNROLL], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
             bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
@@ -611,7 +619,7 @@ align4CellsChunkKernel(
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
                 if(s0 + uint32_t(u) * groupStride >= streamCount) {                // no such group (uniform)
-                    w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0; m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0;
+                    w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0; matches[u] = 0;
                     continue;
                 }
                 const uint32_t h = hash32(km[u]);
@@ -620,10 +628,9 @@ align4CellsChunkKernel(
                 w[u][2] = aSlots[2 * b2]; w[u][3] = aSlots[2 * b2 + 1];
                 const uint32_t pattern = (tagOf(h) << xBits) * 0x00010001u, fieldMask = (tagMask << xBits) * 0x00010001u;
                 const bool same = b1 == b2;
-#pragma unroll
-                for(int i = 0; i < 4; i++) m[u][i] = zeroHalves((w[u][i] ^ pattern) & fieldMask);
-                if(same) { m[u][2] = 0; m[u][3] = 0; }
-                if(!valid[u]) { m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; }
+                const uint32_t first = zeroHalves((w[u][0] ^ pattern) & fieldMask) | (zeroHalves((w[u][1] ^ pattern) & fieldMask) << 1);
+                const uint32_t second = (zeroHalves((w[u][2] ^ pattern) & fieldMask) << 2) | (zeroHalves((w[u][3] ^ pattern) & fieldMask) << 3);
+                matches[u] = valid[u] ? (same ? first : (first | second)) : 0u;
             }
             SUBPHASE_ADD(0);
             // First pass: the first tag match of each of the lane's four markers, resolved against the kmer ids in LDS.
@@ -633,16 +640,14 @@ align4CellsChunkKernel(
                 for(int u = 0; u < CELLS_UNROLL; u++) {
                     ts[u] = s0 + uint32_t(u) * groupStride + uint32_t(lane);
                     if(s0 + uint32_t(u) * groupStride >= streamCount) { hit[u] = false; ti[u] = 0; ka[u] = 0; continue; }
-                    // (static register indexing only)
-                    const bool s0m = m[u][0] != 0, s1m = !s0m && m[u][1] != 0, s2m = !s0m && !s1m && m[u][2] != 0;
-                    const uint32_t mm = s0m ? m[u][0] : (s1m ? m[u][1] : (s2m ? m[u][2] : m[u][3]));
-                    const uint32_t ww = s0m ? w[u][0] : (s1m ? w[u][1] : (s2m ? w[u][2] : w[u][3]));
-                    const bool cand = mm != 0;
-                    const bool low = (mm & LOW_HALF) != 0;
-                    ti[u] = (low ? ww : (ww >> 16)) & xMask;
+                    // The first match: find-first-bit, then the word among the marker's four (static register indexing only).
+                    const bool cand = matches[u] != 0u;
+                    const uint32_t bit = cand ? uint32_t(__ffs(int(matches[u]))) - 1u : 0u;
+                    matches[u] &= matches[u] - 1u;
+                    const uint64_t c0 = __ballot((bit & 1u) != 0u), c1 = __ballot((bit & 2u) != 0u);
+                    const uint32_t ww = laneSelect(c1, laneSelect(c0, w[u][3], w[u][2]), laneSelect(c0, w[u][1], w[u][0]));
+                    ti[u] = ((bit & 16u) ? (ww >> 16) : ww) & xMask;
                     ka[u] = aKmers[cand ? ti[u] : 0u];
-                    const uint32_t cleared = mm & (low ? ~LOW_HALF : ~HIGH_HALF);
-                    if(s0m) m[u][0] = cleared; else if(s1m) m[u][1] = cleared; else if(s2m) m[u][2] = cleared; else m[u][3] = cleared;
                     hit[u] = cand;
                 }
                 bool anyHit = false;
@@ -656,7 +661,7 @@ align4CellsChunkKernel(
             // over the 8000-marker alphabet of k = 10 has a second occurrence with probability 0.2: a handful of the 256
             // markers of a round), or a false tag match in front of the true one.  Half of the kernel's time went here
             // (a build without this loop: 69 -> 35 ms solo), at 2.5 iterations per round with few lanes at work in each.  So:
-            // the match flags that are left (bits 0 and 16 of the sixteen words) are packed into ONE mask per lane, bit 4 u + i
+            // the match flags that are left are packed into ONE mask per lane, bit 4 u + i
             // for the low half of word i of marker u, bit 16 + 4 u + i for the high half; an iteration takes the lane's next
             // CELLS_FURTHER set bits -- find-first-bit, a four-level select of the word, the kmer compare in LDS -- and counts
             // them together (independent LDS chains).  (Before: the marker, then the word, then the half were found with
@@ -664,10 +669,7 @@ align4CellsChunkKernel(
             {
                 uint32_t pending = 0;
 #pragma unroll
-                for(int u = CELLS_UNROLL - 1; u >= 0; u--) {
-                    const uint32_t ofMarker = m[u][0] | (m[u][1] << 1) | (m[u][2] << 2) | (m[u][3] << 3);
-                    pending = (pending << 4) | ofMarker;
-                }
+                for(int u = CELLS_UNROLL - 1; u >= 0; u--) pending = (pending << 4) | matches[u];
                 while(__any(pending != 0u)) {
                     SUBPHASE_COUNT(5);
                     bool hitF[CELLS_FURTHER];
