@@ -382,7 +382,11 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 #ifndef SHASTA_CELLS_WAVES_PER_SIMD
 #define SHASTA_CELLS_WAVES_PER_SIMD 5
 #endif
+#ifdef __HIPCC__
 #define SHASTA_CELLS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SHASTA_CELLS_WAVES_PER_SIMD, SHASTA_CELLS_WAVES_PER_SIMD)))
+#else
+#define SHASTA_CELLS_OCCUPANCY            // (the wave64 emulator of tests/emu compiles this file as plain C++)
+#endif
 template<int Q>
 __global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS) SHASTA_CELLS_OCCUPANCY
 align4CellsChunkKernel(
