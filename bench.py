@@ -364,6 +364,7 @@ def main():
     ctx.kernel_table_reset()
     t0 = time.perf_counter()
     lh_dev = al_dev = lh_wall = al_wall = 0.0
+    each_step = []                                  # (LowHash0 device ms, aligner device ms) of every timed step: outliers show here
     for _ in range(args.steps):
         lh, al, pairs_total = step()
         if world == 1:
@@ -372,6 +373,7 @@ def main():
         if al is not None:
             al_dev += al.device_seconds
             al_wall += al.seconds
+        each_step.append([round(1e3 * lh.device_seconds, 2) if world == 1 else None, round(1e3 * al.device_seconds, 2) if al is not None else None])
     sync()
     elapsed = time.perf_counter() - t0
     table = ctx.kernel_table()
@@ -457,6 +459,7 @@ def main():
                                "%d GPUs, one job: reads sharded by id range, RCCL all-to-all of low-hash records and of pair "
                                "keys per MinHash iteration, candidates re-split by sum(nx+ny) for Align4" % world,
             },
+            "stage_device_ms_each_step": each_step,
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
                                        "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps},
             "kernel_seconds_per_step": kernel_seconds,

@@ -232,10 +232,11 @@ bandedDpForwardKernel(
         // stored value as it is, a diagonal move (two anti-diagonals on) adds the match or mismatch score minus two gap
         // penalties -- one addition per cell instead of two, same comparisons (all three candidates carry the same offset).
         const int32_t dg = hd + (eq ? MATCH_SCORE - 2 * GAP_SCORE : MISMATCH_SCORE - 2 * GAP_SCORE);
-        const bool isV = hv > dg;                                   // from (i, j-1): diagonal b+1
-        const int32_t m1 = max(dg, hv);
-        const bool isH = hh > m1;                                   // from (i-1, j): diagonal b-1
-        int32_t v = max(m1, hh);
+        // hv: from (i, j-1), diagonal b+1; hh: from (i-1, j), diagonal b-1.  Ties go to the diagonal, then to the vertical move
+        // (the restated SeqAn policy: vertical only if hv > dg, horizontal only if hh > max(dg, hv)) -- which is "the first of
+        // dg, hv, hh that equals their maximum": one v_max3 and two equality tests instead of two maxima and two comparisons.
+        int32_t v = max(max(dg, hv), hh);
+        const bool isD = v == dg, isVertical = v == hv;            // (isVertical only counts where isD is false)
         if constexpr (STEADY) {
             SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
             H[c] = exists[c] ? v : 0;
@@ -244,9 +245,9 @@ bandedDpForwardKernel(
             v = (sc == lo[c]) ? BIAS - GAP_SCORE * sc : v;          // i == 0 or j == 0: free leading gaps (score 0)
             H[c] = valid ? v : H[c];
         }
-        const uint64_t bEq = ballot64(eq), bV = ballot64(isV), bH = ballot64(isH);
-        loPlane = bH | ~(bV | bEq);                                 // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
-        hiPlane = bV | bH;
+        const uint64_t bEq = ballot64(eq), bD = ballot64(isD), bVertical = ballot64(isVertical);
+        loPlane = ~(bD | bVertical) | (bD & ~bEq);                  // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
+        hiPlane = ~bD;
     };
     // aw(k), bw(h): the kmer ids of this iteration.
     auto antiDiagonals = [&](auto steadyTag, int32_t s, auto aw, auto bw, uint64_t (&words)[RW]) {
