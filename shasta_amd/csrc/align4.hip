@@ -35,6 +35,7 @@
 #include <memory>
 #include <mutex>
 #include <set>
+#include <unordered_map>
 #include <thread>
 #include <type_traits>
 
@@ -108,7 +109,9 @@ struct BatchScratch {
     DeviceBuffer<PairDesc> pairs;
     DeviceBuffer<shasta_oriented_read_pair> candidates;
     DeviceBuffer<DpTask> tasks;
-    DeviceBuffer<uint32_t> counters;            // [0]=taskCount, [1..5]=class counts
+    DeviceBuffer<uint32_t> counters;            // [0]=taskCount, [1..8]=class counts, [12]=tied candidates seen by winnerKernel
+    DeviceBuffer<uint32_t> tieMembers, tieKeys, tieCounts;     // resolveComponentTies
+    DeviceBuffer<CellsChunk> tieChunks;
     DeviceBuffer<uint8_t> pairFlags, pairTie, status;
     DeviceBuffer<unsigned long long> pairBest, dpCells;
     DeviceBuffer<uint32_t> pairWinner, classLists, storedFlags, storedIndex, scanTemp32;
@@ -195,7 +198,7 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
     SHASTA_TIMED(ctx, name, ws.stream, kmerIdBytes, candidateCount,
         hipLaunchKernelGGL((align4CellsChunkKernel<Q>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, ws.stream,
             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
-            opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data()));
+            opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(), (uint32_t*)nullptr, (uint32_t*)nullptr));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -318,6 +321,226 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     timed(0, stream, [&](hipStream_t st) { launchDpForward<16, 2>(in, st, b, sortedIds, layout, 0); });
     if(fork) HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     return f;
+}
+
+// ---- component ties ------------------------------------------------------------------------------
+// Align4 returns the FIRST alignment with the largest markerCount (src/Align4.cpp:126-147), in the order of the
+// connected components of the active cells, and that order is the order of their union-find representatives
+// (findActiveCellsConnectedComponents, :792-868: cell ids in (iY, iX) order, unions in the iteration order of a
+// std::unordered_map keyed by MurmurHash64A of the coordinates, boost::disjoint_sets' union by rank, components in a
+// std::map by representative).  Only a tie on markerCount between two components of a candidate can observe it.  For such
+// candidates (none on the benchmark workload, a few on tandem repeats) the host repeats exactly that bookkeeping on the
+// candidate's set of active cells -- the same container from the same standard library, the same hash, the same link rule --
+// and picks the tied component whose representative is smallest.
+uint64_t referenceMurmurHash64A(const void* key, int len, uint64_t seed)          // src/MurmurHash2.cpp:96-140
+{
+    const uint64_t m = 0xc6a4a7935bd1e995ULL;
+    const int r = 47;
+    uint64_t h = seed ^ (uint64_t(len) * m);
+    const uint8_t* data = static_cast<const uint8_t*>(key);
+    const uint8_t* const end = data + (len / 8) * 8;
+    while(data != end) {
+        uint64_t k;
+        std::memcpy(&k, data, 8); data += 8;
+        k *= m; k ^= k >> r; k *= m;
+        h ^= k; h *= m;
+    }
+    switch(len & 7) {
+        case 7: h ^= uint64_t(data[6]) << 48; [[fallthrough]];
+        case 6: h ^= uint64_t(data[5]) << 40; [[fallthrough]];
+        case 5: h ^= uint64_t(data[4]) << 32; [[fallthrough]];
+        case 4: h ^= uint64_t(data[3]) << 24; [[fallthrough]];
+        case 3: h ^= uint64_t(data[2]) << 16; [[fallthrough]];
+        case 2: h ^= uint64_t(data[1]) << 8; [[fallthrough]];
+        case 1: h ^= uint64_t(data[0]); h *= m;
+    }
+    h ^= h >> r; h *= m; h ^= h >> r;
+    return h;
+}
+struct CoordinatesHash {                                                              // HashTuple<Coordinates>, src/hashArray.hpp:12-18
+    size_t operator()(const std::pair<uint32_t, uint32_t>& v) const { return size_t(referenceMurmurHash64A(&v, sizeof(v), 15741)); }
+};
+// keys: the active cells (iY << 16 | iX), sorted ascending = the reference's cell ids.  Returns the representative of every cell.
+std::vector<uint32_t> referenceComponentRepresentatives(const std::vector<uint32_t>& keys)
+{
+    const uint32_t n = uint32_t(keys.size());
+    std::unordered_map<std::pair<uint32_t, uint32_t>, uint32_t, CoordinatesHash> activeCells;
+    for(uint32_t id = 0; id < n; id++) activeCells.insert(std::make_pair(std::make_pair(keys[id] & 0xffffu, keys[id] >> 16), id));
+    std::vector<uint32_t> rank(n, 0), parent(n);
+    for(uint32_t i = 0; i < n; i++) parent[i] = i;
+    auto findSet = [&](uint32_t v) {                                                 // find_with_full_path_compression
+        uint32_t root = v;
+        while(parent[root] != root) root = parent[root];
+        while(parent[v] != root) { const uint32_t next = parent[v]; parent[v] = root; v = next; }
+        return root;
+    };
+    auto unionSet = [&](uint32_t x, uint32_t y) {                                     // boost::disjoint_sets::union_set -> link_sets
+        uint32_t i = findSet(x), j = findSet(y);
+        if(i == j) return;
+        if(rank[i] > rank[j]) parent[j] = i;
+        else { parent[i] = j; if(rank[i] == rank[j]) ++rank[j]; }
+    };
+    for(const auto& p : activeCells) {
+        const uint32_t iX0 = p.first.first, iY0 = p.first.second;
+        for(int32_t dY = -1; dY <= 1; dY++) {
+            const int32_t iY1 = int32_t(iY0) + dY;
+            if(iY1 < 0) continue;
+            for(int32_t dX = -1; dX <= 1; dX++) {
+                if(dX == 0 && dY == 0) continue;
+                const int32_t iX1 = int32_t(iX0) + dX;
+                if(iX1 < 0) continue;
+                const auto it = activeCells.find(std::make_pair(uint32_t(iX1), uint32_t(iY1)));
+                if(it == activeCells.end()) continue;
+                unionSet(p.second, it->second);
+            }
+        }
+    }
+    std::vector<uint32_t> representative(n);
+    for(uint32_t i = 0; i < n; i++) representative[i] = findSet(i);
+    return representative;
+}
+
+void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount);
+
+// After winnerKernel, before finalizeKernel.  pairClass[k]: the table class candidate k's cells were computed in (CELLS_CLASSES:
+// the HBM-scratch kernel -- such a candidate keeps its tie flag).
+void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t n, uint32_t taskCount, const std::vector<PairDesc>& hostPairs,
+    const std::vector<int>& pairClass, const std::vector<uint8_t>& pairSlotsLog2, const DeviceOptions& opt, uint32_t magicX, uint32_t magicY)
+{
+    hipStream_t stream = ws.stream;
+    std::vector<uint8_t> tie(n);
+    std::vector<uint32_t> winner(n);
+    std::vector<unsigned long long> best(n);
+    std::vector<DpTask> tasks(taskCount);
+    std::vector<DpResult> results(taskCount);
+    HIP_CHECK(hipMemcpyAsync(tie.data(), b.pairTie.data(), n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(winner.data(), b.pairWinner.data(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(best.data(), b.pairBest.data(), n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(tasks.data(), b.tasks.data(), taskCount * sizeof(DpTask), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(results.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    // One chunk of one candidate per tied candidate, by class.
+    std::vector<uint32_t> members;
+    std::vector<CellsChunk> chunks[CELLS_CLASSES];
+    std::vector<uint32_t> chunkPair[CELLS_CLASSES];
+    std::vector<uint32_t> big;                                               // tied candidates of the HBM-scratch kernel
+    for(uint32_t k = 0; k < n; k++) {
+        if(tie[k] && pairClass[k] == CELLS_CLASSES && pairSlotsLog2[k] >= 10) big.push_back(k);
+        if(!tie[k] || pairClass[k] < 0 || pairClass[k] >= CELLS_CLASSES) continue;
+        const int c = pairClass[k];
+        const uint64_t capacity = 1ULL << CELLS_NA_LOG2[c];
+        CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = 1;
+        ch.swapped = hostPairs[k].nx < capacity ? 0 : 1;                      // (either read may be tabled: the cells are the same)
+        if(ch.swapped && hostPairs[k].ny >= capacity) continue;
+        ch.naLog2 = uint32_t(CELLS_NA_LOG2[c]); ch.scLog2 = uint32_t(CELLS_SC_LOG2[c]);
+        members.push_back(k);
+        chunks[c].push_back(ch); chunkPair[c].push_back(k);
+    }
+    if(std::getenv("SHASTA_MI355X_DEBUG")) std::fprintf(stderr, "ties: %zu + %zu candidates to look at again\n", members.size(), big.size());
+    if(members.empty() && big.empty()) return;
+    constexpr uint32_t MAXC = 64 * 2;
+    static_assert(CELLS_Q[0] == 2 && CELLS_Q[1] == 2 && CELLS_Q[2] == 2, "the dump launches use the Q = 2 instance");
+    std::unordered_map<uint32_t, std::vector<uint32_t>> activeOf;              // candidate -> its active cells
+    if(!members.empty()) {
+        const uint32_t total = uint32_t(members.size());
+        b.tieMembers.reserve(total, stream); b.tieChunks.reserve(total, stream); b.tieKeys.reserve(size_t(total) * MAXC, stream); b.tieCounts.reserve(total, stream);
+        HIP_CHECK(hipMemcpyAsync(b.tieMembers.data(), members.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(b.tieCounts.data(), 0xff, total * sizeof(uint32_t), stream));
+        uint32_t offset = 0;
+        std::vector<uint32_t> order;                                         // candidate of dump slot s
+        for(int c = 0; c < CELLS_CLASSES; c++) {
+            if(chunks[c].empty()) continue;
+            const uint32_t count = uint32_t(chunks[c].size());
+            HIP_CHECK(hipMemcpyAsync(b.tieChunks.data() + offset, chunks[c].data(), count * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
+            const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[c], CELLS_SC_LOG2[c], 2, CELLS_WAVES) * sizeof(uint32_t);
+            static std::once_flag attribute;
+            std::call_once(attribute, [] {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            });
+            hipLaunchKernelGGL((align4CellsChunkKernel<2, true>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, stream,
+                (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const CellsChunk*)(b.tieChunks.data() + offset), count, (const uint32_t*)b.tieMembers.data(),
+                opt, magicX, magicY, (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr, b.tieKeys.data() + size_t(offset) * MAXC, b.tieCounts.data() + offset);
+            HIP_CHECK(hipGetLastError());
+            order.insert(order.end(), chunkPair[c].begin(), chunkPair[c].end());
+            offset += count;
+        }
+        std::vector<uint32_t> keys(size_t(total) * MAXC), counts(total);
+        HIP_CHECK(hipMemcpyAsync(keys.data(), b.tieKeys.data(), keys.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(counts.data(), b.tieCounts.data(), total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for(uint32_t slot = 0; slot < total; slot++) {
+            if(counts[slot] == 0xffffffffu || counts[slot] == 0 || counts[slot] > MAXC) continue;
+            activeOf[order[slot]].assign(keys.begin() + size_t(slot) * MAXC, keys.begin() + size_t(slot) * MAXC + counts[slot]);
+        }
+    }
+    // The candidates of the HBM-scratch kernel, a few at a time (their key lists may be long).
+    for(size_t begin = 0; begin < big.size(); ) {
+        std::vector<uint64_t> scratchOffsets, keyOffsets;
+        std::vector<uint8_t> log2s;
+        uint64_t words = 0, keyWords = 0;
+        size_t end = begin;
+        while(end < big.size()) {
+            const int l = pairSlotsLog2[big[end]];
+            const uint64_t need = (9ULL << l) / 2, keyNeed = 1ULL << (l - 1);
+            if(end > begin && (words + need > (1ULL << 31) || keyWords + keyNeed > (1ULL << 28))) break;
+            scratchOffsets.push_back(words); keyOffsets.push_back(keyWords); log2s.push_back(uint8_t(l));
+            words += need; keyWords += keyNeed; ++end;
+        }
+        const uint32_t count = uint32_t(end - begin);
+        b.bigScratch.reserve(words, stream); b.bigOffsets.reserve(2 * size_t(count), stream); b.bigLog2.reserve(count, stream);
+        b.tieMembers.reserve(count, stream); b.tieKeys.reserve(keyWords, stream); b.tieCounts.reserve(count, stream);
+        HIP_CHECK(hipMemcpyAsync(b.tieMembers.data(), big.data() + begin, count * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.bigOffsets.data(), scratchOffsets.data(), count * 8ULL, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.bigOffsets.data() + count, keyOffsets.data(), count * 8ULL, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.bigLog2.data(), log2s.data(), count, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(b.tieCounts.data(), 0xff, count * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL((align4CellsKernel<true, true>), dim3(count), dim3(CELLS_THREADS), 0, stream,
+            (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.tieMembers.data(), count, opt,
+            (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr,
+            b.bigScratch.data(), (const uint64_t*)b.bigOffsets.data(), (const uint8_t*)b.bigLog2.data(),
+            b.tieKeys.data(), (const uint64_t*)(b.bigOffsets.data() + count), b.tieCounts.data());
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> keys(keyWords), counts(count);
+        HIP_CHECK(hipMemcpyAsync(keys.data(), b.tieKeys.data(), keyWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(counts.data(), b.tieCounts.data(), count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for(uint32_t q = 0; q < count; q++) {
+            if(counts[q] == 0xffffffffu || counts[q] == 0 || uint64_t(counts[q]) > (1ULL << (log2s[q] - 1))) continue;
+            activeOf[big[begin + q]].assign(keys.begin() + keyOffsets[q], keys.begin() + keyOffsets[q] + counts[q]);
+        }
+        begin = end;
+    }
+    // Tasks by candidate (only the tied ones matter).
+    std::unordered_map<uint32_t, std::vector<uint32_t>> tasksOf;
+    for(uint32_t t = 0; t < taskCount; t++) if(tie[tasks[t].pair] && results[t].passes) tasksOf[tasks[t].pair].push_back(t);
+    bool changed = false;
+    for(auto& entry : activeOf) {
+        const uint32_t k = entry.first;
+        std::vector<uint32_t>& cells = entry.second;
+        std::sort(cells.begin(), cells.end());
+        const std::vector<uint32_t> representative = referenceComponentRepresentatives(cells);
+        const uint32_t bestCount = uint32_t(best[k] >> 32);
+        uint32_t chosenTask = 0xffffffffu, chosenRepresentative = 0xffffffffu;
+        bool complete = true;
+        for(uint32_t t : tasksOf[k]) {
+            if(results[t].markerCount != bestCount) continue;
+            const auto it = std::lower_bound(cells.begin(), cells.end(), tasks[t].label);
+            if(it == cells.end() || *it != tasks[t].label) { complete = false; break; }
+            const uint32_t r = representative[size_t(it - cells.begin())];
+            if(r < chosenRepresentative) { chosenRepresentative = r; chosenTask = t; }
+        }
+        static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
+        if(debug) std::fprintf(stderr, "ties: candidate %u: %zu active cells, %zu passing tasks, best %u markers, %s, task %u (was %u)\n", k, cells.size(),
+            tasksOf[k].size(), bestCount, complete ? "complete" : "a task's seed cell is not among the active cells", chosenTask, winner[k]);
+        if(!complete || chosenTask == 0xffffffffu) continue;
+        winner[k] = chosenTask; tie[k] = 0; changed = true;
+    }
+    if(changed) {
+        HIP_CHECK(hipMemcpyAsync(b.pairWinner.data(), winner.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.pairTie.data(), tie.data(), n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));                             // the host vectors go out of scope
+    }
 }
 
 uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
@@ -561,6 +784,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         auto phaseMs = [&](std::chrono::steady_clock::time_point from) { return std::chrono::duration<double, std::milli>(phaseClock() - from).count(); };
         double phaseCells = 0., phaseDp = 0., phaseFinish = 0.;
         uint32_t taskCount = 0;
+        std::vector<int> pairClass;                    // method 4: the table class of every candidate's cells (CELLS_CLASSES: HBM scratch)
+        std::vector<uint8_t> pairSlotsLog2;            //           ... and the table size the HBM-scratch kernel last ran it with
+        uint32_t cellsMagicX = 0, cellsMagicY = 0;
         for(;;) {
         if(m3) {
             // Method 3, step 1: every diagonal of the down-sampled pair, then the band of step 2.
@@ -683,7 +909,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 }
                 return CELLS_CLASSES;
             };
-            std::vector<int> pairClass(n);
+            pairClass.assign(n, -1); pairSlotsLog2.assign(n, 0);
             std::vector<CellsChunk> classChunks[CELLS_CLASSES];
             std::vector<uint32_t> members;                             // candidate indices, chunk after chunk
             members.reserve(n);
@@ -741,6 +967,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             // deltaX, deltaY >= 2 here (packedOk fails for 1 x anything >= 2046... and d = 1 gives magic 2^32): guard.
             const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX + 1, 0xffffffffULL));
             const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY + 1, 0xffffffffULL));
+            cellsMagicX = magicX; cellsMagicY = magicY;
             // Every candidate is a member once, plus once per class it climbs to after an overflow.
             const uint64_t memberCapacity = uint64_t(CELLS_CLASSES) * n + 16;
             b.pairList.reserve(memberCapacity, stream);
@@ -835,7 +1062,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                         hipLaunchKernelGGL(align4CellsKernel<true>, dim3(count), dim3(CELLS_THREADS), 0, stream,
                             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), count, opt,
                             b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),
-                            b.bigScratch.data(), (const uint64_t*)b.bigOffsets.data(), (const uint8_t*)b.bigLog2.data()));
+                            b.bigScratch.data(), (const uint64_t*)b.bigOffsets.data(), (const uint8_t*)b.bigLog2.data(),
+                            (uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr));
+                    for(size_t q = begin; q < end; q++) pairSlotsLog2[bigList[q]] = bigLog2[q];
                     HIP_CHECK(hipGetLastError());
                     HIP_CHECK(hipStreamSynchronize(stream));
                     begin = end;
@@ -869,11 +1098,17 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(taskCount) {
             out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats);
             out.hadTasks = true;
+            HIP_CHECK(hipMemsetAsync(b.counters.data() + 12, 0, sizeof(uint32_t), stream));
             SHASTA_TIMED(ctx, "winnerKernel", stream, 0, taskCount,
                 hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
                     (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
-                    (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data()));
+                    (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data(), b.counters.data() + 12));
             HIP_CHECK(hipGetLastError());
+            // Candidates whose best components tie on markerCount: the reference's component order decides (method 4 only:
+            // method 3 has one alignment per candidate).
+            if(!m3 && readDevice(b.counters.data() + 12, stream) != 0) {
+                resolveComponentTies(ctx, ws, b, n, taskCount, hostPairs, pairClass, pairSlotsLog2, opt, cellsMagicX, cellsMagicY);
+            }
         } else {
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
         }

@@ -46,14 +46,18 @@ template<bool BIG> __device__ __forceinline__ uint32_t ld(const uint32_t* p)
 // One workgroup per candidate.  SMALL keeps the cell table (CELL_SLOTS) and the kept-cell
 // list (MAX_CELLS) in LDS; BIG uses a per-candidate region of HBM scratch of 2^slotsLog2
 // table slots (layout: keys[S] vals[S] cKey[S/2] cFlags[S/2] cLabel[S/2] cYMin[S/2] cYMax[S/2]).
-template<bool BIG>
+// DUMP (the second look at a candidate whose best components tie, see align4CellsChunkKernel): instead of DP tasks, the
+// candidate's active cells at activeKeys[activeOffsets[blockIdx.x] ...] (room for half its table slots) and their number in
+// activeCounts[blockIdx.x] (~0 if the tables overflowed).
+template<bool BIG, bool DUMP = false>
 __global__ void __launch_bounds__(CELLS_THREADS)
 align4CellsKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const uint32_t* __restrict__ pairList, uint32_t listCount,
     DeviceOptions opt, DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
     uint8_t* __restrict__ pairFlags,
-    uint32_t* __restrict__ bigScratch, const uint64_t* __restrict__ bigOffsets, const uint8_t* __restrict__ bigSlotsLog2)
+    uint32_t* __restrict__ bigScratch, const uint64_t* __restrict__ bigOffsets, const uint8_t* __restrict__ bigSlotsLog2,
+    uint32_t* __restrict__ activeKeys, const uint64_t* __restrict__ activeOffsets, uint32_t* __restrict__ activeCounts)
 {
     __shared__ uint64_t matchTab[MATCH_SLOTS];
     __shared__ uint32_t sCellKeys[BIG ? 1 : CELL_SLOTS];
@@ -151,6 +155,7 @@ align4CellsKernel(
         }
     }
     __syncthreads();
+    if(DUMP && (sOverflow || sCells == 0)) { if(tid == 0) activeCounts[blockIdx.x] = sOverflow ? 0xffffffffu : 0u; return; }
     if(sOverflow) { if(tid == 0) pairFlags[pair] = (sOverflow == 2) ? PAIR_TOO_LONG : PAIR_RESOURCE; return; }
     const int n = int(sCells);
     if(n == 0) return;
@@ -259,6 +264,18 @@ align4CellsKernel(
         }
         __syncthreads();
         if(!sChanged) break;
+    }
+    if(DUMP) {
+        __syncthreads();
+        if(tid == 0) sChanged = 0;
+        __syncthreads();
+        uint32_t* const out = activeKeys + activeOffsets[blockIdx.x];
+        for(int c = tid; c < n; c += CELLS_THREADS) {
+            if(ld<BIG>(&cLabel[c]) != EMPTY32) out[atomicAdd(&sChanged, 1u)] = ld<BIG>(&cKey[c]);      // (n <= half the slots: the room the host gave)
+        }
+        __syncthreads();
+        if(tid == 0) activeCounts[blockIdx.x] = sChanged;
+        return;
     }
     // iY range of each component, stored at its root cell (the cell whose key is the label).
     for(int c = tid; c < n; c += CELLS_THREADS) {
@@ -387,14 +404,18 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 #else
 #define SHASTA_CELLS_OCCUPANCY            // (the wave64 emulator of tests/emu compiles this file as plain C++)
 #endif
-template<int Q>
+// DUMP (chunks of ONE candidate; the second look at a candidate whose best components tie on markerCount): instead of DP
+// tasks the kernel leaves the candidate's active cells, activeKeys[64 Q blockIdx.x ...] and activeCounts[blockIdx.x] (~0 if the
+// tables overflowed) -- the reference breaks such ties by the order of its union-find representatives, which the host
+// reproduces from the set of active cells (resolveComponentTies, align4.hip).
+template<int Q, bool DUMP = false>
 __global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS) SHASTA_CELLS_OCCUPANCY
 align4CellsChunkKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
     DeviceOptions opt, uint32_t magicX, uint32_t magicY,
     DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
-    uint8_t* __restrict__ pairFlags)
+    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts)
 {
     extern __shared__ uint32_t ldsWords[];
     // Markers whose two buckets were both full when they arrived (the two-choice table runs at two
@@ -471,6 +492,7 @@ align4CellsChunkKernel(
     if(stashed > STASH) {
         // Too many markers of the tabled read share their buckets (a tandem repeat): the whole
         // chunk goes to the next class.
+        if(DUMP) { if(threadIdx.x == 0) activeCounts[blockIdx.x] = 0xffffffffu; return; }
         for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x80);
         return;
     }
@@ -734,13 +756,14 @@ align4CellsChunkKernel(
         const int n = int(scratch[0]);
         if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
         const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
+        if(DUMP && (anyHard || anySoft)) { if(lane == 0) activeCounts[blockIdx.x] = 0xffffffffu; break; }
         if(anyHard || anySoft) {
             // Bits 4-6 carry the reason (cell table full / kept list full / geometry) for diagnostics.
             const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0);
             if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
             break;
         }
-        if(n == 0) break;
+        if(n == 0) { if(DUMP && lane == 0) activeCounts[blockIdx.x] = 0; break; }
         const int nq = (n + WAVE - 1) / WAVE;
 
         // --- kept cells in registers: boundary flags (:424-429 with the corner rules of :530-626) ---
@@ -868,6 +891,16 @@ align4CellsChunkKernel(
         bool anyRemaining = false;
 #pragma unroll
         for(int q = 0; q < Q; q++) { remaining[q] = fwd[q] & bwd[q]; anyRemaining |= remaining[q] != 0; }
+        if(DUMP) {
+            uint32_t base = 0;
+#pragma unroll
+            for(int q = 0; q < Q; q++) {
+                if((remaining[q] >> lane) & 1ULL) activeKeys[size_t(blockIdx.x) * MAXC + base + uint32_t(__popcll(remaining[q] & laneMaskLt()))] = key[q];
+                base += uint32_t(__popcll(remaining[q]));
+            }
+            if(lane == 0) activeCounts[blockIdx.x] = base;
+            break;
+        }
         while(anyRemaining) {
             uint32_t myMin = EMPTY32;
 #pragma unroll

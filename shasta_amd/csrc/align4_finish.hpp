@@ -5,7 +5,7 @@
 
 __global__ void __launch_bounds__(256)
 winnerKernel(const DpTask* __restrict__ tasks, const DpResult* __restrict__ results, uint32_t taskCount,
-    const unsigned long long* __restrict__ pairBest, uint32_t* __restrict__ pairWinner, uint8_t* __restrict__ pairTie)
+    const unsigned long long* __restrict__ pairBest, uint32_t* __restrict__ pairWinner, uint8_t* __restrict__ pairTie, uint32_t* __restrict__ tieCounter)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= taskCount) return;
@@ -15,7 +15,7 @@ winnerKernel(const DpTask* __restrict__ tasks, const DpResult* __restrict__ resu
     const unsigned long long best = pairBest[task.pair];
     const unsigned long long key = ((unsigned long long)r.markerCount << 32) | (unsigned long long)(0xffffffffu - task.label);
     if(key == best) pairWinner[task.pair] = t;
-    else if((key >> 32) == (best >> 32)) pairTie[task.pair] = 1;
+    else if((key >> 32) == (best >> 32)) { pairTie[task.pair] = 1; atomicAdd(tieCounter, 1u); }      // (rare: see resolveComponentTies)
 }
 
 // Per candidate: AlignmentInfo (src/Alignment.cpp:67-113) and the outer filters of

@@ -135,8 +135,8 @@ from tests import adversarial
 
 
 @pytest.mark.parametrize("name", adversarial.READ_SET_NAMES[:-1])      # the long reads are too slow on CPU fibers
-def test_adversarial_read_sets_through_both_aligners(emu_lib, oracle_lib, name):
-    adversarial.aligner_case(emu_lib, oracle_lib, name, long_reads=False)
+def test_adversarial_read_sets_through_both_aligners(emu_lib, oracle_lib, ref_lib, name):
+    adversarial.aligner_case(emu_lib, oracle_lib, name, long_reads=False, ref_lib=ref_lib)
 
 
 def test_adversarial_lowhash0(emu_lib, oracle_lib):

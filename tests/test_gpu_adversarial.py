@@ -9,8 +9,8 @@ from tests import adversarial
 
 
 @pytest.mark.parametrize("name", adversarial.READ_SET_NAMES)
-def test_adversarial_read_sets_through_both_aligners(gpu_lib, oracle_lib, name):
-    adversarial.aligner_case(gpu_lib, oracle_lib, name)
+def test_adversarial_read_sets_through_both_aligners(gpu_lib, oracle_lib, ref_lib, name):
+    adversarial.aligner_case(gpu_lib, oracle_lib, name, ref_lib=ref_lib)
 
 
 @pytest.mark.parametrize("name", adversarial.LOWHASH_CASE_NAMES)
