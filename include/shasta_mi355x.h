@@ -143,9 +143,11 @@ enum {
     SHASTA_ALIGN_EMPTY         = 2,  /* Align4 found no acceptable component        */
     SHASTA_ALIGN_SKIPPED       = 3,  /* resource limit: the reference's "skip+log"  */
                                      /* lane (src/AssemblerAlign.cpp:419-435)       */
-    SHASTA_ALIGN_TIE_FLAG      = 0x80 /* or-ed in: two components tied on           */
-                                     /* markerCount; reference order is libstdc++   */
-                                     /* hash-order dependent (src/Align4.cpp:792-872)*/
+    SHASTA_ALIGN_TIE_FLAG      = 0x80 /* or-ed in: two components tied on markerCount */
+                                     /* (the reference takes the first in its union- */
+                                     /* find order, src/Align4.cpp:792-872) and the  */
+                                     /* tie could not be resolved the reference's way */
+                                     /* (normally it is: DESIGN.md section 2)         */
 };
 
 typedef struct shasta_align4_result {
