@@ -194,7 +194,7 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
     MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
     // Booked under the template instance that runs, the name a profiler shows.
     // Algorithmic bytes: 4 (nx + ny) per candidate, summed by the caller; work = candidates.
-    const char* const name = Q == 2 ? "align4CellsChunkKernel<2>" : "align4CellsChunkKernel<4>";
+    const char* const name = Q == 2 ? "align4CellsChunkKernel<2, false>" : "align4CellsChunkKernel<4, false>";
     SHASTA_TIMED(ctx, name, ws.stream, kmerIdBytes, candidateCount,
         hipLaunchKernelGGL((align4CellsChunkKernel<Q>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, ws.stream,
             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
@@ -1058,7 +1058,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     HIP_CHECK(hipMemcpyAsync(b.bigLog2.data(), bigLog2.data() + begin, count, hipMemcpyHostToDevice, stream));
                     uint64_t bigBytes = 0;
                     for(size_t q = begin; q < end; q++) bigBytes += 4ULL * (uint64_t(hostPairs[bigList[q]].nx) + hostPairs[bigList[q]].ny);
-                    SHASTA_TIMED(ctx, "align4CellsKernel<true>", stream, bigBytes, count,
+                    SHASTA_TIMED(ctx, "align4CellsKernel<true, false>", stream, bigBytes, count,
                         hipLaunchKernelGGL(align4CellsKernel<true>, dim3(count), dim3(CELLS_THREADS), 0, stream,
                             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const uint32_t*)b.pairList.data(), count, opt,
                             b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(),

@@ -15,7 +15,7 @@ from shasta_amd import abi
 FAKE_TABLE = {
     "hashWindowsKernel<4>": {"seconds": 0.02, "launches": 20, "bytes": 20 * 1_250_000_000, "work": 20 * 300_000_000},
     "radix sort of low-hash records": {"seconds": 0.004, "launches": 20, "bytes": 20 * 300_000_000, "work": 20 * 3_000_000},
-    "align4CellsChunkKernel<2>": {"seconds": 0.22, "launches": 64, "bytes": 64 * 500_000_000, "work": 3_000_000},
+    "align4CellsChunkKernel<2, false>": {"seconds": 0.22, "launches": 64, "bytes": 64 * 500_000_000, "work": 3_000_000},
     "bandedDpForwardKernel<16, 2>": {"seconds": 0.08, "launches": 32, "bytes": 32 * 296_000_000, "work": int(3e10)},
     "bandedDpForwardKernel<16, 4>": {"seconds": 0.28, "launches": 32, "bytes": 32 * 1_186_000_000, "work": int(2.2e11)},
     "bandedDpForwardKernel<32, 4>": {"seconds": 0.20, "launches": 32, "bytes": 32 * 353_000_000, "work": int(1.1e11)},
