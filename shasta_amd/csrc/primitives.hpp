@@ -26,23 +26,6 @@ __device__ __forceinline__ uint32_t reverseComplementKmerId(uint32_t kmerId, uin
     return ((__brev(high) >> (32u - k)) << k) | (__brev(low) >> (32u - k));
 }
 
-// v_writelane_b32: lane `lane` of the result holds `value` (uniform across the wavefront), every other lane keeps `old`.
-// The compiler has no builtin for it; the wave64 emulator of tests/emu supplies its own (SHASTA_WRITELANE_DEFINED).
-#ifndef SHASTA_WRITELANE_DEFINED
-// `lane` must be a constant by the time the code is generated (a literal, or an expression of unrolled loop counters).
-__device__ __forceinline__ uint32_t writeLaneImmediate(uint32_t value, int lane, uint32_t old)
-{
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "i"(lane));
-    return old;
-}
-__device__ __forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uint32_t old)
-{
-    // One scalar register per VALU instruction on gfx9 (constant bus): the lane select goes through M0.
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(lane) : "m0");
-    return old;
-}
-#endif
-
 // v_pk_min_u16: the minimum of the two 16-bit halves of a and b, half by half (the compiler splits the generic vector form into
 // two 16-bit operations).  The wave64 emulator supplies its own (SHASTA_PACKED_MIN_DEFINED).
 #ifndef SHASTA_PACKED_MIN_DEFINED

@@ -236,11 +236,6 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 {
     return uint32_t(((uint64_t(hi) << 32) | uint64_t(lo)) >> (8u * (c & 3u)));
 }
-// v_writelane_b32 (shasta_amd/csrc/primitives.hpp uses inline assembly for it): lane `lane` of the result holds `value`
-// (uniform across the wavefront), every other lane keeps `old`.
-#define SHASTA_WRITELANE_DEFINED 1
-__forceinline__ uint32_t writeLane(uint32_t value, uint32_t lane, uint32_t old) { return (uint32_t(threadIdx.x) & 63u) == (lane & 63u) ? value : old; }
-__forceinline__ uint32_t writeLaneImmediate(uint32_t value, int lane, uint32_t old) { return writeLane(value, uint32_t(lane), old); }
 // v_cndmask_b32 on a ballot (inline assembly in primitives.hpp).
 #define SHASTA_LANE_SELECT_DEFINED 1
 __forceinline__ uint32_t laneSelect(uint64_t laneMask, uint32_t ifSet, uint32_t ifClear) { return ((laneMask >> (uint32_t(threadIdx.x) & 63u)) & 1ull) ? ifSet : ifClear; }
