@@ -1197,6 +1197,49 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
     };
 
+    // Borrowed results live in arrays the context keeps from call to call: a batch whose predecessors are all done is copied
+    // to its place in them at once, by the worker that finished it, while the other workers' batches are still on the device
+    // (the positions of a batch are the sums over the batches before it).  A batch that does not fit the arrays as they are
+    // (first call, or more output than last time) waits for the end, where the arrays grow.
+    struct Placement { uint64_t rowBase = 0, byteBase = 0, ordBase = 0; bool placed = false; };
+    std::vector<Placement> placements(batchCount);
+    std::vector<char> batchDone(batchCount, 0);
+    std::mutex placeMutex;
+    uint64_t nextToPlace = 0, placeRows = 0, placeBytes = 0, placeOrdinals = 0;
+    bool placeEarly = borrowed;
+    if(placeEarly) {
+        // Rows and offsets have a bound (one per candidate); bytes and ordinals take what the arrays already hold.
+        if(store.rows.size() < candidateCount) store.rows.resize(std::max<uint64_t>(1, candidateCount));
+        if(store.compressedToc.size() < candidateCount + 1) store.compressedToc.resize(candidateCount + 1);
+        if(wantOrdinals && store.ordinalsToc.size() < candidateCount + 1) store.ordinalsToc.resize(candidateCount + 1);
+    }
+    auto copyBatch = [&](uint64_t k, const Placement& at, shasta_alignment_data* rows, uint64_t* toc, uint8_t* bytes, uint64_t* ordinalsToc, uint32_t* ordinals) {
+        const BatchOutput& o = outputs[k];
+        if(!o.rows.empty()) std::memcpy(rows + at.rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
+        if(!o.bytes.empty()) std::memcpy(bytes + at.byteBase, o.bytes.data(), o.bytes.size());
+        for(size_t q = 0; q < o.tocEnds.size(); q++) toc[at.rowBase + q + 1] = at.byteBase + o.tocEnds[q];
+        if(wantOrdinals) {
+            if(!o.ordinals.empty()) std::memcpy(ordinals + 2 * at.ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
+            for(size_t q = 1; q < o.ordToc.size(); q++) ordinalsToc[k * BATCH + q] = at.ordBase + o.ordToc[q];
+        }
+    };
+    auto placeFinished = [&](uint64_t finished) {
+        std::vector<uint64_t> mine;
+        {
+            std::lock_guard<std::mutex> lock(placeMutex);
+            batchDone[finished] = 1;
+            while(nextToPlace < batchCount && batchDone[nextToPlace]) {
+                const BatchOutput& o = outputs[nextToPlace];
+                Placement& at = placements[nextToPlace];
+                at.rowBase = placeRows; at.byteBase = placeBytes; at.ordBase = placeOrdinals;
+                placeRows += o.rows.size(); placeBytes += o.bytes.size(); placeOrdinals += o.ordinals.size() / 2;
+                if(placeEarly && (placeBytes > store.bytes.size() || (wantOrdinals && 2 * placeOrdinals > store.ordinals.size()))) placeEarly = false;
+                if(placeEarly) { at.placed = true; mine.push_back(nextToPlace); }
+                ++nextToPlace;
+            }
+        }
+        for(uint64_t k : mine) copyBatch(k, placements[k], store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data());
+    };
     std::atomic<uint64_t> nextBatch(0);
     auto workerLoop = [&](int k) {
         try {
@@ -1205,6 +1248,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 const uint64_t batchIndex = nextBatch.fetch_add(1);
                 if(batchIndex >= batchCount) break;
                 processBatch(workers[k], batchIndex);
+                placeFinished(batchIndex);
             }
         } catch(const std::exception& e) {
             workers[k].error = e.what();
@@ -1250,12 +1294,15 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         dpCellsTotal += o.dpCells; kmerIdBytes += o.kmerIdBytes; alignedBytes += o.alignedBytes;
     }
     if(borrowed) {
-        store.rows.resize(std::max<uint64_t>(1, rowTotal)); store.compressedToc.resize(rowTotal + 1);
-        store.bytes.resize(std::max<uint64_t>(1, byteTotalAll));
+        // (grow only: the arrays keep their size from call to call so that batches can be placed early next time)
+        if(store.rows.size() < std::max<uint64_t>(1, rowTotal)) store.rows.resize(std::max<uint64_t>(1, rowTotal));
+        if(store.compressedToc.size() < rowTotal + 1) store.compressedToc.resize(rowTotal + 1);
+        if(store.bytes.size() < std::max<uint64_t>(1, byteTotalAll)) store.bytes.resize(std::max<uint64_t>(1, byteTotalAll) + byteTotalAll / 16);
         result.alignmentData = store.rows.data(); result.compressedToc = store.compressedToc.data();
         result.compressedData = store.bytes.data(); result.status = store.status.data();
         if(wantOrdinals) {
-            store.ordinalsToc.resize(candidateCount + 1); store.ordinals.resize(std::max<uint64_t>(1, 2 * ordTotalAll));
+            if(store.ordinalsToc.size() < candidateCount + 1) store.ordinalsToc.resize(candidateCount + 1);
+            if(store.ordinals.size() < std::max<uint64_t>(1, 2 * ordTotalAll)) store.ordinals.resize(std::max<uint64_t>(1, 2 * ordTotalAll) + ordTotalAll / 8);
             result.ordinalsToc = store.ordinalsToc.data(); result.ordinals = store.ordinals.data();
             result.ordinalsToc[0] = 0;
         }
@@ -1274,29 +1321,18 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
     }
     result.compressedToc[0] = 0;
-    // Every batch's share of the output arrays is known now: the copies (a few hundred megabytes) run on as many
-    // host threads as there were workers instead of one.
-    std::vector<uint64_t> rowBases(batchCount + 1, 0), byteBases(batchCount + 1, 0), ordBases(batchCount + 1, 0);
-    for(uint64_t k = 0; k < batchCount; k++) {
-        rowBases[k + 1] = rowBases[k] + outputs[k].rows.size();
-        byteBases[k + 1] = byteBases[k] + outputs[k].bytes.size();
-        ordBases[k + 1] = ordBases[k] + outputs[k].ordinals.size() / 2;
-    }
+    // What was not placed early: every batch's share of the output arrays is known now, the copies (a few hundred megabytes when
+    // it is all of them) run on as many host threads as there were workers instead of one.
+    MI355X_ASSERT(nextToPlace == batchCount && placeRows == rowTotal && placeBytes == byteTotalAll);
     auto assemble = [&](uint64_t first, uint64_t stride) {
         for(uint64_t k = first; k < batchCount; k += stride) {
-            const BatchOutput& o = outputs[k];
-            const uint64_t rowBase = rowBases[k], byteBase = byteBases[k], ordBase = ordBases[k];
-            if(!o.rows.empty()) std::memcpy(result.alignmentData + rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
-            if(!o.bytes.empty()) std::memcpy(result.compressedData + byteBase, o.bytes.data(), o.bytes.size());
-            for(size_t q = 0; q < o.tocEnds.size(); q++) result.compressedToc[rowBase + q + 1] = byteBase + o.tocEnds[q];
-            if(wantOrdinals) {
-                if(!o.ordinals.empty()) std::memcpy(result.ordinals + 2 * ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
-                for(size_t q = 1; q < o.ordToc.size(); q++) result.ordinalsToc[k * BATCH + q] = ordBase + o.ordToc[q];
-            }
+            if(!placements[k].placed) copyBatch(k, placements[k], result.alignmentData, result.compressedToc, result.compressedData, result.ordinalsToc, result.ordinals);
         }
     };
     {
-        const uint64_t threads = std::min<uint64_t>(uint64_t(workerCount), std::max<uint64_t>(1, batchCount));
+        uint64_t left = 0;
+        for(const Placement& at : placements) left += at.placed ? 0 : 1;
+        const uint64_t threads = std::min<uint64_t>(uint64_t(workerCount), std::max<uint64_t>(1, left));
         std::vector<std::thread> others;
         for(uint64_t k = 1; k < threads; k++) others.emplace_back(assemble, k, threads);
         assemble(0, threads);

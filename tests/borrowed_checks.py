@@ -1,0 +1,38 @@
+"""Borrowed aligner results (align4_run_borrowed) over SEVERAL batches: a batch whose predecessors are done is copied into the
+context's arrays while later batches are still running; the result must equal the owned one, call after call (the second call
+finds arrays sized by the first and places every batch early; a third, larger call outgrows them again).
+Run in a process of its own (the batch size is read once per process):
+    SHASTA_MI355X_ALIGN_BATCH_LOG2=10 python -m tests.borrowed_checks <library.so>"""
+import sys
+
+import numpy as np
+
+
+def main(path):
+    from shasta_amd import abi, lib as libmod
+    from tests import support
+    lib = libmod.Library(path)
+    toc, kmer, data7 = support.small_marker_set(n_reads=160, genome_markers=9000, seed=77)
+    p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=40, minFrequency=1)
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    with lib.context(0) as ctx:
+        ctx.set_kmer_ids(toc, kmer)
+        cand = ctx.lowhash0(p).candidates
+        assert len(cand) > 1300, len(cand)                    # two batches of 1024
+        for count, wants in ((1100, (False,)), (1100, (True,)), (1300, (True,)), (300, (False,))):
+            part = cand[:count]
+            for want in wants:
+                owned = ctx.align4(part, o, want_ordinals=want)
+                kept = [owned.status.copy(), owned.info_table(), owned.compressed_toc.copy(), owned.compressed_data.copy(),
+                        None if not want else owned.ordinals.copy()]
+                borrowed = ctx.align4(part, o, want_ordinals=want, borrow=True)
+                assert np.array_equal(borrowed.status, kept[0]) and np.array_equal(borrowed.info_table(), kept[1])
+                assert np.array_equal(borrowed.compressed_toc, kept[2]) and np.array_equal(borrowed.compressed_data, kept[3])
+                if want:
+                    assert np.array_equal(borrowed.ordinals, kept[4])
+                del borrowed
+    print("borrowed results equal owned results")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

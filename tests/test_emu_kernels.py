@@ -94,6 +94,14 @@ def test_align3_context_paths(emu_lib, oracle_lib):
     align3_checks.context_paths(emu_lib, oracle_lib)
 
 
+def test_borrowed_results_over_several_batches(emu_lib):
+    # (a process of its own: the batch size is read once per process)
+    import subprocess, sys
+    env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10")
+    out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", emu_lib.path], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_candidate_and_alignment_tables_and_read_graph_selection(emu_lib):
     from tests import table_checks
     table_checks.check(emu_lib)
