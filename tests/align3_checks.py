@@ -72,7 +72,7 @@ def rejected_options(lib):
     assert len(out.alignment_data) == 0 and len(out.status) == 0
 
 
-def long_reads(lib, oracle_lib, seed=41, mean_markers=18000.0, factors=(0.5, 0.1)):
+def long_reads(lib, oracle_lib, seed=41, mean_markers=18000.0, factors=(0.5, 0.1), cases=(0, 1)):
     """Step 1 of pairs whose down-sampled matrix has more diagonals than a register-resident DP task holds (1024: the
     LDS-row kernel) and more than its LDS rows hold (8192: rows in HBM scratch) -- the reference has no limit there."""
     from shasta_amd import synthetic
@@ -82,7 +82,7 @@ def long_reads(lib, oracle_lib, seed=41, mean_markers=18000.0, factors=(0.5, 0.1
     order = np.argsort(-lengths)
     a, b, c = (int(x) for x in order[:3])
     cand = abi.make_pairs([min(a, b), min(a, c), min(b, c)], [max(a, b), max(a, c), max(b, c)], [1, 1, 0])
-    for kw, least in ((dict(downsamplingFactor=factors[0], minAlignedMarkerCount=40), 8192), (dict(downsamplingFactor=factors[1], minAlignedMarkerCount=40), 1024)):
+    for kw, least in [((dict(downsamplingFactor=factors[0], minAlignedMarkerCount=40), 8192), (dict(downsamplingFactor=factors[1], minAlignedMarkerCount=40), 1024))[c] for c in cases]:
         o = abi.default_align3_options(**kw)
         ref = oracle_lib.align3_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
         out = lib.align3_batch(toc, data7, cand, o, want_ordinals=True)

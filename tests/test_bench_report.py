@@ -111,7 +111,7 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "150", "--steps", "1", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "150", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
