@@ -454,8 +454,7 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
             const uint32_t count = uint32_t(chunks[c].size());
             HIP_CHECK(hipMemcpyAsync(b.tieChunks.data() + offset, chunks[c].data(), count * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
             const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[c], CELLS_SC_LOG2[c], 2, CELLS_WAVES) * sizeof(uint32_t);
-            static std::once_flag attribute;
-            std::call_once(attribute, [] {
+            std::call_once(ctx.cellsDumpLdsAttribute, [] {
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             });
             hipLaunchKernelGGL((align4CellsChunkKernel<2, true>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, stream,
