@@ -83,8 +83,7 @@ void palindromicScreen(Context& ctx, uint64_t deltaThreshold, uint32_t* bound)
     const size_t ldsBytes = size_t(SCREEN_WAVES) * (64 + 2 * size_t(deltaThreshold)) * sizeof(uint32_t);
     if(ldsBytes > 48 * 1024) {
         // Above the default limit of dynamic LDS per workgroup (the largest window is 132 KB of gfx950's 160 KB).
-        static std::once_flag attributeOnce;
-        std::call_once(attributeOnce, [] {
+        std::call_once(ctx.palindromicLdsAttribute, [] {                    // per context = per device
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&palindromicScreenKernel),
                 hipFuncAttributeMaxDynamicSharedMemorySize, int(size_t(SCREEN_WAVES) * (64 + 2 * 4096) * sizeof(uint32_t))));
         });
