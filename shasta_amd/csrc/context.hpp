@@ -37,6 +37,7 @@ struct Context {
     std::shared_ptr<void> alignScratch[ALIGN_MAX_WORKERS];
     std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress
+    std::shared_ptr<void> lowhashBuffers;    // the last finished job, kept for its device allocations (the next job adopts them)
     uint64_t lowhashRecordsHint = 0, lowhashPairsHint = 0;   // capacities the last jobs needed (first guesses of the next)
     std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
     // Kernels that need more dynamic LDS than the default get the attribute once per context, i.e. on this context's device

@@ -530,6 +530,7 @@ Context::~Context()
     (void)hipSetDevice(device);
     for(auto& scratch : alignScratch) scratch.reset();
     lowhashJob.reset();
+    lowhashBuffers.reset();
     for(hipStream_t w : workerStream) if(w) (void)hipStreamDestroy(w);
     for(hipStream_t w : wideStream) if(w) (void)hipStreamDestroy(w);
     if(stream) (void)hipStreamDestroy(stream);
@@ -698,7 +699,28 @@ struct LowHash0Job {
 
     uint64_t* pairKeys() { return pairsInB ? pairKeysB.data() : pairKeysA.data(); }
     uint32_t* pairTags() { return pairsInB ? pairTagsB.data() : pairTagsA.data(); }
+    // The device allocations of a finished job (the context keeps it for that): a call does not allocate and free some thirty
+    // buffers of hundreds of megabytes between its two events (that was most of the 5 ms between the kernels' 16 ms and the
+    // call's 21, and an occasional 40 ms in the second call after a context was made).
+    void adoptBuffers(LowHash0Job& old)
+    {
+        recKeysA.swap(old.recKeysA); recKeysB.swap(old.recKeysB); pairTagsA.swap(old.pairTagsA); pairTagsB.swap(old.pairTagsB);
+        flags.swap(old.flags); pos.swap(old.pos); starts.swap(old.starts); scanTemp32.swap(old.scanTemp32); boundKeys32.swap(old.boundKeys32);
+        recValsA.swap(old.recValsA); recValsB.swap(old.recValsB); pairKeysA.swap(old.pairKeysA); pairKeysB.swap(old.pairKeysB);
+        iterKeysA.swap(old.iterKeysA); iterKeysB.swap(old.iterKeysB); pairCounts.swap(old.pairCounts); scanTemp64.swap(old.scanTemp64);
+        boundKeys64.swap(old.boundKeys64); boundOut.swap(old.boundOut);
+        counters.swap(old.counters); stats.swap(old.stats); sizeHist.swap(old.sizeHist); iterationTable.swap(old.iterationTable);
+        overflowSizes.swap(old.overflowSizes); highPerIteration.swap(old.highPerIteration); totalPerIteration.swap(old.totalPerIteration);
+        candidatesDevice.swap(old.candidatesDevice);
+    }
 };
+
+// The job is over: its allocations stay with the context for the next one.
+void retireJob(Context& ctx)
+{
+    if(ctx.lowhashJob) ctx.lowhashBuffers = ctx.lowhashJob;
+    ctx.lowhashJob.reset();
+}
 
 namespace {
 LowHash0Job& jobOf(Context& ctx)
@@ -712,6 +734,14 @@ void reserveIterationRows(LowHash0Job& job, uint64_t rows, hipStream_t stream)
 {
     if(rows <= job.histRows) return;
     const uint64_t newRows = std::max<uint64_t>(rows, 2 * job.histRows);
+    if(job.histRows == 0 && job.sizeHist.capacity() >= newRows * SIZE_HIST_CAP && job.iterationTable.capacity() >= newRows * 4) {
+        // A new job in the allocations of the previous one: they only need clearing.
+        HIP_CHECK(hipMemsetAsync(job.sizeHist.data(), 0, newRows * SIZE_HIST_CAP * sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(job.iterationTable.data(), 0, newRows * 4 * sizeof(unsigned long long), stream));
+        job.highPerIteration.reserve(newRows, stream); job.totalPerIteration.reserve(newRows, stream);
+        job.histRows = newRows;
+        return;
+    }
     DeviceBuffer<unsigned long long> hist, table;
     hist.reserve(newRows * SIZE_HIST_CAP, stream); table.reserve(newRows * 4, stream);
     HIP_CHECK(hipMemsetAsync(hist.data(), 0, newRows * SIZE_HIST_CAP * sizeof(unsigned long long), stream));
@@ -865,6 +895,7 @@ void lowhash0Begin(Context& ctx, const shasta_lowhash0_params& p, int rank, int 
     if(world < 1 || rank < 0 || rank >= world) throw std::runtime_error("LowHash0: invalid rank / world size.");
     auto jobPtr = std::make_shared<LowHash0Job>();
     LowHash0Job& job = *jobPtr;
+    if(ctx.lowhashBuffers) { job.adoptBuffers(*static_cast<LowHash0Job*>(ctx.lowhashBuffers.get())); ctx.lowhashBuffers.reset(); }
     job.p = p; job.rank = rank; job.world = world;
     job.boundaries.assign(size_t(world) + 1, 0);
     if(readBoundaries) job.boundaries.assign(readBoundaries, readBoundaries + world + 1);
@@ -1073,7 +1104,7 @@ void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<s
     HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, job.stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     ctx.lowhashPairsHint = std::max(ctx.lowhashPairsHint, job.pairCount + job.pairCount / 8);
-    ctx.lowhashJob.reset();
+    retireJob(ctx);
 }
 
 // The whole of LowHash0::LowHash0 on one GPU.
@@ -1137,7 +1168,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
                 const uint64_t iterationsDone = std::max<uint64_t>(1, job.iterations);
                 const uint64_t planned = p.minHashIterationCount ? p.minHashIterationCount : 2 * iterationsDone;
                 ctx.lowhashPairsHint = std::max<uint64_t>(ctx.lowhashPairsHint, (host[C_PAIRS] / iterationsDone + 1) * planned * 5 / 4);
-                ctx.lowhashJob.reset();
+                retireJob(ctx);
                 continue;
             }
             if(host[C_OVERFLOW] > LowHash0Job::overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");

@@ -196,3 +196,18 @@ def test_several_devices_behind_one_call(emu_lib, oracle_lib):
     from tests import group_checks
     assert group_checks.lowhash0_and_aligners(emu_lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_reads=160, limit=300) == 4
     group_checks.errors_do_not_hang(emu_lib)
+
+
+def test_lowhash0_calls_of_one_context_share_their_allocations(emu_lib, oracle_lib):
+    # A context keeps the device allocations of its last LowHash0 job for the next one: different parameters in turn
+    # (more and fewer records, more and fewer iterations, a dynamic iteration count) must each equal the oracle.
+    toc, kmer, data7 = support.small_marker_set(n_reads=120, genome_markers=8000, seed=61)
+    cases = [abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30),
+             abi.default_lowhash0_params(m=3, hashFraction=0.05, minHashIterationCount=4, minBucketSize=2, maxBucketSize=60, minFrequency=1),
+             abi.default_lowhash0_params(minHashIterationCount=0, alignmentCandidatesPerRead=6.0, minBucketSize=2, maxBucketSize=30),
+             abi.default_lowhash0_params(m=5, hashFraction=0.002, minHashIterationCount=25, minBucketSize=2, maxBucketSize=30, minFrequency=1),
+             abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)]
+    with emu_lib.context(0) as ctx:
+        ctx.set_kmer_ids(toc, kmer)
+        for p in cases:
+            support.same_lowhash(ctx.lowhash0(p), oracle_lib.lowhash0(toc, data7, None, p))
