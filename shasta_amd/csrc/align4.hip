@@ -400,9 +400,6 @@ std::vector<uint32_t> referenceComponentRepresentatives(const std::vector<uint32
     return representative;
 }
 
-void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
-    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount);
-
 // After winnerKernel, before finalizeKernel.  pairClass[k]: the table class candidate k's cells were computed in (CELLS_CLASSES:
 // the HBM-scratch kernel -- such a candidate keeps its tie flag).
 void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t n, uint32_t taskCount, const std::vector<PairDesc>& hostPairs,
