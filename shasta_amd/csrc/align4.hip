@@ -932,12 +932,31 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     Keyed kd; kd.tabled = sw ? pd.begin1 : pd.begin0; kd.pair = q; kd.cls = uint8_t(c); kd.swapped = sw ? 1 : 0;
                     keyed.push_back(kd);
                 }
-                std::sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) {
-                    if(a.swapped != b.swapped) return a.swapped < b.swapped;
-                    if(a.tabled != b.tabled) return a.tabled < b.tabled;
-                    if(a.cls != b.cls) return a.cls < b.cls;
-                    return a.pair < b.pair;
-                });
+                // Order: (swapped, tabled read, class, candidate).  The candidates arrive in ascending order, so a STABLE sort on the
+                // composite key (swapped | tabled | class) is that order: an LSD radix sort with byte digits over the bits the
+                // key uses -- 4 ms for a batch where std::sort with a four-field comparison took 21 (a sixth of a step for a
+                // worker, and at the start of a call every worker does this before its first kernel can start).
+                {
+                    uint64_t maxTabled = 0;
+                    for(const Keyed& kd : keyed) maxTabled = std::max(maxTabled, kd.tabled);
+                    int tabledBits = 1;
+                    while(tabledBits < 58 && (maxTabled >> tabledBits) != 0) ++tabledBits;
+                    const int keyBits = 1 + tabledBits + 2;                     // swapped | tabled | class (CELLS_CLASSES <= 4)
+                    static_assert(CELLS_CLASSES <= 4, "two bits of class in the sort key");
+                    std::vector<uint64_t> keyA(keyed.size()), keyB(keyed.size());
+                    std::vector<Keyed> other(keyed.size());
+                    for(size_t k = 0; k < keyed.size(); k++) keyA[k] = (uint64_t(keyed[k].swapped) << (tabledBits + 2)) | (keyed[k].tabled << 2) | uint64_t(keyed[k].cls);
+                    for(int shift = 0; shift < keyBits; shift += 8) {
+                        size_t counts[257] = {0};
+                        for(uint64_t key : keyA) ++counts[((key >> shift) & 0xff) + 1];
+                        for(int d = 0; d < 256; d++) counts[d + 1] += counts[d];
+                        for(size_t k = 0; k < keyed.size(); k++) {
+                            const size_t to = counts[(keyA[k] >> shift) & 0xff]++;
+                            keyB[to] = keyA[k]; other[to] = keyed[k];
+                        }
+                        keyA.swap(keyB); keyed.swap(other);
+                    }
+                }
                 std::vector<uint32_t> list;
                 for(size_t k = 0; k < keyed.size(); ) {
                     size_t e = k + 1;
