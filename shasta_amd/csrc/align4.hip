@@ -133,7 +133,24 @@ struct BatchScratch {
     DeviceBuffer<WideTask> wideTasks;           //                         pairs with more than 1024 diagonals
     DeviceBuffer<int32_t> hugeRows;             //                         the three anti-diagonals of the pairs with more than 8192 diagonals
     DeviceBuffer<WideEnd> wideEnds;
+    // (worker scratch only) all the buffers above, for raiseToMarks
+    std::vector<SharedCapacityMember*> sharedBuffers;
+    void raiseToMarks(hipStream_t stream) { for(SharedCapacityMember* m : sharedBuffers) m->raiseToMark(stream); }
 };
+
+// The scratch of a host worker: each of its buffers shares a high-water mark with the same buffer of the other workers.
+std::shared_ptr<BatchScratch> makeWorkerScratch(SharedCapacities& shared)
+{
+    std::vector<SharedCapacityMember*> members;
+    SharedCapacityBinding binding{&shared, &members, 0};
+    struct Bound {
+        Bound(SharedCapacityBinding* b) { sharedCapacityBinding = b; }
+        ~Bound() { sharedCapacityBinding = nullptr; }
+    } bound(&binding);
+    std::shared_ptr<BatchScratch> scratch = std::make_shared<BatchScratch>();
+    scratch->sharedBuffers = std::move(members);
+    return scratch;
+}
 
 // A host worker's stream and sort workspace (two workers pipeline the batches of one call).
 // `wide` is a side stream for the few wide-band DP tasks (one wavefront each, latency-bound): they
@@ -715,7 +732,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     std::vector<Worker> workers;
     workers.resize(size_t(workerCount));
     for(int k = 0; k < workerCount; k++) {
-        if(!ctx.alignScratch[k]) ctx.alignScratch[k] = std::make_shared<BatchScratch>();
+        if(!ctx.alignScratch[k]) ctx.alignScratch[k] = makeWorkerScratch(ctx.alignCapacities);
         if(k > 0 && !ctx.workerStream[k]) HIP_CHECK(hipStreamCreateWithFlags(&ctx.workerStream[k], hipStreamNonBlocking));
         workers[k].stream = k == 0 ? ctx.stream : ctx.workerStream[k];
         workers[k].sortWs = k == 0 ? &ctx.sortWs : &ctx.workerSortWs[k];
@@ -755,6 +772,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
         // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
         // SHASTA_MI355X_INITIAL_TASKS overrides the first guess (tests use it to force the second run).
+        b.raiseToMarks(stream);          // what other workers' batches needed so far: grown to now, not in the middle of the batch
         uint32_t taskCapacity = 8 * n + 1024;
         if(const char* e = std::getenv("SHASTA_MI355X_INITIAL_TASKS")) taskCapacity = uint32_t(std::max(1L, std::atol(e)));
         b.pairs.reserve(n, stream); b.candidates.reserve(n, stream); b.tasks.reserve(taskCapacity, stream);

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
@@ -43,11 +45,46 @@ inline uint64_t referenceDoubleToUint64(double x)
     return cvttsd2si(x);
 }
 
+// Buffers that play the same role in the scratch of several host workers share a high-water mark: what one worker had to
+// grow to, the others grow to at the start of their next batch (raiseToMark) instead of each finding out in the middle of one.
+// hipFree waits for the whole device, so a reallocation stalls every worker's stream; with the marks the reallocations of a
+// repeated workload end after its first pass.  A buffer is bound to the mark of its position when it is constructed while
+// a SharedCapacityBinding is active on the thread (makeWorkerScratch in align4.hip); otherwise it has none.
+class SharedCapacityMember {
+public:
+    virtual void raiseToMark(hipStream_t stream) = 0;
+protected:
+    ~SharedCapacityMember() = default;
+};
+struct SharedCapacities {
+    static constexpr int MAX_BUFFERS = 128;
+    std::atomic<size_t> marks[MAX_BUFFERS];
+    SharedCapacities() { for(auto& m : marks) m.store(0); }
+};
+struct SharedCapacityBinding { SharedCapacities* shared; std::vector<SharedCapacityMember*>* members; int next; };
+inline thread_local SharedCapacityBinding* sharedCapacityBinding = nullptr;
+inline std::atomic<size_t>* bindSharedCapacity(SharedCapacityMember* member)
+{
+    SharedCapacityBinding* s = sharedCapacityBinding;
+    if(!s) return nullptr;
+    if(s->next >= SharedCapacities::MAX_BUFFERS) throw std::runtime_error("SharedCapacities: too many buffers in one scratch.");
+    s->members->push_back(member);
+    return &s->shared->marks[s->next++];
+}
+// The capacity to allocate when `wanted` is needed: at least the mark, and the mark raised to it.
+inline size_t sharedCapacityFor(std::atomic<size_t>* mark, size_t wanted)
+{
+    if(!mark) return wanted;
+    size_t m = mark->load();
+    while(m < wanted && !mark->compare_exchange_weak(m, wanted)) {}
+    return std::max(m, wanted);
+}
+
 // A device allocation that only grows.  HBM is 288 GB: buffers are sized once
 // from the marker count and kept for the life of the context.
-template<class T> class DeviceBuffer {
+template<class T> class DeviceBuffer : public SharedCapacityMember {
 public:
-    DeviceBuffer() = default;
+    DeviceBuffer() : mark(bindSharedCapacity(this)) {}
     DeviceBuffer(const DeviceBuffer&) = delete;
     DeviceBuffer& operator=(const DeviceBuffer&) = delete;
     ~DeviceBuffer() { release(); }
@@ -56,7 +93,20 @@ public:
     void reserve(size_t n, hipStream_t stream = nullptr, bool keep = false)
     {
         if(n <= cap) return;
-        size_t newCap = n + n / 8 + 64;
+        reallocate(sharedCapacityFor(mark, n + n / 8 + 64), stream, keep);
+    }
+    // Contents are not preserved.
+    void raiseToMark(hipStream_t stream) override
+    {
+        const size_t m = mark ? mark->load() : 0;
+        if(m > cap) reallocate(m, stream, false);
+    }
+    T* data() const { return p; }
+    size_t capacity() const { return cap; }
+    void swap(DeviceBuffer& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
+private:
+    void reallocate(size_t newCap, hipStream_t stream, bool keep)
+    {
         T* q = nullptr;
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&q), newCap * sizeof(T)));
         if(keep && p && cap) {
@@ -66,37 +116,41 @@ public:
         if(p) (void)hipFree(p);
         p = q; cap = newCap;
     }
-    T* data() const { return p; }
-    size_t capacity() const { return cap; }
-    void swap(DeviceBuffer& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
-private:
     T* p = nullptr;
     size_t cap = 0;
+    std::atomic<size_t>* mark;
 };
 
 // Page-locked host staging memory that only grows (device-to-host copies into pageable memory go
 // through the runtime's small bounce buffers; into pinned memory they run at PCIe speed).
-class PinnedBuffer {
+class PinnedBuffer : public SharedCapacityMember {
 public:
-    PinnedBuffer() = default;
+    PinnedBuffer() : mark(bindSharedCapacity(this)) {}
     PinnedBuffer(const PinnedBuffer&) = delete;
     PinnedBuffer& operator=(const PinnedBuffer&) = delete;
     ~PinnedBuffer() { if(p) (void)hipHostFree(p); }
     void* reserve(size_t bytes)
     {
-        if(bytes > cap) {
-            if(p) (void)hipHostFree(p);
-            p = nullptr; cap = 0;
-            const size_t newCap = bytes + bytes / 4 + 4096;
-            HIP_CHECK(hipHostMalloc(&p, newCap, hipHostMallocDefault));
-            cap = newCap;
-        }
+        if(bytes > cap) reallocate(sharedCapacityFor(mark, bytes + bytes / 4 + 4096));
         return p;
+    }
+    void raiseToMark(hipStream_t) override
+    {
+        const size_t m = mark ? mark->load() : 0;
+        if(m > cap) reallocate(m);
     }
     void* data() const { return p; }
 private:
+    void reallocate(size_t newCap)
+    {
+        if(p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        HIP_CHECK(hipHostMalloc(&p, newCap, hipHostMallocDefault));
+        cap = newCap;
+    }
     void* p = nullptr;
     size_t cap = 0;
+    std::atomic<size_t>* mark;
 };
 
 struct EventTimer {

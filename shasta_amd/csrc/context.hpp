@@ -35,6 +35,7 @@ struct Context {
     hipStream_t workerStream[ALIGN_MAX_WORKERS] = {};
     hipStream_t wideStream[ALIGN_MAX_WORKERS] = {};
     std::shared_ptr<void> alignScratch[ALIGN_MAX_WORKERS];
+    SharedCapacities alignCapacities;        // high-water marks the workers' scratch buffers share (common.hpp)
     std::shared_ptr<void> alignStore;        // results of borrowed Align4 calls (valid until the next call)
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress
     std::shared_ptr<void> lowhashBuffers;    // the last finished job, kept for its device allocations (the next job adopts them)
