@@ -693,7 +693,27 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const int l = e ? std::atoi(e) : 18;
         return 1ULL << std::min(std::max(l, 10), 20);
     }();
-    const uint64_t batchCount = (candidateCount + BATCH - 1) / BATCH;
+    // Where the batches begin: every BATCH candidates.  SHASTA_MI355X_ALIGN_GRADED_BATCHES=1 (a timing experiment, measured and not
+    // adopted: 171-174 against 167-171 ms per call, profiles/r02_call36_batch_schedule.log) makes the first batches short (all
+    // workers prepare their first batch together and the device waits for the first of them) and lets the last ones shrink with
+    // what is left (a share of it per worker, not below a quarter of a batch; the workers that are done wait for the last batch).
+    std::vector<uint64_t> batchStart(1, 0);
+    {
+        const char* e = std::getenv("SHASTA_MI355X_ALIGN_GRADED_BATCHES");
+        const bool equalBatches = !(e && std::atoi(e) != 0) || candidateCount < 2 * BATCH;
+        const uint64_t share = uint64_t(ALIGN_DEFAULT_WORKERS);
+        const uint64_t ramp[3] = {BATCH / 8, BATCH / 4, BATCH / 2};
+        while(batchStart.back() < candidateCount) {
+            const uint64_t left = candidateCount - batchStart.back();
+            uint64_t size = BATCH;
+            if(!equalBatches) {
+                const size_t k = batchStart.size() - 1;
+                size = k < 3 ? ramp[k] : std::min(BATCH, std::max(BATCH / 4, left / share));
+            }
+            batchStart.push_back(batchStart.back() + std::min(left, size));
+        }
+    }
+    const uint64_t batchCount = batchStart.size() - 1;
 
     if(borrowed && !ctx.alignStore) ctx.alignStore = std::make_shared<AlignStore>();
     AlignStore localStore;
@@ -752,8 +772,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         BatchOutput& out = outputs[batchIndex];
         std::vector<PairDesc>& hostPairs = w.hostPairs;
         std::vector<uint64_t>& hostToc64 = w.hostToc64;
-        const uint64_t batchBegin = batchIndex * BATCH;
-        const uint32_t n = uint32_t(std::min<uint64_t>(BATCH, candidateCount - batchBegin));
+        const uint64_t batchBegin = batchStart[batchIndex];
+        const uint32_t n = uint32_t(batchStart[batchIndex + 1] - batchBegin);
         hostPairs.resize(n);
         for(uint32_t k = 0; k < n; k++) {
             const shasta_oriented_read_pair& c = candidates[batchBegin + k];
@@ -1253,7 +1273,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         for(size_t q = 0; q < o.tocEnds.size(); q++) toc[at.rowBase + q + 1] = at.byteBase + o.tocEnds[q];
         if(wantOrdinals) {
             if(!o.ordinals.empty()) std::memcpy(ordinals + 2 * at.ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
-            for(size_t q = 1; q < o.ordToc.size(); q++) ordinalsToc[k * BATCH + q] = at.ordBase + o.ordToc[q];
+            for(size_t q = 1; q < o.ordToc.size(); q++) ordinalsToc[batchStart[k] + q] = at.ordBase + o.ordToc[q];
         }
     };
     auto placeFinished = [&](uint64_t finished) {

@@ -1,14 +1,17 @@
 """Borrowed aligner results (align4_run_borrowed) over SEVERAL batches: a batch whose predecessors are done is copied into the
 context's arrays while later batches are still running; the result must equal the owned one, call after call (the second call
 finds arrays sized by the first and places every batch early; a third, larger call outgrows them again).
+And the graded batch schedule (an experiment switch: short first batches, shrinking last ones) against batches of equal
+size, and both against the oracle.
 Run in a process of its own (the batch size is read once per process):
-    SHASTA_MI355X_ALIGN_BATCH_LOG2=10 python -m tests.borrowed_checks <library.so>"""
+    SHASTA_MI355X_ALIGN_BATCH_LOG2=10 python -m tests.borrowed_checks <library.so> [oracle]"""
+import os
 import sys
 
 import numpy as np
 
 
-def main(path):
+def main(path, oracle=None):
     from shasta_amd import abi, lib as libmod
     from tests import support
     lib = libmod.Library(path)
@@ -31,8 +34,22 @@ def main(path):
                 if want:
                     assert np.array_equal(borrowed.ordinals, kept[4])
                 del borrowed
+        # 2060 candidates in batches of 1024 or less: 128, 256, 512, then a sixth of what is left but at least 256 each.
+        assert len(cand) >= 2048, len(cand)
+        equal = ctx.align4(cand, o, want_ordinals=True)
+        os.environ["SHASTA_MI355X_ALIGN_GRADED_BATCHES"] = "1"           # (read at every call)
+        scheduled = ctx.align4(cand, o, want_ordinals=True)
+        del os.environ["SHASTA_MI355X_ALIGN_GRADED_BATCHES"]
+        support.same_align(scheduled, equal)
+        if oracle:
+            from oracle import bindings
+            expected = bindings.OracleLib().align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+            if not (expected.status & 0x80).any():
+                support.same_align(expected, scheduled)
+            else:
+                assert np.array_equal(expected.status, scheduled.status)
     print("borrowed results equal owned results")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

@@ -94,11 +94,11 @@ def test_align3_context_paths(emu_lib, oracle_lib):
     align3_checks.context_paths(emu_lib, oracle_lib)
 
 
-def test_borrowed_results_over_several_batches(emu_lib):
+def test_borrowed_results_and_batch_schedule_over_several_batches(emu_lib, oracle_lib):
     # (a process of its own: the batch size is read once per process)
     import subprocess, sys
     env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10")
-    out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", emu_lib.path], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", emu_lib.path, "oracle"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
