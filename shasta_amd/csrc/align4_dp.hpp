@@ -176,7 +176,7 @@ bandedDpForwardKernel(
     uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
 {
     constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C, U = DP_BLOCK;
-    constexpr int AL = U;                                 // steady iterations come in groups of AL: whole blocks
+    constexpr int AL = 2 * U;                             // steady iterations come in groups of AL: two blocks, one on each of the two register sets of kmer ids
     constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
     static_assert(C >= 2 && C <= 16 && U >= 3 && AL % U == 0, "block geometry");
     const int lane = laneId();
@@ -337,14 +337,19 @@ bandedDpForwardKernel(
     } else {
         general(0, steadyBegin);
         {
-            // Block registers: a[x] = A[ib + l HC - 1 + x], x = 0..U+HC-1; e[x] = B[ib - bandMin - l HC - HC + x], x = 0..U+HC-2.
-            // Iteration u of the block: aw(k) = a[u + k], bw(h) = e[u + HC - 1 - h].
+            // Block registers.  Logically a[x] = A[ib + l HC - 1 + x], x = 0..U+HC-1, and e[x] = B[ib - bandMin - l HC - HC + x],
+            // x = 0..U+HC-2; iteration u of the block takes aw(k) = a[u + k], bw(h) = e[u + HC - 1 - h].  The last U elements of
+            // each are the 16-byte load of the block (quadA / quadB [blk & 1]: two register sets, the load of the next block goes
+            // into the other one, a block ahead), the first HC (HC - 1) are the end of the previous block's, kept in tailA /
+            // tailB: HC + HC - 1 register moves per block where copying the prefetched quads into one array took 2 U more
+            // (8 of 75 VALU instructions of a block for C = 2).
             const int32_t ib = ib0 + int32_t(steadyBegin);
-            uint32_t a[U + HC], e[U + HC - 1];
+            uint32_t tailA[HC], tailB[HC > 1 ? HC - 1 : 1];
+            KmerQuad quadA[2], quadB[2];
 #pragma unroll
-            for(int x = 0; x < U + HC; x++) a[x] = loadA(ib + l * HC - 1 + x);
+            for(int x = 0; x < U + HC; x++) { const uint32_t v = loadA(ib + l * HC - 1 + x); if(x < HC) tailA[x] = v; else quadA[0].v[x - HC] = v; }
 #pragma unroll
-            for(int x = 0; x < U + HC - 1; x++) e[x] = loadB(ib - bandMin - l * HC - HC + x);
+            for(int x = 0; x < U + HC - 1; x++) { const uint32_t v = loadB(ib - bandMin - l * HC - HC + x); if(x < HC - 1) tailB[x] = v; else quadB[0].v[x - (HC - 1)] = v; }
             const uint32_t* __restrict__ pa = p0 + (int64_t(iaBlock) + int64_t(steadyBegin));
             const uint32_t* __restrict__ pb = p1 + (int64_t(jbBlock) + int64_t(steadyBegin));
             uint64_t* groupRecords = tr + uint64_t(steadyBegin) * RW;
@@ -352,24 +357,23 @@ bandedDpForwardKernel(
             for(uint32_t grp = 0; grp < groups; grp++, groupRecords += AL * RW) {
 #pragma unroll
                 for(int blk = 0; blk < AL / U; blk++) {
+                    const int cur = blk & 1, nxt = cur ^ 1;
                     SHASTA_DEVICE_CHECK(pa >= p0 && pa + U <= p0 + nx && pb >= p1 && pb + U <= p1 + ny);
-                    const KmerQuad newA = *reinterpret_cast<const KmerQuad*>(pa);
-                    const KmerQuad newB = *reinterpret_cast<const KmerQuad*>(pb);
+                    quadA[nxt] = *reinterpret_cast<const KmerQuad*>(pa);
+                    quadB[nxt] = *reinterpret_cast<const KmerQuad*>(pb);
                     pa += U; pb += U;
+                    auto a = [&](int x) { return x < HC ? tailA[x < HC ? x : 0] : quadA[cur].v[x < HC ? 0 : x - HC]; };
+                    auto e = [&](int x) { return x < HC - 1 ? tailB[x < HC - 1 ? x : 0] : quadB[cur].v[x < HC - 1 ? 0 : x - (HC - 1)]; };
 #pragma unroll
                     for(int u = 0; u < U; u++) {
                         uint64_t words[RW];
-                        antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a[u + k]; }, [&](int h) { return e[u + HC - 1 - h]; }, words);
+                        antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a(u + k); }, [&](int h) { return e(u + HC - 1 - h); }, words);
                         putRecordOfGroup(groupRecords, blk * U + u, words);
                     }
 #pragma unroll
-                    for(int x = 0; x < HC; x++) a[x] = a[x + U];
+                    for(int x = 0; x < HC; x++) tailA[x] = a(x + U);
 #pragma unroll
-                    for(int j = 0; j < U; j++) a[HC + j] = newA.v[j];
-#pragma unroll
-                    for(int x = 0; x < HC - 1; x++) e[x] = e[x + U];
-#pragma unroll
-                    for(int j = 0; j < U; j++) e[HC - 1 + j] = newB.v[j];
+                    for(int x = 0; x < HC - 1; x++) tailB[x] = e(x + U);
                 }
             }
         }
