@@ -285,7 +285,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
     exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
     const bool inB = radixSort<uint32_t, uint32_t, true>(b.dpKeysA.data(), b.dpKeysB.data(), b.dpIdsA.data(), b.dpIdsB.data(),
-        taskCount, 27, *ws.sortWs, stream);
+        taskCount, 28, *ws.sortWs, stream);
     const uint32_t* sortedKeys = inB ? b.dpKeysB.data() : b.dpKeysA.data();
     const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
     f.sortedIds = sortedIds;
@@ -785,7 +785,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             PairDesc pd;
             pd.begin0 = ctx.hostToc[o0]; pd.begin1 = ctx.hostToc[o1];
             const uint64_t nx = ctx.hostToc[o0 + 1] - pd.begin0, ny = ctx.hostToc[o1 + 1] - pd.begin1;
-            MI355X_ASSERT(nx < (1ULL << 30) && ny < (1ULL << 30));
+            // (the DP's sort key holds (nx + ny) / 2 iterations in 24 bits, its biased scores i + j < 2^25: align4_dp.hpp)
+            if(nx + ny >= (1ULL << 25)) throw std::runtime_error("Align4: a candidate's two reads have 2^25 markers or more between them (not supported).");
             pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
@@ -1462,6 +1463,7 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     std::vector<DpTask> tasks(taskCount);
     for(uint64_t t = 0; t < taskCount; t++) {
         if(nx[t] == 0 || ny[t] == 0 || begin0[t] + nx[t] > kmerCount || begin1[t] + ny[t] > kmerCount) throw std::runtime_error("banded_dp_many: a sequence is empty or outside kmerIds.");
+        if(uint64_t(nx[t]) + uint64_t(ny[t]) >= (1ULL << 25)) throw std::runtime_error("banded_dp_many: two sequences of 2^25 elements or more between them.");
         if(bandMin[t] > bandMax[t] || bandMax[t] - bandMin[t] + 1 > 1024) throw std::runtime_error("banded_dp_many: band width must be in [1, 1024].");
         if(bandMin[t] > int32_t(nx[t]) || bandMax[t] < -int32_t(ny[t])) throw std::runtime_error("banded_dp_many: the band misses the matrix.");
         pairs[t].begin0 = begin0[t]; pairs[t].begin1 = begin1[t]; pairs[t].nx = nx[t]; pairs[t].ny = ny[t];

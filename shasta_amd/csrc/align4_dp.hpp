@@ -76,7 +76,11 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
         const PairDesc pd = pairs[task.pair];
         const DpGeometry g = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
         cls = g.cls;
-        keys[t] = (uint32_t(g.cls) << 24) | min(g.iters, 0xffffffu);
+        // (class, band width not a multiple of the class's diagonals per lane, iterations): the tasks of a wavefront of the
+        // forward kernel then mostly agree on whether every lane has all of its diagonals or none (its steady loop without
+        // the "exists" select, see there).
+        const uint32_t partial = (uint32_t(task.bandMax - task.bandMin + 1) & uint32_t(dpDiagonals(g.cls) - 1)) != 0 ? 1u : 0u;
+        keys[t] = (uint32_t(g.cls) << 25) | (partial << 24) | min(g.iters, 0xffffffu);
         ids[t] = t;
         ordCap[t] = min(pd.nx, pd.ny);
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
@@ -117,10 +121,12 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
     while(bundle >= layout.bundleStart[cls + 1]) ++cls;
     const uint32_t T = 64u / uint32_t(dpLanes(cls));
     const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
-    const uint32_t last = min(first + T, layout.taskStart[cls + 1]) - 1;
-    // sorted ascending: the last task has the most iterations.  Rounded to 256 bytes so that the
-    // traceback's chunks are whole cache lines.
-    bundleWords[bundle] = (uint64_t(sortedKeys[last] & 0xffffffu) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
+    const uint32_t end = min(first + T, layout.taskStart[cls + 1]);
+    // The task of the bundle with the most iterations (the list of a class is two ascending runs).  Rounded to 256 bytes so
+    // that the traceback's chunks are whole cache lines.
+    uint32_t iterations = 0;
+    for(uint32_t k = first; k < end; k++) iterations = max(iterations, sortedKeys[k] & 0xffffffu);
+    bundleWords[bundle] = (uint64_t(iterations) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
 }
 
 // ---- forward kernel ---------------------------------------------------------------------------
@@ -148,6 +154,10 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
 //    scripts/microbench/trace_store.hip measured both ways of writing the same records: identical bytes, 0.84 -> 0.62 ms.)
 //  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
 constexpr int DP_BLOCK = 4;
+#ifndef SHASTA_DP_WHOLE_LANES
+#define SHASTA_DP_WHOLE_LANES 1
+#endif
+constexpr bool DP_WHOLE_LANES = SHASTA_DP_WHOLE_LANES != 0;     // (0: timing experiments without the steady loop that switches lanes off)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // The value of the lane below / above in a G-lane group; 0 at the group's edge.
@@ -166,9 +176,19 @@ template<int G> __device__ __forceinline__ int32_t fromLaneAbove(int32_t v, int 
     return r;
 }
 struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // four consecutive kmer ids, 4-byte aligned
+// Which loop a cell is computed in: the general one, the steady one, or the steady one of a wavefront in which every lane has
+// either all of its C diagonals or none (WHOLE_LANES: the lanes without diagonals are switched off for the loop, see below).
+template<bool STEADY, bool WHOLE_LANES> struct DpPhase { static constexpr bool value = STEADY, wholeLanes = WHOLE_LANES; };
 
+// Room for six wavefronts per SIMD (80 vector registers) in the classes of up to four diagonals per lane, as before the second
+// steady loop: the allocator took 84-85 with it (five wavefronts).
+#ifdef __HIPCC__
+#define SHASTA_DP_FORWARD_OCCUPANCY(C) __attribute__((amdgpu_waves_per_eu((C) <= 4 ? 6 : 1)))
+#else
+#define SHASTA_DP_FORWARD_OCCUPANCY(C)      // (the wave64 emulator of tests/emu compiles this file as plain C++)
+#endif
 template<int G, int C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SHASTA_DP_FORWARD_OCCUPANCY(C)
 bandedDpForwardKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
     const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
@@ -239,7 +259,8 @@ bandedDpForwardKernel(
         const bool isD = v == dg, isVertical = v == hv;            // (isVertical only counts where isD is false)
         if constexpr (STEADY) {
             SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
-            H[c] = exists[c] ? v : 0;
+            if constexpr (decltype(steadyTag)::wholeLanes) { SHASTA_DEVICE_CHECK(exists[c]); H[c] = v; }
+            else H[c] = exists[c] ? v : 0;
         } else {
             const bool valid = uint32_t(sc - lo[c]) <= span[c];
             v = (sc == lo[c]) ? BIAS - GAP_SCORE * sc : v;          // i == 0 or j == 0: free leading gaps (score 0)
@@ -294,7 +315,7 @@ bandedDpForwardKernel(
         uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
         for(uint32_t it = from; it < to; it++) {
             uint64_t words[RW];
-            antiDiagonals(std::false_type{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
+            antiDiagonals(DpPhase<false, false>{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
             putRecord(it, words);
 #pragma unroll
             for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
@@ -336,7 +357,7 @@ bandedDpForwardKernel(
         general(0, iters);
     } else {
         general(0, steadyBegin);
-        {
+        auto steady = [&](auto phaseTag) {
             // Block registers.  Logically a[x] = A[ib + l HC - 1 + x], x = 0..U+HC-1, and e[x] = B[ib - bandMin - l HC - HC + x],
             // x = 0..U+HC-2; iteration u of the block takes aw(k) = a[u + k], bw(h) = e[u + HC - 1 - h].  The last U elements of
             // each are the 16-byte load of the block (quadA / quadB [blk & 1]: two register sets, the load of the next block goes
@@ -367,7 +388,7 @@ bandedDpForwardKernel(
 #pragma unroll
                     for(int u = 0; u < U; u++) {
                         uint64_t words[RW];
-                        antiDiagonals(std::true_type{}, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a(u + k); }, [&](int h) { return e(u + HC - 1 - h); }, words);
+                        antiDiagonals(phaseTag, geo.s0 + 2 * int32_t(steadyBegin + grp * AL + blk * U + u), [&](int k) { return a(u + k); }, [&](int h) { return e(u + HC - 1 - h); }, words);
                         putRecordOfGroup(groupRecords, blk * U + u, words);
                     }
 #pragma unroll
@@ -376,7 +397,18 @@ bandedDpForwardKernel(
                     for(int x = 0; x < HC - 1; x++) tailB[x] = e(x + U);
                 }
             }
-        }
+        };
+        // A value outside the band must read as 0 to its neighbours.  When every lane of the wavefront has all of its C diagonals
+        // or none of them (band widths that are multiples of C: 30, 40, 60, 80 ... of the default options' multiples of 10), the
+        // lanes without diagonals sit the steady loop out: their H stay 0, a DPP move whose source lane is switched off returns 0
+        // like one from beyond the row (bound_ctrl; measured, profiles/r02_dpp_exec_probe.jsonl), their ballot bits are 0 (cells
+        // no path visits) -- and the select "exists ? v : 0" of every cell is gone (1 of 8 VALU instructions per cell).
+        bool laneAll = true, laneNone = true;
+#pragma unroll
+        for(int c = 0; c < C; c++) { laneAll = laneAll && exists[c]; laneNone = laneNone && !exists[c]; }
+        const bool wholeLanes = DP_WHOLE_LANES && ballot64(laneAll || laneNone) == ~0ULL && ballot64(laneAll) != 0;
+        if(wholeLanes) { if(laneAll) steady(DpPhase<true, true>{}); }
+        else steady(DpPhase<true, false>{});
         general(steadyBegin + groups * AL, iters);
     }
     scalarStoreFlush();                                   // the scalar data cache is write-back

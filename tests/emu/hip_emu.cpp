@@ -116,6 +116,11 @@ void releaseGroup(std::vector<Fiber>& fibers, int waveBase, uint64_t group)
             f.result = (src >= 0 && src < 64 && ((group >> src) & 1)) ? fibers[waveBase + src].value : f.value;
             break;
         }
+        case DPP_MOVE: {                // bit 32: the source lane is active
+            const int src = int(f.aux);
+            f.result = (src >= 0 && src < 64 && ((group >> src) & 1)) ? ((1ULL << 32) | uint32_t(fibers[waveBase + src].value)) : 0;
+            break;
+        }
         case FIRSTLANE: f.result = fibers[waveBase + first].value; break;
         default: f.result = 0; break;
         }

@@ -115,7 +115,7 @@ struct Fiber {                     // one work-item
 };
 extern thread_local Fiber* cur;
 
-enum Kind { BALLOT = 1, SHUFFLE, FIRSTLANE, WAVE_BARRIER, BLOCK_BARRIER };
+enum Kind { BALLOT = 1, SHUFFLE, FIRSTLANE, WAVE_BARRIER, BLOCK_BARRIER, DPP_MOVE };
 
 // Blocks the calling fiber until its wavefront (workgroup for BLOCK_BARRIER) has arrived.
 uint64_t collective(int kind, uint64_t value, uint64_t aux) __attribute__((noinline));
@@ -208,8 +208,11 @@ __forceinline__ int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int 
         default: std::fprintf(stderr, "hip_emu: DPP control 0x%x is not modelled\n", ctrl); std::abort();
     }
     if(rowMask != 0xf || bankMask != 0xf) { std::fprintf(stderr, "hip_emu: DPP row/bank masks are not modelled\n"); std::abort(); }
-    const uint32_t got = uint32_t(hipemu::collective(hipemu::SHUFFLE, uint32_t(src), uint64_t(from < 0 ? lane : from)));
-    return from < 0 ? (boundCtrl ? 0 : old) : int(got);
+    // A source lane that is out of range OR switched off (not at this call site with the others) is invalid: 0 with bound_ctrl,
+    // `old` without -- measured on gfx950 (scripts/microbench/dpp_exec_probe.hip, profiles/r02_dpp_exec_probe.jsonl).
+    const uint64_t got = hipemu::collective(hipemu::DPP_MOVE, uint32_t(src), uint64_t(from < 0 ? lane : from));
+    const bool valid = from >= 0 && (got >> 32) != 0;
+    return valid ? int(uint32_t(got)) : (boundCtrl ? 0 : old);
 }
 __forceinline__ uint32_t __builtin_amdgcn_readfirstlane(uint32_t v)
 {
