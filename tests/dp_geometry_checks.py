@@ -87,6 +87,39 @@ def many(lib, orc, seed, tasks=140):
     return len(spec), bad
 
 
+def straddling_bundles(lib, orc, seed, long_tasks=6, short_tasks=7):
+    """One band class (widths 49 .. 64: 16 lanes x 4 diagonals, four tasks to a wavefront) whose task list is two runs: long
+    tasks with every lane whole (width 64, 60) first, short tasks with a partly filled lane (widths 50, 54) after them, the
+    counts chosen so that one wavefront holds tasks of both runs -- its trace must be sized by the LONGEST of its tasks, not by
+    the last, and it runs the masked steady loop while its neighbours run the one with lanes switched off."""
+    rng = np.random.default_rng(seed)
+    pieces, spec = [], []
+    at = 0
+    for t in range(long_tasks + short_tasks):
+        long_task = t < long_tasks
+        width = int(rng.choice([64, 60])) if long_task else int(rng.choice([50, 54]))
+        n = int(rng.integers(900, 1400)) if long_task else int(rng.integers(120, 300))
+        alphabet = (1 << 20) if t % 2 == 0 else 9
+        genome = rng.integers(0, alphabet, size=2 * n + 200, dtype=np.uint32)
+        off = int(rng.integers(0, 60))
+        a = noisy(rng, genome[:n], alphabet)
+        b = noisy(rng, genome[off:off + n], alphabet)
+        lo = off - width // 2 + int(rng.integers(-8, 8))
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), lo, lo + width - 1))
+        at += len(a) + len(b)
+    kmer = np.concatenate(pieces)
+    spec = np.asarray(spec, dtype=np.int64)
+    got = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5])
+    bad = 0
+    for (b0, nx, b1, ny, lo, hi), (y, sy) in zip(spec, got):
+        x, sx = orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi))
+        if not (sx == sy and np.array_equal(x, y)):
+            bad += 1
+            print("MISMATCH in a straddling bundle: nx %d ny %d band [%d, %d]: score %d / %d" % (nx, ny, lo, hi, sx, sy))
+    return len(spec), bad
+
+
 def check(lib, orc, seed=11, tasks=140, trials=6):
     cases, bad = sweep(lib, orc, seed, trials)
     assert bad == 0 and cases >= 12 * trials, (cases, bad)

@@ -175,6 +175,15 @@ def test_banded_dp_geometries_against_oracle(emu_lib, oracle_lib):
     dp_geometry_checks.check(emu_lib, oracle_lib, seed=5, tasks=48, trials=3)
 
 
+def test_banded_dp_wavefront_with_tasks_of_both_runs_of_its_class(emu_lib, oracle_lib):
+    # (written after the round's last GPU call: on the emulated build, whose device checks watch the trace bounds; joins the
+    # -m gpu suite with the next round's first call)
+    from tests import dp_geometry_checks
+    for seed in (3, 4):
+        cases, bad = dp_geometry_checks.straddling_bundles(emu_lib, oracle_lib, seed)
+        assert cases == 13 and bad == 0
+
+
 def test_window_hash_kernel_for_every_m(emu_lib, oracle_lib):
     from tests import hash_every_m_checks
     assert hash_every_m_checks.sweep(emu_lib, oracle_lib, reads=60) > 8 * 60
