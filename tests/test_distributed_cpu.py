@@ -51,6 +51,8 @@ def _worker(rank, world, port, out_dir, seed, kw):
     (2, 61, dict(minBucketSize=2, maxBucketSize=30, minFrequency=2)),
     (2, 62, dict(m=3, hashFraction=0.05, minHashIterationCount=0, alignmentCandidatesPerRead=6.0, maxBucketSize=40)),
     (3, 63, dict(hashFraction=0.03, log2MinHashBucketCount=14, minFrequency=1, minHashIterationCount=4)),
+    (4, 64, dict(minBucketSize=2, maxBucketSize=30, minFrequency=2)),
+    (8, 65, dict(m=3, hashFraction=0.04, minBucketSize=2, maxBucketSize=40, minFrequency=1, minHashIterationCount=5)),     # the node's eight GPUs: 15 reads per rank
 ])
 def test_sharded_lowhash0_equals_single_process(oracle_lib, world, seed, kw):
     port = 29600 + seed
