@@ -35,7 +35,14 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 # (the guide's 157.3 TFLOP/s fp32 = 2 flops x 64 lanes x this).  Dependent integer chains measured on the device reach
 # 1.35-1.55 of the 2 instructions per cycle and CU (scripts/microbench/valu_rates.hip, profiles/r02_valu_rates.jsonl).
 VALU_PEAK_WAVE_INSTRUCTIONS_PER_S = 256 * 4 * 0.5 * 2.4e9
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_100k_reads.json")
+def _latest_pmc_file():
+    # The newest round's counter summary (profiles/rNN_pmc_100k_reads.json, written by scripts/gpu_profile.sh).
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_100k_reads.json")))
+    return files[-1] if files else os.path.join(ROOT, "profiles", "r02_pmc_100k_reads.json")
+
+
+PMC_FILE = _latest_pmc_file()
 # Kernels whose natural bound is HBM (streaming / sorting); the others are bound by VALU issue and LDS (integer DP, hash joins).
 HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
 
