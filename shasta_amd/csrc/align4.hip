@@ -133,6 +133,9 @@ struct BatchScratch {
     DeviceBuffer<WideTask> wideTasks;           //                         pairs with more than 1024 diagonals
     DeviceBuffer<int32_t> hugeRows;             //                         the three anti-diagonals of the pairs with more than 8192 diagonals
     DeviceBuffer<WideEnd> wideEnds;
+    DeviceBuffer<uint64_t> prepareKeysA, prepareKeysB;      // a batch's first chunk lists made on the device (align4_prepare.hpp)
+    DeviceBuffer<uint32_t> prepareIdsA, prepareIdsB;
+    DeviceBuffer<unsigned long long> prepareInfo;
     // (worker scratch only) all the buffers above, for raiseToMarks
     std::vector<SharedCapacityMember*> sharedBuffers;
     void raiseToMarks(hipStream_t stream) { for(SharedCapacityMember* m : sharedBuffers) m->raiseToMark(stream); }
@@ -191,6 +194,7 @@ constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1
 constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2};
 constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16};
 constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call
+#include "align4_prepare.hpp"    // the class of a candidate; a batch's first chunk lists made on the device
 
 // Wavefronts of a chunk's workgroup: they stream one candidate at a time together, then take one kept-cell graph each.
 #ifndef SHASTA_CELLS_WAVES
@@ -927,23 +931,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 while((1ULL << l) < 2 * cells && l < 24) ++l;
                 return uint8_t(l);
             };
-            // Class of a candidate: table of the tabled read at load <= 1/2, cell table sized for the
-            // expected number of distinct cells (random background ~ nx*ny / alphabet, plus the
-            // diagonal) at load <= 3/4.  Overflow is detected on the device and climbs one class.
-            // The packed LDS cell word counts up to 2^CELLS_COUNT_BITS - 1 entries; a cell holds at most
-            // ceil(deltaX * deltaY / 2) (one (x,y) per lattice point of the right parity).
-            const bool packedOk = (uint64_t(opt.deltaX) * opt.deltaY + 1) / 2 < (1ULL << CELLS_COUNT_BITS) && opt.deltaX >= 2 && opt.deltaY >= 2;
-            auto classFor = [&](uint64_t tabled, uint64_t nx, uint64_t ny) -> int {
-                if(nx >= 65535 || ny >= 65535 || !packedOk) return CELLS_CLASSES;
-                // Cell indices must fit the packed word and the single-multiply division must be exact.
-                if((nx + ny) / opt.deltaX >= (1ULL << CELLS_IX_BITS) || (nx + ny) / opt.deltaY >= (1ULL << CELLS_IY_BITS)) return CELLS_CLASSES;
-                if((nx + ny) * std::max<uint64_t>(opt.deltaX, opt.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
-                const uint64_t cells = (nx * ny >> SHASTA_CELLS_ESTIMATE_SHIFT) + (nx + ny) / 32 + 32;
-                for(int c = 0; c < CELLS_CLASSES; c++) {
-                    if(tabled < (1ULL << CELLS_NA_LOG2[c]) && 4 * cells <= (3ULL << CELLS_SC_LOG2[c])) return c;
-                }
-                return CELLS_CLASSES;
-            };
+            const CellsClassRule classRule = cellsClassRule(opt);            // (the class of a candidate: align4_prepare.hpp)
             pairClass.assign(n, -1); pairSlotsLog2.assign(n, 0);
             std::vector<CellsChunk> classChunks[CELLS_CLASSES];
             std::vector<uint32_t> members;                             // candidate indices, chunk after chunk
@@ -954,6 +942,59 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 members.insert(members.end(), list, list + count);
                 classChunks[c].push_back(ch);
             };
+            // deltaX, deltaY >= 2 here (packedOk fails for 1 x anything >= 2046... and d = 1 gives magic 2^32): guard.
+            const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX + 1, 0xffffffffULL));
+            const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY + 1, 0xffffffffULL));
+            cellsMagicX = magicX; cellsMagicY = magicY;
+            // Every candidate is a member once, plus once per class it climbs to after an overflow.
+            const uint64_t memberCapacity = uint64_t(CELLS_CLASSES) * n + 16;
+            b.pairList.reserve(memberCapacity, stream);
+            size_t membersUploaded = 0;
+            // SHASTA_MI355X_DEVICE_BATCH_PREP=1 (pre-flighted on the emulated build, not yet on the GPU: off by default): the first
+            // round's member list and chunk lists are made by kernels on the batch's stream and its cells kernels launched from
+            // them at once; what the host needs for the later rounds (every candidate's class, the HBM-scratch list) it
+            // computes while they run.  Same chunks, same order within a class (align4_prepare.hpp).
+            const bool devicePrepare = [] { const char* e = std::getenv("SHASTA_MI355X_DEVICE_BATCH_PREP"); return e && std::atoi(e) != 0; }();      // (read for every batch: tests switch it)
+            bool firstRoundLaunched = false, firstRoundAny = false;
+            if(devicePrepare) {
+                int tabledBits = 1;
+                while(tabledBits < 58 && (ctx.hostToc.back() >> tabledBits) != 0) ++tabledBits;
+                b.prepareKeysA.reserve(n, stream); b.prepareKeysB.reserve(n, stream); b.prepareIdsA.reserve(n, stream); b.prepareIdsB.reserve(n, stream);
+                b.prepareInfo.reserve(CELLS_PREPARE_INFO, stream); b.chunks.reserve(n, stream);
+                HIP_CHECK(hipMemsetAsync(b.prepareInfo.data(), 0, CELLS_PREPARE_INFO * sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(cellsClassKeysKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
+                    (const PairDesc*)b.pairs.data(), n, classRule, tabledBits, b.prepareKeysA.data(), b.prepareIdsA.data(), b.prepareInfo.data());
+                const bool inB = radixSort<uint64_t, uint32_t, true>(b.prepareKeysA.data(), b.prepareKeysB.data(), b.prepareIdsA.data(), b.prepareIdsB.data(),
+                    n, tabledBits + 3, *ws.sortWs, stream);
+                const uint64_t* sortedKeys = inB ? b.prepareKeysB.data() : b.prepareKeysA.data();
+                const uint32_t* sortedIds = inB ? b.prepareIdsB.data() : b.prepareIdsA.data();
+                hipLaunchKernelGGL(cellsChunkHeadsKernel, dim3(divUp(uint64_t(n) + 1, 256)), dim3(256), 0, stream, sortedKeys, n, tabledBits, b.storedFlags.data());
+                exclusiveScan<uint32_t>(b.storedFlags.data(), b.storedIndex.data(), uint64_t(n) + 1, b.scanTemp32.data(), stream);
+                hipLaunchKernelGGL(cellsChunkWriteKernel, dim3(divUp(uint64_t(n) + 1, 256)), dim3(256), 0, stream,
+                    sortedKeys, (const uint32_t*)b.storedIndex.data(), n, tabledBits, b.chunks.data(), b.prepareInfo.data());
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(b.pairList.data(), sortedIds, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+                unsigned long long info[CELLS_PREPARE_INFO];
+                HIP_CHECK(hipMemcpyAsync(info, b.prepareInfo.data(), sizeof(info), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                for(int c = 0; c < CELLS_CLASSES; c++) {
+                    const uint32_t count = uint32_t(info[c + 1] - info[c]);
+                    if(count == 0) continue;
+                    firstRoundAny = true;
+                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[8 + c], info[5 + c]);
+                }
+                firstRoundLaunched = true;
+                members.assign(n, 0);                       // (positions 0 .. n-1 of the device's list: later rounds append after them)
+                membersUploaded = n;
+                for(uint32_t q = 0; q < n; q++) {
+                    const int c = cellsChoice(classRule, hostPairs[q].nx, hostPairs[q].ny).cls;
+                    pairClass[q] = c;
+                    if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); }
+                }
+                MI355X_ASSERT(uint64_t(n) - info[4] == bigList.size());
+                static const bool debugPrepare = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
+                if(debugPrepare) std::fprintf(stderr, "cells: lists made on the device: %llu + %llu + %llu chunks, %llu + %llu + %llu candidates\n", info[1] - info[0], info[2] - info[1], info[3] - info[2], info[5], info[6], info[7]);
+            } else
             // Every candidate tables whichever of its two reads lands in the smaller class (ties: read
             // 0) and is grouped with the other candidates that table the same oriented read.
             {
@@ -962,10 +1003,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 keyed.reserve(n);
                 for(uint32_t q = 0; q < n; q++) {
                     const PairDesc& pd = hostPairs[q];
-                    const int c0 = classFor(pd.nx, pd.nx, pd.ny);
-                    const int c1 = pd.ny < pd.nx ? classFor(pd.ny, pd.nx, pd.ny) : CELLS_CLASSES;
-                    const bool sw = c1 < c0;
-                    const int c = sw ? c1 : c0;
+                    const CellsChoice choice = cellsChoice(classRule, pd.nx, pd.ny);
+                    const bool sw = choice.swapped;
+                    const int c = choice.cls;
                     pairClass[q] = c;
                     if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); continue; }
                     Keyed kd; kd.tabled = sw ? pd.begin1 : pd.begin0; kd.pair = q; kd.cls = uint8_t(c); kd.swapped = sw ? 1 : 0;
@@ -1018,16 +1058,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 }
                 std::fprintf(stderr, "cells: HBM-scratch list %zu\n", bigList.size());
             }
-            // deltaX, deltaY >= 2 here (packedOk fails for 1 x anything >= 2046... and d = 1 gives magic 2^32): guard.
-            const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX + 1, 0xffffffffULL));
-            const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY + 1, 0xffffffffULL));
-            cellsMagicX = magicX; cellsMagicY = magicY;
-            // Every candidate is a member once, plus once per class it climbs to after an overflow.
-            const uint64_t memberCapacity = uint64_t(CELLS_CLASSES) * n + 16;
-            b.pairList.reserve(memberCapacity, stream);
-            size_t membersUploaded = 0;
             for(int round = 0; round < CELLS_CLASSES; round++) {
                 bool any = false;
+                if(round == 0 && firstRoundLaunched) any = firstRoundAny;
+                else {
                 if(members.size() > membersUploaded) {
                     MI355X_ASSERT(members.size() <= memberCapacity);
                     HIP_CHECK(hipMemcpyAsync(b.pairList.data() + membersUploaded, members.data() + membersUploaded,
@@ -1052,6 +1086,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     }
                     launchCellsChunks(ctx, ws, b, c, b.chunks.data() + chunkOffset, uint32_t(list.size()), opt, magicX, magicY, taskCapacity, bytes, candidatesIn);
                     chunkOffset += list.size();
+                }
                 }
                 if(!any) break;
                 // Candidates that overflowed their tables climb one class.

@@ -1,0 +1,134 @@
+// Align4 on MI355X: which table class a candidate's cells run in (one function for the host and the device), and the
+// preparation of a batch's first round on the device -- classes, the grouping of the candidates by (class, tabled oriented
+// read) and the chunk lists of the three classes -- where the host did it with a loop, a sort and a walk over the sorted
+// list before the batch's first kernel could start.  Included by align4.hip inside its anonymous namespace, after the class
+// geometry (CELLS_NA_LOG2, CELLS_SC_LOG2, CELLS_CHUNK_MAX).
+#pragma once
+
+// (constexpr arrays cannot be indexed by a run-time value in device code; these can)
+__host__ __device__ inline int cellsNaLog2(int c) { return c == 0 ? CELLS_NA_LOG2[0] : (c == 1 ? CELLS_NA_LOG2[1] : CELLS_NA_LOG2[2]); }
+__host__ __device__ inline int cellsScLog2(int c) { return c == 0 ? CELLS_SC_LOG2[0] : (c == 1 ? CELLS_SC_LOG2[1] : CELLS_SC_LOG2[2]); }
+__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : CELLS_CHUNK_MAX[2]); }
+static_assert(CELLS_CLASSES == 3, "cellsNaLog2 / cellsScLog2 / cellsChunkMax name three classes");
+
+struct CellsClassRule { uint64_t deltaX, deltaY; bool packedOk; };
+inline CellsClassRule cellsClassRule(const DeviceOptions& opt)
+{
+    CellsClassRule r;
+    r.deltaX = opt.deltaX; r.deltaY = opt.deltaY;
+    // The packed LDS cell word counts up to 2^CELLS_COUNT_BITS - 1 entries; a cell holds at most
+    // ceil(deltaX * deltaY / 2) (one (x,y) per lattice point of the right parity).
+    r.packedOk = (uint64_t(opt.deltaX) * opt.deltaY + 1) / 2 < (1ULL << CELLS_COUNT_BITS) && opt.deltaX >= 2 && opt.deltaY >= 2;
+    return r;
+}
+// Class of a candidate that tables a read of `tabled` markers: table of the tabled read at load <= 1/2, cell table sized for
+// the expected number of distinct cells (random background ~ nx*ny / alphabet, plus the diagonal) at load <= 3/4.  Overflow is
+// detected on the device and climbs one class.  CELLS_CLASSES: the kernel with its tables in HBM scratch.
+__host__ __device__ inline int cellsClassFor(const CellsClassRule& rule, uint64_t tabled, uint64_t nx, uint64_t ny)
+{
+    if(nx >= 65535 || ny >= 65535 || !rule.packedOk) return CELLS_CLASSES;
+    // Cell indices must fit the packed word and the single-multiply division must be exact.
+    if((nx + ny) / rule.deltaX >= (1ULL << CELLS_IX_BITS) || (nx + ny) / rule.deltaY >= (1ULL << CELLS_IY_BITS)) return CELLS_CLASSES;
+    if((nx + ny) * (rule.deltaX > rule.deltaY ? rule.deltaX : rule.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
+    const uint64_t cells = (nx * ny >> SHASTA_CELLS_ESTIMATE_SHIFT) + (nx + ny) / 32 + 32;
+    for(int c = 0; c < CELLS_CLASSES; c++) {
+        if(tabled < (1ULL << cellsNaLog2(c)) && 4 * cells <= (3ULL << cellsScLog2(c))) return c;
+    }
+    return CELLS_CLASSES;
+}
+// Every candidate tables whichever of its two reads lands in the smaller class (ties: read 0).
+struct CellsChoice { int cls; bool swapped; };
+__host__ __device__ inline CellsChoice cellsChoice(const CellsClassRule& rule, uint32_t nx, uint32_t ny)
+{
+    const int c0 = cellsClassFor(rule, nx, nx, ny);
+    const int c1 = ny < nx ? cellsClassFor(rule, ny, nx, ny) : CELLS_CLASSES;
+    CellsChoice r;
+    r.swapped = c1 < c0;
+    r.cls = r.swapped ? c1 : c0;
+    return r;
+}
+
+// ---- the first round's lists on the device ------------------------------------------------------------------------------
+// Sort key of a candidate: class | swapped | first marker of the tabled oriented read (tabledBits bits).  A STABLE sort leaves
+// the candidates of a (class, swapped, tabled read) group adjacent and in ascending order -- the groups the host walk made,
+// class by class -- and the candidates of the HBM-scratch kernel (class CELLS_CLASSES) at the end.
+// info: [0..3] = first chunk of class 0, 1, 2 and the number of chunks; [4] = position of the first HBM-scratch candidate
+//       in the sorted list; [5 + c] = candidates of class c; [8 + c] = their algorithmic bytes, 4 (nx + ny) each.
+constexpr int CELLS_PREPARE_INFO = 12;
+
+__global__ void __launch_bounds__(256)
+cellsClassKeysKernel(const PairDesc* __restrict__ pairs, uint32_t n, CellsClassRule rule, int tabledBits,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ ids, unsigned long long* __restrict__ info)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    unsigned long long bytes = 0;
+    if(q < n) {
+        const PairDesc pd = pairs[q];
+        const CellsChoice choice = cellsChoice(rule, pd.nx, pd.ny);
+        cls = choice.cls;
+        const uint64_t tabled = choice.swapped ? pd.begin1 : pd.begin0;
+        keys[q] = (uint64_t(cls) << (tabledBits + 1)) | (uint64_t(choice.swapped ? 1 : 0) << tabledBits) | tabled;
+        ids[q] = q;
+        bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
+    }
+#pragma unroll
+    for(int c = 0; c < CELLS_CLASSES; c++) {
+        const uint64_t votes = __ballot(cls == c);
+        if(votes == 0) continue;
+        unsigned long long classBytes = cls == c ? bytes : 0;
+        for(int d = 32; d >= 1; d >>= 1) classBytes += __shfl_down(classBytes, d, WAVE);
+        if(laneId() == 0) {
+            atomicAdd(&info[5 + c], (unsigned long long)__popcll(votes));
+            atomicAdd(&info[8 + c], classBytes);
+        }
+    }
+}
+
+// First position of the sorted keys that is not below `key`.
+__device__ inline uint32_t cellsLowerBound(const uint64_t* __restrict__ keys, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while(lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if(keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// flags[i] = 1 where a chunk begins: every cellsChunkMax(class) candidates of a group; flags[n] = 0.
+__global__ void __launch_bounds__(256)
+cellsChunkHeadsKernel(const uint64_t* __restrict__ sortedKeys, uint32_t n, int tabledBits, uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i > n) return;
+    uint32_t head = 0;
+    if(i < n) {
+        const uint64_t key = sortedKeys[i];
+        const int cls = int(key >> (tabledBits + 1));
+        if(cls < CELLS_CLASSES) head = ((i - cellsLowerBound(sortedKeys, n, key)) % cellsChunkMax(cls)) == 0 ? 1u : 0u;
+    }
+    flags[i] = head;
+}
+
+// ranks = exclusive scan of the flags over n + 1 elements.
+__global__ void __launch_bounds__(256)
+cellsChunkWriteKernel(const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ ranks, uint32_t n, int tabledBits,
+    CellsChunk* __restrict__ chunks, unsigned long long* __restrict__ info)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n && ranks[i + 1] != ranks[i]) {
+        const uint64_t key = sortedKeys[i];
+        const int cls = int(key >> (tabledBits + 1));
+        const uint32_t groupEnd = cellsLowerBound(sortedKeys, n, key + 1);
+        CellsChunk ch;
+        ch.firstMember = i; ch.count = uint16_t(min(cellsChunkMax(cls), groupEnd - i)); ch.swapped = uint16_t((key >> tabledBits) & 1);
+        ch.naLog2 = uint32_t(cellsNaLog2(cls)); ch.scLog2 = uint32_t(cellsScLog2(cls));
+        chunks[ranks[i]] = ch;
+    }
+    if(i <= uint32_t(CELLS_CLASSES)) {
+        const uint32_t first = cellsLowerBound(sortedKeys, n, uint64_t(i) << (tabledBits + 1));      // first candidate of class i
+        info[i] = ranks[first];
+        if(i == uint32_t(CELLS_CLASSES)) info[4] = first;
+    }
+}

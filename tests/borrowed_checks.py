@@ -1,8 +1,8 @@
 """Borrowed aligner results (align4_run_borrowed) over SEVERAL batches: a batch whose predecessors are done is copied into the
 context's arrays while later batches are still running; the result must equal the owned one, call after call (the second call
 finds arrays sized by the first and places every batch early; a third, larger call outgrows them again).
-And the graded batch schedule (an experiment switch: short first batches, shrinking last ones) against batches of equal
-size, and both against the oracle.
+And the graded batch schedule (an experiment switch: short first batches, shrinking last ones) and batches whose first chunk
+lists are made on the device (another one) against batches of equal size prepared by the host, and those against the oracle.
 Run in a process of its own (the batch size is read once per process):
     SHASTA_MI355X_ALIGN_BATCH_LOG2=10 python -m tests.borrowed_checks <library.so> [oracle]"""
 import os
@@ -41,6 +41,10 @@ def main(path, oracle=None):
         scheduled = ctx.align4(cand, o, want_ordinals=True)
         del os.environ["SHASTA_MI355X_ALIGN_GRADED_BATCHES"]
         support.same_align(scheduled, equal)
+        os.environ["SHASTA_MI355X_DEVICE_BATCH_PREP"] = "1"              # every batch's first chunk lists made by kernels (align4_prepare.hpp)
+        prepared = ctx.align4(cand, o, want_ordinals=True)
+        del os.environ["SHASTA_MI355X_DEVICE_BATCH_PREP"]
+        support.same_align(prepared, equal)
         if oracle:
             from oracle import bindings
             expected = bindings.OracleLib().align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)

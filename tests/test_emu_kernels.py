@@ -149,6 +149,29 @@ def test_adversarial_read_sets_through_both_aligners(emu_lib, oracle_lib, ref_li
     adversarial.aligner_case(emu_lib, oracle_lib, name, long_reads=False, ref_lib=ref_lib)
 
 
+@pytest.mark.parametrize("name", [n for n in adversarial.READ_SET_NAMES[:-1]])
+def test_adversarial_read_sets_with_the_first_chunk_lists_made_on_the_device(emu_lib, oracle_lib, ref_lib, monkeypatch, name):
+    # SHASTA_MI355X_DEVICE_BATCH_PREP=1 (read for every batch): classes, grouping sort and chunk lists by kernels (align4_prepare.hpp)
+    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "1")
+    adversarial.aligner_case(emu_lib, oracle_lib, name, long_reads=False, ref_lib=ref_lib)
+
+
+def test_mixed_length_reads_with_the_first_chunk_lists_made_on_the_device(emu_lib, oracle_lib, monkeypatch):
+    # Every table class, swapped chunks, the overflow ladder after device-made lists, the HBM-scratch list (the test of
+    # tests/test_gpu_align4.py, its second read set cut to 450 candidates for the emulator's time).
+    from shasta_amd import synthetic
+    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "1")
+    toc, kmer = synthetic.marker_reads(160, 60000, mean_markers=6000.0, sigma=0.6, min_markers=300, seed=52)
+    data7 = synthetic.pack_markers(toc, kmer)
+    p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=40, minFrequency=1)
+    cand = oracle_lib.lowhash0(toc, data7, None, p).candidates[:450]
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    a = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+    b = emu_lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
+    support.same_align(a, b)
+    assert (a.status == abi.SHASTA_ALIGN_STORED).sum() > 10
+
+
 def test_adversarial_lowhash0(emu_lib, oracle_lib):
     adversarial.lowhash0(emu_lib, oracle_lib)
 
