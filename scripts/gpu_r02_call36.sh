@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the switch this script toggles existed in commit c87ea6f only)
 # A/B of the aligner's batch schedule (short first batches, shrinking last ones) against batches of equal size, same box, same session.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

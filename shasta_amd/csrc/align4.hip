@@ -697,26 +697,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const int l = e ? std::atoi(e) : 18;
         return 1ULL << std::min(std::max(l, 10), 20);
     }();
-    // Where the batches begin: every BATCH candidates.  SHASTA_MI355X_ALIGN_GRADED_BATCHES=1 (a timing experiment, measured and not
-    // adopted: 171-174 against 167-171 ms per call, profiles/r02_call36_batch_schedule.log) makes the first batches short (all
-    // workers prepare their first batch together and the device waits for the first of them) and lets the last ones shrink with
-    // what is left (a share of it per worker, not below a quarter of a batch; the workers that are done wait for the last batch).
+    // Where the batches begin: every BATCH candidates.  (Graded batches -- short first ones, because all workers prepare their
+    // first batch together while the device waits, and shrinking last ones -- were measured against these and dropped: 171-174
+    // against 167-171 ms per call, profiles/r02_call36_batch_schedule.log.)
     std::vector<uint64_t> batchStart(1, 0);
-    {
-        const char* e = std::getenv("SHASTA_MI355X_ALIGN_GRADED_BATCHES");
-        const bool equalBatches = !(e && std::atoi(e) != 0) || candidateCount < 2 * BATCH;
-        const uint64_t share = uint64_t(ALIGN_DEFAULT_WORKERS);
-        const uint64_t ramp[3] = {BATCH / 8, BATCH / 4, BATCH / 2};
-        while(batchStart.back() < candidateCount) {
-            const uint64_t left = candidateCount - batchStart.back();
-            uint64_t size = BATCH;
-            if(!equalBatches) {
-                const size_t k = batchStart.size() - 1;
-                size = k < 3 ? ramp[k] : std::min(BATCH, std::max(BATCH / 4, left / share));
-            }
-            batchStart.push_back(batchStart.back() + std::min(left, size));
-        }
-    }
+    while(batchStart.back() < candidateCount) batchStart.push_back(std::min<uint64_t>(candidateCount, batchStart.back() + BATCH));
     const uint64_t batchCount = batchStart.size() - 1;
 
     if(borrowed && !ctx.alignStore) ctx.alignStore = std::make_shared<AlignStore>();

@@ -111,7 +111,7 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "150", "--steps", "1", "--warmup", "0"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "100", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -141,7 +141,7 @@ def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):
     env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, HIPEMU_THREADS="4")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "150"],
+                          "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "100"],
                          env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
