@@ -123,7 +123,7 @@ struct BatchScratch {
     DeviceBuffer<uint8_t> bytes, bigLog2;
     DeviceBuffer<uint32_t> pairList, bigScratch;
     DeviceBuffer<CellsChunk> chunks;
-    DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, iterations)
+    DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, whole / partial lanes, iterations)
     DeviceBuffer<uint64_t> bundleWords;
     DeviceBuffer<DpEnd> ends;
     PinnedBuffer pinRows, pinToc, pinBytes, pinStatus, pinOrdToc, pinOrdinals;   // device-to-host staging
@@ -587,7 +587,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
         std::fprintf(stderr, "\n");
     }
     const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
-    // The traceback of every class in one launch (the list is sorted by class, then length; the kernel takes it from the end).
+    // The traceback of every class in one launch (the list is sorted by class, then in two runs of ascending length; the kernel takes it from the end).
     // Booked: the trace it has to read = 2 bits per cell of the padded bands (iterations x 2 C words, bounded by sums[1] for
     // the whole batch), work = tasks.
     {

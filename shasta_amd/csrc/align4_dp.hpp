@@ -62,7 +62,7 @@ __host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMa
 // What the forward kernel leaves for the traceback of a task.
 struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase, bundleIterations, pad; };   // bundleIterations: of the longest task of the bundle
 
-// Per task: sort key (class, iterations), ordinal capacity, statistics.
+// Per task: sort key (class, whole / partial lanes, iterations), ordinal capacity, statistics.
 __global__ void __launch_bounds__(256)
 dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
@@ -465,7 +465,7 @@ bandedDpForwardKernel(
 //    the walk unrolled over a chunk's iterations and both cells of each for C = 2 and 4 -- 66 VALU instructions per
 //    possible cell, issued whether the lane's path was there or not -- plus this kernel for C = 8, 16) paid for three
 //    longest paths: 77 ms per step solo against 52 for this kernel alone, before it was trimmed;
-//  * the longest tasks go first (the list is sorted by class, then ascending length: lane order is reversed), so that
+//  * the longest tasks go first (the list is sorted by class, then in two runs of ascending length: lane order is reversed), so that
 //    the tail of the launch is made of short paths.
 // The walk itself only stores the aligned pairs (from the end of the task's ordinal range downwards) and counts
 // them; everything that can be computed from the stored pairs afterwards -- AlignmentInfo's metrics, the inner
