@@ -6,7 +6,11 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstdio>
 #include <mutex>
 #include <stdexcept>
@@ -225,6 +229,54 @@ uint64_t collective(int kind, uint64_t value, uint64_t aux)
     return f->result;
 }
 
+// Helper threads that live as long as the process: a launch hands out tickets for its block loop, runs the loop itself too,
+// and when its own pass is over takes back the tickets nobody picked up and waits for the helpers that did.  (A thread per
+// launch mapped and unmapped its fiber stacks every time: most of a test run was spent in the kernel's memory management.)
+struct Job { const std::function<void()>* work; int active = 0; };
+struct HelperPool {
+    std::mutex mutex;
+    std::condition_variable ticketPosted, helperDone;
+    std::deque<Job*> tickets;
+    unsigned threadCount = 0;
+};
+HelperPool& helperPool() { static HelperPool* pool = new HelperPool; return *pool; }       // (never destroyed: its threads never end)
+
+void helperLoop()
+{
+    HelperPool& pool = helperPool();
+    for(;;) {
+        Job* job = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(pool.mutex);
+            pool.ticketPosted.wait(lock, [&] { return !pool.tickets.empty(); });
+            job = pool.tickets.front(); pool.tickets.pop_front();
+            ++job->active;
+        }
+        (*job->work)();
+        {
+            std::lock_guard<std::mutex> lock(pool.mutex);
+            --job->active;
+        }
+        pool.helperDone.notify_all();
+    }
+}
+
+void runWithHelpers(const std::function<void()>& work, unsigned helpers, unsigned poolSize)
+{
+    HelperPool& pool = helperPool();
+    Job job; job.work = &work;
+    {
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        for(; pool.threadCount < poolSize; ++pool.threadCount) std::thread(helperLoop).detach();
+        for(unsigned k = 0; k < helpers; k++) pool.tickets.push_back(&job);
+    }
+    pool.ticketPosted.notify_all();
+    work();
+    std::unique_lock<std::mutex> lock(pool.mutex);
+    pool.tickets.erase(std::remove(pool.tickets.begin(), pool.tickets.end(), &job), pool.tickets.end());
+    pool.helperDone.wait(lock, [&] { return job.active == 0; });
+}
+
 void launch(const Launch& L)
 {
     const uint64_t blocks = uint64_t(L.grid.x) * L.grid.y * L.grid.z;
@@ -236,7 +288,7 @@ void launch(const Launch& L)
     }();
     std::atomic<uint64_t> next(0);
     std::string error;
-    auto work = [&]() {
+    const std::function<void()> work = [&]() {
         try {
             for(;;) {
                 const uint64_t b = next.fetch_add(1);
@@ -252,12 +304,7 @@ void launch(const Launch& L)
     };
     const unsigned threads = unsigned(std::min<uint64_t>(maxThreads, blocks));
     if(threads <= 1) work();
-    else {
-        std::vector<std::thread> pool;
-        for(unsigned t = 1; t < threads; t++) pool.emplace_back(work);
-        work();
-        for(auto& t : pool) t.join();
-    }
+    else runWithHelpers(work, threads - 1, maxThreads - 1);
     if(!error.empty()) throw std::runtime_error(error);
 }
 
