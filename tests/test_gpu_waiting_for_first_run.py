@@ -1,0 +1,48 @@
+"""GPU tests of what was written after the round's last GPU call and has run on the emulated build only: they join the -m gpu
+suite when SHASTA_TEST_FIRST_GPU_RUN=1 is set for the first call of the next round (scripts/gpu_profile.sh does not set it;
+run `SHASTA_TEST_FIRST_GPU_RUN=1 python -m pytest tests/test_gpu_waiting_for_first_run.py -m gpu` first), and lose the
+switch once they have passed there."""
+import os
+
+import numpy as np
+import pytest
+
+from shasta_amd import abi, synthetic
+from tests import adversarial, support
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.environ.get("SHASTA_TEST_FIRST_GPU_RUN"), reason="waits for its first GPU run (SHASTA_TEST_FIRST_GPU_RUN=1)")]
+
+
+def test_banded_dp_wavefront_with_tasks_of_both_runs_of_its_class(gpu_lib, oracle_lib):
+    from tests import dp_geometry_checks
+    for seed in (3, 4, 5, 6):
+        cases, bad = dp_geometry_checks.straddling_bundles(gpu_lib, oracle_lib, seed, long_tasks=6 + seed, short_tasks=7)
+        assert cases == 13 + seed and bad == 0
+
+
+@pytest.mark.parametrize("name", adversarial.READ_SET_NAMES)
+def test_adversarial_read_sets_with_the_first_chunk_lists_made_on_the_device(gpu_lib, oracle_lib, ref_lib, monkeypatch, name):
+    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "1")
+    adversarial.aligner_case(gpu_lib, oracle_lib, name, long_reads=True, ref_lib=ref_lib)
+
+
+@pytest.mark.parametrize("seed,mean,sigma", [(51, 3000.0, 0.8), (52, 6000.0, 0.6)])
+def test_mixed_length_reads_with_the_first_chunk_lists_made_on_the_device(gpu_lib, oracle_lib, monkeypatch, seed, mean, sigma):
+    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "1")
+    toc, kmer = synthetic.marker_reads(160, 60000, mean_markers=mean, sigma=sigma, min_markers=300, seed=seed)
+    data7 = synthetic.pack_markers(toc, kmer)
+    p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=40, minFrequency=1)
+    cand = oracle_lib.lowhash0(toc, data7, None, p).candidates[:1200]
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    a = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+    b = gpu_lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
+    support.same_align(a, b)
+
+
+def test_many_small_batches_with_the_first_chunk_lists_made_on_the_device(gpu_lib):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10")
+    out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", gpu_lib.path, "oracle", "device-prepare"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
