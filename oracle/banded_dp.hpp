@@ -50,6 +50,22 @@ struct TiePolicy {
     bool firstMaximumWins = true;
 };
 
+// The policy in force in this process (each shared library that includes this header has its own copy and its own
+// setter: oracle_set_tie_policy / ref_set_tie_policy).  Default-constructed = the reading above.  The tie census of
+// bench.py and tests/test_tie_census.py run the aligner under every other policy to count what depends on the reading.
+inline TiePolicy& activeTiePolicy() { static TiePolicy policy; return policy; }
+// Policies by number: index = 2 * order + (lastMaximumWins ? 1 : 0), order over the six priority orders of
+// (diagonal, vertical, horizontal): 0 DVH (the reading), 1 DHV, 2 VDH, 3 VHD, 4 HDV, 5 HVD.
+inline TiePolicy tiePolicyByIndex(int index)
+{
+    static const int ranks[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};   // {diagonal, vertical, horizontal} rank
+    TiePolicy p;
+    const int order = (index / 2) % 6;
+    p.diagonalRank = ranks[order][0]; p.verticalRank = ranks[order][1]; p.horizontalRank = ranks[order][2];
+    p.firstMaximumWins = (index & 1) == 0;
+    return p;
+}
+
 enum TraceOp : uint8_t { TRACE_NONE = 0, TRACE_DIAG = 1, TRACE_VERT = 2, TRACE_HORI = 3 };
 
 struct BandedDpResult {
@@ -69,7 +85,7 @@ inline void bandedOverlapAlignment(
     int32_t matchScore, int32_t mismatchScore, int32_t gapScore,
     int32_t bandMin, int32_t bandMax,
     BandedDpResult& result,
-    const TiePolicy& policy = TiePolicy())
+    const TiePolicy& policy = activeTiePolicy())
 {
     result = BandedDpResult();
     if(bandMin > bandMax) return;

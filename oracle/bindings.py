@@ -48,6 +48,11 @@ class _Base:
         if rc != 0:
             raise RuntimeError("%s failed: %s" % (what, self._last_error().decode()))
 
+    def set_tie_policy(self, index):
+        """The DP tie policy of this library's shimmed / restated SeqAn call (oracle/banded_dp.hpp, tiePolicyByIndex):
+        0 = the restated reading (diagonal >= vertical >= horizontal, first maximum); 1..11 the alternatives."""
+        getattr(self.lib, self.prefix + "set_tie_policy")(C.c_int(index))
+
     def _align4(self, toc, data7, candidates, options, want_ordinals):
         toc = _u64(toc)
         data7 = np.ascontiguousarray(data7, dtype=np.uint8)

@@ -45,6 +45,8 @@ extern "C" {
 
 const char* oracle_last_error() { return lastError.c_str(); }
 void oracle_free(void* p) { std::free(p); }
+// The DP tie policy of this process's oracle (banded_dp.hpp, tiePolicyByIndex; 0 = the restated reading).  Set between runs, never during one.
+void oracle_set_tie_policy(int index) { activeTiePolicy() = tiePolicyByIndex(index); }
 void oracle_set_threads(uint64_t n) { threadCountSetting = n ? n : std::thread::hardware_concurrency(); }
 
 uint64_t oracle_murmur64a(const void* key, int len, uint64_t seed) { return murmurHash64A(key, len, seed); }

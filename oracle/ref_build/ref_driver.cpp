@@ -71,6 +71,7 @@ using namespace shasta;
 #include <unistd.h>
 
 #include "../../include/shasta_mi355x.h"
+#include "../banded_dp.hpp"
 
 static_assert(sizeof(CompressedMarker) == 7, "CompressedMarker");
 static_assert(sizeof(OrientedReadPair) == sizeof(shasta_oriented_read_pair), "OrientedReadPair");
@@ -499,6 +500,10 @@ static void copyInfo(const AlignmentInfo& info, shasta_alignment_info& out)
     out.maxSkip = info.maxSkip;
     out.maxDrift = info.maxDrift;
 }
+
+// The tie policy of the shimmed SeqAn call inside this library's Align4.cpp / AssemblerAlign3.cpp (shims/seqan/align.h ->
+// oracle/banded_dp.hpp): 0 = the restated reading; the tie census runs the reference's control flow under the others.
+void ref_set_tie_policy(int index) { oracle::activeTiePolicy() = oracle::tiePolicyByIndex(index); }
 
 int ref_align4_batch_mt(
     uint64_t readCount,

@@ -89,7 +89,7 @@ constexpr uint32_t ALIGN3_WIDE_MAX_DIAGONALS = 8192;      // 3 rows of 32 KB in 
 // here (src/AssemblerAlign3.cpp:22-314), this path's limit is the size of the trace, 2 W ceil(W / 64) words per pair.
 constexpr uint32_t ALIGN3_HUGE_MAX_DIAGONALS = 65536;
 
-template<bool HUGE>
+template<bool HUGE, int TIE>
 __global__ void __launch_bounds__(HUGE ? 256 : 64)
 align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ dsPairs,
     const WideTask* __restrict__ tasks, uint32_t taskCount, uint32_t rowWords,
@@ -112,7 +112,7 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
     uint64_t* __restrict__ tr = trace + task.traceOffset;
     for(uint32_t k = threadIdx.x; k < 3u * rowWords; k += blockDim.x) rows[k] = NEG_SCORE;
     __syncthreads();
-    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+    int32_t bestScore = NEG_SCORE, bestI = DpTie<TIE>::noEndCell, bestJ = DpTie<TIE>::noEndCell;
     for(int32_t s = 0; s <= nx + ny; s++) {
         int32_t* const cur = rows + uint32_t(s % 3) * rowWords;
         const int32_t* const prev1 = rows + uint32_t((s + 2) % 3) * rowWords;     // s - 1
@@ -132,13 +132,15 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
                     const int32_t dg = prev2[b] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
                     const int32_t vg = (b + 1 < W ? prev1[b + 1] : NEG_SCORE) + GAP_SCORE;     // from (i, j-1)
                     const int32_t hg = (b >= 1 ? prev1[b - 1] : NEG_SCORE) + GAP_SCORE;        // from (i-1, j)
-                    isV = vg > dg;
-                    const int32_t m1 = max(dg, vg);
-                    isH = hg > m1;
-                    v = max(m1, hg);
+                    // The first of the tie policy's order of (diagonal, vertical, horizontal) that reaches the maximum.
+                    v = max(max(dg, vg), hg);
+                    const int32_t candidates[3] = {dg, vg, hg};
+                    const bool first = v == candidates[DpTie<TIE>::first], second = !first && v == candidates[DpTie<TIE>::second], third = !first && !second;
+                    isV = DpTie<TIE>::first == DpTie<TIE>::VERTICAL ? first : (DpTie<TIE>::second == DpTie<TIE>::VERTICAL ? second : third);
+                    isH = DpTie<TIE>::first == DpTie<TIE>::HORIZONTAL ? first : (DpTie<TIE>::second == DpTie<TIE>::HORIZONTAL ? second : third);
                 }
-                // Free trailing gaps: the best cell of the last row and column, ties to the smallest (i, j).
-                if((i == nx || j == ny) && (v > bestScore || (v == bestScore && (i < bestI || (i == bestI && j < bestJ))))) {
+                // Free trailing gaps: the best cell of the last row and column, ties by the policy.
+                if((i == nx || j == ny) && (v > bestScore || (v == bestScore && DpTie<TIE>::endCellWins(i, j, bestI, bestJ)))) {
                     bestScore = v; bestI = i; bestJ = j;
                 }
             }
@@ -154,7 +156,7 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const int32_t os = __shfl_xor(bestScore, dlt, WAVE);
         const int32_t oi = __shfl_xor(bestI, dlt, WAVE);
         const int32_t oj = __shfl_xor(bestJ, dlt, WAVE);
-        if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+        if(os > bestScore || (os == bestScore && DpTie<TIE>::endCellWins(oi, oj, bestI, bestJ))) { bestScore = os; bestI = oi; bestJ = oj; }
     }
     if(HUGE) {
         // The wavefronts' best cells meet in LDS.
@@ -162,7 +164,7 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         __syncthreads();
         for(uint32_t w = 0; w < waves; w++) {
             const int32_t os = sBest[3 * w], oi = sBest[3 * w + 1], oj = sBest[3 * w + 2];
-            if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+            if(os > bestScore || (os == bestScore && DpTie<TIE>::endCellWins(oi, oj, bestI, bestJ))) { bestScore = os; bestI = oi; bestJ = oj; }
         }
     }
     if(threadIdx.x == 0) { WideEnd e; e.bestI = bestI; e.bestJ = bestJ; e.score = bestScore; e.pad = 0; ends[t] = e; }

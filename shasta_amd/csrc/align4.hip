@@ -123,7 +123,7 @@ struct BatchScratch {
     DeviceBuffer<uint8_t> bytes, bigLog2;
     DeviceBuffer<uint32_t> pairList, bigScratch;
     DeviceBuffer<CellsChunk> chunks;
-    DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, whole / partial lanes, iterations)
+    DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, iterations)
     DeviceBuffer<uint64_t> bundleWords;
     DeviceBuffer<DpEnd> ends;
     PinnedBuffer pinRows, pinToc, pinBytes, pinStatus, pinOrdToc, pinOrdinals;   // device-to-host staging
@@ -232,7 +232,20 @@ void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int 
 }
 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
-struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; };
+struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; int tie; };
+
+// The tie policy of a call (align4_dp.hpp, DpTie): the build's DP_TIE_POLICY, unless SHASTA_MI355X_DP_TIE_POLICY names the one
+// alternative compiled beside it (parity tests of the switch; read for every call: tests change it).
+int dpTiePolicyOfCall()
+{
+    const char* e = std::getenv("SHASTA_MI355X_DP_TIE_POLICY");
+    if(!e || !*e) return DP_TIE_POLICY;
+    const int v = std::atoi(e);
+    if(v != DP_TIE_POLICY && v != DP_TIE_ALTERNATIVE)
+        throw std::runtime_error("SHASTA_MI355X_DP_TIE_POLICY=" + std::string(e) + ": this build holds the tie policies " + std::to_string(DP_TIE_POLICY) +
+            " (default) and " + std::to_string(DP_TIE_ALTERNATIVE) + " (rebuild with -DSHASTA_DP_TIE_POLICY=<n> for another).");
+    return v;
+}
 
 template<int G, int C>
 void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, const uint32_t* sortedIds, const DpClassLayout& layout, int cls)
@@ -240,12 +253,16 @@ void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, con
     const uint32_t taskCount = layout.taskStart[cls + 1] - layout.taskStart[cls];
     const uint32_t bundleCount = layout.bundleStart[cls + 1] - layout.bundleStart[cls];
     if(taskCount == 0) return;
-    hipLaunchKernelGGL((bandedDpForwardKernel<G, C>), dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
-        in.kmerIds, in.pairs, in.tasks,
-        sortedIds + layout.taskStart[cls], taskCount,
-        (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
-        b.trace.data(), b.ends.data());
-    HIP_CHECK(hipGetLastError());
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(divUp(bundleCount, 4)), dim3(256), 0, stream,
+            in.kmerIds, in.pairs, in.tasks,
+            sortedIds + layout.taskStart[cls], taskCount,
+            (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
+            b.trace.data(), b.ends.data());
+        HIP_CHECK(hipGetLastError());
+    };
+    if(in.tie == DP_TIE_POLICY) launch(&bandedDpForwardKernel<G, C, DP_TIE_POLICY>);
+    else launch(&bandedDpForwardKernel<G, C, DP_TIE_ALTERNATIVE>);
 }
 
 // K10 for the taskCount tasks in b.tasks (pairs in b.pairs): fills b.results, b.ordScratch and
@@ -289,7 +306,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
     exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
     const bool inB = radixSort<uint32_t, uint32_t, true>(b.dpKeysA.data(), b.dpKeysB.data(), b.dpIdsA.data(), b.dpIdsB.data(),
-        taskCount, 28, *ws.sortWs, stream);
+        taskCount, DP_SORT_KEY_BITS, *ws.sortWs, stream);
     const uint32_t* sortedKeys = inB ? b.dpKeysB.data() : b.dpKeysA.data();
     const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
     f.sortedIds = sortedIds;
@@ -564,7 +581,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     DpEvents* ev, DpBatchStats* stats)
 {
     hipStream_t stream = ws.stream;
-    const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data()};
+    const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data(), dpTiePolicyOfCall()};
     static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
     if(debug) {
         // Band widths of the batch's tasks, DP cells (nx x width) per width.
@@ -587,7 +604,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
         std::fprintf(stderr, "\n");
     }
     const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
-    // The traceback of every class in one launch (the list is sorted by class, then in two runs of ascending length; the kernel takes it from the end).
+    // The traceback of every class in one launch (the list is sorted by class, then by ascending length; the kernel takes it from the end).
     // Booked: the trace it has to read = 2 bits per cell of the padded bands (iterations x 2 C words, bounded by sums[1] for
     // the whole batch), work = tasks.
     {
@@ -775,7 +792,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             pd.begin0 = ctx.hostToc[o0]; pd.begin1 = ctx.hostToc[o1];
             const uint64_t nx = ctx.hostToc[o0 + 1] - pd.begin0, ny = ctx.hostToc[o1 + 1] - pd.begin1;
             // (the DP's sort key holds (nx + ny) / 2 iterations in 24 bits, its biased scores i + j < 2^25: align4_dp.hpp)
-            if(nx + ny >= (1ULL << 25)) throw std::runtime_error("Align4: a candidate's two reads have 2^25 markers or more between them (not supported).");
+            if(nx + ny >= (1ULL << 25) - 4) throw std::runtime_error("Align4: a candidate's two reads have 2^25 - 4 markers or more between them (not supported).");
             pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
@@ -844,7 +861,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
             if(taskCount1) {
                 HIP_CHECK(hipMemcpyAsync(b.tasks1.data(), tasks1.data(), taskCount1 * sizeof(DpTask), hipMemcpyHostToDevice, stream));
-                const DpInput in{ds->kmerIds.data(), b.dsPairs.data(), b.tasks1.data()};
+                const DpInput in{ds->kmerIds.data(), b.dsPairs.data(), b.tasks1.data(), dpTiePolicyOfCall()};
                 const DpForwardState f = runDpForward(ws, b, in, taskCount1, false, nullptr, nullptr);
                 out.dpCells += f.sums[0];
                 hipLaunchKernelGGL(align3BandKernel<false>, dim3(divUp(taskCount1, 256)), dim3(256), 0, stream,
@@ -876,18 +893,24 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), wide.data() + begin, count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
                 const size_t ldsBytes = 3 * size_t(rowWords) * sizeof(int32_t);
                 std::call_once(ctx.wideDpLdsAttribute, [] {
-                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false>),
+                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_POLICY>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
+                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_ALTERNATIVE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
                 });
+                const bool alternativeTie = dpTiePolicyOfCall() != DP_TIE_POLICY;
                 if(hugeRows) {
                     b.hugeRows.reserve(size_t(count) * 3u * rowWords, stream);
-                    hipLaunchKernelGGL(align3WideDpKernel<true>, dim3(count), dim3(256), 0, stream,
+                    const auto kernel = alternativeTie ? &align3WideDpKernel<true, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<true, DP_TIE_POLICY>;
+                    hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, stream,
                         (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
                         b.trace.data(), b.wideEnds.data(), b.hugeRows.data());
-                } else
-                hipLaunchKernelGGL(align3WideDpKernel<false>, dim3(count), dim3(64), ldsBytes, stream,
-                    (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
-                    b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr);
+                } else {
+                    const auto kernel = alternativeTie ? &align3WideDpKernel<false, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<false, DP_TIE_POLICY>;
+                    hipLaunchKernelGGL(kernel, dim3(count), dim3(64), ldsBytes, stream,
+                        (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
+                        b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr);
+                }
                 HIP_CHECK(hipGetLastError());
                 hipLaunchKernelGGL(align3BandKernel<true>, dim3(divUp(count, 256)), dim3(256), 0, stream,
                     (const PairDesc*)b.dsPairs.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)nullptr, (const uint32_t*)nullptr, count,
@@ -1483,7 +1506,7 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     std::vector<DpTask> tasks(taskCount);
     for(uint64_t t = 0; t < taskCount; t++) {
         if(nx[t] == 0 || ny[t] == 0 || begin0[t] + nx[t] > kmerCount || begin1[t] + ny[t] > kmerCount) throw std::runtime_error("banded_dp_many: a sequence is empty or outside kmerIds.");
-        if(uint64_t(nx[t]) + uint64_t(ny[t]) >= (1ULL << 25)) throw std::runtime_error("banded_dp_many: two sequences of 2^25 elements or more between them.");
+        if(uint64_t(nx[t]) + uint64_t(ny[t]) >= (1ULL << 25) - 4) throw std::runtime_error("banded_dp_many: two sequences of 2^25 - 4 elements or more between them.");
         if(bandMin[t] > bandMax[t] || bandMax[t] - bandMin[t] + 1 > 1024) throw std::runtime_error("banded_dp_many: band width must be in [1, 1024].");
         if(bandMin[t] > int32_t(nx[t]) || bandMax[t] < -int32_t(ny[t])) throw std::runtime_error("banded_dp_many: the band misses the matrix.");
         pairs[t].begin0 = begin0[t]; pairs[t].begin1 = begin1[t]; pairs[t].nx = nx[t]; pairs[t].ny = ny[t];

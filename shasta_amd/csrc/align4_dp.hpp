@@ -59,10 +59,21 @@ __host__ __device__ inline DpGeometry dpGeometry(int32_t bandMin, int32_t bandMa
     return g;
 }
 
+// The DP tasks' sort key: (class, iterations) -- 3 bits of class over 24 bits of iterations (the host refuses pairs with
+// nx + ny >= 2^25 - 4, so the count fits).  One ascending run per class: the forward kernel and the traceback take a class's
+// list from its end, longest first.  (Round 2 shipped (class, band width a multiple of C or not, iterations) for a steady loop
+// that switched lanes without diagonals off instead of masking their cells: 6.8 instead of 7.8 VALU instructions per cell by
+// the ISA, and 83 -> 95 ms per step for the forward launches once it was timed -- two ascending runs per class start the
+// second run's longest bundles in the middle of a launch; with one run, or with the two interleaved in steps of 64
+// iterations, the loop itself gained nothing measurable: 83.1 / 83.8 / 84.0 ms, profiles/r03_forward_dp_ab.log.  Both are gone.)
+__host__ __device__ inline uint32_t dpSortKey(int cls, uint32_t iters) { return (uint32_t(cls) << 24) | (iters < 0xffffffu ? iters : 0xffffffu); }
+__host__ __device__ inline uint32_t dpSortKeyIterations(uint32_t key) { return key & 0xffffffu; }
+constexpr int DP_SORT_KEY_BITS = 27;
+
 // What the forward kernel leaves for the traceback of a task.
 struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase, bundleIterations, pad; };   // bundleIterations: of the longest task of the bundle
 
-// Per task: sort key (class, whole / partial lanes, iterations), ordinal capacity, statistics.
+// Per task: sort key (class, iterations), ordinal capacity, statistics.
 __global__ void __launch_bounds__(256)
 dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
@@ -76,11 +87,7 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
         const PairDesc pd = pairs[task.pair];
         const DpGeometry g = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
         cls = g.cls;
-        // (class, band width not a multiple of the class's diagonals per lane, iterations): the tasks of a wavefront of the
-        // forward kernel then mostly agree on whether every lane has all of its diagonals or none (its steady loop without
-        // the "exists" select, see there).
-        const uint32_t partial = (uint32_t(task.bandMax - task.bandMin + 1) & uint32_t(dpDiagonals(g.cls) - 1)) != 0 ? 1u : 0u;
-        keys[t] = (uint32_t(g.cls) << 25) | (partial << 24) | min(g.iters, 0xffffffu);
+        keys[t] = dpSortKey(g.cls, g.iters);
         ids[t] = t;
         ordCap[t] = min(pd.nx, pd.ny);
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
@@ -122,12 +129,52 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
     const uint32_t T = 64u / uint32_t(dpLanes(cls));
     const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
     const uint32_t end = min(first + T, layout.taskStart[cls + 1]);
-    // The task of the bundle with the most iterations (the list of a class is two ascending runs).  Rounded to 256 bytes so
-    // that the traceback's chunks are whole cache lines.
-    uint32_t iterations = 0;
-    for(uint32_t k = first; k < end; k++) iterations = max(iterations, sortedKeys[k] & 0xffffffu);
+    // The task of the bundle with the most iterations = its last (ascending list).  Rounded to 256 bytes so that the
+    // traceback's chunks are whole cache lines.
+    const uint32_t iterations = dpSortKeyIterations(sortedKeys[end - 1]);
     bundleWords[bundle] = (uint64_t(iterations) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
 }
+
+// ---- tie policy --------------------------------------------------------------------------------
+// What SeqAn decides inside seqan::globalAlignment and no test of the reference pins (SeqAn is an un-vendored dependency that
+// is absent here, oracle/banded_dp.hpp): which predecessor a cell keeps when two of them tie, and which border cell ends the
+// alignment when several tie on the maximum.  ONE place: the kernels take the policy as a template parameter, numbered as
+// oracle::tiePolicyByIndex -- TIE = 2 * order + (last maximum wins), order over the six priority orders of (diagonal,
+// vertical, horizontal): 0 DVH, 1 DHV, 2 VDH, 3 VHD, 4 HDV, 5 HVD.  TIE = 0 is the reading of SeqAn 2.4.0 that the oracle
+// restates (dp_formula_linear.h: the diagonal candidate first, replaced by the vertical and then by the horizontal one only on
+// a strictly larger score; dp_scout.h: a later border cell replaces the best only if strictly greater, cells visited
+// column by column).  If a SeqAn run ever disagrees, DP_TIE_POLICY is the line to change; DP_TIE_ALTERNATIVE is compiled
+// beside it and parity-tested against the oracle under the same policy (tests/test_gpu_tie_policy.py) so that the switch is
+// known to work: SHASTA_MI355X_DP_TIE_POLICY=<n> selects it at run time, any other value is an error.
+#ifndef SHASTA_DP_TIE_POLICY
+#define SHASTA_DP_TIE_POLICY 0
+#endif
+#ifndef SHASTA_DP_TIE_ALTERNATIVE
+#define SHASTA_DP_TIE_ALTERNATIVE 3          // D >= H >= V, last maximum
+#endif
+constexpr int DP_TIE_POLICY = SHASTA_DP_TIE_POLICY, DP_TIE_ALTERNATIVE = SHASTA_DP_TIE_ALTERNATIVE;
+static_assert(DP_TIE_POLICY >= 0 && DP_TIE_POLICY < 12 && DP_TIE_ALTERNATIVE >= 0 && DP_TIE_ALTERNATIVE < 12 && DP_TIE_POLICY != DP_TIE_ALTERNATIVE, "tie policies");
+template<int TIE> struct DpTie {
+    enum Move { DIAGONAL = 0, VERTICAL = 1, HORIZONTAL = 2 };
+    static constexpr int order = TIE / 2;
+    static constexpr bool lastMaximum = (TIE & 1) != 0;
+    static constexpr int first = order <= 1 ? DIAGONAL : (order <= 3 ? VERTICAL : HORIZONTAL);
+    static constexpr int second = (order == 2 || order == 4) ? DIAGONAL : ((order == 0 || order == 5) ? VERTICAL : HORIZONTAL);
+    static constexpr int third = 3 - first - second;
+    // kept[m]: the cells (a bit per lane) whose move is m, from equal[m] = "candidate m equals the maximum of the three"
+    // (only equal[first] and equal[second] are read): the first of the order that reaches the maximum.
+    __host__ __device__ static void keep(const uint64_t (&equal)[3], uint64_t (&kept)[3])
+    {
+        kept[first] = equal[first]; kept[second] = equal[second] & ~equal[first]; kept[third] = ~(equal[first] | equal[second]);
+    }
+    // Border cell (i, j) against the best so far at equal score: the first maximum in the scan order (columns i ascending,
+    // rows j ascending inside a column) is the lexicographically smallest (i, j), the last one the largest.
+    __host__ __device__ static bool endCellWins(int32_t i, int32_t j, int32_t bestI, int32_t bestJ)
+    {
+        return lastMaximum ? (i > bestI || (i == bestI && j > bestJ)) : (i < bestI || (i == bestI && j < bestJ));
+    }
+    static constexpr int32_t noEndCell = lastMaximum ? -1 : 0x7fffffff;
+};
 
 // ---- forward kernel ---------------------------------------------------------------------------
 // (The round-1 kernel it replaced -- 75 VALU instructions per iteration, 830 GCUPS on the dominant class against 1360 --
@@ -154,10 +201,6 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, ui
 //    scripts/microbench/trace_store.hip measured both ways of writing the same records: identical bytes, 0.84 -> 0.62 ms.)
 //  * trip counts are made scalar (readfirstlane), so loop control runs on the scalar unit.
 constexpr int DP_BLOCK = 4;
-#ifndef SHASTA_DP_WHOLE_LANES
-#define SHASTA_DP_WHOLE_LANES 1
-#endif
-constexpr bool DP_WHOLE_LANES = SHASTA_DP_WHOLE_LANES != 0;     // (0: timing experiments without the steady loop that switches lanes off)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // The value of the lane below / above in a G-lane group; 0 at the group's edge.
@@ -176,18 +219,16 @@ template<int G> __device__ __forceinline__ int32_t fromLaneAbove(int32_t v, int 
     return r;
 }
 struct __attribute__((packed, aligned(4))) KmerQuad { uint32_t v[4]; };     // four consecutive kmer ids, 4-byte aligned
-// Which loop a cell is computed in: the general one, the steady one, or the steady one of a wavefront in which every lane has
-// either all of its C diagonals or none (WHOLE_LANES: the lanes without diagonals are switched off for the loop, see below).
-template<bool STEADY, bool WHOLE_LANES> struct DpPhase { static constexpr bool value = STEADY, wholeLanes = WHOLE_LANES; };
+// Which loop a cell is computed in: the general one or the steady one.
+template<bool STEADY> struct DpPhase { static constexpr bool value = STEADY; };
 
-// Room for six wavefronts per SIMD (80 vector registers) in the classes of up to four diagonals per lane, as before the second
-// steady loop: the allocator took 84-85 with it (five wavefronts).
+// Room for six wavefronts per SIMD (80 vector registers) in the classes of up to four diagonals per lane.
 #ifdef __HIPCC__
 #define SHASTA_DP_FORWARD_OCCUPANCY(C) __attribute__((amdgpu_waves_per_eu((C) <= 4 ? 6 : 1)))
 #else
 #define SHASTA_DP_FORWARD_OCCUPANCY(C)      // (the wave64 emulator of tests/emu compiles this file as plain C++)
 #endif
-template<int G, int C>
+template<int G, int C, int TIE>
 __global__ void __launch_bounds__(256) SHASTA_DP_FORWARD_OCCUPANCY(C)
 bandedDpForwardKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
@@ -252,23 +293,25 @@ bandedDpForwardKernel(
         // stored value as it is, a diagonal move (two anti-diagonals on) adds the match or mismatch score minus two gap
         // penalties -- one addition per cell instead of two, same comparisons (all three candidates carry the same offset).
         const int32_t dg = hd + (eq ? MATCH_SCORE - 2 * GAP_SCORE : MISMATCH_SCORE - 2 * GAP_SCORE);
-        // hv: from (i, j-1), diagonal b+1; hh: from (i-1, j), diagonal b-1.  Ties go to the diagonal, then to the vertical move
-        // (the restated SeqAn policy: vertical only if hv > dg, horizontal only if hh > max(dg, hv)) -- which is "the first of
-        // dg, hv, hh that equals their maximum": one v_max3 and two equality tests instead of two maxima and two comparisons.
+        // hv: from (i, j-1), diagonal b+1; hh: from (i-1, j), diagonal b-1.  The move kept is the first in the tie policy's order
+        // of (diagonal, vertical, horizontal) that equals their maximum (for the restated SeqAn policy: vertical only if
+        // hv > dg, horizontal only if hh > max(dg, hv)): one v_max3 and two equality tests instead of two maxima and two comparisons.
         int32_t v = max(max(dg, hv), hh);
-        const bool isD = v == dg, isVertical = v == hv;            // (isVertical only counts where isD is false)
+        const int32_t candidates[3] = {dg, hv, hh};
+        const bool equalsFirst = v == candidates[DpTie<TIE>::first], equalsSecond = v == candidates[DpTie<TIE>::second];
         if constexpr (STEADY) {
             SHASTA_DEVICE_CHECK(!exists[c] || (sc > lo[c] && uint32_t(sc - lo[c]) <= span[c]));
-            if constexpr (decltype(steadyTag)::wholeLanes) { SHASTA_DEVICE_CHECK(exists[c]); H[c] = v; }
-            else H[c] = exists[c] ? v : 0;
+            H[c] = exists[c] ? v : 0;
         } else {
             const bool valid = uint32_t(sc - lo[c]) <= span[c];
             v = (sc == lo[c]) ? BIAS - GAP_SCORE * sc : v;          // i == 0 or j == 0: free leading gaps (score 0)
             H[c] = valid ? v : H[c];
         }
-        const uint64_t bEq = ballot64(eq), bD = ballot64(isD), bVertical = ballot64(isVertical);
-        loPlane = ~(bD | bVertical) | (bD & ~bEq);                  // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
-        hiPlane = ~bD;
+        uint64_t equal[3] = {0, 0, 0}, kept[3];
+        equal[DpTie<TIE>::first] = ballot64(equalsFirst); equal[DpTie<TIE>::second] = ballot64(equalsSecond);
+        DpTie<TIE>::keep(equal, kept);
+        loPlane = kept[DpTie<TIE>::HORIZONTAL] | (kept[DpTie<TIE>::DIAGONAL] & ~ballot64(eq));     // codes: 0 diagonal+equal, 1 diagonal+different, 2 vertical, 3 horizontal
+        hiPlane = ~kept[DpTie<TIE>::DIAGONAL];
     };
     // aw(k), bw(h): the kmer ids of this iteration.
     auto antiDiagonals = [&](auto steadyTag, int32_t s, auto aw, auto bw, uint64_t (&words)[RW]) {
@@ -315,7 +358,7 @@ bandedDpForwardKernel(
         uint32_t bNext1 = loadB(ib - bandMin - l * HC), bNext2 = loadB(ib + 1 - bandMin - l * HC);
         for(uint32_t it = from; it < to; it++) {
             uint64_t words[RW];
-            antiDiagonals(DpPhase<false, false>{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
+            antiDiagonals(DpPhase<false>{}, geo.s0 + 2 * int32_t(it), [&](int k) { return aw[k]; }, [&](int h) { return bw[h]; }, words);
             putRecord(it, words);
 #pragma unroll
             for(int k = 0; k < HC; k++) aw[k] = aw[k + 1];
@@ -398,29 +441,19 @@ bandedDpForwardKernel(
                 }
             }
         };
-        // A value outside the band must read as 0 to its neighbours.  When every lane of the wavefront has all of its C diagonals
-        // or none of them (band widths that are multiples of C: 30, 40, 60, 80 ... of the default options' multiples of 10), the
-        // lanes without diagonals sit the steady loop out: their H stay 0, a DPP move whose source lane is switched off returns 0
-        // like one from beyond the row (bound_ctrl; measured, profiles/r02_dpp_exec_probe.jsonl), their ballot bits are 0 (cells
-        // no path visits) -- and the select "exists ? v : 0" of every cell is gone (1 of 8 VALU instructions per cell).
-        bool laneAll = true, laneNone = true;
-#pragma unroll
-        for(int c = 0; c < C; c++) { laneAll = laneAll && exists[c]; laneNone = laneNone && !exists[c]; }
-        const bool wholeLanes = DP_WHOLE_LANES && ballot64(laneAll || laneNone) == ~0ULL && ballot64(laneAll) != 0;
-        if(wholeLanes) { if(laneAll) steady(DpPhase<true, true>{}); }
-        else steady(DpPhase<true, false>{});
+        steady(DpPhase<true>{});
         general(steadyBegin + groups * AL, iters);
     }
     scalarStoreFlush();                                   // the scalar data cache is write-back
 
-    // End cell: maximum over the border cells = final value of every diagonal; ties to the smallest (i, j).
-    int32_t bestScore = NEG_SCORE, bestI = 0x7fffffff, bestJ = 0x7fffffff;
+    // End cell: maximum over the border cells = final value of every diagonal; ties by the policy (the reading: the smallest (i, j)).
+    int32_t bestScore = NEG_SCORE, bestI = DpTie<TIE>::noEndCell, bestJ = DpTie<TIE>::noEndCell;
 #pragma unroll
     for(int c = 0; c < C; c++) {
         const int32_t d = bandMin + l * C + c;
         const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
         const int32_t v = exists[c] ? H[c] - BIAS + GAP_SCORE * (i + j) : NEG_SCORE;
-        if(v > bestScore || (v == bestScore && v > NEG_SCORE && (i < bestI || (i == bestI && j < bestJ)))) { bestScore = v; bestI = i; bestJ = j; }
+        if(v > bestScore || (v == bestScore && v > NEG_SCORE && DpTie<TIE>::endCellWins(i, j, bestI, bestJ))) { bestScore = v; bestI = i; bestJ = j; }
     }
     if constexpr ((G & (G - 1)) == 0) {
 #pragma unroll
@@ -428,7 +461,7 @@ bandedDpForwardKernel(
             const int32_t os = __shfl_xor(bestScore, d, G);
             const int32_t oi = __shfl_xor(bestI, d, G);
             const int32_t oj = __shfl_xor(bestJ, d, G);
-            if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+            if(os > bestScore || (os == bestScore && DpTie<TIE>::endCellWins(oi, oj, bestI, bestJ))) { bestScore = os; bestI = oi; bestJ = oj; }
         }
     } else {
         // A group of 12 or 20 lanes: every lane looks at the other lanes of its group in turn (the order is total, so every
@@ -439,7 +472,7 @@ bandedDpForwardKernel(
             const int32_t os = __shfl(ownScore, source, WAVE);
             const int32_t oi = __shfl(ownI, source, WAVE);
             const int32_t oj = __shfl(ownJ, source, WAVE);
-            if(os > bestScore || (os == bestScore && (oi < bestI || (oi == bestI && oj < bestJ)))) { bestScore = os; bestI = oi; bestJ = oj; }
+            if(os > bestScore || (os == bestScore && DpTie<TIE>::endCellWins(oi, oj, bestI, bestJ))) { bestScore = os; bestI = oi; bestJ = oj; }
         }
     }
     if(hasTask && l == 0) {
@@ -465,7 +498,7 @@ bandedDpForwardKernel(
 //    the walk unrolled over a chunk's iterations and both cells of each for C = 2 and 4 -- 66 VALU instructions per
 //    possible cell, issued whether the lane's path was there or not -- plus this kernel for C = 8, 16) paid for three
 //    longest paths: 77 ms per step solo against 52 for this kernel alone, before it was trimmed;
-//  * the longest tasks go first (the list is sorted by class, then in two runs of ascending length: lane order is reversed), so that
+//  * the longest tasks go first (the list is sorted by class, then by ascending length: lane order is reversed), so that
 //    the tail of the launch is made of short paths.
 // The walk itself only stores the aligned pairs (from the end of the task's ordinal range downwards) and counts
 // them; everything that can be computed from the stored pairs afterwards -- AlignmentInfo's metrics, the inner

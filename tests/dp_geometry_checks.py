@@ -88,10 +88,10 @@ def many(lib, orc, seed, tasks=140):
 
 
 def straddling_bundles(lib, orc, seed, long_tasks=6, short_tasks=7):
-    """One band class (widths 49 .. 64: 16 lanes x 4 diagonals, four tasks to a wavefront) whose task list is two runs: long
-    tasks with every lane whole (width 64, 60) first, short tasks with a partly filled lane (widths 50, 54) after them, the
-    counts chosen so that one wavefront holds tasks of both runs -- its trace must be sized by the LONGEST of its tasks, not by
-    the last, and it runs the masked steady loop while its neighbours run the one with lanes switched off."""
+    """One band class (widths 49 .. 64: 16 lanes x 4 diagonals, four tasks to a wavefront) with long tasks whose lanes are all
+    whole (width 64, 60) and short tasks with a partly filled lane (widths 50, 54), the counts chosen so that one wavefront
+    holds tasks of both kinds -- its trace is sized by the longest of its tasks, and its steady loop covers only the
+    iterations that are steady for every task."""
     rng = np.random.default_rng(seed)
     pieces, spec = [], []
     at = 0

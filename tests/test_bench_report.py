@@ -67,7 +67,7 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
     monkeypatch.setattr(shasta_amd, "load", lambda: FakeLibrary())
     monkeypatch.setattr(bench, "make_workload", lambda reads, seed: (np.zeros(2 * 10 + 1, np.uint64), np.zeros(0, np.uint32)))
-    monkeypatch.setattr(bench, "cpu_baseline", lambda *a: ({"value": 18000.0, "unit": "candidate read-pairs aligned/s", "cores": 64,
+    monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: ({"value": 18000.0, "unit": "candidate read-pairs aligned/s", "cores": 64,
                                                            "host_cores": 256, "kind": "reference", "sample": "fake"},
                                                           {"lowhash0_equal": True, "aligner_mismatches": 0}))
     # Counters as scripts/pmc_summary.py writes them, for the workload of this run.
@@ -125,6 +125,9 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert parity["lowhash0_equal"] is True and parity["aligner_mismatches"] == 0 and parity["aligner_tie_flags_equal"] is True
     assert any(k.startswith("align4CellsChunkKernel") for k in line["kernels"]) and any(k.startswith("dpTracebackKernel") for k in line["kernels"])
     assert line["config"]["candidates"] > 0 and "workload" in line["config"]
+    census = line["dp_tie_sensitive"]             # the checker under the 11 other DP tie policies
+    assert census["candidates"] > 0 and len(census["per_policy"]) == 11
+    assert census["candidates_changed"] >= census["markerCount_changed"] and census["candidates_changed"] >= census["stored_set_changed"]
 
 
 def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):

@@ -45,6 +45,15 @@ def test_banded_dp(emu_lib, oracle_lib, width):
         assert sx == sy and np.array_equal(x, y)
 
 
+def test_dp_tie_policy_switch(emu_lib, oracle_lib):
+    from tests import tie_policy_checks
+    tasks, bad_default, bad_alternative, differ = tie_policy_checks.dp_tasks_under_the_alternative_policy(emu_lib, oracle_lib)
+    assert tasks >= 50 and bad_default == 0 and bad_alternative == 0 and differ >= 10
+    candidates, differ = tie_policy_checks.aligner_under_the_alternative_policy(emu_lib, oracle_lib, reads=80, candidates=120)
+    assert candidates >= 100
+    assert tie_policy_checks.unknown_policy_is_refused(emu_lib)
+
+
 def test_lowhash0_and_align4(emu_lib, oracle_lib):
     toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=12000, seed=5)
     flags = np.zeros(150, np.uint8)

@@ -1,7 +1,7 @@
-"""GPU tests of what was written after the round's last GPU call and has run on the emulated build only: they join the -m gpu
-suite when SHASTA_TEST_FIRST_GPU_RUN=1 is set for the first call of the next round (scripts/gpu_profile.sh does not set it;
-run `SHASTA_TEST_FIRST_GPU_RUN=1 python -m pytest tests/test_gpu_waiting_for_first_run.py -m gpu` first), and lose the
-switch once they have passed there."""
+"""The aligner with a batch's first round prepared on the device (SHASTA_MI355X_DEVICE_BATCH_PREP=1: classes, the grouping sort
+and the chunk lists by kernels on the batch's stream, align4_prepare.hpp) against the oracle: the adversarial read sets,
+mixed-length reads (all classes, the overflow ladder, the HBM-scratch list) and many small batches.  First run on the MI355X in
+round 3 (profiles/r03_first_gpu_run.log); the switch's A/B is in DESIGN.md."""
 import os
 
 import numpy as np
@@ -10,15 +10,7 @@ import pytest
 from shasta_amd import abi, synthetic
 from tests import adversarial, support
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("SHASTA_TEST_FIRST_GPU_RUN"), reason="waits for its first GPU run (SHASTA_TEST_FIRST_GPU_RUN=1)")]
-
-
-def test_banded_dp_wavefront_with_tasks_of_both_runs_of_its_class(gpu_lib, oracle_lib):
-    from tests import dp_geometry_checks
-    for seed in (3, 4, 5, 6):
-        cases, bad = dp_geometry_checks.straddling_bundles(gpu_lib, oracle_lib, seed, long_tasks=6 + seed, short_tasks=7)
-        assert cases == 13 + seed and bad == 0
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", adversarial.READ_SET_NAMES)
