@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-SHASTA_TEST_FIRST_GPU_RUN=1 timeout 900 python -m pytest tests/test_gpu_waiting_for_first_run.py -q -m gpu --timeout 600 -p no:cacheprovider 2>&1 | tail -15
-bash scripts/gpu_ab.sh "shipped_wl1k1||" "wl0k0|_build_wl0k0|" "wl1k0|_build_wl1k0|" "wl1k2|_build_wl1k2|" "wl0k1|_build_wl0k1|" "devprep||SHASTA_MI355X_DEVICE_BATCH_PREP=1"
+export SHASTA_BENCH_WORKLOAD_CACHE=/tmp/shasta_workload
+SHASTA_MI355X_LIBRARY=$GRAFT_REPO_ROOT/shasta_amd/_build_prof/libshasta_mi355x.so SHASTA_MI355X_ALIGN_WORKERS=1 timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof_bench.err
+tail -5 gpurun_out/prof_bench.err | cut -c1-2000

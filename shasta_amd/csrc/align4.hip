@@ -441,7 +441,7 @@ std::vector<uint32_t> referenceComponentRepresentatives(const std::vector<uint32
 // After winnerKernel, before finalizeKernel.  pairClass[k]: the table class candidate k's cells were computed in (CELLS_CLASSES:
 // the HBM-scratch kernel -- such a candidate keeps its tie flag).
 void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t n, uint32_t taskCount, const std::vector<PairDesc>& hostPairs,
-    const std::vector<int>& pairClass, const std::vector<uint8_t>& pairSlotsLog2, const DeviceOptions& opt, uint32_t magicX, uint32_t magicY)
+    const std::vector<int>& pairClass, const std::vector<uint8_t>& pairSlotsLog2, const std::vector<uint8_t>& pairNoGrid, const DeviceOptions& opt, uint32_t magicX, uint32_t magicY)
 {
     hipStream_t stream = ws.stream;
     std::vector<uint8_t> tie(n);
@@ -468,6 +468,7 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
         CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = 1;
         ch.swapped = hostPairs[k].nx < capacity ? 0 : 1;                      // (either read may be tabled: the cells are the same)
         if(ch.swapped && hostPairs[k].ny >= capacity) continue;
+        if(!pairNoGrid.empty() && pairNoGrid[k]) ch.swapped |= 2;             // (counted in the packed table the first time: again)
         ch.naLog2 = uint32_t(CELLS_NA_LOG2[c]); ch.scLog2 = uint32_t(CELLS_SC_LOG2[c]);
         members.push_back(k);
         chunks[c].push_back(ch); chunkPair[c].push_back(k);
@@ -827,6 +828,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         uint32_t taskCount = 0;
         std::vector<int> pairClass;                    // method 4: the table class of every candidate's cells (CELLS_CLASSES: HBM scratch)
         std::vector<uint8_t> pairSlotsLog2;            //           ... and the table size the HBM-scratch kernel last ran it with
+        std::vector<uint8_t> pairNoGrid;               //           ... and whether its cells were counted in the packed table because a byte of its grid overflowed
         uint32_t cellsMagicX = 0, cellsMagicY = 0;
         for(;;) {
         if(m3) {
@@ -940,12 +942,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 return uint8_t(l);
             };
             const CellsClassRule classRule = cellsClassRule(opt);            // (the class of a candidate: align4_prepare.hpp)
-            pairClass.assign(n, -1); pairSlotsLog2.assign(n, 0);
+            pairClass.assign(n, -1); pairSlotsLog2.assign(n, 0); pairNoGrid.assign(n, 0);
             std::vector<CellsChunk> classChunks[CELLS_CLASSES];
             std::vector<uint32_t> members;                             // candidate indices, chunk after chunk
             members.reserve(n);
-            auto addChunk = [&](const uint32_t* list, uint32_t count, bool swapped, int c) {
-                CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = uint16_t(count); ch.swapped = swapped ? 1 : 0;
+            auto addChunk = [&](const uint32_t* list, uint32_t count, bool swapped, int c, bool noGrid = false) {
+                CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = uint16_t(count); ch.swapped = uint16_t((swapped ? 1 : 0) | (noGrid ? 2 : 0));
                 ch.naLog2 = uint32_t(CELLS_NA_LOG2[c]); ch.scLog2 = uint32_t(CELLS_SC_LOG2[c]);
                 members.insert(members.end(), list, list + count);
                 classChunks[c].push_back(ch);
@@ -958,11 +960,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             const uint64_t memberCapacity = uint64_t(CELLS_CLASSES) * n + 16;
             b.pairList.reserve(memberCapacity, stream);
             size_t membersUploaded = 0;
-            // SHASTA_MI355X_DEVICE_BATCH_PREP=1 (pre-flighted on the emulated build, not yet on the GPU: off by default): the first
-            // round's member list and chunk lists are made by kernels on the batch's stream and its cells kernels launched from
+            // The first round's member list and chunk lists are made by kernels on the batch's stream and its cells kernels launched from
             // them at once; what the host needs for the later rounds (every candidate's class, the HBM-scratch list) it
             // computes while they run.  Same chunks, same order within a class (align4_prepare.hpp).
-            const bool devicePrepare = [] { const char* e = std::getenv("SHASTA_MI355X_DEVICE_BATCH_PREP"); return e && std::atoi(e) != 0; }();      // (read for every batch: tests switch it)
+            // SHASTA_MI355X_DEVICE_BATCH_PREP=0: the host loop + sort + walk that it replaced (kept as the cross-check of the lists; on the
+            // MI355X the device's lists take a step's aligner calls from 172 to 165 ms, profiles/r03_device_batch_prep_ab.log).
+            const bool devicePrepare = [] { const char* e = std::getenv("SHASTA_MI355X_DEVICE_BATCH_PREP"); return !e || std::atoi(e) != 0; }();      // (read for every batch: tests switch it)
             bool firstRoundLaunched = false, firstRoundAny = false;
             if(devicePrepare) {
                 int tabledBits = 1;
@@ -1066,7 +1069,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 }
                 std::fprintf(stderr, "cells: HBM-scratch list %zu\n", bigList.size());
             }
-            for(int round = 0; round < CELLS_CLASSES; round++) {
+            // (A candidate climbs at most CELLS_CLASSES classes and repeats one of them once, in the packed table.)
+            for(int round = 0; round < 2 * CELLS_CLASSES + 1; round++) {
                 bool any = false;
                 if(round == 0 && firstRoundLaunched) any = firstRoundAny;
                 else {
@@ -1107,10 +1111,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     if((hostFlags[k] & 0x0f) != PAIR_RESOURCE) continue;
                     if(debug) ++reasonHistogram[hostFlags[k] >> 4];
                     retry = true;
+                    // Retry alone in the next class whose table holds one of the two reads (read 0 if both fit) -- or, when a byte
+                    // of its cell grid overflowed (bit 7), in the same class once more with its cells in the packed table.
+                    const bool gridOverflow = (hostFlags[k] & 0x80) != 0 && !pairNoGrid[k];
+                    if(gridOverflow) pairNoGrid[k] = 1;
                     hostFlags[k] = 0;
-                    // Retry alone in the next class whose table holds one of the two reads
-                    // (read 0 if both fit).
-                    int c = pairClass[k] + 1;
+                    int c = pairClass[k] + (gridOverflow ? 0 : 1);
                     bool sw = false;
                     for(; c < CELLS_CLASSES; c++) {
                         const uint64_t cap = 1ULL << CELLS_NA_LOG2[c];
@@ -1119,14 +1125,15 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     }
                     pairClass[k] = c;
                     if(c >= CELLS_CLASSES) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
-                    else addChunk(&k, 1, sw, c);
+                    else addChunk(&k, 1, sw, c, pairNoGrid[k] != 0);
                 }
                 if(!retry) break;
                 if(debug) {
                     for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: round %d retries -> class %d: %zu\n", round, c, classChunks[c].size());
-                    std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu; reasons cell-table %llu kept-list %llu geometry %llu both %llu tabled-read %llu\n", round, bigList.size(),
+                    std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu; reasons cell-table %llu kept-list %llu geometry %llu both %llu grid-byte %llu\n", round, bigList.size(),
                         (unsigned long long)reasonHistogram[1], (unsigned long long)reasonHistogram[2], (unsigned long long)reasonHistogram[4],
-                        (unsigned long long)(reasonHistogram[3] + reasonHistogram[5] + reasonHistogram[6] + reasonHistogram[7]), (unsigned long long)reasonHistogram[8]);
+                        (unsigned long long)(reasonHistogram[3] + reasonHistogram[5] + reasonHistogram[6] + reasonHistogram[7]),
+                        (unsigned long long)(reasonHistogram[8] + reasonHistogram[9] + reasonHistogram[10] + reasonHistogram[11] + reasonHistogram[12] + reasonHistogram[13] + reasonHistogram[14] + reasonHistogram[15]));
                 }
                 HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
             }
@@ -1204,7 +1211,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             // Candidates whose best components tie on markerCount: the reference's component order decides (method 4 only:
             // method 3 has one alignment per candidate).
             if(!m3 && readDevice(b.counters.data() + 12, stream) != 0) {
-                resolveComponentTies(ctx, ws, b, n, taskCount, hostPairs, pairClass, pairSlotsLog2, opt, cellsMagicX, cellsMagicY);
+                resolveComponentTies(ctx, ws, b, n, taskCount, hostPairs, pairClass, pairSlotsLog2, pairNoGrid, opt, cellsMagicX, cellsMagicY);
             }
         } else {
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);

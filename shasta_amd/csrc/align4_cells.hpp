@@ -330,7 +330,7 @@ align4CellsKernel(
 //   or iY | iX | count packed) | per wavefront a slot: kept[64 Q] (the graph's cell map[128 Q] later) | scratch[8] | stage[4 CELLS_STAGE].
 // ---------------------------------------------------------------------------
 // firstMember indexes the member list (candidate indices of the batch).
-struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };
+struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };      // swapped: bit 0 = read 1 is the tabled one, bit 1 = count in the packed table even if the byte grid would fit
 
 #ifdef SHASTA_PROFILE_PHASES
 __device__ unsigned long long g_phaseCycles[16];
@@ -452,7 +452,7 @@ align4CellsChunkKernel(
     // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
     //     candidates gathered by the host because they share a short read 1) read 1 ---
     const PairDesc pdFirst = pairs[members[chunk.firstMember]];
-    const bool swapped = chunk.swapped != 0;
+    const bool swapped = (chunk.swapped & 1) != 0, noGrid = (chunk.swapped & 2) != 0;
     const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
     const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
     for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
@@ -493,7 +493,7 @@ align4CellsChunkKernel(
         // Too many markers of the tabled read share their buckets (a tandem repeat): the whole
         // chunk goes to the next class.
         if(DUMP) { if(threadIdx.x == 0) activeCounts[blockIdx.x] = 0xffffffffu; return; }
-        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x80);
+        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x10);        // (booked with the cell tables that overflow: the chunk climbs a class)
         return;
     }
 
@@ -527,10 +527,14 @@ align4CellsChunkKernel(
 
         // When the candidate's whole cell grid fits the wavefront's cell region as one BYTE per cell (nx + ny up to about 4000
         // at the default cell size: nearly every candidate of the first class), the entries are counted in a direct grid: one LDS
-        // atomic per hit, no keys, no probing.  A lane adds only while the byte is below the threshold, so a byte never exceeds
-        // threshold - 1 + 64.  Otherwise: the open-addressing table of packed (iY | iX | count) words.
+        // atomic per hit, no keys, no probing.  A lane adds only while the byte is below the threshold, so a byte stays below
+        // threshold + the adds in flight between such a read and its add (at most 64 per wave instruction, four slots, four
+        // wavefronts: more than a byte holds only if they all hit ONE cell, which takes a tandem repeat); the add returns the byte
+        // as it was, and one that finds 255 has carried into the next byte: the candidate is flagged (reason 8) and the host runs
+        // it again with bit 1 of `swapped` set -- counted in the open-addressing table of packed (iY | iX | count) words, whose
+        // ten count bits hold any cell (cellsClassRule.packedOk).  That table also serves the candidates whose grid does not fit.
         const uint32_t gridX = divMagic(nx + ny - 2, magicX) + 1, gridY = divMagic(nx + ny - 2, magicY) + 1;
-        const bool useGrid = nx + ny >= 2 && uint64_t(gridX) * gridY <= 4ull * SC && threshold <= 191;
+        const bool useGrid = !noGrid && nx + ny >= 2 && uint64_t(gridX) * gridY <= 4ull * SC && threshold <= 191;
         {
             const uint32_t first = threadIdx.x, stride = blockDim.x;
             if(useGrid) {
@@ -579,6 +583,7 @@ align4CellsChunkKernel(
                         const uint32_t at = atomicAdd(&scratch[0], 1u);
                         if(at < uint32_t(MAXC)) kept[at] = (iY[u] << 16) | iX[u];
                     }
+                    if(before[u] == 255u) { overflow = max(overflow, 1); reason |= 8; }     // the byte wrapped
                 }
                 return;
             }
@@ -630,7 +635,10 @@ align4CellsChunkKernel(
 #pragma unroll
         for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
         SUBPHASE_DECLARE();
-        for(uint32_t s0 = firstRound; s0 < streamCount; s0 += roundStride) {
+#ifndef SHASTA_ABLATE
+#define SHASTA_ABLATE 0          // timing experiments (wrong results): 1 = without the kept-cell graphs, 2 = without the stream
+#endif
+        for(uint32_t s0 = firstRound; s0 < (SHASTA_ABLATE == 2 ? 0u : streamCount); s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
             // matches[u]: the tag matches of marker u, bit i for the low half of its word i, bit 16 + i for the high half.
             uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], matches[CELLS_UNROLL], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
@@ -742,24 +750,26 @@ align4CellsChunkKernel(
         }
         SUBPHASE_FLUSH();
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
-        if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
+        if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason & 7) | ((reason & 8) ? 0x20u : 0u) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
         __syncthreads();                                              // the cell region is cleared for the next candidate
         PHASE_MARK(2);
     }
 
         // The kept-cell graphs of the group, one per wavefront.
-        if(group + wave < groupEnd) do {
+        if(SHASTA_ABLATE != 1 && group + wave < groupEnd) do {
         kept = ownKept; scratch = ownScratch;
         const uint32_t pair = scratch[5], nx = scratch[6], ny = scratch[7];
         const uint32_t seen = scratch[4];
-        int overflow = (seen & 0x10u) ? 2 : ((seen & 0x08u) ? 1 : 0), reason = int(seen & 7u);
+        int overflow = (seen & 0x10u) ? 2 : ((seen & 0x08u) ? 1 : 0), reason = int(seen & 7u) | ((seen & 0x20u) ? 8 : 0);
         const int n = int(scratch[0]);
         if(n > MAXC) { overflow = max(overflow, 1); reason |= 2; }
         const uint64_t anyHard = __ballot(overflow == 2), anySoft = __ballot(overflow == 1);
         if(DUMP && (anyHard || anySoft)) { if(lane == 0) activeCounts[blockIdx.x] = 0xffffffffu; break; }
         if(anyHard || anySoft) {
-            // Bits 4-6 carry the reason (cell table full / kept list full / geometry) for diagnostics.
-            const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0);
+            // Bits 4-7 carry the reason: cell table full / kept list full / geometry (diagnostics) and, bit 7, a byte of the grid
+            // that overflowed (the host runs the candidate again in the packed table of the same class) or, from the table build, a
+            // tabled read whose markers crowd their buckets (the whole chunk climbs a class).
+            const int reasons = (__ballot(reason & 1) ? 1 : 0) | (__ballot(reason & 2) ? 2 : 0) | (__ballot(reason & 4) ? 4 : 0) | (__ballot(reason & 8) ? 8 : 0);
             if(lane == 0) pairFlags[pair] = anyHard ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
             break;
         }

@@ -4,7 +4,7 @@ finds arrays sized by the first and places every batch early; a third, larger ca
 And a call of several batches against the oracle, prepared by the host and with the batches' first chunk lists made on the
 device (an experiment switch).
 Run in a process of its own (the batch size is read once per process):
-    SHASTA_MI355X_ALIGN_BATCH_LOG2=10 python -m tests.borrowed_checks <library.so> [oracle [device-prepare]]"""
+    SHASTA_MI355X_ALIGN_BATCH_LOG2=10 python -m tests.borrowed_checks <library.so> [oracle [both-preparations]]"""
 import os
 import sys
 
@@ -37,8 +37,8 @@ def main(path, oracle=None, device_prepare=None):
         # 2060 candidates in three batches.
         assert len(cand) >= 2048, len(cand)
         equal = ctx.align4(cand, o, want_ordinals=True)
-        if device_prepare:                  # (the emulated build only until the switch has had its first GPU run)
-            os.environ["SHASTA_MI355X_DEVICE_BATCH_PREP"] = "1"              # every batch's first chunk lists made by kernels (align4_prepare.hpp)
+        if device_prepare:
+            os.environ["SHASTA_MI355X_DEVICE_BATCH_PREP"] = "0"              # every batch's first chunk lists made by the host loop instead of kernels (align4_prepare.hpp)
             prepared = ctx.align4(cand, o, want_ordinals=True)
             del os.environ["SHASTA_MI355X_DEVICE_BATCH_PREP"]
             support.same_align(prepared, equal)

@@ -107,7 +107,7 @@ def test_borrowed_results_and_calls_of_several_batches(emu_lib, oracle_lib):
     # (a process of its own: the batch size is read once per process)
     import subprocess, sys
     env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10")
-    out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", emu_lib.path, "oracle", "device-prepare"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", emu_lib.path, "oracle", "both-preparations"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
@@ -158,18 +158,19 @@ def test_adversarial_read_sets_through_both_aligners(emu_lib, oracle_lib, ref_li
     adversarial.aligner_case(emu_lib, oracle_lib, name, long_reads=False, ref_lib=ref_lib)
 
 
-@pytest.mark.parametrize("name", ["degenerate lengths", "tandem repeats", "duplicated segments"])      # (retries after device-made lists in the first two)
-def test_adversarial_read_sets_with_the_first_chunk_lists_made_on_the_device(emu_lib, oracle_lib, ref_lib, monkeypatch, name):
-    # SHASTA_MI355X_DEVICE_BATCH_PREP=1 (read for every batch): classes, grouping sort and chunk lists by kernels (align4_prepare.hpp)
-    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "1")
+@pytest.mark.parametrize("name", ["degenerate lengths", "tandem repeats", "duplicated segments"])      # (retries after host-made lists in the first two)
+def test_adversarial_read_sets_with_the_first_chunk_lists_made_on_the_host(emu_lib, oracle_lib, ref_lib, monkeypatch, name):
+    # SHASTA_MI355X_DEVICE_BATCH_PREP=0 (read for every batch): classes, grouping sort and chunk lists by the host loop instead of
+    # the kernels of align4_prepare.hpp (the default, which every other test runs)
+    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "0")
     adversarial.aligner_case(emu_lib, oracle_lib, name, long_reads=False, ref_lib=ref_lib)
 
 
-def test_mixed_length_reads_with_the_first_chunk_lists_made_on_the_device(emu_lib, oracle_lib, monkeypatch):
-    # Every table class, swapped chunks, the overflow ladder after device-made lists, the HBM-scratch list (the test of
+def test_mixed_length_reads_with_the_first_chunk_lists_made_on_the_host(emu_lib, oracle_lib, monkeypatch):
+    # Every table class, swapped chunks, the overflow ladder after host-made lists, the HBM-scratch list (the test of
     # tests/test_gpu_align4.py, its second read set cut to 450 candidates for the emulator's time).
     from shasta_amd import synthetic
-    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "1")
+    monkeypatch.setenv("SHASTA_MI355X_DEVICE_BATCH_PREP", "0")
     toc, kmer = synthetic.marker_reads(160, 60000, mean_markers=6000.0, sigma=0.6, min_markers=300, seed=52)
     data7 = synthetic.pack_markers(toc, kmer)
     p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=40, minFrequency=1)
