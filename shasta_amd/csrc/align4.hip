@@ -285,6 +285,7 @@ struct DpForwardState {
     uint32_t taskStart[DP_CLASSES + 1];   // class c = tasks [taskStart[c], taskStart[c + 1]) of the sorted list
     uint32_t classCounts[DP_CLASSES];
     unsigned long long sums[2 + 2 * DP_CLASSES];   // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c
+    uint64_t traceWords;                  // of the bundles' trace (2 bits per cell of the padded bands, once per bundle)
 };
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers)
@@ -313,27 +314,21 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     HIP_CHECK(hipGetLastError());
     uint32_t* classCounts = f.classCounts;
     unsigned long long* sums = f.sums;
+    // The bundles' trace words and their scan before the host knows the class counts (a thread per possible bundle: there are
+    // no more bundles than tasks): one synchronisation for the counts, the ordinal total and the trace total.
+    b.bundleWords.reserve(uint64_t(taskCount) + 1, stream);
+    hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
+        sortedKeys, (const uint32_t*)(b.counters.data() + 1), taskCount, b.bundleWords.data());
+    exclusiveScan<uint64_t>(b.bundleWords.data(), b.bundleWords.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
     HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, sizeof(f.classCounts), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(sums, b.dpCells.data(), sizeof(f.sums), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&f.traceWords, b.bundleWords.data() + taskCount, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
-    DpClassLayout layout;
-    layout.taskStart[0] = 0; layout.bundleStart[0] = 0;
-    for(int c = 0; c < DP_CLASSES; c++) {
-        const uint32_t T = 64u / uint32_t(dpLanes(c));
-        layout.taskStart[c + 1] = layout.taskStart[c] + classCounts[c];
-        layout.bundleStart[c + 1] = layout.bundleStart[c] + (classCounts[c] + T - 1) / T;
-    }
+    const DpClassLayout layout = dpClassLayout(classCounts);
     MI355X_ASSERT(layout.taskStart[DP_CLASSES] == taskCount);
     for(int c = 0; c <= DP_CLASSES; c++) f.taskStart[c] = layout.taskStart[c];
-    const uint32_t bundleTotal = layout.bundleStart[DP_CLASSES];
-    b.bundleWords.reserve(uint64_t(bundleTotal) + 1, stream);
-    b.scanTemp64.reserve(scanTempElements(uint64_t(bundleTotal) + 1), stream);
-    hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(bundleTotal) + 1, 256)), dim3(256), 0, stream,
-        sortedKeys, layout, b.bundleWords.data());
-    exclusiveScan<uint64_t>(b.bundleWords.data(), b.bundleWords.data(), uint64_t(bundleTotal) + 1, b.scanTemp64.data(), stream);
     if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
-    // sums[1] bounds the trace (a bundle needs no more than the sum over its tasks): no read-back.
-    b.trace.reserve(sums[1] + 64, stream);
+    b.trace.reserve(f.traceWords + 64, stream);
     if(reserveOrdinals) b.ordScratch.reserve(2 * ordTotal + 2, stream);
 
     // Wide bands (classes 5-7: few tasks, one wavefront each) go to the side stream, widest first;
@@ -606,10 +601,10 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     }
     const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
     // The traceback of every class in one launch (the list is sorted by class, then by ascending length; the kernel takes it from the end).
-    // Booked: the trace it has to read = 2 bits per cell of the padded bands (iterations x 2 C words, bounded by sums[1] for
-    // the whole batch), work = tasks.
+    // Booked: the trace it has to read = 2 bits per cell of the padded bands, once per bundle (the bundles' trace words as
+    // dpBundleKernel laid them out; the tasks of a bundle walk the same records) -- work = tasks.
     {
-        SHASTA_TIMED(ctx, "dpTracebackKernel", stream, 8 * f.sums[1], taskCount,
+        SHASTA_TIMED(ctx, "dpTracebackKernel", stream, 8 * f.traceWords, taskCount,
             hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
                 in.pairs, in.tasks, f.sortedIds, 0u, taskCount,
                 (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),

@@ -117,13 +117,29 @@ dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pair
 // Trace words of each bundle (64/G consecutive tasks of the sorted list of one class).
 struct DpClassLayout { uint32_t taskStart[DP_CLASSES + 1]; uint32_t bundleStart[DP_CLASSES + 1]; };
 
+__host__ __device__ inline DpClassLayout dpClassLayout(const uint32_t* classCounts)
+{
+    DpClassLayout layout;
+    layout.taskStart[0] = 0; layout.bundleStart[0] = 0;
+    for(int c = 0; c < DP_CLASSES; c++) {
+        const uint32_t T = 64u / uint32_t(dpLanes(c));
+        layout.taskStart[c + 1] = layout.taskStart[c] + classCounts[c];
+        layout.bundleStart[c + 1] = layout.bundleStart[c] + (classCounts[c] + T - 1) / T;
+    }
+    return layout;
+}
+
+// One thread per possible bundle (`capacity` of them: the host does not know the class counts yet); the class layout from the
+// counts dpSizeKernel left on the device.  Words of a position beyond the last bundle: 0, so that the exclusive scan over all
+// `capacity` + 1 positions leaves the total at the end.
 __global__ void __launch_bounds__(256)
-dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpClassLayout layout, uint64_t* __restrict__ bundleWords)
+dpBundleKernel(const uint32_t* __restrict__ sortedKeys, const uint32_t* __restrict__ classCounts, uint32_t capacity, uint64_t* __restrict__ bundleWords)
 {
     const uint32_t bundle = blockIdx.x * blockDim.x + threadIdx.x;
+    if(bundle > capacity) return;
+    const DpClassLayout layout = dpClassLayout(classCounts);
     const uint32_t total = layout.bundleStart[DP_CLASSES];
-    if(bundle > total) return;
-    if(bundle == total) { bundleWords[bundle] = 0; return; }
+    if(bundle >= total) { bundleWords[bundle] = 0; return; }
     int cls = 0;
     while(bundle >= layout.bundleStart[cls + 1]) ++cls;
     const uint32_t T = 64u / uint32_t(dpLanes(cls));
@@ -500,6 +516,14 @@ bandedDpForwardKernel(
 //    longest paths: 77 ms per step solo against 52 for this kernel alone, before it was trimmed;
 //  * the longest tasks go first (the list is sorted by class, then by ascending length: lane order is reversed), so that
 //    the tail of the launch is made of short paths.
+//  * (round 3, measured and dropped: ONE window per bundle instead of one per lane -- the lanes of a bundle read the same
+//    records, so a wavefront's 16 KB held four chunks of each bundle and the 64 lanes filled it together, a whole epoch of 16
+//    iterations ahead; with 8 KB windows four workgroups per CU instead of two; the 64-lane classes in a launch of their own
+//    on the side stream; branch-free steps; pairs staged in LDS and stored seven at a time.  Parity-green, 4.9 ms per launch
+//    for the narrow classes + 5.4 ms beside it for the wide ones against 4.6 ms for this kernel, 196 against 188 ms per step:
+//    neither the memory latency per chunk nor the occupancy is what a launch waits for -- it is its longest paths, at a
+//    dependent chain of address arithmetic, one LDS read and the move per step; without any stores the narrow launch still
+//    took 3.7 ms.  profiles/r03_traceback_experiments.log.)
 // The walk itself only stores the aligned pairs (from the end of the task's ordinal range downwards) and counts
 // them; everything that can be computed from the stored pairs afterwards -- AlignmentInfo's metrics, the inner
 // acceptance -- is computed by dpMetricsKernel, a wavefront per task, in parallel: each instruction taken out of the

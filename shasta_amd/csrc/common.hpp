@@ -179,10 +179,13 @@ public:
     struct Entry { std::string name; double seconds = 0; uint64_t launches = 0, bytes = 0, work = 0; };
     struct Span { int id = -1; hipEvent_t begin = nullptr, end = nullptr; hipStream_t stream = nullptr; };
     ~KernelTimers() { for(hipEvent_t e : pool) (void)hipEventDestroy(e); for(Pending& p : pending) { (void)hipEventDestroy(p.begin); (void)hipEventDestroy(p.end); } }
+    // SHASTA_MI355X_KERNEL_TIMERS=0: no events around the launches (a caller that never reads the table; spans are no-ops).
+    KernelTimers() { const char* e = std::getenv("SHASTA_MI355X_KERNEL_TIMERS"); enabled = !(e && e[0] == '0'); }
     Span begin(const char* name, hipStream_t stream)
     {
         Span s;
         s.stream = stream;
+        if(!enabled) return s;
         {
             std::lock_guard<std::mutex> lock(mutex);
             s.id = idOf(name);
@@ -194,16 +197,19 @@ public:
     // Returns a handle with which bytes / work can be set later (counts that are only known after a read-back).
     size_t end(const Span& s, uint64_t bytes = 0, uint64_t work = 0)
     {
+        if(s.id < 0) return ~size_t(0);
         HIP_CHECK(hipEventRecord(s.end, s.stream));
         std::lock_guard<std::mutex> lock(mutex);
         if(pending.size() >= 8192) collectLocked();       // a caller that never reads the table must not pile up events
-        pending.push_back(Pending{s.id, s.begin, s.end, bytes, work});
-        return serial + pending.size() - 1;
+        pending.push_back(Pending{s.id, s.begin, s.end, bytes, work, nextHandle});
+        return nextHandle++;
     }
+    // (Launches of several streams finish out of order and are folded as they finish: a handle names its launch, not a
+    // position in the list; a launch that has been folded already keeps what it was booked with.)
     void amend(size_t handle, uint64_t bytes, uint64_t work)
     {
         std::lock_guard<std::mutex> lock(mutex);
-        if(handle >= serial && handle - serial < pending.size()) { pending[handle - serial].bytes = bytes; pending[handle - serial].work = work; }
+        for(Pending& p : pending) if(p.handle == handle) { p.bytes = bytes; p.work = work; return; }
     }
     // Folds every finished launch into the table.  The caller has synchronised the streams it launched on;
     // a launch that is still running stays pending.
@@ -225,10 +231,9 @@ private:
                 pending[kept++] = p;
             }
         }
-        serial += pending.size() - kept;      // handles of folded launches expire
         pending.resize(kept);
     }
-    struct Pending { int id; hipEvent_t begin, end; uint64_t bytes, work; };
+    struct Pending { int id; hipEvent_t begin, end; uint64_t bytes, work; size_t handle; };
     int idOf(const char* name)
     {
         for(size_t k = 0; k < entries.size(); k++) if(entries[k].name == name) return int(k);
@@ -246,7 +251,8 @@ private:
     std::vector<Entry> entries;
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
-    size_t serial = 0;
+    size_t nextHandle = 0;
+    bool enabled = true;
 };
 
 }  // namespace shasta_mi355x

@@ -92,3 +92,17 @@ def test_murmur_known_answers(oracle_lib):
     h = oracle_lib.murmur64a(bytes(range(16)), 37)
     assert h == oracle_lib.murmur64a(bytes(range(16)), 37)
     assert h != oracle_lib.murmur64a(bytes(range(16)), 74)
+
+
+@pytest.mark.parametrize("name", ["log2 = 31", "log2 = 40 (capped at 31)"])
+def test_restatement_at_2_to_the_31_buckets_against_the_reference_digest(oracle_lib, name):
+    """log2MinHashBucketCount = 31 (the human-genome value: bit 31 of the hash takes part in neither the bucket id nor the match
+    key, src/LowHash0.hpp:99-105) and a request of 40 (capped, src/LowHash0.cpp:73-98): the reference needs 32 GB and minutes
+    per run there, so its results are committed as digests (tests/golden/make_log2_31_digest.py ran oracle/_ref) and the
+    restatement -- which the GPU tests of these values compare with -- is checked against them here."""
+    import json
+    import os
+    from tests.golden import make_log2_31_digest as made
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "log2_31_digests.json")) as f:
+        golden = json.load(f)["cases"][name]
+    assert made.run(oracle_lib, name) == golden

@@ -98,3 +98,14 @@ def test_marker_finding(ref_lib, oracle_lib, tmp_path, k, seed):
     toc, data = oracle_lib.find_markers(z["reads_toc"], z["reads_data"], z["base_counts"], k, z["is_marker"])
     assert np.array_equal(toc, z["toc"]) and np.array_equal(data, z["data7"]) and int(toc[-1]) > 10000
 
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("SHASTA_SLOW_TESTS"), reason="32 GB of bucket arrays and minutes per run in the reference (SHASTA_SLOW_TESTS=1); its digests are committed, tests/golden/log2_31_digests.json")
+@pytest.mark.parametrize("name", ["log2 = 31", "log2 = 40 (capped at 31)"])
+def test_reference_at_2_to_the_31_buckets_reproduces_the_committed_digest(ref_lib, name):
+    import json
+    import os
+    from tests.golden import make_log2_31_digest as made
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "log2_31_digests.json")) as f:
+        golden = json.load(f)["cases"][name]
+    assert made.run(ref_lib, name) == golden
