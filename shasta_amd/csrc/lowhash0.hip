@@ -127,7 +127,14 @@ __device__ __forceinline__ uint64_t fromNextLane64(uint64_t v)
     return uint64_t(fromNextLane(uint32_t(v))) | (uint64_t(fromNextLane(uint32_t(v >> 32))) << 32);
 }
 
-template<int M_FIXED>
+// ALL (round 3): every MinHash iteration of the job in ONE pass over the markers.  The seed only enters a window's hash through
+// h0 = seed ^ (len mul) (src/MurmurHash2.cpp:96-140): the block transforms murmurMix(block) -- two of the five 64 x 64-bit
+// multiplies per window and iteration at m = 4 -- the read boundaries, the palindromic flags and the marker loads do not depend
+// on it.  So a tile is loaded and prepared once and hashed `iterations` times (seed = 37 t, :316): 8 + 12 iterations multiplies
+// per lane and tile instead of 20 iterations, 4 M bytes read instead of 4 M iterations, one launch instead of `iterations`.
+// The records of iteration t carry t above the bucket id -- key = t << iterationShift | bucket id -- so that ONE sort leaves
+// them grouped by (iteration, bucket) and the bucket kernels run once over all of them.  `seed` is unused then.
+template<int M_FIXED, bool ALL = false>
 __global__ void __launch_bounds__(HASH_THREADS)
 hashWindowsKernel(
     const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc,
@@ -135,7 +142,7 @@ hashWindowsKernel(
     uint64_t markerBegin, uint64_t markerEnd, uint64_t markerCount,
     uint32_t m, uint64_t seed, uint64_t hashThreshold, uint32_t mask,
     uint32_t* __restrict__ outKeys, uint64_t* __restrict__ outVals,
-    unsigned long long* __restrict__ counter, uint64_t capacity)
+    unsigned long long* __restrict__ counter, uint64_t capacity, uint32_t iterations, uint32_t iterationShift)
 {
     __shared__ uint32_t stageKeys[HASH_THREADS / WAVE][HASH_STAGE];
     __shared__ uint64_t stageVals[HASH_THREADS / WAVE][HASH_STAGE];
@@ -162,12 +169,13 @@ hashWindowsKernel(
         fill = 0;
     };
     // Appends the hits of one window slot of the wavefront (at most 64) to the stage.
-    auto append = [&](bool hit, uint64_t hash, uint32_t orientedReadId) {
+    auto append = [&](bool hit, uint64_t hash, uint32_t orientedReadId, uint32_t iterationBits) {
         const uint64_t votes = __ballot(hit);
         if(votes == 0) return;
+        if constexpr (ALL) { if(fill + uint32_t(WAVE) > uint32_t(HASH_STAGE)) flush(); }       // (a tile adds up to HASH_TILE records per iteration)
         if(hit) {
             const uint32_t slot = fill + uint32_t(__popcll(votes & laneMaskLt()));
-            sKeys[slot] = uint32_t(hash) & mask;                              // bucket id, :352
+            sKeys[slot] = (uint32_t(hash) & mask) | iterationBits;            // bucket id, :352 (under the iteration, ALL)
             sVals[slot] = (hash & 0xffffffff00000000ULL) | orientedReadId;    // BucketEntry: hashHighBits, orientedReadId
         }
         fill += uint32_t(__popcll(votes));
@@ -187,7 +195,7 @@ hashWindowsKernel(
     for(; tile < lastTile; tile += waves) {
         const uint4 K = nextK, desc = nextDesc;
         if(tile + waves < lastTile) loadTile(tile + waves, nextK, nextDesc);
-        if(fill + HASH_TILE > HASH_STAGE) flush();                            // room for every window of this tile
+        if(!ALL && fill + HASH_TILE > HASH_STAGE) flush();                    // room for every window of this tile
         const uint64_t i0 = tile * HASH_TILE + 4 * uint64_t(lane);           // first of this lane's four markers
         const bool owner = lane < WAVE - 1;                                    // lane 63 only feeds lane 62
 
@@ -208,37 +216,39 @@ hashWindowsKernel(
             }
         };
 
-        uint64_t hash[4];
+        // What does not depend on the seed: the lane's markers and its neighbour's, the block transforms, and (below) which
+        // of the four windows count.
+        uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, k6 = 0, k7 = 0;
+        uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
         if constexpr (M_FIXED >= 3 && M_FIXED <= 5) {
             // Markers 0..3 are the lane's own, 4..7 the next lane's.
-            const uint32_t k0 = K.x, k1 = K.y, k2 = K.z, k3 = K.w;
-            const uint32_t k4 = fromNextLane(K.x), k5 = fromNextLane(K.y), k6 = fromNextLane(K.z), k7 = fromNextLane(K.w);
+            k0 = K.x; k1 = K.y; k2 = K.z; k3 = K.w;
+            k4 = fromNextLane(K.x); k5 = fromNextLane(K.y); k6 = fromNextLane(K.z); k7 = fromNextLane(K.w);
             // Block transforms that start at the lane's own markers, and the next lane's first two.
-            const uint64_t p0 = murmurMix(uint64_t(k0) | (uint64_t(k1) << 32)), p1 = murmurMix(uint64_t(k1) | (uint64_t(k2) << 32));
-            const uint64_t p2 = murmurMix(uint64_t(k2) | (uint64_t(k3) << 32)), p3 = murmurMix(uint64_t(k3) | (uint64_t(k4) << 32));
-            const uint64_t h0 = seed ^ (uint64_t(4u * M_FIXED) * mul);
+            p0 = murmurMix(uint64_t(k0) | (uint64_t(k1) << 32)); p1 = murmurMix(uint64_t(k1) | (uint64_t(k2) << 32));
+            p2 = murmurMix(uint64_t(k2) | (uint64_t(k3) << 32)); p3 = murmurMix(uint64_t(k3) | (uint64_t(k4) << 32));
+            if constexpr (M_FIXED >= 4) { p4 = fromNextLane64(p0); p5 = fromNextLane64(p1); }
+        }
+        (void)k0; (void)k1; (void)k5; (void)k6; (void)k7; (void)p4; (void)p5;
+        auto hashes = [&](uint64_t seedNow, uint64_t (&hash)[4]) {
+        if constexpr (M_FIXED >= 3 && M_FIXED <= 5) {
+            const uint64_t h0 = seedNow ^ (uint64_t(4u * M_FIXED) * mul);
             auto finish = [&](uint64_t h) { h ^= h >> 47; h *= mul; h ^= h >> 47; return h; };
             if constexpr (M_FIXED == 3) {
-                (void)k6; (void)k7;
                 hash[0] = finish(((h0 ^ p0) * mul ^ uint64_t(k2)) * mul);
                 hash[1] = finish(((h0 ^ p1) * mul ^ uint64_t(k3)) * mul);
                 hash[2] = finish(((h0 ^ p2) * mul ^ uint64_t(k4)) * mul);
                 hash[3] = finish(((h0 ^ p3) * mul ^ uint64_t(k5)) * mul);
+            } else if constexpr (M_FIXED == 4) {
+                hash[0] = finish(((h0 ^ p0) * mul ^ p2) * mul);
+                hash[1] = finish(((h0 ^ p1) * mul ^ p3) * mul);
+                hash[2] = finish(((h0 ^ p2) * mul ^ p4) * mul);
+                hash[3] = finish(((h0 ^ p3) * mul ^ p5) * mul);
             } else {
-                const uint64_t p4 = fromNextLane64(p0), p5 = fromNextLane64(p1);
-                if constexpr (M_FIXED == 4) {
-                    (void)k5; (void)k6; (void)k7;
-                    hash[0] = finish(((h0 ^ p0) * mul ^ p2) * mul);
-                    hash[1] = finish(((h0 ^ p1) * mul ^ p3) * mul);
-                    hash[2] = finish(((h0 ^ p2) * mul ^ p4) * mul);
-                    hash[3] = finish(((h0 ^ p3) * mul ^ p5) * mul);
-                } else {
-                    (void)k5;
-                    hash[0] = finish((((h0 ^ p0) * mul ^ p2) * mul ^ uint64_t(k4)) * mul);
-                    hash[1] = finish((((h0 ^ p1) * mul ^ p3) * mul ^ uint64_t(k5)) * mul);
-                    hash[2] = finish((((h0 ^ p2) * mul ^ p4) * mul ^ uint64_t(k6)) * mul);
-                    hash[3] = finish((((h0 ^ p3) * mul ^ p5) * mul ^ uint64_t(k7)) * mul);
-                }
+                hash[0] = finish((((h0 ^ p0) * mul ^ p2) * mul ^ uint64_t(k4)) * mul);
+                hash[1] = finish((((h0 ^ p1) * mul ^ p3) * mul ^ uint64_t(k5)) * mul);
+                hash[2] = finish((((h0 ^ p2) * mul ^ p4) * mul ^ uint64_t(k6)) * mul);
+                hash[3] = finish((((h0 ^ p3) * mul ^ p5) * mul ^ uint64_t(k7)) * mul);
             }
         } else {
             // Any m: the window's markers one by one (they are in L1 after the tile load).
@@ -246,9 +256,12 @@ hashWindowsKernel(
             for(int w = 0; w < 4; w++) {
                 uint32_t win[HASH_HALO + 1];
                 for(uint32_t q = 0; q < mm; q++) win[q] = kmerIds[i0 + uint32_t(w) + q];
-                hash[w] = murmurWindow<0>(win, mm, seed);
+                hash[w] = murmurWindow<0>(win, mm, seedNow);
             }
         }
+        };
+        bool counts[4];
+        uint32_t readOfWindow[4];
 #pragma unroll
         for(int w = 0; w < 4; w++) {
             const uint64_t i = i0 + uint32_t(w);
@@ -261,7 +274,20 @@ hashWindowsKernel(
                 // Reads with fewer than m markers (:337) and palindromic reads (:325) produce nothing.
                 ok = i + mm <= ee && !pp;
             }
-            append(ok && hash[w] < hashThreshold, hash[w], rr);               // :350, strict
+            counts[w] = ok; readOfWindow[w] = rr;
+        }
+        if constexpr (ALL) {
+            for(uint32_t t = 0; t < iterations; t++) {
+                uint64_t hash[4];
+                hashes(uint64_t(t) * 37ULL, hash);                                // :316
+#pragma unroll
+                for(int w = 0; w < 4; w++) append(counts[w] && hash[w] < hashThreshold, hash[w], readOfWindow[w], t << iterationShift);
+            }
+        } else {
+            uint64_t hash[4];
+            hashes(seed, hash);
+#pragma unroll
+            for(int w = 0; w < 4; w++) append(counts[w] && hash[w] < hashThreshold, hash[w], readOfWindow[w], 0u);               // :350, strict
         }
     }
     if(fill) flush();
@@ -296,6 +322,7 @@ enum : int {
     C_OVERFLOW = 2,         // entries of the list of bucket sizes beyond the histogram bins
     C_MAX_RECORDS = 3,      // largest C_RECORDS of any iteration
     C_BUCKETS = 4,          // buckets used by the current iteration
+    C_TOTAL_RECORDS = 5,    // (all iterations in one pass) low hashes the hash kernel found in all
     C_COUNT = 8
 };
 
@@ -324,12 +351,14 @@ groupStartsKernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict_
 
 // Per record: pass-2 statistics (src/LowHash0.cpp:386-393), bucket-size histogram (:566-613, one vote per bucket =
 // per first record), and the number of pairs this record starts in pass 3 (:430-457).
+// iterationKeys (records of all iterations in one array, key = iteration << iterationShift | bucket id): the iteration of a
+// record is read off its key and sizeHist is the table of all rows; otherwise `iteration` and its row.
 __global__ void __launch_bounds__(256)
 bucketStatsKernel(
     const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts, Count count,
-    uint64_t minBucketSize, uint64_t maxBucketSize, uint32_t iteration,
+    uint64_t minBucketSize, uint64_t maxBucketSize, uint32_t iteration, const uint32_t* __restrict__ iterationKeys, uint32_t iterationShift,
     unsigned long long* __restrict__ stats,             // [R][3]
-    unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP] of this iteration
+    unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP] of this iteration (of iteration 0 with iterationKeys)
     unsigned long long* __restrict__ overflowSizes, uint32_t overflowCapacity,     // iteration << 32 | size
     unsigned long long* __restrict__ counters,
     uint64_t* __restrict__ pairCounts)                  // [n+1]
@@ -339,7 +368,14 @@ bucketStatsKernel(
     sHist[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    // The workgroup's LDS histogram belongs to the iteration of its first record; a record of another one (a workgroup on an
+    // iteration boundary) votes in its own row directly.
+    const uint64_t blockFirst = uint64_t(blockIdx.x) * blockDim.x;
+    const uint32_t blockIteration = (iterationKeys && blockFirst < n) ? iterationKeys[blockFirst] >> iterationShift : iteration;
+    if(iterationKeys) sizeHist += uint64_t(blockIteration) * SIZE_HIST_CAP;
     if(i < n) {
+        if(iterationKeys) iteration = iterationKeys[i] >> iterationShift;
+        unsigned long long* const myHist = sizeHist + (int64_t(iteration) - int64_t(blockIteration)) * SIZE_HIST_CAP;
         const uint32_t b = pos[i + 1] - 1;
         const uint32_t begin = starts[b], end = starts[b + 1];
         const uint64_t size = end - begin;
@@ -349,8 +385,8 @@ bucketStatsKernel(
         const int cls = (size < minBucketSize) ? 0 : ((size > maxBucketSize) ? 2 : 1);
         atomicAdd(&stats[3ULL * readId + cls], 1ULL);
         if(i == begin) {
-            if(size < SIZE_HIST_LDS) atomicAdd(&sHist[size], 1u);
-            else if(size < SIZE_HIST_CAP) atomicAdd(&sizeHist[size], 1ULL);
+            if(size < SIZE_HIST_LDS && iteration == blockIteration) atomicAdd(&sHist[size], 1u);
+            else if(size < SIZE_HIST_CAP) atomicAdd(&myHist[size], 1ULL);
             else {
                 const unsigned long long o = atomicAdd(&counters[C_OVERFLOW], 1ULL);
                 if(o < overflowCapacity) overflowSizes[o] = ((unsigned long long)iteration << 32) | (unsigned long long)(size < 0xffffffffULL ? size : 0xffffffffULL);
@@ -381,7 +417,7 @@ bucketStatsKernel(
 __global__ void __launch_bounds__(256)
 pairWriteKernel(
     const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts,
-    const uint64_t* __restrict__ pairOffsets, Count count, int readBits, uint32_t iteration,
+    const uint64_t* __restrict__ pairOffsets, Count count, int readBits, uint32_t iteration, const uint32_t* __restrict__ iterationKeys, uint32_t iterationShift,
     const unsigned long long* __restrict__ counters, uint64_t* __restrict__ pairKeys, uint32_t* __restrict__ pairTags, uint64_t pairCapacity)
 {
     const uint64_t n = count.get();
@@ -389,6 +425,7 @@ pairWriteKernel(
     if(i >= n) return;
     uint64_t dst = pairOffsets[i];
     if(pairOffsets[i + 1] == dst) return;
+    if(iterationKeys) iteration = iterationKeys[i] >> iterationShift;
     dst += counters[C_PAIRS];
     const uint32_t b = pos[i + 1] - 1;
     const uint32_t begin = starts[b], end = starts[b + 1];
@@ -427,6 +464,36 @@ __global__ void noteIterationKernel(unsigned long long* __restrict__ counters, u
     iterationTable[4ULL * iteration + 3] = 0;
     if(records > counters[C_MAX_RECORDS]) counters[C_MAX_RECORDS] = records;
     counters[C_RECORDS] = 0;
+}
+
+// The same for the records of ALL iterations in one sorted array (key = iteration << shift | bucket id): thread t files
+// iteration t -- its records are [first record with key >= t << shift, first with key >= (t + 1) << shift), its buckets and its
+// pair keys what the two scans say at those positions.  counters[C_RECORDS] holds what the hash kernel found in all.
+__global__ void __launch_bounds__(64)
+noteAllIterationsKernel(unsigned long long* __restrict__ counters, unsigned long long* __restrict__ iterationTable, uint32_t iterations, uint32_t shift,
+    const uint32_t* __restrict__ keys, Count count, const uint32_t* __restrict__ pos, const uint64_t* __restrict__ pairOffsets)
+{
+    const unsigned long long found = count.device ? *count.device : count.bound;
+    const uint64_t n = count.get();
+    auto firstAtLeast = [&](uint32_t t) -> uint64_t {           // first record of iteration >= t
+        if(t >= iterations) return n;
+        uint64_t lo = 0, hi = n;
+        while(lo < hi) { const uint64_t mid = (lo + hi) >> 1; if((keys[mid] >> shift) < t) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    for(uint32_t t = threadIdx.x; t < iterations; t += blockDim.x) {
+        const uint64_t begin = firstAtLeast(t), end = firstAtLeast(t + 1);
+        iterationTable[4ULL * t + 0] = end - begin;
+        iterationTable[4ULL * t + 1] = n ? pos[end] - pos[begin] : 0;
+        iterationTable[4ULL * t + 2] = n ? pairOffsets[end] : 0;
+        iterationTable[4ULL * t + 3] = 0;
+    }
+    if(threadIdx.x == 0) {
+        counters[C_PAIRS] += n ? pairOffsets[n] : 0;
+        counters[C_BUCKETS] = n ? pos[n] : 0;
+        counters[C_TOTAL_RECORDS] = found;
+        counters[C_RECORDS] = 0;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -605,8 +672,16 @@ template<class T> T* mallocCopy(const std::vector<T>& v)
 int bitsFor(uint64_t maxValue) { int b = 1; while((maxValue >> b) != 0) ++b; return b; }
 
 // The row of the kernel table a launch for this m is booked under (the template instance that runs).
-const char* hashKernelName(uint32_t m)
+const char* hashKernelName(uint32_t m, bool all = false)
 {
+    if(all) {
+        switch(m) {
+            case 3: return "hashWindowsKernel<3, true> (all iterations)";
+            case 4: return "hashWindowsKernel<4, true> (all iterations)";
+            case 5: return "hashWindowsKernel<5, true> (all iterations)";
+            default: return "hashWindowsKernel<0, true> (any m, all iterations)";
+        }
+    }
     switch(m) {
         case 3: return "hashWindowsKernel<3>";
         case 4: return "hashWindowsKernel<4>";
@@ -615,24 +690,34 @@ const char* hashKernelName(uint32_t m)
     }
 }
 
+// iterations = 0: one iteration with `seed`; otherwise all of them in one pass (hashWindowsKernel<m, true>).
 void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uint32_t mask,
     uint64_t markerBegin, uint64_t markerEnd,
-    uint32_t* outKeys, uint64_t* outVals, unsigned long long* counter, uint64_t capacity)
+    uint32_t* outKeys, uint64_t* outVals, unsigned long long* counter, uint64_t capacity, uint32_t iterations = 0, uint32_t iterationShift = 0)
 {
     const uint64_t tiles = (markerEnd + HASH_TILE - 1) / HASH_TILE - markerBegin / HASH_TILE;
     if(tiles == 0) return;
     // Persistent wavefronts: 256 CUs x 8 blocks x 4 independent wavefronts, each walking many tiles, so that one global
     // atomic serves a few hundred low hashes.
     const unsigned blocks = unsigned(std::min<uint64_t>(divUp(tiles, uint64_t(HASH_THREADS / WAVE)), 256 * 8));
-#define SHASTA_LAUNCH_HASH(MF) hipLaunchKernelGGL(hashWindowsKernel<MF>, dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
+#define SHASTA_LAUNCH_HASH(MF, ALL) hipLaunchKernelGGL((hashWindowsKernel<MF, ALL>), dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
         (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), (const uint8_t*)ctx.readFlags.data(), \
         (const uint4*)ctx.tileDesc.data(), markerBegin, markerEnd, ctx.markerCount, \
-        m, seed, threshold, mask, outKeys, outVals, counter, capacity)
-    switch(m) {
-        case 3: SHASTA_LAUNCH_HASH(3); break;
-        case 4: SHASTA_LAUNCH_HASH(4); break;
-        case 5: SHASTA_LAUNCH_HASH(5); break;
-        default: SHASTA_LAUNCH_HASH(0); break;
+        m, seed, threshold, mask, outKeys, outVals, counter, capacity, iterations, iterationShift)
+    if(iterations) {
+        switch(m) {
+            case 3: SHASTA_LAUNCH_HASH(3, true); break;
+            case 4: SHASTA_LAUNCH_HASH(4, true); break;
+            case 5: SHASTA_LAUNCH_HASH(5, true); break;
+            default: SHASTA_LAUNCH_HASH(0, true); break;
+        }
+    } else {
+        switch(m) {
+            case 3: SHASTA_LAUNCH_HASH(3, false); break;
+            case 4: SHASTA_LAUNCH_HASH(4, false); break;
+            case 5: SHASTA_LAUNCH_HASH(5, false); break;
+            default: SHASTA_LAUNCH_HASH(0, false); break;
+        }
     }
 #undef SHASTA_LAUNCH_HASH
     HIP_CHECK(hipGetLastError());
@@ -777,35 +862,45 @@ void enqueueHash(Context& ctx, LowHash0Job& job, uint64_t iteration)
 
 // K2: the records sorted by bucket id (radix partition on the bucket id).  Which side holds the result depends on
 // the key width only.
-void enqueueSortRecords(Context& ctx, LowHash0Job& job, const uint32_t*& keys, const uint64_t*& vals, Count count)
+void enqueueSortRecords(Context& ctx, LowHash0Job& job, const uint32_t*& keys, const uint64_t*& vals, Count count, uint32_t allIterations = 0)
 {
     hipStream_t stream = ctx.stream;
     keys = job.recKeysA.data(); vals = job.recValsA.data();
-    const uint64_t passes = (job.log2BucketCount + 7) / 8;
-    const KernelTimers::Span span = ctx.timers.begin("radix sort of low-hash records", stream);
+    const int bits = int(job.log2BucketCount) + (allIterations ? bitsFor(allIterations - 1) : 0);      // (allIterations: the iteration above the bucket id)
+    const uint64_t passes = (uint64_t(bits) + 7) / 8;
+    const KernelTimers::Span span = ctx.timers.begin(allIterations ? "radix sort of the low-hash records of all iterations" : "radix sort of low-hash records", stream);
     if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
-        count, int(job.log2BucketCount), ctx.sortWs, stream)) {
+        count, bits, ctx.sortWs, stream)) {
         keys = job.recKeysB.data(); vals = job.recValsB.data();
     }
     // 12 bytes per record read + written per 8-bit pass; the record count is booked from the expected fraction.
-    const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin));
+    const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin)) * std::max<uint32_t>(1, allIterations);
     (void)ctx.timers.end(span, 2 * 12 * expected * passes, expected);
 }
 
 // K3 + K4 on sorted records: statistics, histogram row `iteration`, pair keys appended at counters[C_PAIRS]; then the
 // iteration's counters are filed (noteIterationKernel).
+// allIterations > 0: the records of that many iterations in one array, key = iteration << log2BucketCount | bucket id (`iteration` unused).
 void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keys, const uint64_t* vals, Count count, uint64_t iteration,
-    uint64_t* pairKeys, uint32_t* pairTags, uint64_t pairCapacity)
+    uint64_t* pairKeys, uint32_t* pairTags, uint64_t pairCapacity, uint32_t allIterations = 0)
 {
     hipStream_t stream = ctx.stream;
     const uint64_t bound = count.bound;
     unsigned long long* counters = job.counters.data();
+    const uint32_t* iterationKeys = allIterations ? keys : nullptr;
+    const uint32_t iterationShift = uint32_t(job.log2BucketCount);
+    if(bound == 0 && allIterations) {
+        hipLaunchKernelGGL(noteAllIterationsKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), allIterations, iterationShift,
+            keys, count, (const uint32_t*)nullptr, (const uint64_t*)nullptr);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if(bound == 0) {
         hipLaunchKernelGGL(noteIterationKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), uint32_t(iteration), count, (const uint32_t*)nullptr, (const uint64_t*)nullptr);
         HIP_CHECK(hipGetLastError());
         return;
     }
-    const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin));
+    const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin)) * std::max<uint32_t>(1, allIterations);
     job.flags.reserve(bound + 1, stream); job.pos.reserve(bound + 1, stream); job.starts.reserve(bound + 2, stream);
     job.scanTemp32.reserve(scanTempElements(bound + 1), stream);
     job.pairCounts.reserve(bound + 1, stream); job.scanTemp64.reserve(scanTempElements(bound + 1), stream);
@@ -817,14 +912,17 @@ void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keys, const 
     SHASTA_TIMED(ctx, "bucketStatsKernel + scan of pair counts", stream, 12 * expected, expected,
         hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
             vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), count,
-            job.p.minBucketSize, job.p.maxBucketSize, uint32_t(iteration), job.stats.data(), job.sizeHist.data() + iteration * SIZE_HIST_CAP,
+            job.p.minBucketSize, job.p.maxBucketSize, uint32_t(iteration), iterationKeys, iterationShift, job.stats.data(),
+            job.sizeHist.data() + (allIterations ? 0 : iteration * SIZE_HIST_CAP),
             job.overflowSizes.data(), LowHash0Job::overflowCapacity, counters, job.pairCounts.data());
         exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), bound + 1, job.scanTemp64.data(), stream));
     SHASTA_TIMED(ctx, "pairWriteKernel", stream, 0, expected,
         hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(bound, 256)), dim3(256), 0, stream,
             vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), (const uint64_t*)job.pairCounts.data(), count, job.readBits, uint32_t(iteration),
-            (const unsigned long long*)counters, pairKeys, pairTags, pairCapacity));
-    hipLaunchKernelGGL(noteIterationKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), uint32_t(iteration), count,
+            iterationKeys, iterationShift, (const unsigned long long*)counters, pairKeys, pairTags, pairCapacity));
+    if(allIterations) hipLaunchKernelGGL(noteAllIterationsKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), allIterations, iterationShift,
+        keys, count, (const uint32_t*)job.pos.data(), (const uint64_t*)job.pairCounts.data());
+    else hipLaunchKernelGGL(noteIterationKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), uint32_t(iteration), count,
         (const uint32_t*)job.pos.data(), (const uint64_t*)job.pairCounts.data());
     HIP_CHECK(hipGetLastError());
 }
@@ -1131,7 +1229,30 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
             unsigned long long host[C_COUNT];
             bool again = false;
             uint64_t highFrequency = 0;
-            for(uint64_t iteration = 0; ; iteration++) {
+            // All iterations in one pass over the markers (hashWindowsKernel<m, true>) whenever their number is known in
+            // advance and iteration | bucket id fits the records' 32-bit sort key (not at 2^31 buckets, the human-genome value:
+            // there, and with the dynamic iteration control, iteration after iteration as before).  SHASTA_MI355X_LOWHASH_ONE_PASS=0: never.
+            const bool onePassAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_LOWHASH_ONE_PASS"); return !(e && e[0] == '0'); }();      // (read for every call: tests switch it)
+            const uint64_t I = p.minHashIterationCount;
+            const bool onePass = onePassAllowed && I >= 1 && I <= 4096 && job.log2BucketCount + uint64_t(bitsFor(I - 1)) <= 32 &&
+                I * job.recCapacity < (1ULL << 32) - 1;
+            uint64_t recordCapacityAll = 0;
+            if(onePass) {
+                reserveIterationRows(job, I, stream);
+                recordCapacityAll = I * job.recCapacity;
+                job.recKeysA.reserve(recordCapacityAll, stream); job.recKeysB.reserve(recordCapacityAll, stream);
+                job.recValsA.reserve(recordCapacityAll, stream); job.recValsB.reserve(recordCapacityAll, stream);
+                const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(p.m), true), stream);
+                launchHash(ctx, uint32_t(p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
+                    job.recKeysA.data(), job.recValsA.data(), counters + C_RECORDS, recordCapacityAll, uint32_t(I), uint32_t(job.log2BucketCount));
+                job.hashHandles.push_back(ctx.timers.end(span, 4 * (job.markerEnd - job.markerBegin), (job.markerEnd - job.markerBegin) * I));
+                const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
+                const Count records(recordCapacityAll, counters + C_RECORDS);
+                enqueueSortRecords(ctx, job, keys, vals, records, uint32_t(I));
+                enqueueBuckets(ctx, job, keys, vals, records, 0, job.pairKeys(), job.pairTags(), job.pairCapacity, uint32_t(I));
+                job.iterations = I;
+            }
+            else for(uint64_t iteration = 0; ; iteration++) {
                 // Iteration control, src/LowHash0.cpp:136-157.
                 if(p.minHashIterationCount == 0) {
                     const double current = 2. * double(highFrequency) / double(readCount);
@@ -1161,6 +1282,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
             }
             HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
+            if(onePass) host[C_MAX_RECORDS] = host[C_TOTAL_RECORDS] > recordCapacityAll ? (host[C_TOTAL_RECORDS] + I - 1) / I + 1 : 0;      // (per iteration, for the hint)
             if(host[C_MAX_RECORDS] > job.recCapacity || host[C_PAIRS] > job.pairCapacity) again = true;
             if(again) {
                 // A capacity guess was too small (keys or records were dropped, counters are exact): once more with room.
@@ -1189,8 +1311,10 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
                 static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
                 appendHistogramRows(iteration, bucketCount, table[4 * iteration + 1], reinterpret_cast<const uint64_t*>(hist.data()) + iteration * SIZE_HIST_CAP, overflow, histogramRows);
                 // Algorithmic bytes of the iteration's hash launch: 4 B per marker read + 12 B per low hash written.
-                if(iteration < job.hashHandles.size()) ctx.timers.amend(job.hashHandles[iteration], 4 * (job.markerEnd - job.markerBegin) + 12 * table[4 * iteration], job.markerEnd - job.markerBegin);
+                if(!onePass && iteration < job.hashHandles.size()) ctx.timers.amend(job.hashHandles[iteration], 4 * (job.markerEnd - job.markerBegin) + 12 * table[4 * iteration], job.markerEnd - job.markerBegin);
             }
+            // (one pass: the markers are read once, the low hashes of every iteration written)
+            if(onePass && !job.hashHandles.empty()) ctx.timers.amend(job.hashHandles[0], 4 * (job.markerEnd - job.markerBegin) + 12 * host[C_TOTAL_RECORDS], (job.markerEnd - job.markerBegin) * I);
             lowhash0Finish(ctx, readLowHashStatistics, hostCandidates, highFrequencyPerIteration, totalPerIteration);
             break;
         }

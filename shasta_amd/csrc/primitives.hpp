@@ -212,13 +212,22 @@ radixHistogramKernel(const K* __restrict__ keys, uint32_t* __restrict__ counts, 
     counts[uint64_t(threadIdx.x) * numBlocks + blockIdx.x] = hist[threadIdx.x];
 }
 
+// The tile leaves through LDS: every key is first put where it belongs inside the tile's own sorted order (digit by digit,
+// and inside a digit in index order), then the tile is written out position by position -- neighbouring positions of one digit
+// go to neighbouring addresses, so that a store instruction writes runs of whole lines where storing from the ranking's
+// registers wrote 64 scattered words (round 3: the sort of 3e7 twelve-byte records 4.0 -> 2.x ms).
 template<class K, class V, bool HAS_V>
 __global__ void __launch_bounds__(RS_THREADS)
 radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
     const V* __restrict__ valsIn, V* __restrict__ valsOut,
     const uint32_t* __restrict__ offsets, Count count, int shift, unsigned numBlocks)
 {
-    __shared__ uint32_t counters[RS_WAVES][RS_BINS];   // per-wave digit counts, then destination bases
+    __shared__ uint32_t counters[RS_WAVES][RS_BINS];   // per-wave digit counts, then the wave's first position of the digit inside the tile
+    __shared__ uint32_t tileStart[RS_BINS];            // first position of the digit inside the tile
+    __shared__ uint32_t globalStart[RS_BINS];          // ... and in the output
+    __shared__ uint32_t waveTotals[RS_WAVES];
+    __shared__ K stagedKeys[RS_TILE];
+    __shared__ V stagedVals[HAS_V ? RS_TILE : 1];
     const uint64_t n = count.get();
     const int lane = laneId();
     const int wave = int(threadIdx.x) >> 6;
@@ -226,7 +235,8 @@ radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
     for(int w = 0; w < RS_WAVES; w++) counters[w][threadIdx.x] = 0;
     __syncthreads();
 
-    const uint64_t waveBase = uint64_t(blockIdx.x) * RS_TILE + uint64_t(wave) * RS_PER_WAVE;
+    const uint64_t tileBase = uint64_t(blockIdx.x) * RS_TILE;
+    const uint64_t waveBase = tileBase + uint64_t(wave) * RS_PER_WAVE;
     K key[RS_ROUNDS];
     uint32_t rank[RS_ROUNDS];
 #pragma unroll
@@ -254,15 +264,23 @@ radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
     }
     __syncthreads();
     {
-        // Thread d turns the per-wave counts of digit d into destination bases.
+        // Thread d: the tile's count of digit d, its exclusive scan over the digits (a wave scan + the waves' totals), the first
+        // position of every wave's keys of digit d inside the tile, and where the digit starts in the output.
         const unsigned d = threadIdx.x;
-        uint32_t base = offsets[uint64_t(d) * numBlocks + blockIdx.x];
+        uint32_t c[RS_WAVES], total = 0;
 #pragma unroll
-        for(int w = 0; w < RS_WAVES; w++) {
-            const uint32_t c = counters[w][d];
-            counters[w][d] = base;
-            base += c;
-        }
+        for(int w = 0; w < RS_WAVES; w++) { c[w] = counters[w][d]; total += c[w]; }
+        uint32_t inclusive = total;
+#pragma unroll
+        for(int delta = 1; delta < WAVE; delta <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), delta, WAVE)); if(lane >= delta) inclusive += o; }
+        if(lane == WAVE - 1) waveTotals[wave] = inclusive;
+        __syncthreads();
+        uint32_t start = inclusive - total;
+        for(int w = 0; w < wave; w++) start += waveTotals[w];
+        tileStart[d] = start;
+        globalStart[d] = offsets[uint64_t(d) * numBlocks + blockIdx.x];
+#pragma unroll
+        for(int w = 0; w < RS_WAVES; w++) { counters[w][d] = start; start += c[w]; }
     }
     __syncthreads();
 #pragma unroll
@@ -270,9 +288,22 @@ radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
         const uint64_t i = waveBase + uint64_t(r) * WAVE + lane;
         if(i < n) {
             const unsigned digit = unsigned(key[r] >> shift) & 255u;
-            const uint32_t dst = counters[wave][digit] + rank[r];
-            keysOut[dst] = key[r];
-            if(HAS_V) valsOut[dst] = valsIn[i];
+            const uint32_t at = counters[wave][digit] + rank[r];
+            stagedKeys[at] = key[r];
+            if(HAS_V) stagedVals[at] = valsIn[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t inTile = uint32_t(n > tileBase ? (n - tileBase < uint64_t(RS_TILE) ? n - tileBase : uint64_t(RS_TILE)) : 0);
+#pragma unroll 4
+    for(int r = 0; r < RS_TILE / RS_THREADS; r++) {
+        const uint32_t at = uint32_t(r) * RS_THREADS + threadIdx.x;
+        if(at < inTile) {
+            const K k = stagedKeys[at];
+            const unsigned digit = unsigned(k >> shift) & 255u;
+            const uint32_t dst = globalStart[digit] + (at - tileStart[digit]);
+            keysOut[dst] = k;
+            if(HAS_V) valsOut[dst] = stagedVals[at];
         }
     }
 }

@@ -79,6 +79,19 @@ def test_lowhash0_and_align4(emu_lib, oracle_lib):
         assert np.array_equal(x.status[keep], y.status[keep])
 
 
+def test_lowhash0_iteration_after_iteration(emu_lib, oracle_lib, monkeypatch):
+    # SHASTA_MI355X_LOWHASH_ONE_PASS=0 against the default (all iterations in one pass) and the oracle.
+    toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=12000, seed=41)
+    for kw in (dict(m=3, minHashIterationCount=16, minBucketSize=2, maxBucketSize=30, minFrequency=2), dict(m=7, minHashIterationCount=5, hashFraction=0.02, minBucketSize=2, maxBucketSize=30, minFrequency=2)):
+        p = abi.default_lowhash0_params(**kw)
+        a = emu_lib.lowhash0(toc, data7, None, p)
+        monkeypatch.setenv("SHASTA_MI355X_LOWHASH_ONE_PASS", "0")
+        b = emu_lib.lowhash0(toc, data7, None, p)
+        monkeypatch.delenv("SHASTA_MI355X_LOWHASH_ONE_PASS")
+        support.same_lowhash(a, b)
+        support.same_lowhash(a, oracle_lib.lowhash0(toc, data7, None, p))
+
+
 def test_lowhash0_golden_fixture(emu_lib):
     g = support.Golden("tiny.npz")
     out = emu_lib.lowhash0(g.toc, g.data7, None, abi.default_lowhash0_params())
