@@ -235,6 +235,54 @@ def roofline_of(name, row, pmc):
     return r
 
 
+def hbm_budget(markers_total, reads_total, n_gpus, hash_fraction=0.01, iterations=10, pairs_per_read=40.0, workers=6):
+    """Per-GPU HBM the path needs for a job of that size on n_gpus GPUs (bytes): every GPU holds the dense
+    kmer ids of ALL reads (the aligner needs both reads of any candidate), its share of the LowHash0 buffers, and the aligner
+    workers' scratch (measured high-water marks at 2^18 candidates per batch).  Printed for BASELINE configs[3] and [4] so that
+    the 288 GB of one MI355X are checked before such a run, not during it."""
+    m, r, g = float(markers_total), float(reads_total), float(n_gpus)
+    records = 2.0 * hash_fraction * m / g                                # capacity of one iteration's low-hash records on a GPU
+    one_pass = (m * hash_fraction > 0 and (5 + np.ceil(np.log2(max(2.0, hash_fraction * m)))) + np.ceil(np.log2(max(2, iterations))) <= 32)
+    record_rows = records * (iterations if one_pass else 1)
+    pairs = pairs_per_read * r * iterations / g * 1.25                   # pair keys of all iterations owned by a GPU
+    parts = {
+        "kmer_ids_of_all_reads": 4.0 * m,
+        "toc_flags_tile_descriptors": 16.0 * r + r + m / 16.0,
+        "lowhash0_records_ping_pong": 24.0 * record_rows,
+        "lowhash0_bucket_tables": 20.0 * record_rows,
+        "lowhash0_pair_keys_ping_pong": 24.0 * pairs,
+        "lowhash0_statistics_histograms": 24.0 * r + 16384.0 * iterations,
+        "aligner_scratch_%d_workers" % workers: workers * 5.0e9,
+    }
+    total = sum(parts.values())
+    return {"n_gpus": int(n_gpus), "bytes_per_gpu": {k: int(v) for k, v in parts.items()}, "total_GB_per_gpu": total / 1e9,
+            "fits_288_GB": bool(total < 288e9 * 0.95), "records_of_all_iterations_in_one_pass": bool(one_pass)}
+
+
+def group_bench(lib, devices, toc, kmer, p, o, args, align_method):
+    """The same step through the in-process group (shasta_mi355x_group: one host thread and one context per device, device-to-
+    device pulls over xGMI for the two exchanges of an iteration) -- the seam a C++ caller of the two Assembler functions uses --
+    timed like the step of the one-process-per-GPU driver."""
+    with lib.group(devices) as g:
+        g.set_kmer_ids(toc, kmer)
+
+        def step():
+            lh = g.lowhash0(p)
+            al = (g.align4 if align_method == 4 else g.align3)(lh.candidates, o, want_ordinals=False)
+            return len(lh.candidates), len(al.alignment_data)
+
+        for _ in range(args.warmup):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pairs, stored = step()
+        elapsed = time.perf_counter() - t0
+    steps = max(1, args.steps)
+    return {"devices": [int(d) for d in devices], "value": pairs / (elapsed / steps), "unit": "pairs/s", "ms_per_step": elapsed / steps * 1e3,
+            "candidates": int(pairs), "alignments_stored": int(stored),
+            "what": "shasta_mi355x_group_lowhash0_run + _group_align%d_run in one process over these devices (host-resident result assembly included)" % align_method}
+
+
 def markers_bench(lib, ctx, args):
     """The widening row `marker finding` (MarkerFinder, src/MarkerFinder.cpp:16-127) on its own: one step = the reads of the
     workload (2-bit planes, 0.25 B per base, uploaded inside the step as the seam does) -> dense kmer ids + toc resident in HBM."""
@@ -276,6 +324,9 @@ def main():
     ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on")
     ap.add_argument("--tie-census", type=int, default=20000,
                     help="candidates (a subset of the baseline sample) the checker re-aligns under the 11 other DP tie policies; 0 = no census")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process drives --gpus devices through the in-process group (shasta_mi355x_group) instead of one process per "
+                         "GPU with RCCL; with torch.distributed.run and N > 1 the group line is measured by rank 0 after the RCCL line anyway")
     ap.add_argument("--lowhash-only", action="store_true", help="BASELINE configs[1]")
     ap.add_argument("--markers", action="store_true",
                     help="marker finding only (SURVEY 8f row 2): random RLE reads of --reads x 20 kb, k = 10, 10 %% of the k-mers markers")
@@ -326,6 +377,24 @@ def main():
             return ctx.align4(candidates, o, want_ordinals=False, borrow=True)
         return ctx.align3(candidates, o, want_ordinals=False, borrow=True)
 
+    if args.group and world == 1:
+        # ONE process, --gpus devices, the in-process group (weak scaling like the other mode: --reads reads per GPU).
+        n = max(1, args.gpus)
+        assert lib.device_count() >= n or DRY_RUN_LIBRARY, "--group --gpus %d needs that many devices" % n
+        toc, kmer = make_workload(args.reads * n, 12345)
+        ctx.close()
+        g = group_bench(lib, list(range(n)) if not DRY_RUN_LIBRARY else [0] * n, toc, kmer, p, o, args, args.align_method)
+        print(json.dumps({
+            "metric": "candidate read-pairs aligned/sec (LowHash0+Align%d), in-process group" % (4 if args.align_method == 4 else 3),
+            "value": g["value"], "unit": "pairs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": g["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32/i32 (integer hash + integer DP)",
+            "data": "synthetic" if not DRY_RUN_LIBRARY else "synthetic; DRY RUN ON THE EMULATED BUILD - NOT A MEASUREMENT",
+            "config": {"workload": "BASELINE configs[2] shape, %d reads/GPU, one job over %d devices in ONE process (shasta_mi355x_group)" % (args.reads, n),
+                       "reads_per_gpu": args.reads, "markers_total": int(toc[-1]), "candidates": g["candidates"], "alignments_stored": g["alignments_stored"],
+                       "parallelism": "%d GPUs, in-process group: device-to-device pulls over xGMI, no RCCL" % n},
+            "in_process_group": g, "hbm_budget_per_gpu": hbm_budget(int(toc[-1]), args.reads * n, n)}))
+        return
+
     toc = kmer = None
     if world == 1:
         # Workload: BASELINE configs[2].
@@ -365,6 +434,7 @@ def main():
         if not DRY_RUN_LIBRARY:
             torch.cuda.synchronize()
         ctx.set_kmer_ids_device(toc, everything.data_ptr())
+        all_kmer_ids = everything          # (rank 0 hands them to the in-process group after the timed region)
         del everything
         marker_count = int(toc[-1])
         read_count = world * args.reads
@@ -437,6 +507,22 @@ def main():
         if status_counts is not None:
             status_counts = [int(x) for x in c[1:].tolist()]
 
+    # N > 1: the same job once more through the in-process group, by rank 0 alone over all N devices (the seam a C++ caller of
+    # the two Assembler functions uses: no RCCL, device-to-device pulls), so that one multi-GPU run compares the two drivers.
+    # The other ranks wait on the HOST (a gloo group: an RCCL barrier would spin on their GPUs meanwhile).  A failure of this
+    # extra line (peer access, memory) is reported in it and does not cost the run its result.
+    group_line = None
+    if dist is not None and not args.lowhash_only and not os.environ.get("SHASTA_BENCH_NO_GROUP_LINE"):
+        waiting = dist.new_group(backend="gloo")
+        if rank == 0:
+            try:
+                host_kmer = all_kmer_ids.cpu().numpy().view(np.uint32)
+                devices = list(range(world)) if not (os.environ.get("SHASTA_BENCH_ONE_DEVICE") or DRY_RUN_LIBRARY) else [0] * world
+                group_line = group_bench(lib, devices, toc, host_kmer, p, o, args, args.align_method)
+            except Exception as e:          # noqa: BLE001 -- reported, not raised
+                group_line = {"error": "%s: %s" % (type(e).__name__, e)}
+        dist.barrier(group=waiting)
+
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = elapsed / steps * 1e3
@@ -493,6 +579,14 @@ def main():
             "kernel_seconds_per_step": kernel_seconds,
             "kernels": kernels,
             "roofline": roofline,
+        }
+        if group_line is not None:
+            out["in_process_group"] = group_line
+        # What a GPU must hold: this run, and BASELINE configs[3] / [4] on 8 GPUs (chr1 50x M = 1.7e9, human 50x M = 2.2e10).
+        out["hbm_budget_per_gpu"] = {
+            "this_run": hbm_budget(marker_count, args.reads * world, world),
+            "configs[3] chr1 50x, 8 GPUs": hbm_budget(1.7e9, 6.2e5, 8, iterations=10),
+            "configs[4] human 50x, 8 GPUs": hbm_budget(2.2e10, 7.7e6, 8, iterations=10),
         }
         if kernels_one_worker is not None:
             out["kernels_one_worker"] = {k: {f: v[f] for f in ("avg_ms", "seconds_per_step", "achieved_GBps", "valu_issue_frac", "gcups") if f in v}

@@ -93,7 +93,7 @@ template<bool HUGE, int TIE>
 __global__ void __launch_bounds__(HUGE ? 256 : 64)
 align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ dsPairs,
     const WideTask* __restrict__ tasks, uint32_t taskCount, uint32_t rowWords,
-    uint64_t* __restrict__ trace, WideEnd* __restrict__ ends, int32_t* __restrict__ hugeRows)
+    uint64_t* __restrict__ trace, WideEnd* __restrict__ ends, int32_t* __restrict__ hugeRows, DpScores scores)
 {
     extern __shared__ int32_t wideRows[];                  // 3 x rowWords (not HUGE)
     __shared__ int32_t sBest[3 * 4];
@@ -129,9 +129,10 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
                 if(i == 0 || j == 0) v = 0;                                            // free leading gaps
                 else {
                     eq = p0[i - 1] == p1[j - 1];
-                    const int32_t dg = prev2[b] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
-                    const int32_t vg = (b + 1 < W ? prev1[b + 1] : NEG_SCORE) + GAP_SCORE;     // from (i, j-1)
-                    const int32_t hg = (b >= 1 ? prev1[b - 1] : NEG_SCORE) + GAP_SCORE;        // from (i-1, j)
+                    // (a neighbour that does not exist stays far below every real score: NEG_SCORE + |gap| never beats one)
+                    const int32_t dg = prev2[b] + (eq ? scores.match : scores.mismatch);
+                    const int32_t vg = (b + 1 < W ? prev1[b + 1] : NEG_SCORE) + scores.gap;     // from (i, j-1)
+                    const int32_t hg = (b >= 1 ? prev1[b - 1] : NEG_SCORE) + scores.gap;        // from (i-1, j)
                     // The first of the tie policy's order of (diagonal, vertical, horizontal) that reaches the maximum.
                     v = max(max(dg, vg), hg);
                     const int32_t candidates[3] = {dg, vg, hg};

@@ -232,7 +232,8 @@ void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int 
 }
 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
-struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; int tie; };
+struct DpInput { const uint32_t* kmerIds; const PairDesc* pairs; const DpTask* tasks; int tie; DpScores scores = {MATCH_SCORE, MISMATCH_SCORE, GAP_SCORE}; };
+inline bool defaultScores(const DpScores& s) { return s.match == MATCH_SCORE && s.mismatch == MISMATCH_SCORE && s.gap == GAP_SCORE; }
 
 // The tie policy of a call (align4_dp.hpp, DpTie): the build's DP_TIE_POLICY, unless SHASTA_MI355X_DP_TIE_POLICY names the one
 // alternative compiled beside it (parity tests of the switch; read for every call: tests change it).
@@ -258,10 +259,14 @@ void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, con
             in.kmerIds, in.pairs, in.tasks,
             sortedIds + layout.taskStart[cls], taskCount,
             (const uint64_t*)(b.bundleWords.data() + layout.bundleStart[cls]), bundleCount,
-            b.trace.data(), b.ends.data());
+            b.trace.data(), b.ends.data(), in.scores);
         HIP_CHECK(hipGetLastError());
     };
-    if(in.tie == DP_TIE_POLICY) launch(&bandedDpForwardKernel<G, C, DP_TIE_POLICY>);
+    if(!defaultScores(in.scores)) {
+        if(in.tie != DP_TIE_POLICY) throw std::runtime_error("align method 3 with scores other than 6 / -1 / -1 is compiled for the default DP tie policy only.");
+        launch(&bandedDpForwardKernel<G, C, DP_TIE_POLICY, true>);
+    }
+    else if(in.tie == DP_TIE_POLICY) launch(&bandedDpForwardKernel<G, C, DP_TIE_POLICY>);
     else launch(&bandedDpForwardKernel<G, C, DP_TIE_ALTERNATIVE>);
 }
 
@@ -574,10 +579,11 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
 }
 
 uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
-    DpEvents* ev, DpBatchStats* stats)
+    DpEvents* ev, DpBatchStats* stats, const DpScores* scores = nullptr)
 {
     hipStream_t stream = ws.stream;
-    const DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data(), dpTiePolicyOfCall()};
+    DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data(), dpTiePolicyOfCall()};
+    if(scores) in.scores = *scores;
     static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
     if(debug) {
         // Band widths of the batch's tasks, DP cells (nx x width) per width.
@@ -641,7 +647,7 @@ struct AlignStore {
 };
 
 // Align method 3: what alignOrientedReads3 needs besides the outer filters.
-struct Align3Plan { uint32_t k, hashThreshold; int32_t bandExtend, maxBand; };
+struct Align3Plan { uint32_t k, hashThreshold; int32_t bandExtend, maxBand; DpScores scores = {MATCH_SCORE, MISMATCH_SCORE, GAP_SCORE}; };
 
 // The markers method 3 keeps in step 1 (src/AssemblerAlign3.cpp:66-82), for every oriented read:
 // CSR of kmer ids and ordinals.  Built once per context and (k, threshold); dropped by setMarkers.
@@ -789,6 +795,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             const uint64_t nx = ctx.hostToc[o0 + 1] - pd.begin0, ny = ctx.hostToc[o1 + 1] - pd.begin1;
             // (the DP's sort key holds (nx + ny) / 2 iterations in 24 bits, its biased scores i + j < 2^25: align4_dp.hpp)
             if(nx + ny >= (1ULL << 25) - 4) throw std::runtime_error("Align4: a candidate's two reads have 2^25 - 4 markers or more between them (not supported).");
+            // (align method 3 with its own scores: biased scores stay inside 32 bits while magnitude x length < 2^28)
+            if(m3 && !defaultScores(m3->scores)) {
+                const uint64_t magnitude = uint64_t(std::abs(m3->scores.match)) + uint64_t(std::abs(m3->scores.mismatch)) + uint64_t(std::abs(m3->scores.gap));
+                if(magnitude * (nx + ny + 2) >= (1ULL << 28)) throw std::runtime_error("Align3: the scores times the length of a candidate's reads exceed the DP kernels' 32-bit range (not supported).");
+            }
             pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
@@ -858,7 +869,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
             if(taskCount1) {
                 HIP_CHECK(hipMemcpyAsync(b.tasks1.data(), tasks1.data(), taskCount1 * sizeof(DpTask), hipMemcpyHostToDevice, stream));
-                const DpInput in{ds->kmerIds.data(), b.dsPairs.data(), b.tasks1.data(), dpTiePolicyOfCall()};
+                const DpInput in{ds->kmerIds.data(), b.dsPairs.data(), b.tasks1.data(), dpTiePolicyOfCall(), m3->scores};
                 const DpForwardState f = runDpForward(ws, b, in, taskCount1, false, nullptr, nullptr);
                 out.dpCells += f.sums[0];
                 hipLaunchKernelGGL(align3BandKernel<false>, dim3(divUp(taskCount1, 256)), dim3(256), 0, stream,
@@ -901,12 +912,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     const auto kernel = alternativeTie ? &align3WideDpKernel<true, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<true, DP_TIE_POLICY>;
                     hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, stream,
                         (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
-                        b.trace.data(), b.wideEnds.data(), b.hugeRows.data());
+                        b.trace.data(), b.wideEnds.data(), b.hugeRows.data(), m3->scores);
                 } else {
                     const auto kernel = alternativeTie ? &align3WideDpKernel<false, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<false, DP_TIE_POLICY>;
                     hipLaunchKernelGGL(kernel, dim3(count), dim3(64), ldsBytes, stream,
                         (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
-                        b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr);
+                        b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr, m3->scores);
                 }
                 HIP_CHECK(hipGetLastError());
                 hipLaunchKernelGGL(align3BandKernel<true>, dim3(divUp(count, 256)), dim3(256), 0, stream,
@@ -1195,7 +1206,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         phaseCells = phaseMs(phaseStart);
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount) {
-            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats);
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr);
             out.hadTasks = true;
             HIP_CHECK(hipMemsetAsync(b.counters.data() + 12, 0, sizeof(uint32_t), stream));
             SHASTA_TIMED(ctx, "winnerKernel", stream, 0, taskCount,
@@ -1458,11 +1469,11 @@ void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
 void align3Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align3_options& o, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
 {
-    // The DP kernels carry the scores as compile-time constants (the values every shipped
-    // configuration uses for method 3 and the ones method 4 hard-wires).
-    if(o.matchScore != MATCH_SCORE || o.mismatchScore != MISMATCH_SCORE || o.gapScore != GAP_SCORE) {
-        throw std::runtime_error("Align3: only matchScore 6, mismatchScore -1, gapScore -1 are supported.");
-    }
+    // Scores as the reference passes them to SeqAn (src/AssemblerAlign3.cpp:22-33, 120, 257): any triple whose sums cannot
+    // leave the DP kernels' 32-bit range -- |score| (nx + ny) stays below 2^28 for the longest pair the kernels take (2^25
+    // markers) when the magnitudes add up to less than 8; larger ones are checked against the call's longest pair below.
+    const int64_t scoreMagnitude = std::llabs(o.matchScore) + std::llabs(o.mismatchScore) + std::llabs(o.gapScore);
+    if(scoreMagnitude >= (1LL << 20)) throw std::runtime_error("Align3: scores of magnitude 2^20 or more are not supported.");
     if(o.k < 1 || o.k > 16) throw std::runtime_error("Align3: k must be in [1, 16].");
     if(!(o.downsamplingFactor >= 0. && o.downsamplingFactor <= 1.)) throw std::runtime_error("Align3: downsamplingFactor must be in [0, 1].");
     if(o.bandExtend < 0 || o.bandExtend > (1 << 20)) throw std::runtime_error("Align3: bandExtend must be in [0, 2^20].");
@@ -1471,6 +1482,7 @@ void align3Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     plan.k = uint32_t(o.k);
     plan.hashThreshold = uint32_t(o.downsamplingFactor * double(std::numeric_limits<uint32_t>::max()));   // src/AssemblerAlign3.cpp:71-72
     plan.bandExtend = int32_t(o.bandExtend); plan.maxBand = int32_t(o.maxBand);
+    plan.scores = DpScores{int32_t(o.matchScore), int32_t(o.mismatchScore), int32_t(o.gapScore)};
     DeviceOptions opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = opt.deltaY = 1;

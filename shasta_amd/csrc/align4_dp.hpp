@@ -244,14 +244,19 @@ template<bool STEADY> struct DpPhase { static constexpr bool value = STEADY; };
 #else
 #define SHASTA_DP_FORWARD_OCCUPANCY(C)      // (the wave64 emulator of tests/emu compiles this file as plain C++)
 #endif
-template<int G, int C, int TIE>
+// The scores of the recurrence.  Align4 hard-wires 6 / -1 / -1 (src/Align4.hpp:159-161: compile-time constants here, SCORES =
+// false); align method 3 takes them from its options (src/AssemblerAlign3.cpp:22-33, 120, 257): any other triple runs the SCORES
+// = true instances, the same code with the three values in scalar registers (the host checks that nothing can overflow).
+struct DpScores { int32_t match, mismatch, gap; };
+template<int G, int C, int TIE, bool SCORES = false>
 __global__ void __launch_bounds__(256) SHASTA_DP_FORWARD_OCCUPANCY(C)
 bandedDpForwardKernel(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
     const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
     const uint64_t* __restrict__ bundleOffsets, uint32_t bundleCount,
-    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends)
+    uint64_t* __restrict__ trace, DpEnd* __restrict__ ends, DpScores scores)
 {
+    const int32_t matchScore = SCORES ? scores.match : MATCH_SCORE, mismatchScore = SCORES ? scores.mismatch : MISMATCH_SCORE, gapScore = SCORES ? scores.gap : GAP_SCORE;
     constexpr int T = WAVE / G, HC = C / 2, RW = 2 * C, U = DP_BLOCK;
     constexpr int AL = 2 * U;                             // steady iterations come in groups of AL: two blocks, one on each of the two register sets of kmer ids
     constexpr int32_t BIAS = -NEG_SCORE, NO_DIAGONAL = 0x40000000;
@@ -308,7 +313,7 @@ bandedDpForwardKernel(
         // Stored values are score + BIAS - GAP_SCORE (i + j): a gap move (one anti-diagonal on, one gap penalty) leaves the
         // stored value as it is, a diagonal move (two anti-diagonals on) adds the match or mismatch score minus two gap
         // penalties -- one addition per cell instead of two, same comparisons (all three candidates carry the same offset).
-        const int32_t dg = hd + (eq ? MATCH_SCORE - 2 * GAP_SCORE : MISMATCH_SCORE - 2 * GAP_SCORE);
+        const int32_t dg = hd + (eq ? matchScore - 2 * gapScore : mismatchScore - 2 * gapScore);
         // hv: from (i, j-1), diagonal b+1; hh: from (i-1, j), diagonal b-1.  The move kept is the first in the tie policy's order
         // of (diagonal, vertical, horizontal) that equals their maximum (for the restated SeqAn policy: vertical only if
         // hv > dg, horizontal only if hh > max(dg, hv)): one v_max3 and two equality tests instead of two maxima and two comparisons.
@@ -320,7 +325,7 @@ bandedDpForwardKernel(
             H[c] = exists[c] ? v : 0;
         } else {
             const bool valid = uint32_t(sc - lo[c]) <= span[c];
-            v = (sc == lo[c]) ? BIAS - GAP_SCORE * sc : v;          // i == 0 or j == 0: free leading gaps (score 0)
+            v = (sc == lo[c]) ? BIAS - gapScore * sc : v;           // i == 0 or j == 0: free leading gaps (score 0)
             H[c] = valid ? v : H[c];
         }
         uint64_t equal[3] = {0, 0, 0}, kept[3];
@@ -468,7 +473,7 @@ bandedDpForwardKernel(
     for(int c = 0; c < C; c++) {
         const int32_t d = bandMin + l * C + c;
         const int32_t i = (d >= nx - ny) ? nx : ny + d, j = i - d;
-        const int32_t v = exists[c] ? H[c] - BIAS + GAP_SCORE * (i + j) : NEG_SCORE;
+        const int32_t v = exists[c] ? H[c] - BIAS + gapScore * (i + j) : NEG_SCORE;
         if(v > bestScore || (v == bestScore && v > NEG_SCORE && DpTie<TIE>::endCellWins(i, j, bestI, bestJ))) { bestScore = v; bestI = i; bestJ = j; }
     }
     if constexpr ((G & (G - 1)) == 0) {

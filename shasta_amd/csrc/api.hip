@@ -141,6 +141,11 @@ int shasta_mi355x_lh_finish(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistic
 {
     API_BEGIN
     if(!c || !readLowHashStatistics || !candidates || !candidateCount || !iterationCount) throw std::runtime_error("lh_finish: null argument");
+    // Checked BEFORE the job is retired (lowhash0Finish discards it): a capacity that is too small, or arrays that are missing,
+    // must not cost the caller the job's result.
+    const uint64_t iterationsOfJob = lowhash0JobIterations(c->impl);
+    if(iterationsOfJob > iterationCapacity) throw std::runtime_error("lh_finish: iteration capacity too small (the job has " + std::to_string(iterationsOfJob) + " iterations; nothing was discarded, call again with room)");
+    if(iterationsOfJob && (!highFrequencyPerIteration || !totalPerIteration)) throw std::runtime_error("lh_finish: null per-iteration array");
     std::vector<shasta_oriented_read_pair> v;
     std::vector<uint64_t> high, total;
     lowhash0Finish(c->impl, readLowHashStatistics, v, high, total);

@@ -153,6 +153,24 @@ private:
     std::atomic<size_t>* mark;
 };
 
+// A stream / an event that is destroyed on every path out of its scope.
+struct ScopedStream {
+    hipStream_t stream = nullptr;
+    ScopedStream() { HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+    ScopedStream(const ScopedStream&) = delete;
+    ScopedStream& operator=(const ScopedStream&) = delete;
+    ~ScopedStream() { if(stream) (void)hipStreamDestroy(stream); }
+    operator hipStream_t() const { return stream; }
+};
+struct ScopedEvent {
+    hipEvent_t event = nullptr;
+    ScopedEvent() { HIP_CHECK(hipEventCreate(&event)); }
+    ScopedEvent(const ScopedEvent&) = delete;
+    ScopedEvent& operator=(const ScopedEvent&) = delete;
+    ~ScopedEvent() { if(event) (void)hipEventDestroy(event); }
+    operator hipEvent_t() const { return event; }
+};
+
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
     EventTimer() { HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); }

@@ -1176,6 +1176,9 @@ void lowhash0Merge(Context& ctx, const uint64_t* keys, uint64_t n, bool evaluate
     }
 }
 
+// Iterations merged so far by the job in progress (what lowhash0Finish will report per iteration).
+uint64_t lowhash0JobIterations(Context& ctx) { return jobOf(ctx).iterations; }
+
 // Stage 4.  Candidates of this rank's readId0 range (sorted), statistics (this rank's partial sums, readCount x 3),
 // this rank's share of the per-iteration counters; ends the job.
 void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& hostCandidates,
@@ -1213,8 +1216,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
     const uint64_t readCount = ctx.readCount;
-    hipEvent_t evBegin, evEnd;
-    HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
+    const ScopedEvent evBegin, evEnd;
     HIP_CHECK(hipEventRecord(evBegin, stream));
 
     std::vector<uint64_t> highFrequencyPerIteration, totalPerIteration, histogramRows;
@@ -1320,7 +1322,6 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
         }
     } catch(...) {
         ctx.lowhashJob.reset();
-        (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
         throw;
     }
     HIP_CHECK(hipEventRecord(evEnd, stream));
@@ -1328,7 +1329,6 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
-    (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
 
     result.log2BucketCount = log2BucketCount;
     result.candidateCount = hostCandidates.size();

@@ -162,8 +162,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
         Rank& me = rankOf(rank);
         HIP_CHECK(hipSetDevice(ctx.device));
         hipStream_t stream = ctx.stream;
-        hipEvent_t evBegin, evEnd;
-        HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd));
+        const ScopedEvent evBegin, evEnd;                   // (destroyed on every path)
         HIP_CHECK(hipEventRecord(evBegin, stream));
         try {
             lowhash0Begin(ctx, p, rank, world, boundaries.data(), &me.log2BucketCount);
@@ -235,13 +234,11 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
             lowhash0Finish(ctx, me.statistics.data(), me.candidates, me.highPerIteration, me.totalPerIteration);
         } catch(...) {
             ctx.lowhashJob.reset();
-            (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
             throw;
         }
         HIP_CHECK(hipEventRecord(evEnd, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if(rank == 0) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd)); deviceSeconds = ms * 1e-3; }
-        (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd);
     });
 
     // Reductions and assembly, in rank order (each device's candidates are sorted and cover its readId0 range:
@@ -253,7 +250,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
     for(int k = 0; k < world; k++) {
         const Rank& r = rankOf(k);
         candidates.insert(candidates.end(), r.candidates.begin(), r.candidates.end());
-        for(uint64_t k = 0; k < 3 * readCount; k++) readLowHashStatistics[k] += r.statistics[k];
+        for(uint64_t q = 0; q < 3 * readCount; q++) readLowHashStatistics[q] += r.statistics[q];
         for(uint64_t t = 0; t < iterations; t++) { high[t] += r.highPerIteration[t]; total[t] += r.totalPerIteration[t]; }
     }
     const uint64_t bucketCount = 1ULL << rankOf(0).log2BucketCount;

@@ -123,8 +123,9 @@ void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, u
     if(count == 0) { std::fill(toc, toc + rows + 1, uint64_t(0)); return; }
     const int otherBits = bitsFor(std::max<uint64_t>(rows, 2));
     if(2 * otherBits > 64) throw std::runtime_error("pair_table: too many reads.");
-    hipStream_t stream;
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const ScopedStream scopedStream;                       // (destroyed on every path, a throwing HIP_CHECK included)
+    hipStream_t stream = scopedStream;
+
     DeviceBuffer<uint8_t> devicePairs;
     DeviceBuffer<uint64_t> keysA, keysB, deviceToc;
     DeviceBuffer<uint32_t> valuesA, valuesB, bad;
@@ -148,7 +149,7 @@ void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, u
     HIP_CHECK(hipMemcpyAsync(toc, deviceToc.data(), (rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(values, sortedValues, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipStreamDestroy(stream));
+
     if(hostBad) throw std::runtime_error("pair_table: a pair names a read beyond readCount.");
 }
 
@@ -159,8 +160,9 @@ void readGraphKeep(int device, const shasta_alignment_data* alignmentData, uint6
     if(count >= (1ULL << 31)) throw std::runtime_error("read_graph_keep: too many alignments.");
     if(count == 0) return;
     const uint64_t n = 2 * count;
-    hipStream_t stream;
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const ScopedStream scopedStream;                       // (destroyed on every path, a throwing HIP_CHECK included)
+    hipStream_t stream = scopedStream;
+
     DeviceBuffer<shasta_alignment_data> rows;
     DeviceBuffer<uint64_t> qualityA, qualityB;
     DeviceBuffer<uint32_t> reads, ids, entryA, entryB, readA, readB, bad;
@@ -191,7 +193,7 @@ void readGraphKeep(int device, const shasta_alignment_data* alignmentData, uint6
     HIP_CHECK(hipMemcpyAsync(&hostBad, bad.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(keep, deviceKeep.data(), count, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipStreamDestroy(stream));
+
     if(hostBad) throw std::runtime_error("read_graph_keep: an alignment names a read beyond readCount.");
 }
 

@@ -52,11 +52,28 @@ class HipBackend:
     def begin(self, params, rank, world, boundaries):
         return self.ctx.lh_begin(params, rank, world, boundaries)
 
+    class _DeviceArray:
+        """n elements at a device address, as torch reads them (__cuda_array_interface__): a VIEW of the library's buffer."""
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
     def _tensor_from(self, ptr, n, dtype):
-        t = torch.empty(int(n), dtype=dtype, device=self.device)
-        if n:
-            self.ctx.memcpy(t.data_ptr(), ptr, int(n) * t.element_size(), 2)
+        """The library's stage output as a tensor WITHOUT a copy: RCCL sends straight from the buffer the stage wrote (it stays
+        valid until the context's next stage call, and the exchange is over by then).  Where torch cannot wrap a raw device
+        address (a CPU-only build driving the emulated library), a copy as before."""
+        n = int(n)
+        if n == 0:
+            return torch.empty(0, dtype=dtype, device=self.device)
+        if self.device.type == "cuda" and not self._copies:
+            try:
+                return torch.as_tensor(self._DeviceArray(ptr, n, "<i4" if dtype == torch.int32 else "<i8"), device=self.device)
+            except Exception:                       # (remembered: every later call copies)
+                self._copies = True
+        t = torch.empty(n, dtype=dtype, device=self.device)
+        self.ctx.memcpy(t.data_ptr(), ptr, n * t.element_size(), 2)
         return t
+
+    _copies = False
 
     def hash(self, iteration):
         offsets, keys, vals = self.ctx.lh_hash(iteration)
@@ -99,13 +116,16 @@ def exchange(tensors, send_offsets, group=None):
     rc = torch.empty(world, dtype=torch.int64, device=comm)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
-    out = []
+    # The data collectives of all the tensors are in flight together (one wait at the end).
+    out, pending = [], []
     for t in tensors:
         src = t.to(comm).contiguous()
         dst = torch.empty(sum(recv_counts), dtype=t.dtype, device=comm)
-        dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=[int(x) for x in send_counts], group=group)
-        out.append(dst.to(home))
-    return out
+        pending.append(dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=[int(x) for x in send_counts], group=group, async_op=True))
+        out.append(dst)
+    for work in pending:
+        work.wait()
+    return [dst.to(home) for dst in out]
 
 
 def all_gather_padded(tensor, counts, group=None):

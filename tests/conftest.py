@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch before anything of this suite loads the product library (test modules do at import, during collection), as in
+    # bench.py: the torch wheel carries a HIP runtime of its own, and whichever libamdhip64 a process loads first is the one
+    # both use -- with ROCm's loaded first, torch.cuda finds no device (test_gpu_beyond_4g_markers.py generates its reads on the
+    # device with torch).  Nothing happens on a machine without a GPU.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -152,4 +152,26 @@ def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line
     assert line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0
+    # Rank 0 measured the same job through the in-process group as well (both drivers on one line), and the line says what a
+    # GPU must hold for this run and for BASELINE configs[3] / [4].
+    g = line["in_process_group"]
+    assert "error" not in g, g
+    assert g["candidates"] == line["config"]["candidates"] and g["alignments_stored"] == line["config"]["alignments_stored"] and g["value"] > 0
+    budget = line["hbm_budget_per_gpu"]
+    assert budget["this_run"]["fits_288_GB"] and budget["configs[4] human 50x, 8 GPUs"]["fits_288_GB"]
+    assert budget["configs[4] human 50x, 8 GPUs"]["bytes_per_gpu"]["kmer_ids_of_all_reads"] == 88_000_000_000
+
+
+def test_bench_script_in_process_group_mode_on_the_emulated_build(emu_lib):
+    """bench.py --group: ONE process, --gpus devices behind shasta_mi355x_group (here device 0 of the emulated build twice)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, HIPEMU_THREADS="4")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--group", "--gpus", "2", "--reads", "100", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "NOT A MEASUREMENT" in line["data"] and "in-process group" in line["metric"]
+    assert line["in_process_group"]["devices"] == [0, 0] and line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0
 

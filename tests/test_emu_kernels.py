@@ -107,6 +107,7 @@ def test_align3_reference_fixture(emu_lib, i):
     (21, dict()),
     (23, dict(downsamplingFactor=0.25, bandExtend=2, maxBand=30, minAlignedMarkerCount=20, suppressContainments=1)),
     (24, dict(downsamplingFactor=0.002, minAlignedMarkerCount=40)),
+    (25, dict(matchScore=3, mismatchScore=-2, gapScore=-3, minAlignedMarkerCount=40)),        # (scores of the caller's choice)
 ])
 def test_align3_against_oracle(emu_lib, oracle_lib, seed, kw):
     align3_checks.against_oracle(emu_lib, oracle_lib, seed, kw)

@@ -18,6 +18,10 @@ def test_align3_matches_reference_fixture(gpu_lib, name, i):
     (22, dict(downsamplingFactor=0.05, minAlignedMarkerCount=40)),
     (23, dict(downsamplingFactor=0.25, bandExtend=2, maxBand=30, minAlignedMarkerCount=20, suppressContainments=1)),
     (24, dict(downsamplingFactor=0.002, minAlignedMarkerCount=40)),
+    # Scores other than 6 / -1 / -1 (the reference hands whatever its options hold to SeqAn, src/AssemblerAlign3.cpp:22-33, 120, 257).
+    (25, dict(matchScore=3, mismatchScore=-2, gapScore=-3, minAlignedMarkerCount=40)),
+    (26, dict(matchScore=10, mismatchScore=-4, gapScore=-1, downsamplingFactor=0.2, minAlignedMarkerCount=40)),
+    (27, dict(matchScore=1, mismatchScore=0, gapScore=-2, downsamplingFactor=0.05, minAlignedMarkerCount=20)),
 ])
 def test_align3_matches_oracle(gpu_lib, oracle_lib, seed, kw):
     align3_checks.against_oracle(gpu_lib, oracle_lib, seed, kw, n_reads=250, genome_markers=15000, limit=1500)
