@@ -266,21 +266,29 @@ def group_bench(lib, devices, toc, kmer, p, o, args, align_method):
     with lib.group(devices) as g:
         g.set_kmer_ids(toc, kmer)
 
+        stage = [0.0, 0.0]
+
         def step():
+            t = time.perf_counter()
             lh = g.lowhash0(p)
-            al = (g.align4 if align_method == 4 else g.align3)(lh.candidates, o, want_ordinals=False)
+            stage[0] += time.perf_counter() - t
+            t = time.perf_counter()
+            al = (g.align4 if align_method == 4 else g.align3)(lh.candidates, o, want_ordinals=False, borrow=True)
+            stage[1] += time.perf_counter() - t
             return len(lh.candidates), len(al.alignment_data)
 
         for _ in range(args.warmup):
             step()
+        stage[0] = stage[1] = 0.0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             pairs, stored = step()
         elapsed = time.perf_counter() - t0
     steps = max(1, args.steps)
     return {"devices": [int(d) for d in devices], "value": pairs / (elapsed / steps), "unit": "pairs/s", "ms_per_step": elapsed / steps * 1e3,
+            "lowhash0_ms_per_step": stage[0] / steps * 1e3, "align_ms_per_step": stage[1] / steps * 1e3,
             "candidates": int(pairs), "alignments_stored": int(stored),
-            "what": "shasta_mi355x_group_lowhash0_run + _group_align%d_run in one process over these devices (host-resident result assembly included)" % align_method}
+            "what": "shasta_mi355x_group_lowhash0_run + _group_align%d_run_borrowed in one process over these devices (result assembly on the host included)" % align_method}
 
 
 def markers_bench(lib, ctx, args):

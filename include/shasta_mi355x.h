@@ -476,6 +476,14 @@ int shasta_mi355x_group_align4_run(shasta_mi355x_group*, uint64_t candidateCount
     const shasta_oriented_read_pair* candidates, const shasta_align4_options*, int wantOrdinals, shasta_align4_result*);
 int shasta_mi355x_group_align3_run(shasta_mi355x_group*, uint64_t candidateCount,
     const shasta_oriented_read_pair* candidates, const shasta_align3_options*, int wantOrdinals, shasta_align4_result*);
+/* The same with the result arrays owned by the group (result->owner != NULL: shasta_mi355x_align4_free only clears the struct):
+ * valid until the group's next aligner call or its destruction.  A caller that copies the result into its own containers at
+ * once -- Shasta's Assembler::computeAlignments appends to memory-mapped vectors, src/AssemblerAlign.cpp:262-283 -- saves the
+ * allocation and first touch of half a gigabyte per call (a third of the call at 100 k reads). */
+int shasta_mi355x_group_align4_run_borrowed(shasta_mi355x_group*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align4_options*, int wantOrdinals, shasta_align4_result*);
+int shasta_mi355x_group_align3_run_borrowed(shasta_mi355x_group*, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align3_options*, int wantOrdinals, shasta_align4_result*);
 int shasta_mi355x_lowhash0_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
     const uint8_t* readFlags, const shasta_lowhash0_params*, int deviceCount, const int* devices,
     uint64_t* readLowHashStatistics, shasta_lowhash0_result*);

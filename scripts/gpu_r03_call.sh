@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider -x 2>&1 | tail -3
-timeout 600 python bench.py --group --gpus 1 --steps 3 --warmup 1 > gpurun_out/bench_group1.json 2> gpurun_out/bench_group1.err; echo "group rc=$?"; python -c "
-import json;d=json.loads(open('gpurun_out/bench_group1.json').read().strip().splitlines()[-1]);print(d['value'],d['ms_per_step'],d['hbm_budget_per_gpu']['total_GB_per_gpu'])"
+STEPS=4 WARMUP=2 PATTERN="Cells" bash scripts/gpu_ab.sh "cur||" 2>&1 | grep "==\|ms/step\|kernel s/step\|Cells"
+export SHASTA_BENCH_WORKLOAD_CACHE=/tmp/shasta_workload
+SHASTA_MI355X_DEBUG=1 SHASTA_MI355X_ALIGN_WORKERS=1 timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 >/dev/null | grep "cells:" | head -8

@@ -160,11 +160,16 @@ std::shared_ptr<BatchScratch> makeWorkerScratch(SharedCapacities& shared)
 // overlap the narrow classes instead of occupying the GPU alone.
 struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; hipStream_t wide; };
 
-constexpr int CELLS_CLASSES = 3;
+constexpr int CELLS_CLASSES = 4;
 #ifndef SHASTA_CELLS_NA0
 #define SHASTA_CELLS_NA0 11
 #endif
-constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13};     // tabled read below 2048 / 4096 / 8192 markers
+// Tabled read below 2048 / 4096 / 8192 / 8192 markers.  The fourth class (round 3) is for the pairs of two long reads, whose
+// random matches touch more distinct cells than the third one's table holds (nx ny / 8192 of them at k = 10): 64 KB of cell
+// region -- a byte grid up to nx + ny = 11 000, a packed table of 16 384 slots beyond -- and 256 kept cells, one workgroup per
+// CU.  Until then those pairs (250 - 450 of a batch's 262 144 at 100 k reads) went to the kernel with its tables in HBM scratch:
+// 1.6 ms per batch of 1024-thread workgroups that waited 95 % of their cycles (profiles/r02_pmc_100k_reads.json).
+constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13};
 // Timing experiments compile other geometries (make EXTRA=-DSHASTA_CELLS_SC0=9 ...): the LDS a workgroup takes
 // decides how many wavefronts a CU holds, and the cells kernels are bound by latency, not by instruction issue.
 #ifndef SHASTA_CELLS_SC0
@@ -179,7 +184,7 @@ constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13};     // 
 #ifndef SHASTA_CELLS_ESTIMATE_SHIFT
 #define SHASTA_CELLS_ESTIMATE_SHIFT 13
 #endif
-constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2};
+constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2, 14};
 // Kept cells per candidate: 64 Q (more: the candidate climbs a class, finally to the HBM-scratch kernel).  Q = 2 everywhere:
 // the kernel then needs 115 vector registers (4 wavefronts per SIMD) instead of 224 (2).
 #ifndef SHASTA_CELLS_Q1
@@ -191,8 +196,8 @@ constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1
 #ifndef SHASTA_CELLS_CHUNK_MAX
 #define SHASTA_CELLS_CHUNK_MAX 24
 #endif
-constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2};
-constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16};
+constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2, 4};
+constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16, 8};
 constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call
 #include "align4_prepare.hpp"    // the class of a candidate; a batch's first chunk lists made on the device
 
@@ -475,38 +480,46 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
     }
     if(std::getenv("SHASTA_MI355X_DEBUG")) std::fprintf(stderr, "ties: %zu + %zu candidates to look at again\n", members.size(), big.size());
     if(members.empty() && big.empty()) return;
-    constexpr uint32_t MAXC = 64 * 2;
-    static_assert(CELLS_Q[0] == 2 && CELLS_Q[1] == 2 && CELLS_Q[2] == 2, "the dump launches use the Q = 2 instance");
     std::unordered_map<uint32_t, std::vector<uint32_t>> activeOf;              // candidate -> its active cells
     if(!members.empty()) {
         const uint32_t total = uint32_t(members.size());
-        b.tieMembers.reserve(total, stream); b.tieChunks.reserve(total, stream); b.tieKeys.reserve(size_t(total) * MAXC, stream); b.tieCounts.reserve(total, stream);
+        // A dump slot holds up to 64 Q keys, Q of the class's kernel instance.
+        size_t keyWords = 0;
+        for(int c = 0; c < CELLS_CLASSES; c++) keyWords += chunks[c].size() * size_t(64 * CELLS_Q[c]);
+        b.tieMembers.reserve(total, stream); b.tieChunks.reserve(total, stream); b.tieKeys.reserve(keyWords, stream); b.tieCounts.reserve(total, stream);
         HIP_CHECK(hipMemcpyAsync(b.tieMembers.data(), members.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemsetAsync(b.tieCounts.data(), 0xff, total * sizeof(uint32_t), stream));
         uint32_t offset = 0;
+        size_t wordOffset = 0;
         std::vector<uint32_t> order;                                         // candidate of dump slot s
+        std::vector<size_t> slotWords;                                       // where slot s's keys start
+        std::vector<uint32_t> slotCapacity;
         for(int c = 0; c < CELLS_CLASSES; c++) {
             if(chunks[c].empty()) continue;
             const uint32_t count = uint32_t(chunks[c].size());
+            const uint32_t maxc = uint32_t(64 * CELLS_Q[c]);
             HIP_CHECK(hipMemcpyAsync(b.tieChunks.data() + offset, chunks[c].data(), count * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
-            const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[c], CELLS_SC_LOG2[c], 2, CELLS_WAVES) * sizeof(uint32_t);
+            const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[c], CELLS_SC_LOG2[c], CELLS_Q[c], CELLS_WAVES) * sizeof(uint32_t);
             std::call_once(ctx.cellsDumpLdsAttribute, [] {
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             });
-            hipLaunchKernelGGL((align4CellsChunkKernel<2, true>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, stream,
+            const auto kernel = CELLS_Q[c] == 2 ? &align4CellsChunkKernel<2, true> : &align4CellsChunkKernel<4, true>;
+            hipLaunchKernelGGL(kernel, dim3(count), dim3(WAVE * CELLS_WAVES), bytes, stream,
                 (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const CellsChunk*)(b.tieChunks.data() + offset), count, (const uint32_t*)b.tieMembers.data(),
-                opt, magicX, magicY, (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr, b.tieKeys.data() + size_t(offset) * MAXC, b.tieCounts.data() + offset);
+                opt, magicX, magicY, (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr, b.tieKeys.data() + wordOffset, b.tieCounts.data() + offset);
             HIP_CHECK(hipGetLastError());
             order.insert(order.end(), chunkPair[c].begin(), chunkPair[c].end());
-            offset += count;
+            for(uint32_t q = 0; q < count; q++) { slotWords.push_back(wordOffset + size_t(q) * maxc); slotCapacity.push_back(maxc); }
+            offset += count; wordOffset += size_t(count) * maxc;
         }
-        std::vector<uint32_t> keys(size_t(total) * MAXC), counts(total);
+        std::vector<uint32_t> keys(keyWords), counts(total);
         HIP_CHECK(hipMemcpyAsync(keys.data(), b.tieKeys.data(), keys.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(counts.data(), b.tieCounts.data(), total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         for(uint32_t slot = 0; slot < total; slot++) {
-            if(counts[slot] == 0xffffffffu || counts[slot] == 0 || counts[slot] > MAXC) continue;
-            activeOf[order[slot]].assign(keys.begin() + size_t(slot) * MAXC, keys.begin() + size_t(slot) * MAXC + counts[slot]);
+            if(counts[slot] == 0xffffffffu || counts[slot] == 0 || counts[slot] > slotCapacity[slot]) continue;
+            activeOf[order[slot]].assign(keys.begin() + slotWords[slot], keys.begin() + slotWords[slot] + counts[slot]);
         }
     }
     // The candidates of the HBM-scratch kernel, a few at a time (their key lists may be long).
@@ -982,7 +995,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 hipLaunchKernelGGL(cellsClassKeysKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
                     (const PairDesc*)b.pairs.data(), n, classRule, tabledBits, b.prepareKeysA.data(), b.prepareIdsA.data(), b.prepareInfo.data());
                 const bool inB = radixSort<uint64_t, uint32_t, true>(b.prepareKeysA.data(), b.prepareKeysB.data(), b.prepareIdsA.data(), b.prepareIdsB.data(),
-                    n, tabledBits + 3, *ws.sortWs, stream);
+                    n, tabledBits + 1 + CELLS_CLASS_BITS, *ws.sortWs, stream);
                 const uint64_t* sortedKeys = inB ? b.prepareKeysB.data() : b.prepareKeysA.data();
                 const uint32_t* sortedIds = inB ? b.prepareIdsB.data() : b.prepareIdsA.data();
                 hipLaunchKernelGGL(cellsChunkHeadsKernel, dim3(divUp(uint64_t(n) + 1, 256)), dim3(256), 0, stream, sortedKeys, n, tabledBits, b.storedFlags.data());
@@ -998,7 +1011,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     const uint32_t count = uint32_t(info[c + 1] - info[c]);
                     if(count == 0) continue;
                     firstRoundAny = true;
-                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[8 + c], info[5 + c]);
+                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[CELLS_INFO_BYTES + c], info[CELLS_INFO_CANDIDATES + c]);
                 }
                 firstRoundLaunched = true;
                 members.assign(n, 0);                       // (positions 0 .. n-1 of the device's list: later rounds append after them)
@@ -1008,9 +1021,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     pairClass[q] = c;
                     if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); }
                 }
-                MI355X_ASSERT(uint64_t(n) - info[4] == bigList.size());
+                MI355X_ASSERT(uint64_t(n) - info[CELLS_INFO_FIRST_BIG] == bigList.size());
                 static const bool debugPrepare = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
-                if(debugPrepare) std::fprintf(stderr, "cells: lists made on the device: %llu + %llu + %llu chunks, %llu + %llu + %llu candidates\n", info[1] - info[0], info[2] - info[1], info[3] - info[2], info[5], info[6], info[7]);
+                if(debugPrepare) for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: lists made on the device: class %d: %llu chunks, %llu candidates\n", c, info[c + 1] - info[c], info[CELLS_INFO_CANDIDATES + c]);
             } else
             // Every candidate tables whichever of its two reads lands in the smaller class (ties: read
             // 0) and is grouped with the other candidates that table the same oriented read.

@@ -6,10 +6,11 @@
 #pragma once
 
 // (constexpr arrays cannot be indexed by a run-time value in device code; these can)
-__host__ __device__ inline int cellsNaLog2(int c) { return c == 0 ? CELLS_NA_LOG2[0] : (c == 1 ? CELLS_NA_LOG2[1] : CELLS_NA_LOG2[2]); }
-__host__ __device__ inline int cellsScLog2(int c) { return c == 0 ? CELLS_SC_LOG2[0] : (c == 1 ? CELLS_SC_LOG2[1] : CELLS_SC_LOG2[2]); }
-__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : CELLS_CHUNK_MAX[2]); }
-static_assert(CELLS_CLASSES == 3, "cellsNaLog2 / cellsScLog2 / cellsChunkMax name three classes");
+__host__ __device__ inline int cellsNaLog2(int c) { return c == 0 ? CELLS_NA_LOG2[0] : (c == 1 ? CELLS_NA_LOG2[1] : (c == 2 ? CELLS_NA_LOG2[2] : CELLS_NA_LOG2[3])); }
+__host__ __device__ inline int cellsScLog2(int c) { return c == 0 ? CELLS_SC_LOG2[0] : (c == 1 ? CELLS_SC_LOG2[1] : (c == 2 ? CELLS_SC_LOG2[2] : CELLS_SC_LOG2[3])); }
+__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : (c == 2 ? CELLS_CHUNK_MAX[2] : CELLS_CHUNK_MAX[3])); }
+static_assert(CELLS_CLASSES == 4, "cellsNaLog2 / cellsScLog2 / cellsChunkMax name four classes");
+constexpr int CELLS_CLASS_BITS = 3;                         // the class (0 .. CELLS_CLASSES, the last = HBM scratch) in the sort key
 
 struct CellsClassRule { uint64_t deltaX, deltaY; bool packedOk; };
 inline CellsClassRule cellsClassRule(const DeviceOptions& opt)
@@ -52,9 +53,11 @@ __host__ __device__ inline CellsChoice cellsChoice(const CellsClassRule& rule, u
 // Sort key of a candidate: class | swapped | first marker of the tabled oriented read (tabledBits bits).  A STABLE sort leaves
 // the candidates of a (class, swapped, tabled read) group adjacent and in ascending order -- the groups the host walk made,
 // class by class -- and the candidates of the HBM-scratch kernel (class CELLS_CLASSES) at the end.
-// info: [0..3] = first chunk of class 0, 1, 2 and the number of chunks; [4] = position of the first HBM-scratch candidate
-//       in the sorted list; [5 + c] = candidates of class c; [8 + c] = their algorithmic bytes, 4 (nx + ny) each.
-constexpr int CELLS_PREPARE_INFO = 12;
+// info: [0 .. CELLS_CLASSES] = first chunk of every class and the number of chunks; [CELLS_INFO_FIRST_BIG] = position of the first
+//       HBM-scratch candidate in the sorted list; [CELLS_INFO_CANDIDATES + c] = candidates of class c; [CELLS_INFO_BYTES + c] =
+//       their algorithmic bytes, 4 (nx + ny) each.
+constexpr int CELLS_INFO_FIRST_BIG = CELLS_CLASSES + 1, CELLS_INFO_CANDIDATES = CELLS_CLASSES + 2, CELLS_INFO_BYTES = 2 * CELLS_CLASSES + 2;
+constexpr int CELLS_PREPARE_INFO = 3 * CELLS_CLASSES + 2;
 
 __global__ void __launch_bounds__(256)
 cellsClassKeysKernel(const PairDesc* __restrict__ pairs, uint32_t n, CellsClassRule rule, int tabledBits,
@@ -79,8 +82,8 @@ cellsClassKeysKernel(const PairDesc* __restrict__ pairs, uint32_t n, CellsClassR
         unsigned long long classBytes = cls == c ? bytes : 0;
         for(int d = 32; d >= 1; d >>= 1) classBytes += __shfl_down(classBytes, d, WAVE);
         if(laneId() == 0) {
-            atomicAdd(&info[5 + c], (unsigned long long)__popcll(votes));
-            atomicAdd(&info[8 + c], classBytes);
+            atomicAdd(&info[CELLS_INFO_CANDIDATES + c], (unsigned long long)__popcll(votes));
+            atomicAdd(&info[CELLS_INFO_BYTES + c], classBytes);
         }
     }
 }
@@ -129,6 +132,6 @@ cellsChunkWriteKernel(const uint64_t* __restrict__ sortedKeys, const uint32_t* _
     if(i <= uint32_t(CELLS_CLASSES)) {
         const uint32_t first = cellsLowerBound(sortedKeys, n, uint64_t(i) << (tabledBits + 1));      // first candidate of class i
         info[i] = ranks[first];
-        if(i == uint32_t(CELLS_CLASSES)) info[4] = first;
+        if(i == uint32_t(CELLS_CLASSES)) info[CELLS_INFO_FIRST_BIG] = first;
     }
 }

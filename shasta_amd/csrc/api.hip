@@ -429,6 +429,26 @@ int shasta_mi355x_group_align3_run(shasta_mi355x_group* g, uint64_t candidateCou
     API_END(1)
 }
 
+int shasta_mi355x_group_align4_run_borrowed(shasta_mi355x_group* g, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align4_options* options, int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!g || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("group_align4_run_borrowed: null argument");
+    g->impl.alignRun(candidateCount, candidates, options, nullptr, wantOrdinals != 0, *result, true);
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_group_align3_run_borrowed(shasta_mi355x_group* g, uint64_t candidateCount,
+    const shasta_oriented_read_pair* candidates, const shasta_align3_options* options, int wantOrdinals, shasta_align4_result* result)
+{
+    API_BEGIN
+    if(!g || (!candidates && candidateCount) || !options || !result) throw std::runtime_error("group_align3_run_borrowed: null argument");
+    g->impl.alignRun(candidateCount, candidates, nullptr, options, wantOrdinals != 0, *result, true);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_lowhash0_multi(uint64_t readCount, const uint64_t* markersToc, const void* markersData,
     const uint8_t* readFlags, const shasta_lowhash0_params* params, int deviceCount, const int* devices,
     uint64_t* readLowHashStatistics, shasta_lowhash0_result* result)

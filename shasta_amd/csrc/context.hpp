@@ -59,8 +59,14 @@ struct Group {
     Group(int deviceCount, const int* devices);          // devices == nullptr: 0 .. deviceCount - 1; a device may be listed more than once
     void setMarkers(uint64_t readCount, const uint64_t* toc, const void* data7, const uint32_t* denseKmerIds, const uint8_t* flags);
     void lowhash0Run(const shasta_lowhash0_params&, uint64_t* readLowHashStatistics, shasta_lowhash0_result&);
+    // borrowed: the result's arrays belong to the group (result.owner = the group) and are reused by its next aligner call.
     void alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
-        const shasta_align4_options* options4, const shasta_align3_options* options3, bool wantOrdinals, shasta_align4_result&);
+        const shasta_align4_options* options4, const shasta_align3_options* options3, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
+    // The concatenated result of a borrowed call over several devices.
+    std::vector<shasta_alignment_data> storeRows;
+    std::vector<uint64_t> storeToc, storeOrdinalsToc;
+    std::vector<uint8_t> storeBytes, storeStatus;
+    std::vector<uint32_t> storeOrdinals;
 };
 
 // One timed launch (or group of launches that form one step): events on `stream` around the statement(s).

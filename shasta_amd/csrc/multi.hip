@@ -284,14 +284,16 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
 
 // computeAlignments (method 4 or 3) over the group: contiguous candidate ranges balanced by the markers they touch.
 void Group::alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
-    const shasta_align4_options* options4, const shasta_align3_options* options3, bool wantOrdinals, shasta_align4_result& result)
+    const shasta_align4_options* options4, const shasta_align3_options* options3, bool wantOrdinals, shasta_align4_result& result, bool borrowed)
 {
     std::memset(&result, 0, sizeof(result));
     const auto t0 = std::chrono::steady_clock::now();
     const int world = int(contexts.size());
+    // (borrowed: every device's share stays in its context's arrays; with several devices the shares are concatenated into the
+    // group's own, which keep their size from call to call)
     auto runOn = [&](Context& ctx, uint64_t begin, uint64_t end, shasta_align4_result& r) {
-        if(options4) align4Run(ctx, end - begin, candidates + begin, *options4, wantOrdinals, r);
-        else align3Run(ctx, end - begin, candidates + begin, *options3, wantOrdinals, r);
+        if(options4) align4Run(ctx, end - begin, candidates + begin, *options4, wantOrdinals, r, borrowed);
+        else align3Run(ctx, end - begin, candidates + begin, *options3, wantOrdinals, r, borrowed);
     };
     if(world == 1) { runOn(*contexts[0], 0, candidateCount, result); return; }
     const uint64_t readCount = contexts[0]->readCount;
@@ -334,6 +336,15 @@ void Group::alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* c
         if(wantOrdinals && q.ordinalsToc) ordinals += q.ordinalsToc[cut[size_t(r) + 1] - cut[size_t(r)]];
     }
     auto allocate = [](size_t n) { void* p = std::malloc(std::max<size_t>(1, n)); if(!p) throw std::bad_alloc(); return p; };
+    if(borrowed) {
+        auto room = [](auto& v, size_t n) { if(v.size() < std::max<size_t>(1, n)) v.resize(std::max<size_t>(1, n) + n / 8); return v.data(); };
+        result.alignmentData = room(storeRows, rows);
+        result.compressedToc = room(storeToc, rows + 1);
+        result.compressedData = room(storeBytes, bytes);
+        result.status = room(storeStatus, candidateCount);
+        if(wantOrdinals) { result.ordinalsToc = room(storeOrdinalsToc, candidateCount + 1); result.ordinals = room(storeOrdinals, 2 * ordinals); result.ordinalsToc[0] = 0; }
+        result.owner = this;
+    } else {
     result.alignmentData = static_cast<shasta_alignment_data*>(allocate(rows * sizeof(shasta_alignment_data)));
     result.compressedToc = static_cast<uint64_t*>(allocate((rows + 1) * sizeof(uint64_t)));
     result.compressedData = static_cast<uint8_t*>(allocate(bytes));
@@ -342,6 +353,7 @@ void Group::alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* c
         result.ordinalsToc = static_cast<uint64_t*>(allocate((candidateCount + 1) * sizeof(uint64_t)));
         result.ordinals = static_cast<uint32_t*>(allocate(2 * ordinals * sizeof(uint32_t)));
         result.ordinalsToc[0] = 0;
+    }
     }
     result.compressedToc[0] = 0;
     uint64_t rowBase = 0, byteBase = 0, ordBase = 0;

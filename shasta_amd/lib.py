@@ -32,6 +32,7 @@ EXPORTS = [
     "shasta_mi355x_palindromic_screen",
     "shasta_mi355x_group_create", "shasta_mi355x_group_destroy", "shasta_mi355x_group_set_markers", "shasta_mi355x_group_set_kmer_ids",
     "shasta_mi355x_group_lowhash0_run", "shasta_mi355x_group_align4_run", "shasta_mi355x_group_align3_run",
+    "shasta_mi355x_group_align4_run_borrowed", "shasta_mi355x_group_align3_run_borrowed",
     "shasta_mi355x_lowhash0_multi", "shasta_mi355x_align4_batch_multi", "shasta_mi355x_align3_batch_multi",
 ]
 
@@ -296,18 +297,21 @@ class Group:
         self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
         return out
 
-    def align4(self, candidates, options, want_ordinals=False):
+    def align4(self, candidates, options, want_ordinals=False, borrow=False):
+        """borrow=True: the arrays of the result are views of memory owned by this group, valid until its next aligner call."""
         candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
         res = abi.Align4Result()
-        self.library._check(self.lib.shasta_mi355x_group_align4_run(
+        fn = self.lib.shasta_mi355x_group_align4_run_borrowed if borrow else self.lib.shasta_mi355x_group_align4_run
+        self.library._check(fn(
             C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_group_align4_run")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
 
-    def align3(self, candidates, options, want_ordinals=False):
+    def align3(self, candidates, options, want_ordinals=False, borrow=False):
         candidates = np.ascontiguousarray(candidates, dtype=abi.PAIR_DTYPE)
         res = abi.Align4Result()
-        self.library._check(self.lib.shasta_mi355x_group_align3_run(
+        fn = self.lib.shasta_mi355x_group_align3_run_borrowed if borrow else self.lib.shasta_mi355x_group_align3_run
+        self.library._check(fn(
             C.c_void_p(self.handle), C.c_uint64(len(candidates)), C.c_void_p(candidates.ctypes.data),
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.byref(res)), "shasta_mi355x_group_align3_run")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)

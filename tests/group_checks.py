@@ -43,6 +43,14 @@ def lowhash0_and_aligners(lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_r
         b = g.align4(cand, o4, want_ordinals=True)
         if not (x4.status & 0x80).any():
             support.same_align(x4, b)
+        # Results owned by the group (valid until its next aligner call): the same arrays, twice over the same buffers.
+        for _ in range(2):
+            c = g.align4(cand, o4, want_ordinals=True, borrow=True)
+            support.same_align(b, c)
+            del c
+        d = g.align3(cand, o3, want_ordinals=True, borrow=True)
+        support.same_align(x3, d)
+        del d
     # Fewer candidates than devices, and none at all.
     few = lib.align4_batch_multi(toc, data7, cand[:2], o4, (0, 0, 0), want_ordinals=True)
     assert np.array_equal(few.status, x4.status[:2])
