@@ -55,7 +55,7 @@ struct DpResult {
     uint32_t maxSkip, maxDrift;
     uint32_t passes;               // inner filters of src/Align4.cpp:944-981
     int32_t score;
-    uint32_t pad;
+    uint32_t compressedBytes;      // of this alignment in shasta::compress form (dpMetricsKernel)
 };
 
 struct DeviceOptions {
@@ -1244,18 +1244,14 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             (const PairDesc*)b.pairs.data(), (const shasta_oriented_read_pair*)b.candidates.data(), n,
             (const DpResult*)b.results.data(), (const unsigned long long*)b.pairBest.data(),
             (const uint32_t*)b.pairWinner.data(), (const uint8_t*)b.pairTie.data(), (const uint8_t*)b.pairFlags.data(),
-            opt, wantOrdinals ? 1 : 0, b.status.data(), b.rows.data(), b.storedFlags.data(), b.ordCounts.data());
+            opt, wantOrdinals ? 1 : 0, b.status.data(), b.rows.data(), b.storedFlags.data(), b.ordCounts.data(), b.sizes.data());
         exclusiveScan<uint32_t>(b.storedFlags.data(), b.storedIndex.data(), uint64_t(n) + 1, b.scanTemp32.data(), stream);
         b.scanTemp64.reserve(scanTempElements(uint64_t(n) + 1), stream);
         exclusiveScan<uint64_t>(b.ordCounts.data(), b.ordCounts.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
+        // (the sizes of the compressed alignments were counted by dpMetricsKernel in its pass over the pairs)
+        exclusiveScan<uint64_t>(b.sizes.data(), b.sizes.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
         (void)ctx.timers.end(finalizeSpan, 64ULL * n, n);
         const unsigned gw = divUp((uint64_t(n) + 1) * WAVE, 256);
-        const KernelTimers::Span sizeSpan = ctx.timers.begin("compressSizeKernel + scan", stream);
-        hipLaunchKernelGGL(compressSizeKernel, dim3(gw), dim3(256), 0, stream,
-            (const uint32_t*)b.storedFlags.data(), (const DpResult*)b.results.data(), (const uint32_t*)b.pairWinner.data(),
-            (const uint32_t*)b.ordScratch.data(), n, b.sizes.data());
-        exclusiveScan<uint64_t>(b.sizes.data(), b.sizes.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
-        const size_t sizeHandle = ctx.timers.end(sizeSpan, 0, n);
         HIP_CHECK(hipGetLastError());
         const uint32_t storedCount = readDevice(b.storedIndex.data() + n, stream);
         const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
@@ -1311,7 +1307,6 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         for(uint32_t k = 0; k < storedCount; k++) out.tocEnds[k] = (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal);
         for(uint32_t k = 0; k < storedCount; k++) out.alignedBytes += 8ULL * out.rows[k].info.markerCount;
         // Both compress kernels read the 8-byte ordinal pairs of the stored alignments; the second writes the blobs and the 64-byte rows.
-        ctx.timers.amend(sizeHandle, out.alignedBytes, n);
         ctx.timers.amend(writeHandle, out.alignedBytes + byteTotal + 64ULL * storedCount, storedCount);
         if(debugPhases) {
             phaseFinish = phaseMs(phaseStart) - phaseCells - phaseDp;

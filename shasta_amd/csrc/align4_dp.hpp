@@ -540,7 +540,7 @@ __device__ __forceinline__ void tracebackFinish(uint32_t pos, const PairDesc& pd
     r.sumOffset = 0;
     r.markerCount = min(pd.nx, pd.ny) - pos;
     r.first0 = r.first1 = r.last0 = r.last1 = 0; r.minOffset = r.maxOffset = 0; r.maxSkip = r.maxDrift = 0;
-    r.passes = 0; r.score = e.score; r.pad = 0;
+    r.passes = 0; r.score = e.score; r.compressedBytes = 0;
     results[t] = r;
 }
 
@@ -621,60 +621,4 @@ dpTracebackKernel(
     }
     storeFound();
     tracebackFinish(pos, pd, e, ordBase, t, results);
-}
-
-// AlignmentInfo's metrics of every task from its stored pairs (src/Alignment.cpp:67-113, :4-31), the inner acceptance
-// (src/Align4.cpp:944-981) and the candidate's best component (:132-139).  One wavefront per task: the pairs of a task
-// are contiguous and ascending, 8 bytes per lane per round.
-__global__ void __launch_bounds__(256)
-dpMetricsKernel(
-    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
-    const uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
-{
-    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if(t >= taskCount) return;
-    const int lane = laneId();
-    DpResult r = results[t];
-    const uint32_t count = r.markerCount;
-    const uint2* __restrict__ p = reinterpret_cast<const uint2*>(ordScratch + 2 * r.ordBegin);
-    int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
-    long long sumOffset = 0;
-    uint32_t maxSkip = 0, maxDrift = 0;
-    for(uint32_t k = uint32_t(lane); k < count; k += WAVE) {
-        const uint2 a = p[k];
-        const int32_t offset = int32_t(a.x) - int32_t(a.y);
-        minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset);
-        sumOffset += offset;
-        if(k + 1 < count) {
-            const uint2 n = p[k + 1];
-            maxSkip = max(maxSkip, max(n.x - a.x, n.y - a.y));
-            const int32_t drift = (int32_t(n.x) - int32_t(n.y)) - offset;
-            maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
-        }
-    }
-#pragma unroll
-    for(int d = 32; d >= 1; d >>= 1) {
-        minOffset = min(minOffset, __shfl_xor(minOffset, d, WAVE)); maxOffset = max(maxOffset, __shfl_xor(maxOffset, d, WAVE));
-        sumOffset += __shfl_xor(sumOffset, d, WAVE);
-        maxSkip = max(maxSkip, uint32_t(__shfl_xor(int(maxSkip), d, WAVE))); maxDrift = max(maxDrift, uint32_t(__shfl_xor(int(maxDrift), d, WAVE)));
-    }
-    if(lane != 0) return;
-    const PairDesc pd = pairs[tasks[t].pair];
-    if(count) { const uint2 f = p[0], l = p[count - 1]; r.first0 = f.x; r.first1 = f.y; r.last0 = l.x; r.last1 = l.y; }
-    r.minOffset = minOffset; r.maxOffset = maxOffset; r.sumOffset = sumOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
-    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
-    if(pass) {
-        const double f0 = double(count) / double(r.last0 + 1 - r.first0);
-        const double f1 = double(count) / double(r.last1 + 1 - r.first1);
-        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
-        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
-        const uint32_t leftTrim = min(r.first0, r.first1);
-        const uint32_t rightTrim = min(pd.nx - 1 - r.last0, pd.ny - 1 - r.last1);
-        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
-    }
-    r.passes = pass ? 1u : 0u;
-    results[t] = r;
-    // Best component = most aligned markers (:132-139); ties resolved towards the
-    // component whose first cell in (iY,iX) order comes first, and flagged later.
-    if(pass) atomicMax(&pairBest[tasks[t].pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - tasks[t].label));
 }

@@ -26,14 +26,14 @@ finalizeKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_read_pa
     const uint32_t* __restrict__ pairWinner, const uint8_t* __restrict__ pairTie, const uint8_t* __restrict__ pairFlags,
     DeviceOptions opt, int wantOrdinals,
     uint8_t* __restrict__ status, shasta_alignment_data* __restrict__ rows,
-    uint32_t* __restrict__ storedFlags, uint64_t* __restrict__ ordCounts)
+    uint32_t* __restrict__ storedFlags, uint64_t* __restrict__ ordCounts, uint64_t* __restrict__ compressedSizes)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if(p == pairCount) { storedFlags[p] = 0; ordCounts[p] = 0; return; }
+    if(p == pairCount) { storedFlags[p] = 0; ordCounts[p] = 0; compressedSizes[p] = 0; return; }
     if(p > pairCount) return;
     uint8_t st;
     uint32_t stored = 0;
-    uint64_t ordCount = 0;
+    uint64_t ordCount = 0, compressedSize = 0;
     if(pairFlags[p]) {
         st = SHASTA_ALIGN_SKIPPED;
     } else if(pairBest[p] == 0) {
@@ -68,10 +68,12 @@ finalizeKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_read_pa
         if(pairTie[p]) st |= SHASTA_ALIGN_TIE_FLAG;
         stored = good ? 1u : 0u;
         ordCount = (wantOrdinals || good) ? r.markerCount : 0;
+        compressedSize = good ? r.compressedBytes : 0;               // (counted by dpMetricsKernel in its pass over the pairs)
     }
     status[p] = st;
     storedFlags[p] = stored;
     ordCounts[p] = ordCount;
+    compressedSizes[p] = compressedSize;
 }
 
 __global__ void __launch_bounds__(256)
@@ -125,8 +127,11 @@ __device__ __forceinline__ void writeStreakRecord(const StreakRecord& r, uint8_t
 // One wavefront per stored alignment: lanes flag the streak starts of 64 marker pairs at a time;
 // a start lane knows its skips at once and its length when the next start is seen (the last
 // start of a chunk is carried to the next chunk).  WRITE=false only counts the bytes.
-template<bool WRITE>
-__device__ __forceinline__ uint64_t compressAlignmentWave(const uint32_t* __restrict__ ord, uint32_t n, uint8_t* __restrict__ out)
+// METRICS: the same pass also takes what AlignmentInfo needs from the pairs (src/Alignment.cpp:67-113, :4-31) -- offsets
+// x - y and, between consecutive pairs, skips and drifts -- as per-lane partial results (the caller reduces them).
+struct PairMetrics { int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000); long long sumOffset = 0; uint32_t maxSkip = 0, maxDrift = 0; };
+template<bool WRITE, bool METRICS = false>
+__device__ __forceinline__ uint64_t compressAlignmentWave(const uint32_t* __restrict__ ord, uint32_t n, uint8_t* __restrict__ out, PairMetrics* metrics = nullptr)
 {
     const int lane = laneId();
     uint64_t bytes = 0;                       // wave-uniform
@@ -143,6 +148,18 @@ __device__ __forceinline__ uint64_t compressAlignmentWave(const uint32_t* __rest
         const bool start = valid && (i == 0 || xy.x != px + 1 || xy.y != py + 1);
         const uint64_t starts = __ballot(start);
         const int32_t skip0 = int32_t(xy.x) - int32_t(px), skip1 = int32_t(xy.y) - int32_t(py);
+        if constexpr (METRICS) {
+            if(valid) {
+                const int32_t offset = int32_t(xy.x) - int32_t(xy.y);
+                metrics->minOffset = min(metrics->minOffset, offset); metrics->maxOffset = max(metrics->maxOffset, offset);
+                metrics->sumOffset += offset;
+                if(i > 0) {
+                    metrics->maxSkip = max(metrics->maxSkip, max(uint32_t(skip0), uint32_t(skip1)));
+                    const int32_t drift = skip0 - skip1;                 // (x - y) of this pair minus (x - y) of the one before
+                    metrics->maxDrift = max(metrics->maxDrift, uint32_t(drift < 0 ? -drift : drift));
+                }
+            }
+        }
         // The first start of this chunk closes the pending streak.
         if(havePending && starts) {
             const uint32_t first = base + uint32_t(__ffsll((unsigned long long)starts) - 1);
@@ -183,20 +200,6 @@ __device__ __forceinline__ uint64_t compressAlignmentWave(const uint32_t* __rest
 }
 
 __global__ void __launch_bounds__(256)
-compressSizeKernel(const uint32_t* __restrict__ storedFlags, const DpResult* __restrict__ results,
-    const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch, uint32_t pairCount, uint64_t* __restrict__ sizes)
-{
-    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if(p > pairCount) return;
-    uint64_t s = 0;
-    if(p < pairCount && storedFlags[p]) {
-        const DpResult r = results[pairWinner[p]];
-        s = compressAlignmentWave<false>(ordScratch + 2 * r.ordBegin, r.markerCount, nullptr);
-    }
-    if(laneId() == 0) sizes[p] = s;
-}
-
-__global__ void __launch_bounds__(256)
 compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __restrict__ storedIndex,
     const DpResult* __restrict__ results, const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch,
     uint32_t pairCount, const uint64_t* __restrict__ byteOffsets, uint8_t* __restrict__ bytes,
@@ -210,4 +213,53 @@ compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __
     if(laneId() == 0) compressedToc[k] = byteOffsets[p];
     // The 64-byte AlignmentData row: one dword per lane.
     if(laneId() < 16) reinterpret_cast<uint32_t*>(rowsOut + k)[laneId()] = reinterpret_cast<const uint32_t*>(rows + p)[laneId()];
+}
+
+// AlignmentInfo's metrics of every task from its stored pairs (src/Alignment.cpp:67-113, :4-31), the inner acceptance
+// (src/Align4.cpp:944-981) and the candidate's best component (:132-139) -- and, in the same pass over the pairs, the size of
+// the task's alignment in shasta::compress form (what compressWriteKernel will write if the task becomes its candidate's stored
+// alignment: until round 3 a kernel of its own read the winners' pairs a second time for that).  One wavefront per task: the
+// pairs of a task are contiguous and ascending, 8 bytes per lane per round.
+__global__ void __launch_bounds__(256)
+dpMetricsKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
+    const uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if(t >= taskCount) return;
+    const int lane = laneId();
+    DpResult r = results[t];
+    const uint32_t count = r.markerCount;
+    const uint2* __restrict__ p = reinterpret_cast<const uint2*>(ordScratch + 2 * r.ordBegin);
+    PairMetrics m;
+    const uint64_t compressedBytes = compressAlignmentWave<false, true>(ordScratch + 2 * r.ordBegin, count, nullptr, &m);
+    int32_t minOffset = m.minOffset, maxOffset = m.maxOffset;
+    long long sumOffset = m.sumOffset;
+    uint32_t maxSkip = m.maxSkip, maxDrift = m.maxDrift;
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) {
+        minOffset = min(minOffset, __shfl_xor(minOffset, d, WAVE)); maxOffset = max(maxOffset, __shfl_xor(maxOffset, d, WAVE));
+        sumOffset += __shfl_xor(sumOffset, d, WAVE);
+        maxSkip = max(maxSkip, uint32_t(__shfl_xor(int(maxSkip), d, WAVE))); maxDrift = max(maxDrift, uint32_t(__shfl_xor(int(maxDrift), d, WAVE)));
+    }
+    if(lane != 0) return;
+    const PairDesc pd = pairs[tasks[t].pair];
+    if(count) { const uint2 f = p[0], l = p[count - 1]; r.first0 = f.x; r.first1 = f.y; r.last0 = l.x; r.last1 = l.y; }
+    r.minOffset = minOffset; r.maxOffset = maxOffset; r.sumOffset = sumOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+    r.compressedBytes = uint32_t(compressedBytes < 0xffffffffULL ? compressedBytes : 0xffffffffULL);
+    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+    if(pass) {
+        const double f0 = double(count) / double(r.last0 + 1 - r.first0);
+        const double f1 = double(count) / double(r.last1 + 1 - r.first1);
+        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
+        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
+        const uint32_t leftTrim = min(r.first0, r.first1);
+        const uint32_t rightTrim = min(pd.nx - 1 - r.last0, pd.ny - 1 - r.last1);
+        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
+    }
+    r.passes = pass ? 1u : 0u;
+    results[t] = r;
+    // Best component = most aligned markers (:132-139); ties resolved towards the
+    // component whose first cell in (iY,iX) order comes first, and flagged later.
+    if(pass) atomicMax(&pairBest[tasks[t].pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - tasks[t].label));
 }
