@@ -374,6 +374,9 @@ __device__ __forceinline__ uint32_t hash32b(uint32_t k) { return k * 0x85ebca6bu
 __device__ __forceinline__ uint32_t zeroHalves(uint32_t v) { return packedMinU16(v, 0x00010001u) ^ 0x00010001u; }
 constexpr uint32_t LOW_HALF = 1u, HIGH_HALF = 0x10000u;
 
+#ifndef SHASTA_CELLS_EXACT_TABLE
+#define SHASTA_CELLS_EXACT_TABLE 1
+#endif
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
 #ifndef SHASTA_CELLS_FURTHER
 #define SHASTA_CELLS_FURTHER 2
@@ -418,22 +421,34 @@ align4CellsChunkKernel(
     uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts)
 {
     extern __shared__ uint32_t ldsWords[];
+#if SHASTA_CELLS_EXACT_TABLE
+    __shared__ uint32_t waveTotals[SHASTA_CELLS_MAX_THREADS / 64];
+#else
     // Markers whose two buckets were both full when they arrived (the two-choice table runs at two
     // entries per four-slot bucket on average, so a nearly full table overflows now and then).
     constexpr uint32_t STASH = 32;
     __shared__ uint32_t stashCount, stashKmer[STASH], stashOrdinal[STASH];
+#endif
     constexpr int MAXC = 64 * Q;
     if(blockIdx.x >= chunkCount) return;
     const CellsChunk chunk = chunks[blockIdx.x];
     const int lane = laneId();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), waves = blockDim.x >> 6;       // scalar: loop control on the scalar unit
     const uint32_t NA = 1u << chunk.naLog2, SC = 1u << chunk.scLog2;
-    const int bucketShift = 32 - (int(chunk.naLog2) - 1), scShift = 32 - int(chunk.scLog2);
-    const int xBits = int(chunk.naLog2);
-    const uint32_t xMask = NA - 1, tagMask = (1u << (16 - xBits)) - 1;
+    const int xBits = int(chunk.naLog2), scShift = 32 - int(chunk.scLog2);
+    const uint32_t xMask = NA - 1;
+#if SHASTA_CELLS_EXACT_TABLE
+    const int bucketShift = 32 - xBits;
+    uint32_t* const range = ldsWords;                             // bucket b: first entry | entries << 16
+    uint32_t* const entries = range + NA;                         // (hash32(kmer id) << xBits) | ordinal, bucket after bucket
+    uint32_t* const cells = entries + NA;
+#else
+    const int bucketShift = 32 - (int(chunk.naLog2) - 1);
+    const uint32_t tagMask = (1u << (16 - xBits)) - 1;
     uint32_t* const aKmers = ldsWords;
     uint32_t* const aSlots = aKmers + NA;
     uint32_t* const cells = aSlots + NA;
+#endif
     uint32_t* const slots = cells + SC;                           // slot w: kept[MAXC], later the map[2 MAXC] of the graph | scratch[8] | stage[4 CELLS_STAGE]
     // The slot the candidate being streamed appends its kept cells to (every wavefront), and this wavefront's own slot
     // (graph of the candidate it was given, staged tasks).  scratch: [0] kept count, [1] min, [2] max, [3] staged tasks,
@@ -446,8 +461,10 @@ align4CellsChunkKernel(
     const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
     PHASE_BEGIN();
 
+#if !SHASTA_CELLS_EXACT_TABLE
     // Tag of a kmer id (never all ones, so that an empty slot matches no tag) and its two buckets.
     auto tagOf = [&](uint32_t h) { const uint32_t t = (h >> 4) & tagMask; return t == tagMask ? 0u : t; };
+#endif
 
     // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
     //     candidates gathered by the host because they share a short read 1) read 1 ---
@@ -455,6 +472,39 @@ align4CellsChunkKernel(
     const bool swapped = (chunk.swapped & 1) != 0, noGrid = (chunk.swapped & 2) != 0;
     const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
     const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
+#if SHASTA_CELLS_EXACT_TABLE
+    // The exact bucketed table: h = kmerId * odd constant is a bijection of the 32-bit values, so (bucket = the top xBits bits of
+    // h, the other bits of h) IS the kmer id; with NA buckets and ordinals below NA an entry -- the low bits of h | the ordinal --
+    // is one word, the buckets are the segments of one array.  A counting sort: two LDS atomics per marker and one scan, no
+    // compare-and-swap loops, nothing that can overflow.
+    for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) range[k] = 0;
+    if(lane == 0) ownScratch[3] = 0;
+    __syncthreads();
+    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) atomicAdd(&range[hash32(tabSeq[t]) >> bucketShift], 1u);
+    __syncthreads();
+    {
+        const uint32_t per = (NA + blockDim.x - 1) / blockDim.x, first = threadIdx.x * per;
+        uint32_t sum = 0;
+        for(uint32_t k = first; k < min(first + per, NA); k++) sum += range[k];
+        uint32_t inclusive = sum;
+#pragma unroll
+        for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
+        if(lane == WAVE - 1) waveTotals[wave] = inclusive;
+        __syncthreads();
+        uint32_t base = inclusive - sum;
+        for(uint32_t w = 0; w < wave; w++) base += waveTotals[w];
+        for(uint32_t k = first; k < min(first + per, NA); k++) { const uint32_t size = range[k]; range[k] = base; base += size; }
+    }
+    __syncthreads();
+    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
+        const uint32_t h = hash32(tabSeq[t]);
+        const uint32_t old = atomicAdd(&range[h >> bucketShift], 0x10000u);
+        entries[(old & 0xffffu) + (old >> 16)] = (h << xBits) | t;
+    }
+    __syncthreads();
+    PHASE_MARK(0);
+
+#else
     for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
     if(threadIdx.x == 0) stashCount = 0;
     if(lane == 0) ownScratch[3] = 0;
@@ -497,6 +547,7 @@ align4CellsChunkKernel(
         return;
     }
 
+#endif
     // The stream in groups of 64 markers dealt to the wavefronts in turn (group g to wavefront g mod waves: every wavefront
     // gets the same number of groups, give or take one); a wavefront takes CELLS_UNROLL of its groups per round, and a slot of
     // the last round whose group lies beyond the stream is skipped (wavefront-uniform).  Slot u of the round that starts at
@@ -638,6 +689,87 @@ align4CellsChunkKernel(
 #ifndef SHASTA_ABLATE
 #define SHASTA_ABLATE 0          // timing experiments (wrong results): 1 = without the kept-cell graphs, 2 = without the stream
 #endif
+#if SHASTA_CELLS_EXACT_TABLE
+        // Matches wait in a queue of the wavefront (the half of its slot that the kept list does not use while candidates are
+        // streamed) and are counted 64 at a time: the loop over the entries of the markers' buckets is thin -- most lanes have
+        // nothing to look at in its later iterations -- and only finds matches; the cell arithmetic and the LDS atomics run on
+        // full wavefronts.  An entry: table ordinal << 16 | stream ordinal (both below 2^16: cellsClassFor).
+        uint32_t* const queue = ownKept + MAXC;
+        uint32_t queued = 0;                                                    // wave-uniform
+        auto drain = [&]() {
+            waveLdsSync();
+            constexpr int N = MAXC / WAVE;                                      // the queue holds MAXC entries
+            bool hit[N];
+            uint32_t ti[N], ts[N];
+#pragma unroll
+            for(int k = 0; k < N; k++) {
+                const uint32_t at = uint32_t(k) * WAVE + uint32_t(lane);
+                hit[k] = at < queued;
+                const uint32_t e = queue[hit[k] ? at : 0u];
+                ti[k] = e >> 16; ts[k] = e & 0xffffu;
+            }
+            waveLdsSync();
+            countHits(std::integral_constant<int, N>{}, hit, ti, ts);
+            queued = 0;
+        };
+        for(uint32_t s0 = firstRound; s0 < (SHASTA_ABLATE == 2 ? 0u : streamCount); s0 += roundStride) {
+            SUBPHASE_START(); SUBPHASE_COUNT(4);
+            // first[u], left[u]: the entries of marker u's bucket that have not been looked at; wanted[u]: its hash bits.
+            uint32_t first[CELLS_UNROLL], left[CELLS_UNROLL], wanted[CELLS_UNROLL], ts[CELLS_UNROLL];
+            uint32_t most = 0;
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) {
+                const uint32_t km = kmNext[u];
+                const uint32_t tn = s0 + roundStride + u * groupStride + lane;
+                kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
+                ts[u] = s0 + uint32_t(u) * groupStride + uint32_t(lane);
+                const uint32_t h = hash32(km);
+                const uint32_t r = range[h >> bucketShift];
+                wanted[u] = h << xBits;
+                first[u] = r & 0xffffu;
+                left[u] = ts[u] < streamCount ? r >> 16 : 0u;
+                most = max(most, left[u]);
+            }
+            SUBPHASE_ADD(0);
+            uint32_t e[CELLS_UNROLL];
+#pragma unroll
+            for(int u = 0; u < CELLS_UNROLL; u++) e[u] = entries[left[u] != 0u ? first[u] : 0u];
+            while(__any(most != 0u)) {
+                SUBPHASE_COUNT(5);
+                bool hit[CELLS_UNROLL];
+                uint32_t packed[CELLS_UNROLL];
+#pragma unroll
+                for(int u = 0; u < CELLS_UNROLL; u++) {
+                    const bool has = left[u] != 0u;
+                    hit[u] = has && ((e[u] ^ wanted[u]) >> xBits) == 0u;             // exact: the hash is a bijection, the bucket is the rest of its bits
+                    packed[u] = ((e[u] & xMask) << 16) | ts[u];
+                    first[u] += 1u; left[u] -= has ? 1u : 0u;
+                }
+                most = most != 0u ? most - 1u : 0u;
+                if(__any(most != 0u)) {
+#pragma unroll
+                    for(int u = 0; u < CELLS_UNROLL; u++) e[u] = entries[left[u] != 0u ? first[u] : 0u];
+                }
+                // Two markers at a time (static_assert below): ONE place where the queue is emptied, so that the counting code
+                // exists once in the loop (emptied at each of the four pushes it was inlined four times: 5000 instructions).
+                static_assert(CELLS_UNROLL == 4, "the matches of a round enter the queue two markers at a time");
+#pragma nounroll
+                for(int half = 0; half < 2; half++) {
+                    const bool hitA = half ? hit[2] : hit[0], hitB = half ? hit[3] : hit[1];
+                    const uint32_t packedA = half ? packed[2] : packed[0], packedB = half ? packed[3] : packed[1];
+                    const uint64_t votesA = __ballot(hitA), votesB = __ballot(hitB);
+                    const uint32_t countA = uint32_t(__popcll(votesA)), countB = uint32_t(__popcll(votesB));
+                    if(countA + countB == 0) continue;
+                    if(queued + countA + countB > uint32_t(MAXC)) { SUBPHASE_COUNT(6); drain(); }
+                    if(hitA) queue[queued + uint32_t(__popcll(votesA & laneMaskLt()))] = packedA;
+                    if(hitB) queue[queued + countA + uint32_t(__popcll(votesB & laneMaskLt()))] = packedB;
+                    queued += countA + countB;
+                }
+                SUBPHASE_ADD(1);
+            }
+        }
+        if(queued) drain();
+#else
         for(uint32_t s0 = firstRound; s0 < (SHASTA_ABLATE == 2 ? 0u : streamCount); s0 += roundStride) {
             SUBPHASE_START(); SUBPHASE_COUNT(4);
             // matches[u]: the tag matches of marker u, bit i for the low half of its word i, bit 16 + i for the high half.
@@ -748,6 +880,7 @@ align4CellsChunkKernel(
                 if(__any(anyHit)) countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts);
             }
         }
+#endif
         SUBPHASE_FLUSH();
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
         if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason & 7) | ((reason & 8) ? 0x20u : 0u) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
