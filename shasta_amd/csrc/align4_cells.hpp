@@ -438,8 +438,8 @@ align4CellsChunkKernel(
     const int xBits = int(chunk.naLog2), scShift = 32 - int(chunk.scLog2);
     const uint32_t xMask = NA - 1;
 #if SHASTA_CELLS_EXACT_TABLE
-    const int bucketShift = 32 - xBits;
-    uint32_t* const range = ldsWords;                             // bucket b: first entry | entries << 16
+    const int bucketShift = 32 - (xBits + 1);                     // 2 NA buckets
+    uint32_t* const range = ldsWords;                             // 16-bit halves: where bucket b's entries start (its end while the table is built)
     uint32_t* const entries = range + NA;                         // (hash32(kmer id) << xBits) | ordinal, bucket after bucket
     uint32_t* const cells = entries + NA;
 #else
@@ -473,19 +473,25 @@ align4CellsChunkKernel(
     const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
     const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
 #if SHASTA_CELLS_EXACT_TABLE
-    // The exact bucketed table: h = kmerId * odd constant is a bijection of the 32-bit values, so (bucket = the top xBits bits of
-    // h, the other bits of h) IS the kmer id; with NA buckets and ordinals below NA an entry -- the low bits of h | the ordinal --
-    // is one word, the buckets are the segments of one array.  A counting sort: two LDS atomics per marker and one scan, no
-    // compare-and-swap loops, nothing that can overflow.
+    // The exact bucketed table: h = kmerId * odd constant is a bijection of the 32-bit values, so (bucket = the top bits of h, the
+    // other bits of h) IS the kmer id.  2 NA buckets for at most NA markers (load factor below 1/2: the loop over a bucket's
+    // entries below runs as long as the fullest bucket of a round's 256 markers); an entry -- the other bits of h | the
+    // ordinal -- is one word, the buckets are the segments of one array, and where they start is a table of 16-bit positions,
+    // two to a word.  A counting sort: the sizes by LDS atomics on the halves, one scan that leaves every bucket's END, and the
+    // fill counts each end down to the bucket's start (the reference's own way of filling its buckets,
+    // MemoryMappedVectorOfVectors::storeMultithreaded) -- no compare-and-swap loops, nothing that can overflow.
     for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) range[k] = 0;
     if(lane == 0) ownScratch[3] = 0;
     __syncthreads();
-    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) atomicAdd(&range[hash32(tabSeq[t]) >> bucketShift], 1u);
+    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
+        const uint32_t b = hash32(tabSeq[t]) >> bucketShift;
+        atomicAdd(&range[b >> 1], (b & 1u) ? 0x10000u : 1u);
+    }
     __syncthreads();
     {
         const uint32_t per = (NA + blockDim.x - 1) / blockDim.x, first = threadIdx.x * per;
         uint32_t sum = 0;
-        for(uint32_t k = first; k < min(first + per, NA); k++) sum += range[k];
+        for(uint32_t k = first; k < min(first + per, NA); k++) { const uint32_t w = range[k]; sum += (w & 0xffffu) + (w >> 16); }
         uint32_t inclusive = sum;
 #pragma unroll
         for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
@@ -493,13 +499,19 @@ align4CellsChunkKernel(
         __syncthreads();
         uint32_t base = inclusive - sum;
         for(uint32_t w = 0; w < wave; w++) base += waveTotals[w];
-        for(uint32_t k = first; k < min(first + per, NA); k++) { const uint32_t size = range[k]; range[k] = base; base += size; }
+        for(uint32_t k = first; k < min(first + per, NA); k++) {
+            const uint32_t w = range[k];
+            const uint32_t endLow = base + (w & 0xffffu), endHigh = endLow + (w >> 16);
+            range[k] = endLow | (endHigh << 16);
+            base = endHigh;
+        }
     }
     __syncthreads();
     for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
         const uint32_t h = hash32(tabSeq[t]);
-        const uint32_t old = atomicAdd(&range[h >> bucketShift], 0x10000u);
-        entries[(old & 0xffffu) + (old >> 16)] = (h << xBits) | t;
+        const uint32_t b = h >> bucketShift;
+        const uint32_t old = atomicAdd(&range[b >> 1], (b & 1u) ? 0xffff0000u : 0xffffffffu);       // (minus one in the half: a low half never borrows, it counts down to its bucket's start)
+        entries[((b & 1u) ? old >> 16 : old & 0xffffu) - 1u] = (h << (32 - bucketShift)) | t;
     }
     __syncthreads();
     PHASE_MARK(0);
@@ -724,10 +736,12 @@ align4CellsChunkKernel(
                 kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
                 ts[u] = s0 + uint32_t(u) * groupStride + uint32_t(lane);
                 const uint32_t h = hash32(km);
-                const uint32_t r = range[h >> bucketShift];
-                wanted[u] = h << xBits;
-                first[u] = r & 0xffffu;
-                left[u] = ts[u] < streamCount ? r >> 16 : 0u;
+                const uint32_t b = h >> bucketShift;
+                const uint16_t* const starts = reinterpret_cast<const uint16_t*>(range);
+                const uint32_t begin = starts[b], end = b + 1u < 2u * NA ? uint32_t(starts[b + 1u < 2u * NA ? b + 1u : b]) : tabCount;
+                wanted[u] = h << (32 - bucketShift);
+                first[u] = begin;
+                left[u] = ts[u] < streamCount ? end - begin : 0u;
                 most = max(most, left[u]);
             }
             SUBPHASE_ADD(0);
@@ -741,7 +755,7 @@ align4CellsChunkKernel(
 #pragma unroll
                 for(int u = 0; u < CELLS_UNROLL; u++) {
                     const bool has = left[u] != 0u;
-                    hit[u] = has && ((e[u] ^ wanted[u]) >> xBits) == 0u;             // exact: the hash is a bijection, the bucket is the rest of its bits
+                    hit[u] = has && ((e[u] ^ wanted[u]) >> (32 - bucketShift)) == 0u;     // exact: the hash is a bijection, the bucket is the rest of its bits
                     packed[u] = ((e[u] & xMask) << 16) | ts[u];
                     first[u] += 1u; left[u] -= has ? 1u : 0u;
                 }
