@@ -74,14 +74,16 @@ downsampleKernel(const uint32_t* __restrict__ kmerIds, const uint64_t* __restric
     if(!WRITE && lane == 0) counts[r] = kept;
 }
 
-// Step 1 of a pair with more than 1024 diagonals: the same recurrence, tie policy and end-cell
-// rule as bandedDpForwardKernel over every diagonal d = i - j = b - ny, b in [0, nx + ny], of the
-// down-sampled matrix.  One wavefront per task sweeps the anti-diagonals s = i + j; the values of
+// A DP over more than 1024 diagonals (step 1 of align method 3 on a long pair: every diagonal of the down-sampled matrix; a
+// wide component of Align4): the same recurrence, tie policy and end-cell rule as bandedDpForwardKernel over the diagonals
+// d = i - j = dMin + b, b in [0, width).  One wavefront per task sweeps the anti-diagonals s = i + j; the values of
 // anti-diagonals s, s-1, s-2 live in three LDS rows of W = nx + ny + 1 words (cells that do not
 // exist hold NEG_SCORE), a lane owns diagonal 64 q + lane of chunk q.  Trace: two bit planes per
 // (s, q), at words 2 (s Q + q) and 2 (s Q + q) + 1 of the task's trace, Q = ceil(W / 64); codes as
 // in bandedDpForwardKernel.  Sized for the few long pairs of a batch, not tuned further.
-struct WideTask { uint32_t pair, chunks; uint64_t traceOffset; };
+// dMin, width: the diagonals d = i - j of the task, dMin .. dMin + width - 1 (the whole matrix for step 1 of align method 3: -ny ..
+// nx; the band of a component of more than 1024 diagonals for Align4, whose maxBand the reference does not bound, src/Align4.cpp:929).
+struct WideTask { uint32_t pair, chunks; uint64_t traceOffset; int32_t dMin; uint32_t width; };
 struct WideEnd { int32_t bestI, bestJ, score, pad; };
 constexpr uint32_t ALIGN3_WIDE_MAX_DIAGONALS = 8192;      // 3 rows of 32 KB in LDS
 // Beyond that (down-sampled reads of more than 4096 markers each: reads of several hundred kilobases) the three rows live
@@ -107,7 +109,7 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
     const int32_t nx = int32_t(pd.nx), ny = int32_t(pd.ny);
     const uint32_t* __restrict__ p0 = kmerIds + pd.begin0;
     const uint32_t* __restrict__ p1 = kmerIds + pd.begin1;
-    const int32_t W = nx + ny + 1;
+    const int32_t W = int32_t(task.width), dMin = task.dMin;
     const uint32_t Q = task.chunks;
     uint64_t* __restrict__ tr = trace + task.traceOffset;
     for(uint32_t k = threadIdx.x; k < 3u * rowWords; k += blockDim.x) rows[k] = NEG_SCORE;
@@ -118,7 +120,7 @@ align3WideDpKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const int32_t* const prev1 = rows + uint32_t((s + 2) % 3) * rowWords;     // s - 1
         const int32_t* const prev2 = rows + uint32_t((s + 1) % 3) * rowWords;     // s - 2
         for(uint32_t q = wave; q < Q; q += waves) {
-            const int32_t b = int32_t(q * 64u) + lane, d = b - ny;
+            const int32_t b = int32_t(q * 64u) + lane, d = b + dMin;
             // Cell (i, j) of this anti-diagonal on diagonal d, if it exists.
             const int32_t i2 = s + d, j2 = s - d;
             const bool exists = b < W && i2 >= 0 && j2 >= 0 && ((i2 & 1) == 0) && (i2 >> 1) <= nx && (j2 >> 1) <= ny;
@@ -189,13 +191,13 @@ align3BandKernel(
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if(idx >= taskCount) return;
     uint32_t pair;
-    int32_t i, j, score, bandMin1 = 0, s0 = 0;
+    int32_t i, j, score, bandMin1 = 0, s0 = 0, dMinWide = 0;
     uint32_t C = 1, laneBase = 0, Q = 0;
     const uint64_t* __restrict__ tr;
     if(WIDE) {
         const WideTask task = wideTasks[idx];
         const WideEnd e = wideEnds[idx];
-        pair = task.pair; i = e.bestI; j = e.bestJ; score = e.score; Q = task.chunks;
+        pair = task.pair; i = e.bestI; j = e.bestJ; score = e.score; Q = task.chunks; dMinWide = task.dMin;
         tr = trace + task.traceOffset;
     } else {
         const uint32_t t = sortedIds[idx];
@@ -217,7 +219,7 @@ align3BandKernel(
         uint64_t lo, hi;
         uint32_t bit;
         if(WIDE) {
-            const uint32_t b = uint32_t(i - j + int32_t(ds.ny));
+            const uint32_t b = uint32_t(i - j - dMinWide);
             const uint64_t w = 2ULL * (uint64_t(uint32_t(i + j)) * Q + (b >> 6));
             lo = tr[w]; hi = tr[w + 1]; bit = b & 63u;
         } else {
@@ -252,4 +254,37 @@ align3BandKernel(
     out.bandMax = min(bandMax, int32_t(pd.nx));
     out.label = 0;
     tasks2[atomicAdd(taskCount2, 1u)] = out;
+}
+
+// Traceback of the wide tasks of Align4 (components of more than 1024 diagonals): one wavefront per task, lane 0 walks the trace
+// align3WideDpKernel wrote and stores the aligned pairs from the end of the task's ordinal range downwards, as dpTracebackKernel
+// does; results[firstResult + k] gets what tracebackFinish leaves.  A handful of tasks in a run whose Align.maxBand admits them:
+// written to be right, not fast.
+__global__ void __launch_bounds__(64)
+wideTracebackKernel(const PairDesc* __restrict__ pairs, const WideTask* __restrict__ wideTasks, const WideEnd* __restrict__ wideEnds, uint32_t count,
+    const uint64_t* __restrict__ trace, const uint64_t* __restrict__ ordBases, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, uint32_t firstResult)
+{
+    const uint32_t k = blockIdx.x;
+    if(k >= count || threadIdx.x != 0) return;
+    const WideTask task = wideTasks[k];
+    const WideEnd e = wideEnds[k];
+    const PairDesc pd = pairs[task.pair];
+    const uint64_t* __restrict__ tr = trace + task.traceOffset;
+    const uint64_t ordBase = ordBases[k];
+    uint32_t pos = min(pd.nx, pd.ny);
+    int32_t i = e.bestI, j = e.bestJ;
+    if(e.score > NEG_SCORE) {
+        while(i > 0 && j > 0) {
+            const uint32_t b = uint32_t(i - j - task.dMin);
+            const uint64_t w = 2ULL * (uint64_t(uint32_t(i + j)) * task.chunks + (b >> 6));
+            const uint64_t lo = tr[w], hi = tr[w + 1];
+            const uint32_t bit = b & 63u;
+            const uint32_t dir = uint32_t((lo >> bit) & 1ULL) | (uint32_t((hi >> bit) & 1ULL) << 1);
+            if(dir == 0u) { --pos; *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(uint32_t(i - 1), uint32_t(j - 1)); }
+            i -= (dir != 2u) ? 1 : 0;
+            j -= (dir != 3u) ? 1 : 0;
+        }
+    }
+    DpEnd end; end.traceOffset = 0; end.bestI = e.bestI; end.bestJ = e.bestJ; end.score = e.score; end.laneBase = 0; end.bundleIterations = 0; end.pad = 0;
+    tracebackFinish(pos, pd, end, ordBase, firstResult + k, results);
 }

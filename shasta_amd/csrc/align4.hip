@@ -98,9 +98,10 @@ DeviceOptions makeOptions(const shasta_align4_options& o)
     d.minAlignedMarkerCount = o.minAlignedMarkerCount;
     d.minAlignedFraction = o.minAlignedFraction;
     d.maxSkip = o.maxSkip; d.maxDrift = o.maxDrift; d.maxTrim = o.maxTrim; d.maxBand = o.maxBand;
-    // The DP kernels hold a band of at most 1024 diagonals (src/AssemblerOptions.cpp: Align.maxBand defaults to 1000).  A
-    // wider limit would let components through that they cannot compute: refused here, loudly, instead of skipping pairs later.
-    if(o.maxBand > 1024) throw std::runtime_error("Align4: maxBand must not exceed 1024 (the banded DP kernels hold 1024 diagonals).");
+    // The banded DP kernels hold 1024 diagonals (src/AssemblerOptions.cpp: Align.maxBand defaults to 1000); a component that a
+    // larger maxBand lets through (the reference only compares, src/Align4.cpp:929) runs in the wide DP (runWideTasks), up to
+    // 65536 diagonals: a limit beyond that cannot be honoured and is refused here, loudly.
+    if(o.maxBand > ALIGN3_HUGE_MAX_DIAGONALS) throw std::runtime_error("Align4: maxBand must not exceed 65536 (the widest band the wide DP holds).");
     d.suppressContainments = o.suppressContainments ? 1u : 0u;
     return d;
 }
@@ -133,6 +134,7 @@ struct BatchScratch {
     DeviceBuffer<WideTask> wideTasks;           //                         pairs with more than 1024 diagonals
     DeviceBuffer<int32_t> hugeRows;             //                         the three anti-diagonals of the pairs with more than 8192 diagonals
     DeviceBuffer<WideEnd> wideEnds;
+    DeviceBuffer<uint64_t> wideTrace, wideOrdBases;   // Align4 components of more than 1024 diagonals (runWideTasks)
     DeviceBuffer<uint64_t> prepareKeysA, prepareKeysB;      // a batch's first chunk lists made on the device (align4_prepare.hpp)
     DeviceBuffer<uint32_t> prepareIdsA, prepareIdsB;
     DeviceBuffer<unsigned long long> prepareInfo;
@@ -296,9 +298,12 @@ struct DpForwardState {
     uint32_t classCounts[DP_CLASSES];
     unsigned long long sums[2 + 2 * DP_CLASSES];   // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c
     uint64_t traceWords;                  // of the bundles' trace (2 bits per cell of the padded bands, once per bundle)
+    uint64_t ordTotal;                    // ordinal pairs reserved for the tasks (the wide tasks' ranges follow)
 };
 
-DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers)
+// extraTasks / extraOrdinals: room behind the taskCount tasks for the wide tasks' results and aligned pairs.
+DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
+    uint32_t extraTasks = 0, uint64_t extraOrdinals = 0)
 {
     hipStream_t stream = ws.stream;
     DpForwardState f;
@@ -306,7 +311,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     b.dpIdsA.reserve(taskCount, stream); b.dpIdsB.reserve(taskCount, stream);
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
     b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
-    b.results.reserve(taskCount, stream); b.ends.reserve(taskCount, stream);
+    b.results.reserve(uint64_t(taskCount) + extraTasks, stream); b.ends.reserve(taskCount, stream);
     b.counters.reserve(16, stream); b.dpCells.reserve(2 + 2 * DP_CLASSES, stream);
     HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
     HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, (2 + 2 * DP_CLASSES) * sizeof(unsigned long long), stream));
@@ -339,7 +344,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     for(int c = 0; c <= DP_CLASSES; c++) f.taskStart[c] = layout.taskStart[c];
     if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
     b.trace.reserve(f.traceWords + 64, stream);
-    if(reserveOrdinals) b.ordScratch.reserve(2 * ordTotal + 2, stream);
+    f.ordTotal = ordTotal;
+    if(reserveOrdinals) b.ordScratch.reserve(2 * (ordTotal + extraOrdinals) + 2, stream);
 
     // Wide bands (classes 5-7: few tasks, one wavefront each) go to the side stream, widest first;
     // the narrow classes run on the main stream meanwhile.
@@ -591,12 +597,89 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
     }
 }
 
+// Components of more than 1024 diagonals (Align.maxBand beyond what the banded DP kernels hold; the reference only compares the
+// band with maxBand, src/Align4.cpp:929): `wide` = their tasks, which sit at tasks[taskCount ...) on the device; each runs in
+// align3WideDpKernel over its own diagonals (three anti-diagonals in LDS up to 8192 diagonals, in HBM scratch up to 65536), its
+// path is walked by wideTracebackKernel, and it leaves results[taskCount + k] and its aligned pairs at ordBase + ... like any task.
+void runWideTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, const std::vector<DpTask>& wide,
+    const std::vector<PairDesc>& hostPairs, uint64_t ordBase, uint64_t& dpCells)
+{
+    hipStream_t stream = ws.stream;
+    const uint64_t traceWordBudget = 1ULL << 29;
+    std::vector<uint64_t> ordBases(wide.size());
+    for(size_t k = 0; k < wide.size(); k++) { ordBases[k] = ordBase; ordBase += std::min(hostPairs[wide[k].pair].nx, hostPairs[wide[k].pair].ny); }
+    for(int pass = 0; pass < 2; pass++) {                       // 0: rows in LDS; 1: rows in HBM scratch
+        for(size_t begin = 0; begin < wide.size(); ) {
+            std::vector<WideTask> list;
+            std::vector<uint64_t> bases;
+            std::vector<uint32_t> resultIndex;
+            uint64_t words = 0;
+            uint32_t rowWords = 0;
+            size_t end = begin;
+            for(; end < wide.size(); end++) {
+                const DpTask& t = wide[end];
+                const PairDesc& pd = hostPairs[t.pair];
+                const uint32_t width = uint32_t(t.bandMax - t.bandMin + 1);
+                if(width > ALIGN3_HUGE_MAX_DIAGONALS) throw std::runtime_error("Align4: a component of more than 65536 diagonals (Align.maxBand beyond what the wide DP holds).");
+                if((width > ALIGN3_WIDE_MAX_DIAGONALS) != (pass == 1)) continue;
+                WideTask w; w.pair = t.pair; w.chunks = (width + 63) / 64; w.dMin = t.bandMin; w.width = width;
+                const uint64_t need = 2ULL * (uint64_t(pd.nx) + pd.ny + 1) * w.chunks;
+                if(!list.empty() && words + need > traceWordBudget) break;
+                w.traceOffset = words; words += need;
+                rowWords = std::max(rowWords, w.chunks * 64u);
+                dpCells += uint64_t(pd.nx) * width;
+                list.push_back(w); bases.push_back(ordBases[end]); resultIndex.push_back(uint32_t(end));
+            }
+            begin = end;
+            if(list.empty()) continue;
+            // (results must land at taskCount + index in `wide`: one launch per run of consecutive indices)
+            const uint32_t count = uint32_t(list.size());
+            b.wideTasks.reserve(count, stream); b.wideEnds.reserve(count, stream); b.wideTrace.reserve(words + 64, stream); b.wideOrdBases.reserve(count, stream);
+            HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), list.data(), count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(b.wideOrdBases.data(), bases.data(), count * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            std::call_once(ctx.wideDpLdsAttribute, [] {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_POLICY>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_ALTERNATIVE>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
+            });
+            const bool alternativeTie = in.tie != DP_TIE_POLICY;
+            if(pass == 1) {
+                b.hugeRows.reserve(size_t(count) * 3u * rowWords, stream);
+                const auto kernel = alternativeTie ? &align3WideDpKernel<true, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<true, DP_TIE_POLICY>;
+                hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, stream,
+                    in.kmerIds, in.pairs, (const WideTask*)b.wideTasks.data(), count, rowWords, b.wideTrace.data(), b.wideEnds.data(), b.hugeRows.data(), in.scores);
+            } else {
+                const auto kernel = alternativeTie ? &align3WideDpKernel<false, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<false, DP_TIE_POLICY>;
+                hipLaunchKernelGGL(kernel, dim3(count), dim3(64), 3 * size_t(rowWords) * sizeof(int32_t), stream,
+                    in.kmerIds, in.pairs, (const WideTask*)b.wideTasks.data(), count, rowWords, b.wideTrace.data(), b.wideEnds.data(), (int32_t*)nullptr, in.scores);
+            }
+            HIP_CHECK(hipGetLastError());
+            // The tasks of this launch are not consecutive in `wide` when the two passes interleave: one traceback launch per task
+            // index run keeps results[taskCount + index] right.
+            for(uint32_t q = 0; q < count; ) {
+                uint32_t r = q + 1;
+                while(r < count && resultIndex[r] == resultIndex[r - 1] + 1) ++r;
+                hipLaunchKernelGGL(wideTracebackKernel, dim3(r - q), dim3(64), 0, stream,
+                    in.pairs, (const WideTask*)(b.wideTasks.data() + q), (const WideEnd*)(b.wideEnds.data() + q), r - q,
+                    (const uint64_t*)b.wideTrace.data(), (const uint64_t*)(b.wideOrdBases.data() + q), b.ordScratch.data(), b.results.data(), taskCount + resultIndex[q]);
+                HIP_CHECK(hipGetLastError());
+                q = r;
+            }
+            HIP_CHECK(hipStreamSynchronize(stream));             // (the host lists go out of scope; the buffers are reused by the next group)
+        }
+    }
+}
+
 uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
-    DpEvents* ev, DpBatchStats* stats, const DpScores* scores = nullptr)
+    DpEvents* ev, DpBatchStats* stats, const DpScores* scores = nullptr, const std::vector<DpTask>* wide = nullptr, const std::vector<PairDesc>* hostPairs = nullptr)
 {
     hipStream_t stream = ws.stream;
     DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data(), dpTiePolicyOfCall()};
     if(scores) in.scores = *scores;
+    const uint32_t wideCount = wide ? uint32_t(wide->size()) : 0u;
+    uint64_t wideOrdinals = 0;
+    if(wideCount) for(const DpTask& t : *wide) wideOrdinals += std::min((*hostPairs)[t.pair].nx, (*hostPairs)[t.pair].ny);
     static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
     if(debug) {
         // Band widths of the batch's tasks, DP cells (nx x width) per width.
@@ -618,11 +701,14 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
         for(const auto& kv : histogram) std::fprintf(stderr, " %d: %llu, %.3g;", kv.first, (unsigned long long)kv.second.first, double(kv.second.second));
         std::fprintf(stderr, "\n");
     }
-    const DpForwardState f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers);
+    DpForwardState f;
+    std::memset(&f, 0, sizeof(f));
+    if(taskCount) f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers, wideCount, wideOrdinals);
+    else { b.results.reserve(wideCount, stream); b.ordScratch.reserve(2 * wideOrdinals + 2, stream); }
     // The traceback of every class in one launch (the list is sorted by class, then by ascending length; the kernel takes it from the end).
     // Booked: the trace it has to read = 2 bits per cell of the padded bands, once per bundle (the bundles' trace words as
     // dpBundleKernel laid them out; the tasks of a bundle walk the same records) -- work = tasks.
-    {
+    if(taskCount) {
         SHASTA_TIMED(ctx, "dpTracebackKernel", stream, 8 * f.traceWords, taskCount,
             hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
                 in.pairs, in.tasks, f.sortedIds, 0u, taskCount,
@@ -630,13 +716,16 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
                 (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data()));
         HIP_CHECK(hipGetLastError());
     }
+    uint64_t wideCells = 0;
+    if(wideCount) runWideTasks(ctx, ws, b, in, taskCount, *wide, *hostPairs, f.ordTotal, wideCells);
     // Booked: 8 bytes per aligned pair are read (unknown here: at most min(nx, ny) per task; the caller amends nothing) -- work = tasks.
-    SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, taskCount,
-        hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(taskCount) * WAVE, 256)), dim3(256), 0, stream,
-            in.pairs, in.tasks, taskCount, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
+    const uint32_t allTasks = taskCount + wideCount;
+    SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, allTasks,
+        hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(allTasks) * WAVE, 256)), dim3(256), 0, stream,
+            in.pairs, in.tasks, allTasks, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
     HIP_CHECK(hipGetLastError());
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[2 + DP_CLASSES + c]; stats->tasks[c] = f.classCounts[c]; }
-    return f.sums[0];
+    return f.sums[0] + wideCells;
 }
 
 struct BatchOutput {
@@ -831,7 +920,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         b.rows.reserve(n, stream); b.rowsOut.reserve(n, stream); b.compressedToc.reserve(n + 1, stream);
         HIP_CHECK(hipMemcpyAsync(b.pairs.data(), hostPairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(b.candidates.data(), candidates + batchBegin, n * sizeof(shasta_oriented_read_pair), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 8 * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 16 * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.pairFlags.data(), 0, n, stream));
         HIP_CHECK(hipMemsetAsync(b.pairTie.data(), 0, n, stream));
         HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, n * sizeof(unsigned long long), stream));
@@ -844,7 +933,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const auto phaseStart = phaseClock();
         auto phaseMs = [&](std::chrono::steady_clock::time_point from) { return std::chrono::duration<double, std::milli>(phaseClock() - from).count(); };
         double phaseCells = 0., phaseDp = 0., phaseFinish = 0.;
-        uint32_t taskCount = 0;
+        uint32_t taskCount = 0, wideCount = 0;
         std::vector<int> pairClass;                    // method 4: the table class of every candidate's cells (CELLS_CLASSES: HBM scratch)
         std::vector<uint8_t> pairSlotsLog2;            //           ... and the table size the HBM-scratch kernel last ran it with
         std::vector<uint8_t> pairNoGrid;               //           ... and whether its cells were counted in the packed table because a byte of its grid overflowed
@@ -870,7 +959,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     DpTask t; t.pair = k; t.bandMin = -int32_t(pd.ny); t.bandMax = int32_t(pd.nx); t.label = 0;
                     tasks1.push_back(t);
                 } else if(diagonals <= ALIGN3_HUGE_MAX_DIAGONALS) {
-                    WideTask t; t.pair = k; t.chunks = uint32_t((diagonals + 63) / 64); t.traceOffset = 0;
+                    WideTask t; t.pair = k; t.chunks = uint32_t((diagonals + 63) / 64); t.traceOffset = 0; t.dMin = -int32_t(pd.ny); t.width = uint32_t(diagonals);
                     (diagonals <= ALIGN3_WIDE_MAX_DIAGONALS ? wide : huge).push_back(t);
                 } else {
                     hostFlags[k] = PAIR_TOO_LONG;
@@ -1204,33 +1293,45 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             }
         }
         taskCount = readDevice(b.counters.data(), stream);
-        if(taskCount <= taskCapacity) break;
+        wideCount = m3 ? 0u : readDevice(b.counters.data() + CELLS_WIDE_COUNTER, stream);      // (components of more than 1024 diagonals, listed from the back)
+        if(uint64_t(taskCount) + wideCount <= taskCapacity) break;
         // More DP tasks than the list was sized for (many small components per candidate: low-complexity
         // reads, or options that keep nearly every cell).  The count is exact -- stores past the
         // capacity were dropped, the counter was not -- so the stage runs once more with room for all.
         if(m3) throw std::runtime_error("Align3: task list overflow.");
         if(std::getenv("SHASTA_MI355X_DEBUG")) std::fprintf(stderr, "cells: %u DP tasks exceed the capacity %u: running the stage again\n", taskCount, taskCapacity);
-        taskCapacity = taskCount + 1024;
+        taskCapacity = taskCount + wideCount + 1024;
         b.tasks.reserve(taskCapacity, stream);
-        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 8 * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 16 * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.pairFlags.data(), 0, n, stream));
+        }
+        // The wide components come forward to tasks[taskCount ...) (their results and aligned pairs follow the others').
+        std::vector<DpTask> wideTasksHost(wideCount);
+        if(wideCount) {
+            HIP_CHECK(hipMemcpyAsync(wideTasksHost.data(), b.tasks.data() + (taskCapacity - wideCount), wideCount * sizeof(DpTask), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            // (the order the atomics gave them is the order of no-one's choosing: by candidate and component, so that runs repeat)
+            std::sort(wideTasksHost.begin(), wideTasksHost.end(), [](const DpTask& x, const DpTask& y) { return x.pair != y.pair ? x.pair < y.pair : x.label < y.label; });
+            HIP_CHECK(hipMemcpyAsync(b.tasks.data() + taskCount, wideTasksHost.data(), wideCount * sizeof(DpTask), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
         }
 
         phaseCells = phaseMs(phaseStart);
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
-        if(taskCount) {
-            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr);
+        if(taskCount + wideCount) {
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs);
             out.hadTasks = true;
+            const uint32_t allTasks = taskCount + wideCount;
             HIP_CHECK(hipMemsetAsync(b.counters.data() + 12, 0, sizeof(uint32_t), stream));
-            SHASTA_TIMED(ctx, "winnerKernel", stream, 0, taskCount,
-                hipLaunchKernelGGL(winnerKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
-                    (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), taskCount,
+            SHASTA_TIMED(ctx, "winnerKernel", stream, 0, allTasks,
+                hipLaunchKernelGGL(winnerKernel, dim3(divUp(allTasks, 256)), dim3(256), 0, stream,
+                    (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), allTasks,
                     (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data(), b.counters.data() + 12));
             HIP_CHECK(hipGetLastError());
             // Candidates whose best components tie on markerCount: the reference's component order decides (method 4 only:
             // method 3 has one alignment per candidate).
             if(!m3 && readDevice(b.counters.data() + 12, stream) != 0) {
-                resolveComponentTies(ctx, ws, b, n, taskCount, hostPairs, pairClass, pairSlotsLog2, pairNoGrid, opt, cellsMagicX, cellsMagicY);
+                resolveComponentTies(ctx, ws, b, n, allTasks, hostPairs, pairClass, pairSlotsLog2, pairNoGrid, opt, cellsMagicX, cellsMagicY);
             }
         } else {
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
@@ -1529,11 +1630,24 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     for(uint64_t t = 0; t < taskCount; t++) {
         if(nx[t] == 0 || ny[t] == 0 || begin0[t] + nx[t] > kmerCount || begin1[t] + ny[t] > kmerCount) throw std::runtime_error("banded_dp_many: a sequence is empty or outside kmerIds.");
         if(uint64_t(nx[t]) + uint64_t(ny[t]) >= (1ULL << 25) - 4) throw std::runtime_error("banded_dp_many: two sequences of 2^25 - 4 elements or more between them.");
-        if(bandMin[t] > bandMax[t] || bandMax[t] - bandMin[t] + 1 > 1024) throw std::runtime_error("banded_dp_many: band width must be in [1, 1024].");
+        if(bandMin[t] > bandMax[t] || int64_t(bandMax[t]) - bandMin[t] + 1 > int64_t(ALIGN3_HUGE_MAX_DIAGONALS)) throw std::runtime_error("banded_dp_many: band width must be in [1, 65536].");
         if(bandMin[t] > int32_t(nx[t]) || bandMax[t] < -int32_t(ny[t])) throw std::runtime_error("banded_dp_many: the band misses the matrix.");
         pairs[t].begin0 = begin0[t]; pairs[t].begin1 = begin1[t]; pairs[t].nx = nx[t]; pairs[t].ny = ny[t];
-        tasks[t].pair = uint32_t(t); tasks[t].bandMin = bandMin[t]; tasks[t].bandMax = bandMax[t]; tasks[t].label = 0;
     }
+    // The tasks of up to 1024 diagonals first (the banded DP kernels), the wider ones behind them (the wide DP), as alignRun
+    // leaves them; position[k] = the input task of list entry k.
+    std::vector<uint32_t> position;
+    std::vector<DpTask> wideTasks;
+    for(int wide = 0; wide < 2; wide++) {
+        for(uint64_t t = 0; t < taskCount; t++) {
+            if((bandMax[t] - bandMin[t] + 1 > 1024) != (wide == 1)) continue;
+            DpTask task; task.pair = uint32_t(t); task.bandMin = bandMin[t]; task.bandMax = bandMax[t]; task.label = 0;
+            tasks[position.size()] = task;
+            if(wide) wideTasks.push_back(task);
+            position.push_back(uint32_t(t));
+        }
+    }
+    const uint32_t narrowCount = uint32_t(taskCount - wideTasks.size());
     std::vector<uint64_t> toc = {0, kmerCount / 2, kmerCount};
     ctx.setMarkers(1, toc.data(), nullptr, kmerIds, nullptr);
     hipStream_t stream = ctx.stream;
@@ -1549,7 +1663,7 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     DpEvents ev;
     DpBatchStats stats;
     ev.create();
-    try { (void)runDpTasks(ctx, ws, b, uint32_t(taskCount), opt, &ev, &stats); } catch(...) { ev.destroy(); throw; }
+    try { (void)runDpTasks(ctx, ws, b, narrowCount, opt, &ev, &stats, nullptr, &wideTasks, &pairs); } catch(...) { ev.destroy(); throw; }
     std::vector<DpResult> results(taskCount);
     HIP_CHECK(hipMemcpyAsync(results.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1559,9 +1673,11 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
         for(int c = 0; c < DP_CLASSES; c++) if(e.name == DP_FORWARD_NAMES[c]) { if(seconds) seconds[c] = e.seconds; if(cells) cells[c] = stats.cells[c]; }
         if(e.name.rfind("dpTraceback", 0) == 0 && seconds) seconds[DP_CLASSES] += e.seconds;
     }
+    std::vector<uint32_t> entryOf(taskCount);
+    for(uint32_t k = 0; k < taskCount; k++) entryOf[position[k]] = k;
     uint64_t used = 0;
     for(uint64_t t = 0; t < taskCount; t++) {
-        const DpResult& r = results[t];
+        const DpResult& r = results[entryOf[t]];
         if(ordinals && used + r.markerCount > capacity) throw std::runtime_error("banded_dp_many: output capacity too small.");
         if(ordinals && r.markerCount) HIP_CHECK(hipMemcpy(ordinals + 2 * used, b.ordScratch.data() + 2 * r.ordBegin, 8ULL * r.markerCount, hipMemcpyDeviceToHost));
         counts[t] = r.markerCount;

@@ -22,7 +22,8 @@ constexpr uint64_t EMPTY64 = ~0ULL;
 
 constexpr uint32_t F_NEAR_LT = 1, F_NEAR_RB = 2, F_FWD = 4, F_BWD = 8;
 constexpr uint8_t PAIR_RESOURCE = 1;       // a cell table overflowed: retried with a larger table in HBM
-constexpr uint8_t PAIR_TOO_LONG = 2;       // outside the supported geometry (iX/iY >= 2^16 or band > 1024): skipped + reported
+constexpr uint8_t PAIR_TOO_LONG = 2;       // outside the supported geometry (iX/iY >= 2^16): skipped + reported
+constexpr int CELLS_WIDE_COUNTER = 13;     // taskCount[13]: components of more than 1024 diagonals, listed from the back of the task list
 
 __device__ __forceinline__ uint32_t hash32(uint32_t k) { return k * 2654435761u; }
 
@@ -297,7 +298,13 @@ align4CellsKernel(
         const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
         const int32_t bandWidth = bandMax - bandMin + 1;
         if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;             // :929
-        if(bandWidth > 1024) { pairFlags[pair] = PAIR_TOO_LONG; continue; }
+        if(bandWidth > 1024) {
+            // More diagonals than the banded DP kernels hold (Align.maxBand beyond 1024): to the BACK of the task list, for the
+            // wide DP (taskCount[CELLS_WIDE_COUNTER] counts them; the host checks that the two ends did not meet).
+            const uint32_t w = atomicAdd(taskCount + CELLS_WIDE_COUNTER, 1u);
+            if(w < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[taskCapacity - 1u - w] = task; }
+            continue;
+        }
         const uint32_t t = atomicAdd(taskCount, 1u);
         if(t < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = key; tasks[t] = task; }
     }
@@ -1098,7 +1105,13 @@ align4CellsChunkKernel(
             const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
             const int32_t bandWidth = bandMax - bandMin + 1;
             if(int64_t(bandWidth) <= int64_t(opt.maxBand)) {                      // :929
-                if(bandWidth > 1024) { if(lane == 0) pairFlags[pair] = PAIR_TOO_LONG; }
+                if(bandWidth > 1024) {
+                    // (to the back of the task list, for the wide DP: see align4CellsKernel)
+                    if(lane == 0) {
+                        const uint32_t w = atomicAdd(taskCount + CELLS_WIDE_COUNTER, 1u);
+                        if(w < taskCapacity) { DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = seedKey; tasks[taskCapacity - 1u - w] = task; }
+                    }
+                }
                 else {
                     uint32_t staged = scratch[3];
                     if(staged == CELLS_STAGE) {

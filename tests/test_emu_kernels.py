@@ -54,6 +54,13 @@ def test_dp_tie_policy_switch(emu_lib, oracle_lib):
     assert tie_policy_checks.unknown_policy_is_refused(emu_lib)
 
 
+def test_bands_of_more_than_1024_diagonals(emu_lib, oracle_lib):
+    from tests import wide_band_checks
+    tasks, bad = wide_band_checks.dp_tasks(emu_lib, oracle_lib, widths=(1100, 40, 2500, 64), n_range=(300, 700))
+    assert tasks == 4 and bad == 0
+    assert wide_band_checks.aligner(emu_lib, oracle_lib, max_band=2000, length=4400, every=3) >= 1
+
+
 def test_lowhash0_and_align4(emu_lib, oracle_lib):
     toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=12000, seed=5)
     flags = np.zeros(150, np.uint8)
