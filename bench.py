@@ -152,15 +152,18 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
                                     and np.array_equal(lh.histogram, gpu_lowhash.histogram))
     # The aligner on a sample spread over the whole candidate list.  The reference's per-thread 2 GiB arena is a fixed
     # set-up cost (seconds): two sample sizes, incremental rate.
-    stride = max(1, len(cand) // max(1, sample_size))
+    # --baseline-sample 0: the WHOLE candidate list through the reference aligner (a minute or two on 64 threads: not the default;
+    # profiles/ holds one such run per round) -- then the rate is the run's own, set-up included, and every candidate is compared.
+    whole = sample_size <= 0 or sample_size >= len(cand)
+    stride = 1 if whole else max(1, len(cand) // max(1, sample_size))
     sample = np.ascontiguousarray(cand[::stride])
     small = np.ascontiguousarray(sample[:max(1, len(sample) // 10)])
     align = lib.align4_batch if align_method == 4 else lib.align3_batch
-    t1 = align(toc, data7, small, o, want_ordinals=True, threads=cores).seconds
+    t1 = 0.0 if whole else align(toc, data7, small, o, want_ordinals=True, threads=cores).seconds
     ref = align(toc, data7, sample, o, want_ordinals=True, threads=cores)
     t2 = ref.seconds
-    per_pair = (t2 - t1) / (len(sample) - len(small)) if len(sample) > len(small) else 0.0
-    if per_pair <= 0.0:                                 # too few candidates for the difference to mean anything
+    per_pair = (t2 - t1) / (len(sample) - len(small)) if (not whole and len(sample) > len(small)) else 0.0
+    if per_pair <= 0.0:                                 # the whole list, or too few candidates for the difference to mean anything
         per_pair = t2 / max(1, len(sample))
     dev = (ctx.align4 if align_method == 4 else ctx.align3)(sample, o, want_ordinals=True)
     ties = (ref.status & 0x80) != 0
@@ -184,7 +187,9 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
         "unit": "candidate read-pairs aligned/s",
         "cores": cores,
         "host_cores": host_cores,
-        "kind": kind if kind == "port" else "reference (LowHash0 in full; aligner: incremental per-candidate rate on a sample x all candidates; DP = the restated SeqAn call)",
+        "kind": kind if kind == "port" else ("reference (LowHash0 and the aligner in full on every candidate; DP = the restated SeqAn call)" if whole else
+                                             "reference (LowHash0 in full; aligner: incremental per-candidate rate on a sample x all candidates; DP = the restated SeqAn call)"),
+        "aligner_seconds_measured": t2,
         "sample": "the bench's own read set (%d reads, M=%d markers): LowHash0 %.2f s on %d of the host's %d cores -> %d candidates; "
                   "align method %d on every %d-th candidate (%d): %.3f ms/candidate incremental on %d threads; anonymous 4 KiB pages "
                   "(the reference warns such runs should not be used for benchmarking, srcMain/main.cpp:369-378)" % (
@@ -329,7 +334,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on")
+    ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on (0 = all of them: a minute or two)")
     ap.add_argument("--tie-census", type=int, default=20000,
                     help="candidates (a subset of the baseline sample) the checker re-aligns under the 11 other DP tie policies; 0 = no census")
     ap.add_argument("--group", action="store_true",

@@ -22,6 +22,21 @@
 // It is written as data (TiePolicy) so that it can be changed in one place if
 // a true SeqAn run ever disagrees.  The HIP kernel implements the same policy.
 //
+// A second reading, made independently in round 3 (again from memory of the 2.4.0
+// sources, which are not in this container), agrees with it and names the code:
+//   * globalAlignment(Graph<Alignment<..>>&, Score, AlignConfig, lowerDiag, upperDiag, LinearGaps) sets up
+//     AlignConfig2<DPGlobal, DPBandConfig<BandOn>, FreeEndGaps_<..>, TracebackOn<TracebackConfig_<SingleTrace, GapsLeft>>>:
+//     ONE trace bit per cell, so the order in which _computeTraceback tests the bits cannot matter;
+//   * dp_formula_linear.h, _computeScore(.., RecursionDirectionAll, ..): the vertical and the horizontal candidate meet in
+//     _maxScore(target, vertical, horizontal, ..) -- "leftCompare < rightCompare ? right : left", the left (vertical) keeps a
+//     tie -- and the winner meets the diagonal in _maxScore(target, diagonal, gap, DIAGONAL, tv): the left (diagonal) keeps a
+//     tie.  Hence diagonal >= vertical >= horizontal.  On the band's edge cells (RecursionDirectionUpperDiagonal /
+//     LowerDiagonal) the missing neighbour simply does not take part, which is what -infinity outside the band gives here;
+//   * dp_scout.h, _scoutBestScore: "if(_scoreOfCell(activeCell) > _scoreOfCell(dpScout._maxScore))" -- strictly greater --
+//     over the tracked cells (last row and last column: all four end gaps free) in the order the cells are computed,
+//     column by column of the horizontal sequence, rows ascending: the first maximum in (i, j) order.
+// It remains a reading: oracle/census.py counts what depends on it.
+//
 // Geometry.  seq0 (nx markers) is SeqAn's horizontal sequence, seq1 (ny) the
 // vertical one.  DP cell (i,j) = i symbols of seq0 and j of seq1 consumed,
 // 0<=i<=nx, 0<=j<=ny.  A cell is inside the band iff bandMin <= i-j <= bandMax

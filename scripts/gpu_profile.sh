@@ -13,7 +13,7 @@ mkdir -p gpurun_out
 echo "host: $(nproc) cores, $(free -g | awk '/Mem:/{print $2" GiB RAM"}')"
 timeout 1500 python -m pytest tests -q -m gpu --timeout 900 -p no:cacheprovider 2>&1 | tail -5
 cd /tmp && export TMPDIR=/tmp
-export PYTHONPATH=$R
+export PYTHONPATH=$R SHASTA_BENCH_WORKLOAD_CACHE=/tmp/shasta_workload
 for PASS in "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "sq2:SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   TAG=${PASS%%:*}; COUNTERS=${PASS#*:}
   rm -rf $R/gpurun_out/pmc_$TAG $R/gpurun_out/pmc_${TAG}_cal
@@ -36,15 +36,21 @@ timeout 900 python bench.py --reads $READS --steps 5 --warmup 2 --no-cpu-baselin
 timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline --align-method 3 > gpurun_out/bench_final_m3.json 2> gpurun_out/bench_final_m3.err
 timeout 900 python bench.py --reads 20000 --steps 3 --warmup 1 --markers > gpurun_out/bench_final_markers.json 2> gpurun_out/bench_final_markers.err
 SHASTA_MI355X_ALIGN_WORKERS=1 timeout 900 python bench.py --reads $READS --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_final_w1.json 2> gpurun_out/bench_final_w1.err
+# The in-process group over one device (the seam a C++ caller uses), and the reference aligner on the WHOLE candidate list.
+timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --group --gpus 1 > gpurun_out/bench_final_group1.json 2> gpurun_out/bench_final_group1.err
+( time timeout 1500 python bench.py --reads $READS --steps 2 --warmup 1 --baseline-sample 0 --tie-census 0 > gpurun_out/bench_final_whole_baseline.json 2> gpurun_out/bench_final_whole_baseline.err ) 2>&1 | grep real
 find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
 python - <<PY
 import json
-for f in ["bench_final", "bench_final_lh", "bench_final_m3", "bench_final_markers", "bench_final_w1"]:
+for f in ["bench_final", "bench_final_lh", "bench_final_m3", "bench_final_markers", "bench_final_w1", "bench_final_group1", "bench_final_whole_baseline"]:
     try:
         d = json.loads(open("gpurun_out/%s.json" % f).read().strip().splitlines()[-1])
         print(f, d["metric"], "value %.0f" % d["value"], "ms/step %.1f" % d["ms_per_step"], d.get("stage_seconds_per_step"))
         if f == "bench_final":
             print("   cpu_baseline", json.dumps(d["cpu_baseline"])[:500]); print("   parity", d["parity_at_bench_size"]); print("   roofline", json.dumps(d["roofline"])[:900])
+            print("   dp_tie_sensitive", json.dumps({k: v for k, v in d["dp_tie_sensitive"].items() if k != "per_policy"}))
+        if f == "bench_final_whole_baseline":
+            print("   cpu_baseline", json.dumps(d["cpu_baseline"])[:700]); print("   parity", d["parity_at_bench_size"])
     except Exception as e:
         print(f, "unreadable", e)
 PY

@@ -287,8 +287,9 @@ struct DpEvents {
     void destroy() { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
 };
 struct DpBatchStats { uint64_t cells[DP_CLASSES] = {0}, bytes[DP_CLASSES] = {0}; uint32_t tasks[DP_CLASSES] = {0}; };
-const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2>", "bandedDpForwardKernel<12, 4>", "bandedDpForwardKernel<16, 4>",
-    "bandedDpForwardKernel<20, 4>", "bandedDpForwardKernel<32, 4>", "bandedDpForwardKernel<64, 4>", "bandedDpForwardKernel<64, 8>", "bandedDpForwardKernel<64, 16>"};
+// (the names a profiler shows for the default instances: tie policy DP_TIE_POLICY = 0, compile-time scores)
+const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2, 0, false>", "bandedDpForwardKernel<12, 4, 0, false>", "bandedDpForwardKernel<16, 4, 0, false>",
+    "bandedDpForwardKernel<20, 4, 0, false>", "bandedDpForwardKernel<32, 4, 0, false>", "bandedDpForwardKernel<64, 4, 0, false>", "bandedDpForwardKernel<64, 8, 0, false>", "bandedDpForwardKernel<64, 16, 0, false>"};
 
 // Forward half of K10 for taskCount tasks: sort by (band class, iterations), bundle, lay out the
 // trace, run the forward kernel of every class.  Leaves b.trace / b.ends for a traceback kernel.

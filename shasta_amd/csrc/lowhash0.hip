@@ -676,17 +676,17 @@ const char* hashKernelName(uint32_t m, bool all = false)
 {
     if(all) {
         switch(m) {
-            case 3: return "hashWindowsKernel<3, true> (all iterations)";
-            case 4: return "hashWindowsKernel<4, true> (all iterations)";
-            case 5: return "hashWindowsKernel<5, true> (all iterations)";
-            default: return "hashWindowsKernel<0, true> (any m, all iterations)";
+            case 3: return "hashWindowsKernel<3, true>";           // (true: all iterations in one pass; the names a profiler shows)
+            case 4: return "hashWindowsKernel<4, true>";
+            case 5: return "hashWindowsKernel<5, true>";
+            default: return "hashWindowsKernel<0, true>";
         }
     }
     switch(m) {
-        case 3: return "hashWindowsKernel<3>";
-        case 4: return "hashWindowsKernel<4>";
-        case 5: return "hashWindowsKernel<5>";
-        default: return "hashWindowsKernel<0> (any m)";
+        case 3: return "hashWindowsKernel<3, false>";
+        case 4: return "hashWindowsKernel<4, false>";
+        case 5: return "hashWindowsKernel<5, false>";
+        default: return "hashWindowsKernel<0, false>";
     }
 }
 

@@ -13,11 +13,11 @@ from shasta_amd import abi
 
 
 FAKE_TABLE = {
-    "hashWindowsKernel<4>": {"seconds": 0.02, "launches": 20, "bytes": 20 * 1_250_000_000, "work": 20 * 300_000_000},
+    "hashWindowsKernel<4, true>": {"seconds": 0.02, "launches": 20, "bytes": 20 * 1_250_000_000, "work": 20 * 300_000_000},
     "radix sort of low-hash records": {"seconds": 0.004, "launches": 20, "bytes": 20 * 300_000_000, "work": 20 * 3_000_000},
     "align4CellsChunkKernel<2, false>": {"seconds": 0.22, "launches": 64, "bytes": 64 * 500_000_000, "work": 3_000_000},
     "bandedDpForwardKernel<16, 2>": {"seconds": 0.08, "launches": 32, "bytes": 32 * 296_000_000, "work": int(3e10)},
-    "bandedDpForwardKernel<16, 4>": {"seconds": 0.28, "launches": 32, "bytes": 32 * 1_186_000_000, "work": int(2.2e11)},
+    "bandedDpForwardKernel<16, 4, 0, false>": {"seconds": 0.28, "launches": 32, "bytes": 32 * 1_186_000_000, "work": int(2.2e11)},
     "bandedDpForwardKernel<32, 4>": {"seconds": 0.20, "launches": 32, "bytes": 32 * 353_000_000, "work": int(1.1e11)},
     "dpTracebackKernel": {"seconds": 0.16, "launches": 32, "bytes": 32 * 1_800_000_000, "work": 32 * 150_000},
 }
@@ -73,8 +73,8 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     # Counters as scripts/pmc_summary.py writes them, for the workload of this run.
     pmc = tmp_path / "pmc.json"
     pmc.write_text(json.dumps({"workload_reads": 100000, "kernels": {
-        "bandedDpForwardKernel<16, 4>": {"hbm_bytes_per_launch": 2.6e9, "valu_wave_instructions_per_launch": 2.3e9},
-        "hashWindowsKernel<4>": {"hbm_bytes_per_launch": 1.5e9, "valu_wave_instructions_per_launch": 3.6e8}}}))
+        "bandedDpForwardKernel<16, 4, 0, false>": {"hbm_bytes_per_launch": 2.6e9, "valu_wave_instructions_per_launch": 2.3e9},
+        "hashWindowsKernel<4, true>": {"hbm_bytes_per_launch": 1.5e9, "valu_wave_instructions_per_launch": 3.6e8}}}))
     monkeypatch.setattr(bench, "PMC_FILE", str(pmc))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--reads", "100000"])
@@ -93,13 +93,13 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # The dominant kernel of the fake table is the <= 64-diagonal DP class: integer VALU work, with the measured
     # instruction count of the PMC file over the live launch time as its VALU fraction.
-    assert r["kernel"] == "bandedDpForwardKernel<16, 4>" and r["bound"] == "valu" and r["traffic"] == 2.6e9
+    assert r["kernel"] == "bandedDpForwardKernel<16, 4, 0, false>" and r["bound"] == "valu" and r["traffic"] == 2.6e9
     assert r["valu"]["frac"] == pytest.approx(2.3e9 / (0.28 / 32) / bench.VALU_PEAK_WAVE_INSTRUCTIONS_PER_S)
     k = d["kernels"]
-    assert k["hashWindowsKernel<4>"]["launches_per_step"] == 10 and k["hashWindowsKernel<4>"]["avg_ms"] == pytest.approx(1.0)
-    assert k["hashWindowsKernel<4>"]["achieved_GBps"] == pytest.approx(1250.0)
+    assert k["hashWindowsKernel<4, true>"]["launches_per_step"] == 10 and k["hashWindowsKernel<4, true>"]["avg_ms"] == pytest.approx(1.0)
+    assert k["hashWindowsKernel<4, true>"]["achieved_GBps"] == pytest.approx(1250.0)
     assert sum(v["share_of_kernel_time"] for v in k.values()) == pytest.approx(1.0)
-    assert d["hbm_natured_kernel"]["kernel"] == "hashWindowsKernel<4>" and d["hbm_natured_kernel"]["traffic"] == 1.5e9
+    assert d["hbm_natured_kernel"]["kernel"] == "hashWindowsKernel<4, true>" and d["hbm_natured_kernel"]["traffic"] == 1.5e9
     assert d["aligner_status"]["stored"] == 999 and d["aligner_status"]["rejected_by_filters"] == 1
     assert d["cpu_baseline"]["cores"] == 64 and d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)
 
