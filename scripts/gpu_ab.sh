@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of builds and switches in ONE GPU call, same box, same read set (cached in /tmp for the call).
 #   usage: scripts/gpu_ab.sh "<tag>|<build dir under shasta_amd/, empty = _build>|<ENV=V ...>" ...
-#   env:   STEPS (4) WARMUP (2) READS (100000) PATTERN (regex of kernel rows to print; default: every kernel above 2 ms solo)
+#   env:   TIMEOUT (600 s per variant) STEPS (4) WARMUP (2) READS (100000) PATTERN (regex of kernel rows to print; default: every kernel above 2 ms solo)
 # Per variant: the bench line (no CPU baseline) -> gpurun_out/ab_<tag>.json, one summary row per kernel (in the step and solo).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -9,7 +9,7 @@ export SHASTA_BENCH_WORKLOAD_CACHE=/tmp/shasta_workload
 for SPEC in "$@"; do
   TAG=$(echo "$SPEC" | cut -d'|' -f1); DIR=$(echo "$SPEC" | cut -d'|' -f2); ENVS=$(echo "$SPEC" | cut -d'|' -f3)
   LIB=$GRAFT_REPO_ROOT/shasta_amd/${DIR:-_build}/libshasta_mi355x.so
-  env $ENVS SHASTA_MI355X_LIBRARY=$LIB timeout 600 python bench.py --reads ${READS:-100000} --steps ${STEPS:-4} --warmup ${WARMUP:-2} --no-cpu-baseline > gpurun_out/ab_$TAG.json 2> gpurun_out/ab_$TAG.err
+  env $ENVS SHASTA_MI355X_LIBRARY=$LIB timeout ${TIMEOUT:-600} python bench.py --reads ${READS:-100000} --steps ${STEPS:-4} --warmup ${WARMUP:-2} --no-cpu-baseline > gpurun_out/ab_$TAG.json 2> gpurun_out/ab_$TAG.err
   echo "== $TAG rc=$? ($ENVS ${DIR:-_build})"
   TAG=$TAG PATTERN="$PATTERN" python - <<'PY'
 import json, os, re

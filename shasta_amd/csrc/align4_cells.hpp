@@ -315,11 +315,11 @@ align4CellsKernel(
 // (candidates arrive sorted by readId0, src/LowHash0.cpp:204-214, and read 0 is always on
 // strand 0, src/AssemblerAlign.cpp:382) or, when read 1 is the shorter one, read 1 ("swapped",
 // gathered by the host).  One workgroup of W wavefronts per chunk.  The whole workgroup works on ONE candidate at a time:
-//   build   all wavefronts copy the shared read's kmer ids to LDS and index them by a two-choice bucketised LDS hash
-//           table (buckets of four 16-bit slots = one ds_read_b64; slot = hash tag | ordinal), once per chunk;
+//   build   all wavefronts index the shared read's markers in an EXACT bucketed LDS table, once per chunk: a counting sort
+//           of (rest of hash | ordinal) words by the top bits of kmerId * odd constant (a bijection: bucket + rest = the kmer
+//           id, so a match needs no second look);
 //   probe   a candidate's other read is streamed through the table, four markers per lane per round, every W-th round
-//           by the same wavefront: both buckets are read, the eight slots are tag-matched with SWAR compares,
-//           the kmer ids are compared in LDS: fixed trip count, no probe chains;
+//           by the same wavefront: a marker walks the entries of its bucket, matches wait in a queue of the wavefront;
 //   count   (x,y) -> cell by magic-number division (getXY + createCells, src/Align4.cpp:171-177,380-436), one LDS
 //           atomic per hit into ONE cell region shared by the wavefronts (LDS atomics work across them); the
 //           increment that reaches minEntryCountPerCell appends the cell to the candidate's kept list (:417);
@@ -333,8 +333,8 @@ align4CellsKernel(
 // wavefronts per CU): the kernel is bound by the latency of its dependent LDS chains, so wavefronts per CU decide.
 // Candidates that overflow a table or the kept list are flagged PAIR_RESOURCE and retried in a
 // larger class, finally by align4CellsKernel<true>.
-// Dynamic LDS (32-bit words): aKmers[NA] | aSlots[NA] (2 NA 16-bit slots) | cells[SC] (one byte per cell of the grid,
-//   or iY | iX | count packed) | per wavefront a slot: kept[64 Q] (the graph's cell map[128 Q] later) | scratch[8] | stage[4 CELLS_STAGE].
+// Dynamic LDS (32-bit words): range[NA << (F - 1)] (16-bit bucket starts, 2^F NA buckets, F = cellsBucketFactorLog2(Q)) | entries[NA] | cells[SC] (one byte
+//   per cell of the grid, or iY | iX | count packed) | per wavefront a slot (cellsSlotLdsWords).
 // ---------------------------------------------------------------------------
 // firstMember indexes the member list (candidate indices of the batch).
 struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };      // swapped: bit 0 = read 1 is the tabled one, bit 1 = count in the packed table even if the byte grid would fit
@@ -345,17 +345,20 @@ __device__ unsigned long long g_phaseCycles[16];
     if((threadIdx.x & 63) == 0) atomicAdd(&g_phaseCycles[k], now_ - phaseT_); phaseT_ = now_; } while(0)
 #define PHASE_BEGIN() unsigned long long phaseT_ = __builtin_readcyclecounter()
 // Inside the stream loop: cycles of probe [7], first resolve pass [8], counting [9], further matches [10]; rounds [11],
-// iterations of the further-matches loop [12], count calls [13].
+// iterations of the further-matches loop [12], count calls [13].  (Exact table: [9] = matches queued, [11] rounds, [12] trips of
+// the loop over the buckets' entries, [13] drains of a full queue, [14] drains at the end of a candidate.)
 #define SUBPHASE_DECLARE() unsigned long long sub_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, subT_ = 0
 #define SUBPHASE_START() subT_ = __builtin_readcyclecounter()
 #define SUBPHASE_ADD(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); sub_[k] += now_ - subT_; subT_ = now_; } while(0)
 #define SUBPHASE_COUNT(k) (++sub_[k])
+#define SUBPHASE_COUNT_N(k, n) (sub_[k] += (n))
 #define SUBPHASE_FLUSH() do { if((threadIdx.x & 63) == 0) for(int k_ = 0; k_ < 8; k_++) atomicAdd(&g_phaseCycles[7 + k_], sub_[k_]); for(int k_ = 0; k_ < 8; k_++) sub_[k_] = 0; } while(0)
 #else
 #define SUBPHASE_DECLARE() do {} while(0)
 #define SUBPHASE_START() do {} while(0)
 #define SUBPHASE_ADD(k) do {} while(0)
 #define SUBPHASE_COUNT(k) do {} while(0)
+#define SUBPHASE_COUNT_N(k, n) do {} while(0)
 #define SUBPHASE_FLUSH() do {} while(0)
 #define PHASE_MARK(k) do {} while(0)
 #define PHASE_BEGIN() do {} while(0)
@@ -374,32 +377,46 @@ __device__ __forceinline__ void waveLdsSync()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ uint32_t hash32b(uint32_t k) { return k * 0x85ebca6bu; }
+// A word of LDS that other lanes change by atomics, read NOW (the compiler must not reuse an earlier value): a relaxed atomic
+// load, which stays a ds_read_b32.  A `volatile` access does not -- the address-space inference leaves volatile accesses
+// alone, so `*(volatile uint32_t*)&cells[k]` was a flat_load_dword sc0 sc1 followed by s_waitcnt vmcnt(0) lgkmcnt(0): a trip
+// through the flat path that also waited for every global load in flight (the next round's markers), once per counted slot,
+// in rounds 2 and 3 alike (found in the ISA, scripts/isa_loop.py does not tell the two apart).
+__device__ __forceinline__ uint32_t ldsLoadNow(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 
-// Bits 0 and 16 of the result flag the 16-bit halves of v that are zero: a packed 16-bit minimum with 1 (v_pk_min_u16) leaves
-// 0 in a zero half and 1 in any other; two instructions where the carry-free SWAR form took four.
-__device__ __forceinline__ uint32_t zeroHalves(uint32_t v) { return packedMinU16(v, 0x00010001u) ^ 0x00010001u; }
-constexpr uint32_t LOW_HALF = 1u, HIGH_HALF = 0x10000u;
-
-#ifndef SHASTA_CELLS_EXACT_TABLE
-#define SHASTA_CELLS_EXACT_TABLE 1
+// Buckets of the exact table per marker the tabled read may have (log2): 2 NA buckets, load factor below 1/2 (the loop over
+// a bucket's entries runs as long as the fullest bucket among a round's 256 markers: 3.7 trips per round at 100 k reads).
+#ifndef SHASTA_CELLS_BUCKET_FACTOR_LOG2
+#define SHASTA_CELLS_BUCKET_FACTOR_LOG2 1
 #endif
+static_assert(SHASTA_CELLS_BUCKET_FACTOR_LOG2 >= 1 && SHASTA_CELLS_BUCKET_FACTOR_LOG2 <= 3, "bucket starts are 16-bit halves, two to a word");
+// (The class with the largest cell region, Q = 4, has no LDS to spare: two buckets per marker there whatever the others get.)
+__host__ __device__ constexpr int cellsBucketFactorLog2(int Q) { return Q >= 4 ? 1 : SHASTA_CELLS_BUCKET_FACTOR_LOG2; }
+#ifndef SHASTA_CELLS_DRAIN
+#define SHASTA_CELLS_DRAIN 2
+#endif
+constexpr int CELLS_DRAIN = SHASTA_CELLS_DRAIN;      // queue entries a lane counts per pass
+constexpr int CELLS_RANGE_PAD = 4;        // words behind the bucket starts: the first holds the end of the last bucket (a marker reads starts[b] and starts[b + 1])
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
-#ifndef SHASTA_CELLS_FURTHER
-#define SHASTA_CELLS_FURTHER 2
-#endif
-constexpr int CELLS_FURTHER = SHASTA_CELLS_FURTHER;   // further matches a lane takes per iteration after the first pass
 constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
 constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
+// A wavefront's slot: kept[64 Q] | queue[max(64 Q, CELLS_QUEUE)] (both the graph's cell map[128 Q] later) | scratch[8] | stage[4 CELLS_STAGE].
+// The queue takes the matches of one trip of all CELLS_UNROLL groups of a round at once: at most CELLS_UNROLL * 64.
+constexpr int CELLS_QUEUE = CELLS_UNROLL * 64;
+__host__ __device__ inline size_t cellsQueueWords(int Q) { return size_t(64 * Q > CELLS_QUEUE ? 64 * Q : CELLS_QUEUE); }
 __host__ __device__ inline size_t cellsSlotLdsWords(int Q)
 {
-    return 128 * size_t(Q) + 8 + 4 * CELLS_STAGE;
+    return 64 * size_t(Q) + cellsQueueWords(Q) + 8 + 4 * CELLS_STAGE;
 }
 __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int Q, int waves)
 {
-    return 2 * (size_t(1) << naLog2) + (size_t(1) << scLog2) + size_t(waves) * cellsSlotLdsWords(Q);
+    return ((size_t(1) << naLog2) << (cellsBucketFactorLog2(Q) - 1)) + CELLS_RANGE_PAD + (size_t(1) << naLog2) + (size_t(1) << scLog2) + size_t(waves) * cellsSlotLdsWords(Q);
 }
 
+#ifndef SHASTA_ABLATE
+#define SHASTA_ABLATE 0          // timing experiments (wrong results): 1 = without the kept-cell graphs, 2 = without the stream,
+                                 // 3 = without the two barriers per candidate, 4 = matches queued but not counted, 5 = without the loop over the buckets' entries
+#endif
 #ifndef SHASTA_CELLS_MAX_THREADS
 #define SHASTA_CELLS_MAX_THREADS 384
 #endif
@@ -428,14 +445,7 @@ align4CellsChunkKernel(
     uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts)
 {
     extern __shared__ uint32_t ldsWords[];
-#if SHASTA_CELLS_EXACT_TABLE
     __shared__ uint32_t waveTotals[SHASTA_CELLS_MAX_THREADS / 64];
-#else
-    // Markers whose two buckets were both full when they arrived (the two-choice table runs at two
-    // entries per four-slot bucket on average, so a nearly full table overflows now and then).
-    constexpr uint32_t STASH = 32;
-    __shared__ uint32_t stashCount, stashKmer[STASH], stashOrdinal[STASH];
-#endif
     constexpr int MAXC = 64 * Q;
     if(blockIdx.x >= chunkCount) return;
     const CellsChunk chunk = chunks[blockIdx.x];
@@ -444,34 +454,25 @@ align4CellsChunkKernel(
     const uint32_t NA = 1u << chunk.naLog2, SC = 1u << chunk.scLog2;
     const int xBits = int(chunk.naLog2), scShift = 32 - int(chunk.scLog2);
     const uint32_t xMask = NA - 1;
-#if SHASTA_CELLS_EXACT_TABLE
-    const int bucketShift = 32 - (xBits + 1);                     // 2 NA buckets
+    constexpr int F = cellsBucketFactorLog2(Q);
+    const int bucketShift = 32 - (xBits + F);                     // 2^F NA buckets
+    const uint32_t bucketCount = NA << F, rangeWords = bucketCount >> 1;
     uint32_t* const range = ldsWords;                             // 16-bit halves: where bucket b's entries start (its end while the table is built)
-    uint32_t* const entries = range + NA;                         // (hash32(kmer id) << xBits) | ordinal, bucket after bucket
+    uint32_t* const entries = range + rangeWords + CELLS_RANGE_PAD;                         // (hash32(kmer id) << xBits) | ordinal, bucket after bucket
     uint32_t* const cells = entries + NA;
-#else
-    const int bucketShift = 32 - (int(chunk.naLog2) - 1);
-    const uint32_t tagMask = (1u << (16 - xBits)) - 1;
-    uint32_t* const aKmers = ldsWords;
-    uint32_t* const aSlots = aKmers + NA;
-    uint32_t* const cells = aSlots + NA;
-#endif
     uint32_t* const slots = cells + SC;                           // slot w: kept[MAXC], later the map[2 MAXC] of the graph | scratch[8] | stage[4 CELLS_STAGE]
     // The slot the candidate being streamed appends its kept cells to (every wavefront), and this wavefront's own slot
     // (graph of the candidate it was given, staged tasks).  scratch: [0] kept count, [1] min, [2] max, [3] staged tasks,
     // [4] what went wrong while streaming.
+    const uint32_t scratchAt = uint32_t(MAXC + cellsQueueWords(Q));
     uint32_t* kept = slots;
-    uint32_t* scratch = kept + 2 * MAXC;
+    uint32_t* scratch = kept + scratchAt;
     uint32_t* const ownKept = slots + wave * cellsSlotLdsWords(Q);
-    uint32_t* const ownScratch = ownKept + 2 * MAXC;
+    uint32_t* const ownScratch = ownKept + scratchAt;
     uint32_t* const stage = ownScratch + 8;
     const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
     PHASE_BEGIN();
 
-#if !SHASTA_CELLS_EXACT_TABLE
-    // Tag of a kmer id (never all ones, so that an empty slot matches no tag) and its two buckets.
-    auto tagOf = [&](uint32_t h) { const uint32_t t = (h >> 4) & tagMask; return t == tagMask ? 0u : t; };
-#endif
 
     // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
     //     candidates gathered by the host because they share a short read 1) read 1 ---
@@ -479,26 +480,35 @@ align4CellsChunkKernel(
     const bool swapped = (chunk.swapped & 1) != 0, noGrid = (chunk.swapped & 2) != 0;
     const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
     const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
-#if SHASTA_CELLS_EXACT_TABLE
     // The exact bucketed table: h = kmerId * odd constant is a bijection of the 32-bit values, so (bucket = the top bits of h, the
-    // other bits of h) IS the kmer id.  2 NA buckets for at most NA markers (load factor below 1/2: the loop over a bucket's
+    // other bits of h) IS the kmer id.  2^F NA buckets (F = cellsBucketFactorLog2(Q) = 1) for at most NA markers (load factor below 1/2: the loop over a bucket's
     // entries below runs as long as the fullest bucket of a round's 256 markers); an entry -- the other bits of h | the
     // ordinal -- is one word, the buckets are the segments of one array, and where they start is a table of 16-bit positions,
     // two to a word.  A counting sort: the sizes by LDS atomics on the halves, one scan that leaves every bucket's END, and the
     // fill counts each end down to the bucket's start (the reference's own way of filling its buckets,
     // MemoryMappedVectorOfVectors::storeMultithreaded) -- no compare-and-swap loops, nothing that can overflow.
-    for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) range[k] = 0;
+    for(uint32_t k = threadIdx.x; k < rangeWords; k += blockDim.x) range[k] = 0;
     if(lane == 0) ownScratch[3] = 0;
     __syncthreads();
-    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
-        const uint32_t b = hash32(tabSeq[t]) >> bucketShift;
-        atomicAdd(&range[b >> 1], (b & 1u) ? 0x10000u : 1u);
+    // (Four markers per thread and trip, loaded before any is used: one marker per trip waited for memory every trip.)
+    const uint32_t tabLast = tabCount ? tabCount - 1u : 0u;
+    const uint32_t* __restrict__ const tabSafe = tabCount ? tabSeq : kmerIds;
+    for(uint32_t t0 = threadIdx.x; t0 < tabCount; t0 += 4u * blockDim.x) {
+        uint32_t km[4];
+#pragma unroll
+        for(int u = 0; u < 4; u++) km[u] = tabSafe[min(t0 + uint32_t(u) * blockDim.x, tabLast)];
+#pragma unroll
+        for(int u = 0; u < 4; u++) {
+            if(t0 + uint32_t(u) * blockDim.x >= tabCount) continue;
+            const uint32_t b = hash32(km[u]) >> bucketShift;
+            atomicAdd(&range[b >> 1], (b & 1u) ? 0x10000u : 1u);
+        }
     }
     __syncthreads();
     {
-        const uint32_t per = (NA + blockDim.x - 1) / blockDim.x, first = threadIdx.x * per;
+        const uint32_t per = (rangeWords + blockDim.x - 1) / blockDim.x, first = threadIdx.x * per;
         uint32_t sum = 0;
-        for(uint32_t k = first; k < min(first + per, NA); k++) { const uint32_t w = range[k]; sum += (w & 0xffffu) + (w >> 16); }
+        for(uint32_t k = first; k < min(first + per, rangeWords); k++) { const uint32_t w = range[k]; sum += (w & 0xffffu) + (w >> 16); }
         uint32_t inclusive = sum;
 #pragma unroll
         for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
@@ -506,67 +516,32 @@ align4CellsChunkKernel(
         __syncthreads();
         uint32_t base = inclusive - sum;
         for(uint32_t w = 0; w < wave; w++) base += waveTotals[w];
-        for(uint32_t k = first; k < min(first + per, NA); k++) {
+        for(uint32_t k = first; k < min(first + per, rangeWords); k++) {
             const uint32_t w = range[k];
             const uint32_t endLow = base + (w & 0xffffu), endHigh = endLow + (w >> 16);
             range[k] = endLow | (endHigh << 16);
             base = endHigh;
         }
+        if(threadIdx.x == 0) range[rangeWords] = tabCount;                 // starts[bucketCount]: where the last bucket ends
     }
     __syncthreads();
-    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
-        const uint32_t h = hash32(tabSeq[t]);
-        const uint32_t b = h >> bucketShift;
-        const uint32_t old = atomicAdd(&range[b >> 1], (b & 1u) ? 0xffff0000u : 0xffffffffu);       // (minus one in the half: a low half never borrows, it counts down to its bucket's start)
-        entries[((b & 1u) ? old >> 16 : old & 0xffffu) - 1u] = (h << (32 - bucketShift)) | t;
-    }
-    __syncthreads();
-    PHASE_MARK(0);
-
-#else
-    for(uint32_t k = threadIdx.x; k < NA; k += blockDim.x) aSlots[k] = 0xffffffffu;
-    if(threadIdx.x == 0) stashCount = 0;
-    if(lane == 0) ownScratch[3] = 0;
-    __syncthreads();
-    for(uint32_t t = threadIdx.x; t < tabCount; t += blockDim.x) {
-        const uint32_t km = tabSeq[t];
-        aKmers[t] = km;
-        const uint32_t h = hash32(km);
-        const uint32_t b1 = h >> bucketShift, b2 = hash32b(km) >> bucketShift;
-        const uint32_t entry = (tagOf(h) << xBits) | t;
-        for(;;) {
-            // Free slots of the two candidate buckets; take the emptier bucket (ties: the first).
-            const uint32_t u0 = aSlots[2 * b1], u1 = aSlots[2 * b1 + 1], v0 = aSlots[2 * b2], v1 = aSlots[2 * b2 + 1];
-            const uint32_t fu0 = zeroHalves(~u0), fu1 = zeroHalves(~u1), fv0 = zeroHalves(~v0), fv1 = zeroHalves(~v1);
-            const int freeU = __popc(fu0) + __popc(fu1), freeV = __popc(fv0) + __popc(fv1);
-            if(freeU == 0 && freeV == 0) {
-                const uint32_t k = atomicAdd(&stashCount, 1u);
-                if(k < STASH) { stashKmer[k] = km; stashOrdinal[k] = t; }
-                break;
-            }
-            const bool useV = freeV > freeU;
-            const uint32_t f0 = useV ? fv0 : fu0, f1 = useV ? fv1 : fu1;
-            const uint32_t w0 = useV ? v0 : u0, w1 = useV ? v1 : u1;
-            const uint32_t base = 2 * (useV ? b2 : b1);
-            const bool second = f0 == 0;
-            const uint32_t f = second ? f1 : f0, old = second ? w1 : w0;
-            const int shift = (f & LOW_HALF) ? 0 : 16;
-            const uint32_t updated = (old & ~(0xffffu << shift)) | (entry << shift);
-            if(atomicCAS(&aSlots[base + (second ? 1 : 0)], old, updated) == old) break;
+    for(uint32_t t0 = threadIdx.x; t0 < tabCount; t0 += 4u * blockDim.x) {
+        uint32_t km[4];
+#pragma unroll
+        for(int u = 0; u < 4; u++) km[u] = tabSafe[min(t0 + uint32_t(u) * blockDim.x, tabLast)];
+#pragma unroll
+        for(int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + uint32_t(u) * blockDim.x;
+            if(t >= tabCount) continue;
+            const uint32_t h = hash32(km[u]);
+            const uint32_t b = h >> bucketShift;
+            const uint32_t old = atomicAdd(&range[b >> 1], (b & 1u) ? 0xffff0000u : 0xffffffffu);   // (minus one in the half: a low half never borrows, it counts down to its bucket's start)
+            entries[((b & 1u) ? old >> 16 : old & 0xffffu) - 1u] = (h << (32 - bucketShift)) | t;
         }
     }
     __syncthreads();
     PHASE_MARK(0);
-    const uint32_t stashed = stashCount;
-    if(stashed > STASH) {
-        // Too many markers of the tabled read share their buckets (a tandem repeat): the whole
-        // chunk goes to the next class.
-        if(DUMP) { if(threadIdx.x == 0) activeCounts[blockIdx.x] = 0xffffffffu; return; }
-        for(uint32_t c = threadIdx.x; c < chunk.count; c += blockDim.x) pairFlags[members[chunk.firstMember + c]] = uint8_t(PAIR_RESOURCE | 0x10);        // (booked with the cell tables that overflow: the chunk climbs a class)
-        return;
-    }
 
-#endif
     // The stream in groups of 64 markers dealt to the wavefronts in turn (group g to wavefront g mod waves: every wavefront
     // gets the same number of groups, give or take one); a wavefront takes CELLS_UNROLL of its groups per round, and a slot of
     // the last round whose group lies beyond the stream is skipped (wavefront-uniform).  Slot u of the round that starts at
@@ -590,7 +565,7 @@ align4CellsChunkKernel(
         const bool more = c + 1 < uint32_t(chunk.count);
         if(more) { pairAhead = members[chunk.firstMember + c + 1]; pdAhead = pairs[pairAhead]; }
         kept = slots + (c - group) * cellsSlotLdsWords(Q);
-        scratch = kept + 2 * MAXC;
+        scratch = kept + scratchAt;
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
@@ -615,7 +590,7 @@ align4CellsChunkKernel(
             }
             if(first == 0) { scratch[0] = 0; scratch[4] = 0; scratch[5] = pair; scratch[6] = nx; scratch[7] = ny; }   // [5..7]: for the graph
         }
-        __syncthreads();
+        if(SHASTA_ABLATE != 3) __syncthreads();
         PHASE_MARK(1);
 
         // --- alignment matrix entries -> per-cell counts (createAlignmentMatrix + createCells) ---
@@ -636,17 +611,24 @@ align4CellsChunkKernel(
             if(useGrid) {
                 // All reads, then all atomics, then the (rare) threshold crossings: the LDS operations of the N slots are
                 // independent of each other, their latencies overlap.
-                uint32_t word[N], shift[N], before[N];
+                uint32_t word[N], shift[N], now[N], raw[N], before[N];
                 bool add[N];
 #pragma unroll
                 for(int u = 0; u < N; u++) {
                     const uint32_t idx = iY[u] * gridX + iX[u];
                     word[u] = pending[u] ? idx >> 2 : 0u; shift[u] = 8u * (idx & 3u);
                 }
+                // (Unconditional reads, and the atomics' results looked at only after the last one is issued: behind `pending &&`
+                // and inside the select each operation sat in its own branch with its own wait -- four LDS round trips one after
+                // the other where two are needed.)
 #pragma unroll
-                for(int u = 0; u < N; u++) add[u] = pending[u] && ((*reinterpret_cast<volatile uint32_t*>(&cells[word[u]]) >> shift[u]) & 0xffu) < threshold;
+                for(int u = 0; u < N; u++) now[u] = ldsLoadNow(&cells[word[u]]);
 #pragma unroll
-                for(int u = 0; u < N; u++) before[u] = add[u] ? (atomicAdd(&cells[word[u]], 1u << shift[u]) >> shift[u]) & 0xffu : 0xffffu;
+                for(int u = 0; u < N; u++) { add[u] = pending[u] && ((now[u] >> shift[u]) & 0xffu) < threshold; raw[u] = 0; }
+#pragma unroll
+                for(int u = 0; u < N; u++) if(add[u]) raw[u] = atomicAdd(&cells[word[u]], 1u << shift[u]);
+#pragma unroll
+                for(int u = 0; u < N; u++) before[u] = add[u] ? (raw[u] >> shift[u]) & 0xffu : 0xffffu;
 #pragma unroll
                 for(int u = 0; u < N; u++) {
                     if(before[u] + 1 == threshold) {                                          // :417
@@ -675,7 +657,7 @@ align4CellsChunkKernel(
 #pragma unroll
                 for(int u = 0; u < N; u++) {
                     if(pending[u]) {
-                        const uint32_t cur = *reinterpret_cast<volatile uint32_t*>(&cells[cs[u]]);
+                        const uint32_t cur = ldsLoadNow(&cells[cs[u]]);
                         bool done = false;
                         uint32_t before = 0;
                         if(cur != EMPTY32 && (cur >> CELLS_COUNT_BITS) == packed[u]) {
@@ -702,33 +684,36 @@ align4CellsChunkKernel(
         };
 
         uint32_t kmNext[CELLS_UNROLL];
+        // (Unconditional loads from a clamped position: behind a branch the compiler cannot count the loads in flight and
+        // waits for all of them -- vmcnt(0) right after issuing the next round's -- where the marker it needs arrived long ago.)
+        const uint32_t* __restrict__ const streamSafe = streamCount ? stream : kmerIds;
+        const uint32_t streamLast = streamCount ? streamCount - 1u : 0u;
 #pragma unroll
-        for(int u = 0; u < CELLS_UNROLL; u++) { const uint32_t t = firstRound + u * groupStride + lane; kmNext[u] = t < streamCount ? stream[t] : 0u; }
+        for(int u = 0; u < CELLS_UNROLL; u++) kmNext[u] = streamSafe[min(firstRound + u * groupStride + lane, streamLast)];
         SUBPHASE_DECLARE();
-#ifndef SHASTA_ABLATE
-#define SHASTA_ABLATE 0          // timing experiments (wrong results): 1 = without the kept-cell graphs, 2 = without the stream
-#endif
-#if SHASTA_CELLS_EXACT_TABLE
-        // Matches wait in a queue of the wavefront (the half of its slot that the kept list does not use while candidates are
-        // streamed) and are counted 64 at a time: the loop over the entries of the markers' buckets is thin -- most lanes have
-        // nothing to look at in its later iterations -- and only finds matches; the cell arithmetic and the LDS atomics run on
+        // Matches wait in a queue of the wavefront (the part of its slot that the kept list does not use while candidates are
+        // streamed) and are counted 128 at a time: the loop over the entries of the markers' buckets is thin -- most lanes have
+        // nothing to look at in its later trips -- and only finds matches; the cell arithmetic and the LDS atomics run on
         // full wavefronts.  An entry: table ordinal << 16 | stream ordinal (both below 2^16: cellsClassFor).
         uint32_t* const queue = ownKept + MAXC;
+        const uint32_t queueCapacity = uint32_t(cellsQueueWords(Q));
         uint32_t queued = 0;                                                    // wave-uniform
         auto drain = [&]() {
             waveLdsSync();
-            constexpr int N = MAXC / WAVE;                                      // the queue holds MAXC entries
-            bool hit[N];
-            uint32_t ti[N], ts[N];
+#pragma nounroll
+            for(uint32_t base = 0; base < queued; base += uint32_t(CELLS_DRAIN) * WAVE) {   // (CELLS_DRAIN entries per lane and pass: the counting code's registers)
+                bool hit[CELLS_DRAIN];
+                uint32_t ti[CELLS_DRAIN], ts[CELLS_DRAIN];
 #pragma unroll
-            for(int k = 0; k < N; k++) {
-                const uint32_t at = uint32_t(k) * WAVE + uint32_t(lane);
-                hit[k] = at < queued;
-                const uint32_t e = queue[hit[k] ? at : 0u];
-                ti[k] = e >> 16; ts[k] = e & 0xffffu;
+                for(int k = 0; k < CELLS_DRAIN; k++) {
+                    const uint32_t at = base + uint32_t(k) * WAVE + uint32_t(lane);
+                    hit[k] = at < queued;
+                    const uint32_t e = queue[hit[k] ? at : 0u];
+                    ti[k] = e >> 16; ts[k] = e & 0xffffu;
+                }
+                if(SHASTA_ABLATE != 4) countHits(std::integral_constant<int, CELLS_DRAIN>{}, hit, ti, ts);
             }
             waveLdsSync();
-            countHits(std::integral_constant<int, N>{}, hit, ti, ts);
             queued = 0;
         };
         for(uint32_t s0 = firstRound; s0 < (SHASTA_ABLATE == 2 ? 0u : streamCount); s0 += roundStride) {
@@ -739,13 +724,12 @@ align4CellsChunkKernel(
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) {
                 const uint32_t km = kmNext[u];
-                const uint32_t tn = s0 + roundStride + u * groupStride + lane;
-                kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
+                kmNext[u] = streamSafe[min(s0 + roundStride + u * groupStride + lane, streamLast)];      // prefetch the next round
                 ts[u] = s0 + uint32_t(u) * groupStride + uint32_t(lane);
                 const uint32_t h = hash32(km);
                 const uint32_t b = h >> bucketShift;
                 const uint16_t* const starts = reinterpret_cast<const uint16_t*>(range);
-                const uint32_t begin = starts[b], end = b + 1u < 2u * NA ? uint32_t(starts[b + 1u < 2u * NA ? b + 1u : b]) : tabCount;
+                const uint32_t begin = starts[b], end = starts[b + 1u];
                 wanted[u] = h << (32 - bucketShift);
                 first[u] = begin;
                 left[u] = ts[u] < streamCount ? end - begin : 0u;
@@ -755,7 +739,7 @@ align4CellsChunkKernel(
             uint32_t e[CELLS_UNROLL];
 #pragma unroll
             for(int u = 0; u < CELLS_UNROLL; u++) e[u] = entries[left[u] != 0u ? first[u] : 0u];
-            while(__any(most != 0u)) {
+            while(SHASTA_ABLATE != 5 && __any(most != 0u)) {
                 SUBPHASE_COUNT(5);
                 bool hit[CELLS_UNROLL];
                 uint32_t packed[CELLS_UNROLL];
@@ -771,141 +755,32 @@ align4CellsChunkKernel(
 #pragma unroll
                     for(int u = 0; u < CELLS_UNROLL; u++) e[u] = entries[left[u] != 0u ? first[u] : 0u];
                 }
-                // Two markers at a time (static_assert below): ONE place where the queue is emptied, so that the counting code
-                // exists once in the loop (emptied at each of the four pushes it was inlined four times: 5000 instructions).
-                static_assert(CELLS_UNROLL == 4, "the matches of a round enter the queue two markers at a time");
-#pragma nounroll
-                for(int half = 0; half < 2; half++) {
-                    const bool hitA = half ? hit[2] : hit[0], hitB = half ? hit[3] : hit[1];
-                    const uint32_t packedA = half ? packed[2] : packed[0], packedB = half ? packed[3] : packed[1];
-                    const uint64_t votesA = __ballot(hitA), votesB = __ballot(hitB);
-                    const uint32_t countA = uint32_t(__popcll(votesA)), countB = uint32_t(__popcll(votesB));
-                    if(countA + countB == 0) continue;
-                    if(queued + countA + countB > uint32_t(MAXC)) { SUBPHASE_COUNT(6); drain(); }
-                    if(hitA) queue[queued + uint32_t(__popcll(votesA & laneMaskLt()))] = packedA;
-                    if(hitB) queue[queued + countA + uint32_t(__popcll(votesB & laneMaskLt()))] = packedB;
-                    queued += countA + countB;
-                }
-                SUBPHASE_ADD(1);
-            }
-        }
-        if(queued) drain();
-#else
-        for(uint32_t s0 = firstRound; s0 < (SHASTA_ABLATE == 2 ? 0u : streamCount); s0 += roundStride) {
-            SUBPHASE_START(); SUBPHASE_COUNT(4);
-            // matches[u]: the tag matches of marker u, bit i for the low half of its word i, bit 16 + i for the high half.
-            uint32_t km[CELLS_UNROLL], w[CELLS_UNROLL][4], matches[CELLS_UNROLL], ti[CELLS_UNROLL], ka[CELLS_UNROLL];
-            bool valid[CELLS_UNROLL], hit[CELLS_UNROLL];
+                // The matches of the four groups enter the queue together -- a ballot per group, a lane's position by the
+                // popcounts below it; the queue holds a whole trip (CELLS_QUEUE), so it is emptied at ONE place, before the
+                // trip that would not fit.  (Round 3's first form pushed two groups at a time through a loop that rebuilt the
+                // flags with selects: 56 of a trip's 116 vector instructions.)
+                uint64_t votes[CELLS_UNROLL];
+                uint32_t count[CELLS_UNROLL], total = 0;
 #pragma unroll
-            for(int u = 0; u < CELLS_UNROLL; u++) {
-                km[u] = kmNext[u];
-                const uint32_t tn = s0 + roundStride + u * groupStride + lane;
-                kmNext[u] = tn < streamCount ? stream[tn] : 0u;                  // prefetch the next round
-                valid[u] = s0 + u * groupStride + lane < streamCount;
-            }
+                for(int u = 0; u < CELLS_UNROLL; u++) { votes[u] = __ballot(hit[u]); count[u] = uint32_t(__popcll(votes[u])); total += count[u]; }
+                if(total != 0u) {
+                    if(queued + total > queueCapacity) { SUBPHASE_COUNT(6); drain(); }
+                    uint32_t at = queued;
 #pragma unroll
-            for(int u = 0; u < CELLS_UNROLL; u++) {
-                if(s0 + uint32_t(u) * groupStride >= streamCount) {                // no such group (uniform)
-                    w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0; matches[u] = 0;
-                    continue;
-                }
-                const uint32_t h = hash32(km[u]);
-                const uint32_t b1 = h >> bucketShift, b2 = hash32b(km[u]) >> bucketShift;
-                w[u][0] = aSlots[2 * b1]; w[u][1] = aSlots[2 * b1 + 1];
-                w[u][2] = aSlots[2 * b2]; w[u][3] = aSlots[2 * b2 + 1];
-                const uint32_t pattern = (tagOf(h) << xBits) * 0x00010001u, fieldMask = (tagMask << xBits) * 0x00010001u;
-                const bool same = b1 == b2;
-                const uint32_t first = zeroHalves((w[u][0] ^ pattern) & fieldMask) | (zeroHalves((w[u][1] ^ pattern) & fieldMask) << 1);
-                const uint32_t second = (zeroHalves((w[u][2] ^ pattern) & fieldMask) << 2) | (zeroHalves((w[u][3] ^ pattern) & fieldMask) << 3);
-                matches[u] = valid[u] ? (same ? first : (first | second)) : 0u;
-            }
-            SUBPHASE_ADD(0);
-            // First pass: the first tag match of each of the lane's four markers, resolved against the kmer ids in LDS.
-            uint32_t ts[CELLS_UNROLL];
-            {
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) {
-                    ts[u] = s0 + uint32_t(u) * groupStride + uint32_t(lane);
-                    if(s0 + uint32_t(u) * groupStride >= streamCount) { hit[u] = false; ti[u] = 0; ka[u] = 0; continue; }
-                    // The first match: find-first-bit, then the word among the marker's four (static register indexing only).
-                    const bool cand = matches[u] != 0u;
-                    const uint32_t bit = cand ? uint32_t(__ffs(int(matches[u]))) - 1u : 0u;
-                    matches[u] &= matches[u] - 1u;
-                    const uint64_t c0 = __ballot((bit & 1u) != 0u), c1 = __ballot((bit & 2u) != 0u);
-                    const uint32_t ww = laneSelect(c1, laneSelect(c0, w[u][3], w[u][2]), laneSelect(c0, w[u][1], w[u][0]));
-                    ti[u] = ((bit & 16u) ? (ww >> 16) : ww) & xMask;
-                    ka[u] = aKmers[cand ? ti[u] : 0u];
-                    hit[u] = cand;
-                }
-                bool anyHit = false;
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = hit[u] && ka[u] == km[u]; anyHit |= hit[u]; }
-                SUBPHASE_ADD(1);
-                if(__any(anyHit)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts); }
-                SUBPHASE_ADD(2);
-            }
-            // Further matches -- a kmer that occurs more than once in the tabled read (a random marker of a 1500-marker read
-            // over the 8000-marker alphabet of k = 10 has a second occurrence with probability 0.2: a handful of the 256
-            // markers of a round), or a false tag match in front of the true one.  Half of the kernel's time went here
-            // (a build without this loop: 69 -> 35 ms solo), at 2.5 iterations per round with few lanes at work in each.  So:
-            // the match flags that are left are packed into ONE mask per lane, bit 4 u + i
-            // for the low half of word i of marker u, bit 16 + 4 u + i for the high half; an iteration takes the lane's next
-            // CELLS_FURTHER set bits -- find-first-bit, a four-level select of the word, the kmer compare in LDS -- and counts
-            // them together (independent LDS chains).  (Before: the marker, then the word, then the half were found with
-            // select chains over all sixteen words, and the flag was cleared with sixteen more, per match.)
-            {
-                uint32_t pending = 0;
-#pragma unroll
-                for(int u = CELLS_UNROLL - 1; u >= 0; u--) pending = (pending << 4) | matches[u];
-                while(__any(pending != 0u)) {
-                    SUBPHASE_COUNT(5);
-                    bool hitF[CELLS_FURTHER];
-                    uint32_t tiF[CELLS_FURTHER], tsF[CELLS_FURTHER];
-                    bool anyHit = false;
-#pragma unroll
-                    for(int f = 0; f < CELLS_FURTHER; f++) {
-                        const bool has = pending != 0u;
-                        const uint32_t bit = has ? uint32_t(__ffs(int(pending))) - 1u : 0u;
-                        pending &= pending - 1u;
-                        const uint32_t word = bit & 15u;                               // 4 u + i
-                        // Word `word` of the sixteen, kmer `word >> 2` of the four: a tree of v_cndmask on the index bits (laneSelect:
-                        // written as `b ? x : y`, or bitwise, the compiler turns the tree into an indexed load from a copy of the
-                        // words in scratch memory).
-                        const uint64_t c0 = __ballot((word & 1u) != 0u), c1 = __ballot((word & 2u) != 0u), c2 = __ballot((word & 4u) != 0u), c3 = __ballot((word & 8u) != 0u);
-                        uint32_t level1[8], level2[4], level3[2];
-#pragma unroll
-                        for(int k = 0; k < 8; k++) level1[k] = laneSelect(c0, w[k >> 1][2 * (k & 1) + 1], w[k >> 1][2 * (k & 1)]);
-#pragma unroll
-                        for(int k = 0; k < 4; k++) level2[k] = laneSelect(c1, level1[2 * k + 1], level1[2 * k]);
-#pragma unroll
-                        for(int k = 0; k < 2; k++) level3[k] = laneSelect(c2, level2[2 * k + 1], level2[2 * k]);
-                        const uint32_t ww = laneSelect(c3, level3[1], level3[0]);
-                        const uint32_t kmSel = laneSelect(c3, laneSelect(c2, km[3], km[2]), laneSelect(c2, km[1], km[0]));
-                        tiF[f] = ((bit & 16u) ? (ww >> 16) : ww) & xMask;
-                        const uint32_t kaSel = aKmers[has ? tiF[f] : 0u];
-                        hitF[f] = has && kaSel == kmSel;
-                        tsF[f] = s0 + (word >> 2) * groupStride + uint32_t(lane);
-                        anyHit |= hitF[f];
+                    for(int u = 0; u < CELLS_UNROLL; u++) {
+                        if(hit[u]) queue[at + uint32_t(__popcll(votes[u] & laneMaskLt()))] = packed[u];
+                        at += count[u];
                     }
-                    SUBPHASE_ADD(3);
-                    if(__any(anyHit)) { SUBPHASE_COUNT(6); countHits(std::integral_constant<int, CELLS_FURTHER>{}, hitF, tiF, tsF); }
-                    SUBPHASE_ADD(2);
+                    queued = at; SUBPHASE_COUNT_N(2, total);
                 }
-            }
-            // The few markers that did not fit their buckets.
-            for(uint32_t k = 0; k < stashed; k++) {
-                const uint32_t sk = stashKmer[k], so = stashOrdinal[k];
-                bool anyHit = false;
-#pragma unroll
-                for(int u = 0; u < CELLS_UNROLL; u++) { hit[u] = valid[u] && km[u] == sk; ti[u] = so; anyHit |= hit[u]; }
-                if(__any(anyHit)) countHits(std::integral_constant<int, CELLS_UNROLL>{}, hit, ti, ts);
+                SUBPHASE_ADD(1);
             }
         }
-#endif
+        if(queued) { SUBPHASE_COUNT(7); drain(); }
         SUBPHASE_FLUSH();
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
         if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason & 7) | ((reason & 8) ? 0x20u : 0u) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
-        __syncthreads();                                              // the cell region is cleared for the next candidate
+        if(SHASTA_ABLATE != 3) __syncthreads();                       // the cell region is cleared for the next candidate
         PHASE_MARK(2);
     }
 

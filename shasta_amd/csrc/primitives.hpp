@@ -26,29 +26,6 @@ __device__ __forceinline__ uint32_t reverseComplementKmerId(uint32_t kmerId, uin
     return ((__brev(high) >> (32u - k)) << k) | (__brev(low) >> (32u - k));
 }
 
-// v_pk_min_u16: the minimum of the two 16-bit halves of a and b, half by half (the compiler splits the generic vector form into
-// two 16-bit operations).  The wave64 emulator supplies its own (SHASTA_PACKED_MIN_DEFINED).
-#ifndef SHASTA_PACKED_MIN_DEFINED
-__device__ __forceinline__ uint32_t packedMinU16(uint32_t a, uint32_t b)
-{
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-#endif
-
-// v_cndmask_b32 with the lane mask of a comparison (a ballot): lane l gets ifSet where bit l of laneMask is set, else ifClear.
-// For selects the compiler must not turn into an indexed load from a scratch copy of the candidates (it does that to a tree
-// of `b ? x[2k+1] : x[2k]`, and to its bitwise form as well).  The wave64 emulator supplies its own (SHASTA_LANE_SELECT_DEFINED).
-#ifndef SHASTA_LANE_SELECT_DEFINED
-__device__ __forceinline__ uint32_t laneSelect(uint64_t laneMask, uint32_t ifSet, uint32_t ifClear)
-{
-    uint32_t r;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(ifClear), "v"(ifSet), "s"(laneMask));
-    return r;
-}
-#endif
-
 // s_store_dwordx4: 16 bytes that live in scalar registers (wave-uniform by construction: ballots) go to global memory without
 // passing through a vector register.  `address` must be wave-uniform (an SGPR pair) and 4-byte aligned.  The scalar data cache
 // is write-back: scalarStoreFlush() before the wavefront ends, or a later kernel may not see the data.

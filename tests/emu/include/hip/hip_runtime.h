@@ -239,16 +239,6 @@ __forceinline__ uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, ui
 {
     return uint32_t(((uint64_t(hi) << 32) | uint64_t(lo)) >> (8u * (c & 3u)));
 }
-// v_cndmask_b32 on a ballot (inline assembly in primitives.hpp).
-#define SHASTA_LANE_SELECT_DEFINED 1
-__forceinline__ uint32_t laneSelect(uint64_t laneMask, uint32_t ifSet, uint32_t ifClear) { return ((laneMask >> (uint32_t(threadIdx.x) & 63u)) & 1ull) ? ifSet : ifClear; }
-// v_pk_min_u16 (inline assembly in primitives.hpp).
-#define SHASTA_PACKED_MIN_DEFINED 1
-__forceinline__ uint32_t packedMinU16(uint32_t a, uint32_t b)
-{
-    const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
-    return (hi << 16) | lo;
-}
 // s_store_dwordx4 + s_dcache_wb (inline assembly in primitives.hpp): lane 0 of the wavefront stores.
 #define SHASTA_SCALAR_STORE_DEFINED 1
 __forceinline__ void scalarStore128(void* address, uint64_t low, uint64_t high)
