@@ -134,23 +134,25 @@ __device__ __forceinline__ uint64_t fromNextLane64(uint64_t v)
 // per lane and tile instead of 20 iterations, 4 M bytes read instead of 4 M iterations, one launch instead of `iterations`.
 // The records of iteration t carry t above the bucket id -- key = t << iterationShift | bucket id -- so that ONE sort leaves
 // them grouped by (iteration, bucket) and the bucket kernels run once over all of them.  `seed` is unused then.
-template<int M_FIXED, bool ALL = false>
+// KEY: the records' key type -- uint32_t wherever iteration | bucket id fits 32 bits; uint64_t (iteration << 32 | bucket id)
+// beyond, e.g. at 2^31 buckets, the human-genome value.
+template<int M_FIXED, bool ALL = false, class KEY = uint32_t>
 __global__ void __launch_bounds__(HASH_THREADS)
 hashWindowsKernel(
     const uint32_t* __restrict__ kmerIds, const uint64_t* __restrict__ toc,
     const uint8_t* __restrict__ readFlags, const uint4* __restrict__ tileDesc,
     uint64_t markerBegin, uint64_t markerEnd, uint64_t markerCount,
     uint32_t m, uint64_t seed, uint64_t hashThreshold, uint32_t mask,
-    uint32_t* __restrict__ outKeys, uint64_t* __restrict__ outVals,
+    KEY* __restrict__ outKeys, uint64_t* __restrict__ outVals,
     unsigned long long* __restrict__ counter, uint64_t capacity, uint32_t iterations, uint32_t iterationShift)
 {
-    __shared__ uint32_t stageKeys[HASH_THREADS / WAVE][HASH_STAGE];
+    __shared__ KEY stageKeys[HASH_THREADS / WAVE][HASH_STAGE];
     __shared__ uint64_t stageVals[HASH_THREADS / WAVE][HASH_STAGE];
     constexpr uint64_t mul = 0xc6a4a7935bd1e995ULL;
     const uint32_t mm = M_FIXED ? uint32_t(M_FIXED) : m;
     const int lane = laneId();
     const uint32_t waveInBlock = threadIdx.x >> 6;
-    uint32_t* const sKeys = stageKeys[waveInBlock];
+    KEY* const sKeys = stageKeys[waveInBlock];
     uint64_t* const sVals = stageVals[waveInBlock];
     uint32_t fill = 0;                                     // wave-uniform
 
@@ -169,13 +171,13 @@ hashWindowsKernel(
         fill = 0;
     };
     // Appends the hits of one window slot of the wavefront (at most 64) to the stage.
-    auto append = [&](bool hit, uint64_t hash, uint32_t orientedReadId, uint32_t iterationBits) {
+    auto append = [&](bool hit, uint64_t hash, uint32_t orientedReadId, KEY iterationBits) {
         const uint64_t votes = __ballot(hit);
         if(votes == 0) return;
         if constexpr (ALL) { if(fill + uint32_t(WAVE) > uint32_t(HASH_STAGE)) flush(); }       // (a tile adds up to HASH_TILE records per iteration)
         if(hit) {
             const uint32_t slot = fill + uint32_t(__popcll(votes & laneMaskLt()));
-            sKeys[slot] = (uint32_t(hash) & mask) | iterationBits;            // bucket id, :352 (under the iteration, ALL)
+            sKeys[slot] = KEY(uint32_t(hash) & mask) | iterationBits;           // bucket id, :352 (under the iteration, ALL)
             sVals[slot] = (hash & 0xffffffff00000000ULL) | orientedReadId;    // BucketEntry: hashHighBits, orientedReadId
         }
         fill += uint32_t(__popcll(votes));
@@ -281,13 +283,13 @@ hashWindowsKernel(
                 uint64_t hash[4];
                 hashes(uint64_t(t) * 37ULL, hash);                                // :316
 #pragma unroll
-                for(int w = 0; w < 4; w++) append(counts[w] && hash[w] < hashThreshold, hash[w], readOfWindow[w], t << iterationShift);
+                for(int w = 0; w < 4; w++) append(counts[w] && hash[w] < hashThreshold, hash[w], readOfWindow[w], KEY(t) << iterationShift);
             }
         } else {
             uint64_t hash[4];
             hashes(seed, hash);
 #pragma unroll
-            for(int w = 0; w < 4; w++) append(counts[w] && hash[w] < hashThreshold, hash[w], readOfWindow[w], 0u);               // :350, strict
+            for(int w = 0; w < 4; w++) append(counts[w] && hash[w] < hashThreshold, hash[w], readOfWindow[w], KEY(0));             // :350, strict
         }
     }
     if(fill) flush();
@@ -326,24 +328,32 @@ enum : int {
     C_COUNT = 8
 };
 
+// The sorted records' keys as the bucket kernels see them: 32-bit words, `words` per key (1: iteration << shift | bucket id;
+// 2: a 64-bit key, bucket id in the low word, iteration in the high one, shift = 0).
+struct RecordKeys {
+    const uint32_t* words; uint32_t perKey, shift;
+    __host__ __device__ uint32_t iteration(uint64_t i) const { return words[i * perKey + (perKey - 1u)] >> shift; }
+    __host__ __device__ bool differ(uint64_t i, uint64_t j) const { return words[i * perKey] != words[j * perKey] || (perKey == 2u && words[i * 2u + 1u] != words[j * 2u + 1u]); }
+};
+
 // flags[i] = 1 where a bucket begins; flags[n] = 0 (n = the exact count; entries past it are never looked at).
 __global__ void __launch_bounds__(256)
-markHeadsKernel(const uint32_t* __restrict__ keys, Count count, uint32_t* __restrict__ flags)
+markHeadsKernel(RecordKeys keys, Count count, uint32_t* __restrict__ flags)
 {
     const uint64_t n = count.get();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if(i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    if(i < n) flags[i] = (i == 0 || keys.differ(i, i - 1)) ? 1u : 0u;
     else if(i == n) flags[i] = 0u;
 }
 
 // pos = exclusive scan of flags.  starts[g] = index of the first record of bucket g; starts[bucket count] = n.
 __global__ void __launch_bounds__(256)
-groupStartsKernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pos, Count count, uint32_t* __restrict__ starts)
+groupStartsKernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos, Count count, uint32_t* __restrict__ starts)
 {
     const uint64_t n = count.get();
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if(i < n) {
-        if(i == 0 || keys[i] != keys[i - 1]) starts[pos[i]] = uint32_t(i);
+        if(flags[i]) starts[pos[i]] = uint32_t(i);
     } else if(i == n) {
         starts[pos[n]] = uint32_t(n);
     }
@@ -356,7 +366,7 @@ groupStartsKernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict_
 __global__ void __launch_bounds__(256)
 bucketStatsKernel(
     const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts, Count count,
-    uint64_t minBucketSize, uint64_t maxBucketSize, uint32_t iteration, const uint32_t* __restrict__ iterationKeys, uint32_t iterationShift,
+    uint64_t minBucketSize, uint64_t maxBucketSize, uint32_t iteration, RecordKeys iterationKeys,
     unsigned long long* __restrict__ stats,             // [R][3]
     unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP] of this iteration (of iteration 0 with iterationKeys)
     unsigned long long* __restrict__ overflowSizes, uint32_t overflowCapacity,     // iteration << 32 | size
@@ -371,10 +381,10 @@ bucketStatsKernel(
     // The workgroup's LDS histogram belongs to the iteration of its first record; a record of another one (a workgroup on an
     // iteration boundary) votes in its own row directly.
     const uint64_t blockFirst = uint64_t(blockIdx.x) * blockDim.x;
-    const uint32_t blockIteration = (iterationKeys && blockFirst < n) ? iterationKeys[blockFirst] >> iterationShift : iteration;
-    if(iterationKeys) sizeHist += uint64_t(blockIteration) * SIZE_HIST_CAP;
+    const uint32_t blockIteration = (iterationKeys.words && blockFirst < n) ? iterationKeys.iteration(blockFirst) : iteration;
+    if(iterationKeys.words) sizeHist += uint64_t(blockIteration) * SIZE_HIST_CAP;
     if(i < n) {
-        if(iterationKeys) iteration = iterationKeys[i] >> iterationShift;
+        if(iterationKeys.words) iteration = iterationKeys.iteration(i);
         unsigned long long* const myHist = sizeHist + (int64_t(iteration) - int64_t(blockIteration)) * SIZE_HIST_CAP;
         const uint32_t b = pos[i + 1] - 1;
         const uint32_t begin = starts[b], end = starts[b + 1];
@@ -417,7 +427,7 @@ bucketStatsKernel(
 __global__ void __launch_bounds__(256)
 pairWriteKernel(
     const uint64_t* __restrict__ vals, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ starts,
-    const uint64_t* __restrict__ pairOffsets, Count count, int readBits, uint32_t iteration, const uint32_t* __restrict__ iterationKeys, uint32_t iterationShift,
+    const uint64_t* __restrict__ pairOffsets, Count count, int readBits, uint32_t iteration, RecordKeys iterationKeys,
     const unsigned long long* __restrict__ counters, uint64_t* __restrict__ pairKeys, uint32_t* __restrict__ pairTags, uint64_t pairCapacity)
 {
     const uint64_t n = count.get();
@@ -425,7 +435,7 @@ pairWriteKernel(
     if(i >= n) return;
     uint64_t dst = pairOffsets[i];
     if(pairOffsets[i + 1] == dst) return;
-    if(iterationKeys) iteration = iterationKeys[i] >> iterationShift;
+    if(iterationKeys.words) iteration = iterationKeys.iteration(i);
     dst += counters[C_PAIRS];
     const uint32_t b = pos[i + 1] - 1;
     const uint32_t begin = starts[b], end = starts[b + 1];
@@ -470,15 +480,15 @@ __global__ void noteIterationKernel(unsigned long long* __restrict__ counters, u
 // iteration t -- its records are [first record with key >= t << shift, first with key >= (t + 1) << shift), its buckets and its
 // pair keys what the two scans say at those positions.  counters[C_RECORDS] holds what the hash kernel found in all.
 __global__ void __launch_bounds__(64)
-noteAllIterationsKernel(unsigned long long* __restrict__ counters, unsigned long long* __restrict__ iterationTable, uint32_t iterations, uint32_t shift,
-    const uint32_t* __restrict__ keys, Count count, const uint32_t* __restrict__ pos, const uint64_t* __restrict__ pairOffsets)
+noteAllIterationsKernel(unsigned long long* __restrict__ counters, unsigned long long* __restrict__ iterationTable, uint32_t iterations,
+    RecordKeys keys, Count count, const uint32_t* __restrict__ pos, const uint64_t* __restrict__ pairOffsets)
 {
     const unsigned long long found = count.device ? *count.device : count.bound;
     const uint64_t n = count.get();
     auto firstAtLeast = [&](uint32_t t) -> uint64_t {           // first record of iteration >= t
         if(t >= iterations) return n;
         uint64_t lo = 0, hi = n;
-        while(lo < hi) { const uint64_t mid = (lo + hi) >> 1; if((keys[mid] >> shift) < t) lo = mid + 1; else hi = mid; }
+        while(lo < hi) { const uint64_t mid = (lo + hi) >> 1; if(keys.iteration(mid) < t) lo = mid + 1; else hi = mid; }
         return lo;
     };
     for(uint32_t t = threadIdx.x; t < iterations; t += blockDim.x) {
@@ -691,16 +701,17 @@ const char* hashKernelName(uint32_t m, bool all = false)
 }
 
 // iterations = 0: one iteration with `seed`; otherwise all of them in one pass (hashWindowsKernel<m, true>).
+template<class K = uint32_t>
 void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uint32_t mask,
     uint64_t markerBegin, uint64_t markerEnd,
-    uint32_t* outKeys, uint64_t* outVals, unsigned long long* counter, uint64_t capacity, uint32_t iterations = 0, uint32_t iterationShift = 0)
+    K* outKeys, uint64_t* outVals, unsigned long long* counter, uint64_t capacity, uint32_t iterations = 0, uint32_t iterationShift = 0)
 {
     const uint64_t tiles = (markerEnd + HASH_TILE - 1) / HASH_TILE - markerBegin / HASH_TILE;
     if(tiles == 0) return;
     // Persistent wavefronts: 256 CUs x 8 blocks x 4 independent wavefronts, each walking many tiles, so that one global
     // atomic serves a few hundred low hashes.
     const unsigned blocks = unsigned(std::min<uint64_t>(divUp(tiles, uint64_t(HASH_THREADS / WAVE)), 256 * 8));
-#define SHASTA_LAUNCH_HASH(MF, ALL) hipLaunchKernelGGL((hashWindowsKernel<MF, ALL>), dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
+#define SHASTA_LAUNCH_HASH(MF, ALL) hipLaunchKernelGGL((hashWindowsKernel<MF, ALL, K>), dim3(blocks), dim3(HASH_THREADS), 0, ctx.stream, \
         (const uint32_t*)ctx.kmerIds.data(), (const uint64_t*)ctx.toc.data(), (const uint8_t*)ctx.readFlags.data(), \
         (const uint4*)ctx.tileDesc.data(), markerBegin, markerEnd, ctx.markerCount, \
         m, seed, threshold, mask, outKeys, outVals, counter, capacity, iterations, iterationShift)
@@ -711,13 +722,15 @@ void launchHash(Context& ctx, uint32_t m, uint64_t seed, uint64_t threshold, uin
             case 5: SHASTA_LAUNCH_HASH(5, true); break;
             default: SHASTA_LAUNCH_HASH(0, true); break;
         }
-    } else {
+    } else if constexpr (std::is_same<K, uint32_t>::value) {       // (one iteration's bucket ids always fit 32 bits)
         switch(m) {
             case 3: SHASTA_LAUNCH_HASH(3, false); break;
             case 4: SHASTA_LAUNCH_HASH(4, false); break;
             case 5: SHASTA_LAUNCH_HASH(5, false); break;
             default: SHASTA_LAUNCH_HASH(0, false); break;
         }
+    } else {
+        MI355X_ASSERT(iterations != 0);
     }
 #undef SHASTA_LAUNCH_HASH
     HIP_CHECK(hipGetLastError());
@@ -861,36 +874,39 @@ void enqueueHash(Context& ctx, LowHash0Job& job, uint64_t iteration)
 }
 
 // K2: the records sorted by bucket id (radix partition on the bucket id).  Which side holds the result depends on
-// the key width only.
-void enqueueSortRecords(Context& ctx, LowHash0Job& job, const uint32_t*& keys, const uint64_t*& vals, Count count, uint32_t allIterations = 0)
+// the key width only.  wideKeys (all iterations in one pass where iteration | bucket id does not fit 32 bits): the key
+// buffers hold 64-bit keys, iteration << 32 | bucket id; `keys` is returned as their 32-bit words.
+void enqueueSortRecords(Context& ctx, LowHash0Job& job, const uint32_t*& keys, const uint64_t*& vals, Count count, uint32_t allIterations = 0, bool wideKeys = false)
 {
     hipStream_t stream = ctx.stream;
     keys = job.recKeysA.data(); vals = job.recValsA.data();
-    const int bits = int(job.log2BucketCount) + (allIterations ? bitsFor(allIterations - 1) : 0);      // (allIterations: the iteration above the bucket id)
+    const int bits = wideKeys ? 32 + bitsFor(allIterations - 1)
+        : int(job.log2BucketCount) + (allIterations ? bitsFor(allIterations - 1) : 0);      // (allIterations: the iteration above the bucket id)
     const uint64_t passes = (uint64_t(bits) + 7) / 8;
     const KernelTimers::Span span = ctx.timers.begin(allIterations ? "radix sort of the low-hash records of all iterations" : "radix sort of low-hash records", stream);
-    if(radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(),
-        count, bits, ctx.sortWs, stream)) {
-        keys = job.recKeysB.data(); vals = job.recValsB.data();
-    }
-    // 12 bytes per record read + written per 8-bit pass; the record count is booked from the expected fraction.
+    const bool inB = wideKeys
+        ? radixSort<uint64_t, uint64_t, true>(reinterpret_cast<uint64_t*>(job.recKeysA.data()), reinterpret_cast<uint64_t*>(job.recKeysB.data()),
+            job.recValsA.data(), job.recValsB.data(), count, bits, ctx.sortWs, stream)
+        : radixSort<uint32_t, uint64_t, true>(job.recKeysA.data(), job.recKeysB.data(), job.recValsA.data(), job.recValsB.data(), count, bits, ctx.sortWs, stream);
+    if(inB) { keys = job.recKeysB.data(); vals = job.recValsB.data(); }
+    // 12 (16) bytes per record read + written per 8-bit pass; the record count is booked from the expected fraction.
     const uint64_t expected = uint64_t(std::min(std::max(job.p.hashFraction, 0.), 1.) * double(job.markerEnd - job.markerBegin)) * std::max<uint32_t>(1, allIterations);
-    (void)ctx.timers.end(span, 2 * 12 * expected * passes, expected);
+    (void)ctx.timers.end(span, 2 * (wideKeys ? 16 : 12) * expected * passes, expected);
 }
 
 // K3 + K4 on sorted records: statistics, histogram row `iteration`, pair keys appended at counters[C_PAIRS]; then the
 // iteration's counters are filed (noteIterationKernel).
 // allIterations > 0: the records of that many iterations in one array, key = iteration << log2BucketCount | bucket id (`iteration` unused).
-void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keys, const uint64_t* vals, Count count, uint64_t iteration,
-    uint64_t* pairKeys, uint32_t* pairTags, uint64_t pairCapacity, uint32_t allIterations = 0)
+void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keyWords, const uint64_t* vals, Count count, uint64_t iteration,
+    uint64_t* pairKeys, uint32_t* pairTags, uint64_t pairCapacity, uint32_t allIterations = 0, bool wideKeys = false)
 {
     hipStream_t stream = ctx.stream;
     const uint64_t bound = count.bound;
     unsigned long long* counters = job.counters.data();
-    const uint32_t* iterationKeys = allIterations ? keys : nullptr;
-    const uint32_t iterationShift = uint32_t(job.log2BucketCount);
+    const RecordKeys keys{keyWords, wideKeys ? 2u : 1u, wideKeys ? 0u : uint32_t(job.log2BucketCount)};
+    const RecordKeys iterationKeys = allIterations ? keys : RecordKeys{nullptr, 1u, 0u};
     if(bound == 0 && allIterations) {
-        hipLaunchKernelGGL(noteAllIterationsKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), allIterations, iterationShift,
+        hipLaunchKernelGGL(noteAllIterationsKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), allIterations,
             keys, count, (const uint32_t*)nullptr, (const uint64_t*)nullptr);
         HIP_CHECK(hipGetLastError());
         return;
@@ -908,19 +924,19 @@ void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keys, const 
     SHASTA_TIMED(ctx, "bucket boundaries (heads, scan, starts)", stream, 12 * expected, expected,
         hipLaunchKernelGGL(markHeadsKernel, dim3(g), dim3(256), 0, stream, keys, count, job.flags.data());
         exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), bound + 1, job.scanTemp32.data(), stream);
-        hipLaunchKernelGGL(groupStartsKernel, dim3(g), dim3(256), 0, stream, keys, (const uint32_t*)job.pos.data(), count, job.starts.data()));
+        hipLaunchKernelGGL(groupStartsKernel, dim3(g), dim3(256), 0, stream, (const uint32_t*)job.flags.data(), (const uint32_t*)job.pos.data(), count, job.starts.data()));
     SHASTA_TIMED(ctx, "bucketStatsKernel + scan of pair counts", stream, 12 * expected, expected,
         hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
             vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), count,
-            job.p.minBucketSize, job.p.maxBucketSize, uint32_t(iteration), iterationKeys, iterationShift, job.stats.data(),
+            job.p.minBucketSize, job.p.maxBucketSize, uint32_t(iteration), iterationKeys, job.stats.data(),
             job.sizeHist.data() + (allIterations ? 0 : iteration * SIZE_HIST_CAP),
             job.overflowSizes.data(), LowHash0Job::overflowCapacity, counters, job.pairCounts.data());
         exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), bound + 1, job.scanTemp64.data(), stream));
     SHASTA_TIMED(ctx, "pairWriteKernel", stream, 0, expected,
         hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(bound, 256)), dim3(256), 0, stream,
             vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), (const uint64_t*)job.pairCounts.data(), count, job.readBits, uint32_t(iteration),
-            iterationKeys, iterationShift, (const unsigned long long*)counters, pairKeys, pairTags, pairCapacity));
-    if(allIterations) hipLaunchKernelGGL(noteAllIterationsKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), allIterations, iterationShift,
+            iterationKeys, (const unsigned long long*)counters, pairKeys, pairTags, pairCapacity));
+    if(allIterations) hipLaunchKernelGGL(noteAllIterationsKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), allIterations,
         keys, count, (const uint32_t*)job.pos.data(), (const uint64_t*)job.pairCounts.data());
     else hipLaunchKernelGGL(noteIterationKernel, dim3(1), dim3(64), 0, stream, counters, job.iterationTable.data(), uint32_t(iteration), count,
         (const uint32_t*)job.pos.data(), (const uint64_t*)job.pairCounts.data());
@@ -1232,26 +1248,30 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
             bool again = false;
             uint64_t highFrequency = 0;
             // All iterations in one pass over the markers (hashWindowsKernel<m, true>) whenever their number is known in
-            // advance and iteration | bucket id fits the records' 32-bit sort key (not at 2^31 buckets, the human-genome value:
-            // there, and with the dynamic iteration control, iteration after iteration as before).  SHASTA_MI355X_LOWHASH_ONE_PASS=0: never.
+            // advance (with the dynamic iteration control: iteration after iteration as before); the records' sort key is
+            // iteration | bucket id in 32 bits where that fits, a 64-bit key beyond (2^31 buckets, the human-genome value).
+            // SHASTA_MI355X_LOWHASH_ONE_PASS=0: never.
             const bool onePassAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_LOWHASH_ONE_PASS"); return !(e && e[0] == '0'); }();      // (read for every call: tests switch it)
             const uint64_t I = p.minHashIterationCount;
-            const bool onePass = onePassAllowed && I >= 1 && I <= 4096 && job.log2BucketCount + uint64_t(bitsFor(I - 1)) <= 32 &&
-                I * job.recCapacity < (1ULL << 32) - 1;
+            const bool onePass = onePassAllowed && I >= 1 && I <= 4096 && I * job.recCapacity < (1ULL << 32) - 1;
+            const bool wideKeys = onePass && job.log2BucketCount + uint64_t(bitsFor(I - 1)) > 32;      // 64-bit record keys: iteration << 32 | bucket id
             uint64_t recordCapacityAll = 0;
             if(onePass) {
                 reserveIterationRows(job, I, stream);
                 recordCapacityAll = I * job.recCapacity;
-                job.recKeysA.reserve(recordCapacityAll, stream); job.recKeysB.reserve(recordCapacityAll, stream);
+                const uint64_t keyWords = recordCapacityAll * (wideKeys ? 2 : 1);
+                job.recKeysA.reserve(keyWords, stream); job.recKeysB.reserve(keyWords, stream);
                 job.recValsA.reserve(recordCapacityAll, stream); job.recValsB.reserve(recordCapacityAll, stream);
                 const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(p.m), true), stream);
-                launchHash(ctx, uint32_t(p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
+                if(wideKeys) launchHash<uint64_t>(ctx, uint32_t(p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
+                    reinterpret_cast<uint64_t*>(job.recKeysA.data()), job.recValsA.data(), counters + C_RECORDS, recordCapacityAll, uint32_t(I), 32u);
+                else launchHash(ctx, uint32_t(p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
                     job.recKeysA.data(), job.recValsA.data(), counters + C_RECORDS, recordCapacityAll, uint32_t(I), uint32_t(job.log2BucketCount));
                 job.hashHandles.push_back(ctx.timers.end(span, 4 * (job.markerEnd - job.markerBegin), (job.markerEnd - job.markerBegin) * I));
                 const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
                 const Count records(recordCapacityAll, counters + C_RECORDS);
-                enqueueSortRecords(ctx, job, keys, vals, records, uint32_t(I));
-                enqueueBuckets(ctx, job, keys, vals, records, 0, job.pairKeys(), job.pairTags(), job.pairCapacity, uint32_t(I));
+                enqueueSortRecords(ctx, job, keys, vals, records, uint32_t(I), wideKeys);
+                enqueueBuckets(ctx, job, keys, vals, records, 0, job.pairKeys(), job.pairTags(), job.pairCapacity, uint32_t(I), wideKeys);
                 job.iterations = I;
             }
             else for(uint64_t iteration = 0; ; iteration++) {
