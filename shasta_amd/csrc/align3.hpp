@@ -186,7 +186,7 @@ align3BandKernel(
     const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
     const DpEnd* __restrict__ ends, const WideTask* __restrict__ wideTasks, const WideEnd* __restrict__ wideEnds,
     const uint64_t* __restrict__ trace, const uint32_t* __restrict__ dsOrdinals,
-    int32_t bandExtend, int32_t maxBand, DpTask* __restrict__ tasks2, uint32_t* __restrict__ taskCount2)
+    int32_t bandExtend, int32_t maxBand, DpTask* __restrict__ tasks2, uint32_t* __restrict__ taskCount2, uint32_t taskCapacity2, uint32_t wideCounter)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if(idx >= taskCount) return;
@@ -253,7 +253,10 @@ align3BandKernel(
     out.bandMin = max(bandMin, -int32_t(pd.ny));
     out.bandMax = min(bandMax, int32_t(pd.nx));
     out.label = 0;
-    tasks2[atomicAdd(taskCount2, 1u)] = out;
+    // A band of more than 1024 diagonals (Align.maxBand beyond what the banded DP kernels hold): listed from the back, for the
+    // wide DP over the band, as the Align4 cells kernels list such components.
+    if(out.bandMax - out.bandMin + 1 > 1024) tasks2[taskCapacity2 - 1u - atomicAdd(taskCount2 + wideCounter, 1u)] = out;
+    else tasks2[atomicAdd(taskCount2, 1u)] = out;
 }
 
 // Traceback of the wide tasks of Align4 (components of more than 1024 diagonals): one wavefront per task, lane 0 walks the trace

@@ -979,7 +979,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     in.pairs, (const PairDesc*)b.pairs.data(), in.tasks, f.sortedIds, taskCount1,
                     (const DpEnd*)b.ends.data(), (const WideTask*)nullptr, (const WideEnd*)nullptr,
                     (const uint64_t*)b.trace.data(), (const uint32_t*)ds->ordinals.data(),
-                    m3->bandExtend, m3->maxBand, b.tasks.data(), b.counters.data());
+                    m3->bandExtend, m3->maxBand, b.tasks.data(), b.counters.data(), taskCapacity, uint32_t(CELLS_WIDE_COUNTER));
                 HIP_CHECK(hipGetLastError());
             }
             // The long pairs, a few gigabytes of trace at a time.
@@ -1027,7 +1027,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     (const PairDesc*)b.dsPairs.data(), (const PairDesc*)b.pairs.data(), (const DpTask*)nullptr, (const uint32_t*)nullptr, count,
                     (const DpEnd*)nullptr, (const WideTask*)b.wideTasks.data(), (const WideEnd*)b.wideEnds.data(),
                     (const uint64_t*)b.trace.data(), (const uint32_t*)ds->ordinals.data(),
-                    m3->bandExtend, m3->maxBand, b.tasks.data(), b.counters.data());
+                    m3->bandExtend, m3->maxBand, b.tasks.data(), b.counters.data(), taskCapacity, uint32_t(CELLS_WIDE_COUNTER));
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipStreamSynchronize(stream));
                 begin = end;
@@ -1294,7 +1294,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             }
         }
         taskCount = readDevice(b.counters.data(), stream);
-        wideCount = m3 ? 0u : readDevice(b.counters.data() + CELLS_WIDE_COUNTER, stream);      // (components of more than 1024 diagonals, listed from the back)
+        wideCount = readDevice(b.counters.data() + CELLS_WIDE_COUNTER, stream);      // (components / step-2 bands of more than 1024 diagonals, listed from the back)
         if(uint64_t(taskCount) + wideCount <= taskCapacity) break;
         // More DP tasks than the list was sized for (many small components per candidate: low-complexity
         // reads, or options that keep nearly every cell).  The count is exact -- stores past the
@@ -1587,7 +1587,8 @@ void align3Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read
     if(o.k < 1 || o.k > 16) throw std::runtime_error("Align3: k must be in [1, 16].");
     if(!(o.downsamplingFactor >= 0. && o.downsamplingFactor <= 1.)) throw std::runtime_error("Align3: downsamplingFactor must be in [0, 1].");
     if(o.bandExtend < 0 || o.bandExtend > (1 << 20)) throw std::runtime_error("Align3: bandExtend must be in [0, 2^20].");
-    if(o.maxBand < 0 || o.maxBand > 1023) throw std::runtime_error("Align3: maxBand must be in [0, 1023] (1024 diagonals per DP).");
+    // (A step-2 band of more than 1024 diagonals runs in the wide DP over its band, as Align4's wide components do.)
+    if(o.maxBand < 0 || o.maxBand >= ALIGN3_HUGE_MAX_DIAGONALS) throw std::runtime_error("Align3: maxBand must be in [0, 65535] (the widest band the wide DP holds).");
     Align3Plan plan;
     plan.k = uint32_t(o.k);
     plan.hashThreshold = uint32_t(o.downsamplingFactor * double(std::numeric_limits<uint32_t>::max()));   // src/AssemblerAlign3.cpp:71-72

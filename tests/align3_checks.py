@@ -62,7 +62,7 @@ def rejected_options(lib):
     import pytest
     toc, kmer, data7 = support.small_marker_set(n_reads=20, genome_markers=3000, seed=1)
     cand = abi.make_pairs([0], [1], [1])
-    for kw in (dict(gapScore=-(1 << 21)), dict(matchScore=1 << 25), dict(maxBand=2000), dict(k=17), dict(downsamplingFactor=1.5),
+    for kw in (dict(gapScore=-(1 << 21)), dict(matchScore=1 << 25), dict(maxBand=70000), dict(k=17), dict(downsamplingFactor=1.5),
                dict(bandExtend=-1)):
         with pytest.raises(RuntimeError, match="Align3"):
             lib.align3_batch(toc, data7, cand, abi.default_align3_options(**kw))

@@ -22,6 +22,9 @@ def test_align3_matches_reference_fixture(gpu_lib, name, i):
     (25, dict(matchScore=3, mismatchScore=-2, gapScore=-3, minAlignedMarkerCount=40)),
     (26, dict(matchScore=10, mismatchScore=-4, gapScore=-1, downsamplingFactor=0.2, minAlignedMarkerCount=40)),
     (27, dict(matchScore=1, mismatchScore=0, gapScore=-2, downsamplingFactor=0.05, minAlignedMarkerCount=20)),
+    # Step-2 bands of more than 1024 diagonals (Align.maxBand beyond what the banded DP kernels hold: the wide DP over the band).
+    (28, dict(bandExtend=700, maxBand=3000, minAlignedMarkerCount=40)),
+    (29, dict(bandExtend=5000, maxBand=20000, downsamplingFactor=0.2, matchScore=3, mismatchScore=-2, gapScore=-3, minAlignedMarkerCount=40)),
 ])
 def test_align3_matches_oracle(gpu_lib, oracle_lib, seed, kw):
     align3_checks.against_oracle(gpu_lib, oracle_lib, seed, kw, n_reads=250, genome_markers=15000, limit=1500)
