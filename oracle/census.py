@@ -28,10 +28,32 @@ def _summary(out):
     return stored, counts
 
 
+def _only_the_reads_of(toc, data7, candidates):
+    reads = np.unique(np.concatenate([candidates["readId0"], candidates["readId1"]])) if len(candidates) else np.zeros(0, np.uint32)
+    if len(reads) == 0 or 2 * len(reads) + 1 >= len(toc):
+        return toc, data7, candidates
+    toc = np.asarray(toc, dtype=np.uint64)
+    begins, ends = toc[2 * reads.astype(np.int64)].astype(np.int64), toc[2 * reads.astype(np.int64) + 2].astype(np.int64)
+    sizes = np.stack([toc[2 * reads.astype(np.int64) + 1].astype(np.int64) - begins, ends - toc[2 * reads.astype(np.int64) + 1].astype(np.int64)], axis=1).reshape(-1)
+    sub_toc = np.zeros(2 * len(reads) + 1, dtype=np.uint64)
+    sub_toc[1:] = np.cumsum(sizes)
+    records = np.asarray(data7, dtype=np.uint8).reshape(-1, 7)
+    lengths = ends - begins
+    rows = np.repeat(begins - (np.cumsum(lengths) - lengths), lengths) + np.arange(int(lengths.sum()))
+    sub_data = np.ascontiguousarray(records[rows]).reshape(-1)
+    renumbered = candidates.copy()
+    renumbered["readId0"] = np.searchsorted(reads, candidates["readId0"])
+    renumbered["readId1"] = np.searchsorted(reads, candidates["readId1"])
+    return sub_toc, sub_data, renumbered
+
+
 def tie_census(lib, toc, data7, candidates, options, align_method=4, threads=1, policies=range(1, 12)):
     """`lib`: oracle.bindings.RefLib or OracleLib.  Leaves the library on policy 0."""
     align = lib.align4_batch if align_method == 4 else lib.align3_batch
     n = len(candidates)
+    # Twelve calls, each of which prepares the markers of every read it is given: give it the census's reads only,
+    # renumbered (at the benchmark's size a third of the reads; 162 -> about 60 seconds for 20 000 candidates).
+    toc, data7, candidates = _only_the_reads_of(toc, data7, candidates)
     try:
         lib.set_tie_policy(0)
         base = align(toc, data7, candidates, options, want_ordinals=True, threads=threads)
