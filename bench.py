@@ -247,10 +247,10 @@ def hbm_budget(markers_total, reads_total, n_gpus, hash_fraction=0.01, iteration
     the 288 GB of one MI355X are checked before such a run, not during it."""
     m, r, g = float(markers_total), float(reads_total), float(n_gpus)
     records = 2.0 * hash_fraction * m / g                                # capacity of one iteration's low-hash records on a GPU
-    # All iterations in one pass on one GPU (the ranks of a sharded job go iteration after iteration); 64-bit record keys
-    # where iteration | bucket id does not fit 32 bits (lowhash0Run, lowhash0.hip).
-    one_pass = bool(g == 1 and m * hash_fraction > 0 and iterations * records < 2.0 ** 32 - 1)
-    wide_keys = one_pass and (5 + np.ceil(np.log2(max(2.0, hash_fraction * m)))) + np.ceil(np.log2(max(2, iterations))) > 32
+    # All iterations in one pass (lowhash0Run and the staged job alike, lowhash0.hip); 64-bit record keys on the ranks of a
+    # sharded job (owner | iteration | bucket id) and where iteration | bucket id does not fit 32 bits.
+    one_pass = bool(m * hash_fraction > 0 and iterations * records < 2.0 ** 32 - 1)
+    wide_keys = one_pass and (g > 1 or (5 + np.ceil(np.log2(max(2.0, hash_fraction * m)))) + np.ceil(np.log2(max(2, iterations))) > 32)
     record_rows = records * (iterations if one_pass else 1)
     pairs = pairs_per_read * r * iterations / g * 1.25                   # pair keys of all iterations owned by a GPU
     parts = {

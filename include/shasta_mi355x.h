@@ -276,6 +276,16 @@ int shasta_mi355x_align4_run(
  *                 (needed after every iteration only when minHashIterationCount = 0) it also evaluates
  *                 them: this rank's share of the latest iteration's "high frequency" and "total"
  *                 counters (all-reduce them); otherwise both come back 0
+ *   or, with a fixed number of iterations (minHashIterationCount > 0), ALL iterations in one pass -- one call of each
+ *   stage and two exchanges per JOB instead of per iteration (fewer, larger collectives; the markers are read once):
+ *     lh_hash_all     records of every iteration {u64: owner << 56 | iteration << 32 | bucketId} / {u64 as above},
+ *                     each owner's records contiguous; sendOffsets[r..r+1] = the records rank r owns
+ *       -- all-to-all of records --
+ *     lh_buckets_all  on the n received records: statistics, bucketsUsed[iteration], sizeHistogram[iteration][2048],
+ *                     the larger sizes as iteration << 32 | size, and the pair keys of all iterations with their
+ *                     iteration tags {u32}, sorted by key; sendOffsets by owner of readId0
+ *       -- all-to-all of pair keys and tags --
+ *     lh_merge_all    takes the n received keys and tags
  *   lh_finish  K5 + K6: evaluates the keys of all iterations at once; this rank's candidates (sorted;
  *              concatenating the ranks in order gives the reference's order) -- free with
  *              shasta_mi355x_free --, its partial readLowHashStatistics[readCount*3] and its share of
@@ -291,6 +301,11 @@ int shasta_mi355x_lh_buckets(shasta_mi355x_ctx*, const void* keysDevice, const v
     uint64_t* sizeHistogram, uint32_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount);
 int shasta_mi355x_lh_merge(shasta_mi355x_ctx*, const void* pairKeysDevice, uint64_t n, int evaluateNow,
     uint64_t* highFrequency, uint64_t* total);
+int shasta_mi355x_lh_hash_all(shasta_mi355x_ctx*, uint64_t* sendOffsets, const void** keysDevice, const void** valsDevice);
+int shasta_mi355x_lh_buckets_all(shasta_mi355x_ctx*, const void* keysDevice, const void* valsDevice, uint64_t n,
+    uint64_t* sendOffsets, const void** pairKeysDevice, const void** pairTagsDevice, uint64_t iterationCapacity, uint64_t* bucketsUsed,
+    uint64_t* sizeHistogram, uint64_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount);
+int shasta_mi355x_lh_merge_all(shasta_mi355x_ctx*, const void* pairKeysDevice, const void* pairTagsDevice, uint64_t n);
 int shasta_mi355x_lh_finish(shasta_mi355x_ctx*, uint64_t* readLowHashStatistics,
     shasta_oriented_read_pair** candidates, uint64_t* candidateCount,
     uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount);

@@ -135,6 +135,45 @@ int shasta_mi355x_lh_merge(shasta_mi355x_ctx* c, const void* pairKeysDevice, uin
     API_END(1)
 }
 
+int shasta_mi355x_lh_hash_all(shasta_mi355x_ctx* c, uint64_t* sendOffsets, const void** keysDevice, const void** valsDevice)
+{
+    API_BEGIN
+    if(!c || !sendOffsets || !keysDevice || !valsDevice) throw std::runtime_error("lh_hash_all: null argument");
+    const uint64_t* k = nullptr; const uint64_t* v = nullptr;
+    lowhash0HashAll(c->impl, sendOffsets, &k, &v);
+    *keysDevice = k; *valsDevice = v;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_buckets_all(shasta_mi355x_ctx* c, const void* keysDevice, const void* valsDevice, uint64_t n,
+    uint64_t* sendOffsets, const void** pairKeysDevice, const void** pairTagsDevice, uint64_t iterationCapacity, uint64_t* bucketsUsed,
+    uint64_t* sizeHistogram, uint64_t* overflowSizes, uint64_t overflowCapacity, uint64_t* overflowCount)
+{
+    API_BEGIN
+    if(!c || !sendOffsets || !pairKeysDevice || !pairTagsDevice || !bucketsUsed || !sizeHistogram || !overflowCount) throw std::runtime_error("lh_buckets_all: null argument");
+    if(iterationCapacity < lowhash0JobPlannedIterations(c->impl)) throw std::runtime_error("lh_buckets_all: iteration capacity too small");
+    const uint64_t* pk = nullptr; const uint32_t* tags = nullptr;
+    std::vector<uint64_t> overflow;
+    lowhash0BucketsAll(c->impl, static_cast<const uint64_t*>(keysDevice), static_cast<const uint64_t*>(valsDevice), n,
+        sendOffsets, &pk, &tags, bucketsUsed, sizeHistogram, overflow);
+    if(overflow.size() > overflowCapacity) throw std::runtime_error("lh_buckets_all: overflow list capacity too small");
+    if(!overflow.empty()) std::memcpy(overflowSizes, overflow.data(), overflow.size() * 8);
+    *overflowCount = overflow.size();
+    *pairKeysDevice = pk; *pairTagsDevice = tags;
+    return 0;
+    API_END(1)
+}
+
+int shasta_mi355x_lh_merge_all(shasta_mi355x_ctx* c, const void* pairKeysDevice, const void* pairTagsDevice, uint64_t n)
+{
+    API_BEGIN
+    if(!c) throw std::runtime_error("lh_merge_all: null argument");
+    lowhash0MergeAll(c->impl, static_cast<const uint64_t*>(pairKeysDevice), static_cast<const uint32_t*>(pairTagsDevice), n);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_lh_finish(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistics,
     shasta_oriented_read_pair** candidates, uint64_t* candidateCount,
     uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount)

@@ -83,7 +83,13 @@ void lowhash0Hash(Context&, uint64_t iteration, uint64_t* sendOffsets, const uin
 void lowhash0Buckets(Context&, const uint32_t* keys, const uint64_t* vals, uint64_t n, uint64_t* sendOffsets,
     const uint64_t** pairKeys, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint32_t>& overflow);
 void lowhash0Merge(Context&, const uint64_t* pairKeys, uint64_t n, bool evaluateNow, uint64_t* highFrequency, uint64_t* total);
+// The same job with all iterations in one pass (fixed minHashIterationCount): one call of each per job.
+void lowhash0HashAll(Context&, uint64_t* sendOffsets, const uint64_t** keys, const uint64_t** vals);
+void lowhash0BucketsAll(Context&, const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* sendOffsets,
+    const uint64_t** pairKeys, const uint32_t** pairTags, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint64_t>& overflow);
+void lowhash0MergeAll(Context&, const uint64_t* pairKeys, const uint32_t* pairTags, uint64_t n);
 uint64_t lowhash0JobIterations(Context&);
+uint64_t lowhash0JobPlannedIterations(Context&);          // minHashIterationCount of the job in progress
 void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates,
     std::vector<uint64_t>& highFrequencyPerIteration, std::vector<uint64_t>& totalPerIteration);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,

@@ -330,9 +330,10 @@ enum : int {
 
 // The sorted records' keys as the bucket kernels see them: 32-bit words, `words` per key (1: iteration << shift | bucket id;
 // 2: a 64-bit key, bucket id in the low word, iteration in the high one, shift = 0).
+// (A sharded job's 64-bit keys carry their owner in the top byte: owner << 56 | iteration << 32 | bucket id.)
 struct RecordKeys {
     const uint32_t* words; uint32_t perKey, shift;
-    __host__ __device__ uint32_t iteration(uint64_t i) const { return words[i * perKey + (perKey - 1u)] >> shift; }
+    __host__ __device__ uint32_t iteration(uint64_t i) const { return perKey == 2u ? (words[2u * i + 1u] & 0x00ffffffu) : words[i] >> shift; }
     __host__ __device__ bool differ(uint64_t i, uint64_t j) const { return words[i * perKey] != words[j * perKey] || (perKey == 2u && words[i * 2u + 1u] != words[j * 2u + 1u]); }
 };
 
@@ -752,6 +753,19 @@ lowerBoundsKernel(const K* __restrict__ keys, uint64_t n, const K* __restrict__ 
         if(keys[mid] < bound) lo = mid + 1; else hi = mid;
     }
     out[k] = lo;
+}
+
+// keys[i] |= owner << 56, owner = the rank whose bucket range [bounds[r], bounds[r + 1]) holds the key's bucket id (low word).
+__global__ void __launch_bounds__(256)
+tagOwnerKernel(uint64_t* __restrict__ keys, uint64_t n, const uint32_t* __restrict__ bounds, uint32_t world)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const uint64_t key = keys[i];
+    const uint32_t bucket = uint32_t(key);
+    uint32_t owner = 0;
+    for(uint32_t r = 1; r < world; r++) owner += bucket >= bounds[r] ? 1u : 0u;       // (bounds ascend; world is small)
+    keys[i] = (key & 0x00ffffffffffffffULL) | (uint64_t(owner) << 56);
 }
 
 // ---------------------------------------------------------------------------
@@ -1192,8 +1206,173 @@ void lowhash0Merge(Context& ctx, const uint64_t* keys, uint64_t n, bool evaluate
     }
 }
 
+// ---- the staged job with all iterations in one pass (fixed minHashIterationCount): three calls and two exchanges per JOB
+// instead of per iteration.  Keys are 64-bit: owner << 56 | iteration << 32 | bucket id.
+
+// Stage 1 (all iterations).  sendOffsets[r..r+1] delimit the records of the buckets rank r owns in (*keys, *vals).
+void lowhash0HashAll(Context& ctx, uint64_t* sendOffsets, const uint64_t** keysOut, const uint64_t** valsOut)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const uint64_t I = job.p.minHashIterationCount;
+    if(I < 1 || I > 4096) throw std::runtime_error("LowHash0: all iterations in one pass needs 1 <= minHashIterationCount <= 4096.");
+    if(job.world > 256) throw std::runtime_error("LowHash0: at most 256 ranks.");
+    unsigned long long* counter = job.counters.data() + C_RECORDS;
+    uint64_t n = 0, capacity = 0;
+    for(;;) {
+        capacity = I * job.recCapacity;
+        MI355X_ASSERT(capacity < (1ULL << 32) - 1);
+        job.recKeysA.reserve(2 * capacity, stream); job.recKeysB.reserve(2 * capacity, stream);
+        job.recValsA.reserve(capacity, stream); job.recValsB.reserve(capacity, stream);
+        HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+        const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(job.p.m), true), stream);
+        launchHash<uint64_t>(ctx, uint32_t(job.p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
+            reinterpret_cast<uint64_t*>(job.recKeysA.data()), job.recValsA.data(), counter, capacity, uint32_t(I), 32u);
+        job.hashHandles.push_back(ctx.timers.end(span, 4 * (job.markerEnd - job.markerBegin), (job.markerEnd - job.markerBegin) * I));
+        n = readDevice(counter, stream);
+        ctx.timers.amend(job.hashHandles.back(), 4 * (job.markerEnd - job.markerBegin) + 16 * std::min(n, capacity), (job.markerEnd - job.markerBegin) * I);
+        if(n <= capacity) break;
+        job.recCapacity = (n + I - 1) / I + n / (4 * I) + 1;       // estimate was too small: grow and hash again
+        ctx.lowhashRecordsHint = job.recCapacity;
+    }
+    HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(job.recKeysA.data());
+    const uint64_t* vals = job.recValsA.data();
+    if(job.world == 1 || n == 0) {
+        for(int r = 0; r <= job.world; r++) sendOffsets[r] = (r == job.world) ? n : 0;
+    } else {
+        // Owners into the keys' top byte, ONE stable radix pass on it (a sender only has to make each owner's records
+        // contiguous: the receiver sorts them), split points by binary search.
+        hipLaunchKernelGGL(tagOwnerKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
+            reinterpret_cast<uint64_t*>(job.recKeysA.data()), n, (const uint32_t*)job.boundKeys32.data(), uint32_t(job.world));
+        HIP_CHECK(hipGetLastError());
+        const KernelTimers::Span span = ctx.timers.begin("records of all iterations partitioned by owner", stream);
+        if(radixSort<uint64_t, uint64_t, true>(reinterpret_cast<uint64_t*>(job.recKeysA.data()), reinterpret_cast<uint64_t*>(job.recKeysB.data()),
+            job.recValsA.data(), job.recValsB.data(), Count(n), 8, ctx.sortWs, stream, 56)) {
+            keys = reinterpret_cast<const uint64_t*>(job.recKeysB.data()); vals = job.recValsB.data();
+        }
+        (void)ctx.timers.end(span, 2 * 16 * n, n);
+        std::vector<uint64_t> bounds(size_t(job.world) + 1);
+        for(int r = 0; r <= job.world; r++) bounds[r] = uint64_t(std::min(r, 255)) << 56;
+        HIP_CHECK(hipMemcpyAsync(job.boundKeys64.data(), bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(lowerBoundsKernel<uint64_t>, dim3(divUp(uint64_t(job.world) + 1, 64)), dim3(64), 0, stream,
+            keys, n, (const uint64_t*)job.boundKeys64.data(), uint32_t(job.world + 1), job.boundOut.data());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(sendOffsets, job.boundOut.data(), (size_t(job.world) + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        sendOffsets[0] = 0; sendOffsets[job.world] = n;
+        // (boundKeys64 holds the pair keys' owner bounds for stage 2: put them back.)
+        std::vector<uint64_t> b64(size_t(job.world) + 1);
+        for(int r = 0; r <= job.world; r++) b64[r] = job.boundaries[r] << (job.readBits + 1);
+        HIP_CHECK(hipMemcpyAsync(job.boundKeys64.data(), b64.data(), b64.size() * 8, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    *keysOut = keys; *valsOut = vals;
+}
+
+// Stage 2 (all iterations).  (keys, vals): the n records of the buckets this rank owns, of every iteration (device pointers, any
+// order).  Statistics, histograms (rows of every iteration), the pair keys of all iterations with their iteration tags, sorted
+// by key and split by owner of readId0.  bucketsUsedOut[iterations], sizeHistogramOut[iterations][SIZE_HIST_CAP];
+// overflowOut: iteration << 32 | size of the buckets beyond the histogram bins.
+void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* valsIn, uint64_t n,
+    uint64_t* sendOffsets, const uint64_t** pairKeysOut, const uint32_t** pairTagsOut,
+    uint64_t* bucketsUsedOut, uint64_t* sizeHistogramOut, std::vector<uint64_t>& overflowOut)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    const uint64_t I = job.p.minHashIterationCount;
+    MI355X_ASSERT(I >= 1 && I <= 4096 && n < (1ULL << 32) - 1 && job.iterations == 0);
+    reserveIterationRows(job, I, stream);
+    job.recKeysA.reserve(2 * std::max<uint64_t>(n, 1), stream); job.recKeysB.reserve(2 * std::max<uint64_t>(n, 1), stream);
+    job.recValsA.reserve(std::max<uint64_t>(n, 1), stream); job.recValsB.reserve(std::max<uint64_t>(n, 1), stream);
+    if(n && (const void*)keysIn != (const void*)job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 8, hipMemcpyDeviceToDevice, stream));
+    if(n && valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
+    const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
+    enqueueSortRecords(ctx, job, keys, vals, Count(n), uint32_t(I), true);
+    unsigned long long* counters = job.counters.data();
+    // The pair keys go where the single-GPU job keeps them; a guess that was too small: everything this call added is
+    // zeroed and the buckets run again with room (the records stay sorted where they are).
+    uint64_t pairCount = 0;
+    for(int attempt = 0; ; attempt++) {
+        MI355X_ASSERT(attempt < 4);
+        HIP_CHECK(hipMemsetAsync(counters + C_PAIRS, 0, sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(counters + C_BUCKETS, 0, sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(counters + C_OVERFLOW, 0, sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(job.stats.data(), 0, 3 * ctx.readCount * sizeof(unsigned long long), stream));
+        HIP_CHECK(hipMemsetAsync(job.sizeHist.data(), 0, I * SIZE_HIST_CAP * sizeof(unsigned long long), stream));
+        enqueueBuckets(ctx, job, keys, vals, Count(n), 0, job.pairKeys(), job.pairTags(), job.pairCapacity, uint32_t(I), true);
+        pairCount = readDevice(counters + C_PAIRS, stream);
+        if(pairCount <= job.pairCapacity) break;
+        reservePairs(job, pairCount + pairCount / 8 + 64, stream, false);
+        ctx.lowhashPairsHint = job.pairCapacity;
+    }
+    std::vector<unsigned long long> table(4 * I);
+    HIP_CHECK(hipMemcpyAsync(table.data(), job.iterationTable.data(), table.size() * 8, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(sizeHistogramOut, job.sizeHist.data(), I * SIZE_HIST_CAP * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    const uint64_t overflow = readDevice(counters + C_OVERFLOW, stream);
+    if(overflow > LowHash0Job::overflowCapacity) throw std::runtime_error("LowHash0: bucket-size overflow list exhausted.");
+    overflowOut.assign(overflow, 0);
+    if(overflow) HIP_CHECK(hipMemcpyAsync(overflowOut.data(), job.overflowSizes.data(), overflow * 8, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for(uint64_t t = 0; t < I; t++) bucketsUsedOut[t] = table[4 * t + 1];
+    // Sorted by key with the tags: an owner's keys are contiguous (readId0 leads the key).
+    const uint64_t* pk = job.pairKeys(); const uint32_t* tags = job.pairTags();
+    if(pairCount) {
+        MI355X_ASSERT(pairCount < (1ULL << 32) - 1);
+        const KernelTimers::Span span = ctx.timers.begin("radix sort of the pair keys of all iterations (staged)", stream);
+        const bool flipped = radixSort<uint64_t, uint32_t, true>(job.pairKeys(), job.pairsInB ? job.pairKeysA.data() : job.pairKeysB.data(),
+            job.pairTags(), job.pairsInB ? job.pairTagsA.data() : job.pairTagsB.data(), pairCount, job.pairKeyBits, ctx.sortWs, stream);
+        if(flipped) job.pairsInB = !job.pairsInB;
+        pk = job.pairKeys(); tags = job.pairTags();
+        (void)ctx.timers.end(span, 2 * 12 * pairCount * uint64_t((job.pairKeyBits + 7) / 8), pairCount);
+    }
+    if(job.world == 1 || pairCount == 0) {
+        for(int r = 0; r <= job.world; r++) sendOffsets[r] = (r == job.world) ? pairCount : 0;
+    } else {
+        hipLaunchKernelGGL(lowerBoundsKernel<uint64_t>, dim3(divUp(uint64_t(job.world) + 1, 64)), dim3(64), 0, stream,
+            pk, pairCount, (const uint64_t*)job.boundKeys64.data(), uint32_t(job.world + 1), job.boundOut.data());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(sendOffsets, job.boundOut.data(), (size_t(job.world) + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        sendOffsets[0] = 0; sendOffsets[job.world] = pairCount;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    *pairKeysOut = pk; *pairTagsOut = tags;
+}
+
+// Stage 3 (all iterations).  The n pair keys whose readId0 this rank owns, with their iteration tags (device pointers: the
+// exchange's receive buffers, or -- one rank -- what stage 2 returned).
+void lowhash0MergeAll(Context& ctx, const uint64_t* keys, const uint32_t* tags, uint64_t n)
+{
+    LowHash0Job& job = jobOf(ctx);
+    HIP_CHECK(hipSetDevice(ctx.device));
+    hipStream_t stream = ctx.stream;
+    MI355X_ASSERT(job.iterations == 0);
+    if(n) {
+        const bool own = keys == job.pairKeys() && tags == job.pairTags();
+        if(!own) {
+            if(n > job.pairCapacity) reservePairs(job, n + n / 8 + 64, stream, false);
+            HIP_CHECK(hipMemcpyAsync(job.pairKeys(), keys, n * 8, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(job.pairTags(), tags, n * 4, hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    job.pairCount = n;
+    job.iterations = job.p.minHashIterationCount;
+    // The evaluation replays a pair's history from the order of its occurrences after a STABLE sort by key: they have to be
+    // in iteration order before it.  What arrived is one run per sender, each sorted by key: sort by iteration (stable).
+    if(n && job.world > 1) {
+        const bool flipped = radixSort<uint32_t, uint64_t, true>(job.pairTags(), job.pairsInB ? job.pairTagsA.data() : job.pairTagsB.data(),
+            job.pairKeys(), job.pairsInB ? job.pairKeysA.data() : job.pairKeysB.data(), n, bitsFor(job.iterations - 1), ctx.sortWs, stream);
+        if(flipped) job.pairsInB = !job.pairsInB;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));              // `keys` / `tags` may be reused by the caller
+}
+
 // Iterations merged so far by the job in progress (what lowhash0Finish will report per iteration).
 uint64_t lowhash0JobIterations(Context& ctx) { return jobOf(ctx).iterations; }
+uint64_t lowhash0JobPlannedIterations(Context& ctx) { return jobOf(ctx).p.minHashIterationCount; }
 
 // Stage 4.  Candidates of this rank's readId0 range (sorted), statistics (this rank's partial sums, readCount x 3),
 // this rank's share of the per-iteration counters; ends the job.

@@ -141,8 +141,8 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
     struct Rank {
         std::vector<uint64_t> offsets;                       // world + 1: segment of every destination in this rank's sorted output
         const void* out0 = nullptr; const void* out1 = nullptr;    // records: keys u32 / vals u64; pair keys: u64 / -
-        DeviceBuffer<uint32_t> recvKeys;
-        DeviceBuffer<uint64_t> recvVals, recvPairs;
+        DeviceBuffer<uint32_t> recvKeys, recvTags;
+        DeviceBuffer<uint64_t> recvVals, recvPairs, recvKeys64;
         uint64_t high = 0;
         std::vector<uint64_t> usedPerIteration, histPerIteration, highPerIteration, totalPerIteration, statistics;
         std::vector<std::vector<uint32_t>> overflowPerIteration;
@@ -154,6 +154,10 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
     auto rankOf = [&](int r) -> Rank& { return *rankStorage[size_t(r)]; };
     CallBarrier barrier(world);
     const bool dynamic = p.minHashIterationCount == 0;
+    // A fixed number of iterations: all of them in one pass -- two exchanges and four barriers per JOB instead of per iteration
+    // (lowhash0HashAll / BucketsAll / MergeAll).  SHASTA_MI355X_LOWHASH_ONE_PASS=0: iteration after iteration.
+    const bool onePass = [&] { const char* e = std::getenv("SHASTA_MI355X_LOWHASH_ONE_PASS"); return !(e && e[0] == '0'); }()
+        && !dynamic && p.minHashIterationCount <= 4096 && world <= 256;
     uint64_t highFrequencyShared = 0;
     double deviceSeconds = 0;
 
@@ -186,7 +190,39 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
                 return n;
             };
             uint64_t highFrequency = 0;
-            for(uint64_t iteration = 0; ; iteration++) {
+            if(onePass) {
+                const uint64_t I = p.minHashIterationCount;
+                const uint64_t* keys = nullptr; const uint64_t* vals = nullptr;
+                lowhash0HashAll(ctx, me.offsets.data(), &keys, &vals);
+                me.out0 = keys; me.out1 = vals;
+                barrier.wait();
+                // C1: the records (of every iteration) of the buckets this device owns.
+                const uint64_t records = incoming();
+                me.recvKeys64.reserve(records + 1, stream); me.recvVals.reserve(records + 1, stream);
+                (void)pull(0, sizeof(uint64_t), me.recvKeys64.data());
+                (void)pull(1, sizeof(uint64_t), me.recvVals.data());
+                HIP_CHECK(hipStreamSynchronize(stream));
+                barrier.wait();                                   // every device has what it needs: the sources may be reused
+                const uint64_t* pairKeys = nullptr; const uint32_t* pairTags = nullptr;
+                std::vector<uint64_t> overflow;
+                me.usedPerIteration.assign(size_t(I), 0);
+                me.histPerIteration.assign(size_t(I) * size_t(LOWHASH0_SIZE_HISTOGRAM_BINS), 0);
+                lowhash0BucketsAll(ctx, me.recvKeys64.data(), me.recvVals.data(), records, me.offsets.data(), &pairKeys, &pairTags,
+                    me.usedPerIteration.data(), me.histPerIteration.data(), overflow);
+                me.overflowPerIteration.assign(size_t(I), std::vector<uint32_t>());
+                for(uint64_t e : overflow) me.overflowPerIteration[size_t(e >> 32)].push_back(uint32_t(e));
+                me.out0 = pairKeys; me.out1 = pairTags;
+                barrier.wait();
+                // C2: the pair keys (with their iteration tags) whose readId0 this device owns.
+                const uint64_t pairs = incoming();
+                me.recvPairs.reserve(pairs + 1, stream); me.recvTags.reserve(pairs + 1, stream);
+                (void)pull(0, sizeof(uint64_t), me.recvPairs.data());
+                (void)pull(1, sizeof(uint32_t), me.recvTags.data());
+                HIP_CHECK(hipStreamSynchronize(stream));
+                barrier.wait();
+                lowhash0MergeAll(ctx, me.recvPairs.data(), me.recvTags.data(), pairs);
+            }
+            else for(uint64_t iteration = 0; ; iteration++) {
                 // Iteration control, src/LowHash0.cpp:136-157 (on the global counter: every device decides alike).
                 if(dynamic) {
                     if(2. * double(highFrequency) / double(readCount) >= p.alignmentCandidatesPerRead) break;

@@ -290,12 +290,12 @@ struct RadixSortWorkspace {
     DeviceBuffer<uint32_t> scanTemp;
 };
 
-// Sorts n (< 2^32) keys on bits [0, bits) with 8-bit passes, ping-ponging between
+// Sorts n (< 2^32) keys on bits [firstBit, firstBit + bits) with 8-bit passes, ping-ponging between
 // (keysA, valsA) and (keysB, valsB).  Returns true if the result is in B (which side holds the result depends on
 // `bits` only, not on the count).
 template<class K, class V, bool HAS_V>
 inline bool radixSort(K* keysA, K* keysB, V* valsA, V* valsB, Count count, int bits,
-    RadixSortWorkspace& ws, hipStream_t stream)
+    RadixSortWorkspace& ws, hipStream_t stream, int firstBit = 0)
 {
     const uint64_t n = count.bound;                    // grids and workspace from the bound; the kernels use the exact count
     if(n == 0 || bits <= 0) return false;
@@ -305,7 +305,7 @@ inline bool radixSort(K* keysA, K* keysB, V* valsA, V* valsB, Count count, int b
     ws.counts.reserve(countN, stream);
     ws.scanTemp.reserve(scanTempElements(countN), stream);
     bool inB = false;
-    for(int shift = 0; shift < bits; shift += 8) {
+    for(int shift = firstBit; shift < firstBit + bits; shift += 8) {
         K* kin = inB ? keysB : keysA;  K* kout = inB ? keysA : keysB;
         V* vin = inB ? valsB : valsA;  V* vout = inB ? valsA : valsB;
         hipLaunchKernelGGL(radixHistogramKernel<K>, dim3(numBlocks), dim3(RS_THREADS), 0, stream,

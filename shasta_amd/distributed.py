@@ -20,6 +20,8 @@ The compute stages are behind a small backend interface (tensors in, tensors out
 backend is HipBackend (the C ABI's shasta_mi355x_lh_* entry points); the CPU tests plug in a numpy
 backend to exercise this file's sharding and exchange logic under gloo.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -99,6 +101,24 @@ class HipBackend:
     def finish(self):
         return self.ctx.lh_finish()
 
+    # All iterations in one pass (fixed minHashIterationCount): one call of each per job.
+    def hash_all(self):
+        offsets, keys, vals = self.ctx.lh_hash_all()
+        n = int(offsets[-1])
+        return offsets, self._tensor_from(keys, n, torch.int64), self._tensor_from(vals, n, torch.int64)
+
+    def buckets_all(self, keys, vals):
+        self._sync()
+        n = keys.numel()
+        offsets, pk, tags, used, hist, overflow = self.ctx.lh_buckets_all(keys.data_ptr() if n else 0, vals.data_ptr() if n else 0, n)
+        m = int(offsets[-1])
+        return offsets, self._tensor_from(pk, m, torch.int64), self._tensor_from(tags, m, torch.int32), used, hist, overflow
+
+    def merge_all(self, pair_keys, tags):
+        self._sync()
+        n = pair_keys.numel()
+        self.ctx.lh_merge_all(pair_keys.data_ptr() if n else 0, tags.data_ptr() if n else 0, n)
+
 
 def _comm_device(tensor_device):
     """Collectives run on the tensors' device with nccl (RCCL) and on the host with gloo."""
@@ -173,7 +193,24 @@ def lowhash0(backend, params, read_count, boundaries, group=None):
     used_rows, hist_rows, overflow_lists = [], [], []
     high_frequency = 0
     iteration = 0
-    while True:
+    # A fixed number of iterations: all of them in ONE pass -- the markers hashed once under every seed, one exchange of the
+    # records of all iterations, one of their pair keys: 2 data exchanges per job instead of 2 per iteration (per-link xGMI
+    # bandwidth wants few large collectives).  SHASTA_MI355X_LOWHASH_ONE_PASS=0: iteration after iteration, as with the dynamic control.
+    one_pass = (not dynamic and 1 <= int(params.minHashIterationCount) <= 4096 and world <= 256 and hasattr(backend, "hash_all")
+                and os.environ.get("SHASTA_MI355X_LOWHASH_ONE_PASS", "1") != "0")
+    if one_pass:
+        offsets, keys, vals = backend.hash_all()
+        keys, vals = exchange([keys, vals], offsets, group)                       # C1: records of all iterations to bucket owners
+        offsets, pair_keys, tags, used, hist, overflow = backend.buckets_all(keys, vals)
+        pair_keys, tags = exchange([pair_keys, tags], offsets, group)             # C2: pair keys + iteration tags to readId0 owners
+        backend.merge_all(pair_keys, tags)
+        iteration = int(params.minHashIterationCount)
+        overflow = np.asarray(overflow, dtype=np.uint64)
+        for t in range(iteration):
+            used_rows.append(int(used[t]))
+            hist_rows.append(np.asarray(hist[t], dtype=np.uint64))
+            overflow_lists.append([int(e & np.uint64(0xffffffff)) for e in overflow[(overflow >> np.uint64(32)) == np.uint64(t)]])
+    while not one_pass:
         # Iteration control, src/LowHash0.cpp:136-157 (on the global counter: every rank decides alike).
         if dynamic:
             if 2.0 * float(high_frequency) / float(read_count) >= params.alignmentCandidatesPerRead:

@@ -26,7 +26,7 @@ EXPORTS = [
     "shasta_mi355x_pair_table", "shasta_mi355x_read_graph_keep",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
-    "shasta_mi355x_lh_finish",
+    "shasta_mi355x_lh_finish", "shasta_mi355x_lh_hash_all", "shasta_mi355x_lh_buckets_all", "shasta_mi355x_lh_merge_all",
     "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
     "shasta_mi355x_find_markers", "shasta_mi355x_find_markers_free",
     "shasta_mi355x_palindromic_screen",
@@ -387,6 +387,7 @@ class Context:
             C.c_void_p(self.handle), C.byref(params), C.c_int(rank), C.c_int(world), abi.as_ptr(b, C.c_uint64),
             C.byref(log2)), "shasta_mi355x_lh_begin")
         self._world = world
+        self._planned_iterations = int(params.minHashIterationCount)
         return int(log2.value)
 
     def lh_hash(self, iteration):
@@ -419,6 +420,36 @@ class Context:
             C.c_void_p(self.handle), C.c_void_p(int(pair_keys_ptr)), C.c_uint64(int(n)), C.c_int(1 if evaluate_now else 0),
             C.byref(high), C.byref(total)), "shasta_mi355x_lh_merge")
         return int(high.value), int(total.value)
+
+    # The same job with all iterations in one pass (fixed minHashIterationCount): one call of each per job.
+    def lh_hash_all(self):
+        """-> (send offsets uint64[world+1], device pointer of keys u64 (owner << 56 | iteration << 32 | bucket id), of vals u64)."""
+        offsets = np.zeros(self._world + 1, dtype=np.uint64)
+        keys, vals = C.c_void_p(), C.c_void_p()
+        self.library._check(self.lib.shasta_mi355x_lh_hash_all(
+            C.c_void_p(self.handle), abi.as_ptr(offsets, C.c_uint64), C.byref(keys), C.byref(vals)), "shasta_mi355x_lh_hash_all")
+        return offsets, keys.value or 0, vals.value or 0
+
+    def lh_buckets_all(self, keys_ptr, vals_ptr, n):
+        """-> (send offsets, pair keys ptr (u64, sorted), their iteration tags ptr (u32), bucketsUsed uint64[iterations],
+        size histograms uint64[iterations, 2048], overflow entries uint64 (iteration << 32 | size))."""
+        iterations = self._planned_iterations
+        offsets = np.zeros(self._world + 1, dtype=np.uint64)
+        pair_keys, pair_tags = C.c_void_p(), C.c_void_p()
+        overflow_count = C.c_uint64()
+        used = np.zeros(max(1, iterations), dtype=np.uint64)
+        hist = np.zeros((max(1, iterations), 2048), dtype=np.uint64)
+        overflow = np.zeros(1 << 20, dtype=np.uint64)
+        self.library._check(self.lib.shasta_mi355x_lh_buckets_all(
+            C.c_void_p(self.handle), C.c_void_p(int(keys_ptr)), C.c_void_p(int(vals_ptr)), C.c_uint64(int(n)),
+            abi.as_ptr(offsets, C.c_uint64), C.byref(pair_keys), C.byref(pair_tags), C.c_uint64(max(1, iterations)), abi.as_ptr(used, C.c_uint64),
+            abi.as_ptr(hist, C.c_uint64), abi.as_ptr(overflow, C.c_uint64), C.c_uint64(len(overflow)),
+            C.byref(overflow_count)), "shasta_mi355x_lh_buckets_all")
+        return offsets, pair_keys.value or 0, pair_tags.value or 0, used[:iterations], hist[:iterations], overflow[:overflow_count.value].copy()
+
+    def lh_merge_all(self, pair_keys_ptr, pair_tags_ptr, n):
+        self.library._check(self.lib.shasta_mi355x_lh_merge_all(
+            C.c_void_p(self.handle), C.c_void_p(int(pair_keys_ptr)), C.c_void_p(int(pair_tags_ptr)), C.c_uint64(int(n))), "shasta_mi355x_lh_merge_all")
 
     def lh_finish(self, max_iterations=1 << 16):
         """-> (this rank's candidates, its partial statistics uint64[R,3], its share of high frequency / total per iteration)."""

@@ -52,7 +52,8 @@ def _worker(rank, world, port, out_dir, seed, kw, library_path):
 
 CASES = [
     (71, dict(minBucketSize=3, maxBucketSize=30, minFrequency=2)),
-    (72, dict(minHashIterationCount=0, alignmentCandidatesPerRead=6.0, maxBucketSize=40)),
+    (72, dict(minHashIterationCount=0, alignmentCandidatesPerRead=6.0, maxBucketSize=40)),      # dynamic control: iteration after iteration
+    (73, dict(log2MinHashBucketCount=31, minHashIterationCount=5, hashFraction=0.03, minBucketSize=2, maxBucketSize=30, minFrequency=2)),
 ]
 
 

@@ -95,6 +95,56 @@ class NumpyBackend:
         offsets[0], offsets[-1] = 0, len(pk)
         return offsets, torch.from_numpy(pk.view(np.int64).copy()), len(starts), hist, np.asarray(overflow, np.uint32)
 
+    # The job with all iterations in one pass: the same stages run iteration by iteration here, packed as the HIP stages
+    # pack them (keys owner << 56 | iteration << 32 | bucket id, each owner's records contiguous; pair keys with tags).
+    def hash_all(self):
+        iterations = int(self.p.minHashIterationCount)
+        per_owner_keys = [[] for _ in range(self.world)]
+        per_owner_vals = [[] for _ in range(self.world)]
+        for t in range(iterations):
+            offsets, keys, vals = self.hash(t)
+            keys = keys.numpy().view(np.uint32).astype(np.uint64)
+            vals = vals.numpy().view(np.uint64)
+            for r in range(self.world):
+                lo, hi = int(offsets[r]), int(offsets[r + 1])
+                per_owner_keys[r].append(keys[lo:hi] | (np.uint64(t) << np.uint64(32)) | (np.uint64(r) << np.uint64(56)))
+                per_owner_vals[r].append(vals[lo:hi])
+        sizes = [sum(len(k) for k in per_owner_keys[r]) for r in range(self.world)]
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        keys = np.concatenate([k for r in range(self.world) for k in per_owner_keys[r]]) if sum(sizes) else np.zeros(0, np.uint64)
+        vals = np.concatenate([v for r in range(self.world) for v in per_owner_vals[r]]) if sum(sizes) else np.zeros(0, np.uint64)
+        return offsets, torch.from_numpy(keys.view(np.int64).copy()), torch.from_numpy(vals.view(np.int64).copy())
+
+    def buckets_all(self, keys, vals):
+        iterations = int(self.p.minHashIterationCount)
+        keys = keys.numpy().view(np.uint64)
+        vals = vals.numpy().view(np.uint64)
+        of = (keys >> np.uint64(32)) & np.uint64(0xffffff)
+        used, hists, overflow, pair_keys, tags = [], [], [], [], []
+        for t in range(iterations):
+            sel = of == np.uint64(t)
+            k32 = (keys[sel] & np.uint64(0xffffffff)).astype(np.uint32)
+            _, pk, u, hist, over = self.buckets(torch.from_numpy(k32.view(np.int32).copy()), torch.from_numpy(vals[sel].view(np.int64).copy()))
+            pk = pk.numpy().view(np.uint64)
+            used.append(u); hists.append(hist)
+            overflow += [(t << 32) | int(s) for s in over]
+            pair_keys.append(pk); tags.append(np.full(len(pk), t, np.uint32))
+        pk = np.concatenate(pair_keys) if pair_keys else np.zeros(0, np.uint64)
+        tg = np.concatenate(tags) if tags else np.zeros(0, np.uint32)
+        order = np.argsort(pk, kind="stable")
+        pk, tg = pk[order], tg[order]
+        bounds = (self.boundaries.astype(np.uint64) << np.uint64(self.read_bits + 1))
+        offsets = self._owner_offsets(pk, bounds)
+        offsets[0], offsets[-1] = 0, len(pk)
+        return (offsets, torch.from_numpy(pk.view(np.int64).copy()), torch.from_numpy(tg.view(np.int32).copy()),
+                np.asarray(used, np.uint64), np.asarray(hists, np.uint64).reshape(iterations, 2048), np.asarray(overflow, np.uint64))
+
+    def merge_all(self, pair_keys, tags):
+        pk = pair_keys.numpy().view(np.uint64)
+        tg = tags.numpy().view(np.uint32)
+        for t in range(int(self.p.minHashIterationCount)):
+            self.merge(torch.from_numpy(pk[tg == t].view(np.int64).copy()), False)
+
     def merge(self, pair_keys, evaluate_now):
         # The reference folds the iteration's pairs into a uint16 frequency (src/LowHash0.hpp:116: additions wrap).
         for k in pair_keys.numpy().view(np.uint64).tolist():
