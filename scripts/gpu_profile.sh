@@ -33,7 +33,7 @@ echo "rocprof stats rc=$?"
 cd $R
 python scripts/kernel_timeline.py $(find gpurun_out/prof_final -name "*kernel_trace.csv" | head -1) 15 100 > gpurun_out/timeline_final.txt 2>&1
 timeout 900 python bench.py --reads $READS --steps 5 --warmup 2 --no-cpu-baseline --lowhash-only > gpurun_out/bench_final_lh.json 2> gpurun_out/bench_final_lh.err
-timeout 900 python bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline --align-method 3 > gpurun_out/bench_final_m3.json 2> gpurun_out/bench_final_m3.err
+timeout 900 python bench.py --reads $READS --steps 4 --warmup 3 --no-cpu-baseline --align-method 3 > gpurun_out/bench_final_m3.json 2> gpurun_out/bench_final_m3.err
 timeout 900 python bench.py --reads 20000 --steps 3 --warmup 1 --markers > gpurun_out/bench_final_markers.json 2> gpurun_out/bench_final_markers.err
 SHASTA_MI355X_ALIGN_WORKERS=1 timeout 900 python bench.py --reads $READS --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_final_w1.json 2> gpurun_out/bench_final_w1.err
 # The in-process group over one device (the seam a C++ caller uses), and the reference aligner on the WHOLE candidate list.

@@ -682,22 +682,31 @@ template<class T> T* mallocCopy(const std::vector<T>& v)
 
 int bitsFor(uint64_t maxValue) { int b = 1; while((maxValue >> b) != 0) ++b; return b; }
 
-// The row of the kernel table a launch for this m is booked under (the template instance that runs).
-const char* hashKernelName(uint32_t m, bool all = false)
+// The row of the kernel table a launch for this m is booked under: the template instance that runs, as a profiler prints it
+// (M_FIXED, all iterations in one pass or not, the records' key type).
+const char* hashKernelName(uint32_t m, bool all = false, bool wideKeys = false)
 {
+    if(all && wideKeys) {
+        switch(m) {
+            case 3: return "hashWindowsKernel<3, true, unsigned long>";
+            case 4: return "hashWindowsKernel<4, true, unsigned long>";
+            case 5: return "hashWindowsKernel<5, true, unsigned long>";
+            default: return "hashWindowsKernel<0, true, unsigned long>";
+        }
+    }
     if(all) {
         switch(m) {
-            case 3: return "hashWindowsKernel<3, true>";           // (true: all iterations in one pass; the names a profiler shows)
-            case 4: return "hashWindowsKernel<4, true>";
-            case 5: return "hashWindowsKernel<5, true>";
-            default: return "hashWindowsKernel<0, true>";
+            case 3: return "hashWindowsKernel<3, true, unsigned int>";
+            case 4: return "hashWindowsKernel<4, true, unsigned int>";
+            case 5: return "hashWindowsKernel<5, true, unsigned int>";
+            default: return "hashWindowsKernel<0, true, unsigned int>";
         }
     }
     switch(m) {
-        case 3: return "hashWindowsKernel<3, false>";
-        case 4: return "hashWindowsKernel<4, false>";
-        case 5: return "hashWindowsKernel<5, false>";
-        default: return "hashWindowsKernel<0, false>";
+        case 3: return "hashWindowsKernel<3, false, unsigned int>";
+        case 4: return "hashWindowsKernel<4, false, unsigned int>";
+        case 5: return "hashWindowsKernel<5, false, unsigned int>";
+        default: return "hashWindowsKernel<0, false, unsigned int>";
     }
 }
 
@@ -1226,7 +1235,7 @@ void lowhash0HashAll(Context& ctx, uint64_t* sendOffsets, const uint64_t** keysO
         job.recKeysA.reserve(2 * capacity, stream); job.recKeysB.reserve(2 * capacity, stream);
         job.recValsA.reserve(capacity, stream); job.recValsB.reserve(capacity, stream);
         HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
-        const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(job.p.m), true), stream);
+        const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(job.p.m), true, true), stream);
         launchHash<uint64_t>(ctx, uint32_t(job.p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
             reinterpret_cast<uint64_t*>(job.recKeysA.data()), job.recValsA.data(), counter, capacity, uint32_t(I), 32u);
         job.hashHandles.push_back(ctx.timers.end(span, 4 * (job.markerEnd - job.markerBegin), (job.markerEnd - job.markerBegin) * I));
@@ -1441,7 +1450,7 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
                 const uint64_t keyWords = recordCapacityAll * (wideKeys ? 2 : 1);
                 job.recKeysA.reserve(keyWords, stream); job.recKeysB.reserve(keyWords, stream);
                 job.recValsA.reserve(recordCapacityAll, stream); job.recValsB.reserve(recordCapacityAll, stream);
-                const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(p.m), true), stream);
+                const KernelTimers::Span span = ctx.timers.begin(hashKernelName(uint32_t(p.m), true, wideKeys), stream);
                 if(wideKeys) launchHash<uint64_t>(ctx, uint32_t(p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,
                     reinterpret_cast<uint64_t*>(job.recKeysA.data()), job.recValsA.data(), counters + C_RECORDS, recordCapacityAll, uint32_t(I), 32u);
                 else launchHash(ctx, uint32_t(p.m), 0, job.hashThreshold, job.mask, job.markerBegin, job.markerEnd,

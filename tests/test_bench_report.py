@@ -13,7 +13,7 @@ from shasta_amd import abi
 
 
 FAKE_TABLE = {
-    "hashWindowsKernel<4, true>": {"seconds": 0.02, "launches": 20, "bytes": 20 * 1_250_000_000, "work": 20 * 300_000_000},
+    "hashWindowsKernel<4, true, unsigned int>": {"seconds": 0.02, "launches": 20, "bytes": 20 * 1_250_000_000, "work": 20 * 300_000_000},
     "radix sort of low-hash records": {"seconds": 0.004, "launches": 20, "bytes": 20 * 300_000_000, "work": 20 * 3_000_000},
     "align4CellsChunkKernel<2, false>": {"seconds": 0.22, "launches": 64, "bytes": 64 * 500_000_000, "work": 3_000_000},
     "bandedDpForwardKernel<16, 2>": {"seconds": 0.08, "launches": 32, "bytes": 32 * 296_000_000, "work": int(3e10)},
@@ -74,7 +74,7 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     pmc = tmp_path / "pmc.json"
     pmc.write_text(json.dumps({"workload_reads": 100000, "kernels": {
         "bandedDpForwardKernel<16, 4, 0, false>": {"hbm_bytes_per_launch": 2.6e9, "valu_wave_instructions_per_launch": 2.3e9},
-        "hashWindowsKernel<4, true>": {"hbm_bytes_per_launch": 1.5e9, "valu_wave_instructions_per_launch": 3.6e8}}}))
+        "hashWindowsKernel<4, true, unsigned int>": {"hbm_bytes_per_launch": 1.5e9, "valu_wave_instructions_per_launch": 3.6e8}}}))
     monkeypatch.setattr(bench, "PMC_FILE", str(pmc))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--reads", "100000"])
@@ -96,10 +96,10 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     assert r["kernel"] == "bandedDpForwardKernel<16, 4, 0, false>" and r["bound"] == "valu" and r["traffic"] == 2.6e9
     assert r["valu"]["frac"] == pytest.approx(2.3e9 / (0.28 / 32) / bench.VALU_PEAK_WAVE_INSTRUCTIONS_PER_S)
     k = d["kernels"]
-    assert k["hashWindowsKernel<4, true>"]["launches_per_step"] == 10 and k["hashWindowsKernel<4, true>"]["avg_ms"] == pytest.approx(1.0)
-    assert k["hashWindowsKernel<4, true>"]["achieved_GBps"] == pytest.approx(1250.0)
+    assert k["hashWindowsKernel<4, true, unsigned int>"]["launches_per_step"] == 10 and k["hashWindowsKernel<4, true, unsigned int>"]["avg_ms"] == pytest.approx(1.0)
+    assert k["hashWindowsKernel<4, true, unsigned int>"]["achieved_GBps"] == pytest.approx(1250.0)
     assert sum(v["share_of_kernel_time"] for v in k.values()) == pytest.approx(1.0)
-    assert d["hbm_natured_kernel"]["kernel"] == "hashWindowsKernel<4, true>" and d["hbm_natured_kernel"]["traffic"] == 1.5e9
+    assert d["hbm_natured_kernel"]["kernel"] == "hashWindowsKernel<4, true, unsigned int>" and d["hbm_natured_kernel"]["traffic"] == 1.5e9
     assert d["aligner_status"]["stored"] == 999 and d["aligner_status"]["rejected_by_filters"] == 1
     assert d["cpu_baseline"]["cores"] == 64 and d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)
 
