@@ -3,10 +3,10 @@
 the unit seam shasta_mi355x_banded_dp_many, without the rest of the Align4 stage: the quick A/B of a kernel edit.
 
     python scripts/dp_microbench.py [--tasks 20000] [--length 1500] [--repeat 3]
-    SHASTA_MI355X_DP_FORWARD=1 python scripts/dp_microbench.py ...      # the first version of the forward kernel
+    SHASTA_MI355X_LIBRARY=<another build> python scripts/dp_microbench.py ...      # the A side of an A/B
 
 Each task aligns two noisy copies of one random marker sequence inside a band around their true diagonal; the band
-widths cover the six classes in the proportions of a real batch (mostly <= 64).  Prints one JSON line per repeat:
+widths cover the band classes in the proportions of a real batch (mostly <= 64).  Prints one JSON line per repeat:
 GCUPS (DP cells = nx x band width per second) per class from HIP events around each launch."""
 import argparse
 import json

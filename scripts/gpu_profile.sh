@@ -1,5 +1,5 @@
 #!/bin/bash
-# A round's measurement call (ROUND=r03 bash scripts/gpu_profile.sh; this round's was scripts/gpu_r02_profile.sh).  Order matters: the PMC passes come first and their per-kernel summary is written to
+# A round's measurement call (ROUND=r03 bash scripts/gpu_profile.sh; round 2's was scripts/gpu_r02_profile.sh, in the git history).  Order matters: the PMC passes come first and their per-kernel summary is written to
 # profiles/${ROUND}_pmc_100k_reads.json ON THE BOX, so that the bench line that follows takes its roofline's `traffic` and VALU
 # instruction counts from counters collected on the same build in the same session.
 #   1 suite   2 PMC passes (one aligner worker: per-kernel counters without overlap) + summary   3 the bench line as the driver
