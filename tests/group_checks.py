@@ -59,6 +59,29 @@ def lowhash0_and_aligners(lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_r
     return compared
 
 
+class _Sharded:
+    """`lib` with lowhash0 routed through the device list: what tests/adversarial.py's LowHash0 cases call."""
+    def __init__(self, lib, devices):
+        self.lib, self.devices = lib, devices
+
+    def lowhash0(self, toc, data7, flags, params):
+        return self.lib.lowhash0_multi(toc, data7, flags, params, self.devices)
+
+
+def adversarial_lowhash0(lib, oracle_lib, devices=(0, 0, 0)):
+    """The adversarial LowHash0 parameter sets and read sets (hashFraction 0 / 1 / 1.5, 2^31 buckets, MinHash 10/50/5, a forced
+    uint16 wrap, the dynamic iteration control, empty and repeated reads ...) through the sharded job: all iterations in one
+    pass where their number is fixed (empty exchanges, 64-bit keys, bucket sizes beyond the histogram bins), iteration after
+    iteration otherwise."""
+    from tests import adversarial
+    sharded = _Sharded(lib, devices)
+    for name in adversarial.LOWHASH_CASE_NAMES:
+        adversarial.lowhash_case(sharded, oracle_lib, name)
+    for name in adversarial.LOWHASH_READ_SET_NAMES:
+        adversarial.lowhash_read_set(sharded, oracle_lib, name)
+    return len(adversarial.LOWHASH_CASE_NAMES) + len(adversarial.LOWHASH_READ_SET_NAMES)
+
+
 def errors_do_not_hang(lib):
     import pytest
     toc, kmer, data7 = support.small_marker_set(n_reads=60, genome_markers=5000, seed=62)

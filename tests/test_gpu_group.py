@@ -14,3 +14,8 @@ def test_several_devices_behind_one_call(gpu_lib, oracle_lib):
 def test_group_errors_do_not_hang(gpu_lib):
     from tests import group_checks
     group_checks.errors_do_not_hang(gpu_lib)
+
+
+def test_adversarial_lowhash0_through_the_group(gpu_lib, oracle_lib):
+    from tests import group_checks
+    assert group_checks.adversarial_lowhash0(gpu_lib, oracle_lib) > 15
