@@ -178,7 +178,9 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
         from oracle import census
         sub = np.ascontiguousarray(sample[::max(1, len(sample) // census_size)])
         t0 = time.time()
-        parity["dp_tie_sensitive"] = census.tie_census(lib, toc, data7, sub, o, align_method=align_method, threads=cores)
+        # (Sixteen threads at most: every call of the checker gives each of its threads the reference's 2-GiB arena,
+        # src/AssemblerAlign.cpp:353-355, and twelve calls on 64 threads spent 140 of their 150 seconds creating arenas.)
+        parity["dp_tie_sensitive"] = census.tie_census(lib, toc, data7, sub, o, align_method=align_method, threads=min(cores, 16))
         parity["dp_tie_sensitive"]["seconds"] = time.time() - t0
     pairs = len(cand)
     total = t_lh + pairs * per_pair
