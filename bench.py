@@ -335,8 +335,8 @@ def markers_bench(lib, ctx, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on (0 = all of them: a minute or two)")

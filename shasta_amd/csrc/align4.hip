@@ -1487,6 +1487,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     }
     HIP_CHECK(hipEventRecord(evEnd, ctx.stream));
     HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    // Every worker's buffers up to what any worker's batches needed, now that nothing is in flight: which worker meets which
+    // batch changes from call to call, and a worker that found a mark above its buffer at the start of a batch of the NEXT call
+    // reallocated there -- hipFree waits for the whole device, in the middle of that call (the second call on a context: 192 ms
+    // against 146 - 157 for the later ones at 100 k reads).
+    for(int k = 0; k < workerCount; k++) if(workers[k].error.empty()) workers[k].scratch->raiseToMarks(workers[k].stream);
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
