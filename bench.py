@@ -47,10 +47,20 @@ PMC_FILE = _latest_pmc_file()
 HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
 
 
-def make_workload(n_reads, seed):
+def make_workload(n_reads, seed, shards=1):
+    """shards > 1: the read set of an N-rank run -- n_reads / shards reads per rank from one genome, each rank's from its own
+    stream, as the ranks generate them -- in one piece (the in-process group's line beside an RCCL run is about the same reads)."""
     from shasta_amd import synthetic
     # 45x coverage: n_reads * 1500 genome markers per read / genome markers.
     genome_markers = max(20000, int(round(n_reads * 1500 / 45.0)))
+    if shards > 1:
+        parts = [synthetic.marker_reads(n_reads // shards, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
+                                        keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, shard=r, shard_count=shards)
+                 for r in range(shards)]
+        sizes = np.concatenate([np.diff(t.astype(np.int64)) for t, _ in parts])
+        toc = np.zeros(len(sizes) + 1, dtype=np.uint64)
+        toc[1:] = np.cumsum(sizes)
+        return toc, np.concatenate([k for _, k in parts])
     # SHASTA_BENCH_WORKLOAD_CACHE=<directory>: measurement scripts that run this command several times in one GPU call keep
     # the generated read set (a minute of host time per run) in a scratch directory; same arrays either way.
     cache = os.environ.get("SHASTA_BENCH_WORKLOAD_CACHE")
@@ -345,6 +355,8 @@ def main():
     ap.add_argument("--group", action="store_true",
                     help="ONE process drives --gpus devices through the in-process group (shasta_mi355x_group) instead of one process per "
                          "GPU with RCCL; with torch.distributed.run and N > 1 the group line is measured by rank 0 after the RCCL line anyway")
+    ap.add_argument("--sharded-workload", action="store_true",
+                    help="(with --group) the reads as the N ranks of `torch.distributed.run ... --gpus N` generate them: what rank 0's child process runs")
     ap.add_argument("--lowhash-only", action="store_true", help="BASELINE configs[1]")
     ap.add_argument("--markers", action="store_true",
                     help="marker finding only (SURVEY 8f row 2): random RLE reads of --reads x 20 kb, k = 10, 10 %% of the k-mers markers")
@@ -398,10 +410,11 @@ def main():
     if args.group and world == 1:
         # ONE process, --gpus devices, the in-process group (weak scaling like the other mode: --reads reads per GPU).
         n = max(1, args.gpus)
-        assert lib.device_count() >= n or DRY_RUN_LIBRARY, "--group --gpus %d needs that many devices" % n
-        toc, kmer = make_workload(args.reads * n, 12345)
+        assert lib.device_count() >= n or DRY_RUN_LIBRARY or os.environ.get("SHASTA_BENCH_ONE_DEVICE"), "--group --gpus %d needs that many devices" % n
+        toc, kmer = make_workload(args.reads * n, 12345, shards=n if args.sharded_workload else 1)
         ctx.close()
-        g = group_bench(lib, list(range(n)) if not DRY_RUN_LIBRARY else [0] * n, toc, kmer, p, o, args, args.align_method)
+        one_device = bool(os.environ.get("SHASTA_BENCH_ONE_DEVICE") or DRY_RUN_LIBRARY)        # (a box with one GPU: device 0 listed n times)
+        g = group_bench(lib, [0] * n if one_device else list(range(n)), toc, kmer, p, o, args, args.align_method)
         print(json.dumps({
             "metric": "candidate read-pairs aligned/sec (LowHash0+Align%d), in-process group" % (4 if args.align_method == 4 else 3),
             "value": g["value"], "unit": "pairs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": g["ms_per_step"],
@@ -452,7 +465,7 @@ def main():
         if not DRY_RUN_LIBRARY:
             torch.cuda.synchronize()
         ctx.set_kmer_ids_device(toc, everything.data_ptr())
-        all_kmer_ids = everything          # (rank 0 hands them to the in-process group after the timed region)
+        all_kmer_ids = everything          # (the context reads them in place: kept alive)
         del everything
         marker_count = int(toc[-1])
         read_count = world * args.reads
@@ -525,20 +538,33 @@ def main():
         if status_counts is not None:
             status_counts = [int(x) for x in c[1:].tolist()]
 
-    # N > 1: the same job once more through the in-process group, by rank 0 alone over all N devices (the seam a C++ caller of
-    # the two Assembler functions uses: no RCCL, device-to-device pulls), so that one multi-GPU run compares the two drivers.
-    # The other ranks wait on the HOST (a gloo group: an RCCL barrier would spin on their GPUs meanwhile).  A failure of this
-    # extra line (peer access, memory) is reported in it and does not cost the run its result.
+    # N > 1: a job of the same shape once more through the in-process group -- ONE process over all N devices, the seam a C++
+    # caller of the two Assembler functions uses: no RCCL, device-to-device pulls -- so that one multi-GPU run compares the two
+    # drivers.  It runs in a CHILD process of rank 0 (`bench.py --group --sharded-workload --gpus N`, which generates the same
+    # reads again): peer access between distinct devices has never executed anywhere, and whatever it does there -- an error, a
+    # crash, a hang that runs into the timeout -- must not cost this run its result.  The other ranks wait on the HOST (a gloo
+    # group: an RCCL barrier would spin on their GPUs meanwhile).
     group_line = None
     if dist is not None and not args.lowhash_only and not os.environ.get("SHASTA_BENCH_NO_GROUP_LINE"):
         waiting = dist.new_group(backend="gloo")
         if rank == 0:
             try:
-                host_kmer = all_kmer_ids.cpu().numpy().view(np.uint32)
-                devices = list(range(world)) if not (os.environ.get("SHASTA_BENCH_ONE_DEVICE") or DRY_RUN_LIBRARY) else [0] * world
-                group_line = group_bench(lib, devices, toc, host_kmer, p, o, args, args.align_method)
-            except Exception as e:          # noqa: BLE001 -- reported, not raised
-                group_line = {"error": "%s: %s" % (type(e).__name__, e)}
+                import subprocess
+                child_env = {k: v for k, v in os.environ.items()
+                             if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                          "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                                          "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--group", "--sharded-workload", "--gpus", str(world), "--reads", str(args.reads),
+                                        "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(min(args.warmup, 2)),
+                                        "--align-method", str(args.align_method)],
+                                       env=child_env, capture_output=True, text=True, timeout=900)
+                lines = [ln for ln in child.stdout.strip().splitlines() if ln.startswith("{")]
+                if child.returncode == 0 and lines:
+                    group_line = json.loads(lines[-1])["in_process_group"]
+                else:
+                    group_line = {"error": "bench.py --group --gpus %d ended with code %d: %s" % (world, child.returncode, child.stderr[-400:])}
+            except Exception as e:          # noqa: BLE001 -- reported, not raised (a timeout included)
+                group_line = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         dist.barrier(group=waiting)
 
     if rank == 0:
