@@ -47,13 +47,13 @@ PMC_FILE = _latest_pmc_file()
 HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
 
 
-def make_workload(n_reads, seed, shards=1):
-    """shards > 1: the read set of an N-rank run -- n_reads / shards reads per rank from one genome, each rank's from its own
+def make_workload(n_reads, seed, shards=0):
+    """shards >= 1: the read set of an N-rank run -- n_reads / shards reads per rank from one genome, each rank's from its own
     stream, as the ranks generate them -- in one piece (the in-process group's line beside an RCCL run is about the same reads)."""
     from shasta_amd import synthetic
     # 45x coverage: n_reads * 1500 genome markers per read / genome markers.
     genome_markers = max(20000, int(round(n_reads * 1500 / 45.0)))
-    if shards > 1:
+    if shards >= 1:
         parts = [synthetic.marker_reads(n_reads // shards, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
                                         keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, shard=r, shard_count=shards)
                  for r in range(shards)]
@@ -371,7 +371,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    # SHASTA_BENCH_FORCE_SHARDED=1: the N-rank code path -- sharded generation, all-gather of the kmer ids, the staged LowHash0
+    # with its exchanges, candidate re-split, every collective over RCCL -- with the ONE rank a one-GPU box allows (a rank
+    # exchanging with itself): what the driver's per-rank work costs beside the one-GPU path, and that the path runs at all.
+    sharded = world > 1 or bool(os.environ.get("SHASTA_BENCH_FORCE_SHARDED"))
+    if args.gpus > 1 or sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -411,7 +415,7 @@ def main():
         # ONE process, --gpus devices, the in-process group (weak scaling like the other mode: --reads reads per GPU).
         n = max(1, args.gpus)
         assert lib.device_count() >= n or DRY_RUN_LIBRARY or os.environ.get("SHASTA_BENCH_ONE_DEVICE"), "--group --gpus %d needs that many devices" % n
-        toc, kmer = make_workload(args.reads * n, 12345, shards=n if args.sharded_workload else 1)
+        toc, kmer = make_workload(args.reads * n, 12345, shards=n if args.sharded_workload else 0)
         ctx.close()
         one_device = bool(os.environ.get("SHASTA_BENCH_ONE_DEVICE") or DRY_RUN_LIBRARY)        # (a box with one GPU: device 0 listed n times)
         g = group_bench(lib, [0] * n if one_device else list(range(n)), toc, kmer, p, o, args, args.align_method)
@@ -427,7 +431,7 @@ def main():
         return
 
     toc = kmer = None
-    if world == 1:
+    if not sharded:
         # Workload: BASELINE configs[2].
         toc, kmer = make_workload(args.reads, 12345)
         marker_count = int(toc[-1])
@@ -474,8 +478,10 @@ def main():
         upload_seconds = None
 
         def step():
+            t_lh = time.perf_counter()
             lh = distributed.lowhash0(backend, p, read_count, boundaries)
             share, total = distributed.candidate_share(lh.candidates, device, toc=toc)
+            lh.seconds = time.perf_counter() - t_lh          # (this rank's wall clock: the staged job, both exchanges, the candidate re-split)
             if args.lowhash_only:
                 return lh, None, total
             al = align(share)
@@ -496,13 +502,15 @@ def main():
     each_step = []                                  # (LowHash0 device ms, aligner device ms) of every timed step: outliers show here
     for _ in range(args.steps):
         lh, al, pairs_total = step()
-        if world == 1:
+        if not sharded:
             lh_dev += lh.device_seconds
+            lh_wall += lh.seconds
+        else:
             lh_wall += lh.seconds
         if al is not None:
             al_dev += al.device_seconds
             al_wall += al.seconds
-        each_step.append([round(1e3 * lh.device_seconds, 2) if world == 1 else None, round(1e3 * al.device_seconds, 2) if al is not None else None])
+        each_step.append([round(1e3 * lh.device_seconds, 2) if not sharded else round(1e3 * lh.seconds, 2), round(1e3 * al.device_seconds, 2) if al is not None else None])
     sync()
     elapsed = time.perf_counter() - t0
     table = ctx.kernel_table()
@@ -510,7 +518,7 @@ def main():
     # the device, and the HIP-event duration of a launch includes the time it spent sharing; this pass gives every kernel's
     # duration alone on the device (what a profiler's per-kernel view and the PMC passes see).
     table_one_worker = None
-    if world == 1 and al is not None and not DRY_RUN_LIBRARY:
+    if not sharded and al is not None and not DRY_RUN_LIBRARY:
         previous = os.environ.get("SHASTA_MI355X_ALIGN_WORKERS")
         os.environ["SHASTA_MI355X_ALIGN_WORKERS"] = "1"
         ctx.kernel_table_reset()
@@ -567,11 +575,12 @@ def main():
                 group_line = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         dist.barrier(group=waiting)
 
+    final_line = None
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = elapsed / steps * 1e3
         value = pairs_total / (elapsed / steps)
-        pmc = load_pmc(args.reads) if world == 1 else {}
+        pmc = load_pmc(args.reads) if not sharded else {}
         kernels = kernel_rows(table, steps, pmc)
         kernel_seconds = sum(r["seconds_per_step"] for r in kernels.values())
         for r in kernels.values():
@@ -613,9 +622,10 @@ def main():
                                                           "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"),
                 "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
-                "parallelism": "1 GPU" if world == 1 else
-                               "%d GPUs, one job: reads sharded by id range, RCCL all-to-all of low-hash records and of pair "
-                               "keys per MinHash iteration, candidates re-split by sum(nx+ny) for Align4" % world,
+                "parallelism": "1 GPU" if not sharded else
+                               "%d GPU%s, one job: reads sharded by id range, RCCL all-to-all of the low-hash records and of the pair "
+                               "keys of all MinHash iterations (two exchanges per job), candidates re-split by sum(nx+ny) for Align4"
+                               % (world, "" if world == 1 else "s"),
             },
             "stage_device_ms_each_step": each_step,
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
@@ -647,18 +657,35 @@ def main():
             # (here 4 B dense kmer ids per marker; 7 B packed through set_markers).  Never part of `value`.
             out["pcie_inclusive"] = {"upload_seconds": upload_seconds, "upload_bytes": 4 * marker_count,
                                      "value_with_upload_every_step": pairs_total / (elapsed / steps + upload_seconds)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not sharded:
             lh_check = ctx.lowhash0(p)
             out["cpu_baseline"], out["parity_at_bench_size"] = cpu_baseline(
                 ctx, toc, kmer, p, o, args.align_method, lh_check, args.baseline_sample if not DRY_RUN_LIBRARY else 200,
                 census_size=args.tie_census if not DRY_RUN_LIBRARY else 60)
             out["dp_tie_sensitive"] = out["parity_at_bench_size"].pop("dp_tie_sensitive", None)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
-        print(json.dumps(out))
+        final_line = json.dumps(out)
     ctx.close()
     if dist is not None:
+        # The JSON line has to be the LAST thing on stdout: RCCL's version banner (it prints one when NCCL_DEBUG asks for it, as
+        # on the GPU box) sits in the C library's stdout buffer of a process until that is flushed -- at exit, i.e. AFTER a line
+        # printed from Python.  So: every rank empties both buffers, all ranks meet, the process group goes, and only then
+        # rank 0 prints.
+        _flush_all_stdio()
         dist.barrier()
         dist.destroy_process_group()
+    _flush_all_stdio()
+    if final_line is not None:
+        print(final_line, flush=True)
+
+
+def _flush_all_stdio():
+    sys.stdout.flush(); sys.stderr.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:          # noqa: BLE001
+        pass
 
 
 if __name__ == "__main__":

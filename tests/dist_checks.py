@@ -12,13 +12,15 @@ from shasta_amd import abi, distributed
 from tests import support
 
 
-def _worker(rank, world, port, out_dir, seed, kw, library_path):
+def _worker(rank, world, port, out_dir, seed, kw, library_path, transport="gloo"):
     import torch
     import torch.distributed as dist
     import shasta_amd
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if transport == "nccl":
+        torch.cuda.set_device(0)                 # (before the process group: RCCL binds the communicator to the current device)
+    dist.init_process_group(transport, rank=rank, world_size=world)
     try:
         if library_path is None:
             torch.cuda.set_device(0)
@@ -57,10 +59,9 @@ CASES = [
 ]
 
 
-def two_ranks_equal_single_process_oracle(oracle_lib, seed, kw, library_path=None, port_base=29700):
-    world = 2
+def two_ranks_equal_single_process_oracle(oracle_lib, seed, kw, library_path=None, port_base=29700, world=2, transport="gloo"):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port_base + seed, d, seed, kw, library_path), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port_base + seed, d, seed, kw, library_path, transport), nprocs=world, join=True)
         toc, kmer, data7 = support.small_marker_set(n_reads=400, genome_markers=25000, seed=seed)
         flags = np.zeros(400, np.uint8)
         flags[[0, 7, 399]] = 1
