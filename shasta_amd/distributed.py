@@ -6,11 +6,12 @@ counterpart -- it is a single shared-memory process -- so this module follows th
 
 * reads are split into contiguous ranges balanced by marker count; every rank hashes its own
   range (no communication);
-* bucket ids are owned in contiguous ranges: all-to-all(v) of the low-hash records (12 bytes
-  each) per iteration;
+* bucket ids are owned in contiguous ranges: all-to-all(v) of the low-hash records -- of ALL
+  iterations at once (16 bytes each) when their number is fixed, per iteration (12 bytes each)
+  under the dynamic iteration control;
 * pair keys are owned by the rank whose read range contains readId0: all-to-all(v) of the 8-byte
-  keys; the per-iteration counters, the bucket-size histograms and the per-read statistics are
-  all-reduced once, after the last iteration;
+  keys (with their iteration tags in the one-pass form); the per-iteration counters, the bucket-size
+  histograms and the per-read statistics are all-reduced once, after the last iteration;
 * each rank's candidates are sorted and cover its readId0 range, so the concatenation in rank
   order is the reference's candidate list;
 * Align4 candidates are independent: the candidate list is all-gathered and re-split into contiguous
@@ -300,9 +301,47 @@ def candidate_share(local_candidates, device="cpu", group=None, toc=None):
     if toc is None:
         lo, hi = candidate_slice(total, rank, world)
         return gathered[3 * lo:3 * hi].cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1), total
-    everything = gathered.cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
-    lo, hi = candidate_slice_by_markers(everything, toc, rank, world)
-    return everything[lo:hi], total
+    # The weights and their prefix sums where the gathered list is (the device): with world ranks the list is world times a
+    # rank's own, and the numpy form of this -- two gathers and a cumulative sum over ALL candidates on every rank's host, after
+    # a device-to-host copy of all of them -- was 17 ms per step with one rank of 2 M candidates.
+    lo, hi = _slice_by_markers_on(gathered, _toc_on(toc, home), rank, world)
+    return gathered[3 * lo:3 * hi].cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1), total
+
+
+_toc_cache = {}
+
+
+def _toc_on(toc, device):
+    """Markers.toc as an int64 tensor on `device` (kept: the same array is handed in at every step)."""
+    key = (id(toc), str(device))
+    hit = _toc_cache.get(key)
+    if hit is None or hit[0] is not toc:
+        _toc_cache.clear()
+        hit = (toc, torch.from_numpy(np.ascontiguousarray(toc, dtype=np.uint64).view(np.int64)).to(device))
+        _toc_cache[key] = hit
+    return hit[1]
+
+
+def _slice_by_markers_on(flat, toc, rank, world):
+    """candidate_slice_by_markers on the tensor of int32 triplets (readId0, readId1, isSameStrand in the low byte): the same
+    cuts, computed where the tensor lives."""
+    n = flat.numel() // 3
+    if n == 0:
+        return 0, 0
+    c = flat.view(-1, 3).to(torch.int64)
+    sizes = toc[1:] - toc[:-1]
+    o0 = 2 * c[:, 0]
+    o1 = 2 * c[:, 1] + ((c[:, 2] & 0xff) == 0).to(torch.int64)
+    prefix = torch.cumsum(sizes[o0] + sizes[o1] + 64, dim=0)
+    last = int(prefix[-1].item())
+    cuts = [0]
+    for r in range(1, world):
+        target = int(float(last) * float(r) / float(world))
+        # first index i of [0, prefix...] with value >= target  (numpy.searchsorted(..., side="left") on the array with a leading 0)
+        at = 0 if target <= 0 else int(torch.searchsorted(prefix, torch.tensor([target], dtype=torch.int64, device=prefix.device), right=False).item()) + 1
+        cuts.append(min(max(at, cuts[-1]), n))
+    cuts.append(n)
+    return cuts[rank], cuts[rank + 1]
 
 
 def candidate_slice(count, rank, world):
