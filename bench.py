@@ -565,7 +565,7 @@ def main():
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--group", "--sharded-workload", "--gpus", str(world), "--reads", str(args.reads),
                                         "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(min(args.warmup, 2)),
                                         "--align-method", str(args.align_method)],
-                                       env=child_env, capture_output=True, text=True, timeout=900)
+                                       env=child_env, capture_output=True, text=True, timeout=300)
                 lines = [ln for ln in child.stdout.strip().splitlines() if ln.startswith("{")]
                 if child.returncode == 0 and lines:
                     group_line = json.loads(lines[-1])["in_process_group"]
