@@ -175,3 +175,19 @@ def test_bench_script_in_process_group_mode_on_the_emulated_build(emu_lib):
     assert line["n_gpus"] == 2 and line["value"] > 0 and "NOT A MEASUREMENT" in line["data"] and "in-process group" in line["metric"]
     assert line["in_process_group"]["devices"] == [0, 0] and line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0
 
+
+
+def test_bench_script_one_rank_through_the_sharded_branch_on_the_emulated_build(emu_lib):
+    """SHASTA_BENCH_FORCE_SHARDED=1: bench.py's N-rank branch with the one rank a one-GPU box allows (on the MI355X over RCCL;
+    here over gloo on the emulated build) -- and the JSON line is the last thing on stdout."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, HIPEMU_THREADS="4", SHASTA_BENCH_FORCE_SHARDED="1", SHASTA_BENCH_NO_GROUP_LINE="1",
+               MASTER_PORT="29641")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "100", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL all-to-all" in line["config"]["parallelism"]
+    assert line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0 and "cpu_baseline" not in line
