@@ -498,6 +498,8 @@ def main():
     sync()
     ctx.kernel_table_reset()
     t0 = time.perf_counter()
+    cpu0 = _process_cpu_seconds()
+    throttled0 = _cgroup_throttled_usec()
     lh_dev = al_dev = lh_wall = al_wall = 0.0
     each_step = []                                  # (LowHash0 device ms, aligner device ms) of every timed step: outliers show here
     for _ in range(args.steps):
@@ -513,6 +515,11 @@ def main():
         each_step.append([round(1e3 * lh.device_seconds, 2) if not sharded else round(1e3 * lh.seconds, 2), round(1e3 * al.device_seconds, 2) if al is not None else None])
     sync()
     elapsed = time.perf_counter() - t0
+    # What the timed region cost the host: the process's CPU seconds per second of wall clock (its threads that spin or work),
+    # beside the CPU quota of the container it runs in and the time the kernel throttled it meanwhile.
+    host_load = {"cpus_busy": (_process_cpu_seconds() - cpu0) / elapsed if elapsed > 0 else None, "cpu_quota": _cgroup_cpu_quota(),
+                 "throttled_ms_per_step": (None if throttled0 is None or _cgroup_throttled_usec() is None
+                                           else (_cgroup_throttled_usec() - throttled0) / 1e3 / max(1, args.steps))}
     table = ctx.kernel_table()
     # Outside the timed region: one more pass with ONE aligner worker.  With six workers the kernels of different batches share
     # the device, and the HIP-event duration of a launch includes the time it spent sharing; this pass gives every kernel's
@@ -628,6 +635,7 @@ def main():
                                % (world, "" if world == 1 else "s"),
             },
             "stage_device_ms_each_step": each_step,
+            "host_load_in_the_timed_region": host_load,
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
                                        "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps},
             "kernel_seconds_per_step": kernel_seconds,
@@ -677,6 +685,30 @@ def main():
     _flush_all_stdio()
     if final_line is not None:
         print(final_line, flush=True)
+
+
+def _process_cpu_seconds():
+    t = os.times()
+    return t.user + t.system
+
+
+def _cgroup_cpu_quota():
+    """CPUs the container may use (cgroup v2 cpu.max), or None."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:          # noqa: BLE001
+        return None
+
+
+def _cgroup_throttled_usec():
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return float(line.split()[1])
+    except Exception:          # noqa: BLE001
+        pass
+    return None
 
 
 def _flush_all_stdio():
