@@ -197,8 +197,10 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
     return {
         "value": pairs / total if total > 0 else 0.0,
         "unit": "candidate read-pairs aligned/s",
-        "cores": cores,
+        "cores": cores if _cgroup_cpu_quota() is None else min(cores, max(1, int(_cgroup_cpu_quota()))),
+        "threads": cores,
         "host_cores": host_cores,
+        "cpu_quota": _cgroup_cpu_quota(),         # (the container's cgroup cpu.max: 16 CPUs on the GPU box of round 3 -- the threads share that much CPU time, whatever their number)
         "kind": kind if kind == "port" else ("reference (LowHash0 and the aligner in full on every candidate; DP = the restated SeqAn call)" if whole else
                                              "reference (LowHash0 in full; aligner: incremental per-candidate rate on a sample x all candidates; DP = the restated SeqAn call)"),
         "aligner_seconds_measured": t2,
