@@ -24,6 +24,13 @@ import os
 import sys
 import time
 
+# The HIP runtime deals a process's streams to GPU_MAX_HW_QUEUES hardware queues (4 by default), and streams that share a
+# queue run one after the other.  An aligner call keeps six workers' streams busy (plus their side streams); which of them
+# share a queue depends on what else created streams before them -- with torch and RCCL initialised first (the N-rank branch)
+# the same call took 185 ms instead of 146.  Eight queues: 146 and 158 (read by the runtime when it starts,
+# so it has to be in the environment before the first HIP call of the process).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
