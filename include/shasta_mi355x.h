@@ -441,7 +441,8 @@ int shasta_mi355x_banded_dp_many(
  * AlignmentData rows, strideBytes = 64) and AlignmentCandidates::computeCandidateTable
  * (src/AssemblerAlignmentCandidates.cpp:388-447; pairs = the candidates, strideBytes = 12).  Every pair appears
  * under its two oriented reads and under their reverse complements.  toc: 2 readCount + 1 offsets; values:
- * 4 pairCount indices.
+ * 4 pairCount indices.  pairCount < 2^32 (the indices are 32-bit); a list of more than 2^29 pairs is sorted range by range
+ * of oriented reads (one radix sort takes 2^31 entries), the pairs passing through the device in slabs.
  * shasta_mi355x_read_graph_keep: createReadGraph's selection (src/AssemblerReadGraph.cpp:55-95): keep[i] = 1 if
  * alignment i is among the maxAlignmentCount alignments with the largest (markerCount, index) of either of
  * its reads, else 0. */

@@ -12,6 +12,7 @@
 #include "context.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -56,6 +57,68 @@ rowStartsKernel(const uint64_t* __restrict__ sortedKeys, uint64_t keyCount, uint
         if((sortedKeys[mid] >> shift) < r) lo = mid + 1; else hi = mid;
     }
     toc[r] = lo;
+}
+
+// ---- the same table for more keys than one radix sort takes (4 N >= 2^32, or the test switch): the oriented reads are cut
+// into ranges of at most `keyLimit` entries, the pairs come through the device in slabs, a range's entries are laid out in
+// pair order (counts per pair, one scan) and sorted on their own; rows are ascending across ranges, so the sorted ranges
+// one after the other ARE the table.
+
+__device__ __forceinline__ void pairEntries(const shasta_oriented_read_pair& pair, uint64_t rows[4], uint64_t others[4])
+{
+    const uint64_t o0 = uint64_t(pair.readIds[0]) << 1, o1 = (uint64_t(pair.readIds[1]) << 1) | (pair.isSameStrand ? 0u : 1u);
+    rows[0] = o0; rows[1] = o1; rows[2] = o0 ^ 1u; rows[3] = o1 ^ 1u;
+    others[0] = o1; others[1] = o0; others[2] = o1 ^ 1u; others[3] = o0 ^ 1u;
+}
+
+// rowCounts[r] += the entries of oriented read r in this slab.
+__global__ void __launch_bounds__(256)
+pairTableRowCountsKernel(const uint8_t* __restrict__ pairs, uint64_t stride, uint64_t count, uint64_t orientedReadCount,
+    unsigned long long* __restrict__ rowCounts, uint32_t* __restrict__ bad)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= count) return;
+    uint64_t rows[4], others[4];
+    pairEntries(pairAt(pairs, stride, i), rows, others);
+    if(rows[0] >= orientedReadCount || rows[1] >= orientedReadCount) { atomicAdd(bad, 1u); return; }
+#pragma unroll
+    for(int k = 0; k < 4; k++) atomicAdd(rowCounts + rows[k], 1ULL);
+}
+
+// inRange[i] = how many of pair i's four entries belong to the oriented reads [rowBegin, rowEnd).
+__global__ void __launch_bounds__(256)
+pairTableInRangeKernel(const uint8_t* __restrict__ pairs, uint64_t stride, uint64_t count, uint64_t rowBegin, uint64_t rowEnd,
+    uint32_t* __restrict__ inRange)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= count) return;
+    uint64_t rows[4], others[4];
+    pairEntries(pairAt(pairs, stride, i), rows, others);
+    uint32_t c = 0;
+#pragma unroll
+    for(int k = 0; k < 4; k++) c += (rows[k] >= rowBegin && rows[k] < rowEnd) ? 1u : 0u;
+    inRange[i] = c;
+}
+
+// The entries of the range, in pair order: entry = position[i] (the scan of inRange) past `cursor`, the range's entries of
+// the slabs before this one.
+__global__ void __launch_bounds__(256)
+pairTableRangeKeysKernel(const uint8_t* __restrict__ pairs, uint64_t stride, uint64_t count, uint64_t firstPair, uint64_t rowBegin, uint64_t rowEnd,
+    int otherBits, const uint32_t* __restrict__ position, uint64_t cursor, uint64_t* __restrict__ keys, uint32_t* __restrict__ values)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= count) return;
+    uint64_t rows[4], others[4];
+    pairEntries(pairAt(pairs, stride, i), rows, others);
+    uint64_t at = cursor + position[i];
+#pragma unroll
+    for(int k = 0; k < 4; k++) {
+        if(rows[k] >= rowBegin && rows[k] < rowEnd) {
+            keys[at] = ((rows[k] - rowBegin) << otherBits) | others[k];
+            values[at] = uint32_t(firstPair + i);
+            ++at;
+        }
+    }
 }
 
 // Two entries per alignment: (read, quality) with quality = (markerCount, alignment id) complemented, so that ascending
@@ -113,11 +176,85 @@ int bitsFor(uint64_t values)            // bits that hold 0 .. values - 1
 
 }  // namespace
 
+namespace {
+
+// The table of a pair list whose 4 N entries are more than one sort takes (see the kernels above).  keyLimit: entries per
+// sorted range and (a quarter of it) pairs per slab.
+void pairTableInRanges(const uint8_t* pairs, uint64_t stride, uint64_t count, uint64_t rows, int otherBits, uint64_t keyLimit,
+    uint64_t* toc, uint32_t* values, hipStream_t stream)
+{
+    const uint64_t slabPairs = std::max<uint64_t>(1, std::min<uint64_t>(count, keyLimit / 4));
+    const uint64_t slabCount = (count + slabPairs - 1) / slabPairs;
+    DeviceBuffer<uint8_t> slab;
+    DeviceBuffer<uint64_t> rowCounts, scanTemp64;
+    DeviceBuffer<uint32_t> inRange, scanTemp32, bad, valuesA, valuesB;
+    DeviceBuffer<uint64_t> keysA, keysB;
+    RadixSortWorkspace ws;
+    slab.reserve(slabPairs * stride, stream); rowCounts.reserve(rows + 1, stream); scanTemp64.reserve(scanTempElements(rows + 1), stream);
+    inRange.reserve(slabPairs + 1, stream); scanTemp32.reserve(scanTempElements(slabPairs + 1), stream); bad.reserve(1, stream);
+    uint64_t resident = ~0ULL;                         // the slab that is on the device (a list of one slab is uploaded once)
+    const auto bring = [&](uint64_t k) -> uint64_t {   // -> pairs in slab k
+        const uint64_t first = k * slabPairs, m = std::min(slabPairs, count - first);
+        if(resident != k) { HIP_CHECK(hipMemcpyAsync(slab.data(), pairs + first * stride, m * stride, hipMemcpyHostToDevice, stream)); resident = k; }
+        return m;
+    };
+
+    // Entries per oriented read, their prefix sums = the table of contents.
+    HIP_CHECK(hipMemsetAsync(rowCounts.data(), 0, (rows + 1) * sizeof(uint64_t), stream));
+    HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(uint32_t), stream));
+    for(uint64_t k = 0; k < slabCount; k++) {
+        const uint64_t m = bring(k);
+        hipLaunchKernelGGL(pairTableRowCountsKernel, dim3(divUp(m, 256)), dim3(256), 0, stream, (const uint8_t*)slab.data(), stride, m, rows, reinterpret_cast<unsigned long long*>(rowCounts.data()), bad.data());
+        HIP_CHECK(hipGetLastError());
+        if(slabCount > 1) HIP_CHECK(hipStreamSynchronize(stream));      // (the next upload overwrites the slab)
+    }
+    exclusiveScan<uint64_t>(rowCounts.data(), rowCounts.data(), rows + 1, scanTemp64.data(), stream);
+    uint32_t hostBad = 0;
+    HIP_CHECK(hipMemcpyAsync(&hostBad, bad.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(toc, rowCounts.data(), (rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if(hostBad) throw std::runtime_error("pair_table: a pair names a read beyond readCount.");
+    MI355X_ASSERT(toc[rows] == 4 * count);
+
+    // Ranges of oriented reads of at most keyLimit entries, each sorted on its own.
+    uint64_t rowBegin = 0;
+    while(rowBegin < rows) {
+        uint64_t rowEnd = std::upper_bound(toc + rowBegin, toc + rows + 1, toc[rowBegin] + keyLimit) - toc - 1;       // the last r with toc[r] - toc[rowBegin] <= keyLimit
+        if(rowEnd == rowBegin) throw std::runtime_error("pair_table: one oriented read takes part in more pairs than one sort takes.");
+        const uint64_t base = toc[rowBegin], m = toc[rowEnd] - base;
+        if(m) {
+            keysA.reserve(m, stream); keysB.reserve(m, stream); valuesA.reserve(m, stream); valuesB.reserve(m, stream);
+            uint64_t cursor = 0;
+            for(uint64_t k = 0; k < slabCount; k++) {
+                const uint64_t n = bring(k);
+                hipLaunchKernelGGL(pairTableInRangeKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, (const uint8_t*)slab.data(), stride, n, rowBegin, rowEnd, inRange.data());
+                HIP_CHECK(hipMemsetAsync(inRange.data() + n, 0, sizeof(uint32_t), stream));
+                exclusiveScan<uint32_t>(inRange.data(), inRange.data(), n + 1, scanTemp32.data(), stream);                // (element n = the slab's total)
+                hipLaunchKernelGGL(pairTableRangeKeysKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, (const uint8_t*)slab.data(), stride, n, k * slabPairs, rowBegin, rowEnd,
+                    otherBits, (const uint32_t*)inRange.data(), cursor, keysA.data(), valuesA.data());
+                HIP_CHECK(hipGetLastError());
+                uint32_t total = 0;
+                HIP_CHECK(hipMemcpyAsync(&total, inRange.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                cursor += total;
+            }
+            MI355X_ASSERT(cursor == m);
+            const bool inB = radixSort<uint64_t, uint32_t, true>(keysA.data(), keysB.data(), valuesA.data(), valuesB.data(), m,
+                otherBits + bitsFor(std::max<uint64_t>(rowEnd - rowBegin, 2)), ws, stream);
+            HIP_CHECK(hipMemcpyAsync(values + base, inB ? valuesB.data() : valuesA.data(), m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        rowBegin = rowEnd;
+    }
+}
+
+}  // namespace
+
 // toc: uint64[2 readCount + 1]; values: uint32[4 count].
 void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, uint64_t readCount, uint64_t* toc, uint32_t* values)
 {
     HIP_CHECK(hipSetDevice(device));
-    if(count >= (1ULL << 30)) throw std::runtime_error("pair_table: too many pairs (the table's indices are 32-bit, as the reference's sort keys are).");
+    if(count >= (1ULL << 32)) throw std::runtime_error("pair_table: too many pairs (the table's indices are 32-bit, as the reference's sort keys are).");
     if(stride < sizeof(shasta_oriented_read_pair) || stride % 4 != 0) throw std::runtime_error("pair_table: bad stride.");
     const uint64_t rows = 2 * readCount, n = 4 * count;
     if(count == 0) { std::fill(toc, toc + rows + 1, uint64_t(0)); return; }
@@ -125,6 +262,13 @@ void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, u
     if(2 * otherBits > 64) throw std::runtime_error("pair_table: too many reads.");
     const ScopedStream scopedStream;                       // (destroyed on every path, a throwing HIP_CHECK included)
     hipStream_t stream = scopedStream;
+    // Entries one radix sort takes (2^31: 32-bit positions, and 56 GB of keys, values and their doubles); beyond it the table
+    // is built range by range.  SHASTA_MI355X_PAIR_TABLE_KEYS lowers it (tests: the ranges at a size a test can hold).
+    const uint64_t keyLimit = [] {
+        const char* e = std::getenv("SHASTA_MI355X_PAIR_TABLE_KEYS");
+        return e ? std::min<uint64_t>(std::max<uint64_t>(std::strtoull(e, nullptr, 10), 4), 1ULL << 31) : (1ULL << 31);
+    }();
+    if(n > keyLimit) { pairTableInRanges(static_cast<const uint8_t*>(pairs), stride, count, rows, otherBits, keyLimit, toc, values, stream); return; }
 
     DeviceBuffer<uint8_t> devicePairs;
     DeviceBuffer<uint64_t> keysA, keysB, deviceToc;

@@ -30,6 +30,28 @@ def check(lib, seed=5, read_count=211, n=3000):
         candidates[name] = rows[name]
     toc12, values12 = lib.pair_table(candidates, read_count)
     assert np.array_equal(toc12, toc) and np.array_equal(values12, values)
+    # The same tables built range by range (what a list of 2^30 pairs or more takes: one radix sort holds 2^31 entries), at a
+    # size a test can hold: SHASTA_MI355X_PAIR_TABLE_KEYS = entries per sorted range, a quarter of it pairs per slab.  0.4 n = ten
+    # ranges and ten slabs; 4 n - 1 = two ranges, one slab short of everything; n / 6 with every pair of one read = a single
+    # oriented read beyond a range.
+    import os
+    import pytest
+    try:
+        for limit in (4 * n // 10 + 100, 4 * n - 1) + ((257,) if n <= 5000 else ()):
+            os.environ["SHASTA_MI355X_PAIR_TABLE_KEYS"] = str(limit)
+            for table in (rows, candidates):
+                toc_r, values_r = lib.pair_table(table, read_count)
+                assert np.array_equal(toc_r, toc) and np.array_equal(values_r, values), limit
+            with pytest.raises(RuntimeError, match="beyond readCount"):
+                lib.pair_table(rows, read_count // 2)
+        os.environ["SHASTA_MI355X_PAIR_TABLE_KEYS"] = str(n // 6)
+        crowded = candidates.copy()
+        crowded["readId0"] = 0
+        crowded["readId1"] = 1 + np.arange(n) % (read_count - 1)
+        with pytest.raises(RuntimeError, match="more pairs than one sort takes"):
+            lib.pair_table(crowded, read_count)
+    finally:
+        os.environ.pop("SHASTA_MI355X_PAIR_TABLE_KEYS", None)
     for k in (1, 6, 30, 10 ** 6):
         keep = lib.read_graph_keep(rows, read_count, k)
         expected = host_support.read_graph_expected(read_count, rows, k)[0]
@@ -37,7 +59,6 @@ def check(lib, seed=5, read_count=211, n=3000):
     # Nothing to do, and what cannot be right.
     toc0, values0 = lib.pair_table(rows[:0], read_count)
     assert not toc0.any() and len(values0) == 0 and len(lib.read_graph_keep(rows[:0], read_count, 6)) == 0
-    import pytest
     with pytest.raises(RuntimeError, match="beyond readCount"):
         lib.pair_table(rows, read_count // 2)
     with pytest.raises(RuntimeError, match="beyond readCount"):
