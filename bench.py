@@ -485,6 +485,25 @@ def main():
         backend = distributed.HipBackend(ctx, device)
         boundaries = np.arange(0, read_count + 1, args.reads, dtype=np.uint64)     # the generated shards
         upload_seconds = None
+        # SHASTA_BENCH_SHARDED_PHASES=1: where the staged LowHash0's wall clock goes -- every stage, exchange and reduction of
+        # the driver bracketed by device synchronisations (which cost a little themselves: a diagnosis, not the headline run).
+        phase_seconds = {}
+        if os.environ.get("SHASTA_BENCH_SHARDED_PHASES"):
+            def _timed(name, f):
+                def g(*a, **k):
+                    if not DRY_RUN_LIBRARY:
+                        torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    r = f(*a, **k)
+                    if not DRY_RUN_LIBRARY:
+                        torch.cuda.synchronize()
+                    phase_seconds[name] = phase_seconds.get(name, 0.0) + time.perf_counter() - t
+                    return r
+                return g
+            for name in ("begin", "hash_all", "buckets_all", "merge_all", "hash", "buckets", "merge", "finish"):
+                setattr(backend, name, _timed("stage " + name, getattr(backend, name)))
+            for name in ("exchange", "all_reduce_sum_u64", "all_gather_padded", "_slice_by_markers_on"):
+                setattr(distributed, name, _timed(name, getattr(distributed, name)))
 
         def step():
             t_lh = time.perf_counter()
@@ -505,6 +524,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if sharded:
+        phase_seconds.clear()
     ctx.kernel_table_reset()
     t0 = time.perf_counter()
     cpu0 = _process_cpu_seconds()
@@ -653,6 +674,8 @@ def main():
         }
         if group_line is not None:
             out["in_process_group"] = group_line
+        if sharded and phase_seconds:
+            out["sharded_lowhash0_phase_ms_per_step"] = {k: round(1e3 * v / steps, 3) for k, v in sorted(phase_seconds.items(), key=lambda kv: -kv[1])}
         # What a GPU must hold: this run, and BASELINE configs[3] / [4] on 8 GPUs (chr1 50x M = 1.7e9, human 50x M = 2.2e10).
         out["hbm_budget_per_gpu"] = {
             "this_run": hbm_budget(marker_count, args.reads * world, world),
