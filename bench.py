@@ -502,12 +502,14 @@ def main():
                 return g
             for name in ("begin", "hash_all", "buckets_all", "merge_all", "hash", "buckets", "merge", "finish"):
                 setattr(backend, name, _timed("stage " + name, getattr(backend, name)))
-            for name in ("exchange", "all_reduce_sum_u64", "all_gather_padded", "_slice_by_markers_on"):
+            for name in ("exchange", "all_reduce_sum_u64", "all_gather_padded", "_slice_by_markers_on", "candidate_share"):
                 setattr(distributed, name, _timed(name, getattr(distributed, name)))
+            from shasta_amd import abi as _abi                     # (inside `stage finish` and the aligner's result: the host copies)
+            _abi.copy_array = _timed("abi.copy_array (inside other rows)", _abi.copy_array)
 
         def step():
             t_lh = time.perf_counter()
-            lh = distributed.lowhash0(backend, p, read_count, boundaries)
+            lh = distributed.lowhash0(backend, p, read_count, boundaries, candidates_on_device=True)     # (the all-gather reads them where they are)
             share, total = distributed.candidate_share(lh.candidates, device, toc=toc)
             lh.seconds = time.perf_counter() - t_lh          # (this rank's wall clock: the staged job, both exchanges, the candidate re-split)
             if args.lowhash_only:

@@ -290,6 +290,9 @@ int shasta_mi355x_align4_run(
  *              concatenating the ranks in order gives the reference's order) -- free with
  *              shasta_mi355x_free --, its partial readLowHashStatistics[readCount*3] and its share of
  *              the per-iteration "high frequency" / "total" counters (all-reduce all three).
+ *   lh_finish_on_device  the same with the candidates left in device memory (*candidatesDevice, 12-byte records; valid until
+ *              this context's next lh_begin / lowhash0_run): the caller's all-gather of the ranks' lists reads them where
+ *              they are instead of after a copy to the host and back.
  * ------------------------------------------------------------------------- */
 #define SHASTA_MI355X_SIZE_HISTOGRAM_BINS 2048
 int shasta_mi355x_lh_begin(shasta_mi355x_ctx*, const shasta_lowhash0_params* params, int rank, int worldSize,
@@ -308,6 +311,9 @@ int shasta_mi355x_lh_buckets_all(shasta_mi355x_ctx*, const void* keysDevice, con
 int shasta_mi355x_lh_merge_all(shasta_mi355x_ctx*, const void* pairKeysDevice, const void* pairTagsDevice, uint64_t n);
 int shasta_mi355x_lh_finish(shasta_mi355x_ctx*, uint64_t* readLowHashStatistics,
     shasta_oriented_read_pair** candidates, uint64_t* candidateCount,
+    uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount);
+int shasta_mi355x_lh_finish_on_device(shasta_mi355x_ctx*, uint64_t* readLowHashStatistics,
+    const shasta_oriented_read_pair** candidatesDevice, uint64_t* candidateCount,
     uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount);
 void shasta_mi355x_free(void*);
 /* Synchronous copy on the context's stream; kind 0 host->device, 1 device->host, 2 device->device. */

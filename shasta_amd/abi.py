@@ -207,7 +207,9 @@ def copy_array(ptr, n, dtype):
     if not ptr or n == 0:
         return np.zeros(0, dtype=dtype)
     buf = C.cast(ptr, C.POINTER(C.c_uint8 * (n * dtype.itemsize))).contents
-    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+    # Copied as bytes: numpy copies a record type with padding (the 12-byte pair) field by field -- 9 ms for 2 M candidates
+    # against 1 ms for their 24 MB.
+    return np.frombuffer(buf, dtype=np.uint8, count=n * dtype.itemsize).copy().view(dtype)
 
 
 def view_array(ptr, n, dtype, owner):

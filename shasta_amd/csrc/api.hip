@@ -199,6 +199,23 @@ int shasta_mi355x_lh_finish(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistic
     API_END(1)
 }
 
+int shasta_mi355x_lh_finish_on_device(shasta_mi355x_ctx* c, uint64_t* readLowHashStatistics,
+    const shasta_oriented_read_pair** candidatesDevice, uint64_t* candidateCount,
+    uint64_t* highFrequencyPerIteration, uint64_t* totalPerIteration, uint64_t iterationCapacity, uint64_t* iterationCount)
+{
+    API_BEGIN
+    if(!c || !readLowHashStatistics || !candidatesDevice || !candidateCount || !iterationCount) throw std::runtime_error("lh_finish_on_device: null argument");
+    const uint64_t iterationsOfJob = lowhash0JobIterations(c->impl);            // (checked before the job is retired, as in lh_finish)
+    if(iterationsOfJob > iterationCapacity) throw std::runtime_error("lh_finish_on_device: iteration capacity too small (the job has " + std::to_string(iterationsOfJob) + " iterations; nothing was discarded, call again with room)");
+    if(iterationsOfJob && (!highFrequencyPerIteration || !totalPerIteration)) throw std::runtime_error("lh_finish_on_device: null per-iteration array");
+    std::vector<uint64_t> high, total;
+    lowhash0Finish(c->impl, readLowHashStatistics, nullptr, high, total, candidatesDevice, candidateCount);
+    for(size_t k = 0; k < high.size(); k++) { highFrequencyPerIteration[k] = high[k]; totalPerIteration[k] = total[k]; }
+    *iterationCount = high.size();
+    return 0;
+    API_END(1)
+}
+
 void shasta_mi355x_free(void* p) { std::free(p); }
 
 int shasta_mi355x_lowhash0_run(shasta_mi355x_ctx* c, const shasta_lowhash0_params* params,

@@ -92,6 +92,9 @@ uint64_t lowhash0JobIterations(Context&);
 uint64_t lowhash0JobPlannedIterations(Context&);          // minHashIterationCount of the job in progress
 void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& candidates,
     std::vector<uint64_t>& highFrequencyPerIteration, std::vector<uint64_t>& totalPerIteration);
+void lowhash0Finish(Context&, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>* candidatesOrNull,
+    std::vector<uint64_t>& highPerIteration, std::vector<uint64_t>& totalPerIteration,
+    const shasta_oriented_read_pair** deviceCandidates, uint64_t* deviceCandidateCount);
 void align4Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options&, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
 void align3Run(Context&, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,

@@ -1388,6 +1388,17 @@ uint64_t lowhash0JobPlannedIterations(Context& ctx) { return jobOf(ctx).p.minHas
 void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>& hostCandidates,
     std::vector<uint64_t>& highPerIteration, std::vector<uint64_t>& totalPerIteration)
 {
+    lowhash0Finish(ctx, readLowHashStatistics, &hostCandidates, highPerIteration, totalPerIteration, nullptr, nullptr);
+}
+
+// hostCandidates == nullptr: the candidates stay where the last kernel wrote them; *deviceCandidates / *deviceCandidateCount
+// name them (valid until the context's next LowHash0 job begins: the retired job's allocations are kept for it).
+void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<shasta_oriented_read_pair>* hostCandidatesOrNull,
+    std::vector<uint64_t>& highPerIteration, std::vector<uint64_t>& totalPerIteration,
+    const shasta_oriented_read_pair** deviceCandidates, uint64_t* deviceCandidateCount)
+{
+    std::vector<shasta_oriented_read_pair> unused;
+    std::vector<shasta_oriented_read_pair>& hostCandidates = hostCandidatesOrNull ? *hostCandidatesOrNull : unused;
     LowHash0Job& job = jobOf(ctx);
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
@@ -1402,10 +1413,14 @@ void lowhash0Finish(Context& ctx, uint64_t* readLowHashStatistics, std::vector<s
             hipLaunchKernelGGL(emitCandidatesKernel, dim3(divUp(job.pairCount, 256)), dim3(256), 0, stream,
                 (const uint64_t*)job.pairKeys(), (const uint32_t*)job.pos.data(), job.pairCount, job.readBits, job.candidatesDevice.data()));
         HIP_CHECK(hipGetLastError());
-        hostCandidates.resize(job.candidateCount);
-        HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), job.candidatesDevice.data(),
-            job.candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
+        if(hostCandidatesOrNull) {
+            hostCandidates.resize(job.candidateCount);
+            HIP_CHECK(hipMemcpyAsync(hostCandidates.data(), job.candidatesDevice.data(),
+                job.candidateCount * sizeof(shasta_oriented_read_pair), hipMemcpyDeviceToHost, stream));
+        }
     }
+    if(deviceCandidates) *deviceCandidates = job.candidateCount ? job.candidatesDevice.data() : nullptr;
+    if(deviceCandidateCount) *deviceCandidateCount = job.candidateCount;
     HIP_CHECK(hipMemcpyAsync(readLowHashStatistics, job.stats.data(), 3 * readCount * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     ctx.lowhashPairsHint = std::max(ctx.lowhashPairsHint, job.pairCount + job.pairCount / 8);

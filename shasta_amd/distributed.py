@@ -102,6 +102,12 @@ class HipBackend:
     def finish(self):
         return self.ctx.lh_finish()
 
+    def finish_on_device(self):
+        """finish() with the candidates left on the device: an int32 tensor of triplets (readId0, readId1, isSameStrand in the
+        low byte) that VIEWS the library's buffer, valid until the context's next LowHash0 job."""
+        ptr, count, stats, high, total = self.ctx.lh_finish_on_device()
+        return self._tensor_from(ptr, 3 * count, torch.int32), stats, high, total
+
     # All iterations in one pass (fixed minHashIterationCount): one call of each per job.
     def hash_all(self):
         offsets, keys, vals = self.ctx.lh_hash_all()
@@ -180,8 +186,10 @@ class LowHash0Result:
         self.log2_bucket_count = 0
 
 
-def lowhash0(backend, params, read_count, boundaries, group=None):
-    """Runs the job; every rank gets the global counters/statistics and its own share of the candidates.
+def lowhash0(backend, params, read_count, boundaries, group=None, candidates_on_device=False):
+    """Runs the job; every rank gets the global counters/statistics and its own share of the candidates (a numpy array of
+    12-byte pairs; with candidates_on_device and a backend that can, an int32 tensor of triplets on the backend's device --
+    candidate_share / gather_candidates take either).
     Per MinHash iteration the ranks only exchange DATA (two all-to-all steps, each preceded by its counts); every
     reduction -- per-iteration counters, bucket histograms, per-read statistics -- happens once, after the last
     iteration.  Only minHashIterationCount = 0 needs the global high-frequency count after every iteration
@@ -229,7 +237,10 @@ def lowhash0(backend, params, read_count, boundaries, group=None):
         hist_rows.append(np.asarray(hist, dtype=np.uint64))
         overflow_lists.append(np.asarray(overflow, dtype=np.uint32).tolist())
         iteration += 1
-    candidates, stats, high_rows, total_rows = backend.finish()
+    if candidates_on_device and hasattr(backend, "finish_on_device"):
+        candidates, stats, high_rows, total_rows = backend.finish_on_device()
+    else:
+        candidates, stats, high_rows, total_rows = backend.finish()
     iterations = iteration
     # One reduction for everything: [high | total | bucketsUsed | overflow counts | histograms] per iteration, then the statistics.
     packed = np.concatenate([np.asarray(high_rows, dtype=np.uint64), np.asarray(total_rows, dtype=np.uint64),
@@ -270,16 +281,26 @@ def gather_candidates(local_candidates, device="cpu", group=None):
     """The global candidate list (rank order = the reference's order) on every rank.  Candidates are
     12-byte records; they travel as int32 triplets in one padded all-gather (24 MB per million)."""
     world = dist.get_world_size(group)
-    local = np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE)
     home = torch.device(device)
-    comm = _comm_device(home)
-    mine = torch.tensor([len(local)], dtype=torch.int64, device=comm)
-    parts = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    counts = [int(p.item()) for p in parts]
-    flat = torch.from_numpy(local.view(np.int32).reshape(-1).copy()).to(home)
+    flat, counts = _flat_candidates_and_counts(local_candidates, home, group)
     gathered = all_gather_padded(flat, [3 * c for c in counts], group)
     return gathered.cpu().numpy().view(abi.PAIR_DTYPE).reshape(-1)
+
+
+def _flat_candidates_and_counts(local_candidates, home, group):
+    """A rank's candidates as an int32 tensor of triplets on `home` (from the numpy array of pairs, or the tensor
+    lowhash0(candidates_on_device=True) returned, as it is) and every rank's number of candidates."""
+    world = dist.get_world_size(group)
+    if isinstance(local_candidates, torch.Tensor):
+        flat = local_candidates.to(home)
+    else:
+        local = np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE).view(np.int32).reshape(-1)
+        flat = torch.from_numpy(local if local.flags.writeable else local.copy()).to(home)
+    comm = _comm_device(home)
+    mine = torch.tensor([flat.numel() // 3], dtype=torch.int64, device=comm)
+    parts = torch.zeros(world, dtype=torch.int64, device=comm)
+    dist.all_gather_into_tensor(parts, mine, group=group)
+    return flat, [int(c) for c in parts.tolist()]
 
 
 def candidate_share(local_candidates, device="cpu", group=None, toc=None):
@@ -288,15 +309,9 @@ def candidate_share(local_candidates, device="cpu", group=None, toc=None):
     contiguous shares are balanced by the markers they touch, sum of nx + ny: reads differ in length by
     an order of magnitude and the aligner's work follows them; without it the split is even."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    local = np.ascontiguousarray(local_candidates, dtype=abi.PAIR_DTYPE)
     home = torch.device(device)
-    comm = _comm_device(home)
-    mine = torch.tensor([len(local)], dtype=torch.int64, device=comm)
-    parts = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    counts = [int(p.item()) for p in parts]
+    flat, counts = _flat_candidates_and_counts(local_candidates, home, group)
     total = sum(counts)
-    flat = torch.from_numpy(local.view(np.int32).reshape(-1).copy()).to(home)
     gathered = all_gather_padded(flat, [3 * c for c in counts], group)
     if toc is None:
         lo, hi = candidate_slice(total, rank, world)

@@ -26,7 +26,7 @@ EXPORTS = [
     "shasta_mi355x_pair_table", "shasta_mi355x_read_graph_keep",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
-    "shasta_mi355x_lh_finish", "shasta_mi355x_lh_hash_all", "shasta_mi355x_lh_buckets_all", "shasta_mi355x_lh_merge_all",
+    "shasta_mi355x_lh_finish", "shasta_mi355x_lh_finish_on_device", "shasta_mi355x_lh_hash_all", "shasta_mi355x_lh_buckets_all", "shasta_mi355x_lh_merge_all",
     "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
     "shasta_mi355x_find_markers", "shasta_mi355x_find_markers_free",
     "shasta_mi355x_palindromic_screen",
@@ -466,6 +466,20 @@ class Context:
         self.lib.shasta_mi355x_free(cand)
         k = int(iterations.value)
         return out, stats, high[:k].copy(), total[:k].copy()
+
+    def lh_finish_on_device(self, max_iterations=1 << 16):
+        """-> (device address of this rank's candidates, their number, statistics, high frequency / total per iteration): the
+        candidates stay in device memory, valid until this context's next LowHash0 job."""
+        stats = np.zeros((self.read_count, 3), dtype=np.uint64)
+        cand, count, iterations = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        high = np.zeros(max_iterations, dtype=np.uint64)
+        total = np.zeros(max_iterations, dtype=np.uint64)
+        self.library._check(self.lib.shasta_mi355x_lh_finish_on_device(
+            C.c_void_p(self.handle), abi.as_ptr(stats, C.c_uint64), C.byref(cand), C.byref(count),
+            abi.as_ptr(high, C.c_uint64), abi.as_ptr(total, C.c_uint64), C.c_uint64(max_iterations), C.byref(iterations)),
+            "shasta_mi355x_lh_finish_on_device")
+        k = int(iterations.value)
+        return cand.value or 0, int(count.value), stats, high[:k].copy(), total[:k].copy()
 
     def lowhash0(self, params):
         stats = np.zeros((self.read_count, 3), dtype=np.uint64)

@@ -36,7 +36,8 @@ def _worker(rank, world, port, out_dir, seed, kw, library_path, transport="gloo"
             ctx.set_markers(toc, data7, flags)
             backend = distributed.HipBackend(ctx, device)
             boundaries = distributed.read_boundaries(toc, world)
-            out = distributed.lowhash0(backend, p, 400, boundaries)
+            # (every other case with the candidates left on the device for the all-gather: lh_finish_on_device)
+            out = distributed.lowhash0(backend, p, 400, boundaries, candidates_on_device=(seed % 2 == 1))
             everything = distributed.gather_candidates(out.candidates, device)
             lo, hi = distributed.candidate_slice(len(everything), rank, world)
             o = abi.default_align4_options(minAlignedMarkerCount=40)
