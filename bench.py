@@ -500,7 +500,7 @@ def main():
                     phase_seconds[name] = phase_seconds.get(name, 0.0) + time.perf_counter() - t
                     return r
                 return g
-            for name in ("begin", "hash_all", "buckets_all", "merge_all", "hash", "buckets", "merge", "finish"):
+            for name in ("begin", "hash_all", "buckets_all", "merge_all", "hash", "buckets", "merge", "finish", "finish_on_device"):
                 setattr(backend, name, _timed("stage " + name, getattr(backend, name)))
             for name in ("exchange", "all_reduce_sum_u64", "all_gather_padded", "_slice_by_markers_on", "candidate_share"):
                 setattr(distributed, name, _timed(name, getattr(distributed, name)))
