@@ -293,9 +293,7 @@ class Group:
         res = abi.LowHash0Result()
         self.library._check(self.lib.shasta_mi355x_group_lowhash0_run(
             C.c_void_p(self.handle), C.byref(params), abi.as_ptr(stats, C.c_uint64), C.byref(res)), "shasta_mi355x_group_lowhash0_run")
-        out = abi.LowHash0Output(res, stats)
-        self.lib.shasta_mi355x_lowhash0_free(C.byref(res))
-        return out
+        return abi.LowHash0Output(res, stats, free=self.lib.shasta_mi355x_lowhash0_free)       # the candidate list stays in the C buffer
 
     def align4(self, candidates, options, want_ordinals=False, borrow=False):
         """borrow=True: the arrays of the result are views of memory owned by this group, valid until its next aligner call."""
