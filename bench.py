@@ -487,7 +487,7 @@ def main():
         upload_seconds = None
         # SHASTA_BENCH_SHARDED_PHASES=1: where the staged LowHash0's wall clock goes -- every stage, exchange and reduction of
         # the driver bracketed by device synchronisations (which cost a little themselves: a diagnosis, not the headline run).
-        phase_seconds = {}
+        phase_seconds, phase_log = {}, []
         if os.environ.get("SHASTA_BENCH_SHARDED_PHASES"):
             def _timed(name, f):
                 def g(*a, **k):
@@ -498,6 +498,7 @@ def main():
                     if not DRY_RUN_LIBRARY:
                         torch.cuda.synchronize()
                     phase_seconds[name] = phase_seconds.get(name, 0.0) + time.perf_counter() - t
+                    phase_log.append((name, round(1e3 * (time.perf_counter() - t), 2)))
                     return r
                 return g
             for name in ("begin", "hash_all", "buckets_all", "merge_all", "hash", "buckets", "merge", "finish", "finish_on_device"):
@@ -528,6 +529,7 @@ def main():
     sync()
     if sharded:
         phase_seconds.clear()
+        del phase_log[:]
     ctx.kernel_table_reset()
     t0 = time.perf_counter()
     cpu0 = _process_cpu_seconds()
@@ -535,6 +537,8 @@ def main():
     lh_dev = al_dev = lh_wall = al_wall = 0.0
     each_step = []                                  # (LowHash0 device ms, aligner device ms) of every timed step: outliers show here
     for _ in range(args.steps):
+        if os.environ.get("SHASTA_MI355X_LOG_ALLOC") == "1":      # (beside the library's allocation log, on its clock)
+            sys.stderr.write("bench: step %d begins at %.1f ms\n" % (len(each_step), 1e3 * time.monotonic()))
         lh, al, pairs_total = step()
         if not sharded:
             lh_dev += lh.device_seconds
@@ -678,6 +682,7 @@ def main():
             out["in_process_group"] = group_line
         if sharded and phase_seconds:
             out["sharded_lowhash0_phase_ms_per_step"] = {k: round(1e3 * v / steps, 3) for k, v in sorted(phase_seconds.items(), key=lambda kv: -kv[1])}
+            out["sharded_lowhash0_phase_ms_each_step"] = [[name, ms] for name, ms in phase_log if ms >= 10.0]      # (outliers show here)
         # What a GPU must hold: this run, and BASELINE configs[3] / [4] on 8 GPUs (chr1 50x M = 1.7e9, human 50x M = 2.2e10).
         out["hbm_budget_per_gpu"] = {
             "this_run": hbm_budget(marker_count, args.reads * world, world),

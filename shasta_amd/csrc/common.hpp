@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -108,6 +110,10 @@ private:
     void reallocate(size_t newCap, hipStream_t stream, bool keep)
     {
         T* q = nullptr;
+        // SHASTA_MI355X_LOG_ALLOC=1: every (re)allocation of a device buffer on stderr -- a steady state allocates nothing.
+        static const bool logAllocations = [] { const char* e = std::getenv("SHASTA_MI355X_LOG_ALLOC"); return e && e[0] == '1'; }();
+        if(logAllocations) std::fprintf(stderr, "shasta_mi355x: device buffer %zu -> %zu bytes at %.1f ms\n", cap * sizeof(T), newCap * sizeof(T),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());      // (the clock of python's time.monotonic())
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&q), newCap * sizeof(T)));
         if(keep && p && cap) {
             HIP_CHECK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
