@@ -1139,8 +1139,8 @@ void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsI
     if(job.world > 1 && n) {
         // Concatenation of one sorted run per sender: sort again.
         job.recKeysA.reserve(n, stream); job.recKeysB.reserve(n, stream); job.recValsA.reserve(n, stream); job.recValsB.reserve(n, stream);
-        if(keysIn != job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 4, hipMemcpyDeviceToDevice, stream));
-        if(valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
+        deviceCopy(job.recKeysA.data(), keysIn, n * 4, stream);
+        deviceCopy(job.recValsA.data(), valsIn, n * 8, stream);
         enqueueSortRecords(ctx, job, keys, vals, Count(n));
     }
     // This iteration's pair keys go to a buffer of their own (they leave for their owners before they are appended),
@@ -1200,7 +1200,7 @@ void lowhash0Merge(Context& ctx, const uint64_t* keys, uint64_t n, bool evaluate
     if(n) {
         const uint64_t needed = job.pairCount + n;
         if(needed > job.pairCapacity) reservePairs(job, needed + needed / 2, stream, true);
-        HIP_CHECK(hipMemcpyAsync(job.pairKeys() + job.pairCount, keys, n * 8, hipMemcpyDeviceToDevice, stream));
+        deviceCopy(job.pairKeys() + job.pairCount, keys, n * 8, stream);
         hipLaunchKernelGGL(fillKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, job.pairTags() + job.pairCount, n, uint32_t(job.iterations));
         HIP_CHECK(hipGetLastError());
         job.pairCount = needed;
@@ -1293,13 +1293,26 @@ void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* va
     hipStream_t stream = ctx.stream;
     const uint64_t I = job.p.minHashIterationCount;
     MI355X_ASSERT(I >= 1 && I <= 4096 && n < (1ULL << 32) - 1 && job.iterations == 0);
+    // SHASTA_MI355X_LOG_STAGES=1: a call of more than 25 ms says on stderr where it spent them (each mark after a stream
+    // synchronisation of its own -- a diagnosis, not for timed runs).
+    static const bool logStages = [] { const char* e = std::getenv("SHASTA_MI355X_LOG_STAGES"); return e && e[0] == '1'; }();
+    std::vector<std::pair<const char*, double>> marks;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto mark = [&](const char* what) {
+        if(!logStages) return;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        marks.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
+    mark("entered (stream idle)");
     reserveIterationRows(job, I, stream);
     job.recKeysA.reserve(2 * std::max<uint64_t>(n, 1), stream); job.recKeysB.reserve(2 * std::max<uint64_t>(n, 1), stream);
     job.recValsA.reserve(std::max<uint64_t>(n, 1), stream); job.recValsB.reserve(std::max<uint64_t>(n, 1), stream);
-    if(n && (const void*)keysIn != (const void*)job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 8, hipMemcpyDeviceToDevice, stream));
-    if(n && valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
+    if(n) deviceCopy(job.recKeysA.data(), keysIn, n * 8, stream);
+    if(n) deviceCopy(job.recValsA.data(), valsIn, n * 8, stream);
     const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
+    mark("records copied in");
     enqueueSortRecords(ctx, job, keys, vals, Count(n), uint32_t(I), true);
+    mark("records sorted");
     unsigned long long* counters = job.counters.data();
     // The pair keys go where the single-GPU job keeps them; a guess that was too small: everything this call added is
     // zeroed and the buckets run again with room (the records stay sorted where they are).
@@ -1313,6 +1326,7 @@ void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* va
         HIP_CHECK(hipMemsetAsync(job.sizeHist.data(), 0, I * SIZE_HIST_CAP * sizeof(unsigned long long), stream));
         enqueueBuckets(ctx, job, keys, vals, Count(n), 0, job.pairKeys(), job.pairTags(), job.pairCapacity, uint32_t(I), true);
         pairCount = readDevice(counters + C_PAIRS, stream);
+        mark("buckets, statistics, pair keys");
         if(pairCount <= job.pairCapacity) break;
         reservePairs(job, pairCount + pairCount / 8 + 64, stream, false);
         ctx.lowhashPairsHint = job.pairCapacity;
@@ -1325,6 +1339,7 @@ void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* va
     overflowOut.assign(overflow, 0);
     if(overflow) HIP_CHECK(hipMemcpyAsync(overflowOut.data(), job.overflowSizes.data(), overflow * 8, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    mark("tables copied out");
     for(uint64_t t = 0; t < I; t++) bucketsUsedOut[t] = table[4 * t + 1];
     // Sorted by key with the tags: an owner's keys are contiguous (readId0 leads the key).
     const uint64_t* pk = job.pairKeys(); const uint32_t* tags = job.pairTags();
@@ -1348,6 +1363,12 @@ void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* va
         sendOffsets[0] = 0; sendOffsets[job.world] = pairCount;
     }
     HIP_CHECK(hipStreamSynchronize(stream));
+    mark("pair keys sorted and split");
+    if(logStages && !marks.empty() && marks.back().second > 25.) {
+        std::string line = "shasta_mi355x: lh_buckets_all took " + std::to_string(marks.back().second) + " ms:";
+        for(const auto& m : marks) line += std::string(" [") + m.first + " " + std::to_string(m.second) + "]";
+        std::fprintf(stderr, "%s\n", line.c_str());
+    }
     *pairKeysOut = pk; *pairTagsOut = tags;
 }
 
@@ -1363,8 +1384,8 @@ void lowhash0MergeAll(Context& ctx, const uint64_t* keys, const uint32_t* tags, 
         const bool own = keys == job.pairKeys() && tags == job.pairTags();
         if(!own) {
             if(n > job.pairCapacity) reservePairs(job, n + n / 8 + 64, stream, false);
-            HIP_CHECK(hipMemcpyAsync(job.pairKeys(), keys, n * 8, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(job.pairTags(), tags, n * 4, hipMemcpyDeviceToDevice, stream));
+            deviceCopy(job.pairKeys(), keys, n * 8, stream);
+            deviceCopy(job.pairTags(), tags, n * 4, stream);
         }
     }
     job.pairCount = n;
