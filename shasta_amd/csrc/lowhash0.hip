@@ -1139,8 +1139,8 @@ void lowhash0Buckets(Context& ctx, const uint32_t* keysIn, const uint64_t* valsI
     if(job.world > 1 && n) {
         // Concatenation of one sorted run per sender: sort again.
         job.recKeysA.reserve(n, stream); job.recKeysB.reserve(n, stream); job.recValsA.reserve(n, stream); job.recValsB.reserve(n, stream);
-        deviceCopy(job.recKeysA.data(), keysIn, n * 4, stream);
-        deviceCopy(job.recValsA.data(), valsIn, n * 8, stream);
+        if(keysIn != job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 4, hipMemcpyDeviceToDevice, stream));
+        if(valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
         enqueueSortRecords(ctx, job, keys, vals, Count(n));
     }
     // This iteration's pair keys go to a buffer of their own (they leave for their owners before they are appended),
@@ -1200,7 +1200,7 @@ void lowhash0Merge(Context& ctx, const uint64_t* keys, uint64_t n, bool evaluate
     if(n) {
         const uint64_t needed = job.pairCount + n;
         if(needed > job.pairCapacity) reservePairs(job, needed + needed / 2, stream, true);
-        deviceCopy(job.pairKeys() + job.pairCount, keys, n * 8, stream);
+        HIP_CHECK(hipMemcpyAsync(job.pairKeys() + job.pairCount, keys, n * 8, hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(fillKernel, dim3(divUp(n, 256)), dim3(256), 0, stream, job.pairTags() + job.pairCount, n, uint32_t(job.iterations));
         HIP_CHECK(hipGetLastError());
         job.pairCount = needed;
@@ -1305,10 +1305,12 @@ void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* va
     };
     mark("entered (stream idle)");
     reserveIterationRows(job, I, stream);
+    mark("iteration rows cleared");
     job.recKeysA.reserve(2 * std::max<uint64_t>(n, 1), stream); job.recKeysB.reserve(2 * std::max<uint64_t>(n, 1), stream);
     job.recValsA.reserve(std::max<uint64_t>(n, 1), stream); job.recValsB.reserve(std::max<uint64_t>(n, 1), stream);
-    if(n) deviceCopy(job.recKeysA.data(), keysIn, n * 8, stream);
-    if(n) deviceCopy(job.recValsA.data(), valsIn, n * 8, stream);
+    if(n && (const void*)keysIn != (const void*)job.recKeysA.data()) HIP_CHECK(hipMemcpyAsync(job.recKeysA.data(), keysIn, n * 8, hipMemcpyDeviceToDevice, stream));
+    mark("keys copied in");
+    if(n && valsIn != job.recValsA.data()) HIP_CHECK(hipMemcpyAsync(job.recValsA.data(), valsIn, n * 8, hipMemcpyDeviceToDevice, stream));
     const uint32_t* keys = nullptr; const uint64_t* vals = nullptr;
     mark("records copied in");
     enqueueSortRecords(ctx, job, keys, vals, Count(n), uint32_t(I), true);
@@ -1384,8 +1386,8 @@ void lowhash0MergeAll(Context& ctx, const uint64_t* keys, const uint32_t* tags, 
         const bool own = keys == job.pairKeys() && tags == job.pairTags();
         if(!own) {
             if(n > job.pairCapacity) reservePairs(job, n + n / 8 + 64, stream, false);
-            deviceCopy(job.pairKeys(), keys, n * 8, stream);
-            deviceCopy(job.pairTags(), tags, n * 4, stream);
+            HIP_CHECK(hipMemcpyAsync(job.pairKeys(), keys, n * 8, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(job.pairTags(), tags, n * 4, hipMemcpyDeviceToDevice, stream));
         }
     }
     job.pairCount = n;

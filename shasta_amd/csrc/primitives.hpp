@@ -70,34 +70,6 @@ struct Count {
 };
 
 // ----------------------------------------------------------------------------
-// Device-to-device copy as a kernel of this library.  (hipMemcpyAsync between two device buffers usually takes tens of
-// microseconds for tens of megabytes, and now and then 25-35 ms -- seen on the staged LowHash0's copy of the records another
-// rank sent, the whole of a 17-ms stage's outliers: profiles/r03_final_check.log.)
-// ----------------------------------------------------------------------------
-template<class T>            // (uint4 or uint32_t; a template so that every translation unit may include it)
-__global__ void __launch_bounds__(256)
-deviceCopyKernel(const T* __restrict__ src, T* __restrict__ dst, uint64_t n)
-{
-    for(uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) dst[i] = src[i];
-}
-// bytes: a multiple of 4; the buffers 4-byte aligned and not overlapping.
-inline void deviceCopy(void* dst, const void* src, uint64_t bytes, hipStream_t stream)
-{
-    if(bytes == 0 || dst == src) return;
-    MI355X_ASSERT(bytes % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 4 == 0);
-    if((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0) {
-        const uint64_t n = bytes / 16;
-        if(n) hipLaunchKernelGGL(deviceCopyKernel<uint4>, dim3(unsigned(std::min<uint64_t>(divUp(n, 256), 8192))), dim3(256), 0, stream, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n);
-        const uint64_t rest = (bytes - 16 * n) / 4;
-        if(rest) hipLaunchKernelGGL(deviceCopyKernel<uint32_t>, dim3(1), dim3(256), 0, stream, static_cast<const uint32_t*>(src) + 4 * n, static_cast<uint32_t*>(dst) + 4 * n, rest);
-    } else {
-        const uint64_t n = bytes / 4;
-        hipLaunchKernelGGL(deviceCopyKernel<uint32_t>, dim3(unsigned(std::min<uint64_t>(divUp(n, 256), 8192))), dim3(256), 0, stream, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), n);
-    }
-    HIP_CHECK(hipGetLastError());
-}
-
-// ----------------------------------------------------------------------------
 // Exclusive scan.
 // ----------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
