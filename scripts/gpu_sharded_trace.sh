@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
-SHASTA_MI355X_LOG_STAGES=1 SHASTA_BENCH_FORCE_SHARDED=1 SHASTA_BENCH_NO_GROUP_LINE=1 timeout 280 rocprofv3 --kernel-trace -d $R/gpurun_out/sharded_trace -o t --output-format csv -- \
+SHASTA_MI355X_LOG_STAGES=1 SHASTA_BENCH_FORCE_SHARDED=1 SHASTA_BENCH_NO_GROUP_LINE=1 timeout ${LIMIT:-280} rocprofv3 --kernel-trace -d $R/gpurun_out/sharded_trace -o t --output-format csv -- \
   python $R/bench.py --steps ${STEPS:-30} --warmup 2 --no-cpu-baseline > $R/gpurun_out/sharded_trace.json 2> $R/gpurun_out/sharded_trace.err
 cd $R
 grep "lh_buckets_all took" gpurun_out/sharded_trace.err | cut -c1-300
