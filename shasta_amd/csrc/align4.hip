@@ -733,6 +733,11 @@ struct BatchOutput {
     std::vector<shasta_alignment_data> rows;
     std::vector<uint64_t> tocEnds, ordToc;
     std::vector<uint8_t> bytes;
+    // The compressed bytes while they are still in the worker's pinned staging buffer and nowhere else (a batch that is placed
+    // in the caller-visible array at once is copied from there: one host copy of a hundred megabytes instead of two); byteCount
+    // is their number wherever they are.
+    const uint8_t* stagedBytes = nullptr;
+    uint64_t byteCount = 0;
     std::vector<uint32_t> ordinals;
     uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0;
     DpBatchStats dpStats;
@@ -834,6 +839,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     for(uint64_t k = 0; k < batchCount; k++) {
         BatchOutput& o = outputs[k];
         o.dpCells = o.kmerIdBytes = o.alignedBytes = 0; o.hadTasks = false;
+        o.stagedBytes = nullptr; o.byteCount = 0; o.bytes.clear();
         o.dpStats = DpBatchStats();
         o.ordToc.clear(); o.ordinals.clear();
     }
@@ -1397,7 +1403,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipStreamSynchronize(stream));
         out.rows.assign(static_cast<const shasta_alignment_data*>(pinRows), static_cast<const shasta_alignment_data*>(pinRows) + storedCount);
         hostToc64.assign(static_cast<const uint64_t*>(pinToc), static_cast<const uint64_t*>(pinToc) + storedCount);
-        out.bytes.assign(static_cast<const uint8_t*>(pinBytes), static_cast<const uint8_t*>(pinBytes) + byteTotal);
+        out.stagedBytes = static_cast<const uint8_t*>(pinBytes); out.byteCount = byteTotal;      // (placeFinished takes them from there)
         std::memcpy(outStatus.data() + batchBegin, pinStatus, n);
         if(wantOrdinals) {
             out.ordToc.assign(static_cast<const uint64_t*>(pinOrdToc), static_cast<const uint64_t*>(pinOrdToc) + uint64_t(n) + 1);
@@ -1433,34 +1439,77 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(store.compressedToc.size() < candidateCount + 1) store.compressedToc.resize(candidateCount + 1);
         if(wantOrdinals && store.ordinalsToc.size() < candidateCount + 1) store.ordinalsToc.resize(candidateCount + 1);
     }
-    auto copyBatch = [&](uint64_t k, const Placement& at, shasta_alignment_data* rows, uint64_t* toc, uint8_t* bytes, uint64_t* ordinalsToc, uint32_t* ordinals) {
+    // (SHASTA_MI355X_SLICE_COPY_MIN_BYTES: from how many bytes on the tail's copy is cut into slices, default 8 MiB -- tests set 1.)
+    static const uint64_t sliceCopyMinimum = [] { const char* e = std::getenv("SHASTA_MI355X_SLICE_COPY_MIN_BYTES"); return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : (8ULL << 20); }();
+    // (`threads` > 1: the copy of the call's last batches, when the other workers have nothing left to do and the device waits
+    // for the host: the bytes in as many slices.)
+    auto copyBatch = [&](uint64_t k, const Placement& at, shasta_alignment_data* rows, uint64_t* toc, uint8_t* bytes, uint64_t* ordinalsToc, uint32_t* ordinals, int threads = 1) {
         const BatchOutput& o = outputs[k];
         if(!o.rows.empty()) std::memcpy(rows + at.rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
-        if(!o.bytes.empty()) std::memcpy(bytes + at.byteBase, o.bytes.data(), o.bytes.size());
+        if(o.byteCount) {
+            const uint8_t* from = o.stagedBytes ? o.stagedBytes : o.bytes.data();
+            uint8_t* to = bytes + at.byteBase;
+            if(threads > 1 && o.byteCount >= sliceCopyMinimum) {
+                const uint64_t slice = (o.byteCount / uint64_t(threads) + 4095) & ~4095ULL;
+                std::vector<std::thread> helpers;
+                for(uint64_t begin = slice; begin < o.byteCount; begin += slice) {
+                    const uint64_t count = std::min<uint64_t>(slice, o.byteCount - begin);
+                    helpers.emplace_back([to, from, begin, count] { std::memcpy(to + begin, from + begin, count); });
+                }
+                std::memcpy(to, from, std::min<uint64_t>(slice, o.byteCount));
+                for(std::thread& t : helpers) t.join();
+            } else {
+                std::memcpy(to, from, o.byteCount);
+            }
+        }
         for(size_t q = 0; q < o.tocEnds.size(); q++) toc[at.rowBase + q + 1] = at.byteBase + o.tocEnds[q];
         if(wantOrdinals) {
             if(!o.ordinals.empty()) std::memcpy(ordinals + 2 * at.ordBase, o.ordinals.data(), o.ordinals.size() * sizeof(uint32_t));
             for(size_t q = 1; q < o.ordToc.size(); q++) ordinalsToc[batchStart[k] + q] = at.ordBase + o.ordToc[q];
         }
     };
+    std::atomic<uint64_t> nextBatch(0);
+    const auto nextBatchTaken = [&] { return nextBatch.load(); };
+    // The bytes of a batch out of the worker's staging buffer (which its next batch overwrites) into the batch's own vector.
+    auto keepBytes = [&](BatchOutput& o) {
+        if(!o.stagedBytes) return;
+        o.bytes.assign(o.stagedBytes, o.stagedBytes + o.byteCount);
+        o.stagedBytes = nullptr;
+    };
     auto placeFinished = [&](uint64_t finished) {
         std::vector<uint64_t> mine;
-        {
-            std::lock_guard<std::mutex> lock(placeMutex);
+        BatchOutput& own = outputs[finished];
+        // Marks `finished` done and gives every batch whose predecessors are all done its place (under the lock).
+        const auto markDone = [&] {
             batchDone[finished] = 1;
             while(nextToPlace < batchCount && batchDone[nextToPlace]) {
                 const BatchOutput& o = outputs[nextToPlace];
                 Placement& at = placements[nextToPlace];
                 at.rowBase = placeRows; at.byteBase = placeBytes; at.ordBase = placeOrdinals;
-                placeRows += o.rows.size(); placeBytes += o.bytes.size(); placeOrdinals += o.ordinals.size() / 2;
+                placeRows += o.rows.size(); placeBytes += o.byteCount; placeOrdinals += o.ordinals.size() / 2;
                 if(placeEarly && (placeBytes > store.bytes.size() || (wantOrdinals && 2 * placeOrdinals > store.ordinals.size()))) placeEarly = false;
                 if(placeEarly) { at.placed = true; mine.push_back(nextToPlace); }
                 ++nextToPlace;
             }
+        };
+        // Another worker places this batch only after it is marked done: its bytes must be out of the staging buffer by then,
+        // unless this worker places it itself, now (its predecessors are all done: the usual case, batches finish in order).
+        bool marked = false, tail = false;
+        {
+            std::lock_guard<std::mutex> lock(placeMutex);
+            if(nextToPlace == finished) { markDone(); marked = true; tail = nextBatchTaken() >= batchCount; }
         }
-        for(uint64_t k : mine) copyBatch(k, placements[k], store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data());
+        if(!marked) {
+            keepBytes(own);
+            std::lock_guard<std::mutex> lock(placeMutex);
+            markDone();
+            tail = nextBatchTaken() >= batchCount;
+        }
+        // (tail: every batch has been taken by some worker -- this one has none to go on with, and fewer and fewer of the others)
+        for(uint64_t k : mine) copyBatch(k, placements[k], store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data(), tail ? 4 : 1);
+        if(placements[finished].placed) own.stagedBytes = nullptr;      // (copied from the staging buffer to its place: nothing else reads it)
+        else keepBytes(own);                                            // (the arrays were too small: the end of the call copies it from its vector)
     };
-    std::atomic<uint64_t> nextBatch(0);
     auto workerLoop = [&](int k) {
         try {
             HIP_CHECK(hipSetDevice(ctx.device));
@@ -1515,7 +1564,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     uint64_t rowTotal = 0, byteTotalAll = 0, ordTotalAll = 0, dpCellsTotal = 0, kmerIdBytes = 0, alignedBytes = 0;
     for(uint64_t k = 0; k < batchCount; k++) {
         const BatchOutput& o = outputs[k];
-        rowTotal += o.rows.size(); byteTotalAll += o.bytes.size(); ordTotalAll += o.ordinals.size() / 2;
+        rowTotal += o.rows.size(); byteTotalAll += o.byteCount; ordTotalAll += o.ordinals.size() / 2;
         dpCellsTotal += o.dpCells; kmerIdBytes += o.kmerIdBytes; alignedBytes += o.alignedBytes;
     }
     if(borrowed) {

@@ -37,6 +37,14 @@ def main(path, oracle=None, device_prepare=None):
         # 2060 candidates in three batches.
         assert len(cand) >= 2048, len(cand)
         equal = ctx.align4(cand, o, want_ordinals=True)
+        # The three batches finish in whatever order their workers get to them: a batch whose predecessors are done goes from the
+        # worker's staging buffer straight to its place, one that finishes early waits in a vector of its own.  Several calls, so
+        # that both happen.
+        for _ in range(6):
+            again = ctx.align4(cand, o, want_ordinals=False, borrow=True)
+            assert np.array_equal(again.status, equal.status) and np.array_equal(again.info_table(), equal.info_table())
+            assert np.array_equal(again.compressed_toc, equal.compressed_toc) and np.array_equal(again.compressed_data, equal.compressed_data)
+            del again
         if device_prepare:
             os.environ["SHASTA_MI355X_DEVICE_BATCH_PREP"] = "0"              # every batch's first chunk lists made by the host loop instead of kernels (align4_prepare.hpp)
             prepared = ctx.align4(cand, o, want_ordinals=True)

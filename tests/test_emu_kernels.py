@@ -127,7 +127,7 @@ def test_align3_context_paths(emu_lib, oracle_lib):
 def test_borrowed_results_and_calls_of_several_batches(emu_lib, oracle_lib):
     # (a process of its own: the batch size is read once per process)
     import subprocess, sys
-    env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10")
+    env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10", SHASTA_MI355X_SLICE_COPY_MIN_BYTES="1")     # (the tail's copies in slices at this size too)
     out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", emu_lib.path, "oracle", "both-preparations"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
