@@ -1507,8 +1507,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
         // (tail: every batch has been taken by some worker -- this one has none to go on with, and fewer and fewer of the others)
         for(uint64_t k : mine) copyBatch(k, placements[k], store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data(), tail ? 4 : 1);
-        if(placements[finished].placed) own.stagedBytes = nullptr;      // (copied from the staging buffer to its place: nothing else reads it)
-        else keepBytes(own);                                            // (the arrays were too small: the end of the call copies it from its vector)
+        if(marked) {       // (this thread gave the batch its place, or found the arrays too small for it)
+            if(placements[finished].placed) own.stagedBytes = nullptr;  // copied from the staging buffer to its place: nothing else reads it
+            else keepBytes(own);                                        // the end of the call copies it from its vector
+        }
     };
     auto workerLoop = [&](int k) {
         try {
