@@ -36,6 +36,7 @@
 #include <mutex>
 #include <set>
 #include <unordered_map>
+#include <functional>
 #include <thread>
 #include <type_traits>
 
@@ -882,6 +883,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd)); HIP_CHECK(hipEventCreate(&evOther));
     HIP_CHECK(hipEventRecord(evBegin, ctx.stream));
 
+    // A batch says how much it will put out (stored alignments, compressed bytes, ordinal pairs) as soon as the device has
+    // told it, before the results are written and copied: its place in the caller-visible arrays is the sum over the batches
+    // before it, which have said theirs by then (defined with the placement, below).
+    std::function<void(uint64_t, uint64_t, uint64_t, uint64_t)> publishSizes;
     auto processBatch = [&](Worker& w, uint64_t batchIndex) {
         hipStream_t stream = w.stream;
         const WorkStream ws{w.stream, w.sortWs, w.wide};
@@ -1364,6 +1369,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const uint32_t storedCount = readDevice(b.storedIndex.data() + n, stream);
         const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
         const uint64_t byteTotal = readDevice(b.sizes.data() + n, stream);
+        publishSizes(batchIndex, storedCount, byteTotal, wantOrdinals ? ordTotalOut : 0);
         b.bytes.reserve(byteTotal + 1, stream);
         const KernelTimers::Span writeSpan = ctx.timers.begin("compressWriteKernel", stream);
         hipLaunchKernelGGL(compressWriteKernel, dim3(gw), dim3(256), 0, stream,
@@ -1423,13 +1429,16 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
     };
 
-    // Borrowed results live in arrays the context keeps from call to call: a batch whose predecessors are all done is copied
-    // to its place in them at once, by the worker that finished it, while the other workers' batches are still on the device
-    // (the positions of a batch are the sums over the batches before it).  A batch that does not fit the arrays as they are
-    // (first call, or more output than last time) waits for the end, where the arrays grow.
-    struct Placement { uint64_t rowBase = 0, byteBase = 0, ordBase = 0; bool placed = false; };
+    // Borrowed results live in arrays the context keeps from call to call: a batch is copied to its place in them at once, by
+    // the worker that finished it, while the other workers' batches are still on the device -- from the worker's staging buffer
+    // to its place, one host copy.  Its place is the sum of what the batches before it put out, known as soon as they have
+    // published their sizes (publishSizes: before their results are even written), so the order in which batches FINISH does
+    // not matter (the short last batch of a call usually finishes before its predecessor).  A batch that does not fit the
+    // arrays as they are (first call, or more output than last time), or whose predecessors have not published yet, keeps its
+    // bytes in a vector of its own and waits for the end, where the arrays grow.
+    struct Placement { uint64_t rowBase = 0, byteBase = 0, ordBase = 0, rows = 0, bytes = 0, ords = 0; bool reserved = false, fits = false, placed = false; };
     std::vector<Placement> placements(batchCount);
-    std::vector<char> batchDone(batchCount, 0);
+    std::vector<char> sized(batchCount, 0);
     std::mutex placeMutex;
     uint64_t nextToPlace = 0, placeRows = 0, placeBytes = 0, placeOrdinals = 0;
     bool placeEarly = borrowed;
@@ -1439,6 +1448,19 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(store.compressedToc.size() < candidateCount + 1) store.compressedToc.resize(candidateCount + 1);
         if(wantOrdinals && store.ordinalsToc.size() < candidateCount + 1) store.ordinalsToc.resize(candidateCount + 1);
     }
+    publishSizes = [&](uint64_t k, uint64_t rows, uint64_t bytes, uint64_t ords) {
+        std::lock_guard<std::mutex> lock(placeMutex);
+        placements[k].rows = rows; placements[k].bytes = bytes; placements[k].ords = ords;
+        sized[k] = 1;
+        while(nextToPlace < batchCount && sized[nextToPlace]) {
+            Placement& at = placements[nextToPlace];
+            at.rowBase = placeRows; at.byteBase = placeBytes; at.ordBase = placeOrdinals;
+            placeRows += at.rows; placeBytes += at.bytes; placeOrdinals += at.ords;
+            if(placeEarly && (placeBytes > store.bytes.size() || (wantOrdinals && 2 * placeOrdinals > store.ordinals.size()))) placeEarly = false;
+            at.fits = placeEarly; at.reserved = true;
+            ++nextToPlace;
+        }
+    };
     // (SHASTA_MI355X_SLICE_COPY_MIN_BYTES: from how many bytes on the tail's copy is cut into slices, default 8 MiB -- tests set 1.)
     static const uint64_t sliceCopyMinimum = [] { const char* e = std::getenv("SHASTA_MI355X_SLICE_COPY_MIN_BYTES"); return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : (8ULL << 20); }();
     // (`threads` > 1: the copy of the call's last batches, when the other workers have nothing left to do and the device waits
@@ -1469,7 +1491,6 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         }
     };
     std::atomic<uint64_t> nextBatch(0);
-    const auto nextBatchTaken = [&] { return nextBatch.load(); };
     // The bytes of a batch out of the worker's staging buffer (which its next batch overwrites) into the batch's own vector.
     auto keepBytes = [&](BatchOutput& o) {
         if(!o.stagedBytes) return;
@@ -1477,39 +1498,23 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         o.stagedBytes = nullptr;
     };
     auto placeFinished = [&](uint64_t finished) {
-        std::vector<uint64_t> mine;
         BatchOutput& own = outputs[finished];
-        // Marks `finished` done and gives every batch whose predecessors are all done its place (under the lock).
-        const auto markDone = [&] {
-            batchDone[finished] = 1;
-            while(nextToPlace < batchCount && batchDone[nextToPlace]) {
-                const BatchOutput& o = outputs[nextToPlace];
-                Placement& at = placements[nextToPlace];
-                at.rowBase = placeRows; at.byteBase = placeBytes; at.ordBase = placeOrdinals;
-                placeRows += o.rows.size(); placeBytes += o.byteCount; placeOrdinals += o.ordinals.size() / 2;
-                if(placeEarly && (placeBytes > store.bytes.size() || (wantOrdinals && 2 * placeOrdinals > store.ordinals.size()))) placeEarly = false;
-                if(placeEarly) { at.placed = true; mine.push_back(nextToPlace); }
-                ++nextToPlace;
-            }
-        };
-        // Another worker places this batch only after it is marked done: its bytes must be out of the staging buffer by then,
-        // unless this worker places it itself, now (its predecessors are all done: the usual case, batches finish in order).
-        bool marked = false, tail = false;
+        Placement at;
+        bool direct = false, tail = false;
         {
             std::lock_guard<std::mutex> lock(placeMutex);
-            if(nextToPlace == finished) { markDone(); marked = true; tail = nextBatchTaken() >= batchCount; }
+            Placement& mine = placements[finished];
+            MI355X_ASSERT(mine.rows == own.rows.size() && mine.bytes == own.byteCount && mine.ords == own.ordinals.size() / 2);
+            direct = mine.reserved && mine.fits;
+            if(direct) mine.placed = true;
+            at = mine;
+            tail = nextBatch.load() >= batchCount;      // every batch has been taken: this worker has none to go on with
         }
-        if(!marked) {
-            keepBytes(own);
-            std::lock_guard<std::mutex> lock(placeMutex);
-            markDone();
-            tail = nextBatchTaken() >= batchCount;
-        }
-        // (tail: every batch has been taken by some worker -- this one has none to go on with, and fewer and fewer of the others)
-        for(uint64_t k : mine) copyBatch(k, placements[k], store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data(), tail ? 4 : 1);
-        if(marked) {       // (this thread gave the batch its place, or found the arrays too small for it)
-            if(placements[finished].placed) own.stagedBytes = nullptr;  // copied from the staging buffer to its place: nothing else reads it
-            else keepBytes(own);                                        // the end of the call copies it from its vector
+        if(direct) {
+            copyBatch(finished, at, store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data(), tail ? 4 : 1);
+            own.stagedBytes = nullptr;       // (copied from the staging buffer to its place: nothing else reads it)
+        } else {
+            keepBytes(own);                  // (the end of the call copies it from its vector)
         }
     };
     auto workerLoop = [&](int k) {
