@@ -739,6 +739,7 @@ struct BatchOutput {
     // is their number wherever they are.
     const uint8_t* stagedBytes = nullptr;
     uint64_t byteCount = 0;
+    bool bytesInPlace = false;      // the device copied them straight to their place in the caller-visible array
     std::vector<uint32_t> ordinals;
     uint64_t dpCells = 0, kmerIdBytes = 0, alignedBytes = 0;
     DpBatchStats dpStats;
@@ -747,11 +748,35 @@ struct BatchOutput {
 
 // Results of a "borrowed" call live here, in the context, and are reused by the next call: no
 // half-gigabyte malloc / page-fault / munmap cycle per call.
+// The caller-visible array of the compressed alignments of borrowed calls: page-locked, so that the device copies a batch's
+// bytes straight to their place in it (no host copy at all); grows keeping its contents.
+class PinnedBytes {
+public:
+    PinnedBytes() = default;
+    PinnedBytes(const PinnedBytes&) = delete;
+    PinnedBytes& operator=(const PinnedBytes&) = delete;
+    ~PinnedBytes() { if(p) (void)hipHostFree(p); }
+    size_t size() const { return n; }
+    uint8_t* data() const { return p; }
+    void resize(size_t m)
+    {
+        if(m <= n) return;
+        void* q = nullptr;
+        HIP_CHECK(hipHostMalloc(&q, m, hipHostMallocDefault));
+        if(p) { std::memcpy(q, p, n); (void)hipHostFree(p); }
+        p = static_cast<uint8_t*>(q); n = m;
+    }
+private:
+    uint8_t* p = nullptr;
+    size_t n = 0;
+};
+
 struct AlignStore {
     std::vector<BatchOutput> outputs;
     std::vector<shasta_alignment_data> rows;
     std::vector<uint64_t> compressedToc, ordinalsToc;
-    std::vector<uint8_t> bytes, status;
+    PinnedBytes bytes;
+    std::vector<uint8_t> status;
     std::vector<uint32_t> ordinals;
 };
 
@@ -840,7 +865,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     for(uint64_t k = 0; k < batchCount; k++) {
         BatchOutput& o = outputs[k];
         o.dpCells = o.kmerIdBytes = o.alignedBytes = 0; o.hadTasks = false;
-        o.stagedBytes = nullptr; o.byteCount = 0; o.bytes.clear();
+        o.stagedBytes = nullptr; o.byteCount = 0; o.bytes.clear(); o.bytesInPlace = false;
         o.dpStats = DpBatchStats();
         o.ordToc.clear(); o.ordinals.clear();
     }
@@ -886,7 +911,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     // A batch says how much it will put out (stored alignments, compressed bytes, ordinal pairs) as soon as the device has
     // told it, before the results are written and copied: its place in the caller-visible arrays is the sum over the batches
     // before it, which have said theirs by then (defined with the placement, below).
-    std::function<void(uint64_t, uint64_t, uint64_t, uint64_t)> publishSizes;
+    std::function<uint8_t*(uint64_t, uint64_t, uint64_t, uint64_t)> publishSizes;      // -> where the batch's bytes go in the caller-visible array, if that is known and has room
     auto processBatch = [&](Worker& w, uint64_t batchIndex) {
         hipStream_t stream = w.stream;
         const WorkStream ws{w.stream, w.sortWs, w.wide};
@@ -1369,7 +1394,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const uint32_t storedCount = readDevice(b.storedIndex.data() + n, stream);
         const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
         const uint64_t byteTotal = readDevice(b.sizes.data() + n, stream);
-        publishSizes(batchIndex, storedCount, byteTotal, wantOrdinals ? ordTotalOut : 0);
+        uint8_t* const bytesPlace = publishSizes(batchIndex, storedCount, byteTotal, wantOrdinals ? ordTotalOut : 0);
         b.bytes.reserve(byteTotal + 1, stream);
         const KernelTimers::Span writeSpan = ctx.timers.begin("compressWriteKernel", stream);
         hipLaunchKernelGGL(compressWriteKernel, dim3(gw), dim3(256), 0, stream,
@@ -1384,7 +1409,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         // Device -> pinned staging (asynchronous, PCIe speed) -> the batch's output vectors.
         void* pinRows = b.pinRows.reserve(storedCount * sizeof(shasta_alignment_data));
         void* pinToc = b.pinToc.reserve(storedCount * sizeof(uint64_t));
-        void* pinBytes = b.pinBytes.reserve(byteTotal);
+        void* pinBytes = bytesPlace ? static_cast<void*>(bytesPlace) : b.pinBytes.reserve(byteTotal);      // (its place in the page-locked array, or the staging buffer)
         void* pinStatus = b.pinStatus.reserve(n);
         void* pinOrdToc = nullptr; void* pinOrdinals = nullptr;
         if(storedCount) {
@@ -1409,7 +1434,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipStreamSynchronize(stream));
         out.rows.assign(static_cast<const shasta_alignment_data*>(pinRows), static_cast<const shasta_alignment_data*>(pinRows) + storedCount);
         hostToc64.assign(static_cast<const uint64_t*>(pinToc), static_cast<const uint64_t*>(pinToc) + storedCount);
-        out.stagedBytes = static_cast<const uint8_t*>(pinBytes); out.byteCount = byteTotal;      // (placeFinished takes them from there)
+        out.bytesInPlace = bytesPlace != nullptr;
+        out.stagedBytes = bytesPlace ? nullptr : static_cast<const uint8_t*>(pinBytes); out.byteCount = byteTotal;      // (placeFinished takes them from there)
         std::memcpy(outStatus.data() + batchBegin, pinStatus, n);
         if(wantOrdinals) {
             out.ordToc.assign(static_cast<const uint64_t*>(pinOrdToc), static_cast<const uint64_t*>(pinOrdToc) + uint64_t(n) + 1);
@@ -1448,7 +1474,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(store.compressedToc.size() < candidateCount + 1) store.compressedToc.resize(candidateCount + 1);
         if(wantOrdinals && store.ordinalsToc.size() < candidateCount + 1) store.ordinalsToc.resize(candidateCount + 1);
     }
-    publishSizes = [&](uint64_t k, uint64_t rows, uint64_t bytes, uint64_t ords) {
+    publishSizes = [&](uint64_t k, uint64_t rows, uint64_t bytes, uint64_t ords) -> uint8_t* {
         std::lock_guard<std::mutex> lock(placeMutex);
         placements[k].rows = rows; placements[k].bytes = bytes; placements[k].ords = ords;
         sized[k] = 1;
@@ -1460,6 +1486,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             at.fits = placeEarly; at.reserved = true;
             ++nextToPlace;
         }
+        const Placement& mine = placements[k];
+        return (mine.reserved && mine.fits && mine.bytes) ? store.bytes.data() + mine.byteBase : nullptr;
     };
     // (SHASTA_MI355X_SLICE_COPY_MIN_BYTES: from how many bytes on the tail's copy is cut into slices, default 8 MiB -- tests set 1.)
     static const uint64_t sliceCopyMinimum = [] { const char* e = std::getenv("SHASTA_MI355X_SLICE_COPY_MIN_BYTES"); return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : (8ULL << 20); }();
@@ -1468,7 +1496,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     auto copyBatch = [&](uint64_t k, const Placement& at, shasta_alignment_data* rows, uint64_t* toc, uint8_t* bytes, uint64_t* ordinalsToc, uint32_t* ordinals, int threads = 1) {
         const BatchOutput& o = outputs[k];
         if(!o.rows.empty()) std::memcpy(rows + at.rowBase, o.rows.data(), o.rows.size() * sizeof(shasta_alignment_data));
-        if(o.byteCount) {
+        if(o.byteCount && !o.bytesInPlace) {
             const uint8_t* from = o.stagedBytes ? o.stagedBytes : o.bytes.data();
             uint8_t* to = bytes + at.byteBase;
             if(threads > 1 && o.byteCount >= sliceCopyMinimum) {
@@ -1506,6 +1534,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             Placement& mine = placements[finished];
             MI355X_ASSERT(mine.rows == own.rows.size() && mine.bytes == own.byteCount && mine.ords == own.ordinals.size() / 2);
             direct = mine.reserved && mine.fits;
+            MI355X_ASSERT(direct || !own.bytesInPlace);
             if(direct) mine.placed = true;
             at = mine;
             tail = nextBatch.load() >= batchCount;      // every batch has been taken: this worker has none to go on with
