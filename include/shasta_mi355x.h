@@ -335,9 +335,10 @@ int shasta_mi355x_align4_run_borrowed(
  * shasta_mi355x_align4_free.  Status EMPTY = empty alignment (a read without down-sampled markers,
  * nothing aligned in step 1, or a band wider than maxBand); SKIPPED = a pair whose down-sampled
  * matrix has more than 65536 diagonals (down-sampled markers of the two reads + 1: reads of several
- * megabases at the default factor), which this version does not align.  Limits: scores 6/-1/-1 (every
- * shipped configuration), maxBand <= 1023, k <= 16.  `borrowed` != 0: result arrays belong to the
- * context, as align4_run_borrowed. */
+ * megabases at the default factor), which this version does not align.  Limits: any scores whose magnitudes
+ * add up to less than 2^20 (6/-1/-1, every shipped configuration, runs the kernels with the scores as
+ * immediates), maxBand <= 65535 (a band of more than 1024 diagonals runs in the wide DP), k <= 16.
+ * `borrowed` != 0: result arrays belong to the context, as align4_run_borrowed. */
 int shasta_mi355x_align3_run(
     shasta_mi355x_ctx*, uint64_t candidateCount,
     const shasta_oriented_read_pair* candidates,
@@ -427,7 +428,7 @@ int shasta_mi355x_banded_dp(
 
 /* The same DP on many tasks in one call: they are sorted by band class and length and bundled several to a
  * wavefront exactly as the tasks of an Align4 batch are.  Task t aligns kmerIds[begin0[t] .. +nx[t]) with
- * kmerIds[begin1[t] .. +ny[t]) inside the band [bandMin[t], bandMax[t]] (width <= 1024, meeting the matrix).
+ * kmerIds[begin1[t] .. +ny[t]) inside the band [bandMin[t], bandMax[t]] (width <= 65536, meeting the matrix; more than 1024 diagonals: the wide DP).
  * counts[t] aligned pairs and scores[t] per task; the pairs of all tasks concatenated in ordinals
  * (capacity in pairs; ordinals may be NULL).  seconds (NULL or 9 entries): HIP-event time of the forward
  * launch of each of the eight band classes (widths <= 32, 48, 64, 80, 128, 256, 512, 1024) and of the traceback;
