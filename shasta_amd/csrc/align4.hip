@@ -755,20 +755,34 @@ public:
     PinnedBytes() = default;
     PinnedBytes(const PinnedBytes&) = delete;
     PinnedBytes& operator=(const PinnedBytes&) = delete;
-    ~PinnedBytes() { if(p) (void)hipHostFree(p); }
+    ~PinnedBytes() { release(); }
     size_t size() const { return n; }
     uint8_t* data() const { return p; }
+    bool pageLocked() const { return locked; }
+    // (Where that much memory cannot be page-locked -- tens of gigabytes of results, a locked-memory limit -- the array is
+    // ordinary memory and the batches come through the workers' staging buffers: one host copy each.)
     void resize(size_t m)
     {
         if(m <= n) return;
         void* q = nullptr;
-        HIP_CHECK(hipHostMalloc(&q, m, hipHostMallocDefault));
-        if(p) { std::memcpy(q, p, n); (void)hipHostFree(p); }
-        p = static_cast<uint8_t*>(q); n = m;
+        bool qLocked = true;
+        // (SHASTA_MI355X_RESULTS_NOT_PAGE_LOCKED=1: as if page-locking had failed -- tests of the staging path.)
+        static const bool never = [] { const char* e = std::getenv("SHASTA_MI355X_RESULTS_NOT_PAGE_LOCKED"); return e && e[0] == '1'; }();
+        if(never || hipHostMalloc(&q, m, hipHostMallocDefault) != hipSuccess || !q) {
+            (void)hipGetLastError();
+            q = std::malloc(m);
+            if(!q) throw std::bad_alloc();
+            qLocked = false;
+        }
+        if(p) std::memcpy(q, p, n);
+        release();
+        p = static_cast<uint8_t*>(q); n = m; locked = qLocked;
     }
 private:
+    void release() { if(p) { if(locked) (void)hipHostFree(p); else std::free(p); } p = nullptr; n = 0; }
     uint8_t* p = nullptr;
     size_t n = 0;
+    bool locked = true;
 };
 
 struct AlignStore {
@@ -1487,7 +1501,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             ++nextToPlace;
         }
         const Placement& mine = placements[k];
-        return (mine.reserved && mine.fits && mine.bytes) ? store.bytes.data() + mine.byteBase : nullptr;
+        return (mine.reserved && mine.fits && mine.bytes && store.bytes.pageLocked()) ? store.bytes.data() + mine.byteBase : nullptr;
     };
     // (SHASTA_MI355X_SLICE_COPY_MIN_BYTES: from how many bytes on the tail's copy is cut into slices, default 8 MiB -- tests set 1.)
     static const uint64_t sliceCopyMinimum = [] { const char* e = std::getenv("SHASTA_MI355X_SLICE_COPY_MIN_BYTES"); return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : (8ULL << 20); }();

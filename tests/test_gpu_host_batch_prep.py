@@ -35,6 +35,7 @@ def test_mixed_length_reads_with_the_first_chunk_lists_made_on_the_host(gpu_lib,
 def test_many_small_batches_with_the_first_chunk_lists_made_on_the_host(gpu_lib):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10")
+    # (and the borrowed results through the workers' staging buffers -- what happens where the result array cannot be page-locked)
+    env = dict(os.environ, SHASTA_MI355X_ALIGN_BATCH_LOG2="10", SHASTA_MI355X_RESULTS_NOT_PAGE_LOCKED="1", SHASTA_MI355X_SLICE_COPY_MIN_BYTES="1")
     out = subprocess.run([sys.executable, "-m", "tests.borrowed_checks", gpu_lib.path, "oracle", "both-preparations"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
