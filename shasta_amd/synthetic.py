@@ -47,6 +47,35 @@ def marker_alphabet(k=10, probability=0.1, seed=231):
     return np.nonzero(marker)[0].astype(np.uint32), rc.astype(np.uint32)
 
 
+class RcMap:
+    """Reverse complement of the ids of a sampled alphabet: map[ids] for ids of the alphabet (an array lookup by binary
+    search, where a table over all 4^k ids would be gigabytes at k = 14 and 16)."""
+    def __init__(self, ids, rc):
+        self.ids, self.rc = ids, rc
+
+    def __getitem__(self, x):
+        x = np.asarray(x)
+        at = np.searchsorted(self.ids, x)
+        assert np.array_equal(self.ids[np.minimum(at, len(self.ids) - 1)], x), "id outside the sampled alphabet"
+        return self.rc[at]
+
+
+def sampled_marker_alphabet(k=14, count=1 << 21, seed=231):
+    """About `count` distinct RLE k-mers (no equal adjacent bases) drawn over the WHOLE id range of k (4^14 = 2^28 for the
+    Nanopore-May2022 configurations, 4^16 = 2^32 at the largest k Shasta's 32-bit KmerId holds), closed under reverse
+    complement -> (ids sorted uint32, RcMap).  marker_alphabet() enumerates all 4^k ids, which stops being practical beyond
+    k = 12; the hot path only ever sees the ids, so a sample with the same structure exercises the same range."""
+    rng = np.random.default_rng([seed, k])
+    first = rng.integers(0, 4, size=count, dtype=np.uint64)
+    steps = rng.integers(1, 4, size=(count, k - 1), dtype=np.uint64)
+    bases = (first[:, None] + np.concatenate([np.zeros((count, 1), np.uint64), np.cumsum(steps, axis=1, dtype=np.uint64)], axis=1)) & np.uint64(3)
+    ids = np.zeros(count, dtype=np.uint64)
+    for i in range(k):
+        ids = (ids << np.uint64(2)) | bases[:, i]
+    ids = np.unique(np.concatenate([ids, reverse_complement_ids(ids, k)]))
+    return ids.astype(np.uint32), RcMap(ids.astype(np.uint32), reverse_complement_ids(ids, k).astype(np.uint32))
+
+
 def marker_genome(rng, alphabet, genome_markers, repeat_fraction=0.02):
     """A random genome over the marker alphabet with a few 200-marker repeats, as real genomes have."""
     genome = alphabet[rng.integers(0, len(alphabet), size=genome_markers)]
@@ -60,13 +89,14 @@ def marker_genome(rng, alphabet, genome_markers, repeat_fraction=0.02):
 
 def marker_reads(n_reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=700,
                  keep_probability=0.65, spurious_probability=0.06, k=10, seed=12345,
-                 repeat_fraction=0.02, shard=None, shard_count=1):
+                 repeat_fraction=0.02, shard=None, shard_count=1, alphabet=None):
     """Returns (toc uint64[2R+1], kmer_ids uint32[M]) for R = n_reads reads, both strands.
     With shard / shard_count the genome (from `seed`) is common to all shards and the n_reads reads
     of shard `shard` come from their own stream, so that shards generated on different ranks are
-    consecutive read ranges of one read set."""
+    consecutive read ranges of one read set.  `alphabet` = (ids, reverse-complement lookup), e.g. sampled_marker_alphabet(14);
+    default: all marker k-mers of marker_alphabet(k)."""
     rng = np.random.default_rng(seed)
-    alphabet, rc_table = marker_alphabet(k=k)
+    alphabet, rc_table = marker_alphabet(k=k) if alphabet is None else alphabet
     genome = marker_genome(rng, alphabet, genome_markers, repeat_fraction)
     if shard is not None:
         rng = np.random.default_rng([seed, 1000003 + int(shard), int(shard_count)])
@@ -138,8 +168,10 @@ def unpack_kmer_ids(data7):
 
 
 def fasta_reads(path, n_reads, genome_length, mean_length=15000.0, sigma=0.35, min_length=10500,
-                sub=0.02, ins=0.015, dele=0.015, seed=12345):
-    """Writes base-level reads to a FASTA file; returns the list of (start, length, flipped)."""
+                sub=0.02, ins=0.015, dele=0.015, seed=12345, homopolymer=0.0):
+    """Writes base-level reads to a FASTA file; returns the list of (start, length, flipped).
+    homopolymer: probability per base of a run-length error (the base is written twice, or dropped when it repeats its
+    predecessor) -- the dominant Nanopore error, which Shasta's run-length representation removes again."""
     rng = np.random.default_rng(seed)
     genome = rng.integers(0, 4, size=genome_length, dtype=np.uint8)
     letters = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -163,6 +195,11 @@ def fasta_reads(path, n_reads, genome_length, mean_length=15000.0, sigma=0.35, m
             copy[1:] = idx[1:] == idx[:-1]
             s = s[idx]
             s[copy] = rng.integers(0, 4, size=int(copy.sum()), dtype=np.uint8)
+            if homopolymer > 0.0:
+                u = rng.random(len(s))
+                repeats_previous = np.zeros(len(s), dtype=bool)
+                repeats_previous[1:] = s[1:] == s[:-1]
+                s = np.repeat(s, np.where(u < homopolymer, 2, np.where((u > 1.0 - homopolymer) & repeats_previous, 0, 1)))
             flipped = bool(rng.random() < 0.5)
             if flipped:
                 s = comp[s[::-1]]

@@ -274,3 +274,17 @@ def test_lowhash0_calls_of_one_context_share_their_allocations(emu_lib, oracle_l
         ctx.set_kmer_ids(toc, kmer)
         for p in cases:
             support.same_lowhash(ctx.lowhash0(p), oracle_lib.lowhash0(toc, data7, None, p))
+
+
+def test_kmer_ids_of_k_14_and_the_top_of_the_32_bit_range(emu_lib, oracle_lib):
+    # BASELINE configs[3] / [4]: Kmers.k = 14 (ids up to 2^28); and raw ids just below 2^32 (tests/config_value_checks.py).
+    from tests import config_value_checks
+    assert config_value_checks.wide_id_range(emu_lib, oracle_lib, None, k=14, n_reads=110, genome_markers=6000, limit=150) > 100
+    assert config_value_checks.top_of_the_id_range(emu_lib, oracle_lib) >= 8
+
+
+def test_base_level_reads_against_the_reference_running_live(emu_lib, ref_lib):
+    # BASELINE configs[0] at a tenth of its size (tests/base_level_checks.py; the -m gpu test runs 4 000 reads).
+    from tests import base_level_checks
+    reads, markers, candidates, stored = base_level_checks.plumbing(emu_lib, ref_lib, n_reads=400, genome_length=150000, limit=400)
+    assert reads >= 360 and stored > 100
