@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole hot path over the workload: LowHash0 (10 MinHash
-iterations) on the resident markers -> candidate list -> Align4 on every candidate ->
-AlignmentData + CompressedAlignments on the host.  Inputs (kmer ids, toc) are resident
+iterations) on the resident markers -> candidate list -> Assembler::computeAlignments
+(src/AssemblerAlign.cpp:208-304) end to end: Align4 on every candidate, AlignmentData +
+CompressedAlignments on the host, and the alignment table (computeAlignmentTable, :296).  Inputs (kmer ids, toc) are resident
 in HBM before the timed region.  Workload: BASELINE.json configs[2]
 ("Synthetic 100k reads, 1xMI355X, LowHash0 + Align4 banded marker alignment end-to-end"),
 generated at marker level (shasta_amd/synthetic.py; SURVEY F5: the path never reads bases).
@@ -135,7 +136,7 @@ def available_memory_gib():
     return 1 << 20
 
 
-def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, census_size=0):
+def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, census_size=0, all_rows=None):
     """The reference CPU path on the SAME read set, on this host's cores, outside the timed region; its outputs
     are compared with the device's (parity at the benchmark's own size).  LowHash0 runs in full; the aligner
     on every (candidates / sample_size)-th candidate (the whole list would take minutes)."""
@@ -162,6 +163,9 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
         lh = lib.lowhash0(toc, data7, None, p)
         t_lh = time.time() - t0
     cand = lh.candidates
+    # Assembler::computeSortedMarkers (src/AssemblerAlign.cpp:236-239): once, for all oriented reads, before the alignment threads
+    # start -- timed on its own; the per-candidate loop below reads it (method 4; method 3 does not use sorted markers).
+    t_sorted = lib.compute_sorted_markers(toc, data7, threads=cores) if (kind == "reference" and align_method == 4) else 0.0
     parity["lowhash0_candidates"] = len(cand)
     parity["lowhash0_equal"] = bool(np.array_equal(lh.candidate_tuples(), gpu_lowhash.candidate_tuples())
                                     and np.array_equal(lh.statistics, gpu_lowhash.statistics)
@@ -182,7 +186,19 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
     per_pair = (t2 - t1) / (len(sample) - len(small)) if (not whole and len(sample) > len(small)) else 0.0
     if per_pair <= 0.0:                                 # the whole list, or too few candidates for the difference to mean anything
         per_pair = t2 / max(1, len(sample))
-    dev = (ctx.align4 if align_method == 4 else ctx.align3)(sample, o, want_ordinals=True)
+    if kind == "reference":
+        lib.drop_sorted_markers()
+    dev = (ctx.align4 if align_method == 4 else ctx.align3)(sample, o, want_ordinals=True, borrow=True)
+    # Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:296, 509-571; serial in the reference) on the alignments of the
+    # WHOLE candidate list -- the device's rows of the bench's last step (equal to the reference's wherever both exist, below) --
+    # and compared with the table the device made from the sample's.
+    t_table = 0.0
+    if kind == "reference":
+        sample_toc, sample_values = ctx.alignment_table()
+        ref_toc, ref_values, _ = lib.alignment_table(np.array(dev.alignment_data, copy=True), (len(toc) - 1) // 2)
+        parity["alignment_table_equal"] = bool(np.array_equal(sample_toc, ref_toc) and np.array_equal(sample_values, ref_values))
+        if all_rows is not None:
+            t_table = lib.alignment_table(all_rows, (len(toc) - 1) // 2)[2]
     ties = (ref.status & 0x80) != 0
     parity["aligner_sampled_candidates"] = len(sample)
     parity["aligner_ties_in_sample"] = int(ties.sum())
@@ -200,7 +216,7 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
         parity["dp_tie_sensitive"] = census.tie_census(lib, toc, data7, sub, o, align_method=align_method, threads=min(cores, 16))
         parity["dp_tie_sensitive"]["seconds"] = time.time() - t0
     pairs = len(cand)
-    total = t_lh + pairs * per_pair
+    total = t_lh + t_sorted + pairs * per_pair + t_table
     return {
         "value": pairs / total if total > 0 else 0.0,
         "unit": "candidate read-pairs aligned/s",
@@ -216,7 +232,10 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
                   "(the reference warns such runs should not be used for benchmarking, srcMain/main.cpp:369-378)" % (
                       (len(toc) - 1) // 2, int(toc[-1]), t_lh, cores, host_cores, pairs, align_method, stride, len(sample), per_pair * 1e3, cores),
         "lowhash0_seconds": t_lh,
+        "sorted_markers_seconds": t_sorted,            # Assembler::computeSortedMarkers, all reads, `threads` threads
         "align_seconds_per_pair": per_pair,
+        "alignment_table_seconds": t_table,            # Assembler::computeAlignmentTable on all stored alignments (serial, as in the reference)
+        "what": "findAlignmentCandidatesLowHash0 + computeAlignments (computeSortedMarkers, the per-candidate loop, computeAlignmentTable)",
     }, parity
 
 
@@ -448,11 +467,17 @@ def main():
         ctx.set_kmer_ids(toc, kmer)                     # host -> HBM, outside the timed region
         upload_seconds = time.perf_counter() - t0
 
+        table_seconds = [0.0]
+
         def step():
             lh = ctx.lowhash0(p)
             if args.lowhash_only:
                 return lh, None, len(lh.candidates)
             al = align(lh.candidates)
+            # The last step of Assembler::computeAlignments (src/AssemblerAlign.cpp:296): the alignment table of what was stored.
+            t = time.perf_counter()
+            al.table = ctx.alignment_table(copy=False)
+            table_seconds[0] += time.perf_counter() - t
             return lh, al, len(lh.candidates)
     else:
         # ONE job over all GPUs (weak scaling: `reads` reads per GPU of one read set at the same
@@ -531,6 +556,8 @@ def main():
         phase_seconds.clear()
         del phase_log[:]
     ctx.kernel_table_reset()
+    if not sharded:
+        table_seconds[0] = 0.0
     t0 = time.perf_counter()
     cpu0 = _process_cpu_seconds()
     throttled0 = _cgroup_throttled_usec()
@@ -663,6 +690,11 @@ def main():
                             "10 iterations 5/30/5; %s" % (args.reads, "Align4 200/10/10/100, maxBand 1000, 6/-1/-1"
                                                           if args.align_method == 4 else
                                                           "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"),
+                "step": ("findAlignmentCandidatesLowHash0 (src/AssemblerLowHash.cpp:10-55) + computeAlignments (src/AssemblerAlign.cpp:208-304) end to end: "
+                         "candidates -> AlignmentData + CompressedAlignments on the host%s"
+                         % (" + the alignment table (computeAlignmentTable, :296)" if not sharded else
+                            "; each rank keeps the alignments of its candidate share (no alignment table: its indices are those of the whole list)"))
+                        if not args.lowhash_only else "findAlignmentCandidatesLowHash0 only",
                 "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
                 "parallelism": "1 GPU" if not sharded else
@@ -673,7 +705,8 @@ def main():
             "stage_device_ms_each_step": each_step,
             "host_load_in_the_timed_region": host_load,
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
-                                       "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps},
+                                       "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps,
+                                       "alignment_table_call": (table_seconds[0] / steps) if not sharded else None},
             "kernel_seconds_per_step": kernel_seconds,
             "kernels": kernels,
             "roofline": roofline,
@@ -706,9 +739,10 @@ def main():
                                      "value_with_upload_every_step": pairs_total / (elapsed / steps + upload_seconds)}
         if not args.no_cpu_baseline and not sharded:
             lh_check = ctx.lowhash0(p)
+            all_rows = np.array(al.alignment_data, copy=True) if al is not None else None      # (the last step's, before the context's arrays are reused)
             out["cpu_baseline"], out["parity_at_bench_size"] = cpu_baseline(
                 ctx, toc, kmer, p, o, args.align_method, lh_check, args.baseline_sample if not DRY_RUN_LIBRARY else 200,
-                census_size=args.tie_census if not DRY_RUN_LIBRARY else 60)
+                census_size=args.tie_census if not DRY_RUN_LIBRARY else 60, all_rows=all_rows)
             out["dp_tie_sensitive"] = out["parity_at_bench_size"].pop("dp_tie_sensitive", None)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         final_line = json.dumps(out)

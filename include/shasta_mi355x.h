@@ -455,6 +455,12 @@ int shasta_mi355x_banded_dp_many(
  * its reads, else 0. */
 int shasta_mi355x_pair_table(int device, const void* pairs, uint64_t strideBytes, uint64_t pairCount, uint64_t readCount,
     uint64_t* toc, uint32_t* values);
+/* The last step of Assembler::computeAlignments (src/AssemblerAlign.cpp:296 -> computeAlignmentTable, :509-571) for the
+ * alignments the context's last shasta_mi355x_align4_run_borrowed / _align3_run_borrowed call stored: the same table as
+ * shasta_mi355x_pair_table gives for those AlignmentData rows (toc: 2 readCount + 1 offsets, values: 4 alignmentCount
+ * indices), built where the aligner left off -- the context's stream and buffers, nothing allocated from the second call on.
+ * *toc and *values point into page-locked arrays of the context, valid until its next aligner or table call. */
+int shasta_mi355x_alignment_table(shasta_mi355x_ctx*, const uint64_t** toc, const uint32_t** values, uint64_t* valueCount);
 int shasta_mi355x_read_graph_keep(int device, const shasta_alignment_data* alignmentData, uint64_t alignmentCount, uint64_t readCount,
     uint32_t maxAlignmentCount, uint8_t* keep);
 

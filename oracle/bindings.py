@@ -253,6 +253,31 @@ class RefLib(_Base):
         return out
 
 
+    def compute_sorted_markers(self, toc, data7, threads=0):
+        """Assembler::computeSortedMarkers (src/AssemblerAlign4.cpp:190-261) in the reference's container, once for all oriented
+        reads, as computeAlignments does before its threads start; align4_batch calls on the SAME data7 array then read it
+        instead of sorting the reads of every candidate.  -> seconds."""
+        toc = _u64(toc)
+        assert data7.dtype == np.uint8 and data7.flags["C_CONTIGUOUS"]            # (kept by address: the caller's array itself)
+        seconds = C.c_double(0.0)
+        self._check(self.lib.ref_compute_sorted_markers(C.c_uint64((len(toc) - 1) // 2), abi.as_ptr(toc, C.c_uint64), C.c_void_p(data7.ctypes.data),
+                                                        C.c_uint64(threads), C.byref(seconds)), "ref_compute_sorted_markers")
+        return seconds.value
+
+    def drop_sorted_markers(self):
+        self.lib.ref_drop_sorted_markers()
+
+    def alignment_table(self, alignment_data, read_count):
+        """Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571) -> (toc uint64[2 R + 1], values uint32[4 N], seconds)."""
+        rows = np.ascontiguousarray(alignment_data)
+        assert rows.dtype.itemsize == 64
+        toc = np.zeros(2 * int(read_count) + 1, np.uint64)
+        values = np.zeros(max(1, 4 * len(rows)), np.uint32)
+        seconds = C.c_double(0.0)
+        self._check(self.lib.ref_alignment_table(C.c_uint64(read_count), C.c_uint64(len(rows)), C.c_void_p(rows.ctypes.data if len(rows) else None),
+                                                 abi.as_ptr(toc, C.c_uint64), abi.as_ptr(values, C.c_uint32), C.byref(seconds)), "ref_alignment_table")
+        return toc, values[:4 * len(rows)], seconds.value
+
     def align3_batch(self, toc, data7, candidates, options, want_ordinals=True, threads=1):
         """Align method 3 through the reference's own Assembler::alignOrientedReads3."""
         toc = _u64(toc)

@@ -485,6 +485,104 @@ static void sortedMarkersOf(const span<const CompressedMarker>& um, vector< pair
     sort(sm.begin(), sm.end(), OrderPairsByFirstOnly<KmerId, uint32_t>());
 }
 
+// Assembler::computeSortedMarkers (src/AssemblerAlign4.cpp:190-261), which the reference runs ONCE before its alignment
+// threads start (src/AssemblerAlign.cpp:236-239): every oriented read's (kmerId, ordinal) pairs sorted by kmerId, in the
+// reference's own container, filled by `threadCount` threads over batches of 10 000 oriented reads.  Kept here between
+// ref_compute_sorted_markers and the ref_align4_batch_mt calls on the SAME markers (bench.py's CPU leg: the pass is timed
+// on its own and the per-candidate loop reads spans of it, as computeAlignmentsThreadFunction does, :397-398); without it
+// ref_align4_batch_mt sorts the two reads of every candidate itself (the small inputs of the tests).
+namespace {
+struct SortedMarkersCache {
+    MemoryMapped::VectorOfVectors< pair<KmerId, uint32_t>, uint64_t > sorted;
+    const void* markersData = nullptr;
+    uint64_t markerCount = 0, readCount = 0;
+    bool valid = false;
+} sortedMarkersCache;
+}  // namespace
+
+int ref_compute_sorted_markers(uint64_t readCount, const uint64_t* markersToc, const void* markersData, uint64_t threadCount, double* seconds)
+{
+    try {
+        const auto t0 = std::chrono::steady_clock::now();
+        SortedMarkersCache& c = sortedMarkersCache;
+        if(c.valid) { c.sorted.remove(); c.valid = false; }
+        if(threadCount == 0) threadCount = std::thread::hardware_concurrency();
+        const CompressedMarker* all = static_cast<const CompressedMarker*>(markersData);
+        const uint64_t orientedReadCount = 2 * readCount;
+        c.sorted.createNew("", 4096);
+        c.sorted.beginPass1(orientedReadCount);
+        for(uint64_t i = 0; i < orientedReadCount; i++) c.sorted.incrementCount(i, markersToc[i + 1] - markersToc[i]);
+        c.sorted.beginPass2();
+        c.sorted.endPass2(false);
+        std::atomic<uint64_t> next(0);
+        auto worker = [&]() {
+            for(;;) {
+                const uint64_t begin = next.fetch_add(10000);
+                if(begin >= orientedReadCount) break;
+                for(uint64_t i = begin; i < std::min(orientedReadCount, begin + 10000); i++) {
+                    const span< pair<KmerId, uint32_t> > sm = c.sorted[i];
+                    const CompressedMarker* m = all + markersToc[i];
+                    for(uint32_t ordinal = 0; ordinal < sm.size(); ordinal++) { sm[ordinal].first = m[ordinal].kmerId; sm[ordinal].second = ordinal; }
+                    sort(sm.begin(), sm.end(), OrderPairsByFirstOnly<KmerId, uint32_t>());
+                }
+            }
+        };
+        std::vector<std::thread> threads;
+        for(uint64_t t = 1; t < threadCount; t++) threads.emplace_back(worker);
+        worker();
+        for(auto& t : threads) t.join();
+        c.markersData = markersData; c.markerCount = markersToc[orientedReadCount]; c.readCount = readCount; c.valid = true;
+        if(seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+void ref_drop_sorted_markers()
+{
+    if(sortedMarkersCache.valid) { sortedMarkersCache.sorted.remove(); sortedMarkersCache.valid = false; }
+}
+
+// Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571), the serial last step of computeAlignments, in the
+// reference's own container: every alignment is listed under its two oriented reads and their reverse complements (two
+// passes), then every oriented read's list is ordered by (the other oriented read, alignment index).
+int ref_alignment_table(uint64_t readCount, uint64_t alignmentCount, const shasta_alignment_data* rows, uint64_t* tocOut, uint32_t* valuesOut, double* seconds)
+{
+    try {
+        const auto t0 = std::chrono::steady_clock::now();
+        const AlignmentData* alignmentData = reinterpret_cast<const AlignmentData*>(rows);
+        MemoryMapped::VectorOfVectors<uint32_t, uint32_t> table;
+        table.createNew("", 4096);
+        table.beginPass1(ReadId(2 * readCount));
+        auto fourReads = [&](const AlignmentData& ad, array<OrientedReadId, 4>& r) {
+            r[0] = OrientedReadId(ad.readIds[0], 0);
+            r[1] = OrientedReadId(ad.readIds[1], ad.isSameStrand ? 0 : 1);
+            r[2] = r[0]; r[2].flipStrand();
+            r[3] = r[1]; r[3].flipStrand();
+        };
+        array<OrientedReadId, 4> r;
+        for(uint64_t i = 0; i < alignmentCount; i++) { fourReads(alignmentData[i], r); for(const OrientedReadId& o : r) table.incrementCount(o.getValue()); }
+        table.beginPass2();
+        for(uint32_t i = 0; i < alignmentCount; i++) { fourReads(alignmentData[i], r); for(const OrientedReadId& o : r) table.store(o.getValue(), i); }
+        table.endPass2();
+        vector< pair<OrientedReadId, uint32_t> > v;
+        for(ReadId readId0 = 0; readId0 < readCount; readId0++) {
+            for(Strand strand0 = 0; strand0 < 2; strand0++) {
+                const OrientedReadId orientedReadId0(readId0, strand0);
+                const span<uint32_t> section = table[orientedReadId0.getValue()];
+                v.clear();
+                for(const uint32_t alignmentIndex : section) v.push_back(make_pair(alignmentData[alignmentIndex].getOther(orientedReadId0), alignmentIndex));
+                sort(v.begin(), v.end());
+                for(size_t i = 0; i < v.size(); i++) section[i] = v[i].second;
+            }
+        }
+        if(seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if(tocOut) { tocOut[0] = 0; for(uint64_t i = 0; i < 2 * readCount; i++) tocOut[i + 1] = tocOut[i] + table.size(i); }
+        if(valuesOut && alignmentCount) std::memcpy(valuesOut, table.begin(), 4ULL * alignmentCount * sizeof(uint32_t));
+        table.remove();
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
 static void copyInfo(const AlignmentInfo& info, shasta_alignment_info& out)
 {
     std::memset(&out, 0, sizeof(out));
@@ -550,6 +648,8 @@ int ref_align4_batch_mt(
             try {
                 MemoryMapped::ByteAllocator byteAllocator("", 4096, 2ULL * 1024 * 1024 * 1024);
                 array<vector< pair<KmerId, uint32_t> >, 2> sorted;
+                const SortedMarkersCache& cache = sortedMarkersCache;
+                const bool precomputed = cache.valid && cache.markersData == markersData && cache.readCount == readCount && cache.markerCount == markersToc[2 * readCount];
                 for(;;) {
                     const uint64_t begin = next.fetch_add(10);
                     if(begin >= candidateCount) break;
@@ -565,6 +665,11 @@ int ref_align4_batch_mt(
                         m[1] = span<const CompressedMarker>(all + markersToc[or1.getValue()], all + markersToc[or1.getValue() + 1]);
                         array<span< const pair<KmerId, uint32_t> >, 2> sm;
                         for(int j = 0; j < 2; j++) {
+                            if(precomputed) {
+                                const uint64_t o = (j == 0 ? or0 : or1).getValue();
+                                sm[j] = span< const pair<KmerId, uint32_t> >(cache.sorted.begin(o), cache.sorted.end(o));
+                                continue;
+                            }
                             sortedMarkersOf(m[j], sorted[j]);
                             const pair<KmerId, uint32_t>* b = sorted[j].data();
                             sm[j] = span< const pair<KmerId, uint32_t> >(b, b + sorted[j].size());

@@ -792,6 +792,8 @@ struct AlignStore {
     PinnedBytes bytes;
     std::vector<uint8_t> status;
     std::vector<uint32_t> ordinals;
+    uint64_t lastRowCount = 0;      // alignments stored by the last borrowed call (alignmentTableOfLastCall)
+    bool valid = false;
 };
 
 // Align method 3: what alignOrientedReads3 needs besides the outer filters.
@@ -1663,6 +1665,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         for(std::thread& t : others) t.join();
     }
 
+    if(borrowed) { store.lastRowCount = rowTotal; store.valid = true; }
     result.alignmentCount = rowTotal;
     result.dpCellCount = dpCellsTotal;
     result.kmerIdBytes = kmerIdBytes;
@@ -1671,6 +1674,15 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
 }
 
 }  // namespace
+
+// The AlignmentData rows the context's last borrowed aligner call stored (tables.hip builds the alignment table from them).
+const shasta_alignment_data* borrowedAlignmentRows(Context& ctx, uint64_t* count)
+{
+    AlignStore* store = static_cast<AlignStore*>(ctx.alignStore.get());
+    if(!store || !store->valid) throw std::runtime_error("alignment_table: the context holds no alignments (it follows a *_run_borrowed call).");
+    *count = store->lastRowCount;
+    return store->rows.data();
+}
 
 void align4Run(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
     const shasta_align4_options& options, bool wantOrdinals, shasta_align4_result& result, bool borrowed)

@@ -416,6 +416,15 @@ int shasta_mi355x_pair_table(int device, const void* pairs, uint64_t strideBytes
     API_END(1)
 }
 
+int shasta_mi355x_alignment_table(shasta_mi355x_ctx* c, const uint64_t** toc, const uint32_t** values, uint64_t* valueCount)
+{
+    API_BEGIN
+    if(!c || !toc || !values || !valueCount) throw std::runtime_error("alignment_table: null argument");
+    alignmentTableOfLastCall(c->impl, toc, values, valueCount);
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_read_graph_keep(int device, const shasta_alignment_data* alignmentData, uint64_t alignmentCount, uint64_t readCount,
     uint32_t maxAlignmentCount, uint8_t* keep)
 {

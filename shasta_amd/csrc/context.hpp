@@ -40,6 +40,7 @@ struct Context {
     std::shared_ptr<void> lowhashJob;        // LowHash0 job in progress
     std::shared_ptr<void> lowhashBuffers;    // the last finished job, kept for its device allocations (the next job adopts them)
     uint64_t lowhashRecordsHint = 0, lowhashPairsHint = 0;   // capacities the last jobs needed (first guesses of the next)
+    std::shared_ptr<void> tableStore;        // alignmentTableOfLastCall: its device buffers and the page-locked arrays the caller reads
     std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
     // Kernels that need more dynamic LDS than the default get the attribute once per context, i.e. on this context's device
     // (hipFuncSetAttribute acts on the current device; the aligner's workers may get there at the same time).
@@ -109,6 +110,9 @@ void findMarkersFree(shasta_markers_result&);
 void palindromicScreen(Context&, uint64_t deltaThreshold, uint32_t* bound);
 // tables.hip: the candidate / alignment table and the read graph's selection.
 void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, uint64_t readCount, uint64_t* toc, uint32_t* values);
+// Assembler::computeAlignmentTable for the alignments of the context's last borrowed aligner call; arrays of the context.
+const shasta_alignment_data* borrowedAlignmentRows(Context&, uint64_t* count);
+void alignmentTableOfLastCall(Context&, const uint64_t** toc, const uint32_t** values, uint64_t* valueCount);
 void readGraphKeep(int device, const shasta_alignment_data* alignmentData, uint64_t count, uint64_t readCount, uint32_t maxAlignmentCount, uint8_t* keep);
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);

@@ -13,7 +13,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 namespace shasta_mi355x {
@@ -295,6 +297,69 @@ void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, u
     HIP_CHECK(hipStreamSynchronize(stream));
 
     if(hostBad) throw std::runtime_error("pair_table: a pair names a read beyond readCount.");
+}
+
+// Assembler::computeAlignmentTable (src/AssemblerAlign.cpp:509-571) as the last step of computeAlignments (:296): the table
+// of the alignments the context's last borrowed aligner call stored.  Everything it needs is kept by the context from call
+// to call (nothing is allocated from the second call on): the 12-byte heads of the rows {readId0, readId1, isSameStrand}
+// go up from a page-locked array (a quarter of the bytes of the rows themselves), one stable sort of the 4 N keys on the
+// context's stream, the table comes back into page-locked arrays that the caller reads in place.
+namespace {
+struct TableStore {
+    PinnedBuffer heads, toc, values;
+    DeviceBuffer<uint8_t> deviceHeads;
+    DeviceBuffer<uint64_t> keysA, keysB, deviceToc;
+    DeviceBuffer<uint32_t> valuesA, valuesB, bad;
+};
+}  // namespace
+
+void alignmentTableOfLastCall(Context& ctx, const uint64_t** tocOut, const uint32_t** valuesOut, uint64_t* valueCount)
+{
+    HIP_CHECK(hipSetDevice(ctx.device));
+    uint64_t count = 0;
+    const shasta_alignment_data* rows = borrowedAlignmentRows(ctx, &count);
+    if(count >= (1ULL << 29)) throw std::runtime_error("alignment_table: 2^29 alignments or more (shasta_mi355x_pair_table builds such a table range by range).");
+    if(!ctx.tableStore) ctx.tableStore = std::make_shared<TableStore>();
+    TableStore& t = *static_cast<TableStore*>(ctx.tableStore.get());
+    hipStream_t stream = ctx.stream;
+    const uint64_t tableRows = 2 * ctx.readCount, n = 4 * count;
+    const int otherBits = bitsFor(std::max<uint64_t>(tableRows, 2));
+    uint64_t* toc = static_cast<uint64_t*>(t.toc.reserve((tableRows + 1) * sizeof(uint64_t)));
+    uint32_t* values = static_cast<uint32_t*>(t.values.reserve(std::max<uint64_t>(1, n) * sizeof(uint32_t)));
+    *tocOut = toc; *valuesOut = values; *valueCount = n;
+    if(count == 0) { std::fill(toc, toc + tableRows + 1, uint64_t(0)); return; }
+    constexpr uint64_t stride = sizeof(shasta_oriented_read_pair);
+    uint8_t* heads = static_cast<uint8_t*>(t.heads.reserve(count * stride));
+    {   // (the rows are 64 bytes apart in ordinary memory: a few host threads, each a contiguous share)
+        const uint64_t threads = std::min<uint64_t>(4, std::max<uint64_t>(1, count >> 16));
+        auto share = [&](uint64_t k) {
+            for(uint64_t i = count * k / threads; i < count * (k + 1) / threads; i++) std::memcpy(heads + i * stride, &rows[i].pair, stride);
+        };
+        std::vector<std::thread> others;
+        for(uint64_t k = 1; k < threads; k++) others.emplace_back(share, k);
+        share(0);
+        for(std::thread& o : others) o.join();
+    }
+    t.deviceHeads.reserve(count * stride, stream); t.keysA.reserve(n, stream); t.keysB.reserve(n, stream);
+    t.valuesA.reserve(n, stream); t.valuesB.reserve(n, stream); t.deviceToc.reserve(tableRows + 1, stream); t.bad.reserve(1, stream);
+    const KernelTimers::Span span = ctx.timers.begin("alignment table (keys, sort, row starts)", stream);
+    HIP_CHECK(hipMemcpyAsync(t.deviceHeads.data(), heads, count * stride, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(t.bad.data(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(pairTableKeysKernel, dim3(divUp(count, 256)), dim3(256), 0, stream,
+        (const uint8_t*)t.deviceHeads.data(), stride, count, tableRows, otherBits, t.keysA.data(), t.valuesA.data(), t.bad.data());
+    HIP_CHECK(hipGetLastError());
+    const bool inB = radixSort<uint64_t, uint32_t, true>(t.keysA.data(), t.keysB.data(), t.valuesA.data(), t.valuesB.data(), n, 2 * otherBits, ctx.sortWs, stream);
+    hipLaunchKernelGGL(rowStartsKernel, dim3(divUp(tableRows + 1, 256)), dim3(256), 0, stream,
+        (const uint64_t*)(inB ? t.keysB.data() : t.keysA.data()), n, tableRows, otherBits, t.deviceToc.data());
+    HIP_CHECK(hipGetLastError());
+    // Booked: the heads read, the keys and values written, and one read + write of both per sorting pass.
+    (void)ctx.timers.end(span, count * stride + 12 * n * (1 + 2 * uint64_t((2 * otherBits + 7) / 8)), count);
+    uint32_t hostBad = 0;
+    HIP_CHECK(hipMemcpyAsync(&hostBad, t.bad.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(toc, t.deviceToc.data(), (tableRows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(values, inB ? t.valuesB.data() : t.valuesA.data(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if(hostBad) throw std::runtime_error("alignment_table: an alignment names a read beyond readCount.");
 }
 
 // keep: uint8[count], 1 where the alignment stays in the read graph.

@@ -23,7 +23,7 @@ EXPORTS = [
     "shasta_mi355x_set_markers", "shasta_mi355x_set_kmer_ids",
     "shasta_mi355x_lowhash0_run", "shasta_mi355x_align4_run", "shasta_mi355x_align4_run_borrowed", "shasta_mi355x_kernel_table", "shasta_mi355x_kernel_table_reset",
     "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_banded_dp_many", "shasta_mi355x_calibrate",
-    "shasta_mi355x_pair_table", "shasta_mi355x_read_graph_keep",
+    "shasta_mi355x_pair_table", "shasta_mi355x_read_graph_keep", "shasta_mi355x_alignment_table",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
     "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish", "shasta_mi355x_lh_finish_on_device", "shasta_mi355x_lh_hash_all", "shasta_mi355x_lh_buckets_all", "shasta_mi355x_lh_merge_all",
@@ -507,6 +507,17 @@ class Context:
             C.byref(options), C.c_int(1 if want_ordinals else 0), C.c_int(1 if borrow else 0), C.byref(res)),
             "shasta_mi355x_align3_run")
         return abi.Align4Output(res, len(candidates), want_ordinals, free=self.lib.shasta_mi355x_align4_free)
+
+    def alignment_table(self, copy=True):
+        """Assembler::computeAlignmentTable for the alignments of this context's last borrowed aligner call ->
+        (toc uint64[2 R + 1], values uint32[4 N]); copy=False: views of the context's page-locked arrays, valid until its
+        next aligner or table call."""
+        toc, values, n = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.c_uint64(0)
+        self.library._check(self.lib.shasta_mi355x_alignment_table(C.c_void_p(self.handle), C.byref(toc), C.byref(values), C.byref(n)),
+                            "shasta_mi355x_alignment_table")
+        t = np.ctypeslib.as_array(toc, shape=(2 * self.read_count + 1,))
+        v = np.ctypeslib.as_array(values, shape=(max(1, n.value),))[:n.value]
+        return (t.copy(), v.copy()) if copy else (t, v)
 
     def palindromic_screen(self, delta_threshold):
         """Per read: an upper bound on the near-diagonal marker count of its method-0 self-alignment."""

@@ -63,3 +63,27 @@ def check(lib, seed=5, read_count=211, n=3000):
         lib.pair_table(rows, read_count // 2)
     with pytest.raises(RuntimeError, match="beyond readCount"):
         lib.read_graph_keep(rows, read_count // 2, 6)
+
+
+def table_of_the_last_aligner_call(lib, oracle_lib, n_reads=150, limit=700):
+    """shasta_mi355x_alignment_table: the last step of computeAlignments on the context that holds the alignments -- equal to
+    the restatement of computeAlignmentTable on the rows the call returned, for both aligners, and refused without a call."""
+    import pytest
+    from tests import support
+    toc, kmer, data7 = support.small_marker_set(n_reads=n_reads, genome_markers=12000, seed=77)
+    cand = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=1)).candidates[:limit]
+    stored = 0
+    with lib.context(0) as ctx:
+        ctx.set_kmer_ids(toc, kmer)
+        with pytest.raises(RuntimeError, match="holds no alignments"):
+            ctx.alignment_table()
+        for run, options in ((ctx.align4, abi.default_align4_options(minAlignedMarkerCount=40)), (ctx.align3, abi.default_align3_options(minAlignedMarkerCount=40)),
+                             (ctx.align4, abi.default_align4_options(minAlignedMarkerCount=100000))):
+            out = run(cand, options, borrow=True)
+            rows = np.array(out.alignment_data, copy=True)
+            table_toc, table_values = ctx.alignment_table()
+            expected_toc, expected_values = host_support.alignment_table_expected(n_reads, rows)
+            assert np.array_equal(table_toc, expected_toc.astype(np.uint64)) and np.array_equal(table_values, expected_values)
+            stored += len(rows)
+            del out
+    return stored

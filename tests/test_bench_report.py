@@ -42,6 +42,9 @@ class FakeContext:
     def align4(self, candidates, o, want_ordinals=False, borrow=False):
         return FakeResult(len(candidates))
 
+    def alignment_table(self, copy=True):
+        return np.zeros(21, np.uint64), np.zeros(0, np.uint32)
+
     def kernel_table(self):
         return FAKE_TABLE
 
@@ -87,6 +90,7 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert "computeAlignmentTable" in d["config"]["step"] and d["stage_seconds_per_step"]["alignment_table_call"] >= 0.0
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
@@ -123,6 +127,11 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert set(["value", "unit", "cores", "kind", "sample"]) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["value"] > 0
     parity = line["parity_at_bench_size"]
     assert parity["lowhash0_equal"] is True and parity["aligner_mismatches"] == 0 and parity["aligner_tie_flags_equal"] is True
+    # The step is computeAlignments end to end: the alignment table is in it, equal to the reference container's; the CPU leg
+    # times computeSortedMarkers and computeAlignmentTable as well.
+    assert parity["alignment_table_equal"] is True and "computeAlignmentTable" in line["config"]["step"]
+    assert line["cpu_baseline"]["sorted_markers_seconds"] > 0 and line["cpu_baseline"]["alignment_table_seconds"] > 0
+    assert any(k.startswith("alignment table") for k in line["kernels"])
     assert any(k.startswith("align4CellsChunkKernel") for k in line["kernels"]) and any(k.startswith("dpTracebackKernel") for k in line["kernels"])
     assert line["config"]["candidates"] > 0 and "workload" in line["config"]
     census = line["dp_tie_sensitive"]             # the checker under the 11 other DP tie policies

@@ -132,9 +132,10 @@ def test_borrowed_results_and_calls_of_several_batches(emu_lib, oracle_lib):
     assert out.returncode == 0 and "equal owned results" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_candidate_and_alignment_tables_and_read_graph_selection(emu_lib):
+def test_candidate_and_alignment_tables_and_read_graph_selection(emu_lib, oracle_lib):
     from tests import table_checks
     table_checks.check(emu_lib)
+    assert table_checks.table_of_the_last_aligner_call(emu_lib, oracle_lib, n_reads=90, limit=250) > 100
 
 
 def test_align3_long_reads(emu_lib, oracle_lib):

@@ -80,7 +80,8 @@ def test_stage_executable_reports_errors_like_the_reference(tmp_path):
     assert out.returncode == 1 and "Error accessing" in out.stdout
 
 
-def test_candidate_and_alignment_tables_and_read_graph_selection_on_the_device(gpu_lib):
+def test_candidate_and_alignment_tables_and_read_graph_selection_on_the_device(gpu_lib, oracle_lib):
     # shasta_mi355x_pair_table / _read_graph_keep against the python restatements of the reference's loops.
     from tests import table_checks
     table_checks.check(gpu_lib, seed=6, read_count=5003, n=200000)
+    assert table_checks.table_of_the_last_aligner_call(gpu_lib, oracle_lib) > 300

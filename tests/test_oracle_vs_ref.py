@@ -109,3 +109,27 @@ def test_reference_at_2_to_the_31_buckets_reproduces_the_committed_digest(ref_li
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "log2_31_digests.json")) as f:
         golden = json.load(f)["cases"][name]
     assert made.run(ref_lib, name) == golden
+
+
+def test_sorted_markers_once_per_run_and_the_alignment_table(ref_lib, oracle_lib):
+    # bench.py's CPU leg: computeSortedMarkers once for all reads (as the reference's computeAlignments does) instead of a sort
+    # per candidate -- the same alignments -- and computeAlignmentTable in the reference's container against its restatement.
+    import numpy as np
+    from shasta_amd import abi
+    from tests import host_support, support
+    toc, kmer, data7 = support.small_marker_set(n_reads=120, genome_markers=9000, seed=88)
+    data7 = np.ascontiguousarray(data7, dtype=np.uint8)
+    cand = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=1)).candidates[:500]
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    a = ref_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=2)
+    assert ref_lib.compute_sorted_markers(toc, data7, threads=2) > 0.0
+    try:
+        b = ref_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=2)
+    finally:
+        ref_lib.drop_sorted_markers()
+    support.same_align(a, b)
+    rows = np.array(a.alignment_data, copy=True)
+    assert len(rows) > 100
+    table_toc, table_values, seconds = ref_lib.alignment_table(rows, 120)
+    expected_toc, expected_values = host_support.alignment_table_expected(120, rows)
+    assert np.array_equal(table_toc, expected_toc.astype(np.uint64)) and np.array_equal(table_values, expected_values)
