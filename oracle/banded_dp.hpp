@@ -48,6 +48,7 @@
 #define ORACLE_BANDED_DP_HPP
 
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <utility>
 #include <vector>
@@ -68,7 +69,6 @@ struct TiePolicy {
 // The policy in force in this process (each shared library that includes this header has its own copy and its own
 // setter: oracle_set_tie_policy / ref_set_tie_policy).  Default-constructed = the reading above.  The tie census of
 // bench.py and tests/test_tie_census.py run the aligner under every other policy to count what depends on the reading.
-inline TiePolicy& activeTiePolicy() { static TiePolicy policy; return policy; }
 // Policies by number: index = 2 * order + (lastMaximumWins ? 1 : 0), order over the six priority orders of
 // (diagonal, vertical, horizontal): 0 DVH (the reading), 1 DHV, 2 VDH, 3 VHD, 4 HDV, 5 HVD.
 inline TiePolicy tiePolicyByIndex(int index)
@@ -79,6 +79,13 @@ inline TiePolicy tiePolicyByIndex(int index)
     p.diagonalRank = ranks[order][0]; p.verticalRank = ranks[order][1]; p.horizontalRank = ranks[order][2];
     p.firstMaximumWins = (index & 1) == 0;
     return p;
+}
+// (ORACLE_TIE_POLICY=<n> in the environment: the policy a process starts with -- tests/test_seqan_pin_kit.py runs the pin kit's
+// program against the SeqAn stand-in under several policies that way.)
+inline TiePolicy& activeTiePolicy()
+{
+    static TiePolicy policy = [] { const char* e = std::getenv("ORACLE_TIE_POLICY"); return (e && *e) ? tiePolicyByIndex(std::atoi(e)) : TiePolicy(); }();
+    return policy;
 }
 
 enum TraceOp : uint8_t { TRACE_NONE = 0, TRACE_DIAG = 1, TRACE_VERT = 2, TRACE_HORI = 3 };

@@ -250,9 +250,9 @@ int dpTiePolicyOfCall()
     const char* e = std::getenv("SHASTA_MI355X_DP_TIE_POLICY");
     if(!e || !*e) return DP_TIE_POLICY;
     const int v = std::atoi(e);
-    if(v != DP_TIE_POLICY && v != DP_TIE_ALTERNATIVE)
+    if(!dpTieCompiled(v))
         throw std::runtime_error("SHASTA_MI355X_DP_TIE_POLICY=" + std::string(e) + ": this build holds the tie policies " + std::to_string(DP_TIE_POLICY) +
-            " (default) and " + std::to_string(DP_TIE_ALTERNATIVE) + " (rebuild with -DSHASTA_DP_TIE_POLICY=<n> for another).");
+            " (default), " + std::to_string(DP_TIE_ALTERNATIVE_A) + " and " + std::to_string(DP_TIE_ALTERNATIVE_B) + " (rebuild with -DSHASTA_DP_TIE_POLICY=<n> for another).");
     return v;
 }
 
@@ -274,8 +274,7 @@ void launchDpForward(const DpInput& in, hipStream_t stream, BatchScratch& b, con
         if(in.tie != DP_TIE_POLICY) throw std::runtime_error("align method 3 with scores other than 6 / -1 / -1 is compiled for the default DP tie policy only.");
         launch(&bandedDpForwardKernel<G, C, DP_TIE_POLICY, true>);
     }
-    else if(in.tie == DP_TIE_POLICY) launch(&bandedDpForwardKernel<G, C, DP_TIE_POLICY>);
-    else launch(&bandedDpForwardKernel<G, C, DP_TIE_ALTERNATIVE>);
+    else withDpTie(in.tie, [&](auto tag) { launch(&bandedDpForwardKernel<G, C, decltype(tag)::value>); });
 }
 
 // K10 for the taskCount tasks in b.tasks (pairs in b.pairs): fills b.results, b.ordScratch and
@@ -640,21 +639,19 @@ void runWideTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, const DpI
             HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), list.data(), count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(b.wideOrdBases.data(), bases.data(), count * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
             std::call_once(ctx.wideDpLdsAttribute, [] {
-                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_POLICY>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
-                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_ALTERNATIVE>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
+                for(const int tie : {DP_TIE_POLICY, DP_TIE_ALTERNATIVE_A, DP_TIE_ALTERNATIVE_B}) withDpTie(tie, [](auto tag) {
+                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, decltype(tag)::value>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t)))); });
             });
-            const bool alternativeTie = in.tie != DP_TIE_POLICY;
             if(pass == 1) {
                 b.hugeRows.reserve(size_t(count) * 3u * rowWords, stream);
-                const auto kernel = alternativeTie ? &align3WideDpKernel<true, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<true, DP_TIE_POLICY>;
-                hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, stream,
-                    in.kmerIds, in.pairs, (const WideTask*)b.wideTasks.data(), count, rowWords, b.wideTrace.data(), b.wideEnds.data(), b.hugeRows.data(), in.scores);
+                withDpTie(in.tie, [&](auto tag) {
+                    hipLaunchKernelGGL((align3WideDpKernel<true, decltype(tag)::value>), dim3(count), dim3(256), 0, stream,
+                        in.kmerIds, in.pairs, (const WideTask*)b.wideTasks.data(), count, rowWords, b.wideTrace.data(), b.wideEnds.data(), b.hugeRows.data(), in.scores); });
             } else {
-                const auto kernel = alternativeTie ? &align3WideDpKernel<false, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<false, DP_TIE_POLICY>;
-                hipLaunchKernelGGL(kernel, dim3(count), dim3(64), 3 * size_t(rowWords) * sizeof(int32_t), stream,
-                    in.kmerIds, in.pairs, (const WideTask*)b.wideTasks.data(), count, rowWords, b.wideTrace.data(), b.wideEnds.data(), (int32_t*)nullptr, in.scores);
+                withDpTie(in.tie, [&](auto tag) {
+                    hipLaunchKernelGGL((align3WideDpKernel<false, decltype(tag)::value>), dim3(count), dim3(64), 3 * size_t(rowWords) * sizeof(int32_t), stream,
+                        in.kmerIds, in.pairs, (const WideTask*)b.wideTasks.data(), count, rowWords, b.wideTrace.data(), b.wideEnds.data(), (int32_t*)nullptr, in.scores); });
             }
             HIP_CHECK(hipGetLastError());
             // The tasks of this launch are not consecutive in `wide` when the two passes interleave: one traceback launch per task
@@ -1056,23 +1053,21 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 HIP_CHECK(hipMemcpyAsync(b.wideTasks.data(), wide.data() + begin, count * sizeof(WideTask), hipMemcpyHostToDevice, stream));
                 const size_t ldsBytes = 3 * size_t(rowWords) * sizeof(int32_t);
                 std::call_once(ctx.wideDpLdsAttribute, [] {
-                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_POLICY>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
-                    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, DP_TIE_ALTERNATIVE>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t))));
+                    for(const int tie : {DP_TIE_POLICY, DP_TIE_ALTERNATIVE_A, DP_TIE_ALTERNATIVE_B}) withDpTie(tie, [](auto tag) {
+                        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align3WideDpKernel<false, decltype(tag)::value>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * ALIGN3_WIDE_MAX_DIAGONALS * sizeof(int32_t)))); });
                 });
-                const bool alternativeTie = dpTiePolicyOfCall() != DP_TIE_POLICY;
                 if(hugeRows) {
                     b.hugeRows.reserve(size_t(count) * 3u * rowWords, stream);
-                    const auto kernel = alternativeTie ? &align3WideDpKernel<true, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<true, DP_TIE_POLICY>;
-                    hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, stream,
-                        (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
-                        b.trace.data(), b.wideEnds.data(), b.hugeRows.data(), m3->scores);
+                    withDpTie(dpTiePolicyOfCall(), [&](auto tag) {
+                        hipLaunchKernelGGL((align3WideDpKernel<true, decltype(tag)::value>), dim3(count), dim3(256), 0, stream,
+                            (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
+                            b.trace.data(), b.wideEnds.data(), b.hugeRows.data(), m3->scores); });
                 } else {
-                    const auto kernel = alternativeTie ? &align3WideDpKernel<false, DP_TIE_ALTERNATIVE> : &align3WideDpKernel<false, DP_TIE_POLICY>;
-                    hipLaunchKernelGGL(kernel, dim3(count), dim3(64), ldsBytes, stream,
-                        (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
-                        b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr, m3->scores);
+                    withDpTie(dpTiePolicyOfCall(), [&](auto tag) {
+                        hipLaunchKernelGGL((align3WideDpKernel<false, decltype(tag)::value>), dim3(count), dim3(64), ldsBytes, stream,
+                            (const uint32_t*)ds->kmerIds.data(), (const PairDesc*)b.dsPairs.data(), (const WideTask*)b.wideTasks.data(), count, rowWords,
+                            b.trace.data(), b.wideEnds.data(), (int32_t*)nullptr, m3->scores); });
                 }
                 HIP_CHECK(hipGetLastError());
                 hipLaunchKernelGGL(align3BandKernel<true>, dim3(divUp(count, 256)), dim3(256), 0, stream,

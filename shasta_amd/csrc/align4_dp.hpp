@@ -159,17 +159,35 @@ dpBundleKernel(const uint32_t* __restrict__ sortedKeys, const uint32_t* __restri
 // vertical, horizontal): 0 DVH, 1 DHV, 2 VDH, 3 VHD, 4 HDV, 5 HVD.  TIE = 0 is the reading of SeqAn 2.4.0 that the oracle
 // restates (dp_formula_linear.h: the diagonal candidate first, replaced by the vertical and then by the horizontal one only on
 // a strictly larger score; dp_scout.h: a later border cell replaces the best only if strictly greater, cells visited
-// column by column).  If a SeqAn run ever disagrees, DP_TIE_POLICY is the line to change; DP_TIE_ALTERNATIVE is compiled
-// beside it and parity-tested against the oracle under the same policy (tests/test_gpu_tie_policy.py) so that the switch is
-// known to work: SHASTA_MI355X_DP_TIE_POLICY=<n> selects it at run time, any other value is an error.
+// column by column).  If a SeqAn run ever disagrees (oracle/seqan_pin), SHASTA_DP_TIE_POLICY is the line to change; two
+// alternatives are compiled beside it and parity-tested against the oracle under the same policy (tests/test_gpu_tie_policy.py)
+// so that the switch is known to work: SHASTA_MI355X_DP_TIE_POLICY=<n> selects one at run time, any other value is an error.
 #ifndef SHASTA_DP_TIE_POLICY
 #define SHASTA_DP_TIE_POLICY 0
 #endif
-#ifndef SHASTA_DP_TIE_ALTERNATIVE
-#define SHASTA_DP_TIE_ALTERNATIVE 3          // D >= H >= V, last maximum
-#endif
-constexpr int DP_TIE_POLICY = SHASTA_DP_TIE_POLICY, DP_TIE_ALTERNATIVE = SHASTA_DP_TIE_ALTERNATIVE;
-static_assert(DP_TIE_POLICY >= 0 && DP_TIE_POLICY < 12 && DP_TIE_ALTERNATIVE >= 0 && DP_TIE_ALTERNATIVE < 12 && DP_TIE_POLICY != DP_TIE_ALTERNATIVE, "tie policies");
+// Compiled beside it, parity-tested against the oracle under the same policy and selected at run time by
+// SHASTA_MI355X_DP_TIE_POLICY=<n>: the nearest other readings -- 2 = diagonal >= horizontal >= vertical, first maximum (the
+// other way to read `_maxScore(left, right)`), 3 = the same with the last maximum (exercises the other end-cell scan) -- and
+// the shipped reading 0 when the build's policy is another (oracle/seqan_pin says which one a SeqAn run follows).
+constexpr int DP_TIE_POLICY = SHASTA_DP_TIE_POLICY;
+constexpr int dpTieAlternative(int k)
+{
+    const int candidates[3] = {0, 2, 3};
+    for(int c = 0; c < 3; c++) { if(candidates[c] == DP_TIE_POLICY) continue; if(k-- == 0) return candidates[c]; }
+    return -1;
+}
+constexpr int DP_TIE_ALTERNATIVE_A = dpTieAlternative(0), DP_TIE_ALTERNATIVE_B = dpTieAlternative(1);
+static_assert(DP_TIE_POLICY >= 0 && DP_TIE_POLICY < 12 && DP_TIE_ALTERNATIVE_A >= 0 && DP_TIE_ALTERNATIVE_B >= 0, "tie policies");
+inline bool dpTieCompiled(int tie) { return tie == DP_TIE_POLICY || tie == DP_TIE_ALTERNATIVE_A || tie == DP_TIE_ALTERNATIVE_B; }
+template<int V> struct DpTieTag { static constexpr int value = V; };
+// f(DpTieTag<TIE>) for the compiled policy `tie`.
+template<class F> inline void withDpTie(int tie, F&& f)
+{
+    if(tie == DP_TIE_POLICY) f(DpTieTag<DP_TIE_POLICY>{});
+    else if(tie == DP_TIE_ALTERNATIVE_A) f(DpTieTag<DP_TIE_ALTERNATIVE_A>{});
+    else if(tie == DP_TIE_ALTERNATIVE_B) f(DpTieTag<DP_TIE_ALTERNATIVE_B>{});
+    else throw std::runtime_error("DP tie policy " + std::to_string(tie) + " is not compiled into this build.");
+}
 template<int TIE> struct DpTie {
     enum Move { DIAGONAL = 0, VERTICAL = 1, HORIZONTAL = 2 };
     static constexpr int order = TIE / 2;

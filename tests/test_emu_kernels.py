@@ -47,9 +47,10 @@ def test_banded_dp(emu_lib, oracle_lib, width):
 
 def test_dp_tie_policy_switch(emu_lib, oracle_lib):
     from tests import tie_policy_checks
-    tasks, bad_default, bad_alternative, differ = tie_policy_checks.dp_tasks_under_the_alternative_policy(emu_lib, oracle_lib)
-    assert tasks >= 50 and bad_default == 0 and bad_alternative == 0 and differ >= 10
-    candidates, differ = tie_policy_checks.aligner_under_the_alternative_policy(emu_lib, oracle_lib, reads=80, candidates=120)
+    for alternative in tie_policy_checks.ALTERNATIVES:
+        tasks, bad_default, bad_alternative, differ = tie_policy_checks.dp_tasks_under_the_alternative_policy(emu_lib, oracle_lib, alternative=alternative)
+        assert tasks >= 50 and bad_default == 0 and bad_alternative == 0 and differ >= 10
+    candidates, differ = tie_policy_checks.aligner_under_the_alternative_policy(emu_lib, oracle_lib, reads=80, candidates=120, alternative=2)
     assert candidates >= 100
     assert tie_policy_checks.unknown_policy_is_refused(emu_lib)
 

@@ -1,5 +1,6 @@
-"""The DP tie policy as a switch (shasta_amd/csrc/align4_dp.hpp, DpTie): the library under its compiled alternative policy
-(SHASTA_MI355X_DP_TIE_POLICY=3: diagonal >= horizontal >= vertical, last maximum) against the oracle set to the same policy
+"""The DP tie policy as a switch (shasta_amd/csrc/align4_dp.hpp, DpTie): the library under each of its two compiled alternative
+policies (SHASTA_MI355X_DP_TIE_POLICY=2: diagonal >= horizontal >= vertical, first maximum -- the nearest other reading of SeqAn's
+_maxScore(left, right) -- and 3: the same with the last maximum) against the oracle set to the same policy
 (oracle/banded_dp.hpp, tiePolicyByIndex) -- on tie-heavy DP tasks of every band class and on the whole aligner -- and the
 proof that the two policies really differ on those inputs.  Test infrastructure: the oracle is the checker."""
 import os
@@ -9,7 +10,7 @@ import numpy as np
 from shasta_amd import abi
 from tests import dp_geometry_checks, support
 
-ALTERNATIVE = 3
+ALTERNATIVES = (2, 3)
 
 
 class policy:
@@ -58,7 +59,7 @@ def tie_heavy_tasks(seed, tasks=60):
     return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
 
 
-def dp_tasks_under_the_alternative_policy(lib, orc, seed=21):
+def dp_tasks_under_the_alternative_policy(lib, orc, seed=21, alternative=2):
     kmer, spec = tie_heavy_tasks(seed)
 
     def oracle_results():
@@ -66,7 +67,7 @@ def dp_tasks_under_the_alternative_policy(lib, orc, seed=21):
 
     base = oracle_results()
     got0 = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5])
-    with policy(orc, ALTERNATIVE):
+    with policy(orc, alternative):
         want = oracle_results()
         got = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5])
     bad = sum(1 for (x, sx), (y, sy) in zip(want, got) if not (sx == sy and np.array_equal(x, y)))
@@ -76,13 +77,13 @@ def dp_tasks_under_the_alternative_policy(lib, orc, seed=21):
     return len(spec), bad0, bad, differ
 
 
-def aligner_under_the_alternative_policy(lib, orc, reads=120, candidates=300):
+def aligner_under_the_alternative_policy(lib, orc, reads=120, candidates=300, alternative=2):
     toc, kmer, data7 = support.small_marker_set(n_reads=reads, genome_markers=9000, seed=31)
     p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=1)
     cand = orc.lowhash0(toc, data7, None, p).candidates[:candidates]
     o = abi.default_align4_options(minAlignedMarkerCount=40)
     base = orc.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
-    with policy(orc, ALTERNATIVE):
+    with policy(orc, alternative):
         want = orc.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
         got = lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
     support.same_align(want, got)
