@@ -419,6 +419,31 @@ class OracleLib(_Base):
             C.byref(count), C.byref(score)), "oracle_banded_dp")
         return out[:count.value].copy(), score.value
 
+    def sparse_dp(self, k0, k1, band_min, band_max, scan_budget=64):
+        """The same task from its matches (oracle/sparse_chain.hpp) -> (ordinals [n, 2], dict(certified, score, hits, scan_steps, reason))."""
+        k0 = np.ascontiguousarray(k0, dtype=np.uint32)
+        k1 = np.ascontiguousarray(k1, dtype=np.uint32)
+        cap = min(len(k0), len(k1)) + 1
+        out = np.zeros(2 * cap, dtype=np.uint32)
+        count = C.c_uint64()
+        info = np.zeros(5, dtype=np.int64)
+        self._check(self.lib.oracle_sparse_dp(abi.as_ptr(k0, C.c_uint32), C.c_uint32(len(k0)), abi.as_ptr(k1, C.c_uint32), C.c_uint32(len(k1)),
+                                              C.c_int32(band_min), C.c_int32(band_max), C.c_uint32(scan_budget), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
+                                              C.byref(count), abi.as_ptr(info, C.c_int64)), "oracle_sparse_dp")
+        return out[:2 * count.value].reshape(-1, 2).copy(), dict(zip(("certified", "score", "hits", "scan_steps", "reason"), (int(v) for v in info)))
+
+    def sparse_census(self, on=None, reset=False):
+        """Bookkeeping of the sparse path's prototype over the DP tasks align4_batch runs (oracle.cpp: oracle_sparse_census_read)."""
+        if reset:
+            self.lib.oracle_sparse_census_reset()
+        if on is not None:
+            self.lib.oracle_sparse_census(C.c_int(1 if on else 0))
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.oracle_sparse_census_read(abi.as_ptr(out, C.c_uint64))
+        names = ("tasks", "certified", "certified_but_different", "dense_cells", "hits", "scan_steps", "reason_certified", "reason_several_chains",
+                 "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs")
+        return dict(zip(names, (int(v) for v in out)))
+
     def compress(self, ordinals):
         o = np.ascontiguousarray(ordinals, dtype=np.uint32).reshape(-1, 2)
         p = C.POINTER(C.c_uint8)()

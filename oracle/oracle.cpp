@@ -385,6 +385,30 @@ int oracle_banded_dp(
     } catch(std::exception& e) { lastError = e.what(); return 1; }
 }
 
+// The same task from its matches (oracle/sparse_chain.hpp).  out[0] certified, [1] score, [2] hits, [3] scan steps, [4] reason.
+int oracle_sparse_dp(
+    const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax, uint32_t scanBudgetPerHit,
+    uint32_t* ordinals, uint64_t capacity, uint64_t* count, int64_t* out)
+{
+    try {
+        SparseChainResult r;
+        sparseChainAlignment(k0, nx, k1, ny, bandMin, bandMax, r, scanBudgetPerHit);
+        if(r.ordinals.size() > capacity) throw std::runtime_error("oracle_sparse_dp: capacity");
+        for(size_t i = 0; i < r.ordinals.size(); i++) { ordinals[2*i] = r.ordinals[i].first; ordinals[2*i+1] = r.ordinals[i].second; }
+        *count = r.ordinals.size();
+        out[0] = r.certified ? 1 : 0; out[1] = r.score; out[2] = int64_t(r.hits); out[3] = int64_t(r.scanSteps); out[4] = r.reason;
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
+// What the sparse path would have done on every DP task the restated Align4 ran since the last reset (oracle_sparse_census(1)
+// switches the bookkeeping on, (0) off): [0] tasks, [1] certified, [2] certified and DIFFERENT from the dense DP under the policy
+// in force (must stay 0), [3] dense cells nx x width, [4] hits, [5] scan steps, [6..9] tasks by reason 0..3,
+// [10] dense cells of the certified tasks, [11] aligned pairs.
+void oracle_sparse_census(int on) { sparseCensus().on = on != 0; }
+void oracle_sparse_census_reset() { for(auto& c : sparseCensus().counters) c.store(0); }
+void oracle_sparse_census_read(uint64_t* out) { for(int i = 0; i < SparseCensus::N; i++) out[i] = sparseCensus().counters[i].load(); }
+
 int oracle_compress(const uint32_t* ordinals, uint64_t n, uint8_t** bytes, uint64_t* byteCount)
 {
     Ordinals ord(n);
