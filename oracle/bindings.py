@@ -432,16 +432,18 @@ class OracleLib(_Base):
                                               C.byref(count), abi.as_ptr(info, C.c_int64)), "oracle_sparse_dp")
         return out[:2 * count.value].reshape(-1, 2).copy(), dict(zip(("certified", "score", "hits", "scan_steps", "reason"), (int(v) for v in info)))
 
-    def sparse_census(self, on=None, reset=False):
+    def sparse_census(self, on=None, reset=False, scan_budget=None, one_hit_per_marker=False, running_max_bound=False):
         """Bookkeeping of the sparse path's prototype over the DP tasks align4_batch runs (oracle.cpp: oracle_sparse_census_read)."""
+        if scan_budget is not None:
+            self.lib.oracle_sparse_census_options(C.c_uint32(scan_budget), C.c_int(1 if one_hit_per_marker else 0), C.c_int(1 if running_max_bound else 0))
         if reset:
             self.lib.oracle_sparse_census_reset()
         if on is not None:
             self.lib.oracle_sparse_census(C.c_int(1 if on else 0))
-        out = np.zeros(12, dtype=np.uint64)
+        out = np.zeros(13, dtype=np.uint64)
         self.lib.oracle_sparse_census_read(abi.as_ptr(out, C.c_uint64))
         names = ("tasks", "certified", "certified_but_different", "dense_cells", "hits", "scan_steps", "reason_certified", "reason_several_chains",
-                 "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs")
+                 "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs", "reason_two_hits_of_one_marker")
         return dict(zip(names, (int(v) for v in out)))
 
     def compress(self, ordinals):

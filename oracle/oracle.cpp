@@ -404,8 +404,12 @@ int oracle_sparse_dp(
 // What the sparse path would have done on every DP task the restated Align4 ran since the last reset (oracle_sparse_census(1)
 // switches the bookkeeping on, (0) off): [0] tasks, [1] certified, [2] certified and DIFFERENT from the dense DP under the policy
 // in force (must stay 0), [3] dense cells nx x width, [4] hits, [5] scan steps, [6..9] tasks by reason 0..3,
-// [10] dense cells of the certified tasks, [11] aligned pairs.
+// [10] dense cells of the certified tasks, [11] aligned pairs, [12] tasks by reason 4.
 void oracle_sparse_census(int on) { sparseCensus().on = on != 0; }
+void oracle_sparse_census_options(uint32_t scanBudget, int oneHitPerMarker, int runningMaxBound)
+{
+    sparseCensus().scanBudget = scanBudget; sparseCensus().oneHitPerMarker = oneHitPerMarker != 0; sparseCensus().runningMaxBound = runningMaxBound != 0;
+}
 void oracle_sparse_census_reset() { for(auto& c : sparseCensus().counters) c.store(0); }
 void oracle_sparse_census_read(uint64_t* out) { for(int i = 0; i < SparseCensus::N; i++) out[i] = sparseCensus().counters[i].load(); }
 

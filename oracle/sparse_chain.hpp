@@ -41,7 +41,7 @@ struct SparseChainResult {
     int32_t score = std::numeric_limits<int32_t>::min();
     std::vector< std::pair<uint32_t, uint32_t> > ordinals;     // the chain, ascending
     uint64_t hits = 0, scanSteps = 0;
-    int reason = 0;                    // 0 certified, 1 several optimal chains, 2 a chain ties with the empty alignment, 3 scan budget
+    int reason = 0;                    // 0 certified, 1 several optimal chains, 2 a chain ties with the empty alignment, 3 scan budget, 4 two hits of one marker
 };
 
 // The best score of a path without any match: the largest -min(i, j) over the border cells (i = nx or j = ny) inside the band.
@@ -63,7 +63,7 @@ inline int32_t bestMatchlessScore(uint32_t nx, uint32_t ny, int32_t bandMin, int
 
 template<class T>
 inline void sparseChainAlignment(const T* seq0, uint32_t nx, const T* seq1, uint32_t ny, int32_t bandMin, int32_t bandMax,
-    SparseChainResult& r, uint32_t scanBudgetPerHit = 64)
+    SparseChainResult& r, uint32_t scanBudgetPerHit = 64, bool oneHitPerMarker = false, bool runningMaxBound = false)
 {
     r = SparseChainResult();
     if(bandMin > bandMax || bandMin > int32_t(nx) || bandMax < -int32_t(ny)) return;       // (the dense DP fails there as well: not a task)
@@ -84,6 +84,9 @@ inline void sparseChainAlignment(const T* seq0, uint32_t nx, const T* seq1, uint
     }
     const size_t n = hits.size();
     r.hits = n;
+    // (The device ranks a task's hits by their ordinal in one of the two reads with a bit per marker: two hits of one marker of
+    // that read inside the band send the task to the dense DP.  oneHitPerMarker restates that, for read 0.)
+    if(oneHitPerMarker) for(size_t k = 1; k < n; k++) if(hits[k].x == hits[k - 1].x) { r.reason = 4; return; }
     std::vector<int32_t> D(n), prefixMax(n);
     std::vector<int32_t> pred(n);
     std::vector<uint8_t> ways(n);          // optimal chains ending here, capped at 2
@@ -100,7 +103,9 @@ inline void sparseChainAlignment(const T* seq0, uint32_t nx, const T* seq1, uint
         uint32_t steps = 0;
         for(int64_t q = int64_t(k) - 1; q >= 0; q--) {
             const int32_t xq = int32_t(hits[size_t(q)].x), yq = int32_t(hits[size_t(q)].y);
-            if(prefixMax[size_t(q)] - (x - xq - 1) < value) break;
+            // (runningMaxBound: the device's form of the bound -- the largest D of ALL hits before m, which it has in a register,
+            // in place of the prefix maximum up to q, which it would have to keep per hit: weaker, never wrong.)
+            if((runningMaxBound ? prefixMax[k - 1] : prefixMax[size_t(q)]) - (x - xq - 1) < value) break;
             if(++steps > scanBudgetPerHit) { overBudget = true; break; }
             if(xq >= x || yq >= y) continue;
             const int32_t candidate = D[size_t(q)] - std::max(x - xq - 1, y - yq - 1);

@@ -26,6 +26,7 @@
 #include "context.hpp"
 
 #include <algorithm>
+#include <numeric>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -69,6 +70,7 @@ struct DeviceOptions {
 
 #include "align4_cells.hpp"      // K8/K9
 #include "align4_dp.hpp"         // K10
+#include "align4_sparse.hpp"     // K10s: the same alignment from the matches inside the band, where it is unique
 #include "align4_finish.hpp"     // K11
 #include "align3.hpp"
 
@@ -136,6 +138,9 @@ struct BatchScratch {
     DeviceBuffer<int32_t> hugeRows;             //                         the three anti-diagonals of the pairs with more than 8192 diagonals
     DeviceBuffer<WideEnd> wideEnds;
     DeviceBuffer<uint64_t> wideTrace, wideOrdBases;   // Align4 components of more than 1024 diagonals (runWideTasks)
+    DeviceBuffer<uint32_t> hits, hitMeta, sparseSorted, sparseInBand, denseFlags, densePositions;     // align4_sparse.hpp: the candidates' match lists, the tasks' ordered hits
+    DeviceBuffer<uint64_t> hitBase;
+    DeviceBuffer<uint8_t> sparseState;
     DeviceBuffer<uint64_t> prepareKeysA, prepareKeysB;      // a batch's first chunk lists made on the device (align4_prepare.hpp)
     DeviceBuffer<uint32_t> prepareIdsA, prepareIdsB;
     DeviceBuffer<unsigned long long> prepareInfo;
@@ -211,7 +216,7 @@ constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (
 constexpr int CELLS_WAVES = SHASTA_CELLS_WAVES;
 template<int Q>
 void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
-    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists)
 {
     // (Fewer workgroups per CU -- 3 instead of 4, by padding the LDS request -- so that other workers' kernels find registers on
     // the same CU: 57 -> 66 ms solo and 214 -> 225 ms per step, scripts/gpu_r02_call29.sh.)
@@ -227,16 +232,16 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
     SHASTA_TIMED(ctx, name, ws.stream, kmerIdBytes, candidateCount,
         hipLaunchKernelGGL((align4CellsChunkKernel<Q>), dim3(count), dim3(WAVE * CELLS_WAVES), bytes, ws.stream,
             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
-            opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(), (uint32_t*)nullptr, (uint32_t*)nullptr));
+            opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(), (uint32_t*)nullptr, (uint32_t*)nullptr, hitLists));
     HIP_CHECK(hipGetLastError());
 }
 
 void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
-    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount)
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists)
 {
     if(count == 0) return;
-    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
-    else launchCellsChunksQ<4>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount);
+    if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists);
+    else launchCellsChunksQ<4>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists);
 }
 
 // What a DP runs on: the kmer-id array its pairs index, the pairs, the tasks.
@@ -294,7 +299,8 @@ const char* const DP_FORWARD_NAMES[DP_CLASSES] = {"bandedDpForwardKernel<16, 2, 
 // Forward half of K10 for taskCount tasks: sort by (band class, iterations), bundle, lay out the
 // trace, run the forward kernel of every class.  Leaves b.trace / b.ends for a traceback kernel.
 struct DpForwardState {
-    const uint32_t* sortedIds;
+    const uint32_t* sortedIds;            // the tasks the dense kernels run: all of them, or (sparse path) those it did not certify
+    uint32_t denseCount;                  // how many
     uint32_t taskStart[DP_CLASSES + 1];   // class c = tasks [taskStart[c], taskStart[c + 1]) of the sorted list
     uint32_t classCounts[DP_CLASSES];
     unsigned long long sums[2 + 2 * DP_CLASSES];   // [0] DP cells, [1] trace word bound, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c
@@ -303,8 +309,13 @@ struct DpForwardState {
 };
 
 // extraTasks / extraOrdinals: room behind the taskCount tasks for the wide tasks' results and aligned pairs.
+// What the sparse path needs beside the tasks: the candidates' match lists (null: every task runs in the dense kernels).
+struct SparseInput { const uint32_t* hits; const uint64_t* hitBase; const uint32_t* hitMeta; };
+// SHASTA_MI355X_SPARSE_DP=0: the dense DP for every task (the A/B switch, and the second implementation the tests compare with).
+bool sparseDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_SPARSE_DP"); return !e || std::atoi(e) != 0; }
+
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
-    uint32_t extraTasks = 0, uint64_t extraOrdinals = 0)
+    uint32_t extraTasks = 0, uint64_t extraOrdinals = 0, const SparseInput* sparse = nullptr)
 {
     hipStream_t stream = ws.stream;
     DpForwardState f;
@@ -326,10 +337,50 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         taskCount, DP_SORT_KEY_BITS, *ws.sortWs, stream);
     const uint32_t* sortedKeys = inB ? b.dpKeysB.data() : b.dpKeysA.data();
     const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
-    f.sortedIds = sortedIds;
+    f.sortedIds = sortedIds; f.denseCount = taskCount;
     HIP_CHECK(hipGetLastError());
     uint32_t* classCounts = f.classCounts;
     unsigned long long* sums = f.sums;
+    uint64_t ordTotalEarly = 0;
+    if(sparse) {
+        // K10s (align4_sparse.hpp): every task whose alignment is the unique optimal chain of the matches inside its band gets
+        // it from those matches; the dense kernels below run what is left.  The tasks' ordered hits need room that depends on the
+        // ordinal total: one synchronisation earlier than the dense path takes its own.
+        MI355X_ASSERT(reserveOrdinals);
+        if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
+        ordTotalEarly = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
+        b.ordScratch.reserve(2 * (ordTotalEarly + extraOrdinals) + 2, stream);
+        b.sparseSorted.reserve(2 * ordTotalEarly + 64ULL * taskCount + 4, stream);
+        b.sparseInBand.reserve(taskCount, stream); b.sparseState.reserve(taskCount, stream);
+        b.denseFlags.reserve(uint64_t(taskCount) + 1, stream); b.densePositions.reserve(uint64_t(taskCount) + 1, stream);
+        b.scanTemp32.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
+        KernelTimers::Span span;
+        if(timers) span = timers->begin("sparseSortKernel", stream);
+        hipLaunchKernelGGL(sparseSortKernel, dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
+            in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data());
+        HIP_CHECK(hipGetLastError());
+        if(timers) (void)timers->end(span, 0, taskCount);
+        if(timers) span = timers->begin("sparseChainKernel", stream);
+        hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
+            in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
+            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data());
+        HIP_CHECK(hipGetLastError());
+        if(timers) (void)timers->end(span, 0, taskCount);
+        if(timers) prepareSpan = timers->begin("DP task sizes, sort by (class, length), bundles", stream);
+        // The sorted list without the certified tasks (into the sort's other pair of buffers), its class counts and sums.
+        uint32_t* const denseKeys = inB ? b.dpKeysA.data() : b.dpKeysB.data();
+        uint32_t* const denseIds = inB ? b.dpIdsA.data() : b.dpIdsB.data();
+        hipLaunchKernelGGL(dpDenseFlagsKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream, sortedIds, (const uint8_t*)b.sparseState.data(), taskCount, b.denseFlags.data());
+        exclusiveScan<uint32_t>(b.denseFlags.data(), b.densePositions.data(), uint64_t(taskCount) + 1, b.scanTemp32.data(), stream);
+        HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(b.dpCells.data() + 2, 0, 2 * DP_CLASSES * sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(dpDenseListKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+            sortedKeys, sortedIds, (const uint32_t*)b.denseFlags.data(), (const uint32_t*)b.densePositions.data(), taskCount, in.tasks, in.pairs,
+            denseKeys, denseIds, b.counters.data() + 1, b.dpCells.data());
+        HIP_CHECK(hipGetLastError());
+        sortedKeys = denseKeys; sortedIds = denseIds; f.sortedIds = denseIds;
+    }
     // The bundles' trace words and their scan before the host knows the class counts (a thread per possible bundle: there are
     // no more bundles than tasks): one synchronisation for the counts, the ordinal total and the trace total.
     b.bundleWords.reserve(uint64_t(taskCount) + 1, stream);
@@ -341,7 +392,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     HIP_CHECK(hipMemcpyAsync(&f.traceWords, b.bundleWords.data() + taskCount, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
     const DpClassLayout layout = dpClassLayout(classCounts);
-    MI355X_ASSERT(layout.taskStart[DP_CLASSES] == taskCount);
+    MI355X_ASSERT(sparse ? layout.taskStart[DP_CLASSES] <= taskCount : layout.taskStart[DP_CLASSES] == taskCount);
+    f.denseCount = layout.taskStart[DP_CLASSES];
     for(int c = 0; c <= DP_CLASSES; c++) f.taskStart[c] = layout.taskStart[c];
     if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
     b.trace.reserve(f.traceWords + 64, stream);
@@ -514,7 +566,7 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
             const auto kernel = CELLS_Q[c] == 2 ? &align4CellsChunkKernel<2, true> : &align4CellsChunkKernel<4, true>;
             hipLaunchKernelGGL(kernel, dim3(count), dim3(WAVE * CELLS_WAVES), bytes, stream,
                 (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const CellsChunk*)(b.tieChunks.data() + offset), count, (const uint32_t*)b.tieMembers.data(),
-                opt, magicX, magicY, (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr, b.tieKeys.data() + wordOffset, b.tieCounts.data() + offset);
+                opt, magicX, magicY, (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr, b.tieKeys.data() + wordOffset, b.tieCounts.data() + offset, HitLists{nullptr, nullptr, nullptr});
             HIP_CHECK(hipGetLastError());
             order.insert(order.end(), chunkPair[c].begin(), chunkPair[c].end());
             for(uint32_t q = 0; q < count; q++) { slotWords.push_back(wordOffset + size_t(q) * maxc); slotCapacity.push_back(maxc); }
@@ -671,7 +723,8 @@ void runWideTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, const DpI
 }
 
 uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_t taskCount, const DeviceOptions& opt,
-    DpEvents* ev, DpBatchStats* stats, const DpScores* scores = nullptr, const std::vector<DpTask>* wide = nullptr, const std::vector<PairDesc>* hostPairs = nullptr)
+    DpEvents* ev, DpBatchStats* stats, const DpScores* scores = nullptr, const std::vector<DpTask>* wide = nullptr, const std::vector<PairDesc>* hostPairs = nullptr,
+    const SparseInput* sparse = nullptr)
 {
     hipStream_t stream = ws.stream;
     DpInput in{ctx.kmerIds.data(), b.pairs.data(), b.tasks.data(), dpTiePolicyOfCall()};
@@ -702,15 +755,15 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     }
     DpForwardState f;
     std::memset(&f, 0, sizeof(f));
-    if(taskCount) f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers, wideCount, wideOrdinals);
+    if(taskCount) f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers, wideCount, wideOrdinals, (sparse && defaultScores(in.scores)) ? sparse : nullptr);
     else { b.results.reserve(wideCount, stream); b.ordScratch.reserve(2 * wideOrdinals + 2, stream); }
     // The traceback of every class in one launch (the list is sorted by class, then by ascending length; the kernel takes it from the end).
     // Booked: the trace it has to read = 2 bits per cell of the padded bands, once per bundle (the bundles' trace words as
     // dpBundleKernel laid them out; the tasks of a bundle walk the same records) -- work = tasks.
-    if(taskCount) {
-        SHASTA_TIMED(ctx, "dpTracebackKernel", stream, 8 * f.traceWords, taskCount,
-            hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
-                in.pairs, in.tasks, f.sortedIds, 0u, taskCount,
+    if(f.denseCount) {
+        SHASTA_TIMED(ctx, "dpTracebackKernel", stream, 8 * f.traceWords, f.denseCount,
+            hipLaunchKernelGGL(dpTracebackKernel, dim3(divUp(f.denseCount, 256)), dim3(256), 0, stream,
+                in.pairs, in.tasks, f.sortedIds, 0u, f.denseCount,
                 (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
                 (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data()));
         HIP_CHECK(hipGetLastError());
@@ -895,7 +948,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         hipStream_t wide = nullptr;
         DpEvents ev;
         std::vector<PairDesc> hostPairs;
-        std::vector<uint64_t> hostToc64;
+        std::vector<uint64_t> hostToc64, hostHitBase;
         std::string error;
     };
     // SHASTA_MI355X_ALIGN_WORKERS overrides the number of workers (for timing experiments; 1 .. ALIGN_MAX_WORKERS).
@@ -935,6 +988,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const uint64_t batchBegin = batchStart[batchIndex];
         const uint32_t n = uint32_t(batchStart[batchIndex + 1] - batchBegin);
         hostPairs.resize(n);
+        // Method 4 with the sparse path: room for every candidate's list of matches (align4_sparse.hpp), laid out here.
+        const bool listHits = !m3 && sparseDpEnabled();
+        std::vector<uint64_t>& hostHitBase = w.hostHitBase;
+        if(listHits) { hostHitBase.resize(uint64_t(n) + 1); hostHitBase[0] = 0; }
         for(uint32_t k = 0; k < n; k++) {
             const shasta_oriented_read_pair& c = candidates[batchBegin + k];
             if(!(c.readIds[0] < c.readIds[1]) || c.readIds[1] >= ctx.readCount) {
@@ -955,6 +1012,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
+            if(listHits) hostHitBase[k + 1] = hostHitBase[k] + ((nx < 65535 && ny < 65535) ? hitListCapacity(pd.nx, pd.ny) : 0u);
         }
         // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
         // SHASTA_MI355X_INITIAL_TASKS overrides the first guess (tests use it to force the second run).
@@ -976,6 +1034,13 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, n * sizeof(unsigned long long), stream));
         HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
         HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
+        HitLists hitLists{nullptr, nullptr, nullptr};
+        if(listHits) {
+            b.hits.reserve(hostHitBase[n] + 1, stream); b.hitBase.reserve(uint64_t(n) + 1, stream); b.hitMeta.reserve(n, stream);
+            HIP_CHECK(hipMemcpyAsync(b.hitBase.data(), hostHitBase.data(), (uint64_t(n) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemsetAsync(b.hitMeta.data(), 0xff, n * sizeof(uint32_t), stream));        // HIT_LIST_NONE until a chunk kernel lists the candidate's matches
+            hitLists = HitLists{b.hits.data(), b.hitBase.data(), b.hitMeta.data()};
+        }
 
         // SHASTA_MI355X_DEBUG: where a batch spends its time on the host's clock (the kernels of other workers run meanwhile).
         static const bool debugPhases = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
@@ -1148,7 +1213,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     const uint32_t count = uint32_t(info[c + 1] - info[c]);
                     if(count == 0) continue;
                     firstRoundAny = true;
-                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[CELLS_INFO_BYTES + c], info[CELLS_INFO_CANDIDATES + c]);
+                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[CELLS_INFO_BYTES + c], info[CELLS_INFO_CANDIDATES + c], hitLists);
                 }
                 firstRoundLaunched = true;
                 members.assign(n, 0);                       // (positions 0 .. n-1 of the device's list: later rounds append after them)
@@ -1252,7 +1317,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                         candidatesIn += ch.count;
                         for(uint32_t q = 0; q < ch.count; q++) { const PairDesc& pd = hostPairs[members[ch.firstMember + q]]; bytes += 4ULL * (uint64_t(pd.nx) + pd.ny); }
                     }
-                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + chunkOffset, uint32_t(list.size()), opt, magicX, magicY, taskCapacity, bytes, candidatesIn);
+                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + chunkOffset, uint32_t(list.size()), opt, magicX, magicY, taskCapacity, bytes, candidatesIn, hitLists);
                     chunkOffset += list.size();
                 }
                 }
@@ -1367,7 +1432,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         phaseCells = phaseMs(phaseStart);
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount + wideCount) {
-            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs);
+            const SparseInput sparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data()};
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs, listHits ? &sparseInput : nullptr);
             out.hadTasks = true;
             const uint32_t allTasks = taskCount + wideCount;
             HIP_CHECK(hipMemsetAsync(b.counters.data() + 12, 0, sizeof(uint32_t), stream));
@@ -1775,8 +1841,49 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
     DpEvents ev;
     DpBatchStats stats;
+    // The sparse path of an Align4 batch (align4_sparse.hpp) takes its matches from the cells kernel; here the host lists them --
+    // every (x, y) with equal kmer ids, whatever the band, as the cells kernel would, in an order of no meaning -- so that the seam
+    // runs the tasks the way a batch does: sparse where the optimal chain is unique, dense otherwise.  Odd tasks say that read 0
+    // was the streamed one (either read may be).
+    SparseInput sparseInput{nullptr, nullptr, nullptr};
+    const bool sparse = sparseDpEnabled();
+    if(sparse) {
+        std::vector<uint64_t> hitBase(taskCount + 1, 0);
+        std::vector<uint32_t> meta(taskCount), hostHits;
+        for(uint64_t t = 0; t < taskCount; t++) hitBase[t + 1] = hitBase[t] + ((nx[t] < 65535 && ny[t] < 65535) ? hitListCapacity(nx[t], ny[t]) : 0u);
+        hostHits.resize(hitBase[taskCount] + 1);
+        std::unordered_map<uint32_t, std::vector<uint32_t>> where;
+        for(uint64_t t = 0; t < taskCount; t++) {
+            const uint32_t capacity = uint32_t(hitBase[t + 1] - hitBase[t]);
+            if(capacity == 0) { meta[t] = HIT_LIST_NONE; continue; }
+            where.clear();
+            for(uint32_t y = 0; y < ny[t]; y++) where[kmerIds[begin1[t] + y]].push_back(y);
+            uint64_t count = 0;
+            for(uint32_t x = 0; x < nx[t]; x++) {
+                const auto it = where.find(kmerIds[begin0[t] + x]);
+                if(it == where.end()) continue;
+                count += it->second.size();
+            }
+            // (a second pass places them: scattered over the room by a stride coprime to the count, so that the list is in no order)
+            const uint64_t stored = std::min<uint64_t>(count, capacity);
+            uint64_t stride = 7919; while(stored && std::__gcd(stride, stored) != 1) ++stride;
+            uint64_t at = 0;
+            for(uint32_t x = 0; x < nx[t] && stored; x++) {
+                const auto it = where.find(kmerIds[begin0[t] + x]);
+                if(it == where.end()) continue;
+                for(const uint32_t y : it->second) { if(at < stored) hostHits[hitBase[t] + (at * stride) % stored] = (x << 16) | y; ++at; }
+            }
+            meta[t] = uint32_t(std::min<uint64_t>(count, 0x7fffffffu)) | ((t & 1) ? 0x80000000u : 0u);
+        }
+        b.hits.reserve(hostHits.size(), stream); b.hitBase.reserve(hitBase.size(), stream); b.hitMeta.reserve(taskCount, stream);
+        HIP_CHECK(hipMemcpyAsync(b.hits.data(), hostHits.data(), hostHits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.hitBase.data(), hitBase.data(), hitBase.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(b.hitMeta.data(), meta.data(), taskCount * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        sparseInput = SparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data()};
+    }
     ev.create();
-    try { (void)runDpTasks(ctx, ws, b, narrowCount, opt, &ev, &stats, nullptr, &wideTasks, &pairs); } catch(...) { ev.destroy(); throw; }
+    try { (void)runDpTasks(ctx, ws, b, narrowCount, opt, &ev, &stats, nullptr, &wideTasks, &pairs, sparse ? &sparseInput : nullptr); } catch(...) { ev.destroy(); throw; }
     std::vector<DpResult> results(taskCount);
     HIP_CHECK(hipMemcpyAsync(results.data(), b.results.data(), taskCount * sizeof(DpResult), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));

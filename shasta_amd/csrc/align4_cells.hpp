@@ -339,6 +339,20 @@ align4CellsKernel(
 // firstMember indexes the member list (candidate indices of the batch).
 struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLog2, scLog2; };      // swapped: bit 0 = read 1 is the tabled one, bit 1 = count in the packed table even if the byte grid would fit
 
+// The matches of every candidate, listed by the cells kernel for the sparse form of the banded alignment (align4_sparse.hpp):
+// hits[base[k] .. base[k + 1]) = room for candidate k's matches, (x << 16) | y in the order the wavefronts found them;
+// meta[k] = how many there were (beyond the room: counted, not stored) | bit 31: the chunk tabled read 1 (the stream was read 0);
+// 0xffffffff = no list (the candidate's cells were computed by the kernel with its tables in HBM scratch).  hits == nullptr: no lists.
+struct HitLists { uint32_t* hits; const uint64_t* base; uint32_t* meta; };
+constexpr uint32_t HIT_LIST_NONE = 0xffffffffu;
+// Room for a candidate's matches: the shorter read's markers and a quarter (every one matched, some twice), the random background
+// (nx ny / alphabet; 2^14 is below any marker alphabet Shasta runs with) and some slack.  Repeat-rich pairs exceed it and take the dense DP.
+__host__ __device__ inline uint32_t hitListCapacity(uint32_t nx, uint32_t ny)
+{
+    const uint32_t shorter = nx < ny ? nx : ny;
+    return shorter + shorter / 4 + uint32_t((uint64_t(nx) * uint64_t(ny)) >> 14) + 128u;
+}
+
 #ifdef SHASTA_PROFILE_PHASES
 __device__ unsigned long long g_phaseCycles[16];
 #define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -442,7 +456,7 @@ align4CellsChunkKernel(
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
     DeviceOptions opt, uint32_t magicX, uint32_t magicY,
     DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
-    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts)
+    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts, HitLists hitLists)
 {
     extern __shared__ uint32_t ldsWords[];
     __shared__ uint32_t waveTotals[SHASTA_CELLS_MAX_THREADS / 64];
@@ -588,8 +602,15 @@ align4CellsChunkKernel(
             } else {
                 for(uint32_t k = first; k < SC; k += stride) cells[k] = EMPTY32;
             }
-            if(first == 0) { scratch[0] = 0; scratch[4] = 0; scratch[5] = pair; scratch[6] = nx; scratch[7] = ny; }   // [5..7]: for the graph
+            if(first == 0) { scratch[0] = 0; scratch[1] = 0; scratch[4] = 0; scratch[5] = pair; scratch[6] = nx; scratch[7] = ny; }   // [1]: matches listed so far (the graph uses it later); [5..7]: for the graph
         }
+        // The candidate's matches are also LISTED (align4_sparse.hpp: the banded alignment from the matches inside the band):
+        // every wavefront appends what it drains from its queue to the candidate's list in HBM, (x << 16) | y, in no particular
+        // order; what does not fit the list's capacity is counted but not stored (the count tells).
+        const bool listHits = !DUMP && hitLists.hits != nullptr;
+        const uint64_t hitBegin = listHits ? hitLists.base[pair] : 0ULL;
+        const uint32_t hitCapacity = listHits ? uint32_t(hitLists.base[pair + 1] - hitBegin) : 0u;
+        uint32_t* __restrict__ const hitList = listHits ? hitLists.hits + hitBegin : nullptr;
         if(SHASTA_ABLATE != 3) __syncthreads();
         PHASE_MARK(1);
 
@@ -700,6 +721,11 @@ align4CellsChunkKernel(
         uint32_t queued = 0;                                                    // wave-uniform
         auto drain = [&]() {
             waveLdsSync();
+            uint32_t listAt = 0;
+            if(listHits) {
+                if(lane == 0) listAt = atomicAdd(&scratch[1], queued);
+                listAt = __builtin_amdgcn_readfirstlane(listAt);
+            }
 #pragma nounroll
             for(uint32_t base = 0; base < queued; base += uint32_t(CELLS_DRAIN) * WAVE) {   // (CELLS_DRAIN entries per lane and pass: the counting code's registers)
                 bool hit[CELLS_DRAIN];
@@ -710,6 +736,7 @@ align4CellsChunkKernel(
                     hit[k] = at < queued;
                     const uint32_t e = queue[hit[k] ? at : 0u];
                     ti[k] = e >> 16; ts[k] = e & 0xffffu;
+                    if(listHits && hit[k] && listAt + at < hitCapacity) hitList[listAt + at] = swapped ? ((ts[k] << 16) | ti[k]) : ((ti[k] << 16) | ts[k]);
                 }
                 if(SHASTA_ABLATE != 4) countHits(std::integral_constant<int, CELLS_DRAIN>{}, hit, ti, ts);
             }
@@ -781,6 +808,7 @@ align4CellsChunkKernel(
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
         if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason & 7) | ((reason & 8) ? 0x20u : 0u) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
         if(SHASTA_ABLATE != 3) __syncthreads();                       // the cell region is cleared for the next candidate
+        if(listHits && threadIdx.x == 0) hitLists.meta[pair] = min(scratch[1], 0x7fffffffu) | (swapped ? 0x80000000u : 0u);
         PHASE_MARK(2);
     }
 

@@ -1,0 +1,278 @@
+// Align4 on MI355X, K10s: the banded overlap alignment of a (candidate, component) task computed from the MATCHES inside its
+// band -- a few hundred per task, listed by the cells kernel while it counts them -- instead of from every cell of the band
+// (a hundred thousand per task: bandedDpForwardKernel + dpTracebackKernel, align4_dp.hpp).  Included by align4.hip inside its
+// anonymous namespace, after align4_dp.hpp.
+//
+// What it computes (oracle/sparse_chain.hpp states it on the CPU and has the proof): only aligned pairs of EQUAL markers leave
+// computeBandedAlignment (/root/reference/src/Align4.cpp:1053-1068).  With scores 6 / -1 / -1 and all end gaps free, a stretch
+// between two consecutive matches costs the Chebyshev distance between them, the way in from the free border costs min(x, y), the
+// way out min(nx - 1 - x, ny - 1 - y); so over the hits of the band, in the order of one of the two ordinals,
+//
+//     D(m) = 6 + max( -min(x, y),  max over hits m' before m in BOTH ordinals of  D(m') - max(x - x' - 1, y - y' - 1) )
+//     best = max over m of  D(m) - min(nx - 1 - x, ny - 1 - y),          Z = the best score of a path without any match
+//
+// is the dense DP's optimum, and the dense traceback returns the match set of SOME optimal chain whatever its tie policy.  The
+// kernel counts the optimal chains (capped at two) and answers only when there is exactly ONE (or when no chain reaches Z: the
+// empty alignment): then every tie policy -- every reading of SeqAn -- gives that very set, and the task is "certified"; all
+// other tasks (several optimal chains, a hit whose search for predecessors goes further back than the ring holds, lists that
+// did not fit, reads beyond the tables here) run in the dense kernels exactly as before.  At 100 k reads 87 % of the tasks
+// (85 % of the DP cells) are certified (oracle's census over the same candidates, profiles/r04_sparse_census.txt).
+//
+//   sparseSortKernel    a wavefront per task: the candidate's hit list filtered by the task's band and ordered by the STREAM
+//                       ordinal (the read the cells kernel streamed; either order serves the recurrence, it is symmetric): a
+//                       counting sort on 4-bit counters per marker in LDS (two hits of one marker inside a band are common: the
+//                       background of a 15 000-k-mer alphabet; sixteen send the task to the dense DP).
+//   sparseChainKernel   a LANE per task (the recurrence is sequential in the hits), the work flattened into units -- one
+//                       predecessor looked at, or one hit finished -- so that a lane whose hit needs a long look back (an
+//                       off-chain hit: as many hits back as the band is wide) does not hold the other 63 at their hits; the last
+//                       64 hits of every lane in an LDS ring {ordinals, D, prefix maximum of D}; the chosen predecessor of a hit
+//                       written back into the task's list, which the lane then walks from the best end to emit the pairs into
+//                       the task's range of the ordinal scratch, as dpTracebackKernel does.
+//   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
+#pragma once
+
+constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the stream read a task may have here (4-bit counters: 4 KB per wavefront)
+constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
+constexpr int SPARSE_RING = 64;                              // hits a lane can look back
+enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2 };
+
+// Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets = exclusive scan of min(nx, ny) over the tasks).
+__host__ __device__ inline uint64_t sparseListBase(const uint64_t* ordOffsets, uint32_t t) { return 2 * ordOffsets[t] + 64ULL * t; }
+__host__ __device__ inline uint32_t sparseListCapacity(uint32_t nx, uint32_t ny) { return 2u * (nx < ny ? nx : ny) + 64u; }
+__device__ __forceinline__ uint32_t nibbleSum(uint32_t v)
+{
+    v = (v & 0x0f0f0f0fu) + ((v >> 4) & 0x0f0f0f0fu);
+    return (v * 0x01010101u) >> 24;
+}
+
+// The best score of a path without a match: the largest -min(i, j) over the border cells (i = nx or j = ny) inside the band
+// (oracle::bestMatchlessScore).
+__host__ __device__ inline int32_t sparseMatchlessScore(uint32_t nx, uint32_t ny, int32_t bandMin, int32_t bandMax)
+{
+    long long best = -(1LL << 40);
+    {
+        const long long jLo = (long long)nx - bandMax > 0 ? (long long)nx - bandMax : 0, jHi = (long long)nx - bandMin < (long long)ny ? (long long)nx - bandMin : (long long)ny;
+        if(jLo <= jHi) { const long long v = -(jLo < (long long)nx ? jLo : (long long)nx); best = v > best ? v : best; }
+    }
+    {
+        const long long iLo = (long long)ny + bandMin > 0 ? (long long)ny + bandMin : 0, iHi = (long long)ny + bandMax < (long long)nx ? (long long)ny + bandMax : (long long)nx;
+        if(iLo <= iHi) { const long long v = -(iLo < (long long)ny ? iLo : (long long)ny); best = v > best ? v : best; }
+    }
+    return int32_t(best > -(1LL << 30) ? best : -(1LL << 30));
+}
+
+__global__ void __launch_bounds__(256)
+sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
+    const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state)
+{
+    __shared__ uint32_t counts[4][SPARSE_COUNTER_WORDS], cursors[4][SPARSE_COUNTER_WORDS];
+    __shared__ uint16_t wordStart[4][SPARSE_COUNTER_WORDS];
+    const int lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * 4u + wave;
+    if(t >= taskCount) return;                             // (whole wavefronts: no block barrier below)
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const uint32_t meta = hitMeta[task.pair];
+    const bool swapped = (meta >> 31) != 0;
+    const uint32_t count = meta & 0x7fffffffu;
+    const uint64_t begin = hitBase[task.pair];
+    const uint32_t capacity = uint32_t(hitBase[task.pair + 1] - begin);
+    const uint32_t streamCount = swapped ? pd.nx : pd.ny;
+    if(meta == HIT_LIST_NONE || count > capacity || streamCount > SPARSE_MAX_STREAM || streamCount == 0) {
+        if(lane == 0) state[t] = SPARSE_DENSE;
+        return;
+    }
+    uint32_t* const myCounts = counts[wave];
+    uint32_t* const myCursors = cursors[wave];
+    uint16_t* const myStart = wordStart[wave];
+    const uint32_t words = (streamCount + 7u) / 8u;
+    for(uint32_t w = uint32_t(lane); w < words; w += WAVE) { myCounts[w] = 0; myCursors[w] = 0; }
+    waveLdsSync();
+    const uint32_t* __restrict__ const list = hits + begin;
+    bool crowded = false;
+    for(uint32_t i0 = 0; i0 < count; i0 += WAVE) {
+        const uint32_t i = i0 + uint32_t(lane);
+        const uint32_t e = list[i < count ? i : 0u];
+        const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
+        const bool in = i < count && x - y >= task.bandMin && x - y <= task.bandMax;
+        const uint32_t p = uint32_t(swapped ? x : y);
+        if(in && p < streamCount) {
+            const uint32_t shift = 4u * (p & 7u);
+            const uint32_t old = atomicAdd(&myCounts[p >> 3], 1u << shift);
+            crowded |= ((old >> shift) & 15u) == 15u;
+        }
+    }
+    waveLdsSync();
+    if(__any(crowded)) { if(lane == 0) state[t] = SPARSE_DENSE; return; }
+    // Where every word's markers start: a scan of the words' sums.
+    const uint32_t per = (words + WAVE - 1) / WAVE, first = uint32_t(lane) * per;
+    uint32_t sum = 0;
+    for(uint32_t w = first; w < min(first + per, words); w++) sum += nibbleSum(myCounts[w]);
+    uint32_t inclusive = sum;
+#pragma unroll
+    for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
+    const uint32_t total = uint32_t(__shfl(int(inclusive), WAVE - 1, WAVE));
+    if(total > sparseListCapacity(pd.nx, pd.ny)) { if(lane == 0) state[t] = SPARSE_DENSE; return; }
+    uint32_t running = inclusive - sum;
+    for(uint32_t w = first; w < min(first + per, words); w++) { myStart[w] = uint16_t(running); running += nibbleSum(myCounts[w]); }
+    waveLdsSync();
+    uint32_t* __restrict__ const out = sorted + sparseListBase(ordOffsets, t);
+    for(uint32_t i0 = 0; i0 < count; i0 += WAVE) {
+        const uint32_t i = i0 + uint32_t(lane);
+        const uint32_t e = list[i < count ? i : 0u];
+        const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
+        const bool in = i < count && x - y >= task.bandMin && x - y <= task.bandMax;
+        const uint32_t p = uint32_t(swapped ? x : y), s = uint32_t(swapped ? y : x);
+        if(in && p < streamCount) {
+            const uint32_t w = p >> 3, shift = 4u * (p & 7u);
+            const uint32_t below = nibbleSum(myCounts[w] & ((1u << shift) - 1u));
+            const uint32_t local = (atomicAdd(&myCursors[w], 1u << shift) >> shift) & 15u;
+            out[uint32_t(myStart[w]) + below + local] = (p << 16) | s;
+        }
+    }
+    if(lane == 0) { inBand[t] = total; state[t] = SPARSE_SORTED; }
+}
+
+// Ring entry: {p << 16 | s,  (D + SPARSE_D_BIAS) | (prefix maximum - D, 1023 = not held) << 20 | (two or more optimal chains end here) << 30}.
+constexpr int32_t SPARSE_D_BIAS = 1 << 17;
+constexpr int32_t SPARSE_NEG = -(1 << 29);
+// A hit of the task's list once it is finished: p << 17 | (s - p - lo) << 7 | how many hits back its predecessor is (0: the chain starts here).
+__global__ void __launch_bounds__(64)
+sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ order, uint32_t taskCount,
+    uint32_t* __restrict__ sorted, const uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, const uint32_t* __restrict__ hitMeta,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
+{
+    __shared__ uint2 ring[SPARSE_RING * WAVE];             // [slot][lane]
+    const int lane = laneId();
+    const uint32_t position = blockIdx.x * uint32_t(WAVE) + uint32_t(lane);
+    const bool has = position < taskCount;
+    const uint32_t t = order[has ? taskCount - 1u - position : 0u];       // the list is ascending in length: the longest tasks first
+    const bool mine = has && state[t] == SPARSE_SORTED;
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const bool swapped = (hitMeta[task.pair] >> 31) != 0;
+    const int32_t n = mine ? int32_t(inBand[t]) : 0;
+    const int32_t np = int32_t(swapped ? pd.nx : pd.ny), ns = int32_t(swapped ? pd.ny : pd.nx);
+    const int32_t lo = swapped ? -task.bandMax : task.bandMin;            // s - p lies in [lo, lo + band width)
+    uint32_t* __restrict__ const list = sorted + sparseListBase(ordOffsets, t);
+    // The hits arrive four ahead of their use.
+    uint32_t ahead[4];
+#pragma unroll
+    for(int a = 0; a < 4; a++) ahead[a] = a < n ? list[a] : 0u;
+    int32_t k = 0, p = int32_t(ahead[0] >> 16), s = int32_t(ahead[0] & 0xffffu);
+    int32_t value = -min(p, s), from = 0, j = 1;
+    uint32_t ways = 1;
+    int32_t prefixMax = SPARSE_NEG, best = SPARSE_NEG, bestAt = -1;
+    uint32_t bestWays = 0;
+    bool failed = false, active = n > 0;
+    while(__any(active)) {
+        if(active) {
+            bool finish = false;
+            if(j > k) finish = true;                                       // no hit further back
+            else if(j > SPARSE_RING) { failed = true; active = false; }    // further back than the ring holds: the dense DP takes the task
+            else {
+                const uint2 e = ring[((k - j) & (SPARSE_RING - 1)) * WAVE + lane];
+                const int32_t pq = int32_t(e.x >> 16), sq = int32_t(e.x & 0xffffu);
+                const int32_t dq = int32_t(e.y & 0xfffffu) - SPARSE_D_BIAS;
+                const uint32_t held = (e.y >> 20) & 1023u;
+                const int32_t maxUpToQ = held == 1023u ? prefixMax : dq + int32_t(held);
+                // No hit at q or before it can reach `value` (every one of them is at least p - pq - 1 away): `<`, so that ties are seen.
+                if(maxUpToQ - (p - pq - 1) < value) finish = true;
+                else {
+                    if(pq < p && sq < s) {
+                        const int32_t candidate = dq - max(p - pq - 1, s - sq - 1);
+                        const uint32_t waysQ = 1u + ((e.y >> 30) & 1u);
+                        if(candidate > value) { value = candidate; from = j; ways = waysQ; }
+                        else if(candidate == value) ways = min(2u, ways + waysQ);
+                    }
+                    ++j;
+                }
+            }
+            if(finish) {
+                const int32_t d = 6 + value;
+                const int32_t newMax = max(prefixMax, d);
+                const uint32_t held = uint32_t(min(newMax - d, 1023));
+                ring[(k & (SPARSE_RING - 1)) * WAVE + lane] = make_uint2((uint32_t(p) << 16) | uint32_t(s),
+                    uint32_t(d + SPARSE_D_BIAS) | (held << 20) | ((ways >= 2u ? 1u : 0u) << 30));
+                prefixMax = newMax;
+                list[k] = (uint32_t(p) << 17) | (uint32_t(s - p - lo) << 7) | uint32_t(from);
+                const int32_t end = d - min(np - 1 - p, ns - 1 - s);
+                if(end > best) { best = end; bestAt = k; bestWays = ways; }
+                else if(end == best) bestWays = min(2u, bestWays + ways);
+                ++k;
+                if(k == n) active = false;
+                else {
+                    ahead[0] = ahead[1]; ahead[1] = ahead[2]; ahead[2] = ahead[3];
+                    ahead[3] = k + 3 < n ? list[k + 3] : 0u;
+                    p = int32_t(ahead[0] >> 16); s = int32_t(ahead[0] & 0xffffu);
+                    value = -min(p, s); from = 0; j = 1; ways = 1;
+                }
+            }
+        }
+    }
+    if(!mine) return;
+    const int32_t matchless = sparseMatchlessScore(pd.nx, pd.ny, task.bandMin, task.bandMax);
+    const bool empty = n == 0 || best < matchless;
+    if(failed || (!empty && (best == matchless || bestWays != 1u))) { state[t] = SPARSE_DENSE; return; }
+    // The chain, from its last hit back, into the end of the task's range of the ordinal scratch (as dpTracebackKernel leaves it).
+    const uint64_t ordBase = ordOffsets[t];
+    uint32_t pos = min(pd.nx, pd.ny);
+    if(!empty) {
+        for(int32_t at = bestAt; ; ) {
+            const uint32_t e = list[at];
+            const int32_t hp = int32_t(e >> 17), hs = hp + lo + int32_t((e >> 7) & 1023u);
+            --pos;
+            *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hp), uint32_t(hs)) : make_uint2(uint32_t(hs), uint32_t(hp));
+            const int32_t back = int32_t(e & 127u);
+            if(back == 0) break;
+            at -= back;
+        }
+    }
+    DpEnd e; e.traceOffset = 0; e.bestI = e.bestJ = 0; e.score = empty ? matchless : best; e.laneBase = 0; e.bundleIterations = 0; e.pad = 0;
+    tracebackFinish(pos, pd, e, ordBase, t, results);
+    state[t] = SPARSE_CERTIFIED;
+}
+
+// The sorted task list without the certified tasks.  flags[i] = 1 where sorted position i stays (flags[taskCount] = 0, for the scan's total).
+__global__ void __launch_bounds__(256)
+dpDenseFlagsKernel(const uint32_t* __restrict__ sortedIds, const uint8_t* __restrict__ state, uint32_t taskCount, uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i > taskCount) return;
+    flags[i] = (i < taskCount && state[sortedIds[i]] != SPARSE_CERTIFIED) ? 1u : 0u;
+}
+
+// positions = exclusive scan of the flags.  Class counts and the per-class sums (DP cells, algorithmic bytes) of the tasks that stay:
+// what dpSizeKernel computed for all of them (the caller zeroes classCounts and sums[2 ...] first).
+__global__ void __launch_bounds__(256)
+dpDenseListKernel(const uint32_t* __restrict__ sortedKeys, const uint32_t* __restrict__ sortedIds, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ positions,
+    uint32_t taskCount, const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs,
+    uint32_t* __restrict__ denseKeys, uint32_t* __restrict__ denseIds, uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    unsigned long long cells = 0, bytes = 0;
+    if(i < taskCount && flags[i]) {
+        const uint32_t key = sortedKeys[i], t = sortedIds[i];
+        denseKeys[positions[i]] = key; denseIds[positions[i]] = t;
+        cls = int(key >> 24);
+        const DpTask task = tasks[t];
+        const PairDesc pd = pairs[task.pair];
+        cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
+        bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
+    }
+#pragma unroll
+    for(int c = 0; c < DP_CLASSES; c++) {
+        const uint64_t votes = __ballot(cls == c);
+        if(votes == 0) continue;
+        unsigned long long classCells = cls == c ? cells : 0, classBytes = cls == c ? bytes : 0;
+        for(int d = 32; d >= 1; d >>= 1) { classCells += __shfl_down(classCells, d, WAVE); classBytes += __shfl_down(classBytes, d, WAVE); }
+        if(laneId() == 0) {
+            atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
+            atomicAdd(&sums[2 + c], classCells);
+            atomicAdd(&sums[2 + DP_CLASSES + c], classBytes);
+        }
+    }
+}

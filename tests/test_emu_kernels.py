@@ -74,12 +74,25 @@ def test_lowhash0_and_align4(emu_lib, oracle_lib):
     x = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
     y = emu_lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
     assert y.dp_cell_count == x.dp_cell_count and y.kmer_id_bytes == x.kmer_id_bytes     # dpSizeKernel's sums
-    with emu_lib.context(0) as ctx:
-        ctx.set_kmer_ids(toc, kmer)
-        z = ctx.align4(cand, o)
-        t = ctx.kernel_table()
-    forward = [v for k, v in t.items() if k.startswith("bandedDpForwardKernel")]
-    assert sum(v["work"] for v in forward) == z.dp_cell_count == x.dp_cell_count and sum(v["bytes"] for v in forward) > 0
+    # The kernel table books the dense kernels' cells: all of the reference's DP cells with the sparse path switched off, a fraction
+    # of them with it (the tasks whose alignment is the unique optimal chain of their matches never reach the dense kernels).
+    for sparse, monkey in (("1", None), ("0", None)):
+        os.environ["SHASTA_MI355X_SPARSE_DP"] = sparse
+        try:
+            with emu_lib.context(0) as ctx:
+                ctx.set_kmer_ids(toc, kmer)
+                z = ctx.align4(cand, o, want_ordinals=True)
+                t = ctx.kernel_table()
+        finally:
+            del os.environ["SHASTA_MI355X_SPARSE_DP"]
+        forward = [v for k, v in t.items() if k.startswith("bandedDpForwardKernel")]
+        assert z.dp_cell_count == x.dp_cell_count and sum(v["bytes"] for v in forward) > 0
+        if sparse == "0":
+            assert sum(v["work"] for v in forward) == z.dp_cell_count and "sparseChainKernel" not in t
+        else:
+            assert 0 < sum(v["work"] for v in forward) < z.dp_cell_count // 2 and t["sparseChainKernel"]["launches"] >= 1
+        if not (x.status & 0x80).any():
+            support.same_align(x, z)
     if not (x.status & 0x80).any():
         support.same_align(x, y)
     else:
@@ -290,3 +303,11 @@ def test_base_level_reads_against_the_reference_running_live(emu_lib, ref_lib):
     from tests import base_level_checks
     reads, markers, candidates, stored = base_level_checks.plumbing(emu_lib, ref_lib, n_reads=400, genome_length=150000, limit=400)
     assert reads >= 360 and stored > 100
+
+
+def test_sparse_form_of_the_banded_alignment(emu_lib, oracle_lib):
+    # align4_sparse.hpp: on and off, under every compiled tie policy, and through the aligner (tests/sparse_checks.py).
+    from tests import sparse_checks
+    tasks, clean_share, tie_heavy_share = sparse_checks.dp_tasks(emu_lib, oracle_lib)
+    assert tasks >= 50 and clean_share > 0.6 and tie_heavy_share < 0.3
+    assert sparse_checks.aligner(emu_lib, oracle_lib, n_reads=100, limit=250) > 0.6

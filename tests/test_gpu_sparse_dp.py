@@ -1,0 +1,17 @@
+"""The sparse form of the banded alignment on the MI355X (tests/sparse_checks.py)."""
+import pytest
+
+from tests import sparse_checks
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dp_tasks_with_the_sparse_path_on_and_off_and_under_every_compiled_tie_policy(gpu_lib, oracle_lib):
+    tasks, clean_share, tie_heavy_share = sparse_checks.dp_tasks(gpu_lib, oracle_lib)
+    assert tasks >= 50
+    assert clean_share > 0.6               # most cells of clean tasks never reach the dense kernels ...
+    assert tie_heavy_share < 0.3           # ... and tie-heavy ones are left to them
+
+
+def test_aligner_with_the_sparse_path_on_and_off(gpu_lib, oracle_lib):
+    assert sparse_checks.aligner(gpu_lib, oracle_lib) > 0.6
