@@ -297,6 +297,11 @@ int shasta_mi355x_align4_run(
 #define SHASTA_MI355X_SIZE_HISTOGRAM_BINS 2048
 int shasta_mi355x_lh_begin(shasta_mi355x_ctx*, const shasta_lowhash0_params* params, int rank, int worldSize,
     const uint64_t* readBoundaries, uint32_t* log2BucketCount);
+/* After lh_begin: *fits = 1 if this rank can take the job's iterations in one pass (lh_hash_all / lh_buckets_all / lh_merge_all):
+ * a fixed number of iterations (1 .. 4096), at most 256 ranks, and the low-hash records of ALL iterations within the 2^32 positions of
+ * one sort with a factor of two to spare.  The caller reduces the answers of all ranks (minimum) and takes the one-pass form only
+ * if every rank said 1; otherwise lh_hash / lh_buckets / lh_merge per iteration, which need one iteration's records to fit. */
+int shasta_mi355x_lh_one_pass_fits(shasta_mi355x_ctx*, int* fits);
 int shasta_mi355x_lh_hash(shasta_mi355x_ctx*, uint64_t iteration, uint64_t* sendOffsets,
     const void** keysDevice, const void** valsDevice);
 int shasta_mi355x_lh_buckets(shasta_mi355x_ctx*, const void* keysDevice, const void* valsDevice, uint64_t n,

@@ -1177,8 +1177,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             const uint32_t magicX = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaX + 1, 0xffffffffULL));
             const uint32_t magicY = uint32_t(std::min<uint64_t>((1ULL << 32) / opt.deltaY + 1, 0xffffffffULL));
             cellsMagicX = magicX; cellsMagicY = magicY;
-            // Every candidate is a member once, plus once per class it climbs to after an overflow.
-            const uint64_t memberCapacity = uint64_t(CELLS_CLASSES) * n + 16;
+            // Every candidate is a member once, plus once per class it climbs to after an overflow, plus once more if a byte of its grid overflowed.
+            const uint64_t memberCapacity = uint64_t(CELLS_CLASSES + 1) * n + 16;       // (its first class, the classes it climbs to, and one repeat in the packed table)
             b.pairList.reserve(memberCapacity, stream);
             size_t membersUploaded = 0;
             // The first round's member list and chunk lists are made by kernels on the batch's stream and its cells kernels launched from

@@ -96,6 +96,15 @@ int shasta_mi355x_lh_begin(shasta_mi355x_ctx* c, const shasta_lowhash0_params* p
     API_END(1)
 }
 
+int shasta_mi355x_lh_one_pass_fits(shasta_mi355x_ctx* c, int* fits)
+{
+    API_BEGIN
+    if(!c || !fits) throw std::runtime_error("lh_one_pass_fits: null argument");
+    *fits = lowhash0OnePassFits(c->impl) ? 1 : 0;
+    return 0;
+    API_END(1)
+}
+
 int shasta_mi355x_lh_hash(shasta_mi355x_ctx* c, uint64_t iteration, uint64_t* sendOffsets, const void** keysDevice, const void** valsDevice)
 {
     API_BEGIN

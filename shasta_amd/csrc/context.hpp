@@ -85,6 +85,7 @@ void lowhash0Buckets(Context&, const uint32_t* keys, const uint64_t* vals, uint6
     const uint64_t** pairKeys, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint32_t>& overflow);
 void lowhash0Merge(Context&, const uint64_t* pairKeys, uint64_t n, bool evaluateNow, uint64_t* highFrequency, uint64_t* total);
 // The same job with all iterations in one pass (fixed minHashIterationCount): one call of each per job.
+bool lowhash0OnePassFits(Context&);           // after lowhash0Begin: may this rank take the one-pass form?  (all ranks must agree)
 void lowhash0HashAll(Context&, uint64_t* sendOffsets, const uint64_t** keys, const uint64_t** vals);
 void lowhash0BucketsAll(Context&, const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* sendOffsets,
     const uint64_t** pairKeys, const uint32_t** pairTags, uint64_t* bucketsUsed, uint64_t* sizeHistogram, std::vector<uint64_t>& overflow);

@@ -1218,6 +1218,33 @@ void lowhash0Merge(Context& ctx, const uint64_t* keys, uint64_t n, bool evaluate
 // ---- the staged job with all iterations in one pass (fixed minHashIterationCount): three calls and two exchanges per JOB
 // instead of per iteration.  Keys are 64-bit: owner << 56 | iteration << 32 | bucket id.
 
+// Whether the job that lowhash0Begin set up on this context can take all its iterations in one pass: a fixed number of them, at
+// most 4096, at most 256 ranks, and the records of ALL iterations -- this rank's own and, the buckets being dealt evenly, about
+// as many received -- within the 32-bit positions of one sort, with a factor of two to spare (the capacity is an estimate that
+// grows when it was short).  Every rank of a job asks its own context and the job takes the one-pass form only if ALL say yes
+// (Group::lowhash0Run, shasta_amd/distributed.py): otherwise iteration after iteration, which only needs ONE iteration's records
+// to fit.  (Human-scale marker counts on few ranks, or hundreds of iterations, are where the answer is no.)
+// (SHASTA_MI355X_ONE_PASS_RECORD_LIMIT lowers the limit: tests of the fall-back at sizes a test can hold;
+// SHASTA_MI355X_DEBUG_ONE_PASS=1 says on stderr when a job falls back.)
+uint64_t onePassRecordLimit()
+{
+    static const uint64_t limit = [] { const char* e = std::getenv("SHASTA_MI355X_ONE_PASS_RECORD_LIMIT"); return e ? std::min<uint64_t>(std::strtoull(e, nullptr, 10), (1ULL << 32) - 1) : (1ULL << 32) - 1; }();
+    return limit;
+}
+void noteOnePassFallback(uint64_t iterations, uint64_t recCapacity)
+{
+    static const bool debug = [] { const char* e = std::getenv("SHASTA_MI355X_DEBUG_ONE_PASS"); return e && e[0] == '1'; }();
+    if(debug) std::fprintf(stderr, "LowHash0: %llu iterations x %llu records do not fit one sort: iteration after iteration\n", (unsigned long long)iterations, (unsigned long long)recCapacity);
+}
+bool lowhash0OnePassFits(Context& ctx)
+{
+    const LowHash0Job& job = jobOf(ctx);
+    const uint64_t I = job.p.minHashIterationCount;
+    const bool fits = I >= 1 && I <= 4096 && job.world <= 256 && 2 * I * job.recCapacity < onePassRecordLimit();
+    if(!fits && I >= 1) noteOnePassFallback(I, job.recCapacity);
+    return fits;
+}
+
 // Stage 1 (all iterations).  sendOffsets[r..r+1] delimit the records of the buckets rank r owns in (*keys, *vals).
 void lowhash0HashAll(Context& ctx, uint64_t* sendOffsets, const uint64_t** keysOut, const uint64_t** valsOut)
 {
@@ -1231,7 +1258,8 @@ void lowhash0HashAll(Context& ctx, uint64_t* sendOffsets, const uint64_t** keysO
     uint64_t n = 0, capacity = 0;
     for(;;) {
         capacity = I * job.recCapacity;
-        MI355X_ASSERT(capacity < (1ULL << 32) - 1);
+        if(capacity >= (1ULL << 32) - 1) throw std::runtime_error("LowHash0: the low hashes of all " + std::to_string(I) + " iterations (" + std::to_string(capacity) +
+            " records on this rank) exceed the 2^32 positions of one sort: run the job iteration after iteration (shasta_mi355x_lh_one_pass_fits says beforehand).");
         job.recKeysA.reserve(2 * capacity, stream); job.recKeysB.reserve(2 * capacity, stream);
         job.recValsA.reserve(capacity, stream); job.recValsB.reserve(capacity, stream);
         HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
@@ -1292,7 +1320,9 @@ void lowhash0BucketsAll(Context& ctx, const uint64_t* keysIn, const uint64_t* va
     HIP_CHECK(hipSetDevice(ctx.device));
     hipStream_t stream = ctx.stream;
     const uint64_t I = job.p.minHashIterationCount;
-    MI355X_ASSERT(I >= 1 && I <= 4096 && n < (1ULL << 32) - 1 && job.iterations == 0);
+    MI355X_ASSERT(I >= 1 && I <= 4096 && job.iterations == 0);
+    if(n >= (1ULL << 32) - 1) throw std::runtime_error("LowHash0: this rank received " + std::to_string(n) + " low-hash records of all iterations, more than the 2^32 positions "
+        "of one sort: run the job iteration after iteration (shasta_mi355x_lh_one_pass_fits says beforehand).");
     // SHASTA_MI355X_LOG_STAGES=1: a call of more than 25 ms says on stderr where it spent them (each mark after a stream
     // synchronisation of its own -- a diagnosis, not for timed runs).
     static const bool logStages = [] { const char* e = std::getenv("SHASTA_MI355X_LOG_STAGES"); return e && e[0] == '1'; }();
@@ -1479,7 +1509,8 @@ void lowhash0Run(Context& ctx, const shasta_lowhash0_params& p, uint64_t* readLo
             // SHASTA_MI355X_LOWHASH_ONE_PASS=0: never.
             const bool onePassAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_LOWHASH_ONE_PASS"); return !(e && e[0] == '0'); }();      // (read for every call: tests switch it)
             const uint64_t I = p.minHashIterationCount;
-            const bool onePass = onePassAllowed && I >= 1 && I <= 4096 && I * job.recCapacity < (1ULL << 32) - 1;
+            const bool onePass = onePassAllowed && I >= 1 && I <= 4096 && I * job.recCapacity < onePassRecordLimit();
+            if(onePassAllowed && !onePass && I >= 1) noteOnePassFallback(I, job.recCapacity);
             const bool wideKeys = onePass && job.log2BucketCount + uint64_t(bitsFor(I - 1)) > 32;      // 64-bit record keys: iteration << 32 | bucket id
             uint64_t recordCapacityAll = 0;
             if(onePass) {

@@ -148,6 +148,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
         std::vector<std::vector<uint32_t>> overflowPerIteration;
         std::vector<shasta_oriented_read_pair> candidates;
         uint32_t log2BucketCount = 0;
+        bool onePassFits = false;
     };
     std::vector<std::unique_ptr<Rank>> rankStorage;                     // (device buffers do not move)
     for(int r = 0; r < world; r++) { rankStorage.emplace_back(new Rank()); rankStorage.back()->offsets.assign(size_t(world) + 1, 0); }
@@ -156,7 +157,9 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
     const bool dynamic = p.minHashIterationCount == 0;
     // A fixed number of iterations: all of them in one pass -- two exchanges and four barriers per JOB instead of per iteration
     // (lowhash0HashAll / BucketsAll / MergeAll).  SHASTA_MI355X_LOWHASH_ONE_PASS=0: iteration after iteration.
-    const bool onePass = [&] { const char* e = std::getenv("SHASTA_MI355X_LOWHASH_ONE_PASS"); return !(e && e[0] == '0'); }()
+    // Whether the records of all iterations fit one sort is known to a device once its job is set up: every device says, all
+    // of them must agree (lowhash0OnePassFits) -- decided below, behind the first barrier.
+    const bool onePassAllowed = [&] { const char* e = std::getenv("SHASTA_MI355X_LOWHASH_ONE_PASS"); return !(e && e[0] == '0'); }()
         && !dynamic && p.minHashIterationCount <= 4096 && world <= 256;
     uint64_t highFrequencyShared = 0;
     double deviceSeconds = 0;
@@ -170,6 +173,10 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
         HIP_CHECK(hipEventRecord(evBegin, stream));
         try {
             lowhash0Begin(ctx, p, rank, world, boundaries.data(), &me.log2BucketCount);
+            me.onePassFits = onePassAllowed && lowhash0OnePassFits(ctx);
+            barrier.wait();
+            bool onePass = true;
+            for(int r = 0; r < world; r++) onePass = onePass && rankOf(r).onePassFits;       // (the same answer on every device)
             // This rank's segment of every rank's output, into `destination`: element size `bytes`, source pointer
             // selected by `which`.  Returns the number of elements received.
             auto pull = [&](int which, size_t bytes, void* destination) {

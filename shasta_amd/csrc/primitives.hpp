@@ -205,6 +205,9 @@ radixScatterKernel(const K* __restrict__ keysIn, K* __restrict__ keysOut,
     __shared__ uint32_t waveTotals[RS_WAVES];
     __shared__ K stagedKeys[RS_TILE];
     __shared__ V stagedVals[HAS_V ? RS_TILE : 1];
+    // LDS per workgroup: the staged tile + 6 KB of tables -- 70 KB for 8-byte keys with 8-byte values (the one-pass LowHash0's
+    // wide record keys and its partition by owner): two workgroups per CU of gfx950's 160 KB; beyond what a 64-KB-LDS part holds.
+    static_assert(sizeof(K) * RS_TILE + (HAS_V ? sizeof(V) * RS_TILE : 0) + (RS_WAVES + 2) * RS_BINS * 4 + 64 <= 80 * 1024, "radixScatterKernel: LDS per workgroup (gfx950: 160 KB per CU)");
     const uint64_t n = count.get();
     const int lane = laneId();
     const int wave = int(threadIdx.x) >> 6;

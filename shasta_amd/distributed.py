@@ -70,8 +70,10 @@ class HipBackend:
         if self.device.type == "cuda" and not self._copies:
             try:
                 return torch.as_tensor(self._DeviceArray(ptr, n, "<i4" if dtype == torch.int32 else "<i8"), device=self.device)
-            except Exception:                       # (remembered: every later call copies)
+            except (TypeError, ValueError, RuntimeError) as e:      # (a torch that cannot wrap a raw address; remembered: every later call copies)
                 self._copies = True
+                import sys
+                sys.stderr.write("shasta_amd.distributed: stage outputs are copied, not viewed (%s: %s)\n" % (type(e).__name__, str(e)[:200]))
         t = torch.empty(n, dtype=dtype, device=self.device)
         self.ctx.memcpy(t.data_ptr(), ptr, n * t.element_size(), 2)
         return t
@@ -104,11 +106,16 @@ class HipBackend:
 
     def finish_on_device(self):
         """finish() with the candidates left on the device: an int32 tensor of triplets (readId0, readId1, isSameStrand in the
-        low byte) that VIEWS the library's buffer, valid until the context's next LowHash0 job."""
+        low byte), copied there from the library's buffer."""
         ptr, count, stats, high, total = self.ctx.lh_finish_on_device()
-        return self._tensor_from(ptr, 3 * count, torch.int32), stats, high, total
+        # (A copy of its own: the caller keeps this tensor, the library's buffer is reused by the context's next job.  The views
+        # of the stage outputs above live only until the exchange that follows them.)
+        return self._tensor_from(ptr, 3 * count, torch.int32).clone(), stats, high, total
 
     # All iterations in one pass (fixed minHashIterationCount): one call of each per job.
+    def one_pass_fits(self):
+        return self.ctx.lh_one_pass_fits()
+
     def hash_all(self):
         offsets, keys, vals = self.ctx.lh_hash_all()
         n = int(offsets[-1])
@@ -176,6 +183,13 @@ def all_reduce_sum_u64(array, device, group=None):
     return t.cpu().numpy().view(np.uint64).reshape(a.shape)
 
 
+def _every_rank_agrees(flag, device, group=None):
+    """True if `flag` is true on every rank (one small all-reduce)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_comm_device(torch.device(device)))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 class LowHash0Result:
     def __init__(self):
         self.candidates = None          # this rank's (sorted) share
@@ -208,8 +222,15 @@ def lowhash0(backend, params, read_count, boundaries, group=None, candidates_on_
     one_pass = (not dynamic and 1 <= int(params.minHashIterationCount) <= 4096 and world <= 256 and hasattr(backend, "hash_all")
                 and os.environ.get("SHASTA_MI355X_LOWHASH_ONE_PASS", "1") != "0")
     if one_pass:
+        # ... and only if the records of all iterations fit one sort on EVERY rank (each asks its own context; a rank that went
+        # ahead alone would leave the others waiting in the exchange): otherwise iteration after iteration.
+        one_pass = _every_rank_agrees(backend.one_pass_fits() if hasattr(backend, "one_pass_fits") else True, device, group)
+    if one_pass:
         offsets, keys, vals = backend.hash_all()
         keys, vals = exchange([keys, vals], offsets, group)                       # C1: records of all iterations to bucket owners
+        if not _every_rank_agrees(int(keys.shape[0] if hasattr(keys, "shape") else len(keys)) < (1 << 32) - 1, device, group):
+            raise RuntimeError("LowHash0: a rank received more low-hash records of all iterations than one sort takes (2^32): "
+                               "run with SHASTA_MI355X_LOWHASH_ONE_PASS=0")
         offsets, pair_keys, tags, used, hist, overflow = backend.buckets_all(keys, vals)
         pair_keys, tags = exchange([pair_keys, tags], offsets, group)             # C2: pair keys + iteration tags to readId0 owners
         backend.merge_all(pair_keys, tags)
@@ -328,7 +349,9 @@ _toc_cache = {}
 
 def _toc_on(toc, device):
     """Markers.toc as an int64 tensor on `device` (kept: the same array is handed in at every step)."""
-    key = (id(toc), str(device))
+    # (keyed on the array AND on what it says -- length, total, a checksum of a sample -- so that a toc changed in place is seen)
+    sample = np.asarray(toc[:: max(1, len(toc) // 4096)], dtype=np.uint64)
+    key = (id(toc), str(device), len(toc), int(toc[-1]) if len(toc) else 0, int(sample.sum(dtype=np.uint64)))
     hit = _toc_cache.get(key)
     if hit is None or hit[0] is not toc:
         _toc_cache.clear()

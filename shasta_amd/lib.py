@@ -25,7 +25,7 @@ EXPORTS = [
     "shasta_mi355x_hash_windows", "shasta_mi355x_banded_dp", "shasta_mi355x_banded_dp_many", "shasta_mi355x_calibrate",
     "shasta_mi355x_pair_table", "shasta_mi355x_read_graph_keep", "shasta_mi355x_alignment_table",
     "shasta_mi355x_set_kmer_ids_device", "shasta_mi355x_memcpy", "shasta_mi355x_free",
-    "shasta_mi355x_lh_begin", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
+    "shasta_mi355x_lh_begin", "shasta_mi355x_lh_one_pass_fits", "shasta_mi355x_lh_hash", "shasta_mi355x_lh_buckets", "shasta_mi355x_lh_merge",
     "shasta_mi355x_lh_finish", "shasta_mi355x_lh_finish_on_device", "shasta_mi355x_lh_hash_all", "shasta_mi355x_lh_buckets_all", "shasta_mi355x_lh_merge_all",
     "shasta_mi355x_align3_run", "shasta_mi355x_align3_batch",
     "shasta_mi355x_find_markers", "shasta_mi355x_find_markers_free",
@@ -387,6 +387,11 @@ class Context:
         self._world = world
         self._planned_iterations = int(params.minHashIterationCount)
         return int(log2.value)
+
+    def lh_one_pass_fits(self):
+        fits = C.c_int(0)
+        self.library._check(self.lib.shasta_mi355x_lh_one_pass_fits(C.c_void_p(self.handle), C.byref(fits)), "shasta_mi355x_lh_one_pass_fits")
+        return bool(fits.value)
 
     def lh_hash(self, iteration):
         """-> (send offsets uint64[world+1], device pointer of keys u32, device pointer of vals u64)."""

@@ -97,7 +97,14 @@ class NumpyBackend:
 
     # The job with all iterations in one pass: the same stages run iteration by iteration here, packed as the HIP stages
     # pack them (keys owner << 56 | iteration << 32 | bucket id, each owner's records contiguous; pair keys with tags).
+    def one_pass_fits(self):
+        # (SHASTA_TEST_NO_ONE_PASS_ON_RANK=<r>: rank r alone says no -- every rank must then run iteration after iteration.)
+        import os
+        self.asked_one_pass = True
+        return os.environ.get("SHASTA_TEST_NO_ONE_PASS_ON_RANK") != str(self.rank)
+
     def hash_all(self):
+        self.ran_one_pass = True
         iterations = int(self.p.minHashIterationCount)
         per_owner_keys = [[] for _ in range(self.world)]
         per_owner_vals = [[] for _ in range(self.world)]

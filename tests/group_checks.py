@@ -89,3 +89,26 @@ def errors_do_not_hang(lib):
         lib.lowhash0_multi(toc, data7, None, abi.default_lowhash0_params(log2MinHashBucketCount=3), (0, 0))
     with pytest.raises(RuntimeError):
         lib.lowhash0_multi(toc, data7, None, abi.default_lowhash0_params(), (0, 99))      # no such device
+
+
+def one_pass_that_does_not_fit(lib, oracle_lib, devices=(0, 0, 0)):
+    """SHASTA_MI355X_ONE_PASS_RECORD_LIMIT lowered until the records of all iterations do not fit "one sort": the group (every
+    device asks its own context, all must agree) and the one-device call fall back to iteration after iteration -- same results."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oracle import bindings; from shasta_amd import abi, lib as libmod; from tests import support\n"
+            "lib = libmod.Library(%r); orc = bindings.OracleLib()\n"
+            "toc, kmer, data7 = support.small_marker_set(n_reads=150, genome_markers=9000, seed=64)\n"
+            "p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=2)\n"
+            "ref = orc.lowhash0(toc, data7, None, p)\n"
+            "support.same_lowhash(lib.lowhash0_multi(toc, data7, None, p, %r), ref)\n"
+            "support.same_lowhash(lib.lowhash0(toc, data7, None, p), ref)\n"
+            "print('fell back and agreed')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), lib.path, tuple(devices))
+    # (a process of its own: the limit is read once per process)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SHASTA_MI355X_ONE_PASS_RECORD_LIMIT="100000", SHASTA_MI355X_DEBUG_ONE_PASS="1"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "fell back and agreed" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.stderr.count("iteration after iteration") >= 1 + len(devices)          # the one-device call and every device of the group
+    return out.stderr

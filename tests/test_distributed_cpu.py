@@ -28,6 +28,11 @@ def _worker(rank, world, port, out_dir, seed, kw):
         backend = dist_support.NumpyBackend(toc, kmer, flags, bindings.OracleLib())
         boundaries = distributed.read_boundaries(toc, world)
         out = distributed.lowhash0(backend, p, 120, boundaries)
+        # One rank that cannot take all iterations in one pass (SHASTA_TEST_NO_ONE_PASS_ON_RANK) sends every rank down the
+        # iteration-by-iteration path: the decision is collective.
+        if p.minHashIterationCount != 0:
+            assert getattr(backend, "asked_one_pass", False)
+            assert getattr(backend, "ran_one_pass", False) == (os.environ.get("SHASTA_TEST_NO_ONE_PASS_ON_RANK") is None)
         everything = distributed.gather_candidates(out.candidates)
         lo, hi = distributed.candidate_slice(len(everything), rank, world)
         share, total = distributed.candidate_share(out.candidates)
@@ -80,6 +85,11 @@ def test_sharded_lowhash0_equals_single_process(oracle_lib, world, seed, kw):
             assert lo == covered
             covered = hi
         assert covered == len(ref.candidates)
+
+
+def test_one_rank_that_cannot_take_one_pass_sends_every_rank_down_the_other_path(oracle_lib, monkeypatch):
+    monkeypatch.setenv("SHASTA_TEST_NO_ONE_PASS_ON_RANK", "1")
+    test_sharded_lowhash0_equals_single_process(oracle_lib, 3, 66, dict(hashFraction=0.03, minFrequency=1, minHashIterationCount=4, minBucketSize=2, maxBucketSize=30))
 
 
 def test_read_boundaries_balance_markers():

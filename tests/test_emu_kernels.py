@@ -274,6 +274,7 @@ def test_several_devices_behind_one_call(emu_lib, oracle_lib):
     from tests import group_checks
     assert group_checks.lowhash0_and_aligners(emu_lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_reads=160, limit=300) == 4
     group_checks.errors_do_not_hang(emu_lib)
+    group_checks.one_pass_that_does_not_fit(emu_lib, oracle_lib)
 
 
 def test_lowhash0_calls_of_one_context_share_their_allocations(emu_lib, oracle_lib):

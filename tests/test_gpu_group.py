@@ -19,3 +19,8 @@ def test_group_errors_do_not_hang(gpu_lib):
 def test_adversarial_lowhash0_through_the_group(gpu_lib, oracle_lib):
     from tests import group_checks
     assert group_checks.adversarial_lowhash0(gpu_lib, oracle_lib) > 15
+
+
+def test_a_job_whose_iterations_do_not_fit_one_pass_falls_back_on_every_device(gpu_lib, oracle_lib):
+    from tests import group_checks
+    group_checks.one_pass_that_does_not_fit(gpu_lib, oracle_lib)
