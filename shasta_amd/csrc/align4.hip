@@ -128,7 +128,8 @@ struct BatchScratch {
     DeviceBuffer<uint32_t> pairList, bigScratch;
     DeviceBuffer<CellsChunk> chunks;
     DeviceBuffer<uint32_t> dpKeysA, dpKeysB, dpIdsA, dpIdsB;    // tasks sorted by (class, iterations)
-    DeviceBuffer<uint64_t> bundleWords;
+    DeviceBuffer<uint64_t> bundleWords;         // where every bundle's trace begins
+    DeviceBuffer<DpControl> dpControl;
     DeviceBuffer<DpEnd> ends;
     PinnedBuffer pinRows, pinToc, pinBytes, pinStatus, pinOrdToc, pinOrdinals;   // device-to-host staging
     DeviceBuffer<uint64_t> bigOffsets;
@@ -322,35 +323,35 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     b.dpKeysA.reserve(taskCount, stream); b.dpKeysB.reserve(taskCount, stream);
     b.dpIdsA.reserve(taskCount, stream); b.dpIdsB.reserve(taskCount, stream);
     b.ordCap.reserve(uint64_t(taskCount) + 1, stream);
-    b.scanTemp64.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
     b.results.reserve(uint64_t(taskCount) + extraTasks, stream); b.ends.reserve(taskCount, stream);
-    b.counters.reserve(16, stream); b.dpCells.reserve(2 + 2 * DP_CLASSES, stream);
-    HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
-    HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, (2 + 2 * DP_CLASSES) * sizeof(unsigned long long), stream));
+    b.dpControl.reserve(1, stream);
+    DpControl* const control = b.dpControl.data();
+    // What the preparation counts lives in one block (align4_dp.hpp, DpControl): one memset before, one copy to the host after.
+    HIP_CHECK(hipMemsetAsync(control, 0, sizeof(DpControl), stream));
     KernelTimers::Span prepareSpan;
-    if(timers) prepareSpan = timers->begin("DP task sizes, sort by (class, length), bundles", stream);
+    if(timers) prepareSpan = timers->begin("DP task sizes, order by (class, length), bundles", stream);
+    // The tasks in the order (class, length) by one counting pass (align4_dp.hpp): keys and bin counts, the bins' first positions, every
+    // task to its place.  Their ranges of the ordinal scratch come from a cursor in the same kernel (b.ordCap = the ranges' starts).
     hipLaunchKernelGGL(dpSizeKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
-        in.tasks, in.pairs, taskCount,
-        b.dpKeysA.data(), b.dpIdsA.data(), b.ordCap.data(), b.counters.data() + 1, b.dpCells.data());
-    exclusiveScan<uint64_t>(b.ordCap.data(), b.ordCap.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
-    const bool inB = radixSort<uint32_t, uint32_t, true>(b.dpKeysA.data(), b.dpKeysB.data(), b.dpIdsA.data(), b.dpIdsB.data(),
-        taskCount, DP_SORT_KEY_BITS, *ws.sortWs, stream);
-    const uint32_t* sortedKeys = inB ? b.dpKeysB.data() : b.dpKeysA.data();
-    const uint32_t* sortedIds = inB ? b.dpIdsB.data() : b.dpIdsA.data();
-    f.sortedIds = sortedIds; f.denseCount = taskCount;
+        in.tasks, in.pairs, taskCount, b.dpKeysA.data(), b.ordCap.data(), control, sparse ? 0 : 1);
+    hipLaunchKernelGGL(dpBinScanKernel, dim3(1), dim3(1024), 0, stream, control);
+    hipLaunchKernelGGL(dpScatterKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
+        (const uint32_t*)b.dpKeysA.data(), taskCount, control, b.dpKeysB.data(), b.dpIdsB.data());
     HIP_CHECK(hipGetLastError());
+    const uint32_t* sortedKeys = b.dpKeysB.data();
+    const uint32_t* sortedIds = b.dpIdsB.data();
+    f.sortedIds = sortedIds; f.denseCount = taskCount;
     uint32_t* classCounts = f.classCounts;
     unsigned long long* sums = f.sums;
-    uint64_t ordTotalEarly = 0;
     if(sparse) {
         // K10s (align4_sparse.hpp): every task whose alignment is the unique optimal chain of the matches inside its band gets
         // it from those matches; the dense kernels below run what is left.  The tasks' ordered hits need room that depends on the
         // ordinal total: one synchronisation earlier than the dense path takes its own.
         MI355X_ASSERT(reserveOrdinals);
         if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
-        ordTotalEarly = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
+        const uint64_t ordTotalEarly = readDevice(&control->ordCursor, stream);      // synchronises
         b.ordScratch.reserve(2 * (ordTotalEarly + extraOrdinals) + 2, stream);
-        b.sparseSorted.reserve(2 * ordTotalEarly + 64ULL * taskCount + 4, stream);
+        b.sparseSorted.reserve(2 * ordTotalEarly + 4, stream);
         b.sparseInBand.reserve(taskCount, stream); b.sparseState.reserve(taskCount, stream);
         b.denseFlags.reserve(uint64_t(taskCount) + 1, stream); b.densePositions.reserve(uint64_t(taskCount) + 1, stream);
         b.scanTemp32.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
@@ -367,30 +368,32 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
             (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data());
         HIP_CHECK(hipGetLastError());
         if(timers) (void)timers->end(span, 0, taskCount);
-        if(timers) prepareSpan = timers->begin("DP task sizes, sort by (class, length), bundles", stream);
-        // The sorted list without the certified tasks (into the sort's other pair of buffers), its class counts and sums.
-        uint32_t* const denseKeys = inB ? b.dpKeysA.data() : b.dpKeysB.data();
-        uint32_t* const denseIds = inB ? b.dpIdsA.data() : b.dpIdsB.data();
+        if(timers) prepareSpan = timers->begin("DP task sizes, order by (class, length), bundles", stream);
+        // The ordered list without the certified tasks (a compaction keeps the order), its class counts and sums.
+        uint32_t* const denseKeys = b.dpKeysA.data();
+        uint32_t* const denseIds = b.dpIdsA.data();
         hipLaunchKernelGGL(dpDenseFlagsKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream, sortedIds, (const uint8_t*)b.sparseState.data(), taskCount, b.denseFlags.data());
         exclusiveScan<uint32_t>(b.denseFlags.data(), b.densePositions.data(), uint64_t(taskCount) + 1, b.scanTemp32.data(), stream);
-        HIP_CHECK(hipMemsetAsync(b.counters.data() + 1, 0, DP_CLASSES * sizeof(uint32_t), stream));
-        HIP_CHECK(hipMemsetAsync(b.dpCells.data() + 2, 0, 2 * DP_CLASSES * sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(dpDenseListKernel, dim3(divUp(taskCount, 256)), dim3(256), 0, stream,
             sortedKeys, sortedIds, (const uint32_t*)b.denseFlags.data(), (const uint32_t*)b.densePositions.data(), taskCount, in.tasks, in.pairs,
-            denseKeys, denseIds, b.counters.data() + 1, b.dpCells.data());
+            denseKeys, denseIds, control->classCounts, control->sums);
         HIP_CHECK(hipGetLastError());
         sortedKeys = denseKeys; sortedIds = denseIds; f.sortedIds = denseIds;
     }
-    // The bundles' trace words and their scan before the host knows the class counts (a thread per possible bundle: there are
-    // no more bundles than tasks): one synchronisation for the counts, the ordinal total and the trace total.
+    // Where every bundle's trace lies (a thread per possible bundle: there are no more bundles than tasks), before the host knows
+    // the class counts: one synchronisation for the counts, the ordinal total and the trace total.
     b.bundleWords.reserve(uint64_t(taskCount) + 1, stream);
     hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
-        sortedKeys, (const uint32_t*)(b.counters.data() + 1), taskCount, b.bundleWords.data());
-    exclusiveScan<uint64_t>(b.bundleWords.data(), b.bundleWords.data(), uint64_t(taskCount) + 1, b.scanTemp64.data(), stream);
-    HIP_CHECK(hipMemcpyAsync(classCounts, b.counters.data() + 1, sizeof(f.classCounts), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(sums, b.dpCells.data(), sizeof(f.sums), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(&f.traceWords, b.bundleWords.data() + taskCount, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    const uint64_t ordTotal = readDevice(b.ordCap.data() + taskCount, stream);      // synchronises
+        sortedKeys, control, taskCount, b.bundleWords.data());
+    HIP_CHECK(hipGetLastError());
+    struct { unsigned long long sums[2 + 2 * DP_CLASSES], ordCursor, traceCursor; uint32_t classCounts[DP_CLASSES]; } head;
+    static_assert(sizeof(head) <= DP_CONTROL_HEAD_BYTES && offsetof(DpControl, ordCursor) == sizeof(head.sums), "DpControl's head");
+    HIP_CHECK(hipMemcpyAsync(&head, control, sizeof(head), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::memcpy(classCounts, head.classCounts, sizeof(f.classCounts));
+    std::memcpy(sums, head.sums, sizeof(f.sums));
+    f.traceWords = head.traceCursor;
+    const uint64_t ordTotal = head.ordCursor;
     const DpClassLayout layout = dpClassLayout(classCounts);
     MI355X_ASSERT(sparse ? layout.taskStart[DP_CLASSES] <= taskCount : layout.taskStart[DP_CLASSES] == taskCount);
     f.denseCount = layout.taskStart[DP_CLASSES];

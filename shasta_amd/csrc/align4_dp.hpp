@@ -73,45 +73,115 @@ constexpr int DP_SORT_KEY_BITS = 27;
 // What the forward kernel leaves for the traceback of a task.
 struct DpEnd { uint64_t traceOffset; int32_t bestI, bestJ, score; uint32_t laneBase, bundleIterations, pad; };   // bundleIterations: of the longest task of the bundle
 
-// Per task: sort key (class, iterations), ordinal capacity, statistics.
+// The tasks of a batch are put in the order (class, length) by ONE counting pass, not by a radix sort: nothing needs the order to
+// be exact or stable -- a bundle wants tasks of about the same length (its trace is laid out for its longest), a launch wants its
+// longest bundles first -- and a radix sort of 3e5 keys is twenty launches of a few microseconds each that wait, one after the
+// other, behind the other workers' kernels (round 3: 0.5 ms alone, 7 ms in flight per batch).  A task's bin: its class and its
+// iteration count to one part in 64 (exact below 256); the order inside a bin is whatever the atomics make it.
+constexpr int DP_BINS_PER_CLASS = 2048, DP_BINS = DP_CLASSES * DP_BINS_PER_CLASS;
+__host__ __device__ inline uint32_t dpBinOfKey(uint32_t key)
+{
+    const uint32_t cls = key >> 24, iters = dpSortKeyIterations(key);
+    uint32_t q = iters;
+    if(iters >= 256u) {
+        const uint32_t e = 31u - uint32_t(__builtin_clz(iters));            // 8 .. 23
+        q = 256u + (e - 8u) * 64u + ((iters >> (e - 6u)) & 63u);
+    }
+    return cls * uint32_t(DP_BINS_PER_CLASS) + q;
+}
+// Everything the DP's preparation counts, in one block of device memory (one memset before, one copy to the host after).
+struct DpControl {
+    unsigned long long sums[2 + 2 * DP_CLASSES];     // [0] DP cells of all tasks, [1] unused, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c (of the tasks the dense kernels run)
+    unsigned long long ordCursor, traceCursor;       // aligned pairs reserved for the tasks; trace words laid out for the bundles
+    uint32_t classCounts[DP_CLASSES];                // tasks per class (of the tasks the dense kernels run)
+    uint32_t pad[8];
+    uint32_t bins[DP_BINS];                          // tasks per bin, then (dpBinScanKernel) the bin's first position
+    uint32_t cursors[DP_BINS];
+};
+constexpr size_t DP_CONTROL_HEAD_BYTES = offsetof(DpControl, bins);
+
+// Per task: key (class, iterations), its bin's count, its range of the ordinal scratch (min(nx, ny) + 32 pairs, handed out by a cursor:
+// a wavefront takes its tasks' total in one atomic -- the ranges are in no order), statistics.
 __global__ void __launch_bounds__(256)
 dpSizeKernel(const DpTask* __restrict__ tasks, const PairDesc* __restrict__ pairs, uint32_t taskCount,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t* __restrict__ ordCap,
-    uint32_t* __restrict__ classCounts, unsigned long long* __restrict__ sums)   // sums[0] dp cells, sums[1] trace word bound, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c
+    uint32_t* __restrict__ keys, uint64_t* __restrict__ ordOffsets, DpControl* __restrict__ control, int countClasses)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long cells = 0, words = 0, bytes = 0;
+    unsigned long long cells = 0, bytes = 0;
+    uint32_t room = 0;
     int cls = -1;
     if(t < taskCount) {
         const DpTask task = tasks[t];
         const PairDesc pd = pairs[task.pair];
         const DpGeometry g = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
         cls = g.cls;
-        keys[t] = dpSortKey(g.cls, g.iters);
-        ids[t] = t;
-        ordCap[t] = min(pd.nx, pd.ny);
+        const uint32_t key = dpSortKey(g.cls, g.iters);
+        keys[t] = key;
+        atomicAdd(&control->bins[dpBinOfKey(key)], 1u);
+        room = min(pd.nx, pd.ny) + 32u;          // (the 32 beyond the alignment's longest: the sparse path's list of the task's hits takes twice this room, align4_sparse.hpp)
         cells = (unsigned long long)(pd.nx) * (unsigned long long)(task.bandMax - task.bandMin + 1);
-        words = (unsigned long long)(g.iters) * (unsigned long long)(2 * dpDiagonals(g.cls)) + 32;
         bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
-    } else if(t == taskCount) {
-        ordCap[t] = 0;
+    }
+    {
+        uint32_t inclusive = room;
+#pragma unroll
+        for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(laneId() >= d) inclusive += o; }
+        unsigned long long base = 0;
+        if(laneId() == WAVE - 1 && inclusive) base = atomicAdd(&control->ordCursor, (unsigned long long)inclusive);
+        base = __shfl(base, WAVE - 1, WAVE);
+        if(t < taskCount) ordOffsets[t] = base + inclusive - room;
     }
     // Per class: one atomic per wavefront and class present in it (tasks of a wave mostly share a
     // class after the cells kernels); one atomic per task serialises the whole launch on six addresses.
+    // (countClasses = 0: the dense list's kernel counts the classes, of the tasks the sparse path leaves.)
+    if(countClasses) {
 #pragma unroll
-    for(int c = 0; c < DP_CLASSES; c++) {
-        const uint64_t votes = __ballot(cls == c);
-        if(votes == 0) continue;
-        unsigned long long classCells = cls == c ? cells : 0, classBytes = cls == c ? bytes : 0;
-        for(int d = 32; d >= 1; d >>= 1) { classCells += __shfl_down(classCells, d, WAVE); classBytes += __shfl_down(classBytes, d, WAVE); }
-        if(laneId() == 0) {
-            atomicAdd(&classCounts[c], uint32_t(__popcll(votes)));
-            atomicAdd(&sums[2 + c], classCells);
-            atomicAdd(&sums[2 + DP_CLASSES + c], classBytes);
+        for(int c = 0; c < DP_CLASSES; c++) {
+            const uint64_t votes = __ballot(cls == c);
+            if(votes == 0) continue;
+            unsigned long long classCells = cls == c ? cells : 0, classBytes = cls == c ? bytes : 0;
+            for(int d = 32; d >= 1; d >>= 1) { classCells += __shfl_down(classCells, d, WAVE); classBytes += __shfl_down(classBytes, d, WAVE); }
+            if(laneId() == 0) {
+                atomicAdd(&control->classCounts[c], uint32_t(__popcll(votes)));
+                atomicAdd(&control->sums[2 + c], classCells);
+                atomicAdd(&control->sums[2 + DP_CLASSES + c], classBytes);
+            }
         }
     }
-    for(int d = 32; d >= 1; d >>= 1) { cells += __shfl_down(cells, d, WAVE); words += __shfl_down(words, d, WAVE); }
-    if(laneId() == 0 && cells) { atomicAdd(&sums[0], cells); atomicAdd(&sums[1], words); }
+    for(int d = 32; d >= 1; d >>= 1) cells += __shfl_down(cells, d, WAVE);
+    if(laneId() == 0 && cells) atomicAdd(&control->sums[0], cells);
+}
+
+// bins[] -> first positions (one workgroup: 16384 bins are 16 per thread).
+__global__ void __launch_bounds__(1024)
+dpBinScanKernel(DpControl* __restrict__ control)
+{
+    __shared__ uint32_t waveSums[16];
+    constexpr int PER = DP_BINS / 1024;
+    const int lane = laneId(), wave = int(threadIdx.x) >> 6;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for(int k = 0; k < PER; k++) { v[k] = control->bins[threadIdx.x * PER + k]; sum += v[k]; }
+    uint32_t inclusive = sum;
+#pragma unroll
+    for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
+    if(lane == WAVE - 1) waveSums[wave] = inclusive;
+    __syncthreads();
+    uint32_t running = inclusive - sum;
+    for(int w = 0; w < wave; w++) running += waveSums[w];
+#pragma unroll
+    for(int k = 0; k < PER; k++) { control->bins[threadIdx.x * PER + k] = running; running += v[k]; }
+}
+
+// Every task to its place: its bin's first position + the next free one of the bin.
+__global__ void __launch_bounds__(256)
+dpScatterKernel(const uint32_t* __restrict__ keys, uint32_t taskCount, DpControl* __restrict__ control, uint32_t* __restrict__ sortedKeys, uint32_t* __restrict__ sortedIds)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= taskCount) return;
+    const uint32_t key = keys[t], bin = dpBinOfKey(key);
+    const uint32_t at = control->bins[bin] + atomicAdd(&control->cursors[bin], 1u);
+    sortedKeys[at] = key; sortedIds[at] = t;
 }
 
 // Trace words of each bundle (64/G consecutive tasks of the sorted list of one class).
@@ -130,25 +200,33 @@ __host__ __device__ inline DpClassLayout dpClassLayout(const uint32_t* classCoun
 }
 
 // One thread per possible bundle (`capacity` of them: the host does not know the class counts yet); the class layout from the
-// counts dpSizeKernel left on the device.  Words of a position beyond the last bundle: 0, so that the exclusive scan over all
-// `capacity` + 1 positions leaves the total at the end.
+// counts on the device.  A bundle's trace: room for its longest task (any of them may be: the order inside a bin is not by
+// length), rounded to 256 bytes so that the traceback's chunks are whole cache lines; where it lies: handed out by a cursor, a
+// wavefront's bundles in one atomic.
 __global__ void __launch_bounds__(256)
-dpBundleKernel(const uint32_t* __restrict__ sortedKeys, const uint32_t* __restrict__ classCounts, uint32_t capacity, uint64_t* __restrict__ bundleWords)
+dpBundleKernel(const uint32_t* __restrict__ sortedKeys, DpControl* __restrict__ control, uint32_t capacity, uint64_t* __restrict__ bundleOffsets)
 {
     const uint32_t bundle = blockIdx.x * blockDim.x + threadIdx.x;
-    if(bundle > capacity) return;
-    const DpClassLayout layout = dpClassLayout(classCounts);
+    const DpClassLayout layout = dpClassLayout(control->classCounts);
     const uint32_t total = layout.bundleStart[DP_CLASSES];
-    if(bundle >= total) { bundleWords[bundle] = 0; return; }
-    int cls = 0;
-    while(bundle >= layout.bundleStart[cls + 1]) ++cls;
-    const uint32_t T = 64u / uint32_t(dpLanes(cls));
-    const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
-    const uint32_t end = min(first + T, layout.taskStart[cls + 1]);
-    // The task of the bundle with the most iterations = its last (ascending list).  Rounded to 256 bytes so that the
-    // traceback's chunks are whole cache lines.
-    const uint32_t iterations = dpSortKeyIterations(sortedKeys[end - 1]);
-    bundleWords[bundle] = (uint64_t(iterations) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
+    unsigned long long words = 0;
+    if(bundle < total && bundle <= capacity) {
+        int cls = 0;
+        while(bundle >= layout.bundleStart[cls + 1]) ++cls;
+        const uint32_t T = 64u / uint32_t(dpLanes(cls));
+        const uint32_t first = layout.taskStart[cls] + (bundle - layout.bundleStart[cls]) * T;
+        const uint32_t end = min(first + T, layout.taskStart[cls + 1]);
+        uint32_t iterations = 0;
+        for(uint32_t k = first; k < end; k++) iterations = max(iterations, dpSortKeyIterations(sortedKeys[k]));
+        words = (uint64_t(iterations) * uint64_t(2 * dpDiagonals(cls)) + 31) & ~31ULL;
+    }
+    unsigned long long inclusive = words;
+#pragma unroll
+    for(int d = 1; d < WAVE; d <<= 1) { const unsigned long long o = __shfl_up(inclusive, d, WAVE); if(laneId() >= d) inclusive += o; }
+    unsigned long long base = 0;
+    if(laneId() == WAVE - 1 && inclusive) base = atomicAdd(&control->traceCursor, inclusive);
+    base = __shfl(base, WAVE - 1, WAVE);
+    if(bundle < total && bundle <= capacity) bundleOffsets[bundle] = base + inclusive - words;
 }
 
 // ---- tie policy --------------------------------------------------------------------------------

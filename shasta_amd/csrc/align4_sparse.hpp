@@ -36,8 +36,9 @@ constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
 constexpr int SPARSE_RING = 64;                              // hits a lane can look back
 enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2 };
 
-// Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets = exclusive scan of min(nx, ny) over the tasks).
-__host__ __device__ inline uint64_t sparseListBase(const uint64_t* ordOffsets, uint32_t t) { return 2 * ordOffsets[t] + 64ULL * t; }
+// Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets[t] = where the task's min(nx, ny) + 32 pairs of
+// the ordinal scratch begin, dpSizeKernel: twice that, in words, is a range of its own for every task).
+__host__ __device__ inline uint64_t sparseListBase(const uint64_t* ordOffsets, uint32_t t) { return 2 * ordOffsets[t]; }
 __host__ __device__ inline uint32_t sparseListCapacity(uint32_t nx, uint32_t ny) { return 2u * (nx < ny ? nx : ny) + 64u; }
 __device__ __forceinline__ uint32_t nibbleSum(uint32_t v)
 {
@@ -220,14 +221,26 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);
     if(!empty) {
-        for(int32_t at = bestAt; ; ) {
-            const uint32_t e = list[at];
-            const int32_t hp = int32_t(e >> 17), hs = hp + lo + int32_t((e >> 7) & 1023u);
-            --pos;
-            *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hp), uint32_t(hs)) : make_uint2(uint32_t(hs), uint32_t(hp));
-            const int32_t back = int32_t(e & 127u);
-            if(back == 0) break;
-            at -= back;
+        // (Four entries per round trip to memory: the chain mostly steps back by one, and a walk of dependent single loads --
+        // a load's address known only when the one before it has arrived -- would be as long as the chain times the latency.)
+        int32_t at = bestAt;
+        bool more = true;
+        while(more) {
+            uint32_t window[4];
+#pragma unroll
+            for(int a = 0; a < 4; a++) window[a] = list[max(at - a, 0)];
+            const int32_t top = at;
+#pragma unroll
+            for(int a = 0; a < 4; a++) {
+                if(more && top - a == at) {
+                    const uint32_t e = window[a];
+                    const int32_t hp = int32_t(e >> 17), hs = hp + lo + int32_t((e >> 7) & 1023u);
+                    --pos;
+                    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hp), uint32_t(hs)) : make_uint2(uint32_t(hs), uint32_t(hp));
+                    const int32_t back = int32_t(e & 127u);
+                    if(back == 0) more = false; else at -= back;
+                }
+            }
         }
     }
     DpEnd e; e.traceOffset = 0; e.bestI = e.bestJ = 0; e.score = empty ? matchless : best; e.laneBase = 0; e.bundleIterations = 0; e.pad = 0;
