@@ -113,12 +113,30 @@ struct BatchScratch {
     DeviceBuffer<PairDesc> pairs;
     DeviceBuffer<shasta_oriented_read_pair> candidates;
     DeviceBuffer<DpTask> tasks;
-    DeviceBuffer<uint32_t> counters;            // [0]=taskCount, [1..8]=class counts, [12]=tied candidates seen by winnerKernel
+    // What a batch starts from zero -- the best component and winner of every candidate, its flags, the task counters -- lies in
+    // ONE block that one memset clears (five memsets in a row at the head of every batch until round 3): views into zeroBlock.
+    template<class T> struct View { T* p = nullptr; T* data() const { return p; } };
+    DeviceBuffer<uint8_t> zeroBlock;
+    View<uint32_t> counters;                    // [0]=taskCount, [12]=tied candidates seen by winnerKernel, [13]=wide components
+    void layoutZeroed(uint64_t n, hipStream_t stream)
+    {
+        const uint64_t bytes = 8 * n + 4 * n + 64 + n + n;
+        zeroBlock.reserve(bytes + 16, stream);
+        uint8_t* at = zeroBlock.data();
+        pairBest.p = reinterpret_cast<unsigned long long*>(at); at += 8 * n;
+        pairWinner.p = reinterpret_cast<uint32_t*>(at); at += 4 * n;
+        counters.p = reinterpret_cast<uint32_t*>(at); at += 64;
+        pairFlags.p = at; at += n;
+        pairTie.p = at;
+        HIP_CHECK(hipMemsetAsync(zeroBlock.data(), 0, bytes, stream));
+    }
     DeviceBuffer<uint32_t> tieMembers, tieKeys, tieCounts;     // resolveComponentTies
     DeviceBuffer<CellsChunk> tieChunks;
-    DeviceBuffer<uint8_t> pairFlags, pairTie, status;
-    DeviceBuffer<unsigned long long> pairBest, dpCells;
-    DeviceBuffer<uint32_t> pairWinner, classLists, storedFlags, storedIndex, scanTemp32;
+    View<uint8_t> pairFlags, pairTie;
+    DeviceBuffer<uint8_t> status;
+    View<unsigned long long> pairBest;
+    View<uint32_t> pairWinner;
+    DeviceBuffer<uint32_t> classLists, storedFlags, storedIndex, scanTemp32;
     DeviceBuffer<uint64_t> traceWords, ordCap, scanTemp64, trace, ordCounts, sizes;
     DeviceBuffer<uint32_t> ordScratch, ordOut;
     DeviceBuffer<DpResult> results;
@@ -1023,20 +1041,14 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         uint32_t taskCapacity = 8 * n + 1024;
         if(const char* e = std::getenv("SHASTA_MI355X_INITIAL_TASKS")) taskCapacity = uint32_t(std::max(1L, std::atol(e)));
         b.pairs.reserve(n, stream); b.candidates.reserve(n, stream); b.tasks.reserve(taskCapacity, stream);
-        b.counters.reserve(16, stream); b.pairFlags.reserve(n, stream); b.pairTie.reserve(n, stream); b.status.reserve(n, stream);
-        b.pairBest.reserve(n, stream); b.dpCells.reserve(1, stream); b.pairWinner.reserve(n, stream);
+        b.status.reserve(n, stream);
+        b.layoutZeroed(n, stream);       // counters, pairFlags, pairTie, pairBest, pairWinner: one block, one memset
         b.storedFlags.reserve(n + 1, stream); b.storedIndex.reserve(n + 1, stream);
         b.scanTemp32.reserve(scanTempElements(uint64_t(n) + 1), stream);
         b.ordCounts.reserve(n + 1, stream); b.sizes.reserve(n + 1, stream);
         b.rows.reserve(n, stream); b.rowsOut.reserve(n, stream); b.compressedToc.reserve(n + 1, stream);
         HIP_CHECK(hipMemcpyAsync(b.pairs.data(), hostPairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(b.candidates.data(), candidates + batchBegin, n * sizeof(shasta_oriented_read_pair), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemsetAsync(b.counters.data(), 0, 16 * sizeof(uint32_t), stream));
-        HIP_CHECK(hipMemsetAsync(b.pairFlags.data(), 0, n, stream));
-        HIP_CHECK(hipMemsetAsync(b.pairTie.data(), 0, n, stream));
-        HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, n * sizeof(unsigned long long), stream));
-        HIP_CHECK(hipMemsetAsync(b.pairWinner.data(), 0, n * sizeof(uint32_t), stream));
-        HIP_CHECK(hipMemsetAsync(b.dpCells.data(), 0, sizeof(unsigned long long), stream));
         HitLists hitLists{nullptr, nullptr, nullptr};
         if(listHits) {
             b.hits.reserve(hostHitBase[n] + 1, stream); b.hitBase.reserve(uint64_t(n) + 1, stream); b.hitMeta.reserve(n, stream);
@@ -1193,12 +1205,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             bool firstRoundLaunched = false, firstRoundAny = false;
             if(devicePrepare) {
                 int tabledBits = 1;
-                while(tabledBits < 58 && (ctx.hostToc.back() >> tabledBits) != 0) ++tabledBits;
+                while(tabledBits < 58 && ((2 * ctx.readCount) >> tabledBits) != 0) ++tabledBits;
                 b.prepareKeysA.reserve(n, stream); b.prepareKeysB.reserve(n, stream); b.prepareIdsA.reserve(n, stream); b.prepareIdsB.reserve(n, stream);
                 b.prepareInfo.reserve(CELLS_PREPARE_INFO, stream); b.chunks.reserve(n, stream);
                 HIP_CHECK(hipMemsetAsync(b.prepareInfo.data(), 0, CELLS_PREPARE_INFO * sizeof(unsigned long long), stream));
                 hipLaunchKernelGGL(cellsClassKeysKernel, dim3(divUp(n, 256)), dim3(256), 0, stream,
-                    (const PairDesc*)b.pairs.data(), n, classRule, tabledBits, b.prepareKeysA.data(), b.prepareIdsA.data(), b.prepareInfo.data());
+                    (const PairDesc*)b.pairs.data(), (const shasta_oriented_read_pair*)b.candidates.data(), n, classRule, tabledBits, b.prepareKeysA.data(), b.prepareIdsA.data(), b.prepareInfo.data());
                 const bool inB = radixSort<uint64_t, uint32_t, true>(b.prepareKeysA.data(), b.prepareKeysB.data(), b.prepareIdsA.data(), b.prepareIdsB.data(),
                     n, tabledBits + 1 + CELLS_CLASS_BITS, *ws.sortWs, stream);
                 const uint64_t* sortedKeys = inB ? b.prepareKeysB.data() : b.prepareKeysA.data();
@@ -1408,8 +1420,13 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 bigList.swap(nextList); bigLog2.swap(nextLog2);
             }
         }
-        taskCount = readDevice(b.counters.data(), stream);
-        wideCount = readDevice(b.counters.data() + CELLS_WIDE_COUNTER, stream);      // (components / step-2 bands of more than 1024 diagonals, listed from the back)
+        {   // (one copy, one synchronisation for both counters)
+            uint32_t hostCounters[16];
+            HIP_CHECK(hipMemcpyAsync(hostCounters, b.counters.data(), sizeof(hostCounters), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            taskCount = hostCounters[0];
+            wideCount = hostCounters[CELLS_WIDE_COUNTER];      // (components / step-2 bands of more than 1024 diagonals, listed from the back)
+        }
         if(uint64_t(taskCount) + wideCount <= taskCapacity) break;
         // More DP tasks than the list was sized for (many small components per candidate: low-complexity
         // reads, or options that keep nearly every cell).  The count is exact -- stores past the
@@ -1439,7 +1456,6 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs, listHits ? &sparseInput : nullptr);
             out.hadTasks = true;
             const uint32_t allTasks = taskCount + wideCount;
-            HIP_CHECK(hipMemsetAsync(b.counters.data() + 12, 0, sizeof(uint32_t), stream));
             SHASTA_TIMED(ctx, "winnerKernel", stream, 0, allTasks,
                 hipLaunchKernelGGL(winnerKernel, dim3(divUp(allTasks, 256)), dim3(256), 0, stream,
                     (const DpTask*)b.tasks.data(), (const DpResult*)b.results.data(), allTasks,
@@ -1471,9 +1487,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         (void)ctx.timers.end(finalizeSpan, 64ULL * n, n);
         const unsigned gw = divUp((uint64_t(n) + 1) * WAVE, 256);
         HIP_CHECK(hipGetLastError());
-        const uint32_t storedCount = readDevice(b.storedIndex.data() + n, stream);
-        const uint64_t ordTotalOut = readDevice(b.ordCounts.data() + n, stream);
-        const uint64_t byteTotal = readDevice(b.sizes.data() + n, stream);
+        uint32_t storedCount = 0;
+        uint64_t ordTotalOut = 0, byteTotal = 0;
+        HIP_CHECK(hipMemcpyAsync(&storedCount, b.storedIndex.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&ordTotalOut, b.ordCounts.data() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&byteTotal, b.sizes.data() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));          // (one synchronisation for the three totals)
         uint8_t* const bytesPlace = publishSizes(batchIndex, storedCount, byteTotal, wantOrdinals ? ordTotalOut : 0);
         b.bytes.reserve(byteTotal + 1, stream);
         const KernelTimers::Span writeSpan = ctx.timers.begin("compressWriteKernel", stream);
@@ -1834,10 +1853,10 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     ctx.setMarkers(1, toc.data(), nullptr, kmerIds, nullptr);
     hipStream_t stream = ctx.stream;
     BatchScratch b;
-    b.pairs.reserve(taskCount, stream); b.tasks.reserve(taskCount, stream); b.pairBest.reserve(taskCount, stream);
+    b.pairs.reserve(taskCount, stream); b.tasks.reserve(taskCount, stream); b.layoutZeroed(taskCount, stream);
     HIP_CHECK(hipMemcpyAsync(b.pairs.data(), pairs.data(), taskCount * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(b.tasks.data(), tasks.data(), taskCount * sizeof(DpTask), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8 * taskCount, stream));
+
     DeviceOptions opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
@@ -1929,10 +1948,10 @@ void bandedDpUnit(const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t 
     BatchScratch b;
     PairDesc pd; pd.begin0 = 0; pd.begin1 = nx; pd.nx = nx; pd.ny = ny;
     DpTask task; task.pair = 0; task.bandMin = bandMin; task.bandMax = bandMax; task.label = 0;
-    b.pairs.reserve(1, stream); b.tasks.reserve(1, stream); b.pairBest.reserve(1, stream);
+    b.pairs.reserve(1, stream); b.tasks.reserve(1, stream); b.layoutZeroed(1, stream);
     HIP_CHECK(hipMemcpyAsync(b.pairs.data(), &pd, sizeof(pd), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(b.tasks.data(), &task, sizeof(task), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemsetAsync(b.pairBest.data(), 0, 8, stream));
+
     DeviceOptions opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;

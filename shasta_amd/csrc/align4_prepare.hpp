@@ -50,7 +50,7 @@ __host__ __device__ inline CellsChoice cellsChoice(const CellsClassRule& rule, u
 }
 
 // ---- the first round's lists on the device ------------------------------------------------------------------------------
-// Sort key of a candidate: class | swapped | first marker of the tabled oriented read (tabledBits bits).  A STABLE sort leaves
+// Sort key of a candidate: class | swapped | the tabled oriented read's id (tabledBits bits).  A STABLE sort leaves
 // the candidates of a (class, swapped, tabled read) group adjacent and in ascending order -- the groups the host walk made,
 // class by class -- and the candidates of the HBM-scratch kernel (class CELLS_CLASSES) at the end.
 // info: [0 .. CELLS_CLASSES] = first chunk of every class and the number of chunks; [CELLS_INFO_FIRST_BIG] = position of the first
@@ -60,7 +60,7 @@ constexpr int CELLS_INFO_FIRST_BIG = CELLS_CLASSES + 1, CELLS_INFO_CANDIDATES = 
 constexpr int CELLS_PREPARE_INFO = 3 * CELLS_CLASSES + 2;
 
 __global__ void __launch_bounds__(256)
-cellsClassKeysKernel(const PairDesc* __restrict__ pairs, uint32_t n, CellsClassRule rule, int tabledBits,
+cellsClassKeysKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_read_pair* __restrict__ candidates, uint32_t n, CellsClassRule rule, int tabledBits,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ ids, unsigned long long* __restrict__ info)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +70,10 @@ cellsClassKeysKernel(const PairDesc* __restrict__ pairs, uint32_t n, CellsClassR
         const PairDesc pd = pairs[q];
         const CellsChoice choice = cellsChoice(rule, pd.nx, pd.ny);
         cls = choice.cls;
-        const uint64_t tabled = choice.swapped ? pd.begin1 : pd.begin0;
+        // The tabled oriented read by its ID (the same order as by its first marker, in 18 bits where that takes 29: three passes
+        // of the sort below instead of five).
+        const shasta_oriented_read_pair c = candidates[q];
+        const uint64_t tabled = choice.swapped ? (2ULL * c.readIds[1] + (c.isSameStrand ? 0u : 1u)) : 2ULL * c.readIds[0];
         keys[q] = (uint64_t(cls) << (tabledBits + 1)) | (uint64_t(choice.swapped ? 1 : 0) << tabledBits) | tabled;
         ids[q] = q;
         bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
