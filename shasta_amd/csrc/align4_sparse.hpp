@@ -225,7 +225,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
         // a load's address known only when the one before it has arrived -- would be as long as the chain times the latency.)
         int32_t at = bestAt;
         bool more = true;
-        while(more) {
+        for(int32_t rounds = 0; more && rounds <= n; rounds++) {          // (a chain has at most n hits: the walk ends whatever the list holds)
             uint32_t window[4];
 #pragma unroll
             for(int a = 0; a < 4; a++) window[a] = list[max(at - a, 0)];
@@ -238,7 +238,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                     --pos;
                     *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hp), uint32_t(hs)) : make_uint2(uint32_t(hs), uint32_t(hp));
                     const int32_t back = int32_t(e & 127u);
-                    if(back == 0) more = false; else at -= back;
+                    if(back == 0 || back > at || pos == 0) more = false; else at -= back;
                 }
             }
         }

@@ -331,7 +331,17 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int)
     return hipSuccess;
 }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
-hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorInvalidValue; }
+// Device memory comes back POISONED (0xA5 in every byte): a kernel that reads what no kernel, copy or memset wrote -- which fresh
+// pages of the host, zero by the operating system's doing, would forgive, and a GPU's reused memory does not -- computes nonsense
+// here too.  HIPEMU_NO_POISON=1 leaves the bytes as the allocator gives them.
+hipError_t hipMalloc(void** p, size_t n)
+{
+    const size_t bytes = (n + 255) / 256 * 256 + 256;
+    *p = std::aligned_alloc(256, bytes);
+    static const bool poison = [] { const char* e = std::getenv("HIPEMU_NO_POISON"); return !(e && e[0] == '1'); }();
+    if(*p && poison) std::memset(*p, 0xA5, bytes);
+    return *p ? hipSuccess : hipErrorInvalidValue;
+}
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
