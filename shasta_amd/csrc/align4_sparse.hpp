@@ -25,7 +25,8 @@
 //   sparseChainKernel   a LANE per task (the recurrence is sequential in the hits), the work flattened into units -- one
 //                       predecessor looked at, or one hit finished -- so that a lane whose hit needs a long look back (an
 //                       off-chain hit: as many hits back as the band is wide) does not hold the other 63 at their hits; the last
-//                       64 hits of every lane in an LDS ring {ordinals, D, prefix maximum of D}; the chosen predecessor of a hit
+//                       56 hits of every lane in an LDS ring {ordinals, D, prefix maximum of D} whose other 8 slots hold the hits
+//                       the lane needs next; the chosen predecessor of a hit
 //                       written back into the task's list, which the lane then walks from the best end to emit the pairs into
 //                       the task's range of the ordinal scratch, as dpTracebackKernel does.
 //   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
@@ -33,7 +34,8 @@
 
 constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the stream read a task may have here (4-bit counters: 4 KB per wavefront)
 constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
-constexpr int SPARSE_RING = 64;                              // hits a lane can look back
+constexpr int SPARSE_RING = 64;                              // slots of a lane's ring: the hits it can look back on and the next ones it will need
+constexpr int SPARSE_LOOK_BACK = 56;                         // hits a lane can look back
 enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2 };
 
 // Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets[t] = where the task's min(nx, ny) + 32 pairs of
@@ -158,21 +160,50 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     const int32_t np = int32_t(swapped ? pd.nx : pd.ny), ns = int32_t(swapped ? pd.ny : pd.nx);
     const int32_t lo = swapped ? -task.bandMax : task.bandMin;            // s - p lies in [lo, lo + band width)
     uint32_t* __restrict__ const list = sorted + sparseListBase(ordOffsets, t);
-    // The hits arrive four ahead of their use.
-    uint32_t ahead[4];
+    // The hits a lane will need next wait in the ring itself: slots k .. k + 7 hold the raw hits k .. k + 7 (the scan looks back
+    // SPARSE_LOOK_BACK = 56 hits at most, so the 64 slots hold both).  They are topped up at a point that is the same for the whole
+    // wavefront, every eighth turn of the loop: the loads issued at one top-up are written into the ring at the next, eight turns
+    // later, so that nothing inside a turn waits for memory (a lane that read its next hit from memory when it finished one --
+    // or kept them in registers that shift along -- waited a memory latency per hit: the compiler can only place the wait where
+    // the register is next touched, and that is the very next hit).
+    uint32_t pending[4];
+    int32_t fetched = 0, pendingBase = 0, pendingCount = 0;       // hits [0, fetched) are in the ring or consumed; [pendingBase, +pendingCount) are in flight
+    {
+        const int32_t first = min(n, 8);
+        for(int32_t a = 0; a < first; a++) ring[(a & (SPARSE_RING - 1)) * WAVE + lane].x = list[a];
+        fetched = first;
+        pendingBase = fetched; pendingCount = max(0, min(4, n - fetched));
 #pragma unroll
-    for(int a = 0; a < 4; a++) ahead[a] = a < n ? list[a] : 0u;
-    int32_t k = 0, p = int32_t(ahead[0] >> 16), s = int32_t(ahead[0] & 0xffffu);
-    int32_t value = -min(p, s), from = 0, j = 1;
+        for(int a = 0; a < 4; a++) pending[a] = list[n > 0 ? min(pendingBase + a, n - 1) : 0];
+    }
+    int32_t k = 0, p = 0, s = 0;
+    int32_t value = 0, from = 0, j = 1;
     uint32_t ways = 1;
     int32_t prefixMax = SPARSE_NEG, best = SPARSE_NEG, bestAt = -1;
     uint32_t bestWays = 0;
-    bool failed = false, active = n > 0;
-    while(__any(active)) {
-        if(active) {
+    bool failed = false, active = n > 0, haveHit = false;
+    for(uint32_t turn = 1; __any(active); turn++) {
+        if((turn & 7u) == 0u) {
+            // Top-up (wave-uniform): what was asked for a top-up ago goes into the ring; ask for up to four more while fewer than
+            // eight hits lie ahead of the lane.
+#pragma unroll
+            for(int a = 0; a < 4; a++) if(a < pendingCount) ring[((pendingBase + a) & (SPARSE_RING - 1)) * WAVE + lane].x = pending[a];
+            fetched += pendingCount;
+            pendingBase = fetched;
+            pendingCount = active ? max(0, min(min(4, 8 - (fetched - k)), n - fetched)) : 0;
+#pragma unroll
+            for(int a = 0; a < 4; a++) pending[a] = list[n > 0 ? min(pendingBase + a, n - 1) : 0];
+        }
+        if(active && !haveHit && k < fetched) {
+            const uint32_t hit = ring[(k & (SPARSE_RING - 1)) * WAVE + lane].x;
+            p = int32_t(hit >> 16); s = int32_t(hit & 0xffffu);
+            value = -min(p, s); from = 0; j = 1; ways = 1;
+            haveHit = true;
+        }
+        else if(active && haveHit) {
             bool finish = false;
             if(j > k) finish = true;                                       // no hit further back
-            else if(j > SPARSE_RING) { failed = true; active = false; }    // further back than the ring holds: the dense DP takes the task
+            else if(j > SPARSE_LOOK_BACK) { failed = true; active = false; }     // further back than the ring holds: the dense DP takes the task
             else {
                 const uint2 e = ring[((k - j) & (SPARSE_RING - 1)) * WAVE + lane];
                 const int32_t pq = int32_t(e.x >> 16), sq = int32_t(e.x & 0xffffu);
@@ -203,13 +234,8 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                 if(end > best) { best = end; bestAt = k; bestWays = ways; }
                 else if(end == best) bestWays = min(2u, bestWays + ways);
                 ++k;
+                haveHit = false;
                 if(k == n) active = false;
-                else {
-                    ahead[0] = ahead[1]; ahead[1] = ahead[2]; ahead[2] = ahead[3];
-                    ahead[3] = k + 3 < n ? list[k + 3] : 0u;
-                    p = int32_t(ahead[0] >> 16); s = int32_t(ahead[0] & 0xffffu);
-                    value = -min(p, s); from = 0; j = 1; ways = 1;
-                }
             }
         }
     }
