@@ -266,7 +266,10 @@ def roofline_of(name, row, pmc):
     hbm = any(name.startswith(h) or h in name for h in HBM_NATURED)
     r = {"bound": "hbm" if hbm else "valu", "achieved": row["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": row["achieved_GBps"] / HBM_PEAK_GBS, "traffic": row.get("hbm_traffic_bytes_per_launch"), "kernel": name,
-         "avg_launch_ms": row["avg_ms"]}
+         "avg_launch_ms": row["avg_ms"],
+         # (where `traffic` and the VALU instruction count come from: the newest committed PMC summary -- a round that could not
+         # profile keeps the previous round's counters, collected on that round's build of the kernel)
+         "counters_from": os.path.relpath(PMC_FILE, ROOT) if pmc else None}
     if not hbm:
         c = pmc_of(pmc, name) or {}
         r["valu"] = {"peak_wave_instructions_per_s": VALU_PEAK_WAVE_INSTRUCTIONS_PER_S,
@@ -300,7 +303,7 @@ def hbm_budget(markers_total, reads_total, n_gpus, hash_fraction=0.01, iteration
         "lowhash0_bucket_tables": 20.0 * record_rows,
         "lowhash0_pair_keys_ping_pong": 24.0 * pairs,
         "lowhash0_statistics_histograms": 24.0 * r + 16384.0 * iterations,
-        "aligner_scratch_%d_workers" % workers: workers * 5.0e9,
+        "aligner_scratch_%d_workers" % workers: workers * 8.0e9,       # (round 4: + the candidates' match lists and the tasks' ordered hits, align4_sparse.hpp)
     }
     total = sum(parts.values())
     return {"n_gpus": int(n_gpus), "bytes_per_gpu": {k: int(v) for k, v in parts.items()}, "total_GB_per_gpu": total / 1e9,
