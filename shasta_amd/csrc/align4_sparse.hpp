@@ -18,8 +18,9 @@
 // did not fit, reads beyond the tables here) run in the dense kernels exactly as before.  At 100 k reads 87 % of the tasks
 // (85 % of the DP cells) are certified (oracle's census over the same candidates, profiles/r04_sparse_census.txt).
 //
-//   sparseSortKernel    a wavefront per task: the candidate's hit list filtered by the task's band and ordered by the STREAM
-//                       ordinal (the read the cells kernel streamed; either order serves the recurrence, it is symmetric): a
+//   sparseSortKernel    a wavefront per task: the candidate's hit list filtered by the task's band and ordered by the ordinal in
+//                       the TABLED read (fewer than 8192 markers by the cells stage's classes, however long the other read is;
+//                       either order serves the recurrence, it is symmetric): a
 //                       counting sort on 4-bit counters per marker in LDS (two hits of one marker inside a band are common: the
 //                       background of a 15 000-k-mer alphabet; sixteen send the task to the dense DP).
 //   sparseChainKernel   a LANE per task (the recurrence is sequential in the hits), the work flattened into units -- one
@@ -32,7 +33,7 @@
 //   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
 #pragma once
 
-constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the stream read a task may have here (4-bit counters: 4 KB per wavefront)
+constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the read the hits are ordered by (4-bit counters: 4 KB per wavefront): the tabled read, always below this
 constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
 constexpr int SPARSE_RING = 64;                              // slots of a lane's ring: the hits it can look back on and the next ones it will need
 constexpr int SPARSE_LOOK_BACK = 56;                         // hits a lane can look back
@@ -82,7 +83,9 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
     const uint32_t count = meta & 0x7fffffffu;
     const uint64_t begin = hitBase[task.pair];
     const uint32_t capacity = uint32_t(hitBase[task.pair + 1] - begin);
-    const uint32_t streamCount = swapped ? pd.nx : pd.ny;
+    // The order is by the ordinal in the TABLED read (read 1 if the chunk was swapped): it has fewer than 8192 markers whenever a
+    // chunk kernel made the list (the LDS table's classes), however long the streamed read is.
+    const uint32_t streamCount = swapped ? pd.ny : pd.nx;          // (markers of the read the order is by)
     if(meta == HIT_LIST_NONE || count > capacity || streamCount > SPARSE_MAX_STREAM || streamCount == 0) {
         if(lane == 0) state[t] = SPARSE_DENSE;
         return;
@@ -100,7 +103,7 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
         const uint32_t e = list[i < count ? i : 0u];
         const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
         const bool in = i < count && x - y >= task.bandMin && x - y <= task.bandMax;
-        const uint32_t p = uint32_t(swapped ? x : y);
+        const uint32_t p = uint32_t(swapped ? y : x);
         if(in && p < streamCount) {
             const uint32_t shift = 4u * (p & 7u);
             const uint32_t old = atomicAdd(&myCounts[p >> 3], 1u << shift);
@@ -127,7 +130,7 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
         const uint32_t e = list[i < count ? i : 0u];
         const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
         const bool in = i < count && x - y >= task.bandMin && x - y <= task.bandMax;
-        const uint32_t p = uint32_t(swapped ? x : y), s = uint32_t(swapped ? y : x);
+        const uint32_t p = uint32_t(swapped ? y : x), s = uint32_t(swapped ? x : y);
         if(in && p < streamCount) {
             const uint32_t w = p >> 3, shift = 4u * (p & 7u);
             const uint32_t below = nibbleSum(myCounts[w] & ((1u << shift) - 1u));
@@ -157,8 +160,8 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     const PairDesc pd = pairs[task.pair];
     const bool swapped = (hitMeta[task.pair] >> 31) != 0;
     const int32_t n = mine ? int32_t(inBand[t]) : 0;
-    const int32_t np = int32_t(swapped ? pd.nx : pd.ny), ns = int32_t(swapped ? pd.ny : pd.nx);
-    const int32_t lo = swapped ? -task.bandMax : task.bandMin;            // s - p lies in [lo, lo + band width)
+    const int32_t np = int32_t(swapped ? pd.ny : pd.nx), ns = int32_t(swapped ? pd.nx : pd.ny);     // p: the ordinal in the tabled read, s: in the other
+    const int32_t lo = swapped ? task.bandMin : -task.bandMax;            // s - p lies in [lo, lo + band width)
     uint32_t* __restrict__ const list = sorted + sparseListBase(ordOffsets, t);
     // The hits a lane will need next wait in the ring itself: slots k .. k + 7 hold the raw hits k .. k + 7 (the scan looks back
     // SPARSE_LOOK_BACK = 56 hits at most, so the 64 slots hold both).  They are topped up at a point that is the same for the whole
@@ -262,7 +265,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                     const uint32_t e = window[a];
                     const int32_t hp = int32_t(e >> 17), hs = hp + lo + int32_t((e >> 7) & 1023u);
                     --pos;
-                    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hp), uint32_t(hs)) : make_uint2(uint32_t(hs), uint32_t(hp));
+                    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hs), uint32_t(hp)) : make_uint2(uint32_t(hp), uint32_t(hs));
                     const int32_t back = int32_t(e & 127u);
                     if(back == 0 || back > at || pos == 0) more = false; else at -= back;
                 }
