@@ -14,6 +14,13 @@ struct shasta_mi355x_group { Group impl; shasta_mi355x_group(int n, const int* d
 
 static thread_local std::string lastError;
 
+// An aligner call keeps six workers' streams and their side streams busy; the HIP runtime deals a process's streams to
+// GPU_MAX_HW_QUEUES hardware queues -- four unless the environment says otherwise -- and streams that share a queue run one after
+// the other (round 3: 185 ms per aligner call with four queues against 158 with eight when other libraries had created streams
+// first).  A caller who knows nothing of this should not lose 15 %: when the variable is unset, loading this library sets it to
+// eight -- the runtime reads it at its first HIP call, which comes after the loader has run this.  An explicit setting is left alone.
+__attribute__((constructor)) static void defaultHardwareQueues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+
 #define API_BEGIN try {
 #define API_END(rc) } catch(const std::exception& e) { lastError = e.what(); return rc; } \
                       catch(...) { lastError = "unknown error"; return rc; }

@@ -81,3 +81,17 @@ def test_compute_entry_points_fail_loudly_without_a_gpu():
         library.context(0)
     with pytest.raises(RuntimeError):
         library.hash_windows(np.arange(10, dtype=np.uint32), 4, 0)
+
+
+def test_loading_the_library_asks_for_eight_hardware_queues_unless_the_environment_says_otherwise():
+    # api.hip's constructor: GPU_MAX_HW_QUEUES=8 when unset (six aligner workers x (stream + side stream) on the runtime's default
+    # four queues cost 15 % of an aligner call); an explicit setting stays.  In processes of their own: the loader runs once.
+    import subprocess
+    import sys
+    code = ("import ctypes, os\n"
+            "ctypes.CDLL(%r)\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())\n") % libmod.SO_PATH
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "8"
+    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4")).decode().strip() == "4"
