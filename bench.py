@@ -730,6 +730,15 @@ def main():
                                          for k, v in kernels_one_worker.items()}
         if status_counts is not None:
             out["aligner_status"] = dict(zip(("stored", "rejected_by_filters", "empty", "skipped", "component_ties_flagged"), status_counts))
+        if al is not None and not sharded:
+            # The banded DP the reference runs for these candidates (nx x band width cells over all tasks) against what reached the dense
+            # kernels here: the rest came from the matches inside the band (align4_sparse.hpp; SHASTA_MI355X_SPARSE_DP=0: all of it dense).
+            dense_cells = sum(r["work"] for k, r in table.items() if k.startswith("bandedDpForwardKernel")) / steps
+            chain = table.get("sparseChainKernel")
+            out["banded_dp"] = {"reference_cells_per_step": int(al.dp_cell_count), "cells_in_the_dense_kernels_per_step": int(dense_cells),
+                                "share_from_the_matches": (1.0 - dense_cells / al.dp_cell_count) if al.dp_cell_count else None,
+                                "sparse_path": chain is not None,
+                                "reference_cells_per_second": al.dp_cell_count / (elapsed / steps) if elapsed > 0 else None}
         if hash_name:
             h = kernels[hash_name]
             out["hbm_natured_kernel"] = {"kernel": hash_name, "achieved_GBps": h["achieved_GBps"], "frac_of_hbm_peak": h["frac_of_hbm_peak"],

@@ -30,6 +30,7 @@ class FakeResult:
         self.status = np.zeros(n, np.uint8)
         self.status[-1] = abi.SHASTA_ALIGN_REJECTED
         self.device_seconds, self.seconds = 0.4, 0.5
+        self.dp_cell_count = int(4e11)
 
 
 class FakeContext:
@@ -132,6 +133,7 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert parity["alignment_table_equal"] is True and "computeAlignmentTable" in line["config"]["step"]
     assert line["cpu_baseline"]["sorted_markers_seconds"] > 0 and line["cpu_baseline"]["alignment_table_seconds"] > 0
     assert any(k.startswith("alignment table") for k in line["kernels"])
+    assert line["banded_dp"]["sparse_path"] is True and 0.3 < line["banded_dp"]["share_from_the_matches"] < 1.0
     assert any(k.startswith("align4CellsChunkKernel") for k in line["kernels"]) and any(k.startswith("dpTracebackKernel") for k in line["kernels"])
     assert line["config"]["candidates"] > 0 and "workload" in line["config"]
     census = line["dp_tie_sensitive"]             # the checker under the 11 other DP tie policies
