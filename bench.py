@@ -303,7 +303,7 @@ def hbm_budget(markers_total, reads_total, n_gpus, hash_fraction=0.01, iteration
         "lowhash0_bucket_tables": 20.0 * record_rows,
         "lowhash0_pair_keys_ping_pong": 24.0 * pairs,
         "lowhash0_statistics_histograms": 24.0 * r + 16384.0 * iterations,
-        "aligner_scratch_%d_workers" % workers: workers * 8.0e9,       # (round 4: + the candidates' match lists and the tasks' ordered hits, align4_sparse.hpp)
+        "aligner_scratch_%d_workers" % workers: workers * 11.0e9,      # (round 4: + the candidates' match lists, 2.2 GB, and the tasks' ordered hits, 3.4 GB, per worker: align4_sparse.hpp; estimated, not yet measured)
     }
     total = sum(parts.values())
     return {"n_gpus": int(n_gpus), "bytes_per_gpu": {k: int(v) for k, v in parts.items()}, "total_GB_per_gpu": total / 1e9,
