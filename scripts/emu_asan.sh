@@ -1,0 +1,24 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: the emulated build under AddressSanitizer.  Device memory is host heap there, so a kernel that reads or writes
+# past a device buffer (what a GPU answers with a page fault or with silent corruption) stops the run with a report.
+#   bash scripts/emu_asan.sh        builds tests/emu/_build_asan and runs the aligner, sparse-path, adversarial, LowHash0 and group checks on it
+cd "$(dirname "$0")/.."
+make -s -C tests/emu OUT=_build_asan SAN=-fsanitize=address _build_asan/libshasta_mi355x_emu.so || exit 1
+ASAN=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
+LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 python - <<'PY'
+import sys
+sys.path.insert(0, ".")
+from oracle import bindings
+from shasta_amd import abi, lib as L
+from tests import adversarial, align3_checks, group_checks, sparse_checks, support
+emu, orc = L.Library("tests/emu/_build_asan/libshasta_mi355x_emu.so"), bindings.OracleLib()
+print("aligner, share of the DP cells from the matches:", sparse_checks.aligner(emu, orc, n_reads=90, limit=160), flush=True)
+print("dp tasks:", sparse_checks.dp_tasks(emu, orc, clean=30, tie_heavy=20, alternatives=(2,), long_every=44), flush=True)
+for name in adversarial.READ_SET_NAMES[:-1]:
+    print(name, adversarial.aligner_case(emu, orc, name, long_reads=False), flush=True)
+adversarial.lowhash0(emu, orc)
+print("adversarial LowHash0 ok", flush=True)
+print("group:", group_checks.lowhash0_and_aligners(emu, orc, device_lists=((0, 0),), n_reads=120, limit=200), flush=True)
+align3_checks.against_oracle(emu, orc, 21, dict())
+print("align method 3 ok")
+PY
