@@ -6,7 +6,7 @@
 #   runs it (with the CPU baseline + parity at bench size)   4 kernel-trace stats + timeline of the same command
 #   5 the lines of the other modes (LowHash0 only = configs[1], align method 3, marker finding)
 READS=${1:-100000}
-ROUND=${ROUND:-r03}          # prefix of the files under profiles/ (bench.py reads the newest rNN_pmc_100k_reads.json)
+ROUND=${ROUND:-r05}          # prefix of the files under profiles/ (bench.py reads the newest rNN_pmc_100k_reads.json)
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
