@@ -945,6 +945,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     const uint64_t batchCount = batchStart.size() - 1;
 
     if(borrowed && !ctx.alignStore) ctx.alignStore = std::make_shared<AlignStore>();
+    // (borrowed calls: the alignment table's keys are made batch by batch from the rows on the device, shasta_mi355x_alignment_table)
+    const bool tableKeys = borrowed;
+    if(tableKeys) alignmentTableKeysBegin(ctx, candidateCount);
     AlignStore localStore;
     AlignStore& store = borrowed ? *static_cast<AlignStore*>(ctx.alignStore.get()) : localStore;
     std::vector<BatchOutput>& outputs = store.outputs;
@@ -1624,7 +1627,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         o.bytes.assign(o.stagedBytes, o.stagedBytes + o.byteCount);
         o.stagedBytes = nullptr;
     };
-    auto placeFinished = [&](uint64_t finished) {
+    auto placeFinished = [&](uint64_t finished, const shasta_alignment_data* workerRows, hipStream_t workerStream) {
         BatchOutput& own = outputs[finished];
         Placement at;
         bool direct = false, tail = false;
@@ -1639,6 +1642,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             tail = nextBatch.load() >= batchCount;      // every batch has been taken: this worker has none to go on with
         }
         if(direct) {
+            // (the table's keys of this batch's rows, while the rows are still in the worker's device buffer: tables.hip)
+            if(tableKeys) alignmentTableKeysOfBatch(ctx, workerRows, at.rows, at.rowBase, workerStream);
             copyBatch(finished, at, store.rows.data(), store.compressedToc.data(), store.bytes.data(), store.ordinalsToc.data(), store.ordinals.data(), tail ? 4 : 1);
             own.stagedBytes = nullptr;       // (copied from the staging buffer to its place: nothing else reads it)
         } else {
@@ -1652,7 +1657,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 const uint64_t batchIndex = nextBatch.fetch_add(1);
                 if(batchIndex >= batchCount) break;
                 processBatch(workers[k], batchIndex);
-                placeFinished(batchIndex);
+                placeFinished(batchIndex, workers[k].scratch->rowsOut.data(), workers[k].stream);
             }
         } catch(const std::exception& e) {
             workers[k].error = e.what();

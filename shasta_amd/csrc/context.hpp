@@ -114,6 +114,8 @@ void pairTable(int device, const void* pairs, uint64_t stride, uint64_t count, u
 // Assembler::computeAlignmentTable for the alignments of the context's last borrowed aligner call; arrays of the context.
 const shasta_alignment_data* borrowedAlignmentRows(Context&, uint64_t* count);
 void alignmentTableOfLastCall(Context&, const uint64_t** toc, const uint32_t** values, uint64_t* valueCount);
+void alignmentTableKeysBegin(Context&, uint64_t maxRows);          // (a borrowed aligner call begins)
+void alignmentTableKeysOfBatch(Context&, const shasta_alignment_data* deviceRows, uint64_t count, uint64_t firstRow, hipStream_t stream);
 void readGraphKeep(int device, const shasta_alignment_data* alignmentData, uint64_t count, uint64_t readCount, uint32_t maxAlignmentCount, uint8_t* keep);
 void calibrateUnit(uint64_t bytes, int mode);
 void hashWindowsUnit(const uint32_t* kmerIds, uint64_t n, uint64_t m, uint64_t iteration, uint64_t* out);

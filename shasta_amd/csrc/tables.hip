@@ -12,6 +12,8 @@
 #include "context.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -310,8 +312,55 @@ struct TableStore {
     DeviceBuffer<uint8_t> deviceHeads;
     DeviceBuffer<uint64_t> keysA, keysB, deviceToc;
     DeviceBuffer<uint32_t> valuesA, valuesB, bad;
+    // The keys of the rows that the aligner's workers handed over while they were still on the device (alignmentTableKeysBegin /
+    // alignmentTableKeysOfBatch): rows [0, keyedRows) when every batch of the call did, in any order, without a gap.
+    std::atomic<uint64_t> keyedRows{0};
+    uint64_t keyedCapacity = 0;
+    int keyedOtherBits = 0;
 };
+
+// pairTableKeysKernel for rows firstRow ... of the table (the rows of one batch, still in the worker's device buffer).
+__global__ void __launch_bounds__(256)
+pairTableKeysOfRowsKernel(const shasta_alignment_data* __restrict__ rows, uint64_t count, uint64_t firstRow, uint64_t orientedReadCount, int otherBits,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t* __restrict__ bad)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if(i >= count) return;
+    const shasta_oriented_read_pair pair = rows[i].pair;
+    const uint64_t o0 = uint64_t(pair.readIds[0]) << 1, o1 = (uint64_t(pair.readIds[1]) << 1) | (pair.isSameStrand ? 0u : 1u);
+    if(o0 >= orientedReadCount || o1 >= orientedReadCount) { atomicAdd(bad, 1u); }
+    const uint64_t tableRows[4] = {o0, o1, o0 ^ 1u, o1 ^ 1u}, others[4] = {o1, o0, o1 ^ 1u, o0 ^ 1u};
+#pragma unroll
+    for(int k = 0; k < 4; k++) { keys[4 * (firstRow + i) + k] = (tableRows[k] << otherBits) | others[k]; values[4 * (firstRow + i) + k] = uint32_t(firstRow + i); }
+}
 }  // namespace
+
+// A borrowed aligner call begins: room for the keys of up to maxRows alignments (nothing in flight on the context).
+void alignmentTableKeysBegin(Context& ctx, uint64_t maxRows)
+{
+    if(!ctx.tableStore) ctx.tableStore = std::make_shared<TableStore>();
+    TableStore& t = *static_cast<TableStore*>(ctx.tableStore.get());
+    t.keyedRows.store(0); t.keyedCapacity = 0;
+    if(maxRows == 0 || maxRows >= (1ULL << 29)) return;
+    const uint64_t n = 4 * maxRows;
+    t.keysA.reserve(n, ctx.stream); t.keysB.reserve(n, ctx.stream); t.valuesA.reserve(n, ctx.stream); t.valuesB.reserve(n, ctx.stream); t.bad.reserve(1, ctx.stream);
+    HIP_CHECK(hipMemsetAsync(t.bad.data(), 0, sizeof(uint32_t), ctx.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    t.keyedCapacity = maxRows;
+    t.keyedOtherBits = bitsFor(std::max<uint64_t>(2 * ctx.readCount, 2));
+}
+
+// A batch whose place in the call's results is known hands its rows over from the worker's device buffer, on the worker's stream:
+// the table's keys of those rows are written where they belong, and the rows need not come back up for the table.
+void alignmentTableKeysOfBatch(Context& ctx, const shasta_alignment_data* deviceRows, uint64_t count, uint64_t firstRow, hipStream_t stream)
+{
+    TableStore* t = static_cast<TableStore*>(ctx.tableStore.get());
+    if(!t || count == 0 || firstRow + count > t->keyedCapacity) return;
+    hipLaunchKernelGGL(pairTableKeysOfRowsKernel, dim3(divUp(count, 256)), dim3(256), 0, stream,
+        deviceRows, count, firstRow, 2 * ctx.readCount, t->keyedOtherBits, t->keysA.data(), t->valuesA.data(), t->bad.data());
+    HIP_CHECK(hipGetLastError());
+    t->keyedRows.fetch_add(count);
+}
 
 void alignmentTableOfLastCall(Context& ctx, const uint64_t** tocOut, const uint32_t** valuesOut, uint64_t* valueCount)
 {
@@ -329,8 +378,13 @@ void alignmentTableOfLastCall(Context& ctx, const uint64_t** tocOut, const uint3
     *tocOut = toc; *valuesOut = values; *valueCount = n;
     if(count == 0) { std::fill(toc, toc + tableRows + 1, uint64_t(0)); return; }
     constexpr uint64_t stride = sizeof(shasta_oriented_read_pair);
-    uint8_t* heads = static_cast<uint8_t*>(t.heads.reserve(count * stride));
-    {   // (the rows are 64 bytes apart in ordinary memory: a few host threads, each a contiguous share)
+    // Every batch of the call handed its rows over on the device: the keys are there already.
+    const bool keyed = t.keyedCapacity >= count && t.keyedRows.load() == count && t.keyedOtherBits == otherBits;
+    t.keyedRows.store(~0ULL);           // (the sort below consumes the keys: a second table of the same call takes the rows from the host)
+    static const bool debug = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
+    if(debug) std::fprintf(stderr, "alignment table: %llu alignments, keys %s\n", (unsigned long long)count, keyed ? "left on the device by the batches" : "from the rows on the host");
+    uint8_t* heads = keyed ? nullptr : static_cast<uint8_t*>(t.heads.reserve(count * stride));
+    if(!keyed) {   // (the rows are 64 bytes apart in ordinary memory: a few host threads, each a contiguous share)
         const uint64_t threads = std::min<uint64_t>(4, std::max<uint64_t>(1, count >> 16));
         auto share = [&](uint64_t k) {
             for(uint64_t i = count * k / threads; i < count * (k + 1) / threads; i++) std::memcpy(heads + i * stride, &rows[i].pair, stride);
@@ -340,14 +394,19 @@ void alignmentTableOfLastCall(Context& ctx, const uint64_t** tocOut, const uint3
         share(0);
         for(std::thread& o : others) o.join();
     }
-    t.deviceHeads.reserve(count * stride, stream); t.keysA.reserve(n, stream); t.keysB.reserve(n, stream);
-    t.valuesA.reserve(n, stream); t.valuesB.reserve(n, stream); t.deviceToc.reserve(tableRows + 1, stream); t.bad.reserve(1, stream);
+    if(!keyed) {
+        t.deviceHeads.reserve(count * stride, stream); t.keysA.reserve(n, stream); t.keysB.reserve(n, stream);
+        t.valuesA.reserve(n, stream); t.valuesB.reserve(n, stream); t.bad.reserve(1, stream);
+    }
+    t.deviceToc.reserve(tableRows + 1, stream);
     const KernelTimers::Span span = ctx.timers.begin("alignment table (keys, sort, row starts)", stream);
-    HIP_CHECK(hipMemcpyAsync(t.deviceHeads.data(), heads, count * stride, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemsetAsync(t.bad.data(), 0, sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(pairTableKeysKernel, dim3(divUp(count, 256)), dim3(256), 0, stream,
-        (const uint8_t*)t.deviceHeads.data(), stride, count, tableRows, otherBits, t.keysA.data(), t.valuesA.data(), t.bad.data());
-    HIP_CHECK(hipGetLastError());
+    if(!keyed) {
+        HIP_CHECK(hipMemcpyAsync(t.deviceHeads.data(), heads, count * stride, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(t.bad.data(), 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(pairTableKeysKernel, dim3(divUp(count, 256)), dim3(256), 0, stream,
+            (const uint8_t*)t.deviceHeads.data(), stride, count, tableRows, otherBits, t.keysA.data(), t.valuesA.data(), t.bad.data());
+        HIP_CHECK(hipGetLastError());
+    }
     const bool inB = radixSort<uint64_t, uint32_t, true>(t.keysA.data(), t.keysB.data(), t.valuesA.data(), t.valuesB.data(), n, 2 * otherBits, ctx.sortWs, stream);
     hipLaunchKernelGGL(rowStartsKernel, dim3(divUp(tableRows + 1, 256)), dim3(256), 0, stream,
         (const uint64_t*)(inB ? t.keysB.data() : t.keysA.data()), n, tableRows, otherBits, t.deviceToc.data());

@@ -81,9 +81,10 @@ def table_of_the_last_aligner_call(lib, oracle_lib, n_reads=150, limit=700):
                              (ctx.align4, abi.default_align4_options(minAlignedMarkerCount=100000))):
             out = run(cand, options, borrow=True)
             rows = np.array(out.alignment_data, copy=True)
-            table_toc, table_values = ctx.alignment_table()
             expected_toc, expected_values = host_support.alignment_table_expected(n_reads, rows)
-            assert np.array_equal(table_toc, expected_toc.astype(np.uint64)) and np.array_equal(table_values, expected_values)
+            for again in range(2):          # (the second time the keys the batches left on the device are gone: the rows go up from the host)
+                table_toc, table_values = ctx.alignment_table()
+                assert np.array_equal(table_toc, expected_toc.astype(np.uint64)) and np.array_equal(table_values, expected_values)
             stored += len(rows)
             del out
     return stored
