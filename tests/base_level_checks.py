@@ -17,7 +17,7 @@ def plumbing(lib, ref_lib, n_reads=4000, genome_length=1_500_000, mean_length=15
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "reads.fasta")
         synthetic.fasta_reads(path, n_reads, genome_length, mean_length=mean_length, seed=seed, homopolymer=0.03)
-        r = ref_lib.reads_and_markers_from_fasta(path, k=10, threads=0)        # Kmers.k, probability: the defaults; minReadLength 10000
+        r = ref_lib.reads_and_markers_from_fasta(path, k=10, threads=support.reference_threads(32))        # Kmers.k, probability: the defaults; minReadLength 10000
     read_count = len(r["base_counts"])
     assert read_count >= 0.9 * n_reads
     # Marker finding: the reference's stored reads in, the reference's Markers out.
@@ -27,13 +27,13 @@ def plumbing(lib, ref_lib, n_reads=4000, genome_length=1_500_000, mean_length=15
         # LowHash0 on the markers that stayed in HBM: m = 4, hashFraction 0.01, 10 iterations, 5/30/5.
         p = abi.default_lowhash0_params(**DEC2019_LOWHASH)
         a = ctx.lowhash0(p)
-        b = ref_lib.lowhash0(r["toc"], r["data7"], None, p, threads=0)
+        b = ref_lib.lowhash0(r["toc"], r["data7"], None, p, threads=support.reference_threads(32))
         support.same_lowhash(a, b)
         cand = b.candidates if limit is None else b.candidates[:limit]
         # computeAlignments, method 4, minAlignedFraction 0.4.
         o = abi.default_align4_options(**DEC2019_ALIGN)
         y = ctx.align4(cand, o, want_ordinals=True)
-    x = ref_lib.align4_batch(r["toc"], r["data7"], cand, o, want_ordinals=True, threads=0)
+    x = ref_lib.align4_batch(r["toc"], r["data7"], cand, o, want_ordinals=True, threads=support.reference_threads())      # (never one per core: 2 GiB of arena each)
     assert not (y.status & 0x80).any()
     support.same_align(x, y)
     return read_count, int(r["toc"][-1]), len(b.candidates), int((x.status == abi.SHASTA_ALIGN_STORED).sum())

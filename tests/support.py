@@ -103,3 +103,24 @@ def small_marker_set(n_reads=300, genome_markers=20000, seed=5, **kw):
     toc, kmer = synthetic.marker_reads(n_reads, genome_markers, mean_markers=900.0, min_markers=300,
                                        seed=seed, **kw)
     return toc, kmer, synthetic.pack_markers(toc, kmer)
+
+
+def reference_threads(limit=16):
+    """Threads for the reference's aligner (oracle/_ref): every one of its threads creates the reference's own 2-GiB arena
+    (src/AssemblerAlign.cpp:353-355), so "one per core" on a 256-core box is half a terabyte -- round 1 lost a GPU box that way.
+    At most `limit`, the cores there are, the container's CPU quota, and a quarter of the available memory in 4-GiB units."""
+    cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(float(quota) / float(period))))
+    except Exception:          # noqa: BLE001
+        pass
+    memory = 1 << 20
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                memory = int(line.split()[1]) >> 20
+    except OSError:
+        pass
+    return max(1, min(limit, cores, memory // 16))
