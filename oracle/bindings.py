@@ -432,18 +432,35 @@ class OracleLib(_Base):
                                               C.byref(count), abi.as_ptr(info, C.c_int64)), "oracle_sparse_dp")
         return out[:2 * count.value].reshape(-1, 2).copy(), dict(zip(("certified", "score", "hits", "scan_steps", "reason"), (int(v) for v in info)))
 
-    def sparse_census(self, on=None, reset=False, scan_budget=None, one_hit_per_marker=False, running_max_bound=False):
+    def anchored_dp(self, k0, k1, band_min, band_max):
+        """The task with the dense DP confined to where the optimal chains differ (oracle/anchored_chain.hpp), under the policy in
+        force -> (ordinals [n, 2], dict(score, hits, anchors, windows, dense_cells, whole_task_dense))."""
+        k0 = np.ascontiguousarray(k0, dtype=np.uint32)
+        k1 = np.ascontiguousarray(k1, dtype=np.uint32)
+        cap = min(len(k0), len(k1)) + 1
+        out = np.zeros(2 * cap, dtype=np.uint32)
+        count = C.c_uint64()
+        info = np.zeros(6, dtype=np.int64)
+        self._check(self.lib.oracle_anchored_dp(abi.as_ptr(k0, C.c_uint32), C.c_uint32(len(k0)), abi.as_ptr(k1, C.c_uint32), C.c_uint32(len(k1)),
+                                                C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
+                                                C.byref(count), abi.as_ptr(info, C.c_int64)), "oracle_anchored_dp")
+        return out[:2 * count.value].reshape(-1, 2).copy(), dict(zip(("score", "hits", "anchors", "windows", "dense_cells", "whole_task_dense"), (int(v) for v in info)))
+
+    def sparse_census(self, on=None, reset=False, scan_budget=None, one_hit_per_marker=False, running_max_bound=False, anchored=None):
         """Bookkeeping of the sparse path's prototype over the DP tasks align4_batch runs (oracle.cpp: oracle_sparse_census_read)."""
         if scan_budget is not None:
             self.lib.oracle_sparse_census_options(C.c_uint32(scan_budget), C.c_int(1 if one_hit_per_marker else 0), C.c_int(1 if running_max_bound else 0))
+        if anchored is not None:
+            self.lib.oracle_sparse_census_anchored(C.c_int(1 if anchored else 0))
         if reset:
             self.lib.oracle_sparse_census_reset()
         if on is not None:
             self.lib.oracle_sparse_census(C.c_int(1 if on else 0))
-        out = np.zeros(13, dtype=np.uint64)
+        out = np.zeros(18, dtype=np.uint64)
         self.lib.oracle_sparse_census_read(abi.as_ptr(out, C.c_uint64))
         names = ("tasks", "certified", "certified_but_different", "dense_cells", "hits", "scan_steps", "reason_certified", "reason_several_chains",
-                 "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs", "reason_two_hits_of_one_marker")
+                 "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs", "reason_two_hits_of_one_marker",
+                 "anchored_different", "anchored_dense_cells", "anchored_windows", "anchored_whole_tasks", "anchors")
         return dict(zip(names, (int(v) for v in out)))
 
     def compress(self, ordinals):

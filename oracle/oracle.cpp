@@ -401,11 +401,29 @@ int oracle_sparse_dp(
     } catch(std::exception& e) { lastError = e.what(); return 1; }
 }
 
+// The same task with the dense DP confined to the stretches where the optimal chains differ (oracle/anchored_chain.hpp), under the
+// policy in force.  out[0] score, [1] hits, [2] anchors, [3] windows, [4] dense cells solved, [5] whole task dense.
+int oracle_anchored_dp(
+    const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
+    uint32_t* ordinals, uint64_t capacity, uint64_t* count, int64_t* out)
+{
+    try {
+        AnchoredResult r;
+        anchoredAlignment(k0, nx, k1, ny, bandMin, bandMax, r);
+        if(r.ordinals.size() > capacity) throw std::runtime_error("oracle_anchored_dp: capacity");
+        for(size_t i = 0; i < r.ordinals.size(); i++) { ordinals[2*i] = r.ordinals[i].first; ordinals[2*i+1] = r.ordinals[i].second; }
+        *count = r.ordinals.size();
+        out[0] = r.score; out[1] = int64_t(r.hits); out[2] = int64_t(r.anchors); out[3] = int64_t(r.windows); out[4] = int64_t(r.denseCells); out[5] = r.wholeTaskDense ? 1 : 0;
+        return 0;
+    } catch(std::exception& e) { lastError = e.what(); return 1; }
+}
+
 // What the sparse path would have done on every DP task the restated Align4 ran since the last reset (oracle_sparse_census(1)
 // switches the bookkeeping on, (0) off): [0] tasks, [1] certified, [2] certified and DIFFERENT from the dense DP under the policy
 // in force (must stay 0), [3] dense cells nx x width, [4] hits, [5] scan steps, [6..9] tasks by reason 0..3,
 // [10] dense cells of the certified tasks, [11] aligned pairs, [12] tasks by reason 4.
 void oracle_sparse_census(int on) { sparseCensus().on = on != 0; }
+void oracle_sparse_census_anchored(int on) { sparseCensus().anchored = on != 0; }
 void oracle_sparse_census_options(uint32_t scanBudget, int oneHitPerMarker, int runningMaxBound)
 {
     sparseCensus().scanBudget = scanBudget; sparseCensus().oneHitPerMarker = oneHitPerMarker != 0; sparseCensus().runningMaxBound = runningMaxBound != 0;
