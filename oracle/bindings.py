@@ -440,11 +440,11 @@ class OracleLib(_Base):
         cap = min(len(k0), len(k1)) + 1
         out = np.zeros(2 * cap, dtype=np.uint32)
         count = C.c_uint64()
-        info = np.zeros(6, dtype=np.int64)
+        info = np.zeros(7, dtype=np.int64)
         self._check(self.lib.oracle_anchored_dp(abi.as_ptr(k0, C.c_uint32), C.c_uint32(len(k0)), abi.as_ptr(k1, C.c_uint32), C.c_uint32(len(k1)),
                                                 C.c_int32(band_min), C.c_int32(band_max), abi.as_ptr(out, C.c_uint32), C.c_uint64(cap),
                                                 C.byref(count), abi.as_ptr(info, C.c_int64)), "oracle_anchored_dp")
-        return out[:2 * count.value].reshape(-1, 2).copy(), dict(zip(("score", "hits", "anchors", "windows", "dense_cells", "whole_task_dense"), (int(v) for v in info)))
+        return out[:2 * count.value].reshape(-1, 2).copy(), dict(zip(("score", "hits", "anchors", "windows", "dense_cells", "whole_task_dense", "largest_window"), (int(v) for v in info)))
 
     def sparse_census(self, on=None, reset=False, scan_budget=None, one_hit_per_marker=False, running_max_bound=False, anchored=None):
         """Bookkeeping of the sparse path's prototype over the DP tasks align4_batch runs (oracle.cpp: oracle_sparse_census_read)."""
@@ -456,11 +456,11 @@ class OracleLib(_Base):
             self.lib.oracle_sparse_census_reset()
         if on is not None:
             self.lib.oracle_sparse_census(C.c_int(1 if on else 0))
-        out = np.zeros(18, dtype=np.uint64)
+        out = np.zeros(20, dtype=np.uint64)
         self.lib.oracle_sparse_census_read(abi.as_ptr(out, C.c_uint64))
         names = ("tasks", "certified", "certified_but_different", "dense_cells", "hits", "scan_steps", "reason_certified", "reason_several_chains",
                  "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs", "reason_two_hits_of_one_marker",
-                 "anchored_different", "anchored_dense_cells", "anchored_windows", "anchored_whole_tasks", "anchors")
+                 "anchored_different", "anchored_dense_cells", "anchored_windows", "anchored_whole_tasks", "anchors", "anchored_largest_window", "anchored_tasks_with_a_window_over_16384")
         return dict(zip(names, (int(v) for v in out)))
 
     def compress(self, ordinals):

@@ -402,7 +402,7 @@ int oracle_sparse_dp(
 }
 
 // The same task with the dense DP confined to the stretches where the optimal chains differ (oracle/anchored_chain.hpp), under the
-// policy in force.  out[0] score, [1] hits, [2] anchors, [3] windows, [4] dense cells solved, [5] whole task dense.
+// policy in force.  out[0] score, [1] hits, [2] anchors, [3] windows, [4] dense cells solved, [5] whole task dense, [6] cells of the largest rectangle.
 int oracle_anchored_dp(
     const uint32_t* k0, uint32_t nx, const uint32_t* k1, uint32_t ny, int32_t bandMin, int32_t bandMax,
     uint32_t* ordinals, uint64_t capacity, uint64_t* count, int64_t* out)
@@ -413,7 +413,7 @@ int oracle_anchored_dp(
         if(r.ordinals.size() > capacity) throw std::runtime_error("oracle_anchored_dp: capacity");
         for(size_t i = 0; i < r.ordinals.size(); i++) { ordinals[2*i] = r.ordinals[i].first; ordinals[2*i+1] = r.ordinals[i].second; }
         *count = r.ordinals.size();
-        out[0] = r.score; out[1] = int64_t(r.hits); out[2] = int64_t(r.anchors); out[3] = int64_t(r.windows); out[4] = int64_t(r.denseCells); out[5] = r.wholeTaskDense ? 1 : 0;
+        out[0] = r.score; out[1] = int64_t(r.hits); out[2] = int64_t(r.anchors); out[3] = int64_t(r.windows); out[4] = int64_t(r.denseCells); out[5] = r.wholeTaskDense ? 1 : 0; out[6] = int64_t(r.largestWindow);
         return 0;
     } catch(std::exception& e) { lastError = e.what(); return 1; }
 }
