@@ -303,7 +303,7 @@ def hbm_budget(markers_total, reads_total, n_gpus, hash_fraction=0.01, iteration
         "lowhash0_bucket_tables": 20.0 * record_rows,
         "lowhash0_pair_keys_ping_pong": 24.0 * pairs,
         "lowhash0_statistics_histograms": 24.0 * r + 16384.0 * iterations,
-        "aligner_scratch_%d_workers" % workers: workers * 11.0e9,      # (round 4: + the candidates' match lists, 2.2 GB, and the tasks' ordered hits, 3.4 GB, per worker: align4_sparse.hpp; estimated, not yet measured)
+        "aligner_scratch_%d_workers" % workers: workers * 14.5e9,      # (round 4: + the candidates' match lists, 2.2 GB, the tasks' ordered hits, 3.4 GB, and their link words, 3.4 GB, per worker: align4_sparse.hpp, align4_anchor.hpp; estimated, not yet measured)
     }
     total = sum(parts.values())
     return {"n_gpus": int(n_gpus), "bytes_per_gpu": {k: int(v) for k, v in parts.items()}, "total_GB_per_gpu": total / 1e9,
@@ -738,6 +738,10 @@ def main():
             out["banded_dp"] = {"reference_cells_per_step": int(al.dp_cell_count), "cells_in_the_dense_kernels_per_step": int(dense_cells),
                                 "share_from_the_matches": (1.0 - dense_cells / al.dp_cell_count) if al.dp_cell_count else None,
                                 "sparse_path": chain is not None,
+                                # (align4_anchor.hpp: matches of the tasks with several optimal chains that the anchor kernel walked,
+                                # against all matches inside the tasks' bands)
+                                "matches_in_the_bands_per_step": int(chain["work"] / steps) if chain else None,
+                                "matches_walked_by_the_anchor_kernel_per_step": int(table["sparseAnchorKernel"]["work"] / steps) if "sparseAnchorKernel" in table else None,
                                 "reference_cells_per_second": al.dp_cell_count / (elapsed / steps) if elapsed > 0 else None}
         if hash_name:
             h = kernels[hash_name]

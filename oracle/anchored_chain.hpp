@@ -44,6 +44,7 @@ struct AnchoredResult {
     uint64_t hits = 0, anchors = 0, windows = 0;
     uint64_t denseCells = 0;          // cells of the dense problems that were solved
     uint64_t largestWindow = 0;       // cells of the largest rectangle
+    uint32_t longestLink = 0;         // how many hits back the furthest optimal link of a LIVE hit goes (the device's link word holds 29)
     bool wholeTaskDense = false;      // no anchor (or a tie with the empty alignment): the dense DP on the whole task, as today
 };
 
@@ -176,7 +177,7 @@ inline void anchoredAlignment(const T* seq0, uint32_t nx, const T* seq1, uint32_
         if(!isLive) continue;
         live[size_t(k)] = 1;
         anchor[size_t(k)] = open == 0 && !enteredLater && k <= firstEnd;
-        for(const int32_t q : links[size_t(k)]) if(!pending[size_t(q)]) { pending[size_t(q)] = 1; ++open; }
+        for(const int32_t q : links[size_t(k)]) { r.longestLink = std::max(r.longestLink, uint32_t(k - q)); if(!pending[size_t(q)]) { pending[size_t(q)] = 1; ++open; } }
         enteredLater = enteredLater || fromBorder[size_t(k)];
     }
     // The chain: anchors as they are, a rectangle wherever something else is live between two of them.

@@ -456,11 +456,12 @@ class OracleLib(_Base):
             self.lib.oracle_sparse_census_reset()
         if on is not None:
             self.lib.oracle_sparse_census(C.c_int(1 if on else 0))
-        out = np.zeros(20, dtype=np.uint64)
+        out = np.zeros(22, dtype=np.uint64)
         self.lib.oracle_sparse_census_read(abi.as_ptr(out, C.c_uint64))
         names = ("tasks", "certified", "certified_but_different", "dense_cells", "hits", "scan_steps", "reason_certified", "reason_several_chains",
                  "reason_ties_with_empty", "reason_scan_budget", "dense_cells_of_certified", "aligned_pairs", "reason_two_hits_of_one_marker",
-                 "anchored_different", "anchored_dense_cells", "anchored_windows", "anchored_whole_tasks", "anchors", "anchored_largest_window", "anchored_tasks_with_a_window_over_16384")
+                 "anchored_different", "anchored_dense_cells", "anchored_windows", "anchored_whole_tasks", "anchors", "anchored_largest_window", "anchored_tasks_with_a_window_over_16384",
+                 "ambiguous_tasks_with_a_live_link_over_29_hits", "anchored_tasks_with_over_128_windows")
         return dict(zip(names, (int(v) for v in out)))
 
     def compress(self, ordinals):

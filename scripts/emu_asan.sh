@@ -14,6 +14,7 @@ from tests import adversarial, align3_checks, group_checks, sparse_checks, suppo
 emu, orc = L.Library("tests/emu/_build_asan/libshasta_mi355x_emu.so"), bindings.OracleLib()
 print("aligner, share of the DP cells from the matches:", sparse_checks.aligner(emu, orc, n_reads=90, limit=160), flush=True)
 print("dp tasks:", sparse_checks.dp_tasks(emu, orc, clean=30, tie_heavy=20, alternatives=(2,), long_every=44), flush=True)
+print("locally ambiguous tasks (anchor kernel):", sparse_checks.anchored_tasks(emu, orc, seeds=(3, 4, 5), tasks=24), flush=True)
 for name in adversarial.READ_SET_NAMES[:-1]:
     print(name, adversarial.aligner_case(emu, orc, name, long_reads=False), flush=True)
 adversarial.lowhash0(emu, orc)

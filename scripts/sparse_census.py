@@ -25,5 +25,5 @@ print('%.1fs'%(time.time()-t), json.dumps(c))
 print('certified tasks %.1f%%, their share of dense cells %.1f%%; hits per task %.0f, scan steps per hit %.2f; dense cells per hit %.0f; aligned pairs per task %.0f' % (
   100*c['certified']/c['tasks'], 100*c['dense_cells_of_certified']/c['dense_cells'], c['hits']/c['tasks'], c['scan_steps']/max(1,c['hits']), c['dense_cells']/max(1,c['hits']), c['aligned_pairs']/c['tasks']))
 if anchored:
-    print('anchored form: %d tasks differ from the dense DP (must be 0); dense cells it solved %.1f%% of all; %d windows, %d tasks run whole; anchors per task %.0f; the largest rectangle %d cells, %d tasks with one of more than 16384' % (
-      c['anchored_different'], 100*c['anchored_dense_cells']/c['dense_cells'], c['anchored_windows'], c['anchored_whole_tasks'], c['anchors']/c['tasks'], c['anchored_largest_window'], c['anchored_tasks_with_a_window_over_16384']))
+    print('anchored form: %d tasks differ from the dense DP (must be 0); dense cells it solved %.1f%% of all; %d windows, %d tasks run whole; anchors per task %.0f; the largest rectangle %d cells, %d tasks with one of more than 16384, %d with an optimal link of a live hit more than 29 hits back, %d with more than 128 windows' % (
+      c['anchored_different'], 100*c['anchored_dense_cells']/c['dense_cells'], c['anchored_windows'], c['anchored_whole_tasks'], c['anchors']/c['tasks'], c['anchored_largest_window'], c['anchored_tasks_with_a_window_over_16384'], c['ambiguous_tasks_with_a_live_link_over_29_hits'], c['anchored_tasks_with_over_128_windows']))

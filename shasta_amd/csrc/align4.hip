@@ -71,6 +71,7 @@ struct DeviceOptions {
 #include "align4_cells.hpp"      // K8/K9
 #include "align4_dp.hpp"         // K10
 #include "align4_sparse.hpp"     // K10s: the same alignment from the matches inside the band, where it is unique
+#include "align4_anchor.hpp"     // K10a: where it is not, the dense DP only between the matches every optimal alignment holds
 #include "align4_finish.hpp"     // K11
 #include "align3.hpp"
 
@@ -157,7 +158,7 @@ struct BatchScratch {
     DeviceBuffer<int32_t> hugeRows;             //                         the three anti-diagonals of the pairs with more than 8192 diagonals
     DeviceBuffer<WideEnd> wideEnds;
     DeviceBuffer<uint64_t> wideTrace, wideOrdBases;   // Align4 components of more than 1024 diagonals (runWideTasks)
-    DeviceBuffer<uint32_t> hits, hitMeta, sparseSorted, sparseInBand, denseFlags, densePositions;     // align4_sparse.hpp: the candidates' match lists, the tasks' ordered hits
+    DeviceBuffer<uint32_t> hits, hitMeta, sparseSorted, sparseLinks, sparseAmbiguous, sparseInBand, denseFlags, densePositions;     // align4_sparse.hpp: the candidates' match lists, the tasks' ordered hits
     DeviceBuffer<uint64_t> hitBase;
     DeviceBuffer<uint8_t> sparseState;
     DeviceBuffer<uint64_t> prepareKeysA, prepareKeysB;      // a batch's first chunk lists made on the device (align4_prepare.hpp)
@@ -332,6 +333,8 @@ struct DpForwardState {
 struct SparseInput { const uint32_t* hits; const uint64_t* hitBase; const uint32_t* hitMeta; };
 // SHASTA_MI355X_SPARSE_DP=0: the dense DP for every task (the A/B switch, and the second implementation the tests compare with).
 bool sparseDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_SPARSE_DP"); return !e || std::atoi(e) != 0; }
+// SHASTA_MI355X_ANCHORED_DP=0: the tasks with several optimal chains go to the dense kernels whole (as before align4_anchor.hpp).
+bool anchoredDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHORED_DP"); return !e || std::atoi(e) != 0; }
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
     uint32_t extraTasks = 0, uint64_t extraOrdinals = 0, const SparseInput* sparse = nullptr)
@@ -361,6 +364,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     f.sortedIds = sortedIds; f.denseCount = taskCount;
     uint32_t* classCounts = f.classCounts;
     unsigned long long* sums = f.sums;
+    size_t sortHandle = 0, chainHandle = 0, anchorHandle = 0;
+    bool anchored = false;
     if(sparse) {
         // K10s (align4_sparse.hpp): every task whose alignment is the unique optimal chain of the matches inside its band gets
         // it from those matches; the dense kernels below run what is left.  The tasks' ordered hits need room that depends on the
@@ -369,7 +374,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
         const uint64_t ordTotalEarly = readDevice(&control->ordCursor, stream);      // synchronises
         b.ordScratch.reserve(2 * (ordTotalEarly + extraOrdinals) + 2, stream);
-        b.sparseSorted.reserve(2 * ordTotalEarly + 4, stream);
+        b.sparseSorted.reserve(2 * ordTotalEarly + 4, stream); b.sparseLinks.reserve(2 * ordTotalEarly + 4, stream);
+        b.sparseAmbiguous.reserve(taskCount, stream);
         b.sparseInBand.reserve(taskCount, stream); b.sparseState.reserve(taskCount, stream);
         b.denseFlags.reserve(uint64_t(taskCount) + 1, stream); b.densePositions.reserve(uint64_t(taskCount) + 1, stream);
         b.scanTemp32.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
@@ -379,13 +385,27 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
             b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data());
         HIP_CHECK(hipGetLastError());
-        if(timers) (void)timers->end(span, 0, taskCount);
+        if(timers) sortHandle = timers->end(span, 0, taskCount);
         if(timers) span = timers->begin("sparseChainKernel", stream);
         hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
             in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
-            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data());
+            (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(),
+            b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), control);
         HIP_CHECK(hipGetLastError());
-        if(timers) (void)timers->end(span, 0, taskCount);
+        if(timers) chainHandle = timers->end(span, 0, taskCount);
+        // K10a (align4_anchor.hpp): the tasks with several optimal chains, the dense DP only where the chains differ.
+        if(anchoredDpEnabled()) {
+            anchored = true;
+            if(timers) span = timers->begin("sparseAnchorKernel", stream);
+            withDpTie(in.tie, [&](auto tag) {
+                hipLaunchKernelGGL(sparseAnchorKernel<decltype(tag)::value>, dim3(std::min<uint32_t>(ANCHOR_GRID, taskCount)), dim3(64), 0, stream,
+                    in.kmerIds, in.pairs, in.tasks, (const uint32_t*)b.sparseAmbiguous.data(), control,
+                    (const uint32_t*)b.sparseSorted.data(), (const uint32_t*)b.sparseLinks.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(),
+                    sparse->hitMeta, (const DpEnd*)b.ends.data(), (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data());
+            });
+            HIP_CHECK(hipGetLastError());
+            if(timers) anchorHandle = timers->end(span, 0, taskCount);
+        }
         if(timers) prepareSpan = timers->begin("DP task sizes, order by (class, length), bundles", stream);
         // The ordered list without the certified tasks (a compaction keeps the order), its class counts and sums.
         uint32_t* const denseKeys = b.dpKeysA.data();
@@ -404,8 +424,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
         sortedKeys, control, taskCount, b.bundleWords.data());
     HIP_CHECK(hipGetLastError());
-    struct { unsigned long long sums[2 + 2 * DP_CLASSES], ordCursor, traceCursor; uint32_t classCounts[DP_CLASSES]; } head;
-    static_assert(sizeof(head) <= DP_CONTROL_HEAD_BYTES && offsetof(DpControl, ordCursor) == sizeof(head.sums), "DpControl's head");
+    struct { unsigned long long sums[2 + 2 * DP_CLASSES], ordCursor, traceCursor; uint32_t classCounts[DP_CLASSES]; uint32_t ambiguousCount, pad; unsigned long long hitsListed, hitsInBand, ambiguousHits; } head;
+    static_assert(sizeof(head) == DP_CONTROL_HEAD_BYTES && offsetof(DpControl, ordCursor) == sizeof(head.sums) && offsetof(DpControl, hitsListed) == 8 * (2 + 2 * DP_CLASSES + 2) + 4 * DP_CLASSES + 8, "DpControl's head");
     HIP_CHECK(hipMemcpyAsync(&head, control, sizeof(head), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     std::memcpy(classCounts, head.classCounts, sizeof(f.classCounts));
@@ -417,6 +437,14 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     f.denseCount = layout.taskStart[DP_CLASSES];
     for(int c = 0; c <= DP_CLASSES; c++) f.taskStart[c] = layout.taskStart[c];
     if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
+    if(timers && sparse) {
+        // The sparse kernels' rows: the matches listed for the tasks' candidates are read (4 bytes each) and those inside the bands
+        // written in order; the chain kernel reads those and writes a list word and a link word beside each; the anchor kernel reads both
+        // for the tasks it walks and writes their aligned pairs (8 bytes: about one per match).  Work = matches inside the bands.
+        timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
+        timers->amend(chainHandle, 12 * head.hitsInBand, head.hitsInBand);
+        if(anchored) timers->amend(anchorHandle, 16 * head.ambiguousHits, head.ambiguousHits);
+    }
     b.trace.reserve(f.traceWords + 64, stream);
     f.ordTotal = ordTotal;
     if(reserveOrdinals) b.ordScratch.reserve(2 * (ordTotal + extraOrdinals) + 2, stream);

@@ -94,7 +94,9 @@ struct DpControl {
     unsigned long long sums[2 + 2 * DP_CLASSES];     // [0] DP cells of all tasks, [1] unused, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c (of the tasks the dense kernels run)
     unsigned long long ordCursor, traceCursor;       // aligned pairs reserved for the tasks; trace words laid out for the bundles
     uint32_t classCounts[DP_CLASSES];                // tasks per class (of the tasks the dense kernels run)
-    uint32_t pad[8];
+    uint32_t ambiguousCount, pad;                    // tasks sparseChainKernel left to sparseAnchorKernel (align4_sparse.hpp, align4_anchor.hpp)
+    unsigned long long hitsListed, hitsInBand;       // matches the sparse kernels read from the candidates' lists / kept inside the tasks' bands
+    unsigned long long ambiguousHits;                // matches of the tasks sparseAnchorKernel walked
     uint32_t bins[DP_BINS];                          // tasks per bin, then (dpBinScanKernel) the bin's first position
     uint32_t cursors[DP_BINS];
 };

@@ -32,12 +32,16 @@
 //                       the task's range of the ordinal scratch, as dpTracebackKernel does.
 //   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
 #pragma once
+#ifndef ANCHOR_REASON
+#define ANCHOR_REASON(why, n)
+#endif
 
 constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the read the hits are ordered by (4-bit counters: 4 KB per wavefront): the tabled read, always below this
 constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
 constexpr int SPARSE_RING = 64;                              // slots of a lane's ring: the hits it can look back on and the next ones it will need
 constexpr int SPARSE_LOOK_BACK = 56;                         // hits a lane can look back
-enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2 };
+enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2, SPARSE_AMBIGUOUS = 3 };   // AMBIGUOUS: several optimal chains, forward pass kept: sparseAnchorKernel's (align4_anchor.hpp)
+constexpr int SPARSE_LINK_REACH = 29;                        // how far back (in hits) a hit's link word names its optimal links; bit 30: one goes further
 
 // Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets[t] = where the task's min(nx, ny) + 32 pairs of
 // the ordinal scratch begin, dpSizeKernel: twice that, in words, is a range of its own for every task).
@@ -148,7 +152,8 @@ constexpr int32_t SPARSE_NEG = -(1 << 29);
 __global__ void __launch_bounds__(64)
 sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ order, uint32_t taskCount,
     uint32_t* __restrict__ sorted, const uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, const uint32_t* __restrict__ hitMeta,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
+    uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, DpControl* __restrict__ control)
 {
     __shared__ uint2 ring[SPARSE_RING * WAVE];             // [slot][lane]
     const int lane = laneId();
@@ -163,6 +168,10 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     const int32_t np = int32_t(swapped ? pd.ny : pd.nx), ns = int32_t(swapped ? pd.nx : pd.ny);     // p: the ordinal in the tabled read, s: in the other
     const int32_t lo = swapped ? task.bandMin : -task.bandMax;            // s - p lies in [lo, lo + band width)
     uint32_t* __restrict__ const list = sorted + sparseListBase(ordOffsets, t);
+    // Beside every finished hit, for the tasks that turn out to have several optimal chains (align4_anchor.hpp): WHICH terms attain its
+    // maximum -- bit 0 the border, bit d the hit d back (d <= 29; bit 30: a hit further back does) -- and, bit 31, whether a chain that ends
+    // with it reaches the best end so far.
+    uint32_t* __restrict__ const myLinks = linkWords + sparseListBase(ordOffsets, t);
     // The hits a lane will need next wait in the ring itself: slots k .. k + 7 hold the raw hits k .. k + 7 (the scan looks back
     // SPARSE_LOOK_BACK = 56 hits at most, so the 64 slots hold both).  They are topped up at a point that is the same for the whole
     // wavefront, every eighth turn of the loop: the loads issued at one top-up are written into the ring at the next, eight turns
@@ -182,6 +191,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     int32_t k = 0, p = 0, s = 0;
     int32_t value = 0, from = 0, j = 1;
     uint32_t ways = 1;
+    uint64_t links = 1;
     int32_t prefixMax = SPARSE_NEG, best = SPARSE_NEG, bestAt = -1;
     uint32_t bestWays = 0;
     bool failed = false, active = n > 0, haveHit = false;
@@ -200,7 +210,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
         if(active && !haveHit && k < fetched) {
             const uint32_t hit = ring[(k & (SPARSE_RING - 1)) * WAVE + lane].x;
             p = int32_t(hit >> 16); s = int32_t(hit & 0xffffu);
-            value = -min(p, s); from = 0; j = 1; ways = 1;
+            value = -min(p, s); from = 0; j = 1; ways = 1; links = 1;
             haveHit = true;
         }
         else if(active && haveHit) {
@@ -219,8 +229,8 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                     if(pq < p && sq < s) {
                         const int32_t candidate = dq - max(p - pq - 1, s - sq - 1);
                         const uint32_t waysQ = 1u + ((e.y >> 30) & 1u);
-                        if(candidate > value) { value = candidate; from = j; ways = waysQ; }
-                        else if(candidate == value) ways = min(2u, ways + waysQ);
+                        if(candidate > value) { value = candidate; from = j; ways = waysQ; links = 1ULL << j; }
+                        else if(candidate == value) { ways = min(2u, ways + waysQ); links |= 1ULL << j; }
                     }
                     ++j;
                 }
@@ -234,6 +244,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                 prefixMax = newMax;
                 list[k] = (uint32_t(p) << 17) | (uint32_t(s - p - lo) << 7) | uint32_t(from);
                 const int32_t end = d - min(np - 1 - p, ns - 1 - s);
+                myLinks[k] = (uint32_t(links) & 0x3fffffffu) | ((links >> (SPARSE_LINK_REACH + 1)) != 0 ? 0x40000000u : 0u) | (end >= best ? 0x80000000u : 0u);
                 if(end > best) { best = end; bestAt = k; bestWays = ways; }
                 else if(end == best) bestWays = min(2u, bestWays + ways);
                 ++k;
@@ -242,10 +253,26 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
             }
         }
     }
+    {
+        // What the two kernels read, for the kernel table: matches listed for the tasks' candidates, matches inside the tasks' bands.
+        const uint32_t meta = hitMeta[task.pair];
+        unsigned long long listed = (has && meta != HIT_LIST_NONE) ? (meta & 0x7fffffffu) : 0u, kept = uint32_t(n);
+        for(int d = 32; d >= 1; d >>= 1) { listed += __shfl_down(listed, d, WAVE); kept += __shfl_down(kept, d, WAVE); }
+        if(lane == 0) { atomicAdd(&control->hitsListed, listed); atomicAdd(&control->hitsInBand, kept); }
+    }
     if(!mine) return;
     const int32_t matchless = sparseMatchlessScore(pd.nx, pd.ny, task.bandMin, task.bandMax);
     const bool empty = n == 0 || best < matchless;
-    if(failed || (!empty && (best == matchless || bestWays != 1u))) { state[t] = SPARSE_DENSE; return; }
+    if(failed || (!empty && best == matchless)) { state[t] = SPARSE_DENSE; return; }
+    if(!empty && bestWays != 1u) {
+        // Several optimal chains: sparseAnchorKernel's.  The best score and the first hit that reaches it travel in the task's DpEnd
+        // (the dense forward kernel writes it anew if the task ends up there).
+        DpEnd e; e.traceOffset = 0; e.bestI = bestAt; e.bestJ = 0; e.score = best; e.laneBase = 0; e.bundleIterations = 0; e.pad = 0;
+        ends[t] = e;
+        ambiguousList[atomicAdd(&control->ambiguousCount, 1u)] = t;
+        state[t] = SPARSE_AMBIGUOUS;
+        return;
+    }
     // The chain, from its last hit back, into the end of the task's range of the ordinal scratch (as dpTracebackKernel leaves it).
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);

@@ -1,7 +1,9 @@
 """The sparse form of the banded alignment (shasta_amd/csrc/align4_sparse.hpp: the alignment from the matches inside the band,
 answered only where the optimal chain of matches is unique) against the dense kernels and the oracle: the same results whether
 the sparse path is on or off and under every compiled tie policy, most tasks of clean reads certified, tie-heavy and repeat-rich
-tasks handed to the dense kernels.  Shared by the -m gpu tests and their pre-flight on the emulated build."""
+tasks handed to the dense kernels; and, where several optimal chains tie only locally, the anchor kernel (align4_anchor.hpp: the
+dense DP on the rectangles between the matches every optimal alignment holds).  Shared by the -m gpu tests and their pre-flight on the
+emulated build."""
 import os
 
 import numpy as np
@@ -103,3 +105,84 @@ def aligner(lib, orc, n_reads=160, limit=500):
             assert got.dp_cell_count == want.dp_cell_count
     assert rows["dense"] == want.dp_cell_count
     return 1.0 - rows["sparse"] / max(1, rows["dense"])
+
+
+class anchors_off:
+    def __enter__(self):
+        self.previous = os.environ.get("SHASTA_MI355X_ANCHORED_DP")
+        os.environ["SHASTA_MI355X_ANCHORED_DP"] = "0"
+
+    def __exit__(self, *exc):
+        if self.previous is None:
+            del os.environ["SHASTA_MI355X_ANCHORED_DP"]
+        else:
+            os.environ["SHASTA_MI355X_ANCHORED_DP"] = self.previous
+
+
+def locally_ambiguous_tasks(seed, tasks=30):
+    """Noisy copies over a large alphabet with markers doubled in place and short stretches copied right behind themselves (what a
+    homopolymer run or a tandem repeat leaves among the markers): the optimal chain is unique except around those places, where two
+    or more sub-chains tie -- at the very ends of the reads too."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+
+    def doubled(s, frac):
+        s = np.repeat(s, 1 + (rng.random(len(s)) < frac).astype(np.int64) + (rng.random(len(s)) < frac / 4).astype(np.int64))
+        for _ in range(int(rng.integers(0, 4))):
+            if len(s) < 20:
+                break
+            p, length = int(rng.integers(0, len(s) - 8)), int(rng.integers(2, 7))
+            s = np.concatenate([s[:p + length], s[p:p + length], s[p + length:]])
+        return s
+
+    for t in range(tasks):
+        width = int(rng.choice([12, 20, 40, 60, 100, 200, 400]))
+        n = int(rng.integers(30, 1200))
+        alphabet = int(rng.choice([1 << 20, 1 << 20, 1 << 20, 5000]))
+        genome = rng.integers(0, alphabet, size=2 * n + 400, dtype=np.uint32)
+        off = int(rng.integers(0, 200))
+        frac = float(rng.choice([0.003, 0.01, 0.03]))
+        a = doubled(dp_geometry_checks.noisy(rng, genome[:n], alphabet), frac)
+        b = doubled(dp_geometry_checks.noisy(rng, genome[off:off + int(rng.integers(n // 3, n + 1))], alphabet), frac)
+        if t % 6 == 1:                                   # an ambiguity at the first and at the last marker of both reads
+            a = np.concatenate([a[:1], a, a[-1:]])
+        if t % 6 == 2:
+            b = np.concatenate([b[:1], b[:1], b, b[-1:]])
+        if t % 5 == 0:
+            a, b = b, a
+            off = -off
+        lo = off - width // 2 + int(rng.integers(-8, 8))
+        lo = min(max(lo, -len(b) - width + 1), len(a))
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), lo, lo + width - 1))
+        at += len(a) + len(b)
+    return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+
+
+def anchored_tasks(lib, orc, seeds=(3, 4), tasks=30, alternatives=tie_policy_checks.ALTERNATIVES):
+    """-> (task runs, DP cells of the tasks, cells the dense kernels ran with the sparse path alone, cells with the anchor kernel too).
+    Equal to the oracle under the default and every alternative tie policy (the rectangles follow the policy), and with the anchor
+    kernel switched off."""
+    runs, cells_all, cells_sparse, cells_anchored = 0, 0, 0, 0
+    for seed in seeds:
+        kmer, spec = locally_ambiguous_tasks(seed, tasks=tasks)
+        for policy in (None,) + tuple(alternatives):
+            if policy is None:
+                want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
+                got = _run(lib, kmer, spec)
+                with anchors_off():
+                    without = _run(lib, kmer, spec)
+                    cells_sparse += int(_run(lib, kmer, spec, timing=True)[3].sum())
+                cells_anchored += int(_run(lib, kmer, spec, timing=True)[3].sum())
+                for (x, sx), (z, sz) in zip(want, without):
+                    assert sx == sz and np.array_equal(x, z)
+            else:
+                with tie_policy_checks.policy(orc, policy):
+                    want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
+                    got = _run(lib, kmer, spec)
+            for i, ((x, sx), (y, sy)) in enumerate(zip(want, got)):
+                assert sx == sy and np.array_equal(x, y), (seed, policy, tuple(int(v) for v in spec[i]))
+            runs += len(spec)
+        narrow = (spec[:, 5] - spec[:, 4] + 1) <= 1024
+        cells_all += int((spec[narrow, 1] * (spec[narrow, 5] - spec[narrow, 4] + 1)).sum())
+    return runs, cells_all, cells_sparse, cells_anchored

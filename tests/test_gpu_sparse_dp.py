@@ -15,3 +15,10 @@ def test_dp_tasks_with_the_sparse_path_on_and_off_and_under_every_compiled_tie_p
 
 def test_aligner_with_the_sparse_path_on_and_off(gpu_lib, oracle_lib):
     assert sparse_checks.aligner(gpu_lib, oracle_lib) > 0.6
+
+
+def test_locally_ambiguous_tasks_through_the_anchor_kernel(gpu_lib, oracle_lib):
+    # align4_anchor.hpp: tasks whose optimal chains differ only around doubled markers and short tandem copies -- the sparse path alone
+    # leaves nearly all of them to the dense kernels, the anchor kernel solves the rectangles between the anchors and leaves a fraction.
+    runs, cells_all, cells_sparse, cells_anchored = sparse_checks.anchored_tasks(gpu_lib, oracle_lib, seeds=(3, 4, 5, 6), tasks=40)
+    assert runs >= 400 and cells_sparse > 0.8 * cells_all and cells_anchored < 0.4 * cells_all
