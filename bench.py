@@ -52,7 +52,7 @@ def _latest_pmc_file():
 
 PMC_FILE = _latest_pmc_file()
 # Kernels whose natural bound is HBM (streaming / sorting); the others are bound by VALU issue and LDS (integer DP, hash joins).
-HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
+HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "readStatistics", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
 
 
 def make_workload(n_reads, seed, shards=0):

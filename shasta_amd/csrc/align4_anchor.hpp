@@ -128,8 +128,10 @@ __device__ int32_t anchorRectangle(AnchorShared& sh, const uint32_t* __restrict_
             waveLdsSync();                                   // (lane 0 of the next chunk reads current[jBase - 1])
         }
     }
-    // Where the traceback starts.
+    // Where the traceback starts.  (A fixed end that no path from the fixed begin reaches, or a walk that does not end in the fixed
+    // begin, would contradict what the anchors are: the task goes to the dense kernels rather than on.)
     int32_t i = wx, j = wy;
+    if(endFixed && sh.row[wx & 1][wy] <= ANCHOR_NEG) return -1;
     if(!endFixed) {
         // The border cells in the order the dense DP scans them -- (0, wy) ... (wx - 1, wy), then (wx, 0) ... (wx, wy) -- and the
         // first or the last of those with the largest score.
@@ -167,6 +169,7 @@ __device__ int32_t anchorRectangle(AnchorShared& sh, const uint32_t* __restrict_
         else --i;
     }
     waveLdsSync();
+    if(beginFixed && (i != 0 || j != 0)) return -1;
     return found;
 }
 

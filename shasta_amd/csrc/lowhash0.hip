@@ -372,7 +372,8 @@ bucketStatsKernel(
     unsigned long long* __restrict__ sizeHist,          // [SIZE_HIST_CAP] of this iteration (of iteration 0 with iterationKeys)
     unsigned long long* __restrict__ overflowSizes, uint32_t overflowCapacity,     // iteration << 32 | size
     unsigned long long* __restrict__ counters,
-    uint64_t* __restrict__ pairCounts)                  // [n+1]
+    uint64_t* __restrict__ pairCounts,                  // [n+1]
+    uint32_t* __restrict__ statKeys)                    // [n]: 3 readId + class of every record, for readStatisticsKernel; null: counted here, an atomic per record
 {
     __shared__ uint32_t sHist[SIZE_HIST_LDS];
     const uint64_t n = count.get();
@@ -394,7 +395,8 @@ bucketStatsKernel(
         const uint32_t orientedReadId = uint32_t(v);
         const uint32_t readId = orientedReadId >> 1;
         const int cls = (size < minBucketSize) ? 0 : ((size > maxBucketSize) ? 2 : 1);
-        atomicAdd(&stats[3ULL * readId + cls], 1ULL);
+        if(statKeys) statKeys[i] = 3u * readId + uint32_t(cls);
+        else atomicAdd(&stats[3ULL * readId + cls], 1ULL);
         if(i == begin) {
             if(size < SIZE_HIST_LDS && iteration == blockIteration) atomicAdd(&sHist[size], 1u);
             else if(size < SIZE_HIST_CAP) atomicAdd(&myHist[size], 1ULL);
@@ -419,6 +421,69 @@ bucketStatsKernel(
     __syncthreads();
     const uint32_t c = sHist[threadIdx.x];
     if(c) atomicAdd(&sizeHist[threadIdx.x], (unsigned long long)c);
+}
+
+// The pass-2 statistics (src/LowHash0.cpp:386-393: per read, its records by the class of their bucket's size) from the keys
+// bucketStatsKernel wrote, 3 readId + class.  The records are in bucket order, so a read's records are anywhere: an atomic per
+// record on the [R][3] table is 3e7 read-modify-writes of random lines at the memory side (the table is shared by the XCDs, so
+// their L2s cannot hold it: 2.2 of the kernel's 2.4 ms, five times its other traffic).  Instead the keys are put in the order of
+// their bits above STAT_LOW_BITS by the radix sort's passes (one pass at 100 k reads: 19-bit keys), after which a workgroup's
+// span of keys lies in one partition of 2^STAT_LOW_BITS table entries, or a few: it counts them in LDS and adds what is not zero
+// to the table when the partition changes and at its end -- 2^STAT_LOW_BITS atomics per span of STAT_SPAN keys at most.
+constexpr int STAT_LOW_BITS = 11;
+constexpr uint32_t STAT_SPAN = 1u << 16;
+__global__ void __launch_bounds__(256)
+readStatisticsKernel(const uint32_t* __restrict__ statKeys, Count count, unsigned long long* __restrict__ stats, uint64_t entries)
+{
+    __shared__ uint32_t counts[1 << STAT_LOW_BITS];
+    __shared__ uint32_t nextPartition;
+    const uint64_t n = count.get();
+    const uint64_t first = uint64_t(blockIdx.x) * STAT_SPAN;
+    if(first >= n) return;
+    const uint64_t end = first + STAT_SPAN < n ? first + STAT_SPAN : n;
+    for(uint32_t k = threadIdx.x; k < (1u << STAT_LOW_BITS); k += blockDim.x) counts[k] = 0;
+    uint32_t partition = statKeys[first] >> STAT_LOW_BITS;          // (the same in every thread)
+    __syncthreads();
+    auto flush = [&]() {
+        for(uint32_t k = threadIdx.x; k < (1u << STAT_LOW_BITS); k += blockDim.x) {
+            const uint32_t c = counts[k];
+            counts[k] = 0;
+            const uint64_t entry = (uint64_t(partition) << STAT_LOW_BITS) + k;
+            if(c && entry < entries) atomicAdd(&stats[entry], (unsigned long long)c);
+        }
+    };
+    constexpr int PER_THREAD = 4;
+    for(uint64_t base = first; base < end; base += uint64_t(PER_THREAD) * blockDim.x) {
+        uint32_t key[PER_THREAD];
+        bool pending[PER_THREAD];
+#pragma unroll
+        for(int u = 0; u < PER_THREAD; u++) {
+            const uint64_t i = base + uint64_t(u) * blockDim.x + threadIdx.x;
+            pending[u] = i < end;
+            key[u] = pending[u] ? statKeys[i] : 0u;
+        }
+        // The keys ascend in their partition: the step's keys are counted partition by partition (one round nearly always).
+        for(;;) {
+            uint32_t least = 0xffffffffu;
+#pragma unroll
+            for(int u = 0; u < PER_THREAD; u++) {
+                if(pending[u] && (key[u] >> STAT_LOW_BITS) == partition) { atomicAdd(&counts[key[u] & ((1u << STAT_LOW_BITS) - 1u)], 1u); pending[u] = false; }
+                if(pending[u]) least = min(least, key[u] >> STAT_LOW_BITS);
+            }
+            if(threadIdx.x == 0) nextPartition = 0xffffffffu;
+            __syncthreads();
+            if(least != 0xffffffffu) atomicMin(&nextPartition, least);
+            __syncthreads();
+            const uint32_t next = nextPartition;                   // (every thread reads the same word: the loop is uniform)
+            __syncthreads();
+            if(next == 0xffffffffu) break;
+            flush();
+            partition = next;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    flush();
 }
 
 // Pass 3 (:424-459): every pair of records of an admissible bucket with equal hashHighBits and readId0 < readId1, as a
@@ -809,7 +874,7 @@ struct LowHash0Job {
     uint64_t pairCount = 0;                 // accumulated pair keys (host copy, valid after a read-back)
     uint64_t evaluatedIterations = ~0ULL, evaluatedPairs = ~0ULL, candidateCount = 0;
     bool pairsInB = false;                  // which side of the ping-pong holds the accumulated keys
-    DeviceBuffer<uint32_t> recKeysA, recKeysB, pairTagsA, pairTagsB, flags, pos, starts, scanTemp32, boundKeys32;
+    DeviceBuffer<uint32_t> recKeysA, recKeysB, pairTagsA, pairTagsB, flags, pos, starts, scanTemp32, boundKeys32, statKeysA, statKeysB;
     DeviceBuffer<uint64_t> recValsA, recValsB, pairKeysA, pairKeysB, iterKeysA, iterKeysB, pairCounts, scanTemp64, boundKeys64, boundOut;
     DeviceBuffer<unsigned long long> counters, stats, sizeHist, iterationTable, overflowSizes, highPerIteration, totalPerIteration;
     DeviceBuffer<shasta_oriented_read_pair> candidatesDevice;
@@ -920,6 +985,7 @@ void enqueueSortRecords(Context& ctx, LowHash0Job& job, const uint32_t*& keys, c
 // K3 + K4 on sorted records: statistics, histogram row `iteration`, pair keys appended at counters[C_PAIRS]; then the
 // iteration's counters are filed (noteIterationKernel).
 // allIterations > 0: the records of that many iterations in one array, key = iteration << log2BucketCount | bucket id (`iteration` unused).
+bool statisticsByAtomics() { const char* e = std::getenv("SHASTA_MI355X_STATISTICS_ATOMICS"); return e && std::atoi(e) != 0; }
 void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keyWords, const uint64_t* vals, Count count, uint64_t iteration,
     uint64_t* pairKeys, uint32_t* pairTags, uint64_t pairCapacity, uint32_t allIterations = 0, bool wideKeys = false)
 {
@@ -948,13 +1014,28 @@ void enqueueBuckets(Context& ctx, LowHash0Job& job, const uint32_t* keyWords, co
         hipLaunchKernelGGL(markHeadsKernel, dim3(g), dim3(256), 0, stream, keys, count, job.flags.data());
         exclusiveScan<uint32_t>(job.flags.data(), job.pos.data(), bound + 1, job.scanTemp32.data(), stream);
         hipLaunchKernelGGL(groupStartsKernel, dim3(g), dim3(256), 0, stream, (const uint32_t*)job.flags.data(), (const uint32_t*)job.pos.data(), count, job.starts.data()));
+    // The per-read statistics through keys, a partition pass and LDS counts (readStatisticsKernel) wherever 3 R fits the 32-bit key;
+    // SHASTA_MI355X_STATISTICS_ATOMICS=1: an atomic per record, as until round 3 (the A/B switch).
+    const uint64_t statEntries = 3 * ctx.readCount;
+    const bool statsByKeys = statEntries < (1ULL << 32) && !statisticsByAtomics();
+    if(statsByKeys) { job.statKeysA.reserve(bound + 1, stream); job.statKeysB.reserve(bound + 1, stream); }
     SHASTA_TIMED(ctx, "bucketStatsKernel + scan of pair counts", stream, 12 * expected, expected,
         hipLaunchKernelGGL(bucketStatsKernel, dim3(g), dim3(256), 0, stream,
             vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), count,
             job.p.minBucketSize, job.p.maxBucketSize, uint32_t(iteration), iterationKeys, job.stats.data(),
             job.sizeHist.data() + (allIterations ? 0 : iteration * SIZE_HIST_CAP),
-            job.overflowSizes.data(), LowHash0Job::overflowCapacity, counters, job.pairCounts.data());
+            job.overflowSizes.data(), LowHash0Job::overflowCapacity, counters, job.pairCounts.data(), statsByKeys ? job.statKeysA.data() : (uint32_t*)nullptr);
         exclusiveScan<uint64_t>(job.pairCounts.data(), job.pairCounts.data(), bound + 1, job.scanTemp64.data(), stream));
+    if(statsByKeys) {
+        int keyBits = 1;
+        while(keyBits < 32 && (1ULL << keyBits) < statEntries) ++keyBits;
+        const int partitionBits = std::max(0, keyBits - STAT_LOW_BITS);
+        // Booked: 4 bytes per record read by the counts, 12 per record and pass of the partition (histogram read, scatter read + write).
+        SHASTA_TIMED(ctx, "readStatisticsKernel + partition of the statistics keys", stream, (4 + 12 * uint64_t((partitionBits + 7) / 8)) * expected, expected,
+            const bool inB = radixSort<uint32_t, uint32_t, false>(job.statKeysA.data(), job.statKeysB.data(), nullptr, nullptr, count, partitionBits, ctx.sortWs, stream, STAT_LOW_BITS);
+            hipLaunchKernelGGL(readStatisticsKernel, dim3(divUp(bound, STAT_SPAN)), dim3(256), 0, stream,
+                (const uint32_t*)(inB ? job.statKeysB.data() : job.statKeysA.data()), count, job.stats.data(), statEntries));
+    }
     SHASTA_TIMED(ctx, "pairWriteKernel", stream, 0, expected,
         hipLaunchKernelGGL(pairWriteKernel, dim3(divUp(bound, 256)), dim3(256), 0, stream,
             vals, (const uint32_t*)job.pos.data(), (const uint32_t*)job.starts.data(), (const uint64_t*)job.pairCounts.data(), count, job.readBits, uint32_t(iteration),

@@ -320,3 +320,9 @@ def test_locally_ambiguous_tasks_through_the_anchor_kernel(emu_lib, oracle_lib):
     from tests import sparse_checks
     runs, cells_all, cells_sparse, cells_anchored = sparse_checks.anchored_tasks(emu_lib, oracle_lib, seeds=(3, 4), tasks=24)
     assert runs >= 120 and cells_sparse > 0.8 * cells_all and cells_anchored < 0.4 * cells_all
+
+
+def test_read_statistics_over_several_partitions_and_spans(emu_lib, oracle_lib):
+    # readStatisticsKernel (lowhash0.hip): 4 200 table entries = 3 partitions, > 65 536 records = several spans; and the atomics form.
+    from tests import statistics_checks
+    assert statistics_checks.several_partitions_and_spans(emu_lib, oracle_lib, cases=((0.05, 6),)) >= 1400
