@@ -31,9 +31,9 @@
 
 constexpr int ANCHOR_MAX_BITWORDS = (2 * int(SPARSE_MAX_STREAM) + 64 + 63) / 64;     // of a task's hits (sparseListCapacity)
 constexpr int ANCHOR_MAX_WINDOWS = 128;
-constexpr int ANCHOR_MAX_CELLS = 16384;          // (wx + 1)(wy + 1) of a rectangle: a byte each
+constexpr int ANCHOR_MAX_CELLS = 4096;           // (wx + 1)(wy + 1) of a rectangle: a byte each (census, profiles/r04_sparse_census.txt: 4 of 2 589 tasks have a larger one; 22 KB of LDS per wavefront instead of 37: seven workgroups per CU instead of four)
 constexpr int ANCHOR_MAX_SIDE = 511;             // markers on a side of a rectangle
-constexpr int ANCHOR_MAX_PAIRS = 1024;           // aligned pairs inside the windows of one task
+constexpr int ANCHOR_MAX_PAIRS = 512;            // aligned pairs inside the windows of one task
 constexpr int32_t ANCHOR_NEG = -(1 << 28);
 static_assert(GAP_SCORE == -1, "the row's prefix maximum of c(j) + j is the recurrence for a gap of -1");
 constexpr uint32_t ANCHOR_GRID = 4096;           // workgroups of one wavefront; each takes tasks blockIdx.x, + gridDim.x, ...
