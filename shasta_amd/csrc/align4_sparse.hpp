@@ -173,67 +173,86 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     // with it reaches the best end so far.
     uint32_t* __restrict__ const myLinks = linkWords + sparseListBase(ordOffsets, t);
     // The hits a lane will need next wait in the ring itself: slots k .. k + 7 hold the raw hits k .. k + 7 (the scan looks back
-    // SPARSE_LOOK_BACK = 56 hits at most, so the 64 slots hold both).  They are topped up at a point that is the same for the whole
-    // wavefront, every eighth turn of the loop: the loads issued at one top-up are written into the ring at the next, eight turns
-    // later, so that nothing inside a turn waits for memory (a lane that read its next hit from memory when it finished one --
-    // or kept them in registers that shift along -- waited a memory latency per hit: the compiler can only place the wait where
-    // the register is next touched, and that is the very next hit).
-    uint32_t pending[4];
-    int32_t fetched = 0, pendingBase = 0, pendingCount = 0;       // hits [0, fetched) are in the ring or consumed; [pendingBase, +pendingCount) are in flight
+    // SPARSE_LOOK_BACK = 56 hits at most, so the 64 slots hold both).  They arrive in two groups of four, A and B, each with its own
+    // place in the loop -- A's every eighth turn, B's four turns later, the same for the whole wavefront: a group is written into
+    // the ring when it is the next one and fits (its last hit below k + 8), and asked for again at once, so a group's loads have
+    // eight turns to arrive and nothing inside a turn waits for memory (a lane that read its next hit from memory when it finished
+    // one -- or kept them in registers that shift along -- waited a memory latency per hit: the compiler can only place the wait
+    // where the register is next touched, and that is the very next hit).  A lane that is behind keeps its groups for a later visit.
+    //
+    // A turn of the loop: up to TWO predecessors looked at (both ring entries read up front), and, if the hit is finished by then,
+    // its results written and the next hit taken from the ring.  The common hit -- its predecessor one back, the bound on
+    // everything before that below it -- takes ONE turn, and the lanes of a wavefront stay in step; a hit that has to look far
+    // back takes a turn for every two entries.  (The first form took a turn for each of: take a hit, look at one entry, finish --
+    // three turns for the common hit, and with the lanes in different states every turn paid for all three: 150 vector
+    // instructions a turn.)
+    uint32_t groupA[4], groupB[4];
+    int32_t baseA = 0, countA = 0, baseB = 0, countB = 0;
+    bool validA = false, validB = false;
+    int32_t fetched = 0, requested = 0;       // hits [0, fetched) are in the ring or consumed; [fetched, requested) are in flight
     {
         const int32_t first = min(n, 8);
         for(int32_t a = 0; a < first; a++) ring[(a & (SPARSE_RING - 1)) * WAVE + lane].x = list[a];
         fetched = first;
-        pendingBase = fetched; pendingCount = max(0, min(4, n - fetched));
+        baseA = fetched; countA = max(0, min(4, n - baseA)); validA = countA > 0;
+        baseB = baseA + countA; countB = max(0, min(4, n - baseB)); validB = countB > 0;
+        requested = baseB + countB;
 #pragma unroll
-        for(int a = 0; a < 4; a++) pending[a] = list[n > 0 ? min(pendingBase + a, n - 1) : 0];
+        for(int a = 0; a < 4; a++) groupA[a] = list[n > 0 ? min(baseA + a, n - 1) : 0];
+#pragma unroll
+        for(int a = 0; a < 4; a++) groupB[a] = list[n > 0 ? min(baseB + a, n - 1) : 0];
     }
     int32_t k = 0, p = 0, s = 0;
     int32_t value = 0, from = 0, j = 1;
     uint32_t ways = 1;
-    uint64_t links = 1;
+    uint32_t links = 1;                       // bit 0 the border, bit d the hit d back (d <= SPARSE_LINK_REACH), bit 30: one further back
     int32_t prefixMax = SPARSE_NEG, best = SPARSE_NEG, bestAt = -1;
     uint32_t bestWays = 0;
     bool failed = false, active = n > 0, haveHit = false;
-    for(uint32_t turn = 1; __any(active); turn++) {
-        if((turn & 7u) == 0u) {
-            // Top-up (wave-uniform): what was asked for a top-up ago goes into the ring; ask for up to four more while fewer than
-            // eight hits lie ahead of the lane.
+    auto takeHit = [&]() {
+        const uint32_t hit = ring[(k & (SPARSE_RING - 1)) * WAVE + lane].x;
+        p = int32_t(hit >> 16); s = int32_t(hit & 0xffffu);
+        value = -min(p, s); from = 0; j = 1; ways = 1; links = 1;
+        haveHit = true;
+    };
+    auto groupVisit = [&](uint32_t (&group)[4], int32_t& base, int32_t& count, bool& valid) {
+        const bool write = valid && base == fetched && fetched + count <= k + 8;
 #pragma unroll
-            for(int a = 0; a < 4; a++) if(a < pendingCount) ring[((pendingBase + a) & (SPARSE_RING - 1)) * WAVE + lane].x = pending[a];
-            fetched += pendingCount;
-            pendingBase = fetched;
-            pendingCount = active ? max(0, min(min(4, 8 - (fetched - k)), n - fetched)) : 0;
+        for(int a = 0; a < 4; a++) if(write && a < count) ring[((base + a) & (SPARSE_RING - 1)) * WAVE + lane].x = group[a];
+        if(write) { fetched += count; valid = false; }
+        if(active && !valid && requested < n) { base = requested; count = min(4, n - requested); requested += count; valid = true; }
+        // (Unconditional loads from a clamped position: a group that stays is read again -- the list's entries from `fetched` on are
+        // still the raw hits -- and one that is not wanted is not looked at.)
 #pragma unroll
-            for(int a = 0; a < 4; a++) pending[a] = list[n > 0 ? min(pendingBase + a, n - 1) : 0];
-        }
-        if(active && !haveHit && k < fetched) {
-            const uint32_t hit = ring[(k & (SPARSE_RING - 1)) * WAVE + lane].x;
-            p = int32_t(hit >> 16); s = int32_t(hit & 0xffffu);
-            value = -min(p, s); from = 0; j = 1; ways = 1; links = 1;
-            haveHit = true;
-        }
-        else if(active && haveHit) {
+        for(int a = 0; a < 4; a++) group[a] = list[n > 0 ? min(base + a, n - 1) : 0];
+    };
+    auto turnOfTheLoop = [&]() {
+        if(active && !haveHit && k < fetched) takeHit();                   // (the first hit, and after a wait for a group)
+        if(active && haveHit) {
+            // Both entries a turn can look at, read before either is needed.
+            const uint2 e0 = ring[((k - j) & (SPARSE_RING - 1)) * WAVE + lane];
+            const uint2 e1 = ring[((k - j - 1) & (SPARSE_RING - 1)) * WAVE + lane];
             bool finish = false;
-            if(j > k) finish = true;                                       // no hit further back
-            else if(j > SPARSE_LOOK_BACK) { failed = true; active = false; }     // further back than the ring holds: the dense DP takes the task
-            else {
-                const uint2 e = ring[((k - j) & (SPARSE_RING - 1)) * WAVE + lane];
+#pragma unroll
+            for(int u = 0; u < 2; u++) {
+                if(finish || !active) continue;
+                if(j > k) { finish = true; continue; }                     // no hit further back
+                if(j > SPARSE_LOOK_BACK) { failed = true; active = false; continue; }      // further back than the ring holds: the dense DP takes the task
+                const uint2 e = u == 0 ? e0 : e1;
                 const int32_t pq = int32_t(e.x >> 16), sq = int32_t(e.x & 0xffffu);
                 const int32_t dq = int32_t(e.y & 0xfffffu) - SPARSE_D_BIAS;
                 const uint32_t held = (e.y >> 20) & 1023u;
                 const int32_t maxUpToQ = held == 1023u ? prefixMax : dq + int32_t(held);
                 // No hit at q or before it can reach `value` (every one of them is at least p - pq - 1 away): `<`, so that ties are seen.
-                if(maxUpToQ - (p - pq - 1) < value) finish = true;
-                else {
-                    if(pq < p && sq < s) {
-                        const int32_t candidate = dq - max(p - pq - 1, s - sq - 1);
-                        const uint32_t waysQ = 1u + ((e.y >> 30) & 1u);
-                        if(candidate > value) { value = candidate; from = j; ways = waysQ; links = 1ULL << j; }
-                        else if(candidate == value) { ways = min(2u, ways + waysQ); links |= 1ULL << j; }
-                    }
-                    ++j;
+                if(maxUpToQ - (p - pq - 1) < value) { finish = true; continue; }
+                if(pq < p && sq < s) {
+                    const int32_t candidate = dq - max(p - pq - 1, s - sq - 1);
+                    const uint32_t waysQ = 1u + ((e.y >> 30) & 1u);
+                    const uint32_t bit = j <= SPARSE_LINK_REACH ? 1u << j : 0x40000000u;
+                    if(candidate > value) { value = candidate; from = j; ways = waysQ; links = bit; }
+                    else if(candidate == value) { ways = min(2u, ways + waysQ); links |= bit; }
                 }
+                ++j;
             }
             if(finish) {
                 const int32_t d = 6 + value;
@@ -244,14 +263,24 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                 prefixMax = newMax;
                 list[k] = (uint32_t(p) << 17) | (uint32_t(s - p - lo) << 7) | uint32_t(from);
                 const int32_t end = d - min(np - 1 - p, ns - 1 - s);
-                myLinks[k] = (uint32_t(links) & 0x3fffffffu) | ((links >> (SPARSE_LINK_REACH + 1)) != 0 ? 0x40000000u : 0u) | (end >= best ? 0x80000000u : 0u);
+                myLinks[k] = links | (end >= best ? 0x80000000u : 0u);
                 if(end > best) { best = end; bestAt = k; bestWays = ways; }
                 else if(end == best) bestWays = min(2u, bestWays + ways);
                 ++k;
                 haveHit = false;
                 if(k == n) active = false;
+                else if(k < fetched) takeHit();
             }
         }
+    };
+    // Eight turns to a round, the two groups' visits at its two fixed places (each group's registers are touched at ONE place of
+    // the program: visited by turn number inside one loop body, the compiler merged the two groups into one set of registers
+    // copied back and forth every turn, behind a wait for everything in flight).
+    while(__any(active)) {
+        groupVisit(groupA, baseA, countA, validA);
+        turnOfTheLoop(); turnOfTheLoop(); turnOfTheLoop(); turnOfTheLoop();
+        groupVisit(groupB, baseB, countB, validB);
+        turnOfTheLoop(); turnOfTheLoop(); turnOfTheLoop(); turnOfTheLoop();
     }
     {
         // What the two kernels read, for the kernel table: matches listed for the tasks' candidates, matches inside the tasks' bands.
