@@ -306,17 +306,18 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);
     if(!empty) {
-        // (Four entries per round trip to memory: the chain mostly steps back by one, and a walk of dependent single loads --
+        // (Eight entries per round trip to memory: the chain mostly steps back by one, and a walk of dependent single loads --
         // a load's address known only when the one before it has arrived -- would be as long as the chain times the latency.)
+        constexpr int WALK = 8;
         int32_t at = bestAt;
         bool more = true;
         for(int32_t rounds = 0; more && rounds <= n; rounds++) {          // (a chain has at most n hits: the walk ends whatever the list holds)
-            uint32_t window[4];
+            uint32_t window[WALK];
 #pragma unroll
-            for(int a = 0; a < 4; a++) window[a] = list[max(at - a, 0)];
+            for(int a = 0; a < WALK; a++) window[a] = list[max(at - a, 0)];
             const int32_t top = at;
 #pragma unroll
-            for(int a = 0; a < 4; a++) {
+            for(int a = 0; a < WALK; a++) {
                 if(more && top - a == at) {
                     const uint32_t e = window[a];
                     const int32_t hp = int32_t(e >> 17), hs = hp + lo + int32_t((e >> 7) & 1023u);
