@@ -232,29 +232,38 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
             // Both entries a turn can look at, read before either is needed.
             const uint2 e0 = ring[((k - j) & (SPARSE_RING - 1)) * WAVE + lane];
             const uint2 e1 = ring[((k - j - 1) & (SPARSE_RING - 1)) * WAVE + lane];
-            bool finish = false;
+            // (Selects, not branches: the lanes of a wavefront differ in what an entry means to them, and the compiler's
+            // structured branches cost more than the arithmetic they skip -- 31 register moves and 14 mask saves per turn.)
+            bool finish = false, looking = true;
 #pragma unroll
             for(int u = 0; u < 2; u++) {
-                if(finish || !active) continue;
-                if(j > k) { finish = true; continue; }                     // no hit further back
-                if(j > SPARSE_LOOK_BACK) { failed = true; active = false; continue; }      // further back than the ring holds: the dense DP takes the task
                 const uint2 e = u == 0 ? e0 : e1;
                 const int32_t pq = int32_t(e.x >> 16), sq = int32_t(e.x & 0xffffu);
                 const int32_t dq = int32_t(e.y & 0xfffffu) - SPARSE_D_BIAS;
                 const uint32_t held = (e.y >> 20) & 1023u;
                 const int32_t maxUpToQ = held == 1023u ? prefixMax : dq + int32_t(held);
+                const bool noMore = j > k;                                  // no hit further back
+                const bool tooFar = j > SPARSE_LOOK_BACK;                   // further back than the ring holds: the dense DP takes the task
                 // No hit at q or before it can reach `value` (every one of them is at least p - pq - 1 away): `<`, so that ties are seen.
-                if(maxUpToQ - (p - pq - 1) < value) { finish = true; continue; }
-                if(pq < p && sq < s) {
-                    const int32_t candidate = dq - max(p - pq - 1, s - sq - 1);
-                    const uint32_t waysQ = 1u + ((e.y >> 30) & 1u);
-                    const uint32_t bit = j <= SPARSE_LINK_REACH ? 1u << j : 0x40000000u;
-                    if(candidate > value) { value = candidate; from = j; ways = waysQ; links = bit; }
-                    else if(candidate == value) { ways = min(2u, ways + waysQ); links |= bit; }
-                }
-                ++j;
+                const bool stop = maxUpToQ - (p - pq - 1) < value;
+                const bool fail = looking && !noMore && tooFar;
+                const bool consider = looking && !noMore && !tooFar && !stop;
+                finish = finish || (looking && (noMore || (!tooFar && stop)));
+                failed = failed || fail;
+                const bool good = consider && pq < p && sq < s;
+                const int32_t candidate = dq - max(p - pq - 1, s - sq - 1);
+                const uint32_t waysQ = 1u + ((e.y >> 30) & 1u);
+                const uint32_t bit = j <= SPARSE_LINK_REACH ? 1u << j : 0x40000000u;
+                const bool better = good && candidate > value, equal = good && candidate == value;
+                ways = better ? waysQ : (equal ? min(2u, ways + waysQ) : ways);
+                links = better ? bit : (equal ? (links | bit) : links);
+                from = better ? j : from;
+                value = better ? candidate : value;
+                j += consider ? 1 : 0;
+                looking = consider;
             }
-            if(finish) {
+            if(failed) active = false;
+            if(finish && active) {
                 const int32_t d = 6 + value;
                 const int32_t newMax = max(prefixMax, d);
                 const uint32_t held = uint32_t(min(newMax - d, 1023));
