@@ -25,6 +25,8 @@
 // A task with no anchor, a live hit whose optimal links reach further back than its link word names (29 hits), a rectangle of more than ANCHOR_MAX_CELLS cells or ANCHOR_MAX_SIDE markers on a side, too many windows or
 // too many pairs inside them stays for the dense kernels (state SPARSE_DENSE), as before.
 #pragma once
+// (An emulated build compiled with -D'ANCHOR_REASON(why, n)=...' reports why the anchor kernel left a task to the dense kernels:
+// 1 no anchor, 2 too many windows, 3 a rectangle or its pairs beyond the limits, 4 an optimal link of a live hit beyond its link word.)
 #ifndef ANCHOR_REASON
 #define ANCHOR_REASON(why, n)
 #endif

@@ -32,9 +32,6 @@
 //                       the task's range of the ordinal scratch, as dpTracebackKernel does.
 //   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
 #pragma once
-#ifndef ANCHOR_REASON
-#define ANCHOR_REASON(why, n)
-#endif
 
 constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the read the hits are ordered by (4-bit counters: 4 KB per wavefront): the tabled read, always below this
 constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;

@@ -597,12 +597,19 @@ evaluatePairsKernel(
 {
     __shared__ int sHigh[EVALUATE_LDS_ITERATIONS], sTotal[EVALUATE_LDS_ITERATIONS];
     const bool inLds = iterations <= uint32_t(EVALUATE_LDS_ITERATIONS);
+    // A run has ten iterations or so: every thread's atomics would land on the same ten words (a wavefront's 64 on one word take
+    // 64 turns in the LDS).  With few iterations each gets EVALUATE_COPIES words, one per bank, a lane adding to the one of its
+    // number: two lanes to a word at most.
+    constexpr uint32_t EVALUATE_COPIES = 32;
+    const bool spread = iterations * EVALUATE_COPIES <= uint32_t(EVALUATE_LDS_ITERATIONS);
+    const uint32_t slots = spread ? iterations * EVALUATE_COPIES : iterations;
+    const uint32_t copy = threadIdx.x & (EVALUATE_COPIES - 1u);
     if(inLds) {
-        for(uint32_t t = threadIdx.x; t < iterations; t += blockDim.x) { sHigh[t] = 0; sTotal[t] = 0; }
+        for(uint32_t t = threadIdx.x; t < slots; t += blockDim.x) { sHigh[t] = 0; sTotal[t] = 0; }
         __syncthreads();
     }
     auto add = [&](int* lds, unsigned long long* global, uint32_t t, int delta) {
-        if(inLds) atomicAdd(&lds[t], delta);
+        if(inLds) atomicAdd(&lds[spread ? t * EVALUATE_COPIES + copy : t], delta);
         else atomicAdd(&global[t], (unsigned long long)(long long)delta);
     };
     for(uint64_t base = uint64_t(blockIdx.x) * blockDim.x; base <= n; base += uint64_t(gridDim.x) * blockDim.x) {
@@ -629,8 +636,11 @@ evaluatePairsKernel(
     if(inLds) {
         __syncthreads();
         for(uint32_t t = threadIdx.x; t < iterations; t += blockDim.x) {
-            if(sHigh[t]) atomicAdd(&highDelta[t], (unsigned long long)(long long)sHigh[t]);
-            if(sTotal[t]) atomicAdd(&totalDelta[t], (unsigned long long)(long long)sTotal[t]);
+            int high = 0, total = 0;
+            if(spread) for(uint32_t c = 0; c < EVALUATE_COPIES; c++) { high += sHigh[t * EVALUATE_COPIES + c]; total += sTotal[t * EVALUATE_COPIES + c]; }
+            else { high = sHigh[t]; total = sTotal[t]; }
+            if(high) atomicAdd(&highDelta[t], (unsigned long long)(long long)high);
+            if(total) atomicAdd(&totalDelta[t], (unsigned long long)(long long)total);
         }
     }
 }
