@@ -189,7 +189,11 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     int32_t fetched = 0, requested = 0;       // hits [0, fetched) are in the ring or consumed; [fetched, requested) are in flight
     {
         const int32_t first = min(n, 8);
-        for(int32_t a = 0; a < first; a++) ring[(a & (SPARSE_RING - 1)) * WAVE + lane].x = list[a];
+        uint32_t head[8];                       // (all eight loads before the first is looked at: one latency, not eight)
+#pragma unroll
+        for(int a = 0; a < 8; a++) head[a] = list[n > 0 ? min(a, n - 1) : 0];
+#pragma unroll
+        for(int a = 0; a < 8; a++) if(a < first) ring[a * WAVE + lane].x = head[a];
         fetched = first;
         baseA = fetched; countA = max(0, min(4, n - baseA)); validA = countA > 0;
         baseB = baseA + countA; countB = max(0, min(4, n - baseB)); validB = countB > 0;
