@@ -13,23 +13,25 @@
 //
 // is the dense DP's optimum, and the dense traceback returns the match set of SOME optimal chain whatever its tie policy.  The
 // kernel counts the optimal chains (capped at two) and answers only when there is exactly ONE (or when no chain reaches Z: the
-// empty alignment): then every tie policy -- every reading of SeqAn -- gives that very set, and the task is "certified"; all
-// other tasks (several optimal chains, a hit whose search for predecessors goes further back than the ring holds, lists that
-// did not fit, reads beyond the tables here) run in the dense kernels exactly as before.  At 100 k reads 87 % of the tasks
-// (85 % of the DP cells) are certified (oracle's census over the same candidates, profiles/r04_sparse_census.txt).
+// empty alignment): then every tie policy -- every reading of SeqAn -- gives that very set, and the task is "certified".  A task
+// with several optimal chains goes on to sparseAnchorKernel (align4_anchor.hpp: the dense DP only between the matches every
+// optimal chain holds), for which this kernel leaves a link word beside every hit; the rest (a hit whose search for predecessors
+// goes further back than the ring holds, lists that did not fit, reads beyond the tables here) runs in the dense kernels exactly
+// as before.  At 100 k reads 87 % of the tasks (85 % of the DP cells) are certified and all but 0.2 % of the others are the anchor
+// kernel's (oracle's census over the same candidates, profiles/r04_sparse_census.txt).
 //
 //   sparseSortKernel    a wavefront per task: the candidate's hit list filtered by the task's band and ordered by the ordinal in
 //                       the TABLED read (fewer than 8192 markers by the cells stage's classes, however long the other read is;
 //                       either order serves the recurrence, it is symmetric): a
 //                       counting sort on 4-bit counters per marker in LDS (two hits of one marker inside a band are common: the
 //                       background of a 15 000-k-mer alphabet; sixteen send the task to the dense DP).
-//   sparseChainKernel   a LANE per task (the recurrence is sequential in the hits), the work flattened into units -- one
-//                       predecessor looked at, or one hit finished -- so that a lane whose hit needs a long look back (an
-//                       off-chain hit: as many hits back as the band is wide) does not hold the other 63 at their hits; the last
-//                       56 hits of every lane in an LDS ring {ordinals, D, prefix maximum of D} whose other 8 slots hold the hits
-//                       the lane needs next; the chosen predecessor of a hit
-//                       written back into the task's list, which the lane then walks from the best end to emit the pairs into
-//                       the task's range of the ordinal scratch, as dpTracebackKernel does.
+//   sparseChainKernel   a LANE per task (the recurrence is sequential in the hits).  A turn of its loop looks at up to two
+//                       predecessors of the lane's hit and, if that settles it, finishes the hit and takes the next: the common
+//                       hit is one turn and the lanes stay in step, while a hit that needs a long look back (an off-chain hit: as
+//                       many hits back as the band is wide) only holds its own lane.  The last 56 hits of every lane in an LDS
+//                       ring {ordinals, D, prefix maximum of D} whose other 8 slots hold the hits the lane needs next; the chosen
+//                       predecessor of a hit written back into the task's list, which the lane then walks from the best end to
+//                       emit the pairs into the task's range of the ordinal scratch, as dpTracebackKernel does.
 //   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
 #pragma once
 
