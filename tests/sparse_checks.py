@@ -186,3 +186,34 @@ def anchored_tasks(lib, orc, seeds=(3, 4), tasks=30, alternatives=tie_policy_che
         narrow = (spec[:, 5] - spec[:, 4] + 1) <= 1024
         cells_all += int((spec[narrow, 1] * (spec[narrow, 5] - spec[narrow, 4] + 1)).sum())
     return runs, cells_all, cells_sparse, cells_anchored
+
+
+def tiny_tasks(lib, orc, seed=11, tasks=400, alternatives=tie_policy_checks.ALTERNATIVES):
+    """Reads of 1 to 40 markers over alphabets of 2^20, 6 and 3 k-mers, bands of 4 to 64 diagonals anywhere in the matrix: tasks
+    with no hit, one hit, fewer hits than the chain kernel takes in its first group, and ties everywhere.  -> task runs."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+    for t in range(tasks):
+        n = int(rng.integers(1, 40))
+        alphabet = int(rng.choice([1 << 20, 6, 3]))
+        g = rng.integers(0, alphabet, size=n + 10, dtype=np.uint32)
+        a = g[:n].copy()
+        b = g[int(rng.integers(0, 5)):][:int(rng.integers(1, n + 1))].copy()
+        if rng.random() < 0.3:
+            b = np.repeat(b, 1 + (rng.random(len(b)) < 0.2))
+        w = int(rng.choice([4, 8, 20, 64]))
+        lo = int(rng.integers(-len(b), len(a))) - w // 2
+        lo = min(max(lo, -len(b) - w + 1), len(a))
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), lo, lo + w - 1))
+        at += len(a) + len(b)
+    kmer, spec = np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+    runs = 0
+    for policy in (0,) + tuple(alternatives):
+        with tie_policy_checks.policy(orc, policy):
+            want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
+            got = _run(lib, kmer, spec)
+        for i, ((x, sx), (y, sy)) in enumerate(zip(want, got)):
+            assert sx == sy and np.array_equal(x, y), (policy, tuple(int(v) for v in spec[i]))
+        runs += len(spec)
+    return runs

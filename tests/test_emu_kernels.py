@@ -320,6 +320,7 @@ def test_locally_ambiguous_tasks_through_the_anchor_kernel(emu_lib, oracle_lib):
     from tests import sparse_checks
     runs, cells_all, cells_sparse, cells_anchored = sparse_checks.anchored_tasks(emu_lib, oracle_lib, seeds=(3, 4), tasks=24)
     assert runs >= 120 and cells_sparse > 0.8 * cells_all and cells_anchored < 0.4 * cells_all
+    assert sparse_checks.tiny_tasks(emu_lib, oracle_lib, tasks=200, alternatives=(3,)) >= 400
 
 
 def test_read_statistics_over_several_partitions_and_spans(emu_lib, oracle_lib):

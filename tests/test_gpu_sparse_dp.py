@@ -22,3 +22,7 @@ def test_locally_ambiguous_tasks_through_the_anchor_kernel(gpu_lib, oracle_lib):
     # leaves nearly all of them to the dense kernels, the anchor kernel solves the rectangles between the anchors and leaves a fraction.
     runs, cells_all, cells_sparse, cells_anchored = sparse_checks.anchored_tasks(gpu_lib, oracle_lib, seeds=(3, 4, 5, 6), tasks=40)
     assert runs >= 400 and cells_sparse > 0.8 * cells_all and cells_anchored < 0.4 * cells_all
+
+
+def test_tiny_tasks_through_the_sparse_and_anchor_kernels(gpu_lib, oracle_lib):
+    assert sparse_checks.tiny_tasks(gpu_lib, oracle_lib) >= 1200
