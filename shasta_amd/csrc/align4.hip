@@ -337,7 +337,7 @@ bool sparseDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_SPARSE_DP");
 bool anchoredDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHORED_DP"); return !e || std::atoi(e) != 0; }
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
-    uint32_t extraTasks = 0, uint64_t extraOrdinals = 0, const SparseInput* sparse = nullptr)
+    uint32_t extraTasks = 0, uint64_t extraOrdinals = 0, const SparseInput* sparse = nullptr, const DeviceOptions* metricsOptions = nullptr)
 {
     hipStream_t stream = ws.stream;
     DpForwardState f;
@@ -370,7 +370,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         // K10s (align4_sparse.hpp): every task whose alignment is the unique optimal chain of the matches inside its band gets
         // it from those matches; the dense kernels below run what is left.  The tasks' ordered hits need room that depends on the
         // ordinal total: one synchronisation earlier than the dense path takes its own.
-        MI355X_ASSERT(reserveOrdinals);
+        MI355X_ASSERT(reserveOrdinals && metricsOptions);
         if(timers) (void)timers->end(prepareSpan, 16ULL * taskCount, taskCount);
         const uint64_t ordTotalEarly = readDevice(&control->ordCursor, stream);      // synchronises
         b.ordScratch.reserve(2 * (ordTotalEarly + extraOrdinals) + 2, stream);
@@ -390,7 +390,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
             in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
             (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(),
-            b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), control);
+            b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), control, *metricsOptions, b.pairBest.data());
         HIP_CHECK(hipGetLastError());
         if(timers) chainHandle = timers->end(span, 0, taskCount);
         // K10a (align4_anchor.hpp): the tasks with several optimal chains, the dense DP only where the chains differ.
@@ -804,7 +804,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     }
     DpForwardState f;
     std::memset(&f, 0, sizeof(f));
-    if(taskCount) f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers, wideCount, wideOrdinals, (sparse && defaultScores(in.scores)) ? sparse : nullptr);
+    if(taskCount) f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers, wideCount, wideOrdinals, (sparse && defaultScores(in.scores)) ? sparse : nullptr, &opt);
     else { b.results.reserve(wideCount, stream); b.ordScratch.reserve(2 * wideOrdinals + 2, stream); }
     // The traceback of every class in one launch (the list is sorted by class, then by ascending length; the kernel takes it from the end).
     // Booked: the trace it has to read = 2 bits per cell of the padded bands, once per bundle (the bundles' trace words as
@@ -823,7 +823,8 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     const uint32_t allTasks = taskCount + wideCount;
     SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, allTasks,
         hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(allTasks) * WAVE, 256)), dim3(256), 0, stream,
-            in.pairs, in.tasks, allTasks, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data()));
+            in.pairs, in.tasks, allTasks, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data(),
+            (taskCount && sparse && defaultScores(in.scores)) ? (const uint8_t*)b.sparseState.data() : (const uint8_t*)nullptr, taskCount));
     HIP_CHECK(hipGetLastError());
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[2 + DP_CLASSES + c]; stats->tasks[c] = f.classCounts[c]; }
     return f.sums[0] + wideCells;

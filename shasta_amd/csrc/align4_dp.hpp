@@ -642,6 +642,49 @@ __device__ __forceinline__ void tracebackFinish(uint32_t pos, const PairDesc& pd
     results[t] = r;
 }
 
+// A streak of the shasta::compress form (src/compressAlignment.cpp): the skips of its first pair against the pair before and
+// its length, in 1, 2, 4, 8 or 16 bytes.
+struct StreakRecord { uint64_t bits; uint32_t w[3]; int len; };
+
+__device__ __forceinline__ StreakRecord makeStreakRecord(int32_t skip0, int32_t skip1, uint32_t streak)
+{
+    StreakRecord r;
+    const uint64_t u0 = uint32_t(skip0), u1 = uint32_t(skip1), nm1 = uint64_t(streak) - 1;
+    r.w[0] = uint32_t(skip0); r.w[1] = uint32_t(skip1); r.w[2] = uint32_t(nm1);
+    if(skip0 >= 0 && skip0 <= 3 && skip1 >= 0 && skip1 <= 3 && streak <= 8) {
+        r.bits = 0 | (u0 & 3) << 1 | (u1 & 3) << 3 | (nm1 & 7) << 5; r.len = 1;
+    } else if(skip0 >= -8 && skip0 <= 7 && skip1 >= -8 && skip1 <= 7 && streak <= 32) {
+        r.bits = 1 | (u0 & 0xf) << 3 | (u1 & 0xf) << 7 | (nm1 & 0x1f) << 11; r.len = 2;
+    } else if(skip0 >= -512 && skip0 <= 511 && skip1 >= -512 && skip1 <= 511 && streak <= 512) {
+        r.bits = 3 | (u0 & 0x3ff) << 3 | (u1 & 0x3ff) << 13 | (nm1 & 0x1ff) << 23; r.len = 4;
+    } else if(skip0 >= -524288 && skip0 <= 524287 && skip1 >= -524288 && skip1 <= 524287 && streak <= 2097152) {
+        r.bits = 5 | (u0 & 0xfffff) << 3 | (u1 & 0xfffff) << 23 | (nm1 & 0x1fffff) << 43; r.len = 8;
+    } else {
+        r.bits = 7; r.len = 16;
+    }
+    return r;
+}
+
+
+// The inner acceptance of a task (src/Align4.cpp:944-981) from its metrics, and its candidate's best component (:132-139): most
+// aligned markers; ties resolved towards the component whose first cell in (iY, iX) order comes first, and flagged later.
+__device__ __forceinline__ void taskAcceptance(DpResult& r, const PairDesc& pd, const DpTask& task, const DeviceOptions& opt, unsigned long long* __restrict__ pairBest)
+{
+    const uint32_t count = r.markerCount;
+    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
+    if(pass) {
+        const double f0 = double(count) / double(r.last0 + 1 - r.first0);
+        const double f1 = double(count) / double(r.last1 + 1 - r.first1);
+        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
+        if(uint64_t(r.maxSkip) > opt.maxSkip || uint64_t(r.maxDrift) > opt.maxDrift) pass = false;
+        const uint32_t leftTrim = min(r.first0, r.first1);
+        const uint32_t rightTrim = min(pd.nx - 1 - r.last0, pd.ny - 1 - r.last1);
+        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
+    }
+    r.passes = pass ? 1u : 0u;
+    if(pass) atomicMax(&pairBest[task.pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - task.label));
+}
+
 // Tasks [taskBegin, taskEnd) of the sorted list, all of a class with C diagonals per lane (C = 2 or 4).
 constexpr int DP_TRACE_CHUNK_QUADS = 16;                    // 16-byte pieces of a 256-byte chunk: {low plane, high plane} of one diagonal of one iteration
 __global__ void __launch_bounds__(256)

@@ -93,27 +93,7 @@ gatherOrdinalsKernel(const DpResult* __restrict__ results, const uint32_t* __res
 // A streak is a maximal run of marker pairs that advance both ordinals by one; its record holds
 // (skip0, skip1) from the last pair of the previous streak (from (0,0) for the first) and its
 // length, in the smallest of five formats (1/2/4/8/16 bytes).
-struct StreakRecord { uint64_t bits; uint32_t w[3]; int len; };
-
-__device__ __forceinline__ StreakRecord makeStreakRecord(int32_t skip0, int32_t skip1, uint32_t streak)
-{
-    StreakRecord r;
-    const uint64_t u0 = uint32_t(skip0), u1 = uint32_t(skip1), nm1 = uint64_t(streak) - 1;
-    r.w[0] = uint32_t(skip0); r.w[1] = uint32_t(skip1); r.w[2] = uint32_t(nm1);
-    if(skip0 >= 0 && skip0 <= 3 && skip1 >= 0 && skip1 <= 3 && streak <= 8) {
-        r.bits = 0 | (u0 & 3) << 1 | (u1 & 3) << 3 | (nm1 & 7) << 5; r.len = 1;
-    } else if(skip0 >= -8 && skip0 <= 7 && skip1 >= -8 && skip1 <= 7 && streak <= 32) {
-        r.bits = 1 | (u0 & 0xf) << 3 | (u1 & 0xf) << 7 | (nm1 & 0x1f) << 11; r.len = 2;
-    } else if(skip0 >= -512 && skip0 <= 511 && skip1 >= -512 && skip1 <= 511 && streak <= 512) {
-        r.bits = 3 | (u0 & 0x3ff) << 3 | (u1 & 0x3ff) << 13 | (nm1 & 0x1ff) << 23; r.len = 4;
-    } else if(skip0 >= -524288 && skip0 <= 524287 && skip1 >= -524288 && skip1 <= 524287 && streak <= 2097152) {
-        r.bits = 5 | (u0 & 0xfffff) << 3 | (u1 & 0xfffff) << 23 | (nm1 & 0x1fffff) << 43; r.len = 8;
-    } else {
-        r.bits = 7; r.len = 16;
-    }
-    return r;
-}
-
+// (StreakRecord, makeStreakRecord: align4_dp.hpp -- the chain kernel counts the bytes of its tasks' alignments too)
 __device__ __forceinline__ void writeStreakRecord(const StreakRecord& r, uint8_t* __restrict__ out)
 {
     if(r.len == 16) {
@@ -223,10 +203,12 @@ compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __
 __global__ void __launch_bounds__(256)
 dpMetricsKernel(
     const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
-    const uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+    const uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, DeviceOptions opt, unsigned long long* __restrict__ pairBest,
+    const uint8_t* __restrict__ sparseState, uint32_t sparseStateCount)       // (null: every task's metrics are taken here)
 {
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if(t >= taskCount) return;
+    if(sparseState && t < sparseStateCount && sparseState[t] == SPARSE_COMPLETE) return;       // sparseChainKernel took them while it walked the chain
     const int lane = laneId();
     DpResult r = results[t];
     const uint32_t count = r.markerCount;
@@ -243,23 +225,11 @@ dpMetricsKernel(
         maxSkip = max(maxSkip, uint32_t(__shfl_xor(int(maxSkip), d, WAVE))); maxDrift = max(maxDrift, uint32_t(__shfl_xor(int(maxDrift), d, WAVE)));
     }
     if(lane != 0) return;
-    const PairDesc pd = pairs[tasks[t].pair];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
     if(count) { const uint2 f = p[0], l = p[count - 1]; r.first0 = f.x; r.first1 = f.y; r.last0 = l.x; r.last1 = l.y; }
     r.minOffset = minOffset; r.maxOffset = maxOffset; r.sumOffset = sumOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
     r.compressedBytes = uint32_t(compressedBytes < 0xffffffffULL ? compressedBytes : 0xffffffffULL);
-    bool pass = count > 0 && uint64_t(count) >= opt.minAlignedMarkerCount;
-    if(pass) {
-        const double f0 = double(count) / double(r.last0 + 1 - r.first0);
-        const double f1 = double(count) / double(r.last1 + 1 - r.first1);
-        if(min(f0, f1) < opt.minAlignedFraction) pass = false;
-        if(uint64_t(maxSkip) > opt.maxSkip || uint64_t(maxDrift) > opt.maxDrift) pass = false;
-        const uint32_t leftTrim = min(r.first0, r.first1);
-        const uint32_t rightTrim = min(pd.nx - 1 - r.last0, pd.ny - 1 - r.last1);
-        if(uint64_t(leftTrim) > opt.maxTrim || uint64_t(rightTrim) > opt.maxTrim) pass = false;
-    }
-    r.passes = pass ? 1u : 0u;
+    taskAcceptance(r, pd, task, opt, pairBest);
     results[t] = r;
-    // Best component = most aligned markers (:132-139); ties resolved towards the
-    // component whose first cell in (iY,iX) order comes first, and flagged later.
-    if(pass) atomicMax(&pairBest[tasks[t].pair], ((unsigned long long)count << 32) | (unsigned long long)(0xffffffffu - tasks[t].label));
 }

@@ -39,7 +39,7 @@ constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the r
 constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
 constexpr int SPARSE_RING = 64;                              // slots of a lane's ring: the hits it can look back on and the next ones it will need
 constexpr int SPARSE_LOOK_BACK = 56;                         // hits a lane can look back
-enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2, SPARSE_AMBIGUOUS = 3 };   // AMBIGUOUS: several optimal chains, forward pass kept: sparseAnchorKernel's (align4_anchor.hpp)
+enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2, SPARSE_AMBIGUOUS = 3, SPARSE_COMPLETE = 4 };   // CERTIFIED: the pairs are in the ordinal scratch; COMPLETE: and the task's metrics in its result (dpMetricsKernel skips it);   // AMBIGUOUS: several optimal chains, forward pass kept: sparseAnchorKernel's (align4_anchor.hpp)
 constexpr int SPARSE_LINK_REACH = 29;                        // how far back (in hits) a hit's link word names its optimal links; bit 30: one goes further
 
 // Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets[t] = where the task's min(nx, ny) + 32 pairs of
@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(64)
 sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ order, uint32_t taskCount,
     uint32_t* __restrict__ sorted, const uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, const uint32_t* __restrict__ hitMeta,
     const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
-    uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, DpControl* __restrict__ control)
+    uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, DpControl* __restrict__ control,
+    DeviceOptions opt, unsigned long long* __restrict__ pairBest)
 {
     __shared__ uint2 ring[SPARSE_RING * WAVE];             // [slot][lane]
     const int lane = laneId();
@@ -314,15 +315,24 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
         state[t] = SPARSE_AMBIGUOUS;
         return;
     }
-    // The chain, from its last hit back, into the end of the task's range of the ordinal scratch (as dpTracebackKernel leaves it).
+    // The chain, from its last hit back, into the end of the task's range of the ordinal scratch (as dpTracebackKernel leaves it) --
+    // and, on the way, what dpMetricsKernel would read the pairs again for: AlignmentInfo's offsets, skips and drifts
+    // (src/Alignment.cpp:67-113) and the size of the alignment in shasta::compress form (a streak of consecutive pairs is a record
+    // of its first pair's skips and its length: walking back, a streak is known when the pair before its first one is met).
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);
+    DpResult r;
+    r.sumOffset = 0; r.first0 = r.first1 = r.last0 = r.last1 = 0; r.minOffset = 0x7fffffff; r.maxOffset = int32_t(0x80000000);
+    r.maxSkip = r.maxDrift = 0; r.passes = 0; r.compressedBytes = 0;
+    uint64_t bytes = 0;
     if(!empty) {
         // (Eight entries per round trip to memory: the chain mostly steps back by one, and a walk of dependent single loads --
         // a load's address known only when the one before it has arrived -- would be as long as the chain times the latency.)
         constexpr int WALK = 8;
         int32_t at = bestAt;
-        bool more = true;
+        bool more = true, haveLater = false;
+        int32_t laterX = 0, laterY = 0;           // the pair met before this one: the next one of the alignment
+        uint32_t streak = 1;                      // pairs of the streak that the later pair belongs to, from it on
         for(int32_t rounds = 0; more && rounds <= n; rounds++) {          // (a chain has at most n hits: the walk ends whatever the list holds)
             uint32_t window[WALK];
 #pragma unroll
@@ -333,17 +343,37 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
                 if(more && top - a == at) {
                     const uint32_t e = window[a];
                     const int32_t hp = int32_t(e >> 17), hs = hp + lo + int32_t((e >> 7) & 1023u);
+                    const int32_t x = swapped ? hs : hp, y = swapped ? hp : hs;
                     --pos;
-                    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = swapped ? make_uint2(uint32_t(hs), uint32_t(hp)) : make_uint2(uint32_t(hp), uint32_t(hs));
+                    *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos)) = make_uint2(uint32_t(x), uint32_t(y));
+                    const int32_t offset = x - y;
+                    r.minOffset = min(r.minOffset, offset); r.maxOffset = max(r.maxOffset, offset); r.sumOffset += offset;
+                    if(haveLater) {
+                        const int32_t skip0 = laterX - x, skip1 = laterY - y;
+                        r.maxSkip = max(r.maxSkip, max(uint32_t(skip0), uint32_t(skip1)));
+                        const int32_t drift = skip0 - skip1;
+                        r.maxDrift = max(r.maxDrift, uint32_t(drift < 0 ? -drift : drift));
+                        if(skip0 == 1 && skip1 == 1) ++streak;
+                        else { bytes += uint64_t(makeStreakRecord(skip0, skip1, streak).len); streak = 1; }
+                    }
+                    else { r.last0 = uint32_t(x); r.last1 = uint32_t(y); haveLater = true; }
+                    laterX = x; laterY = y;
                     const int32_t back = int32_t(e & 127u);
                     if(back == 0 || back > at || pos == 0) more = false; else at -= back;
                 }
             }
         }
+        // The first pair: its streak's skips are taken against (0, 0).
+        r.first0 = uint32_t(laterX); r.first1 = uint32_t(laterY);
+        bytes += uint64_t(makeStreakRecord(laterX, laterY, streak).len);
     }
-    DpEnd e; e.traceOffset = 0; e.bestI = e.bestJ = 0; e.score = empty ? matchless : best; e.laneBase = 0; e.bundleIterations = 0; e.pad = 0;
-    tracebackFinish(pos, pd, e, ordBase, t, results);
-    state[t] = SPARSE_CERTIFIED;
+    r.ordBegin = ordBase + pos;
+    r.markerCount = min(pd.nx, pd.ny) - pos;
+    r.score = empty ? matchless : best;
+    r.compressedBytes = uint32_t(bytes < 0xffffffffULL ? bytes : 0xffffffffULL);
+    taskAcceptance(r, pd, task, opt, pairBest);
+    results[t] = r;
+    state[t] = SPARSE_COMPLETE;
 }
 
 // The sorted task list without the certified tasks.  flags[i] = 1 where sorted position i stays (flags[taskCount] = 0, for the scan's total).
@@ -352,7 +382,8 @@ dpDenseFlagsKernel(const uint32_t* __restrict__ sortedIds, const uint8_t* __rest
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i > taskCount) return;
-    flags[i] = (i < taskCount && state[sortedIds[i]] != SPARSE_CERTIFIED) ? 1u : 0u;
+    const uint8_t st = i < taskCount ? state[sortedIds[i]] : uint8_t(SPARSE_CERTIFIED);
+    flags[i] = (st != SPARSE_CERTIFIED && st != SPARSE_COMPLETE) ? 1u : 0u;
 }
 
 // positions = exclusive scan of the flags.  Class counts and the per-class sums (DP cells, algorithmic bytes) of the tasks that stay:
