@@ -203,3 +203,19 @@ def test_bench_script_one_rank_through_the_sharded_branch_on_the_emulated_build(
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL all-to-all" in line["config"]["parallelism"]
     assert line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0 and "cpu_baseline" not in line
+
+
+def test_bench_script_falls_back_on_the_library_switches_after_a_parity_failure(emu_lib):
+    """bench.py's safety net: a failed parity check at bench size (forced here) makes the script run again with the library's own
+    switch back to the earlier form of its kernels, and the line says so -- never silently."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, SHASTA_BENCH_FORCE_PARITY_FAILURE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "100", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "SHASTA_MI355X_ANCHORED_DP=0" in line["path"] and len(line["earlier_attempts"]) == 1 and line["earlier_attempts"][0]["switches"] == {}
+    assert line["banded_dp"]["matches_walked_by_the_anchor_kernel_per_step"] is None and line["value"] > 0
+    assert "FAILED on this path" in out.stderr
