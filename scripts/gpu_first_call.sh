@@ -24,6 +24,8 @@ for name in (os.environ.get("ROUND", "r05") + "_bench_a", os.environ.get("ROUND"
     except Exception as e:
         print(name, "unreadable", e); continue
     print("==", name, "ms/step %.1f value %.0f" % (d["ms_per_step"], d["value"]), {k: (round(v * 1e3, 2) if v is not None else None) for k, v in d["stage_seconds_per_step"].items()})
+    if d.get("path"):
+        print("!!", d["path"], "after", d.get("earlier_attempts"))
     print("each", d["stage_device_ms_each_step"])
     if "cpu_baseline" in d:
         print("cpu", json.dumps(d["cpu_baseline"])[:1400]); print("parity", d["parity_at_bench_size"])
