@@ -219,3 +219,19 @@ def test_bench_script_falls_back_on_the_library_switches_after_a_parity_failure(
     assert "SHASTA_MI355X_ANCHORED_DP=0" in line["path"] and len(line["earlier_attempts"]) == 1 and line["earlier_attempts"][0]["switches"] == {}
     assert line["banded_dp"]["matches_walked_by_the_anchor_kernel_per_step"] is None and line["value"] > 0
     assert "FAILED on this path" in out.stderr
+
+
+def test_fallback_switches_one_step_at_a_time(monkeypatch):
+    import bench
+    for k in bench.FALLBACK_SWITCHES + ("SHASTA_BENCH_FORCE_PARITY_FAILURE", "SHASTA_BENCH_EARLIER_ATTEMPTS"):
+        monkeypatch.delenv(k, raising=False)
+    good = {"lowhash0_equal": True, "aligner_mismatches": 0, "alignment_table_equal": True, "aligner_tie_flags_equal": True}
+    assert bench._fallback_environment(good, None) is None and bench._fallback_environment(None, None) is None
+    assert bench._fallback_environment(dict(good, aligner_mismatches=3), None) == {"SHASTA_MI355X_ANCHORED_DP": "0"}
+    assert bench._fallback_environment(dict(good, lowhash0_equal=False), None) == {"SHASTA_MI355X_STATISTICS_ATOMICS": "1"}
+    monkeypatch.setenv("SHASTA_MI355X_ANCHORED_DP", "0")
+    assert bench._fallback_environment(dict(good, alignment_table_equal=False), None) == {"SHASTA_MI355X_SPARSE_DP": "0"}
+    monkeypatch.setenv("SHASTA_MI355X_SPARSE_DP", "0")
+    assert bench._fallback_environment(dict(good, aligner_mismatches=1), None) is None               # nothing left to switch: the line stands as it is
+    monkeypatch.delenv("SHASTA_MI355X_ANCHORED_DP"); monkeypatch.delenv("SHASTA_MI355X_SPARSE_DP")
+    assert bench._fallback_environment(None, RuntimeError("HIP error")) == {"SHASTA_MI355X_STATISTICS_ATOMICS": "1", "SHASTA_MI355X_SPARSE_DP": "0"}
