@@ -110,7 +110,12 @@ def load_pmc(reads):
         return {}
     with open(PMC_FILE) as f:
         d = json.load(f)
-    return d.get("kernels", {}) if d.get("workload_reads") == reads else {}
+    # Counters describe the build they were collected on: another build's instruction counts over this build's launch times
+    # are not evidence (round 4 printed VALU fractions above 1 that way).  No match, no counters.
+    import shasta_amd
+    if d.get("workload_reads") != reads or d.get("kernel_source_hash") != shasta_amd.kernel_source_hash():
+        return {}
+    return d.get("kernels", {})
 
 
 def pmc_of(pmc, name):
@@ -231,6 +236,7 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
                   "align method %d on every %d-th candidate (%d): %.3f ms/candidate incremental on %d threads; anonymous 4 KiB pages "
                   "(the reference warns such runs should not be used for benchmarking, srcMain/main.cpp:369-378)" % (
                       (len(toc) - 1) // 2, int(toc[-1]), t_lh, cores, host_cores, pairs, align_method, stride, len(sample), per_pair * 1e3, cores),
+        "sample_short": "%d reads, LowHash0 in full, aligner on every %d-th candidate (%d) x rate" % ((len(toc) - 1) // 2, stride, len(sample)),
         "lowhash0_seconds": t_lh,
         "sorted_markers_seconds": t_sorted,            # Assembler::computeSortedMarkers, all reads, `threads` threads
         "align_seconds_per_pair": per_pair,
@@ -766,6 +772,7 @@ def main():
         earlier = os.environ.get("SHASTA_BENCH_EARLIER_ATTEMPTS")
         if earlier:
             out["earlier_attempts"] = json.loads(earlier)
+            out["default_path_parity_failed"] = True        # (the headline below is the fallback's; the default path's numbers are in earlier_attempts)
             out["path"] = "NOT the default path: " + ", ".join("%s=%s" % (k, os.environ[k]) for k in FALLBACK_SWITCHES if k in os.environ)
         retry_with = _fallback_environment(out.get("parity_at_bench_size"), None) if (world == 1 and not args.group) else None
         if retry_with:
@@ -773,7 +780,8 @@ def main():
             attempts.append({"switches": {k: os.environ[k] for k in FALLBACK_SWITCHES if k in os.environ}, "ms_per_step": out["ms_per_step"], "value": out["value"],
                              "parity_at_bench_size": out.get("parity_at_bench_size")})
             retry_with["SHASTA_BENCH_EARLIER_ATTEMPTS"] = json.dumps(attempts)
-        final_line = json.dumps(out)
+        details_path = write_details(out)
+        final_line = json.dumps(headline(out, details_path), allow_nan=False)
     ctx.close()
     if final_line is not None and retry_with:
         sys.stderr.write("bench.py: the parity check at bench size FAILED on this path; running again with %s\n" % {k: v for k, v in retry_with.items() if k in FALLBACK_SWITCHES})
@@ -790,6 +798,104 @@ def main():
     _flush_all_stdio()
     if final_line is not None:
         print(final_line, flush=True)
+
+
+# The final stdout line is the driver's contract: it stays under FINAL_LINE_LIMIT bytes (round 4's 20-odd KB line was cut by the
+# driver's tail capture and could not be parsed).  Everything else -- the per-kernel tables, the tie census, the HBM budget -- goes
+# to the details file (and to stderr as one line), which scripts/ copy under profiles/.
+FINAL_LINE_LIMIT = 4096
+DETAILS_FILE = os.environ.get("SHASTA_BENCH_DETAILS") or os.path.join(ROOT, "gpurun_out", "bench_details.json")
+
+
+def _finite(x):
+    """JSON has no NaN/Infinity: they become null (the line must pass a strict parser)."""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating,)):
+        return _finite(float(x))
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    return x
+
+
+def write_details(out):
+    """The whole report -> DETAILS_FILE + one stderr line; returns the path relative to the repo (or None when it cannot be written)."""
+    text = json.dumps(_finite(out), allow_nan=False)
+    sys.stderr.write("bench details: " + text + "\n")
+    try:
+        os.makedirs(os.path.dirname(DETAILS_FILE), exist_ok=True)
+        with open(DETAILS_FILE, "w") as f:
+            f.write(text + "\n")
+        return os.path.relpath(DETAILS_FILE, ROOT)
+    except OSError:
+        return None
+
+
+def _rounded(x, digits=6):
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _rounded(v, digits) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_rounded(v, digits) for v in x]
+    return x
+
+
+def headline(out, details_path):
+    """The short final line: the contract keys, config, roofline of ONE kernel, cpu_baseline as numbers, parity at bench size."""
+    out = _finite(out)
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in out}
+    c = out.get("config", {})
+    line["config"] = {k: c[k] for k in ("workload", "step", "reads_per_gpu", "markers_total", "candidates", "alignments_stored", "parallelism") if k in c}
+    r = out.get("roofline")
+    if r:
+        short = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "counters_from")}
+        if r.get("valu"):
+            short["valu_issue_frac"] = r["valu"].get("frac")
+        if "gcups" in r:
+            short["gcups"] = r["gcups"]
+        if r.get("one_worker"):
+            short["one_worker"] = {k: v for k, v in r["one_worker"].items() if k != "note"}
+        line["roofline"] = short
+    b = out.get("cpu_baseline")
+    if b:
+        line["cpu_baseline"] = {k: b[k] for k in ("value", "unit", "cores", "kind", "sample", "threads", "host_cores", "cpu_quota", "lowhash0_seconds",
+                                                  "sorted_markers_seconds", "align_seconds_per_pair", "alignment_table_seconds", "aligner_seconds_measured") if k in b}
+        line["cpu_baseline"]["kind"] = str(b.get("kind", "")).split(" ")[0]
+        line["cpu_baseline"]["sample"] = str(b.get("sample_short") or b.get("sample", ""))[:160]
+    for k in ("parity_at_bench_size", "speedup_vs_cpu_baseline", "stage_seconds_per_step", "aligner_status", "path", "default_path_parity_failed"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    h = out.get("hbm_natured_kernel")
+    if h:
+        line["hbm_natured_kernel"] = {k: h.get(k) for k in ("kernel", "achieved_GBps", "frac_of_hbm_peak", "avg_ms", "traffic")}
+    d = out.get("banded_dp")
+    if d:
+        line["banded_dp"] = {k: d.get(k) for k in ("reference_cells_per_step", "cells_in_the_dense_kernels_per_step", "sparse_path")}
+    t = out.get("dp_tie_sensitive")
+    if t:
+        line["dp_tie_sensitive"] = {k: t.get(k) for k in ("candidates", "candidates_changed", "markerCount_changed", "stored_set_changed")}
+    g = out.get("in_process_group")
+    if g:
+        line["in_process_group"] = {k: g[k] for k in ("value", "ms_per_step", "error") if k in g}
+    if out.get("earlier_attempts"):
+        line["earlier_attempts"] = [{k: a.get(k) for k in ("switches", "ms_per_step", "raised") if k in a} for a in out["earlier_attempts"]]
+    line["details"] = details_path
+    line = _rounded(line)
+    # Whatever a future key adds, the line stays short: optional parts go first, the contract keys never.
+    for optional in ("dp_tie_sensitive", "banded_dp", "hbm_natured_kernel", "aligner_status", "stage_seconds_per_step", "earlier_attempts", "in_process_group"):
+        if len(json.dumps(line, allow_nan=False)) < FINAL_LINE_LIMIT:
+            break
+        line.pop(optional, None)
+    assert len(json.dumps(line, allow_nan=False)) < FINAL_LINE_LIMIT, "final line too long"
+    return line
 
 
 def _process_cpu_seconds():

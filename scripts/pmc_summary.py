@@ -50,7 +50,9 @@ def main():
             if name in c:
                 row[name + "_per_launch"] = c[name] / n
         kernels[k] = row
-    json.dump({"workload_reads": reads,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import shasta_amd
+    json.dump({"workload_reads": reads, "kernel_source_hash": shasta_amd.kernel_source_hash(),
                "what": "rocprofv3 --pmc passes (one run each) over `python bench.py --reads %d --steps 1 --warmup 0 --no-cpu-baseline`, per kernel and launch" % reads,
                "calibration": {k: v for k, v in calibration.items()}, "kernels": kernels}, open(out_path, "w"), indent=1)
     for k in sorted(kernels, key=lambda k: -kernels[k].get("SQ_WAVE_CYCLES_per_launch", 0) * kernels[k]["launches"])[:12]:

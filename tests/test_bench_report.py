@@ -23,6 +23,13 @@ FAKE_TABLE = {
 }
 
 
+def strict_loads(text):
+    """json.loads that refuses NaN / Infinity (the driver's parser may)."""
+    def refuse(name):
+        raise ValueError("non-finite constant in the line: " + name)
+    return json.loads(text, parse_constant=refuse)
+
+
 class FakeResult:
     def __init__(self, n):
         self.candidates = abi.make_pairs(np.arange(n), np.arange(n) + 1, np.ones(n))
@@ -76,16 +83,28 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
                                                           {"lowhash0_equal": True, "aligner_mismatches": 0}))
     # Counters as scripts/pmc_summary.py writes them, for the workload of this run.
     pmc = tmp_path / "pmc.json"
-    pmc.write_text(json.dumps({"workload_reads": 100000, "kernels": {
+    pmc.write_text(json.dumps({"workload_reads": 100000, "kernel_source_hash": shasta_amd.kernel_source_hash(), "kernels": {
         "bandedDpForwardKernel<16, 4, 0, false>": {"hbm_bytes_per_launch": 2.6e9, "valu_wave_instructions_per_launch": 2.3e9},
         "hashWindowsKernel<4, true, unsigned int>": {"hbm_bytes_per_launch": 1.5e9, "valu_wave_instructions_per_launch": 3.6e8}}}))
     monkeypatch.setattr(bench, "PMC_FILE", str(pmc))
+    monkeypatch.setattr(bench, "DETAILS_FILE", str(tmp_path / "details.json"))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--reads", "100000"])
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    head = strict_loads(lines[0])
+    # The driver's line: short (round 4's 20 KB line was cut and could not be parsed), strict JSON, the contract keys with the
+    # roofline of one kernel and the CPU baseline as numbers; the tables are in the details file.
+    assert len(lines[0]) < 4096
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_at_bench_size", "details"):
+        assert key in head, key
+    assert "kernels" not in head and "kernels_one_worker" not in head and "hbm_budget_per_gpu" not in head
+    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"]) <= set(head["roofline"])
+    assert set(["value", "unit", "cores", "kind", "sample"]) <= set(head["cpu_baseline"]) and len(head["cpu_baseline"]["sample"]) <= 160
+    d = strict_loads(open(str(tmp_path / "details.json")).read())
+    assert d["value"] == pytest.approx(head["value"], rel=1e-5) and d["roofline"]["kernel"] == head["roofline"]["kernel"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_at_bench_size", "aligner_status"):
         assert key in d, key
@@ -109,17 +128,53 @@ def test_bench_prints_one_contract_line(monkeypatch, capsys, tmp_path):
     assert d["cpu_baseline"]["cores"] == 64 and d["speedup_vs_cpu_baseline"] == pytest.approx(d["value"] / 18000.0)
 
 
+def test_counters_of_another_build_are_refused(monkeypatch, tmp_path):
+    """A PMC summary collected on other kernel sources prices nothing (round 4 divided round 3's instruction counts by round 4's
+    launch times and printed VALU fractions above 1)."""
+    import shasta_amd
+    pmc = tmp_path / "pmc.json"
+    rows = {"k": {"hbm_bytes_per_launch": 1.0, "valu_wave_instructions_per_launch": 2.0}}
+    monkeypatch.setattr(bench, "PMC_FILE", str(pmc))
+    pmc.write_text(json.dumps({"workload_reads": 100000, "kernel_source_hash": "0123456789abcdef", "kernels": rows}))
+    assert bench.load_pmc(100000) == {}
+    pmc.write_text(json.dumps({"workload_reads": 100000, "kernels": rows}))
+    assert bench.load_pmc(100000) == {}
+    pmc.write_text(json.dumps({"workload_reads": 100000, "kernel_source_hash": shasta_amd.kernel_source_hash(), "kernels": rows}))
+    assert bench.load_pmc(100000) == rows and bench.load_pmc(20000) == {}
+
+
+def test_headline_stays_short_whatever_the_details_hold():
+    out = {"metric": "m", "value": float("nan"), "unit": "pairs/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": "w" * 300, "junk": "x" * 5000}, "kernels": {"k%d" % i: {"a": 1.0} for i in range(500)},
+           "roofline": {"bound": "valu", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 1 / 8000.0, "traffic": None, "kernel": "k",
+                        "note": "n" * 2000, "one_worker": {"frac": 0.1, "note": "n" * 2000}},
+           "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 1, "kind": "reference (long prose)", "sample": "s" * 2000},
+           "stage_seconds_per_step": {"x%d" % i: 0.1 for i in range(400)},
+           "dp_tie_sensitive": {"candidates": 1, "per_policy": ["p" * 100] * 11}}
+    line = bench.headline(out, "gpurun_out/bench_details.json")
+    text = json.dumps(line, allow_nan=False)
+    assert len(text) < bench.FINAL_LINE_LIMIT and strict_loads(text)["value"] is None
+    assert line["cpu_baseline"]["kind"] == "reference" and "stage_seconds_per_step" not in line and "junk" not in line["config"]
+
+
 def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     """The real bench.py, real library calls (emulated build), real CPU baseline: every key of the
     driver's contract, the roofline and cpu_baseline objects, and the dry-run marker."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path)
+    import tempfile
+    details = os.path.join(tempfile.mkdtemp(), "details.json")
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, SHASTA_BENCH_DETAILS=details)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "100", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    last = out.stdout.strip().splitlines()[-1]
+    head = strict_loads(last)
+    assert len(last) < 4096 and head["details"] and head["roofline"]["kernel"] and head["cpu_baseline"]["value"] > 0
+    assert head["parity_at_bench_size"]["aligner_mismatches"] == 0
+    line = strict_loads(open(details).read())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -153,7 +208,9 @@ def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, HIPEMU_THREADS="4")
+    import tempfile
+    details = os.path.join(tempfile.mkdtemp(), "details.json")
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, HIPEMU_THREADS="4", SHASTA_BENCH_DETAILS=details)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "100"],
@@ -161,7 +218,8 @@ def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
-    line = json.loads(lines[0])
+    assert len(lines[0]) < 4096 and strict_loads(lines[0])["n_gpus"] == 2 and strict_loads(lines[0])["in_process_group"]["value"] > 0
+    line = strict_loads(open(details).read())
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line
     assert line["config"]["candidates"] > 0 and line["config"]["alignments_stored"] > 0
     # Rank 0 measured the same job through the in-process group as well (both drivers on one line), and the line says what a
@@ -211,11 +269,15 @@ def test_bench_script_falls_back_on_the_library_switches_after_a_parity_failure(
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, SHASTA_BENCH_FORCE_PARITY_FAILURE="1")
+    import tempfile
+    details = os.path.join(tempfile.mkdtemp(), "details.json")
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, SHASTA_BENCH_FORCE_PARITY_FAILURE="1", SHASTA_BENCH_DETAILS=details)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "100", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                          env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    head = strict_loads(out.stdout.strip().splitlines()[-1])
+    assert "SHASTA_MI355X_ANCHORED_DP=0" in head["path"] and head["earlier_attempts"][0]["switches"] == {}
+    line = strict_loads(open(details).read())
     assert "SHASTA_MI355X_ANCHORED_DP=0" in line["path"] and len(line["earlier_attempts"]) == 1 and line["earlier_attempts"][0]["switches"] == {}
     assert line["banded_dp"]["matches_walked_by_the_anchor_kernel_per_step"] is None and line["value"] > 0
     assert "FAILED on this path" in out.stderr
