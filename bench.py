@@ -245,11 +245,20 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
     }, parity
 
 
+GIVE_UP_PREFIX = "dense DP because: "      # rows of the kernel table that count tasks, not launches (align4_dp.hpp, DpGiveUp)
+
+
+def give_up_rows(table, steps):
+    """Why DP tasks ended in the dense kernels although the sparse path is on: tasks and their DP cells per step, by reason."""
+    return {name[len(GIVE_UP_PREFIX):]: {"tasks_per_step": r["launches"] / steps, "dp_cells_per_step": r["work"] / steps}
+            for name, r in table.items() if name.startswith(GIVE_UP_PREFIX) and r["launches"]}
+
+
 def kernel_rows(table, steps, pmc):
     """kernels{} of the report from the library's kernel table (accumulated over the timed steps)."""
     rows = {}
     for name, r in table.items():
-        if r["launches"] == 0:
+        if r["launches"] == 0 or name.startswith(GIVE_UP_PREFIX):
             continue
         avg = r["seconds"] / r["launches"]
         per_launch = r["bytes"] / r["launches"]
@@ -741,7 +750,7 @@ def main():
             # The banded DP the reference runs for these candidates (nx x band width cells over all tasks) against what reached the dense
             # kernels here: the rest came from the matches inside the band (align4_sparse.hpp; SHASTA_MI355X_SPARSE_DP=0: all of it dense).
             dense_cells = sum(r["work"] for k, r in table.items() if k.startswith("bandedDpForwardKernel")) / steps
-            chain = table.get("sparseChainKernel")
+            chain = table.get("sparseChainWaveKernel") or table.get("sparseChainKernel")      # (the row the matches inside the bands are booked on)
             out["banded_dp"] = {"reference_cells_per_step": int(al.dp_cell_count), "cells_in_the_dense_kernels_per_step": int(dense_cells),
                                 "share_from_the_matches": (1.0 - dense_cells / al.dp_cell_count) if al.dp_cell_count else None,
                                 "sparse_path": chain is not None,
@@ -750,6 +759,8 @@ def main():
                                 "matches_in_the_bands_per_step": int(chain["work"] / steps) if chain else None,
                                 "matches_walked_by_the_anchor_kernel_per_step": int(table["sparseAnchorKernel"]["work"] / steps) if "sparseAnchorKernel" in table else None,
                                 "reference_cells_per_second": al.dp_cell_count / (elapsed / steps) if elapsed > 0 else None}
+        if give_up_rows(table, steps):
+            out["give_ups"] = give_up_rows(table, steps)
         if hash_name:
             h = kernels[hash_name]
             out["hbm_natured_kernel"] = {"kernel": hash_name, "achieved_GBps": h["achieved_GBps"], "frac_of_hbm_peak": h["frac_of_hbm_peak"],

@@ -71,6 +71,7 @@ struct DeviceOptions {
 #include "align4_cells.hpp"      // K8/K9
 #include "align4_dp.hpp"         // K10
 #include "align4_sparse.hpp"     // K10s: the same alignment from the matches inside the band, where it is unique
+#include "align4_chainwave.hpp"  // K10w: the chain recurrence with a wavefront per task, the task's hits in LDS
 #include "align4_anchor.hpp"     // K10a: where it is not, the dense DP only between the matches every optimal alignment holds
 #include "align4_finish.hpp"     // K11
 #include "align3.hpp"
@@ -336,6 +337,43 @@ bool sparseDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_SPARSE_DP");
 // SHASTA_MI355X_ANCHORED_DP=0: the tasks with several optimal chains go to the dense kernels whole (as before align4_anchor.hpp).
 bool anchoredDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHORED_DP"); return !e || std::atoi(e) != 0; }
 
+// SHASTA_MI355X_ANCHOR_BIG=0: no second launch of the anchor kernel (tasks with a rectangle beyond 4 096 cells go to the dense kernels, as before it).
+bool anchorBigEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHOR_BIG"); return !e || std::atoi(e) != 0; }
+// SHASTA_MI355X_CHAIN_WAVE=0: every sorted task to sparseChainKernel (a lane per task), as before align4_chainwave.hpp.
+bool chainWaveEnabled() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE"); return !e || std::atoi(e) != 0; }
+
+template<int CLS>
+void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const uint32_t* hitMeta, DpControl* control, const DeviceOptions& opt)
+{
+    constexpr uint32_t CAP = CHAIN_WAVE_CAPACITY[CLS];
+    constexpr size_t ldsBytes = size_t(CAP) * 10u;
+    static_assert(ldsBytes <= 160u * 1024u, "a wavefront's hits in LDS");
+    if(ldsBytes > 64u * 1024u) {
+        // (more dynamic LDS than the default limit: the attribute once per device)
+        static std::mutex mutex;
+        static std::vector<int> done;
+        int device = 0;
+        HIP_CHECK(hipGetDevice(&device));
+        std::lock_guard<std::mutex> lock(mutex);
+        if(std::find(done.begin(), done.end(), device) == done.end()) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparseChainWaveKernel<int(CAP)>), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
+            done.push_back(device);
+        }
+    }
+    hipLaunchKernelGGL(sparseChainWaveKernel<int(CAP)>, dim3(std::min<uint32_t>(CHAIN_WAVE_GRID[CLS], divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
+        in.pairs, in.tasks, taskCount, CLS, control,
+        b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), hitMeta,
+        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), opt, b.pairBest.data());
+    HIP_CHECK(hipGetLastError());
+}
+void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const uint32_t* hitMeta, DpControl* control, const DeviceOptions& opt)
+{
+    // (the few large tasks first: their wavefronts run longest)
+    launchChainWaveClass<2>(stream, b, in, taskCount, hitMeta, control, opt);
+    launchChainWaveClass<1>(stream, b, in, taskCount, hitMeta, control, opt);
+    launchChainWaveClass<0>(stream, b, in, taskCount, hitMeta, control, opt);
+}
+
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
     uint32_t extraTasks = 0, uint64_t extraOrdinals = 0, const SparseInput* sparse = nullptr, const DeviceOptions* metricsOptions = nullptr)
 {
@@ -364,7 +402,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     f.sortedIds = sortedIds; f.denseCount = taskCount;
     uint32_t* classCounts = f.classCounts;
     unsigned long long* sums = f.sums;
-    size_t sortHandle = 0, chainHandle = 0, anchorHandle = 0;
+    size_t sortHandle = 0, chainHandle = 0, anchorHandle = 0, waveHandle = 0;
     bool anchored = false;
     if(sparse) {
         // K10s (align4_sparse.hpp): every task whose alignment is the unique optimal chain of the matches inside its band gets
@@ -375,17 +413,24 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         const uint64_t ordTotalEarly = readDevice(&control->ordCursor, stream);      // synchronises
         b.ordScratch.reserve(2 * (ordTotalEarly + extraOrdinals) + 2, stream);
         b.sparseSorted.reserve(2 * ordTotalEarly + 4, stream); b.sparseLinks.reserve(2 * ordTotalEarly + 4, stream);
-        b.sparseAmbiguous.reserve(taskCount, stream);
+        b.sparseAmbiguous.reserve(2 * uint64_t(taskCount), stream);          // (the chain kernels' list, and behind it the anchor kernel's list for its second launch)
         b.sparseInBand.reserve(taskCount, stream); b.sparseState.reserve(taskCount, stream);
         b.denseFlags.reserve(uint64_t(taskCount) + 1, stream); b.densePositions.reserve(uint64_t(taskCount) + 1, stream);
         b.scanTemp32.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
+        const bool chainWave = chainWaveEnabled();
         KernelTimers::Span span;
         if(timers) span = timers->begin("sparseSortKernel", stream);
         hipLaunchKernelGGL(sparseSortKernel, dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
-            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data());
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control);
         HIP_CHECK(hipGetLastError());
         if(timers) sortHandle = timers->end(span, 0, taskCount);
+        if(chainWave) {
+            // K10w (align4_chainwave.hpp): a wavefront per task, the task's hits in LDS; one launch of persistent wavefronts per capacity class.
+            if(timers) span = timers->begin("sparseChainWaveKernel", stream);
+            launchChainWave(stream, b, in, taskCount, sparse->hitMeta, control, *metricsOptions);
+            if(timers) waveHandle = timers->end(span, 0, taskCount);
+        }
         if(timers) span = timers->begin("sparseChainKernel", stream);
         hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
             in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
@@ -398,10 +443,32 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
             anchored = true;
             if(timers) span = timers->begin("sparseAnchorKernel", stream);
             withDpTie(in.tie, [&](auto tag) {
-                hipLaunchKernelGGL(sparseAnchorKernel<decltype(tag)::value>, dim3(std::min<uint32_t>(ANCHOR_GRID, taskCount)), dim3(64), 0, stream,
-                    in.kmerIds, in.pairs, in.tasks, (const uint32_t*)b.sparseAmbiguous.data(), control,
-                    (const uint32_t*)b.sparseSorted.data(), (const uint32_t*)b.sparseLinks.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(),
-                    sparse->hitMeta, (const DpEnd*)b.ends.data(), (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data());
+                constexpr int TIE = decltype(tag)::value;
+                auto launch = [&](auto big, uint32_t grid, size_t ldsBytes) {
+                    constexpr bool BIG = decltype(big)::value;
+                    hipLaunchKernelGGL((sparseAnchorKernel<TIE, BIG>), dim3(grid), dim3(64), ldsBytes, stream,
+                        in.kmerIds, in.pairs, in.tasks, (const uint32_t*)b.sparseAmbiguous.data(), control,
+                        (const uint32_t*)b.sparseSorted.data(), (const uint32_t*)b.sparseLinks.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(),
+                        sparse->hitMeta, (const DpEnd*)b.ends.data(), (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(),
+                        anchorBigEnabled() ? b.sparseAmbiguous.data() : nullptr, taskCount);
+                };
+                launch(std::false_type(), std::min<uint32_t>(ANCHOR_GRID, taskCount), sizeof(AnchorShared));
+                if(anchorBigEnabled()) {
+                    // The few tasks with a rectangle beyond the first launch's LDS: once more with 118 KB (dynamic LDS above the default limit:
+                    // the attribute once per device).
+                    static std::mutex mutex;
+                    static std::vector<int> done;
+                    int device = 0;
+                    HIP_CHECK(hipGetDevice(&device));
+                    {
+                        std::lock_guard<std::mutex> lock(mutex);
+                        if(std::find(done.begin(), done.end(), device * 16 + TIE) == done.end()) {
+                            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparseAnchorKernel<TIE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(AnchorSharedBig))));
+                            done.push_back(device * 16 + TIE);
+                        }
+                    }
+                    launch(std::true_type(), std::min<uint32_t>(256u, taskCount), sizeof(AnchorSharedBig));
+                }
             });
             HIP_CHECK(hipGetLastError());
             if(timers) anchorHandle = timers->end(span, 0, taskCount);
@@ -424,7 +491,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     hipLaunchKernelGGL(dpBundleKernel, dim3(divUp(uint64_t(taskCount) + 1, 256)), dim3(256), 0, stream,
         sortedKeys, control, taskCount, b.bundleWords.data());
     HIP_CHECK(hipGetLastError());
-    struct { unsigned long long sums[2 + 2 * DP_CLASSES], ordCursor, traceCursor; uint32_t classCounts[DP_CLASSES]; uint32_t ambiguousCount, pad; unsigned long long hitsListed, hitsInBand, ambiguousHits; } head;
+    struct { unsigned long long sums[2 + 2 * DP_CLASSES], ordCursor, traceCursor; uint32_t classCounts[DP_CLASSES]; uint32_t ambiguousCount, pad; unsigned long long hitsListed, hitsInBand, ambiguousHits, giveUpCells[DP_GIVE_UP_REASONS]; uint32_t giveUpTasks[DP_GIVE_UP_REASONS]; } head;
     static_assert(sizeof(head) == DP_CONTROL_HEAD_BYTES && offsetof(DpControl, ordCursor) == sizeof(head.sums) && offsetof(DpControl, hitsListed) == 8 * (2 + 2 * DP_CLASSES + 2) + 4 * DP_CLASSES + 8, "DpControl's head");
     HIP_CHECK(hipMemcpyAsync(&head, control, sizeof(head), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -442,8 +509,13 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         // written in order; the chain kernel reads those and writes a list word and a link word beside each; the anchor kernel reads both
         // for the tasks it walks and writes their aligned pairs (8 bytes: about one per match).  Work = matches inside the bands.
         timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
-        timers->amend(chainHandle, 12 * head.hitsInBand, head.hitsInBand);
+        // (with align4_chainwave.hpp on, nearly all tasks are the wave kernel's: it reads a hit once, 4 bytes, and writes a pair, 8)
+        if(chainWaveEnabled()) { timers->amend(waveHandle, 12 * head.hitsInBand, head.hitsInBand); timers->amend(chainHandle, 0, 0); }
+        else timers->amend(chainHandle, 12 * head.hitsInBand, head.hitsInBand);
         if(anchored) timers->amend(anchorHandle, 16 * head.ambiguousHits, head.ambiguousHits);
+        else if(head.ambiguousCount) timers->count(DP_GIVE_UP_NAMES[GIVE_UP_ANCHORS_OFF], head.ambiguousCount, 0, 0);
+        // Why tasks went on to the dense kernels: rows without time (launches = tasks, work = their DP cells).
+        for(int why = 0; why < DP_GIVE_UP_REASONS; why++) if(head.giveUpTasks[why]) timers->count(DP_GIVE_UP_NAMES[why], head.giveUpTasks[why], 0, head.giveUpCells[why]);
     }
     b.trace.reserve(f.traceWords + 64, stream);
     f.ordTotal = ordTotal;

@@ -40,16 +40,25 @@ constexpr int32_t ANCHOR_NEG = -(1 << 28);
 static_assert(GAP_SCORE == -1, "the row's prefix maximum of c(j) + j is the recurrence for a gap of -1");
 constexpr uint32_t ANCHOR_GRID = 4096;           // workgroups of one wavefront; each takes tasks blockIdx.x, + gridDim.x, ...
 
-struct AnchorShared {
+// What a wavefront holds of its task.  Two sizes: the first launch's (22 KB: seven workgroups per CU) and, for the few tasks with a
+// rectangle beyond it (0.3 % of the tasks at 100 k reads: they went to the dense kernels, a handful of wavefronts per launch, 60 ms of
+// launches per step for 0.1 % of the DP cells), a second launch's (118 KB, dynamic LDS, one workgroup per CU).
+template<int MAX_CELLS, int MAX_SIDE, int MAX_PAIRS>
+struct AnchorSharedT {
+    static constexpr int maxCells = MAX_CELLS, maxSide = MAX_SIDE, maxPairs = MAX_PAIRS;
     uint64_t live[ANCHOR_MAX_BITWORDS], anchor[ANCHOR_MAX_BITWORDS];
-    uint8_t trace[ANCHOR_MAX_CELLS];             // [i * (wy + 1) + j]: move (DpTie::Move) | markers equal << 2
-    int32_t row[2][ANCHOR_MAX_SIDE + 1];         // H of the previous and of the current row
-    int32_t lastColumn[ANCHOR_MAX_SIDE + 1];     // H(i, wy)
-    uint32_t kmers0[ANCHOR_MAX_SIDE + 1], kmers1[ANCHOR_MAX_SIDE + 1];
-    uint32_t pairs[ANCHOR_MAX_PAIRS];            // x << 16 | y, every window's from its last pair to its first
+    uint8_t trace[MAX_CELLS];                    // [i * (wy + 1) + j]: move (DpTie::Move) | markers equal << 2
+    int32_t row[2][MAX_SIDE + 1];                // H of the previous and of the current row
+    int32_t lastColumn[MAX_SIDE + 1];            // H(i, wy)
+    uint32_t kmers0[MAX_SIDE + 1], kmers1[MAX_SIDE + 1];
+    uint32_t pairs[MAX_PAIRS];                   // x << 16 | y, every window's from its last pair to its first
     int32_t windowFrom[ANCHOR_MAX_WINDOWS], windowTo[ANCHOR_MAX_WINDOWS];       // anchors (hit indices) before and behind; -1 / n: the border
     uint32_t windowPairs[ANCHOR_MAX_WINDOWS], windowBegin[ANCHOR_MAX_WINDOWS];
 };
+using AnchorShared = AnchorSharedT<ANCHOR_MAX_CELLS, ANCHOR_MAX_SIDE, ANCHOR_MAX_PAIRS>;
+constexpr int ANCHOR_BIG_CELLS = 65536, ANCHOR_BIG_SIDE = 2047, ANCHOR_BIG_PAIRS = 2048;
+using AnchorSharedBig = AnchorSharedT<ANCHOR_BIG_CELLS, ANCHOR_BIG_SIDE, ANCHOR_BIG_PAIRS>;
+static_assert(sizeof(AnchorSharedBig) <= 160 * 1024, "the second launch's LDS");
 
 __device__ __forceinline__ uint64_t bitsFrom(int b) { return b >= 64 ? 0ULL : ~0ULL << b; }       // bits b .. 63
 __device__ __forceinline__ int32_t waveMaxScan(int32_t v, int lane)                               // inclusive prefix maximum over the lanes
@@ -61,8 +70,8 @@ __device__ __forceinline__ int32_t waveMaxScan(int32_t v, int lane)             
 
 // The rectangle of markers [x0, x1] x [y0, y1]; the aligned pairs of its traced path go to sh.pairs[begin ...] from the last to the
 // first.  Returns their number, or -1 if they do not fit.
-template<int TIE>
-__device__ int32_t anchorRectangle(AnchorShared& sh, const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1,
+template<int TIE, class Shared>
+__device__ int32_t anchorRectangle(Shared& sh, const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1,
     int32_t x0, int32_t x1, int32_t y0, int32_t y1, bool beginFixed, bool endFixed, int32_t bandMin, int32_t bandMax, uint32_t begin, int lane)
 {
     using Tie = DpTie<TIE>;
@@ -162,7 +171,7 @@ __device__ int32_t anchorRectangle(AnchorShared& sh, const uint32_t* __restrict_
         if(move == Tie::DIAGONAL) {
             --i; --j;
             if(t & 4u) {
-                if(begin + uint32_t(found) >= uint32_t(ANCHOR_MAX_PAIRS)) return -1;
+                if(begin + uint32_t(found) >= uint32_t(Shared::maxPairs)) return -1;
                 if(lane == 0) sh.pairs[begin + uint32_t(found)] = (uint32_t(x0 + i) << 16) | uint32_t(y0 + j);
                 ++found;
             }
@@ -175,17 +184,21 @@ __device__ int32_t anchorRectangle(AnchorShared& sh, const uint32_t* __restrict_
     return found;
 }
 
-template<int TIE>
+template<int TIE, bool BIG>
 __global__ void __launch_bounds__(64)
 sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks,
     const uint32_t* __restrict__ ambiguousList, DpControl* __restrict__ control,
     const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ linkWords, const uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
     const uint32_t* __restrict__ hitMeta, const DpEnd* __restrict__ ends,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results, uint32_t* __restrict__ bigList, uint32_t listStride)
 {
-    __shared__ AnchorShared sh;
+    using Shared = std::conditional_t<BIG, AnchorSharedBig, AnchorShared>;
+    extern __shared__ uint32_t ldsWords[];
+    Shared& sh = *reinterpret_cast<Shared*>(ldsWords);
     const int lane = laneId();
-    const uint32_t count = control->ambiguousCount;
+    // (the second launch: the tasks the first one listed because a rectangle did not fit it -- behind the first list, from `listStride` on)
+    const uint32_t count = BIG ? control->anchorBigCount : control->ambiguousCount;
+    if(BIG) ambiguousList += listStride;
     unsigned long long walked = 0;
     for(uint32_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
         const uint32_t t = ambiguousList[slot];
@@ -199,7 +212,7 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const int32_t firstEnd = ends[t].bestI;
         const int32_t chunks = (n + WAVE - 1) / WAVE;
         walked += uint32_t(n);
-        auto giveUp = [&](int why = 0) { if(lane == 0) { state[t] = SPARSE_DENSE; ANCHOR_REASON(why, n); } };
+        auto giveUp = [&](int why) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_FAR_LINK + (why == 4 ? 0 : why), pd, task); ANCHOR_REASON(why, n); } };
         waveLdsSync();                                       // (the task before has left the shared arrays)
         // ---- sweep: live hits and anchors ----
         uint32_t window = 0;                                 // bit d: the hit d before the current one has a link from a live later hit
@@ -273,18 +286,23 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const uint32_t* __restrict__ const p0 = kmerIds + pd.begin0;
         const uint32_t* __restrict__ const p1 = kmerIds + pd.begin1;
         uint32_t windowPairsTotal = 0;
-        bool fits = true;
+        bool fits = true, tooBig = false;
         for(int32_t w = 0; w < windows && fits; w++) {
             const int32_t from = sh.windowFrom[w], to = sh.windowTo[w];
             int32_t x0 = 0, y0 = 0, x1 = int32_t(pd.nx) - 1, y1 = int32_t(pd.ny) - 1;
             if(from >= 0) { hitAt(from, x0, y0); ++x0; ++y0; }
             if(to < n) { hitAt(to, x1, y1); --x1; --y1; }
             const int32_t wx = x1 - x0 + 1, wy = y1 - y0 + 1;
-            if(wx < 1 || wy < 1 || wx > ANCHOR_MAX_SIDE || wy > ANCHOR_MAX_SIDE || (wx + 1) * (wy + 1) > ANCHOR_MAX_CELLS) { fits = false; break; }
+            if(wx < 1 || wy < 1 || wx > Shared::maxSide || wy > Shared::maxSide || (wx + 1) * (wy + 1) > Shared::maxCells) { fits = false; tooBig = true; break; }
             const int32_t found = anchorRectangle<TIE>(sh, p0, p1, x0, x1, y0, y1, from >= 0, to < n, task.bandMin, task.bandMax, windowPairsTotal, lane);
-            if(found < 0) { fits = false; break; }
+            if(found < 0) { fits = false; tooBig = true; break; }       // (the pairs did not fit, or the walk contradicted the anchors: the larger form tries once more)
             if(lane == 0) { sh.windowBegin[w] = windowPairsTotal; sh.windowPairs[w] = uint32_t(found); }
             windowPairsTotal += uint32_t(found);
+        }
+        if(!BIG && tooBig && bigList) {
+            // (stays SPARSE_AMBIGUOUS: the second launch's)
+            if(lane == 0) bigList[listStride + atomicAdd(&control->anchorBigCount, 1u)] = t;
+            continue;
         }
         if(!fits || uint32_t(anchorCount) + windowPairsTotal > min(pd.nx, pd.ny)) { giveUp(3); continue; }
         waveLdsSync();

@@ -1,0 +1,358 @@
+// Align4 on MI355X, K10w: the chain recurrence of align4_sparse.hpp with a WAVEFRONT per task and the task's hits in LDS.
+// Included by align4.hip inside its anonymous namespace, after align4_sparse.hpp (whose definitions of D, the certificate, the
+// list and link words it shares: /root/reference/src/Align4.cpp:993-1088 is what both replace for the tasks they answer).
+//
+// Why a second form.  sparseChainKernel gives every task a LANE: 64 tasks' lists are read and written four bytes at a time at 64
+// unrelated addresses per instruction.  Round 5's first hardware profile (profiles/r05_pmc_100k_reads.json): 6.1 GB written to HBM
+// per launch for 1.4 GB of list and link words (partial lines leave the L2 before they fill), 53 ms per step; and a hit whose search
+// for predecessors reaches further back than the lane's LDS ring (56 hits) sends the task to the dense kernels -- 0.5 % of the
+// tasks, but the long wide ones: 2 % of the DP cells, 75 ms per step of dense kernels launched for a few wavefronts each.
+//
+// What a wavefront can do that a lane cannot: 99 % of the hits of a task lie on its one optimal chain, each linked to the hit just
+// before it (profiles/r04_sparse_census.txt: 712 hits per task, 705 aligned pairs, 1.09 predecessors looked at per hit).  So the
+// wavefront takes 64 consecutive hits, ASSUMES that each one's only optimal predecessor is the hit before it, and checks that for
+// all 64 at once:
+//     D(i) = D(i-1) + 6 - c(i),  c(i) = max(p(i) - p(i-1) - 1, s(i) - s(i-1) - 1)           a prefix sum over the lanes
+//     the hit before is dominated (p, s both smaller);
+//     no hit further back reaches that:  prefixMax D [.. i-2] - (p(i) - p(i-2) - 1)  <  D(i) - 6      a prefix maximum
+//     nor does the border:               -min(p(i), s(i))  <  D(i) - 6
+// (strict: a tie would be another optimal predecessor).  The recurrence defines D(i) from the D of earlier hits only, so the lanes
+// up to the first one whose check fails hold the true D (their sums and maxima involve lower lanes only) -- they are accepted, with
+// `from` = 1 and the certificate's count inherited.  The failing hit is an EXCEPTION: the wavefront scans back over ALL earlier hits,
+// 64 per step, every lane one candidate, until the bound says nothing further back can matter -- no ring, no look-back limit -- and
+// the next 64 hits start behind it.  About 14 exceptions per task (an off-chain hit and the hit after it, a long insertion).
+//
+// Then, still in LDS: the chain from the best end back (runs of `from` = 1 are whole bit ranges of a ballot; the exceptions are
+// the only sequential steps), the aligned pairs written in order, 64 at a time, and AlignmentInfo's metrics and the size in
+// shasta::compress form from ballots over the links between consecutive pairs.  HBM sees the sorted hits once (read) and the pairs
+// once (written).  A task with several optimal chains gets its list and link words written out as sparseChainKernel leaves them
+// (links of the exceptions recomputed from the final D: 64 candidates per step again) and goes to sparseAnchorKernel.
+//
+// LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Three launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
+// tasks at 100 k reads), 2 048, 15 360 -- of wavefronts that go over the task list in blocks of 64 and run the tasks of their class;
+// what does not fit the largest stays with sparseChainKernel.  SHASTA_MI355X_CHAIN_WAVE=0: as before this file.
+#pragma once
+
+constexpr uint32_t CHAIN_WAVE_GRID[CHAIN_WAVE_CLASSES] = {256u * 16u, 256u * 8u, 256u};       // workgroups of one wavefront, as many as the LDS lets a CU hold
+constexpr uint32_t CHAIN_WAVE_BLOCK = 16;          // tasks a wavefront takes from the cursor at a time
+constexpr uint32_t CHAIN_OFF_MASK = 0x3fffu, CHAIN_OFF_EXCEPTION = 0x4000u, CHAIN_OFF_WAYS = 0x8000u;
+static_assert(CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES - 1] <= CHAIN_OFF_MASK, "`from` in 14 bits");
+
+// v_mov_b32_dpp with `identity` where the row is masked out or the source lane does not exist.
+template<int CTRL, int ROW_MASK> __device__ __forceinline__ int32_t dppOr(int32_t identity, int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// Inclusive scans over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then lane 15 of a row into the next row (rows 1 and
+// 3), then lane 31 into rows 2 and 3 -- six DPP operations (the compiler folds the move into the add / max).
+__device__ __forceinline__ int32_t waveInclusiveSum(int32_t v)
+{
+    v += dppOr<0x111, 0xf>(0, v); v += dppOr<0x112, 0xf>(0, v); v += dppOr<0x114, 0xf>(0, v); v += dppOr<0x118, 0xf>(0, v);
+    v += dppOr<0x142, 0xa>(0, v); v += dppOr<0x143, 0xc>(0, v);
+    return v;
+}
+constexpr int32_t CHAIN_NEG = -(1 << 29);
+__device__ __forceinline__ int32_t waveInclusiveMax(int32_t v)
+{
+    v = max(v, dppOr<0x111, 0xf>(CHAIN_NEG, v)); v = max(v, dppOr<0x112, 0xf>(CHAIN_NEG, v));
+    v = max(v, dppOr<0x114, 0xf>(CHAIN_NEG, v)); v = max(v, dppOr<0x118, 0xf>(CHAIN_NEG, v));
+    v = max(v, dppOr<0x142, 0xa>(CHAIN_NEG, v)); v = max(v, dppOr<0x143, 0xc>(CHAIN_NEG, v));
+    return v;
+}
+__device__ __forceinline__ int32_t waveMax(int32_t v) { return int32_t(__builtin_amdgcn_readlane(uint32_t(waveInclusiveMax(v)), WAVE - 1)); }
+__device__ __forceinline__ int32_t laneValue(int32_t v, int lane) { return int32_t(__builtin_amdgcn_readlane(uint32_t(v), lane)); }
+__device__ __forceinline__ uint64_t bitsUpTo(int b) { return b >= 63 ? ~0ULL : ((2ULL << b) - 1ULL); }       // bits 0 .. b
+__device__ __forceinline__ uint64_t bitsAbove(uint64_t m, int lane) { return (m >> lane) >> 1; }              // bits lane + 1 .. 63, moved down to bit 0
+
+template<int CAP>
+__global__ void __launch_bounds__(64)
+sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount, int cls,
+    DpControl* __restrict__ control, uint32_t* __restrict__ sorted, const uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
+    const uint32_t* __restrict__ hitMeta, const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
+    uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+{
+    extern __shared__ uint32_t ldsWords[];
+    uint32_t* const H = ldsWords;                                            // p << 16 | s
+    int32_t* const Dv = reinterpret_cast<int32_t*>(ldsWords + CAP);          // D of the finished hits
+    uint16_t* const OFF = reinterpret_cast<uint16_t*>(ldsWords + 2 * CAP);   // how many hits back the predecessor is (0: the chain starts here) | flags
+    const int lane = laneId();
+    unsigned long long walked = 0;
+    // The tasks in blocks of CHAIN_WAVE_BLOCK, taken through a cursor (an atomic per block: a few thousand per launch -- an atomic per
+    // TASK on one address, 275 000 per launch, cost the sort kernel 8 ms a step when it appended the tasks to class lists): a lane per
+    // task looks at its state and hit count, and the wavefront runs those of its class one after the other.
+    for(;;) {
+    uint32_t blockIndex = 0;
+    if(lane == 0) blockIndex = atomicAdd(&control->waveNext[cls], 1u);
+    blockIndex = __builtin_amdgcn_readfirstlane(blockIndex);
+    const uint32_t blockBase = blockIndex * CHAIN_WAVE_BLOCK;
+    if(blockBase >= taskCount) break;
+    const uint32_t candidateTask = blockBase + uint32_t(lane);
+    uint64_t todoTasks = ballot64(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount && state[candidateTask] == SPARSE_SORTED && chainWaveClassOf(inBand[candidateTask]) == cls);
+    while(todoTasks) {
+        const uint32_t t = blockBase + uint32_t(__ffsll((unsigned long long)todoTasks) - 1);
+        todoTasks &= todoTasks - 1;
+        const DpTask task = tasks[t];
+        const PairDesc pd = pairs[task.pair];
+        const bool swapped = (hitMeta[task.pair] >> 31) != 0;
+        const int32_t n = int32_t(inBand[t]);
+        const int32_t np = int32_t(swapped ? pd.ny : pd.nx), ns = int32_t(swapped ? pd.nx : pd.ny);
+        const int32_t lo = swapped ? task.bandMin : -task.bandMax;
+        uint32_t* __restrict__ const list = sorted + sparseListBase(ordOffsets, t);
+        walked += uint32_t(n);
+        waveLdsSync();                                                      // (the task before has left the arrays)
+        for(int32_t i = lane; i < n; i += WAVE) H[i] = list[i];
+        waveLdsSync();
+
+        // ---- forward: D, `from`, the count of optimal chains (capped at two) ----
+        int32_t k = 0;
+        int32_t pmAll = CHAIN_NEG, pmBut1 = CHAIN_NEG;                      // the largest D of the hits [0, k), and of [0, k - 1)
+        int32_t best = CHAIN_NEG, bestAt = -1;
+        uint32_t bestWays = 0;
+        while(k < n) {
+            const int32_t i = k + lane;
+            const bool valid = i < n;
+            const uint32_t h = H[valid ? i : n - 1];
+            const uint32_t h1 = H[i >= 1 && valid ? i - 1 : 0], h2 = H[i >= 2 && valid ? i - 2 : 0];
+            const int32_t p = int32_t(h >> 16), s = int32_t(h & 0xffffu);
+            const int32_t a = p - int32_t(h1 >> 16) - 1, b = s - int32_t(h1 & 0xffffu) - 1;
+            const bool simple = valid && i >= 1 && a >= 0 && b >= 0;
+            const int32_t step = simple ? 6 - max(a, b) : 0;
+            const int32_t dBefore = k > 0 ? Dv[k - 1] : 0;
+            const uint32_t waysBefore = k > 0 ? (uint32_t(OFF[k - 1]) >> 15) : 0u;       // (of the hit before the first lane's: what an accepted run inherits)
+            const int32_t d = dBefore + waveInclusiveSum(step);
+            const int32_t pmIncl = max(pmAll, waveInclusiveMax(d));
+            int32_t pm2 = __shfl_up(pmIncl, 2, WAVE);                         // the largest D up to the hit two before
+            pm2 = lane == 0 ? pmBut1 : (lane == 1 ? pmAll : pm2);
+            const int32_t value = d - 6;                                      // D(i - 1) - c(i)
+            const bool boundHolds = i < 2 || pm2 - (p - int32_t(h2 >> 16) - 1) < value;
+            const bool ok = simple && boundHolds && -min(p, s) < value;
+            const uint64_t okMask = ballot64(ok);
+            const int accepted = okMask == ~0ULL ? WAVE : (__ffsll((unsigned long long)~okMask) - 1);
+#ifdef CHAIN_DEBUG
+            if(lane < 3) std::fprintf(stderr, "  k %d lane %d h %x d %d step %d pmIncl %d pm2 %d ok %d accepted %d dBefore %d\n", k, lane, h, d, step, pmIncl, pm2, int(ok), accepted, dBefore);
+#endif
+            if(accepted > 0) {
+                if(lane < accepted) { Dv[i] = d; OFF[i] = uint16_t(1u | (waysBefore ? CHAIN_OFF_WAYS : 0u)); }
+                const int32_t end = d - min(np - 1 - p, ns - 1 - s);
+                const int32_t runBest = waveMax(lane < accepted ? end : CHAIN_NEG);
+                const uint64_t at = ballot64(lane < accepted && end == runBest);
+                const uint32_t ways = min(2u, uint32_t(__popcll(at)) * (waysBefore ? 2u : 1u));
+                if(runBest > best) { best = runBest; bestAt = k + (__ffsll((unsigned long long)at) - 1); bestWays = ways; }
+                else if(runBest == best) bestWays = min(2u, bestWays + ways);
+                const int32_t newAll = laneValue(pmIncl, accepted - 1);
+                pmBut1 = accepted >= 2 ? laneValue(pmIncl, accepted - 2) : pmAll;
+                pmAll = newAll;
+                k += accepted;
+                waveLdsSync();                                                // (the exception's scan reads what the accepted lanes wrote)
+            }
+            if(accepted < WAVE && k < n) {
+                // The exception: hit k against every hit before it, 64 per step from the nearest back.
+                const uint32_t he = H[k];
+                const int32_t pe = int32_t(he >> 16), se = int32_t(he & 0xffffu);
+                int32_t value = -min(pe, se);
+                uint32_t ways = 1;
+                int32_t from = 0;
+                for(int32_t top = k - 1; top >= 0; top -= WAVE) {
+                    // (nothing at `top` or before it can reach `value`: every one of them is at least pe - p(top) - 1 away)
+                    if(pmAll - (pe - int32_t(H[top] >> 16) - 1) < value) break;
+                    const int32_t q = top - lane;
+                    const uint32_t hq = H[q >= 0 ? q : 0];
+                    const int32_t pq = int32_t(hq >> 16), sq = int32_t(hq & 0xffffu);
+                    const bool good = q >= 0 && pq < pe && sq < se;
+                    const int32_t candidate = good ? Dv[q] - max(pe - pq - 1, se - sq - 1) : CHAIN_NEG;
+                    const bool two = good && (uint32_t(OFF[q]) & CHAIN_OFF_WAYS) != 0;
+                    const int32_t blockBest = waveMax(candidate);
+                    if(blockBest > value) { value = blockBest; ways = 0; from = -1; }
+                    if(blockBest == value) {
+                        const uint64_t at = ballot64(candidate == value), atTwo = ballot64(candidate == value && two);
+                        ways = min(2u, ways + uint32_t(__popcll(at)) + uint32_t(__popcll(atTwo)));
+                        if(from < 0) from = k - top + (__ffsll((unsigned long long)at) - 1);       // the nearest hit that attains it
+                    }
+                }
+                const int32_t dk = 6 + value;
+                if(lane == 0) { Dv[k] = dk; OFF[k] = uint16_t(uint32_t(from) | CHAIN_OFF_EXCEPTION | (ways >= 2u ? CHAIN_OFF_WAYS : 0u)); }
+                const int32_t end = dk - min(np - 1 - pe, ns - 1 - se);
+                if(end > best) { best = end; bestAt = k; bestWays = ways; }
+                else if(end == best) bestWays = min(2u, bestWays + ways);
+                pmBut1 = pmAll; pmAll = max(pmAll, dk);
+                ++k;
+            }
+            waveLdsSync();
+        }
+
+#ifdef CHAIN_DEBUG
+        if(lane == 0) std::fprintf(stderr, "chainwave: task %u n %d best %d bestAt %d bestWays %u np %d ns %d\n", t, n, best, bestAt, bestWays, np, ns);
+#endif
+        // ---- what the task is ----
+        const int32_t matchless = sparseMatchlessScore(pd.nx, pd.ny, task.bandMin, task.bandMax);
+        const bool empty = n == 0 || best < matchless;
+        if(!empty && best == matchless) {
+            if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_TIE_WITH_EMPTY, pd, task); }
+            continue;
+        }
+        if(!empty && bestWays != 1u) {
+            // Several optimal chains: the list and link words as sparseChainKernel leaves them, for sparseAnchorKernel.  A link word:
+            // bit 0 the border attains the hit's maximum, bit d the hit d back (d <= 29; bit 30: one further back); bit 31: a chain
+            // that ends with the hit reaches the best end so far.
+            uint32_t* __restrict__ const myLinks = linkWords + sparseListBase(ordOffsets, t);
+            int32_t pmRunning = CHAIN_NEG, endRunning = CHAIN_NEG;
+            for(int32_t base = 0; base < n; base += WAVE) {
+                const int32_t i = base + lane;
+                const bool valid = i < n;
+                const uint32_t h = H[valid ? i : n - 1];
+                const int32_t p = int32_t(h >> 16), s = int32_t(h & 0xffffu);
+                const int32_t d = valid ? Dv[i] : CHAIN_NEG;
+                const uint32_t off = valid ? uint32_t(OFF[i]) : 1u;
+                const int32_t pmIncl = max(pmRunning, waveInclusiveMax(d));
+                const int32_t end = valid ? d - min(np - 1 - p, ns - 1 - s) : CHAIN_NEG;
+                const int32_t endIncl = max(endRunning, waveInclusiveMax(end));
+                int32_t endBefore = __shfl_up(endIncl, 1, WAVE);
+                if(lane == 0) endBefore = endRunning;
+                uint32_t links = 2u;                                          // an accepted hit: the hit before it, nothing else
+                uint64_t todo = ballot64(valid && (off & CHAIN_OFF_EXCEPTION) != 0);
+                while(todo) {
+                    const int j = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int32_t e = base + j;
+                    const uint32_t he = H[e];
+                    const int32_t pe = int32_t(he >> 16), se = int32_t(he & 0xffffu);
+                    const int32_t target = Dv[e] - 6;
+                    const int32_t pmBefore = j == 0 ? pmRunning : laneValue(pmIncl, j - 1);
+                    uint32_t word = -min(pe, se) == target ? 1u : 0u;
+                    for(int32_t top = e - 1; top >= 0; top -= WAVE) {
+                        if(pmBefore - (pe - int32_t(H[top] >> 16) - 1) < target) break;
+                        const int32_t q = top - lane;
+                        const uint32_t hq = H[q >= 0 ? q : 0];
+                        const int32_t pq = int32_t(hq >> 16), sq = int32_t(hq & 0xffffu);
+                        const bool attains = q >= 0 && pq < pe && sq < se && Dv[q] - max(pe - pq - 1, se - sq - 1) == target;
+                        const uint64_t at = ballot64(attains);
+                        if(at) {
+                            const int32_t nearest = e - top;                  // lane 0's distance
+                            // lane l is the hit nearest + l back
+                            if(nearest <= SPARSE_LINK_REACH) word |= uint32_t((at << nearest) & 0x3ffffffeULL);
+                            const int reach = SPARSE_LINK_REACH - nearest;    // lanes beyond it are further back than the word names
+                            if(reach < 0 || (reach < 63 && (at >> (reach + 1)) != 0)) word |= 0x40000000u;
+                        }
+                    }
+                    if(lane == j) links = word;
+                }
+                if(valid) {
+                    myLinks[i] = links | (end >= endBefore ? 0x80000000u : 0u);
+                    list[i] = (uint32_t(p) << 17) | (uint32_t(s - p - lo) << 7) | min(off & CHAIN_OFF_MASK, 127u);
+                }
+                pmRunning = laneValue(pmIncl, WAVE - 1);
+                endRunning = laneValue(endIncl, WAVE - 1);
+            }
+            if(lane == 0) {
+                DpEnd e; e.traceOffset = 0; e.bestI = bestAt; e.bestJ = 0; e.score = best; e.laneBase = 0; e.bundleIterations = 0; e.pad = 0;
+                ends[t] = e;
+                ambiguousList[atomicAdd(&control->ambiguousCount, 1u)] = t;
+                state[t] = SPARSE_AMBIGUOUS;
+            }
+            continue;
+        }
+
+        // ---- the chain, its pairs, AlignmentInfo's metrics (src/Alignment.cpp:67-113), its size in shasta::compress form ----
+        const uint64_t ordBase = ordOffsets[t];
+        uint32_t pos = min(pd.nx, pd.ny);
+        int32_t minOffset = 0x7fffffff, maxOffset = int32_t(0x80000000);
+        long long sumOffset = 0;
+        uint32_t maxSkip = 0, maxDrift = 0;
+        unsigned long long bytes = 0;
+        int32_t laterX = 0, laterY = 0, lastX = 0, lastY = 0;                 // the lowest pair met so far (the successor of the next one met); the last pair of the alignment
+        bool haveLater = false;
+        uint32_t carryLength = 0;             // pairs from the lowest one met up to and including the first one that is followed by a new streak (or up to the end)
+        int32_t cur = empty ? -1 : bestAt;
+        while(cur >= 0) {
+            const int32_t base = (cur >> 6) << 6;
+            const int32_t i = base + lane;
+            const bool valid = i < n;
+            const uint32_t off = valid ? (uint32_t(OFF[i]) & CHAIN_OFF_MASK) : 1u;
+            const uint32_t h = H[valid ? i : n - 1];
+            const uint64_t notOne = ballot64(valid && off != 1u);
+            uint64_t on = 0;
+            while(cur >= base) {
+                const int top = cur - base;
+                const uint64_t below = notOne & bitsUpTo(top);
+                if(below == 0) { on |= bitsUpTo(top); cur = base - 1; break; }
+                const int j = 63 - __clzll((unsigned long long)below);
+                on |= bitsUpTo(top) & ~(bitsUpTo(j) >> 1);
+                const int32_t back = laneValue(int32_t(off), j);
+                cur = back == 0 ? -1 : base + j - back;
+            }
+            const bool isOn = ((on >> lane) & 1ULL) != 0;
+            const uint32_t count = uint32_t(__popcll(on));
+            const uint32_t rank = uint32_t(__popcll(on & laneMaskLt()));
+            const int32_t hp = int32_t(h >> 16), hs = int32_t(h & 0xffffu);
+            const int32_t x = swapped ? hs : hp, y = swapped ? hp : hs;
+            pos -= count;
+            if(isOn) *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos + rank)) = make_uint2(uint32_t(x), uint32_t(y));
+            // The pair after this one: the next lane up that is on the chain, or the lowest pair of the part met before.
+            const uint64_t above = bitsAbove(on, lane);
+            const int nextLane = above ? lane + __ffsll((unsigned long long)above) : lane;
+            int32_t nextX = __shfl(x, nextLane, WAVE), nextY = __shfl(y, nextLane, WAVE);
+            const bool hasNext = above != 0 || haveLater;
+            if(above == 0) { nextX = laterX; nextY = laterY; }
+            bool newStreak = false;
+            int32_t skip0 = 0, skip1 = 0;
+            if(isOn) {
+                const int32_t offset = x - y;
+                minOffset = min(minOffset, offset); maxOffset = max(maxOffset, offset); sumOffset += offset;
+                if(hasNext) {
+                    skip0 = nextX - x; skip1 = nextY - y;
+                    maxSkip = max(maxSkip, max(uint32_t(skip0), uint32_t(skip1)));
+                    const int32_t drift = skip0 - skip1;
+                    maxDrift = max(maxDrift, uint32_t(drift < 0 ? -drift : drift));
+                    newStreak = !(skip0 == 1 && skip1 == 1);
+                }
+            }
+            const uint64_t starts = ballot64(newStreak);      // lanes whose successor begins a streak
+            if(newStreak) {
+                // The streak that begins with the successor: up to and including the next pair that is followed by a new one.
+                const uint64_t startsAbove = bitsAbove(starts, lane);
+                uint32_t length;
+                if(startsAbove) {
+                    const int until = lane + __ffsll((unsigned long long)startsAbove);
+                    length = uint32_t(__popcll(on & bitsUpTo(until) & ~bitsUpTo(lane)));
+                } else length = uint32_t(__popcll(above)) + carryLength;
+                bytes += uint64_t(makeStreakRecord(skip0, skip1, length).len);
+            }
+            if(starts) carryLength = uint32_t(__popcll(on & bitsUpTo(__ffsll((unsigned long long)starts) - 1)));
+            else carryLength += count;
+            if(on) {
+                if(!haveLater) { const int topLane = 63 - __clzll((unsigned long long)on); lastX = laneValue(x, topLane); lastY = laneValue(y, topLane); }
+                const int lowLane = __ffsll((unsigned long long)on) - 1;
+                laterX = laneValue(x, lowLane); laterY = laneValue(y, lowLane);
+                haveLater = true;
+            }
+        }
+        // Sums over the lanes.
+#pragma unroll
+        for(int dlt = 32; dlt >= 1; dlt >>= 1) {
+            minOffset = min(minOffset, __shfl_xor(minOffset, dlt, WAVE)); maxOffset = max(maxOffset, __shfl_xor(maxOffset, dlt, WAVE));
+            sumOffset += __shfl_xor(sumOffset, dlt, WAVE);
+            maxSkip = max(maxSkip, uint32_t(__shfl_xor(int(maxSkip), dlt, WAVE))); maxDrift = max(maxDrift, uint32_t(__shfl_xor(int(maxDrift), dlt, WAVE)));
+            bytes += __shfl_xor(bytes, dlt, WAVE);
+        }
+        if(lane == 0) {
+            DpResult r;
+            r.sumOffset = 0; r.first0 = r.first1 = r.last0 = r.last1 = 0; r.minOffset = 0x7fffffff; r.maxOffset = int32_t(0x80000000);
+            r.maxSkip = r.maxDrift = 0; r.passes = 0; r.compressedBytes = 0;
+            if(haveLater) {
+                // (the first pair: its streak's skips are taken against (0, 0))
+                bytes += uint64_t(makeStreakRecord(laterX, laterY, carryLength).len);
+                r.sumOffset = sumOffset; r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
+                r.first0 = uint32_t(laterX); r.first1 = uint32_t(laterY); r.last0 = uint32_t(lastX); r.last1 = uint32_t(lastY);
+            }
+            r.ordBegin = ordBase + pos;
+            r.markerCount = min(pd.nx, pd.ny) - pos;
+            r.score = empty ? matchless : best;
+            r.compressedBytes = uint32_t(bytes < 0xffffffffULL ? bytes : 0xffffffffULL);
+            taskAcceptance(r, pd, task, opt, pairBest);
+            results[t] = r;
+            state[t] = SPARSE_COMPLETE;
+        }
+    }
+    }
+    if(lane == 0 && walked) atomicAdd(&control->hitsInBand, walked);
+}

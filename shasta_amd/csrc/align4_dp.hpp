@@ -89,6 +89,17 @@ __host__ __device__ inline uint32_t dpBinOfKey(uint32_t key)
     }
     return cls * uint32_t(DP_BINS_PER_CLASS) + q;
 }
+// Why a task of the sparse path ends in the dense kernels (counted on the device, reported in the kernel table as rows without time).
+enum DpGiveUp : int { GIVE_UP_NO_LIST = 0, GIVE_UP_LIST_OVERFLOW, GIVE_UP_LONG_STREAM, GIVE_UP_CROWDED_MARKER, GIVE_UP_SORTED_CAPACITY,
+    GIVE_UP_LOOK_BACK, GIVE_UP_TIE_WITH_EMPTY, GIVE_UP_FAR_LINK, GIVE_UP_NO_ANCHOR, GIVE_UP_WINDOWS, GIVE_UP_RECTANGLE, GIVE_UP_ANCHORS_OFF };
+constexpr int DP_GIVE_UP_REASONS = 12;
+const char* const DP_GIVE_UP_NAMES[DP_GIVE_UP_REASONS] = {
+    "dense DP because: the candidate's matches were not listed (HBM-scratch cells kernel)", "dense DP because: the candidate's match list overflowed",
+    "dense DP because: the tabled read has more than 8192 markers", "dense DP because: 16 matches of one marker inside the band",
+    "dense DP because: more matches inside the band than the task's list holds", "dense DP because: a match's predecessors lie further back than the chain kernel looks",
+    "dense DP because: the best chain ties with the empty alignment", "dense DP because: an optimal link of a live match beyond its link word",
+    "dense DP because: no match lies on every optimal chain", "dense DP because: more than 128 windows between anchors",
+    "dense DP because: a rectangle between anchors beyond the anchor kernel's limits", "dense DP because: several optimal chains and the anchor kernel is switched off"};
 // Everything the DP's preparation counts, in one block of device memory (one memset before, one copy to the host after).
 struct DpControl {
     unsigned long long sums[2 + 2 * DP_CLASSES];     // [0] DP cells of all tasks, [1] unused, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c (of the tasks the dense kernels run)
@@ -97,8 +108,12 @@ struct DpControl {
     uint32_t ambiguousCount, pad;                    // tasks sparseChainKernel left to sparseAnchorKernel (align4_sparse.hpp, align4_anchor.hpp)
     unsigned long long hitsListed, hitsInBand;       // matches the sparse kernels read from the candidates' lists / kept inside the tasks' bands
     unsigned long long ambiguousHits;                // matches of the tasks sparseAnchorKernel walked
+    unsigned long long giveUpCells[DP_GIVE_UP_REASONS];   // DP cells of the tasks the sparse kernels left to the dense ones, by reason (DpGiveUp)
+    uint32_t giveUpTasks[DP_GIVE_UP_REASONS];             // ... and how many tasks
     uint32_t bins[DP_BINS];                          // tasks per bin, then (dpBinScanKernel) the bin's first position
     uint32_t cursors[DP_BINS];
+    uint32_t anchorBigCount, anchorPad;              // align4_anchor.hpp: tasks with a rectangle beyond the first launch's LDS, listed for the second
+    uint32_t waveNext[4];                            // align4_chainwave.hpp: the cursor through which the wavefronts of a capacity class take their blocks of tasks
 };
 constexpr size_t DP_CONTROL_HEAD_BYTES = offsetof(DpControl, bins);
 

@@ -68,10 +68,24 @@ __host__ __device__ inline int32_t sparseMatchlessScore(uint32_t nx, uint32_t ny
     return int32_t(best > -(1LL << 30) ? best : -(1LL << 30));
 }
 
+// align4_chainwave.hpp's capacity classes (hits a wavefront holds in LDS).
+constexpr int CHAIN_WAVE_CLASSES = 3;
+constexpr uint32_t CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES] = {1024u, 2048u, 15360u};
+__host__ __device__ inline int chainWaveClassOf(uint32_t hits)
+{
+    return hits <= CHAIN_WAVE_CAPACITY[0] ? 0 : (hits <= CHAIN_WAVE_CAPACITY[1] ? 1 : (hits <= CHAIN_WAVE_CAPACITY[2] ? 2 : -1));
+}
+
+__device__ __forceinline__ void noteGiveUp(DpControl* control, int why, const PairDesc& pd, const DpTask& task)
+{
+    atomicAdd(&control->giveUpTasks[why], 1u);
+    atomicAdd(&control->giveUpCells[why], (unsigned long long)pd.nx * (unsigned long long)(task.bandMax - task.bandMin + 1));
+}
+
 __global__ void __launch_bounds__(256)
 sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control)
 {
     __shared__ uint32_t counts[4][SPARSE_COUNTER_WORDS], cursors[4][SPARSE_COUNTER_WORDS];
     __shared__ uint16_t wordStart[4][SPARSE_COUNTER_WORDS];
@@ -90,7 +104,10 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
     // chunk kernel made the list (the LDS table's classes), however long the streamed read is.
     const uint32_t streamCount = swapped ? pd.ny : pd.nx;          // (markers of the read the order is by)
     if(meta == HIT_LIST_NONE || count > capacity || streamCount > SPARSE_MAX_STREAM || streamCount == 0) {
-        if(lane == 0) state[t] = SPARSE_DENSE;
+        if(lane == 0) {
+            state[t] = SPARSE_DENSE;
+            noteGiveUp(control, meta == HIT_LIST_NONE ? GIVE_UP_NO_LIST : (count > capacity ? GIVE_UP_LIST_OVERFLOW : GIVE_UP_LONG_STREAM), pd, task);
+        }
         return;
     }
     uint32_t* const myCounts = counts[wave];
@@ -114,7 +131,7 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
         }
     }
     waveLdsSync();
-    if(__any(crowded)) { if(lane == 0) state[t] = SPARSE_DENSE; return; }
+    if(__any(crowded)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_CROWDED_MARKER, pd, task); } return; }
     // Where every word's markers start: a scan of the words' sums.
     const uint32_t per = (words + WAVE - 1) / WAVE, first = uint32_t(lane) * per;
     uint32_t sum = 0;
@@ -123,7 +140,7 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
 #pragma unroll
     for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
     const uint32_t total = uint32_t(__shfl(int(inclusive), WAVE - 1, WAVE));
-    if(total > sparseListCapacity(pd.nx, pd.ny)) { if(lane == 0) state[t] = SPARSE_DENSE; return; }
+    if(total > sparseListCapacity(pd.nx, pd.ny)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_SORTED_CAPACITY, pd, task); } return; }
     uint32_t running = inclusive - sum;
     for(uint32_t w = first; w < min(first + per, words); w++) { myStart[w] = uint16_t(running); running += nibbleSum(myCounts[w]); }
     waveLdsSync();
@@ -305,7 +322,7 @@ sparseChainKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__
     if(!mine) return;
     const int32_t matchless = sparseMatchlessScore(pd.nx, pd.ny, task.bandMin, task.bandMax);
     const bool empty = n == 0 || best < matchless;
-    if(failed || (!empty && best == matchless)) { state[t] = SPARSE_DENSE; return; }
+    if(failed || (!empty && best == matchless)) { state[t] = SPARSE_DENSE; noteGiveUp(control, failed ? GIVE_UP_LOOK_BACK : GIVE_UP_TIE_WITH_EMPTY, pd, task); return; }
     if(!empty && bestWays != 1u) {
         // Several optimal chains: sparseAnchorKernel's.  The best score and the first hit that reaches it travel in the task's DpEnd
         // (the dense forward kernel writes it anew if the task ends up there).

@@ -235,6 +235,14 @@ public:
         std::lock_guard<std::mutex> lock(mutex);
         for(Pending& p : pending) if(p.handle == handle) { p.bytes = bytes; p.work = work; return; }
     }
+    // A row that counts something other than launches (no time): what the caller says, added up.
+    void count(const char* name, uint64_t launches, uint64_t bytes, uint64_t work)
+    {
+        if(!enabled) return;
+        std::lock_guard<std::mutex> lock(mutex);
+        Entry& e = entries[size_t(idOf(name))];
+        e.launches += launches; e.bytes += bytes; e.work += work;
+    }
     // Folds every finished launch into the table.  The caller has synchronised the streams it launched on;
     // a launch that is still running stays pending.
     void collect() { std::lock_guard<std::mutex> lock(mutex); collectLocked(); }

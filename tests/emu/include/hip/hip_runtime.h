@@ -205,12 +205,20 @@ __forceinline__ int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int 
         case 0x101: from = (lane % 16) <= 14 ? lane + 1 : -1; break;     // row_shl:1
         case 0x138: from = lane >= 1 ? lane - 1 : -1; break;             // wave_shr:1
         case 0x130: from = lane <= 62 ? lane + 1 : -1; break;            // wave_shl:1
-        default: std::fprintf(stderr, "hip_emu: DPP control 0x%x is not modelled\n", ctrl); std::abort();
+        case 0x142: from = lane >= 16 ? (lane / 16) * 16 - 1 : -1; break;    // row_bcast:15 (lane 15 of a row to every lane of the next row)
+        case 0x143: from = lane >= 32 ? 31 : -1; break;                      // row_bcast:31 (lane 31 to rows 2 and 3)
+        default:
+            if(ctrl > 0x110 && ctrl <= 0x11f) { const int n = ctrl - 0x110; from = (lane % 16) >= n ? lane - n : -1; break; }      // row_shr:n
+            std::fprintf(stderr, "hip_emu: DPP control 0x%x is not modelled\n", ctrl); std::abort();
     }
-    if(rowMask != 0xf || bankMask != 0xf) { std::fprintf(stderr, "hip_emu: DPP row/bank masks are not modelled\n"); std::abort(); }
+    if(bankMask != 0xf) { std::fprintf(stderr, "hip_emu: DPP bank masks are not modelled\n"); std::abort(); }
+    // row_mask: a row (16 lanes) whose bit is clear keeps `old` (it still takes part in the exchange: other rows may read its lanes).
+    const bool rowOff = ((rowMask >> (lane / 16)) & 1) == 0;
+    if(rowOff) from = -1;
     // A source lane that is out of range OR switched off (not at this call site with the others) is invalid: 0 with bound_ctrl,
     // `old` without -- measured on gfx950 (scripts/microbench/dpp_exec_probe.hip, profiles/r02_dpp_exec_probe.jsonl).
     const uint64_t got = hipemu::collective(hipemu::DPP_MOVE, uint32_t(src), uint64_t(from < 0 ? lane : from));
+    if(rowOff) return old;
     const bool valid = from >= 0 && (got >> 32) != 0;
     return valid ? int(uint32_t(got)) : (boundCtrl ? 0 : old);
 }
