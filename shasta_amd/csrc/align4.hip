@@ -343,7 +343,7 @@ bool anchorBigEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHOR_BIG"
 bool chainWaveEnabled() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE"); return !e || std::atoi(e) != 0; }
 
 template<int CLS>
-void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const uint32_t* hitMeta, DpControl* control, const DeviceOptions& opt)
+void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
     constexpr uint32_t CAP = CHAIN_WAVE_CAPACITY[CLS];
     constexpr size_t ldsBytes = size_t(CAP) * 10u;
@@ -362,16 +362,16 @@ void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in
     }
     hipLaunchKernelGGL(sparseChainWaveKernel<int(CAP)>, dim3(std::min<uint32_t>(CHAIN_WAVE_GRID[CLS], divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
-        b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), hitMeta,
+        b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
         (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), opt, b.pairBest.data());
     HIP_CHECK(hipGetLastError());
 }
-void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const uint32_t* hitMeta, DpControl* control, const DeviceOptions& opt)
+void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
-    // (the few large tasks first: their wavefronts run longest)
-    launchChainWaveClass<2>(stream, b, in, taskCount, hitMeta, control, opt);
-    launchChainWaveClass<1>(stream, b, in, taskCount, hitMeta, control, opt);
-    launchChainWaveClass<0>(stream, b, in, taskCount, hitMeta, control, opt);
+    // (the first class's launch also marks the tasks that no class holds; the few large tasks after it)
+    launchChainWaveClass<0>(stream, b, in, taskCount, sparse, control, opt);
+    launchChainWaveClass<2>(stream, b, in, taskCount, sparse, control, opt);
+    launchChainWaveClass<1>(stream, b, in, taskCount, sparse, control, opt);
 }
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
@@ -419,18 +419,19 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         b.scanTemp32.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
         const bool chainWave = chainWaveEnabled();
         KernelTimers::Span span;
+        if(chainWave) {
+            // K10w (align4_chainwave.hpp): a wavefront per task orders the band's hits in LDS and runs the chain recurrence on them there;
+            // one launch of wavefronts per capacity class.
+            if(timers) span = timers->begin("sparseChainWaveKernel", stream);
+            launchChainWave(stream, b, in, taskCount, *sparse, control, *metricsOptions);
+            if(timers) waveHandle = timers->end(span, 0, taskCount);
+        } else {
         if(timers) span = timers->begin("sparseSortKernel", stream);
         hipLaunchKernelGGL(sparseSortKernel, dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
             b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control);
         HIP_CHECK(hipGetLastError());
         if(timers) sortHandle = timers->end(span, 0, taskCount);
-        if(chainWave) {
-            // K10w (align4_chainwave.hpp): a wavefront per task, the task's hits in LDS; one launch of persistent wavefronts per capacity class.
-            if(timers) span = timers->begin("sparseChainWaveKernel", stream);
-            launchChainWave(stream, b, in, taskCount, sparse->hitMeta, control, *metricsOptions);
-            if(timers) waveHandle = timers->end(span, 0, taskCount);
-        }
         if(timers) span = timers->begin("sparseChainKernel", stream);
         hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
             in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
@@ -438,6 +439,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
             b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), control, *metricsOptions, b.pairBest.data());
         HIP_CHECK(hipGetLastError());
         if(timers) chainHandle = timers->end(span, 0, taskCount);
+        }
         // K10a (align4_anchor.hpp): the tasks with several optimal chains, the dense DP only where the chains differ.
         if(anchoredDpEnabled()) {
             anchored = true;
@@ -508,9 +510,10 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         // The sparse kernels' rows: the matches listed for the tasks' candidates are read (4 bytes each) and those inside the bands
         // written in order; the chain kernel reads those and writes a list word and a link word beside each; the anchor kernel reads both
         // for the tasks it walks and writes their aligned pairs (8 bytes: about one per match).  Work = matches inside the bands.
-        timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
+        if(!chainWaveEnabled()) timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
         // (with align4_chainwave.hpp on, nearly all tasks are the wave kernel's: it reads a hit once, 4 bytes, and writes a pair, 8)
-        if(chainWaveEnabled()) { timers->amend(waveHandle, 12 * head.hitsInBand, head.hitsInBand); timers->amend(chainHandle, 0, 0); }
+        // (the wave kernel reads the listed matches twice, 4 bytes each, and writes a pair, 8 bytes, per match inside the bands)
+        if(chainWaveEnabled()) timers->amend(waveHandle, 8 * head.hitsListed + 8 * head.hitsInBand, head.hitsInBand);
         else timers->amend(chainHandle, 12 * head.hitsInBand, head.hitsInBand);
         if(anchored) timers->amend(anchorHandle, 16 * head.ambiguousHits, head.ambiguousHits);
         else if(head.ambiguousCount) timers->count(DP_GIVE_UP_NAMES[GIVE_UP_ANCHORS_OFF], head.ambiguousCount, 0, 0);

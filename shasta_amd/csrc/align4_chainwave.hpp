@@ -28,9 +28,14 @@
 // once (written).  A task with several optimal chains gets its list and link words written out as sparseChainKernel leaves them
 // (links of the exceptions recomputed from the final D: 64 candidates per step again) and goes to sparseAnchorKernel.
 //
+// The kernel also ORDERS the hits itself (sparseSortKernel's counting sort, into LDS): the candidate's match list is read from HBM,
+// the ordered hits never go there (the sort kernel wrote 4 bytes per hit and this one read them again: 15 ms per step alone, 80 ms
+// of launches sharing the device).
+//
 // LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Three launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
-// tasks at 100 k reads), 2 048, 15 360 -- of wavefronts that go over the task list in blocks of 64 and run the tasks of their class;
-// what does not fit the largest stays with sparseChainKernel.  SHASTA_MI355X_CHAIN_WAVE=0: as before this file.
+// tasks at 100 k reads), 2 048, 15 360 -- of wavefronts that go over the task list in blocks of 16 and run the tasks of their class
+// (the class from the matches LISTED for the candidate, known before any is counted); what fits none goes to the dense kernels.
+// SHASTA_MI355X_CHAIN_WAVE=0: sparseSortKernel + sparseChainKernel, as before this file.
 #pragma once
 
 constexpr uint32_t CHAIN_WAVE_GRID[CHAIN_WAVE_CLASSES] = {256u * 16u, 256u * 8u, 256u};       // workgroups of one wavefront, as many as the LDS lets a CU hold
@@ -64,11 +69,28 @@ __device__ __forceinline__ int32_t laneValue(int32_t v, int lane) { return int32
 __device__ __forceinline__ uint64_t bitsUpTo(int b) { return b >= 63 ? ~0ULL : ((2ULL << b) - 1ULL); }       // bits 0 .. b
 __device__ __forceinline__ uint64_t bitsAbove(uint64_t m, int lane) { return (m >> lane) >> 1; }              // bits lane + 1 .. 63, moved down to bit 0
 
+// The capacity class of a task, from what is known before its hits are counted: the matches LISTED for its candidate (an upper bound of
+// those inside its band) and the markers of the tabled read (the counting sort's 4-bit counters lie where D and `from` will be:
+// 1.5 words per hit of capacity for 2.5 words per 8 markers).  -1 and the reason: no class (the dense kernels run the task).
+__device__ __forceinline__ int chainWaveClassOfTask(const PairDesc& pd, uint32_t meta, uint64_t room, int& why)
+{
+    if(meta == HIT_LIST_NONE) { why = GIVE_UP_NO_LIST; return -1; }
+    const uint32_t count = meta & 0x7fffffffu;
+    if(uint64_t(count) > room) { why = GIVE_UP_LIST_OVERFLOW; return -1; }
+    const uint32_t streamCount = (meta >> 31) ? pd.ny : pd.nx;
+    if(streamCount > SPARSE_MAX_STREAM || streamCount == 0) { why = GIVE_UP_LONG_STREAM; return -1; }
+    const uint32_t counterWords = 5u * ((streamCount + 7u) / 8u);        // in half words: counts, cursors, starts
+#pragma unroll
+    for(int c = 0; c < CHAIN_WAVE_CLASSES; c++) if(count <= CHAIN_WAVE_CAPACITY[c] && counterWords <= 3u * CHAIN_WAVE_CAPACITY[c]) return c;
+    why = GIVE_UP_SORTED_CAPACITY;
+    return -1;
+}
+
 template<int CAP>
 __global__ void __launch_bounds__(64)
 sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount, int cls,
-    DpControl* __restrict__ control, uint32_t* __restrict__ sorted, const uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
-    const uint32_t* __restrict__ hitMeta, const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
+    DpControl* __restrict__ control, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
+    const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta, const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
     uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
 {
     extern __shared__ uint32_t ldsWords[];
@@ -76,7 +98,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
     int32_t* const Dv = reinterpret_cast<int32_t*>(ldsWords + CAP);          // D of the finished hits
     uint16_t* const OFF = reinterpret_cast<uint16_t*>(ldsWords + 2 * CAP);   // how many hits back the predecessor is (0: the chain starts here) | flags
     const int lane = laneId();
-    unsigned long long walked = 0;
+    unsigned long long walked = 0, listed = 0;
     // The tasks in blocks of CHAIN_WAVE_BLOCK, taken through a cursor (an atomic per block: a few thousand per launch -- an atomic per
     // TASK on one address, 275 000 per launch, cost the sort kernel 8 ms a step when it appended the tasks to class lists): a lane per
     // task looks at its state and hit count, and the wavefront runs those of its class one after the other.
@@ -87,24 +109,87 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
     const uint32_t blockBase = blockIndex * CHAIN_WAVE_BLOCK;
     if(blockBase >= taskCount) break;
     const uint32_t candidateTask = blockBase + uint32_t(lane);
-    uint64_t todoTasks = ballot64(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount && state[candidateTask] == SPARSE_SORTED && chainWaveClassOf(inBand[candidateTask]) == cls);
+    int myClass = -2;                                  // -2: not a task of this block; -1: none of the classes holds it (the dense kernels')
+    if(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount) {
+        const DpTask mine = tasks[candidateTask];
+        const PairDesc myPair = pairs[mine.pair];
+        int why = -1;
+        myClass = chainWaveClassOfTask(myPair, hitMeta[mine.pair], hitBase[mine.pair + 1] - hitBase[mine.pair], why);
+        if(myClass < 0 && cls == 0) { state[candidateTask] = SPARSE_DENSE; noteGiveUp(control, why, myPair, mine); }      // (said once: by the first class's launch)
+    }
+    uint64_t todoTasks = ballot64(myClass == cls);
     while(todoTasks) {
         const uint32_t t = blockBase + uint32_t(__ffsll((unsigned long long)todoTasks) - 1);
         todoTasks &= todoTasks - 1;
         const DpTask task = tasks[t];
         const PairDesc pd = pairs[task.pair];
         const bool swapped = (hitMeta[task.pair] >> 31) != 0;
-        const int32_t n = int32_t(inBand[t]);
         const int32_t np = int32_t(swapped ? pd.ny : pd.nx), ns = int32_t(swapped ? pd.nx : pd.ny);
         const int32_t lo = swapped ? task.bandMin : -task.bandMax;
         uint32_t* __restrict__ const list = sorted + sparseListBase(ordOffsets, t);
+        // ---- the band's hits in the order of the ordinal in the tabled read (what sparseSortKernel does, into LDS instead of HBM):
+        // a counting sort on 4-bit counters per marker; the counters lie where D and `from` will be ----
+        int32_t n = 0;
+        {
+            const uint32_t listedHits = hitMeta[task.pair] & 0x7fffffffu;
+            const uint32_t* __restrict__ const raw = hits + hitBase[task.pair];
+            const uint32_t streamCount = uint32_t(np);
+            const uint32_t words = (streamCount + 7u) / 8u;
+            uint32_t* const counts = ldsWords + CAP;
+            uint32_t* const cursors = counts + words;
+            uint16_t* const wordStart = reinterpret_cast<uint16_t*>(cursors + words);
+            listed += listedHits;
+            waveLdsSync();                                                  // (the task before has left the arrays)
+            for(uint32_t w = uint32_t(lane); w < 2u * words; w += WAVE) counts[w] = 0;
+            waveLdsSync();
+            bool crowded = false;
+            for(uint32_t i0 = 0; i0 < listedHits; i0 += WAVE) {
+                const uint32_t i = i0 + uint32_t(lane);
+                const uint32_t e = raw[i < listedHits ? i : 0u];
+                const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
+                const bool in = i < listedHits && x - y >= task.bandMin && x - y <= task.bandMax;
+                const uint32_t p = uint32_t(swapped ? y : x);
+                if(in && p < streamCount) {
+                    const uint32_t shift = 4u * (p & 7u);
+                    const uint32_t old = atomicAdd(&counts[p >> 3], 1u << shift);
+                    crowded |= ((old >> shift) & 15u) == 15u;
+                }
+            }
+            waveLdsSync();
+            if(__any(crowded)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_CROWDED_MARKER, pd, task); } continue; }
+            const uint32_t per = (words + WAVE - 1) / WAVE, first = uint32_t(lane) * per;
+            uint32_t sum = 0;
+            for(uint32_t w = first; w < min(first + per, words); w++) sum += nibbleSum(counts[w]);
+            const uint32_t inclusive = uint32_t(waveInclusiveSum(int32_t(sum)));
+            const uint32_t total = uint32_t(laneValue(int32_t(inclusive), WAVE - 1));
+            if(total > sparseListCapacity(pd.nx, pd.ny) || total > uint32_t(CAP)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_SORTED_CAPACITY, pd, task); } continue; }
+            uint32_t running = inclusive - sum;
+            for(uint32_t w = first; w < min(first + per, words); w++) { wordStart[w] = uint16_t(running); running += nibbleSum(counts[w]); }
+            waveLdsSync();
+            for(uint32_t i0 = 0; i0 < listedHits; i0 += WAVE) {
+                const uint32_t i = i0 + uint32_t(lane);
+                const uint32_t e = raw[i < listedHits ? i : 0u];
+                const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
+                const bool in = i < listedHits && x - y >= task.bandMin && x - y <= task.bandMax;
+                const uint32_t p = uint32_t(swapped ? y : x), sOrdinal = uint32_t(swapped ? x : y);
+                if(in && p < streamCount) {
+                    const uint32_t w = p >> 3, shift = 4u * (p & 7u);
+                    const uint32_t below = nibbleSum(counts[w] & ((1u << shift) - 1u));
+                    const uint32_t local = (atomicAdd(&cursors[w], 1u << shift) >> shift) & 15u;
+                    H[uint32_t(wordStart[w]) + below + local] = (p << 16) | sOrdinal;
+                }
+            }
+            n = int32_t(total);
+            if(lane == 0) inBand[t] = total;
+            waveLdsSync();
+        }
         walked += uint32_t(n);
-        waveLdsSync();                                                      // (the task before has left the arrays)
-        for(int32_t i = lane; i < n; i += WAVE) H[i] = list[i];
-        waveLdsSync();
 
         // ---- forward: D, `from`, the count of optimal chains (capped at two) ----
         int32_t k = 0;
+#ifdef CHAIN_DEBUG
+        int dbgPasses = 0, dbgExceptions = 0, dbgBlocks = 0;
+#endif
         int32_t pmAll = CHAIN_NEG, pmBut1 = CHAIN_NEG;                      // the largest D of the hits [0, k), and of [0, k - 1)
         int32_t best = CHAIN_NEG, bestAt = -1;
         uint32_t bestWays = 0;
@@ -129,7 +214,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             const uint64_t okMask = ballot64(ok);
             const int accepted = okMask == ~0ULL ? WAVE : (__ffsll((unsigned long long)~okMask) - 1);
 #ifdef CHAIN_DEBUG
-            if(lane < 3) std::fprintf(stderr, "  k %d lane %d h %x d %d step %d pmIncl %d pm2 %d ok %d accepted %d dBefore %d\n", k, lane, h, d, step, pmIncl, pm2, int(ok), accepted, dBefore);
+            ++dbgPasses;
 #endif
             if(accepted > 0) {
                 if(lane < accepted) { Dv[i] = d; OFF[i] = uint16_t(1u | (waysBefore ? CHAIN_OFF_WAYS : 0u)); }
@@ -152,7 +237,13 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 int32_t value = -min(pe, se);
                 uint32_t ways = 1;
                 int32_t from = 0;
+#ifdef CHAIN_DEBUG
+                ++dbgExceptions;
+#endif
                 for(int32_t top = k - 1; top >= 0; top -= WAVE) {
+#ifdef CHAIN_DEBUG
+                    ++dbgBlocks;
+#endif
                     // (nothing at `top` or before it can reach `value`: every one of them is at least pe - p(top) - 1 away)
                     if(pmAll - (pe - int32_t(H[top] >> 16) - 1) < value) break;
                     const int32_t q = top - lane;
@@ -181,7 +272,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
         }
 
 #ifdef CHAIN_DEBUG
-        if(lane == 0) std::fprintf(stderr, "chainwave: task %u n %d best %d bestAt %d bestWays %u np %d ns %d\n", t, n, best, bestAt, bestWays, np, ns);
+        if(lane == 0) std::fprintf(stderr, "chainwave: task %u n %d passes %d exceptions %d blocks %d\n", t, n, dbgPasses, dbgExceptions, dbgBlocks);
 #endif
         // ---- what the task is ----
         const int32_t matchless = sparseMatchlessScore(pd.nx, pd.ny, task.bandMin, task.bandMax);
@@ -354,5 +445,5 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
         }
     }
     }
-    if(lane == 0 && walked) atomicAdd(&control->hitsInBand, walked);
+    if(lane == 0 && walked) { atomicAdd(&control->hitsInBand, walked); atomicAdd(&control->hitsListed, listed); }
 }

@@ -96,7 +96,7 @@ def aligner(lib, orc, n_reads=160, limit=500):
                 got = ctx.align4(cand, o, want_ordinals=True)
             table = ctx.kernel_table()
             rows[name] = sum(v["work"] for k, v in table.items() if k.startswith("bandedDpForwardKernel"))
-            assert ("sparseChainKernel" in table) == (name == "sparse")
+            assert ("sparseChainWaveKernel" in table or "sparseChainKernel" in table) == (name == "sparse")
             ties = (want.status & 0x80) != 0
             if not ties.any():
                 support.same_align(want, got)

@@ -190,7 +190,7 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert any(k.startswith("alignment table") for k in line["kernels"])
     assert line["banded_dp"]["sparse_path"] is True and 0.3 < line["banded_dp"]["share_from_the_matches"] <= 1.0       # (1.0: what the chain kernel does not answer, the anchor kernel does)
     assert line["banded_dp"]["matches_in_the_bands_per_step"] > 0 and line["banded_dp"]["matches_walked_by_the_anchor_kernel_per_step"] is not None
-    assert any(k.startswith("align4CellsChunkKernel") for k in line["kernels"]) and any(k.startswith("sparseChainKernel") for k in line["kernels"])
+    assert any(k.startswith("align4CellsChunkKernel") for k in line["kernels"]) and any(k.startswith("sparseChainWaveKernel") for k in line["kernels"])
     assert line["config"]["candidates"] > 0 and "workload" in line["config"]
     census = line["dp_tie_sensitive"]             # the checker under the 11 other DP tie policies
     assert census["candidates"] > 0 and len(census["per_policy"]) == 11

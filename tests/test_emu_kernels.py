@@ -88,10 +88,10 @@ def test_lowhash0_and_align4(emu_lib, oracle_lib):
         forward = [v for k, v in t.items() if k.startswith("bandedDpForwardKernel")]
         assert z.dp_cell_count == x.dp_cell_count
         if sparse == "0":
-            assert sum(v["work"] for v in forward) == z.dp_cell_count and "sparseChainKernel" not in t and sum(v["bytes"] for v in forward) > 0
+            assert sum(v["work"] for v in forward) == z.dp_cell_count and "sparseChainKernel" not in t and "sparseChainWaveKernel" not in t and sum(v["bytes"] for v in forward) > 0
         else:
             # (possibly none at all: what the chain kernel does not certify, the anchor kernel mostly does)
-            assert sum(v["work"] for v in forward) < z.dp_cell_count // 2 and t["sparseChainKernel"]["launches"] >= 1 and t["sparseAnchorKernel"]["launches"] >= 1
+            assert sum(v["work"] for v in forward) < z.dp_cell_count // 2 and t["sparseChainWaveKernel"]["launches"] >= 1 and t["sparseAnchorKernel"]["launches"] >= 1
         if not (x.status & 0x80).any():
             support.same_align(x, z)
     if not (x.status & 0x80).any():
