@@ -162,6 +162,7 @@ struct BatchScratch {
     DeviceBuffer<uint32_t> hits, hitMeta, sparseSorted, sparseLinks, sparseAmbiguous, sparseInBand, denseFlags, densePositions;     // align4_sparse.hpp: the candidates' match lists, the tasks' ordered hits
     DeviceBuffer<uint64_t> hitBase;
     DeviceBuffer<uint8_t> sparseState;
+    DeviceBuffer<uint32_t> chainWaveRetry;       // align4_chainwave.hpp: tasks too large for the class they were tried in, one list per further class
     DeviceBuffer<uint64_t> prepareKeysA, prepareKeysB;      // a batch's first chunk lists made on the device (align4_prepare.hpp)
     DeviceBuffer<uint32_t> prepareIdsA, prepareIdsB;
     DeviceBuffer<unsigned long long> prepareInfo;
@@ -363,15 +364,16 @@ void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in
     hipLaunchKernelGGL(sparseChainWaveKernel<int(CAP)>, dim3(std::min<uint32_t>(CHAIN_WAVE_GRID[CLS], divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
         b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
-        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), opt, b.pairBest.data());
+        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data());
     HIP_CHECK(hipGetLastError());
 }
 void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
-    // (the first class's launch also marks the tasks that no class holds; the few large tasks after it)
+    // (in the order of the classes: a launch lists the tasks that turned out too large for it for the next one)
+    b.chainWaveRetry.reserve(uint64_t(CHAIN_WAVE_CLASSES - 1) * taskCount, stream);
     launchChainWaveClass<0>(stream, b, in, taskCount, sparse, control, opt);
-    launchChainWaveClass<2>(stream, b, in, taskCount, sparse, control, opt);
     launchChainWaveClass<1>(stream, b, in, taskCount, sparse, control, opt);
+    launchChainWaveClass<2>(stream, b, in, taskCount, sparse, control, opt);
 }
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,

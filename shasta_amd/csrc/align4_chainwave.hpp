@@ -34,11 +34,13 @@
 //
 // LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Three launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
 // tasks at 100 k reads), 2 048, 15 360 -- of wavefronts that go over the task list in blocks of 16 and run the tasks of their class
-// (the class from the matches LISTED for the candidate, known before any is counted); what fits none goes to the dense kernels.
+// (the class from the matches LISTED for the candidate less the usual background, known before any is counted; a task with more
+// inside its band than the class holds is listed for the next class's launch); what fits none goes to the dense kernels.
 // SHASTA_MI355X_CHAIN_WAVE=0: sparseSortKernel + sparseChainKernel, as before this file.
 #pragma once
 
 constexpr uint32_t CHAIN_WAVE_GRID[CHAIN_WAVE_CLASSES] = {256u * 16u, 256u * 8u, 256u};       // workgroups of one wavefront, as many as the LDS lets a CU hold
+constexpr uint32_t CHAIN_WAVE_SLACK = 512;         // matches listed for a candidate beyond those inside a task's band, usually fewer than this: the background of the whole matrix, other components
 constexpr uint32_t CHAIN_WAVE_BLOCK = 16;          // tasks a wavefront takes from the cursor at a time
 constexpr uint32_t CHAIN_OFF_MASK = 0x3fffu, CHAIN_OFF_EXCEPTION = 0x4000u, CHAIN_OFF_WAYS = 0x8000u;
 static_assert(CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES - 1] <= CHAIN_OFF_MASK, "`from` in 14 bits");
@@ -81,7 +83,7 @@ __device__ __forceinline__ int chainWaveClassOfTask(const PairDesc& pd, uint32_t
     if(streamCount > SPARSE_MAX_STREAM || streamCount == 0) { why = GIVE_UP_LONG_STREAM; return -1; }
     const uint32_t counterWords = 5u * ((streamCount + 7u) / 8u);        // in half words: counts, cursors, starts
 #pragma unroll
-    for(int c = 0; c < CHAIN_WAVE_CLASSES; c++) if(count <= CHAIN_WAVE_CAPACITY[c] && counterWords <= 3u * CHAIN_WAVE_CAPACITY[c]) return c;
+    for(int c = 0; c < CHAIN_WAVE_CLASSES; c++) if(count <= CHAIN_WAVE_CAPACITY[c] + CHAIN_WAVE_SLACK && counterWords <= 3u * CHAIN_WAVE_CAPACITY[c]) return c;
     why = GIVE_UP_SORTED_CAPACITY;
     return -1;
 }
@@ -91,7 +93,8 @@ __global__ void __launch_bounds__(64)
 sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount, int cls,
     DpControl* __restrict__ control, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta, const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
-    uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+    uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, uint32_t* __restrict__ retryList,
+    DeviceOptions opt, unsigned long long* __restrict__ pairBest)
 {
     extern __shared__ uint32_t ldsWords[];
     uint32_t* const H = ldsWords;                                            // p << 16 | s
@@ -102,25 +105,39 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
     // The tasks in blocks of CHAIN_WAVE_BLOCK, taken through a cursor (an atomic per block: a few thousand per launch -- an atomic per
     // TASK on one address, 275 000 per launch, cost the sort kernel 8 ms a step when it appended the tasks to class lists): a lane per
     // task looks at its state and hit count, and the wavefront runs those of its class one after the other.
+    uint64_t todoTasks = 0;
+    uint32_t blockBase = 0;
+    bool scanning = true;
+    const uint32_t retried = cls > 0 ? control->retryCount[cls] : 0u;       // (listed by the launch of the class below, which has ended)
+    uint32_t retrySlot = blockIdx.x;
     for(;;) {
-    uint32_t blockIndex = 0;
-    if(lane == 0) blockIndex = atomicAdd(&control->waveNext[cls], 1u);
-    blockIndex = __builtin_amdgcn_readfirstlane(blockIndex);
-    const uint32_t blockBase = blockIndex * CHAIN_WAVE_BLOCK;
-    if(blockBase >= taskCount) break;
-    const uint32_t candidateTask = blockBase + uint32_t(lane);
-    int myClass = -2;                                  // -2: not a task of this block; -1: none of the classes holds it (the dense kernels')
-    if(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount) {
-        const DpTask mine = tasks[candidateTask];
-        const PairDesc myPair = pairs[mine.pair];
-        int why = -1;
-        myClass = chainWaveClassOfTask(myPair, hitMeta[mine.pair], hitBase[mine.pair + 1] - hitBase[mine.pair], why);
-        if(myClass < 0 && cls == 0) { state[candidateTask] = SPARSE_DENSE; noteGiveUp(control, why, myPair, mine); }      // (said once: by the first class's launch)
-    }
-    uint64_t todoTasks = ballot64(myClass == cls);
-    while(todoTasks) {
-        const uint32_t t = blockBase + uint32_t(__ffsll((unsigned long long)todoTasks) - 1);
-        todoTasks &= todoTasks - 1;
+        uint32_t t;
+        if(todoTasks) {
+            t = blockBase + uint32_t(__ffsll((unsigned long long)todoTasks) - 1);
+            todoTasks &= todoTasks - 1;
+        } else if(scanning) {
+            uint32_t blockIndex = 0;
+            if(lane == 0) blockIndex = atomicAdd(&control->waveNext[cls], 1u);
+            blockIndex = __builtin_amdgcn_readfirstlane(blockIndex);
+            blockBase = blockIndex * CHAIN_WAVE_BLOCK;
+            if(blockBase >= taskCount) { scanning = false; continue; }
+            const uint32_t candidateTask = blockBase + uint32_t(lane);
+            int myClass = -2;                              // -2: not a task of this block; -1: none of the classes holds it (the dense kernels')
+            if(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount) {
+                const DpTask mine = tasks[candidateTask];
+                const PairDesc myPair = pairs[mine.pair];
+                int why = -1;
+                myClass = chainWaveClassOfTask(myPair, hitMeta[mine.pair], hitBase[mine.pair + 1] - hitBase[mine.pair], why);
+                if(myClass < 0 && cls == 0) { state[candidateTask] = SPARSE_DENSE; noteGiveUp(control, why, myPair, mine); }      // (said once: by the first class's launch)
+            }
+            todoTasks = ballot64(myClass == cls);
+            continue;
+        } else {
+            // The tasks whose hits inside the band turned out more than the class below holds.
+            if(retrySlot >= retried) break;
+            t = retryList[uint64_t(cls - 1) * taskCount + retrySlot];
+            retrySlot += gridDim.x;
+        }
         const DpTask task = tasks[t];
         const PairDesc pd = pairs[task.pair];
         const bool swapped = (hitMeta[task.pair] >> 31) != 0;
@@ -162,6 +179,11 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             for(uint32_t w = first; w < min(first + per, words); w++) sum += nibbleSum(counts[w]);
             const uint32_t inclusive = uint32_t(waveInclusiveSum(int32_t(sum)));
             const uint32_t total = uint32_t(laneValue(int32_t(inclusive), WAVE - 1));
+            if(total > uint32_t(CAP) && total <= sparseListCapacity(pd.nx, pd.ny) && cls + 1 < CHAIN_WAVE_CLASSES && total <= CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES - 1]) {
+                // (the class was chosen from the matches listed for the candidate less the usual background: this task has more inside its band)
+                if(lane == 0) retryList[uint64_t(cls) * taskCount + atomicAdd(&control->retryCount[cls + 1], 1u)] = t;
+                continue;
+            }
             if(total > sparseListCapacity(pd.nx, pd.ny) || total > uint32_t(CAP)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_SORTED_CAPACITY, pd, task); } continue; }
             uint32_t running = inclusive - sum;
             for(uint32_t w = first; w < min(first + per, words); w++) { wordStart[w] = uint16_t(running); running += nibbleSum(counts[w]); }
@@ -443,7 +465,6 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             results[t] = r;
             state[t] = SPARSE_COMPLETE;
         }
-    }
     }
     if(lane == 0 && walked) { atomicAdd(&control->hitsInBand, walked); atomicAdd(&control->hitsListed, listed); }
 }
