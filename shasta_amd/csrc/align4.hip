@@ -343,7 +343,9 @@ bool anchorBigEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHOR_BIG"
 // SHASTA_MI355X_CHAIN_WAVE=0: every sorted task to sparseChainKernel (a lane per task), as before align4_chainwave.hpp.
 bool chainWaveEnabled() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE"); return !e || std::atoi(e) != 0; }
 
-template<int CLS>
+// SHASTA_MI355X_CHAIN_WAVE_SORT=1: the wave kernel orders the hits itself (no sparseSortKernel); slower on the MI355X, kept for the A/B.
+bool chainWaveOwnSort() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SORT"); return e && std::atoi(e) != 0; }
+template<int CLS, bool OWN_SORT>
 void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
     constexpr uint32_t CAP = CHAIN_WAVE_CAPACITY[CLS];
@@ -352,16 +354,16 @@ void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in
     if(ldsBytes > 64u * 1024u) {
         // (more dynamic LDS than the default limit: the attribute once per device)
         static std::mutex mutex;
-        static std::vector<int> done;
+        static std::vector<int> done;           // (one per instantiation of this function template)
         int device = 0;
         HIP_CHECK(hipGetDevice(&device));
         std::lock_guard<std::mutex> lock(mutex);
         if(std::find(done.begin(), done.end(), device) == done.end()) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparseChainWaveKernel<int(CAP)>), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparseChainWaveKernel<int(CAP), OWN_SORT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
             done.push_back(device);
         }
     }
-    hipLaunchKernelGGL(sparseChainWaveKernel<int(CAP)>, dim3(std::min<uint32_t>(CHAIN_WAVE_GRID[CLS], divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
+    hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT>), dim3(std::min<uint32_t>(CHAIN_WAVE_GRID[CLS], divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
         b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
         (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data());
@@ -371,9 +373,15 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
 {
     // (in the order of the classes: a launch lists the tasks that turned out too large for it for the next one)
     b.chainWaveRetry.reserve(uint64_t(CHAIN_WAVE_CLASSES - 1) * taskCount, stream);
-    launchChainWaveClass<0>(stream, b, in, taskCount, sparse, control, opt);
-    launchChainWaveClass<1>(stream, b, in, taskCount, sparse, control, opt);
-    launchChainWaveClass<2>(stream, b, in, taskCount, sparse, control, opt);
+    if(chainWaveOwnSort()) {
+        launchChainWaveClass<0, true>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<1, true>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<2, true>(stream, b, in, taskCount, sparse, control, opt);
+    } else {
+        launchChainWaveClass<0, false>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<1, false>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<2, false>(stream, b, in, taskCount, sparse, control, opt);
+    }
 }
 
 DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput& in, uint32_t taskCount, bool reserveOrdinals, DpEvents* ev, KernelTimers* timers,
@@ -421,19 +429,23 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         b.scanTemp32.reserve(scanTempElements(uint64_t(taskCount) + 1), stream);
         const bool chainWave = chainWaveEnabled();
         KernelTimers::Span span;
-        if(chainWave) {
-            // K10w (align4_chainwave.hpp): a wavefront per task orders the band's hits in LDS and runs the chain recurrence on them there;
-            // one launch of wavefronts per capacity class.
-            if(timers) span = timers->begin("sparseChainWaveKernel", stream);
-            launchChainWave(stream, b, in, taskCount, *sparse, control, *metricsOptions);
-            if(timers) waveHandle = timers->end(span, 0, taskCount);
-        } else {
+        const bool ownSort = chainWave && chainWaveOwnSort();
+        if(!ownSort) {
         if(timers) span = timers->begin("sparseSortKernel", stream);
         hipLaunchKernelGGL(sparseSortKernel, dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
             b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control);
         HIP_CHECK(hipGetLastError());
         if(timers) sortHandle = timers->end(span, 0, taskCount);
+        }
+        if(chainWave) {
+            // K10w (align4_chainwave.hpp): a wavefront per task, the task's hits in LDS; one launch of wavefronts per capacity class.
+            if(timers) span = timers->begin("sparseChainWaveKernel", stream);
+            launchChainWave(stream, b, in, taskCount, *sparse, control, *metricsOptions);
+            if(timers) waveHandle = timers->end(span, 0, taskCount);
+        }
+        if(!ownSort) {
+        // (with the wave kernel on: the tasks with more hits than its largest class holds)
         if(timers) span = timers->begin("sparseChainKernel", stream);
         hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
             in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
@@ -512,10 +524,10 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         // The sparse kernels' rows: the matches listed for the tasks' candidates are read (4 bytes each) and those inside the bands
         // written in order; the chain kernel reads those and writes a list word and a link word beside each; the anchor kernel reads both
         // for the tasks it walks and writes their aligned pairs (8 bytes: about one per match).  Work = matches inside the bands.
-        if(!chainWaveEnabled()) timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
+        if(!(chainWaveEnabled() && chainWaveOwnSort())) timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
         // (with align4_chainwave.hpp on, nearly all tasks are the wave kernel's: it reads a hit once, 4 bytes, and writes a pair, 8)
         // (the wave kernel reads the listed matches twice, 4 bytes each, and writes a pair, 8 bytes, per match inside the bands)
-        if(chainWaveEnabled()) timers->amend(waveHandle, 8 * head.hitsListed + 8 * head.hitsInBand, head.hitsInBand);
+        if(chainWaveEnabled()) { timers->amend(waveHandle, (chainWaveOwnSort() ? 8 * head.hitsListed + 8 * head.hitsInBand : 12 * head.hitsInBand), head.hitsInBand); if(!chainWaveOwnSort()) timers->amend(chainHandle, 0, 0); }
         else timers->amend(chainHandle, 12 * head.hitsInBand, head.hitsInBand);
         if(anchored) timers->amend(anchorHandle, 16 * head.ambiguousHits, head.ambiguousHits);
         else if(head.ambiguousCount) timers->count(DP_GIVE_UP_NAMES[GIVE_UP_ANCHORS_OFF], head.ambiguousCount, 0, 0);

@@ -28,9 +28,10 @@
 // once (written).  A task with several optimal chains gets its list and link words written out as sparseChainKernel leaves them
 // (links of the exceptions recomputed from the final D: 64 candidates per step again) and goes to sparseAnchorKernel.
 //
-// The kernel also ORDERS the hits itself (sparseSortKernel's counting sort, into LDS): the candidate's match list is read from HBM,
-// the ordered hits never go there (the sort kernel wrote 4 bytes per hit and this one read them again: 15 ms per step alone, 80 ms
-// of launches sharing the device).
+// OWN_SORT (SHASTA_MI355X_CHAIN_WAVE_SORT=1; not the default): the kernel orders the hits itself (sparseSortKernel's counting sort, into
+// LDS), so that the ordered hits never go to HBM.  Measured on the MI355X it LOSES: 82 ms per step alone against 49 + 15 for the two
+// kernels, 166 ms per step against 143 (profiles/r05_call5*, r05_call3*): the sort's two passes over the candidate's list are chains of
+// dependent loads, and a wavefront that holds 10 KB of LDS while it waits for them keeps the next task's wavefront out.
 //
 // LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Three launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
 // tasks at 100 k reads), 2 048, 15 360 -- of wavefronts that go over the task list in blocks of 16 and run the tasks of their class
@@ -88,7 +89,7 @@ __device__ __forceinline__ int chainWaveClassOfTask(const PairDesc& pd, uint32_t
     return -1;
 }
 
-template<int CAP>
+template<int CAP, bool OWN_SORT>
 __global__ void __launch_bounds__(64)
 sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount, int cls,
     DpControl* __restrict__ control, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
@@ -123,6 +124,10 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             if(blockBase >= taskCount) { scanning = false; continue; }
             const uint32_t candidateTask = blockBase + uint32_t(lane);
             int myClass = -2;                              // -2: not a task of this block; -1: none of the classes holds it (the dense kernels')
+            if(!OWN_SORT) {
+                // (sparseSortKernel has ordered the hits: the class from their number; what it left to the dense kernels, or what no class holds, is not taken)
+                if(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount && state[candidateTask] == SPARSE_SORTED) myClass = chainWaveClassOf(inBand[candidateTask]);
+            } else
             if(uint32_t(lane) < CHAIN_WAVE_BLOCK && candidateTask < taskCount) {
                 const DpTask mine = tasks[candidateTask];
                 const PairDesc myPair = pairs[mine.pair];
@@ -147,7 +152,12 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
         // ---- the band's hits in the order of the ordinal in the tabled read (what sparseSortKernel does, into LDS instead of HBM):
         // a counting sort on 4-bit counters per marker; the counters lie where D and `from` will be ----
         int32_t n = 0;
-        {
+        if(!OWN_SORT) {
+            n = int32_t(inBand[t]);
+            waveLdsSync();                                                  // (the task before has left the arrays)
+            for(int32_t i = lane; i < n; i += WAVE) H[i] = list[i];
+            waveLdsSync();
+        } else {
             const uint32_t listedHits = hitMeta[task.pair] & 0x7fffffffu;
             const uint32_t* __restrict__ const raw = hits + hitBase[task.pair];
             const uint32_t streamCount = uint32_t(np);
