@@ -349,7 +349,7 @@ template<int CLS, bool OWN_SORT>
 void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
     constexpr uint32_t CAP = CHAIN_WAVE_CAPACITY[CLS];
-    constexpr size_t ldsBytes = size_t(CAP) * 10u;
+    constexpr size_t ldsBytes = size_t(CAP) * 10u + size_t(CAP) / 16u;        // (10 bytes per hit, 4 per window of 64)
     static_assert(ldsBytes <= 160u * 1024u, "a wavefront's hits in LDS");
     if(ldsBytes > 64u * 1024u) {
         // (more dynamic LDS than the default limit: the attribute once per device)
@@ -369,7 +369,10 @@ void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in
         (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data());
     HIP_CHECK(hipGetLastError());
 }
-void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
+// side + events: the launches of the two larger classes (13 % and 0.1 % of the tasks at 100 k reads, 8 and 1 wavefronts per CU) on the
+// side stream beside the first class's, which they would otherwise follow: 2.2 + 1.9 + 2.0 ms one after the other (profiles/r05_call6).
+void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt,
+    hipStream_t side = nullptr, DpEvents* ev = nullptr)
 {
     // (in the order of the classes: a launch lists the tasks that turned out too large for it for the next one)
     b.chainWaveRetry.reserve(uint64_t(CHAIN_WAVE_CLASSES - 1) * taskCount, stream);
@@ -377,6 +380,14 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
         launchChainWaveClass<0, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, true>(stream, b, in, taskCount, sparse, control, opt);
+    } else if(side && ev) {
+        // (classes from the hits the sort kernel counted: no class lists tasks for another, so the launches need no order)
+        HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(side, ev->fork, 0));
+        launchChainWaveClass<2, false>(side, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<1, false>(side, b, in, taskCount, sparse, control, opt);
+        HIP_CHECK(hipEventRecord(ev->join, side));
+        launchChainWaveClass<0, false>(stream, b, in, taskCount, sparse, control, opt);
+        HIP_CHECK(hipStreamWaitEvent(stream, ev->join, 0));
     } else {
         launchChainWaveClass<0, false>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, false>(stream, b, in, taskCount, sparse, control, opt);
@@ -441,7 +452,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         if(chainWave) {
             // K10w (align4_chainwave.hpp): a wavefront per task, the task's hits in LDS; one launch of wavefronts per capacity class.
             if(timers) span = timers->begin("sparseChainWaveKernel", stream);
-            launchChainWave(stream, b, in, taskCount, *sparse, control, *metricsOptions);
+            launchChainWave(stream, b, in, taskCount, *sparse, control, *metricsOptions, ws.wide, ev);
             if(timers) waveHandle = timers->end(span, 0, taskCount);
         }
         if(!ownSort) {

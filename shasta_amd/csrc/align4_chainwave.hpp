@@ -101,6 +101,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
     uint32_t* const H = ldsWords;                                            // p << 16 | s
     int32_t* const Dv = reinterpret_cast<int32_t*>(ldsWords + CAP);          // D of the finished hits
     uint16_t* const OFF = reinterpret_cast<uint16_t*>(ldsWords + 2 * CAP);   // how many hits back the predecessor is (0: the chain starts here) | flags
+    int32_t* const WM = reinterpret_cast<int32_t*>(ldsWords + 2 * CAP + CAP / 2);     // the largest D up to the end of every window of 64 hits
     const int lane = laneId();
     unsigned long long walked = 0, listed = 0;
     // The tasks in blocks of CHAIN_WAVE_BLOCK, taken through a cursor (an atomic per block: a few thousand per launch -- an atomic per
@@ -218,14 +219,15 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
         walked += uint32_t(n);
 
         // ---- forward: D, `from`, the count of optimal chains (capped at two) ----
-        int32_t k = 0;
+        // Windows of 64 hits at fixed places.  The lanes' steps 6 - c(i) and their prefix sums are made once per window; an exception
+        // in the window only shifts the D of the lanes behind it by what its own D turned out to differ from the assumed one, so the
+        // window goes on behind it with a new prefix maximum and the same sums (a window restarted behind every exception made 24
+        // passes for a task's 11 windows).
 #ifdef CHAIN_DEBUG
         int dbgPasses = 0, dbgExceptions = 0, dbgBlocks = 0;
 #endif
-        int32_t pmAll = CHAIN_NEG, pmBut1 = CHAIN_NEG;                      // the largest D of the hits [0, k), and of [0, k - 1)
-        int32_t best = CHAIN_NEG, bestAt = -1;
-        uint32_t bestWays = 0;
-        while(k < n) {
+        int32_t pmAll = CHAIN_NEG, pmBut1 = CHAIN_NEG;                      // the largest D of the hits before the first undecided one, and of those before the last of them
+        for(int32_t k = 0; k < n; k += WAVE) {
             const int32_t i = k + lane;
             const bool valid = i < n;
             const uint32_t h = H[valid ? i : n - 1];
@@ -233,51 +235,48 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             const int32_t p = int32_t(h >> 16), s = int32_t(h & 0xffffu);
             const int32_t a = p - int32_t(h1 >> 16) - 1, b = s - int32_t(h1 & 0xffffu) - 1;
             const bool simple = valid && i >= 1 && a >= 0 && b >= 0;
-            const int32_t step = simple ? 6 - max(a, b) : 0;
-            const int32_t dBefore = k > 0 ? Dv[k - 1] : 0;
-            const uint32_t waysBefore = k > 0 ? (uint32_t(OFF[k - 1]) >> 15) : 0u;       // (of the hit before the first lane's: what an accepted run inherits)
-            const int32_t d = dBefore + waveInclusiveSum(step);
-            const int32_t pmIncl = max(pmAll, waveInclusiveMax(d));
-            int32_t pm2 = __shfl_up(pmIncl, 2, WAVE);                         // the largest D up to the hit two before
-            pm2 = lane == 0 ? pmBut1 : (lane == 1 ? pmAll : pm2);
-            const int32_t value = d - 6;                                      // D(i - 1) - c(i)
-            const bool boundHolds = i < 2 || pm2 - (p - int32_t(h2 >> 16) - 1) < value;
-            const bool ok = simple && boundHolds && -min(p, s) < value;
-            const uint64_t okMask = ballot64(ok);
-            const int accepted = okMask == ~0ULL ? WAVE : (__ffsll((unsigned long long)~okMask) - 1);
+            const int32_t border = -min(p, s);
+            const int32_t reach2 = p - int32_t(h2 >> 16) - 1;                 // what separates the hit from the one two before, at least
+            int32_t d = (k > 0 ? Dv[k - 1] : 0) + waveInclusiveSum(simple ? 6 - max(a, b) : 0);
+            uint32_t waysBefore = k > 0 ? (uint32_t(OFF[k - 1]) >> 15) : 0u;      // (of the last decided hit: what a run of accepted hits inherits)
+            int first = 0;                                                    // the first undecided lane
+            for(;;) {
 #ifdef CHAIN_DEBUG
-            ++dbgPasses;
+                ++dbgPasses;
 #endif
-            if(accepted > 0) {
-                if(lane < accepted) { Dv[i] = d; OFF[i] = uint16_t(1u | (waysBefore ? CHAIN_OFF_WAYS : 0u)); }
-                const int32_t end = d - min(np - 1 - p, ns - 1 - s);
-                const int32_t runBest = waveMax(lane < accepted ? end : CHAIN_NEG);
-                const uint64_t at = ballot64(lane < accepted && end == runBest);
-                const uint32_t ways = min(2u, uint32_t(__popcll(at)) * (waysBefore ? 2u : 1u));
-                if(runBest > best) { best = runBest; bestAt = k + (__ffsll((unsigned long long)at) - 1); bestWays = ways; }
-                else if(runBest == best) bestWays = min(2u, bestWays + ways);
-                const int32_t newAll = laneValue(pmIncl, accepted - 1);
-                pmBut1 = accepted >= 2 ? laneValue(pmIncl, accepted - 2) : pmAll;
-                pmAll = newAll;
-                k += accepted;
+                const int32_t pmIncl = max(pmAll, waveInclusiveMax(lane >= first ? d : CHAIN_NEG));
+                int32_t pm2 = __shfl_up(pmIncl, 2, WAVE);                     // the largest D up to the hit two before
+                pm2 = lane == first ? pmBut1 : (lane == first + 1 ? pmAll : pm2);
+                const int32_t value = d - 6;                                  // D(i - 1) - c(i)
+                const bool ok = lane < first || (simple && (i < 2 || pm2 - reach2 < value) && border < value);
+                const uint64_t okMask = ballot64(ok);
+                const int accepted = okMask == ~0ULL ? WAVE : (__ffsll((unsigned long long)~okMask) - 1);      // lanes [first, accepted) hold their true D
+                if(accepted > first) {
+                    if(lane >= first && lane < accepted) { Dv[i] = d; OFF[i] = uint16_t(1u | (waysBefore ? CHAIN_OFF_WAYS : 0u)); }
+                    const int32_t newAll = laneValue(pmIncl, accepted - 1);
+                    pmBut1 = accepted - 2 >= first ? laneValue(pmIncl, accepted - 2) : pmAll;
+                    pmAll = newAll;
+                }
+                const int32_t e = k + accepted;
+                if(accepted >= WAVE || e >= n) break;
                 waveLdsSync();                                                // (the exception's scan reads what the accepted lanes wrote)
-            }
-            if(accepted < WAVE && k < n) {
-                // The exception: hit k against every hit before it, 64 per step from the nearest back.
-                const uint32_t he = H[k];
-                const int32_t pe = int32_t(he >> 16), se = int32_t(he & 0xffffu);
-                int32_t value = -min(pe, se);
-                uint32_t ways = 1;
-                int32_t from = 0;
+                // The exception: hit e against every hit before it, 64 per step from the nearest back.
 #ifdef CHAIN_DEBUG
                 ++dbgExceptions;
 #endif
-                for(int32_t top = k - 1; top >= 0; top -= WAVE) {
+                const uint32_t he = H[e];
+                const int32_t pe = int32_t(he >> 16), se = int32_t(he & 0xffffu);
+                int32_t bestValue = -min(pe, se);
+                uint32_t ways = 1;
+                int32_t from = 0;
+                for(int32_t top = e - 1; top >= 0; top -= WAVE) {
+                    // Nothing at `top` or before it can reach bestValue: every one of them is at least pe - p(top) - 1 away, and none has a
+                    // larger D than the largest up to the end of top's window (of the windows before this one: WM; of this one: so far).
+                    const int32_t bound = (top >> 6) < (k >> 6) ? WM[top >> 6] : pmAll;
+                    if(bound - (pe - int32_t(H[top] >> 16) - 1) < bestValue) break;
 #ifdef CHAIN_DEBUG
                     ++dbgBlocks;
 #endif
-                    // (nothing at `top` or before it can reach `value`: every one of them is at least pe - p(top) - 1 away)
-                    if(pmAll - (pe - int32_t(H[top] >> 16) - 1) < value) break;
                     const int32_t q = top - lane;
                     const uint32_t hq = H[q >= 0 ? q : 0];
                     const int32_t pq = int32_t(hq >> 16), sq = int32_t(hq & 0xffffu);
@@ -285,24 +284,41 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                     const int32_t candidate = good ? Dv[q] - max(pe - pq - 1, se - sq - 1) : CHAIN_NEG;
                     const bool two = good && (uint32_t(OFF[q]) & CHAIN_OFF_WAYS) != 0;
                     const int32_t blockBest = waveMax(candidate);
-                    if(blockBest > value) { value = blockBest; ways = 0; from = -1; }
-                    if(blockBest == value) {
-                        const uint64_t at = ballot64(candidate == value), atTwo = ballot64(candidate == value && two);
+                    if(blockBest > bestValue) { bestValue = blockBest; ways = 0; from = -1; }
+                    if(blockBest == bestValue) {
+                        const uint64_t at = ballot64(candidate == bestValue), atTwo = ballot64(candidate == bestValue && two);
                         ways = min(2u, ways + uint32_t(__popcll(at)) + uint32_t(__popcll(atTwo)));
-                        if(from < 0) from = k - top + (__ffsll((unsigned long long)at) - 1);       // the nearest hit that attains it
+                        if(from < 0) from = e - top + (__ffsll((unsigned long long)at) - 1);       // the nearest hit that attains it
                     }
                 }
-                const int32_t dk = 6 + value;
-                if(lane == 0) { Dv[k] = dk; OFF[k] = uint16_t(uint32_t(from) | CHAIN_OFF_EXCEPTION | (ways >= 2u ? CHAIN_OFF_WAYS : 0u)); }
-                const int32_t end = dk - min(np - 1 - pe, ns - 1 - se);
-                if(end > best) { best = end; bestAt = k; bestWays = ways; }
-                else if(end == best) bestWays = min(2u, bestWays + ways);
-                pmBut1 = pmAll; pmAll = max(pmAll, dk);
-                ++k;
+                const int32_t de = 6 + bestValue;
+                if(lane == 0) { Dv[e] = de; OFF[e] = uint16_t(uint32_t(from) | CHAIN_OFF_EXCEPTION | (ways >= 2u ? CHAIN_OFF_WAYS : 0u)); }
+                pmBut1 = pmAll; pmAll = max(pmAll, de);
+                waysBefore = ways >= 2u ? 1u : 0u;
+                // The lanes behind it: their sums were taken from the D assumed for it.
+                d += de - laneValue(d, accepted);
+                first = accepted + 1;
+                if(first >= WAVE || k + first >= n) break;
             }
+            if(lane == 0) WM[k >> 6] = pmAll;                                 // the largest D up to the end of this window
             waveLdsSync();
         }
-
+        // The best end: D - what is left to the border, its first hit, the count of optimal chains that end there (capped at two).
+        int32_t best = CHAIN_NEG, bestAt = -1;
+        uint32_t bestWays = 0;
+        for(int32_t k = 0; k < n; k += WAVE) {
+            const int32_t i = k + lane;
+            const bool valid = i < n;
+            const uint32_t h = H[valid ? i : n - 1];
+            const int32_t end = valid ? Dv[i] - min(np - 1 - int32_t(h >> 16), ns - 1 - int32_t(h & 0xffffu)) : CHAIN_NEG;
+            const int32_t windowBest = waveMax(end);
+            if(windowBest >= best) {
+                const uint64_t at = ballot64(end == windowBest), atTwo = ballot64(end == windowBest && (uint32_t(OFF[valid ? i : 0]) & CHAIN_OFF_WAYS) != 0);
+                const uint32_t ways = min(2u, uint32_t(__popcll(at)) + uint32_t(__popcll(atTwo)));
+                if(windowBest > best) { best = windowBest; bestAt = k + (__ffsll((unsigned long long)at) - 1); bestWays = ways; }
+                else bestWays = min(2u, bestWays + ways);
+            }
+        }
 #ifdef CHAIN_DEBUG
         if(lane == 0) std::fprintf(stderr, "chainwave: task %u n %d passes %d exceptions %d blocks %d\n", t, n, dbgPasses, dbgExceptions, dbgBlocks);
 #endif
