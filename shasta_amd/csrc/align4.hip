@@ -343,6 +343,8 @@ bool anchorBigEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHOR_BIG"
 // SHASTA_MI355X_CHAIN_WAVE=0: every sorted task to sparseChainKernel (a lane per task), as before align4_chainwave.hpp.
 bool chainWaveEnabled() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE"); return !e || std::atoi(e) != 0; }
 
+// SHASTA_MI355X_CHAIN_WAVE_SIDE=1: the two larger classes' launches on the worker's side stream, beside the first class's.
+bool chainWaveSideStream() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SIDE"); return e && std::atoi(e) != 0; }
 // SHASTA_MI355X_CHAIN_WAVE_SORT=1: the wave kernel orders the hits itself (no sparseSortKernel); slower on the MI355X, kept for the A/B.
 bool chainWaveOwnSort() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SORT"); return e && std::atoi(e) != 0; }
 template<int CLS, bool OWN_SORT>
@@ -380,7 +382,7 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
         launchChainWaveClass<0, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, true>(stream, b, in, taskCount, sparse, control, opt);
-    } else if(side && ev) {
+    } else if(side && ev && chainWaveSideStream()) {
         // (classes from the hits the sort kernel counted: no class lists tasks for another, so the launches need no order)
         HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(side, ev->fork, 0));
         launchChainWaveClass<2, false>(side, b, in, taskCount, sparse, control, opt);
@@ -445,7 +447,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         if(timers) span = timers->begin("sparseSortKernel", stream);
         hipLaunchKernelGGL(sparseSortKernel, dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
-            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control);
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave);
         HIP_CHECK(hipGetLastError());
         if(timers) sortHandle = timers->end(span, 0, taskCount);
         }
@@ -455,8 +457,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
             launchChainWave(stream, b, in, taskCount, *sparse, control, *metricsOptions, ws.wide, ev);
             if(timers) waveHandle = timers->end(span, 0, taskCount);
         }
-        if(!ownSort) {
-        // (with the wave kernel on: the tasks with more hits than its largest class holds)
+        if(!chainWave) {
         if(timers) span = timers->begin("sparseChainKernel", stream);
         hipLaunchKernelGGL(sparseChainKernel, dim3(divUp(taskCount, 64)), dim3(64), 0, stream,
             in.pairs, in.tasks, sortedIds, taskCount, b.sparseSorted.data(), (const uint32_t*)b.sparseInBand.data(), b.sparseState.data(), sparse->hitMeta,
@@ -538,7 +539,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         if(!(chainWaveEnabled() && chainWaveOwnSort())) timers->amend(sortHandle, 4 * (head.hitsListed + head.hitsInBand), head.hitsInBand);
         // (with align4_chainwave.hpp on, nearly all tasks are the wave kernel's: it reads a hit once, 4 bytes, and writes a pair, 8)
         // (the wave kernel reads the listed matches twice, 4 bytes each, and writes a pair, 8 bytes, per match inside the bands)
-        if(chainWaveEnabled()) { timers->amend(waveHandle, (chainWaveOwnSort() ? 8 * head.hitsListed + 8 * head.hitsInBand : 12 * head.hitsInBand), head.hitsInBand); if(!chainWaveOwnSort()) timers->amend(chainHandle, 0, 0); }
+        if(chainWaveEnabled()) { timers->amend(waveHandle, (chainWaveOwnSort() ? 8 * head.hitsListed + 8 * head.hitsInBand : 12 * head.hitsInBand), head.hitsInBand); }
         else timers->amend(chainHandle, 12 * head.hitsInBand, head.hitsInBand);
         if(anchored) timers->amend(anchorHandle, 16 * head.ambiguousHits, head.ambiguousHits);
         else if(head.ambiguousCount) timers->count(DP_GIVE_UP_NAMES[GIVE_UP_ANCHORS_OFF], head.ambiguousCount, 0, 0);

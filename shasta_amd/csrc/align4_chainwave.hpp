@@ -155,6 +155,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
         int32_t n = 0;
         if(!OWN_SORT) {
             n = int32_t(inBand[t]);
+            listed += hitMeta[task.pair] & 0x7fffffffu;                     // (what sparseSortKernel read for the task: for the kernel table)
             waveLdsSync();                                                  // (the task before has left the arrays)
             for(int32_t i = lane; i < n; i += WAVE) H[i] = list[i];
             waveLdsSync();

@@ -85,7 +85,7 @@ __device__ __forceinline__ void noteGiveUp(DpControl* control, int why, const Pa
 __global__ void __launch_bounds__(256)
 sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control, bool noLaneKernel)
 {
     __shared__ uint32_t counts[4][SPARSE_COUNTER_WORDS], cursors[4][SPARSE_COUNTER_WORDS];
     __shared__ uint16_t wordStart[4][SPARSE_COUNTER_WORDS];
@@ -117,18 +117,33 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
     for(uint32_t w = uint32_t(lane); w < words; w += WAVE) { myCounts[w] = 0; myCursors[w] = 0; }
     waveLdsSync();
     const uint32_t* __restrict__ const list = hits + begin;
+    // A list of up to 64 x SORT_HELD hits (nearly all: 850 listed per candidate at 100 k reads) is read ONCE, every lane's share into
+    // registers with all the loads in flight together; both passes below then run from the registers.  (Until round 5 each pass read
+    // the list 64 hits per step, a step's load issued when the one before had been used: 2 x 13 trips to memory per task, one after
+    // the other -- the kernel waited, it did not compute.)  Longer lists: the two passes over memory, as before.
+    constexpr int SORT_HELD = 16;
+    uint32_t held[SORT_HELD];
+    const bool holdsAll = count <= uint32_t(WAVE * SORT_HELD);
+    if(holdsAll) {
+#pragma unroll
+        for(int a = 0; a < SORT_HELD; a++) { const uint32_t i = uint32_t(a * WAVE + lane); held[a] = list[i < count ? i : 0u]; }
+    }
     bool crowded = false;
-    for(uint32_t i0 = 0; i0 < count; i0 += WAVE) {
-        const uint32_t i = i0 + uint32_t(lane);
-        const uint32_t e = list[i < count ? i : 0u];
+    auto countHit = [&](uint32_t e, bool exists) {
         const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
-        const bool in = i < count && x - y >= task.bandMin && x - y <= task.bandMax;
+        const bool in = exists && x - y >= task.bandMin && x - y <= task.bandMax;
         const uint32_t p = uint32_t(swapped ? y : x);
         if(in && p < streamCount) {
             const uint32_t shift = 4u * (p & 7u);
             const uint32_t old = atomicAdd(&myCounts[p >> 3], 1u << shift);
             crowded |= ((old >> shift) & 15u) == 15u;
         }
+    };
+    if(holdsAll) {
+#pragma unroll
+        for(int a = 0; a < SORT_HELD; a++) if(uint32_t(a * WAVE) < count) countHit(held[a], uint32_t(a * WAVE + lane) < count);
+    } else {
+        for(uint32_t i0 = 0; i0 < count; i0 += WAVE) { const uint32_t i = i0 + uint32_t(lane); countHit(list[i < count ? i : 0u], i < count); }
     }
     waveLdsSync();
     if(__any(crowded)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_CROWDED_MARKER, pd, task); } return; }
@@ -140,16 +155,18 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
 #pragma unroll
     for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
     const uint32_t total = uint32_t(__shfl(int(inclusive), WAVE - 1, WAVE));
-    if(total > sparseListCapacity(pd.nx, pd.ny)) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_SORTED_CAPACITY, pd, task); } return; }
+    if(total > sparseListCapacity(pd.nx, pd.ny) || (noLaneKernel && chainWaveClassOf(total) < 0)) {
+        // (noLaneKernel: the wave kernel is on and sparseChainKernel is not launched -- what the wave kernel's largest class does not hold is the dense kernels')
+        if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_SORTED_CAPACITY, pd, task); }
+        return;
+    }
     uint32_t running = inclusive - sum;
     for(uint32_t w = first; w < min(first + per, words); w++) { myStart[w] = uint16_t(running); running += nibbleSum(myCounts[w]); }
     waveLdsSync();
     uint32_t* __restrict__ const out = sorted + sparseListBase(ordOffsets, t);
-    for(uint32_t i0 = 0; i0 < count; i0 += WAVE) {
-        const uint32_t i = i0 + uint32_t(lane);
-        const uint32_t e = list[i < count ? i : 0u];
+    auto placeHit = [&](uint32_t e, bool exists) {
         const int32_t x = int32_t(e >> 16), y = int32_t(e & 0xffffu);
-        const bool in = i < count && x - y >= task.bandMin && x - y <= task.bandMax;
+        const bool in = exists && x - y >= task.bandMin && x - y <= task.bandMax;
         const uint32_t p = uint32_t(swapped ? y : x), s = uint32_t(swapped ? x : y);
         if(in && p < streamCount) {
             const uint32_t w = p >> 3, shift = 4u * (p & 7u);
@@ -157,6 +174,12 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
             const uint32_t local = (atomicAdd(&myCursors[w], 1u << shift) >> shift) & 15u;
             out[uint32_t(myStart[w]) + below + local] = (p << 16) | s;
         }
+    };
+    if(holdsAll) {
+#pragma unroll
+        for(int a = 0; a < SORT_HELD; a++) if(uint32_t(a * WAVE) < count) placeHit(held[a], uint32_t(a * WAVE + lane) < count);
+    } else {
+        for(uint32_t i0 = 0; i0 < count; i0 += WAVE) { const uint32_t i = i0 + uint32_t(lane); placeHit(list[i < count ? i : 0u], i < count); }
     }
     if(lane == 0) { inBand[t] = total; state[t] = SPARSE_SORTED; }
 }
