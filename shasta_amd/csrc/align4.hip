@@ -338,6 +338,11 @@ bool sparseDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_SPARSE_DP");
 // SHASTA_MI355X_ANCHORED_DP=0: the tasks with several optimal chains go to the dense kernels whole (as before align4_anchor.hpp).
 bool anchoredDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHORED_DP"); return !e || std::atoi(e) != 0; }
 
+__global__ void hitListNoneKernel(const uint32_t* __restrict__ list, uint32_t count, uint32_t* __restrict__ hitMeta)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < count) hitMeta[list[k]] = HIT_LIST_NONE;
+}
 // SHASTA_MI355X_ANCHOR_BIG=0: no second launch of the anchor kernel (tasks with a rectangle beyond 4 096 cells go to the dense kernels, as before it).
 bool anchorBigEnabled() { const char* e = std::getenv("SHASTA_MI355X_ANCHOR_BIG"); return !e || std::atoi(e) != 0; }
 // SHASTA_MI355X_CHAIN_WAVE=0: every sorted task to sparseChainKernel (a lane per task), as before align4_chainwave.hpp.
@@ -1529,6 +1534,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     HIP_CHECK(hipMemcpyAsync(b.pairList.data(), bigList.data() + begin, count * 4ULL, hipMemcpyHostToDevice, stream));
                     HIP_CHECK(hipMemcpyAsync(b.bigOffsets.data(), offsets.data(), count * 8ULL, hipMemcpyHostToDevice, stream));
                     HIP_CHECK(hipMemcpyAsync(b.bigLog2.data(), bigLog2.data() + begin, count, hipMemcpyHostToDevice, stream));
+                    // (a candidate that climbed here from a chunk kernel keeps no match list: what the attempt that overflowed wrote is not
+                    // the sparse path's to read -- its header says 0xffffffff for "cells computed by the HBM kernel")
+                    if(listHits) hipLaunchKernelGGL(hitListNoneKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, (const uint32_t*)b.pairList.data(), count, b.hitMeta.data());
                     uint64_t bigBytes = 0;
                     for(size_t q = begin; q < end; q++) bigBytes += 4ULL * (uint64_t(hostPairs[bigList[q]].nx) + hostPairs[bigList[q]].ny);
                     SHASTA_TIMED(ctx, "align4CellsKernel<true, false>", stream, bigBytes, count,

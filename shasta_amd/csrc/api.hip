@@ -7,6 +7,7 @@
 #include <vector>
 #include <string>
 
+#include <mutex>
 using namespace shasta_mi355x;
 
 struct shasta_mi355x_ctx { Context impl; explicit shasta_mi355x_ctx(int d) : impl(d) {} };
@@ -17,9 +18,19 @@ static thread_local std::string lastError;
 // An aligner call keeps six workers' streams and their side streams busy; the HIP runtime deals a process's streams to
 // GPU_MAX_HW_QUEUES hardware queues -- four unless the environment says otherwise -- and streams that share a queue run one after
 // the other (round 3: 185 ms per aligner call with four queues against 158 with eight when other libraries had created streams
-// first).  A caller who knows nothing of this should not lose 15 %: when the variable is unset, loading this library sets it to
-// eight -- the runtime reads it at its first HIP call, which comes after the loader has run this.  An explicit setting is left alone.
-__attribute__((constructor)) static void defaultHardwareQueues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// first).  The library does NOT touch the environment (round 4's constructor called setenv at load: a write to the host process's
+// environment that races with getenv in a threaded host such as Shasta, and does nothing when the runtime is already up): the
+// caller sets GPU_MAX_HW_QUEUES=8 before its first HIP call (shasta_amd/lib.py and bench.py do), and a context
+// created while the variable is unset says so once on stderr.
+static void noteHardwareQueuesOnce()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if(!std::getenv("GPU_MAX_HW_QUEUES") && !std::getenv("SHASTA_MI355X_QUIET"))
+            std::fprintf(stderr, "shasta_mi355x: GPU_MAX_HW_QUEUES is not set; set it to 8 before the first HIP call of the process "
+                "(the aligner's streams share four hardware queues otherwise: about 15 %% slower; INTEGRATION.md)\n");
+    });
+}
 
 #define API_BEGIN try {
 #define API_END(rc) } catch(const std::exception& e) { lastError = e.what(); return rc; } \
@@ -45,6 +56,7 @@ int shasta_mi355x_device_count(void)
 shasta_mi355x_ctx* shasta_mi355x_create(int device)
 {
     API_BEGIN
+    noteHardwareQueuesOnce();
     return new shasta_mi355x_ctx(device);
     API_END(nullptr)
 }

@@ -48,6 +48,11 @@ class Library:
                 "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C shasta_amd/csrc). There is no CPU fallback." % path)
         self.path = path
+        # The aligner keeps six workers' streams busy; the HIP runtime deals streams to GPU_MAX_HW_QUEUES hardware queues (default 4)
+        # and reads the variable at its first call: set here, before the library (and with it the runtime) is loaded, unless the
+        # caller's environment already says something.  (A process that initialised HIP earlier -- torch imported first -- has to
+        # set it itself: INTEGRATION.md.)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         self.lib = C.CDLL(path)
         for name in EXPORTS:
             getattr(self.lib, name)          # AttributeError if the ABI is incomplete
