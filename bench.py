@@ -55,15 +55,23 @@ PMC_FILE = _latest_pmc_file()
 HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "readStatistics", "pairWriteKernel", "evaluatePairs", "emitCandidates", "compress", "markerSweep", "packMarkers")
 
 
+# The two read-set shapes of the bench (both at marker level, 45x coverage): BASELINE configs[2] -- mean 1 500 markers (~20 kb) per read --
+# and the shape of configs[4]'s conf/Nanopore-UL-May2022.conf -- minReadLength 50 000 bases: no read below 3 750 markers, mean 7 500
+# (~100 kb), a tail beyond 30 000.
+WORKLOAD_SHAPES = {"configs2": dict(mean_markers=1500.0, sigma=0.5, min_markers=790), "ul": dict(mean_markers=7500.0, sigma=0.5, min_markers=3750)}
+WORKLOAD_SHAPE = ["configs2"]          # (set by main() from --workload)
+
+
 def make_workload(n_reads, seed, shards=0):
     """shards >= 1: the read set of an N-rank run -- n_reads / shards reads per rank from one genome, each rank's from its own
     stream, as the ranks generate them -- in one piece (the in-process group's line beside an RCCL run is about the same reads)."""
     from shasta_amd import synthetic
     # 45x coverage: n_reads * 1500 genome markers per read / genome markers.
-    genome_markers = max(20000, int(round(n_reads * 1500 / 45.0)))
+    shape = WORKLOAD_SHAPES[WORKLOAD_SHAPE[0]]
+    genome_markers = max(20000, int(round(n_reads * shape["mean_markers"] / 45.0)))
     if shards >= 1:
-        parts = [synthetic.marker_reads(n_reads // shards, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
-                                        keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, shard=r, shard_count=shards)
+        parts = [synthetic.marker_reads(n_reads // shards, genome_markers,
+                                        keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, shard=r, shard_count=shards, **shape)
                  for r in range(shards)]
         sizes = np.concatenate([np.diff(t.astype(np.int64)) for t, _ in parts])
         toc = np.zeros(len(sizes) + 1, dtype=np.uint64)
@@ -73,11 +81,10 @@ def make_workload(n_reads, seed, shards=0):
     # the generated read set (a minute of host time per run) in a scratch directory; same arrays either way.
     cache = os.environ.get("SHASTA_BENCH_WORKLOAD_CACHE")
     if cache:
-        files = [os.path.join(cache, "workload_%d_%d_%s.npy" % (n_reads, seed, x)) for x in ("toc", "kmer")]
+        files = [os.path.join(cache, "workload_%s_%d_%d_%s.npy" % (WORKLOAD_SHAPE[0], n_reads, seed, x)) for x in ("toc", "kmer")]
         if all(os.path.exists(f) for f in files):
             return np.load(files[0]), np.load(files[1])
-    toc, kmer = synthetic.marker_reads(n_reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
-                                       keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed)
+    toc, kmer = synthetic.marker_reads(n_reads, genome_markers, keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, **shape)
     if cache:
         os.makedirs(cache, exist_ok=True)
         np.save(files[0], toc); np.save(files[1], kmer)
@@ -87,6 +94,8 @@ def make_workload(n_reads, seed, shards=0):
 def lowhash_params():
     from shasta_amd import abi
     # m=4, f=0.01, 10 iterations, minBucketSize/maxBucketSize/minFrequency 5/30/5.
+    if WORKLOAD_SHAPE[0] == "ul":          # conf/Nanopore-UL-May2022.conf: MinHash 10/50/5
+        return abi.default_lowhash0_params(minBucketSize=10, maxBucketSize=50, minFrequency=5)
     return abi.default_lowhash0_params(minBucketSize=5, maxBucketSize=30, minFrequency=5)
 
 
@@ -99,7 +108,22 @@ def align3_options():
 
 def align_options():
     from shasta_amd import abi
+    if WORKLOAD_SHAPE[0] == "ul":          # conf/Nanopore-UL-May2022.conf, [Align]: maxSkip / maxDrift / maxTrim 100, minAlignedMarkerCount 10, minAlignedFraction 0.1
+        return abi.default_align4_options(maxSkip=100, maxDrift=100, maxTrim=100, minAlignedMarkerCount=10, minAlignedFraction=0.1)
     return abi.default_align4_options()
+
+
+def candidate_paths(table, steps, candidates):
+    """Which kernels a step's candidates took (the kernel table's work counts: candidates per cells-kernel class -- one that overflows
+    its class's tables is counted again in the class it climbs to -- and what the banded DP's tasks ended in)."""
+    per = {}
+    for name, r in table.items():
+        if name.startswith("align4CellsChunkKernel") or name.startswith("align4CellsKernel"):
+            per[name] = r["work"] / steps
+    out = {"cells_kernel_candidates_per_step": per,
+           "share_in_the_LDS_chunk_kernels": (sum(v for k, v in per.items() if k.startswith("align4CellsChunkKernel")) / candidates) if candidates else None,
+           "share_in_the_HBM_scratch_kernel": (sum(v for k, v in per.items() if k.startswith("align4CellsKernel")) / candidates) if candidates else None}
+    return out
 
 
 def load_pmc(reads):
@@ -393,7 +417,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default 100000; 20000 with --workload ul)")
+    ap.add_argument("--workload", choices=sorted(WORKLOAD_SHAPES), default="configs2",
+                    help="configs2 = BASELINE configs[2] (the headline); ul = the read shape and parameters of configs[4]'s conf/Nanopore-UL-May2022.conf on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on (0 = all of them: a minute or two)")
     ap.add_argument("--tie-census", type=int, default=20000,
@@ -409,6 +435,9 @@ def main():
     ap.add_argument("--align-method", type=int, default=4, choices=[3, 4],
                     help="4 = Align4 (BASELINE's metric, the default); 3 = the reference's default method, for comparison")
     args = ap.parse_args()
+    WORKLOAD_SHAPE[0] = args.workload
+    if args.reads is None:
+        args.reads = 20000 if args.workload == "ul" else 100000
 
     import torch
     import shasta_amd
@@ -505,10 +534,10 @@ def main():
         # evenly for Align4.  Setup (generation, all-gather) is outside the timed region.
         from shasta_amd import distributed, synthetic
         device = torch.device("cuda", local_rank) if not DRY_RUN_LIBRARY else torch.device("cpu")
-        genome_markers = max(20000, int(round(world * args.reads * 1500 / 45.0)))
-        toc_s, kmer_s = synthetic.marker_reads(args.reads, genome_markers, mean_markers=1500.0, sigma=0.5, min_markers=790,
-                                               keep_probability=0.8, spurious_probability=0.25, k=10, seed=12345,
-                                               shard=rank, shard_count=world)
+        shape = WORKLOAD_SHAPES[WORKLOAD_SHAPE[0]]
+        genome_markers = max(20000, int(round(world * args.reads * shape["mean_markers"] / 45.0)))
+        toc_s, kmer_s = synthetic.marker_reads(args.reads, genome_markers, keep_probability=0.8, spurious_probability=0.25, k=10, seed=12345,
+                                               shard=rank, shard_count=world, **shape)
         sizes = [None] * world
         dist.all_gather_object(sizes, np.diff(toc_s.astype(np.int64)).astype(np.uint32).tobytes())
         per_shard = [np.frombuffer(b, dtype=np.uint32).astype(np.uint64) for b in sizes]
@@ -669,7 +698,7 @@ def main():
         steps = max(1, args.steps)
         ms_per_step = elapsed / steps * 1e3
         value = pairs_total / (elapsed / steps)
-        pmc = load_pmc(args.reads) if not sharded else {}
+        pmc = load_pmc(args.reads) if (not sharded and args.workload == "configs2") else {}
         kernels = kernel_rows(table, steps, pmc)
         kernel_seconds = sum(r["seconds_per_step"] for r in kernels.values())
         for r in kernels.values():
@@ -704,11 +733,15 @@ def main():
             "dtype": "u32/i32 (integer hash + integer DP)",
             "data": "synthetic" if not DRY_RUN_LIBRARY else "synthetic; DRY RUN ON THE EMULATED BUILD - NOT A MEASUREMENT",
             "config": {
-                "workload": "BASELINE configs[2]: synthetic ONT-like reads, marker level, %d reads/GPU, "
-                            "mean 1500 markers (~20 kb) per oriented read, 45x coverage; LowHash0 m=4 f=0.01 "
-                            "10 iterations 5/30/5; %s" % (args.reads, "Align4 200/10/10/100, maxBand 1000, 6/-1/-1"
-                                                          if args.align_method == 4 else
-                                                          "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"),
+                "workload": ("BASELINE configs[2]: synthetic ONT-like reads, marker level, %d reads/GPU, "
+                             "mean 1500 markers (~20 kb) per oriented read, 45x coverage; LowHash0 m=4 f=0.01 "
+                             "10 iterations 5/30/5; %s" % (args.reads, "Align4 200/10/10/100, maxBand 1000, 6/-1/-1"
+                                                           if args.align_method == 4 else
+                                                           "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"))
+                            if args.workload == "configs2" else
+                            ("the read shape and parameters of BASELINE configs[4] (conf/Nanopore-UL-May2022.conf) on one GPU: synthetic reads, marker level, "
+                             "%d reads/GPU, none below 3750 markers (50 kb), mean 7500 (~100 kb), 45x coverage; LowHash0 m=4 f=0.01 10 iterations 10/50/5; "
+                             "Align4 100/100/100, minAlignedMarkerCount 10, minAlignedFraction 0.1, maxBand 1000" % args.reads),
                 "step": ("findAlignmentCandidatesLowHash0 (src/AssemblerLowHash.cpp:10-55) + computeAlignments (src/AssemblerAlign.cpp:208-304) end to end: "
                          "candidates -> AlignmentData + CompressedAlignments on the host%s"
                          % (" + the alignment table (computeAlignmentTable, :296)" if not sharded else
@@ -761,6 +794,8 @@ def main():
                                 "reference_cells_per_second": al.dp_cell_count / (elapsed / steps) if elapsed > 0 else None}
         if give_up_rows(table, steps):
             out["give_ups"] = give_up_rows(table, steps)
+        if al is not None and not sharded:
+            out["candidate_paths"] = candidate_paths(table, steps, pairs_total)
         if hash_name:
             h = kernels[hash_name]
             out["hbm_natured_kernel"] = {"kernel": hash_name, "achieved_GBps": h["achieved_GBps"], "frac_of_hbm_peak": h["frac_of_hbm_peak"],
@@ -881,6 +916,9 @@ def headline(out, details_path):
                                                   "sorted_markers_seconds", "align_seconds_per_pair", "alignment_table_seconds", "aligner_seconds_measured") if k in b}
         line["cpu_baseline"]["kind"] = str(b.get("kind", "")).split(" ")[0]
         line["cpu_baseline"]["sample"] = str(b.get("sample_short") or b.get("sample", ""))[:160]
+    p = out.get("candidate_paths")
+    if p and "BASELINE configs[4]" in str(c.get("workload", "")):
+        line["candidate_paths"] = {k: p.get(k) for k in ("share_in_the_LDS_chunk_kernels", "share_in_the_HBM_scratch_kernel")}
     for k in ("parity_at_bench_size", "speedup_vs_cpu_baseline", "stage_seconds_per_step", "aligner_status", "path", "default_path_parity_failed"):
         if out.get(k) is not None:
             line[k] = out[k]
