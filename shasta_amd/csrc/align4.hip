@@ -1075,8 +1075,26 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     // Where the batches begin: every BATCH candidates.  (Graded batches -- short first ones, because all workers prepare their
     // first batch together while the device waits, and shrinking last ones -- were measured against these and dropped: 171-174
     // against 167-171 ms per call, profiles/r02_call36_batch_schedule.log.)
+    // ... or sooner, when the candidates' reads are long: a batch's scratch (match lists, DP tasks' ranges, traces) grows with the
+    // markers of its candidates, not with their number, and 2^18 candidates of the ultra-long shape (15 000 markers a pair against
+    // 3 000) asked the six workers for more than the 288 GB (round 5, bench.py --workload ul).  So a batch also ends at 3 200 markers
+    // per candidate of a full batch: the 100 k-read workload's batches stay what they were.
     std::vector<uint64_t> batchStart(1, 0);
-    while(batchStart.back() < candidateCount) batchStart.push_back(std::min<uint64_t>(candidateCount, batchStart.back() + BATCH));
+    {
+        const uint64_t markerBudget = BATCH * 3200ULL;
+        uint64_t count = 0, markers = 0;
+        for(uint64_t k = 0; k < candidateCount; k++) {
+            const shasta_oriented_read_pair& c = candidates[k];
+            uint64_t pairMarkers = 0;
+            if(c.readIds[0] < ctx.readCount && c.readIds[1] < ctx.readCount) {       // (an invalid candidate is reported by the batch that meets it)
+                const uint64_t o0 = 2ULL * c.readIds[0], o1 = 2ULL * c.readIds[1];
+                pairMarkers = (ctx.hostToc[o0 + 1] - ctx.hostToc[o0]) + (ctx.hostToc[o1 + 1] - ctx.hostToc[o1]);
+            }
+            if(count && (count == BATCH || markers + pairMarkers > markerBudget)) { batchStart.push_back(k); count = 0; markers = 0; }
+            ++count; markers += pairMarkers;
+        }
+        if(candidateCount) batchStart.push_back(candidateCount);
+    }
     const uint64_t batchCount = batchStart.size() - 1;
 
     if(borrowed && !ctx.alignStore) ctx.alignStore = std::make_shared<AlignStore>();
@@ -1151,6 +1169,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const bool listHits = !m3 && sparseDpEnabled();
         std::vector<uint64_t>& hostHitBase = w.hostHitBase;
         if(listHits) { hostHitBase.resize(uint64_t(n) + 1); hostHitBase[0] = 0; }
+        const CellsClassRule listClassRule = cellsClassRule(opt);
         for(uint32_t k = 0; k < n; k++) {
             const shasta_oriented_read_pair& c = candidates[batchBegin + k];
             if(!(c.readIds[0] < c.readIds[1]) || c.readIds[1] >= ctx.readCount) {
@@ -1171,7 +1190,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             pd.nx = uint32_t(nx); pd.ny = uint32_t(ny);
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
-            if(listHits) hostHitBase[k + 1] = hostHitBase[k] + ((nx < 65535 && ny < 65535) ? hitListCapacity(pd.nx, pd.ny) : 0u);
+            // (no room for a candidate whose cells the HBM-scratch kernel computes -- both reads beyond the LDS tables: it lists no matches)
+            if(listHits) hostHitBase[k + 1] = hostHitBase[k] + ((nx < 65535 && ny < 65535 && cellsChoice(listClassRule, pd.nx, pd.ny).cls < CELLS_CLASSES) ? hitListCapacity(pd.nx, pd.ny) : 0u);
         }
         // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
         // SHASTA_MI355X_INITIAL_TASKS overrides the first guess (tests use it to force the second run).

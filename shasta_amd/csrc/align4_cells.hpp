@@ -346,13 +346,13 @@ struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLo
 struct HitLists { uint32_t* hits; const uint64_t* base; uint32_t* meta; };
 constexpr uint32_t HIT_LIST_NONE = 0xffffffffu;
 // Room for a candidate's matches: the shorter read's markers and a quarter (every one matched, some twice), the random background
-// (nx ny / alphabet: 2^12 is below the marker alphabets of Shasta's configurations -- k = 10 at markerDensity 0.1 has about 7 900
-// marker k-mers, the bench's synthetic reads 15 000) and some slack.  Repeat-rich pairs exceed it and take the dense DP (counted:
+// (nx ny / alphabet: 2^13 is about the smallest marker alphabet of Shasta's configurations -- k = 10 at markerDensity 0.1 has about
+// 7 900 marker k-mers, the bench's synthetic reads 15 000; 2^12 asked for 24 GB per batch of ultra-long pairs) and some slack.  Repeat-rich pairs exceed it and take the dense DP (counted:
 // the kernel table's "dense DP because: the candidate's match list overflowed").
 __host__ __device__ inline uint32_t hitListCapacity(uint32_t nx, uint32_t ny)
 {
     const uint32_t shorter = nx < ny ? nx : ny;
-    return shorter + shorter / 4 + uint32_t((uint64_t(nx) * uint64_t(ny)) >> 12) + 192u;
+    return shorter + shorter / 4 + uint32_t((uint64_t(nx) * uint64_t(ny)) >> 13) + 192u;
 }
 
 #ifdef SHASTA_PROFILE_PHASES
