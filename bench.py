@@ -494,6 +494,18 @@ def main():
         ctx.close()
         one_device = bool(os.environ.get("SHASTA_BENCH_ONE_DEVICE") or DRY_RUN_LIBRARY)        # (a box with one GPU: device 0 listed n times)
         g = group_bench(lib, [0] * n if one_device else list(range(n)), toc, kmer, p, o, args, args.align_method)
+        # The same job with the group's exchanges over RCCL (multi.hip's second transport: grouped ncclSend / ncclRecv on communicators
+        # from ncclCommInitAll) -- only where the devices are distinct (RCCL wants one rank per device); an error is reported, not raised.
+        g_rccl = None
+        if n > 1 and not one_device and not os.environ.get("SHASTA_MI355X_GROUP_TRANSPORT"):
+            os.environ["SHASTA_MI355X_GROUP_TRANSPORT"] = "rccl"
+            try:
+                g_rccl = group_bench(lib, list(range(n)), toc, kmer, p, o, args, args.align_method)
+                g_rccl["what"] += "; exchanges over RCCL (SHASTA_MI355X_GROUP_TRANSPORT=rccl)"
+            except Exception as e:          # noqa: BLE001
+                g_rccl = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            finally:
+                del os.environ["SHASTA_MI355X_GROUP_TRANSPORT"]
         print(json.dumps({
             "metric": "candidate read-pairs aligned/sec (LowHash0+Align%d), in-process group" % (4 if args.align_method == 4 else 3),
             "value": g["value"], "unit": "pairs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": g["ms_per_step"],
@@ -502,7 +514,7 @@ def main():
             "config": {"workload": "BASELINE configs[2] shape, %d reads/GPU, one job over %d devices in ONE process (shasta_mi355x_group)" % (args.reads, n),
                        "reads_per_gpu": args.reads, "markers_total": int(toc[-1]), "candidates": g["candidates"], "alignments_stored": g["alignments_stored"],
                        "parallelism": "%d GPUs, in-process group: device-to-device pulls over xGMI, no RCCL" % n},
-            "in_process_group": g, "hbm_budget_per_gpu": hbm_budget(int(toc[-1]), args.reads * n, n)}))
+            "in_process_group": g, "in_process_group_over_rccl": g_rccl, "hbm_budget_per_gpu": hbm_budget(int(toc[-1]), args.reads * n, n)}))
         return
 
     toc = kmer = None
@@ -682,10 +694,11 @@ def main():
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--group", "--sharded-workload", "--gpus", str(world), "--reads", str(args.reads),
                                         "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(min(args.warmup, 2)),
                                         "--align-method", str(args.align_method)],
-                                       env=child_env, capture_output=True, text=True, timeout=300)
+                                       env=child_env, capture_output=True, text=True, timeout=420)
                 lines = [ln for ln in child.stdout.strip().splitlines() if ln.startswith("{")]
                 if child.returncode == 0 and lines:
                     group_line = json.loads(lines[-1])["in_process_group"]
+                    group_line["over_rccl"] = json.loads(lines[-1]).get("in_process_group_over_rccl")
                 else:
                     group_line = {"error": "bench.py --group --gpus %d ended with code %d: %s" % (world, child.returncode, child.stderr[-400:])}
             except Exception as e:          # noqa: BLE001 -- reported, not raised (a timeout included)
@@ -934,6 +947,8 @@ def headline(out, details_path):
     g = out.get("in_process_group")
     if g:
         line["in_process_group"] = {k: g[k] for k in ("value", "ms_per_step", "error") if k in g}
+        if isinstance(g.get("over_rccl"), dict):
+            line["in_process_group"]["over_rccl"] = {k: g["over_rccl"][k] for k in ("value", "ms_per_step", "error") if k in g["over_rccl"]}
     if out.get("earlier_attempts"):
         line["earlier_attempts"] = [{k: a.get(k) for k in ("switches", "ms_per_step", "raised") if k in a} for a in out["earlier_attempts"]]
     line["details"] = details_path

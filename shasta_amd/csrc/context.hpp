@@ -63,6 +63,11 @@ struct Group {
     // borrowed: the result's arrays belong to the group (result.owner = the group) and are reused by its next aligner call.
     void alignRun(uint64_t candidateCount, const shasta_oriented_read_pair* candidates,
         const shasta_align4_options* options4, const shasta_align3_options* options3, bool wantOrdinals, shasta_align4_result&, bool borrowed = false);
+    ~Group();
+    // The exchanges' second transport (multi.hip): RCCL, one communicator per device of the group (ncclCommInitAll), grouped
+    // ncclSend / ncclRecv over xGMI.  Created at the first call that asks for it; empty: the peer-copy transport.
+    std::vector<void*> rcclCommunicators;
+    bool rcclTried = false;
     // The concatenated result of a borrowed call over several devices.
     std::vector<shasta_alignment_data> storeRows;
     std::vector<uint64_t> storeToc, storeOrdinalsToc;

@@ -13,7 +13,15 @@
 // balanced by the markers they touch (sum of nx + ny), one range per device, results concatenated in candidate order.
 // Reductions (per-read statistics, per-iteration counters, bucket histograms) happen on the host after the last
 // iteration -- they are a few megabytes.
+//
+// Second transport, SHASTA_MI355X_GROUP_TRANSPORT=rccl: the same two exchanges as ONE grouped ncclSend / ncclRecv all-to-all each
+// (RCCL over xGMI: one communicator per device from ncclCommInitAll, every device's host thread posts its sends and receives on its
+// own stream) -- what BASELINE.json's north_star names for the redistribution of the bucket hits.  librccl.so is opened at run time
+// (dlopen), so the library links against nothing but the HIP runtime and a machine without RCCL keeps the peer copies.  RCCL refuses a
+// device listed twice, so the one-device tests of the group (device 0 three times) stay on peer copies; with ONE device and
+// SHASTA_MI355X_GROUP_STAGED=1 the staged job runs with a world of one and RCCL sends to itself -- all a one-GPU box can exercise.
 #include "context.hpp"
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -81,7 +89,75 @@ template<class F> void onEveryDevice(int world, CallBarrier& barrier, F fn)
     if(!first.empty()) throw std::runtime_error(first);
 }
 
+// librccl.so's entry points, resolved at run time.
+struct RcclApi {
+    void* handle = nullptr;
+    int (*commInitAll)(void**, int, const int*) = nullptr;
+    int (*commDestroy)(void*) = nullptr;
+    int (*groupStart)() = nullptr;
+    int (*groupEnd)() = nullptr;
+    int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*errorString)(int) = nullptr;
+    bool ok() const { return handle && commInitAll && commDestroy && groupStart && groupEnd && send && recv; }
+};
+const RcclApi& rcclApi()
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        for(const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if(a.handle) break; }
+        if(!a.handle) return a;
+        a.commInitAll = reinterpret_cast<decltype(a.commInitAll)>(dlsym(a.handle, "ncclCommInitAll"));
+        a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+        a.groupStart = reinterpret_cast<decltype(a.groupStart)>(dlsym(a.handle, "ncclGroupStart"));
+        a.groupEnd = reinterpret_cast<decltype(a.groupEnd)>(dlsym(a.handle, "ncclGroupEnd"));
+        a.send = reinterpret_cast<decltype(a.send)>(dlsym(a.handle, "ncclSend"));
+        a.recv = reinterpret_cast<decltype(a.recv)>(dlsym(a.handle, "ncclRecv"));
+        a.errorString = reinterpret_cast<decltype(a.errorString)>(dlsym(a.handle, "ncclGetErrorString"));
+        return a;
+    }();
+    return api;
+}
+void rcclCheck(int result, const char* what)
+{
+    if(result == 0) return;
+    const RcclApi& api = rcclApi();
+    throw std::runtime_error(std::string("RCCL error in ") + what + ": " + (api.errorString ? api.errorString(result) : std::to_string(result).c_str()));
+}
+constexpr int RCCL_UINT8 = 1;                 // ncclUint8 (rccl.h)
+bool rcclTransportWanted() { const char* e = std::getenv("SHASTA_MI355X_GROUP_TRANSPORT"); return e && std::string(e) == "rccl"; }
+// (test switch: the staged job with its exchanges even for a group of one device)
+bool stagedWithOneDevice() { const char* e = std::getenv("SHASTA_MI355X_GROUP_STAGED"); return e && std::atoi(e) != 0; }
+
+// The group's communicators, made at the first call that wants them; false: stay on peer copies (said once on stderr why).
+bool ensureRccl(Group& group)
+{
+    if(!group.rcclCommunicators.empty()) return true;
+    if(group.rcclTried) return false;
+    group.rcclTried = true;
+    const RcclApi& api = rcclApi();
+    std::vector<int> devices;
+    for(const auto& c : group.contexts) devices.push_back(c->device);
+    std::vector<int> sorted = devices;
+    std::sort(sorted.begin(), sorted.end());
+    const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+    if(!api.ok() || !distinct) {
+        std::fprintf(stderr, "shasta_mi355x group: SHASTA_MI355X_GROUP_TRANSPORT=rccl, but %s; the exchanges stay device-to-device copies\n",
+            !api.ok() ? "librccl.so could not be opened" : "a device is listed more than once (RCCL wants one rank per device)");
+        return false;
+    }
+    std::vector<void*> communicators(devices.size(), nullptr);
+    rcclCheck(api.commInitAll(communicators.data(), int(devices.size()), devices.data()), "ncclCommInitAll");
+    group.rcclCommunicators = communicators;
+    return true;
+}
+
 }  // namespace
+
+Group::~Group()
+{
+    if(!rcclCommunicators.empty()) { const RcclApi& api = rcclApi(); for(void* c : rcclCommunicators) if(c && api.commDestroy) (void)api.commDestroy(c); }
+}
 
 Group::Group(int deviceCount, const int* devices)
 {
@@ -119,7 +195,8 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
     std::memset(&result, 0, sizeof(result));
     const auto t0 = std::chrono::steady_clock::now();
     const int world = int(contexts.size());
-    if(world == 1) { shasta_mi355x::lowhash0Run(*contexts[0], p, readLowHashStatistics, result); return; }
+    if(world == 1 && !stagedWithOneDevice()) { shasta_mi355x::lowhash0Run(*contexts[0], p, readLowHashStatistics, result); return; }
+    const bool overRccl = rcclTransportWanted() && ensureRccl(*this);
     const uint64_t readCount = contexts[0]->readCount;
     const std::vector<uint64_t>& toc = contexts[0]->hostToc;
     if(readCount == 0) throw std::runtime_error("LowHash0: no reads.");
@@ -181,6 +258,26 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
             // selected by `which`.  Returns the number of elements received.
             auto pull = [&](int which, size_t bytes, void* destination) {
                 uint64_t at = 0;
+                if(overRccl) {
+                    // The same exchange as one grouped all-to-all: this device sends every destination its segment of its own output
+                    // and receives every source's segment for it, in source order (where the copies below would put them).
+                    const RcclApi& api = rcclApi();
+                    void* const communicator = rcclCommunicators[size_t(rank)];
+                    const char* const mine = static_cast<const char*>(which == 0 ? me.out0 : me.out1);
+                    rcclCheck(api.groupStart(), "ncclGroupStart");
+                    for(int d = 0; d < world; d++) {
+                        const uint64_t begin = me.offsets[size_t(d)], count = me.offsets[size_t(d) + 1] - begin;
+                        if(count) rcclCheck(api.send(mine + begin * bytes, size_t(count * bytes), RCCL_UINT8, d, communicator, stream), "ncclSend");
+                    }
+                    for(int s = 0; s < world; s++) {
+                        const Rank& source = rankOf(s);
+                        const uint64_t count = source.offsets[size_t(rank) + 1] - source.offsets[size_t(rank)];
+                        if(count) rcclCheck(api.recv(static_cast<char*>(destination) + at * bytes, size_t(count * bytes), RCCL_UINT8, s, communicator, stream), "ncclRecv");
+                        at += count;
+                    }
+                    rcclCheck(api.groupEnd(), "ncclGroupEnd");
+                    return at;
+                }
                 for(int s = 0; s < world; s++) {
                     const Rank& source = rankOf(s);
                     const uint64_t begin = source.offsets[size_t(rank)], count = source.offsets[size_t(rank) + 1] - begin;

@@ -112,3 +112,38 @@ def one_pass_that_does_not_fit(lib, oracle_lib, devices=(0, 0, 0)):
     assert out.returncode == 0 and "fell back and agreed" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
     assert out.stderr.count("iteration after iteration") >= 1 + len(devices)          # the one-device call and every device of the group
     return out.stderr
+
+
+class _environment:
+    def __init__(self, **values):
+        self.values = values
+
+    def __enter__(self):
+        import os
+        self.previous = {k: os.environ.get(k) for k in self.values}
+        os.environ.update(self.values)
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.previous.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def staged_job_of_one_device(lib, oracle_lib, transport="peer", n_reads=260):
+    """SHASTA_MI355X_GROUP_STAGED=1: a group of ONE device runs the staged LowHash0 -- begin, hash, exchange, buckets, exchange,
+    merge -- with a world of one, the device exchanging with itself.  transport "rccl": both exchanges as grouped ncclSend / ncclRecv
+    on a communicator from ncclCommInitAll (multi.hip's second transport; all of it that a one-GPU box can run)."""
+    toc, kmer, data7 = support.small_marker_set(n_reads=n_reads, genome_markers=14000, seed=67)
+    compared = 0
+    for p in (abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30, minFrequency=2),
+              abi.default_lowhash0_params(m=5, hashFraction=0.03, minHashIterationCount=0, alignmentCandidatesPerRead=6.0, minBucketSize=2, maxBucketSize=40)):
+        ref = oracle_lib.lowhash0(toc, data7, None, p)
+        assert len(ref.candidates) > 100
+        with _environment(SHASTA_MI355X_GROUP_STAGED="1", SHASTA_MI355X_GROUP_TRANSPORT=transport):
+            out = lib.lowhash0_multi(toc, data7, None, p, (0,))
+        support.same_lowhash(out, ref)
+        compared += 1
+    return compared

@@ -276,6 +276,7 @@ def test_several_devices_behind_one_call(emu_lib, oracle_lib):
     assert group_checks.lowhash0_and_aligners(emu_lib, oracle_lib, device_lists=((0, 0), (0, 0, 0)), n_reads=160, limit=300) == 4
     group_checks.errors_do_not_hang(emu_lib)
     group_checks.one_pass_that_does_not_fit(emu_lib, oracle_lib)
+    assert group_checks.staged_job_of_one_device(emu_lib, oracle_lib, "peer", n_reads=160) == 2        # (a world of one through the staged job)
 
 
 def test_lowhash0_calls_of_one_context_share_their_allocations(emu_lib, oracle_lib):

@@ -24,3 +24,11 @@ def test_adversarial_lowhash0_through_the_group(gpu_lib, oracle_lib):
 def test_a_job_whose_iterations_do_not_fit_one_pass_falls_back_on_every_device(gpu_lib, oracle_lib):
     from tests import group_checks
     group_checks.one_pass_that_does_not_fit(gpu_lib, oracle_lib)
+
+
+def test_the_staged_job_of_one_device_over_peer_copies_and_over_rccl(gpu_lib, oracle_lib):
+    """The C++ seam's two transports with the one rank a one-GPU box has: device-to-device copies, and RCCL (librccl.so opened at
+    run time, ncclCommInitAll, both exchanges as grouped ncclSend / ncclRecv)."""
+    from tests import group_checks
+    assert group_checks.staged_job_of_one_device(gpu_lib, oracle_lib, "peer") == 2
+    assert group_checks.staged_job_of_one_device(gpu_lib, oracle_lib, "rccl") == 2
