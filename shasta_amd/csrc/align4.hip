@@ -370,7 +370,11 @@ void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in
             done.push_back(device);
         }
     }
-    hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT>), dim3(std::min<uint32_t>(CHAIN_WAVE_GRID[CLS], divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
+    // (SHASTA_MI355X_CHAIN_WAVE_SHARE=<percent>: the share of the wavefronts the LDS would let a CU hold that the launch asks for --
+    // a timing experiment: what the kernel leaves of a CU's LDS is what the other workers' kernels can run in beside it)
+    static const uint32_t share = [] { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SHARE"); return e ? uint32_t(std::min(std::max(std::atoi(e), 10), 100)) : 100u; }();
+    const uint32_t grid = std::max<uint32_t>(256u, CHAIN_WAVE_GRID[CLS] * share / 100u);
+    hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT>), dim3(std::min<uint32_t>(grid, divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
         b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
         (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data());

@@ -142,7 +142,7 @@ __device__ int32_t anchorRectangle(Shared& sh, const uint32_t* __restrict__ p0, 
     // Where the traceback starts.  (A fixed end that no path from the fixed begin reaches, or a walk that does not end in the fixed
     // begin, would contradict what the anchors are: the task goes to the dense kernels rather than on.)
     int32_t i = wx, j = wy;
-    if(endFixed && sh.row[wx & 1][wy] <= ANCHOR_NEG) return -1;
+    if(endFixed && sh.row[wx & 1][wy] <= ANCHOR_NEG) return -2;                  // (-2: the walk contradicts the anchors)
     if(!endFixed) {
         // The border cells in the order the dense DP scans them -- (0, wy) ... (wx - 1, wy), then (wx, 0) ... (wx, wy) -- and the
         // first or the last of those with the largest score.
@@ -171,7 +171,7 @@ __device__ int32_t anchorRectangle(Shared& sh, const uint32_t* __restrict__ p0, 
         if(move == Tie::DIAGONAL) {
             --i; --j;
             if(t & 4u) {
-                if(begin + uint32_t(found) >= uint32_t(Shared::maxPairs)) return -1;
+                if(begin + uint32_t(found) >= uint32_t(Shared::maxPairs)) return -1;        // (-1: the pairs do not fit)
                 if(lane == 0) sh.pairs[begin + uint32_t(found)] = (uint32_t(x0 + i) << 16) | uint32_t(y0 + j);
                 ++found;
             }
@@ -180,7 +180,7 @@ __device__ int32_t anchorRectangle(Shared& sh, const uint32_t* __restrict__ p0, 
         else --i;
     }
     waveLdsSync();
-    if(beginFixed && (i != 0 || j != 0)) return -1;
+    if(beginFixed && (i != 0 || j != 0)) return -2;
     return found;
 }
 
@@ -287,6 +287,7 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const uint32_t* __restrict__ const p1 = kmerIds + pd.begin1;
         uint32_t windowPairsTotal = 0;
         bool fits = true, tooBig = false;
+        int why = GIVE_UP_RECTANGLE;
         for(int32_t w = 0; w < windows && fits; w++) {
             const int32_t from = sh.windowFrom[w], to = sh.windowTo[w];
             int32_t x0 = 0, y0 = 0, x1 = int32_t(pd.nx) - 1, y1 = int32_t(pd.ny) - 1;
@@ -295,7 +296,7 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
             const int32_t wx = x1 - x0 + 1, wy = y1 - y0 + 1;
             if(wx < 1 || wy < 1 || wx > Shared::maxSide || wy > Shared::maxSide || (wx + 1) * (wy + 1) > Shared::maxCells) { fits = false; tooBig = true; break; }
             const int32_t found = anchorRectangle<TIE>(sh, p0, p1, x0, x1, y0, y1, from >= 0, to < n, task.bandMin, task.bandMax, windowPairsTotal, lane);
-            if(found < 0) { fits = false; tooBig = true; break; }       // (the pairs did not fit, or the walk contradicted the anchors: the larger form tries once more)
+            if(found < 0) { fits = false; tooBig = true; why = found == -1 ? GIVE_UP_RECTANGLE_PAIRS : GIVE_UP_RECTANGLE_WALK; break; }       // (the pairs did not fit, or the walk contradicted the anchors: the larger form tries once more)
             if(lane == 0) { sh.windowBegin[w] = windowPairsTotal; sh.windowPairs[w] = uint32_t(found); }
             windowPairsTotal += uint32_t(found);
         }
@@ -304,7 +305,10 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
             if(lane == 0) bigList[listStride + atomicAdd(&control->anchorBigCount, 1u)] = t;
             continue;
         }
-        if(!fits || uint32_t(anchorCount) + windowPairsTotal > min(pd.nx, pd.ny)) { giveUp(3); continue; }
+        if(!fits || uint32_t(anchorCount) + windowPairsTotal > min(pd.nx, pd.ny)) {
+            if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, fits ? int(GIVE_UP_PAIR_TOTAL) : why, pd, task); ANCHOR_REASON(3, n); }
+            continue;
+        }
         waveLdsSync();
         // ---- emit: from the end of the task's range downwards ----
         const uint64_t ordBase = ordOffsets[t];

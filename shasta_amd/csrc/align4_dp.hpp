@@ -91,15 +91,18 @@ __host__ __device__ inline uint32_t dpBinOfKey(uint32_t key)
 }
 // Why a task of the sparse path ends in the dense kernels (counted on the device, reported in the kernel table as rows without time).
 enum DpGiveUp : int { GIVE_UP_NO_LIST = 0, GIVE_UP_LIST_OVERFLOW, GIVE_UP_LONG_STREAM, GIVE_UP_CROWDED_MARKER, GIVE_UP_SORTED_CAPACITY,
-    GIVE_UP_LOOK_BACK, GIVE_UP_TIE_WITH_EMPTY, GIVE_UP_FAR_LINK, GIVE_UP_NO_ANCHOR, GIVE_UP_WINDOWS, GIVE_UP_RECTANGLE, GIVE_UP_ANCHORS_OFF };
-constexpr int DP_GIVE_UP_REASONS = 12;
+    GIVE_UP_LOOK_BACK, GIVE_UP_TIE_WITH_EMPTY, GIVE_UP_FAR_LINK, GIVE_UP_NO_ANCHOR, GIVE_UP_WINDOWS, GIVE_UP_RECTANGLE, GIVE_UP_ANCHORS_OFF,
+    GIVE_UP_RECTANGLE_PAIRS, GIVE_UP_RECTANGLE_WALK, GIVE_UP_PAIR_TOTAL };
+constexpr int DP_GIVE_UP_REASONS = 16;
 const char* const DP_GIVE_UP_NAMES[DP_GIVE_UP_REASONS] = {
     "dense DP because: the candidate's matches were not listed (HBM-scratch cells kernel)", "dense DP because: the candidate's match list overflowed",
     "dense DP because: the tabled read has more than 8192 markers", "dense DP because: 16 matches of one marker inside the band",
     "dense DP because: more matches inside the band than the task's list holds", "dense DP because: a match's predecessors lie further back than the chain kernel looks",
     "dense DP because: the best chain ties with the empty alignment", "dense DP because: an optimal link of a live match beyond its link word",
     "dense DP because: no match lies on every optimal chain", "dense DP because: more than 128 windows between anchors",
-    "dense DP because: a rectangle between anchors beyond the anchor kernel's limits", "dense DP because: several optimal chains and the anchor kernel is switched off"};
+    "dense DP because: a rectangle between anchors beyond the anchor kernel's limits", "dense DP because: several optimal chains and the anchor kernel is switched off",
+    "dense DP because: more aligned pairs inside the rectangles than the anchor kernel holds", "dense DP because: a rectangle's walk did not reach its fixed corner",
+    "dense DP because: anchors and rectangle pairs exceed the shorter read", "dense DP because: (unused)"};
 // Everything the DP's preparation counts, in one block of device memory (one memset before, one copy to the host after).
 struct DpControl {
     unsigned long long sums[2 + 2 * DP_CLASSES];     // [0] DP cells of all tasks, [1] unused, [2+c] cells of class c, [2+DP_CLASSES+c] bytes of class c (of the tasks the dense kernels run)

@@ -217,3 +217,94 @@ def tiny_tasks(lib, orc, seed=11, tasks=400, alternatives=tie_policy_checks.ALTE
             assert sx == sy and np.array_equal(x, y), (policy, tuple(int(v) for v in spec[i]))
         runs += len(spec)
     return runs
+
+
+class _environment:
+    def __init__(self, **values):
+        self.values = values
+
+    def __enter__(self):
+        self.previous = {k: os.environ.get(k) for k in self.values}
+        os.environ.update(self.values)
+
+    def __exit__(self, *exc):
+        for k, v in self.previous.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def large_tasks(seed=5, tasks=16):
+    """Tasks of 1 100 to 3 100 aligned pairs: beyond the wave kernel's first capacity class (1 024 hits in LDS), some beyond its
+    second (2 048), lists of more than 1 024 matches (the sort kernel's passes over memory)."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+    for t in range(tasks):
+        n = int(rng.integers(2000, 4600))
+        width = int(rng.choice([40, 60, 100, 300]))
+        genome = rng.integers(0, 1 << 20, size=2 * n + 400, dtype=np.uint32)
+        off = int(rng.integers(0, 100))
+        a = dp_geometry_checks.noisy(rng, genome[:n], 1 << 20)
+        b = dp_geometry_checks.noisy(rng, genome[off:off + n], 1 << 20)
+        lo = off - width // 2
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), lo, lo + width - 1))
+        at += len(a) + len(b)
+    return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+
+
+def wave_kernel_forms(lib, orc):
+    """align4_chainwave.hpp against the oracle and against the forms it can be switched to: the lane-per-task chain kernel
+    (SHASTA_MI355X_CHAIN_WAVE=0), the wave kernel ordering the hits itself (SHASTA_MI355X_CHAIN_WAVE_SORT=1: classes chosen from the
+    listed matches, tasks that turn out too large handed to the next class), on clean tasks of every size class.
+    -> tasks compared."""
+    compared = 0
+    for kmer, spec in (clean_tasks(91, tasks=40, long_every=9), large_tasks()):
+        want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
+        for env in ({}, {"SHASTA_MI355X_CHAIN_WAVE": "0"}, {"SHASTA_MI355X_CHAIN_WAVE_SORT": "1"}, {"SHASTA_MI355X_CHAIN_WAVE_SIDE": "1"}):
+            with _environment(**env):
+                got = _run(lib, kmer, spec)
+            for (x, sx), (y, sy) in zip(want, got):
+                assert sx == sy and np.array_equal(x, y), env
+            compared += len(want)
+    return compared
+
+
+def inverted_block_tasks(blocks=(20, 70, 71, 120, 300), flank=220, seed=17):
+    """Two reads that agree except for one block of m markers which the second read has in REVERSED order: every chain can take one
+    match of the block, the two in its middle tie (m even) -- two optimal chains, and between the anchors before and behind the block
+    a rectangle of (m + 1)^2 cells: within the anchor kernel's first launch (4 096 cells) for m = 20, its second (65 536) for 70 to
+    120, beyond both for 300 (the dense kernels)."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+    for m in blocks:
+        ids = rng.permutation(1 << 20)[:2 * flank + m].astype(np.uint32)
+        a = ids
+        b = np.concatenate([ids[:flank], ids[flank:flank + m][::-1], ids[flank + m:]])
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), -40, 40))
+        at += len(a) + len(b)
+    return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+
+
+def anchor_kernel_second_launch(lib, orc, alternatives=tie_policy_checks.ALTERNATIVES):
+    """-> (DP cells the dense kernels ran with the anchor kernel's second launch, without it).  Equal to the oracle either way and
+    under every compiled tie policy (the rectangle's walk follows the policy)."""
+    kmer, spec = inverted_block_tasks()
+    cells = {}
+
+    def compare(want, record):
+        for big in ("1", "0"):
+            with _environment(SHASTA_MI355X_ANCHOR_BIG=big):
+                got = _run(lib, kmer, spec)
+                if record:
+                    cells[big] = int(_run(lib, kmer, spec, timing=True)[3].sum())
+            for (x, sx), (y, sy) in zip(want, got):
+                assert sx == sy and np.array_equal(x, y), big
+
+    compare([orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec], True)
+    for alternative in alternatives:
+        with tie_policy_checks.policy(orc, alternative):
+            compare([orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec], False)
+    return cells["1"], cells["0"]

@@ -324,6 +324,15 @@ def test_locally_ambiguous_tasks_through_the_anchor_kernel(emu_lib, oracle_lib):
     assert sparse_checks.tiny_tasks(emu_lib, oracle_lib, tasks=200, alternatives=(3,)) >= 400
 
 
+def test_wave_kernel_forms_and_the_anchor_kernel_second_launch(emu_lib, oracle_lib):
+    """align4_chainwave.hpp against the oracle and the forms it can be switched to (lane-per-task kernel, its own ordering of the hits,
+    the side stream), tasks of every capacity class; align4_anchor.hpp's second launch on rectangles beyond the first one's LDS."""
+    from tests import sparse_checks
+    assert sparse_checks.wave_kernel_forms(emu_lib, oracle_lib) >= 200
+    with_second, without = sparse_checks.anchor_kernel_second_launch(emu_lib, oracle_lib)
+    assert 0 < with_second < without
+
+
 def test_read_statistics_over_several_partitions_and_spans(emu_lib, oracle_lib):
     # readStatisticsKernel (lowhash0.hip): 4 200 table entries = 3 partitions, > 65 536 records = several spans; and the atomics form.
     from tests import statistics_checks

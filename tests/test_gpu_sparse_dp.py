@@ -26,3 +26,16 @@ def test_locally_ambiguous_tasks_through_the_anchor_kernel(gpu_lib, oracle_lib):
 
 def test_tiny_tasks_through_the_sparse_and_anchor_kernels(gpu_lib, oracle_lib):
     assert sparse_checks.tiny_tasks(gpu_lib, oracle_lib) >= 1200
+
+
+def test_the_wave_kernel_against_the_forms_it_can_be_switched_to(gpu_lib, oracle_lib):
+    # align4_chainwave.hpp: tasks of every capacity class; the lane-per-task kernel, the wave kernel with its own ordering of the hits,
+    # the larger classes on the side stream.
+    assert sparse_checks.wave_kernel_forms(gpu_lib, oracle_lib) >= 200
+
+
+def test_the_anchor_kernel_second_launch(gpu_lib, oracle_lib):
+    # Rectangles of 441, 5 041, 5 184, 14 641 and 90 601 cells between two anchors: with the second launch only the last one's task is
+    # left to the dense kernels, without it the last four.
+    with_second, without = sparse_checks.anchor_kernel_second_launch(gpu_lib, oracle_lib)
+    assert 0 < with_second < without
