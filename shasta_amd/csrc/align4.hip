@@ -1081,11 +1081,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     // against 167-171 ms per call, profiles/r02_call36_batch_schedule.log.)
     // ... or sooner, when the candidates' reads are long: a batch's scratch (match lists, DP tasks' ranges, traces) grows with the
     // markers of its candidates, not with their number, and 2^18 candidates of the ultra-long shape (15 000 markers a pair against
-    // 3 000) asked the six workers for more than the 288 GB (round 5, bench.py --workload ul).  So a batch also ends at 3 200 markers
+    // 3 000) asked the six workers for more than the 288 GB (round 5, bench.py --workload ul).  So a batch also ends at 4 000 markers
     // per candidate of a full batch: the 100 k-read workload's batches stay what they were.
     std::vector<uint64_t> batchStart(1, 0);
     {
-        const uint64_t markerBudget = BATCH * 3200ULL;
+        const uint64_t markerBudget = BATCH * 4000ULL;
         uint64_t count = 0, markers = 0;
         for(uint64_t k = 0; k < candidateCount; k++) {
             const shasta_oriented_read_pair& c = candidates[k];

@@ -83,15 +83,22 @@ def test_compute_entry_points_fail_loudly_without_a_gpu():
         library.hash_windows(np.arange(10, dtype=np.uint32), 4, 0)
 
 
-def test_loading_the_library_asks_for_eight_hardware_queues_unless_the_environment_says_otherwise():
-    # api.hip's constructor: GPU_MAX_HW_QUEUES=8 when unset (six aligner workers x (stream + side stream) on the runtime's default
-    # four queues cost 15 % of an aligner call); an explicit setting stays.  In processes of their own: the loader runs once.
+def test_the_python_wrapper_asks_for_eight_hardware_queues_and_the_library_leaves_the_environment_alone():
+    # GPU_MAX_HW_QUEUES=8 (six aligner workers x (stream + side stream) on the runtime's default four queues cost 15 % of an aligner
+    # call) is the CALLER's to set before the first HIP call: shasta_amd/lib.py does when it loads the library, unless the environment
+    # says otherwise; the library itself does not write the host process's environment (round 4's load-time setenv is gone).
     import subprocess
     import sys
-    code = ("import ctypes, os\n"
-            "ctypes.CDLL(%r)\n"
-            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
-            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())\n") % libmod.SO_PATH
+    raw = ("import ctypes, os\n"
+           "ctypes.CDLL(%r)\n"
+           "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+           "v = libc.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else 'unset')\n") % libmod.SO_PATH
+    wrapped = ("import sys, ctypes; sys.path.insert(0, %r)\n"
+               "from shasta_amd import lib as libmod\n"
+               "libmod.Library(libmod.SO_PATH)\n"
+               "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+               "v = libc.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else 'unset')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "8"
-    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4")).decode().strip() == "4"
+    assert subprocess.check_output([sys.executable, "-c", raw], env=env).decode().strip() == "unset"
+    assert subprocess.check_output([sys.executable, "-c", wrapped], env=env).decode().strip() == "8"
+    assert subprocess.check_output([sys.executable, "-c", wrapped], env=dict(env, GPU_MAX_HW_QUEUES="4")).decode().strip() == "4"
