@@ -246,7 +246,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 ++dbgPasses;
 #endif
                 const int32_t pmIncl = max(pmAll, waveInclusiveMax(lane >= first ? d : CHAIN_NEG));
-                int32_t pm2 = __shfl_up(pmIncl, 2, WAVE);                     // the largest D up to the hit two before
+                int32_t pm2 = dppOr<0x138, 0xf>(CHAIN_NEG, dppOr<0x138, 0xf>(CHAIN_NEG, pmIncl));      // the largest D up to the hit two before (wave_shr:1 twice)
                 pm2 = lane == first ? pmBut1 : (lane == first + 1 ? pmAll : pm2);
                 const int32_t value = d - 6;                                  // D(i - 1) - c(i)
                 const bool ok = lane < first || (simple && (i < 2 || pm2 - reach2 < value) && border < value);
@@ -346,7 +346,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 const int32_t pmIncl = max(pmRunning, waveInclusiveMax(d));
                 const int32_t end = valid ? d - min(np - 1 - p, ns - 1 - s) : CHAIN_NEG;
                 const int32_t endIncl = max(endRunning, waveInclusiveMax(end));
-                int32_t endBefore = __shfl_up(endIncl, 1, WAVE);
+                int32_t endBefore = dppOr<0x138, 0xf>(CHAIN_NEG, endIncl);
                 if(lane == 0) endBefore = endRunning;
                 uint32_t links = 2u;                                          // an accepted hit: the hit before it, nothing else
                 uint64_t todo = ballot64(valid && (off & CHAIN_OFF_EXCEPTION) != 0);
