@@ -454,7 +454,10 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         const bool ownSort = chainWave && chainWaveOwnSort();
         if(!ownSort) {
         if(timers) span = timers->begin("sparseSortKernel", stream);
-        hipLaunchKernelGGL(sparseSortKernel, dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
+        hipLaunchKernelGGL((sparseSortKernel<4096, 0>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
+            in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave);
+        hipLaunchKernelGGL((sparseSortKernel<int(SPARSE_MAX_STREAM), 4096>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
             b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave);
         HIP_CHECK(hipGetLastError());

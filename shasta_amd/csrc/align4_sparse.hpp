@@ -82,13 +82,18 @@ __device__ __forceinline__ void noteGiveUp(DpControl* control, int why, const Pa
     atomicAdd(&control->giveUpCells[why], (unsigned long long)pd.nx * (unsigned long long)(task.bandMax - task.bandMin + 1));
 }
 
+// Two launches by the markers of the read the order is by: up to 4 096 (5 KB of counters a wavefront: 32 wavefronts per CU; 99 % of
+// the tasks at 100 k reads) and beyond (10 KB, 16 per CU).  The kernel waits for memory, it does not compute: twice the wavefronts
+// in flight is what it needed (one launch sized for 8 192 markers: 14 ms per step alone, 72 ms of launches sharing the device).
+template<int MAX_STREAM, int MIN_STREAM>
 __global__ void __launch_bounds__(256)
 sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta,
     const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control, bool noLaneKernel)
 {
-    __shared__ uint32_t counts[4][SPARSE_COUNTER_WORDS], cursors[4][SPARSE_COUNTER_WORDS];
-    __shared__ uint16_t wordStart[4][SPARSE_COUNTER_WORDS];
+    static_assert(MAX_STREAM <= int(SPARSE_MAX_STREAM) && MIN_STREAM < MAX_STREAM && MAX_STREAM % 8 == 0, "classes of the tabled read's markers");
+    __shared__ uint32_t counts[4][MAX_STREAM / 8], cursors[4][MAX_STREAM / 8];
+    __shared__ uint16_t wordStart[4][MAX_STREAM / 8];
     const int lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * 4u + wave;
@@ -104,12 +109,13 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
     // chunk kernel made the list (the LDS table's classes), however long the streamed read is.
     const uint32_t streamCount = swapped ? pd.ny : pd.nx;          // (markers of the read the order is by)
     if(meta == HIT_LIST_NONE || count > capacity || streamCount > SPARSE_MAX_STREAM || streamCount == 0) {
-        if(lane == 0) {
+        if(lane == 0 && MIN_STREAM == 0) {                 // (said once: by the first launch)
             state[t] = SPARSE_DENSE;
             noteGiveUp(control, meta == HIT_LIST_NONE ? GIVE_UP_NO_LIST : (count > capacity ? GIVE_UP_LIST_OVERFLOW : GIVE_UP_LONG_STREAM), pd, task);
         }
         return;
     }
+    if(streamCount > uint32_t(MAX_STREAM) || streamCount <= uint32_t(MIN_STREAM)) return;      // (the other launch's)
     uint32_t* const myCounts = counts[wave];
     uint32_t* const myCursors = cursors[wave];
     uint16_t* const myStart = wordStart[wave];
