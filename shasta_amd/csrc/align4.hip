@@ -386,14 +386,15 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
     hipStream_t side = nullptr, DpEvents* ev = nullptr)
 {
     // (in the order of the classes: a launch lists the tasks that turned out too large for it for the next one)
-    b.chainWaveRetry.reserve(uint64_t(CHAIN_WAVE_CLASSES - 1) * taskCount, stream);
     if(chainWaveOwnSort()) {
         launchChainWaveClass<0, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, true>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<3, true>(stream, b, in, taskCount, sparse, control, opt);
     } else if(side && ev && chainWaveSideStream()) {
         // (classes from the hits the sort kernel counted: no class lists tasks for another, so the launches need no order)
         HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(side, ev->fork, 0));
+        launchChainWaveClass<3, false>(side, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, false>(side, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, false>(side, b, in, taskCount, sparse, control, opt);
         HIP_CHECK(hipEventRecord(ev->join, side));
@@ -403,6 +404,7 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
         launchChainWaveClass<0, false>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, false>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, false>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<3, false>(stream, b, in, taskCount, sparse, control, opt);
     }
 }
 
@@ -452,14 +454,15 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         const bool chainWave = chainWaveEnabled();
         KernelTimers::Span span;
         const bool ownSort = chainWave && chainWaveOwnSort();
+        if(chainWave) b.chainWaveRetry.reserve(uint64_t(CHAIN_WAVE_CLASSES - 1) * taskCount, stream);       // (the listed classes' tasks; own-sort form: tasks handed on to the next class)
         if(!ownSort) {
         if(timers) span = timers->begin("sparseSortKernel", stream);
         hipLaunchKernelGGL((sparseSortKernel<4096, 0>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
-            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave);
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave, chainWave ? b.chainWaveRetry.data() : nullptr);
         hipLaunchKernelGGL((sparseSortKernel<int(SPARSE_MAX_STREAM), 4096>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
-            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave);
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave, chainWave ? b.chainWaveRetry.data() : nullptr);
         HIP_CHECK(hipGetLastError());
         if(timers) sortHandle = timers->end(span, 0, taskCount);
         }

@@ -33,14 +33,15 @@
 // kernels, 166 ms per step against 143 (profiles/r05_call5*, r05_call3*): the sort's two passes over the candidate's list are chains of
 // dependent loads, and a wavefront that holds 10 KB of LDS while it waits for them keeps the next task's wavefront out.
 //
-// LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Three launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
-// tasks at 100 k reads), 2 048, 15 360 -- of wavefronts that go over the task list in blocks of 16 and run the tasks of their class
-// (the class from the matches LISTED for the candidate less the usual background, known before any is counted; a task with more
-// inside its band than the class holds is listed for the next class's launch); what fits none goes to the dense kernels.
+// LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Four launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
+// tasks at 100 k reads), 2 048 (13 %), 4 096 (0.1 %), 15 360 -- the first two of wavefronts that go over the task list in blocks of
+// 16 and run the tasks of their class, the last two over the few tasks sparseSortKernel listed for them (a launch that went over all
+// tasks for a few hundred of them, at one wavefront per CU, took as long as the first class's); what fits none goes to the dense
+// kernels.
 // SHASTA_MI355X_CHAIN_WAVE=0: sparseSortKernel + sparseChainKernel, as before this file.
 #pragma once
 
-constexpr uint32_t CHAIN_WAVE_GRID[CHAIN_WAVE_CLASSES] = {256u * 16u, 256u * 8u, 256u};       // workgroups of one wavefront, as many as the LDS lets a CU hold
+constexpr uint32_t CHAIN_WAVE_GRID[CHAIN_WAVE_CLASSES] = {256u * 16u, 256u * 8u, 256u * 4u, 256u};       // workgroups of one wavefront, as many as the LDS lets a CU hold
 constexpr uint32_t CHAIN_WAVE_SLACK = 512;         // matches listed for a candidate beyond those inside a task's band, usually fewer than this: the background of the whole matrix, other components
 constexpr uint32_t CHAIN_WAVE_BLOCK = 16;          // tasks a wavefront takes from the cursor at a time
 constexpr uint32_t CHAIN_OFF_MASK = 0x3fffu, CHAIN_OFF_EXCEPTION = 0x4000u, CHAIN_OFF_WAYS = 0x8000u;
@@ -109,7 +110,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
     // task looks at its state and hit count, and the wavefront runs those of its class one after the other.
     uint64_t todoTasks = 0;
     uint32_t blockBase = 0;
-    bool scanning = true;
+    bool scanning = OWN_SORT || cls < CHAIN_WAVE_LISTED_FROM;          // (the few tasks of the larger classes come listed by sparseSortKernel)
     const uint32_t retried = cls > 0 ? control->retryCount[cls] : 0u;       // (listed by the launch of the class below, which has ended)
     uint32_t retrySlot = blockIdx.x;
     for(;;) {

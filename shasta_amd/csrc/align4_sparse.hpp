@@ -69,11 +69,15 @@ __host__ __device__ inline int32_t sparseMatchlessScore(uint32_t nx, uint32_t ny
 }
 
 // align4_chainwave.hpp's capacity classes (hits a wavefront holds in LDS).
-constexpr int CHAIN_WAVE_CLASSES = 3;
-constexpr uint32_t CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES] = {1024u, 2048u, 15360u};
+constexpr int CHAIN_WAVE_CLASSES = 4;
+constexpr uint32_t CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES] = {1024u, 2048u, 4096u, 15360u};
+// The classes from this one on are few tasks each (0.1 % of the tasks at 100 k reads): the sort kernel LISTS them (an atomic each on the
+// class's counter), and their launches run the list instead of going over all the tasks for them.
+constexpr int CHAIN_WAVE_LISTED_FROM = 2;
 __host__ __device__ inline int chainWaveClassOf(uint32_t hits)
 {
-    return hits <= CHAIN_WAVE_CAPACITY[0] ? 0 : (hits <= CHAIN_WAVE_CAPACITY[1] ? 1 : (hits <= CHAIN_WAVE_CAPACITY[2] ? 2 : -1));
+    for(int c = 0; c < CHAIN_WAVE_CLASSES; c++) if(hits <= CHAIN_WAVE_CAPACITY[c]) return c;
+    return -1;
 }
 
 __device__ __forceinline__ void noteGiveUp(DpControl* control, int why, const PairDesc& pd, const DpTask& task)
@@ -89,7 +93,8 @@ template<int MAX_STREAM, int MIN_STREAM>
 __global__ void __launch_bounds__(256)
 sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta,
-    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control, bool noLaneKernel)
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control, bool noLaneKernel,
+    uint32_t* __restrict__ waveLists)
 {
     static_assert(MAX_STREAM <= int(SPARSE_MAX_STREAM) && MIN_STREAM < MAX_STREAM && MAX_STREAM % 8 == 0, "classes of the tabled read's markers");
     __shared__ uint32_t counts[4][MAX_STREAM / 8], cursors[4][MAX_STREAM / 8];
@@ -187,7 +192,11 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
     } else {
         for(uint32_t i0 = 0; i0 < count; i0 += WAVE) { const uint32_t i = i0 + uint32_t(lane); placeHit(list[i < count ? i : 0u], i < count); }
     }
-    if(lane == 0) { inBand[t] = total; state[t] = SPARSE_SORTED; }
+    if(lane == 0) {
+        inBand[t] = total; state[t] = SPARSE_SORTED;
+        const int cls = chainWaveClassOf(total);
+        if(waveLists && cls >= CHAIN_WAVE_LISTED_FROM) waveLists[uint64_t(cls - 1) * taskCount + atomicAdd(&control->retryCount[cls], 1u)] = t;
+    }
 }
 
 // Ring entry: {p << 16 | s,  (D + SPARSE_D_BIAS) | (prefix maximum - D, 1023 = not held) << 20 | (two or more optimal chains end here) << 30}.
