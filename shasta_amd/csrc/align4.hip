@@ -1392,12 +1392,27 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 unsigned long long info[CELLS_PREPARE_INFO];
                 HIP_CHECK(hipMemcpyAsync(info, b.prepareInfo.data(), sizeof(info), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
-                for(int c = 0; c < CELLS_CLASSES; c++) {
-                    const uint32_t count = uint32_t(info[c + 1] - info[c]);
-                    if(count == 0) continue;
-                    firstRoundAny = true;
-                    launchCellsChunks(ctx, ws, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[CELLS_INFO_BYTES + c], info[CELLS_INFO_CANDIDATES + c], hitLists);
+                // The classes with the large tables (one or two workgroups per CU: 140 KB of LDS in the last) hold few candidates and wait long
+                // for whole CUs while other workers' kernels run -- 0.37 ms alone, 3.9 ms in a step for the last class's 275 candidates
+                // (profiles/r05_call19.log).  SHASTA_MI355X_CELLS_SIDE_FROM=<class> puts the classes from that one on on the worker's side
+                // stream, beside the first classes' launches; measured: 137.7 / 136.7 / 137.4 ms per step with 3 / 2 / none
+                // (profiles/r05_call20.log) -- no difference, so none is the default (4).
+                static const int sideFrom = [] { const char* e = std::getenv("SHASTA_MI355X_CELLS_SIDE_FROM"); return e ? std::atoi(e) : 4; }();
+                bool onSide = false;
+                for(int pass = 0; pass < 2; pass++) {
+                    for(int c = 0; c < CELLS_CLASSES; c++) {
+                        const bool side = ws.wide != nullptr && c >= sideFrom;
+                        if(side != (pass == 0)) continue;                 // (the side stream's launches first: they wait longest)
+                        const uint32_t count = uint32_t(info[c + 1] - info[c]);
+                        if(count == 0) continue;
+                        firstRoundAny = true;
+                        const WorkStream where{side ? ws.wide : ws.stream, ws.sortWs, ws.wide};
+                        launchCellsChunks(ctx, where, b, c, b.chunks.data() + info[c], count, opt, magicX, magicY, taskCapacity, info[CELLS_INFO_BYTES + c], info[CELLS_INFO_CANDIDATES + c], hitLists);
+                        onSide = onSide || side;
+                    }
+                    if(pass == 0 && onSide) HIP_CHECK(hipEventRecord(w.ev.join, ws.wide));
                 }
+                if(onSide) HIP_CHECK(hipStreamWaitEvent(stream, w.ev.join, 0));
                 firstRoundLaunched = true;
                 members.assign(n, 0);                       // (positions 0 .. n-1 of the device's list: later rounds append after them)
                 membersUploaded = n;
