@@ -147,6 +147,17 @@ def pmc_of(pmc, name):
     for k, v in pmc.items():
         if k.replace(" ", "") == key:
             return v
+    # A row of the kernel table that stands for one launch of each of several template instances (the wave kernel's capacity
+    # classes, the anchor kernel's two launches, the sort kernel's two): their per-launch counters added up.
+    parts = [v for k, v in pmc.items() if k.replace(" ", "").startswith(key + "<")]
+    if parts and "<" not in key:
+        total = {}
+        for v in parts:
+            for field in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "valu_wave_instructions_per_launch"):
+                if v.get(field) is not None:
+                    total[field] = total.get(field, 0.0) + v[field]
+        total["instances"] = len(parts)
+        return total
     return None
 
 
