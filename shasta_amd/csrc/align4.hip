@@ -1089,21 +1089,27 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     // markers of its candidates, not with their number, and 2^18 candidates of the ultra-long shape (15 000 markers a pair against
     // 3 000) asked the six workers for more than the 288 GB (round 5, bench.py --workload ul).  So a batch also ends at 4 000 markers
     // per candidate of a full batch: the 100 k-read workload's batches stay what they were.
-    std::vector<uint64_t> batchStart(1, 0);
+    // The batches are cut from the END of the list backwards, so that the short one (what is left over) is the FIRST: a batch's
+    // results go straight to their place in the caller-visible arrays only when every batch before it has said how much it puts out,
+    // and a short LAST batch finished before its full-size predecessor had -- its 50-odd MB were then copied by one thread after the
+    // device had gone idle, 5 to 11 ms of a 130 ms call (round 5, SHASTA_MI355X_LOG_HOST=1).
+    std::vector<uint64_t> batchStart;
     {
         const uint64_t markerBudget = BATCH * 4000ULL;
         uint64_t count = 0, markers = 0;
-        for(uint64_t k = 0; k < candidateCount; k++) {
+        batchStart.push_back(candidateCount);
+        for(uint64_t k = candidateCount; k-- > 0; ) {
             const shasta_oriented_read_pair& c = candidates[k];
             uint64_t pairMarkers = 0;
             if(c.readIds[0] < ctx.readCount && c.readIds[1] < ctx.readCount) {       // (an invalid candidate is reported by the batch that meets it)
                 const uint64_t o0 = 2ULL * c.readIds[0], o1 = 2ULL * c.readIds[1];
                 pairMarkers = (ctx.hostToc[o0 + 1] - ctx.hostToc[o0]) + (ctx.hostToc[o1 + 1] - ctx.hostToc[o1]);
             }
-            if(count && (count == BATCH || markers + pairMarkers > markerBudget)) { batchStart.push_back(k); count = 0; markers = 0; }
+            if(count && (count == BATCH || markers + pairMarkers > markerBudget)) { batchStart.push_back(k + 1); count = 0; markers = 0; }
             ++count; markers += pairMarkers;
         }
-        if(candidateCount) batchStart.push_back(candidateCount);
+        if(batchStart.back() != 0) batchStart.push_back(0);
+        std::reverse(batchStart.begin(), batchStart.end());
     }
     const uint64_t batchCount = batchStart.size() - 1;
 
@@ -1155,11 +1161,15 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         workers[k].scratch = static_cast<BatchScratch*>(ctx.alignScratch[k].get());
         if(!ctx.wideStream[k]) HIP_CHECK(hipStreamCreateWithFlags(&ctx.wideStream[k], hipStreamNonBlocking));
         workers[k].wide = ctx.wideStream[k];
-        workers[k].ev.create();
+        workers[k].ev.fork = ctx.alignEvent(3 + 2 * size_t(k)); workers[k].ev.join = ctx.alignEvent(4 + 2 * size_t(k));       // (the context's, kept from call to call)
     }
     hipEvent_t evBegin, evEnd, evOther;
-    HIP_CHECK(hipEventCreate(&evBegin)); HIP_CHECK(hipEventCreate(&evEnd)); HIP_CHECK(hipEventCreate(&evOther));
+    evBegin = ctx.alignEvent(0); evEnd = ctx.alignEvent(1); evOther = ctx.alignEvent(2);
     HIP_CHECK(hipEventRecord(evBegin, ctx.stream));
+    // SHASTA_MI355X_LOG_HOST=1: where the call's wall clock goes on the host (ms since entry), on stderr.
+    static const bool logHost = std::getenv("SHASTA_MI355X_LOG_HOST") != nullptr;
+    auto hostMs = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const double msAtBegin = hostMs();
 
     // A batch says how much it will put out (stored alignments, compressed bytes, ordinal pairs) as soon as the device has
     // told it, before the results are written and copied: its place in the caller-visible arrays is the sum over the batches
@@ -1857,8 +1867,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         HIP_CHECK(hipEventRecord(evOther, workers[k].stream));
         HIP_CHECK(hipStreamWaitEvent(ctx.stream, evOther, 0));
     }
+    const double msWorkersDone = hostMs();
     HIP_CHECK(hipEventRecord(evEnd, ctx.stream));
     HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    const double msDeviceDone = hostMs();
     // Every worker's buffers up to what any worker's batches needed, now that nothing is in flight: which worker meets which
     // batch changes from call to call, and a worker that found a mark above its buffer at the start of a batch of the NEXT call
     // reallocated there -- hipFree waits for the whole device, in the middle of that call (the second call on a context: 192 ms
@@ -1867,8 +1879,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd));
     result.deviceSeconds = ms * 1e-3;
-    (void)hipEventDestroy(evBegin); (void)hipEventDestroy(evEnd); (void)hipEventDestroy(evOther);
-    for(Worker& w : workers) w.ev.destroy();
+    // (the events are the context's: nothing to destroy)
     for(Worker& w : workers) if(!w.error.empty()) throw std::runtime_error(w.error);
 
 #ifdef SHASTA_PROFILE_PHASES
@@ -1923,7 +1934,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     MI355X_ASSERT(nextToPlace == batchCount && placeRows == rowTotal && placeBytes == byteTotalAll);
     auto assemble = [&](uint64_t first, uint64_t stride) {
         for(uint64_t k = first; k < batchCount; k += stride) {
-            if(!placements[k].placed) copyBatch(k, placements[k], result.alignmentData, result.compressedToc, result.compressedData, result.ordinalsToc, result.ordinals);
+            // (one or two batches left: each copy in slices on several threads instead of the batches side by side)
+            if(!placements[k].placed) copyBatch(k, placements[k], result.alignmentData, result.compressedToc, result.compressedData, result.ordinalsToc, result.ordinals, stride <= 2 ? 4 : 1);
         }
     };
     {
@@ -1942,6 +1954,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     result.kmerIdBytes = kmerIdBytes;
     result.alignedBytes = alignedBytes;
     result.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if(logHost) std::fprintf(stderr, "alignRun host clock: first event at %.2f ms, workers joined at %.2f, device done at %.2f, return at %.2f (%llu batches)\n",
+        msAtBegin, msWorkersDone, msDeviceDone, result.seconds * 1e3, (unsigned long long)batchCount);
 }
 
 }  // namespace

@@ -46,6 +46,15 @@ struct Context {
     // (hipFuncSetAttribute acts on the current device; the aligner's workers may get there at the same time).
     std::once_flag cellsLdsAttribute[2], cellsDumpLdsAttribute, wideDpLdsAttribute, palindromicLdsAttribute;      // per context = per device (hipFuncSetAttribute is per device)
     KernelTimers timers;                     // per-kernel HIP-event times since the last reset (shasta_mi355x_kernel_table)
+    // The aligner's own events (a call's begin / end / join, two per worker): made once and kept -- fifteen hipEventCreate at the head
+    // of every call and fifteen hipEventDestroy at its end were 4 + 5-10 ms of a 130 ms call on the host's clock (round 5,
+    // SHASTA_MI355X_LOG_HOST=1).  Index: 0-2 the call's, 3 + 2 k and 4 + 2 k worker k's.
+    std::vector<hipEvent_t> alignEvents;
+    hipEvent_t alignEvent(size_t index)
+    {
+        while(alignEvents.size() <= index) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); alignEvents.push_back(e); }
+        return alignEvents[index];
+    }
 
     explicit Context(int device);
     ~Context();

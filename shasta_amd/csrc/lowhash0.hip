@@ -684,6 +684,7 @@ Context::~Context()
     for(auto& scratch : alignScratch) scratch.reset();
     lowhashJob.reset();
     lowhashBuffers.reset();
+    for(hipEvent_t e : alignEvents) (void)hipEventDestroy(e);
     for(hipStream_t w : workerStream) if(w) (void)hipStreamDestroy(w);
     for(hipStream_t w : wideStream) if(w) (void)hipStreamDestroy(w);
     if(stream) (void)hipStreamDestroy(stream);
