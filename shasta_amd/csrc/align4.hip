@@ -1095,18 +1095,39 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
     // device had gone idle, 5 to 11 ms of a 130 ms call (round 5, SHASTA_MI355X_LOG_HOST=1).
     std::vector<uint64_t> batchStart;
     {
+        // (in blocks of 4 096 candidates counted from the end, their markers summed by four threads: one thread over two million
+        // candidates was 3 ms at the head of every call)
         const uint64_t markerBudget = BATCH * 4000ULL;
+        const uint64_t BLOCK = std::max<uint64_t>(1, std::min<uint64_t>(4096, BATCH / 8));      // (a batch is a whole number of blocks)
+        const uint64_t blocks = (candidateCount + BLOCK - 1) / BLOCK;
+        std::vector<uint64_t> blockMarkers(size_t(blocks), 0);
+        auto sumBlocks = [&](uint64_t first, uint64_t stride) {
+            for(uint64_t j = first; j < blocks; j += stride) {
+                const uint64_t end = candidateCount - j * BLOCK, begin = end > BLOCK ? end - BLOCK : 0;
+                uint64_t markers = 0;
+                for(uint64_t k = begin; k < end; k++) {
+                    const shasta_oriented_read_pair& c = candidates[k];
+                    if(c.readIds[0] < ctx.readCount && c.readIds[1] < ctx.readCount) {       // (an invalid candidate is reported by the batch that meets it)
+                        const uint64_t o0 = 2ULL * c.readIds[0], o1 = 2ULL * c.readIds[1];
+                        markers += (ctx.hostToc[o0 + 1] - ctx.hostToc[o0]) + (ctx.hostToc[o1 + 1] - ctx.hostToc[o1]);
+                    }
+                }
+                blockMarkers[size_t(j)] = markers;
+            }
+        };
+        {
+            const uint64_t threads = blocks >= 64 ? 4 : 1;
+            std::vector<std::thread> others;
+            for(uint64_t k = 1; k < threads; k++) others.emplace_back(sumBlocks, k, threads);
+            sumBlocks(0, threads);
+            for(std::thread& t : others) t.join();
+        }
         uint64_t count = 0, markers = 0;
         batchStart.push_back(candidateCount);
-        for(uint64_t k = candidateCount; k-- > 0; ) {
-            const shasta_oriented_read_pair& c = candidates[k];
-            uint64_t pairMarkers = 0;
-            if(c.readIds[0] < ctx.readCount && c.readIds[1] < ctx.readCount) {       // (an invalid candidate is reported by the batch that meets it)
-                const uint64_t o0 = 2ULL * c.readIds[0], o1 = 2ULL * c.readIds[1];
-                pairMarkers = (ctx.hostToc[o0 + 1] - ctx.hostToc[o0]) + (ctx.hostToc[o1 + 1] - ctx.hostToc[o1]);
-            }
-            if(count && (count == BATCH || markers + pairMarkers > markerBudget)) { batchStart.push_back(k + 1); count = 0; markers = 0; }
-            ++count; markers += pairMarkers;
+        for(uint64_t j = 0; j < blocks; j++) {
+            const uint64_t end = candidateCount - j * BLOCK, begin = end > BLOCK ? end - BLOCK : 0;
+            if(count && (count + (end - begin) > BATCH || markers + blockMarkers[size_t(j)] > markerBudget)) { batchStart.push_back(end); count = 0; markers = 0; }
+            count += end - begin; markers += blockMarkers[size_t(j)];
         }
         if(batchStart.back() != 0) batchStart.push_back(0);
         std::reverse(batchStart.begin(), batchStart.end());
