@@ -115,6 +115,10 @@ private:
         if(logAllocations) std::fprintf(stderr, "shasta_mi355x: device buffer %zu -> %zu bytes at %.1f ms\n", cap * sizeof(T), newCap * sizeof(T),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());      // (the clock of python's time.monotonic())
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&q), newCap * sizeof(T)));
+        // SHASTA_MI355X_POISON=<byte>: every new device buffer filled with that byte (a test switch: a kernel that reads memory nothing
+        // wrote gives results that change with the value; fresh hipMalloc memory otherwise holds whatever the process freed before).
+        static const int poison = [] { const char* e = std::getenv("SHASTA_MI355X_POISON"); return e ? int(std::strtol(e, nullptr, 0)) & 0xff : -1; }();
+        if(poison >= 0) { HIP_CHECK(hipMemsetAsync(q, poison, newCap * sizeof(T), stream)); HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipDeviceSynchronize()); }
         if(keep && p && cap) {
             HIP_CHECK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipStreamSynchronize(stream));

@@ -87,13 +87,23 @@ def same_lowhash(a, b):
     assert a.log2_bucket_count == b.log2_bucket_count
 
 
+def _where_ordinals_differ(a, b):
+    """For the assertion's message: the first candidate whose aligned pairs differ, how many values differ in all, the two lists there."""
+    x, y = np.asarray(a.ordinals).reshape(-1), np.asarray(b.ordinals).reshape(-1)
+    d = np.nonzero(x != y)[0]
+    toc = np.asarray(a.ordinals_toc).astype(np.int64)
+    k = int(np.searchsorted(toc, d[0] // 2, side="right") - 1)
+    lo, hi = 2 * int(toc[k]), 2 * int(toc[k + 1])
+    return "aligned pairs differ in %d values; first at candidate %d (pairs %d..%d): %s  vs  %s" % (len(d), k, lo // 2, hi // 2, x[lo:hi][:40].tolist(), y[lo:hi][:40].tolist())
+
+
 def same_align(a, b, ties_ok=True):
     sa, sb = a.status & 0x7f, b.status & 0x7f
     assert np.array_equal(sa, sb)
     assert np.array_equal(a.status & 0x80, b.status & 0x80)
     if a.ordinals_toc is not None and b.ordinals_toc is not None:
         assert np.array_equal(a.ordinals_toc, b.ordinals_toc)
-        assert np.array_equal(a.ordinals, b.ordinals)
+        assert np.array_equal(a.ordinals, b.ordinals), _where_ordinals_differ(a, b)
     assert np.array_equal(a.info_table(), b.info_table())
     assert np.array_equal(a.compressed_toc, b.compressed_toc)
     assert np.array_equal(a.compressed_data, b.compressed_data)
