@@ -43,9 +43,10 @@ constexpr uint32_t ANCHOR_GRID = 4096;           // workgroups of one wavefront;
 // What a wavefront holds of its task.  Two sizes: the first launch's (22 KB: seven workgroups per CU) and, for the few tasks with a
 // rectangle beyond it (0.3 % of the tasks at 100 k reads: they went to the dense kernels, a handful of wavefronts per launch, 60 ms of
 // launches per step for 0.1 % of the DP cells), a second launch's (118 KB, dynamic LDS, one workgroup per CU).
-template<int MAX_CELLS, int MAX_SIDE, int MAX_PAIRS>
+template<int MAX_CELLS, int MAX_SIDE, int MAX_PAIRS, bool BAND_TRACE = false>
 struct AnchorSharedT {
     static constexpr int maxCells = MAX_CELLS, maxSide = MAX_SIDE, maxPairs = MAX_PAIRS;
+    static constexpr bool bandTrace = BAND_TRACE;        // the trace holds the band's cells only, two bits each (anchorRectangleBand)
     uint64_t live[ANCHOR_MAX_BITWORDS], anchor[ANCHOR_MAX_BITWORDS];
     uint8_t trace[MAX_CELLS];                    // [i * (wy + 1) + j]: move (DpTie::Move) | markers equal << 2
     int32_t row[2][MAX_SIDE + 1];                // H of the previous and of the current row
@@ -56,8 +57,10 @@ struct AnchorSharedT {
     uint32_t windowPairs[ANCHOR_MAX_WINDOWS], windowBegin[ANCHOR_MAX_WINDOWS];
 };
 using AnchorShared = AnchorSharedT<ANCHOR_MAX_CELLS, ANCHOR_MAX_SIDE, ANCHOR_MAX_PAIRS>;
-constexpr int ANCHOR_BIG_CELLS = 65536, ANCHOR_BIG_SIDE = 2047, ANCHOR_BIG_PAIRS = 2048;
-using AnchorSharedBig = AnchorSharedT<ANCHOR_BIG_CELLS, ANCHOR_BIG_SIDE, ANCHOR_BIG_PAIRS>;
+// The second launch: 64 KB of trace = 262 144 cells of the BAND at two bits (a rectangle that is most of a task -- a task with hardly any
+// anchor -- has a million cells, of which the band holds a tenth), sides of up to 3 071 markers, 4 096 pairs.
+constexpr int ANCHOR_BIG_CELLS = 65536, ANCHOR_BIG_SIDE = 3071, ANCHOR_BIG_PAIRS = 4096;
+using AnchorSharedBig = AnchorSharedT<ANCHOR_BIG_CELLS, ANCHOR_BIG_SIDE, ANCHOR_BIG_PAIRS, true>;
 static_assert(sizeof(AnchorSharedBig) <= 160 * 1024, "the second launch's LDS");
 
 __device__ __forceinline__ uint64_t bitsFrom(int b) { return b >= 64 ? 0ULL : ~0ULL << b; }       // bits b .. 63
@@ -172,6 +175,133 @@ __device__ int32_t anchorRectangle(Shared& sh, const uint32_t* __restrict__ p0, 
             --i; --j;
             if(t & 4u) {
                 if(begin + uint32_t(found) >= uint32_t(Shared::maxPairs)) return -1;        // (-1: the pairs do not fit)
+                if(lane == 0) sh.pairs[begin + uint32_t(found)] = (uint32_t(x0 + i) << 16) | uint32_t(y0 + j);
+                ++found;
+            }
+        }
+        else if(move == Tie::VERTICAL) --j;
+        else --i;
+    }
+    waveLdsSync();
+    if(beginFixed && (i != 0 || j != 0)) return -2;
+    return found;
+}
+
+// The same rectangle for the second launch: only the cells inside the band are computed (a row's chunks of 64 columns that the band
+// touches, one more column than it holds so that the cell behind its upper end reads as "outside" in the next row) and only they are
+// traced, two bits each at (row, column - the band's lower end in that row); whether a diagonal step aligns equal markers is read
+// from the markers when the path is walked.  Returns the number of aligned pairs, -1 (the pairs do not fit), -2 (the walk contradicts
+// the anchors) or -3 (the band's cells do not fit the trace).
+template<int TIE, class Shared>
+__device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1,
+    int32_t x0, int32_t x1, int32_t y0, int32_t y1, bool beginFixed, bool endFixed, int32_t bandMin, int32_t bandMax, uint32_t begin, int lane)
+{
+    using Tie = DpTie<TIE>;
+    const int32_t wx = x1 - x0 + 1, wy = y1 - y0 + 1;
+    const int32_t bandWidth = bandMax - bandMin + 1, rowWords = (bandWidth + 15) / 16;
+    uint32_t* const traceWords = reinterpret_cast<uint32_t*>(sh.trace);
+    if(int64_t(wx + 1) * rowWords > int64_t(Shared::maxCells / 4)) return -3;
+    for(int32_t a = lane; a < wx; a += WAVE) sh.kmers0[a] = p0[x0 + a];
+    for(int32_t a = lane; a < wy; a += WAVE) sh.kmers1[a] = p1[y0 + a];
+    for(int32_t a = lane; a < (wx + 1) * rowWords; a += WAVE) traceWords[a] = 0;
+    const int32_t shift = x0 - y0;
+    auto jLow = [&](int32_t i) { return max(0, i + shift - bandMax); };
+    auto jHigh = [&](int32_t i) { return min(wy, i + shift - bandMin); };
+    auto bandBase = [&](int32_t i) { return i + shift - bandMax; };                  // the column of the band's lowest diagonal in row i (may be negative)
+    auto putMove = [&](int32_t i, int32_t j, int move) {
+        const int32_t b = j - bandBase(i);
+        atomicOr(&traceWords[i * rowWords + (b >> 4)], uint32_t(move) << (2 * (b & 15)));
+    };
+    waveLdsSync();
+    {
+        const int32_t lo = jLow(0), hi = jHigh(0);
+        for(int32_t j = lane; j <= wy; j += WAVE) {
+            const bool in = j >= lo && j <= hi;
+            sh.row[0][j] = !in ? ANCHOR_NEG : (beginFixed ? -j : 0);
+            if(in) putMove(0, j, Tie::VERTICAL);
+        }
+        if(lane == 0) sh.lastColumn[0] = (wy >= lo && wy <= hi) ? (beginFixed ? -wy : 0) : ANCHOR_NEG;
+    }
+    waveLdsSync();
+    for(int32_t i = 1; i <= wx; i++) {
+        const int32_t* const previous = sh.row[(i - 1) & 1];
+        int32_t* const current = sh.row[i & 1];
+        const int32_t lo = jLow(i), hi = jHigh(i);
+        const uint32_t k0 = sh.kmers0[i - 1];
+        int32_t carry = 2 * ANCHOR_NEG;                     // the largest c(j') + j' of the chunks before
+        const int32_t firstBase = (lo / WAVE) * WAVE, lastColumnVisited = min(wy, hi + 1);
+        if(lane == 0 && lastColumnVisited < wy) sh.lastColumn[i] = ANCHOR_NEG;       // (the last column lies outside the band in this row)
+        for(int32_t jBase = firstBase; jBase <= lastColumnVisited; jBase += WAVE) {
+            const int32_t j = jBase + lane;
+            const bool in = j >= lo && j <= hi;
+            int32_t diagonal = ANCHOR_NEG, horizontal = ANCHOR_NEG;
+            bool equal = false;
+            if(in && j <= wy) {
+                const int32_t h0 = previous[j];
+                horizontal = h0 <= ANCHOR_NEG ? ANCHOR_NEG : h0 - 1;
+                if(j > 0) {
+                    const int32_t d0 = previous[j - 1];
+                    equal = k0 == sh.kmers1[j - 1];
+                    diagonal = d0 <= ANCHOR_NEG ? ANCHOR_NEG : d0 + (equal ? MATCH_SCORE : MISMATCH_SCORE);
+                }
+                else if(!beginFixed) horizontal = 0;        // the free border: H(i, 0) = 0
+            }
+            const int32_t c = max(diagonal, horizontal);
+            const int32_t scanned = max(waveMaxScan(c + j, lane), carry);
+            carry = __shfl(scanned, WAVE - 1, WAVE);
+            int32_t h = scanned - j;
+            if(!in || j > wy || h <= ANCHOR_NEG / 2) h = ANCHOR_NEG;
+            int32_t left = __shfl_up(h, 1, WAVE);            // H(i, j - 1)
+            if(lane == 0) left = jBase > firstBase ? current[jBase - 1] : ANCHOR_NEG;     // (before the first chunk the row is outside the band)
+            const int32_t vertical = (j == 0 || left <= ANCHOR_NEG) ? ANCHOR_NEG : left - 1;
+            int move;
+            if(j == 0) move = Tie::HORIZONTAL;
+            else {
+                bool attains[3];
+                attains[Tie::DIAGONAL] = diagonal == h; attains[Tie::VERTICAL] = vertical == h; attains[Tie::HORIZONTAL] = horizontal == h;
+                move = attains[Tie::first] ? Tie::first : (attains[Tie::second] ? Tie::second : Tie::third);
+            }
+            if(j <= wy) {
+                current[j] = h;
+                if(in) putMove(i, j, move);
+                if(j == wy) sh.lastColumn[i] = h;
+            }
+            waveLdsSync();                                   // (lane 0 of the next chunk reads current[jBase - 1])
+        }
+    }
+    int32_t i = wx, j = wy;
+    const bool cornerInBand = wy >= jLow(wx) && wy <= jHigh(wx);
+    if(endFixed && (!cornerInBand || sh.row[wx & 1][wy] <= ANCHOR_NEG)) return -2;
+    if(!endFixed) {
+        const int32_t* const last = sh.row[wx & 1];
+        const int32_t total = wx + wy + 1;
+        const int32_t lastLo = jLow(wx), lastHi = jHigh(wx);
+        int32_t bestScore = ANCHOR_NEG, bestAt = Tie::lastMaximum ? -1 : 0x7fffffff;
+        for(int32_t a = lane; a < total; a += WAVE) {
+            // (the last row's buffer holds this row's values only where the band is)
+            const int32_t score = a < wx ? sh.lastColumn[a] : ((a - wx >= lastLo && a - wx <= lastHi) ? last[a - wx] : ANCHOR_NEG);
+            if(score <= ANCHOR_NEG) continue;
+            if(score > bestScore || (score == bestScore && (Tie::lastMaximum ? a > bestAt : a < bestAt))) { bestScore = score; bestAt = a; }
+        }
+#pragma unroll
+        for(int d = 32; d >= 1; d >>= 1) {
+            const int32_t otherScore = __shfl_xor(bestScore, d, WAVE), otherAt = __shfl_xor(bestAt, d, WAVE);
+            if(otherScore > bestScore || (otherScore == bestScore && otherScore > ANCHOR_NEG && (Tie::lastMaximum ? otherAt > bestAt : otherAt < bestAt))) { bestScore = otherScore; bestAt = otherAt; }
+        }
+        if(bestScore <= ANCHOR_NEG) return 0;
+        if(bestAt < wx) { i = bestAt; j = wy; } else { i = wx; j = bestAt - wx; }
+    }
+    // The traceback: the same walk in every lane (LDS reads of one address), lane 0 writes.
+    int32_t found = 0;
+    for(int32_t steps = 0; steps <= wx + wy + 1; steps++) {
+        if(beginFixed ? (i == 0 && j == 0) : (i == 0 || j == 0)) break;
+        const int32_t b = j - bandBase(i);
+        if(b < 0 || b >= bandWidth) return -2;               // (the walk left the band: it cannot)
+        const int move = int((traceWords[i * rowWords + (b >> 4)] >> (2 * (b & 15))) & 3u);
+        if(move == Tie::DIAGONAL) {
+            --i; --j;
+            if(sh.kmers0[i] == sh.kmers1[j]) {
+                if(begin + uint32_t(found) >= uint32_t(Shared::maxPairs)) return -1;
                 if(lane == 0) sh.pairs[begin + uint32_t(found)] = (uint32_t(x0 + i) << 16) | uint32_t(y0 + j);
                 ++found;
             }
@@ -311,9 +441,11 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
             if(from >= 0) { hitAt(from, x0, y0); ++x0; ++y0; }
             if(to < n) { hitAt(to, x1, y1); --x1; --y1; }
             const int32_t wx = x1 - x0 + 1, wy = y1 - y0 + 1;
-            if(wx < 1 || wy < 1 || wx > Shared::maxSide || wy > Shared::maxSide || (wx + 1) * (wy + 1) > Shared::maxCells) { fits = false; tooBig = true; break; }
-            const int32_t found = anchorRectangle<TIE>(sh, p0, p1, x0, x1, y0, y1, from >= 0, to < n, task.bandMin, task.bandMax, windowPairsTotal, lane);
-            if(found < 0) { fits = false; tooBig = true; why = found == -1 ? GIVE_UP_RECTANGLE_PAIRS : GIVE_UP_RECTANGLE_WALK; break; }       // (the pairs did not fit, or the walk contradicted the anchors: the larger form tries once more)
+            if(wx < 1 || wy < 1 || wx > Shared::maxSide || wy > Shared::maxSide || (!Shared::bandTrace && (wx + 1) * (wy + 1) > Shared::maxCells)) { fits = false; tooBig = true; break; }
+            int32_t found;
+            if constexpr (Shared::bandTrace) found = anchorRectangleBand<TIE>(sh, p0, p1, x0, x1, y0, y1, from >= 0, to < n, task.bandMin, task.bandMax, windowPairsTotal, lane);
+            else found = anchorRectangle<TIE>(sh, p0, p1, x0, x1, y0, y1, from >= 0, to < n, task.bandMin, task.bandMax, windowPairsTotal, lane);
+            if(found < 0) { fits = false; tooBig = true; why = found == -1 ? GIVE_UP_RECTANGLE_PAIRS : (found == -2 ? GIVE_UP_RECTANGLE_WALK : GIVE_UP_RECTANGLE); break; }       // (the pairs did not fit, or the walk contradicted the anchors: the larger form tries once more)
             if(lane == 0) { sh.windowBegin[w] = windowPairsTotal; sh.windowPairs[w] = uint32_t(found); }
             windowPairsTotal += uint32_t(found);
         }

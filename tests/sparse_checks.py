@@ -271,11 +271,11 @@ def wave_kernel_forms(lib, orc):
     return compared
 
 
-def inverted_block_tasks(blocks=(20, 70, 71, 120, 300), flank=220, seed=17):
+def inverted_block_tasks(blocks=(20, 70, 71, 120, 300, 3200), flank=220, seed=17):
     """Two reads that agree except for one block of m markers which the second read has in REVERSED order: every chain can take one
     match of the block, the two in its middle tie (m even) -- two optimal chains, and between the anchors before and behind the block
-    a rectangle of (m + 1)^2 cells: within the anchor kernel's first launch (4 096 cells) for m = 20, its second (65 536) for 70 to
-    120, beyond both for 300 (the dense kernels)."""
+    a rectangle of (m + 1)^2 cells: within the anchor kernel's first launch (4 096 cells) for m = 20, its second (the band's cells at
+    two bits each, sides of up to 3 071 markers) for 70 to 300, beyond both for 3 200 (the dense kernels)."""
     rng = np.random.default_rng(seed)
     pieces, spec, at = [], [], 0
     for m in blocks:
@@ -285,6 +285,15 @@ def inverted_block_tasks(blocks=(20, 70, 71, 120, 300), flank=220, seed=17):
         pieces += [a, b]
         spec.append((at, len(a), at + len(a), len(b), -40, 40))
         at += len(a) + len(b)
+    # The same block at the very beginning and at the very end of the reads: rectangles with a free border on one side.
+    for where in ("begin", "end"):
+        for m in (30, 150):
+            ids = rng.permutation(1 << 20)[:flank + m].astype(np.uint32)
+            a = ids
+            b = np.concatenate([ids[:m][::-1], ids[m:]]) if where == "begin" else np.concatenate([ids[:flank], ids[flank:][::-1]])
+            pieces += [a, b]
+            spec.append((at, len(a), at + len(a), len(b), -40, 40))
+            at += len(a) + len(b)
     return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
 
 

@@ -35,7 +35,7 @@ def test_the_wave_kernel_against_the_forms_it_can_be_switched_to(gpu_lib, oracle
 
 
 def test_the_anchor_kernel_second_launch(gpu_lib, oracle_lib):
-    # Rectangles of 441, 5 041, 5 184, 14 641 and 90 601 cells between two anchors: with the second launch only the last one's task is
-    # left to the dense kernels, without it the last four.
+    # Rectangles of 441 to 90 601 cells and one with sides of 3 201 markers between two anchors: with the second launch only the last
+    # one's task is left to the dense kernels, without it the last five.
     with_second, without = sparse_checks.anchor_kernel_second_launch(gpu_lib, oracle_lib)
     assert 0 < with_second < without
