@@ -230,7 +230,10 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
         const uint32_t k0 = sh.kmers0[i - 1];
         int32_t carry = 2 * ANCHOR_NEG;                     // the largest c(j') + j' of the chunks before
         const int32_t firstBase = (lo / WAVE) * WAVE, lastColumnVisited = min(wy, hi + 1);
-        if(lane == 0 && lastColumnVisited < wy) sh.lastColumn[i] = ANCHOR_NEG;       // (the last column lies outside the band in this row)
+        // (a row the band does not touch at all -- beyond the shorter side of a rectangle that ends at the free border -- or does not
+        // reach the last column in: H(i, wy) is "outside")
+        if(lane == 0 && (lo > hi || lastColumnVisited < wy)) sh.lastColumn[i] = ANCHOR_NEG;
+        if(lo > hi) continue;
         for(int32_t jBase = firstBase; jBase <= lastColumnVisited; jBase += WAVE) {
             const int32_t j = jBase + lane;
             const bool in = j >= lo && j <= hi;
@@ -269,9 +272,15 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
             waveLdsSync();                                   // (lane 0 of the next chunk reads current[jBase - 1])
         }
     }
+    waveLdsSync();                                           // (rows the band does not touch end without one; the end cells are read by all lanes)
     int32_t i = wx, j = wy;
     const bool cornerInBand = wy >= jLow(wx) && wy <= jHigh(wx);
-    if(endFixed && (!cornerInBand || sh.row[wx & 1][wy] <= ANCHOR_NEG)) return -2;
+    if(endFixed && (!cornerInBand || sh.row[wx & 1][wy] <= ANCHOR_NEG)) {
+#ifdef ANCHOR_DEBUG
+        if(lane == 0) std::fprintf(stderr, "band rectangle: end corner unreachable: wx %d wy %d shift %d band [%d, %d] cornerInBand %d value %d beginFixed %d\n", wx, wy, shift, bandMin, bandMax, int(cornerInBand), sh.row[wx & 1][wy], int(beginFixed));
+#endif
+        return -2;
+    }
     if(!endFixed) {
         const int32_t* const last = sh.row[wx & 1];
         const int32_t total = wx + wy + 1;
@@ -296,7 +305,12 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
     for(int32_t steps = 0; steps <= wx + wy + 1; steps++) {
         if(beginFixed ? (i == 0 && j == 0) : (i == 0 || j == 0)) break;
         const int32_t b = j - bandBase(i);
-        if(b < 0 || b >= bandWidth) return -2;               // (the walk left the band: it cannot)
+        if(b < 0 || b >= bandWidth) {
+#ifdef ANCHOR_DEBUG
+            if(lane == 0) std::fprintf(stderr, "band rectangle: walk left the band at (%d, %d) b %d after %d steps: wx %d wy %d shift %d band [%d, %d] beginFixed %d endFixed %d x0 %d y0 %d\n", i, j, b, steps, wx, wy, shift, bandMin, bandMax, int(beginFixed), int(endFixed), x0, y0);
+#endif
+            return -2;               // (the walk left the band: it cannot)
+        }
         const int move = int((traceWords[i * rowWords + (b >> 4)] >> (2 * (b & 15))) & 3u);
         if(move == Tie::DIAGONAL) {
             --i; --j;
@@ -310,7 +324,12 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
         else --i;
     }
     waveLdsSync();
-    if(beginFixed && (i != 0 || j != 0)) return -2;
+    if(beginFixed && (i != 0 || j != 0)) {
+#ifdef ANCHOR_DEBUG
+        if(lane == 0) std::fprintf(stderr, "band rectangle: walk ended at (%d, %d): wx %d wy %d shift %d band [%d, %d] endFixed %d\n", i, j, wx, wy, shift, bandMin, bandMax, int(endFixed));
+#endif
+        return -2;
+    }
     return found;
 }
 
