@@ -654,6 +654,15 @@ def main():
                  "throttled_ms_per_step": (None if throttled0 is None or _cgroup_throttled_usec() is None
                                            else (_cgroup_throttled_usec() - throttled0) / 1e3 / max(1, args.steps))}
     table = ctx.kernel_table()
+    # What the device holds after the timed steps (the library's buffers only grow: kmer ids, LowHash0's job, six workers' scratch).
+    hbm_measured = None
+    if not DRY_RUN_LIBRARY:
+        try:
+            free_bytes, total_bytes = torch.cuda.mem_get_info(local_rank)
+            hbm_measured = {"used_GB": (total_bytes - free_bytes) / 1e9, "total_GB": total_bytes / 1e9,
+                            "what": "hipMemGetInfo after the timed steps: everything this process holds on the device (kmer ids, LowHash0 buffers, aligner workers' scratch, torch's context)"}
+        except Exception:          # noqa: BLE001
+            hbm_measured = None
     # Outside the timed region: one more pass with ONE aligner worker.  With six workers the kernels of different batches share
     # the device, and the HIP-event duration of a launch includes the time it spent sharing; this pass gives every kernel's
     # duration alone on the device (what a profiler's per-kernel view and the PMC passes see).
@@ -794,6 +803,7 @@ def main():
             out["sharded_lowhash0_phase_ms_each_step"] = [[name, ms] for name, ms in phase_log if ms >= 10.0]      # (outliers show here)
         # What a GPU must hold: this run, and BASELINE configs[3] / [4] on 8 GPUs (chr1 50x M = 1.7e9, human 50x M = 2.2e10).
         out["hbm_budget_per_gpu"] = {
+            "this_run_measured": hbm_measured,
             "this_run": hbm_budget(marker_count, args.reads * world, world),
             "configs[3] chr1 50x, 8 GPUs": hbm_budget(1.7e9, 6.2e5, 8, iterations=10),
             "configs[4] human 50x, 8 GPUs": hbm_budget(2.2e10, 7.7e6, 8, iterations=10),
