@@ -356,7 +356,8 @@ template<int CLS, bool OWN_SORT>
 void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
     constexpr uint32_t CAP = CHAIN_WAVE_CAPACITY[CLS];
-    constexpr size_t ldsBytes = size_t(CAP) * 10u + size_t(CAP) / 16u;        // (10 bytes per hit, 4 per window of 64)
+    constexpr size_t ldsBytes = size_t(CAP) * 10u + 4u * ((size_t(CAP) + 63u) / 64u);        // (10 bytes per hit, 4 per window of 64)
+    static_assert(CAP % 8 == 0, "the arrays behind the hits start at word boundaries");
     static_assert(ldsBytes <= 160u * 1024u, "a wavefront's hits in LDS");
     if(ldsBytes > 64u * 1024u) {
         // (more dynamic LDS than the default limit: the attribute once per device)

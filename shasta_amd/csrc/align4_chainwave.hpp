@@ -33,8 +33,8 @@
 // kernels, 166 ms per step against 143 (profiles/r05_call5*, r05_call3*): the sort's two passes over the candidate's list are chains of
 // dependent loads, and a wavefront that holds 10 KB of LDS while it waits for them keeps the next task's wavefront out.
 //
-// LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Four launches by capacity -- 1 024 hits (10 KB a wavefront: 87 % of the
-// tasks at 100 k reads), 2 048 (13 %), 4 096 (0.1 %), 15 360 -- the first two of wavefronts that go over the task list in blocks of
+// LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Four launches by capacity -- 1 016 hits (10 KB a wavefront: 87 % of the
+// tasks at 100 k reads), 2 032 (13 %), 4 064 (0.1 %), 15 360 -- the first two of wavefronts that go over the task list in blocks of
 // 16 and run the tasks of their class, the last two over the few tasks sparseSortKernel listed for them (a launch that went over all
 // tasks for a few hundred of them, at one wavefront per CU, took as long as the first class's); what fits none goes to the dense
 // kernels.
