@@ -285,15 +285,21 @@ def inverted_block_tasks(blocks=(20, 70, 71, 120, 300, 3200), flank=220, seed=17
         pieces += [a, b]
         spec.append((at, len(a), at + len(a), len(b), -40, 40))
         at += len(a) + len(b)
-    # The same block at the very beginning and at the very end of the reads: rectangles with a free border on one side.
-    for where in ("begin", "end"):
-        for m in (30, 150):
-            ids = rng.permutation(1 << 20)[:flank + m].astype(np.uint32)
-            a = ids
-            b = np.concatenate([ids[:m][::-1], ids[m:]]) if where == "begin" else np.concatenate([ids[:flank], ids[flank:][::-1]])
-            pieces += [a, b]
-            spec.append((at, len(a), at + len(a), len(b), -40, 40))
-            at += len(a) + len(b)
+    # Rectangles that end at the FREE border, too large for the first launch: the second read stops (or begins) inside the first one
+    # with its last (first) matching marker doubled -- two optimal ends -- and a few markers of its own beyond, so that the window
+    # between the last anchor and the border is 600 markers of the first read by 20 of the second, nearly all of it outside the band.
+    for where in ("end", "begin"):
+        g = rng.permutation(1 << 20)[:1300].astype(np.uint32)
+        own = rng.permutation(1 << 20)[:20].astype(np.uint32) + np.uint32(1 << 21)          # (ids the other read does not hold)
+        a = g
+        if where == "end":
+            b = np.concatenate([g[400:700], g[699:700], own])
+        else:
+            b = np.concatenate([own, g[600:601], g[600:900]])
+        pieces += [a, b]
+        diagonal = 400 if where == "end" else 600 - 21
+        spec.append((at, len(a), at + len(a), len(b), diagonal - 30, diagonal + 30))
+        at += len(a) + len(b)
     return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
 
 
