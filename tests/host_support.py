@@ -1,4 +1,4 @@
-"""ctypes access to the host layer's file classes (shasta_amd/host/test_shim.cpp) for the tests."""
+"""ctypes access to the host layer's file classes (tests/host_shim/test_shim.cpp) for the tests."""
 import ctypes as C
 import os
 
