@@ -15,6 +15,9 @@ emu, orc = L.Library("tests/emu/_build_asan/libshasta_mi355x_emu.so"), bindings.
 print("aligner, share of the DP cells from the matches:", sparse_checks.aligner(emu, orc, n_reads=90, limit=160), flush=True)
 print("dp tasks:", sparse_checks.dp_tasks(emu, orc, clean=30, tie_heavy=20, alternatives=(2,), long_every=44), flush=True)
 print("locally ambiguous tasks (anchor kernel):", sparse_checks.anchored_tasks(emu, orc, seeds=(3, 4, 5), tasks=24), flush=True)
+print("tiny tasks:", sparse_checks.tiny_tasks(emu, orc, tasks=150, alternatives=(2,)), flush=True)
+print("wave kernel forms (every capacity class, own ordering, side stream):", sparse_checks.wave_kernel_forms(emu, orc), flush=True)
+print("anchor kernel, second launch (dense cells with, without):", sparse_checks.anchor_kernel_second_launch(emu, orc, alternatives=(2,)), flush=True)
 for name in adversarial.READ_SET_NAMES[:-1]:
     print(name, adversarial.aligner_case(emu, orc, name, long_reads=False), flush=True)
 adversarial.lowhash0(emu, orc)
