@@ -352,11 +352,13 @@ bool chainWaveEnabled() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE"
 bool chainWaveSideStream() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SIDE"); return e && std::atoi(e) != 0; }
 // SHASTA_MI355X_CHAIN_WAVE_SORT=1: the wave kernel orders the hits itself (no sparseSortKernel); slower on the MI355X, kept for the A/B.
 bool chainWaveOwnSort() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SORT"); return e && std::atoi(e) != 0; }
-template<int CLS, bool OWN_SORT>
-void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
+// SHASTA_MI355X_CHAIN_WAVE_WIDE_D=1: D in 32 bits in every class (10 bytes of LDS per hit instead of 8: the form before, kept for the A/B).
+bool chainWaveWideD() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_WIDE_D"); return e && std::atoi(e) != 0; }
+template<int CLS, bool OWN_SORT, bool NARROW>
+void launchChainWaveClassAs(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
 {
     constexpr uint32_t CAP = CHAIN_WAVE_CAPACITY[CLS];
-    constexpr size_t ldsBytes = size_t(CAP) * 10u + 4u * ((size_t(CAP) + 63u) / 64u);        // (10 bytes per hit, 4 per window of 64)
+    constexpr size_t ldsBytes = chainWaveLdsBytes(CAP, NARROW);        // (8 or 10 bytes per hit, 4 per window of 64)
     static_assert(CAP % 8 == 0, "the arrays behind the hits start at word boundaries");
     static_assert(ldsBytes <= 160u * 1024u, "a wavefront's hits in LDS");
     if(ldsBytes > 64u * 1024u) {
@@ -367,19 +369,25 @@ void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in
         HIP_CHECK(hipGetDevice(&device));
         std::lock_guard<std::mutex> lock(mutex);
         if(std::find(done.begin(), done.end(), device) == done.end()) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparseChainWaveKernel<int(CAP), OWN_SORT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparseChainWaveKernel<int(CAP), OWN_SORT, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
             done.push_back(device);
         }
     }
     // (SHASTA_MI355X_CHAIN_WAVE_SHARE=<percent>: the share of the wavefronts the LDS would let a CU hold that the launch asks for --
     // a timing experiment: what the kernel leaves of a CU's LDS is what the other workers' kernels can run in beside it)
     static const uint32_t share = [] { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SHARE"); return e ? uint32_t(std::min(std::max(std::atoi(e), 10), 100)) : 100u; }();
-    const uint32_t grid = std::max<uint32_t>(256u, CHAIN_WAVE_GRID[CLS] * share / 100u);
-    hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT>), dim3(std::min<uint32_t>(grid, divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
+    const uint32_t grid = std::max<uint32_t>(256u, chainWaveGrid(CAP, NARROW) * share / 100u);
+    hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT, NARROW>), dim3(std::min<uint32_t>(grid, divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
         b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
         (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data());
     HIP_CHECK(hipGetLastError());
+}
+template<int CLS, bool OWN_SORT>
+void launchChainWaveClass(hipStream_t stream, BatchScratch& b, const DpInput& in, uint32_t taskCount, const SparseInput& sparse, DpControl* control, const DeviceOptions& opt)
+{
+    if(chainWaveWideD()) launchChainWaveClassAs<CLS, OWN_SORT, false>(stream, b, in, taskCount, sparse, control, opt);
+    else launchChainWaveClassAs<CLS, OWN_SORT, true>(stream, b, in, taskCount, sparse, control, opt);
 }
 // side + events: the launches of the two larger classes (13 % and 0.1 % of the tasks at 100 k reads, 8 and 1 wavefronts per CU) on the
 // side stream beside the first class's, which they would otherwise follow: 2.2 + 1.9 + 2.0 ms one after the other (profiles/r05_call6).

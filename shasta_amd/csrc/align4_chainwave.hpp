@@ -33,7 +33,10 @@
 // kernels, 166 ms per step against 143 (profiles/r05_call5*, r05_call3*): the sort's two passes over the candidate's list are chains of
 // dependent loads, and a wavefront that holds 10 KB of LDS while it waits for them keeps the next task's wavefront out.
 //
-// LDS: 10 bytes per hit (ordinals, D, `from` + flags).  Four launches by capacity -- 1 016 hits (10 KB a wavefront: 87 % of the
+// LDS: 8 bytes per hit (ordinals, D in 16 bits, `from` + flags) in the classes whose D fits -- the tabled read has fewer than
+// SPARSE_MAX_STREAM markers, so D >= 6 - min(p, s) > -8 192, and D <= 6 per hit of the class's capacity; 10 bytes (D in 32 bits) in
+// the last class, and in all of them with SHASTA_MI355X_CHAIN_WAVE_WIDE_D=1 (the form before: 16, 8, 4 wavefronts per CU instead of
+// 20, 10, 5).  Four launches by capacity -- 1 016 hits (8 KB a wavefront: 87 % of the
 // tasks at 100 k reads), 2 032 (13 %), 4 064 (0.1 %), 15 360 -- the first two of wavefronts that go over the task list in blocks of
 // 16 and run the tasks of their class, the last two over the few tasks sparseSortKernel listed for them (a launch that went over all
 // tasks for a few hundred of them, at one wavefront per CU, took as long as the first class's); what fits none goes to the dense
@@ -41,7 +44,13 @@
 // SHASTA_MI355X_CHAIN_WAVE=0: sparseSortKernel + sparseChainKernel, as before this file.
 #pragma once
 
-constexpr uint32_t CHAIN_WAVE_GRID[CHAIN_WAVE_CLASSES] = {256u * 16u, 256u * 8u, 256u * 4u, 256u};       // workgroups of one wavefront, as many as the LDS lets a CU hold
+// D in 16 bits where every D of a task of the class fits: above -SPARSE_MAX_STREAM (the border term of a hit, -min(p, s), p an ordinal in
+// the tabled read) and at most 6 per hit.
+constexpr bool chainWaveNarrowD(uint32_t capacity) { return SPARSE_MAX_STREAM < 32768u && 6u * capacity + 6u < 32768u; }
+constexpr uint32_t chainWaveHitBytes(uint32_t capacity, bool narrow) { return narrow && chainWaveNarrowD(capacity) ? 8u : 10u; }
+constexpr size_t chainWaveLdsBytes(uint32_t capacity, bool narrow) { return size_t(capacity) * chainWaveHitBytes(capacity, narrow) + 4u * ((size_t(capacity) + 63u) / 64u); }
+// Workgroups of one wavefront, as many as the LDS lets a CU hold.
+constexpr uint32_t chainWaveGrid(uint32_t capacity, bool narrow) { return 256u * uint32_t(std::max<size_t>(1u, (160u * 1024u) / chainWaveLdsBytes(capacity, narrow))); }
 constexpr uint32_t CHAIN_WAVE_SLACK = 512;         // matches listed for a candidate beyond those inside a task's band, usually fewer than this: the background of the whole matrix, other components
 constexpr uint32_t CHAIN_WAVE_BLOCK = 16;          // tasks a wavefront takes from the cursor at a time
 constexpr uint32_t CHAIN_OFF_MASK = 0x3fffu, CHAIN_OFF_EXCEPTION = 0x4000u, CHAIN_OFF_WAYS = 0x8000u;
@@ -75,8 +84,8 @@ __device__ __forceinline__ uint64_t bitsAbove(uint64_t m, int lane) { return (m 
 
 // The capacity class of a task, from what is known before its hits are counted: the matches LISTED for its candidate (an upper bound of
 // those inside its band) and the markers of the tabled read (the counting sort's 4-bit counters lie where D and `from` will be:
-// 1.5 words per hit of capacity for 2.5 words per 8 markers).  -1 and the reason: no class (the dense kernels run the task).
-__device__ __forceinline__ int chainWaveClassOfTask(const PairDesc& pd, uint32_t meta, uint64_t room, int& why)
+// 1.5 words per hit of capacity, 1 where D is held in 16 bits, for 2.5 words per 8 markers).  -1 and the reason: no class (the dense kernels run the task).
+__device__ __forceinline__ int chainWaveClassOfTask(const PairDesc& pd, uint32_t meta, uint64_t room, int& why, bool narrow)
 {
     if(meta == HIT_LIST_NONE) { why = GIVE_UP_NO_LIST; return -1; }
     const uint32_t count = meta & 0x7fffffffu;
@@ -85,12 +94,13 @@ __device__ __forceinline__ int chainWaveClassOfTask(const PairDesc& pd, uint32_t
     if(streamCount > SPARSE_MAX_STREAM || streamCount == 0) { why = GIVE_UP_LONG_STREAM; return -1; }
     const uint32_t counterWords = 5u * ((streamCount + 7u) / 8u);        // in half words: counts, cursors, starts
 #pragma unroll
-    for(int c = 0; c < CHAIN_WAVE_CLASSES; c++) if(count <= CHAIN_WAVE_CAPACITY[c] + CHAIN_WAVE_SLACK && counterWords <= 3u * CHAIN_WAVE_CAPACITY[c]) return c;
+    for(int c = 0; c < CHAIN_WAVE_CLASSES; c++)
+        if(count <= CHAIN_WAVE_CAPACITY[c] + CHAIN_WAVE_SLACK && counterWords <= (chainWaveHitBytes(CHAIN_WAVE_CAPACITY[c], narrow) - 4u) / 2u * CHAIN_WAVE_CAPACITY[c]) return c;
     why = GIVE_UP_SORTED_CAPACITY;
     return -1;
 }
 
-template<int CAP, bool OWN_SORT>
+template<int CAP, bool OWN_SORT, bool NARROW>
 __global__ void __launch_bounds__(64)
 sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount, int cls,
     DpControl* __restrict__ control, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
@@ -100,9 +110,15 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
 {
     extern __shared__ uint32_t ldsWords[];
     uint32_t* const H = ldsWords;                                            // p << 16 | s
-    int32_t* const Dv = reinterpret_cast<int32_t*>(ldsWords + CAP);          // D of the finished hits
-    uint16_t* const OFF = reinterpret_cast<uint16_t*>(ldsWords + 2 * CAP);   // how many hits back the predecessor is (0: the chain starts here) | flags
-    int32_t* const WM = reinterpret_cast<int32_t*>(ldsWords + 2 * CAP + CAP / 2);     // the largest D up to the end of every window of 64 hits
+    // NARROW: the launches of all classes hold D in 16 bits where the class allows it (the classes' capacities for the counting sort
+    // of OWN_SORT depend on it, and every launch has to see the same classes).
+    constexpr bool NARROW_D = NARROW && chainWaveNarrowD(CAP);
+    using StoredD = std::conditional_t<NARROW_D, int16_t, int32_t>;
+    constexpr int D_WORDS = NARROW_D ? CAP / 2 : CAP;
+    static_assert(size_t(CAP + D_WORDS + CAP / 2 + (CAP + 63) / 64) * 4u == chainWaveLdsBytes(CAP, NARROW), "the arrays below fill exactly what the launch asks for");
+    StoredD* const Dv = reinterpret_cast<StoredD*>(ldsWords + CAP);          // D of the finished hits
+    uint16_t* const OFF = reinterpret_cast<uint16_t*>(ldsWords + CAP + D_WORDS);   // how many hits back the predecessor is (0: the chain starts here) | flags
+    int32_t* const WM = reinterpret_cast<int32_t*>(ldsWords + CAP + D_WORDS + CAP / 2);     // the largest D up to the end of every window of 64 hits
     const int lane = laneId();
     unsigned long long walked = 0, listed = 0;
     // The tasks in blocks of CHAIN_WAVE_BLOCK, taken through a cursor (an atomic per block: a few thousand per launch -- an atomic per
@@ -134,7 +150,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 const DpTask mine = tasks[candidateTask];
                 const PairDesc myPair = pairs[mine.pair];
                 int why = -1;
-                myClass = chainWaveClassOfTask(myPair, hitMeta[mine.pair], hitBase[mine.pair + 1] - hitBase[mine.pair], why);
+                myClass = chainWaveClassOfTask(myPair, hitMeta[mine.pair], hitBase[mine.pair + 1] - hitBase[mine.pair], why, NARROW);
                 if(myClass < 0 && cls == 0) { state[candidateTask] = SPARSE_DENSE; noteGiveUp(control, why, myPair, mine); }      // (said once: by the first class's launch)
             }
             todoTasks = ballot64(myClass == cls);
@@ -219,6 +235,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             waveLdsSync();
         }
         walked += uint32_t(n);
+        SHASTA_DEVICE_CHECK(n >= 0 && n <= CAP);
 
         // ---- forward: D, `from`, the count of optimal chains (capped at two) ----
         // Windows of 64 hits at fixed places.  The lanes' steps 6 - c(i) and their prefix sums are made once per window; an exception
@@ -254,7 +271,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 const uint64_t okMask = ballot64(ok);
                 const int accepted = okMask == ~0ULL ? WAVE : (__ffsll((unsigned long long)~okMask) - 1);      // lanes [first, accepted) hold their true D
                 if(accepted > first) {
-                    if(lane >= first && lane < accepted) { Dv[i] = d; OFF[i] = uint16_t(1u | (waysBefore ? CHAIN_OFF_WAYS : 0u)); }
+                    if(lane >= first && lane < accepted) { SHASTA_DEVICE_CHECK(int32_t(StoredD(d)) == d); Dv[i] = StoredD(d); OFF[i] = uint16_t(1u | (waysBefore ? CHAIN_OFF_WAYS : 0u)); }
                     const int32_t newAll = laneValue(pmIncl, accepted - 1);
                     pmBut1 = accepted - 2 >= first ? laneValue(pmIncl, accepted - 2) : pmAll;
                     pmAll = newAll;
@@ -323,7 +340,8 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                     }
                 }
                 const int32_t de = 6 + bestValue;
-                if(lane == 0) { Dv[e] = de; OFF[e] = uint16_t(uint32_t(from) | CHAIN_OFF_EXCEPTION | (ways >= 2u ? CHAIN_OFF_WAYS : 0u)); }
+                SHASTA_DEVICE_CHECK(int32_t(StoredD(de)) == de);
+                if(lane == 0) { Dv[e] = StoredD(de); OFF[e] = uint16_t(uint32_t(from) | CHAIN_OFF_EXCEPTION | (ways >= 2u ? CHAIN_OFF_WAYS : 0u)); }
                 pmBut1 = pmAll; pmAll = max(pmAll, de);
                 waysBefore = ways >= 2u ? 1u : 0u;
                 int last = accepted;                                          // the last lane decided here
@@ -340,7 +358,8 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                         else if(candidate == bestValue2) { ways2 = min(2u, ways2 + waysE); if(from2 != 0) from2 = 1; }       // (from2 == 0: the border attains it)
                     }
                     const int32_t de2 = 6 + bestValue2;
-                    if(lane == 0) { Dv[e + 1] = de2; OFF[e + 1] = uint16_t(uint32_t(from2) | CHAIN_OFF_EXCEPTION | (ways2 >= 2u ? CHAIN_OFF_WAYS : 0u)); }
+                    SHASTA_DEVICE_CHECK(int32_t(StoredD(de2)) == de2);
+                    if(lane == 0) { Dv[e + 1] = StoredD(de2); OFF[e + 1] = uint16_t(uint32_t(from2) | CHAIN_OFF_EXCEPTION | (ways2 >= 2u ? CHAIN_OFF_WAYS : 0u)); }
                     pmBut1 = pmAll; pmAll = max(pmAll, de2);
                     waysBefore = ways2 >= 2u ? 1u : 0u;
                     last = accepted + 1; dLast = de2;

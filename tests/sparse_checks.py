@@ -254,15 +254,35 @@ def large_tasks(seed=5, tasks=16):
     return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
 
 
+def deep_block_tasks(seed=23, depths=(2500, 5200, 7700), n=8100, block=320):
+    """Two unrelated reads of 8 100 markers (the longest the hits are ordered by: 8 192) that share one block deep inside: the chain
+    enters from the border at a cost of the block's depth, so D of its hits lies near -depth -- the low end of what the wave kernel
+    keeps in 16 bits."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+    for depth in depths:
+        a = rng.integers(0, 1 << 20, size=n, dtype=np.uint32)
+        b = rng.integers(0, 1 << 20, size=n, dtype=np.uint32)
+        shift = int(rng.integers(-20, 20))
+        copy = dp_geometry_checks.noisy(rng, a[depth:depth + block], 1 << 20)
+        b[depth + shift:depth + shift + len(copy)] = copy
+        pieces += [a, b]
+        spec.append((at, n, at + n, n, -shift - 40, -shift + 40))
+        at += 2 * n
+    return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+
+
 def wave_kernel_forms(lib, orc):
     """align4_chainwave.hpp against the oracle and against the forms it can be switched to: the lane-per-task chain kernel
     (SHASTA_MI355X_CHAIN_WAVE=0), the wave kernel ordering the hits itself (SHASTA_MI355X_CHAIN_WAVE_SORT=1: classes chosen from the
-    listed matches, tasks that turn out too large handed to the next class), on clean tasks of every size class.
+    listed matches, tasks that turn out too large handed to the next class), D in 32 bits (SHASTA_MI355X_CHAIN_WAVE_WIDE_D=1), on clean
+    tasks of every size class and on blocks deep inside long reads.
     -> tasks compared."""
     compared = 0
-    for kmer, spec in (clean_tasks(91, tasks=40, long_every=9), large_tasks()):
+    for kmer, spec in (clean_tasks(91, tasks=40, long_every=9), large_tasks(), deep_block_tasks()):
         want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
-        for env in ({}, {"SHASTA_MI355X_CHAIN_WAVE": "0"}, {"SHASTA_MI355X_CHAIN_WAVE_SORT": "1"}, {"SHASTA_MI355X_CHAIN_WAVE_SIDE": "1"}):
+        for env in ({}, {"SHASTA_MI355X_CHAIN_WAVE": "0"}, {"SHASTA_MI355X_CHAIN_WAVE_SORT": "1"}, {"SHASTA_MI355X_CHAIN_WAVE_SIDE": "1"},
+                    {"SHASTA_MI355X_CHAIN_WAVE_WIDE_D": "1"}, {"SHASTA_MI355X_CHAIN_WAVE_WIDE_D": "1", "SHASTA_MI355X_CHAIN_WAVE_SORT": "1"}):
             with _environment(**env):
                 got = _run(lib, kmer, spec)
             for (x, sx), (y, sy) in zip(want, got):
