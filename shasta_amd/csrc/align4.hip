@@ -133,6 +133,8 @@ struct BatchScratch {
         HIP_CHECK(hipMemsetAsync(zeroBlock.data(), 0, bytes, stream));
     }
     DeviceBuffer<uint32_t> tieMembers, tieKeys, tieCounts;     // resolveComponentTies
+    uint32_t sparseStateTasks = 0;       // of the batch in hand: the tasks sparseState speaks of (0: the sparse path did not run)
+    bool streamsInLists = false;         // ... and whether the wave kernel leaves its alignments in shasta::compress form in their lists (compressWriteKernel copies them)
     DeviceBuffer<CellsChunk> tieChunks;
     View<uint8_t> pairFlags, pairTie;
     DeviceBuffer<uint8_t> status;
@@ -352,6 +354,9 @@ bool chainWaveEnabled() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE"
 bool chainWaveSideStream() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SIDE"); return e && std::atoi(e) != 0; }
 // SHASTA_MI355X_CHAIN_WAVE_SORT=1: the wave kernel orders the hits itself (no sparseSortKernel); slower on the MI355X, kept for the A/B.
 bool chainWaveOwnSort() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_SORT"); return e && std::atoi(e) != 0; }
+// SHASTA_MI355X_CHAIN_WAVE_STREAM=0: the wave kernel leaves the shasta::compress form of its alignments to compressWriteKernel's pass over
+// the aligned pairs (the form before: 1.5 GB read per launch there for 0.15 GB written).
+bool chainWaveStream() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_STREAM"); return !e || std::atoi(e) != 0; }
 // SHASTA_MI355X_CHAIN_WAVE_WIDE_D=1: D in 32 bits in every class (10 bytes of LDS per hit instead of 8: the form before, kept for the A/B).
 bool chainWaveWideD() { const char* e = std::getenv("SHASTA_MI355X_CHAIN_WAVE_WIDE_D"); return e && std::atoi(e) != 0; }
 template<int CLS, bool OWN_SORT, bool NARROW>
@@ -380,7 +385,7 @@ void launchChainWaveClassAs(hipStream_t stream, BatchScratch& b, const DpInput& 
     hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT, NARROW>), dim3(std::min<uint32_t>(grid, divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
         b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
-        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data());
+        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data(), b.streamsInLists ? 1u : 0u);
     HIP_CHECK(hipGetLastError());
 }
 template<int CLS, bool OWN_SORT>
@@ -929,6 +934,8 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     }
     DpForwardState f;
     std::memset(&f, 0, sizeof(f));
+    b.sparseStateTasks = (taskCount && sparse && defaultScores(in.scores)) ? taskCount : 0u;
+    b.streamsInLists = b.sparseStateTasks && chainWaveEnabled() && chainWaveStream();
     if(taskCount) f = runDpForward(ws, b, in, taskCount, true, ev, &ctx.timers, wideCount, wideOrdinals, (sparse && defaultScores(in.scores)) ? sparse : nullptr, &opt);
     else { b.results.reserve(wideCount, stream); b.ordScratch.reserve(2 * wideOrdinals + 2, stream); }
     // The traceback of every class in one launch (the list is sorted by class, then by ascending length; the kernel takes it from the end).
@@ -949,7 +956,7 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
     SHASTA_TIMED(ctx, "dpMetricsKernel", stream, 0, allTasks,
         hipLaunchKernelGGL(dpMetricsKernel, dim3(divUp(uint64_t(allTasks) * WAVE, 256)), dim3(256), 0, stream,
             in.pairs, in.tasks, allTasks, (const uint32_t*)b.ordScratch.data(), b.results.data(), opt, b.pairBest.data(),
-            (taskCount && sparse && defaultScores(in.scores)) ? (const uint8_t*)b.sparseState.data() : (const uint8_t*)nullptr, taskCount));
+            b.sparseStateTasks ? (const uint8_t*)b.sparseState.data() : (const uint8_t*)nullptr, b.sparseStateTasks));
     HIP_CHECK(hipGetLastError());
     if(stats) for(int c = 0; c < DP_CLASSES; c++) { stats->cells[c] = f.sums[2 + c]; stats->bytes[c] = f.sums[2 + DP_CLASSES + c]; stats->tasks[c] = f.classCounts[c]; }
     return f.sums[0] + wideCells;
@@ -1694,6 +1701,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             }
         } else {
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
+            b.sparseStateTasks = 0; b.streamsInLists = false;
         }
 
         if(debugPhases) { HIP_CHECK(hipStreamSynchronize(stream)); phaseDp = phaseMs(phaseStart) - phaseCells; }
@@ -1726,7 +1734,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             (const uint32_t*)b.storedFlags.data(), (const uint32_t*)b.storedIndex.data(), (const DpResult*)b.results.data(),
             (const uint32_t*)b.pairWinner.data(), (const uint32_t*)b.ordScratch.data(), n,
             (const uint64_t*)b.sizes.data(), b.bytes.data(), b.compressedToc.data(),
-            (const shasta_alignment_data*)b.rows.data(), b.rowsOut.data());
+            (const shasta_alignment_data*)b.rows.data(), b.rowsOut.data(),
+            (b.sparseStateTasks && b.streamsInLists) ? (const uint8_t*)b.sparseState.data() : (const uint8_t*)nullptr, b.sparseStateTasks,
+            (const PairDesc*)b.pairs.data(), (const uint64_t*)b.ordCap.data(), (const uint32_t*)b.sparseSorted.data());
         const size_t writeHandle = ctx.timers.end(writeSpan, 0, storedCount);
         HIP_CHECK(hipGetLastError());
 

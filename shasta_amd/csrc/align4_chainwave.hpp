@@ -106,7 +106,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
     DpControl* __restrict__ control, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta, const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results,
     uint32_t* __restrict__ linkWords, DpEnd* __restrict__ ends, uint32_t* __restrict__ ambiguousList, uint32_t* __restrict__ retryList,
-    DeviceOptions opt, unsigned long long* __restrict__ pairBest)
+    DeviceOptions opt, unsigned long long* __restrict__ pairBest, uint32_t emitStream)
 {
     extern __shared__ uint32_t ldsWords[];
     uint32_t* const H = ldsWords;                                            // p << 16 | s
@@ -467,6 +467,11 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
         long long sumOffset = 0;
         uint32_t maxSkip = 0, maxDrift = 0;
         unsigned long long bytes = 0;
+        // emitStream: the streaks are written as they are met, from the last one back, so that the alignment in shasta::compress form ends
+        // where the task's room in the list of sorted hits ends (the hits are in LDS by now; a streak takes at most 8 bytes -- ordinals
+        // have 16 bits -- and the room is 8 bytes per marker of the shorter read: it always fits).  compressWriteKernel copies it.
+        uint8_t* const streamEnd = reinterpret_cast<uint8_t*>(list + sparseListCapacity(pd.nx, pd.ny));
+        uint32_t tail = 0;                    // bytes written so far
         int32_t laterX = 0, laterY = 0, lastX = 0, lastY = 0;                 // the lowest pair met so far (the successor of the next one met); the last pair of the alignment
         bool haveLater = false;
         uint32_t carryLength = 0;             // pairs from the lowest one met up to and including the first one that is followed by a new streak (or up to the end)
@@ -515,6 +520,8 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 }
             }
             const uint64_t starts = ballot64(newStreak);      // lanes whose successor begins a streak
+            StreakRecord record;
+            uint32_t recordBytes = 0;
             if(newStreak) {
                 // The streak that begins with the successor: up to and including the next pair that is followed by a new one.
                 const uint64_t startsAbove = bitsAbove(starts, lane);
@@ -523,7 +530,17 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                     const int until = lane + __ffsll((unsigned long long)startsAbove);
                     length = uint32_t(__popcll(on & bitsUpTo(until) & ~bitsUpTo(lane)));
                 } else length = uint32_t(__popcll(above)) + carryLength;
-                bytes += uint64_t(makeStreakRecord(skip0, skip1, length).len);
+                record = makeStreakRecord(skip0, skip1, length);
+                recordBytes = uint32_t(record.len);
+                bytes += uint64_t(recordBytes);
+            }
+            if(emitStream && starts) {
+                // (in the order of the lanes: a lane's streak lies behind those of the lanes below it)
+                const uint32_t inclusive = uint32_t(waveInclusiveSum(int32_t(recordBytes)));
+                const uint32_t total = uint32_t(laneValue(int32_t(inclusive), WAVE - 1));
+                SHASTA_DEVICE_CHECK(tail + total <= 4u * sparseListCapacity(pd.nx, pd.ny));
+                if(newStreak) writeStreakRecord(record, streamEnd - tail - (total - inclusive) - recordBytes);
+                tail += total;
             }
             if(starts) carryLength = uint32_t(__popcll(on & bitsUpTo(__ffsll((unsigned long long)starts) - 1)));
             else carryLength += count;
@@ -548,7 +565,10 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             r.maxSkip = r.maxDrift = 0; r.passes = 0; r.compressedBytes = 0;
             if(haveLater) {
                 // (the first pair: its streak's skips are taken against (0, 0))
-                bytes += uint64_t(makeStreakRecord(laterX, laterY, carryLength).len);
+                const StreakRecord record = makeStreakRecord(laterX, laterY, carryLength);
+                SHASTA_DEVICE_CHECK(!emitStream || (bytes == tail && tail + uint32_t(record.len) <= 4u * sparseListCapacity(pd.nx, pd.ny)));
+                if(emitStream) writeStreakRecord(record, streamEnd - tail - uint32_t(record.len));
+                bytes += uint64_t(record.len);
                 r.sumOffset = sumOffset; r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
                 r.first0 = uint32_t(laterX); r.first1 = uint32_t(laterY); r.last0 = uint32_t(lastX); r.last1 = uint32_t(lastY);
             }
@@ -558,7 +578,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             r.compressedBytes = uint32_t(bytes < 0xffffffffULL ? bytes : 0xffffffffULL);
             taskAcceptance(r, pd, task, opt, pairBest);
             results[t] = r;
-            state[t] = SPARSE_COMPLETE;
+            state[t] = emitStream ? SPARSE_COMPLETE_STREAM : SPARSE_COMPLETE;
         }
     }
     if(lane == 0 && walked) { atomicAdd(&control->hitsInBand, walked); atomicAdd(&control->hitsListed, listed); }

@@ -684,6 +684,16 @@ __device__ __forceinline__ StreakRecord makeStreakRecord(int32_t skip0, int32_t 
     return r;
 }
 
+__device__ __forceinline__ void writeStreakRecord(const StreakRecord& r, uint8_t* __restrict__ out)
+{
+    if(r.len == 16) {
+        const uint32_t w[4] = {7u, r.w[0], r.w[1], r.w[2]};
+        for(int k = 0; k < 16; k++) out[k] = uint8_t(w[k >> 2] >> (8 * (k & 3)));
+    } else {
+        for(int k = 0; k < r.len; k++) out[k] = uint8_t(r.bits >> (8 * k));
+    }
+}
+
 
 // The inner acceptance of a task (src/Align4.cpp:944-981) from its metrics, and its candidate's best component (:132-139): most
 // aligned markers; ties resolved towards the component whose first cell in (iY, iX) order comes first, and flagged later.

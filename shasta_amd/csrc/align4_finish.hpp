@@ -94,15 +94,7 @@ gatherOrdinalsKernel(const DpResult* __restrict__ results, const uint32_t* __res
 // (skip0, skip1) from the last pair of the previous streak (from (0,0) for the first) and its
 // length, in the smallest of five formats (1/2/4/8/16 bytes).
 // (StreakRecord, makeStreakRecord: align4_dp.hpp -- the chain kernel counts the bytes of its tasks' alignments too)
-__device__ __forceinline__ void writeStreakRecord(const StreakRecord& r, uint8_t* __restrict__ out)
-{
-    if(r.len == 16) {
-        const uint32_t w[4] = {7u, r.w[0], r.w[1], r.w[2]};
-        for(int k = 0; k < 16; k++) out[k] = uint8_t(w[k >> 2] >> (8 * (k & 3)));
-    } else {
-        for(int k = 0; k < r.len; k++) out[k] = uint8_t(r.bits >> (8 * k));
-    }
-}
+// (writeStreakRecord too: the wave kernel writes the streaks of its tasks' alignments as it walks their chains)
 
 // One wavefront per stored alignment: lanes flag the streak starts of 64 marker pairs at a time;
 // a start lane knows its skips at once and its length when the next start is seen (the last
@@ -183,11 +175,20 @@ __global__ void __launch_bounds__(256)
 compressWriteKernel(const uint32_t* __restrict__ storedFlags, const uint32_t* __restrict__ storedIndex,
     const DpResult* __restrict__ results, const uint32_t* __restrict__ pairWinner, const uint32_t* __restrict__ ordScratch,
     uint32_t pairCount, const uint64_t* __restrict__ byteOffsets, uint8_t* __restrict__ bytes,
-    uint64_t* __restrict__ compressedToc, const shasta_alignment_data* __restrict__ rows, shasta_alignment_data* __restrict__ rowsOut)
+    uint64_t* __restrict__ compressedToc, const shasta_alignment_data* __restrict__ rows, shasta_alignment_data* __restrict__ rowsOut,
+    const uint8_t* __restrict__ sparseState, uint32_t sparseStateCount, const PairDesc* __restrict__ pairs, const uint64_t* __restrict__ ordOffsets, const uint32_t* __restrict__ sorted)
 {
     const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if(p >= pairCount || !storedFlags[p]) return;
-    const DpResult r = results[pairWinner[p]];
+    const uint32_t t = pairWinner[p];
+    const DpResult r = results[t];
+    if(sparseState && t < sparseStateCount && sparseState[t] == SPARSE_COMPLETE_STREAM) {
+        // The wave kernel wrote the streaks while it walked the chain: they end where the task's room in the list of sorted hits ends.
+        const PairDesc pd = pairs[p];
+        const uint8_t* __restrict__ const from = reinterpret_cast<const uint8_t*>(sorted + sparseListBase(ordOffsets, t) + sparseListCapacity(pd.nx, pd.ny)) - r.compressedBytes;
+        uint8_t* __restrict__ const to = bytes + byteOffsets[p];
+        for(uint32_t i = uint32_t(laneId()); i < r.compressedBytes; i += WAVE) to[i] = from[i];
+    } else
     (void)compressAlignmentWave<true>(ordScratch + 2 * r.ordBegin, r.markerCount, bytes + byteOffsets[p]);
     const uint32_t k = storedIndex[p];
     if(laneId() == 0) compressedToc[k] = byteOffsets[p];
@@ -208,7 +209,7 @@ dpMetricsKernel(
 {
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if(t >= taskCount) return;
-    if(sparseState && t < sparseStateCount && sparseState[t] == SPARSE_COMPLETE) return;       // sparseChainKernel took them while it walked the chain
+    if(sparseState && t < sparseStateCount && (sparseState[t] == SPARSE_COMPLETE || sparseState[t] == SPARSE_COMPLETE_STREAM)) return;       // sparseChainKernel took them while it walked the chain
     const int lane = laneId();
     DpResult r = results[t];
     const uint32_t count = r.markerCount;

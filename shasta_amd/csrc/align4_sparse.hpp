@@ -39,7 +39,8 @@ constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the r
 constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
 constexpr int SPARSE_RING = 64;                              // slots of a lane's ring: the hits it can look back on and the next ones it will need
 constexpr int SPARSE_LOOK_BACK = 56;                         // hits a lane can look back
-enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2, SPARSE_AMBIGUOUS = 3, SPARSE_COMPLETE = 4 };   // CERTIFIED: the pairs are in the ordinal scratch; COMPLETE: and the task's metrics in its result (dpMetricsKernel skips it);   // AMBIGUOUS: several optimal chains, forward pass kept: sparseAnchorKernel's (align4_anchor.hpp)
+enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2, SPARSE_AMBIGUOUS = 3, SPARSE_COMPLETE = 4, SPARSE_COMPLETE_STREAM = 5 };   // COMPLETE_STREAM: COMPLETE, and the alignment in shasta::compress form at the end of the task's room in the list of sorted hits (the wave kernel's; compressWriteKernel copies it)
+//   // CERTIFIED: the pairs are in the ordinal scratch; COMPLETE: and the task's metrics in its result (dpMetricsKernel skips it);   // AMBIGUOUS: several optimal chains, forward pass kept: sparseAnchorKernel's (align4_anchor.hpp)
 constexpr int SPARSE_LINK_REACH = 29;                        // how far back (in hits) a hit's link word names its optimal links; bit 30: one goes further
 
 // Where task t's ordered hits go: room for 2 min(nx, ny) + 64 of them (ordOffsets[t] = where the task's min(nx, ny) + 32 pairs of
@@ -440,7 +441,7 @@ dpDenseFlagsKernel(const uint32_t* __restrict__ sortedIds, const uint8_t* __rest
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i > taskCount) return;
     const uint8_t st = i < taskCount ? state[sortedIds[i]] : uint8_t(SPARSE_CERTIFIED);
-    flags[i] = (st != SPARSE_CERTIFIED && st != SPARSE_COMPLETE) ? 1u : 0u;
+    flags[i] = (st != SPARSE_CERTIFIED && st != SPARSE_COMPLETE && st != SPARSE_COMPLETE_STREAM) ? 1u : 0u;
 }
 
 // positions = exclusive scan of the flags.  Class counts and the per-class sums (DP cells, algorithmic bytes) of the tasks that stay:
