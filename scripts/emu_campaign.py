@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE: seeded read sets through the aligner of the EMULATED build (tests/emu) against the oracle, candidate for candidate
 (AlignmentData, the compressed bytes, the ordinals where asked for).   python scripts/emu_campaign.py <first seed> <seeds> [processes]
-Every seed draws its own read count, genome length, read length and MinHash parameters; odd seeds ask for the ordinals."""
+Every seed draws its own read count, genome length, read length and MinHash parameters; odd seeds ask for the ordinals.
+CAMPAIGN_LONG=1: a few dozen reads of 3 000 to 7 000 markers each."""
 import os
 import sys
 from multiprocessing import Pool
@@ -18,6 +19,8 @@ def one(seed):
     n_reads = int(rng.integers(50, 150))
     genome = int(rng.integers(4000, 16000))
     mean = float(rng.choice([500.0, 900.0, 1600.0]))
+    if os.environ.get("CAMPAIGN_LONG") == "1":            # (reads of thousands of markers: the wave kernel's larger capacity classes)
+        n_reads, genome, mean = int(rng.integers(24, 48)), int(rng.integers(12000, 30000)), float(rng.choice([3000.0, 5000.0, 7000.0]))
     toc, kmer = synthetic.marker_reads(n_reads, genome, mean_markers=mean, min_markers=200, seed=seed)
     data7 = synthetic.pack_markers(toc, kmer)
     orc = bindings.OracleLib()
