@@ -145,3 +145,23 @@ class Assembler:
             downsamplingFactor=float(alignOptions.downsamplingFactor), bandExtend=int(alignOptions.bandExtend))
         self._check(self._lib.shasta_mi355x_host_compute_alignments(self._data.encode(), C.byref(o), C.c_uint64(threadCount),
                                                                     C.c_uint64(self._page)))
+
+
+def suppress_candidates_in_memory(candidates, meta_data, delta, hostLibrary=None):
+    """Assembler::suppressAlignmentCandidates (src/AssemblerAlign.cpp:1168-1240) on arrays in memory -- the step the assemble path
+    runs between the two seams (srcMain/main.cpp:697-702): `candidates` = the first seam's OrientedReadPair array, `meta_data` =
+    (toc uint64[R + 1], bytes) in the layout of Data/ReadMetaData.  Returns the candidates that stay (a prefix of a copy)."""
+    import numpy as np
+    lib = C.CDLL(hostLibrary or HOST_SO)
+    lib.shasta_mi355x_host_last_error.restype = C.c_char_p
+    toc, data = meta_data
+    toc = np.ascontiguousarray(toc, dtype=np.uint64)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.array(candidates, copy=True)
+    kept = C.c_uint64()
+    rc = lib.shasta_mi355x_host_suppress_candidates_in_memory(
+        toc.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p), C.c_uint64(len(toc) - 1),
+        out.ctypes.data_as(C.c_void_p), C.c_uint64(len(out)), C.c_uint64(delta), C.byref(kept))
+    if rc != 0:
+        raise RuntimeError(lib.shasta_mi355x_host_last_error().decode())
+    return out[:int(kept.value)]

@@ -192,7 +192,8 @@ std::shared_ptr<BatchScratch> makeWorkerScratch(SharedCapacities& shared)
 // overlap the narrow classes instead of occupying the GPU alone.
 struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; hipStream_t wide; };
 
-constexpr int CELLS_CLASSES = 4;
+constexpr int CELLS_CLASSES = 5;
+constexpr int CELLS_LONG = 4;          // the windowed class (align4CellsLongKernel): its own kernel instance, chunks of any sixteen candidates
 #ifndef SHASTA_CELLS_NA0
 #define SHASTA_CELLS_NA0 11
 #endif
@@ -201,7 +202,10 @@ constexpr int CELLS_CLASSES = 4;
 // region -- a byte grid up to nx + ny = 11 000, a packed table of 16 384 slots beyond -- and 256 kept cells, one workgroup per
 // CU.  Until then those pairs (250 - 450 of a batch's 262 144 at 100 k reads) went to the kernel with its tables in HBM scratch:
 // 1.6 ms per batch of 1024-thread workgroups that waited 95 % of their cycles (profiles/r02_pmc_100k_reads.json).
-constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13};
+// The fifth class (round 6, CELLS_LONG) tables the SHORTER read of a candidate in windows of 2^13 markers: pairs of two reads beyond
+// 8 192 markers (29 % of the candidates of the ultra-long shape, conf/Nanopore-UL-May2022.conf) and pairs whose cell indices do not
+// fit the packed word of the others (nx + ny beyond 40 960 at deltaY = 10).
+constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13, 13};
 // Timing experiments compile other geometries (make EXTRA=-DSHASTA_CELLS_SC0=9 ...): the LDS a workgroup takes
 // decides how many wavefronts a CU holds, and the cells kernels are bound by latency, not by instruction issue.
 #ifndef SHASTA_CELLS_SC0
@@ -216,7 +220,7 @@ constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13};
 #ifndef SHASTA_CELLS_ESTIMATE_SHIFT
 #define SHASTA_CELLS_ESTIMATE_SHIFT 13
 #endif
-constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2, 14};
+constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2, 14, 13};
 // Kept cells per candidate: 64 Q (more: the candidate climbs a class, finally to the HBM-scratch kernel).  Q = 2 everywhere:
 // the kernel then needs 115 vector registers (4 wavefronts per SIMD) instead of 224 (2).
 #ifndef SHASTA_CELLS_Q1
@@ -228,8 +232,8 @@ constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1
 #ifndef SHASTA_CELLS_CHUNK_MAX
 #define SHASTA_CELLS_CHUNK_MAX 24
 #endif
-constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2, 4};
-constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16, 8};
+constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2, 4, 4};
+constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16, 8, uint32_t(CELLS_LONG_WAVES)};
 constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call
 #include "align4_prepare.hpp"    // the class of a candidate; a batch's first chunk lists made on the device
 
@@ -260,10 +264,28 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
     HIP_CHECK(hipGetLastError());
 }
 
+// The windowed class: workgroups of sixteen wavefronts.  Algorithmic bytes as the other classes' (what the reference reads: 4 (nx + ny)
+// per candidate; the kernel itself reads the stream once per window of the tabled read).
+void launchCellsLong(Context& ctx, const WorkStream& ws, BatchScratch& b, const CellsChunk* chunks, uint32_t count,
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists)
+{
+    const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[CELLS_LONG], CELLS_SC_LOG2[CELLS_LONG], CELLS_Q[CELLS_LONG], CELLS_LONG_WAVES) * sizeof(uint32_t);
+    std::call_once(ctx.cellsLdsAttribute[2], [] {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsLongKernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    });
+    MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
+    SHASTA_TIMED(ctx, "align4CellsLongKernel<false>", ws.stream, kmerIdBytes, candidateCount,
+        hipLaunchKernelGGL((align4CellsLongKernel<false>), dim3(count), dim3(CELLS_LONG_THREADS), bytes, ws.stream,
+            (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
+            opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(), (uint32_t*)nullptr, (uint32_t*)nullptr, hitLists));
+    HIP_CHECK(hipGetLastError());
+}
+
 void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int cls, const CellsChunk* chunks, uint32_t count,
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists)
 {
     if(count == 0) return;
+    if(cls == CELLS_LONG) { launchCellsLong(ctx, ws, b, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists); return; }
     if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists);
     else launchCellsChunksQ<4>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists);
 }
@@ -334,7 +356,7 @@ struct DpForwardState {
 
 // extraTasks / extraOrdinals: room behind the taskCount tasks for the wide tasks' results and aligned pairs.
 // What the sparse path needs beside the tasks: the candidates' match lists (null: every task runs in the dense kernels).
-struct SparseInput { const uint32_t* hits; const uint64_t* hitBase; const uint32_t* hitMeta; };
+struct SparseInput { const uint32_t* hits; const uint64_t* hitBase; const uint32_t* hitMeta; uint32_t maxOrdered = 0; };      // maxOrdered: the most markers a read the hits are ordered by has (the sort kernel's launches)
 // SHASTA_MI355X_SPARSE_DP=0: the dense DP for every task (the A/B switch, and the second implementation the tests compare with).
 bool sparseDpEnabled() { const char* e = std::getenv("SHASTA_MI355X_SPARSE_DP"); return !e || std::atoi(e) != 0; }
 // SHASTA_MI355X_ANCHORED_DP=0: the tasks with several optimal chains go to the dense kernels whole (as before align4_anchor.hpp).
@@ -474,7 +496,14 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         hipLaunchKernelGGL((sparseSortKernel<4096, 0>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
             b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave, chainWave ? b.chainWaveRetry.data() : nullptr);
-        hipLaunchKernelGGL((sparseSortKernel<int(SPARSE_MAX_STREAM), 4096>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
+        hipLaunchKernelGGL((sparseSortKernel<8192, 4096>), dim3(divUp(taskCount, 4)), dim3(256), 0, stream,
+            in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave, chainWave ? b.chainWaveRetry.data() : nullptr);
+        // (the windowed class's candidates: hits ordered by a read of up to 32 768 markers)
+        if(sparse->maxOrdered > 8192) hipLaunchKernelGGL((sparseSortKernel<16384, 8192, 2>), dim3(divUp(taskCount, 2)), dim3(128), 0, stream,
+            in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
+            b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave, chainWave ? b.chainWaveRetry.data() : nullptr);
+        if(sparse->maxOrdered > 16384) hipLaunchKernelGGL((sparseSortKernel<int(SPARSE_MAX_STREAM), 16384, 1>), dim3(taskCount), dim3(64), 0, stream,
             in.pairs, in.tasks, taskCount, sparse->hits, sparse->hitBase, sparse->hitMeta, (const uint64_t*)b.ordCap.data(),
             b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), control, chainWave, chainWave ? b.chainWaveRetry.data() : nullptr);
         HIP_CHECK(hipGetLastError());
@@ -709,7 +738,7 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
         const int c = pairClass[k];
         const uint64_t capacity = 1ULL << CELLS_NA_LOG2[c];
         CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = 1;
-        ch.swapped = hostPairs[k].nx < capacity ? 0 : 1;                      // (either read may be tabled: the cells are the same)
+        ch.swapped = (c == CELLS_LONG || hostPairs[k].nx < capacity) ? 0 : 1;     // (either read may be tabled: the cells are the same; the windowed class picks for itself)
         if(ch.swapped && hostPairs[k].ny >= capacity) continue;
         if(!pairNoGrid.empty() && pairNoGrid[k]) ch.swapped |= 2;             // (counted in the packed table the first time: again)
         ch.naLog2 = uint32_t(CELLS_NA_LOG2[c]); ch.scLog2 = uint32_t(CELLS_SC_LOG2[c]);
@@ -737,13 +766,15 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
             const uint32_t count = uint32_t(chunks[c].size());
             const uint32_t maxc = uint32_t(64 * CELLS_Q[c]);
             HIP_CHECK(hipMemcpyAsync(b.tieChunks.data() + offset, chunks[c].data(), count * sizeof(CellsChunk), hipMemcpyHostToDevice, stream));
-            const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[c], CELLS_SC_LOG2[c], CELLS_Q[c], CELLS_WAVES) * sizeof(uint32_t);
+            const int wavesOfClass = c == CELLS_LONG ? CELLS_LONG_WAVES : CELLS_WAVES;
+            const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[c], CELLS_SC_LOG2[c], CELLS_Q[c], wavesOfClass) * sizeof(uint32_t);
             std::call_once(ctx.cellsDumpLdsAttribute, [] {
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsChunkKernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsLongKernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             });
-            const auto kernel = CELLS_Q[c] == 2 ? &align4CellsChunkKernel<2, true> : &align4CellsChunkKernel<4, true>;
-            hipLaunchKernelGGL(kernel, dim3(count), dim3(WAVE * CELLS_WAVES), bytes, stream,
+            const auto kernel = c == CELLS_LONG ? &align4CellsLongKernel<true> : (CELLS_Q[c] == 2 ? &align4CellsChunkKernel<2, true> : &align4CellsChunkKernel<4, true>);
+            hipLaunchKernelGGL(kernel, dim3(count), dim3(WAVE * wavesOfClass), bytes, stream,
                 (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), (const CellsChunk*)(b.tieChunks.data() + offset), count, (const uint32_t*)b.tieMembers.data(),
                 opt, magicX, magicY, (DpTask*)nullptr, (uint32_t*)nullptr, 0u, (uint8_t*)nullptr, b.tieKeys.data() + wordOffset, b.tieCounts.data() + offset, HitLists{nullptr, nullptr, nullptr});
             HIP_CHECK(hipGetLastError());
@@ -1226,7 +1257,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         const bool listHits = !m3 && sparseDpEnabled();
         std::vector<uint64_t>& hostHitBase = w.hostHitBase;
         if(listHits) { hostHitBase.resize(uint64_t(n) + 1); hostHitBase[0] = 0; }
-        const CellsClassRule listClassRule = cellsClassRule(opt);
+        uint32_t maxOrdered = 0;
+        const CellsClassRule listClassRule = cellsClassRule(opt, ctx.matchShift);
         for(uint32_t k = 0; k < n; k++) {
             const shasta_oriented_read_pair& c = candidates[batchBegin + k];
             if(!(c.readIds[0] < c.readIds[1]) || c.readIds[1] >= ctx.readCount) {
@@ -1248,7 +1280,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             hostPairs[k] = pd;
             out.kmerIdBytes += 4 * (nx + ny);
             // (no room for a candidate whose cells the HBM-scratch kernel computes -- both reads beyond the LDS tables: it lists no matches)
-            if(listHits) hostHitBase[k + 1] = hostHitBase[k] + ((nx < 65535 && ny < 65535 && cellsChoice(listClassRule, pd.nx, pd.ny).cls < CELLS_CLASSES) ? hitListCapacity(pd.nx, pd.ny) : 0u);
+            if(listHits) {
+                const CellsChoice choice = cellsChoice(listClassRule, pd.nx, pd.ny);
+                hostHitBase[k + 1] = hostHitBase[k] + ((nx < 65535 && ny < 65535 && choice.cls < CELLS_CLASSES) ? hitListCapacity(pd.nx, pd.ny, ctx.matchShift) : 0u);
+                if(choice.cls == CELLS_LONG) maxOrdered = std::max(maxOrdered, std::min(pd.nx, pd.ny));       // (the windowed class orders by the shorter read; the others by a read below 8 192 markers)
+            }
         }
         // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
         // SHASTA_MI355X_INITIAL_TASKS overrides the first guess (tests use it to force the second run).
@@ -1392,7 +1428,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 while((1ULL << l) < 2 * cells && l < 24) ++l;
                 return uint8_t(l);
             };
-            const CellsClassRule classRule = cellsClassRule(opt);            // (the class of a candidate: align4_prepare.hpp)
+            const CellsClassRule classRule = cellsClassRule(opt, ctx.matchShift);            // (the class of a candidate: align4_prepare.hpp)
             pairClass.assign(n, -1); pairSlotsLog2.assign(n, 0); pairNoGrid.assign(n, 0);
             std::vector<CellsChunk> classChunks[CELLS_CLASSES];
             std::vector<uint32_t> members;                             // candidate indices, chunk after chunk
@@ -1486,6 +1522,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     pairClass[q] = c;
                     if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); continue; }
                     Keyed kd; kd.tabled = sw ? pd.begin1 : pd.begin0; kd.pair = q; kd.cls = uint8_t(c); kd.swapped = sw ? 1 : 0;
+                    if(c == CELLS_LONG) { kd.tabled = 0; kd.swapped = 0; }      // (the windowed class: one group, chunks of any sixteen candidates)
                     keyed.push_back(kd);
                 }
                 // Order: (swapped, tabled read, class, candidate).  The candidates arrive in ascending order, so a STABLE sort on the
@@ -1497,11 +1534,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     for(const Keyed& kd : keyed) maxTabled = std::max(maxTabled, kd.tabled);
                     int tabledBits = 1;
                     while(tabledBits < 58 && (maxTabled >> tabledBits) != 0) ++tabledBits;
-                    const int keyBits = 1 + tabledBits + 2;                     // swapped | tabled | class (CELLS_CLASSES <= 4)
-                    static_assert(CELLS_CLASSES <= 4, "two bits of class in the sort key");
+                    const int keyBits = 1 + tabledBits + 3;                     // swapped | tabled | class (CELLS_CLASSES <= 8)
+                    static_assert(CELLS_CLASSES <= 8, "three bits of class in the sort key");
                     std::vector<uint64_t> keyA(keyed.size()), keyB(keyed.size());
                     std::vector<Keyed> other(keyed.size());
-                    for(size_t k = 0; k < keyed.size(); k++) keyA[k] = (uint64_t(keyed[k].swapped) << (tabledBits + 2)) | (keyed[k].tabled << 2) | uint64_t(keyed[k].cls);
+                    for(size_t k = 0; k < keyed.size(); k++) keyA[k] = (uint64_t(keyed[k].swapped) << (tabledBits + 3)) | (keyed[k].tabled << 3) | uint64_t(keyed[k].cls);
                     for(int shift = 0; shift < keyBits; shift += 8) {
                         size_t counts[257] = {0};
                         for(uint64_t key : keyA) ++counts[((key >> shift) & 0xff) + 1];
@@ -1586,6 +1623,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     bool sw = false;
                     for(; c < CELLS_CLASSES; c++) {
                         const uint64_t cap = 1ULL << CELLS_NA_LOG2[c];
+                        if(c == CELLS_LONG) continue;      // (the windowed class has no larger cell table and no longer kept list than the class before it: nothing to climb to)
                         if(hostPairs[k].nx < cap) { sw = false; break; }
                         if(hostPairs[k].ny < cap) { sw = true; break; }
                     }
@@ -1685,7 +1723,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         phaseCells = phaseMs(phaseStart);
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount + wideCount) {
-            const SparseInput sparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data()};
+            const SparseInput sparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data(), maxOrdered};
             out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs, listHits ? &sparseInput : nullptr);
             out.hadTasks = true;
             const uint32_t allTasks = taskCount + wideCount;
@@ -2109,12 +2147,12 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     // every (x, y) with equal kmer ids, whatever the band, as the cells kernel would, in an order of no meaning -- so that the seam
     // runs the tasks the way a batch does: sparse where the optimal chain is unique, dense otherwise.  Odd tasks say that read 0
     // was the streamed one (either read may be).
-    SparseInput sparseInput{nullptr, nullptr, nullptr};
+    SparseInput sparseInput{nullptr, nullptr, nullptr, 0};
     const bool sparse = sparseDpEnabled();
     if(sparse) {
         std::vector<uint64_t> hitBase(taskCount + 1, 0);
         std::vector<uint32_t> meta(taskCount), hostHits;
-        for(uint64_t t = 0; t < taskCount; t++) hitBase[t + 1] = hitBase[t] + ((nx[t] < 65535 && ny[t] < 65535) ? hitListCapacity(nx[t], ny[t]) : 0u);
+        for(uint64_t t = 0; t < taskCount; t++) hitBase[t + 1] = hitBase[t] + ((nx[t] < 65535 && ny[t] < 65535) ? hitListCapacity(nx[t], ny[t], 13) : 0u);
         hostHits.resize(hitBase[taskCount] + 1);
         std::unordered_map<uint32_t, std::vector<uint32_t>> where;
         for(uint64_t t = 0; t < taskCount; t++) {
@@ -2144,7 +2182,9 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
         HIP_CHECK(hipMemcpyAsync(b.hitBase.data(), hitBase.data(), hitBase.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(b.hitMeta.data(), meta.data(), taskCount * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        sparseInput = SparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data()};
+        uint32_t longest = 0;
+        for(uint64_t t = 0; t < taskCount; t++) longest = std::max(longest, std::max(nx[t], ny[t]));
+        sparseInput = SparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data(), longest};
     }
     ev.create();
     try { (void)runDpTasks(ctx, ws, b, narrowCount, opt, &ev, &stats, nullptr, &wideTasks, &pairs, sparse ? &sparseInput : nullptr); } catch(...) { ev.destroy(); throw; }

@@ -31,7 +31,7 @@
 #define ANCHOR_REASON(why, n)
 #endif
 
-constexpr int ANCHOR_MAX_BITWORDS = (2 * int(SPARSE_MAX_STREAM) + 64 + 63) / 64;     // of a task's hits (sparseListCapacity)
+constexpr int ANCHOR_MAX_BITWORDS = (2 * 8192 + 64 + 63) / 64;     // of a task's hits: 16 448 of them (the wave kernel's largest class holds 15 360; the lane kernel lists up to sparseListCapacity: a task with more stays for the dense kernels)
 constexpr int ANCHOR_MAX_WINDOWS = 128;
 constexpr int ANCHOR_MAX_CELLS = 4096;           // (wx + 1)(wy + 1) of a rectangle: a byte each (census, profiles/r04_sparse_census.txt: 4 of 2 589 tasks have a larger one; 22 KB of LDS per wavefront instead of 37: seven workgroups per CU instead of four)
 constexpr int ANCHOR_MAX_SIDE = 511;             // markers on a side of a rectangle
@@ -362,6 +362,7 @@ sparseAnchorKernel(const uint32_t* __restrict__ kmerIds, const PairDesc* __restr
         const int32_t chunks = (n + WAVE - 1) / WAVE;
         walked += uint32_t(n);
         auto giveUp = [&](int why) { if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_FAR_LINK + (why == 4 ? 0 : why), pd, task); ANCHOR_REASON(why, n); } };
+        if(chunks > ANCHOR_MAX_BITWORDS) { giveUp(3); continue; }           // (more hits than the bit words hold: only the lane kernel lists that many)
         waveLdsSync();                                       // (the task before has left the shared arrays)
         // ---- sweep: live hits and anchors ----
         uint32_t window = 0;                                 // bit d: the hit d before the current one has a link from a live later hit

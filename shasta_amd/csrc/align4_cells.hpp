@@ -346,13 +346,14 @@ struct CellsChunk { uint32_t firstMember; uint16_t count, swapped; uint32_t naLo
 struct HitLists { uint32_t* hits; const uint64_t* base; uint32_t* meta; };
 constexpr uint32_t HIT_LIST_NONE = 0xffffffffu;
 // Room for a candidate's matches: the shorter read's markers and a quarter (every one matched, some twice), the random background
-// (nx ny / alphabet: 2^13 is about the smallest marker alphabet of Shasta's configurations -- k = 10 at markerDensity 0.1 has about
-// 7 900 marker k-mers, the bench's synthetic reads 15 000; 2^12 asked for 24 GB per batch of ultra-long pairs) and some slack.  Repeat-rich pairs exceed it and take the dense DP (counted:
+// (nx ny >> matchShift, Context::matchShift: measured on a sample of the read set's markers, 13 at least -- 2^13 is about the smallest
+// marker alphabet of Shasta's configurations: k = 10 at markerDensity 0.1 has about 7 900 marker k-mers, the bench's synthetic reads
+// 15 000; 2^12 asked for 24 GB per batch of ultra-long pairs; k = 14 has 640 000 and gets 18) and some slack.  Repeat-rich pairs exceed it and take the dense DP (counted:
 // the kernel table's "dense DP because: the candidate's match list overflowed").
-__host__ __device__ inline uint32_t hitListCapacity(uint32_t nx, uint32_t ny)
+__host__ __device__ inline uint32_t hitListCapacity(uint32_t nx, uint32_t ny, int matchShift)
 {
     const uint32_t shorter = nx < ny ? nx : ny;
-    return shorter + shorter / 4 + uint32_t((uint64_t(nx) * uint64_t(ny)) >> 13) + 192u;
+    return shorter + shorter / 4 + uint32_t((uint64_t(nx) * uint64_t(ny)) >> matchShift) + 192u;
 }
 
 #ifdef SHASTA_PROFILE_PHASES
@@ -415,6 +416,11 @@ constexpr int CELLS_DRAIN = SHASTA_CELLS_DRAIN;      // queue entries a lane cou
 constexpr int CELLS_RANGE_PAD = 4;        // words behind the bucket starts: the first holds the end of the last bucket (a marker reads starts[b] and starts[b + 1])
 constexpr int CELLS_UNROLL = 4;           // markers per lane per round
 constexpr int CELLS_IX_BITS = 10, CELLS_IY_BITS = 12, CELLS_COUNT_BITS = 10;   // packed LDS cell word
+// The windowed class (align4CellsLongKernel: either read of any length below 65 535 markers): fourteen bits of iY (nx + ny up to
+// 163 000 at deltaY = 10) and EIGHT of count -- a lane adds only while the count it sees is below the threshold (the count beyond
+// it means nothing: createCells only asks whether a cell has minEntryCountPerCell entries), so the field holds threshold + the adds
+// in flight; an add that finds 255 has carried into the cell's key: the candidate is flagged and climbs to the HBM-scratch kernel.
+constexpr int CELLS_LONG_IY_BITS = 14, CELLS_LONG_COUNT_BITS = 8;
 constexpr int CELLS_STAGE = 8;            // DP tasks staged per wave before one global append
 // A wavefront's slot: kept[64 Q] | queue[max(64 Q, CELLS_QUEUE)] (both the graph's cell map[128 Q] later) | scratch[8] | stage[4 CELLS_STAGE].
 // The queue takes the matches of one trip of all CELLS_UNROLL groups of a round at once: at most CELLS_UNROLL * 64.
@@ -451,17 +457,23 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 // tasks the kernel leaves the candidate's active cells, activeKeys[64 Q blockIdx.x ...] and activeCounts[blockIdx.x] (~0 if the
 // tables overflowed) -- the reference breaks such ties by the order of its union-find representatives, which the host
 // reproduces from the set of active cells (resolveComponentTies, align4.hip).
-template<int Q, bool DUMP = false>
-__global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS) SHASTA_CELLS_OCCUPANCY
-align4CellsChunkKernel(
+// LONG (align4CellsLongKernel): the windowed class.  A chunk is any CELLS_LONG_WAVES candidates; each tables its SHORTER read in
+// windows of 2^13 markers, one after the other -- the whole workgroup builds the window's table and streams the other read through
+// it, the cell counts (the packed table with the wider fields above) staying from window to window -- so that a pair of two reads
+// beyond every LDS table class (/root/reference/conf/Nanopore-UL-May2022.conf: no read below 50 000 bases) has its cells counted
+// and its matches LISTED in LDS like any other, instead of in the kernel with its tables in HBM scratch, which lists nothing.
+constexpr int CELLS_LONG_WAVES = 16, CELLS_LONG_THREADS = 64 * CELLS_LONG_WAVES;
+template<int Q, bool DUMP, bool LONG>
+__device__ __forceinline__ void cellsChunkBody(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
-    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY,
     DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
-    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts, HitLists hitLists)
+    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts, const HitLists& hitLists)
 {
     extern __shared__ uint32_t ldsWords[];
-    __shared__ uint32_t waveTotals[SHASTA_CELLS_MAX_THREADS / 64];
+    __shared__ uint32_t waveTotals[(LONG ? CELLS_LONG_THREADS : SHASTA_CELLS_MAX_THREADS) / 64];
+    constexpr int IY_BITS = LONG ? CELLS_LONG_IY_BITS : CELLS_IY_BITS, COUNT_BITS = LONG ? CELLS_LONG_COUNT_BITS : CELLS_COUNT_BITS;
     constexpr int MAXC = 64 * Q;
     if(blockIdx.x >= chunkCount) return;
     const CellsChunk chunk = chunks[blockIdx.x];
@@ -493,9 +505,7 @@ align4CellsChunkKernel(
     // --- table of the read shared by every candidate of the chunk: read 0, or (swapped chunk:
     //     candidates gathered by the host because they share a short read 1) read 1 ---
     const PairDesc pdFirst = pairs[members[chunk.firstMember]];
-    const bool swapped = (chunk.swapped & 1) != 0, noGrid = (chunk.swapped & 2) != 0;
-    const uint32_t* __restrict__ tabSeq = kmerIds + (swapped ? pdFirst.begin1 : pdFirst.begin0);
-    const uint32_t tabCount = swapped ? pdFirst.ny : pdFirst.nx;  // < NA (host)
+    const bool chunkSwapped = (chunk.swapped & 1) != 0, noGrid = LONG || (chunk.swapped & 2) != 0;
     // The exact bucketed table: h = kmerId * odd constant is a bijection of the 32-bit values, so (bucket = the top bits of h, the
     // other bits of h) IS the kmer id.  2^F NA buckets (F = cellsBucketFactorLog2(Q) = 1) for at most NA markers (load factor below 1/2: the loop over a bucket's
     // entries below runs as long as the fullest bucket of a round's 256 markers); an entry -- the other bits of h | the
@@ -503,8 +513,11 @@ align4CellsChunkKernel(
     // two to a word.  A counting sort: the sizes by LDS atomics on the halves, one scan that leaves every bucket's END, and the
     // fill counts each end down to the bucket's start (the reference's own way of filling its buckets,
     // MemoryMappedVectorOfVectors::storeMultithreaded) -- no compare-and-swap loops, nothing that can overflow.
-    for(uint32_t k = threadIdx.x; k < rangeWords; k += blockDim.x) range[k] = 0;
     if(lane == 0) ownScratch[3] = 0;
+    // tabSeq[0 .. tabCount): the tabled read, or (LONG) a window of it; tabCount < NA, or = NA for a window (the entries' ordinal
+    // field holds NA values, the 16-bit bucket starts NA <= 2^13 positions).
+    auto buildTable = [&](const uint32_t* __restrict__ tabSeq, const uint32_t tabCount) {
+    for(uint32_t k = threadIdx.x; k < rangeWords; k += blockDim.x) range[k] = 0;
     __syncthreads();
     // (Four markers per thread and trip, loaded before any is used: one marker per trip waited for memory every trip.)
     const uint32_t tabLast = tabCount ? tabCount - 1u : 0u;
@@ -556,6 +569,8 @@ align4CellsChunkKernel(
         }
     }
     __syncthreads();
+    };
+    if(!LONG) buildTable(kmerIds + (chunkSwapped ? pdFirst.begin1 : pdFirst.begin0), chunkSwapped ? pdFirst.ny : pdFirst.nx);      // (fewer than NA markers: the host's classes)
     PHASE_MARK(0);
 
     // The stream in groups of 64 markers dealt to the wavefronts in turn (group g to wavefront g mod waves: every wavefront
@@ -582,6 +597,7 @@ align4CellsChunkKernel(
         if(more) { pairAhead = members[chunk.firstMember + c + 1]; pdAhead = pairs[pairAhead]; }
         kept = slots + (c - group) * cellsSlotLdsWords(Q);
         scratch = kept + scratchAt;
+        const bool swapped = LONG ? ny < nx : chunkSwapped;        // (LONG: every candidate tables its own shorter read)
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
@@ -668,7 +684,7 @@ align4CellsChunkKernel(
 #pragma unroll
             for(int u = 0; u < N; u++) {
                 key[u] = pending[u] ? ((iY[u] << 16) | iX[u]) : EMPTY32;
-                packed[u] = (iY[u] << CELLS_IX_BITS) | iX[u];
+                packed[u] = (iY[u] << CELLS_IX_BITS) | iX[u];                   // (LONG: fourteen bits of iY, the host's class rule)
                 cs[u] = hash32(key[u]) >> scShift;
                 probes[u] = 0;
             }
@@ -683,12 +699,16 @@ align4CellsChunkKernel(
                         const uint32_t cur = ldsLoadNow(&cells[cs[u]]);
                         bool done = false;
                         uint32_t before = 0;
-                        if(cur != EMPTY32 && (cur >> CELLS_COUNT_BITS) == packed[u]) {
-                            before = atomicAdd(&cells[cs[u]], 1u) & ((1u << CELLS_COUNT_BITS) - 1);
+                        if(cur != EMPTY32 && (cur >> COUNT_BITS) == packed[u]) {
+                            if(LONG && (cur & ((1u << COUNT_BITS) - 1)) >= threshold) before = threshold;      // (a kept cell: its count is not needed any more)
+                            else {
+                                before = atomicAdd(&cells[cs[u]], 1u) & ((1u << COUNT_BITS) - 1);
+                                if(LONG && before == (1u << COUNT_BITS) - 1) { overflow = max(overflow, 1); reason |= 1; }     // (carried into the key)
+                            }
                             done = true;
                         } else if(cur == EMPTY32) {
                             // Claim the slot; on failure look at the same slot again.
-                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << CELLS_COUNT_BITS) | 1u) == EMPTY32;
+                            done = atomicCAS(&cells[cs[u]], EMPTY32, (packed[u] << COUNT_BITS) | 1u) == EMPTY32;
                         } else {
                             cs[u] = (cs[u] + 1) & (SC - 1);
                             if(++probes[u] == SC) { overflow = max(overflow, 1); reason |= 1; pending[u] = false; }
@@ -706,6 +726,11 @@ align4CellsChunkKernel(
             }
         };
 
+        // LONG: the tabled read in windows of NA markers, the stream once per window; table ordinal = window's first marker + the entry's.
+        const uint32_t tabTotal = LONG ? (swapped ? ny : nx) : 1u;
+        const uint32_t* __restrict__ const tabAll = kmerIds + (swapped ? pd.begin1 : pd.begin0);
+        for(uint32_t windowBase = 0; windowBase < tabTotal; windowBase += (LONG ? NA : 1u)) {
+        if(LONG) buildTable(tabAll + windowBase, min(NA, tabTotal - windowBase));          // (ends with a barrier)
         uint32_t kmNext[CELLS_UNROLL];
         // (Unconditional loads from a clamped position: behind a branch the compiler cannot count the loads in flight and
         // waits for all of them -- vmcnt(0) right after issuing the next round's -- where the marker it needs arrived long ago.)
@@ -737,7 +762,7 @@ align4CellsChunkKernel(
                     const uint32_t at = base + uint32_t(k) * WAVE + uint32_t(lane);
                     hit[k] = at < queued;
                     const uint32_t e = queue[hit[k] ? at : 0u];
-                    ti[k] = e >> 16; ts[k] = e & 0xffffu;
+                    ti[k] = (e >> 16) + (LONG ? windowBase : 0u); ts[k] = e & 0xffffu;
                     if(listHits && hit[k] && listAt + at < hitCapacity) hitList[listAt + at] = swapped ? ((ts[k] << 16) | ti[k]) : ((ti[k] << 16) | ts[k]);
                 }
                 if(SHASTA_ABLATE != 4) countHits(std::integral_constant<int, CELLS_DRAIN>{}, hit, ti, ts);
@@ -807,6 +832,8 @@ align4CellsChunkKernel(
         }
         if(queued) { SUBPHASE_COUNT(7); drain(); }
         SUBPHASE_FLUSH();
+        if(LONG && windowBase + NA < tabTotal) __syncthreads();       // (every wavefront is done with this window's table)
+        }
         // What went wrong in any wavefront's share of the rounds reaches the candidate's graph through its slot.
         if(overflow | reason) atomicOr(&scratch[4], uint32_t(reason & 7) | ((reason & 8) ? 0x20u : 0u) | (overflow == 2 ? 0x10u : (overflow == 1 ? 0x08u : 0u)));
         if(SHASTA_ABLATE != 3) __syncthreads();                       // the cell region is cleared for the next candidate
@@ -869,7 +896,8 @@ align4CellsChunkKernel(
             for(int r = 0; r < Q; r++) { before[q][r] = 0; after[q][r] = 0; }
         {
             constexpr int MAP = 2 * MAXC, MAP_LOG2 = (Q == 2 ? 8 : 9), IDX_BITS = MAP_LOG2 - 1;
-            static_assert(MAP == (1 << MAP_LOG2) && CELLS_IX_BITS + CELLS_IY_BITS + IDX_BITS < 32, "map entry");
+            // (LONG: 24 + 8 bits fill the word; the all-ones entry is no cell: the class rule keeps iY below 2^14 - 1)
+            static_assert(MAP == (1 << MAP_LOG2) && CELLS_IX_BITS + IY_BITS + IDX_BITS <= (LONG ? 32 : 31), "map entry");
             uint32_t* const map = kept;
             waveLdsSync();                                                  // every lane has read its keys
             for(int k = lane; k < MAP; k += WAVE) map[k] = EMPTY32;
@@ -893,7 +921,7 @@ align4CellsChunkKernel(
                 for(int d = 0; d < 8; d++) {                                 // the eight neighbours: all reads first
                     const int dX = (d < 3) ? -1 : (d < 5 ? 0 : 1), dY = (d < 3) ? d - 1 : (d == 3 ? -1 : (d == 4 ? 1 : d - 6));
                     const int32_t nX = iX + dX, nY = iY + dY;
-                    live[d] = key[q] != EMPTY32 && uint32_t(nX) < (1u << CELLS_IX_BITS) && uint32_t(nY) < (1u << CELLS_IY_BITS);
+                    live[d] = key[q] != EMPTY32 && uint32_t(nX) < (1u << CELLS_IX_BITS) && uint32_t(nY) < (1u << IY_BITS) - (LONG ? 1u : 0u);
                     target[d] = (uint32_t(nY) << CELLS_IX_BITS) | uint32_t(nX);
                     h[d] = hash32(target[d]) >> (32 - MAP_LOG2);
                     e[d] = map[live[d] ? h[d] : 0u];
@@ -1061,4 +1089,30 @@ align4CellsChunkKernel(
         }
     }
     PHASE_MARK(6);
+}
+
+template<int Q, bool DUMP = false>
+__global__ void __launch_bounds__(SHASTA_CELLS_MAX_THREADS) SHASTA_CELLS_OCCUPANCY
+align4CellsChunkKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
+    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
+    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts, HitLists hitLists)
+{
+    cellsChunkBody<Q, DUMP, false>(kmerIds, pairs, chunks, chunkCount, members, opt, magicX, magicY, tasks, taskCount, taskCapacity, pairFlags, activeKeys, activeCounts, hitLists);
+}
+
+// The windowed class: sixteen wavefronts a workgroup (one workgroup per CU by its LDS: four wavefronts per SIMD stream a candidate
+// together), 256 kept cells per candidate.
+template<bool DUMP = false>
+__global__ void __launch_bounds__(CELLS_LONG_THREADS)
+align4CellsLongKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
+    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
+    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags, uint32_t* __restrict__ activeKeys, uint32_t* __restrict__ activeCounts, HitLists hitLists)
+{
+    cellsChunkBody<4, DUMP, true>(kmerIds, pairs, chunks, chunkCount, members, opt, magicX, magicY, tasks, taskCount, taskCapacity, pairFlags, activeKeys, activeCounts, hitLists);
 }

@@ -34,7 +34,7 @@
 // dependent loads, and a wavefront that holds 10 KB of LDS while it waits for them keeps the next task's wavefront out.
 //
 // LDS: 8 bytes per hit (ordinals, D in 16 bits, `from` + flags) in the classes whose D fits -- the tabled read has fewer than
-// SPARSE_MAX_STREAM markers, so D >= 6 - min(p, s) > -8 192, and D <= 6 per hit of the class's capacity; 10 bytes (D in 32 bits) in
+// SPARSE_MAX_STREAM = 32 768 markers, so D >= 6 - min(p, s) > -32 768, and D <= 6 per hit of the class's capacity; 10 bytes (D in 32 bits) in
 // the last class, and in all of them with SHASTA_MI355X_CHAIN_WAVE_WIDE_D=1 (the form before: 16, 8, 4 wavefronts per CU instead of
 // 20, 10, 5).  Four launches by capacity -- 1 016 hits (8 KB a wavefront: 87 % of the
 // tasks at 100 k reads), 2 032 (13 %), 4 064 (0.1 %), 15 360 -- the first two of wavefronts that go over the task list in blocks of
@@ -46,7 +46,7 @@
 
 // D in 16 bits where every D of a task of the class fits: above -SPARSE_MAX_STREAM (the border term of a hit, -min(p, s), p an ordinal in
 // the tabled read) and at most 6 per hit.
-constexpr bool chainWaveNarrowD(uint32_t capacity) { return SPARSE_MAX_STREAM < 32768u && 6u * capacity + 6u < 32768u; }
+constexpr bool chainWaveNarrowD(uint32_t capacity) { return SPARSE_MAX_STREAM <= 32768u && 6u * capacity + 6u < 32768u; }      // (p < 32 768: 6 - min(p, s) >= -32 761)
 constexpr uint32_t chainWaveHitBytes(uint32_t capacity, bool narrow) { return narrow && chainWaveNarrowD(capacity) ? 8u : 10u; }
 constexpr size_t chainWaveLdsBytes(uint32_t capacity, bool narrow) { return size_t(capacity) * chainWaveHitBytes(capacity, narrow) + 4u * ((size_t(capacity) + 63u) / 64u); }
 // Workgroups of one wavefront, as many as the LDS lets a CU hold.

@@ -96,7 +96,7 @@ enum DpGiveUp : int { GIVE_UP_NO_LIST = 0, GIVE_UP_LIST_OVERFLOW, GIVE_UP_LONG_S
 constexpr int DP_GIVE_UP_REASONS = 16;
 const char* const DP_GIVE_UP_NAMES[DP_GIVE_UP_REASONS] = {
     "dense DP because: the candidate's matches were not listed (HBM-scratch cells kernel)", "dense DP because: the candidate's match list overflowed",
-    "dense DP because: the tabled read has more than 8192 markers", "dense DP because: 16 matches of one marker inside the band",
+    "dense DP because: the tabled read has more than 32768 markers", "dense DP because: 16 matches of one marker inside the band",
     "dense DP because: more matches inside the band than the task's list holds", "dense DP because: a match's predecessors lie further back than the chain kernel looks",
     "dense DP because: the best chain ties with the empty alignment", "dense DP because: an optimal link of a live match beyond its link word",
     "dense DP because: no match lies on every optimal chain", "dense DP because: more than 128 windows between anchors",

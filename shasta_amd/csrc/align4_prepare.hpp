@@ -6,38 +6,49 @@
 #pragma once
 
 // (constexpr arrays cannot be indexed by a run-time value in device code; these can)
-__host__ __device__ inline int cellsNaLog2(int c) { return c == 0 ? CELLS_NA_LOG2[0] : (c == 1 ? CELLS_NA_LOG2[1] : (c == 2 ? CELLS_NA_LOG2[2] : CELLS_NA_LOG2[3])); }
-__host__ __device__ inline int cellsScLog2(int c) { return c == 0 ? CELLS_SC_LOG2[0] : (c == 1 ? CELLS_SC_LOG2[1] : (c == 2 ? CELLS_SC_LOG2[2] : CELLS_SC_LOG2[3])); }
-__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : (c == 2 ? CELLS_CHUNK_MAX[2] : CELLS_CHUNK_MAX[3])); }
-static_assert(CELLS_CLASSES == 4, "cellsNaLog2 / cellsScLog2 / cellsChunkMax name four classes");
+__host__ __device__ inline int cellsNaLog2(int c) { return c == 0 ? CELLS_NA_LOG2[0] : (c == 1 ? CELLS_NA_LOG2[1] : (c == 2 ? CELLS_NA_LOG2[2] : (c == 3 ? CELLS_NA_LOG2[3] : CELLS_NA_LOG2[4]))); }
+__host__ __device__ inline int cellsScLog2(int c) { return c == 0 ? CELLS_SC_LOG2[0] : (c == 1 ? CELLS_SC_LOG2[1] : (c == 2 ? CELLS_SC_LOG2[2] : (c == 3 ? CELLS_SC_LOG2[3] : CELLS_SC_LOG2[4]))); }
+__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : (c == 2 ? CELLS_CHUNK_MAX[2] : (c == 3 ? CELLS_CHUNK_MAX[3] : CELLS_CHUNK_MAX[4]))); }
+static_assert(CELLS_CLASSES == 5 && CELLS_LONG == 4, "cellsNaLog2 / cellsScLog2 / cellsChunkMax name five classes, the last one the windowed one");
 constexpr int CELLS_CLASS_BITS = 3;                         // the class (0 .. CELLS_CLASSES, the last = HBM scratch) in the sort key
 
-struct CellsClassRule { uint64_t deltaX, deltaY; bool packedOk; };
-inline CellsClassRule cellsClassRule(const DeviceOptions& opt)
+// estimateShift: a candidate's random background is about nx ny >> estimateShift matches (Context::matchShift: from a sample of the
+// read set's markers; 13 for the k = 10 alphabets, 18 at k = 14).
+struct CellsClassRule { uint64_t deltaX, deltaY; bool packedOk, longOk; int estimateShift; };
+inline CellsClassRule cellsClassRule(const DeviceOptions& opt, int estimateShift)
 {
     CellsClassRule r;
     r.deltaX = opt.deltaX; r.deltaY = opt.deltaY;
     // The packed LDS cell word counts up to 2^CELLS_COUNT_BITS - 1 entries; a cell holds at most
     // ceil(deltaX * deltaY / 2) (one (x,y) per lattice point of the right parity).
     r.packedOk = (uint64_t(opt.deltaX) * opt.deltaY + 1) / 2 < (1ULL << CELLS_COUNT_BITS) && opt.deltaX >= 2 && opt.deltaY >= 2;
+    // The windowed class counts in 8 bits and stops adding at the threshold (align4_cells.hpp): thresholds up to 191 leave the
+    // adds in flight room (a count that reaches 255 all the same is detected and the candidate climbs to the HBM-scratch kernel).
+    r.longOk = opt.deltaX >= 2 && opt.deltaY >= 2 && opt.minEntryCountPerCell <= 191;
+    r.estimateShift = estimateShift;
     return r;
 }
 // Class of a candidate that tables a read of `tabled` markers: table of the tabled read at load <= 1/2, cell table sized for
 // the expected number of distinct cells (random background ~ nx*ny / alphabet, plus the diagonal) at load <= 3/4.  Overflow is
-// detected on the device and climbs one class.  CELLS_CLASSES: the kernel with its tables in HBM scratch.
+// detected on the device and climbs one class.  CELLS_LONG: the class that tables the shorter read in windows of 2^13 markers
+// (either read of any length below 65 535; wider cell indices).  CELLS_CLASSES: the kernel with its tables in HBM scratch.
 __host__ __device__ inline int cellsClassFor(const CellsClassRule& rule, uint64_t tabled, uint64_t nx, uint64_t ny)
 {
-    if(nx >= 65535 || ny >= 65535 || !rule.packedOk) return CELLS_CLASSES;
-    // Cell indices must fit the packed word and the single-multiply division must be exact.
-    if((nx + ny) / rule.deltaX >= (1ULL << CELLS_IX_BITS) || (nx + ny) / rule.deltaY >= (1ULL << CELLS_IY_BITS)) return CELLS_CLASSES;
+    if(nx >= 65535 || ny >= 65535) return CELLS_CLASSES;
+    // The single-multiply division must be exact.
     if((nx + ny) * (rule.deltaX > rule.deltaY ? rule.deltaX : rule.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
-    const uint64_t cells = (nx * ny >> SHASTA_CELLS_ESTIMATE_SHIFT) + (nx + ny) / 32 + 32;
-    for(int c = 0; c < CELLS_CLASSES; c++) {
-        if(tabled < (1ULL << cellsNaLog2(c)) && 4 * cells <= (3ULL << cellsScLog2(c))) return c;
+    const uint64_t cells = (nx * ny >> rule.estimateShift) + (nx + ny) / 32 + 32;
+    // Cell indices must fit the packed word.
+    if(rule.packedOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_IY_BITS)) {
+        for(int c = 0; c < CELLS_LONG; c++) {
+            if(tabled < (1ULL << cellsNaLog2(c)) && 4 * cells <= (3ULL << cellsScLog2(c))) return c;
+        }
     }
+    if(rule.longOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_LONG_IY_BITS) - 1 && 4 * cells <= (3ULL << cellsScLog2(CELLS_LONG))) return CELLS_LONG;
     return CELLS_CLASSES;
 }
-// Every candidate tables whichever of its two reads lands in the smaller class (ties: read 0).
+// Every candidate tables whichever of its two reads lands in the smaller class (ties: read 0).  (The windowed class tables the
+// shorter read whatever this says: align4CellsLongKernel decides for itself.)
 struct CellsChoice { int cls; bool swapped; };
 __host__ __device__ inline CellsChoice cellsChoice(const CellsClassRule& rule, uint32_t nx, uint32_t ny)
 {
@@ -46,6 +57,7 @@ __host__ __device__ inline CellsChoice cellsChoice(const CellsClassRule& rule, u
     CellsChoice r;
     r.swapped = c1 < c0;
     r.cls = r.swapped ? c1 : c0;
+    if(r.cls == CELLS_LONG) r.swapped = ny < nx;
     return r;
 }
 
@@ -73,8 +85,10 @@ cellsClassKeysKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_r
         // The tabled oriented read by its ID (the same order as by its first marker, in 18 bits where that takes 29: three passes
         // of the sort below instead of five).
         const shasta_oriented_read_pair c = candidates[q];
-        const uint64_t tabled = choice.swapped ? (2ULL * c.readIds[1] + (c.isSameStrand ? 0u : 1u)) : 2ULL * c.readIds[0];
-        keys[q] = (uint64_t(cls) << (tabledBits + 1)) | (uint64_t(choice.swapped ? 1 : 0) << tabledBits) | tabled;
+        // (the windowed class tables every candidate's read anew: its chunks are any sixteen candidates, one group)
+        const bool grouped = cls != CELLS_LONG;
+        const uint64_t tabled = !grouped ? 0ULL : (choice.swapped ? (2ULL * c.readIds[1] + (c.isSameStrand ? 0u : 1u)) : 2ULL * c.readIds[0]);
+        keys[q] = (uint64_t(cls) << (tabledBits + 1)) | (uint64_t(grouped && choice.swapped ? 1 : 0) << tabledBits) | tabled;
         ids[q] = q;
         bytes = 4ULL * (uint64_t(pd.nx) + pd.ny);
     }

@@ -35,8 +35,10 @@
 //   dpDenseFlagsKernel / dpDenseListKernel   the sorted task list without the certified tasks, and the class counts of what is left.
 #pragma once
 
-constexpr uint32_t SPARSE_MAX_STREAM = 8192;                 // markers of the read the hits are ordered by (4-bit counters: 4 KB per wavefront): the tabled read, always below this
-constexpr uint32_t SPARSE_COUNTER_WORDS = SPARSE_MAX_STREAM / 8;
+// Markers of the read the hits are ordered by (4-bit counters: 1.25 bytes of LDS per marker and wavefront): the tabled read -- below
+// 8 192 in the cells stage's first four classes, the shorter read of the candidate in the windowed one (round 6).  32 768: the list word
+// of a finished hit holds the ordinal in 15 bits, and D of a hit of such a read still fits the wave kernel's 16 bits (6 - min(p, s) > -32 768).
+constexpr uint32_t SPARSE_MAX_STREAM = 32768;
 constexpr int SPARSE_RING = 64;                              // slots of a lane's ring: the hits it can look back on and the next ones it will need
 constexpr int SPARSE_LOOK_BACK = 56;                         // hits a lane can look back
 enum SparseState : uint8_t { SPARSE_DENSE = 0, SPARSE_CERTIFIED = 1, SPARSE_SORTED = 2, SPARSE_AMBIGUOUS = 3, SPARSE_COMPLETE = 4, SPARSE_COMPLETE_STREAM = 5 };   // COMPLETE_STREAM: COMPLETE, and the alignment in shasta::compress form at the end of the task's room in the list of sorted hits (the wave kernel's; compressWriteKernel copies it)
@@ -92,19 +94,21 @@ __device__ __forceinline__ void noteGiveUp(DpControl* control, int why, const Pa
 // Two launches by the markers of the read the order is by: up to 4 096 (5 KB of counters a wavefront: 32 wavefronts per CU; 99 % of
 // the tasks at 100 k reads) and beyond (10 KB, 16 per CU).  The kernel waits for memory, it does not compute: twice the wavefronts
 // in flight is what it needed (one launch sized for 8 192 markers: 14 ms per step alone, 72 ms of launches sharing the device).
-template<int MAX_STREAM, int MIN_STREAM>
-__global__ void __launch_bounds__(256)
+// (round 6) ... and two more for the windowed class's candidates: up to 16 384 markers (two wavefronts a workgroup, 20 KB each) and up to
+// 32 768 (one, 40 KB); launched only for a batch that has such candidates.
+template<int MAX_STREAM, int MIN_STREAM, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES)
 sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, uint32_t taskCount,
     const uint32_t* __restrict__ hits, const uint64_t* __restrict__ hitBase, const uint32_t* __restrict__ hitMeta,
     const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ sorted, uint32_t* __restrict__ inBand, uint8_t* __restrict__ state, DpControl* __restrict__ control, bool noLaneKernel,
     uint32_t* __restrict__ waveLists)
 {
     static_assert(MAX_STREAM <= int(SPARSE_MAX_STREAM) && MIN_STREAM < MAX_STREAM && MAX_STREAM % 8 == 0, "classes of the tabled read's markers");
-    __shared__ uint32_t counts[4][MAX_STREAM / 8], cursors[4][MAX_STREAM / 8];
-    __shared__ uint16_t wordStart[4][MAX_STREAM / 8];
+    __shared__ uint32_t counts[WAVES][MAX_STREAM / 8], cursors[WAVES][MAX_STREAM / 8];
+    __shared__ uint16_t wordStart[WAVES][MAX_STREAM / 8];
     const int lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * 4u + wave;
+    const uint32_t t = blockIdx.x * uint32_t(WAVES) + wave;
     if(t >= taskCount) return;                             // (whole wavefronts: no block barrier below)
     const DpTask task = tasks[t];
     const PairDesc pd = pairs[task.pair];
@@ -169,7 +173,7 @@ sparseSortKernel(const PairDesc* __restrict__ pairs, const DpTask* __restrict__ 
 #pragma unroll
     for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
     const uint32_t total = uint32_t(__shfl(int(inclusive), WAVE - 1, WAVE));
-    if(total > sparseListCapacity(pd.nx, pd.ny) || (noLaneKernel && chainWaveClassOf(total) < 0)) {
+    if(total > sparseListCapacity(pd.nx, pd.ny) || total > 0xffffu || (noLaneKernel && chainWaveClassOf(total) < 0)) {          // (0xffff: the words' first positions are 16-bit)
         // (noLaneKernel: the wave kernel is on and sparseChainKernel is not launched -- what the wave kernel's largest class does not hold is the dense kernels')
         if(lane == 0) { state[t] = SPARSE_DENSE; noteGiveUp(control, GIVE_UP_SORTED_CAPACITY, pd, task); }
         return;

@@ -27,6 +27,7 @@ struct Context {
     DeviceBuffer<uint32_t> kmerIds;          // M
     DeviceBuffer<uint8_t> readFlags;         // R
     DeviceBuffer<uint4> tileDesc;            // ceil(M/HASH_TILE)+1: {first oriented read, its palindromic flag, its end (u64)} per hash tile
+    int matchShift = 13;                     // two random markers of the read set are equal about once in 2^(matchShift + 1) .. 2^(matchShift + 2) pairs (setMarkers' sample; never below 13)
 
     // The aligner runs its batches on several host workers (ALIGN_MAX_WORKERS at most), each with its own stream, sort
     // workspace, side stream (wide-band DP classes) and grow-only batch scratch: worker 0 uses `stream` / `sortWs`.
@@ -44,7 +45,7 @@ struct Context {
     std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
     // Kernels that need more dynamic LDS than the default get the attribute once per context, i.e. on this context's device
     // (hipFuncSetAttribute acts on the current device; the aligner's workers may get there at the same time).
-    std::once_flag cellsLdsAttribute[2], cellsDumpLdsAttribute, wideDpLdsAttribute, palindromicLdsAttribute;      // per context = per device (hipFuncSetAttribute is per device)
+    std::once_flag cellsLdsAttribute[3], cellsDumpLdsAttribute, wideDpLdsAttribute, palindromicLdsAttribute;      // per context = per device (hipFuncSetAttribute is per device)
     KernelTimers timers;                     // per-kernel HIP-event times since the last reset (shasta_mi355x_kernel_table)
     // The aligner's own events (a call's begin / end / join, two per worker): made once and kept -- fifteen hipEventCreate at the head
     // of every call and fifteen hipEventDestroy at its end were 4 + 5-10 ms of a 130 ms call on the host's clock (round 5,

@@ -71,6 +71,14 @@ stripMarkersKernel(const uint32_t* __restrict__ words, uint32_t* __restrict__ km
     }
 }
 
+// Every stride-th marker, for Context::setMarkers' estimate of how often two markers of the read set are equal.
+__global__ void __launch_bounds__(256)
+sampleMarkersKernel(const uint32_t* __restrict__ kmerIds, uint64_t stride, uint32_t count, uint32_t* __restrict__ sample)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < count) sample[i] = kmerIds[uint64_t(i) * stride];
+}
+
 // Per hash tile (256 consecutive markers): the oriented read that owns its first marker, where
 // that read ends, and the read's palindromic flag -- everything most threads of the tile need,
 // in one 16-byte record (upper_bound on toc).
@@ -726,6 +734,36 @@ void Context::setMarkers(uint64_t readCountArg, const uint64_t* tocArg, const vo
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(stream));
         }
+    }
+    // How often two markers of this read set are equal -- the random background of a candidate's marker-match matrix, nx ny times
+    // this -- from a sample of 2^16 markers spread over all reads: floor(log2(1 / P)) - 1, never below 13 (k = 10 at markerDensity
+    // 0.1 has about 7 900 marker k-mers; k = 14 has 640 000: sixty times fewer random matches per pair of reads).  The aligner sizes
+    // its match lists and picks its cell-table classes by it (align4_prepare.hpp); a wrong estimate costs speed, never results --
+    // whatever overflows its room or its table is detected on the device and runs again in a larger one.
+    matchShift = 13;
+    if(markerCount >= 2) {
+        const uint32_t sampleCount = uint32_t(std::min<uint64_t>(markerCount, 65536));
+        const uint64_t stride = markerCount / sampleCount;
+        DeviceBuffer<uint32_t> sampleDevice;
+        sampleDevice.reserve(sampleCount, stream);
+        hipLaunchKernelGGL(sampleMarkersKernel, dim3(divUp(sampleCount, 256)), dim3(256), 0, stream, (const uint32_t*)kmerIds.data(), stride, sampleCount, sampleDevice.data());
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> sample(sampleCount);
+        HIP_CHECK(hipMemcpyAsync(sample.data(), sampleDevice.data(), sampleCount * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::sort(sample.begin(), sample.end());
+        uint64_t equalPairs = 0;
+        for(size_t i = 0; i < sample.size(); ) {
+            size_t j = i + 1;
+            while(j < sample.size() && sample[j] == sample[i]) ++j;
+            equalPairs += uint64_t(j - i) * uint64_t(j - i - 1) / 2;
+            i = j;
+        }
+        const double pairs = double(sampleCount) * double(sampleCount - 1) / 2.;
+        int shift = 30;
+        if(equalPairs) { shift = 0; while(shift < 30 && double(equalPairs) * double(2ULL << shift) <= pairs) ++shift; shift -= 1; }      // floor(log2(pairs / equalPairs)) - 1
+        matchShift = std::min(std::max(shift, 13), 30);
+        if(const char* e = std::getenv("SHASTA_MI355X_MATCH_SHIFT")) matchShift = std::min(std::max(std::atoi(e), 8), 30);       // (tests and timing experiments)
     }
     const uint64_t tileCount = (markerCount + HASH_TILE - 1) / HASH_TILE;
     tileDesc.reserve(tileCount + 1, stream);

@@ -49,7 +49,41 @@ uint64_t decimal(const Text& t)
     return n;
 }
 
+// Assembler::suppressAlignment (src/AssemblerAlign.cpp:1078-1162) on the meta data of two reads.
+bool suppressPair(const char* m0, const char* e0, const char* m1, const char* e1, uint64_t delta)
+{
+    for(const char* key : {"ch", "sampleid", "runid"}) {                               // :1089-1131
+        const Text v0 = metaDataValue(m0, e0, key);
+        if(v0.empty()) return false;
+        const Text v1 = metaDataValue(m1, e1, key);
+        if(v1.empty()) return false;
+        if(!same(v0, v1)) return false;
+    }
+    const Text read0 = metaDataValue(m0, e0, "read");                                  // :1138-1146
+    if(read0.empty()) return false;
+    const Text read1 = metaDataValue(m1, e1, "read");
+    if(read1.empty()) return false;
+    const int64_t r0 = int64_t(decimal(read0)), r1 = int64_t(decimal(read1));       // :1152-1153
+    return std::llabs(r0 - r1) < int64_t(delta);                                       // :1160
+}
+
 }  // namespace
+
+// The same step on arrays in memory (what a caller that holds the candidates of the first seam in memory runs before the second
+// -- bench.py's steps of the configs[3] / [4] workloads): candidates compacted in place, no side file, no console lines.
+uint64_t suppressAlignmentCandidatesInMemory(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount,
+    shasta_oriented_read_pair* candidates, uint64_t candidateCount, uint64_t delta)
+{
+    uint64_t kept = 0;
+    for(uint64_t i = 0; i < candidateCount; i++) {
+        const shasta_oriented_read_pair c = candidates[i];
+        if(c.readIds[0] >= readCount || c.readIds[1] >= readCount) throw std::runtime_error("suppressAlignmentCandidates: a candidate names a read that has no meta data.");
+        const bool drop = suppressPair(metaData + metaDataToc[c.readIds[0]], metaData + metaDataToc[c.readIds[0] + 1],
+            metaData + metaDataToc[c.readIds[1]], metaData + metaDataToc[c.readIds[1] + 1], delta);
+        if(!drop) candidates[kept++] = c;
+    }
+    return kept;
+}
 
 uint64_t suppressAlignmentCandidates(const std::string& dataDirectory, uint64_t delta, size_t /* threadCount */)
 {
@@ -62,24 +96,10 @@ uint64_t suppressAlignmentCandidates(const std::string& dataDirectory, uint64_t 
     const uint64_t candidateCount = candidates.size();
     const uint64_t readCount = metaData.size();
 
-    auto value = [&](uint32_t readId, const char* key) {
-        if(readId >= readCount) throw std::runtime_error("suppressAlignmentCandidates: a candidate names a read that has no meta data.");
-        return metaDataValue(metaData.begin(readId), metaData.begin(readId) + (metaData.toc[readId + 1] - metaData.toc[readId]), key);
-    };
     auto suppress = [&](uint32_t readId0, uint32_t readId1) {
-        for(const char* key : {"ch", "sampleid", "runid"}) {                               // :1089-1131
-            const Text v0 = value(readId0, key);
-            if(v0.empty()) return false;
-            const Text v1 = value(readId1, key);
-            if(v1.empty()) return false;
-            if(!same(v0, v1)) return false;
-        }
-        const Text read0 = value(readId0, "read");                                         // :1138-1146
-        if(read0.empty()) return false;
-        const Text read1 = value(readId1, "read");
-        if(read1.empty()) return false;
-        const int64_t r0 = int64_t(decimal(read0)), r1 = int64_t(decimal(read1));       // :1152-1153
-        return std::llabs(r0 - r1) < int64_t(delta);                                       // :1160
+        if(readId0 >= readCount || readId1 >= readCount) throw std::runtime_error("suppressAlignmentCandidates: a candidate names a read that has no meta data.");
+        return suppressPair(metaData.begin(readId0), metaData.begin(readId0) + (metaData.toc[readId0 + 1] - metaData.toc[readId0]),
+            metaData.begin(readId1), metaData.begin(readId1) + (metaData.toc[readId1 + 1] - metaData.toc[readId1]), delta);
     };
 
     std::ofstream csv("SuppressedAlignmentCandidates.csv");                                 // :1187-1188

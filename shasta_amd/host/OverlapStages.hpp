@@ -111,6 +111,10 @@ uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignment
 // with `read=` numbers closer than delta.  Data/ReadNames, Data/ReadMetaData in; Data/AlignmentCandidates rewritten;
 // SuppressedAlignmentCandidates.csv and the reference's three console lines.  Returns the number dropped.
 uint64_t suppressAlignmentCandidates(const std::string& dataDirectory, uint64_t delta, size_t threadCount);
+// ... and on arrays in memory: metaDataToc[readCount + 1] offsets into metaData (the layout of Data/ReadMetaData); the candidates
+// that stay are moved to the front, their number is returned.
+uint64_t suppressAlignmentCandidatesInMemory(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount,
+    shasta_oriented_read_pair* candidates, uint64_t candidateCount, uint64_t delta);
 
 void computeAlignmentTable(uint64_t readCount, const AlignmentDataVector& alignmentData,
     const std::string& dataDirectory, size_t largeDataPageSize = 4096);

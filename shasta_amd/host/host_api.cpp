@@ -98,6 +98,16 @@ int shasta_mi355x_host_suppress_alignment_candidates(const char* dataDirectory, 
     HOST_END
 }
 
+// The same decision on arrays in memory: the candidates that stay move to the front, *kept = their number.
+int shasta_mi355x_host_suppress_candidates_in_memory(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount,
+    shasta_oriented_read_pair* candidates, uint64_t candidateCount, uint64_t delta, uint64_t* kept)
+{
+    HOST_BEGIN
+    if(!metaDataToc || !metaData || (!candidates && candidateCount) || !kept) throw std::runtime_error("suppress_candidates_in_memory: null argument");
+    *kept = suppressAlignmentCandidatesInMemory(metaDataToc, metaData, readCount, candidates, candidateCount, delta);
+    HOST_END
+}
+
 // Assembler::flagPalindromicReads, src/AssemblerAlign.cpp:652-698.  alignment (optional): for tests, the method-0
 // self-alignment of one read is available through shasta_mi355x_host_self_alignment_method0.
 int shasta_mi355x_host_flag_palindromic_reads(const char* dataDirectory, uint32_t maxSkip, uint32_t maxDrift, uint32_t maxMarkerFrequency,

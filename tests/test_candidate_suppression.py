@@ -88,6 +88,12 @@ def test_suppression_equals_reference(ref_lib, tmp_path, monkeypatch, delta):
     assert np.array_equal(stored.view("<u4").reshape(-1, 3)[:, 0], r0[kept].astype(np.uint32))
     assert np.array_equal(stored.view("<u4").reshape(-1, 3)[:, 1], r1[kept].astype(np.uint32))
     assert np.array_equal(stored[:, 8], same[kept].astype(np.uint8))
+    # The same decision on arrays in memory (what bench.py's configs[3] / [4] steps run between the seams).
+    meta = [h[1].encode() for h in headers]
+    meta_toc = np.concatenate([[0], np.cumsum([len(m) for m in meta])]).astype(np.uint64)
+    in_memory = shasta.suppress_candidates_in_memory(candidates, (meta_toc, np.frombuffer(b"".join(meta) + b" ", dtype=np.uint8)), delta, hostLibrary=HOST_SO)
+    assert np.array_equal(in_memory["readId0"], r0[kept].astype(np.uint32)) and np.array_equal(in_memory["readId1"], r1[kept].astype(np.uint32))
+    assert np.array_equal(in_memory["isSameStrand"], same[kept].astype(np.uint8))
     # The side file, src/AssemblerAlign.cpp:1187-1203: one row per suppressed candidate, names and meta data verbatim.
     rows = open(tmp_path / "SuppressedAlignmentCandidates.csv").read().splitlines()
     assert rows[0] == "ReadId0,ReadId1,SameStrand,Name0,Name1,MetaData0,MetaData1" and len(rows) == 1 + int(expected.sum())
