@@ -58,8 +58,28 @@ HBM_NATURED = ("hashWindowsKernel", "radix sort", "bucket", "readStatistics", "p
 # The two read-set shapes of the bench (both at marker level, 45x coverage): BASELINE configs[2] -- mean 1 500 markers (~20 kb) per read --
 # and the shape of configs[4]'s conf/Nanopore-UL-May2022.conf -- minReadLength 50 000 bases: no read below 3 750 markers, mean 7 500
 # (~100 kb), a tail beyond 30 000.
-WORKLOAD_SHAPES = {"configs2": dict(mean_markers=1500.0, sigma=0.5, min_markers=790), "ul": dict(mean_markers=7500.0, sigma=0.5, min_markers=3750)}
+# (round 6) ... and the shape of configs[3]'s conf/Nanopore-May2022.conf -- minReadLength 10 000 bases: no read below 750 markers, mean 1 875
+# (~25 kb).  Both human configurations set Kmers.k = 14: their reads are generated over a k = 14 marker alphabet (about 609 000 run-length
+# 14-mers closed under reverse complement: 4 x 3^13 run-length 14-mers at markerDensity 0.1 are 638 000 -- sixty times fewer random
+# marker matches per pair of reads than the 7 900 marker k-mers of k = 10), and their steps run Assembler::suppressAlignmentCandidates
+# (Align.sameChannelReadAlignment.suppressDeltaThreshold = 30) between the two stages as srcMain/main.cpp:697-702 does.
+WORKLOAD_SHAPES = {"configs2": dict(mean_markers=1500.0, sigma=0.5, min_markers=790), "ul": dict(mean_markers=7500.0, sigma=0.5, min_markers=3750),
+                   "may2022": dict(mean_markers=1875.0, sigma=0.5, min_markers=750)}
+WORKLOAD_K = {"configs2": 10, "ul": 14, "may2022": 14}
+WORKLOAD_SUPPRESS_DELTA = {"configs2": 0, "ul": 30, "may2022": 30}
 WORKLOAD_SHAPE = ["configs2"]          # (set by main() from --workload)
+_ALPHABET = {}
+
+
+def workload_alphabet():
+    """None (synthetic.marker_reads' default: every marker k-mer of k = 10) or the sampled k = 14 alphabet."""
+    k = WORKLOAD_K[WORKLOAD_SHAPE[0]]
+    if k == 10:
+        return None
+    if k not in _ALPHABET:
+        from shasta_amd import synthetic
+        _ALPHABET[k] = synthetic.sampled_marker_alphabet(k, count=320000)
+    return _ALPHABET[k]
 
 
 def make_workload(n_reads, seed, shards=0):
@@ -71,7 +91,7 @@ def make_workload(n_reads, seed, shards=0):
     genome_markers = max(20000, int(round(n_reads * shape["mean_markers"] / 45.0)))
     if shards >= 1:
         parts = [synthetic.marker_reads(n_reads // shards, genome_markers,
-                                        keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, shard=r, shard_count=shards, **shape)
+                                        keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, shard=r, shard_count=shards, alphabet=workload_alphabet(), **shape)
                  for r in range(shards)]
         sizes = np.concatenate([np.diff(t.astype(np.int64)) for t, _ in parts])
         toc = np.zeros(len(sizes) + 1, dtype=np.uint64)
@@ -84,11 +104,35 @@ def make_workload(n_reads, seed, shards=0):
         files = [os.path.join(cache, "workload_%s_%d_%d_%s.npy" % (WORKLOAD_SHAPE[0], n_reads, seed, x)) for x in ("toc", "kmer")]
         if all(os.path.exists(f) for f in files):
             return np.load(files[0]), np.load(files[1])
-    toc, kmer = synthetic.marker_reads(n_reads, genome_markers, keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, **shape)
+    toc, kmer = synthetic.marker_reads(n_reads, genome_markers, keep_probability=0.8, spurious_probability=0.25, k=10, seed=seed, alphabet=workload_alphabet(), **shape)
     if cache:
         os.makedirs(cache, exist_ok=True)
         np.save(files[0], toc); np.save(files[1], kmer)
     return toc, kmer
+
+
+def make_meta_data(n_reads, candidates, seed=4321, share=0.001):
+    """ONT-style read meta data (`runid= sampleid= read= ch= start_time=`, the keys Assembler::suppressAlignment reads,
+    src/AssemblerAlign.cpp:1078-1162) for the synthetic reads, in the layout of Data/ReadMetaData (toc uint64[R + 1], bytes): every read
+    its own channel-and-number, except that the second read of about one candidate in a thousand comes from the channel of the first
+    with the next read number -- the two strands of one molecule through one pore, what the suppression step is there to drop."""
+    rng = np.random.default_rng(seed)
+    channel = rng.integers(1, 2049, size=n_reads)
+    number = rng.integers(0, 200000, size=n_reads) * 100          # (far apart: only the pairs made below are within delta)
+    if len(candidates):
+        pick = rng.choice(len(candidates), size=max(1, int(len(candidates) * share)), replace=False)
+        taken = np.zeros(n_reads, dtype=bool)
+        for i in np.sort(pick):
+            r0, r1 = int(candidates["readId0"][i]), int(candidates["readId1"][i])
+            if taken[r0] or taken[r1]:
+                continue
+            taken[r0] = taken[r1] = True
+            channel[r1] = channel[r0]
+            number[r1] = number[r0] + 1
+    rows = [("runid=0f3c9a sampleid=s1 read=%d ch=%d start_time=2022-05-01T00:00:00Z" % (number[r], channel[r])).encode() for r in range(n_reads)]
+    toc = np.zeros(n_reads + 1, dtype=np.uint64)
+    toc[1:] = np.cumsum([len(x) for x in rows])
+    return toc, np.frombuffer(b"".join(rows) + b" ", dtype=np.uint8)
 
 
 def lowhash_params():
@@ -96,7 +140,7 @@ def lowhash_params():
     # m=4, f=0.01, 10 iterations, minBucketSize/maxBucketSize/minFrequency 5/30/5.
     if WORKLOAD_SHAPE[0] == "ul":          # conf/Nanopore-UL-May2022.conf: MinHash 10/50/5
         return abi.default_lowhash0_params(minBucketSize=10, maxBucketSize=50, minFrequency=5)
-    return abi.default_lowhash0_params(minBucketSize=5, maxBucketSize=30, minFrequency=5)
+    return abi.default_lowhash0_params(minBucketSize=5, maxBucketSize=30, minFrequency=5)       # (conf/Nanopore-May2022.conf: the same 5/30/5)
 
 
 def align3_options():
@@ -108,7 +152,7 @@ def align3_options():
 
 def align_options():
     from shasta_amd import abi
-    if WORKLOAD_SHAPE[0] == "ul":          # conf/Nanopore-UL-May2022.conf, [Align]: maxSkip / maxDrift / maxTrim 100, minAlignedMarkerCount 10, minAlignedFraction 0.1
+    if WORKLOAD_SHAPE[0] in ("ul", "may2022"):          # conf/Nanopore-May2022.conf and -UL-, [Align]: maxSkip / maxDrift / maxTrim 100, minAlignedMarkerCount 10, minAlignedFraction 0.1
         return abi.default_align4_options(maxSkip=100, maxDrift=100, maxTrim=100, minAlignedMarkerCount=10, minAlignedFraction=0.1)
     return abi.default_align4_options()
 
@@ -118,10 +162,11 @@ def candidate_paths(table, steps, candidates):
     its class's tables is counted again in the class it climbs to -- and what the banded DP's tasks ended in)."""
     per = {}
     for name, r in table.items():
-        if name.startswith("align4CellsChunkKernel") or name.startswith("align4CellsKernel"):
+        if name.startswith("align4CellsChunkKernel") or name.startswith("align4CellsKernel") or name.startswith("align4CellsLongKernel"):
             per[name] = r["work"] / steps
     out = {"cells_kernel_candidates_per_step": per,
-           "share_in_the_LDS_chunk_kernels": (sum(v for k, v in per.items() if k.startswith("align4CellsChunkKernel")) / candidates) if candidates else None,
+           "share_in_the_LDS_chunk_kernels": (sum(v for k, v in per.items() if k.startswith("align4CellsChunkKernel") or k.startswith("align4CellsLongKernel")) / candidates) if candidates else None,
+           "share_in_the_windowed_LDS_kernel": (sum(v for k, v in per.items() if k.startswith("align4CellsLongKernel")) / candidates) if candidates else None,
            "share_in_the_HBM_scratch_kernel": (sum(v for k, v in per.items() if k.startswith("align4CellsKernel")) / candidates) if candidates else None}
     return out
 
@@ -176,7 +221,7 @@ def available_memory_gib():
     return 1 << 20
 
 
-def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, census_size=0, all_rows=None):
+def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, census_size=0, all_rows=None, suppress=None):
     """The reference CPU path on the SAME read set, on this host's cores, outside the timed region; its outputs
     are compared with the device's (parity at the benchmark's own size).  LowHash0 runs in full; the aligner
     on every (candidates / sample_size)-th candidate (the whole list would take minutes)."""
@@ -203,10 +248,19 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
         lh = lib.lowhash0(toc, data7, None, p)
         t_lh = time.time() - t0
     cand = lh.candidates
+    t_suppress = 0.0
+    if suppress is not None:
+        # Assembler::suppressAlignmentCandidates between the stages (srcMain/main.cpp:697-702): the host layer's own function either side
+        # (string meta data, one serial pass: shasta_amd/host/CandidateSuppression.cpp, checked against the reference's parser in tests/).
+        t0 = time.time()
+        cand = suppress(cand)
+        t_suppress = time.time() - t0
     # Assembler::computeSortedMarkers (src/AssemblerAlign.cpp:236-239): once, for all oriented reads, before the alignment threads
     # start -- timed on its own; the per-candidate loop below reads it (method 4; method 3 does not use sorted markers).
     t_sorted = lib.compute_sorted_markers(toc, data7, threads=cores) if (kind == "reference" and align_method == 4) else 0.0
-    parity["lowhash0_candidates"] = len(cand)
+    parity["lowhash0_candidates"] = len(lh.candidates)
+    if suppress is not None:
+        parity["candidates_after_suppression"] = len(cand)
     parity["lowhash0_equal"] = bool(np.array_equal(lh.candidate_tuples(), gpu_lowhash.candidate_tuples())
                                     and np.array_equal(lh.statistics, gpu_lowhash.statistics)
                                     and np.array_equal(lh.high_frequency, gpu_lowhash.high_frequency)
@@ -256,7 +310,7 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
         parity["dp_tie_sensitive"] = census.tie_census(lib, toc, data7, sub, o, align_method=align_method, threads=min(cores, 16))
         parity["dp_tie_sensitive"]["seconds"] = time.time() - t0
     pairs = len(cand)
-    total = t_lh + t_sorted + pairs * per_pair + t_table
+    total = t_lh + t_suppress + t_sorted + pairs * per_pair + t_table
     return {
         "value": pairs / total if total > 0 else 0.0,
         "unit": "candidate read-pairs aligned/s",
@@ -273,6 +327,7 @@ def cpu_baseline(ctx, toc, kmer, p, o, align_method, gpu_lowhash, sample_size, c
                       (len(toc) - 1) // 2, int(toc[-1]), t_lh, cores, host_cores, pairs, align_method, stride, len(sample), per_pair * 1e3, cores),
         "sample_short": "%d reads, LowHash0 in full, aligner on every %d-th candidate (%d) x rate" % ((len(toc) - 1) // 2, stride, len(sample)),
         "lowhash0_seconds": t_lh,
+        "suppress_seconds": t_suppress,
         "sorted_markers_seconds": t_sorted,            # Assembler::computeSortedMarkers, all reads, `threads` threads
         "align_seconds_per_pair": per_pair,
         "alignment_table_seconds": t_table,            # Assembler::computeAlignmentTable on all stored alignments (serial, as in the reference)
@@ -430,9 +485,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default 100000; 20000 with --workload ul)")
     ap.add_argument("--workload", choices=sorted(WORKLOAD_SHAPES), default="configs2",
-                    help="configs2 = BASELINE configs[2] (the headline); ul = the read shape and parameters of configs[4]'s conf/Nanopore-UL-May2022.conf on one GPU")
+                    help="configs2 = BASELINE configs[2] (the headline); may2022 / ul = the read shape, k = 14 marker alphabet and parameters of configs[3]'s "
+                         "conf/Nanopore-May2022.conf / configs[4]'s conf/Nanopore-UL-May2022.conf on one GPU, suppressAlignmentCandidates between the stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--baseline-sample", type=int, default=60000, help="candidates the reference aligner runs on (0 = all of them: a minute or two)")
+    ap.add_argument("--baseline-sample", type=int, default=250000, help="candidates the reference aligner runs on: one in eight at 100 k reads (0 = all of them: a minute or two)")
     ap.add_argument("--tie-census", type=int, default=20000,
                     help="candidates (a subset of the baseline sample) the checker re-aligns under the 11 other DP tie policies; 0 = no census")
     ap.add_argument("--group", action="store_true",
@@ -538,17 +594,33 @@ def main():
         upload_seconds = time.perf_counter() - t0
 
         table_seconds = [0.0]
+        suppress_seconds = [0.0]
+        suppressed = [0]
+        suppress = None
+        if WORKLOAD_SUPPRESS_DELTA[args.workload] and not args.lowhash_only:
+            # Assembler::suppressAlignmentCandidates between the two stages (srcMain/main.cpp:697-702), on meta data made once, outside the
+            # timed region, from the candidates of an untimed LowHash0 call.
+            import shasta_amd.assembler as host_layer
+            meta_data = make_meta_data(args.reads, ctx.lowhash0(p).candidates)
+            host_so = os.environ.get("SHASTA_BENCH_HOST_LIBRARY")           # (the emulated twin, for the dry run)
+            suppress = lambda c: host_layer.suppress_candidates_in_memory(c, meta_data, WORKLOAD_SUPPRESS_DELTA[args.workload], hostLibrary=host_so)
 
         def step():
             lh = ctx.lowhash0(p)
             if args.lowhash_only:
                 return lh, None, len(lh.candidates)
-            al = align(lh.candidates)
+            candidates = lh.candidates
+            if suppress is not None:
+                t = time.perf_counter()
+                candidates = suppress(candidates)
+                suppress_seconds[0] += time.perf_counter() - t
+                suppressed[0] = len(lh.candidates) - len(candidates)
+            al = align(candidates)
             # The last step of Assembler::computeAlignments (src/AssemblerAlign.cpp:296): the alignment table of what was stored.
             t = time.perf_counter()
             al.table = ctx.alignment_table(copy=False)
             table_seconds[0] += time.perf_counter() - t
-            return lh, al, len(lh.candidates)
+            return lh, al, len(candidates)
     else:
         # ONE job over all GPUs (weak scaling: `reads` reads per GPU of one read set at the same
         # coverage).  Every rank generates its own read range, the dense kmer ids are all-gathered
@@ -560,7 +632,7 @@ def main():
         shape = WORKLOAD_SHAPES[WORKLOAD_SHAPE[0]]
         genome_markers = max(20000, int(round(world * args.reads * shape["mean_markers"] / 45.0)))
         toc_s, kmer_s = synthetic.marker_reads(args.reads, genome_markers, keep_probability=0.8, spurious_probability=0.25, k=10, seed=12345,
-                                               shard=rank, shard_count=world, **shape)
+                                               shard=rank, shard_count=world, alphabet=workload_alphabet(), **shape)
         sizes = [None] * world
         dist.all_gather_object(sizes, np.diff(toc_s.astype(np.int64)).astype(np.uint32).tobytes())
         per_shard = [np.frombuffer(b, dtype=np.uint32).astype(np.uint64) for b in sizes]
@@ -628,6 +700,7 @@ def main():
     ctx.kernel_table_reset()
     if not sharded:
         table_seconds[0] = 0.0
+        suppress_seconds[0] = 0.0
     t0 = time.perf_counter()
     cpu0 = _process_cpu_seconds()
     throttled0 = _cgroup_throttled_usec()
@@ -772,9 +845,13 @@ def main():
                                                            if args.align_method == 4 else
                                                            "align method 3: downsamplingFactor 0.05, bandExtend 10, maxBand 1000, 6/-1/-1"))
                             if args.workload == "configs2" else
-                            ("the read shape and parameters of BASELINE configs[4] (conf/Nanopore-UL-May2022.conf) on one GPU: synthetic reads, marker level, "
+                            ("the read shape and parameters of BASELINE configs[4] (conf/Nanopore-UL-May2022.conf) on one GPU: synthetic reads, marker level, k = 14 marker alphabet (609 k ids), "
                              "%d reads/GPU, none below 3750 markers (50 kb), mean 7500 (~100 kb), 45x coverage; LowHash0 m=4 f=0.01 10 iterations 10/50/5; "
-                             "Align4 100/100/100, minAlignedMarkerCount 10, minAlignedFraction 0.1, maxBand 1000" % args.reads),
+                             "suppressAlignmentCandidates (delta 30) between the stages; Align4 100/100/100, minAlignedMarkerCount 10, minAlignedFraction 0.1, maxBand 1000" % args.reads)
+                            if args.workload == "ul" else
+                            ("the read shape and parameters of BASELINE configs[3] (conf/Nanopore-May2022.conf) on one GPU: synthetic reads, marker level, k = 14 marker alphabet (609 k ids), "
+                             "%d reads/GPU, none below 750 markers (10 kb), mean 1875 (~25 kb), 45x coverage; LowHash0 m=4 f=0.01 10 iterations 5/30/5; "
+                             "suppressAlignmentCandidates (delta 30) between the stages; Align4 100/100/100, minAlignedMarkerCount 10, minAlignedFraction 0.1, maxBand 1000" % args.reads),
                 "step": ("findAlignmentCandidatesLowHash0 (src/AssemblerLowHash.cpp:10-55) + computeAlignments (src/AssemblerAlign.cpp:208-304) end to end: "
                          "candidates -> AlignmentData + CompressedAlignments on the host%s"
                          % (" + the alignment table (computeAlignmentTable, :296)" if not sharded else
@@ -782,6 +859,7 @@ def main():
                         if not args.lowhash_only else "findAlignmentCandidatesLowHash0 only",
                 "reads_per_gpu": args.reads, "markers_total": marker_count,
                 "candidates": pairs_total, "alignments_stored": stored_total,
+                "candidates_suppressed_between_the_stages": (suppressed[0] if (not sharded and suppress is not None) else None),
                 "parallelism": "1 GPU" if not sharded else
                                "%d GPU%s, one job: reads sharded by id range, RCCL all-to-all of the low-hash records and of the pair "
                                "keys of all MinHash iterations (two exchanges per job), candidates re-split by sum(nx+ny) for Align4"
@@ -791,7 +869,8 @@ def main():
             "host_load_in_the_timed_region": host_load,
             "stage_seconds_per_step": {"lowhash0_device": lh_dev / steps, "align4_device": al_dev / steps,
                                        "lowhash0_call": lh_wall / steps, "align4_call": al_wall / steps,
-                                       "alignment_table_call": (table_seconds[0] / steps) if not sharded else None},
+                                       "alignment_table_call": (table_seconds[0] / steps) if not sharded else None,
+                                       "suppress_candidates_call": (suppress_seconds[0] / steps) if (not sharded and suppress is not None) else None},
             "kernel_seconds_per_step": kernel_seconds,
             "kernels": kernels,
             "roofline": roofline,
@@ -845,7 +924,7 @@ def main():
             all_rows = np.array(al.alignment_data, copy=True) if al is not None else None      # (the last step's, before the context's arrays are reused)
             out["cpu_baseline"], out["parity_at_bench_size"] = cpu_baseline(
                 ctx, toc, kmer, p, o, args.align_method, lh_check, args.baseline_sample if not DRY_RUN_LIBRARY else 200,
-                census_size=args.tie_census if not DRY_RUN_LIBRARY else 60, all_rows=all_rows)
+                census_size=args.tie_census if not DRY_RUN_LIBRARY else 60, all_rows=all_rows, suppress=suppress)
             out["dp_tie_sensitive"] = out["parity_at_bench_size"].pop("dp_tie_sensitive", None)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         # The safety net (one process, one GPU, the full line with its parity check): see _fallback_environment.
@@ -933,7 +1012,8 @@ def headline(out, details_path):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data") if k in out}
     c = out.get("config", {})
-    line["config"] = {k: c[k] for k in ("workload", "step", "reads_per_gpu", "markers_total", "candidates", "alignments_stored", "parallelism") if k in c}
+    line["config"] = {k: c[k] for k in ("workload", "step", "reads_per_gpu", "markers_total", "candidates", "alignments_stored", "candidates_suppressed_between_the_stages", "parallelism")
+                      if k in c and c[k] is not None}
     r = out.get("roofline")
     if r:
         short = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "counters_from")}
@@ -951,8 +1031,12 @@ def headline(out, details_path):
         line["cpu_baseline"]["kind"] = str(b.get("kind", "")).split(" ")[0]
         line["cpu_baseline"]["sample"] = str(b.get("sample_short") or b.get("sample", ""))[:160]
     p = out.get("candidate_paths")
-    if p and "BASELINE configs[4]" in str(c.get("workload", "")):
-        line["candidate_paths"] = {k: p.get(k) for k in ("share_in_the_LDS_chunk_kernels", "share_in_the_HBM_scratch_kernel")}
+    if p and "BASELINE configs[2]" not in str(c.get("workload", "")):
+        line["candidate_paths"] = {k: p.get(k) for k in ("share_in_the_LDS_chunk_kernels", "share_in_the_windowed_LDS_kernel", "share_in_the_HBM_scratch_kernel")}
+    u = out.get("pcie_inclusive")
+    if u:
+        # What a one-shot call of the seams pays in addition (the markers cross PCIe on every call): never `value`.
+        line["pcie_inclusive"] = {k: u.get(k) for k in ("value_with_upload_every_step", "upload_seconds")}
     for k in ("parity_at_bench_size", "speedup_vs_cpu_baseline", "stage_seconds_per_step", "aligner_status", "path", "default_path_parity_failed"):
         if out.get(k) is not None:
             line[k] = out[k]
@@ -975,11 +1059,28 @@ def headline(out, details_path):
     line["details"] = details_path
     line = _rounded(line)
     # Whatever a future key adds, the line stays short: optional parts go first, the contract keys never.
-    for optional in ("dp_tie_sensitive", "banded_dp", "hbm_natured_kernel", "aligner_status", "stage_seconds_per_step", "earlier_attempts", "in_process_group"):
+    for optional in ("dp_tie_sensitive", "banded_dp", "hbm_natured_kernel", "aligner_status", "stage_seconds_per_step", "earlier_attempts", "in_process_group",
+                     "candidate_paths", "pcie_inclusive"):
         if len(json.dumps(line, allow_nan=False)) < FINAL_LINE_LIMIT:
             break
         line.pop(optional, None)
-    assert len(json.dumps(line, allow_nan=False)) < FINAL_LINE_LIMIT, "final line too long"
+    if len(json.dumps(line, allow_nan=False)) >= FINAL_LINE_LIMIT:
+        # The last resort (a long string in a key that is not optional): the contract keys and the details file, long strings cut -- a
+        # line is ALWAYS printed.
+        def cut(x):
+            if isinstance(x, str):
+                return x[:200]
+            if isinstance(x, dict):
+                return {k: cut(v) for k, v in x.items()}
+            if isinstance(x, list):
+                return [cut(v) for v in x[:8]]
+            return x
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "parity_at_bench_size", "details")
+        line = cut({k: line[k] for k in keep if k in line})
+        line["line_shortened"] = True
+        if len(json.dumps(line, allow_nan=False)) >= FINAL_LINE_LIMIT:
+            line = {k: line[k] for k in keep[:12] + ("details", "line_shortened") if k in line}
     return line
 
 

@@ -1666,7 +1666,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     HIP_CHECK(hipMemcpyAsync(b.bigLog2.data(), bigLog2.data() + begin, count, hipMemcpyHostToDevice, stream));
                     // (a candidate that climbed here from a chunk kernel keeps no match list: what the attempt that overflowed wrote is not
                     // the sparse path's to read -- its header says 0xffffffff for "cells computed by the HBM kernel")
-                    if(listHits) hipLaunchKernelGGL(hitListNoneKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, (const uint32_t*)b.pairList.data(), count, b.hitMeta.data());
+                    if(listHits) { hipLaunchKernelGGL(hitListNoneKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, (const uint32_t*)b.pairList.data(), count, b.hitMeta.data()); HIP_CHECK(hipGetLastError()); }
                     uint64_t bigBytes = 0;
                     for(size_t q = begin; q < end; q++) bigBytes += 4ULL * (uint64_t(hostPairs[bigList[q]].nx) + hostPairs[bigList[q]].ny);
                     SHASTA_TIMED(ctx, "align4CellsKernel<true, false>", stream, bigBytes, count,
@@ -1820,7 +1820,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         for(uint32_t k = 0; k < storedCount; k++) out.tocEnds[k] = (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal);
         for(uint32_t k = 0; k < storedCount; k++) out.alignedBytes += 8ULL * out.rows[k].info.markerCount;
         // Both compress kernels read the 8-byte ordinal pairs of the stored alignments; the second writes the blobs and the 64-byte rows.
-        ctx.timers.amend(writeHandle, out.alignedBytes + byteTotal + 64ULL * storedCount, storedCount);
+        // (round 5: the wave kernel leaves its alignments in shasta::compress form, which this kernel copies -- the bytes are read and written,
+        // the rows read and written; only the other tasks' alignments, a tenth, are still made from their aligned pairs: booked as copies all)
+        ctx.timers.amend(writeHandle, (b.streamsInLists ? byteTotal : out.alignedBytes) + byteTotal + 128ULL * storedCount, storedCount);
         if(debugPhases) {
             phaseFinish = phaseMs(phaseStart) - phaseCells - phaseDp;
             std::fprintf(stderr, "batch %llu (%u candidates, %u tasks): candidates -> DP tasks %.1f ms, DP %.1f ms, filters + compression + copies %.1f ms\n",

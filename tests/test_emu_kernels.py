@@ -337,3 +337,12 @@ def test_read_statistics_over_several_partitions_and_spans(emu_lib, oracle_lib):
     # readStatisticsKernel (lowhash0.hip): 4 200 table entries = 3 partitions, > 65 536 records = several spans; and the atomics form.
     from tests import statistics_checks
     assert statistics_checks.several_partitions_and_spans(emu_lib, oracle_lib, cases=((0.05, 6),)) >= 1400
+
+
+def test_pairs_of_two_long_reads(emu_lib, oracle_lib, monkeypatch):
+    """The windowed class of the cells stage (align4CellsLongKernel) and the sort kernel's classes for reads beyond 8 192 markers."""
+    from tests import long_read_checks
+    monkeypatch.setenv("SHASTA_MI355X_MATCH_SHIFT", "20")
+    monkeypatch.setenv("SHASTA_MI355X_ALIGN_WORKERS", "1")
+    r = long_read_checks.both_long(emu_lib, oracle_lib, lengths=(9000, 12500, 9500, 8300, 4000), genome_markers=16000)
+    assert r["both_long"] == 12 and r["in_the_windowed_class"] == 12 and r["in_the_hbm_scratch_kernel"] == 0 and not r["dense_because"]

@@ -1,0 +1,36 @@
+"""-m gpu: pairs of two reads beyond 8 192 markers (the ordinary pair of conf/Nanopore-UL-May2022.conf) through the windowed class
+of the cells stage and the sparse path's classes for long reads -- parity with the oracle and with the reference's own Align4, and
+the kernel table's word on which kernels the candidates took (tests/long_read_checks.py)."""
+import pytest
+
+from tests import long_read_checks
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pairs_of_two_long_reads_take_the_windowed_class(gpu_lib, oracle_lib, monkeypatch):
+    # (the read set is a handful of reads over one small genome: every second pair of markers of the sample is a true match, and the
+    # library's estimate of the random background -- right for a real read set -- would send the pairs to the HBM-scratch kernel)
+    monkeypatch.setenv("SHASTA_MI355X_MATCH_SHIFT", "20")
+    r = long_read_checks.both_long(gpu_lib, oracle_lib)
+    assert r["both_long"] >= 60 and r["stored"] >= 15
+    assert r["in_the_windowed_class"] == r["both_long"]                    # every such pair starts there
+    assert r["in_the_hbm_scratch_kernel"] <= r["both_long"] // 8          # (overlaps of 24 000 markers and more keep more cells than the class's graph holds)
+
+
+def test_long_reads_against_the_reference(gpu_lib, oracle_lib, ref_lib, monkeypatch):
+    monkeypatch.setenv("SHASTA_MI355X_MATCH_SHIFT", "20")
+    r = long_read_checks.both_long(gpu_lib, oracle_lib, ref_lib, seed=67)
+    assert r["in_the_windowed_class"] == r["both_long"] and r["stored"] >= 15
+
+
+def test_long_reads_over_a_small_alphabet(gpu_lib, oracle_lib):
+    """8 000 distinct ids (the random background of k = 10): the windowed class's cell table overflows or is not tried at all, the
+    HBM-scratch kernel and the dense DP answer -- the path of round 5, still equal to the oracle."""
+    r = long_read_checks.both_long(gpu_lib, oracle_lib, alphabet_size=8000, lengths=(9000, 12500, 9500, 8300, 4000, 17000), genome_markers=20000)
+    assert r["both_long"] >= 15 and r["in_the_hbm_scratch_kernel"] >= 10 and r["stored"] >= 10
+
+
+def test_long_reads_with_the_librarys_own_estimate(gpu_lib, oracle_lib):
+    r = long_read_checks.both_long(gpu_lib, oracle_lib, seed=68)
+    assert r["both_long"] >= 60 and r["stored"] >= 15
