@@ -603,7 +603,8 @@ def main():
             import shasta_amd.assembler as host_layer
             meta_data = make_meta_data(args.reads, ctx.lowhash0(p).candidates)
             host_so = os.environ.get("SHASTA_BENCH_HOST_LIBRARY")           # (the emulated twin, for the dry run)
-            suppress = lambda c: host_layer.suppress_candidates_in_memory(c, meta_data, WORKLOAD_SUPPRESS_DELTA[args.workload], hostLibrary=host_so)
+            # (the reads' meta data parsed once, as a caller that holds it for a whole run would: keys per read, then integer comparisons per candidate)
+            suppress = host_layer.CandidateSuppression(meta_data, WORKLOAD_SUPPRESS_DELTA[args.workload], hostLibrary=host_so).apply
 
         def step():
             lh = ctx.lowhash0(p)

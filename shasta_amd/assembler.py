@@ -165,3 +165,38 @@ def suppress_candidates_in_memory(candidates, meta_data, delta, hostLibrary=None
     if rc != 0:
         raise RuntimeError(lib.shasta_mi355x_host_last_error().decode())
     return out[:int(kept.value)]
+
+
+class CandidateSuppression:
+    """The same step with the reads' meta data parsed ONCE (a run's meta data does not change between calls): keys per read at
+    construction, then `apply(candidates)` -> the candidates that stay, per call a pass of integer comparisons on a few host threads."""
+
+    def __init__(self, meta_data, delta, hostLibrary=None, threads=8):
+        import numpy as np
+        self._lib = C.CDLL(hostLibrary or HOST_SO)
+        self._lib.shasta_mi355x_host_last_error.restype = C.c_char_p
+        toc, data = meta_data
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.read_count = len(toc) - 1
+        self.delta, self.threads = int(delta), int(threads)
+        self._keys = np.zeros(3 * max(1, self.read_count), dtype=np.uint64)          # 24 bytes per read
+        rc = self._lib.shasta_mi355x_host_suppression_keys(toc.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p),
+                                                            C.c_uint64(self.read_count), self._keys.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(self._lib.shasta_mi355x_host_last_error().decode())
+
+    def apply(self, candidates):
+        """-> the candidates that stay: a view of a buffer this object keeps (valid until its next call; no 30 MB of fresh pages per call)."""
+        import numpy as np
+        candidates = np.ascontiguousarray(candidates)
+        if getattr(self, "_out", None) is None or len(self._out) < len(candidates) or self._out.dtype != candidates.dtype:
+            self._out = np.empty(len(candidates) + len(candidates) // 8 + 1, dtype=candidates.dtype)
+        out = self._out[:len(candidates)]
+        kept = C.c_uint64()
+        rc = self._lib.shasta_mi355x_host_suppress_candidates_by_keys(
+            self._keys.ctypes.data_as(C.c_void_p), C.c_uint64(self.read_count), candidates.ctypes.data_as(C.c_void_p), C.c_uint64(len(candidates)),
+            out.ctypes.data_as(C.c_void_p), C.c_uint64(self.delta), C.c_uint64(self.threads), C.byref(kept))
+        if rc != 0:
+            raise RuntimeError(self._lib.shasta_mi355x_host_last_error().decode())
+        return out[:int(kept.value)]

@@ -10,7 +10,12 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <algorithm>
+#include <cstring>
 #include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace shasta_mi355x {
@@ -68,6 +73,80 @@ bool suppressPair(const char* m0, const char* e0, const char* m1, const char* e1
 }
 
 }  // namespace
+
+// The decision from keys made once per read: the values of ch / sampleid / runid as numbers (equal strings, equal numbers; 0: no value)
+// and the read number.  The reference parses the two reads' meta data anew for every candidate (string searches: 0.2 us a candidate,
+// half a second for the 2.4 million candidates of 100 000 reads); a read's meta data does not change between candidates.
+void suppressionKeys(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount, SuppressionKey* keys)
+{
+    std::unordered_map<std::string, uint32_t> ids[3];
+    const char* const names[3] = {"ch", "sampleid", "runid"};
+    for(uint64_t r = 0; r < readCount; r++) {
+        const char* const begin = metaData + metaDataToc[r];
+        const char* const end = metaData + metaDataToc[r + 1];
+        SuppressionKey& k = keys[r];
+        for(int f = 0; f < 3; f++) {
+            const Text v = metaDataValue(begin, end, names[f]);
+            k.field[f] = 0;
+            if(!v.empty()) k.field[f] = ids[f].emplace(std::string(v.begin, v.end), uint32_t(ids[f].size() + 1)).first->second;
+        }
+        const Text read = metaDataValue(begin, end, "read");
+        k.flags = 0; k.read = 0;
+        if(!read.empty()) {
+            k.flags = 1;
+            // (a value that is not a number makes the reference throw when a candidate gets as far as reading it, not before)
+            for(const char* p = read.begin; p != read.end; ++p) if(!std::isdigit(static_cast<unsigned char>(*p))) k.flags = 3;
+            if(k.flags == 1) k.read = decimal(read);
+        }
+    }
+}
+
+uint64_t suppressAlignmentCandidatesByKeys(const SuppressionKey* keys, uint64_t readCount, const shasta_oriented_read_pair* candidates, uint64_t candidateCount,
+    shasta_oriented_read_pair* out, uint64_t delta, size_t threadCount)
+{
+    auto drop = [&](const shasta_oriented_read_pair& c) {
+        if(c.readIds[0] >= readCount || c.readIds[1] >= readCount) throw std::runtime_error("suppressAlignmentCandidates: a candidate names a read that has no meta data.");
+        const SuppressionKey& a = keys[c.readIds[0]];
+        const SuppressionKey& b = keys[c.readIds[1]];
+        for(int f = 0; f < 3; f++) if(a.field[f] == 0 || b.field[f] == 0 || a.field[f] != b.field[f]) return false;      // :1089-1131
+        if(!(a.flags & 1)) return false;                                                                             // :1138-1146
+        if(a.flags & 2) throw std::runtime_error("Non-digit found in the read number of a read's meta data");
+        if(!(b.flags & 1)) return false;
+        if(b.flags & 2) throw std::runtime_error("Non-digit found in the read number of a read's meta data");
+        return std::llabs(int64_t(a.read) - int64_t(b.read)) < int64_t(delta);                                       // :1152-1160
+    };
+    // Slices on as many threads: each lists the candidates it drops (few), the slices' places in the output follow from the counts, and
+    // each then copies the runs between its dropped candidates to its place -- `out` may be `candidates` itself (one thread then: the
+    // runs move down in order) or another array (the copy a caller needs anyway, done here once and in parallel).
+    const bool inPlace = out == candidates;
+    const size_t threads = inPlace ? 1 : std::max<size_t>(1, std::min<size_t>(threadCount ? threadCount : 8, candidateCount / 65536 + 1));
+    std::vector<uint64_t> begin(threads + 1), base(threads + 1, 0);
+    for(size_t t = 0; t <= threads; t++) begin[t] = candidateCount * t / threads;
+    std::vector<std::vector<uint64_t>> dropped(threads);
+    std::vector<std::string> errors(threads);
+    auto onThreads = [&](auto&& f) {
+        std::vector<std::thread> others;
+        for(size_t t = 1; t < threads; t++) others.emplace_back(f, t);
+        f(0);
+        for(std::thread& t : others) t.join();
+        for(const std::string& e : errors) if(!e.empty()) throw std::runtime_error(e);
+    };
+    onThreads([&](size_t t) {
+        try { for(uint64_t i = begin[t]; i < begin[t + 1]; i++) if(drop(candidates[i])) dropped[t].push_back(i); }
+        catch(const std::exception& e) { errors[t] = e.what(); }
+    });
+    for(size_t t = 0; t < threads; t++) base[t + 1] = base[t] + (begin[t + 1] - begin[t]) - dropped[t].size();
+    onThreads([&](size_t t) {
+        uint64_t from = begin[t], to = base[t];
+        auto run = [&](uint64_t end) {
+            if(end > from && (!inPlace || to != from)) std::memmove(out + to, candidates + from, (end - from) * sizeof(shasta_oriented_read_pair));
+            to += end - from;
+        };
+        for(const uint64_t i : dropped[t]) { run(i); from = i + 1; }
+        run(begin[t + 1]);
+    });
+    return base[threads];
+}
 
 // The same step on arrays in memory (what a caller that holds the candidates of the first seam in memory runs before the second
 // -- bench.py's steps of the configs[3] / [4] workloads): candidates compacted in place, no side file, no console lines.

@@ -111,6 +111,13 @@ uint64_t createReadGraph(const std::string& dataDirectory, uint32_t maxAlignment
 // with `read=` numbers closer than delta.  Data/ReadNames, Data/ReadMetaData in; Data/AlignmentCandidates rewritten;
 // SuppressedAlignmentCandidates.csv and the reference's three console lines.  Returns the number dropped.
 uint64_t suppressAlignmentCandidates(const std::string& dataDirectory, uint64_t delta, size_t threadCount);
+// ... and from keys made once per read (the meta data of a run does not change: a caller of the step parses it once): the candidates that
+// stay move to the front, in order; their number is returned.  Same decisions as the string form (tests/test_candidate_suppression.py).
+struct SuppressionKey { uint32_t field[3]; uint32_t flags; uint64_t read; };       // ch, sampleid, runid as numbers (0: none); flags: 1 = has a read number, 2 = it is not a number
+void suppressionKeys(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount, SuppressionKey* keys);
+// (out: where the candidates that stay go, in order -- `candidates` itself, or an array of candidateCount entries that does not overlap it)
+uint64_t suppressAlignmentCandidatesByKeys(const SuppressionKey* keys, uint64_t readCount, const shasta_oriented_read_pair* candidates, uint64_t candidateCount,
+    shasta_oriented_read_pair* out, uint64_t delta, size_t threadCount);
 // ... and on arrays in memory: metaDataToc[readCount + 1] offsets into metaData (the layout of Data/ReadMetaData); the candidates
 // that stay are moved to the front, their number is returned.
 uint64_t suppressAlignmentCandidatesInMemory(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount,

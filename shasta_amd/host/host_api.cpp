@@ -108,6 +108,23 @@ int shasta_mi355x_host_suppress_candidates_in_memory(const uint64_t* metaDataToc
     HOST_END
 }
 
+// ... from keys made once per read: keys = 24 bytes per read (SuppressionKey), filled by the first call, read by the second.
+int shasta_mi355x_host_suppression_keys(const uint64_t* metaDataToc, const char* metaData, uint64_t readCount, void* keys)
+{
+    HOST_BEGIN
+    if(!metaDataToc || !metaData || !keys) throw std::runtime_error("suppression_keys: null argument");
+    suppressionKeys(metaDataToc, metaData, readCount, static_cast<SuppressionKey*>(keys));
+    HOST_END
+}
+int shasta_mi355x_host_suppress_candidates_by_keys(const void* keys, uint64_t readCount, const shasta_oriented_read_pair* candidates, uint64_t candidateCount,
+    shasta_oriented_read_pair* out, uint64_t delta, uint64_t threadCount, uint64_t* kept)
+{
+    HOST_BEGIN
+    if(!keys || ((!candidates || !out) && candidateCount) || !kept) throw std::runtime_error("suppress_candidates_by_keys: null argument");
+    *kept = suppressAlignmentCandidatesByKeys(static_cast<const SuppressionKey*>(keys), readCount, candidates, candidateCount, out, delta, size_t(threadCount));
+    HOST_END
+}
+
 // Assembler::flagPalindromicReads, src/AssemblerAlign.cpp:652-698.  alignment (optional): for tests, the method-0
 // self-alignment of one read is available through shasta_mi355x_host_self_alignment_method0.
 int shasta_mi355x_host_flag_palindromic_reads(const char* dataDirectory, uint32_t maxSkip, uint32_t maxDrift, uint32_t maxMarkerFrequency,

@@ -94,6 +94,11 @@ def test_suppression_equals_reference(ref_lib, tmp_path, monkeypatch, delta):
     in_memory = shasta.suppress_candidates_in_memory(candidates, (meta_toc, np.frombuffer(b"".join(meta) + b" ", dtype=np.uint8)), delta, hostLibrary=HOST_SO)
     assert np.array_equal(in_memory["readId0"], r0[kept].astype(np.uint32)) and np.array_equal(in_memory["readId1"], r1[kept].astype(np.uint32))
     assert np.array_equal(in_memory["isSameStrand"], same[kept].astype(np.uint8))
+    # ... and from keys made once per read, on one thread and on several (slices of a list this short are a few candidates each).
+    meta_data = (meta_toc, np.frombuffer(b"".join(meta) + b" ", dtype=np.uint8))
+    for threads in (1, 5):
+        by_keys = shasta.CandidateSuppression(meta_data, delta, hostLibrary=HOST_SO, threads=threads).apply(candidates)
+        assert np.array_equal(by_keys, in_memory)
     # The side file, src/AssemblerAlign.cpp:1187-1203: one row per suppressed candidate, names and meta data verbatim.
     rows = open(tmp_path / "SuppressedAlignmentCandidates.csv").read().splitlines()
     assert rows[0] == "ReadId0,ReadId1,SameStrand,Name0,Name1,MetaData0,MetaData1" and len(rows) == 1 + int(expected.sum())
