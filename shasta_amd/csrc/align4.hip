@@ -192,8 +192,9 @@ std::shared_ptr<BatchScratch> makeWorkerScratch(SharedCapacities& shared)
 // overlap the narrow classes instead of occupying the GPU alone.
 struct WorkStream { hipStream_t stream; RadixSortWorkspace* sortWs; hipStream_t wide; };
 
-constexpr int CELLS_CLASSES = 5;
+constexpr int CELLS_CLASSES = 6;
 constexpr int CELLS_LONG = 4;          // the windowed class (align4CellsLongKernel): its own kernel instance, chunks of any sixteen candidates
+constexpr int CELLS_LONG_BIG = 5;      // ... and its candidates that keep more cells than a wavefront's registers hold (align4CellsLongBigKernel): never a first choice, one candidate a chunk
 #ifndef SHASTA_CELLS_NA0
 #define SHASTA_CELLS_NA0 11
 #endif
@@ -205,7 +206,7 @@ constexpr int CELLS_LONG = 4;          // the windowed class (align4CellsLongKer
 // The fifth class (round 6, CELLS_LONG) tables the SHORTER read of a candidate in windows of 2^13 markers: pairs of two reads beyond
 // 8 192 markers (29 % of the candidates of the ultra-long shape, conf/Nanopore-UL-May2022.conf) and pairs whose cell indices do not
 // fit the packed word of the others (nx + ny beyond 40 960 at deltaY = 10).
-constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13, 13};
+constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13, 13, 13};
 // Timing experiments compile other geometries (make EXTRA=-DSHASTA_CELLS_SC0=9 ...): the LDS a workgroup takes
 // decides how many wavefronts a CU holds, and the cells kernels are bound by latency, not by instruction issue.
 #ifndef SHASTA_CELLS_SC0
@@ -220,7 +221,7 @@ constexpr int CELLS_NA_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_NA0, 12, 13, 13, 13};
 #ifndef SHASTA_CELLS_ESTIMATE_SHIFT
 #define SHASTA_CELLS_ESTIMATE_SHIFT 13
 #endif
-constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2, 14, 13};
+constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1, SHASTA_CELLS_SC2, 14, 13, 13};
 // Kept cells per candidate: 64 Q (more: the candidate climbs a class, finally to the HBM-scratch kernel).  Q = 2 everywhere:
 // the kernel then needs 115 vector registers (4 wavefronts per SIMD) instead of 224 (2).
 #ifndef SHASTA_CELLS_Q1
@@ -232,8 +233,8 @@ constexpr int CELLS_SC_LOG2[CELLS_CLASSES] = {SHASTA_CELLS_SC0, SHASTA_CELLS_SC1
 #ifndef SHASTA_CELLS_CHUNK_MAX
 #define SHASTA_CELLS_CHUNK_MAX 24
 #endif
-constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2, 4, 4};
-constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16, 8, uint32_t(CELLS_LONG_WAVES)};
+constexpr int CELLS_Q[CELLS_CLASSES] = {2, SHASTA_CELLS_Q1, SHASTA_CELLS_Q2, 4, 4, 4};
+constexpr uint32_t CELLS_CHUNK_MAX[CELLS_CLASSES] = {SHASTA_CELLS_CHUNK_MAX, SHASTA_CELLS_CHUNK_MAX, 16, 8, uint32_t(CELLS_LONG_WAVES), 1};
 constexpr int ALIGN_DEFAULT_WORKERS = 6;                       // host workers (streams) that pipeline the batches of one call
 #include "align4_prepare.hpp"    // the class of a candidate; a batch's first chunk lists made on the device
 
@@ -267,8 +268,22 @@ void launchCellsChunksQ(Context& ctx, const WorkStream& ws, BatchScratch& b, int
 // The windowed class: workgroups of sixteen wavefronts.  Algorithmic bytes as the other classes' (what the reference reads: 4 (nx + ny)
 // per candidate; the kernel itself reads the stream once per window of the tabled read).
 void launchCellsLong(Context& ctx, const WorkStream& ws, BatchScratch& b, const CellsChunk* chunks, uint32_t count,
-    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists)
+    const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists, bool big)
 {
+    if(big) {
+        // (the candidates with more kept cells than the class's graphs hold: one a workgroup, their kept cells behind the wavefronts' slots)
+        const size_t bytes = (cellsChunkLdsWords(CELLS_NA_LOG2[CELLS_LONG_BIG], CELLS_SC_LOG2[CELLS_LONG_BIG], CELLS_Q[CELLS_LONG_BIG], CELLS_LONG_WAVES) + size_t(CELLS_BIG_KEPT)) * sizeof(uint32_t);
+        std::call_once(ctx.cellsLdsAttribute[3], [] {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsLongBigKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        });
+        MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
+        SHASTA_TIMED(ctx, "align4CellsLongBigKernel", ws.stream, kmerIdBytes, candidateCount,
+            hipLaunchKernelGGL(align4CellsLongBigKernel, dim3(count), dim3(CELLS_LONG_THREADS), bytes, ws.stream,
+                (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
+                opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(), hitLists));
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[CELLS_LONG], CELLS_SC_LOG2[CELLS_LONG], CELLS_Q[CELLS_LONG], CELLS_LONG_WAVES) * sizeof(uint32_t);
     std::call_once(ctx.cellsLdsAttribute[2], [] {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsLongKernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
@@ -285,7 +300,7 @@ void launchCellsChunks(Context& ctx, const WorkStream& ws, BatchScratch& b, int 
     const DeviceOptions& opt, uint32_t magicX, uint32_t magicY, uint32_t taskCapacity, uint64_t kmerIdBytes, uint64_t candidateCount, const HitLists& hitLists)
 {
     if(count == 0) return;
-    if(cls == CELLS_LONG) { launchCellsLong(ctx, ws, b, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists); return; }
+    if(cls == CELLS_LONG || cls == CELLS_LONG_BIG) { launchCellsLong(ctx, ws, b, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists, cls == CELLS_LONG_BIG); return; }
     if(CELLS_Q[cls] == 2) launchCellsChunksQ<2>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists);
     else launchCellsChunksQ<4>(ctx, ws, b, cls, chunks, count, opt, magicX, magicY, taskCapacity, kmerIdBytes, candidateCount, hitLists);
 }
@@ -733,8 +748,8 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
     std::vector<uint32_t> chunkPair[CELLS_CLASSES];
     std::vector<uint32_t> big;                                               // tied candidates of the HBM-scratch kernel
     for(uint32_t k = 0; k < n; k++) {
-        if(tie[k] && pairClass[k] == CELLS_CLASSES && pairSlotsLog2[k] >= 10) big.push_back(k);
-        if(!tie[k] || pairClass[k] < 0 || pairClass[k] >= CELLS_CLASSES) continue;
+        if(tie[k] && (pairClass[k] == CELLS_CLASSES || pairClass[k] == CELLS_LONG_BIG) && pairSlotsLog2[k] >= 10) big.push_back(k);      // (the large graph has no dump form: the HBM-scratch kernel's)
+        if(!tie[k] || pairClass[k] < 0 || pairClass[k] >= CELLS_LONG_BIG) continue;
         const int c = pairClass[k];
         const uint64_t capacity = 1ULL << CELLS_NA_LOG2[c];
         CellsChunk ch; ch.firstMember = uint32_t(members.size()); ch.count = 1;
@@ -752,7 +767,7 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
         const uint32_t total = uint32_t(members.size());
         // A dump slot holds up to 64 Q keys, Q of the class's kernel instance.
         size_t keyWords = 0;
-        for(int c = 0; c < CELLS_CLASSES; c++) keyWords += chunks[c].size() * size_t(64 * CELLS_Q[c]);
+        for(int c = 0; c < CELLS_LONG_BIG; c++) keyWords += chunks[c].size() * size_t(64 * CELLS_Q[c]);
         b.tieMembers.reserve(total, stream); b.tieChunks.reserve(total, stream); b.tieKeys.reserve(keyWords, stream); b.tieCounts.reserve(total, stream);
         HIP_CHECK(hipMemcpyAsync(b.tieMembers.data(), members.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemsetAsync(b.tieCounts.data(), 0xff, total * sizeof(uint32_t), stream));
@@ -761,7 +776,7 @@ void resolveComponentTies(Context& ctx, const WorkStream& ws, BatchScratch& b, u
         std::vector<uint32_t> order;                                         // candidate of dump slot s
         std::vector<size_t> slotWords;                                       // where slot s's keys start
         std::vector<uint32_t> slotCapacity;
-        for(int c = 0; c < CELLS_CLASSES; c++) {
+        for(int c = 0; c < CELLS_LONG_BIG; c++) {
             if(chunks[c].empty()) continue;
             const uint32_t count = uint32_t(chunks[c].size());
             const uint32_t maxc = uint32_t(64 * CELLS_Q[c]);
@@ -1283,7 +1298,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             if(listHits) {
                 const CellsChoice choice = cellsChoice(listClassRule, pd.nx, pd.ny);
                 hostHitBase[k + 1] = hostHitBase[k] + ((nx < 65535 && ny < 65535 && choice.cls < CELLS_CLASSES) ? hitListCapacity(pd.nx, pd.ny, ctx.matchShift) : 0u);
-                if(choice.cls == CELLS_LONG) maxOrdered = std::max(maxOrdered, std::min(pd.nx, pd.ny));       // (the windowed class orders by the shorter read; the others by a read below 8 192 markers)
+                if(choice.cls == CELLS_LONG || choice.cls == CELLS_LONG_BIG) maxOrdered = std::max(maxOrdered, std::min(pd.nx, pd.ny));       // (the windowed class orders by the shorter read; the others by a read below 8 192 markers)
             }
         }
         // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
@@ -1503,6 +1518,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     const int c = cellsChoice(classRule, hostPairs[q].nx, hostPairs[q].ny).cls;
                     pairClass[q] = c;
                     if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); }
+                    if(c == CELLS_LONG_BIG) pairSlotsLog2[q] = estimateLog2(q);       // (a tie of its components is looked at by the HBM-scratch kernel's dump form)
                 }
                 MI355X_ASSERT(uint64_t(n) - info[CELLS_INFO_FIRST_BIG] == bigList.size());
                 static const bool debugPrepare = std::getenv("SHASTA_MI355X_DEBUG") != nullptr;
@@ -1520,9 +1536,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     const bool sw = choice.swapped;
                     const int c = choice.cls;
                     pairClass[q] = c;
+                    if(c == CELLS_LONG_BIG) pairSlotsLog2[q] = estimateLog2(q);
                     if(c == CELLS_CLASSES) { bigList.push_back(q); bigLog2.push_back(estimateLog2(q)); continue; }
                     Keyed kd; kd.tabled = sw ? pd.begin1 : pd.begin0; kd.pair = q; kd.cls = uint8_t(c); kd.swapped = sw ? 1 : 0;
-                    if(c == CELLS_LONG) { kd.tabled = 0; kd.swapped = 0; }      // (the windowed class: one group, chunks of any sixteen candidates)
+                    if(c == CELLS_LONG || c == CELLS_LONG_BIG) { kd.tabled = 0; kd.swapped = 0; }      // (the windowed class: one group, chunks of any sixteen candidates)
                     keyed.push_back(kd);
                 }
                 // Order: (swapped, tabled read, class, candidate).  The candidates arrive in ascending order, so a STABLE sort on the
@@ -1618,16 +1635,24 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     // of its cell grid overflowed (bit 7), in the same class once more with its cells in the packed table.
                     const bool gridOverflow = (hostFlags[k] & 0x80) != 0 && !pairNoGrid[k];
                     if(gridOverflow) pairNoGrid[k] = 1;
-                    hostFlags[k] = 0;
                     int c = pairClass[k] + (gridOverflow ? 0 : 1);
                     bool sw = false;
-                    for(; c < CELLS_CLASSES; c++) {
+                    const int reasons = hostFlags[k] >> 4;            // 1 the cell table, 2 the kept list, 4 geometry (8: the grid byte, handled above)
+                    for(; c < CELLS_LONG; c++) {
                         const uint64_t cap = 1ULL << CELLS_NA_LOG2[c];
-                        if(c == CELLS_LONG) continue;      // (the windowed class has no larger cell table and no longer kept list than the class before it: nothing to climb to)
                         if(hostPairs[k].nx < cap) { sw = false; break; }
                         if(hostPairs[k].ny < cap) { sw = true; break; }
                     }
+                    if(c >= CELLS_LONG) {
+                        // Beyond the last chunk class, or out of the windowed one: only the kept list too short (more kept cells than a
+                        // wavefront's registers hold: a long overlap) has somewhere to go in LDS -- the windowed class's large graph, which
+                        // takes any two reads the windowed class takes; a full cell table goes on to the HBM-scratch kernel.
+                        const bool keptOnly = (reasons & 2) != 0 && (reasons & 5) == 0;
+                        c = (pairClass[k] < CELLS_LONG_BIG && keptOnly && cellsLongGeometryOk(classRule, hostPairs[k].nx, hostPairs[k].ny)) ? CELLS_LONG_BIG : CELLS_CLASSES;
+                    }
+                    hostFlags[k] = 0;
                     pairClass[k] = c;
+                    if(c == CELLS_LONG_BIG) pairSlotsLog2[k] = estimateLog2(k);
                     if(c >= CELLS_CLASSES) { bigList.push_back(k); bigLog2.push_back(estimateLog2(k)); }
                     else addChunk(&k, 1, sw, c, pairNoGrid[k] != 0);
                 }

@@ -463,7 +463,206 @@ __host__ __device__ inline size_t cellsChunkLdsWords(int naLog2, int scLog2, int
 // beyond every LDS table class (/root/reference/conf/Nanopore-UL-May2022.conf: no read below 50 000 bases) has its cells counted
 // and its matches LISTED in LDS like any other, instead of in the kernel with its tables in HBM scratch, which lists nothing.
 constexpr int CELLS_LONG_WAVES = 16, CELLS_LONG_THREADS = 64 * CELLS_LONG_WAVES;
-template<int Q, bool DUMP, bool LONG>
+
+// ---- the kept-cell graph of a candidate with more kept cells than a wavefront holds in registers (64 Q) ----------------------------
+// A pair of two long reads with a long overlap keeps about a cell and a half per 100 markers of it in each read: beyond 256 from overlaps of
+// some 20 000 markers on (1 000 candidates per step of the ultra-long shape; until round 6 they went on to the HBM-scratch kernel, which
+// lists no matches, and from there to the dense DP: 570 ms of kernels per step for 0.15 % of the candidates).  One wavefront, the kept cells
+// in LDS, up to CELLS_BIG_KEPT of them:
+//   order     the cells by (iX, iY): a counting sort by column (iX < 2^CELLS_IX_BITS), then every cell's rank among its column's;
+//   sweeps    forwardSearch / backwardSearch (src/Align4.cpp:682-788) move by at most one column, and inside a column along runs of
+//             consecutive iY: ONE pass over the columns in ascending (descending) order settles them -- a column's cells in the lanes, the
+//             reached cells of the column before in registers, the runs closed by shifts of a ballot.  Components (:792-868, 8-neighbourhood
+//             of the active cells): the smallest position of a component's cells, passed along in alternating sweeps until one changes nothing
+//             (two for a chain of cells; more only where branches meet);
+//   tasks     one per component from the iY range of its cells (:890-934).
+// A column of more than 64 kept cells (6 400 matches inside 200 anti-diagonals: a tandem repeat) is left to the HBM-scratch kernel.
+constexpr int CELLS_BIG_KEPT = 4096;
+constexpr int CELLS_BIG_COLUMNS = 1 << CELLS_IX_BITS;
+// Words of LDS the graph works in (colStart | cursor | the cells in column order | state bytes | labels (16-bit) | iY ranges of the components).
+constexpr int CELLS_BIG_WORK_WORDS = (CELLS_BIG_COLUMNS + 1) + CELLS_BIG_COLUMNS + CELLS_BIG_KEPT + CELLS_BIG_KEPT / 4 + CELLS_BIG_KEPT / 2 + 2 * CELLS_BIG_KEPT;
+constexpr uint32_t BIG_NEAR_LT = 1, BIG_NEAR_RB = 2, BIG_FWD = 4, BIG_BWD = 8;
+
+// keys[0 .. n): the kept cells (iY << 16 | iX), any order; afterwards in (iX, iY) order.  Returns false if the graph does not fit (the
+// caller flags the candidate).  One wavefront; `work`: CELLS_BIG_WORK_WORDS words of LDS no other wavefront touches meanwhile.
+__device__ inline bool cellsBigGraph(uint32_t* __restrict__ keys, int n, uint32_t* __restrict__ work, uint32_t pair, uint32_t nx, uint32_t ny, const DeviceOptions& opt,
+    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity)
+{
+    const int lane = laneId();
+    uint32_t* const colStart = work;                                              // [COLUMNS + 1]
+    uint32_t* const cursor = colStart + CELLS_BIG_COLUMNS + 1;                    // [COLUMNS]
+    uint32_t* const sorted = cursor + CELLS_BIG_COLUMNS;                          // [KEPT]
+    uint8_t* const state = reinterpret_cast<uint8_t*>(sorted + CELLS_BIG_KEPT);   // [KEPT]
+    uint16_t* const label = reinterpret_cast<uint16_t*>(sorted + CELLS_BIG_KEPT + CELLS_BIG_KEPT / 4);          // [KEPT]
+    uint32_t* const yMin = sorted + CELLS_BIG_KEPT + CELLS_BIG_KEPT / 4 + CELLS_BIG_KEPT / 2;                    // [KEPT]
+    uint32_t* const yMax = yMin + CELLS_BIG_KEPT;                                 // [KEPT]
+    // ---- the cells in (iX, iY) order ----
+    for(int k = lane; k <= CELLS_BIG_COLUMNS; k += WAVE) colStart[k] = 0;
+    waveLdsSync();
+    for(int i = lane; i < n; i += WAVE) atomicAdd(&colStart[(keys[i] & 0xffffu) + 1u], 1u);
+    waveLdsSync();
+    bool crowded = false;
+    uint32_t firstColumn = CELLS_BIG_COLUMNS, lastColumn = 0;
+    {
+        constexpr int PER = (CELLS_BIG_COLUMNS + 1 + WAVE - 1) / WAVE;
+        const int first = lane * PER, end = min(first + PER, CELLS_BIG_COLUMNS + 1);
+        uint32_t sum = 0;
+        for(int k = first; k < end; k++) {
+            const uint32_t m = colStart[k];                                       // cells of column k - 1
+            sum += m; crowded |= m > uint32_t(WAVE);
+            if(m) { firstColumn = min(firstColumn, uint32_t(k - 1)); lastColumn = max(lastColumn, uint32_t(k - 1)); }
+        }
+        uint32_t inclusive = sum;
+#pragma unroll
+        for(int d = 1; d < WAVE; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inclusive), d, WAVE)); if(lane >= d) inclusive += o; }
+        uint32_t running = inclusive - sum;
+        for(int k = first; k < end; k++) { running += colStart[k]; colStart[k] = running; }       // colStart[k] = cells of the columns below k
+#pragma unroll
+        for(int d = 32; d >= 1; d >>= 1) {
+            firstColumn = min(firstColumn, uint32_t(__shfl_xor(int(firstColumn), d, WAVE))); lastColumn = max(lastColumn, uint32_t(__shfl_xor(int(lastColumn), d, WAVE)));
+        }
+    }
+    if(__any(crowded)) return false;
+    waveLdsSync();
+    for(int k = lane; k < CELLS_BIG_COLUMNS; k += WAVE) cursor[k] = colStart[k];
+    waveLdsSync();
+    for(int i = lane; i < n; i += WAVE) { const uint32_t key = keys[i]; sorted[atomicAdd(&cursor[key & 0xffffu], 1u)] = key; }
+    waveLdsSync();
+    for(int i = lane; i < n; i += WAVE) {
+        const uint32_t key = sorted[i], column = key & 0xffffu;
+        const uint32_t s = colStart[column], e = colStart[column + 1u];
+        uint32_t rank = 0;
+        for(uint32_t j = s; j < e; j++) rank += (sorted[j] >> 16) < (key >> 16) ? 1u : 0u;
+        keys[s + rank] = key;
+    }
+    waveLdsSync();
+    // ---- boundary flags (:424-429 with the corner rules of :530-626) ----
+    for(int i = lane; i < n; i += WAVE) {
+        const uint32_t key = keys[i];
+        const uint32_t iX = key & 0xffffu, iY = key >> 16;
+        int32_t x, y;
+        getxy(iX * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t left = x < 0 ? 0u : uint32_t(x);
+        getxy((iX + 1) * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t right = (x >= int32_t(nx) - 1) ? 0u : uint32_t(nx - 1 - uint32_t(x));
+        getxy(iX * opt.deltaX, iY * opt.deltaY, nx, x, y);
+        const uint32_t top = y < 0 ? 0u : uint32_t(y);
+        getxy((iX + 1) * opt.deltaX, (iY + 1) * opt.deltaY, nx, x, y);
+        const uint32_t bottom = (y >= int32_t(ny) - 1) ? 0u : uint32_t(ny - 1 - uint32_t(y));
+        uint32_t f = 0;
+        if(uint64_t(left) < opt.maxDistanceFromBoundary || uint64_t(top) < opt.maxDistanceFromBoundary) f |= BIG_NEAR_LT;
+        if(uint64_t(right) < opt.maxDistanceFromBoundary || uint64_t(bottom) < opt.maxDistanceFromBoundary) f |= BIG_NEAR_RB;
+        state[i] = uint8_t(f);
+        yMin[i] = EMPTY32; yMax[i] = 0;
+    }
+    waveLdsSync();
+    // A column's cells in the lanes (m <= 64 of them, iY ascending); A: lane i and lane i + 1 hold consecutive iY.
+    // closeRuns: the lanes of `reached` and every lane joined to one of them through consecutive iY.
+    auto closeRuns = [](uint64_t reached, uint64_t A) {
+        for(;;) {
+            const uint64_t grown = reached | ((reached & A) << 1) | ((reached >> 1) & A);
+            if(grown == reached) return reached;
+            reached = grown;
+        }
+    };
+    // ---- forwardSearch (:682-729), then backwardSearch (:736-787): seeds near right / bottom AND forward accessible ----
+    for(int pass = 0; pass < 2; pass++) {
+        const bool forward = pass == 0;
+        uint64_t neighbourReached = 0;                      // reached cells of the column before (forward) / behind (backward), by lane
+        uint32_t neighbourY = 0;                            // ... their iY
+        for(int32_t step = 0; step <= int32_t(lastColumn) - int32_t(firstColumn); step++) {
+            const uint32_t column = forward ? firstColumn + uint32_t(step) : lastColumn - uint32_t(step);
+            const uint32_t s = colStart[column], m = colStart[column + 1u] - s;
+            if(m == 0) { neighbourReached = 0; continue; }
+            const bool valid = uint32_t(lane) < m;
+            const uint32_t y = keys[s + (valid ? uint32_t(lane) : 0u)] >> 16;
+            const uint32_t st = state[s + (valid ? uint32_t(lane) : 0u)];
+            bool hit = false;
+            for(uint64_t todo = neighbourReached; todo; todo &= todo - 1) {
+                const uint32_t other = __builtin_amdgcn_readlane(neighbourY, __ffsll((unsigned long long)todo) - 1);
+                hit = hit || (y + 1u - other) <= 2u;                            // |y - other| <= 1
+            }
+            const bool seed = forward ? (st & BIG_NEAR_LT) != 0 : ((st & BIG_NEAR_RB) != 0 && (st & BIG_FWD) != 0);
+            const uint32_t above = uint32_t(__shfl_down(int(y), 1, WAVE));
+            const uint64_t A = __ballot(valid && uint32_t(lane) + 1u < m && above == y + 1u);
+            const uint64_t reached = closeRuns(__ballot(valid && (seed || hit)), A);
+            if(valid && ((reached >> lane) & 1ULL)) state[s + uint32_t(lane)] = uint8_t(st | (forward ? BIG_FWD : BIG_BWD));
+            neighbourReached = reached; neighbourY = y;
+        }
+        waveLdsSync();
+    }
+    // ---- connected components of the active cells, 8-neighbourhood (:792-868): the smallest position of a component's cells ----
+    for(int i = lane; i < n; i += WAVE) label[i] = (state[i] & (BIG_FWD | BIG_BWD)) == (BIG_FWD | BIG_BWD) ? uint16_t(i) : uint16_t(0xffff);
+    waveLdsSync();
+    for(int sweep = 0; sweep < 2 * CELLS_BIG_COLUMNS + 4; sweep++) {
+        const bool forward = (sweep & 1) == 0;
+        bool changed = false;
+        uint64_t neighbourActive = 0;
+        uint32_t neighbourY = 0, neighbourLabel = 0xffffu;
+        for(int32_t step = 0; step <= int32_t(lastColumn) - int32_t(firstColumn); step++) {
+            const uint32_t column = forward ? firstColumn + uint32_t(step) : lastColumn - uint32_t(step);
+            const uint32_t s = colStart[column], m = colStart[column + 1u] - s;
+            if(m == 0) { neighbourActive = 0; continue; }
+            const bool valid = uint32_t(lane) < m;
+            const uint32_t y = keys[s + (valid ? uint32_t(lane) : 0u)] >> 16;
+            const uint32_t before = valid ? uint32_t(label[s + uint32_t(lane)]) : 0xffffu;
+            const bool active = before != 0xffffu;
+            uint32_t mine = before;
+            for(uint64_t todo = neighbourActive; todo; todo &= todo - 1) {
+                const int j = __ffsll((unsigned long long)todo) - 1;
+                const uint32_t otherY = __builtin_amdgcn_readlane(neighbourY, j), otherLabel = __builtin_amdgcn_readlane(neighbourLabel, j);
+                if(active && (y + 1u - otherY) <= 2u) mine = min(mine, otherLabel);
+            }
+            // Inside the column: along runs of consecutive iY whose cells are active.
+            const uint64_t activeLanes = __ballot(active);
+            const uint32_t above = uint32_t(__shfl_down(int(y), 1, WAVE));
+            const uint64_t A = __ballot(valid && uint32_t(lane) + 1u < m && above == y + 1u) & activeLanes & (activeLanes >> 1);
+            for(;;) {
+                const uint32_t up = uint32_t(__shfl_down(int(mine), 1, WAVE)), down = uint32_t(__shfl_up(int(mine), 1, WAVE));
+                uint32_t next = mine;
+                if((A >> lane) & 1ULL) next = min(next, up);
+                if(lane > 0 && ((A >> (lane - 1)) & 1ULL)) next = min(next, down);
+                const bool moved = next != mine;
+                mine = next;
+                if(!__any(moved)) break;
+            }
+            if(active && mine != before) { label[s + uint32_t(lane)] = uint16_t(mine); changed = true; }
+            neighbourActive = activeLanes; neighbourY = y; neighbourLabel = mine;
+        }
+        waveLdsSync();
+        if(!__any(changed) && sweep >= 1) break;             // (the first backward sweep that changes nothing: a fixed point of both directions)
+    }
+    // ---- one banded alignment per component (:890-934) ----
+    for(int i = lane; i < n; i += WAVE) {
+        const uint32_t l = label[i];
+        if(l == 0xffffu) continue;
+        atomicMin(&yMin[l], keys[i] >> 16);
+        atomicMax(&yMax[l], keys[i] >> 16);
+    }
+    waveLdsSync();
+    for(int i = lane; i < n; i += WAVE) {
+        if(uint32_t(label[i]) != uint32_t(i)) continue;
+        const uint32_t YMin = yMin[i] * opt.deltaY;
+        const uint32_t YMax = (yMax[i] + 1) * opt.deltaY - 1;
+        const int32_t bandMin = int32_t(nx) - 1 - int32_t(YMax);
+        const int32_t bandMax = int32_t(nx) - 1 - int32_t(YMin);
+        const int32_t bandWidth = bandMax - bandMin + 1;
+        if(int64_t(bandWidth) > int64_t(opt.maxBand)) continue;                // :929
+        DpTask task; task.pair = pair; task.bandMin = bandMin; task.bandMax = bandMax; task.label = keys[i];
+        if(bandWidth > 1024) {
+            // (to the back of the task list, for the wide DP: see align4CellsKernel)
+            const uint32_t w = atomicAdd(taskCount + CELLS_WIDE_COUNTER, 1u);
+            if(w < taskCapacity) tasks[taskCapacity - 1u - w] = task;
+        } else {
+            const uint32_t t = atomicAdd(taskCount, 1u);
+            if(t < taskCapacity) tasks[t] = task;
+        }
+    }
+    return true;
+}
+// BIG (align4CellsLongBigKernel): LONG for the candidates that keep more cells than its graphs hold -- one candidate at a time, up to
+// CELLS_BIG_KEPT kept cells in LDS behind the wavefronts' slots, the graph by cellsBigGraph (wavefront 0, in the LDS of the tables).
+template<int Q, bool DUMP, bool LONG, bool BIG = false>
 __device__ __forceinline__ void cellsChunkBody(
     const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
     const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
@@ -475,6 +674,8 @@ __device__ __forceinline__ void cellsChunkBody(
     __shared__ uint32_t waveTotals[(LONG ? CELLS_LONG_THREADS : SHASTA_CELLS_MAX_THREADS) / 64];
     constexpr int IY_BITS = LONG ? CELLS_LONG_IY_BITS : CELLS_IY_BITS, COUNT_BITS = LONG ? CELLS_LONG_COUNT_BITS : CELLS_COUNT_BITS;
     constexpr int MAXC = 64 * Q;
+    static_assert(!BIG || (LONG && !DUMP), "the large graph belongs to the windowed class");
+    constexpr uint32_t KEPT_ROOM = BIG ? uint32_t(CELLS_BIG_KEPT) : uint32_t(MAXC);          // kept cells listed per candidate
     if(blockIdx.x >= chunkCount) return;
     const CellsChunk chunk = chunks[blockIdx.x];
     const int lane = laneId();
@@ -499,6 +700,7 @@ __device__ __forceinline__ void cellsChunkBody(
     uint32_t* const ownScratch = ownKept + scratchAt;
     uint32_t* const stage = ownScratch + 8;
     const uint32_t threshold = uint32_t(opt.minEntryCountPerCell > 1 ? min(opt.minEntryCountPerCell, uint64_t(0xffffffffu)) : 1);
+    uint32_t* const bigKept = slots + waves * cellsSlotLdsWords(Q);       // (BIG: the one candidate's kept cells, behind the slots)
     PHASE_BEGIN();
 
 
@@ -587,8 +789,8 @@ __device__ __forceinline__ void cellsChunkBody(
     PairDesc pdAhead = pdFirst;
 
     // Groups of `waves` candidates: streamed one after the other by the whole workgroup, then one graph per wavefront.
-    for(uint32_t group = 0; group < chunk.count; group += waves) {
-    const uint32_t groupEnd = min(group + waves, uint32_t(chunk.count));
+    for(uint32_t group = 0; group < chunk.count; group += (BIG ? 1u : waves)) {
+    const uint32_t groupEnd = min(group + (BIG ? 1u : waves), uint32_t(chunk.count));
     for(uint32_t c = group; c < groupEnd; c++) {
         const uint32_t pair = pairAhead;
         const PairDesc pd = pdAhead;
@@ -597,6 +799,7 @@ __device__ __forceinline__ void cellsChunkBody(
         if(more) { pairAhead = members[chunk.firstMember + c + 1]; pdAhead = pairs[pairAhead]; }
         kept = slots + (c - group) * cellsSlotLdsWords(Q);
         scratch = kept + scratchAt;
+        if(BIG) kept = bigKept;
         const bool swapped = LONG ? ny < nx : chunkSwapped;        // (LONG: every candidate tables its own shorter read)
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
@@ -672,7 +875,7 @@ __device__ __forceinline__ void cellsChunkBody(
                 for(int u = 0; u < N; u++) {
                     if(before[u] + 1 == threshold) {                                          // :417
                         const uint32_t at = atomicAdd(&scratch[0], 1u);
-                        if(at < uint32_t(MAXC)) kept[at] = (iY[u] << 16) | iX[u];
+                        if(at < KEPT_ROOM) kept[at] = (iY[u] << 16) | iX[u];
                     }
                     if(before[u] == 255u) { overflow = max(overflow, 1); reason |= 8; }     // the byte wrapped
                 }
@@ -716,7 +919,7 @@ __device__ __forceinline__ void cellsChunkBody(
                         if(done) {
                             if(before < threshold && before + 1 >= threshold) {                // :417
                                 const uint32_t idx = atomicAdd(&scratch[0], 1u);
-                                if(idx < uint32_t(MAXC)) kept[idx] = key[u];
+                                if(idx < KEPT_ROOM) kept[idx] = key[u];
                             }
                             pending[u] = false;
                         }
@@ -841,6 +1044,20 @@ __device__ __forceinline__ void cellsChunkBody(
         PHASE_MARK(2);
     }
 
+        if constexpr (BIG) {
+            // The one candidate's graph: wavefront 0, working in the LDS of the tables (the others wait at the barrier below).
+            if(wave == 0) {
+                scratch = slots + scratchAt;
+                const uint32_t pair = scratch[5], nx = scratch[6], ny = scratch[7];
+                const uint32_t seen = scratch[4];
+                const uint32_t n = scratch[0];
+                static_assert(CELLS_BIG_WORK_WORDS <= (1 << 13) + CELLS_RANGE_PAD + (1 << 13) + (1 << 13), "the graph's arrays fit the tables' LDS (class geometry: align4.hip)");
+                bool fits = seen == 0 && n <= KEPT_ROOM;
+                int reasons = int(seen & 7u) | (n > KEPT_ROOM ? 2 : 0);
+                if(fits && n) { fits = cellsBigGraph(bigKept, int(n), ldsWords, pair, nx, ny, opt, tasks, taskCount, taskCapacity); if(!fits) reasons |= 2; }
+                if(!fits && lane == 0) pairFlags[pair] = (seen & 0x10u) ? PAIR_TOO_LONG : uint8_t(PAIR_RESOURCE | (reasons << 4));
+            }
+        } else
         // The kept-cell graphs of the group, one per wavefront.
         if(SHASTA_ABLATE != 1 && group + wave < groupEnd) do {
         kept = ownKept; scratch = ownScratch;
@@ -1105,6 +1322,18 @@ align4CellsChunkKernel(
 
 // The windowed class: sixteen wavefronts a workgroup (one workgroup per CU by its LDS: four wavefronts per SIMD stream a candidate
 // together), 256 kept cells per candidate.
+// ... and its candidates with more kept cells than that: one at a time, up to CELLS_BIG_KEPT kept cells (cellsBigGraph).
+__global__ void __launch_bounds__(CELLS_LONG_THREADS)
+align4CellsLongBigKernel(
+    const uint32_t* __restrict__ kmerIds, const PairDesc* __restrict__ pairs,
+    const CellsChunk* __restrict__ chunks, uint32_t chunkCount, const uint32_t* __restrict__ members,
+    DeviceOptions opt, uint32_t magicX, uint32_t magicY,
+    DpTask* __restrict__ tasks, uint32_t* __restrict__ taskCount, uint32_t taskCapacity,
+    uint8_t* __restrict__ pairFlags, HitLists hitLists)
+{
+    cellsChunkBody<4, false, true, true>(kmerIds, pairs, chunks, chunkCount, members, opt, magicX, magicY, tasks, taskCount, taskCapacity, pairFlags, nullptr, nullptr, hitLists);
+}
+
 template<bool DUMP = false>
 __global__ void __launch_bounds__(CELLS_LONG_THREADS)
 align4CellsLongKernel(

@@ -8,13 +8,16 @@
 // (constexpr arrays cannot be indexed by a run-time value in device code; these can)
 __host__ __device__ inline int cellsNaLog2(int c) { return c == 0 ? CELLS_NA_LOG2[0] : (c == 1 ? CELLS_NA_LOG2[1] : (c == 2 ? CELLS_NA_LOG2[2] : (c == 3 ? CELLS_NA_LOG2[3] : CELLS_NA_LOG2[4]))); }
 __host__ __device__ inline int cellsScLog2(int c) { return c == 0 ? CELLS_SC_LOG2[0] : (c == 1 ? CELLS_SC_LOG2[1] : (c == 2 ? CELLS_SC_LOG2[2] : (c == 3 ? CELLS_SC_LOG2[3] : CELLS_SC_LOG2[4]))); }
-__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : (c == 2 ? CELLS_CHUNK_MAX[2] : (c == 3 ? CELLS_CHUNK_MAX[3] : CELLS_CHUNK_MAX[4]))); }
-static_assert(CELLS_CLASSES == 5 && CELLS_LONG == 4, "cellsNaLog2 / cellsScLog2 / cellsChunkMax name five classes, the last one the windowed one");
+__host__ __device__ inline uint32_t cellsChunkMax(int c) { return c == 0 ? CELLS_CHUNK_MAX[0] : (c == 1 ? CELLS_CHUNK_MAX[1] : (c == 2 ? CELLS_CHUNK_MAX[2] : (c == 3 ? CELLS_CHUNK_MAX[3] : (c == 4 ? CELLS_CHUNK_MAX[4] : CELLS_CHUNK_MAX[5])))); }
+static_assert(CELLS_CLASSES == 6 && CELLS_LONG == 4 && CELLS_LONG_BIG == 5 && CELLS_NA_LOG2[4] == CELLS_NA_LOG2[5] && CELLS_SC_LOG2[4] == CELLS_SC_LOG2[5],
+    "cellsNaLog2 / cellsScLog2 / cellsChunkMax name the five classes a candidate starts in, the last one the windowed one (its large-graph form is never a first choice)");
 constexpr int CELLS_CLASS_BITS = 3;                         // the class (0 .. CELLS_CLASSES, the last = HBM scratch) in the sort key
 
 // estimateShift: a candidate's random background is about nx ny >> estimateShift matches (Context::matchShift: from a sample of the
 // read set's markers; 13 for the k = 10 alphabets, 18 at k = 14).
-struct CellsClassRule { uint64_t deltaX, deltaY; bool packedOk, longOk; int estimateShift; };
+// force: 0, or (SHASTA_MI355X_CELLS_FORCE=long / big: the tests' switch) 1 / 2 = every candidate the windowed class can take starts in it / in its
+// large-graph form, whatever smaller class would do -- the whole suite's read sets through those two kernels.
+struct CellsClassRule { uint64_t deltaX, deltaY; bool packedOk, longOk; int estimateShift; int force; };
 inline CellsClassRule cellsClassRule(const DeviceOptions& opt, int estimateShift)
 {
     CellsClassRule r;
@@ -26,6 +29,8 @@ inline CellsClassRule cellsClassRule(const DeviceOptions& opt, int estimateShift
     // adds in flight room (a count that reaches 255 all the same is detected and the candidate climbs to the HBM-scratch kernel).
     r.longOk = opt.deltaX >= 2 && opt.deltaY >= 2 && opt.minEntryCountPerCell <= 191;
     r.estimateShift = estimateShift;
+    r.force = 0;
+    if(const char* e = std::getenv("SHASTA_MI355X_CELLS_FORCE")) r.force = std::string(e) == "long" ? 1 : (std::string(e) == "big" ? 2 : 0);      // (read for every batch: tests switch it)
     return r;
 }
 // Class of a candidate that tables a read of `tabled` markers: table of the tabled read at load <= 1/2, cell table sized for
@@ -38,14 +43,22 @@ __host__ __device__ inline int cellsClassFor(const CellsClassRule& rule, uint64_
     // The single-multiply division must be exact.
     if((nx + ny) * (rule.deltaX > rule.deltaY ? rule.deltaX : rule.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
     const uint64_t cells = (nx * ny >> rule.estimateShift) + (nx + ny) / 32 + 32;
+    const bool longFits = rule.longOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_LONG_IY_BITS) - 1 && 4 * cells <= (3ULL << cellsScLog2(CELLS_LONG));
+    if(rule.force && longFits) return rule.force == 2 ? CELLS_LONG_BIG : CELLS_LONG;
     // Cell indices must fit the packed word.
     if(rule.packedOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_IY_BITS)) {
         for(int c = 0; c < CELLS_LONG; c++) {
             if(tabled < (1ULL << cellsNaLog2(c)) && 4 * cells <= (3ULL << cellsScLog2(c))) return c;
         }
     }
-    if(rule.longOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_LONG_IY_BITS) - 1 && 4 * cells <= (3ULL << cellsScLog2(CELLS_LONG))) return CELLS_LONG;
+    if(longFits) return CELLS_LONG;
     return CELLS_CLASSES;
+}
+// What the windowed class asks of a candidate's geometry (not the estimate of its cells): for a candidate that climbs to its large-graph form.
+__host__ __device__ inline bool cellsLongGeometryOk(const CellsClassRule& rule, uint64_t nx, uint64_t ny)
+{
+    return nx < 65535 && ny < 65535 && rule.longOk && (nx + ny) * (rule.deltaX > rule.deltaY ? rule.deltaX : rule.deltaY) < (1ULL << 32) &&
+        (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_LONG_IY_BITS) - 1;
 }
 // Every candidate tables whichever of its two reads lands in the smaller class (ties: read 0).  (The windowed class tables the
 // shorter read whatever this says: align4CellsLongKernel decides for itself.)
@@ -57,7 +70,7 @@ __host__ __device__ inline CellsChoice cellsChoice(const CellsClassRule& rule, u
     CellsChoice r;
     r.swapped = c1 < c0;
     r.cls = r.swapped ? c1 : c0;
-    if(r.cls == CELLS_LONG) r.swapped = ny < nx;
+    if(r.cls == CELLS_LONG || r.cls == CELLS_LONG_BIG) r.swapped = ny < nx;
     return r;
 }
 
@@ -86,7 +99,7 @@ cellsClassKeysKernel(const PairDesc* __restrict__ pairs, const shasta_oriented_r
         // of the sort below instead of five).
         const shasta_oriented_read_pair c = candidates[q];
         // (the windowed class tables every candidate's read anew: its chunks are any sixteen candidates, one group)
-        const bool grouped = cls != CELLS_LONG;
+        const bool grouped = cls != CELLS_LONG && cls != CELLS_LONG_BIG;
         const uint64_t tabled = !grouped ? 0ULL : (choice.swapped ? (2ULL * c.readIds[1] + (c.isSameStrand ? 0u : 1u)) : 2ULL * c.readIds[0]);
         keys[q] = (uint64_t(cls) << (tabledBits + 1)) | (uint64_t(grouped && choice.swapped ? 1 : 0) << tabledBits) | tabled;
         ids[q] = q;

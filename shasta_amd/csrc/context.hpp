@@ -45,7 +45,7 @@ struct Context {
     std::shared_ptr<void> downsampled;       // align method 3: the markers its step 1 keeps (dropped by setMarkers)
     // Kernels that need more dynamic LDS than the default get the attribute once per context, i.e. on this context's device
     // (hipFuncSetAttribute acts on the current device; the aligner's workers may get there at the same time).
-    std::once_flag cellsLdsAttribute[3], cellsDumpLdsAttribute, wideDpLdsAttribute, palindromicLdsAttribute;      // per context = per device (hipFuncSetAttribute is per device)
+    std::once_flag cellsLdsAttribute[4], cellsDumpLdsAttribute, wideDpLdsAttribute, palindromicLdsAttribute;      // per context = per device (hipFuncSetAttribute is per device)
     KernelTimers timers;                     // per-kernel HIP-event times since the last reset (shasta_mi355x_kernel_table)
     // The aligner's own events (a call's begin / end / join, two per worker): made once and kept -- fifteen hipEventCreate at the head
     // of every call and fifteen hipEventDestroy at its end were 4 + 5-10 ms of a 130 ms call on the host's clock (round 5,

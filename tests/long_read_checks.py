@@ -68,3 +68,43 @@ def both_long(lib, oracle_lib, ref_lib=None, alphabet_size=None, seed=66, **kw):
     return {"candidates": len(cand), "stored": int((x.status == abi.SHASTA_ALIGN_STORED).sum()), "both_long": expected_long,
             "in_the_windowed_class": int(sum(r["work"] for r in long_rows)), "in_the_hbm_scratch_kernel": int(sum(r["work"] for r in hbm_rows)),
             "dense_because": {name: int(r["launches"]) for name, r in rows.items() if name.startswith("dense DP because")}, "rows": rows}
+
+
+def forced(lib, oracle_lib, ref_lib, force, n_reads=200, limit=1500, adversarial_sets=True):
+    """SHASTA_MI355X_CELLS_FORCE=long / big: every candidate the windowed class can take starts in it (or in its large-graph form) --
+    ordinary reads and the adversarial read sets through align4CellsLongKernel / align4CellsLongBigKernel, against the reference's own
+    Align4 (component ties included: the reference resolves them, the library must pick the same component)."""
+    os.environ["SHASTA_MI355X_CELLS_FORCE"] = force
+    try:
+        checked = 0
+        toc, kmer, data7 = support.small_marker_set(n_reads=n_reads, genome_markers=12000, seed=99)
+        p = abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)
+        cand = oracle_lib.lowhash0(toc, data7, None, p).candidates[:limit]
+        for o in (abi.default_align4_options(minAlignedMarkerCount=40), abi.default_align4_options(**UL_ALIGN)):
+            with lib.context(0) as ctx:
+                ctx.set_markers(toc, data7)
+                ctx.kernel_table_reset()
+                x = ctx.align4(cand, o, want_ordinals=True)
+                rows = kernel_rows(ctx)
+            name = "align4CellsLongBigKernel" if force == "big" else "align4CellsLongKernel<false>"
+            assert name in rows and rows[name]["work"] >= len(cand) // 2, rows.keys()
+            y = (ref_lib or oracle_lib).align4_batch(toc, data7, cand, o, want_ordinals=True)
+            if ref_lib is not None:
+                support.same_align(x, y)
+            else:
+                ties = (y.status & 0x80) != 0
+                assert x.per_candidate(~ties) == y.per_candidate(~ties)
+            checked += len(cand)
+        if adversarial_sets:
+            for _, reads in adversarial.read_sets(long_reads=False):
+                toc, kmer, data7 = adversarial.build(reads)
+                cand = adversarial.all_pairs(len(reads))
+                o = abi.default_align4_options(minAlignedMarkerCount=10)
+                x = lib.align4_batch(toc, data7, cand, o, want_ordinals=True)
+                y = (ref_lib or oracle_lib).align4_batch(toc, data7, cand, o, want_ordinals=True)
+                ties = (y.status & 0x80) != 0
+                assert x.per_candidate(~ties) == y.per_candidate(~ties) and np.array_equal(x.status[~ties], y.status[~ties])
+                checked += len(cand)
+        return checked
+    finally:
+        del os.environ["SHASTA_MI355X_CELLS_FORCE"]

@@ -346,3 +346,10 @@ def test_pairs_of_two_long_reads(emu_lib, oracle_lib, monkeypatch):
     monkeypatch.setenv("SHASTA_MI355X_ALIGN_WORKERS", "1")
     r = long_read_checks.both_long(emu_lib, oracle_lib, lengths=(9000, 12500, 9500, 8300, 4000), genome_markers=16000)
     assert r["both_long"] == 12 and r["in_the_windowed_class"] == 12 and r["in_the_hbm_scratch_kernel"] == 0 and not r["dense_because"]
+
+
+@pytest.mark.parametrize("force", ["long", "big"])
+def test_every_candidate_through_the_windowed_kernels(emu_lib, oracle_lib, force, monkeypatch):
+    from tests import long_read_checks
+    monkeypatch.setenv("SHASTA_MI355X_ALIGN_WORKERS", "1")
+    assert long_read_checks.forced(emu_lib, oracle_lib, None, force, n_reads=120, limit=400, adversarial_sets=False) >= 700

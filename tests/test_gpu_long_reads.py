@@ -34,3 +34,8 @@ def test_long_reads_over_a_small_alphabet(gpu_lib, oracle_lib):
 def test_long_reads_with_the_librarys_own_estimate(gpu_lib, oracle_lib):
     r = long_read_checks.both_long(gpu_lib, oracle_lib, seed=68)
     assert r["both_long"] >= 60 and r["stored"] >= 15
+
+
+@pytest.mark.parametrize("force", ["long", "big"])
+def test_every_candidate_through_the_windowed_kernels(gpu_lib, oracle_lib, ref_lib, force):
+    assert long_read_checks.forced(gpu_lib, oracle_lib, ref_lib, force) >= 3000
