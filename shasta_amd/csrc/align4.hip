@@ -135,6 +135,7 @@ struct BatchScratch {
     DeviceBuffer<uint32_t> tieMembers, tieKeys, tieCounts;     // resolveComponentTies
     uint32_t sparseStateTasks = 0;       // of the batch in hand: the tasks sparseState speaks of (0: the sparse path did not run)
     bool streamsInLists = false;         // ... and whether the wave kernel leaves its alignments in shasta::compress form in their lists (compressWriteKernel copies them)
+    bool pairsWanted = true;             // ... and whether anyone reads the aligned pairs of such a task (the caller asked for the ordinals): if not, the wave kernel does not write them
     DeviceBuffer<CellsChunk> tieChunks;
     View<uint8_t> pairFlags, pairTie;
     DeviceBuffer<uint8_t> status;
@@ -422,7 +423,8 @@ void launchChainWaveClassAs(hipStream_t stream, BatchScratch& b, const DpInput& 
     hipLaunchKernelGGL((sparseChainWaveKernel<int(CAP), OWN_SORT, NARROW>), dim3(std::min<uint32_t>(grid, divUp(taskCount, CHAIN_WAVE_BLOCK))), dim3(64), ldsBytes, stream,
         in.pairs, in.tasks, taskCount, CLS, control,
         b.sparseSorted.data(), b.sparseInBand.data(), b.sparseState.data(), sparse.hits, sparse.hitBase, sparse.hitMeta,
-        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data(), b.streamsInLists ? 1u : 0u);
+        (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data(), b.sparseLinks.data(), b.ends.data(), b.sparseAmbiguous.data(), b.chainWaveRetry.data(), opt, b.pairBest.data(),
+        (b.streamsInLists ? 1u : 0u) | (b.streamsInLists && !b.pairsWanted ? 2u : 0u));
     HIP_CHECK(hipGetLastError());
 }
 template<int CLS, bool OWN_SORT>
@@ -1495,7 +1497,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 // (profiles/r05_call19.log).  SHASTA_MI355X_CELLS_SIDE_FROM=<class> puts the classes from that one on on the worker's side
                 // stream, beside the first classes' launches; measured: 137.7 / 136.7 / 137.4 ms per step with 3 / 2 / none
                 // (profiles/r05_call20.log) -- no difference, so none is the default (4).
-                static const int sideFrom = [] { const char* e = std::getenv("SHASTA_MI355X_CELLS_SIDE_FROM"); return e ? std::atoi(e) : 4; }();
+                static const int sideFrom = [] { const char* e = std::getenv("SHASTA_MI355X_CELLS_SIDE_FROM"); return e ? std::atoi(e) : CELLS_CLASSES; }();
                 bool onSide = false;
                 for(int pass = 0; pass < 2; pass++) {
                     for(int c = 0; c < CELLS_CLASSES; c++) {
@@ -1749,6 +1751,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         // K10: sort the tasks by (band class, length), bundle, forward DP, traceback.
         if(taskCount + wideCount) {
             const SparseInput sparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data(), maxOrdered};
+            b.pairsWanted = wantOrdinals;
             out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs, listHits ? &sparseInput : nullptr);
             out.hadTasks = true;
             const uint32_t allTasks = taskCount + wideCount;

@@ -499,7 +499,9 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             const int32_t hp = int32_t(h >> 16), hs = int32_t(h & 0xffffu);
             const int32_t x = swapped ? hs : hp, y = swapped ? hp : hs;
             pos -= count;
-            if(isOn) *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos + rank)) = make_uint2(uint32_t(x), uint32_t(y));
+            // (emitStream bit 1: nobody reads the aligned pairs of this task -- the caller did not ask for the ordinals and the streaks below are what
+            // compressWriteKernel copies: 8 bytes per pair, 1 GB per launch at 100 k reads, not written)
+            if(isOn && !(emitStream & 2u)) *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos + rank)) = make_uint2(uint32_t(x), uint32_t(y));
             // The pair after this one: the next lane up that is on the chain, or the lowest pair of the part met before.
             const uint64_t above = bitsAbove(on, lane);
             const int nextLane = above ? lane + __ffsll((unsigned long long)above) : lane;
@@ -534,7 +536,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
                 recordBytes = uint32_t(record.len);
                 bytes += uint64_t(recordBytes);
             }
-            if(emitStream && starts) {
+            if((emitStream & 1u) && starts) {
                 // (in the order of the lanes: a lane's streak lies behind those of the lanes below it)
                 const uint32_t inclusive = uint32_t(waveInclusiveSum(int32_t(recordBytes)));
                 const uint32_t total = uint32_t(laneValue(int32_t(inclusive), WAVE - 1));
@@ -566,8 +568,8 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             if(haveLater) {
                 // (the first pair: its streak's skips are taken against (0, 0))
                 const StreakRecord record = makeStreakRecord(laterX, laterY, carryLength);
-                SHASTA_DEVICE_CHECK(!emitStream || (bytes == tail && tail + uint32_t(record.len) <= 4u * sparseListCapacity(pd.nx, pd.ny)));
-                if(emitStream) writeStreakRecord(record, streamEnd - tail - uint32_t(record.len));
+                SHASTA_DEVICE_CHECK(!(emitStream & 1u) || (bytes == tail && tail + uint32_t(record.len) <= 4u * sparseListCapacity(pd.nx, pd.ny)));
+                if(emitStream & 1u) writeStreakRecord(record, streamEnd - tail - uint32_t(record.len));
                 bytes += uint64_t(record.len);
                 r.sumOffset = sumOffset; r.minOffset = minOffset; r.maxOffset = maxOffset; r.maxSkip = maxSkip; r.maxDrift = maxDrift;
                 r.first0 = uint32_t(laterX); r.first1 = uint32_t(laterY); r.last0 = uint32_t(lastX); r.last1 = uint32_t(lastY);
@@ -578,7 +580,7 @@ sparseChainWaveKernel(const PairDesc* __restrict__ pairs, const DpTask* __restri
             r.compressedBytes = uint32_t(bytes < 0xffffffffULL ? bytes : 0xffffffffULL);
             taskAcceptance(r, pd, task, opt, pairBest);
             results[t] = r;
-            state[t] = emitStream ? SPARSE_COMPLETE_STREAM : SPARSE_COMPLETE;
+            state[t] = (emitStream & 1u) ? SPARSE_COMPLETE_STREAM : SPARSE_COMPLETE;
         }
     }
     if(lane == 0 && walked) { atomicAdd(&control->hitsInBand, walked); atomicAdd(&control->hitsListed, listed); }

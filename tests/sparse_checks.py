@@ -348,3 +348,21 @@ def anchor_kernel_second_launch(lib, orc, alternatives=tie_policy_checks.ALTERNA
         with tie_policy_checks.policy(orc, alternative):
             compare([orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec], False)
     return cells["1"], cells["0"]
+
+
+def without_ordinals(lib, oracle_lib, n_reads=200, limit=1200):
+    """A call that does not ask for the ordinals (Assembler::computeAlignments stores AlignmentData and the compressed alignments only):
+    the wave kernel then does not write the aligned pairs of its tasks at all -- rows and compressed bytes must be what they are with them."""
+    toc, kmer, data7 = support.small_marker_set(n_reads=n_reads, genome_markers=12000, seed=31)
+    cand = oracle_lib.lowhash0(toc, data7, None, abi.default_lowhash0_params(minBucketSize=2, maxBucketSize=30)).candidates[:limit]
+    o = abi.default_align4_options(minAlignedMarkerCount=40)
+    x = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+    with lib.context(0) as ctx:
+        ctx.set_markers(toc, data7)
+        y = ctx.align4(cand, o, want_ordinals=False)
+        z = ctx.align4(cand, o, want_ordinals=True)
+    for r in (y, z):
+        assert np.array_equal(r.status & 0x7f, x.status & 0x7f) and np.array_equal(r.info_table(), x.info_table())
+        assert np.array_equal(r.compressed_toc, x.compressed_toc) and np.array_equal(r.compressed_data, x.compressed_data)
+    assert np.array_equal(z.ordinals, x.ordinals)
+    return int((x.status == abi.SHASTA_ALIGN_STORED).sum())

@@ -353,3 +353,8 @@ def test_every_candidate_through_the_windowed_kernels(emu_lib, oracle_lib, force
     from tests import long_read_checks
     monkeypatch.setenv("SHASTA_MI355X_ALIGN_WORKERS", "1")
     assert long_read_checks.forced(emu_lib, oracle_lib, None, force, n_reads=120, limit=400, adversarial_sets=False) >= 700
+
+
+def test_a_call_without_ordinals(emu_lib, oracle_lib):
+    from tests import sparse_checks
+    assert sparse_checks.without_ordinals(emu_lib, oracle_lib, n_reads=120, limit=400) >= 100

@@ -39,3 +39,7 @@ def test_the_anchor_kernel_second_launch(gpu_lib, oracle_lib):
     # one's task is left to the dense kernels, without it the last five.
     with_second, without = sparse_checks.anchor_kernel_second_launch(gpu_lib, oracle_lib)
     assert 0 < with_second < without
+
+
+def test_a_call_without_ordinals(gpu_lib, oracle_lib):
+    assert sparse_checks.without_ordinals(gpu_lib, oracle_lib) >= 300
