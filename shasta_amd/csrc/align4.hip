@@ -1336,7 +1336,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         std::vector<uint8_t> pairSlotsLog2;            //           ... and the table size the HBM-scratch kernel last ran it with
         std::vector<uint8_t> pairNoGrid;               //           ... and whether its cells were counted in the packed table because a byte of its grid overflowed
         uint32_t cellsMagicX = 0, cellsMagicY = 0;
+        uint32_t hostCounters[16];
         for(;;) {
+        bool flagsAndCountersCurrent = false;
         if(m3) {
             // Method 3, step 1: every diagonal of the down-sampled pair, then the band of step 2.
             std::vector<PairDesc> dsPairs(n);
@@ -1623,9 +1625,12 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 }
                 }
                 if(!any) break;
-                // Candidates that overflowed their tables climb one class.
+                // Candidates that overflowed their tables climb one class.  (The task counters come with the flags: if nothing climbs and nothing
+                // goes on to the HBM-scratch kernel, they are the batch's final ones -- one synchronisation instead of three.)
                 HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(hostCounters, b.counters.data(), sizeof(hostCounters), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
+                flagsAndCountersCurrent = true;
                 for(int c = 0; c < CELLS_CLASSES; c++) classChunks[c].clear();
                 bool retry = false;
                 uint64_t reasonHistogram[16] = {0};
@@ -1659,6 +1664,7 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     else addChunk(&k, 1, sw, c, pairNoGrid[k] != 0);
                 }
                 if(!retry) break;
+                flagsAndCountersCurrent = false;
                 if(debug) {
                     for(int c = 0; c < CELLS_CLASSES; c++) std::fprintf(stderr, "cells: round %d retries -> class %d: %zu\n", round, c, classChunks[c].size());
                     std::fprintf(stderr, "cells: round %d HBM-scratch list now %zu; reasons cell-table %llu kept-list %llu geometry %llu both %llu grid-byte %llu\n", round, bigList.size(),
@@ -1668,11 +1674,14 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 }
                 HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
             }
-            HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            if(!flagsAndCountersCurrent) {
+                HIP_CHECK(hipMemcpyAsync(hostFlags.data(), b.pairFlags.data(), n, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
             b.pairList.reserve(n, stream);
             const uint64_t scratchWordCap = 1ULL << 31;             // 8 GiB of HBM scratch per launch
             while(!bigList.empty()) {
+                flagsAndCountersCurrent = false;
                 // Clear the flags of the candidates about to be retried.
                 for(uint32_t k : bigList) hostFlags[k] = 0;
                 HIP_CHECK(hipMemcpyAsync(b.pairFlags.data(), hostFlags.data(), n, hipMemcpyHostToDevice, stream));
@@ -1718,10 +1727,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                 bigList.swap(nextList); bigLog2.swap(nextLog2);
             }
         }
-        {   // (one copy, one synchronisation for both counters)
-            uint32_t hostCounters[16];
-            HIP_CHECK(hipMemcpyAsync(hostCounters, b.counters.data(), sizeof(hostCounters), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+        {   // (one copy, one synchronisation for both counters -- unless they came with the flags)
+            if(!flagsAndCountersCurrent) {
+                HIP_CHECK(hipMemcpyAsync(hostCounters, b.counters.data(), sizeof(hostCounters), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
             taskCount = hostCounters[0];
             wideCount = hostCounters[CELLS_WIDE_COUNTER];      // (components / step-2 bands of more than 1024 diagonals, listed from the back)
         }

@@ -57,10 +57,25 @@ struct AnchorSharedT {
     uint32_t windowPairs[ANCHOR_MAX_WINDOWS], windowBegin[ANCHOR_MAX_WINDOWS];
 };
 using AnchorShared = AnchorSharedT<ANCHOR_MAX_CELLS, ANCHOR_MAX_SIDE, ANCHOR_MAX_PAIRS>;
-// The second launch: 64 KB of trace = 262 144 cells of the BAND at two bits (a rectangle that is most of a task -- a task with hardly any
-// anchor -- has a million cells, of which the band holds a tenth), sides of up to 3 071 markers, 4 096 pairs.
-constexpr int ANCHOR_BIG_CELLS = 65536, ANCHOR_BIG_SIDE = 3071, ANCHOR_BIG_PAIRS = 4096;
-using AnchorSharedBig = AnchorSharedT<ANCHOR_BIG_CELLS, ANCHOR_BIG_SIDE, ANCHOR_BIG_PAIRS, true>;
+// The second launch: 96 KB of trace = 393 216 cells of the BAND at two bits (a rectangle that is most of a task -- a task with hardly any
+// anchor -- has a million cells, of which the band holds a tenth), 8 192 pairs, and (round 6) sides of ANY length: the rows of H hold the
+// band's cells only (position = column - the band's lowest column in that row: 1 024 at most), the markers of read 1 under the band
+// slide through a ring, those of read 0 come a block of 64 rows at a time in a register, the last column's values are kept for the rows
+// whose band reaches it.  (Until then the rows were as long as the rectangle's side, 3 071 markers at most by the LDS: the one reason
+// left for a task of the 100 k-read workload to end in the dense kernels -- 26 a step, 16 ms of launches.)
+constexpr int ANCHOR_BIG_TRACE_BYTES = 96 * 1024, ANCHOR_BIG_BAND = 1024, ANCHOR_BIG_PAIRS = 8192, ANCHOR_BIG_RING = 2048;
+struct AnchorSharedBig {
+    static constexpr int maxCells = 4 * ANCHOR_BIG_TRACE_BYTES, maxSide = 0x7ffffff0, maxPairs = ANCHOR_BIG_PAIRS;
+    static constexpr bool bandTrace = true;
+    uint64_t live[ANCHOR_MAX_BITWORDS], anchor[ANCHOR_MAX_BITWORDS];
+    uint8_t trace[ANCHOR_BIG_TRACE_BYTES];       // two bits per cell of the band: [row * rowWords + position / 16]; 0 diagonal over different markers, 1 vertical, 2 horizontal, 3 diagonal over equal markers
+    int32_t row[2][ANCHOR_BIG_BAND + 2];         // H of the previous and of the current row, by position in the band (one more: "outside")
+    int32_t lastColumn[ANCHOR_BIG_BAND + 2];     // H(i, wy) of the rows whose band holds the last column, from the first of them on
+    uint32_t ring1[ANCHOR_BIG_RING];             // markers of read 1, [index & (ANCHOR_BIG_RING - 1)]: those under the band of the rows being computed
+    uint32_t pairs[ANCHOR_BIG_PAIRS];
+    int32_t windowFrom[ANCHOR_MAX_WINDOWS], windowTo[ANCHOR_MAX_WINDOWS];
+    uint32_t windowPairs[ANCHOR_MAX_WINDOWS], windowBegin[ANCHOR_MAX_WINDOWS];
+};
 static_assert(sizeof(AnchorSharedBig) <= 160 * 1024, "the second launch's LDS");
 
 __device__ __forceinline__ uint64_t bitsFrom(int b) { return b >= 64 ? 0ULL : ~0ULL << b; }       // bits b .. 63
@@ -187,64 +202,84 @@ __device__ int32_t anchorRectangle(Shared& sh, const uint32_t* __restrict__ p0, 
     return found;
 }
 
-// The same rectangle for the second launch: only the cells inside the band are computed (a row's chunks of 64 columns that the band
-// touches, one more column than it holds so that the cell behind its upper end reads as "outside" in the next row) and only they are
-// traced, two bits each at (row, column - the band's lower end in that row); whether a diagonal step aligns equal markers is read
-// from the markers when the path is walked.  Returns the number of aligned pairs, -1 (the pairs do not fit), -2 (the walk contradicts
-// the anchors) or -3 (the band's cells do not fit the trace).
+// The same rectangle for the second launch: only the cells inside the band are computed, a row's cells at their POSITION in the band
+// (position b of row i = column b + i + shift - bandMax: the cell above it has position b + 1 in its row, the one above and to the left
+// position b), and only they are traced, two bits each; a diagonal step over equal markers has a code of its own, so the walk reads
+// nothing but the trace.  Returns the number of aligned pairs, -1 (the pairs do not fit), -2 (the walk contradicts the anchors) or -3
+// (the band's cells do not fit the trace, or the band is wider than the rows).
 template<int TIE, class Shared>
 __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1,
     int32_t x0, int32_t x1, int32_t y0, int32_t y1, bool beginFixed, bool endFixed, int32_t bandMin, int32_t bandMax, uint32_t begin, int lane)
 {
     using Tie = DpTie<TIE>;
+    constexpr int EQUAL_DIAGONAL = 3;
+    static_assert(Tie::DIAGONAL == 0 && Tie::VERTICAL == 1 && Tie::HORIZONTAL == 2, "the fourth code is free");
     const int32_t wx = x1 - x0 + 1, wy = y1 - y0 + 1;
     const int32_t bandWidth = bandMax - bandMin + 1, rowWords = (bandWidth + 15) / 16;
     uint32_t* const traceWords = reinterpret_cast<uint32_t*>(sh.trace);
-    if(int64_t(wx + 1) * rowWords > int64_t(Shared::maxCells / 4)) return -3;
-    for(int32_t a = lane; a < wx; a += WAVE) sh.kmers0[a] = p0[x0 + a];
-    for(int32_t a = lane; a < wy; a += WAVE) sh.kmers1[a] = p1[y0 + a];
+    if(bandWidth > ANCHOR_BIG_BAND || int64_t(wx + 1) * rowWords > int64_t(Shared::maxCells / 16)) return -3;
     for(int32_t a = lane; a < (wx + 1) * rowWords; a += WAVE) traceWords[a] = 0;
     const int32_t shift = x0 - y0;
-    auto jLow = [&](int32_t i) { return max(0, i + shift - bandMax); };
-    auto jHigh = [&](int32_t i) { return min(wy, i + shift - bandMin); };
     auto bandBase = [&](int32_t i) { return i + shift - bandMax; };                  // the column of the band's lowest diagonal in row i (may be negative)
-    auto putMove = [&](int32_t i, int32_t j, int move) {
-        const int32_t b = j - bandBase(i);
-        atomicOr(&traceWords[i * rowWords + (b >> 4)], uint32_t(move) << (2 * (b & 15)));
-    };
+    auto jLow = [&](int32_t i) { return max(0, bandBase(i)); };
+    auto jHigh = [&](int32_t i) { return min(wy, i + shift - bandMin); };
+    auto putMove = [&](int32_t i, int32_t b, int move) { atomicOr(&traceWords[i * rowWords + (b >> 4)], uint32_t(move) << (2 * (b & 15))); };
+    // The rows whose band holds the last column: iFirst .. iFirst + bandWidth - 1.
+    const int32_t iFirst = max(0, wy - shift + bandMin);
+    for(int32_t a = lane; a < ANCHOR_BIG_BAND + 2; a += WAVE) sh.lastColumn[a] = ANCHOR_NEG;
+    // Markers of read 1 (column j compares kmers1[j - 1]) into the ring: what the first 128 rows can touch now, 64 more at the head of
+    // every block of 64 rows, loaded a block ahead.
+    auto ringStore = [&](int32_t index, uint32_t value) { sh.ring1[uint32_t(index) & uint32_t(ANCHOR_BIG_RING - 1)] = value; };
+    int32_t ringLoaded = max(0, jLow(1) - 1);                                    // markers [.., ringLoaded) are in the ring (or below every row's band)
+    {
+        const int32_t until = min(wy, jHigh(min(wx, 128)));
+        for(int32_t a = ringLoaded + lane; a < until; a += WAVE) ringStore(a, p1[y0 + a]);
+        ringLoaded = max(ringLoaded, until);
+    }
+    int32_t pendingIndex = -1;
+    uint32_t pendingValue = 0;
+    // Markers of read 0: the block of 64 rows in hand in a register, the next one on its way.
+    uint32_t block0 = p0[x0 + min(lane, wx - 1)], block0Next = p0[x0 + min(WAVE + lane, wx - 1)];
     waveLdsSync();
     {
-        const int32_t lo = jLow(0), hi = jHigh(0);
-        for(int32_t j = lane; j <= wy; j += WAVE) {
-            const bool in = j >= lo && j <= hi;
-            sh.row[0][j] = !in ? ANCHOR_NEG : (beginFixed ? -j : 0);
-            if(in) putMove(0, j, Tie::VERTICAL);
+        for(int32_t b = lane; b <= bandWidth; b += WAVE) {
+            const int32_t j = b + bandBase(0);
+            const bool in = b < bandWidth && j >= 0 && j <= wy;
+            sh.row[0][b] = !in ? ANCHOR_NEG : (beginFixed ? -j : 0);
+            if(in) putMove(0, b, Tie::VERTICAL);
+            if(in && j == wy && iFirst == 0) sh.lastColumn[0] = beginFixed ? -wy : 0;
         }
-        if(lane == 0) sh.lastColumn[0] = (wy >= lo && wy <= hi) ? (beginFixed ? -wy : 0) : ANCHOR_NEG;
     }
     waveLdsSync();
+    const int32_t chunks = (bandWidth + WAVE) / WAVE;                             // (position bandWidth included: it is written "outside" for the row below)
     for(int32_t i = 1; i <= wx; i++) {
+        if(((i - 1) & (WAVE - 1)) == 0 && i > 1) {
+            // A new block of 64 rows: its markers of read 0 become the block in hand, the ring takes what was asked for a block ago, and
+            // the next 64 markers of either read are asked for.
+            block0 = block0Next;
+            block0Next = p0[x0 + min(i - 1 + WAVE + lane, wx - 1)];
+            if(pendingIndex >= 0) ringStore(pendingIndex, pendingValue);
+            pendingIndex = (ringLoaded + lane < wy) ? ringLoaded + lane : -1;
+            pendingValue = p1[y0 + min(ringLoaded + lane, wy - 1)];
+            ringLoaded = min(wy, ringLoaded + WAVE);
+            waveLdsSync();
+        }
         const int32_t* const previous = sh.row[(i - 1) & 1];
         int32_t* const current = sh.row[i & 1];
-        const int32_t lo = jLow(i), hi = jHigh(i);
-        const uint32_t k0 = sh.kmers0[i - 1];
+        const int32_t lo = jLow(i), hi = jHigh(i), base = bandBase(i);
+        const uint32_t k0 = __builtin_amdgcn_readlane(block0, (i - 1) & (WAVE - 1));
         int32_t carry = 2 * ANCHOR_NEG;                     // the largest c(j') + j' of the chunks before
-        const int32_t firstBase = (lo / WAVE) * WAVE, lastColumnVisited = min(wy, hi + 1);
-        // (a row the band does not touch at all -- beyond the shorter side of a rectangle that ends at the free border -- or does not
-        // reach the last column in: H(i, wy) is "outside")
-        if(lane == 0 && (lo > hi || lastColumnVisited < wy)) sh.lastColumn[i] = ANCHOR_NEG;
-        if(lo > hi) continue;
-        for(int32_t jBase = firstBase; jBase <= lastColumnVisited; jBase += WAVE) {
-            const int32_t j = jBase + lane;
-            const bool in = j >= lo && j <= hi;
+        for(int32_t chunk = 0; chunk < chunks; chunk++) {
+            const int32_t b = chunk * WAVE + lane, j = b + base;
+            const bool in = b < bandWidth && j >= lo && j <= hi;
             int32_t diagonal = ANCHOR_NEG, horizontal = ANCHOR_NEG;
             bool equal = false;
-            if(in && j <= wy) {
-                const int32_t h0 = previous[j];
+            if(in) {
+                const int32_t h0 = previous[b + 1];                                 // H(i - 1, j)
                 horizontal = h0 <= ANCHOR_NEG ? ANCHOR_NEG : h0 - 1;
                 if(j > 0) {
-                    const int32_t d0 = previous[j - 1];
-                    equal = k0 == sh.kmers1[j - 1];
+                    const int32_t d0 = previous[b];                                 // H(i - 1, j - 1)
+                    equal = k0 == sh.ring1[uint32_t(j - 1) & uint32_t(ANCHOR_BIG_RING - 1)];
                     diagonal = d0 <= ANCHOR_NEG ? ANCHOR_NEG : d0 + (equal ? MATCH_SCORE : MISMATCH_SCORE);
                 }
                 else if(!beginFixed) horizontal = 0;        // the free border: H(i, 0) = 0
@@ -253,9 +288,9 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
             const int32_t scanned = max(waveMaxScan(c + j, lane), carry);
             carry = __shfl(scanned, WAVE - 1, WAVE);
             int32_t h = scanned - j;
-            if(!in || j > wy || h <= ANCHOR_NEG / 2) h = ANCHOR_NEG;
+            if(!in || h <= ANCHOR_NEG / 2) h = ANCHOR_NEG;
             int32_t left = __shfl_up(h, 1, WAVE);            // H(i, j - 1)
-            if(lane == 0) left = jBase > firstBase ? current[jBase - 1] : ANCHOR_NEG;     // (before the first chunk the row is outside the band)
+            if(lane == 0) left = chunk > 0 ? current[b - 1] : ANCHOR_NEG;          // (before the band's first position the row is outside)
             const int32_t vertical = (j == 0 || left <= ANCHOR_NEG) ? ANCHOR_NEG : left - 1;
             int move;
             if(j == 0) move = Tie::HORIZONTAL;
@@ -264,34 +299,35 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
                 attains[Tie::DIAGONAL] = diagonal == h; attains[Tie::VERTICAL] = vertical == h; attains[Tie::HORIZONTAL] = horizontal == h;
                 move = attains[Tie::first] ? Tie::first : (attains[Tie::second] ? Tie::second : Tie::third);
             }
-            if(j <= wy) {
-                current[j] = h;
-                if(in) putMove(i, j, move);
-                if(j == wy) sh.lastColumn[i] = h;
+            if(b <= bandWidth) {
+                current[b] = h;
+                if(in) putMove(i, b, (move == Tie::DIAGONAL && equal) ? EQUAL_DIAGONAL : move);
+                if(in && j == wy && i >= iFirst && i - iFirst <= ANCHOR_BIG_BAND + 1) sh.lastColumn[i - iFirst] = h;
             }
-            waveLdsSync();                                   // (lane 0 of the next chunk reads current[jBase - 1])
+            waveLdsSync();                                   // (lane 0 of the next chunk reads current[b - 1])
         }
     }
-    waveLdsSync();                                           // (rows the band does not touch end without one; the end cells are read by all lanes)
+    waveLdsSync();                                           // (the end cells are read by all lanes)
     int32_t i = wx, j = wy;
     const bool cornerInBand = wy >= jLow(wx) && wy <= jHigh(wx);
-    if(endFixed && (!cornerInBand || sh.row[wx & 1][wy] <= ANCHOR_NEG)) {
+    const int32_t* const last = sh.row[wx & 1];
+    if(endFixed && (!cornerInBand || last[wy - bandBase(wx)] <= ANCHOR_NEG)) {
 #ifdef ANCHOR_DEBUG
-        if(lane == 0) std::fprintf(stderr, "band rectangle: end corner unreachable: wx %d wy %d shift %d band [%d, %d] cornerInBand %d value %d beginFixed %d\n", wx, wy, shift, bandMin, bandMax, int(cornerInBand), sh.row[wx & 1][wy], int(beginFixed));
+        if(lane == 0) std::fprintf(stderr, "band rectangle: end corner unreachable: wx %d wy %d shift %d band [%d, %d] cornerInBand %d beginFixed %d\n", wx, wy, shift, bandMin, bandMax, int(cornerInBand), int(beginFixed));
 #endif
         return -2;
     }
     if(!endFixed) {
-        const int32_t* const last = sh.row[wx & 1];
-        const int32_t total = wx + wy + 1;
+        // The border cells in the order the dense DP scans them -- (0, wy) ... (wx - 1, wy), then (wx, 0) ... (wx, wy) -- and the first or
+        // the last of those with the largest score: the last column's cells the band holds, then the last row's.
         const int32_t lastLo = jLow(wx), lastHi = jHigh(wx);
         int32_t bestScore = ANCHOR_NEG, bestAt = Tie::lastMaximum ? -1 : 0x7fffffff;
-        for(int32_t a = lane; a < total; a += WAVE) {
-            // (the last row's buffer holds this row's values only where the band is)
-            const int32_t score = a < wx ? sh.lastColumn[a] : ((a - wx >= lastLo && a - wx <= lastHi) ? last[a - wx] : ANCHOR_NEG);
-            if(score <= ANCHOR_NEG) continue;
+        auto take = [&](int32_t score, int32_t a) {
+            if(score <= ANCHOR_NEG) return;
             if(score > bestScore || (score == bestScore && (Tie::lastMaximum ? a > bestAt : a < bestAt))) { bestScore = score; bestAt = a; }
-        }
+        };
+        for(int32_t a = iFirst + lane; a < wx && a - iFirst <= ANCHOR_BIG_BAND + 1; a += WAVE) take(sh.lastColumn[a - iFirst], a);
+        for(int32_t column = lastLo + lane; column <= lastHi; column += WAVE) take(last[column - bandBase(wx)], wx + column);
 #pragma unroll
         for(int d = 32; d >= 1; d >>= 1) {
             const int32_t otherScore = __shfl_xor(bestScore, d, WAVE), otherAt = __shfl_xor(bestAt, d, WAVE);
@@ -312,9 +348,9 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
             return -2;               // (the walk left the band: it cannot)
         }
         const int move = int((traceWords[i * rowWords + (b >> 4)] >> (2 * (b & 15))) & 3u);
-        if(move == Tie::DIAGONAL) {
+        if(move == Tie::DIAGONAL || move == EQUAL_DIAGONAL) {
             --i; --j;
-            if(sh.kmers0[i] == sh.kmers1[j]) {
+            if(move == EQUAL_DIAGONAL) {
                 if(begin + uint32_t(found) >= uint32_t(Shared::maxPairs)) return -1;
                 if(lane == 0) sh.pairs[begin + uint32_t(found)] = (uint32_t(x0 + i) << 16) | uint32_t(y0 + j);
                 ++found;

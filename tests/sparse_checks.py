@@ -296,11 +296,12 @@ def wave_kernel_forms(lib, orc):
     return compared
 
 
-def inverted_block_tasks(blocks=(20, 70, 71, 120, 300, 3200), flank=220, seed=17):
+def inverted_block_tasks(blocks=(20, 70, 71, 120, 300, 3200, 4000, 6000), flank=220, seed=17):
     """Two reads that agree except for one block of m markers which the second read has in REVERSED order: every chain can take one
     match of the block, the two in its middle tie (m even) -- two optimal chains, and between the anchors before and behind the block
     a rectangle of (m + 1)^2 cells: within the anchor kernel's first launch (4 096 cells) for m = 20, its second (the band's cells at
-    two bits each, sides of up to 3 071 markers) for 70 to 300, beyond both for 3 200 (the dense kernels)."""
+    two bits each -- 393 216 of them; sides of any length since round 6: 3 071 markers at most before) for 70 to 4 000, beyond both
+    for 6 000 (486 000 cells of the band: the dense kernels)."""
     rng = np.random.default_rng(seed)
     pieces, spec, at = [], [], 0
     for m in blocks:
@@ -313,16 +314,19 @@ def inverted_block_tasks(blocks=(20, 70, 71, 120, 300, 3200), flank=220, seed=17
     # Rectangles that end at the FREE border, too large for the first launch: the second read stops (or begins) inside the first one
     # with its last (first) matching marker doubled -- two optimal ends -- and a few markers of its own beyond, so that the window
     # between the last anchor and the border is 600 markers of the first read by 20 of the second, nearly all of it outside the band.
-    for where in ("end", "begin"):
-        g = rng.permutation(1 << 20)[:1300].astype(np.uint32)
+    # (... of 600 markers, and -- round 6: sides beyond 3 071 markers -- of 4 600 and 4 400: the free border on either side of a long read.)
+    for where, total in (("end", 1300), ("begin", 1300), ("end", 5300), ("begin", 5000)):
+        g = rng.permutation(1 << 20)[:total].astype(np.uint32)
         own = rng.permutation(1 << 20)[:20].astype(np.uint32) + np.uint32(1 << 21)          # (ids the other read does not hold)
         a = g
         if where == "end":
             b = np.concatenate([g[400:700], g[699:700], own])
+            diagonal = 400
         else:
-            b = np.concatenate([own, g[600:601], g[600:900]])
+            first = total - 700                                                               # (the second read begins this far into the first)
+            b = np.concatenate([own, g[first:first + 1], g[first:first + 300]])
+            diagonal = first - 21
         pieces += [a, b]
-        diagonal = 400 if where == "end" else 600 - 21
         spec.append((at, len(a), at + len(a), len(b), diagonal - 30, diagonal + 30))
         at += len(a) + len(b)
     return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
