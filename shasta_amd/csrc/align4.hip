@@ -996,6 +996,13 @@ uint64_t runDpTasks(Context& ctx, const WorkStream& ws, BatchScratch& b, uint32_
                 (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
                 (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data()));
         HIP_CHECK(hipGetLastError());
+        // ... and the long paths, a wavefront each (the tasks of DP_TRACEBACK_LONG iterations and more: the others' wavefronts leave at once).
+        SHASTA_TIMED(ctx, "dpTracebackWaveKernel", stream, 0, f.denseCount,
+            hipLaunchKernelGGL(dpTracebackWaveKernel, dim3(f.denseCount), dim3(64), 0, stream,
+                in.pairs, in.tasks, f.sortedIds, f.denseCount,
+                (const DpEnd*)b.ends.data(), (const uint64_t*)b.trace.data(),
+                (const uint64_t*)b.ordCap.data(), b.ordScratch.data(), b.results.data()));
+        HIP_CHECK(hipGetLastError());
     }
     uint64_t wideCells = 0;
     if(wideCount) runWideTasks(ctx, ws, b, in, taskCount, *wide, *hostPairs, f.ordTotal, wideCells);

@@ -716,6 +716,10 @@ __device__ __forceinline__ void taskAcceptance(DpResult& r, const PairDesc& pd, 
 
 // Tasks [taskBegin, taskEnd) of the sorted list, all of a class with C diagonals per lane (C = 2 or 4).
 constexpr int DP_TRACE_CHUNK_QUADS = 16;                    // 16-byte pieces of a 256-byte chunk: {low plane, high plane} of one diagonal of one iteration
+// (round 6) From this many iterations on a task's path is walked by a WAVEFRONT of its own (dpTracebackWaveKernel): the lane kernel has one
+// chunk of the trace in flight per lane -- one or two iterations of a wide band -- and a launch lasts as long as its longest path at a
+// memory latency every chunk: 13 ms for the 30 000-iteration tasks of the ultra-long shape, 172 ms of 700 per step.
+constexpr uint32_t DP_TRACEBACK_LONG = 2048;
 __global__ void __launch_bounds__(256)
 dpTracebackKernel(
     const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskBegin, uint32_t taskEnd,
@@ -741,6 +745,7 @@ dpTracebackKernel(
     const uint64_t ordBase = ordOffsets[t];
     uint32_t pos = min(pd.nx, pd.ny);                      // aligned pairs are stored from the end of the task's range downwards
     int32_t i = e.bestI, j = e.bestJ;
+    if(geo.iters >= DP_TRACEBACK_LONG) return;             // (a long path: dpTracebackWaveKernel's, result included)
     // Epochs: every lane moves its prefetched chunk into the window and prefetches the next one at
     // the same point of the program, then walks until its path leaves the chunk.  The wave waits
     // for memory once per epoch, for loads issued a whole epoch earlier.
@@ -791,4 +796,94 @@ dpTracebackKernel(
     }
     storeFound();
     tracebackFinish(pos, pd, e, ordBase, t, results);
+}
+
+// The walk of a LONG path (DP_TRACEBACK_LONG iterations and more): one wavefront per task.  The trace goes through LDS in blocks of 32
+// chunks (8 KB), the block under the path in one half of a ring, the block below it asked for -- 64 lanes x 8 loads, all in flight at once --
+// when the walk enters the one above: by the time the walk gets there the data has been in registers for a whole block.  Every lane walks (the
+// same LDS words for all: broadcast reads), lane 0 notes the aligned pairs in LDS, the wavefront stores them together.  Same decisions, same
+// output as dpTracebackKernel, which leaves these tasks alone.
+constexpr int DP_WAVE_BLOCK_CHUNKS = 32, DP_WAVE_FOUND = 512;
+__global__ void __launch_bounds__(64)
+dpTracebackWaveKernel(
+    const PairDesc* __restrict__ pairs, const DpTask* __restrict__ tasks, const uint32_t* __restrict__ sortedIds, uint32_t taskCount,
+    const DpEnd* __restrict__ ends, const uint64_t* __restrict__ trace,
+    const uint64_t* __restrict__ ordOffsets, uint32_t* __restrict__ ordScratch, DpResult* __restrict__ results)
+{
+    constexpr int QUADS = DP_TRACE_CHUNK_QUADS, BLOCK_QUADS = DP_WAVE_BLOCK_CHUNKS * QUADS, PER_LANE = BLOCK_QUADS / WAVE;
+    __shared__ uint4 ring[2][BLOCK_QUADS];
+    __shared__ uint2 found[DP_WAVE_FOUND];
+    const uint32_t k = blockIdx.x;
+    if(k >= taskCount) return;
+    const int lane = laneId();
+    const uint32_t t = sortedIds[taskCount - 1 - k];
+    const DpTask task = tasks[t];
+    const PairDesc pd = pairs[task.pair];
+    const DpGeometry geo = dpGeometry(task.bandMin, task.bandMax, pd.nx, pd.ny);
+    if(geo.iters < DP_TRACEBACK_LONG) return;              // (dpTracebackKernel's)
+    const DpEnd e = ends[t];
+    const int cLog2 = dpDiagonalsLog2(geo.cls);
+    const uint32_t cMask = (1u << cLog2) - 1u;
+    const int ipcLog2 = 4 - cLog2;                         // QUADS / C iterations per chunk
+    const uint32_t ipcMask = (1u << ipcLog2) - 1u;
+    const uint4* __restrict__ tr = reinterpret_cast<const uint4*>(trace + e.traceOffset);
+    const int64_t lastQuad = (int64_t((e.bundleIterations - 1u) >> ipcLog2) + 1) * QUADS - 1;       // the bundle's trace ends here
+    const uint64_t ordBase = ordOffsets[t];
+    uint32_t pos = min(pd.nx, pd.ny);                      // aligned pairs are stored from the end of the task's range downwards
+    int32_t i = e.bestI, j = e.bestJ;
+    uint32_t foundCount = 0;
+    auto storeFound = [&]() {
+        waveLdsSync();
+        for(uint32_t q = uint32_t(lane); q < foundCount; q += WAVE) *reinterpret_cast<uint2*>(ordScratch + 2 * (ordBase + pos - 1u - q)) = found[q];
+        pos -= foundCount; foundCount = 0;
+        waveLdsSync();
+    };
+    if(e.score > NEG_SCORE && i > 0 && j > 0) {
+        auto blockOf = [&](int32_t ii, int32_t jj) { return int32_t(((uint32_t(ii + jj - geo.s0) >> 1) >> ipcLog2) / uint32_t(DP_WAVE_BLOCK_CHUNKS)); };
+        uint4 ahead[PER_LANE];
+        auto loadBlock = [&](int32_t block) {
+#pragma unroll
+            for(int a = 0; a < PER_LANE; a++) ahead[a] = tr[min(int64_t(block) * BLOCK_QUADS + a * WAVE + lane, lastQuad)];
+        };
+        auto keepBlock = [&](int32_t block) {
+#pragma unroll
+            for(int a = 0; a < PER_LANE; a++) ring[block & 1][a * WAVE + lane] = ahead[a];
+        };
+        int32_t block = blockOf(i, j);
+        loadBlock(block); keepBlock(block);
+        if(block > 0) loadBlock(block - 1);
+        waveLdsSync();
+        for(;;) {
+            // The walk inside the block.
+            const uint32_t* const words = reinterpret_cast<const uint32_t*>(ring[block & 1]);
+            bool done = false;
+            for(;;) {
+                const uint32_t b = uint32_t(i - j - task.bandMin);
+                const uint32_t it = uint32_t(i + j - geo.s0) >> 1;
+                const uint32_t chunk = it >> ipcLog2;
+                if(int32_t(chunk / uint32_t(DP_WAVE_BLOCK_CHUNKS)) != block) break;
+                const uint32_t bit = e.laneBase + (b >> cLog2);
+                const uint32_t piece = (chunk % uint32_t(DP_WAVE_BLOCK_CHUNKS)) * QUADS + ((it & ipcMask) << cLog2) + (b & cMask);
+                // The piece is {low plane: bits 0-31, 32-63; high plane: bits 0-31, 32-63}: the two dwords that hold bit `bit`.
+                const uint32_t lo = words[4u * piece + ((bit >> 5) & 1u)], hi = words[4u * piece + 2u + ((bit >> 5) & 1u)];
+                const uint32_t dir = ((lo >> (bit & 31u)) & 1u) | (((hi >> (bit & 31u)) & 1u) << 1);
+                // A diagonal step over equal kmers: an aligned marker pair (src/Align4.cpp:1057-1061).
+                if(dir == 0u) {
+                    if(lane == 0) found[foundCount] = make_uint2(uint32_t(i - 1), uint32_t(j - 1));
+                    if(++foundCount == uint32_t(DP_WAVE_FOUND)) storeFound();
+                }
+                i -= (dir != 2u) ? 1 : 0;
+                j -= (dir != 3u) ? 1 : 0;
+                if(!(i > 0 && j > 0)) { done = true; break; }
+            }
+            if(done || block == 0) break;
+            // Into the block below: what was asked for a block ago goes into the other half of the ring, the block below that is asked for.
+            --block;
+            keepBlock(block);
+            if(block > 0) loadBlock(block - 1);
+            waveLdsSync();
+        }
+    }
+    storeFound();
+    if(lane == 0) tracebackFinish(pos, pd, e, ordBase, t, results);
 }

@@ -370,3 +370,32 @@ def without_ordinals(lib, oracle_lib, n_reads=200, limit=1200):
         assert np.array_equal(r.compressed_toc, x.compressed_toc) and np.array_equal(r.compressed_data, x.compressed_data)
     assert np.array_equal(z.ordinals, x.ordinals)
     return int((x.status == abi.SHASTA_ALIGN_STORED).sum())
+
+
+def long_dense_paths(lib, orc, seed=91):
+    """Tasks of 2 048 iterations and more with the sparse path OFF: the dense forward kernel of every band class, then the walk of a
+    wavefront per task (dpTracebackWaveKernel: the trace through LDS in blocks of 32 chunks) -- paths that end at either border, small
+    alphabets (ties), bundles of several such tasks."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+    for width in (20, 40, 64, 80, 128, 250, 500, 1000, 30, 300):
+        for alphabet in ((1 << 20), 12):
+            n = int(rng.integers(3600, 4400))
+            genome = rng.integers(0, alphabet, size=2 * n + 600, dtype=np.uint32)
+            off = int(rng.integers(0, 400))
+            a = dp_geometry_checks.noisy(rng, genome[:n], alphabet)
+            b = dp_geometry_checks.noisy(rng, genome[off:off + int(rng.integers(3 * n // 4, n + 1))], alphabet)
+            if width in (40, 250):
+                a, b, off = b, a, -off
+            lo = off - width // 2 + int(rng.integers(-6, 6))
+            pieces += [a, b]
+            spec.append((at, len(a), at + len(a), len(b), lo, lo + width - 1))
+            at += len(a) + len(b)
+    kmer, spec = np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+    want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
+    with switched_off():
+        got = _run(lib, kmer, spec)
+    for (x, sx), (y, sy) in zip(want, got):
+        assert sx == sy and np.array_equal(x, y)
+    assert all(int(nx) + int(ny) >= 4300 for _, nx, _, ny, _, _ in spec), [int(nx) + int(ny) for _, nx, _, ny, _, _ in spec]
+    return len(spec)

@@ -358,3 +358,8 @@ def test_every_candidate_through_the_windowed_kernels(emu_lib, oracle_lib, force
 def test_a_call_without_ordinals(emu_lib, oracle_lib):
     from tests import sparse_checks
     assert sparse_checks.without_ordinals(emu_lib, oracle_lib, n_reads=120, limit=400) >= 100
+
+
+def test_long_dense_paths(emu_lib, oracle_lib):
+    from tests import sparse_checks
+    assert sparse_checks.long_dense_paths(emu_lib, oracle_lib) == 20

@@ -43,3 +43,7 @@ def test_the_anchor_kernel_second_launch(gpu_lib, oracle_lib):
 
 def test_a_call_without_ordinals(gpu_lib, oracle_lib):
     assert sparse_checks.without_ordinals(gpu_lib, oracle_lib) >= 300
+
+
+def test_long_dense_paths(gpu_lib, oracle_lib):
+    assert sparse_checks.long_dense_paths(gpu_lib, oracle_lib) == 20
