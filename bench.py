@@ -580,7 +580,8 @@ def main():
             "data": "synthetic" if not DRY_RUN_LIBRARY else "synthetic; DRY RUN ON THE EMULATED BUILD - NOT A MEASUREMENT",
             "config": {"workload": "BASELINE configs[2] shape, %d reads/GPU, one job over %d devices in ONE process (shasta_mi355x_group)" % (args.reads, n),
                        "reads_per_gpu": args.reads, "markers_total": int(toc[-1]), "candidates": g["candidates"], "alignments_stored": g["alignments_stored"],
-                       "parallelism": "%d GPUs, in-process group: device-to-device pulls over xGMI, no RCCL" % n},
+                       "parallelism": "%d GPUs, in-process group: `value` with device-to-device pulls over xGMI%s" % (
+                           n, "; in_process_group_over_rccl = the same job with the exchanges as grouped ncclSend / ncclRecv" if g_rccl is not None else "")},
             "in_process_group": g, "in_process_group_over_rccl": g_rccl, "hbm_budget_per_gpu": hbm_budget(int(toc[-1]), args.reads * n, n)}))
         return
 

@@ -177,6 +177,10 @@ const char* shasta_mi355x_last_error(void);
 const char* shasta_mi355x_version(void);
 /* Number of usable gfx950 devices (0 if none; never throws). */
 int shasta_mi355x_device_count(void);
+/* What in the process's environment costs the library speed, as bits (0: nothing): bit 0 = GPU_MAX_HW_QUEUES is not set -- the HIP
+ * runtime then deals the aligner's streams to four hardware queues and a call of the second seam is about 15 % slower (set it to 8 before
+ * the process's first HIP call).  The library says the same once on stderr when a context or a group is created. */
+int shasta_mi355x_environment_warnings(void);
 
 /* ------------------------------------------------------------------------- */
 /* One-shot, host-pointer seams (what the C++ adapter calls)                  */

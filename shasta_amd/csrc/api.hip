@@ -41,6 +41,10 @@ extern "C" {
 const char* shasta_mi355x_last_error(void) { return lastError.c_str(); }
 const char* shasta_mi355x_version(void) { return "shasta_mi355x 0.1 (gfx950)"; }
 
+// What in the process's environment costs the library speed (the stderr note of noteHardwareQueuesOnce, as a value an integrator can test):
+// bit 0: GPU_MAX_HW_QUEUES is not set (the aligner's streams share four hardware queues: about 15 % slower).
+int shasta_mi355x_environment_warnings(void) { return std::getenv("GPU_MAX_HW_QUEUES") ? 0 : 1; }
+
 int shasta_mi355x_device_count(void)
 {
     int n = 0;
@@ -466,6 +470,7 @@ int shasta_mi355x_read_graph_keep(int device, const shasta_alignment_data* align
 shasta_mi355x_group* shasta_mi355x_group_create(int deviceCount, const int* devices)
 {
     API_BEGIN
+    noteHardwareQueuesOnce();
     return new shasta_mi355x_group(deviceCount, devices);
     API_END(nullptr)
 }

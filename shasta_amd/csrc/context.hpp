@@ -78,6 +78,7 @@ struct Group {
     // ncclSend / ncclRecv over xGMI.  Created at the first call that asks for it; empty: the peer-copy transport.
     std::vector<void*> rcclCommunicators;
     bool rcclTried = false;
+    std::atomic<bool> rcclAborted{false};      // a rank's RCCL call failed and the communicators were aborted (multi.hip)
     // The concatenated result of a borrowed call over several devices.
     std::vector<shasta_alignment_data> storeRows;
     std::vector<uint64_t> storeToc, storeOrdinalsToc;

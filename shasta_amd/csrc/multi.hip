@@ -94,6 +94,7 @@ struct RcclApi {
     void* handle = nullptr;
     int (*commInitAll)(void**, int, const int*) = nullptr;
     int (*commDestroy)(void*) = nullptr;
+    int (*commAbort)(void*) = nullptr;
     int (*groupStart)() = nullptr;
     int (*groupEnd)() = nullptr;
     int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -109,6 +110,7 @@ const RcclApi& rcclApi()
         if(!a.handle) return a;
         a.commInitAll = reinterpret_cast<decltype(a.commInitAll)>(dlsym(a.handle, "ncclCommInitAll"));
         a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+        a.commAbort = reinterpret_cast<decltype(a.commAbort)>(dlsym(a.handle, "ncclCommAbort"));
         a.groupStart = reinterpret_cast<decltype(a.groupStart)>(dlsym(a.handle, "ncclGroupStart"));
         a.groupEnd = reinterpret_cast<decltype(a.groupEnd)>(dlsym(a.handle, "ncclGroupEnd"));
         a.send = reinterpret_cast<decltype(a.send)>(dlsym(a.handle, "ncclSend"));
@@ -133,7 +135,11 @@ bool stagedWithOneDevice() { const char* e = std::getenv("SHASTA_MI355X_GROUP_ST
 bool ensureRccl(Group& group)
 {
     if(!group.rcclCommunicators.empty()) return true;
-    if(group.rcclTried) return false;
+    if(group.rcclTried) {
+        // (an earlier call could not make the communicators, or one of its exchanges failed and they were aborted: said at every call, not once)
+        std::fprintf(stderr, "shasta_mi355x group: SHASTA_MI355X_GROUP_TRANSPORT=rccl, but RCCL failed in an earlier call of this group; the exchanges are device-to-device copies\n");
+        return false;
+    }
     group.rcclTried = true;
     const RcclApi& api = rcclApi();
     std::vector<int> devices;
@@ -241,6 +247,7 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
     uint64_t highFrequencyShared = 0;
     double deviceSeconds = 0;
 
+    try {
     onEveryDevice(world, barrier, [&](int rank) {
         Context& ctx = *contexts[size_t(rank)];
         Rank& me = rankOf(rank);
@@ -264,6 +271,14 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
                     const RcclApi& api = rcclApi();
                     void* const communicator = rcclCommunicators[size_t(rank)];
                     const char* const mine = static_cast<const char*>(which == 0 ? me.out0 : me.out1);
+                    // A rank whose RCCL call fails aborts EVERY communicator of the group before it throws: the other ranks, which would
+                    // wait in ncclGroupEnd or in their streams for a peer that never comes, get an error from their own calls instead and
+                    // throw too (the call ends with the first rank's message; the group's later calls use the peer copies and say so).
+                    auto rcclCheck = [&](int code, const char* what) {
+                        if(code == 0) return;
+                        if(api.commAbort && !rcclAborted.exchange(true)) for(void* c : rcclCommunicators) if(c) (void)api.commAbort(c);
+                        throw std::runtime_error(std::string("RCCL error in ") + what + ": " + (api.errorString ? api.errorString(code) : std::to_string(code).c_str()));
+                    };
                     rcclCheck(api.groupStart(), "ncclGroupStart");
                     for(int d = 0; d < world; d++) {
                         const uint64_t begin = me.offsets[size_t(d)], count = me.offsets[size_t(d) + 1] - begin;
@@ -380,6 +395,10 @@ void Group::lowhash0Run(const shasta_lowhash0_params& p, uint64_t* readLowHashSt
         HIP_CHECK(hipStreamSynchronize(stream));
         if(rank == 0) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, evBegin, evEnd)); deviceSeconds = ms * 1e-3; }
     });
+    } catch(...) {
+        if(rcclAborted.load()) rcclCommunicators.clear();        // (aborted communicators are gone: the destructor must not destroy them, later calls use the peer copies)
+        throw;
+    }
 
     // Reductions and assembly, in rank order (each device's candidates are sorted and cover its readId0 range:
     // their concatenation is the reference's order).

@@ -16,7 +16,7 @@ SO_PATH = os.path.join(HERE, "_build", "libshasta_mi355x.so")
 
 # Every symbol include/shasta_mi355x.h declares.
 EXPORTS = [
-    "shasta_mi355x_last_error", "shasta_mi355x_version", "shasta_mi355x_device_count",
+    "shasta_mi355x_last_error", "shasta_mi355x_version", "shasta_mi355x_device_count", "shasta_mi355x_environment_warnings",
     "shasta_mi355x_lowhash0", "shasta_mi355x_lowhash0_free",
     "shasta_mi355x_align4_batch", "shasta_mi355x_align4_free",
     "shasta_mi355x_create", "shasta_mi355x_destroy",
@@ -72,6 +72,10 @@ class Library:
 
     def device_count(self):
         return int(self.lib.shasta_mi355x_device_count())
+
+    def environment_warnings(self):
+        """Bits: 1 = GPU_MAX_HW_QUEUES unset (the aligner about 15 % slower)."""
+        return int(self.lib.shasta_mi355x_environment_warnings())
 
     # --- one-shot seams -------------------------------------------------------------
     def lowhash0(self, toc, data7, flags, params):
