@@ -285,13 +285,15 @@ void launchCellsLong(Context& ctx, const WorkStream& ws, BatchScratch& b, const 
         HIP_CHECK(hipGetLastError());
         return;
     }
+    // (SHASTA_MI355X_LONG_WAVES=<4 .. 16>: wavefronts of a workgroup of the windowed class -- a timing experiment; the LDS asked for stays that of sixteen)
+    static const int wavesLong = [] { const char* e = std::getenv("SHASTA_MI355X_LONG_WAVES"); return e ? std::min(std::max(std::atoi(e), 4), CELLS_LONG_WAVES) : CELLS_LONG_WAVES; }();
     const size_t bytes = cellsChunkLdsWords(CELLS_NA_LOG2[CELLS_LONG], CELLS_SC_LOG2[CELLS_LONG], CELLS_Q[CELLS_LONG], CELLS_LONG_WAVES) * sizeof(uint32_t);
     std::call_once(ctx.cellsLdsAttribute[2], [] {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&align4CellsLongKernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     });
     MI355X_ASSERT(bytes <= 160 * 1024 - 1024);
     SHASTA_TIMED(ctx, "align4CellsLongKernel<false>", ws.stream, kmerIdBytes, candidateCount,
-        hipLaunchKernelGGL((align4CellsLongKernel<false>), dim3(count), dim3(CELLS_LONG_THREADS), bytes, ws.stream,
+        hipLaunchKernelGGL((align4CellsLongKernel<false>), dim3(count), dim3(WAVE * wavesLong), bytes, ws.stream,
             (const uint32_t*)ctx.kmerIds.data(), (const PairDesc*)b.pairs.data(), chunks, count, (const uint32_t*)b.pairList.data(),
             opt, magicX, magicY, b.tasks.data(), b.counters.data(), taskCapacity, b.pairFlags.data(), (uint32_t*)nullptr, (uint32_t*)nullptr, hitLists));
     HIP_CHECK(hipGetLastError());
