@@ -17,6 +17,8 @@ SHASTA_MI355X_CELLS_SIDE_FROM=4 run call3_ul_long_on_side --workload ul --steps 
 SHASTA_MI355X_LONG_WAVES=8 run call3_ul_long_8_waves --workload ul --steps 3 --warmup 1 --no-cpu-baseline
 run call3_ul_whole_baseline --workload ul --steps 2 --warmup 1 --baseline-sample 0 --tie-census 0
 run call3_group1 --steps 10 --warmup 3 --group --gpus 1
+SHASTA_MI355X_DEBUG=1 SHASTA_MI355X_ALIGN_WORKERS=1 run call3_ul_debug --workload ul --steps 1 --warmup 0 --no-cpu-baseline
+grep "cells: round\|cells: HBM" gpurun_out/${ROUND}_call3_ul_debug.err | sort | uniq -c | sort -rn | head -20
 python scripts/bench_summary.py gpurun_out/${ROUND}_call3_headline gpurun_out/${ROUND}_call3_may2022 gpurun_out/${ROUND}_call3_ul gpurun_out/${ROUND}_call3_ul_whole_baseline 2>&1 | cut -c1-330
 for f in call3_headline call3_headline_no_second_anchor_launch call3_headline_again call3_ul call3_ul_long_on_side call3_ul_long_8_waves call3_group1; do python - <<PY
 import json
