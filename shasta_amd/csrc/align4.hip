@@ -441,14 +441,19 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
     hipStream_t side = nullptr, DpEvents* ev = nullptr)
 {
     // (in the order of the classes: a launch lists the tasks that turned out too large for it for the next one)
+    static_assert(CHAIN_WAVE_CLASSES == 6, "one launch per capacity class below");
     if(chainWaveOwnSort()) {
         launchChainWaveClass<0, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, true>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<3, true>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<4, true>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<5, true>(stream, b, in, taskCount, sparse, control, opt);
     } else if(side && ev && chainWaveSideStream()) {
         // (classes from the hits the sort kernel counted: no class lists tasks for another, so the launches need no order)
         HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(side, ev->fork, 0));
+        launchChainWaveClass<5, false>(side, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<4, false>(side, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<3, false>(side, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<2, false>(side, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, false>(side, b, in, taskCount, sparse, control, opt);
@@ -458,8 +463,12 @@ void launchChainWave(hipStream_t stream, BatchScratch& b, const DpInput& in, uin
     } else {
         launchChainWaveClass<0, false>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<1, false>(stream, b, in, taskCount, sparse, control, opt);
+        // (the listed classes: a batch without a task for one of them skips its launch -- the sort kernel's counts are not on the host, so the
+        // launches go out whatever they hold; the few wavefronts of an empty class leave at once)
         launchChainWaveClass<2, false>(stream, b, in, taskCount, sparse, control, opt);
         launchChainWaveClass<3, false>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<4, false>(stream, b, in, taskCount, sparse, control, opt);
+        launchChainWaveClass<5, false>(stream, b, in, taskCount, sparse, control, opt);
     }
 }
 

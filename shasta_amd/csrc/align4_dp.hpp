@@ -116,8 +116,8 @@ struct DpControl {
     uint32_t bins[DP_BINS];                          // tasks per bin, then (dpBinScanKernel) the bin's first position
     uint32_t cursors[DP_BINS];
     uint32_t anchorBigCount, anchorPad;              // align4_anchor.hpp: tasks with a rectangle beyond the first launch's LDS, listed for the second
-    uint32_t retryCount[4];                          // align4_chainwave.hpp: tasks a class's launch found too large for it, listed for the next class's
-    uint32_t waveNext[4];                            // align4_chainwave.hpp: the cursor through which the wavefronts of a capacity class take their blocks of tasks
+    uint32_t retryCount[8];                          // align4_chainwave.hpp: tasks a class's launch found too large for it, listed for the next class's
+    uint32_t waveNext[8];                            // align4_chainwave.hpp: the cursor through which the wavefronts of a capacity class take their blocks of tasks
 };
 constexpr size_t DP_CONTROL_HEAD_BYTES = offsetof(DpControl, bins);
 

@@ -72,10 +72,12 @@ __host__ __device__ inline int32_t sparseMatchlessScore(uint32_t nx, uint32_t ny
 }
 
 // align4_chainwave.hpp's capacity classes (hits a wavefront holds in LDS).
-constexpr int CHAIN_WAVE_CLASSES = 4;
+constexpr int CHAIN_WAVE_CLASSES = 6;
 // (a little under the powers of two: with the 4 bytes per window of 64 hits beside the 10 per hit, 1 024 hits were 10 304 bytes a
 // wavefront -- fifteen to a CU's 160 KB instead of sixteen)
-constexpr uint32_t CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES] = {1016u, 2032u, 4064u, 15360u};
+// (round 6: two classes between 4 064 and 15 360 hits -- 5 456, the most whose D fits 16 bits: three wavefronts to a CU, and 8 000 with D in
+// 32 bits: two -- for the tasks of two long reads, 4 500 hits on average in the ultra-long shape: half of them ran one wavefront to a CU)
+constexpr uint32_t CHAIN_WAVE_CAPACITY[CHAIN_WAVE_CLASSES] = {1016u, 2032u, 4064u, 5456u, 8000u, 15360u};
 // The classes from this one on are few tasks each (0.1 % of the tasks at 100 k reads): the sort kernel LISTS them (an atomic each on the
 // class's counter), and their launches run the list instead of going over all the tasks for them.
 constexpr int CHAIN_WAVE_LISTED_FROM = 2;

@@ -259,6 +259,24 @@ def large_tasks(seed=5, tasks=16):
     return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
 
 
+def huge_tasks(seed=6, sizes=(7000, 9000, 11500, 14000)):
+    """Tasks of 4 300 to 8 700 aligned pairs between two reads of up to 10 000 markers: the wave kernel's classes of 5 456 hits (D in 16
+    bits) and of 8 000 and 15 360 (32), hits ordered by a read beyond 8 192 markers (the sort kernel's classes for long reads)."""
+    rng = np.random.default_rng(seed)
+    pieces, spec, at = [], [], 0
+    for n in sizes:
+        width = int(rng.choice([60, 100, 300]))
+        genome = rng.integers(0, 1 << 20, size=n + 400, dtype=np.uint32)
+        off = int(rng.integers(0, 100))
+        a = dp_geometry_checks.noisy(rng, genome[:n], 1 << 20)
+        b = dp_geometry_checks.noisy(rng, genome[off:off + n], 1 << 20)
+        lo = off - width // 2
+        pieces += [a, b]
+        spec.append((at, len(a), at + len(a), len(b), lo, lo + width - 1))
+        at += len(a) + len(b)
+    return np.concatenate(pieces), np.asarray(spec, dtype=np.int64)
+
+
 def deep_block_tasks(seed=23, depths=(2500, 5200, 7700), n=8100, block=320):
     """Two unrelated reads of 8 100 markers (the longest the hits are ordered by: 8 192) that share one block deep inside: the chain
     enters from the border at a cost of the block's depth, so D of its hits lies near -depth -- the low end of what the wave kernel
@@ -284,7 +302,7 @@ def wave_kernel_forms(lib, orc):
     tasks of every size class and on blocks deep inside long reads.
     -> tasks compared."""
     compared = 0
-    for kmer, spec in (clean_tasks(91, tasks=40, long_every=9), large_tasks(), deep_block_tasks()):
+    for kmer, spec in (clean_tasks(91, tasks=40, long_every=9), large_tasks(), huge_tasks(), deep_block_tasks()):
         want = [orc.banded_dp(kmer[b0:b0 + nx], kmer[b1:b1 + ny], int(lo), int(hi)) for b0, nx, b1, ny, lo, hi in spec]
         for env in ({}, {"SHASTA_MI355X_CHAIN_WAVE": "0"}, {"SHASTA_MI355X_CHAIN_WAVE_SORT": "1"}, {"SHASTA_MI355X_CHAIN_WAVE_SIDE": "1"},
                     {"SHASTA_MI355X_CHAIN_WAVE_WIDE_D": "1"}, {"SHASTA_MI355X_CHAIN_WAVE_WIDE_D": "1", "SHASTA_MI355X_CHAIN_WAVE_SORT": "1"}):
