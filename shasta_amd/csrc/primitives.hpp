@@ -30,6 +30,26 @@ __device__ __forceinline__ uint32_t reverseComplementKmerId(uint32_t kmerId, uin
 // passing through a vector register.  `address` must be wave-uniform (an SGPR pair) and 4-byte aligned.  The scalar data cache
 // is write-back: scalarStoreFlush() before the wavefront ends, or a later kernel may not see the data.
 // (The wave64 emulator of tests/emu supplies its own: SHASTA_SCALAR_STORE_DEFINED.)
+#if !defined(SHASTA_SCALAR_STORE_DEFINED) && defined(SHASTA_TRACE_VECTOR_STORES)
+// (the same three entry points as plain vector stores of lane 0: the A/B build of the search for round 5's method-3 failure, and the
+// form to fall back on should scalar stores ever be at fault -- make OUT=../_build_vector_stores EXTRA=-DSHASTA_TRACE_VECTOR_STORES=1)
+#define SHASTA_SCALAR_STORE_DEFINED
+__device__ __forceinline__ void scalarStore128(void* address, uint64_t low, uint64_t high)
+{
+    if(laneId() == 0) *reinterpret_cast<uint4*>(address) = make_uint4(uint32_t(low), uint32_t(low >> 32), uint32_t(high), uint32_t(high >> 32));
+}
+__device__ __forceinline__ void scalarStore128At(void* address, int byteOffset, uint64_t low, uint64_t high)
+{
+    scalarStore128(static_cast<char*>(address) + byteOffset, low, high);
+}
+__device__ __forceinline__ void scalarStoreFlush() {}
+template<class T> __device__ __forceinline__ T* uniformPointer(T* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return reinterpret_cast<T*>((uint64_t(hi) << 32) | lo);
+}
+#endif
 #ifndef SHASTA_SCALAR_STORE_DEFINED
 __device__ __forceinline__ void scalarStore128(void* address, uint64_t low, uint64_t high)
 {
