@@ -633,6 +633,10 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
         for(int why = 0; why < DP_GIVE_UP_REASONS; why++) if(head.giveUpTasks[why]) timers->count(DP_GIVE_UP_NAMES[why], head.giveUpTasks[why], 0, head.giveUpCells[why]);
     }
     b.trace.reserve(f.traceWords + 64, stream);
+    // (SHASTA_MI355X_TRACE_POISON=1: the trace filled with a byte pattern before the forward kernels write it -- a walk that reads a record
+    // the forward kernel's stores have not delivered then reads that, not what an identical earlier call left at the same address)
+    static const bool tracePoison = [] { const char* e = std::getenv("SHASTA_MI355X_TRACE_POISON"); return e && e[0] == '1'; }();
+    if(tracePoison && f.traceWords) HIP_CHECK(hipMemsetAsync(b.trace.data(), 0xA5, (f.traceWords + 64) * sizeof(uint64_t), stream));
     f.ordTotal = ordTotal;
     if(reserveOrdinals) b.ordScratch.reserve(2 * (ordTotal + extraOrdinals) + 2, stream);
 
