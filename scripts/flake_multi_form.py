@@ -46,6 +46,26 @@ def main():
             if digest(got) != digest(want):
                 bad += 1
                 print("repeat", it, key, "the DEVICE differs:", describe(want, got), flush=True)
+                # Everything about the first candidate that differs: both lists of aligned pairs, the rows, and what the same call gives when
+                # it is made again at once (does the difference stay?).
+                try:
+                    wt, gt = np.asarray(want.ordinals_toc).astype(np.int64), np.asarray(got.ordinals_toc).astype(np.int64)
+                    if np.array_equal(wt, gt):
+                        d = np.nonzero(np.asarray(want.ordinals).reshape(-1) != np.asarray(got.ordinals).reshape(-1))[0]
+                        c = int(np.searchsorted(wt, d[0] // 2, side="right") - 1)
+                        again = (lib.align3_batch_multi if key[2] == 3 else lib.align4_batch_multi)(toc, data7, cand, o, devices, want_ordinals=True)
+                        w, g, a = want.ordinals_of(c), got.ordinals_of(c), again.ordinals_of(c)
+                        rows = np.nonzero((w != g).any(axis=1))[0]
+                        print("   candidate", c, tuple(int(x) for x in (cand["readId0"][c], cand["readId1"][c], cand["isSameStrand"][c])), "pairs", len(w),
+                              "rows that differ", rows[:12].tolist(), "... of", len(rows), "; the call made again equals the oracle:", bool(np.array_equal(a, w)),
+                              "equals the first answer:", bool(np.array_equal(a, g)), flush=True)
+                        lo, hi = max(0, int(rows[0]) - 3), min(len(w), int(rows[-1]) + 4)
+                        print("   oracle", w[lo:hi].tolist(), flush=True)
+                        print("   device", g[lo:hi].tolist(), flush=True)
+                        np.savez(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r06_flake_event_%d_%d.npz" % (it, bad)), oracle=w, device=g, again=a,
+                                 candidate=np.array([c, key[0], key[2]]), name=np.array([key[1]]))
+                except Exception as e:          # noqa: BLE001
+                    print("   (could not describe it further: %s)" % e, flush=True)
     print("library %s, %d contexts on device 0: repeats %d, calls %d, differences %d, %.0f s" % (path or "(the product)", len(devices), repeats, calls, bad, time.time() - t0))
 
 

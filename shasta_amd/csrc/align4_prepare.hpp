@@ -43,7 +43,10 @@ __host__ __device__ inline int cellsClassFor(const CellsClassRule& rule, uint64_
     // The single-multiply division must be exact.
     if((nx + ny) * (rule.deltaX > rule.deltaY ? rule.deltaX : rule.deltaY) >= (1ULL << 32)) return CELLS_CLASSES;
     const uint64_t cells = (nx * ny >> rule.estimateShift) + (nx + ny) / 32 + 32;
-    const bool longFits = rule.longOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_LONG_IY_BITS) - 1 && 4 * cells <= (3ULL << cellsScLog2(CELLS_LONG));
+    // (the windowed class's own estimate is the expected number of cells, not twice it: what overflows its table goes on to the HBM-scratch kernel
+    // either way, and a pair of two reads of 40 000 markers -- 17 a step of the ultra-long shape -- has 2 600 random matches at k = 14, not 6 100)
+    const uint64_t cellsLong = (nx * ny >> (rule.estimateShift + 1)) + (nx + ny) / 64 + 32;
+    const bool longFits = rule.longOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_LONG_IY_BITS) - 1 && 4 * cellsLong <= (3ULL << cellsScLog2(CELLS_LONG));
     if(rule.force && longFits) return rule.force == 2 ? CELLS_LONG_BIG : CELLS_LONG;
     // Cell indices must fit the packed word.
     if(rule.packedOk && (nx + ny) / rule.deltaX < (1ULL << CELLS_IX_BITS) && (nx + ny) / rule.deltaY < (1ULL << CELLS_IY_BITS)) {
