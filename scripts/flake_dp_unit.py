@@ -54,6 +54,31 @@ def main():
     rng = np.random.default_rng(3)
     sets = [tasks_of(orc, 14, 154, rng), tasks_of(orc, 16, 156, rng)]
     first, bad, t0 = [None, None], 0, time.time()
+    threads = int(os.environ.get("FLAKE_THREADS", "1"))
+    if threads > 1:
+        # Several host threads, each making the same calls on the same device at the same time (ctypes releases the interpreter lock for the
+        # call): what two contexts of a device list, or the aligner's own worker threads, do to the runtime and the device.
+        import threading
+        for s, (kmer, spec) in enumerate(sets):
+            first[s] = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5])
+        counts = [0] * threads
+
+        def work(me):
+            for it in range(repeats):
+                for s, (kmer, spec) in enumerate(sets):
+                    got = lib.banded_dp_many(kmer, spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3], spec[:, 4], spec[:, 5])
+                    for t, ((x, sx), (y, sy)) in enumerate(zip(first[s], got)):
+                        if sx != sy or not np.array_equal(x, y):
+                            counts[me] += 1
+                            d = int(np.sum(x != y)) if x.shape == y.shape else -1
+                            print("thread", me, "repeat", it, "set", s, "task", t, "spec", spec[t].tolist(), "differs from the first run: scores", sx, sy, "pairs", len(x), len(y), "values that differ", d, flush=True)
+        pool = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+        for th in pool:
+            th.start()
+        for th in pool:
+            th.join()
+        print("library %s: %d threads x repeats %d x (%d + %d tasks), differences from the first run %d, %.0f s" % (path or "(the product)", threads, repeats, len(sets[0][1]), len(sets[1][1]), sum(counts), time.time() - t0))
+        return
     for it in range(repeats):
         for s, (kmer, spec) in enumerate(sets):
             if os.environ.get("FLAKE_PERMUTE") == "1" and first[s] is not None:

@@ -24,6 +24,9 @@ run bench_final_m3 --steps 4 --warmup 3 --no-cpu-baseline --align-method 3
 SHASTA_MI355X_ALIGN_WORKERS=1 run bench_final_w1 --steps 2 --warmup 1 --no-cpu-baseline
 run bench_final_group1 --steps 10 --warmup 3 --group --gpus 1
 SHASTA_BENCH_FORCE_SHARDED=1 SHASTA_BENCH_NO_GROUP_LINE=1 run bench_final_one_rank_rccl --steps 10 --warmup 3 --no-cpu-baseline
+# (why is LowHash0 through the group slower than on a context?  allocations per step, and the host's clock inside the call)
+SHASTA_MI355X_LOG_ALLOC=1 run group1_alloc_log --steps 3 --warmup 3 --group --gpus 1
+grep -c "device buffer" gpurun_out/${ROUND}_group1_alloc_log.err; grep "device buffer" gpurun_out/${ROUND}_group1_alloc_log.err | tail -12
 python scripts/bench_summary.py gpurun_out/${ROUND}_bench_final gpurun_out/${ROUND}_bench_final_default gpurun_out/${ROUND}_bench_final_whole_baseline gpurun_out/${ROUND}_bench_ul gpurun_out/${ROUND}_bench_may2022 2>&1 | cut -c1-400
 for f in bench_final_lh bench_final_m3 bench_final_w1 bench_final_group1 bench_final_one_rank_rccl; do python - <<PY
 import json
