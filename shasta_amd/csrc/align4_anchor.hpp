@@ -218,12 +218,21 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
     const int32_t bandWidth = bandMax - bandMin + 1, rowWords = (bandWidth + 15) / 16;
     uint32_t* const traceWords = reinterpret_cast<uint32_t*>(sh.trace);
     if(bandWidth > ANCHOR_BIG_BAND || int64_t(wx + 1) * rowWords > int64_t(Shared::maxCells / 16)) return -3;
-    for(int32_t a = lane; a < (wx + 1) * rowWords; a += WAVE) traceWords[a] = 0;
     const int32_t shift = x0 - y0;
     auto bandBase = [&](int32_t i) { return i + shift - bandMax; };                  // the column of the band's lowest diagonal in row i (may be negative)
     auto jLow = [&](int32_t i) { return max(0, bandBase(i)); };
     auto jHigh = [&](int32_t i) { return min(wy, i + shift - bandMin); };
-    auto putMove = [&](int32_t i, int32_t b, int move) { atomicOr(&traceWords[i * rowWords + (b >> 4)], uint32_t(move) << (2 * (b & 15))); };
+    // The codes of the 64 positions a chunk's lanes hold, as the four words of the row's trace they make: two ballots, the planes' bits
+    // interleaved by the first four lanes, four plain stores -- every word of a row is written exactly once, so the trace needs no clearing.
+    // (Until round 6 every lane OR-ed its two bits in with an LDS atomic: sixteen lanes on each of four words, sixteen serialised atomics per
+    // word and chunk.)
+    auto spread16 = [](uint32_t x) { x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; return (x | (x << 1)) & 0x55555555u; };
+    auto putCodes = [&](int32_t i, int32_t chunk, int code) {
+        const uint64_t low = __ballot((code & 1) != 0), high = __ballot((code & 2) != 0);
+        const int32_t word = chunk * 4 + lane;
+        if(lane < 4 && word < rowWords)
+            traceWords[i * rowWords + word] = spread16(uint32_t(low >> (16 * lane)) & 0xffffu) | (spread16(uint32_t(high >> (16 * lane)) & 0xffffu) << 1);
+    };
     // The rows whose band holds the last column: iFirst .. iFirst + bandWidth - 1.
     const int32_t iFirst = max(0, wy - shift + bandMin);
     for(int32_t a = lane; a < ANCHOR_BIG_BAND + 2; a += WAVE) sh.lastColumn[a] = ANCHOR_NEG;
@@ -241,17 +250,15 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
     // Markers of read 0: the block of 64 rows in hand in a register, the next one on its way.
     uint32_t block0 = p0[x0 + min(lane, wx - 1)], block0Next = p0[x0 + min(WAVE + lane, wx - 1)];
     waveLdsSync();
-    {
-        for(int32_t b = lane; b <= bandWidth; b += WAVE) {
-            const int32_t j = b + bandBase(0);
-            const bool in = b < bandWidth && j >= 0 && j <= wy;
-            sh.row[0][b] = !in ? ANCHOR_NEG : (beginFixed ? -j : 0);
-            if(in) putMove(0, b, Tie::VERTICAL);
-            if(in && j == wy && iFirst == 0) sh.lastColumn[0] = beginFixed ? -wy : 0;
-        }
+    const int32_t chunks = (bandWidth + WAVE) / WAVE;                             // (position bandWidth included: it is written "outside" for the row below)
+    for(int32_t chunk = 0; chunk < chunks; chunk++) {
+        const int32_t b = chunk * WAVE + lane, j = b + bandBase(0);
+        const bool in = b < bandWidth && j >= 0 && j <= wy;
+        if(b <= bandWidth) sh.row[0][b] = !in ? ANCHOR_NEG : (beginFixed ? -j : 0);
+        putCodes(0, chunk, in ? int(Tie::VERTICAL) : 0);
+        if(in && j == wy && iFirst == 0) sh.lastColumn[0] = beginFixed ? -wy : 0;
     }
     waveLdsSync();
-    const int32_t chunks = (bandWidth + WAVE) / WAVE;                             // (position bandWidth included: it is written "outside" for the row below)
     for(int32_t i = 1; i <= wx; i++) {
         if(((i - 1) & (WAVE - 1)) == 0 && i > 1) {
             // A new block of 64 rows: its markers of read 0 become the block in hand, the ring takes what was asked for a block ago, and
@@ -301,9 +308,9 @@ __device__ int32_t anchorRectangleBand(Shared& sh, const uint32_t* __restrict__ 
             }
             if(b <= bandWidth) {
                 current[b] = h;
-                if(in) putMove(i, b, (move == Tie::DIAGONAL && equal) ? EQUAL_DIAGONAL : move);
                 if(in && j == wy && i >= iFirst && i - iFirst <= ANCHOR_BIG_BAND + 1) sh.lastColumn[i - iFirst] = h;
             }
+            putCodes(i, chunk, !in ? 0 : ((move == Tie::DIAGONAL && equal) ? EQUAL_DIAGONAL : move));
             waveLdsSync();                                   // (lane 0 of the next chunk reads current[b - 1])
         }
     }
