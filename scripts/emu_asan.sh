@@ -10,8 +10,20 @@ import sys
 sys.path.insert(0, ".")
 from oracle import bindings
 from shasta_amd import abi, lib as L
-from tests import adversarial, align3_checks, group_checks, sparse_checks, support
+import os
+from tests import adversarial, align3_checks, group_checks, long_read_checks, sparse_checks, support
 emu, orc = L.Library("tests/emu/_build_asan/libshasta_mi355x_emu.so"), bindings.OracleLib()
+# (round 6's kernels first: the windowed class and its large graph, the wavefront walk of long dense paths, a call without ordinals)
+os.environ["SHASTA_MI355X_ALIGN_WORKERS"] = "1"
+os.environ["SHASTA_MI355X_MATCH_SHIFT"] = "20"
+r = long_read_checks.both_long(emu, orc, lengths=(9000, 12500, 9500, 8300, 4000), genome_markers=16000)
+print("pairs of two long reads:", {k: v for k, v in r.items() if k != "rows"}, flush=True)
+del os.environ["SHASTA_MI355X_MATCH_SHIFT"]
+for force in ("long", "big"):
+    print("every candidate forced through the windowed kernels (%s):" % force, long_read_checks.forced(emu, orc, None, force, n_reads=100, limit=250, adversarial_sets=True), flush=True)
+print("long dense paths:", sparse_checks.long_dense_paths(emu, orc), flush=True)
+print("a call without ordinals:", sparse_checks.without_ordinals(emu, orc, n_reads=100, limit=300), flush=True)
+del os.environ["SHASTA_MI355X_ALIGN_WORKERS"]
 print("aligner, share of the DP cells from the matches:", sparse_checks.aligner(emu, orc, n_reads=90, limit=160), flush=True)
 print("dp tasks:", sparse_checks.dp_tasks(emu, orc, clean=30, tie_heavy=20, alternatives=(2,), long_every=44), flush=True)
 print("locally ambiguous tasks (anchor kernel):", sparse_checks.anchored_tasks(emu, orc, seeds=(3, 4, 5), tasks=24), flush=True)

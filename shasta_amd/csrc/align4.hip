@@ -172,6 +172,7 @@ struct BatchScratch {
     // (worker scratch only) all the buffers above, for raiseToMarks
     std::vector<SharedCapacityMember*> sharedBuffers;
     void raiseToMarks(hipStream_t stream) { for(SharedCapacityMember* m : sharedBuffers) m->raiseToMark(stream); }
+    void scrambleAll(hipStream_t stream) { for(SharedCapacityMember* m : sharedBuffers) m->scramble(stream); }
 };
 
 // The scratch of a host worker: each of its buffers shares a high-water mark with the same buffer of the other workers.
@@ -1328,6 +1329,9 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         // Room for the DP tasks of the batch; the stage runs again with the exact count if it is short.
         // SHASTA_MI355X_INITIAL_TASKS overrides the first guess (tests use it to force the second run).
         b.raiseToMarks(stream);          // what other workers' batches needed so far: grown to now, not in the middle of the batch
+        // (SHASTA_MI355X_SCRAMBLE=1, a test switch: every scratch buffer of the worker overwritten with pseudo-random data before the batch touches
+        // it -- a kernel that reads what its own batch has not written then answers differently from call to call)
+        if(const char* e = std::getenv("SHASTA_MI355X_SCRAMBLE")) if(e[0] == '1') b.scrambleAll(stream);
         uint32_t taskCapacity = 8 * n + 1024;
         if(const char* e = std::getenv("SHASTA_MI355X_INITIAL_TASKS")) taskCapacity = uint32_t(std::max(1L, std::atol(e)));
         b.pairs.reserve(n, stream); b.candidates.reserve(n, stream); b.tasks.reserve(taskCapacity, stream);

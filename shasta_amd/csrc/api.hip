@@ -7,6 +7,8 @@
 #include <vector>
 #include <string>
 
+#include <atomic>
+#include <algorithm>
 #include <mutex>
 using namespace shasta_mi355x;
 
@@ -14,6 +16,26 @@ struct shasta_mi355x_ctx { Context impl; explicit shasta_mi355x_ctx(int d) : imp
 struct shasta_mi355x_group { Group impl; shasta_mi355x_group(int n, const int* devices) : impl(n, devices) {} };
 
 static thread_local std::string lastError;
+
+namespace shasta_mi355x {
+__global__ void __launch_bounds__(256) scrambleKernel(uint32_t* __restrict__ words, uint64_t count, uint64_t seed)
+{
+    for(uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += uint64_t(gridDim.x) * blockDim.x) {
+        uint64_t x = (i + 1) * 0x9e3779b97f4a7c15ULL ^ seed;
+        x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ULL; x ^= x >> 32;
+        words[i] = uint32_t(x);
+    }
+}
+void scrambleDeviceMemory(void* p, size_t bytes, hipStream_t stream)
+{
+    static std::atomic<uint64_t> counter(0);
+    const uint64_t count = bytes / 4;
+    if(count == 0) return;
+    const uint64_t seed = (counter.fetch_add(1) + 1) * 0xd6e8feb86659fd93ULL;
+    hipLaunchKernelGGL(scrambleKernel, dim3(unsigned(std::min<uint64_t>((count + 255) / 256, 4096))), dim3(256), 0, stream, static_cast<uint32_t*>(p), count, seed);
+    HIP_CHECK(hipGetLastError());
+}
+}  // namespace shasta_mi355x
 
 // An aligner call keeps six workers' streams and their side streams busy; the HIP runtime deals a process's streams to
 // GPU_MAX_HW_QUEUES hardware queues -- four unless the environment says otherwise -- and streams that share a queue run one after

@@ -52,9 +52,12 @@ inline uint64_t referenceDoubleToUint64(double x)
 // hipFree waits for the whole device, so a reallocation stalls every worker's stream; with the marks the reallocations of a
 // repeated workload end after its first pass.  A buffer is bound to the mark of its position when it is constructed while
 // a SharedCapacityBinding is active on the thread (makeWorkerScratch in align4.hip); otherwise it has none.
+// (api.hip) `bytes` at p filled with pseudo-random words that differ from call to call: SHASTA_MI355X_SCRAMBLE.
+void scrambleDeviceMemory(void* p, size_t bytes, hipStream_t stream);
 class SharedCapacityMember {
 public:
     virtual void raiseToMark(hipStream_t stream) = 0;
+    virtual void scramble(hipStream_t) {}
 protected:
     ~SharedCapacityMember() = default;
 };
@@ -103,6 +106,9 @@ public:
         const size_t m = mark ? mark->load() : 0;
         if(m > cap) reallocate(m, stream, false);
     }
+    // SHASTA_MI355X_SCRAMBLE=1 (a test switch): the whole buffer overwritten with pseudo-random data at the head of every batch -- what a kernel
+    // reads without its batch having written it is then neither what an earlier, similar batch left there nor a constant byte.
+    void scramble(hipStream_t stream) override { if(p && cap) scrambleDeviceMemory(p, cap * sizeof(T), stream); }
     T* data() const { return p; }
     size_t capacity() const { return cap; }
     void swap(DeviceBuffer& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
@@ -119,6 +125,10 @@ private:
         // wrote gives results that change with the value; fresh hipMalloc memory otherwise holds whatever the process freed before).
         static const int poison = [] { const char* e = std::getenv("SHASTA_MI355X_POISON"); return e ? int(std::strtol(e, nullptr, 0)) & 0xff : -1; }();
         if(poison >= 0) { HIP_CHECK(hipMemsetAsync(q, poison, newCap * sizeof(T), stream)); HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipDeviceSynchronize()); }
+        // SHASTA_MI355X_SCRAMBLE=1: ... and with pseudo-random data that differs from allocation to allocation (the aligner's workers also
+        // scramble their scratch at the head of every batch: align4.hip).
+        static const bool scrambleNew = [] { const char* e = std::getenv("SHASTA_MI355X_SCRAMBLE"); return e && e[0] == '1'; }();
+        if(scrambleNew) { scrambleDeviceMemory(q, newCap * sizeof(T), stream); HIP_CHECK(hipStreamSynchronize(stream)); }
         if(keep && p && cap) {
             HIP_CHECK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
