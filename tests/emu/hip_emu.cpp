@@ -3,6 +3,9 @@
 // switch only at cross-lane operations and barriers) and the host runtime stubs.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <elf.h>
+#include <link.h>
 #include <sys/mman.h>
 
 #include <atomic>
@@ -10,6 +13,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <fstream>
 #include <functional>
 #include <cstdio>
 #include <mutex>
@@ -100,6 +104,105 @@ void prepare(Fiber& f, char* stackTop)
     f.sp = p;
 }
 
+// HIPEMU_LDS_SCRAMBLE=<seed>: LDS is not cleared between workgroups on the hardware -- a workgroup finds what the last one on its CU
+// left there, of whatever kernel of whatever process.  Here a __shared__ variable is a function-scope thread_local: zero when the OS
+// thread first meets it and the SAME kernel's residue afterwards, which forgives a read of LDS the workgroup has not written.  With the
+// switch every __shared__ variable of the library is filled with pseudo-random data before every workgroup (all ones, small integers and
+// small signed values take turns with random words: residue that looks like counts, indices and scores), and a shuffle whose source lane
+// is switched off returns garbage instead of the reader's own value.  The variables are found in the library's own symbol table:
+// the STT_TLS symbols of local statics (_ZZ...) and the arrays that stand in for the dynamic LDS (dynamic_lds_*.h).
+struct LdsMap {
+    bool on = false;
+    uint64_t seed = 0;
+    std::vector<std::pair<size_t, size_t>> ranges;     // (offset in the module's TLS block, bytes)
+    size_t tlsBytes = 0, totalBytes = 0;
+};
+LdsMap buildLdsMap()
+{
+    LdsMap m;
+    const char* e = std::getenv("HIPEMU_LDS_SCRAMBLE");
+    if(!e || !e[0] || (e[0] == '0' && !e[1])) return m;
+    m.seed = std::strtoull(e, nullptr, 0);
+    Dl_info info;
+    if(!dladdr(reinterpret_cast<void*>(&hipemu::launch), &info) || !info.dli_fname) { std::fprintf(stderr, "hipemu: HIPEMU_LDS_SCRAMBLE: the library's file is unknown\n"); std::abort(); }
+    std::ifstream in(info.dli_fname, std::ios::binary);
+    std::vector<char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    if(file.size() < sizeof(Elf64_Ehdr)) { std::fprintf(stderr, "hipemu: HIPEMU_LDS_SCRAMBLE: cannot read %s\n", info.dli_fname); std::abort(); }
+    const Elf64_Ehdr* eh = reinterpret_cast<const Elf64_Ehdr*>(file.data());
+    const Elf64_Phdr* ph = reinterpret_cast<const Elf64_Phdr*>(file.data() + eh->e_phoff);
+    for(int i = 0; i < eh->e_phnum; i++) if(ph[i].p_type == PT_TLS) m.tlsBytes = ph[i].p_memsz;
+    const Elf64_Shdr* sh = reinterpret_cast<const Elf64_Shdr*>(file.data() + eh->e_shoff);
+    const Elf64_Shdr* symtab = nullptr;
+    for(int i = 0; i < eh->e_shnum; i++) if(sh[i].sh_type == SHT_SYMTAB) symtab = &sh[i];
+    if(!symtab || !m.tlsBytes) { std::fprintf(stderr, "hipemu: HIPEMU_LDS_SCRAMBLE: %s has no symbol table or no TLS segment\n", info.dli_fname); std::abort(); }
+    const char* names = file.data() + sh[symtab->sh_link].sh_offset;
+    const Elf64_Sym* syms = reinterpret_cast<const Elf64_Sym*>(file.data() + symtab->sh_offset);
+    const size_t count = symtab->sh_size / sizeof(Elf64_Sym);
+    for(size_t i = 0; i < count; i++) {
+        if(ELF64_ST_TYPE(syms[i].st_info) != STT_TLS || syms[i].st_size == 0) continue;
+        const std::string name = names + syms[i].st_name;
+        const bool localStatic = name.compare(0, 3, "_ZZ") == 0;
+        const bool dynamicLds = name.find("ldsWords") != std::string::npos || name.find("wideRows") != std::string::npos || name.find("screenWindows") != std::string::npos;
+        if(!localStatic && !dynamicLds) continue;
+        if(syms[i].st_value + syms[i].st_size > m.tlsBytes) { std::fprintf(stderr, "hipemu: HIPEMU_LDS_SCRAMBLE: %s lies outside the TLS segment\n", name.c_str()); std::abort(); }
+        m.ranges.emplace_back(size_t(syms[i].st_value), size_t(syms[i].st_size));
+    }
+    std::sort(m.ranges.begin(), m.ranges.end());
+    m.ranges.erase(std::unique(m.ranges.begin(), m.ranges.end()), m.ranges.end());
+    for(const auto& r : m.ranges) m.totalBytes += r.second;
+    std::fprintf(stderr, "hipemu: HIPEMU_LDS_SCRAMBLE: %zu __shared__ variables, %zu bytes, filled before every workgroup\n", m.ranges.size(), m.totalBytes);
+    m.on = true;
+    return m;
+}
+const LdsMap& ldsMap() { static const LdsMap m = buildLdsMap(); return m; }
+
+thread_local char* tlsBlock = nullptr;
+thread_local uint64_t garbageState = 0;
+std::atomic<uint64_t> scrambleCounter(0);
+
+inline uint64_t nextGarbage(uint64_t& s) { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1DULL; }
+
+char* tlsBlockOfThisThread(size_t bytes)
+{
+    if(tlsBlock) return tlsBlock;
+    struct Query { const void* inside; char* block; } q{reinterpret_cast<const void*>(&hipemu::launch), nullptr};
+    (void)cur;                                           // (the module's block exists in this thread once one of its variables was touched)
+    dl_iterate_phdr([](dl_phdr_info* info, size_t, void* data) {
+        Query* q = static_cast<Query*>(data);
+        for(int i = 0; i < info->dlpi_phnum; i++) {
+            const ElfW(Phdr)& p = info->dlpi_phdr[i];
+            const uintptr_t a = info->dlpi_addr + p.p_vaddr, x = reinterpret_cast<uintptr_t>(q->inside);
+            if(p.p_type == PT_LOAD && x >= a && x < a + p.p_memsz) { q->block = static_cast<char*>(info->dlpi_tls_data); return 1; }
+        }
+        return 0;
+    }, &q);
+    const char* own = reinterpret_cast<const char*>(&cur);
+    if(!q.block || own < q.block || own >= q.block + bytes) { std::fprintf(stderr, "hipemu: HIPEMU_LDS_SCRAMBLE: this thread's TLS block was not found\n"); std::abort(); }
+    return tlsBlock = q.block;
+}
+
+void scrambleLds()
+{
+    const LdsMap& m = ldsMap();
+    if(!m.on) return;
+    char* block = tlsBlockOfThisThread(m.tlsBytes);
+    const uint64_t n = scrambleCounter.fetch_add(1);
+    uint64_t s = (m.seed + 1) * 0x9E3779B97F4A7C15ULL + n * 0xD1B54A32D192ED03ULL; if(!s) s = 1;
+    const unsigned mode = unsigned(n & 3u);
+    for(const auto& r : m.ranges) {
+        char* p = block + r.first; size_t left = r.second;
+        while(left) {
+            uint64_t w = nextGarbage(s);
+            if(mode == 1) w = ~uint64_t(0);
+            else if(mode == 2) w &= 0x00000fff00000fffULL;                                                  // small counts and indices
+            else if(mode == 3) { const uint32_t a = uint32_t(int32_t(w % 6000) - 1000), b = uint32_t(int32_t((w >> 32) % 6000) - 1000); w = (uint64_t(b) << 32) | a; }   // scores
+            const size_t k = std::min<size_t>(left, 8);
+            std::memcpy(p, &w, k); p += k; left -= k;
+        }
+    }
+    garbageState = s;
+}
+
 // Completes the collective of the lanes in `group` (all waiting at the same call site).
 void releaseGroup(std::vector<Fiber>& fibers, int waveBase, uint64_t group)
 {
@@ -116,8 +219,8 @@ void releaseGroup(std::vector<Fiber>& fibers, int waveBase, uint64_t group)
         case BALLOT: f.result = ballot; break;
         case SHUFFLE: {
             const int src = int(f.aux);
-            // An inactive source lane returns garbage on hardware; the own value keeps runs reproducible.
-            f.result = (src >= 0 && src < 64 && ((group >> src) & 1)) ? fibers[waveBase + src].value : f.value;
+            // An inactive source lane returns garbage on hardware; the own value keeps runs reproducible (HIPEMU_LDS_SCRAMBLE: garbage).
+            f.result = (src >= 0 && src < 64 && ((group >> src) & 1)) ? fibers[waveBase + src].value : (garbageState ? nextGarbage(garbageState) : f.value);
             break;
         }
         case DPP_MOVE: {                // bit 32: the source lane is active
@@ -139,6 +242,7 @@ void runBlock(const Launch& L, unsigned bx, unsigned by, unsigned bz)
     worker.reserve(n);
     worker.launch = &L;
     worker.error.clear();
+    scrambleLds();
     std::vector<Fiber> fibers(n);
     for(unsigned t = 0; t < n; t++) {
         Fiber& f = fibers[t];
