@@ -157,7 +157,7 @@ LdsMap buildLdsMap()
 const LdsMap& ldsMap() { static const LdsMap m = buildLdsMap(); return m; }
 
 thread_local char* tlsBlock = nullptr;
-thread_local uint64_t garbageState = 0;
+thread_local uint64_t garbageState = 0, scheduleState = 0;
 std::atomic<uint64_t> scrambleCounter(0);
 
 inline uint64_t nextGarbage(uint64_t& s) { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1DULL; }
@@ -253,14 +253,24 @@ void runBlock(const Launch& L, unsigned bx, unsigned by, unsigned bz)
         prepare(f, worker.stacks + size_t(t + 1) * STACK_BYTES);
     }
     const unsigned waves = (n + 63) / 64;
+    // HIPEMU_SCHEDULE=<seed>: the wavefronts of a workgroup run in a random order that changes at every pass, and a wavefront whose lanes
+    // all wait at one cross-lane operation is let go only every other time (by a coin): wavefronts get ahead of each other by several
+    // such operations, as they do on a CU, instead of advancing side by side -- LDS traffic between wavefronts that lacks a
+    // barrier then shows as a changed result.  (The lanes of a wavefront keep their order: lock-step code relies on it, see above.)
+    static const uint64_t scheduleSeed = [] { const char* e = std::getenv("HIPEMU_SCHEDULE"); return e && e[0] ? std::strtoull(e, nullptr, 0) + 1 : 0; }();
+    const bool shuffled = scheduleSeed != 0;
+    if(shuffled && !scheduleState) scheduleState = scheduleSeed * 0x9E3779B97F4A7C15ULL + scrambleCounter.fetch_add(1) * 0xD1B54A32D192ED03ULL + 1;
+    std::vector<unsigned> waveOrder(waves);
+    for(unsigned w = 0; w < waves; w++) waveOrder[w] = w;
     unsigned done = 0;
     while(done < n) {
         bool progressed = false;
         // Within a wavefront the highest lane runs first, so the usual leader (lane 0) runs last: a
         // follower's LDS read that precedes the leader's LDS write in program order, with no
         // cross-lane operation in between, sees the old value -- as it does in lock-step.
-        for(unsigned q = 0; q < n; q++) {
-            const unsigned w = q >> 6, top = std::min(n, (w + 1) * 64u) - 1;
+        if(shuffled) for(unsigned k = waves; k > 1; k--) std::swap(waveOrder[k - 1], waveOrder[nextGarbage(scheduleState) % k]);
+        for(unsigned q = 0; q < waves * 64u; q++) {
+            const unsigned w = waveOrder[q >> 6], top = std::min(n, (w + 1) * 64u) - 1;
             const unsigned t = top - (q & 63u);
             if(t < w * 64u || t >= n) continue;
             Fiber& f = fibers[t];
@@ -272,6 +282,7 @@ void runBlock(const Launch& L, unsigned bx, unsigned by, unsigned bz)
             if(f.state == DONE) ++done;
         }
         // Wavefronts whose live lanes all wait at one call site: the common case.
+        bool held = false;
         for(unsigned w = 0; w < waves; w++) {
             const int base = int(w * 64), count = int(std::min(64u, n - w * 64));
             uint64_t waiting = 0, live = 0;
@@ -285,8 +296,12 @@ void runBlock(const Launch& L, unsigned bx, unsigned by, unsigned bz)
                     waiting |= 1ULL << l;
                 }
             }
-            if(waiting && waiting == live && same) { releaseGroup(fibers, base, waiting); progressed = true; }
+            if(waiting && waiting == live && same) {
+                if(shuffled && (progressed || w + 1 < waves) && (nextGarbage(scheduleState) & 1u)) { held = true; continue; }      // (held back this time)
+                releaseGroup(fibers, base, waiting); progressed = true;
+            }
         }
+        if(held && !progressed) continue;                  // (every ready wavefront was held back: toss again)
         // Workgroup barrier: every live work-item waits at it.
         {
             unsigned atBarrier = 0;
