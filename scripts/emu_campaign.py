@@ -2,7 +2,10 @@
 """TEST INFRASTRUCTURE: seeded read sets through the aligner of the EMULATED build (tests/emu) against the oracle, candidate for candidate
 (AlignmentData, the compressed bytes, the ordinals where asked for).   python scripts/emu_campaign.py <first seed> <seeds> [processes]
 Every seed draws its own read count, genome length, read length and MinHash parameters; odd seeds ask for the ordinals.
-CAMPAIGN_LONG=1: a few dozen reads of 3 000 to 7 000 markers each."""
+CAMPAIGN_LONG=1: a few dozen reads of 3 000 to 7 000 markers each.  CAMPAIGN_UL=1: a dozen reads of 9 000 to 16 000 markers (pairs of two long
+reads: the windowed cells class, the sort and wave kernels' largest classes; the match-rate estimate set as a k = 14 alphabet's would be).
+The switches of the build and of the emulator apply as everywhere (SHASTA_MI355X_CELLS_FORCE=long|big, SHASTA_MI355X_SCRAMBLE=1,
+HIPEMU_LDS_SCRAMBLE, HIPEMU_SCHEDULE)."""
 import os
 import sys
 from multiprocessing import Pool
@@ -19,9 +22,14 @@ def one(seed):
     n_reads = int(rng.integers(50, 150))
     genome = int(rng.integers(4000, 16000))
     mean = float(rng.choice([500.0, 900.0, 1600.0]))
+    alphabet = None
     if os.environ.get("CAMPAIGN_LONG") == "1":            # (reads of thousands of markers: the wave kernel's larger capacity classes)
         n_reads, genome, mean = int(rng.integers(24, 48)), int(rng.integers(12000, 30000)), float(rng.choice([3000.0, 5000.0, 7000.0]))
-    toc, kmer = synthetic.marker_reads(n_reads, genome, mean_markers=mean, min_markers=200, seed=seed)
+    if os.environ.get("CAMPAIGN_UL") == "1":
+        n_reads, genome, mean = int(rng.integers(8, 14)), int(rng.integers(24000, 48000)), float(rng.choice([9000.0, 12000.0, 16000.0]))
+        os.environ.setdefault("SHASTA_MI355X_MATCH_SHIFT", "20")
+        alphabet = synthetic.sampled_marker_alphabet(14, count=40000)        # (79 000 ids: few random matches, as at k = 14)
+    toc, kmer = synthetic.marker_reads(n_reads, genome, mean_markers=mean, min_markers=200, seed=seed, alphabet=alphabet)
     data7 = synthetic.pack_markers(toc, kmer)
     orc = bindings.OracleLib()
     emu = L.Library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "emu", "_build", "libshasta_mi355x_emu.so"))

@@ -643,7 +643,9 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
 
     // Wide bands (classes 5-7: few tasks, one wavefront each) go to the side stream, widest first;
     // the narrow classes run on the main stream meanwhile.
-    const bool fork = ws.wide != nullptr && ev != nullptr && (classCounts[5] || classCounts[6] || classCounts[7]);
+    // (SHASTA_MI355X_DP_FORK=0: every class on the main stream -- the A/B switch of the fork, for timing and for the search for order-dependent results.)
+    static const bool forkAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_DP_FORK"); return !(e && e[0] == '0'); }();
+    const bool fork = forkAllowed && ws.wide != nullptr && ev != nullptr && (classCounts[5] || classCounts[6] || classCounts[7]);
     hipStream_t wideStream = fork ? ws.wide : stream;
     if(fork) { HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); }
     // Booked per class: algorithmic bytes 4 (nx + ny) per task, work = DP cells nx x bandWidth (dpSizeKernel's sums).
@@ -2206,7 +2208,9 @@ void bandedDpManyUnit(const uint32_t* kmerIds, uint64_t kmerCount, uint64_t task
     DeviceOptions opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.deltaX = 200; opt.deltaY = 10; opt.maxSkip = opt.maxDrift = opt.maxTrim = ~0ULL; opt.maxBand = 1024;
-    const WorkStream ws{ctx.stream, &ctx.sortWs, nullptr};
+    // (with the side stream a worker of a batch has: the wide-band classes fork to it and join again, as they do in a call)
+    if(!ctx.wideStream[0]) HIP_CHECK(hipStreamCreateWithFlags(&ctx.wideStream[0], hipStreamNonBlocking));
+    const WorkStream ws{ctx.stream, &ctx.sortWs, ctx.wideStream[0]};
     DpEvents ev;
     DpBatchStats stats;
     // The sparse path of an Align4 batch (align4_sparse.hpp) takes its matches from the cells kernel; here the host lists them --
