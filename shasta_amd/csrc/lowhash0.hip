@@ -941,6 +941,7 @@ struct LowHash0Job {
     {
         recKeysA.swap(old.recKeysA); recKeysB.swap(old.recKeysB); pairTagsA.swap(old.pairTagsA); pairTagsB.swap(old.pairTagsB);
         flags.swap(old.flags); pos.swap(old.pos); starts.swap(old.starts); scanTemp32.swap(old.scanTemp32); boundKeys32.swap(old.boundKeys32);
+        statKeysA.swap(old.statKeysA); statKeysB.swap(old.statKeysB);      // (round 6: these two were left out -- allocated and freed by every call, SHASTA_MI355X_LOG_ALLOC=1 on the emulated build showed it)
         recValsA.swap(old.recValsA); recValsB.swap(old.recValsB); pairKeysA.swap(old.pairKeysA); pairKeysB.swap(old.pairKeysB);
         iterKeysA.swap(old.iterKeysA); iterKeysB.swap(old.iterKeysB); pairCounts.swap(old.pairCounts); scanTemp64.swap(old.scanTemp64);
         boundKeys64.swap(old.boundKeys64); boundOut.swap(old.boundOut);
