@@ -396,8 +396,10 @@ void runWithHelpers(const std::function<void()>& work, unsigned helpers, unsigne
     pool.helperDone.wait(lock, [&] { return job.active == 0; });
 }
 
+void countLaunch();
 void launch(const Launch& L)
 {
+    countLaunch();
     const uint64_t blocks = uint64_t(L.grid.x) * L.grid.y * L.grid.z;
     if(blocks == 0 || L.block.x == 0) throw std::runtime_error("hipemu: empty launch configuration");
     static const unsigned maxThreads = [] {
@@ -433,6 +435,18 @@ void launch(const Launch& L)
 // Host runtime.
 // ---------------------------------------------------------------------------
 struct hipemuStream { int dummy; };
+// What the host asked of the runtime so far, by kind (hipemu_api_counts: tests and scripts/emu_api_counts.py read the difference
+// between two points of a run -- synchronisations, copies, launches and allocations per step are the same here as on the device).
+namespace { enum { N_LAUNCH, N_STREAM_SYNC, N_DEVICE_SYNC, N_EVENT_SYNC, N_COPY_H2D, N_COPY_D2H, N_COPY_D2D, N_MEMSET, N_MALLOC, N_FREE, N_HOST_MALLOC, N_HOST_FREE, N_EVENT_RECORD, N_STREAM_WAIT, N_EVENT_CREATE, N_STREAM_CREATE, N_KINDS };
+std::atomic<uint64_t> apiCounts[N_KINDS]; inline void counted(int kind) { apiCounts[kind].fetch_add(1, std::memory_order_relaxed); }
+inline void countedCopy(hipMemcpyKind k) { counted(k == hipMemcpyHostToDevice ? N_COPY_H2D : (k == hipMemcpyDeviceToHost ? N_COPY_D2H : N_COPY_D2D)); } }
+namespace hipemu { void countLaunch() { counted(N_LAUNCH); } }
+extern "C" int hipemu_api_counts(uint64_t* out, int room)
+{
+    for(int k = 0; k < N_KINDS && k < room; k++) out[k] = apiCounts[k].load();
+    return N_KINDS;
+}
+extern "C" const char* hipemu_api_count_names() { return "launch stream_sync device_sync event_sync copy_h2d copy_d2h copy_d2d memset malloc free host_malloc host_free event_record stream_wait_event event_create stream_create"; }
 struct hipemuEvent { std::chrono::steady_clock::time_point t; };
 
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
@@ -449,36 +463,37 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int)
     p->totalGlobalMem = size_t(16) << 30;
     return hipSuccess;
 }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { counted(N_DEVICE_SYNC); return hipSuccess; }
 // Device memory comes back POISONED (0xA5 in every byte): a kernel that reads what no kernel, copy or memset wrote -- which fresh
 // pages of the host, zero by the operating system's doing, would forgive, and a GPU's reused memory does not -- computes nonsense
 // here too.  HIPEMU_NO_POISON=1 leaves the bytes as the allocator gives them.
 hipError_t hipMalloc(void** p, size_t n)
 {
+    counted(N_MALLOC);
     const size_t bytes = (n + 255) / 256 * 256 + 256;
     *p = std::aligned_alloc(256, bytes);
     static const bool poison = [] { const char* e = std::getenv("HIPEMU_NO_POISON"); return !(e && e[0] == '1'); }();
     if(*p && poison) std::memset(*p, 0xA5, bytes);
     return *p ? hipSuccess : hipErrorInvalidValue;
 }
-hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
-hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
-hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if(n) std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if(n) std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipFree(void* p) { counted(N_FREE); std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { counted(N_HOST_MALLOC); *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostFree(void* p) { counted(N_HOST_FREE); std::free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { countedCopy(k); counted(N_STREAM_SYNC); if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { countedCopy(k); if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { counted(N_COPY_D2D); if(n) std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
-hipError_t hipMemset(void* d, int v, size_t n) { if(n) std::memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if(n) std::memset(d, v, n); return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemuStream{0}; return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { counted(N_MEMSET); if(n) std::memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { counted(N_MEMSET); if(n) std::memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { counted(N_STREAM_CREATE); *s = new hipemuStream{0}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{std::chrono::steady_clock::now()}; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { counted(N_STREAM_SYNC); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { counted(N_STREAM_WAIT); return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { counted(N_EVENT_CREATE); *e = new hipemuEvent{std::chrono::steady_clock::now()}; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { counted(N_EVENT_RECORD); e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { counted(N_EVENT_SYNC); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
 {
