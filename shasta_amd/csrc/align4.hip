@@ -644,7 +644,7 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
     // Wide bands (classes 5-7: few tasks, one wavefront each) go to the side stream, widest first;
     // the narrow classes run on the main stream meanwhile.
     // (SHASTA_MI355X_DP_FORK=0: every class on the main stream -- the A/B switch of the fork, for timing and for the search for order-dependent results.)
-    static const bool forkAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_DP_FORK"); return !(e && e[0] == '0'); }();
+    const bool forkAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_DP_FORK"); return !(e && e[0] == '0'); }();       // (read for every batch: tests and searches switch it)
     const bool fork = forkAllowed && ws.wide != nullptr && ev != nullptr && (classCounts[5] || classCounts[6] || classCounts[7]);
     hipStream_t wideStream = fork ? ws.wide : stream;
     if(fork) { HIP_CHECK(hipEventRecord(ev->fork, stream)); HIP_CHECK(hipStreamWaitEvent(ws.wide, ev->fork, 0)); }
