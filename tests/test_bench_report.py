@@ -197,6 +197,28 @@ def test_bench_script_end_to_end_on_the_emulated_build(emu_lib):
     assert census["candidates_changed"] >= census["markerCount_changed"] and census["candidates_changed"] >= census["stored_set_changed"]
 
 
+def test_bench_script_may2022_workload_on_the_emulated_build(emu_lib):
+    """--workload may2022: reads over the k = 14 marker alphabet, conf/Nanopore-May2022.conf's MinHash and Align sections, and
+    Assembler::suppressAlignmentCandidates between the two stages (the host layer's emulated twin)."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    details = os.path.join(tempfile.mkdtemp(), "details.json")
+    host = os.path.join(os.path.dirname(emu_lib.path), "libshasta_mi355x_host_emu.so")
+    env = dict(os.environ, SHASTA_BENCH_LIBRARY=emu_lib.path, SHASTA_BENCH_HOST_LIBRARY=host, SHASTA_BENCH_DETAILS=details)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "100", "--steps", "1", "--warmup", "0", "--workload", "may2022", "--tie-census", "0"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    head = strict_loads(out.stdout.strip().splitlines()[-1])
+    assert "NOT A MEASUREMENT" in head["data"] and "Nanopore-May2022.conf" in head["config"]["workload"] and "k = 14" in head["config"]["workload"]
+    line = strict_loads(open(details).read())
+    parity = line["parity_at_bench_size"]
+    assert parity["lowhash0_equal"] is True and parity["aligner_mismatches"] == 0 and parity["alignment_table_equal"] is True
+    assert parity["candidates_after_suppression"] <= parity["lowhash0_candidates"] and line["config"]["candidates"] == parity["candidates_after_suppression"] > 0
+    assert "candidates_suppressed_between_the_stages" in line["config"]
+
+
 def test_bench_script_two_ranks_on_the_emulated_build(emu_lib):
     """The N > 1 path of the real bench.py as the driver launches it (torch.distributed.run, one process
     per rank): sharded generation, all-gather of the kmer ids, staged LowHash0 with both exchanges,
