@@ -937,6 +937,13 @@ struct LowHash0Job {
     // The device allocations of a finished job (the context keeps it for that): a call does not allocate and free some thirty
     // buffers of hundreds of megabytes between its two events (that was most of the 5 ms between the kernels' 16 ms and the
     // call's 21, and an occasional 40 ms in the second call after a context was made).
+    void scrambleBuffers(hipStream_t stream)
+    {
+        SharedCapacityMember* const all[] = {&recKeysA, &recKeysB, &pairTagsA, &pairTagsB, &flags, &pos, &starts, &scanTemp32, &boundKeys32, &statKeysA, &statKeysB,
+            &recValsA, &recValsB, &pairKeysA, &pairKeysB, &iterKeysA, &iterKeysB, &pairCounts, &scanTemp64, &boundKeys64, &boundOut,
+            &counters, &stats, &sizeHist, &iterationTable, &overflowSizes, &highPerIteration, &totalPerIteration, &candidatesDevice};
+        for(SharedCapacityMember* b : all) b->scramble(stream);
+    }
     void adoptBuffers(LowHash0Job& old)
     {
         recKeysA.swap(old.recKeysA); recKeysB.swap(old.recKeysB); pairTagsA.swap(old.pairTagsA); pairTagsB.swap(old.pairTagsB);
@@ -1164,6 +1171,8 @@ void lowhash0Begin(Context& ctx, const shasta_lowhash0_params& p, int rank, int 
     auto jobPtr = std::make_shared<LowHash0Job>();
     LowHash0Job& job = *jobPtr;
     if(ctx.lowhashBuffers) { job.adoptBuffers(*static_cast<LowHash0Job*>(ctx.lowhashBuffers.get())); ctx.lowhashBuffers.reset(); }
+    // (SHASTA_MI355X_SCRAMBLE=1, a test switch: what the last job left in the buffers this one takes over is overwritten with pseudo-random data)
+    if(const char* e = std::getenv("SHASTA_MI355X_SCRAMBLE")) if(e[0] == '1') { job.scrambleBuffers(ctx.stream); HIP_CHECK(hipStreamSynchronize(ctx.stream)); }
     job.p = p; job.rank = rank; job.world = world;
     job.boundaries.assign(size_t(world) + 1, 0);
     if(readBoundaries) job.boundaries.assign(readBoundaries, readBoundaries + world + 1);
