@@ -409,11 +409,22 @@ void launch(const Launch& L)
     }();
     std::atomic<uint64_t> next(0);
     std::string error;
+    // HIPEMU_SCHEDULE: the workgroups of a launch are handed out in a scattered order (a stride coprime to their number, another one for
+    // every launch) instead of 0, 1, 2 ...: a kernel whose workgroup k relies on workgroup k - 1 having run would show.
+    static const bool scattered = [] { const char* e = std::getenv("HIPEMU_SCHEDULE"); return e && e[0]; }();
+    uint64_t stride = 1, offset = 0;
+    if(scattered && blocks > 2) {
+        uint64_t s = scrambleCounter.fetch_add(1) * 0x9E3779B97F4A7C15ULL + 12345;
+        offset = nextGarbage(s) % blocks;
+        stride = 1 + nextGarbage(s) % (blocks - 1);
+        while(std::__gcd(stride, blocks) != 1) stride = stride % (blocks - 1) + 1;
+    }
     const std::function<void()> work = [&]() {
         try {
             for(;;) {
-                const uint64_t b = next.fetch_add(1);
-                if(b >= blocks) break;
+                const uint64_t ticket = next.fetch_add(1);
+                if(ticket >= blocks) break;
+                const uint64_t b = uint64_t((static_cast<unsigned __int128>(ticket) * stride + offset) % blocks);
                 const unsigned bx = unsigned(b % L.grid.x), by = unsigned((b / L.grid.x) % L.grid.y), bz = unsigned(b / (uint64_t(L.grid.x) * L.grid.y));
                 runBlock(L, bx, by, bz);
             }
