@@ -17,6 +17,25 @@ def test_kmer_ids_of_k_16(gpu_lib, oracle_lib):
     assert config_value_checks.wide_id_range(gpu_lib, oracle_lib, None, k=16, n_reads=160, genome_markers=9000, limit=400) > 100
 
 
+def test_kmer_ids_of_k_16_with_every_scratch_buffer_scrambled(gpu_lib):
+    """The same calls in a process of their own with SHASTA_MI355X_SCRAMBLE=1: every worker's scratch is overwritten with pseudo-random
+    data before every batch, every new device buffer when it is allocated, the buffers a LowHash0 job takes over from the last one too --
+    a kernel that reads what its own batch has not written (what round 5's one unexplained difference in this test was suspected to be)
+    then differs from the oracle at once instead of once in tens of thousands of calls."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r)\n"
+              "from oracle import bindings\nfrom shasta_amd import lib as L\nfrom tests import config_value_checks\n"
+              "lib, orc = L.Library(%r), bindings.OracleLib()\n"
+              "for repeat in range(%d):\n"
+              "    assert config_value_checks.wide_id_range(lib, orc, None, k=16, n_reads=160, genome_markers=9000, limit=400) > 100\n"
+              "print('scrambled: equal to the oracle')\n") % (root, gpu_lib.path, 1 if os.environ.get("SHASTA_EMU") == "1" else 3)
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SHASTA_MI355X_SCRAMBLE="1"), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and "scrambled: equal to the oracle" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_kmer_ids_at_the_top_of_the_32_bit_range(gpu_lib, oracle_lib):
     assert config_value_checks.top_of_the_id_range(gpu_lib, oracle_lib) >= 8
 
