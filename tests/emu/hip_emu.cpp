@@ -16,6 +16,7 @@
 #include <fstream>
 #include <functional>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -445,7 +446,6 @@ void launch(const Launch& L)
 // ---------------------------------------------------------------------------
 // Host runtime.
 // ---------------------------------------------------------------------------
-struct hipemuStream { int dummy; };
 // What the host asked of the runtime so far, by kind (hipemu_api_counts: tests and scripts/emu_api_counts.py read the difference
 // between two points of a run -- synchronisations, copies, launches and allocations per step are the same here as on the device).
 namespace { enum { N_LAUNCH, N_STREAM_SYNC, N_DEVICE_SYNC, N_EVENT_SYNC, N_COPY_H2D, N_COPY_D2H, N_COPY_D2D, N_MEMSET, N_MALLOC, N_FREE, N_HOST_MALLOC, N_HOST_FREE, N_EVENT_RECORD, N_STREAM_WAIT, N_EVENT_CREATE, N_STREAM_CREATE, N_KINDS };
@@ -458,7 +458,111 @@ extern "C" int hipemu_api_counts(uint64_t* out, int room)
     return N_KINDS;
 }
 extern "C" const char* hipemu_api_count_names() { return "launch stream_sync device_sync event_sync copy_h2d copy_d2h copy_d2d memset malloc free host_malloc host_free event_record stream_wait_event event_create stream_create"; }
-struct hipemuEvent { std::chrono::steady_clock::time_point t; };
+
+// Streams and events.  Default: every launch and copy completes before its call returns (streams and events order nothing because
+// nothing is ever pending).  HIPEMU_ASYNC=<seed>: the work WAITS in its stream's queue, as it does on the device, and runs as late as
+// the host's own synchronisation allows -- when the stream, an event recorded behind it or the device is synchronised, when something
+// that waits for one of its events has to run, when memory is freed -- with the other streams' queues drained up to a random point
+// first.  A kernel that reads what another stream has not been told to finish, a host read of a result before the synchronisation
+// that delivers it, a pinned source overwritten while its copy is pending: each answers differently from the oracle here, where the
+// immediate mode (and, most of the time, the device) forgives it.  Copies from pageable host memory are staged at the call and
+// copies to pageable host memory complete before the call returns, as the runtime does it; pinned memory is read and written
+// when the copy runs.
+struct hipemuEvent {
+    std::chrono::steady_clock::time_point t;
+    uint64_t recorded = 0, completed = 0;       // record calls so far; the last one that has run
+    hipemuStream* stream = nullptr;             // where the last record waits
+};
+namespace {
+struct Op {
+    std::function<void()> run;
+    hipemuEvent* records = nullptr; uint64_t recordId = 0;
+    hipemuEvent* waitsFor = nullptr; uint64_t waitId = 0;
+};
+}
+struct hipemuStream { std::deque<Op> queue; };
+namespace {
+const uint64_t asyncSeed = [] { const char* e = std::getenv("HIPEMU_ASYNC"); return e && e[0] && !(e[0] == '0' && !e[1]) ? std::strtoull(e, nullptr, 0) + 1 : 0; }();
+std::recursive_mutex deviceMutex;               // queues, events, and the one kernel or copy that runs at a time in this mode
+std::vector<hipemuStream*> allStreams;
+hipemuStream nullStream;
+uint64_t asyncState = asyncSeed * 0x9E3779B97F4A7C15ULL + 1;
+std::vector<std::pair<const char*, size_t>> pinnedRanges;
+std::mutex pinnedMutex;
+bool isPinned(const void* p)
+{
+    std::lock_guard<std::mutex> lock(pinnedMutex);
+    for(const auto& r : pinnedRanges) if(static_cast<const char*>(p) >= r.first && static_cast<const char*>(p) < r.first + r.second) return true;
+    return false;
+}
+hipemuStream* streamOf(hipStream_t s) { return s ? s : &nullStream; }
+void runFront(hipemuStream* s, int depth);
+// Runs the stream's queue until `count` operations are left in it.
+void drainTo(hipemuStream* s, size_t left, int depth = 0)
+{
+    if(depth > 64) { std::fprintf(stderr, "hipemu: HIPEMU_ASYNC: streams wait for each other's events in a circle\n"); std::abort(); }
+    while(s->queue.size() > left) runFront(s, depth);
+}
+void runFront(hipemuStream* s, int depth)
+{
+    Op op = std::move(s->queue.front());
+    s->queue.pop_front();
+    if(op.waitsFor && op.waitsFor->completed < op.waitId) {
+        // The record it waits for is still in another stream's queue: that stream runs up to it first.
+        hipemuStream* other = op.waitsFor->stream;
+        while(other && other != s && op.waitsFor->completed < op.waitId && !other->queue.empty()) runFront(other, depth + 1);
+    }
+    if(op.run) op.run();
+    if(op.records) { op.records->completed = std::max(op.records->completed, op.recordId); op.records->t = std::chrono::steady_clock::now(); }
+}
+// Before a synchronisation delivers one stream's work, the others run up to a random point of their queues: the interleaving changes
+// from call to call with the seed, and what is not asked for stays pending.
+void disturbOthers(hipemuStream* except)
+{
+    for(hipemuStream* s : allStreams) {
+        if(s == except || s->queue.empty()) continue;
+        const uint64_t r = hipemu::nextGarbage(asyncState);
+        if(r & 1u) drainTo(s, size_t((r >> 8) % (s->queue.size() + 1)));
+    }
+}
+void enqueue(hipStream_t stream, Op op)
+{
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    hipemuStream* s = streamOf(stream);
+    if(op.records) op.records->stream = s;
+    s->queue.push_back(std::move(op));
+}
+void synchronizeStream(hipStream_t stream)
+{
+    if(!asyncSeed) return;
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    disturbOthers(streamOf(stream));
+    drainTo(streamOf(stream), 0);
+}
+void synchronizeDevice()
+{
+    if(!asyncSeed) return;
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    // (in a random order of the streams; a stream that waits for another's event pulls that one along)
+    std::vector<hipemuStream*> order(allStreams);
+    order.push_back(&nullStream);
+    for(size_t k = order.size(); k > 1; k--) std::swap(order[k - 1], order[hipemu::nextGarbage(asyncState) % k]);
+    for(hipemuStream* s : order) drainTo(s, 0);
+}
+}  // namespace
+
+namespace hipemu {
+void launchOn(hipStream_t stream, const Launch& L, void* (*copy)(const void*), void (*destroy)(void*))
+{
+    if(!asyncSeed) { launch(L); return; }
+    countLaunch();
+    Launch own = L;
+    own.args = copy(L.args);
+    Op op;
+    op.run = [own, destroy]() { try { launch(own); } catch(...) { destroy(own.args); throw; } destroy(own.args); };
+    enqueue(stream, std::move(op));
+}
+}  // namespace hipemu
 
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 hipError_t hipGetLastError() { return hipSuccess; }
@@ -474,7 +578,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int)
     p->totalGlobalMem = size_t(16) << 30;
     return hipSuccess;
 }
-hipError_t hipDeviceSynchronize() { counted(N_DEVICE_SYNC); return hipSuccess; }
+hipError_t hipDeviceSynchronize() { counted(N_DEVICE_SYNC); synchronizeDevice(); return hipSuccess; }
 // Device memory comes back POISONED (0xA5 in every byte): a kernel that reads what no kernel, copy or memset wrote -- which fresh
 // pages of the host, zero by the operating system's doing, would forgive, and a GPU's reused memory does not -- computes nonsense
 // here too.  HIPEMU_NO_POISON=1 leaves the bytes as the allocator gives them.
@@ -487,27 +591,125 @@ hipError_t hipMalloc(void** p, size_t n)
     if(*p && poison) std::memset(*p, 0xA5, bytes);
     return *p ? hipSuccess : hipErrorInvalidValue;
 }
-hipError_t hipFree(void* p) { counted(N_FREE); std::free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { counted(N_HOST_MALLOC); *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
-hipError_t hipHostFree(void* p) { counted(N_HOST_FREE); std::free(p); return hipSuccess; }
-hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { countedCopy(k); counted(N_STREAM_SYNC); if(n) std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { countedCopy(k); if(n) std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { counted(N_COPY_D2D); if(n) std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipFree(void* p) { counted(N_FREE); synchronizeDevice(); std::free(p); return hipSuccess; }       // (hipFree waits for the device)
+hipError_t hipHostMalloc(void** p, size_t n, unsigned)
+{
+    counted(N_HOST_MALLOC);
+    *p = std::malloc(n ? n : 1);
+    if(*p) { std::lock_guard<std::mutex> lock(pinnedMutex); pinnedRanges.emplace_back(static_cast<const char*>(*p), n ? n : 1); }
+    return *p ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipHostFree(void* p)
+{
+    counted(N_HOST_FREE);
+    synchronizeDevice();
+    { std::lock_guard<std::mutex> lock(pinnedMutex); for(size_t k = 0; k < pinnedRanges.size(); k++) if(pinnedRanges[k].first == p) { pinnedRanges.erase(pinnedRanges.begin() + long(k)); break; } }
+    std::free(p);
+    return hipSuccess;
+}
+namespace {
+hipError_t copyOn(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t stream, bool blocking)
+{
+    countedCopy(k);
+    if(!asyncSeed) { if(n) std::memmove(d, s, n); return hipSuccess; }
+    const bool fromHost = k == hipMemcpyHostToDevice || (k == hipMemcpyDefault && false);
+    const bool toHost = k == hipMemcpyDeviceToHost;
+    Op op;
+    if(fromHost && !isPinned(s)) {
+        // pageable source: staged now, delivered when the stream gets there
+        std::shared_ptr<std::vector<char>> staged = std::make_shared<std::vector<char>>(static_cast<const char*>(s), static_cast<const char*>(s) + n);
+        op.run = [d, staged]() { if(!staged->empty()) std::memcpy(d, staged->data(), staged->size()); };
+    } else {
+        op.run = [d, s, n]() { if(n) std::memmove(d, s, n); };
+    }
+    enqueue(stream, std::move(op));
+    if(blocking || (toHost && !isPinned(d))) synchronizeStream(stream);      // (a copy to pageable memory is complete when the call returns)
+    return hipSuccess;
+}
+}
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { counted(N_STREAM_SYNC); return copyOn(d, s, n, k, nullptr, true); }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t stream) { return copyOn(d, s, n, k, stream, false); }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t stream) { return copyOn(d, s, n, hipMemcpyDeviceToDevice, stream, false); }
 hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
-hipError_t hipMemset(void* d, int v, size_t n) { counted(N_MEMSET); if(n) std::memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { counted(N_MEMSET); if(n) std::memset(d, v, n); return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { counted(N_STREAM_CREATE); *s = new hipemuStream{0}; return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { counted(N_STREAM_SYNC); return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { counted(N_STREAM_WAIT); return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t* e) { counted(N_EVENT_CREATE); *e = new hipemuEvent{std::chrono::steady_clock::now()}; return hipSuccess; }
-hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { counted(N_EVENT_RECORD); e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { counted(N_EVENT_SYNC); return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+namespace {
+hipError_t memsetOn(void* d, int v, size_t n, hipStream_t stream, bool blocking)
+{
+    counted(N_MEMSET);
+    if(!asyncSeed) { if(n) std::memset(d, v, n); return hipSuccess; }
+    Op op;
+    op.run = [d, v, n]() { if(n) std::memset(d, v, n); };
+    enqueue(stream, std::move(op));
+    if(blocking) synchronizeStream(stream);
+    return hipSuccess;
+}
+}
+hipError_t hipMemset(void* d, int v, size_t n) { return memsetOn(d, v, n, nullptr, true); }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t stream) { return memsetOn(d, v, n, stream, false); }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned)
+{
+    counted(N_STREAM_CREATE);
+    *s = new hipemuStream;
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    allStreams.push_back(*s);
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s)
+{
+    synchronizeStream(s);
+    { std::lock_guard<std::recursive_mutex> lock(deviceMutex); allStreams.erase(std::remove(allStreams.begin(), allStreams.end(), s), allStreams.end()); }
+    delete s;
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) { counted(N_STREAM_SYNC); synchronizeStream(s); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    counted(N_STREAM_WAIT);
+    if(!asyncSeed) return hipSuccess;
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    Op op;
+    op.waitsFor = e; op.waitId = e->recorded;          // (the record made last BEFORE this call: a later one does not count)
+    enqueue(s, std::move(op));
+    return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t* e) { counted(N_EVENT_CREATE); *e = new hipemuEvent; (*e)->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e)
+{
+    if(asyncSeed) { std::lock_guard<std::recursive_mutex> lock(deviceMutex); if(e->stream && e->completed < e->recorded) drainTo(e->stream, 0); }
+    delete e;
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
+{
+    counted(N_EVENT_RECORD);
+    if(!asyncSeed) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    Op op;
+    op.records = e; op.recordId = ++e->recorded;
+    enqueue(s, std::move(op));
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e)
+{
+    counted(N_EVENT_SYNC);
+    if(!asyncSeed) return hipSuccess;
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    const uint64_t want = e->recorded;
+    if(e->completed < want && e->stream) { disturbOthers(e->stream); while(e->completed < want && !e->stream->queue.empty()) runFront(e->stream, 0); }
+    return hipSuccess;
+}
+hipError_t hipEventQuery(hipEvent_t e)
+{
+    if(!asyncSeed) return hipSuccess;
+    std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+    return e->completed >= e->recorded ? hipSuccess : hipErrorNotReady;
+}
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
 {
+    if(asyncSeed) {
+        std::lock_guard<std::recursive_mutex> lock(deviceMutex);
+        if(a->completed < a->recorded || b->completed < b->recorded) return hipErrorNotReady;
+    }
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }

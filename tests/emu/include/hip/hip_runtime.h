@@ -57,6 +57,7 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr hipError_t hipErrorInvalidValue = 1;
+constexpr hipError_t hipErrorNotReady = 600;
 constexpr hipError_t hipErrorPeerAccessAlreadyEnabled = 704;
 constexpr hipError_t hipErrorLaunchFailure = 719;
 typedef struct hipemuStream* hipStream_t;
@@ -127,6 +128,8 @@ struct Launch {
     void* args;
 };
 void launch(const Launch&);
+// HIPEMU_ASYNC (hip_emu.cpp): the launch waits in its stream's queue; `copy` makes the arguments outlive the caller's frame.
+void launchOn(hipStream_t stream, const Launch&, void* (*copy)(const void*), void (*destroy)(void*));
 
 template<class T> __forceinline__ uint64_t toBits(T v)
 {
@@ -143,13 +146,12 @@ template<class T> __forceinline__ T fromBits(uint64_t b) { T v; std::memcpy(&v, 
 #define gridDim (hipemu::cur->gDim)
 
 template<class... P, class... A>
-void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t dynamicLdsBytes, hipStream_t, A&&... a)
+void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t dynamicLdsBytes, hipStream_t stream, A&&... a)
 {
-    std::tuple<std::decay_t<P>...> args{static_cast<std::decay_t<P>>(a)...};
-    struct Call { void (*kernel)(P...); std::tuple<std::decay_t<P>...>* args; } call{kernel, &args};
+    struct Call { void (*kernel)(P...); std::tuple<std::decay_t<P>...> args; } call{kernel, std::tuple<std::decay_t<P>...>{static_cast<std::decay_t<P>>(a)...}};
     hipemu::Launch l{grid, block, dynamicLdsBytes,
-        [](void* p) { Call* c = static_cast<Call*>(p); std::apply(c->kernel, *c->args); }, &call};
-    hipemu::launch(l);
+        [](void* p) { Call* c = static_cast<Call*>(p); std::apply(c->kernel, c->args); }, &call};
+    hipemu::launchOn(stream, l, [](const void* p) -> void* { return new Call(*static_cast<const Call*>(p)); }, [](void* p) { delete static_cast<Call*>(p); });
 }
 
 // ---------------------------------------------------------------------------
