@@ -2,7 +2,7 @@
 """TEST INFRASTRUCTURE: what one steady-state step asks of the HIP runtime -- launches, synchronisations, copies, allocations -- counted by
 the emulated runtime (tests/emu/hip_emu.cpp: hipemu_api_counts) while the unmodified host code of shasta_amd/csrc drives it.  The host
 code does not know it is emulated: the counts per batch are those of a run on the device (their cost is not: that is the device's).
-    python scripts/emu_api_counts.py [reads] [workers]"""
+    python scripts/emu_api_counts.py [reads] [workers] [path of another emulated build's .so]"""
 import ctypes as C
 import os
 import sys
@@ -11,12 +11,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 def main():
-    reads = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-    if len(sys.argv) > 2:
-        os.environ["SHASTA_MI355X_ALIGN_WORKERS"] = sys.argv[2]
+    numbers = [a for a in sys.argv[1:] if not a.endswith(".so")]
+    path = next((a for a in sys.argv[1:] if a.endswith(".so")), os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "emu", "_build", "libshasta_mi355x_emu.so"))
+    reads = int(numbers[0]) if numbers else 400
+    if len(numbers) > 1:
+        os.environ["SHASTA_MI355X_ALIGN_WORKERS"] = numbers[1]
     from shasta_amd import abi, lib as L
     from tests import support
-    emu = L.Library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "emu", "_build", "libshasta_mi355x_emu.so"))
+    emu = L.Library(path)
     raw = emu.lib
     raw.hipemu_api_count_names.restype = C.c_char_p
     names = raw.hipemu_api_count_names().decode().split()

@@ -155,6 +155,7 @@ struct BatchScratch {
     DeviceBuffer<DpControl> dpControl;
     DeviceBuffer<DpEnd> ends;
     PinnedBuffer pinRows, pinToc, pinBytes, pinStatus, pinOrdToc, pinOrdinals;   // device-to-host staging
+    PinnedBuffer pinTotals;                                                      // the few numbers a batch's host code waits for at its end, in ONE synchronisation (a copy to pageable memory blocks by itself)
     DeviceBuffer<uint64_t> bigOffsets;
     DeviceBuffer<PairDesc> dsPairs;             // align method 3, step 1: the down-sampled pairs
     DeviceBuffer<DpTask> tasks1;                //                         and their (unbanded) DP tasks
@@ -1360,6 +1361,8 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         auto phaseMs = [&](std::chrono::steady_clock::time_point from) { return std::chrono::duration<double, std::milli>(phaseClock() - from).count(); };
         double phaseCells = 0., phaseDp = 0., phaseFinish = 0.;
         uint32_t taskCount = 0, wideCount = 0;
+        bool tieCounterWanted = false;                 // (the batch has DP tasks of method 4: two components of a candidate may tie)
+        uint32_t tieTasks = 0;
         std::vector<int> pairClass;                    // method 4: the table class of every candidate's cells (CELLS_CLASSES: HBM scratch)
         std::vector<uint8_t> pairSlotsLog2;            //           ... and the table size the HBM-scratch kernel last ran it with
         std::vector<uint8_t> pairNoGrid;               //           ... and whether its cells were counted in the packed table because a byte of its grid overflowed
@@ -1799,10 +1802,11 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
                     (const unsigned long long*)b.pairBest.data(), b.pairWinner.data(), b.pairTie.data(), b.counters.data() + 12));
             HIP_CHECK(hipGetLastError());
             // Candidates whose best components tie on markerCount: the reference's component order decides (method 4 only:
-            // method 3 has one alignment per candidate).
-            if(!m3 && readDevice(b.counters.data() + 12, stream) != 0) {
-                resolveComponentTies(ctx, ws, b, n, allTasks, hostPairs, pairClass, pairSlotsLog2, pairNoGrid, opt, cellsMagicX, cellsMagicY);
-            }
+            // method 3 has one alignment per candidate).  Whether there is one comes with the batch's totals below (round 6: it was
+            // a synchronisation of its own between the DP and the filters); the rare batch that has one resolves it then and runs
+            // the filters again.
+            tieCounterWanted = !m3;
+            tieTasks = allTasks;
         } else {
             b.results.reserve(1, stream); b.ordScratch.reserve(2, stream);
             b.sparseStateTasks = 0; b.streamsInLists = false;
@@ -1811,6 +1815,10 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(debugPhases) { HIP_CHECK(hipStreamSynchronize(stream)); phaseDp = phaseMs(phaseStart) - phaseCells; }
         // K11.
         const unsigned gp = divUp(uint64_t(n) + 1, 256);
+        const unsigned gw = divUp((uint64_t(n) + 1) * WAVE, 256);
+        uint32_t storedCount = 0;
+        uint64_t ordTotalOut = 0, byteTotal = 0;
+        for(int attempt = 0; ; attempt++) {
         const KernelTimers::Span finalizeSpan = ctx.timers.begin("finalizeKernel + scans", stream);
         hipLaunchKernelGGL(finalizeKernel, dim3(gp), dim3(256), 0, stream,
             (const PairDesc*)b.pairs.data(), (const shasta_oriented_read_pair*)b.candidates.data(), n,
@@ -1823,14 +1831,22 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         // (the sizes of the compressed alignments were counted by dpMetricsKernel in its pass over the pairs)
         exclusiveScan<uint64_t>(b.sizes.data(), b.sizes.data(), uint64_t(n) + 1, b.scanTemp64.data(), stream);
         (void)ctx.timers.end(finalizeSpan, 64ULL * n, n);
-        const unsigned gw = divUp((uint64_t(n) + 1) * WAVE, 256);
         HIP_CHECK(hipGetLastError());
-        uint32_t storedCount = 0;
-        uint64_t ordTotalOut = 0, byteTotal = 0;
-        HIP_CHECK(hipMemcpyAsync(&storedCount, b.storedIndex.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(&ordTotalOut, b.ordCounts.data() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(&byteTotal, b.sizes.data() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));          // (one synchronisation for the three totals)
+        // The three totals and the tie counter into page-locked memory, one synchronisation for all four.
+        uint64_t* const totals = static_cast<uint64_t*>(b.pinTotals.reserve(4 * sizeof(uint64_t)));
+        totals[0] = totals[1] = totals[2] = totals[3] = 0;
+        HIP_CHECK(hipMemcpyAsync(&totals[0], b.storedIndex.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&totals[1], b.ordCounts.data() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&totals[2], b.sizes.data() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        if(tieCounterWanted) HIP_CHECK(hipMemcpyAsync(&totals[3], b.counters.data() + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if(tieCounterWanted && uint32_t(totals[3]) != 0 && attempt == 0) {
+            resolveComponentTies(ctx, ws, b, n, tieTasks, hostPairs, pairClass, pairSlotsLog2, pairNoGrid, opt, cellsMagicX, cellsMagicY);
+            continue;                                     // (the filters and the scans once more, on the winners as they are now)
+        }
+        storedCount = uint32_t(totals[0]); ordTotalOut = totals[1]; byteTotal = totals[2];
+        break;
+        }
         uint8_t* const bytesPlace = publishSizes(batchIndex, storedCount, byteTotal, wantOrdinals ? ordTotalOut : 0);
         b.bytes.reserve(byteTotal + 1, stream);
         const KernelTimers::Span writeSpan = ctx.timers.begin("compressWriteKernel", stream);
@@ -1880,7 +1896,6 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
             out.ordToc.assign(static_cast<const uint64_t*>(pinOrdToc), static_cast<const uint64_t*>(pinOrdToc) + uint64_t(n) + 1);
             out.ordinals.assign(static_cast<const uint32_t*>(pinOrdinals), static_cast<const uint32_t*>(pinOrdinals) + 2 * ordTotalOut);
         }
-        HIP_CHECK(hipStreamSynchronize(stream));
         // CSR of CompressedAlignments: end offset of each stored alignment, relative to this batch.
         out.tocEnds.resize(storedCount);
         for(uint32_t k = 0; k < storedCount; k++) out.tocEnds[k] = (k + 1 < storedCount ? hostToc64[k + 1] : byteTotal);

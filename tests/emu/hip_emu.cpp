@@ -448,7 +448,7 @@ void launch(const Launch& L)
 // ---------------------------------------------------------------------------
 // What the host asked of the runtime so far, by kind (hipemu_api_counts: tests and scripts/emu_api_counts.py read the difference
 // between two points of a run -- synchronisations, copies, launches and allocations per step are the same here as on the device).
-namespace { enum { N_LAUNCH, N_STREAM_SYNC, N_DEVICE_SYNC, N_EVENT_SYNC, N_COPY_H2D, N_COPY_D2H, N_COPY_D2D, N_MEMSET, N_MALLOC, N_FREE, N_HOST_MALLOC, N_HOST_FREE, N_EVENT_RECORD, N_STREAM_WAIT, N_EVENT_CREATE, N_STREAM_CREATE, N_KINDS };
+namespace { enum { N_LAUNCH, N_STREAM_SYNC, N_DEVICE_SYNC, N_EVENT_SYNC, N_COPY_H2D, N_COPY_D2H, N_COPY_D2D, N_MEMSET, N_MALLOC, N_FREE, N_HOST_MALLOC, N_HOST_FREE, N_EVENT_RECORD, N_STREAM_WAIT, N_EVENT_CREATE, N_STREAM_CREATE, N_COPY_D2H_PAGEABLE, N_KINDS };
 std::atomic<uint64_t> apiCounts[N_KINDS]; inline void counted(int kind) { apiCounts[kind].fetch_add(1, std::memory_order_relaxed); }
 inline void countedCopy(hipMemcpyKind k) { counted(k == hipMemcpyHostToDevice ? N_COPY_H2D : (k == hipMemcpyDeviceToHost ? N_COPY_D2H : N_COPY_D2D)); } }
 namespace hipemu { void countLaunch() { counted(N_LAUNCH); } }
@@ -457,7 +457,7 @@ extern "C" int hipemu_api_counts(uint64_t* out, int room)
     for(int k = 0; k < N_KINDS && k < room; k++) out[k] = apiCounts[k].load();
     return N_KINDS;
 }
-extern "C" const char* hipemu_api_count_names() { return "launch stream_sync device_sync event_sync copy_h2d copy_d2h copy_d2d memset malloc free host_malloc host_free event_record stream_wait_event event_create stream_create"; }
+extern "C" const char* hipemu_api_count_names() { return "launch stream_sync device_sync event_sync copy_h2d copy_d2h copy_d2d memset malloc free host_malloc host_free event_record stream_wait_event event_create stream_create copy_d2h_to_pageable_memory"; }
 
 // Streams and events.  Default: every launch and copy completes before its call returns (streams and events order nothing because
 // nothing is ever pending).  HIPEMU_ASYNC=<seed>: the work WAITS in its stream's queue, as it does on the device, and runs as late as
@@ -611,11 +611,16 @@ namespace {
 hipError_t copyOn(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t stream, bool blocking)
 {
     countedCopy(k);
+    if(k == hipMemcpyDeviceToHost && !isPinned(d)) counted(N_COPY_D2H_PAGEABLE);      // (these block the calling thread by themselves)
     if(!asyncSeed) { if(n) std::memmove(d, s, n); return hipSuccess; }
     const bool fromHost = k == hipMemcpyHostToDevice || (k == hipMemcpyDefault && false);
     const bool toHost = k == hipMemcpyDeviceToHost;
     Op op;
-    if(fromHost && !isPinned(s)) {
+    // (HIPEMU_ASYNC_STAGE=0: a pageable source is NOT staged but read when the copy runs, as the runtime does when it pins a large
+    // source in place instead: host code that reuses or frees the source before a synchronisation then shows -- under AddressSanitizer
+    // as a use after free)
+    static const bool stage = [] { const char* e = std::getenv("HIPEMU_ASYNC_STAGE"); return !(e && e[0] == '0'); }();
+    if(fromHost && stage && !isPinned(s)) {
         // pageable source: staged now, delivered when the stream gets there
         std::shared_ptr<std::vector<char>> staged = std::make_shared<std::vector<char>>(static_cast<const char*>(s), static_cast<const char*>(s) + n);
         op.run = [d, staged]() { if(!staged->empty()) std::memcpy(d, staged->data(), staged->size()); };
@@ -661,7 +666,20 @@ hipError_t hipStreamDestroy(hipStream_t s)
     delete s;
     return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t s) { counted(N_STREAM_SYNC); synchronizeStream(s); return hipSuccess; }
+// HIPEMU_TRACE_SYNC=1: where the host synchronises from -- "hipemu: sync <offset in the library>" on stderr, for addr2line (scripts/emu_api_counts.py
+// counts them; this says which they are).
+hipError_t hipStreamSynchronize(hipStream_t s)
+{
+    counted(N_STREAM_SYNC);
+    static const bool trace = [] { const char* e = std::getenv("HIPEMU_TRACE_SYNC"); return e && e[0] == '1'; }();
+    if(trace) {
+        void* const from = __builtin_return_address(0);
+        Dl_info info;
+        if(dladdr(from, &info) && info.dli_fbase) std::fprintf(stderr, "hipemu: sync %#zx\n", size_t(static_cast<char*>(from) - static_cast<char*>(info.dli_fbase)));
+    }
+    synchronizeStream(s);
+    return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
     counted(N_STREAM_WAIT);
