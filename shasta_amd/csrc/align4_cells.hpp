@@ -27,6 +27,13 @@ constexpr int CELLS_WIDE_COUNTER = 13;     // taskCount[13]: components of more 
 
 __device__ __forceinline__ uint32_t hash32(uint32_t k) { return k * 2654435761u; }
 
+// A word of LDS that other lanes change by atomics, read NOW (the compiler must not reuse an earlier value): a relaxed atomic
+// load, which stays a ds_read_b32.  A `volatile` access does not -- the address-space inference leaves volatile accesses
+// alone, so `*(volatile uint32_t*)&cells[k]` was a flat_load_dword sc0 sc1 followed by s_waitcnt vmcnt(0) lgkmcnt(0): a trip
+// through the flat path that also waited for every global load in flight (the next round's markers), once per counted slot,
+// in rounds 2 and 3 alike (found in the ISA, scripts/isa_loop.py does not tell the two apart).
+__device__ __forceinline__ uint32_t ldsLoadNow(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+
 // getxy, src/Align4.cpp:184-191 (int32, C++ truncating division).
 __device__ __forceinline__ void getxy(uint32_t X, uint32_t Y, uint32_t nx, int32_t& x, int32_t& y)
 {
@@ -115,6 +122,9 @@ align4CellsKernel(
         }
         __syncthreads();
         for(uint32_t x = tid; x < nx; x += CELLS_THREADS) {
+            // (The candidate runs again in a larger table, or is reported, whatever else is counted; and every further match of a
+            // FULL table walks all of it -- `slots` compare-and-swaps in device memory each -- before saying so again.)
+            if(ldsLoadNow(&sOverflow) != 0u) break;
             const uint32_t k = p0[x];
             uint32_t slot = hash32(k) >> (32 - MATCH_SLOTS_LOG2);
             for(;;) {
@@ -394,12 +404,6 @@ __device__ __forceinline__ void waveLdsSync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// A word of LDS that other lanes change by atomics, read NOW (the compiler must not reuse an earlier value): a relaxed atomic
-// load, which stays a ds_read_b32.  A `volatile` access does not -- the address-space inference leaves volatile accesses
-// alone, so `*(volatile uint32_t*)&cells[k]` was a flat_load_dword sc0 sc1 followed by s_waitcnt vmcnt(0) lgkmcnt(0): a trip
-// through the flat path that also waited for every global load in flight (the next round's markers), once per counted slot,
-// in rounds 2 and 3 alike (found in the ISA, scripts/isa_loop.py does not tell the two apart).
-__device__ __forceinline__ uint32_t ldsLoadNow(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 
 // Buckets of the exact table per marker the tabled read may have (log2): 2 NA buckets, load factor below 1/2 (the loop over
 // a bucket's entries runs as long as the fullest bucket among a round's 256 markers: 3.7 trips per round at 100 k reads).
@@ -804,6 +808,7 @@ __device__ __forceinline__ void cellsChunkBody(
         const uint32_t* __restrict__ stream = kmerIds + (swapped ? pd.begin0 : pd.begin1);
         const uint32_t streamCount = swapped ? nx : ny;
         int overflow = 0, reason = 0;
+        bool gaveUp = false;                                       // wave-uniform: the candidate's cell table is full (see drain)
 
         // When the candidate's whole cell grid fits the wavefront's cell region as one BYTE per cell (nx + ny up to about 4000
         // at the default cell size: nearly every candidate of the first class), the entries are counted in a direct grid: one LDS
@@ -949,7 +954,13 @@ __device__ __forceinline__ void cellsChunkBody(
         uint32_t* const queue = ownKept + MAXC;
         const uint32_t queueCapacity = uint32_t(cellsQueueWords(Q));
         uint32_t queued = 0;                                                    // wave-uniform
+        // (A candidate whose cell table is full climbs to a larger one whatever else is counted -- PAIR_RESOURCE below -- and every
+        // further match would walk the WHOLE table before saying so again: SC probes per drained match, 36 s per candidate of two
+        // repeat-rich reads of 10 000 markers on the emulated build, real reads at k = 10.  The wavefront that has seen it, and in
+        // the windowed class every wavefront of the candidate through the slot's word, stops counting and streaming.)
         auto drain = [&]() {
+            if(!gaveUp && LONG && (ldsLoadNow(&scratch[4]) & 0x18u) != 0u) gaveUp = true;
+            if(gaveUp) { queued = 0; return; }
             waveLdsSync();
             uint32_t listAt = 0;
             if(listHits) {
@@ -969,11 +980,17 @@ __device__ __forceinline__ void cellsChunkBody(
                     if(listHits && hit[k] && listAt + at < hitCapacity) hitList[listAt + at] = swapped ? ((ts[k] << 16) | ti[k]) : ((ti[k] << 16) | ts[k]);
                 }
                 if(SHASTA_ABLATE != 4) countHits(std::integral_constant<int, CELLS_DRAIN>{}, hit, ti, ts);
+                if(__any(overflow != 0)) {
+                    gaveUp = true;
+                    if(LONG && lane == 0) atomicOr(&scratch[4], 0x08u);          // (which lane saw it and why follows at the end of the stream)
+                    break;
+                }
             }
             waveLdsSync();
             queued = 0;
         };
         for(uint32_t s0 = firstRound; s0 < (SHASTA_ABLATE == 2 ? 0u : streamCount); s0 += roundStride) {
+            if(gaveUp) break;                                                   // (wave-uniform; the barriers are outside this loop)
             SUBPHASE_START(); SUBPHASE_COUNT(4);
             // first[u], left[u]: the entries of marker u's bucket that have not been looked at; wanted[u]: its hash bits.
             uint32_t first[CELLS_UNROLL], left[CELLS_UNROLL], wanted[CELLS_UNROLL], ts[CELLS_UNROLL];

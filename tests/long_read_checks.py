@@ -70,6 +70,32 @@ def both_long(lib, oracle_lib, ref_lib=None, alphabet_size=None, seed=66, **kw):
             "dense_because": {name: int(r["launches"]) for name, r in rows.items() if name.startswith("dense DP because")}, "rows": rows}
 
 
+def full_tables(lib, oracle_lib, ref_lib=None, lengths=(8600, 9100), alphabet_size=400, seed=71):
+    """Repeat-rich pairs of two long reads (a few hundred distinct marker ids: every cell of the alignment matrix collects matches, as
+    between real reads at k = 10): the windowed class's cell table fills, the candidate climbs to the kernel with its tables in device
+    memory, whose first tables fill as well.  A full table ends the candidate's counting there and then (round 6: every further match
+    walked the whole table before saying so again -- 36 s per candidate on the emulated build, `slots` compare-and-swaps in device
+    memory per match in the HBM-scratch kernel); what is checked is that the climb still ends in the reference's answer."""
+    toc, kmer, data7 = long_read_set(seed=seed, lengths=lengths, genome_markers=int(1.3 * max(lengths)), alphabet_size=alphabet_size)
+    n_reads = (len(toc) - 1) // 2
+    cand = adversarial.all_pairs(n_reads)
+    o = abi.default_align4_options(**UL_ALIGN)
+    x = oracle_lib.align4_batch(toc, data7, cand, o, want_ordinals=True, threads=0)
+    with lib.context(0) as ctx:
+        ctx.set_markers(toc, data7)
+        ctx.kernel_table_reset()
+        y = ctx.align4(cand, o, want_ordinals=True)
+        rows = kernel_rows(ctx)
+    ties = (x.status & 0x80) != 0
+    assert x.per_candidate(~ties) == y.per_candidate(~ties)
+    if ref_lib is not None:
+        support.same_align(ref_lib.align4_batch(toc, data7, cand, o, want_ordinals=True), y)
+    return {"candidates": len(cand),
+            "windowed_launches": int(sum(r["launches"] for name, r in rows.items() if name.startswith("align4CellsLongKernel"))),
+            "hbm_scratch_launches": int(sum(r["launches"] for name, r in rows.items() if name.startswith("align4CellsKernel"))),
+            "hbm_scratch_candidates": int(sum(r["work"] for name, r in rows.items() if name.startswith("align4CellsKernel")))}
+
+
 def forced(lib, oracle_lib, ref_lib, force, n_reads=200, limit=1500, adversarial_sets=True):
     """SHASTA_MI355X_CELLS_FORCE=long / big: every candidate the windowed class can take starts in it (or in its large-graph form) --
     ordinary reads and the adversarial read sets through align4CellsLongKernel / align4CellsLongBigKernel, against the reference's own

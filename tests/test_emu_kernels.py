@@ -348,6 +348,15 @@ def test_pairs_of_two_long_reads(emu_lib, oracle_lib, monkeypatch):
     assert r["both_long"] == 12 and r["in_the_windowed_class"] == 12 and r["in_the_hbm_scratch_kernel"] == 0 and not r["dense_because"]
 
 
+def test_a_full_cell_table_ends_the_counting_and_the_climb_ends_in_the_reference_answer(emu_lib, oracle_lib, monkeypatch):
+    """Repeat-rich pairs of two long reads fill the windowed class's cell table and the first tables of the HBM-scratch kernel
+    (tests/long_read_checks.py: before the early exit this took five minutes here, four seconds since)."""
+    from tests import long_read_checks
+    monkeypatch.setenv("SHASTA_MI355X_ALIGN_WORKERS", "1")
+    r = long_read_checks.full_tables(emu_lib, oracle_lib, lengths=(9000, 12000, 8800), alphabet_size=150)
+    assert r["candidates"] == 6 and r["windowed_launches"] >= 1 and r["hbm_scratch_launches"] >= 2 and r["hbm_scratch_candidates"] > r["candidates"]
+
+
 @pytest.mark.parametrize("force", ["long", "big"])
 def test_every_candidate_through_the_windowed_kernels(emu_lib, oracle_lib, force, monkeypatch):
     from tests import long_read_checks

@@ -31,6 +31,16 @@ def test_long_reads_over_a_small_alphabet(gpu_lib, oracle_lib):
     assert r["both_long"] >= 15 and r["in_the_hbm_scratch_kernel"] >= 10 and r["stored"] >= 10
 
 
+def test_full_cell_tables_climb_to_the_reference_answer(gpu_lib, oracle_lib, ref_lib):
+    """A few hundred distinct ids: every cell of the alignment matrix collects matches, the windowed class's table fills, then the
+    first tables of the HBM-scratch kernel; a full table ends the candidate's counting at once (it walked the whole table for
+    every further match before) and the candidate runs again in a larger one."""
+    r = long_read_checks.full_tables(gpu_lib, oracle_lib, ref_lib, lengths=(9000, 12000, 8800, 15000), alphabet_size=150)
+    assert r["candidates"] == 12 and r["hbm_scratch_launches"] >= 2 and r["hbm_scratch_candidates"] > r["candidates"]
+    r = long_read_checks.full_tables(gpu_lib, oracle_lib, ref_lib)
+    assert r["windowed_launches"] >= 1 and r["hbm_scratch_launches"] >= 1
+
+
 def test_long_reads_with_the_librarys_own_estimate(gpu_lib, oracle_lib):
     r = long_read_checks.both_long(gpu_lib, oracle_lib, seed=68)
     assert r["both_long"] >= 60 and r["stored"] >= 15
