@@ -15,6 +15,7 @@
 #include <deque>
 #include <fstream>
 #include <functional>
+#include <map>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -398,7 +399,35 @@ void runWithHelpers(const std::function<void()>& work, unsigned helpers, unsigne
 }
 
 void countLaunch();
+// HIPEMU_PROFILE=1: at exit, the wall-clock seconds and launches of every kernel (by the symbol of its launch stub), largest first,
+// on stderr.  The emulator's time is lane-operations, not device time: what it shows is WORK -- a kernel whose emulated time is out of
+// proportion to its input is doing something a device would also pay for (round 6: a full cell table walked again for every match).
+namespace {
+struct ProfileRow { double seconds = 0; uint64_t launches = 0, blocks = 0; const char* name = "?"; };
+std::mutex profileMutex;
+std::map<const void*, ProfileRow>& profileRows() { static auto* const rows = new std::map<const void*, ProfileRow>; return *rows; }      // (never destroyed: the exit handler reads it)
+void profilePrint()
+{
+    std::vector<ProfileRow> rows;
+    for(const auto& r : profileRows()) rows.push_back(r.second);
+    std::sort(rows.begin(), rows.end(), [](const ProfileRow& a, const ProfileRow& b) { return a.seconds > b.seconds; });
+    std::fprintf(stderr, "hipemu profile (wall-clock seconds on the host, launches, workgroups; one row per instantiation):\n");
+    for(const ProfileRow& r : rows) std::fprintf(stderr, "  %9.2f s %7llu %9llu  %s\n", r.seconds, (unsigned long long)r.launches, (unsigned long long)r.blocks, r.name);
+}
+const bool profileOn = [] { const char* e = std::getenv("HIPEMU_PROFILE"); const bool on = e && e[0] == '1'; if(on) std::atexit(profilePrint); return on; }();
+}
+void launchBody(const Launch& L);
 void launch(const Launch& L)
+{
+    if(!profileOn) { launchBody(L); return; }
+    const auto t0 = std::chrono::steady_clock::now();
+    launchBody(L);
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lock(profileMutex);
+    ProfileRow& r = profileRows()[L.kernel];
+    r.name = L.name; r.seconds += s; r.launches += 1; r.blocks += uint64_t(L.grid.x) * L.grid.y * L.grid.z;
+}
+void launchBody(const Launch& L)
 {
     countLaunch();
     const uint64_t blocks = uint64_t(L.grid.x) * L.grid.y * L.grid.z;

@@ -126,6 +126,8 @@ struct Launch {
     size_t dynamicLdsBytes;
     void (*invoke)(void* args);
     void* args;
+    const char* name = "?";            // the kernel as the launch site spells it, and its address (HIPEMU_PROFILE's key)
+    const void* kernel = nullptr;
 };
 void launch(const Launch&);
 // HIPEMU_ASYNC (hip_emu.cpp): the launch waits in its stream's queue; `copy` makes the arguments outlive the caller's frame.
@@ -146,13 +148,14 @@ template<class T> __forceinline__ T fromBits(uint64_t b) { T v; std::memcpy(&v, 
 #define gridDim (hipemu::cur->gDim)
 
 template<class... P, class... A>
-void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t dynamicLdsBytes, hipStream_t stream, A&&... a)
+void hipLaunchKernelNamed(const char* name, void (*kernel)(P...), dim3 grid, dim3 block, size_t dynamicLdsBytes, hipStream_t stream, A&&... a)
 {
     struct Call { void (*kernel)(P...); std::tuple<std::decay_t<P>...> args; } call{kernel, std::tuple<std::decay_t<P>...>{static_cast<std::decay_t<P>>(a)...}};
     hipemu::Launch l{grid, block, dynamicLdsBytes,
-        [](void* p) { Call* c = static_cast<Call*>(p); std::apply(c->kernel, c->args); }, &call};
+        [](void* p) { Call* c = static_cast<Call*>(p); std::apply(c->kernel, c->args); }, &call, name, reinterpret_cast<const void*>(kernel)};
     hipemu::launchOn(stream, l, [](const void* p) -> void* { return new Call(*static_cast<const Call*>(p)); }, [](void* p) { delete static_cast<Call*>(p); });
 }
+#define hipLaunchKernelGGL(kernel, ...) hipLaunchKernelNamed(#kernel, kernel, __VA_ARGS__)
 
 // ---------------------------------------------------------------------------
 // Device intrinsics.
