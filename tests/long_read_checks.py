@@ -84,13 +84,16 @@ def full_tables(lib, oracle_lib, ref_lib=None, lengths=(8600, 9100), alphabet_si
     with lib.context(0) as ctx:
         ctx.set_markers(toc, data7)
         ctx.kernel_table_reset()
+        import time
+        t0 = time.perf_counter()
         y = ctx.align4(cand, o, want_ordinals=True)
+        seconds = time.perf_counter() - t0
         rows = kernel_rows(ctx)
     ties = (x.status & 0x80) != 0
     assert x.per_candidate(~ties) == y.per_candidate(~ties)
     if ref_lib is not None:
         support.same_align(ref_lib.align4_batch(toc, data7, cand, o, want_ordinals=True), y)
-    return {"candidates": len(cand),
+    return {"candidates": len(cand), "aligner_seconds": seconds,
             "windowed_launches": int(sum(r["launches"] for name, r in rows.items() if name.startswith("align4CellsLongKernel"))),
             "hbm_scratch_launches": int(sum(r["launches"] for name, r in rows.items() if name.startswith("align4CellsKernel"))),
             "hbm_scratch_candidates": int(sum(r["work"] for name, r in rows.items() if name.startswith("align4CellsKernel")))}
