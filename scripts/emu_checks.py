@@ -30,6 +30,7 @@ def main():
     r = long_read_checks.both_long(emu, orc, lengths=(9000, 12500, 9500, 8300, 4000), genome_markers=16000)
     print("pairs of two long reads:", {k: v for k, v in r.items() if k != "rows"}, flush=True)
     del os.environ["SHASTA_MI355X_MATCH_SHIFT"]
+    print("repeat-rich pairs of long reads (full cell tables):", long_read_checks.full_tables(emu, orc, lengths=(9000, 12000, 8800), alphabet_size=150), flush=True)
     for force in ("long", "big"):
         print("every candidate forced through the windowed kernels (%s):" % force,
               long_read_checks.forced(emu, orc, None, force, n_reads=100, limit=250, adversarial_sets=not quick), flush=True)

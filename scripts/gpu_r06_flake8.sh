@@ -7,6 +7,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 N=${1:-1500}
-( time SHASTA_MI355X_SCRAMBLE=1 timeout 1500 python scripts/flake_k16_suite_context.py $N ) > gpurun_out/r06_flake8_context_scramble.log 2>&1; grep -v "^$\|amdgpu.ids" gpurun_out/r06_flake8_context_scramble.log | tail -n 6
+( time SHASTA_MI355X_DP_FORK=1 SHASTA_MI355X_SCRAMBLE=1 timeout 1500 python scripts/flake_k16_suite_context.py $N ) > gpurun_out/r06_flake8_context_scramble.log 2>&1; grep -v "^$\|amdgpu.ids" gpurun_out/r06_flake8_context_scramble.log | tail -n 6
 ( time SHASTA_MI355X_DP_FORK=0 timeout 1500 python scripts/flake_k16_suite_context.py $N ) > gpurun_out/r06_flake8_context_no_fork.log 2>&1; grep -v "^$\|amdgpu.ids" gpurun_out/r06_flake8_context_no_fork.log | tail -n 6
-( time timeout 1200 python scripts/flake_dp_unit.py 10000 ) > gpurun_out/r06_flake8_dp_unit_fork.log 2>&1; grep -v "^$\|amdgpu.ids" gpurun_out/r06_flake8_dp_unit_fork.log | tail -n 6
+( time SHASTA_MI355X_DP_FORK=1 timeout 1200 python scripts/flake_dp_unit.py 10000 ) > gpurun_out/r06_flake8_dp_unit_fork.log 2>&1; grep -v "^$\|amdgpu.ids" gpurun_out/r06_flake8_dp_unit_fork.log | tail -n 6

@@ -644,7 +644,8 @@ DpForwardState runDpForward(const WorkStream& ws, BatchScratch& b, const DpInput
 
     // Wide bands (classes 5-7: few tasks, one wavefront each) go to the side stream, widest first;
     // the narrow classes run on the main stream meanwhile.
-    // (SHASTA_MI355X_DP_FORK=0: every class on the main stream -- the A/B switch of the fork, for timing and for the search for order-dependent results.)
+    // (SHASTA_MI355X_DP_FORK=0: every class on the main stream -- the A/B switch of the fork, for timing and for the search for order-dependent results;
+    // align method 3 comes without events, i.e. without the fork, unless the switch is 1: alignRun.)
     const bool forkAllowed = [] { const char* e = std::getenv("SHASTA_MI355X_DP_FORK"); return !(e && e[0] == '0'); }();       // (read for every batch: tests and searches switch it)
     const bool fork = forkAllowed && ws.wide != nullptr && ev != nullptr && (classCounts[5] || classCounts[6] || classCounts[7]);
     hipStream_t wideStream = fork ? ws.wide : stream;
@@ -1793,7 +1794,13 @@ void alignRun(Context& ctx, uint64_t candidateCount, const shasta_oriented_read_
         if(taskCount + wideCount) {
             const SparseInput sparseInput{b.hits.data(), b.hitBase.data(), b.hitMeta.data(), maxOrdered};
             b.pairsWanted = wantOrdinals;
-            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs, listHits ? &sparseInput : nullptr);
+            // Align method 3 keeps the classes of its second step on the worker's main stream (no events: no fork) unless
+            // SHASTA_MI355X_DP_FORK=1 asks for the fork: the one difference between two runs this library has shown was a method-3
+            // call, every method-3 task runs the dense kernels, and those kernels on ONE stream are what 64 million task
+            // executions on the device showed to be repeatable (profiles/r06_flake5_dp_unit_40000.log) -- the fork's own A/B
+            // (scripts/gpu_r06_flake8.sh) has not run.  Method 4 forks as before: its dense remainder is what its measurements had.
+            const bool forkMethod3 = [] { const char* e = std::getenv("SHASTA_MI355X_DP_FORK"); return e && e[0] == '1'; }();
+            out.dpCells += runDpTasks(ctx, ws, b, taskCount, dpOpt, (m3 && !forkMethod3) ? nullptr : &w.ev, &out.dpStats, m3 ? &m3->scores : nullptr, &wideTasksHost, &hostPairs, listHits ? &sparseInput : nullptr);
             out.hadTasks = true;
             const uint32_t allTasks = taskCount + wideCount;
             SHASTA_TIMED(ctx, "winnerKernel", stream, 0, allTasks,
